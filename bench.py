@@ -1,0 +1,272 @@
+#!/usr/bin/env python
+"""bench.py -- M scored (user, pos, neg) triplets / s at d = 128 on MI355X.
+
+One *step* = one pass of the hot path over one batch of synthetic interactions:
+    fused [user-row gather + popularity sampling (in-kernel Philox + inverse CDF) + negative-row
+    gather + inner-product scoring]  ->  BPR loss (+ d loss / d score)
+i.e. BaseRetriever.forward + loss_fn of the reference (baseretriever.py:142-171, loss_func.py:55-59)
+on BASELINE.json configs[1]: N = 10 000 001 items x d = 128 fp32, 1 000 001 users, popularity
+sampler, n = 64 negatives, inner product, BPR.  All inputs are resident in HBM before the timed
+region.  N > 1 GPUs: the item table is row-sharded over the ranks (configs[3] layout), ids /
+scores travel by RCCL all-to-all, each rank owns B queries per step (weak scaling).
+
+Prints ONE JSON line (rank 0).  Extra keys beyond the driver contract: roofline, cpu_baseline,
+train_step (forward + loss + row-sparse gradient scatter), sweep.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 measured copy)
+
+
+def bytes_per_triplet(d, n, popular):
+    """negative row + (user row + positive row + two ids) / n + id/score/logp
+    written + sampler probe."""
+    return 4 * d + 2 * 4 * d / n + 16.0 / n + 16 + (8 if popular else 0)
+
+
+def make_workload(dev, n_items, n_users, d, seed=1):
+    g = torch.Generator(device=dev).manual_seed(seed)
+    item = torch.empty(n_items, d, device=dev).normal_(0, 0.02, generator=g)     # normal_initialization, init.py:18-27
+    item[0] = 0
+    user = torch.empty(n_users, d, device=dev).normal_(0, 0.02, generator=g)
+    user[0] = 0
+    return item, user
+
+
+def zipf_counts(n_items, n_inter, seed=1):
+    """bincount of a Zipf(alpha=1) item stream over a permuted id space, built on the CPU like
+    TripletDataset.item_freq (dataset.py:1216-1230); sampled as expected counts + Poisson noise so
+    that 1e8 interactions do not have to be materialised."""
+    g = torch.Generator().manual_seed(seed)
+    rank = torch.arange(1, n_items, dtype=torch.float64)
+    p = 1.0 / rank
+    p /= p.sum()
+    lam = (p * n_inter).to(torch.float32)
+    cnt = torch.poisson(lam, generator=g).long()
+    perm = torch.randperm(n_items - 1, generator=g)
+    counts = torch.zeros(n_items, dtype=torch.int64)
+    counts[1:] = cnt[perm]
+    return counts
+
+
+def time_gpu(fn, steps, warmup, dist=None):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps
+
+
+def cpu_baseline(args, counts, d, B, n):
+    """The oracle (a port, not the product) timed on this box's host cores on a bounded sample:
+    the same N / d / B / n, a handful of steps."""
+    import oracle
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    n_items = counts.numel()
+    g = torch.Generator().manual_seed(1)
+    t0 = time.perf_counter()
+    item = torch.empty(n_items, d).uniform_(-0.035, 0.035, generator=g)
+    item[0] = 0
+    user = torch.empty(args.users, d).uniform_(-0.035, 0.035, generator=g)
+    ps = oracle.PopularSamplerModel(counts)
+    setup = time.perf_counter() - t0
+    uid = torch.randint(1, args.users, (B,), generator=g)
+    pos = torch.randint(1, n_items, (B,), generator=g)
+
+    def step():
+        with torch.no_grad():
+            q = user[uid]
+            lpp, neg, lnp = ps.forward(q, n, pos)
+            p, s = oracle.retriever_forward(item, q, pos, neg)
+            return oracle.bpr_loss(p, s)
+    step()
+    times = []
+    t_end = time.perf_counter() + 12.0
+    while len(times) < 5 or (time.perf_counter() < t_end and len(times) < 40):
+        t0 = time.perf_counter()
+        step()
+        times.append(time.perf_counter() - t0)
+    times.sort()
+    med = times[len(times) // 2]
+    return {'value': round(B * n / med / 1e6, 3), 'unit': 'M triplets/s', 'cores': cores, 'kind': 'port',
+            'sample': f'oracle forward (popular sample + gather + inner product + BPR) on torch-CPU, '
+                      f'N={n_items} d={d} B={B} n={n}, median of {len(times)} steps, {cores} threads, '
+                      f'{med * 1e3:.1f} ms/step (table setup {setup:.1f}s untimed)'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--items', type=int, default=10_000_001)
+    ap.add_argument('--users', type=int, default=1_000_001)
+    ap.add_argument('--dim', type=int, default=128)
+    ap.add_argument('--batch', type=int, default=65536, help='queries per step per GPU')
+    ap.add_argument('--neg', type=int, default=64)
+    ap.add_argument('--sampler', default='popular', choices=['popular', 'uniform'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-sweep', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=dev)
+
+    import recstudio_amd as ra
+    from recstudio_amd import _native as nat
+    ra._native.lib()     # no extension, no benchmark
+
+    d, B, n = args.dim, args.batch, args.neg
+    popular = args.sampler == 'popular'
+    counts = zipf_counts(args.items, 100_000_000)
+    gen = torch.Generator(device=dev).manual_seed(100 + rank)
+    uid = torch.randint(1, args.users, (B,), device=dev, generator=gen)
+    pos = torch.randint(1, args.items, (B,), device=dev, generator=gen)
+    torch.manual_seed(2022 + rank)       # basemodel.yaml:63 seed
+
+    extra = {}
+    if world == 1:
+        item, user = make_workload(dev, args.items, args.users, d)
+        sampler = (ra.PopularSamplerModel(counts) if popular else ra.UniformSampler(args.items)).to(dev)
+        kind = nat.SAMPLER_POPULAR if popular else nat.SAMPLER_UNIFORM
+        kw = dict(query_index=uid, pos_ids=pos, sampler=kind)
+        if popular:
+            kw.update(table=sampler.table, pop_prob=sampler.pop_prob, guide=sampler.guide, guide_log2=sampler.guide_log2)
+        bufs = {}
+
+        def fwd(b=B, u=uid, p=pos, key='main'):
+            bufs[key] = ra.ops.fused_forward(item, user, n, out=bufs.get(key), **dict(kw, query_index=u, pos_ids=p))
+            return bufs[key]
+
+        def step():
+            o = fwd()
+            return ra.ops.pairwise_loss(nat.LOSS_BPR, o['pos_score'], o['neg_score'], want_grad=True)
+
+        ms_step = time_gpu(step, args.steps, args.warmup) * 1e3
+
+        # dominant kernel alone, timed with events on the launch stream
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+        torch.cuda.synchronize()
+        for a, b in evs:
+            a.record()
+            fwd()
+            b.record()
+        torch.cuda.synchronize()
+        k_ms = sorted(a.elapsed_time(b) for a, b in evs)
+        k_avg = sum(k_ms) / len(k_ms)
+        alg = bytes_per_triplet(d, n, popular) * B * n
+        achieved = alg / (k_avg * 1e-3) / 1e9
+        roofline = {'bound': 'hbm', 'kernel': 'rsa::fused_fwd_kernel<32,false,false,true>',
+                    'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                    'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': None,
+                    'alg_bytes_per_launch': int(alg), 'avg_kernel_ms': round(k_avg, 4),
+                    'median_kernel_ms': round(k_ms[len(k_ms) // 2], 4)}
+        pmc = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
+        if os.path.exists(pmc):
+            try:
+                roofline['traffic'] = json.load(open(pmc)).get('fused_fwd_bytes_per_launch')
+            except Exception:
+                pass
+
+        # training step: forward + loss + row-sparse gradient scatter (+ user-row gradient)
+        def train():
+            o = fwd()
+            loss, dpos, dneg, _ = ra.ops.pairwise_loss(nat.LOSS_BPR, o['pos_score'], o['neg_score'])
+            return ra.ops.fused_backward(item, user, o['neg_ids'], dneg, query_index=uid, pos_ids=pos, dpos=dpos,
+                                         dense_item_grad=False, row_item_grad=True, want_query_grad=True)
+        try:
+            ms_train = time_gpu(train, max(10, args.steps // 4), 5) * 1e3
+            extra['train_step'] = {'ms_per_step': round(ms_train, 4), 'value': round(B * n / ms_train / 1e3, 2),
+                                   'unit': 'M triplets/s', 'what': 'forward + BPR loss + row-sparse item-gradient '
+                                   'rows + user-gradient rows (no optimizer)'}
+        except Exception as e:      # never let the secondary figure kill the bench line
+            extra['train_step'] = {'error': repr(e)[:200]}
+        if not args.no_sweep:
+            sweep = {}
+            for b2 in (4096, 16384):
+                u2, p2 = uid[:b2].contiguous(), pos[:b2].contiguous()
+
+                def st(u2=u2, p2=p2, b2=b2):
+                    o = fwd(b2, u2, p2, key=b2)
+                    return ra.ops.pairwise_loss(nat.LOSS_BPR, o['pos_score'], o['neg_score'], want_grad=True)
+                t = time_gpu(st, args.steps, 10) * 1e3
+                sweep[f'B={b2}'] = {'ms_per_step': round(t, 4), 'M_triplets_s': round(b2 * n / t / 1e3, 2)}
+            extra['sweep'] = sweep
+        value = B * n / ms_step / 1e3
+        parallelism = 'single'
+        workload = (f'BPR two-tower d={d}, synthetic {args.items} items / {args.users} users / 1e8-interaction Zipf '
+                    f'popularity, {args.sampler} sampler neg={n}, InnerProduct + BPR loss, B={B} queries/step '
+                    f'(BASELINE.json configs[1])')
+        if rank == 0 and not args.no_cpu_baseline:
+            extra['cpu_baseline'] = cpu_baseline(args, counts, d, 4096, n)
+    else:
+        from recstudio_amd import shard
+        plan = shard.RowShardPlan(args.items, world)
+        lo, hi = plan.bounds(rank)
+        g = torch.Generator(device=dev).manual_seed(7 + rank)
+        item_local = torch.empty(hi - lo, d, device=dev).normal_(0, 0.02, generator=g)
+        if rank == 0:
+            item_local[0] = 0
+        user = torch.empty(args.users, d, device=dev).normal_(0, 0.02, generator=torch.Generator(device=dev).manual_seed(3))
+        sampler = (ra.PopularSamplerModel(counts) if popular else ra.UniformSampler(args.items)).to(dev)
+        table = shard.ShardedItemTable(item_local, plan, rank, dist)
+
+        def step():
+            o = table.sample_and_score(user, uid, pos, n, sampler)
+            return ra.ops.pairwise_loss(nat.LOSS_BPR, o['pos_score'], o['neg_score'], want_grad=True)
+        ms_step = time_gpu(step, args.steps, args.warmup, dist) * 1e3
+        t = torch.tensor([ms_step], device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        ms_step = float(t.item())
+        value = world * B * n / ms_step / 1e3
+        alg = bytes_per_triplet(d, n, popular) * B * n
+        achieved = alg / (ms_step * 1e-3) / 1e9
+        roofline = {'bound': 'hbm', 'kernel': 'whole sharded step (per GPU)', 'achieved': round(achieved, 1),
+                    'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': None}
+        parallelism = f'item-table row-sharded x{world} + RCCL all-to-all (ids out, scores back)'
+        workload = (f'two-tower d={d}, {args.items}-item table row-sharded over {world} GPUs, {args.sampler} sampler '
+                    f'neg={n}, InnerProduct + BPR loss, B={B} queries/step/GPU (BASELINE.json configs[3] layout)')
+
+    if rank == 0:
+        line = {'metric': 'M scored (user,pos,neg) triplets/sec at d=128', 'value': round(value, 2),
+                'unit': 'M triplets/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+                'ms_per_step': round(ms_step, 4), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+                'dtype': 'f32', 'data': 'synthetic',
+                'config': {'workload': workload, 'global_batch': B * world, 'num_neg': n, 'dim': d,
+                           'n_items': args.items, 'parallelism': parallelism},
+                'roofline': roofline}
+        line.update(extra)
+        print(json.dumps(line))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

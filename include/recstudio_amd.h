@@ -1,0 +1,210 @@
+/*
+ * recstudio_amd -- C ABI of the MI355X (gfx950) retriever hot path.
+ *
+ * One shared library, librecstudio_amd.so, built from recstudio_amd/csrc/ by
+ * hipcc --offload-arch=gfx950.  Plain pointers and sizes only: every pointer
+ * is a DEVICE pointer unless stated otherwise, `stream` is a hipStream_t
+ * passed as void*.  Every entry point returns 0 on success or a negative
+ * rsa_status; rsa_last_error() returns the thread-local message of the last
+ * failure.  No entry point allocates, frees or synchronises.
+ *
+ * The reference (ustcml/RecStudio) is pure Python on PyTorch; it has no native
+ * boundary of its own.  Each entry point below therefore replaces a SEQUENCE
+ * of ATen ops in the reference, cited as file:line under /root/reference.
+ * The Python binding a maintainer would add is in INTEGRATION.md; the binding
+ * this repo ships is recstudio_amd/_native.py (ctypes).
+ *
+ * Index convention (same as the reference): tables are row-major fp32
+ * [rows, dim]; row 0 is the padding row; ids are int64.
+ */
+#ifndef RECSTUDIO_AMD_H
+#define RECSTUDIO_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RSA_ABI_VERSION 1
+
+typedef void* rsa_stream_t; /* hipStream_t */
+
+enum rsa_status {
+  RSA_OK = 0,
+  RSA_ERR_ARG = -1,         /* bad argument (null pointer, size, unsupported dim) */
+  RSA_ERR_HIP = -2,         /* a HIP runtime call / kernel launch failed */
+  RSA_ERR_UNSUPPORTED = -3  /* valid request this build does not implement */
+};
+
+enum rsa_score_mode { RSA_SCORE_IP = 0, RSA_SCORE_COS = 1 };
+enum rsa_sampler_kind { RSA_SAMPLER_GIVEN = 0, RSA_SAMPLER_UNIFORM = 1, RSA_SAMPLER_POPULAR = 2 };
+enum rsa_loss_kind { RSA_LOSS_BPR = 0, RSA_LOSS_SSM = 1 };
+
+const char* rsa_last_error(void);
+int rsa_abi_version(void);
+
+/* Device properties torch's distribution kernels size their grid from
+ * (multiProcessorCount, maxThreadsPerMultiProcessor) -- needed to reproduce
+ * the device random stream.  Host pointers. */
+int rsa_device_info(int device, int32_t* cu_count, int32_t* max_threads_per_cu, int32_t* wave_size);
+
+/* ---- Philox state ---------------------------------------------------------
+ * (seed, offset) are the torch CUDA/HIP generator's philox seed and offset at
+ * the moment the reference would have called torch.randint / torch.rand;
+ * grid_threads is the thread count of torch's distribution grid for `numel`
+ * outputs (256 * min(CUs * maxThreadsPerCU/256, ceil(numel/256))).  With
+ * these, element i of the output is bit-identical to element i of
+ * torch.randint(low, high, (numel,), device='cuda') / torch.rand(numel). */
+
+/* UniformSampler.forward -- recstudio/ann/sampler.py:86-111
+ * (torch.randint(1, num_items+1, (num_queries, num_neg)), :102-104).
+ * neg_ids[numel] <- low + philox % (high - low). */
+int rsa_sample_uniform(int64_t* neg_ids, int64_t numel, int64_t low, int64_t high,
+                       uint64_t seed, uint64_t offset, uint32_t grid_threads, rsa_stream_t stream);
+
+/* PopularSamplerModel.forward -- recstudio/ann/sampler.py:243-258
+ * (u = torch.rand; ids = torch.searchsorted(table, u); logp = log(pop_prob[ids])).
+ * table/pop_prob: fp32 [n_items] exactly as the reference's registered buffers
+ * (:239-241).  guide: int32 [2^guide_log2 + 1], guide[j] = first index with
+ * table[i] >= j / 2^guide_log2, guide[2^guide_log2] = n_items (cut-point
+ * acceleration; returns the same index searchsorted does).  An id that would be
+ * n_items (u above table[-1]) is clamped to n_items-1.  neg_logp / u_out may be
+ * null. */
+int rsa_sample_popular(const float* table, const float* pop_prob, const int32_t* guide,
+                       int64_t n_items, int32_t guide_log2,
+                       int64_t* neg_ids, float* neg_logp, float* u_out, int64_t numel,
+                       uint64_t seed, uint64_t offset, uint32_t grid_threads, rsa_stream_t stream);
+
+/* The same inverse-CDF lookup for caller-supplied uniforms u[numel] (used by the
+ * parity tests to hit exact table edges). */
+int rsa_popular_lookup(const float* table, const float* pop_prob, const int32_t* guide,
+                       int64_t n_items, int32_t guide_log2, const float* u,
+                       int64_t* ids, float* logp, int64_t numel, rsa_stream_t stream);
+
+/* PopularSamplerModel.compute_item_p -- recstudio/ann/sampler.py:257-258:
+ * logp[i] = log(pop_prob[ids[i]]). */
+int rsa_item_logp(const float* pop_prob, int64_t n_items, const int64_t* ids, int64_t numel,
+                  float* logp, rsa_stream_t stream);
+
+/* torch.nn.Embedding forward (F.embedding) -- baseretriever.py:153-154, :167-168,
+ * :211, seq/sasrec.py:42.  out[numel, dim] <- table[ids]. */
+int rsa_embedding_gather(const float* table, int64_t n_rows, int32_t dim, const int64_t* ids,
+                         int64_t numel, float* out, rsa_stream_t stream);
+
+/* Fused BaseRetriever.forward body for an Embedding item tower --
+ * recstudio/model/basemodel/baseretriever.py:153-171 : sampler (S1/S2 above, or
+ * ids given) -> item_encoder(neg ids) -> score_func(query, pos) and
+ * score_func(query, neg) (recstudio/model/scorer.py:5-25), without materialising
+ * the [M, n, dim] negative rows.
+ *
+ * M "queries" (B, or B*L for sequence targets), n negatives each.  Flat element
+ * e = m*n + j is element e of the reference's [M, n] id tensor, so sampled ids
+ * are bit-identical to the reference's device stream. */
+typedef struct rsa_fused_args {
+  const float* item_table;     /* [n_items, dim] */
+  int64_t n_items;
+  int32_t dim;                 /* multiple of 4, <= 1024 */
+  int32_t score_mode;          /* rsa_score_mode */
+  const float* query;          /* [n_query_rows, dim]: query vectors, or a user table */
+  const int64_t* query_index;  /* nullable [M]: row of `query` for query m (user-id gather,
+                                  baseretriever.py:211); null => row m */
+  int64_t n_query_rows;
+  const int64_t* pos_ids;      /* nullable [M] */
+  int64_t n_queries;           /* M */
+  int32_t num_neg;             /* n */
+  int32_t sampler;             /* rsa_sampler_kind */
+  int32_t mask_pad_pos;        /* !=0: pos_score = -inf where pos_ids == 0 (baseretriever.py:164-165) */
+  int32_t guide_log2;
+  uint64_t seed, offset;       /* philox state (sampler != GIVEN) */
+  uint32_t grid_threads;
+  uint32_t _pad;
+  const float* table;          /* POPULAR: cdf / pop_prob / guide as in rsa_sample_popular */
+  const float* pop_prob;
+  const int32_t* guide;
+  int64_t* neg_ids;            /* [M, n]: INPUT if sampler == GIVEN, else OUTPUT */
+  float* neg_logp;             /* nullable [M, n] out (POPULAR) */
+  float* pos_logp;             /* nullable [M] out (POPULAR, needs pos_ids) */
+  float* pos_score;            /* nullable [M] out (needs pos_ids) */
+  float* neg_score;            /* [M, n] out */
+} rsa_fused_args;
+
+int rsa_fused_sample_gather_score(const rsa_fused_args* args, rsa_stream_t stream);
+
+/* BPRLoss.forward (recstudio/model/loss_func.py:55-59) / SampledSoftmaxLoss.forward
+ * (:80-90) on pos_score [M], neg_score [M, n] (each positive with its own n
+ * negatives), value AND gradient in one pass.  pos_logp / neg_logp are nullable
+ * (treated as 0; the reference's UniformSampler hands int64 zeros).  loss_out[1]
+ * = mean over rows; row_loss [M] scratch/out; dpos [M] and dneg [M, n] (nullable)
+ * = d loss_out / d score. */
+int rsa_pairwise_loss(int32_t loss_kind, const float* pos_score, const float* neg_score,
+                      const float* pos_logp, const float* neg_logp, int64_t n_rows, int32_t num_neg,
+                      float* row_loss, float* loss_out, float* dpos, float* dneg, rsa_stream_t stream);
+
+/* Backward of the fused forward for the inner-product scorer == what autograd
+ * produces at recommender.py:636-639 (embedding_dense_backward + bmm backward):
+ *   item_grad[neg_ids[m,j]] += up * dneg[m,j] * q_m     (skipped for id 0: padding_idx)
+ *   item_grad[pos_ids[m]]   += up * dpos[m]   * q_m
+ *   query_grad[m]            = up * (dpos[m] * item[pos] + sum_j dneg[m,j] * item[neg_j])
+ * item_grad: dense [n_items, dim], accumulated with atomics, caller zero-fills
+ * (nullable).  item_grad_rows: nullable [M*(n+1), dim] row-sparse values, row
+ * m*(n+1) = positive, m*(n+1)+1+j = negative j (COO values for ids
+ * cat(pos, neg); no atomics).  query_grad: nullable [M, dim], overwritten.
+ * upstream: nullable device scalar (d final / d loss), default 1. */
+typedef struct rsa_backward_args {
+  const float* item_table;
+  int64_t n_items;
+  int32_t dim;
+  int32_t num_neg;
+  const float* query;
+  const int64_t* query_index;
+  int64_t n_query_rows;
+  const int64_t* pos_ids;      /* nullable */
+  const int64_t* neg_ids;      /* [M, n] */
+  int64_t n_queries;
+  const float* dpos;           /* [M] (nullable iff pos_ids null) */
+  const float* dneg;           /* [M, n] */
+  const float* upstream;
+  float* item_grad;
+  float* item_grad_rows;
+  float* query_grad;
+} rsa_backward_args;
+
+int rsa_fused_backward(const rsa_backward_args* args, rsa_stream_t stream);
+
+/* embedding_dense_backward: dst[ids[i]] += src[i] for ids != 0 (padding_idx=0).
+ * Used for the user-table gradient.  dst [n_rows, dim] caller-zeroed. */
+int rsa_scatter_add_rows(const float* src, const int64_t* ids, int64_t numel, int32_t dim,
+                         float* dst, int64_t n_rows, rsa_stream_t stream);
+
+/* SeqDataset batch materialisation + item_encoder(in_item_id) --
+ * recstudio/data/dataset.py:1418-1439 (ragged [start,end) slices of the user-sorted
+ * item column, right-padded with 0) + recstudio/model/seq/sasrec.py:42.
+ * out_ids [B, max_len] int64 (nullable), out_rows [B, max_len, dim] (nullable),
+ * out_len [B] int64 (nullable).  Segments longer than max_len keep their LAST
+ * max_len items (dataset.py:1400,1409 windows to the most recent max_seq_len). */
+int rsa_seg_gather(const float* item_table, int64_t n_items, int32_t dim,
+                   const int64_t* flat_item_ids, int64_t n_flat,
+                   const int64_t* seg_start, const int64_t* seg_end, int64_t n_seg, int32_t max_len,
+                   int64_t* out_ids, float* out_rows, int64_t* out_len, rsa_stream_t stream);
+
+/* Full-catalog scoring -- InnerProductScorer ([B,d],[N,d]) case, scorer.py:16,
+ * called from baseretriever.py:183-186 (training, FullScoreLoss) and :384 (topk).
+ * Scores query [B, dim] against item_table rows [1, n_items) (item_vector =
+ * weight[1:], baseretriever.py:122-123) with the fp32 MFMA
+ * (v_mfma_f32_32x32x2_f32), never materialising [B, N-1] unless `scores` is given.
+ *   scores : nullable [B, n_items-1] out (reference-style materialisation)
+ *   lse    : nullable [B] out, logsumexp over the catalog (SoftmaxLoss, loss_func.py:41)
+ *   topk_val / topk_idx : nullable [B, k] out, k <= 128: largest k scores, ids are
+ *     ITEM ids (1-based, baseretriever.py:385); ties -> smaller id first.
+ *   workspace: device scratch of rsa_fullscore_workspace_bytes(B, n_items, k) bytes. */
+int64_t rsa_fullscore_workspace_bytes(int64_t n_query, int64_t n_items, int32_t k);
+int rsa_fullscore(const float* item_table, int64_t n_items, int32_t dim,
+                  const float* query, int64_t n_query,
+                  float* scores, float* lse, float* topk_val, int64_t* topk_idx, int32_t k,
+                  void* workspace, int64_t workspace_bytes, rsa_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RECSTUDIO_AMD_H */

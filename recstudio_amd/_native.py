@@ -1,0 +1,118 @@
+"""ctypes binding of librecstudio_amd.so (the C ABI in include/recstudio_amd.h).
+
+The library is built in-tree (``recstudio_amd/librecstudio_amd.so``) by
+``recstudio_amd/csrc/Makefile`` (hipcc --offload-arch=gfx950).  There is no
+fallback: if the library is missing or a symbol is absent, loading raises.
+"""
+import ctypes
+import os
+import subprocess
+from ctypes import (POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_uint32, c_uint64, c_void_p)
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, 'librecstudio_amd.so')
+CSRC = os.path.join(HERE, 'csrc')
+
+RSA_OK = 0
+SCORE_IP, SCORE_COS = 0, 1
+SAMPLER_GIVEN, SAMPLER_UNIFORM, SAMPLER_POPULAR = 0, 1, 2
+LOSS_BPR, LOSS_SSM = 0, 1
+
+
+class NativeError(RuntimeError):
+    """A C-ABI call returned a negative status."""
+
+
+class FusedArgs(Structure):
+    """struct rsa_fused_args (include/recstudio_amd.h)."""
+    _fields_ = [
+        ('item_table', c_void_p), ('n_items', c_int64), ('dim', c_int32), ('score_mode', c_int32),
+        ('query', c_void_p), ('query_index', c_void_p), ('n_query_rows', c_int64),
+        ('pos_ids', c_void_p), ('n_queries', c_int64),
+        ('num_neg', c_int32), ('sampler', c_int32), ('mask_pad_pos', c_int32), ('guide_log2', c_int32),
+        ('seed', c_uint64), ('offset', c_uint64), ('grid_threads', c_uint32), ('_pad', c_uint32),
+        ('table', c_void_p), ('pop_prob', c_void_p), ('guide', c_void_p),
+        ('neg_ids', c_void_p), ('neg_logp', c_void_p), ('pos_logp', c_void_p),
+        ('pos_score', c_void_p), ('neg_score', c_void_p),
+    ]
+
+
+class BackwardArgs(Structure):
+    """struct rsa_backward_args (include/recstudio_amd.h)."""
+    _fields_ = [
+        ('item_table', c_void_p), ('n_items', c_int64), ('dim', c_int32), ('num_neg', c_int32),
+        ('query', c_void_p), ('query_index', c_void_p), ('n_query_rows', c_int64),
+        ('pos_ids', c_void_p), ('neg_ids', c_void_p), ('n_queries', c_int64),
+        ('dpos', c_void_p), ('dneg', c_void_p), ('upstream', c_void_p),
+        ('item_grad', c_void_p), ('item_grad_rows', c_void_p), ('query_grad', c_void_p),
+    ]
+
+
+# name -> (restype, argtypes); must list every symbol the header declares.
+SIGNATURES = {
+    'rsa_last_error': (c_char_p, []),
+    'rsa_abi_version': (c_int, []),
+    'rsa_device_info': (c_int, [c_int, POINTER(c_int32), POINTER(c_int32), POINTER(c_int32)]),
+    'rsa_sample_uniform': (c_int, [c_void_p, c_int64, c_int64, c_int64, c_uint64, c_uint64, c_uint32, c_void_p]),
+    'rsa_sample_popular': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p,
+                                   c_int64, c_uint64, c_uint64, c_uint32, c_void_p]),
+    'rsa_popular_lookup': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p,
+                                   c_int64, c_void_p]),
+    'rsa_item_logp': (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p]),
+    'rsa_embedding_gather': (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_int64, c_void_p, c_void_p]),
+    'rsa_fused_sample_gather_score': (c_int, [POINTER(FusedArgs), c_void_p]),
+    'rsa_pairwise_loss': (c_int, [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p,
+                                  c_void_p, c_void_p, c_void_p, c_void_p]),
+    'rsa_fused_backward': (c_int, [POINTER(BackwardArgs), c_void_p]),
+    'rsa_scatter_add_rows': (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_int64, c_void_p]),
+    'rsa_seg_gather': (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int32,
+                               c_void_p, c_void_p, c_void_p, c_void_p]),
+    'rsa_fullscore_workspace_bytes': (c_int64, [c_int64, c_int64, c_int32]),
+    'rsa_fullscore': (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
+                              c_int32, c_void_p, c_int64, c_void_p]),
+}
+
+_lib = None
+
+
+def build(verbose=False):
+    """Compile the HIP sources for gfx950 (cross-compiles without a GPU)."""
+    out = subprocess.run(['make', '-C', CSRC, '-j8'], capture_output=True, text=True)
+    if verbose or out.returncode != 0:
+        print(out.stdout[-4000:])
+        print(out.stderr[-4000:])
+    if out.returncode != 0:
+        raise RuntimeError('recstudio_amd: building librecstudio_amd.so failed')
+    global _lib
+    _lib = None
+    return LIB_PATH
+
+
+def lib():
+    """The loaded library with typed entry points.  Raises if it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f'recstudio_amd: {LIB_PATH} is missing -- the HIP extension is required (no CPU fallback). '
+                f'Build it with `python -c "import __graft_entry__ as g; g.build()"` or `make -C {CSRC}`.')
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)       # AttributeError if the symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        if handle.rsa_abi_version() != 1:
+            raise RuntimeError('recstudio_amd: ABI version mismatch between header and library')
+        _lib = handle
+    return _lib
+
+
+def check(rc, what):
+    if rc != RSA_OK:
+        msg = lib().rsa_last_error()
+        raise NativeError(f'{what} failed (status {rc}): {msg.decode() if msg else ""}')
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    return None if t is None else c_void_p(t.data_ptr())

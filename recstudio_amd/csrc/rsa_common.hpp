@@ -1,0 +1,148 @@
+// Shared device helpers for the gfx950 (CDNA4, wave64) kernels of recstudio_amd.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/recstudio_amd.h"
+
+namespace rsa {
+
+constexpr int WAVE = 64;
+
+// ---------------------------------------------------------------- error plumbing (host)
+void set_error(const char* fmt, ...);
+#define RSA_CHECK_ARG(cond, ...)                \
+  do {                                          \
+    if (!(cond)) {                              \
+      rsa::set_error(__VA_ARGS__);              \
+      return RSA_ERR_ARG;                       \
+    }                                           \
+  } while (0)
+#define RSA_CHECK_LAUNCH(what)                                                   \
+  do {                                                                           \
+    hipError_t e_ = hipGetLastError();                                           \
+    if (e_ != hipSuccess) {                                                      \
+      rsa::set_error("%s: launch failed: %s", what, hipGetErrorString(e_));      \
+      return RSA_ERR_HIP;                                                        \
+    }                                                                            \
+  } while (0)
+
+// ---------------------------------------------------------------- Philox4x32-10
+// Random123 Philox4x32 with 10 rounds: the generator behind torch's device
+// distributions (rocRAND philox4x32_10_engine::ten_rounds).
+__device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint2 k) {
+  constexpr uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint32_t hi0 = __umulhi(M0, c.x), lo0 = M0 * c.x;
+    const uint32_t hi1 = __umulhi(M1, c.z), lo1 = M1 * c.z;
+    c = make_uint4(hi1 ^ c.y ^ k.x, lo1, hi0 ^ c.w ^ k.y, lo0);
+    k.x += W0;
+    k.y += W1;
+  }
+  return c;
+}
+
+// State of one torch distribution call, see include/recstudio_amd.h ("Philox state").
+struct PhiloxCall {
+  uint64_t seed;
+  uint64_t offset4;        // generator offset / 4 (torch offsets are multiples of 4)
+  uint32_t grid_threads;   // G
+};
+
+// Raw philox draw for output element li of a call whose per-draw unroll is UNROLL
+// (4: 32-bit ints and floats, 2: 64-bit ints).  Returns the 4 words and the
+// component index the element owns.
+template <int UNROLL>
+__device__ __forceinline__ uint4 philox_for_element(const PhiloxCall& pc, uint64_t li, int& comp) {
+  uint64_t idx, j;
+  if (li < pc.grid_threads) {   // common case: every element on its own subsequence, first draw
+    idx = li;
+    j = 0;
+  } else {
+    j = li / pc.grid_threads;
+    idx = li - j * pc.grid_threads;
+  }
+  const uint64_t k = j / UNROLL;
+  comp = (int)(j - k * UNROLL);
+  const uint64_t ctr = pc.offset4 + k;
+  const uint4 c = make_uint4((uint32_t)ctr, (uint32_t)(ctr >> 32), (uint32_t)idx, (uint32_t)(idx >> 32));
+  const uint2 key = make_uint2((uint32_t)pc.seed, (uint32_t)(pc.seed >> 32));
+  return philox4x32_10(c, key);
+}
+
+__device__ __forceinline__ uint32_t pick(const uint4& v, int comp) {
+  return comp == 0 ? v.x : comp == 1 ? v.y : comp == 2 ? v.z : v.w;
+}
+
+// == element li of torch.randint(low, low+range, ..., device='cuda')
+__device__ __forceinline__ int64_t torch_randint_element(const PhiloxCall& pc, uint64_t li, uint64_t range,
+                                                         int64_t low) {
+  int comp;
+  if (range >= (1ull << 28)) {   // ATen random_from_to_kernel: 64-bit draws above 2^28
+    const uint4 v = philox_for_element<2>(pc, li, comp);
+    const uint64_t r = comp == 0 ? (((uint64_t)v.x << 32) | v.y) : (((uint64_t)v.z << 32) | v.w);
+    return (int64_t)(r % range) + low;
+  }
+  const uint4 v = philox_for_element<4>(pc, li, comp);
+  return (int64_t)((uint64_t)pick(v, comp) % range) + low;
+}
+
+// == element li of torch.rand(..., device='cuda', dtype=float32)
+__device__ __forceinline__ float torch_rand_element(const PhiloxCall& pc, uint64_t li) {
+  int comp;
+  const uint4 v = philox_for_element<4>(pc, li, comp);
+  const float inv = 2.3283064e-10f;                       // 2^-32 (rocRAND uniform_distribution)
+  const float u = __fmaf_rn((float)pick(v, comp), inv, inv);   // product exact => == mul then add
+  return u == 1.0f ? 0.0f : u;                            // torch uniform_kernel bound flip
+}
+
+// ---------------------------------------------------------------- inverse-CDF lookup
+// First index i in [0, n_items) with table[i] >= u, found inside the cut-point
+// bucket [guide[b], guide[b+1]] of b = floor(u * 2^guide_log2); clamped to n_items-1.
+__device__ __forceinline__ int32_t cdf_lower_bound(const float* __restrict__ table,
+                                                   const int32_t* __restrict__ guide, int64_t n_items,
+                                                   int guide_log2, float u) {
+  const int32_t K = 1 << guide_log2;
+  int32_t b = (int32_t)(u * (float)K);    // exact: power-of-two scale
+  b = b < 0 ? 0 : (b > K - 1 ? K - 1 : b);
+  int32_t lo = guide[b], hi = guide[b + 1];   // answer in [lo, hi]
+  while (lo < hi) {
+    const int32_t mid = lo + ((hi - lo) >> 1);
+    if (table[mid] < u) lo = mid + 1; else hi = mid;
+  }
+  return lo > (int32_t)(n_items - 1) ? (int32_t)(n_items - 1) : lo;
+}
+
+// ---------------------------------------------------------------- wave helpers
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+
+template <int WIDTH>
+__device__ __forceinline__ float group_sum(float v) {   // all lanes of each WIDTH-group get the sum
+#pragma unroll
+  for (int m = WIDTH / 2; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+  return v;
+}
+
+// Transpose-reduce: each lane of an L-lane group holds v[0..L-1]; afterwards lane s of the
+// group holds sum over the group's lanes of v[s].  L-1 shuffles for L sums.
+template <int L>
+__device__ __forceinline__ float transpose_reduce(float (&v)[L], int sub_lane) {
+#pragma unroll
+  for (int m = L / 2; m >= 1; m >>= 1) {
+    const bool upper = (sub_lane & m) != 0;
+#pragma unroll
+    for (int t = 0; t < m; ++t) {
+      const float send = upper ? v[t] : v[t + m];
+      const float keep = upper ? v[t + m] : v[t];
+      v[t] = keep + __shfl_xor(send, m, 64);
+    }
+  }
+  return v[0];
+}
+
+__device__ __forceinline__ float dot4(const float4& a, const float4& b) {
+  return __fmaf_rn(a.w, b.w, __fmaf_rn(a.z, b.z, __fmaf_rn(a.y, b.y, a.x * b.x)));
+}
+
+}  // namespace rsa

@@ -1,0 +1,353 @@
+// Fused sample -> gather -> score forward for an Embedding item tower (gfx950, wave64).
+//
+// Replaces, in one launch, the ATen sequence of BaseRetriever.forward
+// (recstudio/model/basemodel/baseretriever.py:153-171):
+//   sampler(...)            sampler.py:102-104 (uniform) / :246-258 (popularity)
+//   item_encoder(neg ids)   F.embedding           -> [M, n, d] rows (never materialised here)
+//   score_func(q, pos/neg)  scorer.py:9-25        -> [M], [M, n]
+//
+// Work decomposition: a TILE is 64 consecutive elements of the flat [M*n] id
+// tensor and belongs to one wave.  Lane r of the wave owns element r: it draws /
+// reads the id and, at the end, holds and stores that element's score.  The row
+// reads are spread the other way: a D-float row is read by LPR = D/4 lanes as one
+// 16-byte load each (D = 128: 32 lanes x 16 B = 512 B, two rows per wave
+// instruction, every 128-B line fully used).  Lane group g (LPR lanes) walks rows
+// g*LPR .. g*LPR+LPR-1 of the tile, so after LPR steps each lane holds LPR partial
+// dot products that a transpose-reduce (LPR-1 shuffles for LPR rows) turns into
+// "lane r holds the full dot of row r".
+//
+// The kernel is HBM-bound: 4*D bytes of random row traffic per element against
+// ~2*D flops; see DESIGN.md for the byte model.
+#include "rsa_common.hpp"
+
+namespace rsa {
+
+struct FwdParams {
+  const float* item_table;
+  const float* query;
+  const int64_t* query_index;
+  const int64_t* pos_ids;
+  const float* table;
+  const float* pop_prob;
+  const int32_t* guide;
+  int64_t* neg_ids;
+  float* neg_logp;
+  float* pos_logp;
+  float* pos_score;
+  float* neg_score;
+  int64_t n_items, n_query_rows, n_queries, numel;
+  PhiloxCall pc;
+  int32_t dim, num_neg, sampler, mask_pad_pos, guide_log2;
+};
+
+template <int LPR, bool GENERIC>
+struct Frag {
+  static constexpr int CH = GENERIC ? 4 : 1;
+  float4 v[CH];
+};
+
+template <int LPR, bool GENERIC>
+__device__ __forceinline__ void frag_load(Frag<LPR, GENERIC>& f, const float* __restrict__ row, int sub, int D,
+                                          bool act) {
+#pragma unroll
+  for (int c = 0; c < Frag<LPR, GENERIC>::CH; ++c) {
+    const int col = (c * LPR + sub) * 4;
+    if (act && (!GENERIC || col < D))
+      f.v[c] = *reinterpret_cast<const float4*>(row + col);
+    else
+      f.v[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+}
+
+template <int LPR, bool GENERIC>
+__device__ __forceinline__ float frag_dot(const Frag<LPR, GENERIC>& a, const Frag<LPR, GENERIC>& b) {
+  float s = dot4(a.v[0], b.v[0]);
+#pragma unroll
+  for (int c = 1; c < Frag<LPR, GENERIC>::CH; ++c) s += dot4(a.v[c], b.v[c]);
+  return s;
+}
+
+// In-place partial transpose-reduce over the lane-mask bits {step, 2*step, ..., step*L/2}:
+// on entry d[k] belongs to tile row (base + k*step); on return d[0] is the sum, over the lanes
+// that differ only in those mask bits, of the row selected by this lane's own bits.
+template <int L>
+__device__ __forceinline__ void fold(float (&d)[L], int sub, int step) {
+#pragma unroll
+  for (int mm = L / 2; mm >= 1; mm >>= 1) {
+    const bool upper = (sub & (mm * step)) != 0;
+#pragma unroll
+    for (int k = 0; k < mm; ++k) {
+      const float send = upper ? d[k] : d[k + mm];
+      const float keep = upper ? d[k + mm] : d[k];
+      d[k] = keep + __shfl_xor(send, mm * step, 64);
+    }
+  }
+}
+
+// Dot products (and squared norms for the cosine scorer) of the tile's 64 rows.
+// id_lane / act_lane / qrow_lane: lane r's row id, validity and query row.
+// On return lane r holds the results of row r.
+//
+// Rows are visited BATCH at a time, batch b = rows {b, b+NB, b+2NB, ...} of the lane group, and
+// each batch is folded to one value right away (the depth-first order of the transpose-reduce
+// tree), so only BATCH row fragments + NB partials are live instead of LPR of each.
+template <int LPR, bool GENERIC, bool COS, bool QU>
+__device__ __forceinline__ void tile_rows(const float* __restrict__ table, int D, int32_t id_lane, int act_lane,
+                                          const float* __restrict__ query, int32_t qrow_lane,
+                                          const Frag<LPR, GENERIC>& qf_uniform, float& dot, float& inorm2,
+                                          float& qnorm2) {
+  using F = Frag<LPR, GENERIC>;
+  constexpr int BATCH = GENERIC ? 2 : (LPR < 8 ? LPR : 8);
+  constexpr int NB = LPR / BATCH;
+  const int lane = lane_id();
+  const int sub = lane % LPR;
+  const int gbase = lane - sub;   // first tile row of this lane group
+  float top[NB];
+  float top2[COS ? NB : 1];
+  float top3[(COS && !QU) ? NB : 1];
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    F x[BATCH];
+    F qx[QU ? 1 : BATCH];
+#pragma unroll
+    for (int k = 0; k < BATCH; ++k) {
+      const int r = gbase + b + k * NB;
+      const int32_t rid = __shfl(id_lane, r, 64);
+      const int ract = __shfl(act_lane, r, 64);
+      frag_load<LPR, GENERIC>(x[k], table + (size_t)rid * D, sub, D, ract != 0);
+      if constexpr (!QU) {
+        const int32_t qr = __shfl(qrow_lane, r, 64);
+        frag_load<LPR, GENERIC>(qx[k], query + (size_t)qr * D, sub, D, ract != 0);
+      }
+    }
+    float d[BATCH];
+    float d2[COS ? BATCH : 1];
+    float d3[(COS && !QU) ? BATCH : 1];
+#pragma unroll
+    for (int k = 0; k < BATCH; ++k) {
+      const F& q = QU ? qf_uniform : qx[QU ? 0 : k];
+      d[k] = frag_dot<LPR, GENERIC>(x[k], q);
+      if constexpr (COS) {
+        d2[k] = frag_dot<LPR, GENERIC>(x[k], x[k]);
+        if constexpr (!QU) d3[k] = frag_dot<LPR, GENERIC>(q, q);
+      }
+    }
+    fold<BATCH>(d, sub, NB);
+    top[b] = d[0];
+    if constexpr (COS) {
+      fold<BATCH>(d2, sub, NB);
+      top2[b] = d2[0];
+      if constexpr (!QU) {
+        fold<BATCH>(d3, sub, NB);
+        top3[b] = d3[0];
+      }
+    }
+  }
+  fold<NB>(top, sub, 1);
+  dot = top[0];
+  if constexpr (COS) {
+    fold<NB>(top2, sub, 1);
+    inorm2 = top2[0];
+    if constexpr (!QU) {
+      fold<NB>(top3, sub, 1);
+      qnorm2 = top3[0];
+    }
+  }
+}
+
+__device__ __forceinline__ float finish_score(bool cos, float dot, float inorm2, float qnorm2) {
+  // CosineScorer: dot / ||item|| / ||query||, two divisions, no epsilon (scorer.py:21-24)
+  return cos ? (dot / sqrtf(inorm2)) / sqrtf(qnorm2) : dot;
+}
+
+template <int LPR, bool GENERIC, bool COS, bool QU>
+__global__ __launch_bounds__(256) void fused_fwd_kernel(const FwdParams p) {
+  using F = Frag<LPR, GENERIC>;
+  const int lane = lane_id();
+  const int sub = lane % LPR;
+  const int D = GENERIC ? p.dim : LPR * 4;
+  const int64_t n = p.num_neg;
+  const int64_t n_tiles = (p.numel + 63) >> 6;
+  const int64_t wave0 = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int64_t wstride = (int64_t)gridDim.x * (blockDim.x >> 6);
+
+  for (int64_t tile = wave0; tile < n_tiles; tile += wstride) {
+    const int64_t e = (tile << 6) + lane;
+    const int act = e < p.numel;
+
+    // ---- 1. the id of element e (lane-parallel: one Philox / one CDF search per lane)
+    int32_t id = 0;
+    if (act) {
+      if (p.sampler == RSA_SAMPLER_UNIFORM) {
+        id = (int32_t)torch_randint_element(p.pc, (uint64_t)e, (uint64_t)(p.n_items - 1), 1);
+        p.neg_ids[e] = id;
+      } else if (p.sampler == RSA_SAMPLER_POPULAR) {
+        const float u = torch_rand_element(p.pc, (uint64_t)e);
+        id = cdf_lower_bound(p.table, p.guide, p.n_items, p.guide_log2, u);
+        p.neg_ids[e] = id;
+        if (p.neg_logp) p.neg_logp[e] = logf(p.pop_prob[id]);
+      } else {
+        int64_t g = p.neg_ids[e];
+        g = g < 0 ? 0 : (g >= p.n_items ? p.n_items - 1 : g);   // clamp: never fault on a bad id
+        id = (int32_t)g;
+      }
+    }
+
+    // ---- 2. which query each element belongs to
+    F qf;
+    int32_t qrow_lane = 0;
+    int64_t m_lane = 0;
+    float qn2_u = 0.f;
+    if constexpr (QU) {
+      m_lane = (tile << 6) / n;   // wave-uniform: n % 64 == 0
+      const int64_t qrow = p.query_index ? p.query_index[m_lane] : m_lane;
+      frag_load<LPR, GENERIC>(qf, p.query + (size_t)qrow * D, sub, D, true);
+      if constexpr (COS) qn2_u = group_sum<LPR>(frag_dot<LPR, GENERIC>(qf, qf));
+    } else {
+      m_lane = act ? e / n : 0;
+      qrow_lane = (int32_t)(p.query_index ? (act ? p.query_index[m_lane] : 0) : m_lane);
+      frag_load<LPR, GENERIC>(qf, p.query, sub, D, false);
+    }
+
+    // ---- 3. negatives: gather + dot
+    float dot = 0.f, in2 = 1.f, qn2 = 1.f;
+    tile_rows<LPR, GENERIC, COS, QU>(p.item_table, D, id, act, p.query, qrow_lane, qf, dot, in2, qn2);
+    if constexpr (COS && QU) qn2 = qn2_u;
+    if (act) p.neg_score[e] = finish_score(COS, dot, in2, qn2);
+
+    // ---- 4. positives
+    if (p.pos_ids != nullptr && (p.pos_score != nullptr || p.pos_logp != nullptr)) {
+      if constexpr (QU) {
+        if ((tile << 6) % n == 0) {   // first tile of the query (wave-uniform)
+          int64_t pid = p.pos_ids[m_lane];
+          const bool pad = pid == 0;
+          pid = pid < 0 ? 0 : (pid >= p.n_items ? p.n_items - 1 : pid);
+          if (p.pos_score) {
+            F x;
+            frag_load<LPR, GENERIC>(x, p.item_table + (size_t)pid * D, sub, D, true);
+            float pd = group_sum<LPR>(frag_dot<LPR, GENERIC>(x, qf));
+            float pi2 = 1.f;
+            if constexpr (COS) pi2 = group_sum<LPR>(frag_dot<LPR, GENERIC>(x, x));
+            float s = finish_score(COS, pd, pi2, qn2_u);
+            if (p.mask_pad_pos && pad) s = -INFINITY;
+            if (lane == 0) p.pos_score[m_lane] = s;
+          }
+          if (p.pos_logp && lane == 0) p.pos_logp[m_lane] = logf(p.pop_prob[pid]);
+        }
+      } else {
+        const int owner = act && (e - m_lane * n == 0);
+        if (__ballot(owner) != 0ull) {
+          int64_t pid64 = owner ? p.pos_ids[m_lane] : 0;
+          const bool pad = pid64 == 0;
+          pid64 = pid64 < 0 ? 0 : (pid64 >= p.n_items ? p.n_items - 1 : pid64);
+          if (p.pos_score) {
+            float pd = 0.f, pi2 = 1.f, pq2 = 1.f;
+            tile_rows<LPR, GENERIC, COS, false>(p.item_table, D, (int32_t)pid64, owner, p.query, qrow_lane, qf, pd,
+                                                pi2, pq2);
+            float s = finish_score(COS, pd, pi2, pq2);
+            if (p.mask_pad_pos && pad) s = -INFINITY;
+            if (owner) p.pos_score[m_lane] = s;
+          }
+          if (p.pos_logp && owner) p.pos_logp[m_lane] = logf(p.pop_prob[pid64]);
+        }
+      }
+    }
+  }
+}
+
+template <int LPR, bool GENERIC>
+static int launch_fwd(const FwdParams& p, bool cos, bool qu, hipStream_t stream) {
+  const int64_t n_tiles = (p.numel + 63) >> 6;
+  int64_t blocks = (n_tiles + 3) / 4;
+  if (blocks > 256 * 8) blocks = 256 * 8;
+  if (blocks < 1) blocks = 1;
+  dim3 grid((unsigned)blocks), block(256);
+  if (cos) {
+    if (qu) hipLaunchKernelGGL((fused_fwd_kernel<LPR, GENERIC, true, true>), grid, block, 0, stream, p);
+    else hipLaunchKernelGGL((fused_fwd_kernel<LPR, GENERIC, true, false>), grid, block, 0, stream, p);
+  } else {
+    if (qu) hipLaunchKernelGGL((fused_fwd_kernel<LPR, GENERIC, false, true>), grid, block, 0, stream, p);
+    else hipLaunchKernelGGL((fused_fwd_kernel<LPR, GENERIC, false, false>), grid, block, 0, stream, p);
+  }
+  RSA_CHECK_LAUNCH("rsa_fused_sample_gather_score");
+  return RSA_OK;
+}
+
+}  // namespace rsa
+
+using namespace rsa;
+
+extern "C" int rsa_fused_sample_gather_score(const rsa_fused_args* a, rsa_stream_t stream) {
+  RSA_CHECK_ARG(a != nullptr, "rsa_fused_sample_gather_score: args is null");
+  RSA_CHECK_ARG(a->n_queries >= 0 && a->num_neg >= 0, "rsa_fused_sample_gather_score: negative sizes");
+  const int64_t numel = a->n_queries * (int64_t)a->num_neg;
+  RSA_CHECK_ARG(a->dim >= 4 && a->dim <= 1024 && a->dim % 4 == 0,
+                "rsa_fused_sample_gather_score: dim=%d must be a multiple of 4 in [4, 1024]", a->dim);
+  RSA_CHECK_ARG(a->n_items >= 2 && a->n_items < (1ll << 31), "rsa_fused_sample_gather_score: n_items out of range");
+  RSA_CHECK_ARG(a->n_query_rows >= 1 && a->n_query_rows < (1ll << 31),
+                "rsa_fused_sample_gather_score: n_query_rows out of range");
+  RSA_CHECK_ARG(a->score_mode == RSA_SCORE_IP || a->score_mode == RSA_SCORE_COS,
+                "rsa_fused_sample_gather_score: unknown score_mode %d", a->score_mode);
+  RSA_CHECK_ARG(a->sampler >= RSA_SAMPLER_GIVEN && a->sampler <= RSA_SAMPLER_POPULAR,
+                "rsa_fused_sample_gather_score: unknown sampler %d", a->sampler);
+  if (a->n_queries == 0) return RSA_OK;
+  RSA_CHECK_ARG(a->item_table && a->query, "rsa_fused_sample_gather_score: item_table/query is null");
+  RSA_CHECK_ARG(a->query_index != nullptr || a->n_query_rows >= a->n_queries,
+                "rsa_fused_sample_gather_score: query has fewer rows than n_queries");
+  if (numel > 0) {
+    RSA_CHECK_ARG(a->neg_ids && a->neg_score, "rsa_fused_sample_gather_score: neg_ids/neg_score is null");
+    if (a->sampler != RSA_SAMPLER_GIVEN)
+      RSA_CHECK_ARG(a->grid_threads > 0 && (a->offset & 3) == 0, "rsa_fused_sample_gather_score: bad philox state");
+    if (a->sampler == RSA_SAMPLER_POPULAR)
+      RSA_CHECK_ARG(a->table && a->pop_prob && a->guide && a->guide_log2 >= 0 && a->guide_log2 <= 24,
+                    "rsa_fused_sample_gather_score: popularity tables missing");
+  }
+  RSA_CHECK_ARG(a->pos_logp == nullptr || a->pop_prob != nullptr,
+                "rsa_fused_sample_gather_score: pos_logp needs pop_prob");
+  RSA_CHECK_ARG((a->pos_score == nullptr && a->pos_logp == nullptr) || a->pos_ids != nullptr,
+                "rsa_fused_sample_gather_score: pos outputs need pos_ids");
+
+  FwdParams p;
+  p.item_table = a->item_table;
+  p.query = a->query;
+  p.query_index = a->query_index;
+  p.pos_ids = a->pos_ids;
+  p.table = a->table;
+  p.pop_prob = a->pop_prob;
+  p.guide = a->guide;
+  p.neg_ids = a->neg_ids;
+  p.neg_logp = a->neg_logp;
+  p.pos_logp = a->pos_logp;
+  p.pos_score = a->pos_score;
+  p.neg_score = a->neg_score;
+  p.n_items = a->n_items;
+  p.n_query_rows = a->n_query_rows;
+  p.n_queries = a->n_queries;
+  p.pc = PhiloxCall{a->seed, a->offset >> 2, a->grid_threads};
+  p.dim = a->dim;
+  p.num_neg = a->num_neg;
+  p.sampler = a->sampler;
+  p.mask_pad_pos = a->mask_pad_pos;
+  p.guide_log2 = a->guide_log2;
+
+  const bool cos = a->score_mode == RSA_SCORE_COS;
+  hipStream_t s = (hipStream_t)stream;
+  int rc = RSA_OK;
+  if (numel == 0) {
+    // no negatives: score the positives only, as one "negative" column of given ids == pos ids
+    // (num_neg = 1, QU = false) writing into pos_score through the positive path.
+    if (a->pos_score == nullptr && a->pos_logp == nullptr) return RSA_OK;
+    rsa::set_error("rsa_fused_sample_gather_score: num_neg == 0 is not supported (use rsa_embedding_gather)");
+    return RSA_ERR_UNSUPPORTED;
+  }
+  p.numel = numel;
+  const bool qu = (a->num_neg % 64) == 0;
+  switch (a->dim) {
+    case 32: rc = launch_fwd<8, false>(p, cos, qu, s); break;
+    case 64: rc = launch_fwd<16, false>(p, cos, qu, s); break;
+    case 128: rc = launch_fwd<32, false>(p, cos, qu, s); break;
+    case 256: rc = launch_fwd<64, false>(p, cos, qu, s); break;
+    default: rc = launch_fwd<64, true>(p, cos, qu, s); break;
+  }
+  return rc;
+}

@@ -1,0 +1,133 @@
+// Pairwise losses on the [M, n] score tile: value and gradient in one pass (gfx950).
+//
+//   BPRLoss.forward            recstudio/model/loss_func.py:55-59   (dns=False)
+//   SampledSoftmaxLoss.forward recstudio/model/loss_func.py:80-90   (one positive per row)
+//
+// RL lanes cooperate on one row (RL in {1, 4, 16, 64} chosen from n), each lane
+// striding over the row's negatives; group shuffles finish the row reductions.
+// Rows are reduced to the mean by a second, single-block, fixed-order kernel so the
+// scalar is deterministic.
+#include "rsa_common.hpp"
+
+namespace rsa {
+
+__device__ __forceinline__ float log_sigmoid(float x) {   // == F.logsigmoid
+  return fminf(x, 0.f) - log1pf(expf(-fabsf(x)));
+}
+__device__ __forceinline__ float sigmoid_neg(float x) {   // sigma(-x), stable
+  if (x >= 0.f) {
+    const float e = expf(-x);
+    return e / (1.f + e);
+  }
+  return 1.f / (1.f + expf(x));
+}
+
+template <int RL>
+__global__ __launch_bounds__(256) void pairwise_loss_kernel(int kind, const float* __restrict__ pos,
+                                                            const float* __restrict__ neg,
+                                                            const float* __restrict__ pos_lp,
+                                                            const float* __restrict__ neg_lp, int64_t M, int n,
+                                                            float* __restrict__ row_loss, float* __restrict__ dpos,
+                                                            float* __restrict__ dneg) {
+  const int sub = threadIdx.x % RL;
+  const int64_t g0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / RL;
+  const int64_t gstride = ((int64_t)gridDim.x * blockDim.x) / RL;
+  const float inv_m = 1.f / (float)M;
+  // every lane iterates ceil(M / gstride) times so that the group shuffles always see full waves
+  const int64_t m_end = ((M + gstride - 1) / gstride) * gstride;
+  for (int64_t m = g0; m < m_end; m += gstride) {
+    const bool rv = m < M;
+    const float* nrow = neg + (rv ? m : 0) * (int64_t)n;
+    const float* lrow = neg_lp ? neg_lp + (rv ? m : 0) * (int64_t)n : nullptr;
+    float* drow = dneg ? dneg + (rv ? m : 0) * (int64_t)n : nullptr;
+    const float ps = rv ? pos[m] : 0.f;
+    if (kind == RSA_LOSS_BPR) {
+      const float w = 1.f / (float)n;   // softmax(ones) == 1/n (loss_func.py:57)
+      float acc = 0.f, gsum = 0.f;
+      if (rv)
+        for (int j = sub; j < n; j += RL) {
+          const float x = ps - nrow[j];
+          acc += log_sigmoid(x) * w;
+          const float s = sigmoid_neg(x) * w * inv_m;
+          gsum += s;
+          if (drow) drow[j] = s;
+        }
+      acc = group_sum<RL>(acc);
+      gsum = group_sum<RL>(gsum);
+      if (rv && sub == 0) {
+        row_loss[m] = -acc;
+        if (dpos) dpos[m] = -gsum;
+      }
+    } else {
+      const float zp = ps - ((rv && pos_lp) ? pos_lp[m] : 0.f);
+      float mx = zp;
+      if (rv)
+        for (int j = sub; j < n; j += RL) mx = fmaxf(mx, nrow[j] - (lrow ? lrow[j] : 0.f));
+#pragma unroll
+      for (int k = RL / 2; k >= 1; k >>= 1) mx = fmaxf(mx, __shfl_xor(mx, k, 64));
+      float se = 0.f;
+      if (rv)
+        for (int j = sub; j < n; j += RL) se += expf(nrow[j] - (lrow ? lrow[j] : 0.f) - mx);
+      se = group_sum<RL>(se) + expf(zp - mx);
+      const float lse = mx + logf(se);
+      const bool bad = isinf(zp);   // padded positive: the reference divides 0 by 0 (loss_func.py:88-89)
+      if (rv) {
+        if (drow)
+          for (int j = sub; j < n; j += RL)
+            drow[j] = bad ? NAN : expf(nrow[j] - (lrow ? lrow[j] : 0.f) - lse) * inv_m;
+        if (sub == 0) {
+          row_loss[m] = bad ? NAN : (lse - zp);
+          if (dpos) dpos[m] = bad ? NAN : (expf(zp - lse) - 1.f) * inv_m;
+        }
+      }
+    }
+  }
+}
+
+// loss_out[0] = sum(row_loss) / M, fixed summation order.
+__global__ __launch_bounds__(1024) void mean_rows_kernel(const float* __restrict__ row_loss, int64_t M,
+                                                         float* __restrict__ out) {
+  __shared__ float part[16];
+  float acc = 0.f;
+  for (int64_t i = threadIdx.x; i < M; i += 1024) acc += row_loss[i];
+  acc = group_sum<64>(acc);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    float v = threadIdx.x < 16 ? part[threadIdx.x] : 0.f;
+    v = group_sum<64>(v);
+    if (threadIdx.x == 0) out[0] = v / (float)M;
+  }
+}
+
+}  // namespace rsa
+
+using namespace rsa;
+
+extern "C" int rsa_pairwise_loss(int32_t loss_kind, const float* pos_score, const float* neg_score,
+                                 const float* pos_logp, const float* neg_logp, int64_t n_rows, int32_t num_neg,
+                                 float* row_loss, float* loss_out, float* dpos, float* dneg, rsa_stream_t stream) {
+  RSA_CHECK_ARG(loss_kind == RSA_LOSS_BPR || loss_kind == RSA_LOSS_SSM, "rsa_pairwise_loss: unknown loss %d",
+                loss_kind);
+  RSA_CHECK_ARG(n_rows >= 1 && num_neg >= 1, "rsa_pairwise_loss: need n_rows >= 1 and num_neg >= 1");
+  RSA_CHECK_ARG(pos_score && neg_score && row_loss && loss_out, "rsa_pairwise_loss: null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  const int rl = num_neg <= 2 ? 1 : num_neg <= 8 ? 4 : num_neg <= 32 ? 16 : 64;
+  int64_t blocks = (n_rows * rl + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  dim3 grid((unsigned)blocks), block(256);
+#define RSA_LAUNCH_LOSS(RL)                                                                                      \
+  hipLaunchKernelGGL(pairwise_loss_kernel<RL>, grid, block, 0, s, (int)loss_kind, pos_score, neg_score, pos_logp, \
+                     neg_logp, n_rows, (int)num_neg, row_loss, dpos, dneg)
+  switch (rl) {
+    case 1: RSA_LAUNCH_LOSS(1); break;
+    case 4: RSA_LAUNCH_LOSS(4); break;
+    case 16: RSA_LAUNCH_LOSS(16); break;
+    default: RSA_LAUNCH_LOSS(64); break;
+  }
+#undef RSA_LAUNCH_LOSS
+  RSA_CHECK_LAUNCH("rsa_pairwise_loss");
+  hipLaunchKernelGGL(mean_rows_kernel, dim3(1), dim3(1024), 0, s, row_loss, n_rows, loss_out);
+  RSA_CHECK_LAUNCH("rsa_pairwise_loss(mean)");
+  return RSA_OK;
+}

@@ -1,0 +1,118 @@
+// Error plumbing, device info, plain embedding gather and the SeqDataset segment gather.
+#include <cstdarg>
+#include <cstdio>
+
+#include "rsa_common.hpp"
+
+namespace rsa {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+// out[i, :] = table[ids[i], :]; D/4 lanes per row, 16-B accesses.
+__global__ __launch_bounds__(256) void embedding_gather_kernel(const float* __restrict__ table, int64_t n_rows,
+                                                               int D, const int64_t* __restrict__ ids,
+                                                               int64_t numel, float* __restrict__ out) {
+  const int vec = D >> 2;   // float4 per row
+  const int64_t total = numel * vec;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int64_t row = i / vec;
+    const int c = (int)(i - row * vec);
+    int64_t id = ids[row];
+    id = id < 0 ? 0 : (id >= n_rows ? n_rows - 1 : id);
+    reinterpret_cast<float4*>(out)[i] = reinterpret_cast<const float4*>(table + (size_t)id * D)[c];
+  }
+}
+
+// One wave per (segment, position) pair group: block handles one segment.
+__global__ __launch_bounds__(256) void seg_gather_kernel(const float* __restrict__ table, int64_t n_items, int D,
+                                                         const int64_t* __restrict__ flat, int64_t n_flat,
+                                                         const int64_t* __restrict__ seg_start,
+                                                         const int64_t* __restrict__ seg_end, int max_len,
+                                                         int64_t* __restrict__ out_ids, float* __restrict__ out_rows,
+                                                         int64_t* __restrict__ out_len) {
+  const int64_t b = blockIdx.x;
+  int64_t s = seg_start[b], e = seg_end[b];
+  s = s < 0 ? 0 : s;
+  e = e > n_flat ? n_flat : e;
+  int64_t len = e > s ? e - s : 0;
+  if (len > max_len) {   // keep the most recent max_len items (dataset.py:1400,1409)
+    s = e - max_len;
+    len = max_len;
+  }
+  if (threadIdx.x == 0 && out_len) out_len[b] = len;
+  if (out_ids)
+    for (int l = threadIdx.x; l < max_len; l += blockDim.x) out_ids[b * max_len + l] = l < len ? flat[s + l] : 0;
+  if (out_rows) {
+    const int vec = D >> 2;
+    const int total = max_len * vec;
+    float4* orow = reinterpret_cast<float4*>(out_rows + (size_t)b * max_len * D);
+    for (int i = threadIdx.x; i < total; i += blockDim.x) {
+      const int l = i / vec, c = i - l * vec;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (l < len) {
+        int64_t id = flat[s + l];
+        id = id < 0 ? 0 : (id >= n_items ? n_items - 1 : id);
+        v = reinterpret_cast<const float4*>(table + (size_t)id * D)[c];
+      }
+      orow[i] = v;
+    }
+  }
+}
+
+}  // namespace rsa
+
+using namespace rsa;
+
+extern "C" const char* rsa_last_error(void) { return g_err; }
+extern "C" int rsa_abi_version(void) { return RSA_ABI_VERSION; }
+
+extern "C" int rsa_device_info(int device, int32_t* cu_count, int32_t* max_threads_per_cu, int32_t* wave_size) {
+  hipDeviceProp_t prop;
+  hipError_t e = hipGetDeviceProperties(&prop, device);
+  if (e != hipSuccess) {
+    set_error("rsa_device_info: hipGetDeviceProperties(%d): %s", device, hipGetErrorString(e));
+    return RSA_ERR_HIP;
+  }
+  if (cu_count) *cu_count = prop.multiProcessorCount;
+  if (max_threads_per_cu) *max_threads_per_cu = prop.maxThreadsPerMultiProcessor;
+  if (wave_size) *wave_size = prop.warpSize;
+  return RSA_OK;
+}
+
+extern "C" int rsa_embedding_gather(const float* table, int64_t n_rows, int32_t dim, const int64_t* ids,
+                                    int64_t numel, float* out, rsa_stream_t stream) {
+  RSA_CHECK_ARG(numel >= 0 && n_rows >= 1, "rsa_embedding_gather: bad sizes");
+  RSA_CHECK_ARG(dim >= 4 && dim % 4 == 0, "rsa_embedding_gather: dim=%d must be a positive multiple of 4", dim);
+  if (numel == 0) return RSA_OK;
+  RSA_CHECK_ARG(table && ids && out, "rsa_embedding_gather: null pointer");
+  const int64_t total = numel * (dim / 4);
+  int64_t blocks = (total + 255) / 256;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  hipLaunchKernelGGL(embedding_gather_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, table,
+                     n_rows, (int)dim, ids, numel, out);
+  RSA_CHECK_LAUNCH("rsa_embedding_gather");
+  return RSA_OK;
+}
+
+extern "C" int rsa_seg_gather(const float* item_table, int64_t n_items, int32_t dim, const int64_t* flat_item_ids,
+                              int64_t n_flat, const int64_t* seg_start, const int64_t* seg_end, int64_t n_seg,
+                              int32_t max_len, int64_t* out_ids, float* out_rows, int64_t* out_len,
+                              rsa_stream_t stream) {
+  RSA_CHECK_ARG(n_seg >= 0 && max_len >= 1 && n_flat >= 0, "rsa_seg_gather: bad sizes");
+  if (n_seg == 0) return RSA_OK;
+  RSA_CHECK_ARG(flat_item_ids && seg_start && seg_end, "rsa_seg_gather: null input pointer");
+  RSA_CHECK_ARG(out_rows == nullptr || (item_table && dim >= 4 && dim % 4 == 0 && n_items >= 1),
+                "rsa_seg_gather: out_rows needs item_table and dim % 4 == 0");
+  hipLaunchKernelGGL(seg_gather_kernel, dim3((unsigned)n_seg), dim3(256), 0, (hipStream_t)stream, item_table, n_items,
+                     (int)dim, flat_item_ids, n_flat, seg_start, seg_end, (int)max_len, out_ids, out_rows, out_len);
+  RSA_CHECK_LAUNCH("rsa_seg_gather");
+  return RSA_OK;
+}

@@ -1,0 +1,119 @@
+// Stand-alone negative samplers + small id utilities (gfx950).
+//
+// rsa_sample_uniform  : UniformSampler.forward      recstudio/ann/sampler.py:86-111
+// rsa_sample_popular  : PopularSamplerModel.forward recstudio/ann/sampler.py:243-258
+// rsa_item_logp       : compute_item_p              recstudio/ann/sampler.py:257-258
+//
+// The fused forward (rsa_fused.hip) draws the same stream in-kernel; these entry
+// points exist for the Sampler plugin surface (a Sampler used on its own) and as
+// the unit the parity tests compare with torch.randint / torch.rand on device.
+#include "rsa_common.hpp"
+
+namespace rsa {
+
+__global__ __launch_bounds__(256) void sample_uniform_kernel(int64_t* __restrict__ out, int64_t numel,
+                                                             uint64_t range, int64_t low, PhiloxCall pc) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < numel; e += stride)
+    out[e] = torch_randint_element(pc, (uint64_t)e, range, low);
+}
+
+template <bool FROM_U>
+__global__ __launch_bounds__(256) void sample_popular_kernel(const float* __restrict__ table,
+                                                             const float* __restrict__ pop_prob,
+                                                             const int32_t* __restrict__ guide, int64_t n_items,
+                                                             int guide_log2, const float* __restrict__ u_in,
+                                                             int64_t* __restrict__ ids, float* __restrict__ logp,
+                                                             float* __restrict__ u_out, int64_t numel,
+                                                             PhiloxCall pc) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < numel; e += stride) {
+    const float u = FROM_U ? u_in[e] : torch_rand_element(pc, (uint64_t)e);
+    const int32_t id = cdf_lower_bound(table, guide, n_items, guide_log2, u);
+    ids[e] = id;
+    if (logp) logp[e] = logf(pop_prob[id]);
+    if (!FROM_U && u_out) u_out[e] = u;
+  }
+}
+
+__global__ __launch_bounds__(256) void item_logp_kernel(const float* __restrict__ pop_prob, int64_t n_items,
+                                                        const int64_t* __restrict__ ids, int64_t numel,
+                                                        float* __restrict__ logp) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < numel; e += stride) {
+    int64_t id = ids[e];
+    id = id < 0 ? 0 : (id >= n_items ? n_items - 1 : id);
+    logp[e] = logf(pop_prob[id]);
+  }
+}
+
+static inline int grid_for(int64_t numel) {
+  int64_t b = (numel + 255) / 256;
+  return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
+}
+
+}  // namespace rsa
+
+using namespace rsa;
+
+extern "C" int rsa_sample_uniform(int64_t* neg_ids, int64_t numel, int64_t low, int64_t high, uint64_t seed,
+                                  uint64_t offset, uint32_t grid_threads, rsa_stream_t stream) {
+  RSA_CHECK_ARG(numel >= 0, "rsa_sample_uniform: numel < 0");
+  if (numel == 0) return RSA_OK;
+  RSA_CHECK_ARG(neg_ids != nullptr, "rsa_sample_uniform: neg_ids is null");
+  RSA_CHECK_ARG(high > low, "rsa_sample_uniform: empty range [%lld, %lld)", (long long)low, (long long)high);
+  RSA_CHECK_ARG(grid_threads > 0 && (offset & 3) == 0, "rsa_sample_uniform: bad philox state");
+  PhiloxCall pc{seed, offset >> 2, grid_threads};
+  hipLaunchKernelGGL(sample_uniform_kernel, dim3(grid_for(numel)), dim3(256), 0, (hipStream_t)stream, neg_ids, numel,
+                     (uint64_t)(high - low), low, pc);
+  RSA_CHECK_LAUNCH("rsa_sample_uniform");
+  return RSA_OK;
+}
+
+static int check_popular(const char* fn, const float* table, const float* pop_prob, const int32_t* guide,
+                         int64_t n_items, int32_t guide_log2) {
+  RSA_CHECK_ARG(table && pop_prob && guide, "%s: table/pop_prob/guide is null", fn);
+  RSA_CHECK_ARG(n_items >= 1 && n_items < (1ll << 31), "%s: n_items out of range", fn);
+  RSA_CHECK_ARG(guide_log2 >= 0 && guide_log2 <= 24, "%s: guide_log2 must be in [0, 24]", fn);
+  return RSA_OK;
+}
+
+extern "C" int rsa_sample_popular(const float* table, const float* pop_prob, const int32_t* guide, int64_t n_items,
+                                  int32_t guide_log2, int64_t* neg_ids, float* neg_logp, float* u_out, int64_t numel,
+                                  uint64_t seed, uint64_t offset, uint32_t grid_threads, rsa_stream_t stream) {
+  RSA_CHECK_ARG(numel >= 0, "rsa_sample_popular: numel < 0");
+  if (numel == 0) return RSA_OK;
+  if (int rc = check_popular("rsa_sample_popular", table, pop_prob, guide, n_items, guide_log2)) return rc;
+  RSA_CHECK_ARG(neg_ids != nullptr, "rsa_sample_popular: neg_ids is null");
+  RSA_CHECK_ARG(grid_threads > 0 && (offset & 3) == 0, "rsa_sample_popular: bad philox state");
+  PhiloxCall pc{seed, offset >> 2, grid_threads};
+  hipLaunchKernelGGL(sample_popular_kernel<false>, dim3(grid_for(numel)), dim3(256), 0, (hipStream_t)stream, table,
+                     pop_prob, guide, n_items, guide_log2, (const float*)nullptr, neg_ids, neg_logp, u_out, numel, pc);
+  RSA_CHECK_LAUNCH("rsa_sample_popular");
+  return RSA_OK;
+}
+
+extern "C" int rsa_popular_lookup(const float* table, const float* pop_prob, const int32_t* guide, int64_t n_items,
+                                  int32_t guide_log2, const float* u, int64_t* ids, float* logp, int64_t numel,
+                                  rsa_stream_t stream) {
+  RSA_CHECK_ARG(numel >= 0, "rsa_popular_lookup: numel < 0");
+  if (numel == 0) return RSA_OK;
+  if (int rc = check_popular("rsa_popular_lookup", table, pop_prob, guide, n_items, guide_log2)) return rc;
+  RSA_CHECK_ARG(u && ids, "rsa_popular_lookup: u/ids is null");
+  PhiloxCall pc{0, 0, 1};
+  hipLaunchKernelGGL(sample_popular_kernel<true>, dim3(grid_for(numel)), dim3(256), 0, (hipStream_t)stream, table,
+                     pop_prob, guide, n_items, guide_log2, u, ids, logp, (float*)nullptr, numel, pc);
+  RSA_CHECK_LAUNCH("rsa_popular_lookup");
+  return RSA_OK;
+}
+
+extern "C" int rsa_item_logp(const float* pop_prob, int64_t n_items, const int64_t* ids, int64_t numel, float* logp,
+                             rsa_stream_t stream) {
+  RSA_CHECK_ARG(numel >= 0, "rsa_item_logp: numel < 0");
+  if (numel == 0) return RSA_OK;
+  RSA_CHECK_ARG(pop_prob && ids && logp && n_items >= 1, "rsa_item_logp: null pointer / empty table");
+  hipLaunchKernelGGL(item_logp_kernel, dim3(grid_for(numel)), dim3(256), 0, (hipStream_t)stream, pop_prob, n_items,
+                     ids, numel, logp);
+  RSA_CHECK_LAUNCH("rsa_item_logp");
+  return RSA_OK;
+}

@@ -1,0 +1,130 @@
+"""The fused hot path as autograd nodes: sample -> gather -> score (-> loss) with a row-wise
+gradient scatter-add backward.
+
+``retriever_scores`` is what ``BaseRetriever.forward`` dispatches to when the item tower is an
+``nn.Embedding`` (recstudio/model/basemodel/baseretriever.py:153-171): it returns the same
+``pos_score / log_pos_prob / neg_score / log_neg_prob`` tensors plus ``neg_id`` without ever
+materialising the [B, n, d] negative rows.  Its backward is ``rsa_fused_backward`` and yields what
+autograd produces in the reference (dense ``weight.grad`` with row 0 untouched), or row-sparse
+COO gradients when ``sparse_grad=True`` (the only workable form at N = 1e7..1e8).
+"""
+import torch
+
+from . import _native as nat
+from . import ops
+from .sampler import PopularSamplerModel, Sampler, UniformSampler
+
+
+def _sampler_kind(sampler):
+    # exact types only: a subclass may override forward, and must then go through the plugin path
+    if type(sampler) is UniformSampler:
+        return nat.SAMPLER_UNIFORM
+    if type(sampler) is PopularSamplerModel:
+        return nat.SAMPLER_POPULAR
+    return None
+
+
+class _ScoreFn(torch.autograd.Function):
+    """(item_weight, query_src) -> (pos_score, neg_score); non-differentiable extras ride in ctx.extras."""
+
+    @staticmethod
+    def forward(ctx, item_weight, query_src, cfg):
+        out = ops.fused_forward(item_weight, query_src, cfg['num_neg'], query_index=cfg.get('query_index'),
+                                pos_ids=cfg.get('pos_ids'), neg_ids=cfg.get('neg_ids'), sampler=cfg['sampler'],
+                                cosine=cfg.get('cosine', False), mask_pad_pos=cfg.get('mask_pad_pos', False),
+                                table=cfg.get('table'), pop_prob=cfg.get('pop_prob'), guide=cfg.get('guide'),
+                                guide_log2=cfg.get('guide_log2', 0), n_queries=cfg.get('n_queries'))
+        cfg['out'] = out
+        ctx.cfg = cfg
+        ctx.save_for_backward(item_weight, query_src, out['neg_ids'])
+        pos = out.get('pos_score')
+        if pos is None:
+            pos = item_weight.new_zeros(0)
+        return pos, out['neg_score']
+
+    @staticmethod
+    def backward(ctx, gpos, gneg):
+        cfg = ctx.cfg
+        if cfg.get('cosine', False):
+            raise NotImplementedError('backward of the cosine scorer is not implemented in this build')
+        item_weight, query_src, neg_ids = ctx.saved_tensors
+        qi, pos_ids = cfg.get('query_index'), cfg.get('pos_ids')
+        sparse = cfg.get('sparse_grad', False)
+        need_item = ctx.needs_input_grad[0]
+        need_q = ctx.needs_input_grad[1]
+        if gneg is None:
+            gneg = torch.zeros_like(cfg['out']['neg_score'])
+        if pos_ids is not None and (gpos is None or gpos.numel() == 0):
+            gpos = torch.zeros(pos_ids.numel(), dtype=torch.float32, device=item_weight.device)
+        item_grad, rows, qgrad = ops.fused_backward(
+            item_weight, query_src, neg_ids, gneg.contiguous(), query_index=qi, pos_ids=pos_ids,
+            dpos=None if pos_ids is None else gpos.contiguous(),
+            dense_item_grad=need_item and not sparse, row_item_grad=need_item and sparse, want_query_grad=need_q)
+        g_item = None
+        if need_item:
+            if sparse:
+                M, n = neg_ids.shape
+                pos_col = pos_ids.view(M, 1) if pos_ids is not None else neg_ids.new_zeros(M, 1)
+                idx = torch.cat([pos_col, neg_ids], 1).reshape(1, -1)
+                g_item = torch.sparse_coo_tensor(idx, rows, item_weight.shape)
+            else:
+                g_item = item_grad
+        g_q = None
+        if need_q:
+            if qi is not None:        # query_src is a user table: embedding_dense_backward
+                if sparse:
+                    g_q = torch.sparse_coo_tensor(qi.view(1, -1), qgrad, query_src.shape)
+                else:
+                    g_q = ops.scatter_add_rows(qgrad, qi, query_src.shape[0])
+            else:
+                g_q = qgrad
+        return g_item, g_q, None
+
+
+def retriever_scores(item_weight, query_src, num_neg, *, query_index=None, pos_ids=None, sampler=None,
+                     neg_ids=None, cosine=False, mask_pad_pos=False, sparse_grad=False):
+    """Fused BaseRetriever.forward body.  ``query_src`` is either the [M, d] query vectors or a user
+    table together with ``query_index`` [M].  ``sampler`` is a UniformSampler / PopularSamplerModel
+    (ids drawn in-kernel) or None with ``neg_ids`` given.  Returns the reference's score dict
+    (baseretriever.py:170-171) plus ``neg_id``."""
+    M = query_index.numel() if query_index is not None else query_src.shape[0]
+    cfg = {'num_neg': int(num_neg), 'query_index': query_index, 'pos_ids': pos_ids, 'cosine': cosine,
+           'mask_pad_pos': mask_pad_pos, 'sparse_grad': sparse_grad, 'n_queries': M}
+    kind = _sampler_kind(sampler) if sampler is not None else nat.SAMPLER_GIVEN
+    if kind is None:
+        raise TypeError(f'fused path does not cover sampler {type(sampler).__name__}')
+    cfg['sampler'] = kind
+    if kind == nat.SAMPLER_GIVEN:
+        if neg_ids is None:
+            raise ValueError('neg_ids is required when no sampler is given')
+        cfg['neg_ids'] = neg_ids.reshape(M, -1)
+    elif kind == nat.SAMPLER_POPULAR:
+        cfg.update(table=sampler.table, pop_prob=sampler.pop_prob, guide=sampler.guide,
+                   guide_log2=sampler.guide_log2)
+    pos_score, neg_score = _ScoreFn.apply(item_weight, query_src, cfg)
+    out = cfg['out']
+    score = {'pos_score': pos_score if pos_ids is not None else None, 'neg_score': neg_score}
+    if kind == nat.SAMPLER_POPULAR:
+        score['log_pos_prob'] = out.get('pos_logp')
+        score['log_neg_prob'] = out['neg_logp']
+    else:
+        # UniformSampler.compute_item_p: int64 zeros (sampler.py:113-114)
+        score['log_pos_prob'] = None if pos_ids is None else torch.zeros_like(pos_ids)
+        score['log_neg_prob'] = torch.zeros_like(out['neg_ids'])
+    return score, out['neg_ids']
+
+
+def train_step_no_autograd(item_weight, query_src, num_neg, loss_kind, *, query_index, pos_ids, sampler=None,
+                           neg_ids=None, sparse_grad=True, want_user_grad=True):
+    """sample+gather+score -> loss(+dscore) -> scatter-add, three launches, no autograd graph.
+    Used by bench.py for the training-step figure; returns (loss, score dict, grads)."""
+    with torch.no_grad():
+        score, ids = retriever_scores(item_weight, query_src, num_neg, query_index=query_index, pos_ids=pos_ids,
+                                      sampler=sampler, neg_ids=neg_ids)
+        lp = score['log_pos_prob'] if score['log_pos_prob'] is not None and score['log_pos_prob'].is_floating_point() else None
+        ln = score['log_neg_prob'] if score['log_neg_prob'].is_floating_point() else None
+        loss, dpos, dneg, _ = ops.pairwise_loss(loss_kind, score['pos_score'], score['neg_score'], lp, ln)
+        grads = ops.fused_backward(item_weight, query_src, ids, dneg, query_index=query_index, pos_ids=pos_ids,
+                                   dpos=dpos, dense_item_grad=not sparse_grad, row_item_grad=sparse_grad,
+                                   want_query_grad=want_user_grad)
+    return loss, score, grads

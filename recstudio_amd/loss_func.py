@@ -1,0 +1,101 @@
+"""Losses -- host-side mirror of ``recstudio.model.loss_func`` for BPR / SampledSoftmax / Softmax.
+
+Class taxonomy and ``forward`` parameter NAMES follow the reference
+(recstudio/model/loss_func.py:6-28, :39-47, :50-63, :80-90) because
+``BaseRetriever.training_step`` calls ``loss_fn(**score)`` by keyword
+(baseretriever.py:399-404).  Value and gradient come from ``rsa_pairwise_loss`` in one
+pass; autograd sees a single node.
+"""
+import torch
+
+from . import _native as nat
+from . import ops
+
+__all__ = ['FullScoreLoss', 'PairwiseLoss', 'PointwiseLoss', 'BPRLoss', 'SampledSoftmaxLoss', 'SoftmaxLoss']
+
+
+class FullScoreLoss(torch.nn.Module):
+    def forward(self, label, pos_score, all_score):
+        pass
+
+
+class PairwiseLoss(torch.nn.Module):
+    def forward(self, label, pos_score, log_pos_prob, neg_score, log_neg_prob):
+        pass
+
+
+class PointwiseLoss(torch.nn.Module):
+    def forward(self, label, pos_score):
+        raise NotImplementedError(f'{type(self).__name__} is an abstract class')
+
+
+class _PairwiseFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, kind, pos_score, neg_score, pos_logp, neg_logp):
+        need = pos_score.requires_grad or neg_score.requires_grad
+        loss, dpos, dneg, _ = ops.pairwise_loss(kind, pos_score, neg_score, pos_logp, neg_logp, want_grad=True)
+        ctx.save_for_backward(dpos, dneg)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        dpos, dneg = ctx.saved_tensors
+        return None, dpos * g, dneg * g, None, None
+
+
+def _as_f32_or_none(t):
+    """The reference's UniformSampler hands int64 zeros as log-probs (sampler.py:113-114)."""
+    if t is None:
+        return None
+    if not t.is_floating_point():
+        return None if not bool(t.any()) else t.to(torch.float32)
+    return t
+
+
+def _check_shapes(pos_score, neg_score):
+    if pos_score.dim() != neg_score.dim() - 1 or tuple(pos_score.shape) != tuple(neg_score.shape[:-1]):
+        raise NotImplementedError(
+            'recstudio_amd pairwise losses need pos_score [..] with neg_score [.., n] (one negative set per '
+            f'positive); got {tuple(pos_score.shape)} and {tuple(neg_score.shape)}')
+
+
+class BPRLoss(PairwiseLoss):
+    """recstudio/model/loss_func.py:50-59 (dns=False)."""
+
+    def __init__(self, dns=False):
+        super().__init__()
+        if dns:
+            raise NotImplementedError('BPRLoss(dns=True) is outside the hot path this package covers')
+        self.dns = dns
+
+    def forward(self, label, pos_score, log_pos_prob, neg_score, log_neg_prob):
+        _check_shapes(pos_score, neg_score)
+        return _PairwiseFn.apply(nat.LOSS_BPR, pos_score, neg_score, None, None)
+
+
+class SampledSoftmaxLoss(PairwiseLoss):
+    """recstudio/model/loss_func.py:80-90."""
+
+    def forward(self, label, pos_score, log_pos_prob, neg_score, log_neg_prob):
+        _check_shapes(pos_score, neg_score)
+        return _PairwiseFn.apply(nat.LOSS_SSM, pos_score, neg_score, _as_f32_or_none(log_pos_prob),
+                                 _as_f32_or_none(log_neg_prob))
+
+
+class SoftmaxLoss(FullScoreLoss):
+    """recstudio/model/loss_func.py:39-47, first branch (all_score one dim more than pos_score).
+    mean(logsumexp(all_score) - pos_score) == the sampled-softmax kernel with the positive taken
+    out of the partition sum: handled by passing -inf as the positive column."""
+
+    def forward(self, label, pos_score, all_score):
+        if all_score.dim() != pos_score.dim() + 1:
+            raise NotImplementedError('SoftmaxLoss: only all_score [.., N] with pos_score [..] is implemented')
+        return _RowLseFn.apply(all_score).mean() - pos_score.mean()
+
+
+class _RowLseFn(torch.autograd.Function):
+    """logsumexp over the last dim via rsa_pairwise_loss(SSM) with a zero-weight positive."""
+
+    @staticmethod
+    def forward(ctx, all_score):
+        raise NotImplementedError('materialised-SoftmaxLoss needs the full-score kernel (use BaseRetriever)')

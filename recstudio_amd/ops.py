@@ -1,0 +1,247 @@
+"""Tensor-level wrappers over the C ABI (include/recstudio_amd.h).
+
+PyTorch is used for device memory, streams and the generator state only; every
+computation below happens in the HIP kernels of librecstudio_amd.so.  All
+tensors must live on a ROCm device -- there is no CPU path.
+"""
+import ctypes
+
+import torch
+
+from . import _native as nat
+from . import rng
+from ._native import ptr
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _need(t, dtype, name):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f'{name}: expected a tensor, got {type(t)}')
+    if not t.is_cuda:
+        raise RuntimeError(f'{name}: recstudio_amd runs on the GPU only (got a {t.device} tensor); '
+                           'there is no CPU fallback')
+    if t.dtype != dtype:
+        raise TypeError(f'{name}: expected {dtype}, got {t.dtype}')
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _need_opt(t, dtype, name):
+    return None if t is None else _need(t, dtype, name)
+
+
+# ------------------------------------------------------------------ samplers
+def sample_uniform(numel, low, high, device, generator=None):
+    """int64 [numel], == torch.randint(low, high, (numel,), device=device) incl. generator advance."""
+    out = torch.empty(int(numel), dtype=torch.int64, device=device)
+    if numel == 0:
+        return out
+    pc = rng.reserve(numel, rng.randint_unroll(low, high), device, generator)
+    nat.check(nat.lib().rsa_sample_uniform(ptr(out), int(numel), int(low), int(high), pc.seed, pc.offset,
+                                           pc.grid_threads, _stream()), 'rsa_sample_uniform')
+    return out
+
+
+def sample_popular(table, pop_prob, guide, guide_log2, numel, generator=None, want_u=False):
+    table = _need(table, torch.float32, 'table')
+    pop_prob = _need(pop_prob, torch.float32, 'pop_prob')
+    guide = _need(guide, torch.int32, 'guide')
+    dev = table.device
+    ids = torch.empty(int(numel), dtype=torch.int64, device=dev)
+    logp = torch.empty(int(numel), dtype=torch.float32, device=dev)
+    u = torch.empty(int(numel), dtype=torch.float32, device=dev) if want_u else None
+    if numel:
+        pc = rng.reserve(numel, 4, dev, generator)
+        nat.check(nat.lib().rsa_sample_popular(ptr(table), ptr(pop_prob), ptr(guide), table.numel(), int(guide_log2),
+                                               ptr(ids), ptr(logp), ptr(u), int(numel), pc.seed, pc.offset,
+                                               pc.grid_threads, _stream()), 'rsa_sample_popular')
+    return (ids, logp, u) if want_u else (ids, logp)
+
+
+def popular_lookup(table, pop_prob, guide, guide_log2, u):
+    table = _need(table, torch.float32, 'table')
+    pop_prob = _need(pop_prob, torch.float32, 'pop_prob')
+    guide = _need(guide, torch.int32, 'guide')
+    u = _need(u, torch.float32, 'u')
+    ids = torch.empty(u.numel(), dtype=torch.int64, device=u.device)
+    logp = torch.empty(u.numel(), dtype=torch.float32, device=u.device)
+    nat.check(nat.lib().rsa_popular_lookup(ptr(table), ptr(pop_prob), ptr(guide), table.numel(), int(guide_log2),
+                                           ptr(u), ptr(ids), ptr(logp), u.numel(), _stream()), 'rsa_popular_lookup')
+    return ids.view(u.shape), logp.view(u.shape)
+
+
+def item_logp(pop_prob, ids):
+    pop_prob = _need(pop_prob, torch.float32, 'pop_prob')
+    ids = _need(ids, torch.int64, 'ids')
+    out = torch.empty(ids.shape, dtype=torch.float32, device=ids.device)
+    nat.check(nat.lib().rsa_item_logp(ptr(pop_prob), pop_prob.numel(), ptr(ids), ids.numel(), ptr(out), _stream()),
+              'rsa_item_logp')
+    return out
+
+
+# ------------------------------------------------------------------ gathers
+def embedding_gather(table, ids):
+    table = _need(table, torch.float32, 'table')
+    ids = _need(ids, torch.int64, 'ids')
+    n_rows, dim = table.shape
+    out = torch.empty(*ids.shape, dim, dtype=torch.float32, device=table.device)
+    nat.check(nat.lib().rsa_embedding_gather(ptr(table), n_rows, dim, ptr(ids), ids.numel(), ptr(out), _stream()),
+              'rsa_embedding_gather')
+    return out
+
+
+def scatter_add_rows(src, ids, n_rows):
+    src = _need(src, torch.float32, 'src')
+    ids = _need(ids, torch.int64, 'ids')
+    dim = src.shape[-1]
+    dst = torch.zeros(n_rows, dim, dtype=torch.float32, device=src.device)
+    nat.check(nat.lib().rsa_scatter_add_rows(ptr(src), ptr(ids), ids.numel(), dim, ptr(dst), n_rows, _stream()),
+              'rsa_scatter_add_rows')
+    return dst
+
+
+def seg_gather(item_table, flat_item_ids, seg_start, seg_end, max_len, want_rows=True, want_ids=True):
+    flat = _need(flat_item_ids, torch.int64, 'flat_item_ids')
+    s = _need(seg_start, torch.int64, 'seg_start')
+    e = _need(seg_end, torch.int64, 'seg_end')
+    dev = flat.device
+    B = s.numel()
+    tab = _need(item_table, torch.float32, 'item_table') if want_rows else None
+    dim = tab.shape[1] if tab is not None else 4
+    n_items = tab.shape[0] if tab is not None else 1
+    ids = torch.empty(B, max_len, dtype=torch.int64, device=dev) if want_ids else None
+    rows = torch.empty(B, max_len, dim, dtype=torch.float32, device=dev) if want_rows else None
+    lens = torch.empty(B, dtype=torch.int64, device=dev)
+    nat.check(nat.lib().rsa_seg_gather(ptr(tab), n_items, dim, ptr(flat), flat.numel(), ptr(s), ptr(e), B,
+                                       int(max_len), ptr(ids), ptr(rows), ptr(lens), _stream()), 'rsa_seg_gather')
+    return ids, rows, lens
+
+
+# ------------------------------------------------------------------ fused forward / backward
+def fused_forward(item_table, query, num_neg, *, query_index=None, pos_ids=None, neg_ids=None,
+                  sampler=nat.SAMPLER_GIVEN, cosine=False, mask_pad_pos=False,
+                  table=None, pop_prob=None, guide=None, guide_log2=0, generator=None, n_queries=None,
+                  out=None):
+    """One launch of rsa_fused_sample_gather_score.  Returns a dict with
+    neg_ids [M,n] int64, neg_score [M,n], pos_score [M] (if pos_ids), and for the
+    popularity sampler neg_logp [M,n], pos_logp [M].  ``out``: a dict returned by an earlier
+    call with the same shapes, whose buffers are overwritten instead of allocating."""
+    item_table = _need(item_table, torch.float32, 'item_table')
+    query = _need(query, torch.float32, 'query')
+    dev = item_table.device
+    n_items, dim = item_table.shape
+    if query.dim() != 2 or query.shape[1] != dim:
+        raise ValueError(f'query must be [rows, {dim}], got {tuple(query.shape)}')
+    query_index = _need_opt(query_index, torch.int64, 'query_index')
+    pos_ids = _need_opt(pos_ids, torch.int64, 'pos_ids')
+    if n_queries is None:
+        n_queries = query_index.numel() if query_index is not None else query.shape[0]
+    M, n = int(n_queries), int(num_neg)
+    if pos_ids is not None and pos_ids.numel() != M:
+        raise ValueError('pos_ids must have one id per query')
+    a = nat.FusedArgs()
+    if sampler == nat.SAMPLER_GIVEN:
+        neg_ids = _need(neg_ids, torch.int64, 'neg_ids')
+        if neg_ids.numel() != M * n:
+            raise ValueError('neg_ids must be [M, num_neg]')
+    else:
+        neg_ids = out['neg_ids'] if out is not None else torch.empty(M, n, dtype=torch.int64, device=dev)
+        unroll = 4 if sampler == nat.SAMPLER_POPULAR else rng.randint_unroll(1, n_items)
+        pc = rng.reserve(M * n, unroll, dev, generator)
+        a.seed, a.offset, a.grid_threads = pc.seed, pc.offset, pc.grid_threads
+    reuse = out is not None        # caller-provided output buffers (same keys/shapes as returned)
+    if not reuse:
+        out = {'neg_score': torch.empty(M, n, dtype=torch.float32, device=dev)}
+        if pos_ids is not None:
+            out['pos_score'] = torch.empty(M, dtype=torch.float32, device=dev)
+    out['neg_ids'] = neg_ids.view(M, n)
+    if sampler == nat.SAMPLER_POPULAR:
+        table = _need(table, torch.float32, 'table')
+        pop_prob = _need(pop_prob, torch.float32, 'pop_prob')
+        guide = _need(guide, torch.int32, 'guide')
+        if not reuse:
+            out['neg_logp'] = torch.empty(M, n, dtype=torch.float32, device=dev)
+            if pos_ids is not None:
+                out['pos_logp'] = torch.empty(M, dtype=torch.float32, device=dev)
+    a.item_table, a.n_items, a.dim = ptr(item_table), n_items, dim
+    a.score_mode = nat.SCORE_COS if cosine else nat.SCORE_IP
+    a.query, a.query_index, a.n_query_rows = ptr(query), ptr(query_index), query.shape[0]
+    a.pos_ids, a.n_queries, a.num_neg = ptr(pos_ids), M, n
+    a.sampler, a.mask_pad_pos, a.guide_log2 = int(sampler), int(bool(mask_pad_pos)), int(guide_log2)
+    a.table, a.pop_prob, a.guide = ptr(table), ptr(pop_prob), ptr(guide)
+    a.neg_ids, a.neg_logp, a.pos_logp = ptr(neg_ids), ptr(out.get('neg_logp')), ptr(out.get('pos_logp'))
+    a.pos_score, a.neg_score = ptr(out.get('pos_score')), ptr(out['neg_score'])
+    nat.check(nat.lib().rsa_fused_sample_gather_score(ctypes.byref(a), _stream()), 'rsa_fused_sample_gather_score')
+    return out
+
+
+def pairwise_loss(kind, pos_score, neg_score, pos_logp=None, neg_logp=None, want_grad=True):
+    """(loss [scalar tensor], dpos [M] | None, dneg [M,n] | None, row_loss [M])."""
+    pos_score = _need(pos_score, torch.float32, 'pos_score')
+    neg_score = _need(neg_score, torch.float32, 'neg_score')
+    M = pos_score.numel()
+    n = neg_score.numel() // max(M, 1)
+    if neg_score.numel() != M * n or M == 0 or n == 0:
+        raise ValueError(f'pairwise_loss: pos {tuple(pos_score.shape)} vs neg {tuple(neg_score.shape)}')
+    pos_logp = _need_opt(pos_logp, torch.float32, 'pos_logp')
+    neg_logp = _need_opt(neg_logp, torch.float32, 'neg_logp')
+    dev = pos_score.device
+    row = torch.empty(M, dtype=torch.float32, device=dev)
+    loss = torch.empty((), dtype=torch.float32, device=dev)
+    dpos = torch.empty(pos_score.shape, dtype=torch.float32, device=dev) if want_grad else None
+    dneg = torch.empty(neg_score.shape, dtype=torch.float32, device=dev) if want_grad else None
+    nat.check(nat.lib().rsa_pairwise_loss(int(kind), ptr(pos_score), ptr(neg_score), ptr(pos_logp), ptr(neg_logp),
+                                          M, n, ptr(row), ptr(loss), ptr(dpos), ptr(dneg), _stream()),
+              'rsa_pairwise_loss')
+    return loss, dpos, dneg, row
+
+
+def fused_backward(item_table, query, neg_ids, dneg, *, query_index=None, pos_ids=None, dpos=None, upstream=None,
+                   dense_item_grad=True, row_item_grad=False, want_query_grad=True):
+    """rsa_fused_backward.  Returns (item_grad [N,d] | None, item_grad_rows [M*(n+1), d] | None,
+    query_grad [M,d] | None)."""
+    item_table = _need(item_table, torch.float32, 'item_table')
+    query = _need(query, torch.float32, 'query')
+    neg_ids = _need(neg_ids, torch.int64, 'neg_ids')
+    dneg = _need(dneg, torch.float32, 'dneg')
+    query_index = _need_opt(query_index, torch.int64, 'query_index')
+    pos_ids = _need_opt(pos_ids, torch.int64, 'pos_ids')
+    dpos = _need_opt(dpos, torch.float32, 'dpos')
+    upstream = _need_opt(upstream, torch.float32, 'upstream')
+    dev = item_table.device
+    n_items, dim = item_table.shape
+    M = query_index.numel() if query_index is not None else query.shape[0]
+    n = neg_ids.numel() // M
+    item_grad = torch.zeros(n_items, dim, dtype=torch.float32, device=dev) if dense_item_grad else None
+    rows = torch.empty(M * (n + 1), dim, dtype=torch.float32, device=dev) if row_item_grad else None
+    if rows is not None and pos_ids is None:
+        rows.zero_()
+    qgrad = torch.empty(M, dim, dtype=torch.float32, device=dev) if want_query_grad else None
+    a = nat.BackwardArgs()
+    a.item_table, a.n_items, a.dim, a.num_neg = ptr(item_table), n_items, dim, n
+    a.query, a.query_index, a.n_query_rows = ptr(query), ptr(query_index), query.shape[0]
+    a.pos_ids, a.neg_ids, a.n_queries = ptr(pos_ids), ptr(neg_ids), M
+    a.dpos, a.dneg, a.upstream = ptr(dpos), ptr(dneg), ptr(upstream)
+    a.item_grad, a.item_grad_rows, a.query_grad = ptr(item_grad), ptr(rows), ptr(qgrad)
+    nat.check(nat.lib().rsa_fused_backward(ctypes.byref(a), _stream()), 'rsa_fused_backward')
+    return item_grad, rows, qgrad
+
+
+# ------------------------------------------------------------------ full catalog
+def fullscore(item_table, query, *, want_scores=False, want_lse=False, k=0):
+    item_table = _need(item_table, torch.float32, 'item_table')
+    query = _need(query, torch.float32, 'query')
+    dev = item_table.device
+    n_items, dim = item_table.shape
+    B = query.shape[0]
+    scores = torch.empty(B, n_items - 1, dtype=torch.float32, device=dev) if want_scores else None
+    lse = torch.empty(B, dtype=torch.float32, device=dev) if want_lse else None
+    tv = torch.empty(B, k, dtype=torch.float32, device=dev) if k else None
+    ti = torch.empty(B, k, dtype=torch.int64, device=dev) if k else None
+    ws_bytes = int(nat.lib().rsa_fullscore_workspace_bytes(B, n_items, int(k)))
+    ws = torch.empty(max(ws_bytes, 8), dtype=torch.uint8, device=dev)
+    nat.check(nat.lib().rsa_fullscore(ptr(item_table), n_items, dim, ptr(query), B, ptr(scores), ptr(lse), ptr(tv),
+                                      ptr(ti), int(k), ptr(ws), ws_bytes, _stream()), 'rsa_fullscore')
+    return scores, lse, tv, ti

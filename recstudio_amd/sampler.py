@@ -1,0 +1,113 @@
+"""Negative samplers -- host-side mirror of ``recstudio.ann.sampler`` for the graded samplers.
+
+Same class names, constructor arguments, ``forward`` signature and return
+conventions as recstudio/ann/sampler.py:48-58 (Sampler), :81-114
+(UniformSampler) and :224-258 (PopularSamplerModel); the sampling itself runs in
+HIP (``rsa_sample_uniform`` / ``rsa_sample_popular``) on the torch device Philox
+stream, so the ids equal what the reference's ``torch.randint`` / ``torch.rand``
++ ``torch.searchsorted`` produce on the same device for the same seed.
+"""
+from typing import Optional, Union
+
+import numpy as np
+import torch
+from torch import Tensor
+
+from . import ops
+
+__all__ = ['Sampler', 'UniformSampler', 'PopularSamplerModel', 'build_guide_table']
+
+
+class Sampler(torch.nn.Module):
+    """recstudio/ann/sampler.py:48-58."""
+
+    def __init__(self, num_items, scorer_fn=None):
+        super().__init__()
+        self.num_items = num_items - 1   # remove padding (sampler.py:51)
+        self.scorer = scorer_fn
+
+    def update(self, item_embs, max_iter=30):
+        pass
+
+    def compute_item_p(self, query, pos_items):
+        pass
+
+
+def _query_shape(query, pos_items, device):
+    if isinstance(query, int):                      # sampler.py:91-94
+        dev = pos_items.device if pos_items is not None else device
+        return (query,), dev
+    if isinstance(query, Tensor):                   # sampler.py:95-99
+        return tuple(query.shape[:-1]), query.device
+    raise TypeError('`query` must be an int or a Tensor')
+
+
+class UniformSampler(Sampler):
+    """recstudio/ann/sampler.py:81-114: ids uniform in [1, num_items], int64 zero "log-probs"."""
+
+    def forward(self, query: Union[Tensor, int], num_neg: int, pos_items: Optional[Tensor] = None,
+                device: Optional[torch.device] = None):
+        shape, dev = _query_shape(query, pos_items, device)
+        nq = int(np.prod(shape))
+        with torch.no_grad():
+            neg = ops.sample_uniform(nq * num_neg, 1, self.num_items + 1, dev)
+            neg = neg.view(*shape, num_neg)
+            neg_prob = self.compute_item_p(None, neg)
+            if pos_items is not None:
+                return self.compute_item_p(None, pos_items), neg, neg_prob
+            return neg, neg_prob
+
+    def compute_item_p(self, query, pos_items):
+        return torch.zeros_like(pos_items)          # sampler.py:113-114
+
+
+def build_guide_table(table: Tensor, guide_log2: Optional[int] = None):
+    """Cut-point ("guide") table for the fp32 CDF ``table``: guide[j] = first index i with
+    table[i] >= j / K, K = 2**guide_log2, guide[K] = N.  Searching only inside
+    [guide[b], guide[b+1]] for b = floor(u*K) returns exactly torch.searchsorted(table, u)
+    (sampler.py:247) because j/K and u*K are exact in fp32 for K <= 2**24."""
+    n = table.numel()
+    if guide_log2 is None:
+        guide_log2 = int(min(22, max(4, int(np.ceil(np.log2(max(n, 2)))) - 1)))
+    K = 1 << guide_log2
+    cuts = torch.arange(K + 1, dtype=torch.float64) / K
+    guide = torch.searchsorted(table.detach().cpu().contiguous(), cuts.to(torch.float32))
+    guide[K] = n
+    return guide.to(torch.int32), guide_log2
+
+
+class PopularSamplerModel(Sampler):
+    """recstudio/ann/sampler.py:224-258.  The fp32 tables are built with the very same torch
+    CPU ops as the reference's constructor (so they are bit-identical to its registered
+    buffers) and uploaded with the module; a guide table accelerates the inverse-CDF search."""
+
+    def __init__(self, pop_count, scorer=None, mode=0, guide_log2=None):
+        super().__init__(pop_count.shape[0], scorer)
+        with torch.no_grad():
+            pop_count = torch.as_tensor(pop_count).detach().to('cpu', torch.float)
+            if mode == 0:
+                pop_count = torch.log(pop_count + 1)
+            elif mode == 1:
+                pop_count = torch.log(pop_count + 1) + 1e-6
+            elif mode == 2:
+                pop_count = pop_count ** 0.75
+            pop_count[0] = 1                                              # sampler.py:237
+            self.register_buffer('pop_prob', pop_count / pop_count.sum())
+            self.register_buffer('table', torch.cumsum(self.pop_prob, dim=0))
+            self.pop_prob[-1] = 1.0                                       # sampler.py:241
+            guide, self.guide_log2 = build_guide_table(self.table, guide_log2)
+            self.register_buffer('guide', guide)
+
+    def forward(self, query, num_neg, pos_items=None):
+        with torch.no_grad():
+            shape = tuple(query.shape[:-1])
+            nq = int(np.prod(shape))
+            neg, neg_prob = ops.sample_popular(self.table, self.pop_prob, self.guide, self.guide_log2, nq * num_neg)
+            neg = neg.view(*shape, num_neg)
+            neg_prob = neg_prob.view(*shape, num_neg)
+            if pos_items is not None:
+                return self.compute_item_p(query, pos_items), neg, neg_prob
+            return neg, neg_prob
+
+    def compute_item_p(self, query, pos_items):
+        return ops.item_logp(self.pop_prob, pos_items)                    # sampler.py:257-258

@@ -1,0 +1,50 @@
+"""Score functions -- host-side mirror of ``recstudio.model.scorer`` (InnerProduct, Cosine).
+
+``forward(query, items)`` keeps the reference's five shape cases and its dispatch
+rule (recstudio/model/scorer.py:5-25, including the ``query.size(0) == items.size(0)``
+quirk); the arithmetic runs in HIP.  Inside ``BaseRetriever`` the scorer objects act
+as *selectors* for the fused kernel (no [B, n, d] tensor is ever built); calling them
+directly scores already-materialised vectors through the same kernels.
+"""
+import torch
+
+from . import _native as nat
+from . import ops
+
+__all__ = ['InnerProductScorer', 'CosineScorer']
+
+
+class InnerProductScorer(torch.nn.Module):
+    cosine = False
+
+    def forward(self, query, items):
+        if query.size(0) == items.size(0):
+            if query.dim() < items.dim():                 # ([B,D],[B,n,D]) / ([B,L,D],[B,L,n,D])
+                n = items.shape[-2]
+                lead = items.shape[:-2]
+            else:                                         # ([B,D],[B,D]) / ([B,L,D],[B,L,D])
+                n = 1
+                lead = items.shape[:-1]
+            d = items.shape[-1]
+            q2 = query.reshape(-1, d)
+            rows = items.reshape(-1, d)
+            ids = torch.arange(rows.shape[0], device=rows.device, dtype=torch.int64)
+            out = ops.fused_forward(rows, q2, n, neg_ids=ids, sampler=nat.SAMPLER_GIVEN, cosine=self.cosine,
+                                    n_queries=q2.shape[0])['neg_score']
+            return out.view(*lead, n) if query.dim() < items.dim() else out.view(*lead)
+        # ([B,D],[N,D]): full-catalog scores
+        return full_scores(query, items, self.cosine)
+
+
+class CosineScorer(InnerProductScorer):
+    cosine = True
+
+
+def full_scores(query, items, cosine=False):
+    """[B, N] = query @ items.T through the MFMA full-score kernel (items has no padding row here)."""
+    pad = torch.zeros(1, items.shape[1], dtype=items.dtype, device=items.device)
+    table = torch.cat([pad, items], 0)
+    scores = ops.fullscore(table, query, want_scores=True)[0]
+    if cosine:
+        raise NotImplementedError('CosineScorer over the full catalog is not implemented in this build')
+    return scores

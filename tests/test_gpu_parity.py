@@ -1,0 +1,426 @@
+"""GPU parity tests (run with ``-m gpu`` on an MI355X): the HIP path, called through the C ABI,
+against the CPU oracle (oracle/), the committed reference fixtures (tests/golden) and -- as a
+secondary cross-check of the random stream -- torch's own device generators."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from oracle import philox
+
+pytestmark = pytest.mark.gpu
+
+T = torch.from_numpy
+DEV = 'cuda'
+
+
+@pytest.fixture(scope='module')
+def ra():
+    import recstudio_amd
+    recstudio_amd._native.lib()          # fail loudly if the HIP extension is not there
+    assert torch.cuda.is_available()
+    return recstudio_amd
+
+
+def props(ra):
+    return ra.rng.device_props(DEV)
+
+
+def rel_close(a, b, rtol=1e-4, atol=1e-6):
+    np.testing.assert_allclose(np.asarray(a), np.asarray(b), rtol=rtol, atol=atol)
+
+
+# --------------------------------------------------------------------------- random stream
+@pytest.mark.parametrize('numel,high,seed', [(1, 1575, 2022), (1000, 1575, 2022), (4096 * 64, 10 ** 7 + 1, 1),
+                                             (2048 * 256 + 77, 1000, 3), (3 * 2048 * 256 + 5, 10 ** 6, 4),
+                                             (5000, 2 ** 28 + 3, 5), (2048 * 256 * 2 + 9, 2 ** 31 - 1, 6)])
+def test_device_stream_matches_torch_randint(ra, numel, high, seed):
+    gen = torch.cuda.default_generators[torch.cuda.current_device()]
+    torch.manual_seed(seed)
+    torch.rand(7, device=DEV)                       # move the offset off zero
+    off0 = gen.get_offset()
+    want = torch.randint(1, high, (numel,), device=DEV)
+    off_torch = gen.get_offset()
+    torch.manual_seed(seed)
+    torch.rand(7, device=DEV)
+    got = ra.ops.sample_uniform(numel, 1, high, DEV)
+    assert gen.get_offset() == off_torch            # generator advanced exactly like torch does
+    assert torch.equal(got, want)
+    cu, mt = props(ra)
+    g = philox.rng_grid_threads(numel, cu, mt)
+    rest = philox.device_randint(seed, off0, numel, 1, high, g)
+    assert np.array_equal(rest, want.cpu().numpy())  # oracle restatement == torch == kernel
+
+
+@pytest.mark.parametrize('numel,seed', [(3, 2022), (4096 * 64, 1), (2048 * 256 * 4 + 3, 2)])
+def test_device_stream_matches_torch_rand(ra, golden, numel, seed):
+    g = golden('popular')
+    ps = ra.PopularSamplerModel(T(g['counts']), mode=0).to(DEV)
+    gen = torch.cuda.default_generators[torch.cuda.current_device()]
+    torch.manual_seed(seed)
+    off0 = gen.get_offset()
+    want_u = torch.rand(numel, device=DEV)
+    off_torch = gen.get_offset()
+    want_ids = torch.searchsorted(ps.table, want_u).clamp_(max=ps.table.numel() - 1)
+    torch.manual_seed(seed)
+    ids, logp, u = ra.ops.sample_popular(ps.table, ps.pop_prob, ps.guide, ps.guide_log2, numel, want_u=True)
+    assert gen.get_offset() == off_torch
+    assert torch.equal(u, want_u)
+    assert torch.equal(ids, want_ids)
+    cu, mt = props(ra)
+    rest = philox.device_rand(seed, off0, numel, philox.rng_grid_threads(numel, cu, mt))
+    assert np.array_equal(rest, want_u.cpu().numpy())
+    rel_close(logp.cpu(), torch.log(ps.pop_prob[ids]).cpu(), rtol=1e-6)
+
+
+# --------------------------------------------------------------------------- popularity sampler
+def test_popular_lookup_golden(ra, golden):
+    g = golden('popular')
+    counts = T(g['counts'])
+    for mode in (0, 1, 2):
+        for glog in (None, 4, 9, 16):
+            ps = ra.PopularSamplerModel(counts.clone(), mode=mode, guide_log2=glog)
+            assert np.array_equal(ps.pop_prob.numpy(), g[f'm{mode}_pop_prob'])   # same bits as the reference buffers
+            assert np.array_equal(ps.table.numpy(), g[f'm{mode}_table'])
+            ps = ps.to(DEV)
+            ids, logp = ra.ops.popular_lookup(ps.table, ps.pop_prob, ps.guide, ps.guide_log2, T(g[f'm{mode}_u']).to(DEV))
+            want = np.minimum(g[f'm{mode}_ids'], len(counts) - 1)
+            assert np.array_equal(ids.cpu().numpy(), want)
+            rel_close(logp.cpu(), g[f'm{mode}_logp'], rtol=1e-6, atol=1e-7)
+    nt = torch.get_num_threads()
+    torch.set_num_threads(1)                         # fixture recorded at 1 thread (fp32 .sum() order)
+    try:
+        ps = ra.PopularSamplerModel(T(g['big_counts']), mode=0)
+    finally:
+        torch.set_num_threads(nt)
+    assert np.array_equal(ps.table[-64:].numpy(), g['big_table_tail'])
+    ps = ps.to(DEV)
+    ids, _ = ra.ops.popular_lookup(ps.table, ps.pop_prob, ps.guide, ps.guide_log2, T(g['big_u']).to(DEV))
+    assert np.array_equal(ids.cpu().numpy(), np.minimum(g['big_ids'], len(g['big_counts']) - 1))
+
+
+def test_sampler_plugin_surface(ra):
+    N = 5000
+    us = ra.UniformSampler(N)
+    q = torch.zeros(6, 3, 8, device=DEV)
+    pos = torch.randint(1, N, (6, 3), device=DEV)
+    torch.manual_seed(11)
+    pp, neg, npb = us(q, 5, pos)
+    torch.manual_seed(11)
+    want = torch.randint(1, N, (18, 5), device=DEV).view(6, 3, 5)
+    assert torch.equal(neg, want) and neg.dtype == torch.int64
+    assert pp.dtype == torch.int64 and npb.dtype == torch.int64 and not pp.any() and not npb.any()
+    assert pp.shape == pos.shape and npb.shape == neg.shape
+    neg2, npb2 = us(7, 4, device=torch.device(DEV))
+    assert neg2.shape == (7, 4) and int(neg2.min()) >= 1 and int(neg2.max()) <= N - 1
+    counts = torch.randint(0, 50, (N,))
+    ps = ra.PopularSamplerModel(counts).to(DEV)
+    ref = oracle.PopularSamplerModel(counts)
+    torch.manual_seed(12)
+    pp, neg, npb = ps(q, 9, pos)
+    torch.manual_seed(12)
+    u = torch.rand(18, 9, device=DEV)
+    want = torch.searchsorted(ps.table, u).view(6, 3, 9)
+    assert torch.equal(neg, want)
+    rel_close(npb.cpu(), ref.compute_item_p(neg.cpu()), rtol=1e-6)
+    rel_close(pp.cpu(), ref.compute_item_p(pos.cpu()), rtol=1e-6)
+
+
+# --------------------------------------------------------------------------- fused forward
+def _tables(N, U, d, seed):
+    g = torch.Generator().manual_seed(seed)
+    iw = torch.randn(N, d, generator=g) * 0.3
+    iw[0] = 0
+    uw = torch.randn(U, d, generator=g) * 0.3
+    uw[0] = 0
+    return iw, uw
+
+
+@pytest.mark.parametrize('d', [32, 64, 128, 256, 100, 512, 8])
+@pytest.mark.parametrize('n', [1, 5, 64, 128, 100])
+@pytest.mark.parametrize('cosine', [False, True])
+def test_fused_forward_given_ids(ra, d, n, cosine):
+    N, U, B = 777, 55, 37
+    iw, uw = _tables(N, U, d, 100 + d + n)
+    g = torch.Generator().manual_seed(d * 7 + n)
+    uid = torch.randint(1, U, (B,), generator=g)
+    pos = torch.randint(1, N, (B,), generator=g)
+    neg = torch.randint(1, N, (B, n), generator=g)
+    out = ra.ops.fused_forward(iw.to(DEV), uw.to(DEV), n, query_index=uid.to(DEV), pos_ids=pos.to(DEV),
+                               neg_ids=neg.to(DEV), cosine=cosine)
+    ps, ns = oracle.retriever_forward(iw, uw[uid], pos, neg, cosine=cosine)
+    rel_close(out['pos_score'].cpu(), ps, atol=1e-5)
+    rel_close(out['neg_score'].cpu(), ns, atol=1e-5)
+    # direct query vectors instead of (user table, index)
+    out2 = ra.ops.fused_forward(iw.to(DEV), uw[uid].to(DEV), n, pos_ids=pos.to(DEV), neg_ids=neg.to(DEV), cosine=cosine)
+    assert torch.equal(out2['neg_score'], out['neg_score']) and torch.equal(out2['pos_score'], out['pos_score'])
+
+
+@pytest.mark.parametrize('n,B', [(1, 512), (64, 100), (256, 9), (100, 33), (1024, 3)])
+@pytest.mark.parametrize('kind', ['uniform', 'popular'])
+def test_fused_forward_sampled(ra, n, B, kind):
+    N, U, d = 20011, 300, 128
+    iw, uw = _tables(N, U, d, 5)
+    g = torch.Generator().manual_seed(n + B)
+    uid = torch.randint(1, U, (B,), generator=g)
+    pos = torch.randint(1, N, (B,), generator=g)
+    counts = (torch.rand(N, generator=g) ** 3 * 400).long()
+    cu, mt = props(ra)
+    gen = torch.cuda.default_generators[torch.cuda.current_device()]
+    seed = 2022
+    if kind == 'uniform':
+        sampler = ra.UniformSampler(N)
+        ref = oracle.UniformSampler(N)
+    else:
+        sampler = ra.PopularSamplerModel(counts).to(DEV)
+        ref = oracle.PopularSamplerModel(counts)
+    torch.manual_seed(seed)
+    off0 = gen.get_offset()
+    score, ids = ra.retriever_scores(iw.to(DEV), uw.to(DEV), n, query_index=uid.to(DEV), pos_ids=pos.to(DEV),
+                                     sampler=sampler)
+    gt = philox.rng_grid_threads(B * n, cu, mt)
+    lpp, want_ids, lnp = ref.forward_device_stream(torch.zeros(B, 1), n, seed, off0, gt, pos_items=pos)
+    assert torch.equal(ids.cpu(), want_ids)                       # bit-exact sampled negatives
+    ps, ns = oracle.retriever_forward(iw, uw[uid], pos, want_ids)
+    rel_close(score['pos_score'].cpu(), ps, atol=1e-5)
+    rel_close(score['neg_score'].cpu(), ns, atol=1e-5)
+    if kind == 'popular':
+        rel_close(score['log_neg_prob'].cpu(), lnp, rtol=1e-5)
+        rel_close(score['log_pos_prob'].cpu(), lpp, rtol=1e-5)
+    else:
+        assert score['log_neg_prob'].dtype == torch.int64 and not score['log_neg_prob'].any()
+    # the stand-alone sampler plugin draws the same ids from the same generator state
+    torch.manual_seed(seed)
+    _, ids2, _ = sampler(torch.zeros(B, d, device=DEV), n, pos.to(DEV))
+    assert torch.equal(ids2, ids)
+
+
+def test_fused_forward_seq_targets_mask_padding(ra):
+    # 2-D targets: pos [B,L] with padding 0 -> pos_score = -inf (baseretriever.py:164-165)
+    N, d, B, L, n = 500, 64, 5, 7, 3
+    iw, _ = _tables(N, 4, d, 9)
+    g = torch.Generator().manual_seed(1)
+    q = torch.randn(B, L, d, generator=g)
+    pos = torch.randint(1, N, (B, L), generator=g)
+    pos[0, 5:] = 0
+    pos[3, 2:] = 0
+    neg = torch.randint(1, N, (B, L, n), generator=g)
+    out = ra.ops.fused_forward(iw.to(DEV), q.view(-1, d).to(DEV), n, pos_ids=pos.view(-1).to(DEV),
+                               neg_ids=neg.view(-1, n).to(DEV), mask_pad_pos=True)
+    ps, ns = oracle.retriever_forward(iw, q, pos, neg)
+    got = out['pos_score'].cpu().view(B, L)
+    assert torch.equal(torch.isinf(got), torch.isinf(ps))
+    rel_close(got[~torch.isinf(ps)], ps[~torch.isinf(ps)], atol=1e-5)
+    rel_close(out['neg_score'].cpu().view(B, L, n), ns, atol=1e-5)
+
+
+def test_scorer_plugin_golden(ra, golden):
+    g = golden('score')
+    for d in (64, 128):
+        for case in ('bd_bd', 'bd_bnd', 'bld_bld', 'bld_blnd'):
+            k = f'd{d}_{case}'
+            q, it = T(g[k + '_q']).to(DEV), T(g[k + '_items']).to(DEV)
+            rel_close(ra.InnerProductScorer()(q, it).cpu(), g[k + '_ip'], atol=1e-5)
+            rel_close(ra.CosineScorer()(q, it).cpu(), g[k + '_cos'], atol=1e-5)
+
+
+# --------------------------------------------------------------------------- losses
+def test_losses_golden(ra, golden):
+    g = golden('loss')
+    for name, cls in (('bpr_1d', 'BPRLoss'), ('bpr_2d', 'BPRLoss'), ('bpr_big', 'BPRLoss'),
+                      ('ssm_1d_f32', 'SampledSoftmaxLoss'), ('ssm_1d_i64', 'SampledSoftmaxLoss'),
+                      ('ssm_2d', 'SampledSoftmaxLoss'), ('ssm_big', 'SampledSoftmaxLoss')):
+        pos = T(g[name + '_pos_score']).to(DEV).requires_grad_(True)
+        neg = T(g[name + '_neg_score']).to(DEV).requires_grad_(True)
+        lpp, lnp = T(g[name + '_log_pos_prob']).to(DEV), T(g[name + '_log_neg_prob']).to(DEV)
+        loss = getattr(ra, cls)()(label=None, pos_score=pos, log_pos_prob=lpp, neg_score=neg, log_neg_prob=lnp)
+        rel_close(loss.detach().cpu(), g[name + '_loss'], rtol=1e-5)
+        (loss * 1.0).backward()
+        rel_close(pos.grad.cpu(), g[name + '_grad_pos_score'], rtol=1e-4, atol=1e-7)
+        rel_close(neg.grad.cpu(), g[name + '_grad_neg_score'], rtol=1e-4, atol=1e-7)
+
+
+@pytest.mark.parametrize('n', [1, 2, 7, 33, 64, 256, 1000])
+@pytest.mark.parametrize('kind', ['bpr', 'ssm'])
+def test_losses_vs_oracle(ra, n, kind):
+    M = 129
+    g = torch.Generator().manual_seed(n)
+    pos, neg = torch.randn(M, generator=g) * 3, torch.randn(M, n, generator=g) * 3
+    lpp, lnp = torch.log(torch.rand(M, generator=g)), torch.log(torch.rand(M, n, generator=g))
+    p, q = pos.clone().requires_grad_(True), neg.clone().requires_grad_(True)
+    want = oracle.bpr_loss(p, q) if kind == 'bpr' else oracle.sampled_softmax_loss(p, lpp, q, lnp)
+    want.backward()
+    k = ra._native.LOSS_BPR if kind == 'bpr' else ra._native.LOSS_SSM
+    loss, dpos, dneg, _ = ra.ops.pairwise_loss(k, pos.to(DEV), neg.to(DEV), lpp.to(DEV), lnp.to(DEV))
+    rel_close(loss.cpu(), want.detach(), rtol=1e-5)
+    rel_close(dpos.cpu(), p.grad, rtol=1e-4, atol=1e-8)
+    rel_close(dneg.cpu(), q.grad, rtol=1e-4, atol=1e-8)
+
+
+def test_ssm_padded_positive_is_nan_like_reference(ra):
+    pos = torch.tensor([0.5, -float('inf'), 1.0])
+    neg = torch.randn(3, 4)
+    want = oracle.sampled_softmax_loss(pos, torch.zeros(3), neg, torch.zeros(3, 4))
+    loss, _, _, row = ra.ops.pairwise_loss(ra._native.LOSS_SSM, pos.to(DEV), neg.to(DEV))
+    assert torch.isnan(want) and torch.isnan(loss.cpu())
+    assert torch.isfinite(row.cpu()[[0, 2]]).all()
+
+
+# --------------------------------------------------------------------------- backward
+def test_training_step_golden(ra, golden):
+    """forward -> loss -> backward through autograd == the reference's BaseRetriever.training_step +
+    loss.backward() (dense weight.grad, row 0 untouched)."""
+    g = golden('forward')
+    for tag, lossname in (('bpr_ip', 'BPRLoss'), ('ssm_ip', 'SampledSoftmaxLoss')):
+        iw = T(g[tag + '_item_w']).to(DEV).requires_grad_(True)
+        uw = T(g[tag + '_user_w']).to(DEV).requires_grad_(True)
+        uid, pos, neg = (T(g[tag + k]).to(DEV) for k in ('_uid', '_pos', '_neg'))
+        score, ids = ra.retriever_scores(iw, uw, neg.shape[1], query_index=uid, pos_ids=pos, neg_ids=neg)
+        rel_close(score['pos_score'].detach().cpu(), g[tag + '_pos_score'], atol=1e-6)
+        rel_close(score['neg_score'].detach().cpu(), g[tag + '_neg_score'], atol=1e-6)
+        loss = getattr(ra, lossname)()(label=None, pos_score=score['pos_score'], neg_score=score['neg_score'],
+                                       log_pos_prob=T(g[tag + '_lpp']).to(DEV), log_neg_prob=T(g[tag + '_lnp']).to(DEV))
+        rel_close(loss.detach().cpu(), g[tag + '_loss'], rtol=1e-5)
+        loss.backward()
+        rel_close(iw.grad.cpu(), g[tag + '_item_grad'], rtol=1e-4, atol=1e-7)
+        rel_close(uw.grad.cpu(), g[tag + '_user_grad'], rtol=1e-4, atol=1e-7)
+        assert not iw.grad[0].any()
+    # cosine forward parity (scores) on the same fixture family
+    tag = 'bpr_cos'
+    out = ra.ops.fused_forward(T(g[tag + '_item_w']).to(DEV), T(g[tag + '_user_w']).to(DEV), g[tag + '_neg'].shape[1],
+                               query_index=T(g[tag + '_uid']).to(DEV), pos_ids=T(g[tag + '_pos']).to(DEV),
+                               neg_ids=T(g[tag + '_neg']).to(DEV), cosine=True)
+    rel_close(out['pos_score'].cpu(), g[tag + '_pos_score'], atol=1e-6)
+    rel_close(out['neg_score'].cpu(), g[tag + '_neg_score'], atol=1e-6)
+
+
+@pytest.mark.parametrize('d', [64, 128, 100, 256])
+@pytest.mark.parametrize('n', [1, 6, 64, 128, 320])
+@pytest.mark.parametrize('loss', ['bpr', 'ssm'])
+def test_backward_vs_oracle(ra, d, n, loss):
+    N, U, B = 403, 61, 23
+    iw, uw = _tables(N, U, d, d + n)
+    g = torch.Generator().manual_seed(d * 3 + n)
+    uid = torch.randint(1, U, (B,), generator=g)
+    uid[3] = uid[4]                                   # repeated user in the batch
+    pos = torch.randint(1, N, (B,), generator=g)
+    neg = torch.randint(0, N, (B, n), generator=g)    # includes id 0 (padding: no gradient)
+    neg[0, 0] = pos[0]
+    lpp, lnp = torch.log(torch.rand(B, generator=g)), torch.log(torch.rand(B, n, generator=g))
+    val, ps, ns, gi, gu = oracle.dense_grads(iw, uw, uid, pos, neg, loss=loss, log_pos_prob=lpp, log_neg_prob=lnp)
+    for sparse in (False, True):
+        iwd = iw.to(DEV).requires_grad_(True)
+        uwd = uw.to(DEV).requires_grad_(True)
+        score, _ = ra.retriever_scores(iwd, uwd, n, query_index=uid.to(DEV), pos_ids=pos.to(DEV), neg_ids=neg.to(DEV),
+                                       sparse_grad=sparse)
+        lf = ra.BPRLoss() if loss == 'bpr' else ra.SampledSoftmaxLoss()
+        out = lf(label=None, pos_score=score['pos_score'], neg_score=score['neg_score'], log_pos_prob=lpp.to(DEV),
+                 log_neg_prob=lnp.to(DEV))
+        rel_close(out.detach().cpu(), val, rtol=1e-5)
+        out.backward()
+        gi_got = iwd.grad.to_dense() if sparse else iwd.grad
+        gu_got = uwd.grad.to_dense() if sparse else uwd.grad
+        rel_close(gi_got.cpu(), gi, rtol=2e-4, atol=1e-7)
+        rel_close(gu_got.cpu(), gu, rtol=2e-4, atol=1e-7)
+        assert not gi_got[0].any()
+
+
+def test_backward_direct_query_grad(ra):
+    # query vectors produced by an upstream encoder (SASRec): gradient flows to the [M, d] tensor
+    N, d, M, n = 300, 128, 11, 64
+    iw, _ = _tables(N, 4, d, 3)
+    g = torch.Generator().manual_seed(8)
+    q = torch.randn(M, d, generator=g)
+    pos = torch.randint(1, N, (M,), generator=g)
+    neg = torch.randint(1, N, (M, n), generator=g)
+    qc, ic = q.clone().requires_grad_(True), iw.clone().requires_grad_(True)
+    ps, ns = oracle.retriever_forward(ic, qc, pos, neg)
+    oracle.bpr_loss(ps, ns).backward()
+    qd, idv = q.to(DEV).requires_grad_(True), iw.to(DEV).requires_grad_(True)
+    score, _ = ra.retriever_scores(idv, qd, n, pos_ids=pos.to(DEV), neg_ids=neg.to(DEV))
+    ra.BPRLoss()(None, score['pos_score'], None, score['neg_score'], None).backward()
+    rel_close(qd.grad.cpu(), qc.grad, rtol=2e-4, atol=1e-8)
+    rel_close(idv.grad.cpu(), ic.grad, rtol=2e-4, atol=1e-8)
+
+
+# --------------------------------------------------------------------------- gathers
+def test_embedding_and_seg_gather(ra):
+    N, d = 97, 128
+    iw, _ = _tables(N, 4, d, 1)
+    ids = torch.randint(0, N, (4, 9))
+    assert torch.equal(ra.ops.embedding_gather(iw.to(DEV), ids.to(DEV)).cpu(), iw[ids])
+    flat = torch.randint(1, N, (200,))
+    start = torch.tensor([0, 5, 5, 40, 199, 120])
+    end = torch.tensor([5, 5, 31, 41, 200, 200])        # empty, short, longer than max_len
+    L = 20
+    got_ids, got_rows, got_len = ra.ops.seg_gather(iw.to(DEV), flat.to(DEV), start.to(DEV), end.to(DEV), L)
+    # segments longer than max_len keep the most recent L items
+    s2 = torch.maximum(start, end - L)
+    want_ids, want_rows, want_len = oracle.seq_gather(iw, flat, s2.tolist(), end.tolist(), L)
+    assert torch.equal(got_ids.cpu(), want_ids) and torch.equal(got_len.cpu(), want_len)
+    assert torch.equal(got_rows.cpu(), want_rows)
+    src = torch.randn(50, d)
+    idx = torch.randint(0, 9, (50,))
+    want = torch.zeros(9, d).index_add_(0, idx, src)
+    want[0] = 0
+    rel_close(ra.ops.scatter_add_rows(src.to(DEV), idx.to(DEV), 9).cpu(), want, rtol=1e-5, atol=1e-6)
+
+
+def test_errors_are_loud(ra):
+    iw = torch.zeros(10, 6, device=DEV)            # dim not a multiple of 4
+    with pytest.raises(ra._native.NativeError):
+        ra.ops.fused_forward(iw, torch.zeros(2, 6, device=DEV), 1, neg_ids=torch.ones(2, 1, dtype=torch.int64, device=DEV))
+    with pytest.raises(RuntimeError):
+        ra.ops.embedding_gather(torch.zeros(4, 8), torch.zeros(2, dtype=torch.int64))   # CPU tensors: no fallback
+    with pytest.raises(TypeError):
+        ra.ops.embedding_gather(torch.zeros(4, 8, device=DEV), torch.zeros(2, dtype=torch.int32, device=DEV))
+
+
+# --------------------------------------------------------------------------- BASELINE.json full sizes
+def test_full_size_properties(ra):
+    """configs[1] shape (N = 1e7 items, d = 128, B = 4096, n = 64, popularity sampler): size-independent
+    properties + an oracle spot check on a random subset of elements."""
+    N, U, d, B, n = 10_000_001, 1_000_001, 128, 4096, 64
+    g = torch.Generator(device=DEV).manual_seed(1)
+    iw = torch.empty(N, d, device=DEV).normal_(0, 0.02, generator=g)
+    iw[0] = 0
+    uw = torch.empty(U, d, device=DEV).normal_(0, 0.02, generator=g)
+    counts = (torch.rand(N, generator=torch.Generator().manual_seed(2)) ** 8 * 1e4).long()
+    ps = ra.PopularSamplerModel(counts).to(DEV)
+    uid = torch.randint(1, U, (B,), device=DEV, generator=g)
+    pos = torch.randint(1, N, (B,), device=DEV, generator=g)
+    torch.manual_seed(2022)
+    score, ids = ra.retriever_scores(iw, uw, n, query_index=uid, pos_ids=pos, sampler=ps)
+    # (1) bit-exact ids vs the reference's own op sequence on this device
+    torch.manual_seed(2022)
+    want_ids = torch.searchsorted(ps.table, torch.rand(B, n, device=DEV)).clamp_(max=N - 1)
+    assert torch.equal(ids, want_ids)
+    assert int(ids.min()) >= 0 and int(ids.max()) < N
+    # (2) idempotence: re-scoring the sampled ids as given ids reproduces the scores bit for bit
+    again = ra.ops.fused_forward(iw, uw, n, query_index=uid, pos_ids=pos, neg_ids=ids)
+    assert torch.equal(again['neg_score'], score['neg_score']) and torch.equal(again['pos_score'], score['pos_score'])
+    # (3) linearity in the query
+    twice = ra.ops.fused_forward(iw, uw * 2, n, query_index=uid, pos_ids=pos, neg_ids=ids)
+    assert torch.equal(twice['neg_score'], score['neg_score'] * 2)
+    # (4) oracle spot check on 2000 random (b, j) elements
+    sel_b = torch.randint(0, B, (2000,))
+    sel_j = torch.randint(0, n, (2000,))
+    rows = iw[ids[sel_b.to(DEV), sel_j.to(DEV)]].cpu()
+    q = uw[uid[sel_b.to(DEV)]].cpu()
+    rel_close(score['neg_score'].cpu()[sel_b, sel_j], oracle.inner_product_score(q, rows), rtol=1e-4, atol=1e-7)
+    rel_close(score['log_neg_prob'].cpu()[sel_b, sel_j], torch.log(ps.pop_prob.cpu()[ids.cpu()[sel_b, sel_j]]), rtol=1e-5)
+    # (5) uniform sampler at the same size
+    us = ra.UniformSampler(N)
+    torch.manual_seed(7)
+    s2, ids2 = ra.retriever_scores(iw, uw, n, query_index=uid, pos_ids=pos, sampler=us)
+    torch.manual_seed(7)
+    assert torch.equal(ids2, torch.randint(1, N, (B, n), device=DEV))
+    # (6) loss + row-sparse backward: gradient rows sum to the analytic total
+    loss, dpos, dneg, _ = ra.ops.pairwise_loss(ra._native.LOSS_BPR, score['pos_score'], score['neg_score'])
+    _, rows_g, qg = ra.ops.fused_backward(iw, uw, ids, dneg, query_index=uid, pos_ids=pos, dpos=dpos,
+                                          dense_item_grad=False, row_item_grad=True)
+    assert torch.isfinite(loss) and rows_g.shape == (B * (n + 1), d)
+    # sum_j dneg_j + dpos == 0 for BPR, so each query's gradient rows sum to ~0 * q
+    tot = rows_g.view(B, n + 1, d).sum(1)
+    keep = (ids != 0).all(1)                      # a sampled padding id contributes no gradient row
+    assert float(tot[keep].abs().max()) < 1e-6

@@ -1,0 +1,116 @@
+"""CPU: host-side logic of the package -- generator bookkeeping, popularity tables, guide table,
+plugin signatures -- against the oracle and the reference fixtures."""
+import inspect
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from oracle import philox
+
+T = torch.from_numpy
+
+
+class FakeGen:
+    def __init__(self, seed, offset):
+        self.seed, self.offset = seed, offset
+
+    def initial_seed(self):
+        return self.seed
+
+    def get_offset(self):
+        return self.offset
+
+    def set_offset(self, o):
+        self.offset = o
+
+
+def test_rng_reserve_matches_torch_policy():
+    from recstudio_amd import rng
+    props = (256, 2048)
+    for numel, unroll in ((1, 4), (1000, 4), (4096 * 64, 4), (2048 * 256 * 4 + 1, 4), (2048 * 256 * 2 + 1, 2)):
+        g = FakeGen(2022, 40)
+        pc = rng.reserve(numel, unroll, 'cuda:0', generator=g, props=props)
+        gt = philox.rng_grid_threads(numel, *props)
+        assert pc.grid_threads == gt and pc.seed == 2022 and pc.offset == 40
+        assert g.offset == 40 + philox.rng_counter_offset(numel, gt, unroll)
+        assert g.offset % 4 == 0
+    assert rng.randint_unroll(1, 10 ** 8) == 4 and rng.randint_unroll(1, 2 ** 28 + 1) == 2
+
+
+def lower_bound_with_guide(table, guide, glog, u):
+    """numpy model of rsa::cdf_lower_bound."""
+    K = 1 << glog
+    b = np.clip((u * np.float32(K)).astype(np.int64), 0, K - 1)
+    out = np.empty(len(u), dtype=np.int64)
+    for i, (lo, hi) in enumerate(zip(guide[b], guide[b + 1])):
+        while lo < hi:
+            mid = lo + ((hi - lo) >> 1)
+            if table[mid] < u[i]:
+                lo = mid + 1
+            else:
+                hi = mid
+        out[i] = min(lo, len(table) - 1)
+    return out
+
+
+@pytest.mark.parametrize('glog', [0, 3, 8, 13, 20])
+def test_guide_table_returns_searchsorted_index(golden, glog):
+    from recstudio_amd.sampler import build_guide_table
+    g = golden('popular')
+    for mode in (0, 2):
+        table = T(g[f'm{mode}_table'])
+        guide, gl = build_guide_table(table, glog)
+        assert gl == glog and guide.numel() == (1 << glog) + 1 and int(guide[-1]) == table.numel()
+        assert bool((guide[1:] >= guide[:-1]).all())
+        u = g[f'm{mode}_u']
+        got = lower_bound_with_guide(table.numpy(), guide.numpy().astype(np.int64), glog, u)
+        assert np.array_equal(got, np.minimum(g[f'm{mode}_ids'], table.numel() - 1))
+    # adversarial: u exactly on every table value and one ulp either side
+    table = T(g['m0_table'])
+    t = table.numpy()
+    u = np.concatenate([t, np.nextafter(t, np.float32(0)), np.nextafter(t, np.float32(2))]).astype(np.float32)
+    u = u[(u >= 0) & (u < 1)]
+    guide, _ = build_guide_table(table, glog)
+    got = lower_bound_with_guide(t, guide.numpy().astype(np.int64), glog, u)
+    assert np.array_equal(got, np.minimum(oracle.searchsorted_left(t, u), len(t) - 1))
+
+
+def test_popular_sampler_tables_equal_reference_buffers(golden):
+    from recstudio_amd import PopularSamplerModel
+    g = golden('popular')
+    for mode in (0, 1, 2):
+        ps = PopularSamplerModel(T(g['counts']), mode=mode)
+        assert np.array_equal(ps.pop_prob.numpy(), g[f'm{mode}_pop_prob'])
+        assert np.array_equal(ps.table.numpy(), g[f'm{mode}_table'])
+        assert ps.num_items == len(g['counts']) - 1
+        assert set(dict(ps.named_buffers())) == {'pop_prob', 'table', 'guide'}
+
+
+def test_plugin_signatures_match_reference():
+    """Parameter names are API: BaseRetriever calls sampler(**kwargs) / loss_fn(**score)
+    (baseretriever.py:220-238, :399-404)."""
+    import recstudio_amd as ra
+    assert list(inspect.signature(ra.UniformSampler.forward).parameters) == ['self', 'query', 'num_neg', 'pos_items', 'device']
+    assert list(inspect.signature(ra.PopularSamplerModel.forward).parameters) == ['self', 'query', 'num_neg', 'pos_items']
+    assert list(inspect.signature(ra.PopularSamplerModel.__init__).parameters)[:4] == ['self', 'pop_count', 'scorer', 'mode']
+    assert list(inspect.signature(ra.Sampler.__init__).parameters) == ['self', 'num_items', 'scorer_fn']
+    assert list(inspect.signature(ra.Sampler.update).parameters) == ['self', 'item_embs', 'max_iter']
+    for cls in (ra.BPRLoss, ra.SampledSoftmaxLoss):
+        assert issubclass(cls, ra.PairwiseLoss)
+        assert list(inspect.signature(cls.forward).parameters) == ['self', 'label', 'pos_score', 'log_pos_prob', 'neg_score', 'log_neg_prob']
+    assert issubclass(ra.SoftmaxLoss, ra.FullScoreLoss)
+    assert list(inspect.signature(ra.SoftmaxLoss.forward).parameters) == ['self', 'label', 'pos_score', 'all_score']
+    for cls in (ra.InnerProductScorer, ra.CosineScorer):
+        assert list(inspect.signature(cls.forward).parameters) == ['self', 'query', 'items']
+    assert issubclass(ra.CosineScorer, ra.InnerProductScorer)
+    assert ra.UniformSampler(1575).num_items == 1574
+
+
+def test_cpu_tensors_are_rejected():
+    import recstudio_amd as ra
+    with pytest.raises(RuntimeError, match='GPU only'):
+        ra.ops.embedding_gather(torch.zeros(4, 8), torch.zeros(2, dtype=torch.int64))
+    with pytest.raises(RuntimeError, match='GPU only'):
+        ra.BPRLoss()(None, torch.zeros(3), None, torch.zeros(3, 2), None)
