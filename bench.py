@@ -98,15 +98,23 @@ def cpu_baseline(args, counts, d, B, n):
             lpp, neg, lnp = ps.forward(q, n, pos)
             p, s = oracle.retriever_forward(item, q, pos, neg)
             return oracle.bpr_loss(p, s)
-    step()
-    times = []
-    t_end = time.perf_counter() + 12.0
-    while len(times) < 5 or (time.perf_counter() < t_end and len(times) < 40):
-        t0 = time.perf_counter()
+    # torch-CPU gathers do not scale to hundreds of threads: try a few thread counts, keep the best
+    best = None
+    for thr in sorted({min(cores, t) for t in (8, 32, 64, cores)}):
+        torch.set_num_threads(thr)
         step()
-        times.append(time.perf_counter() - t0)
-    times.sort()
-    med = times[len(times) // 2]
+        times = []
+        t_end = time.perf_counter() + 5.0
+        while len(times) < 3 or (time.perf_counter() < t_end and len(times) < 30):
+            t0 = time.perf_counter()
+            step()
+            times.append(time.perf_counter() - t0)
+        times.sort()
+        m = times[len(times) // 2]
+        if best is None or m < best[0]:
+            best = (m, thr, len(times))
+    med, cores, ntimes = best
+    times = [0] * ntimes
     return {'value': round(B * n / med / 1e6, 3), 'unit': 'M triplets/s', 'cores': cores, 'kind': 'port',
             'sample': f'oracle forward (popular sample + gather + inner product + BPR) on torch-CPU, '
                       f'N={n_items} d={d} B={B} n={n}, median of {len(times)} steps, {cores} threads, '

@@ -59,6 +59,8 @@ def reserve(numel, unroll, device, generator=None, props=None):
         idx = torch.device(device).index
         if idx is None:
             idx = torch.cuda.current_device()
+        if not torch.cuda.is_initialized():
+            torch.cuda.init()               # default_generators is empty before the lazy init
         generator = torch.cuda.default_generators[idx]
     cu, mt = props if props is not None else device_props(device)
     g = grid_threads(numel, cu, mt)

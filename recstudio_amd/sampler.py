@@ -98,6 +98,18 @@ class PopularSamplerModel(Sampler):
             guide, self.guide_log2 = build_guide_table(self.table, guide_log2)
             self.register_buffer('guide', guide)
 
+    @classmethod
+    def from_tables(cls, pop_prob, table, guide_log2=None):
+        """Build from already-computed reference buffers (e.g. a loaded RecStudio checkpoint's
+        ``sampler.pop_prob`` / ``sampler.table``) instead of recomputing them from counts."""
+        self = cls.__new__(cls)
+        Sampler.__init__(self, table.numel(), None)
+        self.register_buffer('pop_prob', pop_prob.detach().clone().to(torch.float32))
+        self.register_buffer('table', table.detach().clone().to(torch.float32))
+        guide, self.guide_log2 = build_guide_table(self.table, guide_log2)
+        self.register_buffer('guide', guide.to(self.table.device))
+        return self
+
     def forward(self, query, num_neg, pos_items=None):
         with torch.no_grad():
             shape = tuple(query.shape[:-1])
