@@ -46,16 +46,22 @@ struct Frag {
   float4 v[CH];
 };
 
+// Unconditional 16-byte loads (a load under a lane predicate becomes a branch + vmcnt(0) per load
+// and serialises the wave's row stream): rows that must not count are redirected to row 0 by the
+// caller, generic-dim tails are clamped to the last in-range column and zeroed with a select.
 template <int LPR, bool GENERIC>
-__device__ __forceinline__ void frag_load(Frag<LPR, GENERIC>& f, const float* __restrict__ row, int sub, int D,
-                                          bool act) {
+__device__ __forceinline__ void frag_load(Frag<LPR, GENERIC>& f, const float* __restrict__ row, int sub, int D) {
 #pragma unroll
   for (int c = 0; c < Frag<LPR, GENERIC>::CH; ++c) {
     const int col = (c * LPR + sub) * 4;
-    if (act && (!GENERIC || col < D))
+    if constexpr (GENERIC) {
+      const int cc = col < D ? col : D - 4;
+      float4 v = *reinterpret_cast<const float4*>(row + cc);
+      const float m = col < D ? 1.f : 0.f;
+      f.v[c] = make_float4(v.x * m, v.y * m, v.z * m, v.w * m);
+    } else {
       f.v[c] = *reinterpret_cast<const float4*>(row + col);
-    else
-      f.v[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
   }
 }
 
@@ -85,14 +91,14 @@ __device__ __forceinline__ void fold(float (&d)[L], int sub, int step) {
 }
 
 // Dot products (and squared norms for the cosine scorer) of the tile's 64 rows.
-// id_lane / act_lane / qrow_lane: lane r's row id, validity and query row.
-// On return lane r holds the results of row r.
+// id_lane / qrow_lane: lane r's row id and query row; lanes whose element is out of range pass
+// row 0 (always readable) and ignore their result.  On return lane r holds the results of row r.
 //
 // Rows are visited BATCH at a time, batch b = rows {b, b+NB, b+2NB, ...} of the lane group, and
 // each batch is folded to one value right away (the depth-first order of the transpose-reduce
 // tree), so only BATCH row fragments + NB partials are live instead of LPR of each.
 template <int LPR, bool GENERIC, bool COS, bool QU>
-__device__ __forceinline__ void tile_rows(const float* __restrict__ table, int D, int32_t id_lane, int act_lane,
+__device__ __forceinline__ void tile_rows(const float* __restrict__ table, int D, int32_t id_lane,
                                           const float* __restrict__ query, int32_t qrow_lane,
                                           const Frag<LPR, GENERIC>& qf_uniform, float& dot, float& inorm2,
                                           float& qnorm2) {
@@ -113,11 +119,10 @@ __device__ __forceinline__ void tile_rows(const float* __restrict__ table, int D
     for (int k = 0; k < BATCH; ++k) {
       const int r = gbase + b + k * NB;
       const int32_t rid = __shfl(id_lane, r, 64);
-      const int ract = __shfl(act_lane, r, 64);
-      frag_load<LPR, GENERIC>(x[k], table + (size_t)rid * D, sub, D, ract != 0);
+      frag_load<LPR, GENERIC>(x[k], table + (size_t)rid * D, sub, D);
       if constexpr (!QU) {
         const int32_t qr = __shfl(qrow_lane, r, 64);
-        frag_load<LPR, GENERIC>(qx[k], query + (size_t)qr * D, sub, D, ract != 0);
+        frag_load<LPR, GENERIC>(qx[k], query + (size_t)qr * D, sub, D);
       }
     }
     float d[BATCH];
@@ -201,17 +206,17 @@ __global__ __launch_bounds__(256) void fused_fwd_kernel(const FwdParams p) {
     if constexpr (QU) {
       m_lane = (tile << 6) / n;   // wave-uniform: n % 64 == 0
       const int64_t qrow = p.query_index ? p.query_index[m_lane] : m_lane;
-      frag_load<LPR, GENERIC>(qf, p.query + (size_t)qrow * D, sub, D, true);
+      frag_load<LPR, GENERIC>(qf, p.query + (size_t)qrow * D, sub, D);
       if constexpr (COS) qn2_u = group_sum<LPR>(frag_dot<LPR, GENERIC>(qf, qf));
     } else {
       m_lane = act ? e / n : 0;
       qrow_lane = (int32_t)(p.query_index ? (act ? p.query_index[m_lane] : 0) : m_lane);
-      frag_load<LPR, GENERIC>(qf, p.query, sub, D, false);
+      frag_load<LPR, GENERIC>(qf, p.query, sub, D);   // unused in this path
     }
 
     // ---- 3. negatives: gather + dot
     float dot = 0.f, in2 = 1.f, qn2 = 1.f;
-    tile_rows<LPR, GENERIC, COS, QU>(p.item_table, D, id, act, p.query, qrow_lane, qf, dot, in2, qn2);
+    tile_rows<LPR, GENERIC, COS, QU>(p.item_table, D, id, p.query, qrow_lane, qf, dot, in2, qn2);
     if constexpr (COS && QU) qn2 = qn2_u;
     if (act) p.neg_score[e] = finish_score(COS, dot, in2, qn2);
 
@@ -224,7 +229,7 @@ __global__ __launch_bounds__(256) void fused_fwd_kernel(const FwdParams p) {
           pid = pid < 0 ? 0 : (pid >= p.n_items ? p.n_items - 1 : pid);
           if (p.pos_score) {
             F x;
-            frag_load<LPR, GENERIC>(x, p.item_table + (size_t)pid * D, sub, D, true);
+            frag_load<LPR, GENERIC>(x, p.item_table + (size_t)pid * D, sub, D);
             float pd = group_sum<LPR>(frag_dot<LPR, GENERIC>(x, qf));
             float pi2 = 1.f;
             if constexpr (COS) pi2 = group_sum<LPR>(frag_dot<LPR, GENERIC>(x, x));
@@ -242,8 +247,8 @@ __global__ __launch_bounds__(256) void fused_fwd_kernel(const FwdParams p) {
           pid64 = pid64 < 0 ? 0 : (pid64 >= p.n_items ? p.n_items - 1 : pid64);
           if (p.pos_score) {
             float pd = 0.f, pi2 = 1.f, pq2 = 1.f;
-            tile_rows<LPR, GENERIC, COS, false>(p.item_table, D, (int32_t)pid64, owner, p.query, qrow_lane, qf, pd,
-                                                pi2, pq2);
+            tile_rows<LPR, GENERIC, COS, false>(p.item_table, D, (int32_t)pid64, p.query, qrow_lane, qf, pd, pi2,
+                                                pq2);
             float s = finish_score(COS, pd, pi2, pq2);
             if (p.mask_pad_pos && pad) s = -INFINITY;
             if (owner) p.pos_score[m_lane] = s;

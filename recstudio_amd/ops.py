@@ -123,11 +123,13 @@ def seg_gather(item_table, flat_item_ids, seg_start, seg_end, max_len, want_rows
 def fused_forward(item_table, query, num_neg, *, query_index=None, pos_ids=None, neg_ids=None,
                   sampler=nat.SAMPLER_GIVEN, cosine=False, mask_pad_pos=False,
                   table=None, pop_prob=None, guide=None, guide_log2=0, generator=None, n_queries=None,
-                  out=None):
+                  out=None, want_logp=True):
     """One launch of rsa_fused_sample_gather_score.  Returns a dict with
     neg_ids [M,n] int64, neg_score [M,n], pos_score [M] (if pos_ids), and for the
     popularity sampler neg_logp [M,n], pos_logp [M].  ``out``: a dict returned by an earlier
-    call with the same shapes, whose buffers are overwritten instead of allocating."""
+    call with the same shapes, whose buffers are overwritten instead of allocating.
+    ``want_logp=False`` skips the log-probability outputs of the popularity sampler (BPR ignores
+    them, loss_func.py:55-59)."""
     item_table = _need(item_table, torch.float32, 'item_table')
     query = _need(query, torch.float32, 'query')
     dev = item_table.device
@@ -161,7 +163,7 @@ def fused_forward(item_table, query, num_neg, *, query_index=None, pos_ids=None,
         table = _need(table, torch.float32, 'table')
         pop_prob = _need(pop_prob, torch.float32, 'pop_prob')
         guide = _need(guide, torch.int32, 'guide')
-        if not reuse:
+        if not reuse and want_logp:
             out['neg_logp'] = torch.empty(M, n, dtype=torch.float32, device=dev)
             if pos_ids is not None:
                 out['pos_logp'] = torch.empty(M, dtype=torch.float32, device=dev)
