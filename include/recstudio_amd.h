@@ -204,6 +204,25 @@ int rsa_fullscore(const float* item_table, int64_t n_items, int32_t dim,
                   float* scores, float* lse, float* topk_val, int64_t* topk_idx, int32_t k,
                   void* workspace, int64_t workspace_bytes, rsa_stream_t stream);
 
+/* ---- Row-sharded item table (BASELINE.json configs[3]; no counterpart in the reference, whose
+ * only multi-device mode re-broadcasts whole tables every step, utils/data_parallel.py:106-159).
+ * Shard g owns item rows [g*rows_per_shard, (g+1)*rows_per_shard).  An "element" is one (query,
+ * item) pair of the [n_queries, 1+num_neg] matrix whose column 0 is pos_ids and columns 1.. are
+ * neg_ids.  Elements are counting-sorted by owner into contiguous per-owner segments and travel
+ * as one packed key = (query_base + query) << 32 | local_row; the fp32 scores come back in the
+ * same order; `positions[i]` is the slot of element i's score in the home buffer
+ * [pos_score (n_queries) | neg_score (n_queries x num_neg)], which rsa_scatter_f32 fills. */
+int rsa_shard_count(const int64_t* pos_ids, const int64_t* neg_ids, int64_t n_queries, int32_t num_neg,
+                    int64_t rows_per_shard, int32_t n_shards, int32_t* counts /* [n_shards] out */,
+                    rsa_stream_t stream);
+/* cursor [n_shards]: IN the exclusive prefix sum of counts (segment starts), clobbered. */
+int rsa_shard_route(const int64_t* pos_ids, const int64_t* neg_ids, int64_t n_queries, int32_t num_neg,
+                    int64_t rows_per_shard, int32_t n_shards, int64_t query_base, int32_t* cursor,
+                    int64_t* keys, int64_t* positions, rsa_stream_t stream);
+int rsa_shard_unpack(const int64_t* keys, int64_t numel, int64_t* local_rows, int64_t* query_index,
+                     rsa_stream_t stream);
+int rsa_scatter_f32(const float* src, const int64_t* positions, int64_t numel, float* dst, rsa_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -67,6 +67,11 @@ SIGNATURES = {
     'rsa_scatter_add_rows': (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_int64, c_void_p]),
     'rsa_seg_gather': (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int32,
                                c_void_p, c_void_p, c_void_p, c_void_p]),
+    'rsa_shard_count': (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_int64, c_int32, c_void_p, c_void_p]),
+    'rsa_shard_route': (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_int64, c_int32, c_int64, c_void_p, c_void_p,
+                                c_void_p, c_void_p]),
+    'rsa_shard_unpack': (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
+    'rsa_scatter_f32': (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     'rsa_fullscore_workspace_bytes': (c_int64, [c_int64, c_int64, c_int32]),
     'rsa_fullscore': (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
                               c_int32, c_void_p, c_int64, c_void_p]),

@@ -49,18 +49,27 @@ struct Frag {
 // Unconditional 16-byte loads (a load under a lane predicate becomes a branch + vmcnt(0) per load
 // and serialises the wave's row stream): rows that must not count are redirected to row 0 by the
 // caller, generic-dim tails are clamped to the last in-range column and zeroed with a select.
-template <int LPR, bool GENERIC>
+__device__ __forceinline__ float4 load16(const float* p, bool nt) {
+  if (nt) {   // streaming hint: rows of a table far larger than the 256 MB Infinity Cache are never re-read
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    const v4f v = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+  }
+  return *reinterpret_cast<const float4*>(p);
+}
+
+template <int LPR, bool GENERIC, bool NT = false>
 __device__ __forceinline__ void frag_load(Frag<LPR, GENERIC>& f, const float* __restrict__ row, int sub, int D) {
 #pragma unroll
   for (int c = 0; c < Frag<LPR, GENERIC>::CH; ++c) {
     const int col = (c * LPR + sub) * 4;
     if constexpr (GENERIC) {
       const int cc = col < D ? col : D - 4;
-      float4 v = *reinterpret_cast<const float4*>(row + cc);
+      float4 v = load16(row + cc, NT);
       const float m = col < D ? 1.f : 0.f;
       f.v[c] = make_float4(v.x * m, v.y * m, v.z * m, v.w * m);
     } else {
-      f.v[c] = *reinterpret_cast<const float4*>(row + col);
+      f.v[c] = load16(row + col, NT);
     }
   }
 }
@@ -97,7 +106,7 @@ __device__ __forceinline__ void fold(float (&d)[L], int sub, int step) {
 // Rows are visited BATCH at a time, batch b = rows {b, b+NB, b+2NB, ...} of the lane group, and
 // each batch is folded to one value right away (the depth-first order of the transpose-reduce
 // tree), so only BATCH row fragments + NB partials are live instead of LPR of each.
-template <int LPR, bool GENERIC, bool COS, bool QU>
+template <int LPR, bool GENERIC, bool COS, bool QU, bool NT>
 __device__ __forceinline__ void tile_rows(const float* __restrict__ table, int D, int32_t id_lane,
                                           const float* __restrict__ query, int32_t qrow_lane,
                                           const Frag<LPR, GENERIC>& qf_uniform, float& dot, float& inorm2,
@@ -119,7 +128,7 @@ __device__ __forceinline__ void tile_rows(const float* __restrict__ table, int D
     for (int k = 0; k < BATCH; ++k) {
       const int r = gbase + b + k * NB;
       const int32_t rid = __shfl(id_lane, r, 64);
-      frag_load<LPR, GENERIC>(x[k], table + (size_t)rid * D, sub, D);
+      frag_load<LPR, GENERIC, NT>(x[k], table + (size_t)rid * D, sub, D);
       if constexpr (!QU) {
         const int32_t qr = __shfl(qrow_lane, r, 64);
         frag_load<LPR, GENERIC>(qx[k], query + (size_t)qr * D, sub, D);
@@ -165,7 +174,7 @@ __device__ __forceinline__ float finish_score(bool cos, float dot, float inorm2,
   return cos ? (dot / sqrtf(inorm2)) / sqrtf(qnorm2) : dot;
 }
 
-template <int LPR, bool GENERIC, bool COS, bool QU>
+template <int LPR, bool GENERIC, bool COS, bool QU, bool NT>
 __global__ __launch_bounds__(256) void fused_fwd_kernel(const FwdParams p) {
   using F = Frag<LPR, GENERIC>;
   const int lane = lane_id();
@@ -216,7 +225,7 @@ __global__ __launch_bounds__(256) void fused_fwd_kernel(const FwdParams p) {
 
     // ---- 3. negatives: gather + dot
     float dot = 0.f, in2 = 1.f, qn2 = 1.f;
-    tile_rows<LPR, GENERIC, COS, QU>(p.item_table, D, id, p.query, qrow_lane, qf, dot, in2, qn2);
+    tile_rows<LPR, GENERIC, COS, QU, NT>(p.item_table, D, id, p.query, qrow_lane, qf, dot, in2, qn2);
     if constexpr (COS && QU) qn2 = qn2_u;
     if (act) p.neg_score[e] = finish_score(COS, dot, in2, qn2);
 
@@ -247,8 +256,8 @@ __global__ __launch_bounds__(256) void fused_fwd_kernel(const FwdParams p) {
           pid64 = pid64 < 0 ? 0 : (pid64 >= p.n_items ? p.n_items - 1 : pid64);
           if (p.pos_score) {
             float pd = 0.f, pi2 = 1.f, pq2 = 1.f;
-            tile_rows<LPR, GENERIC, COS, false>(p.item_table, D, (int32_t)pid64, p.query, qrow_lane, qf, pd, pi2,
-                                                pq2);
+            tile_rows<LPR, GENERIC, COS, false, false>(p.item_table, D, (int32_t)pid64, p.query, qrow_lane, qf, pd,
+                                                       pi2, pq2);
             float s = finish_score(COS, pd, pi2, pq2);
             if (p.mask_pad_pos && pad) s = -INFINITY;
             if (owner) p.pos_score[m_lane] = s;
@@ -260,6 +269,14 @@ __global__ __launch_bounds__(256) void fused_fwd_kernel(const FwdParams p) {
   }
 }
 
+template <int LPR, bool GENERIC, bool COS, bool QU>
+static void launch_fwd2(const FwdParams& p, dim3 grid, dim3 block, hipStream_t stream) {
+  // streaming (nontemporal) row loads once the table cannot live in the 256 MB Infinity Cache
+  const bool nt = !GENERIC && (size_t)p.n_items * p.dim * sizeof(float) > (512ull << 20);
+  if (nt) hipLaunchKernelGGL((fused_fwd_kernel<LPR, GENERIC, COS, QU, !GENERIC>), grid, block, 0, stream, p);
+  else hipLaunchKernelGGL((fused_fwd_kernel<LPR, GENERIC, COS, QU, false>), grid, block, 0, stream, p);
+}
+
 template <int LPR, bool GENERIC>
 static int launch_fwd(const FwdParams& p, bool cos, bool qu, hipStream_t stream) {
   const int64_t n_tiles = (p.numel + 63) >> 6;
@@ -268,11 +285,11 @@ static int launch_fwd(const FwdParams& p, bool cos, bool qu, hipStream_t stream)
   if (blocks < 1) blocks = 1;
   dim3 grid((unsigned)blocks), block(256);
   if (cos) {
-    if (qu) hipLaunchKernelGGL((fused_fwd_kernel<LPR, GENERIC, true, true>), grid, block, 0, stream, p);
-    else hipLaunchKernelGGL((fused_fwd_kernel<LPR, GENERIC, true, false>), grid, block, 0, stream, p);
+    if (qu) launch_fwd2<LPR, GENERIC, true, true>(p, grid, block, stream);
+    else launch_fwd2<LPR, GENERIC, true, false>(p, grid, block, stream);
   } else {
-    if (qu) hipLaunchKernelGGL((fused_fwd_kernel<LPR, GENERIC, false, true>), grid, block, 0, stream, p);
-    else hipLaunchKernelGGL((fused_fwd_kernel<LPR, GENERIC, false, false>), grid, block, 0, stream, p);
+    if (qu) launch_fwd2<LPR, GENERIC, false, true>(p, grid, block, stream);
+    else launch_fwd2<LPR, GENERIC, false, false>(p, grid, block, stream);
   }
   RSA_CHECK_LAUNCH("rsa_fused_sample_gather_score");
   return RSA_OK;

@@ -68,7 +68,7 @@ def build_guide_table(table: Tensor, guide_log2: Optional[int] = None):
     (sampler.py:247) because j/K and u*K are exact in fp32 for K <= 2**24."""
     n = table.numel()
     if guide_log2 is None:
-        guide_log2 = int(min(22, max(4, int(np.ceil(np.log2(max(n, 2)))) - 1)))
+        guide_log2 = int(min(24, max(4, int(np.ceil(np.log2(max(n, 2)))) + 1)))
     K = 1 << guide_log2
     cuts = torch.arange(K + 1, dtype=torch.float64) / K
     guide = torch.searchsorted(table.detach().cpu().contiguous(), cuts.to(torch.float32))

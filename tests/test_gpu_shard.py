@@ -1,0 +1,71 @@
+"""GPU: the HIP routing kernels of the sharded path against the checker backend used by the gloo
+test, and a world_size-1 RCCL run of the whole sharded step against the unsharded fused forward."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from test_shard_gloo import CheckerBackend, _free_port
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+@pytest.mark.parametrize('world,B,n', [(4, 33, 7), (8, 1000, 64), (2, 5, 1), (3, 17, 100)])
+def test_route_kernels_match_checker(world, B, n):
+    from recstudio_amd.shard import HipBackend, RowShardPlan
+    n_items = 10007
+    plan = RowShardPlan(n_items, world)
+    g = torch.Generator().manual_seed(B + n)
+    pos = torch.randint(0, n_items, (B,), generator=g)
+    neg = torch.randint(0, n_items, (B, n), generator=g)
+    hb, cb = HipBackend(), CheckerBackend()
+    counts = hb.count(pos.to(DEV), neg.to(DEV), plan).cpu()
+    want_counts = cb.count(pos, neg, plan)
+    assert torch.equal(counts, want_counts)
+    starts = torch.tensor([0] + counts.tolist()[:-1]).cumsum(0)
+    keys, positions = hb.route(pos.to(DEV), neg.to(DEV), plan, 1000, starts)
+    wkeys, wpos = cb.route(pos, neg, plan, 1000, starts)
+    keys, positions = keys.cpu(), positions.cpu()
+    # same multiset of (key, position) pairs inside every owner segment (order inside is free)
+    ends = counts.cumsum(0).tolist()
+    for s, e in zip([0] + ends[:-1], ends):
+        got = sorted(zip(keys[s:e].tolist(), positions[s:e].tolist()))
+        want = sorted(zip(wkeys[s:e].tolist(), wpos[s:e].tolist()))
+        assert got == want
+    assert sorted(positions.tolist()) == list(range(B * (n + 1)))
+    src = torch.randn(B * (n + 1))
+    out = hb.scatter(src.to(DEV), positions.to(DEV), B * (n + 1)).cpu()
+    assert torch.equal(out[positions], src)
+
+
+def test_world1_rccl_step_equals_unsharded():
+    import torch.distributed as dist
+    import recstudio_amd as ra
+    from recstudio_amd.shard import RowShardPlan, ShardedItemTable
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(_free_port())
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+    try:
+        N, U, d, B, n = 30011, 500, 128, 257, 64
+        g = torch.Generator().manual_seed(3)
+        item = (torch.randn(N, d, generator=g) * 0.1).to(DEV)
+        user = (torch.randn(U, d, generator=g) * 0.1).to(DEV)
+        uid = torch.randint(1, U, (B,), generator=g).to(DEV)
+        pos = torch.randint(1, N, (B,), generator=g).to(DEV)
+        counts = (torch.rand(N, generator=g) ** 3 * 100).long()
+        for sampler in (ra.UniformSampler(N), ra.PopularSamplerModel(counts).to(DEV)):
+            table = ShardedItemTable(item, RowShardPlan(N, 1), 0, dist)
+            torch.manual_seed(11)
+            out = table.sample_and_score(user, uid, pos, n, sampler)
+            torch.manual_seed(11)
+            score, ids = ra.retriever_scores(item, user, n, query_index=uid, pos_ids=pos, sampler=sampler)
+            assert torch.equal(out['neg_ids'], ids)                     # same Philox stream either way
+            np.testing.assert_allclose(out['neg_score'].cpu(), score['neg_score'].cpu(), rtol=1e-5, atol=1e-6)
+            np.testing.assert_allclose(out['pos_score'].cpu(), score['pos_score'].cpu(), rtol=1e-5, atol=1e-6)
+            want_p, want_n = oracle.retriever_forward(item.cpu(), user.cpu()[uid.cpu()], pos.cpu(), ids.cpu())
+            np.testing.assert_allclose(out['neg_score'].cpu(), want_n, rtol=1e-4, atol=1e-6)
+    finally:
+        dist.destroy_process_group()

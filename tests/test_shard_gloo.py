@@ -1,0 +1,112 @@
+"""CPU, world_size = 2, gloo: the row-sharded exchange protocol (split sizes, all-to-all order,
+reassembly) must reproduce single-process scores exactly.  The device work is supplied by a
+checker backend built on the oracle (this test is the importer; the product has no CPU path)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import oracle
+
+
+class CheckerBackend:
+    """Same interface as recstudio_amd.shard.HipBackend, restated with torch-CPU ops."""
+
+    def gather_rows(self, table, ids):
+        return table[ids]
+
+    def sample(self, sampler, n_queries, n, device, pos_ids):
+        return sampler.forward(torch.zeros(n_queries, 1), n, pos_ids)
+
+    def _elements(self, pos, neg):
+        return torch.cat([pos.view(-1, 1), neg], 1).reshape(-1)
+
+    def count(self, pos, neg, plan):
+        return torch.bincount(plan.owner(self._elements(pos, neg)), minlength=plan.world).to(torch.int32)
+
+    def route(self, pos, neg, plan, query_base, starts):
+        B, n = neg.shape
+        ids = self._elements(pos, neg)
+        owner = plan.owner(ids)
+        order = torch.argsort(owner, stable=True)
+        m = torch.arange(B).repeat_interleave(n + 1)
+        c = torch.arange(n + 1).repeat(B)
+        key = ((query_base + m) << 32) | (ids - owner * plan.rows_per_shard)
+        position = torch.where(c == 0, m, B + m * n + (c - 1))
+        return key[order], position[order]
+
+    def score_keys(self, item_local, q_all, keys):
+        rows, qidx = keys & 0xffffffff, keys >> 32
+        return (item_local[rows] * q_all[qidx]).sum(-1)
+
+    def scatter(self, scores, positions, numel):
+        out = torch.empty(numel)
+        out[positions] = scores
+        return out
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, n_items, d, B, n, result_dir):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from recstudio_amd.shard import RowShardPlan, ShardedItemTable
+        g = torch.Generator().manual_seed(5)
+        item = torch.randn(n_items, d, generator=g)
+        item[0] = 0
+        user = torch.randn(50, d, generator=g)
+        plan = RowShardPlan(n_items, world)
+        lo, hi = plan.bounds(rank)
+        table = ShardedItemTable(item[lo:hi].clone(), plan, rank, dist, backend=CheckerBackend())
+        gr = torch.Generator().manual_seed(100 + rank)
+        uid = torch.randint(1, 50, (B,), generator=gr)
+        pos = torch.randint(1, n_items, (B,), generator=gr)
+        torch.manual_seed(7 + rank)
+        sampler = oracle.UniformSampler(n_items)
+        out = table.sample_and_score(user, uid, pos, n, sampler)
+        want_pos, want_neg = oracle.retriever_forward(item, user[uid], pos, out['neg_ids'])
+        np.testing.assert_allclose(out['pos_score'].numpy(), want_pos.numpy(), rtol=1e-6, atol=1e-6)
+        np.testing.assert_allclose(out['neg_score'].numpy(), want_neg.numpy(), rtol=1e-6, atol=1e-6)
+        # skewed ids: everything owned by the last rank, and an empty segment for rank 0
+        neg2 = torch.full((B, n), n_items - 1, dtype=torch.int64)
+        pos2 = torch.full((B,), n_items - 2, dtype=torch.int64)
+        p2, s2 = table.score_ids(user[uid], pos2, neg2)
+        w2p, w2n = oracle.retriever_forward(item, user[uid], pos2, neg2)
+        np.testing.assert_allclose(p2.numpy(), w2p.numpy(), rtol=1e-6, atol=1e-6)
+        np.testing.assert_allclose(s2.numpy(), w2n.numpy(), rtol=1e-6, atol=1e-6)
+        open(os.path.join(result_dir, f'ok{rank}'), 'w').write('ok')
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('n_items,n', [(101, 5), (64, 1)])
+def test_sharded_scores_equal_single_process(tmp_path, n_items, n):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), n_items, 16, 9, n, str(tmp_path)), nprocs=world, join=True)
+    assert all(os.path.exists(tmp_path / f'ok{r}') for r in range(world))
+
+
+def test_plan_partitions_all_rows():
+    from recstudio_amd.shard import RowShardPlan
+    for n_items, world in ((100_000_001, 8), (101, 2), (7, 8), (64, 4)):
+        plan = RowShardPlan(n_items, world)
+        spans = [plan.bounds(r) for r in range(world)]
+        assert spans[0][0] == 0 and spans[-1][1] == n_items
+        assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+        ids = torch.tensor([0, 1, n_items // 2, n_items - 1])
+        own = plan.owner(ids)
+        for i, o in zip(ids.tolist(), own.tolist()):
+            lo, hi = plan.bounds(o)
+            assert lo <= i < hi
