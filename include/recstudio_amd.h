@@ -141,6 +141,12 @@ int rsa_pairwise_loss(int32_t loss_kind, const float* pos_score, const float* ne
                       const float* pos_logp, const float* neg_logp, int64_t n_rows, int32_t num_neg,
                       float* row_loss, float* loss_out, float* dpos, float* dneg, rsa_stream_t stream);
 
+/* SoftmaxLoss.forward on a MATERIALISED score matrix -- recstudio/model/loss_func.py:41:
+ * lse[m] = logsumexp(x[m, :]); softmax_scaled (nullable) [n_rows, n_cols] = softmax(x) * scale
+ * (= d mean(lse) / d x for scale = 1/n_rows). */
+int rsa_row_lse(const float* x, int64_t n_rows, int64_t n_cols, float* lse, float* softmax_scaled,
+                float scale, rsa_stream_t stream);
+
 /* Backward of the fused forward for the inner-product scorer == what autograd
  * produces at recommender.py:636-639 (embedding_dense_backward + bmm backward):
  *   item_grad[neg_ids[m,j]] += up * dneg[m,j] * q_m     (skipped for id 0: padding_idx)
@@ -195,14 +201,23 @@ int rsa_seg_gather(const float* item_table, int64_t n_items, int32_t dim,
  * (v_mfma_f32_32x32x2_f32), never materialising [B, N-1] unless `scores` is given.
  *   scores : nullable [B, n_items-1] out (reference-style materialisation)
  *   lse    : nullable [B] out, logsumexp over the catalog (SoftmaxLoss, loss_func.py:41)
- *   topk_val / topk_idx : nullable [B, k] out, k <= 128: largest k scores, ids are
- *     ITEM ids (1-based, baseretriever.py:385); ties -> smaller id first.
+ *   topk_val / topk_idx : nullable [B, k] out, k <= 1024: largest k scores in descending order,
+ *     ids are ITEM ids (1-based, baseretriever.py:385); equal scores -> smaller id first.
+ *   dim must be 32, 64 or 128 (RSA_ERR_UNSUPPORTED otherwise).
  *   workspace: device scratch of rsa_fullscore_workspace_bytes(B, n_items, k) bytes. */
 int64_t rsa_fullscore_workspace_bytes(int64_t n_query, int64_t n_items, int32_t k);
 int rsa_fullscore(const float* item_table, int64_t n_items, int32_t dim,
                   const float* query, int64_t n_query,
                   float* scores, float* lse, float* topk_val, int64_t* topk_idx, int32_t k,
                   void* workspace, int64_t workspace_bytes, rsa_stream_t stream);
+
+/* History exclusion of BaseRetriever.topk -- baseretriever.py:386-392: candidates (sorted
+ * descending, [n_query, n_cand], item ids) that appear in user_hist [n_query, hist_len] (0-padded)
+ * get score -inf; out = the k best survivors in order (masked ones, as -inf, fill the tail only
+ * when fewer than k survive). */
+int rsa_topk_mask_history(const float* cand_val, const int64_t* cand_idx, int32_t n_cand,
+                          const int64_t* user_hist, int32_t hist_len, int64_t n_query, int32_t k,
+                          float* out_val, int64_t* out_idx, rsa_stream_t stream);
 
 /* ---- Row-sharded item table (BASELINE.json configs[3]; no counterpart in the reference, whose
  * only multi-device mode re-broadcasts whole tables every step, utils/data_parallel.py:106-159).

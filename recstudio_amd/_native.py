@@ -63,10 +63,13 @@ SIGNATURES = {
     'rsa_fused_sample_gather_score': (c_int, [POINTER(FusedArgs), c_void_p]),
     'rsa_pairwise_loss': (c_int, [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p,
                                   c_void_p, c_void_p, c_void_p, c_void_p]),
+    'rsa_row_lse': (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_float, c_void_p]),
     'rsa_fused_backward': (c_int, [POINTER(BackwardArgs), c_void_p]),
     'rsa_scatter_add_rows': (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_int64, c_void_p]),
     'rsa_seg_gather': (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int32,
                                c_void_p, c_void_p, c_void_p, c_void_p]),
+    'rsa_topk_mask_history': (c_int, [c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_int64, c_int32, c_void_p,
+                                      c_void_p, c_void_p]),
     'rsa_shard_count': (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_int64, c_int32, c_void_p, c_void_p]),
     'rsa_shard_route': (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_int64, c_int32, c_int64, c_void_p, c_void_p,
                                 c_void_p, c_void_p]),

@@ -1,13 +1,392 @@
-// Full-catalog scoring (fp32 MFMA) -- placeholder until the MFMA kernel lands.
+// Full-catalog scoring with the fp32 MFMA (gfx950): scores = Q [B,d] x Items[1:N]^T.
+//
+//   InnerProductScorer ([B,D],[N,D]) case     recstudio/model/scorer.py:16
+//   called from BaseRetriever.forward         baseretriever.py:183-186  (FullScoreLoss training)
+//   and BaseRetriever.topk                    baseretriever.py:384      (torch.topk(k + more))
+//   SoftmaxLoss                               loss_func.py:41           (logsumexp over the catalog)
+//
+// GEMM kernel.  v_mfma_f32_32x32x2_f32 with the ITEM rows as the A operand and the QUERY rows as
+// the B operand ("swapped" orientation): a lane then owns one query column (lane & 31) and 16 item
+// rows of every 32x32 output tile, so the per-query reductions (running max / sum-exp of the
+// online logsumexp) stay inside the lane -- no cross-lane traffic in the main loop.  The K index is
+// permuted (lane half h owns k in [h*D/2, (h+1)*D/2)) so that each lane's A and B operands are
+// CONTIGUOUS floats of one row: 16-byte LDS / global reads instead of stride-2 gathers; a sum over k
+// does not care about the order.  A workgroup = 4 waves = 128 queries; the 32-item A tile is staged
+// through LDS (row stride D+4 floats: conflict-free ds_read_b128) and shared by the 4 waves; the
+// query operand lives in registers for the whole item range.  Exact fp32 (fmaf chain), 157 TFLOP/s peak.
+//
+// Top-k.  Scores go to HBM (caller's `scores` or the workspace) and a per-row 3-pass radix select
+// (11/11/10 bits) finds the exact k-th key, collects the k winners and bitonic-sorts them.
 #include "rsa_common.hpp"
 
-extern "C" int64_t rsa_fullscore_workspace_bytes(int64_t n_query, int64_t n_items, int32_t k) {
-  (void)n_query; (void)n_items; (void)k;
-  return 0;
+namespace rsa {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int QB = 128;   // queries per workgroup (4 waves x 32)
+constexpr int TI = 32;    // items per tile
+
+template <int D>
+__global__ __launch_bounds__(256) void fullscore_kernel(const float* __restrict__ item_table, int64_t n_items,
+                                                        const float* __restrict__ query, int64_t n_query,
+                                                        float* __restrict__ scores, float2* __restrict__ lse_part,
+                                                        int splits, int64_t items_per_split) {
+  constexpr int KH = D / 2;         // k values per lane half
+  constexpr int LD = D + 4;         // padded LDS row stride (floats)
+  constexpr int V4 = D / 4;         // float4 per row
+  __shared__ float tile[2][TI][LD];
+  __shared__ float tpose[4][32][33];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 31, h = lane >> 5;
+  const int64_t q = (int64_t)blockIdx.y * QB + wave * 32 + j;
+  const int64_t n_cols = n_items - 1;
+
+  float bq[KH];
+  {
+    const bool qv = q < n_query;
+    const float4* src = reinterpret_cast<const float4*>(query + (size_t)(qv ? q : 0) * D + h * KH);
+#pragma unroll
+    for (int c = 0; c < KH / 4; ++c) {
+      float4 v = src[c];
+      if (!qv) v = make_float4(0.f, 0.f, 0.f, 0.f);
+      bq[4 * c + 0] = v.x; bq[4 * c + 1] = v.y; bq[4 * c + 2] = v.z; bq[4 * c + 3] = v.w;
+    }
+  }
+
+  const int64_t i_begin = 1 + (int64_t)blockIdx.x * items_per_split;
+  int64_t i_end = i_begin + items_per_split;
+  if (i_end > n_items) i_end = n_items;
+  const int n_tiles = i_begin < i_end ? (int)((i_end - i_begin + TI - 1) / TI) : 0;
+
+  constexpr int LOADS = (TI * V4) / 256;    // float4 per thread per tile (D=128: 4)
+  static_assert((TI * V4) % 256 == 0, "tile must split evenly over the workgroup");
+  float4 stage[LOADS];
+  auto fetch = [&](int t) {
+#pragma unroll
+    for (int f = 0; f < LOADS; ++f) {
+      const int idx = f * 256 + tid;
+      const int row = idx / V4, c4 = idx - row * V4;
+      const int64_t item = i_begin + (int64_t)t * TI + row;
+      stage[f] = item < i_end ? reinterpret_cast<const float4*>(item_table + (size_t)item * D)[c4]
+                              : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto commit = [&](int buf) {
+#pragma unroll
+    for (int f = 0; f < LOADS; ++f) {
+      const int idx = f * 256 + tid;
+      const int row = idx / V4, c4 = idx - row * V4;
+      *reinterpret_cast<float4*>(&tile[buf][row][c4 * 4]) = stage[f];
+    }
+  };
+
+  float run_m = -INFINITY, run_s = 0.f;
+  if (n_tiles > 0) {
+    fetch(0);
+    commit(0);
+  }
+  __syncthreads();
+  for (int t = 0; t < n_tiles; ++t) {
+    const int cur = t & 1;
+    if (t + 1 < n_tiles) fetch(t + 1);          // global loads fly under the MFMA chain
+    f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const float* arow = &tile[cur][j][h * KH];   // lane's item row of this tile, its k half
+#pragma unroll
+    for (int c = 0; c < KH / 4; ++c) {
+      const float4 a = *reinterpret_cast<const float4*>(arow + 4 * c);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bq[4 * c + 0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bq[4 * c + 1], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bq[4 * c + 2], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bq[4 * c + 3], acc, 0, 0, 0);
+    }
+    // acc[r] = <item (i0 + row(r)), query q>, row(r) = (r & 3) + 8 * (r >> 2) + 4 * h
+    const int64_t i0 = i_begin + (int64_t)t * TI;
+    if (lse_part != nullptr) {
+      float tmax = -INFINITY;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (i0 + row < i_end) tmax = fmaxf(tmax, acc[r]);
+      }
+      if (tmax > -INFINITY) {
+        const float m_new = fmaxf(run_m, tmax);
+        float s = run_s * __expf(run_m - m_new);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+          if (i0 + row < i_end) s += __expf(acc[r] - m_new);
+        }
+        run_m = m_new;
+        run_s = s;
+      }
+    }
+    if (scores != nullptr) {
+      // transpose the wave's 32 (items) x 32 (queries) tile through LDS so that every half-wave
+      // writes 128 contiguous bytes of one query's score row
+#pragma unroll
+      for (int r = 0; r < 16; ++r) tpose[wave][j][(r & 3) + 8 * (r >> 2) + 4 * h] = acc[r];
+      __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the wave's own LDS writes have landed
+#pragma unroll
+      for (int tt = 0; tt < 16; ++tt) {
+        const int qq = 2 * tt + h;
+        const int64_t qg = (int64_t)blockIdx.y * QB + wave * 32 + qq;
+        const int64_t item = i0 + j;
+        if (qg < n_query && item < i_end) scores[(size_t)qg * n_cols + (item - 1)] = tpose[wave][qq][j];
+      }
+    }
+    if (t + 1 < n_tiles) commit(cur ^ 1);
+    __syncthreads();
+  }
+  if (lse_part != nullptr) {
+    // fold the two k-halves' item subsets (lanes j and j+32 hold the same query)
+    const float om = __shfl_xor(run_m, 32, 64), os = __shfl_xor(run_s, 32, 64);
+    const float m = fmaxf(run_m, om);
+    float s = 0.f;
+    if (m > -INFINITY) s = run_s * __expf(run_m - m) + os * __expf(om - m);
+    if (h == 0 && q < n_query) lse_part[(size_t)q * splits + blockIdx.x] = make_float2(m, s);
+  }
 }
 
-extern "C" int rsa_fullscore(const float*, int64_t, int32_t, const float*, int64_t, float*, float*, float*, int64_t*,
-                             int32_t, void*, int64_t, rsa_stream_t) {
-  rsa::set_error("rsa_fullscore: not implemented in this build");
-  return RSA_ERR_UNSUPPORTED;
+__global__ __launch_bounds__(256) void lse_merge_kernel(const float2* __restrict__ part, int64_t n_query, int splits,
+                                                        float* __restrict__ lse) {
+  const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= n_query) return;
+  float m = -INFINITY;
+  for (int s = 0; s < splits; ++s) m = fmaxf(m, part[(size_t)q * splits + s].x);
+  float acc = 0.f;
+  for (int s = 0; s < splits; ++s) {
+    const float2 p = part[(size_t)q * splits + s];
+    if (p.x > -INFINITY) acc += p.y * expf(p.x - m);
+  }
+  lse[q] = m + logf(acc);
+}
+
+// ------------------------------------------------------------------ exact top-k of one row
+__device__ __forceinline__ uint32_t order_key(float x) {   // monotone float -> uint
+  const uint32_t u = __float_as_uint(x);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float key_value(uint32_t k) {
+  return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+}
+
+__global__ __launch_bounds__(1024) void topk_row_kernel(const float* __restrict__ scores, int64_t n_cols, int k,
+                                                        float* __restrict__ topk_val, int64_t* __restrict__ topk_idx) {
+  __shared__ uint32_t hist[2048];
+  __shared__ uint32_t s_digit, s_krem, s_cnt_gt, s_cnt_eq;
+  __shared__ uint32_t okey[1024];
+  __shared__ int32_t oidx[1024];
+  const int tid = threadIdx.x;
+  const float* row = scores + (size_t)blockIdx.x * n_cols;
+  uint32_t prefix = 0, pmask = 0;
+  uint32_t k_rem = (uint32_t)k;
+  const int shifts[3] = {21, 10, 0}, nbits[3] = {11, 11, 10};
+  for (int pass = 0; pass < 3; ++pass) {
+    const int shift = shifts[pass], nb = 1 << nbits[pass];
+    for (int b = tid; b < 2048; b += 1024) hist[b] = 0;
+    __syncthreads();
+    for (int64_t i = tid; i < n_cols; i += 1024) {
+      const uint32_t key = order_key(row[i]);
+      if ((key & pmask) == prefix) atomicAdd(&hist[(key >> shift) & (nb - 1)], 1u);
+    }
+    __syncthreads();
+    // suffix sums: hist[b] <- number of keys with digit >= b (Hillis-Steele over 2048 bins)
+    for (int off = 1; off < 2048; off <<= 1) {
+      uint32_t v0 = 0, v1 = 0;
+      const int b0 = tid, b1 = tid + 1024;
+      if (b0 + off < 2048) v0 = hist[b0 + off];
+      if (b1 + off < 2048) v1 = hist[b1 + off];
+      __syncthreads();
+      hist[b0] += v0;
+      hist[b1] += v1;
+      __syncthreads();
+    }
+    // the digit d with suffix(d) >= k_rem > suffix(d+1)
+    for (int b = tid; b < nb; b += 1024) {
+      const uint32_t ge = hist[b], gt = (b + 1 < 2048) ? hist[b + 1] : 0u;
+      if (ge >= k_rem && gt < k_rem) {
+        s_digit = (uint32_t)b;
+        s_krem = k_rem - gt;
+      }
+    }
+    __syncthreads();
+    prefix |= s_digit << shift;
+    pmask |= (uint32_t)(nb - 1) << shift;
+    k_rem = s_krem;
+    __syncthreads();
+  }
+  // prefix = key of the k-th largest; k_rem of the keys equal to it are needed
+  if (tid == 0) {
+    s_cnt_gt = 0;
+    s_cnt_eq = 0;
+  }
+  okey[tid] = 0;
+  oidx[tid] = 0x7fffffff;
+  __syncthreads();
+  const uint32_t n_gt = (uint32_t)k - k_rem;
+  for (int64_t i = tid; i < n_cols; i += 1024) {
+    const uint32_t key = order_key(row[i]);
+    if (key > prefix) {
+      const uint32_t p = atomicAdd(&s_cnt_gt, 1u);
+      okey[p] = key;
+      oidx[p] = (int32_t)i;
+    } else if (key == prefix) {
+      const uint32_t p = atomicAdd(&s_cnt_eq, 1u);
+      if (p < k_rem) {
+        okey[n_gt + p] = key;
+        oidx[n_gt + p] = (int32_t)i;
+      }
+    }
+  }
+  __syncthreads();
+  // bitonic sort, descending by key, ascending index among equal keys
+  for (int size = 2; size <= 1024; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      const int partner = tid ^ stride;
+      if (partner > tid) {
+        const bool desc = (tid & size) == 0;
+        const uint32_t ka = okey[tid], kb = okey[partner];
+        const int32_t ia = oidx[tid], ib = oidx[partner];
+        const bool a_first = ka > kb || (ka == kb && ia < ib);
+        if (a_first != desc) {
+          okey[tid] = kb; okey[partner] = ka;
+          oidx[tid] = ib; oidx[partner] = ia;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  if (tid < k) {
+    topk_val[(size_t)blockIdx.x * k + tid] = key_value(okey[tid]);
+    topk_idx[(size_t)blockIdx.x * k + tid] = (int64_t)oidx[tid] + 1;   // item id (baseretriever.py:385)
+  }
+}
+
+// score[mask] = -inf where the item is in the user's history, then the k best survivors
+// (baseretriever.py:386-392).  One wave per query; cand are sorted descending.
+__global__ __launch_bounds__(256) void mask_history_kernel(const float* __restrict__ cand_val,
+                                                           const int64_t* __restrict__ cand_idx, int kc,
+                                                           const int64_t* __restrict__ hist, int hist_len, int k,
+                                                           int64_t n_query, float* __restrict__ out_val,
+                                                           int64_t* __restrict__ out_idx) {
+  const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (q >= n_query) return;
+  const int lane = lane_id();
+  const float* cv = cand_val + (size_t)q * kc;
+  const int64_t* ci = cand_idx + (size_t)q * kc;
+  const int64_t* hq = hist + (size_t)q * hist_len;
+  int kept = 0, dropped = 0;
+  for (int base = 0; base < kc; base += 64) {
+    const int c = base + lane;
+    bool in_hist = false, valid = c < kc;
+    int64_t id = 0;
+    float v = 0.f;
+    if (valid) {
+      id = ci[c];
+      v = cv[c];
+      for (int t = 0; t < hist_len; ++t) in_hist |= (hq[t] == id);
+    }
+    const unsigned long long keep_mask = __ballot(valid && !in_hist);
+    const unsigned long long drop_mask = __ballot(valid && in_hist);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    if (valid && !in_hist) {
+      const int p = kept + __popcll(keep_mask & below);
+      if (p < k) {
+        out_val[(size_t)q * k + p] = v;
+        out_idx[(size_t)q * k + p] = id;
+      }
+    }
+    // masked candidates fill the tail (as -inf) only if fewer than k survive
+    if (valid && in_hist) {
+      const int p = (kc - 1) - (dropped + __popcll(drop_mask & below));
+      // position from the end among all kc slots; it lands in the output only when p < k
+      if (p < k) {
+        out_val[(size_t)q * k + p] = -INFINITY;
+        out_idx[(size_t)q * k + p] = id;
+      }
+    }
+    kept += __popcll(keep_mask);
+    dropped += __popcll(drop_mask);
+  }
+}
+
+}  // namespace rsa
+
+using namespace rsa;
+
+static int64_t fullscore_splits(int64_t n_query, int64_t n_items) {
+  const int64_t groups = (n_query + QB - 1) / QB;
+  int64_t splits = (1024 + groups - 1) / groups;   // ~4 workgroups per CU in flight
+  const int64_t max_splits = (n_items - 1 + TI - 1) / TI;
+  if (splits > max_splits) splits = max_splits;
+  if (splits < 1) splits = 1;
+  return splits;
+}
+
+extern "C" int64_t rsa_fullscore_workspace_bytes(int64_t n_query, int64_t n_items, int32_t k) {
+  if (n_query <= 0 || n_items <= 1) return 0;
+  int64_t bytes = n_query * fullscore_splits(n_query, n_items) * (int64_t)sizeof(float2);   // lse partials
+  if (k > 0) bytes += n_query * (n_items - 1) * (int64_t)sizeof(float);                     // score rows
+  return bytes + 256;
+}
+
+extern "C" int rsa_fullscore(const float* item_table, int64_t n_items, int32_t dim, const float* query,
+                             int64_t n_query, float* scores, float* lse, float* topk_val, int64_t* topk_idx, int32_t k,
+                             void* workspace, int64_t workspace_bytes, rsa_stream_t stream) {
+  RSA_CHECK_ARG(n_query >= 0 && n_items >= 2, "rsa_fullscore: need n_items >= 2");
+  if (n_query == 0) return RSA_OK;
+  RSA_CHECK_ARG(item_table && query, "rsa_fullscore: item_table/query is null");
+  RSA_CHECK_ARG(scores || lse || k > 0, "rsa_fullscore: no output requested");
+  RSA_CHECK_ARG(k >= 0 && k <= 1024 && (int64_t)k <= n_items - 1, "rsa_fullscore: k must be in [0, min(1024, n_items-1)]");
+  RSA_CHECK_ARG(k == 0 || (topk_val && topk_idx), "rsa_fullscore: topk outputs are null");
+  if (dim != 32 && dim != 64 && dim != 128) {
+    rsa::set_error("rsa_fullscore: dim=%d: the MFMA full-score kernel is built for dim in {32, 64, 128}", dim);
+    return RSA_ERR_UNSUPPORTED;
+  }
+  const int64_t need = rsa_fullscore_workspace_bytes(n_query, n_items, scores ? 0 : k);
+  RSA_CHECK_ARG(workspace != nullptr && workspace_bytes >= need, "rsa_fullscore: workspace too small (%lld < %lld)",
+                (long long)workspace_bytes, (long long)need);
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t splits = fullscore_splits(n_query, n_items);
+  const int64_t per = (((n_items - 1) + splits - 1) / splits + TI - 1) / TI * TI;
+  const int64_t splits_used = ((n_items - 1) + per - 1) / per;
+  float2* part = reinterpret_cast<float2*>(workspace);
+  float* score_rows = scores;
+  if (k > 0 && scores == nullptr)
+    score_rows = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) +
+                                          ((n_query * splits * (int64_t)sizeof(float2) + 255) / 256) * 256);
+  dim3 grid((unsigned)splits_used, (unsigned)((n_query + QB - 1) / QB)), block(256);
+  float2* lp = lse ? part : nullptr;
+  switch (dim) {
+    case 32: hipLaunchKernelGGL(fullscore_kernel<32>, grid, block, 0, s, item_table, n_items, query, n_query, score_rows, lp, (int)splits_used, per); break;
+    case 64: hipLaunchKernelGGL(fullscore_kernel<64>, grid, block, 0, s, item_table, n_items, query, n_query, score_rows, lp, (int)splits_used, per); break;
+    default: hipLaunchKernelGGL(fullscore_kernel<128>, grid, block, 0, s, item_table, n_items, query, n_query, score_rows, lp, (int)splits_used, per); break;
+  }
+  RSA_CHECK_LAUNCH("rsa_fullscore(gemm)");
+  if (lse) {
+    hipLaunchKernelGGL(lse_merge_kernel, dim3((unsigned)((n_query + 255) / 256)), dim3(256), 0, s, part, n_query,
+                       (int)splits_used, lse);
+    RSA_CHECK_LAUNCH("rsa_fullscore(lse)");
+  }
+  if (k > 0) {
+    hipLaunchKernelGGL(topk_row_kernel, dim3((unsigned)n_query), dim3(1024), 0, s, score_rows, n_items - 1, (int)k,
+                       topk_val, topk_idx);
+    RSA_CHECK_LAUNCH("rsa_fullscore(topk)");
+  }
+  return RSA_OK;
+}
+
+extern "C" int rsa_topk_mask_history(const float* cand_val, const int64_t* cand_idx, int32_t n_cand,
+                                     const int64_t* user_hist, int32_t hist_len, int64_t n_query, int32_t k,
+                                     float* out_val, int64_t* out_idx, rsa_stream_t stream) {
+  RSA_CHECK_ARG(n_query >= 0 && n_cand >= 1 && k >= 1 && k <= n_cand && hist_len >= 0,
+                "rsa_topk_mask_history: need 1 <= k <= n_cand");
+  if (n_query == 0) return RSA_OK;
+  RSA_CHECK_ARG(cand_val && cand_idx && out_val && out_idx && (user_hist || hist_len == 0),
+                "rsa_topk_mask_history: null pointer");
+  hipLaunchKernelGGL(mask_history_kernel, dim3((unsigned)((n_query + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                     cand_val, cand_idx, (int)n_cand, user_hist, (int)hist_len, (int)k, n_query, out_val, out_idx);
+  RSA_CHECK_LAUNCH("rsa_topk_mask_history");
+  return RSA_OK;
 }

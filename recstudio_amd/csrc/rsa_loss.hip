@@ -100,9 +100,47 @@ __global__ __launch_bounds__(1024) void mean_rows_kernel(const float* __restrict
   }
 }
 
+// lse[m] = logsumexp(x[m, :]); optionally grad[m, :] = softmax(x[m, :]) * scale.  One workgroup per row.
+__global__ __launch_bounds__(256) void row_lse_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ lse,
+                                                      float* __restrict__ grad, float scale) {
+  __shared__ float red[4];
+  const float* row = x + (size_t)blockIdx.x * n;
+  float m = -INFINITY;
+  for (int64_t i = threadIdx.x; i < n; i += 256) m = fmaxf(m, row[i]);
+#pragma unroll
+  for (int k = 32; k >= 1; k >>= 1) m = fmaxf(m, __shfl_xor(m, k, 64));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  __syncthreads();
+  float s = 0.f;
+  for (int64_t i = threadIdx.x; i < n; i += 256) s += expf(row[i] - m);
+  s = group_sum<64>(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  s = (red[0] + red[1]) + (red[2] + red[3]);
+  const float l = m + logf(s);
+  if (threadIdx.x == 0) lse[blockIdx.x] = l;
+  if (grad != nullptr) {
+    float* g = grad + (size_t)blockIdx.x * n;
+    for (int64_t i = threadIdx.x; i < n; i += 256) g[i] = expf(row[i] - l) * scale;
+  }
+}
+
 }  // namespace rsa
 
 using namespace rsa;
+
+extern "C" int rsa_row_lse(const float* x, int64_t n_rows, int64_t n_cols, float* lse, float* softmax_scaled,
+                           float scale, rsa_stream_t stream) {
+  RSA_CHECK_ARG(n_rows >= 0 && n_cols >= 1, "rsa_row_lse: bad sizes");
+  if (n_rows == 0) return RSA_OK;
+  RSA_CHECK_ARG(x && lse, "rsa_row_lse: null pointer");
+  hipLaunchKernelGGL(row_lse_kernel, dim3((unsigned)n_rows), dim3(256), 0, (hipStream_t)stream, x, n_cols, lse,
+                     softmax_scaled, scale);
+  RSA_CHECK_LAUNCH("rsa_row_lse");
+  return RSA_OK;
+}
 
 extern "C" int rsa_pairwise_loss(int32_t loss_kind, const float* pos_score, const float* neg_score,
                                  const float* pos_logp, const float* neg_logp, int64_t n_rows, int32_t num_neg,

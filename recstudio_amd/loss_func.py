@@ -82,20 +82,28 @@ class SampledSoftmaxLoss(PairwiseLoss):
                                  _as_f32_or_none(log_neg_prob))
 
 
+class _MeanLseFn(torch.autograd.Function):
+    """mean over rows of logsumexp(all_score[m, :]) with the softmax gradient produced in the same call."""
+
+    @staticmethod
+    def forward(ctx, all_score):
+        x = all_score.reshape(-1, all_score.shape[-1])
+        lse, sm = ops.row_lse(x, want_softmax=all_score.requires_grad, scale=1.0 / x.shape[0])
+        ctx.shape = all_score.shape
+        ctx.save_for_backward(sm)
+        return lse.mean()
+
+    @staticmethod
+    def backward(ctx, g):
+        (sm,) = ctx.saved_tensors
+        return (sm * g).view(ctx.shape)
+
+
 class SoftmaxLoss(FullScoreLoss):
-    """recstudio/model/loss_func.py:39-47, first branch (all_score one dim more than pos_score).
-    mean(logsumexp(all_score) - pos_score) == the sampled-softmax kernel with the positive taken
-    out of the partition sum: handled by passing -inf as the positive column."""
+    """recstudio/model/loss_func.py:39-47, first branch (all_score one dim more than pos_score):
+    mean(logsumexp(all_score, -1) - pos_score)."""
 
     def forward(self, label, pos_score, all_score):
         if all_score.dim() != pos_score.dim() + 1:
             raise NotImplementedError('SoftmaxLoss: only all_score [.., N] with pos_score [..] is implemented')
-        return _RowLseFn.apply(all_score).mean() - pos_score.mean()
-
-
-class _RowLseFn(torch.autograd.Function):
-    """logsumexp over the last dim via rsa_pairwise_loss(SSM) with a zero-weight positive."""
-
-    @staticmethod
-    def forward(ctx, all_score):
-        raise NotImplementedError('materialised-SoftmaxLoss needs the full-score kernel (use BaseRetriever)')
+        return _MeanLseFn.apply(all_score) - pos_score.mean()

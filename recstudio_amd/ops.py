@@ -232,11 +232,36 @@ def fused_backward(item_table, query, neg_ids, dneg, *, query_index=None, pos_id
 
 
 # ------------------------------------------------------------------ full catalog
-def fullscore(item_table, query, *, want_scores=False, want_lse=False, k=0):
+def row_lse(x, want_softmax=False, scale=1.0):
+    x = _need(x, torch.float32, 'x')
+    M, n = x.shape
+    lse = torch.empty(M, dtype=torch.float32, device=x.device)
+    sm = torch.empty_like(x) if want_softmax else None
+    nat.check(nat.lib().rsa_row_lse(ptr(x), M, n, ptr(lse), ptr(sm), float(scale), _stream()), 'rsa_row_lse')
+    return lse, sm
+
+
+def fullscore(item_table, query, *, want_scores=False, want_lse=False, k=0, items_without_pad=False):
+    """rsa_fullscore: scores of query [B,d] against rows 1.. of item_table [N,d].
+    ``items_without_pad``: ``item_table`` is the reference's ``item_vector`` (= weight[1:], no padding
+    row); the kernel never touches row 0, so the base pointer is simply moved one row back."""
     item_table = _need(item_table, torch.float32, 'item_table')
     query = _need(query, torch.float32, 'query')
     dev = item_table.device
     n_items, dim = item_table.shape
+    if dim not in (32, 64, 128):
+        # the MFMA kernel is built for d in {32, 64, 128}: zero-pad the k dimension (a copy -- only
+        # for unusual dims; the dot products are unchanged)
+        if dim > 128:
+            raise NotImplementedError(f'full-catalog scoring supports embed_dim <= 128, got {dim}')
+        pad = (32 if dim < 32 else 64 if dim < 64 else 128) - dim
+        item_table = torch.nn.functional.pad(item_table, (0, pad))
+        query = torch.nn.functional.pad(query, (0, pad))
+        dim += pad
+    table_ptr = ptr(item_table)
+    if items_without_pad:
+        n_items += 1
+        table_ptr = ctypes.c_void_p(item_table.data_ptr() - dim * 4)
     B = query.shape[0]
     scores = torch.empty(B, n_items - 1, dtype=torch.float32, device=dev) if want_scores else None
     lse = torch.empty(B, dtype=torch.float32, device=dev) if want_lse else None
@@ -244,6 +269,19 @@ def fullscore(item_table, query, *, want_scores=False, want_lse=False, k=0):
     ti = torch.empty(B, k, dtype=torch.int64, device=dev) if k else None
     ws_bytes = int(nat.lib().rsa_fullscore_workspace_bytes(B, n_items, int(k)))
     ws = torch.empty(max(ws_bytes, 8), dtype=torch.uint8, device=dev)
-    nat.check(nat.lib().rsa_fullscore(ptr(item_table), n_items, dim, ptr(query), B, ptr(scores), ptr(lse), ptr(tv),
+    nat.check(nat.lib().rsa_fullscore(table_ptr, n_items, dim, ptr(query), B, ptr(scores), ptr(lse), ptr(tv),
                                       ptr(ti), int(k), ptr(ws), ws_bytes, _stream()), 'rsa_fullscore')
     return scores, lse, tv, ti
+
+
+def topk_mask_history(cand_val, cand_idx, user_hist, k):
+    """baseretriever.py:386-392 on sorted candidates: drop history items, keep the k best."""
+    cand_val = _need(cand_val, torch.float32, 'cand_val')
+    cand_idx = _need(cand_idx, torch.int64, 'cand_idx')
+    user_hist = _need(user_hist, torch.int64, 'user_hist')
+    B, kc = cand_val.shape
+    out_v = torch.empty(B, k, dtype=torch.float32, device=cand_val.device)
+    out_i = torch.empty(B, k, dtype=torch.int64, device=cand_val.device)
+    nat.check(nat.lib().rsa_topk_mask_history(ptr(cand_val), ptr(cand_idx), kc, ptr(user_hist), user_hist.shape[1], B,
+                                              int(k), ptr(out_v), ptr(out_i), _stream()), 'rsa_topk_mask_history')
+    return out_v, out_i

@@ -40,11 +40,25 @@ class CosineScorer(InnerProductScorer):
     cosine = True
 
 
+class _FullScoreFn(torch.autograd.Function):
+    """[B, N] = query @ items.T with the fp32-MFMA kernel; the backward GEMMs are plain library
+    GEMMs (rocBLAS through torch.matmul)."""
+
+    @staticmethod
+    def forward(ctx, query, items):
+        ctx.save_for_backward(query, items)
+        return ops.fullscore(items, query, want_scores=True, items_without_pad=True)[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        query, items = ctx.saved_tensors
+        gq = g @ items if ctx.needs_input_grad[0] else None
+        gi = g.t() @ query if ctx.needs_input_grad[1] else None
+        return gq, gi
+
+
 def full_scores(query, items, cosine=False):
-    """[B, N] = query @ items.T through the MFMA full-score kernel (items has no padding row here)."""
-    pad = torch.zeros(1, items.shape[1], dtype=items.dtype, device=items.device)
-    table = torch.cat([pad, items], 0)
-    scores = ops.fullscore(table, query, want_scores=True)[0]
+    """([B,D],[N,D]) case of the scorers (scorer.py:16): items has no padding row here."""
     if cosine:
         raise NotImplementedError('CosineScorer over the full catalog is not implemented in this build')
-    return scores
+    return _FullScoreFn.apply(query, items.contiguous())

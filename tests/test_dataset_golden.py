@@ -1,0 +1,104 @@
+"""CPU: the product loaders (recstudio_amd/dataset.py) against fixtures recorded from the
+reference's TripletDataset / SeqDataset on its bundled ml-100k demo file."""
+import numpy as np
+import pytest
+import torch
+
+from recstudio_amd.dataset import DataSampler, SeqDataset, SortedDataSampler, TripletDataset, synthetic_interactions
+
+
+def seed_everything(seed):
+    """What recstudio.utils.seed_everything does for the host generators (utils.py:374-377)."""
+    import random
+    random.seed(seed)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+
+
+def make(cls, g, **cfg):
+    conf = {'low_rating_thres': 3.0}
+    conf.update(cfg)
+    ds = cls('ml-100k', conf, _interactions=(g['raw_user'].astype(str), g['raw_item'].astype(str),
+                                             g['raw_rating'].astype(np.float64), g['raw_time'].astype(np.float64)))
+    return ds
+
+
+def test_triplet_dataset_matches_reference(golden):
+    g = golden('data_ml100k')
+    seed_everything(2022)
+    ds = make(TripletDataset, g)
+    assert (ds.num_users, ds.num_items) == (int(g['t_num_users']), int(g['t_num_items'])) == (944, 1575)
+    trn, val, tst = ds.build(split_ratio=[0.8, 0.1, 0.1], shuffle=True, split_mode='user_entry')
+    assert trn.num_inters == int(g['t_num_inter'])
+    assert np.array_equal(trn.inter_feat['user_id'].numpy(), g['t_inter_user'])
+    assert np.array_equal(trn.inter_feat['item_id'].numpy(), g['t_inter_item'])     # incl. the seeded per-user shuffle
+    assert np.array_equal(trn.inter_feat['rating'].numpy().astype(np.int8), g['t_inter_rating'])
+    assert np.array_equal(trn.data_index.numpy(), g['t_train_index']) and len(trn) == 66868
+    assert np.array_equal(val.data_index.numpy(), g['t_val_index'])
+    assert np.array_equal(tst.data_index.numpy(), g['t_test_index'])
+    assert np.array_equal(trn.item_freq.numpy(), g['t_item_freq'])
+    assert np.array_equal(trn.user_count.numpy(), g['t_user_count'])
+    assert tuple(trn.user_hist.shape) == tuple(g['t_user_hist_shape'])
+    assert np.array_equal(trn.user_hist[:8].numpy(), g['t_user_hist_head'])
+    assert tuple(tst.user_hist.shape) == tuple(g['t_test_user_hist_shape'])
+    assert np.array_equal(tst.user_hist[:8].numpy(), g['t_test_user_hist_head'])
+    assert np.array_equal(tst.user_count.numpy(), g['t_test_user_count'])
+    trn.drop_feat(trn.use_field)
+    loader = trn.train_loader(batch_size=512, shuffle=False)
+    assert len(loader) == int(g['t_n_train_batches']) == 131
+    for i, b in zip(range(2), loader):
+        assert sorted(b) == ['item_id', 'rating', 'user_id']
+        assert np.array_equal(b['user_id'].numpy(), g[f't_trainbatch{i}_user'])
+        assert np.array_equal(b['item_id'].numpy(), g[f't_trainbatch{i}_item'])
+        assert np.array_equal(b['rating'].numpy(), g[f't_trainbatch{i}_rating']) and b['rating'].dtype == torch.float32
+    ev = val.eval_loader(batch_size=20)
+    assert len(ev) == int(g['t_n_val_batches'])
+    for i, b in zip(range(2), ev):
+        for k in ('user_id', 'item_id', 'rating', 'user_hist'):
+            assert np.array_equal(b[k].numpy(), g[f't_valbatch{i}_{k}']), k
+
+
+def test_seq_dataset_matches_reference(golden):
+    g = golden('data_ml100k')
+    seed_everything(2022)
+    sq = make(SeqDataset, g, max_seq_len=50)
+    strn, sval, stst = sq.build(split_ratio=2, split_mode='user_entry')
+    assert (sq.num_users, sq.num_items, sq.num_inters) == (int(g['s_num_users']), int(g['s_num_items']), int(g['s_num_inter']))
+    assert [len(strn), len(sval), len(stst)] == g['s_sizes'].tolist()
+    assert np.array_equal(strn.inter_feat['item_id'].numpy(), g['s_inter_item'])
+    assert np.array_equal(strn.data_index[:300].numpy(), g['s_train_index_head'])
+    assert np.array_equal(strn.data_index[-300:].numpy(), g['s_train_index_tail'])
+    assert np.array_equal(sval.data_index.numpy(), g['s_val_index'])
+    assert np.array_equal(stst.data_index.numpy(), g['s_test_index'])
+    assert np.array_equal(strn.item_freq.numpy(), g['s_item_freq'])
+    strn.drop_feat(strn.use_field)
+    for i, b in zip(range(2), strn.train_loader(batch_size=64, shuffle=False)):
+        assert sorted(b) == g[f's_trainbatch{i}_keys'].tolist()
+        for k in ('user_id', 'seqlen', 'in_item_id', 'item_id', 'in_rating', 'rating'):
+            assert np.array_equal(b[k].numpy(), g[f's_trainbatch{i}_{k}']), k
+    flat, start, end = strn.segments(torch.arange(5))
+    assert torch.equal(flat[start[3]:end[3]], strn[torch.arange(5)]['in_item_id'][3, :int(end[3] - start[3])])
+
+
+def test_samplers_and_synthetic_stream():
+    class Src:
+        sample_length = torch.tensor([5, 1, 3, 3, 9, 2, 7])
+
+        def __len__(self):
+            return 7
+    torch.manual_seed(3)
+    a = list(DataSampler(Src(), 3, shuffle=True))
+    assert sorted(torch.cat(a).tolist()) == list(range(7)) and [len(x) for x in a] == [3, 3, 1]
+    assert [len(x) for x in DataSampler(Src(), 3, shuffle=False, drop_last=True)] == [3, 3]
+    b = torch.cat(list(SortedDataSampler(Src(), 3)))
+    assert Src.sample_length[b].tolist() == sorted(Src.sample_length.tolist())
+    u, i = synthetic_interactions(50, 200, 5000, seed=2)
+    assert u.min() >= 1 and u.max() <= 50 and i.min() >= 1 and i.max() <= 200
+    u2, i2 = synthetic_interactions(50, 200, 5000, seed=2)
+    assert np.array_equal(i, i2)
+    cnt = np.bincount(i, minlength=201)
+    assert cnt.max() > 20 * np.median(cnt[1:])          # Zipf head
+    ds = TripletDataset.from_interactions(u, i)
+    trn, val, tst = ds.build()
+    assert len(trn) + sum(int(x) for x in (val.data_index[:, 2] - val.data_index[:, 1])) + \
+        sum(int(x) for x in (tst.data_index[:, 2] - tst.data_index[:, 1])) == ds.num_inters
