@@ -12,5 +12,9 @@ from .scorer import InnerProductScorer, CosineScorer              # noqa: F401
 from .loss_func import (FullScoreLoss, PairwiseLoss, PointwiseLoss, BPRLoss,   # noqa: F401
                         SampledSoftmaxLoss, SoftmaxLoss)
 from .fused import retriever_scores                               # noqa: F401
+from .dataset import TripletDataset, SeqDataset, DataSampler, SortedDataSampler   # noqa: F401
+from .retriever import (BaseRetriever, TwoTowerRecommender, ItemTowerRecommender, BPR, SASRec,   # noqa: F401
+                        default_config, seed_everything)
+from . import eval                                                # noqa: F401
 
 __version__ = '0.1.0'

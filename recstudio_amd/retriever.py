@@ -1,0 +1,560 @@
+"""``BaseRetriever`` -- host-side mirror of recstudio/model/basemodel/baseretriever.py (the class the
+reference's READMEs call TwoTowerRecommender / ItemTowerRecommender) with its forward dispatched to
+the fused HIP path.
+
+Kept from the reference: constructor kwargs (``item_encoder``, ``query_encoder``, ``scorer``,
+``sampler``, ``loss``; baseretriever.py:14-43, recommender.py:48-56), the overridable hooks
+(``_get_dataset_class``, ``_get_item_encoder``, ``_get_query_encoder``, ``_get_score_func``,
+``_get_loss_func``, ``_get_sampler``, ``_set_data_field``), ``forward`` with its ``return_*`` flags
+and output dict layout (:142-192), ``sampling`` / ``_sample`` for ``method='none'`` (:204-278),
+``topk`` (:374-397), ``training_step`` / ``validation_step`` / ``test_step`` / ``_test_step``
+(:399-431), ``fit`` / ``evaluate`` and the config keys read on the path.  The train/eval loop around
+it is a minimal compatible one (the reference's Recommender loop is out of scope).
+
+Dispatch rule (mirrors the reference's own check at baseretriever.py:122): the fused kernels are
+used when the item tower is a plain ``nn.Embedding`` over the item id, the scorer is exactly
+InnerProductScorer / CosineScorer, the sampler exactly UniformSampler / PopularSamplerModel (or None
+for full-score losses) and ``sampling_method == 'none'``; anything else goes through the per-plugin
+path (sampler / scorer / loss objects called one by one, like the reference does).
+"""
+import copy
+import inspect
+import logging
+import time
+from typing import Dict
+
+import numpy as np
+import torch
+
+from . import _native as nat
+from . import eval as rs_eval
+from . import ops
+from .dataset import SeqDataset, TripletDataset
+from .fused import retriever_scores
+from .loss_func import BPRLoss, FullScoreLoss, PairwiseLoss, PointwiseLoss, SampledSoftmaxLoss, SoftmaxLoss
+from .sampler import PopularSamplerModel, Sampler, UniformSampler
+from .scorer import CosineScorer, InnerProductScorer
+
+__all__ = ['BaseRetriever', 'TwoTowerRecommender', 'ItemTowerRecommender', 'BPR', 'SASRec', 'default_config',
+           'seed_everything']
+
+
+def default_config():
+    """recstudio/model/basemodel/basemodel.yaml."""
+    return {
+        'data': {'binarized_rating_thres': None, 'fm_eval': False, 'neg_count': 0, 'sampler': None, 'shuffle': True,
+                 'split_mode': 'user_entry', 'split_ratio': [0.8, 0.1, 0.1]},
+        'model': {'embed_dim': 64, 'item_bias': False},
+        'train': {'accelerator': 'gpu', 'ann': None, 'batch_size': 512, 'early_stop_mode': 'max',
+                  'early_stop_patience': 10, 'epochs': 1000, 'gpu': 1, 'grad_clip_norm': None,
+                  'init_method': 'xavier_normal', 'item_batch_size': 1024, 'learner': 'adam', 'learning_rate': 0.001,
+                  'num_threads': 10, 'sampling_method': 'none', 'sampler': 'uniform', 'negative_count': 0,
+                  'excluding_hist': False, 'scheduler': None, 'seed': 2022, 'weight_decay': 0.0,
+                  'tensorboard_path': None, 'sparse_grad': False},
+        'eval': {'batch_size': 128, 'cutoff': [5, 10, 20], 'val_metrics': ['ndcg', 'recall'], 'val_n_epoch': 1,
+                 'test_metrics': ['ndcg', 'recall', 'precision', 'map', 'mrr', 'hit'], 'topk': 100,
+                 'save_path': './saved/'},
+    }
+
+
+def seed_everything(seed):
+    """recstudio/utils/utils.py:334-381: python / numpy / torch CPU + all device generators."""
+    import random
+    random.seed(seed)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    return seed
+
+
+def _init_weights(module, method):
+    """recstudio/model/init.py: xavier_normal / xavier_uniform / normal(0.02); the padding row is zeroed."""
+    if isinstance(module, torch.nn.Embedding):
+        if method == 'xavier_normal':
+            torch.nn.init.xavier_normal_(module.weight.data)
+        elif method == 'xavier_uniform':
+            torch.nn.init.xavier_uniform_(module.weight.data)
+        else:
+            module.weight.data.normal_(mean=0.0, std=0.02)
+        if module.padding_idx is not None:
+            torch.nn.init.constant_(module.weight.data[module.padding_idx], 0.)
+    elif isinstance(module, torch.nn.Linear):
+        if method == 'xavier_normal':
+            torch.nn.init.xavier_normal_(module.weight.data)
+        elif method == 'xavier_uniform':
+            torch.nn.init.xavier_uniform_(module.weight.data)
+        else:
+            module.weight.data.normal_(mean=0.0, std=0.02)
+        if module.bias is not None:
+            torch.nn.init.constant_(module.bias.data, 0)
+    elif isinstance(module, torch.nn.LayerNorm):
+        module.bias.data.zero_()
+        module.weight.data.fill_(1.0)
+
+
+class BaseRetriever(torch.nn.Module):
+    def __init__(self, config: Dict = None, **kwargs):
+        super().__init__()
+        self.config = default_config()
+        if config is not None:
+            for group, values in config.items():
+                if isinstance(values, dict) and group in self.config:
+                    self.config[group].update(values)
+                else:
+                    self.config[group] = values
+        if self.config['train']['seed'] is not None:
+            seed_everything(self.config['train']['seed'])          # recommender.py:34-35
+        self.embed_dim = self.config['model']['embed_dim']
+        self.logged_metrics = {}
+        self.logger = logging.getLogger('recstudio_amd')
+        for key, attr in (('item_encoder', 'item_encoder'), ('query_encoder', 'query_encoder')):
+            if key in kwargs:
+                assert isinstance(kwargs[key], torch.nn.Module), f'{key} must be torch.nn.Module'
+                setattr(self, attr, kwargs[key])
+            else:
+                setattr(self, attr, None)
+        if 'scorer' in kwargs:
+            assert isinstance(kwargs['scorer'], torch.nn.Module), 'scorer must be torch.nn.Module'
+            self.score_func = kwargs['scorer']
+        else:
+            self.score_func = self._get_score_func()
+        if 'sampler' in kwargs:
+            assert isinstance(kwargs['sampler'], Sampler), 'sampler must be recstudio_amd.Sampler'
+            self.sampler = kwargs['sampler']
+        else:
+            self.sampler = None
+        if 'loss' in kwargs:
+            assert isinstance(kwargs['loss'], (FullScoreLoss, PairwiseLoss, PointwiseLoss)), \
+                'loss should be a FullScoreLoss, PairwiseLoss or PointwiseLoss'
+            self.loss_fn = kwargs['loss']
+        else:
+            self.loss_fn = None
+        if self.config['train']['ann'] is not None:
+            raise NotImplementedError('ANN indexes (train.ann) are outside the path this package covers')
+        self.use_index = False
+        self.ckpt_path = None
+
+    # ------------------------------------------------------------------ hooks (reference API)
+    def _get_dataset_class():
+        return TripletDataset
+
+    def _set_data_field(self, data):
+        data.use_field = set([data.fuid, data.fiid, data.frating])
+
+    def _get_item_encoder(self, train_data):
+        return torch.nn.Embedding(train_data.num_items, self.embed_dim, padding_idx=0)
+
+    def _get_query_encoder(self, train_data):
+        if self.fuid in self.query_fields:
+            return torch.nn.Embedding(train_data.num_users, self.embed_dim, padding_idx=0)
+        raise ValueError('query_encoder missing.')
+
+    def _get_score_func(self):
+        return InnerProductScorer()
+
+    def _get_loss_func(self):
+        return None
+
+    def _get_sampler(self, train_data):
+        return UniformSampler(train_data.num_items)
+
+    # ------------------------------------------------------------------ model set-up
+    def _init_model(self, train_data, drop_unused_field=True):
+        self._set_data_field(train_data)
+        self.fields = train_data.use_field
+        self.frating = train_data.frating
+        assert self.frating in self.fields, 'rating field is required.'
+        if drop_unused_field:
+            train_data.drop_feat(self.fields)
+        self.fiid, self.fuid = train_data.fiid, train_data.fuid
+        self.item_fields = {self.fiid} & set(self.fields)
+        assert self.fiid in self.item_fields, 'item id is required to use.'
+        self.query_fields = {self.fuid} & set(self.fields)
+        if isinstance(train_data, SeqDataset):
+            self.query_fields = self.query_fields | {'in_' + f for f in self.item_fields} | {'seqlen'}
+        self.neg_count = self.config['train']['negative_count']
+        if self.loss_fn is None:
+            if 'train_data' in inspect.signature(self._get_loss_func).parameters:
+                self.loss_fn = self._get_loss_func(train_data)
+            else:
+                self.loss_fn = self._get_loss_func()
+        self.item_encoder = self._get_item_encoder(train_data) if not self.item_encoder else self.item_encoder
+        self.query_encoder = self._get_query_encoder(train_data) if not self.query_encoder else self.query_encoder
+        self.sampler = self._get_sampler(train_data) if not self.sampler else self.sampler
+
+    def _init_parameter(self):
+        method = self.config['train']['init_method']
+        for _, module in self.named_children():
+            module.apply(lambda m: _init_weights(m, method))
+
+    def _get_item_feat(self, data):
+        return data[self.fiid] if isinstance(data, dict) else data
+
+    def _get_query_feat(self, data):
+        if isinstance(data, dict):
+            if len(self.query_fields) == 1:
+                return data[list(self.query_fields)[0]]
+            return {f: v for f, v in data.items() if f in self.query_fields}
+        return data
+
+    def _get_item_vector(self):
+        if len(self.item_fields) == 1 and isinstance(self.item_encoder, torch.nn.Embedding):
+            return self.item_encoder.weight[1:]                        # baseretriever.py:122-123
+        raise NotImplementedError('item towers other than nn.Embedding over the item id are not covered')
+
+    def _update_item_vector(self):
+        item_vector = self._get_item_vector()
+        if not hasattr(self, 'item_vector'):
+            self.register_buffer('item_vector', item_vector.detach().clone())
+        else:
+            self.item_vector = item_vector
+
+    # ------------------------------------------------------------------ forward
+    def _fused_ok(self):
+        return (isinstance(self.item_encoder, torch.nn.Embedding) and len(self.item_fields) == 1
+                and type(self.score_func) in (InnerProductScorer, CosineScorer)
+                and (self.sampler is None or type(self.sampler) in (UniformSampler, PopularSamplerModel))
+                and self.config['train'].get('sampling_method', 'none') == 'none')
+
+    def forward(self, batch: Dict, full_score: bool = False, return_query: bool = False, return_item: bool = False,
+                return_neg_item: bool = False, return_neg_id: bool = False):
+        if not self._fused_ok():
+            return self._forward_plugins(batch, full_score, return_query, return_item, return_neg_item, return_neg_id)
+        output = {}
+        pos_items = self._get_item_feat(batch)
+        cosine = isinstance(self.score_func, CosineScorer)
+        query = None
+        if self.sampler is not None:
+            if self.neg_count is None:
+                raise ValueError('`negative_count` value is required when `sampler` is not none.')
+            qfeat = self._get_query_feat(batch)
+            if isinstance(self.query_encoder, torch.nn.Embedding) and isinstance(qfeat, torch.Tensor) \
+                    and qfeat.dim() == 1 and pos_items.dim() == 1 and not return_query:
+                qsrc, qidx = self.query_encoder.weight, qfeat          # user-row gather fused into the kernel
+            else:
+                query = self.query_encoder(qfeat)
+                qsrc, qidx = query.reshape(-1, query.shape[-1]), None
+            lead = tuple(pos_items.shape)
+            score, neg_ids = retriever_scores(
+                self.item_encoder.weight, qsrc, self.neg_count, query_index=qidx, pos_ids=pos_items.reshape(-1),
+                sampler=self.sampler, cosine=cosine, mask_pad_pos=pos_items.dim() > 1,
+                sparse_grad=self.config['train'].get('sparse_grad', False))
+            n = self.neg_count
+            output['score'] = {
+                'pos_score': score['pos_score'].view(lead), 'log_pos_prob': score['log_pos_prob'].view(lead).detach(),
+                'neg_score': score['neg_score'].view(*lead, n), 'log_neg_prob': score['log_neg_prob'].view(*lead, n).detach()}
+            neg_ids = neg_ids.view(*lead, n)
+            if return_neg_item:
+                output['neg_item'] = self.item_encoder(neg_ids)
+            if return_neg_id:
+                output['neg_id'] = neg_ids
+        else:
+            query = self.query_encoder(self._get_query_feat(batch))
+            pos_score = self.score_func(query, self.item_encoder(pos_items))
+            if batch[self.fiid].dim() > 1:
+                pos_score = pos_score.masked_fill(batch[self.fiid] == 0, -float('inf'))
+            output['score'] = {'pos_score': pos_score}
+            if full_score:
+                output['score']['all_score'] = self.score_func(query, self._get_item_vector())
+        if return_query:
+            output['query'] = query
+        if return_item:
+            output['item'] = self.item_encoder(pos_items)
+        return output
+
+    def _forward_plugins(self, batch, full_score, return_query, return_item, return_neg_item, return_neg_id):
+        """baseretriever.py:142-192 step by step: sampler -> item_encoder -> score_func."""
+        output = {}
+        pos_items = self._get_item_feat(batch)
+        pos_item_vec = self.item_encoder(pos_items)
+        if self.sampler is not None:
+            (log_pos_prob, neg_item_idx, log_neg_prob), query = self.sampling(
+                batch=batch, num_neg=self.neg_count, excluding_hist=self.config['train'].get('excluding_hist', False),
+                method=self.config['train'].get('sampling_method', 'none'), return_query=True)
+            pos_score = self.score_func(query, pos_item_vec)
+            if batch[self.fiid].dim() > 1:
+                pos_score = pos_score.masked_fill(batch[self.fiid] == 0, -float('inf'))
+            neg_item_vec = self.item_encoder(self._get_item_feat(neg_item_idx))
+            neg_score = self.score_func(query, neg_item_vec)
+            output['score'] = {'pos_score': pos_score, 'log_pos_prob': log_pos_prob, 'neg_score': neg_score,
+                               'log_neg_prob': log_neg_prob}
+            if return_neg_item:
+                output['neg_item'] = neg_item_vec
+            if return_neg_id:
+                output['neg_id'] = neg_item_idx
+        else:
+            query = self.query_encoder(self._get_query_feat(batch))
+            pos_score = self.score_func(query, pos_item_vec)
+            if batch[self.fiid].dim() > 1:
+                pos_score = pos_score.masked_fill(batch[self.fiid] == 0, -float('inf'))
+            output['score'] = {'pos_score': pos_score}
+            if full_score:
+                output['score']['all_score'] = self.score_func(query, self._get_item_vector())
+        if return_query:
+            output['query'] = query
+        if return_item:
+            output['item'] = pos_item_vec
+        return output
+
+    def _sample(self, batch, neg: int = 1, excluding_hist: bool = False, return_query: bool = True):
+        query = self.query_encoder(self._get_query_feat(batch))
+        pos_items = batch.get(self.fiid, None)
+        user_hist = batch.get('user_hist', batch.get(self.fiid, None)) if excluding_hist else None
+        if not isinstance(self.sampler, Sampler):
+            raise TypeError('`sampler` only support Sampler type.')
+        kwargs = {'num_neg': neg, 'pos_items': pos_items}
+        params = inspect.signature(self.sampler.forward).parameters      # baseretriever.py:225-228
+        if 'excluding_hist' in params:
+            kwargs['excluding_hist'] = excluding_hist
+        if 'user_hist' in params:
+            kwargs['user_hist'] = user_hist
+        kwargs['query'] = query
+        pos_prob, neg_id, neg_prob = self.sampler(**kwargs)
+        return (pos_prob, neg_id, neg_prob, query) if return_query else (pos_prob, neg_id, neg_prob)
+
+    def sampling(self, batch, num_neg, method='none', excluding_hist=False, t=1, return_query=False, query=None):
+        if method != 'none':
+            raise NotImplementedError("only sampling_method='none' (the reference default) is covered")
+        assert self.sampler is not None, 'excepted sampler of retriever to be Sampler, but get None.'
+        n = num_neg[1] if isinstance(num_neg, (list, tuple)) else num_neg
+        log_pos_prob, neg_id, log_neg_prob, query = self._sample(batch, n, excluding_hist, True)
+        log_pos_prob = log_pos_prob.view_as(batch.get(self.fiid))
+        result = (log_pos_prob.detach(), neg_id, log_neg_prob.detach())
+        return (result, query) if return_query else (result, None)
+
+    # ------------------------------------------------------------------ retrieval
+    def topk(self, batch, k, user_h=None, return_query=False):
+        """baseretriever.py:374-397: full-catalog scores -> top (k + |hist|) -> drop history -> top k."""
+        query = self.query_encoder(self._get_query_feat(batch))
+        more = user_h.size(1) if user_h is not None else 0
+        if type(self.score_func) is InnerProductScorer and isinstance(self.item_encoder, torch.nn.Embedding):
+            n_items = self.item_encoder.weight.shape[0]
+            kc = min(k + more, n_items - 1)
+            table = self.item_vector if hasattr(self, 'item_vector') else self._get_item_vector()
+            _, _, score, topk_items = ops.fullscore(table.detach(), query.detach().contiguous(), k=kc,
+                                                    items_without_pad=True)
+        else:
+            score, topk_items = torch.topk(self.score_func(query, self.item_vector), k + more)
+            topk_items = topk_items + 1
+        if user_h is not None:
+            score, topk_items = ops.topk_mask_history(score, topk_items, user_h, min(k, score.shape[1]))
+        return (score, topk_items, query) if return_query else (score, topk_items)
+
+    # ------------------------------------------------------------------ steps
+    def training_step(self, batch):
+        output = self.forward(batch, isinstance(self.loss_fn, FullScoreLoss))
+        score = output['score']
+        score['label'] = batch[self.frating]
+        return self.loss_fn(**score)
+
+    def validation_step(self, batch):
+        cutoff = self.config['eval']['cutoff']
+        cutoff = cutoff[0] if isinstance(cutoff, list) else cutoff
+        return self._test_step(batch, self.config['eval']['val_metrics'], [cutoff])
+
+    def test_step(self, batch):
+        cutoff = self.config['eval']['cutoff']
+        return self._test_step(batch, self.config['eval']['test_metrics'], cutoff if isinstance(cutoff, list) else [cutoff])
+
+    def _test_step(self, batch, metric, cutoffs):
+        rank_m = rs_eval.get_rank_metrics(metric)
+        topk = self.config['eval']['topk']
+        bs = batch[self.frating].size(0)
+        assert len(rank_m) > 0
+        score, topk_items = self.topk(batch, topk, batch['user_hist'])
+        if batch[self.fiid].dim() > 1:
+            target, _ = batch[self.fiid].sort()
+            idx_ = torch.searchsorted(target, topk_items)
+            idx_[idx_ == target.size(1)] = target.size(1) - 1
+            label = torch.gather(target, 1, idx_) == topk_items
+            pos_rating = batch[self.frating]
+        else:
+            label = batch[self.fiid].view(-1, 1) == topk_items
+            pos_rating = batch[self.frating].view(-1, 1)
+        return {f'{name}@{cutoff}': func(label, pos_rating, cutoff) for cutoff in cutoffs for name, func in rank_m}, bs
+
+    # ------------------------------------------------------------------ minimal fit / evaluate loop
+    def _device(self):
+        if not torch.cuda.is_available():
+            raise RuntimeError('recstudio_amd trains on a ROCm GPU only (no CPU fallback)')
+        gpu = self.config['train'].get('gpu', 1)
+        idx = gpu[0] if isinstance(gpu, (list, tuple)) and gpu else 0
+        return torch.device('cuda', int(idx) if isinstance(idx, int) and idx < torch.cuda.device_count() else 0)
+
+    def _get_optimizer(self):
+        tr = self.config['train']
+        name, lr, wd = tr['learner'].lower(), tr['learning_rate'], tr['weight_decay']
+        params = [p for p in self.parameters() if p.requires_grad]
+        if tr.get('sparse_grad', False):
+            return torch.optim.SparseAdam(params, lr=lr) if name == 'adam' else torch.optim.SGD(params, lr=lr)
+        table = {'adam': torch.optim.Adam, 'sgd': torch.optim.SGD, 'adagrad': torch.optim.Adagrad,
+                 'rmsprop': torch.optim.RMSprop}
+        return table.get(name, torch.optim.Adam)(params, lr=lr, weight_decay=wd)
+
+    def _to_device(self, batch, device):
+        return {k: (v.to(device, non_blocking=True) if isinstance(v, torch.Tensor) else v) for k, v in batch.items()}
+
+    def fit(self, train_data, val_data=None, run_mode='light', config: Dict = None, **kwargs):
+        if config is not None:
+            self.config.update(config)
+        self._init_model(train_data)
+        self._init_parameter()
+        device = self._device()
+        self.to(device)
+        if val_data is not None:
+            val_data.use_field = train_data.use_field
+        optimizer = self._get_optimizer()
+        tr = self.config['train']
+        val_metrics = self.config['eval']['val_metrics']
+        cutoff = self.config['eval']['cutoff']
+        cutoff0 = cutoff[0] if isinstance(cutoff, list) else cutoff
+        self.val_metric = f"{(val_metrics[0] if isinstance(val_metrics, list) else val_metrics)}@{cutoff0}"
+        best, best_state, bad = None, None, 0
+        for epoch in range(tr['epochs']):
+            t0 = time.time()
+            self.train()
+            self._update_item_vector()
+            if self.sampler is not None:
+                self.sampler.update(item_embs=self.item_vector)                 # recommender.py:564-570
+            losses = []
+            for batch in train_data.train_loader(batch_size=tr['batch_size'], shuffle=True, drop_last=False):
+                batch = self._to_device(batch, device)
+                optimizer.zero_grad()
+                loss = self.training_step(batch)
+                loss.backward()
+                if tr['grad_clip_norm'] is not None:
+                    torch.nn.utils.clip_grad_norm_(self.parameters(), tr['grad_clip_norm'])
+                optimizer.step()
+                losses.append(loss.detach())
+            log = {'epoch': epoch, 'train_loss': float(torch.stack(losses).mean()), 'train_time': time.time() - t0}
+            if val_data is not None and (epoch + 1) % self.config['eval']['val_n_epoch'] == 0:
+                log.update(self._eval_epoch(val_data, self.validation_step, device))
+                cur = log[self.val_metric]
+                better = best is None or (cur > best if tr['early_stop_mode'] == 'max' else cur < best)
+                if better:
+                    best, best_state, bad = cur, copy.deepcopy(self.state_dict()), 0
+                else:
+                    bad += 1
+            self.logged_metrics = log
+            self.logger.info(' '.join(f'{k}={v:.4f}' if isinstance(v, float) else f'{k}={v}' for k, v in log.items()))
+            if val_data is not None and bad >= tr['early_stop_patience']:
+                break
+        if best_state is not None:
+            self.load_state_dict(best_state)
+        return best
+
+    @torch.no_grad()
+    def _eval_epoch(self, data, step, device):
+        self.eval()
+        self._update_item_vector()
+        total, acc = 0, {}
+        for batch in data.eval_loader(batch_size=self.config['eval']['batch_size']):
+            metrics, bs = step(self._to_device(batch, device))
+            for k, v in metrics.items():
+                acc[k] = acc.get(k, 0.0) + float(v) * bs                       # weighted mean, recommender.py:308-324
+            total += bs
+        return {k: v / max(total, 1) for k, v in acc.items()}
+
+    def evaluate(self, test_data, verbose=True, **kwargs):
+        test_data.use_field = self.fields
+        out = self._eval_epoch(test_data, self.test_step, next(self.parameters()).device)
+        if verbose:
+            self.logger.info(str(out))
+        return out
+
+
+TwoTowerRecommender = BaseRetriever      # README.md:29-31 names
+ItemTowerRecommender = BaseRetriever
+
+
+class BPR(BaseRetriever):
+    """recstudio/model/mf/bpr.py:7-25."""
+
+    def _get_dataset_class():
+        return TripletDataset
+
+    def _get_item_encoder(self, train_data):
+        return torch.nn.Embedding(train_data.num_items, self.embed_dim, padding_idx=0)
+
+    def _get_query_encoder(self, train_data):
+        return torch.nn.Embedding(train_data.num_users, self.embed_dim, padding_idx=0)
+
+    def _get_score_func(self):
+        return InnerProductScorer()
+
+    def _get_loss_func(self):
+        return BPRLoss()
+
+    def _get_sampler(self, train_data):
+        return UniformSampler(train_data.num_items)
+
+
+class _EmbedFn(torch.autograd.Function):
+    """item_encoder(ids) with the HIP gather forward and the HIP row scatter-add backward."""
+
+    @staticmethod
+    def forward(ctx, weight, ids):
+        ctx.save_for_backward(ids)
+        ctx.n_rows = weight.shape[0]
+        return ops.embedding_gather(weight, ids)
+
+    @staticmethod
+    def backward(ctx, g):
+        (ids,) = ctx.saved_tensors
+        d = g.shape[-1]
+        return ops.scatter_add_rows(g.reshape(-1, d).contiguous(), ids.reshape(-1), ctx.n_rows), None
+
+
+class SASRecQueryEncoder(torch.nn.Module):
+    """recstudio/model/seq/sasrec.py:8-67: item-embedding gather of the history (HIP) + learned positions
+    + causal nn.TransformerEncoder (stock PyTorch-ROCm, out of scope) + last-position pooling."""
+
+    def __init__(self, fiid, embed_dim, max_seq_len, n_head, hidden_size, dropout, activation, layer_norm_eps, n_layer,
+                 item_encoder):
+        super().__init__()
+        self.fiid = fiid
+        self.item_encoder = item_encoder
+        self.position_emb = torch.nn.Embedding(max_seq_len, embed_dim)
+        layer = torch.nn.TransformerEncoderLayer(d_model=embed_dim, nhead=n_head, dim_feedforward=hidden_size,
+                                                 dropout=dropout, activation=activation, layer_norm_eps=layer_norm_eps,
+                                                 batch_first=True, norm_first=False)
+        self.transformer_layer = torch.nn.TransformerEncoder(layer, num_layers=n_layer)
+        self.dropout = torch.nn.Dropout(p=dropout)
+
+    def forward(self, batch):
+        user_hist = batch['in_' + self.fiid]
+        B, L = user_hist.shape
+        positions = torch.arange(L, dtype=torch.long, device=user_hist.device).unsqueeze(0).expand(B, L)
+        seq = _EmbedFn.apply(self.item_encoder.weight, user_hist) + self.position_emb(positions)
+        causal = torch.triu(torch.ones(L, L, dtype=torch.bool, device=user_hist.device), 1)
+        out = self.transformer_layer(self.dropout(seq), mask=causal, src_key_padding_mask=user_hist == 0)
+        last = (batch['seqlen'] - 1).clamp(min=0).view(-1, 1, 1).expand(-1, 1, out.shape[-1])
+        return out.gather(1, last).squeeze(1)
+
+
+class SASRec(BaseRetriever):
+    """recstudio/model/seq/sasrec.py:70-123 with the retriever tail on the fused path."""
+
+    def __init__(self, config=None, **kwargs):
+        super().__init__(config, **kwargs)
+        m = self.config['model']
+        for k, v in (('hidden_size', 128), ('layer_num', 2), ('head_num', 2), ('dropout_rate', 0.5),
+                     ('activation', 'gelu'), ('layer_norm_eps', 1e-12)):
+            m.setdefault(k, v)
+
+    def _get_dataset_class():
+        return SeqDataset
+
+    def _get_query_encoder(self, train_data):
+        m = self.config['model']
+        return SASRecQueryEncoder(self.fiid, self.embed_dim, train_data.config['max_seq_len'], m['head_num'],
+                                  m['hidden_size'], m['dropout_rate'], m['activation'], m['layer_norm_eps'],
+                                  m['layer_num'], self.item_encoder)
+
+    def _get_query_feat(self, data):
+        return data if isinstance(data, dict) else super()._get_query_feat(data)
+
+    def _get_loss_func(self):
+        return SampledSoftmaxLoss()
+
+    def _get_sampler(self, train_data):
+        return UniformSampler(train_data.num_items)

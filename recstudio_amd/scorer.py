@@ -14,6 +14,32 @@ from . import ops
 __all__ = ['InnerProductScorer', 'CosineScorer']
 
 
+class _RowScoreFn(torch.autograd.Function):
+    """scores of materialised item vectors [M, n, d] against queries [M, d] through the gather+score
+    kernel (the vectors are addressed as rows 0..M*n-1 of a table).  The backward of this
+    compatibility path is two broadcast products in torch."""
+
+    @staticmethod
+    def forward(ctx, q2, rows, n, cosine):
+        ids = torch.arange(rows.shape[0], device=rows.device, dtype=torch.int64)
+        out = ops.fused_forward(rows, q2, n, neg_ids=ids, sampler=nat.SAMPLER_GIVEN, cosine=cosine,
+                                n_queries=q2.shape[0])['neg_score']
+        ctx.save_for_backward(q2, rows)
+        ctx.n, ctx.cosine = n, cosine
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        if ctx.cosine:
+            raise NotImplementedError('backward of the cosine scorer is not implemented in this build')
+        q2, rows = ctx.saved_tensors
+        M, d = q2.shape
+        r3 = rows.view(M, ctx.n, d)
+        gq = (g.unsqueeze(-1) * r3).sum(1) if ctx.needs_input_grad[0] else None
+        gr = (g.unsqueeze(-1) * q2.unsqueeze(1)).reshape(-1, d) if ctx.needs_input_grad[1] else None
+        return gq, gr, None, None
+
+
 class InnerProductScorer(torch.nn.Module):
     cosine = False
 
@@ -26,11 +52,8 @@ class InnerProductScorer(torch.nn.Module):
                 n = 1
                 lead = items.shape[:-1]
             d = items.shape[-1]
-            q2 = query.reshape(-1, d)
-            rows = items.reshape(-1, d)
-            ids = torch.arange(rows.shape[0], device=rows.device, dtype=torch.int64)
-            out = ops.fused_forward(rows, q2, n, neg_ids=ids, sampler=nat.SAMPLER_GIVEN, cosine=self.cosine,
-                                    n_queries=q2.shape[0])['neg_score']
+            out = _RowScoreFn.apply(query.reshape(-1, d).contiguous(), items.reshape(-1, d).contiguous(), n,
+                                    self.cosine)
             return out.view(*lead, n) if query.dim() < items.dim() else out.view(*lead)
         # ([B,D],[N,D]): full-catalog scores
         return full_scores(query, items, self.cosine)
