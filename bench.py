@@ -160,13 +160,20 @@ def main():
     torch.manual_seed(2022 + rank)       # basemodel.yaml:63 seed
 
     extra = {}
-    if world == 1:
+    force_shard = world == 1 and os.environ.get('RSA_BENCH_FORCE_SHARD') == '1'   # exercise the N>1 branch on one GPU
+    if force_shard:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29533')
+        dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
+    if world == 1 and not force_shard:
         item, user = make_workload(dev, args.items, args.users, d)
         sampler = (ra.PopularSamplerModel(counts) if popular else ra.UniformSampler(args.items)).to(dev)
         kind = nat.SAMPLER_POPULAR if popular else nat.SAMPLER_UNIFORM
         kw = dict(query_index=uid, pos_ids=pos, sampler=kind)
         if popular:
-            kw.update(table=sampler.table, pop_prob=sampler.pop_prob, guide=sampler.guide, guide_log2=sampler.guide_log2)
+            kw.update(table=sampler.table, pop_prob=sampler.pop_prob, guide=sampler.guide, guide_log2=sampler.guide_log2,
+                      table_prob=sampler.table_prob)
         bufs = {}
 
         def fwd(b=B, u=uid, p=pos, key='main'):
@@ -196,7 +203,7 @@ def main():
                     'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': None,
                     'alg_bytes_per_launch': int(alg), 'avg_kernel_ms': round(k_avg, 4),
                     'median_kernel_ms': round(k_ms[len(k_ms) // 2], 4)}
-        pmc = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
+        pmc = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')
         if os.path.exists(pmc):
             try:
                 roofline['traffic'] = json.load(open(pmc)).get('fused_fwd_bytes_per_launch')
@@ -227,6 +234,22 @@ def main():
                 t = time_gpu(st, args.steps, 10) * 1e3
                 sweep[f'B={b2}'] = {'ms_per_step': round(t, 4), 'M_triplets_s': round(b2 * n / t / 1e3, 2)}
             extra['sweep'] = sweep
+        # configs[4]: full-catalog scores on the fp32 MFMA (N = 1e6, d = 128), logsumexp fused, + exact top-100
+        try:
+            del bufs
+            torch.cuda.empty_cache()
+            n5, b5, k5 = 1_000_001, 2048, 100
+            it5 = item[:n5]
+            q5 = user[1:b5 + 1].contiguous()
+            t_lse = time_gpu(lambda: ra.ops.fullscore(it5, q5, want_lse=True), 10, 3) * 1e3
+            t_topk = time_gpu(lambda: ra.ops.fullscore(it5, q5, want_lse=True, k=k5), 5, 2) * 1e3
+            flops = 2.0 * b5 * d * (n5 - 1)
+            extra['fullscore'] = {'workload': f'B={b5} queries x N={n5} items, d={d}, fp32 MFMA (BASELINE.json configs[4])',
+                                  'gemm_lse_ms': round(t_lse, 3), 'gemm_lse_tflops': round(flops / t_lse / 1e9, 1),
+                                  'with_top100_ms': round(t_topk, 3), 'peak_tflops_fp32_matrix': 157.3,
+                                  'frac_of_peak': round(flops / t_lse / 1e9 / 157.3, 3)}
+        except Exception as e:
+            extra['fullscore'] = {'error': repr(e)[:200]}
         value = B * n / ms_step / 1e3
         parallelism = 'single'
         workload = (f'BPR two-tower d={d}, synthetic {args.items} items / {args.users} users / 1e8-interaction Zipf '

@@ -33,7 +33,7 @@ class FusedArgs(Structure):
         ('seed', c_uint64), ('offset', c_uint64), ('grid_threads', c_uint32), ('_pad', c_uint32),
         ('table', c_void_p), ('pop_prob', c_void_p), ('guide', c_void_p),
         ('neg_ids', c_void_p), ('neg_logp', c_void_p), ('pos_logp', c_void_p),
-        ('pos_score', c_void_p), ('neg_score', c_void_p),
+        ('pos_score', c_void_p), ('neg_score', c_void_p), ('table_prob', c_void_p),
     ]
 
 

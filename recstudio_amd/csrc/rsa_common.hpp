@@ -100,6 +100,7 @@ __device__ __forceinline__ float torch_rand_element(const PhiloxCall& pc, uint64
 // ---------------------------------------------------------------- inverse-CDF lookup
 // First index i in [0, n_items) with table[i] >= u, found inside the cut-point
 // bucket [guide[b], guide[b+1]] of b = floor(u * 2^guide_log2); clamped to n_items-1.
+template <int STRIDE = 1>
 __device__ __forceinline__ int32_t cdf_lower_bound(const float* __restrict__ table,
                                                    const int32_t* __restrict__ guide, int64_t n_items,
                                                    int guide_log2, float u) {
@@ -109,7 +110,7 @@ __device__ __forceinline__ int32_t cdf_lower_bound(const float* __restrict__ tab
   int32_t lo = guide[b], hi = guide[b + 1];   // answer in [lo, hi]
   while (lo < hi) {
     const int32_t mid = lo + ((hi - lo) >> 1);
-    if (table[mid] < u) lo = mid + 1; else hi = mid;
+    if (table[(size_t)mid * STRIDE] < u) lo = mid + 1; else hi = mid;
   }
   return lo > (int32_t)(n_items - 1) ? (int32_t)(n_items - 1) : lo;
 }

@@ -29,6 +29,7 @@ struct FwdParams {
   const int64_t* pos_ids;
   const float* table;
   const float* pop_prob;
+  const float* table_prob;
   const int32_t* guide;
   int64_t* neg_ids;
   float* neg_logp;
@@ -197,9 +198,15 @@ __global__ __launch_bounds__(256) void fused_fwd_kernel(const FwdParams p) {
         p.neg_ids[e] = id;
       } else if (p.sampler == RSA_SAMPLER_POPULAR) {
         const float u = torch_rand_element(p.pc, (uint64_t)e);
-        id = cdf_lower_bound(p.table, p.guide, p.n_items, p.guide_log2, u);
-        p.neg_ids[e] = id;
-        if (p.neg_logp) p.neg_logp[e] = logf(p.pop_prob[id]);
+        if (p.table_prob) {   // interleaved {cdf, prob}: the search and the log-prob share cache lines
+          id = cdf_lower_bound<2>(p.table_prob, p.guide, p.n_items, p.guide_log2, u);
+          p.neg_ids[e] = id;
+          if (p.neg_logp) p.neg_logp[e] = logf(p.table_prob[2 * (size_t)id + 1]);
+        } else {
+          id = cdf_lower_bound<1>(p.table, p.guide, p.n_items, p.guide_log2, u);
+          p.neg_ids[e] = id;
+          if (p.neg_logp) p.neg_logp[e] = logf(p.pop_prob[id]);
+        }
       } else {
         int64_t g = p.neg_ids[e];
         g = g < 0 ? 0 : (g >= p.n_items ? p.n_items - 1 : g);   // clamp: never fault on a bad id
@@ -336,6 +343,7 @@ extern "C" int rsa_fused_sample_gather_score(const rsa_fused_args* a, rsa_stream
   p.pos_ids = a->pos_ids;
   p.table = a->table;
   p.pop_prob = a->pop_prob;
+  p.table_prob = a->table_prob;
   p.guide = a->guide;
   p.neg_ids = a->neg_ids;
   p.neg_logp = a->neg_logp;

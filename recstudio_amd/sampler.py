@@ -97,6 +97,11 @@ class PopularSamplerModel(Sampler):
             self.pop_prob[-1] = 1.0                                       # sampler.py:241
             guide, self.guide_log2 = build_guide_table(self.table, guide_log2)
             self.register_buffer('guide', guide)
+            self._register_pairs()
+
+    def _register_pairs(self):
+        # interleaved {table[i], pop_prob[i]} copy for the fused kernel (not part of the reference's state)
+        self.register_buffer('table_prob', torch.stack([self.table, self.pop_prob], 1).contiguous(), persistent=False)
 
     @classmethod
     def from_tables(cls, pop_prob, table, guide_log2=None):
@@ -108,6 +113,7 @@ class PopularSamplerModel(Sampler):
         self.register_buffer('table', table.detach().clone().to(torch.float32))
         guide, self.guide_log2 = build_guide_table(self.table, guide_log2)
         self.register_buffer('guide', guide.to(self.table.device))
+        self._register_pairs()
         return self
 
     def forward(self, query, num_neg, pos_items=None):
