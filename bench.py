@@ -180,25 +180,30 @@ def main():
             bufs[key] = ra.ops.fused_forward(item, user, n, out=bufs.get(key), **dict(kw, query_index=u, pos_ids=p))
             return bufs[key]
 
-        def step():
+        def step():          # sample + gather + score + BPR loss (value and d loss/d score): one kernel + the mean
+            bufs['step'] = ra.ops.fused_forward(item, user, n, out=bufs.get('step'), fused_bpr=True, **kw)
+            return bufs['step']
+
+        def step_unfused():  # the same with the loss as its own kernel
             o = fwd()
             return ra.ops.pairwise_loss(nat.LOSS_BPR, o['pos_score'], o['neg_score'], want_grad=True)
 
         ms_step = time_gpu(step, args.steps, args.warmup) * 1e3
+        extra['unfused_loss_ms_per_step'] = round(time_gpu(step_unfused, args.steps, args.warmup) * 1e3, 4)
 
         # dominant kernel alone, timed with events on the launch stream
         evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
         torch.cuda.synchronize()
-        for a, b in evs:
+        for a, b in evs:      # exactly one launch between the events: the fused kernel (no mean reduction)
             a.record()
-            fwd()
+            bufs['step'] = ra.ops.fused_forward(item, user, n, out=bufs['step'], fused_bpr=True, want_mean=False, **kw)
             b.record()
         torch.cuda.synchronize()
         k_ms = sorted(a.elapsed_time(b) for a, b in evs)
         k_avg = sum(k_ms) / len(k_ms)
         alg = bytes_per_triplet(d, n, popular) * B * n
         achieved = alg / (k_avg * 1e-3) / 1e9
-        roofline = {'bound': 'hbm', 'kernel': 'rsa::fused_fwd_kernel<32,false,false,true>',
+        roofline = {'bound': 'hbm', 'kernel': 'rsa::fused_fwd_kernel<32,false,false,true,true> (sample+gather+score+BPR epilogue)',
                     'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                     'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': None,
                     'alg_bytes_per_launch': int(alg), 'avg_kernel_ms': round(k_avg, 4),
@@ -212,10 +217,9 @@ def main():
 
         # training step: forward + loss + row-sparse gradient scatter (+ user-row gradient)
         def train():
-            o = fwd()
-            loss, dpos, dneg, _ = ra.ops.pairwise_loss(nat.LOSS_BPR, o['pos_score'], o['neg_score'])
-            return ra.ops.fused_backward(item, user, o['neg_ids'], dneg, query_index=uid, pos_ids=pos, dpos=dpos,
-                                         dense_item_grad=False, row_item_grad=True, want_query_grad=True)
+            o = step()
+            return ra.ops.fused_backward(item, user, o['neg_ids'], o['dneg'], query_index=uid, pos_ids=pos,
+                                         dpos=o['dpos'], dense_item_grad=False, row_item_grad=True, want_query_grad=True)
         try:
             ms_train = time_gpu(train, max(10, args.steps // 4), 5) * 1e3
             extra['train_step'] = {'ms_per_step': round(ms_train, 4), 'value': round(B * n / ms_train / 1e3, 2),

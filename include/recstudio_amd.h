@@ -6,7 +6,8 @@
  * is a DEVICE pointer unless stated otherwise, `stream` is a hipStream_t
  * passed as void*.  Every entry point returns 0 on success or a negative
  * rsa_status; rsa_last_error() returns the thread-local message of the last
- * failure.  No entry point allocates, frees or synchronises.
+ * failure.  No entry point synchronises or allocates caller-visible memory (the library keeps one
+ * 1 KB device scratch for deterministic partial sums, allocated on first use).
  *
  * The reference (ustcml/RecStudio) is pure Python on PyTorch; it has no native
  * boundary of its own.  Each entry point below therefore replaces a SEQUENCE
@@ -130,6 +131,13 @@ typedef struct rsa_fused_args {
   const float* table_prob;     /* nullable [n_items][2]: interleaved copy {table[i], pop_prob[i]}.  When given,
                                   the CDF probes and the log-prob read share cache lines (one Infinity-Cache
                                   round trip fewer per sampled id); results are identical. */
+  int32_t fused_loss;          /* 0 = none; 1 = BPRLoss (loss_func.py:55-59) evaluated in the kernel's epilogue:
+                                  needs num_neg % 64 == 0, pos_ids, pos_score.  Outputs below. */
+  int32_t _pad2;
+  float* row_loss;             /* [M] out: per-query loss */
+  float* loss_out;             /* nullable [1] out: mean over queries (deterministic; rsa_mean_rows) */
+  float* dpos;                 /* nullable [M] out: d loss_out / d pos_score */
+  float* dneg;                 /* nullable [M, n] out: d loss_out / d neg_score */
 } rsa_fused_args;
 
 int rsa_fused_sample_gather_score(const rsa_fused_args* args, rsa_stream_t stream);
@@ -143,6 +151,9 @@ int rsa_fused_sample_gather_score(const rsa_fused_args* args, rsa_stream_t strea
 int rsa_pairwise_loss(int32_t loss_kind, const float* pos_score, const float* neg_score,
                       const float* pos_logp, const float* neg_logp, int64_t n_rows, int32_t num_neg,
                       float* row_loss, float* loss_out, float* dpos, float* dneg, rsa_stream_t stream);
+
+/* out[0] = mean(row_loss[0..n_rows)) in a fixed summation order (two tiny launches). */
+int rsa_mean_rows(const float* row_loss, int64_t n_rows, float* out, rsa_stream_t stream);
 
 /* SoftmaxLoss.forward on a MATERIALISED score matrix -- recstudio/model/loss_func.py:41:
  * lse[m] = logsumexp(x[m, :]); softmax_scaled (nullable) [n_rows, n_cols] = softmax(x) * scale

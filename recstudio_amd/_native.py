@@ -34,6 +34,8 @@ class FusedArgs(Structure):
         ('table', c_void_p), ('pop_prob', c_void_p), ('guide', c_void_p),
         ('neg_ids', c_void_p), ('neg_logp', c_void_p), ('pos_logp', c_void_p),
         ('pos_score', c_void_p), ('neg_score', c_void_p), ('table_prob', c_void_p),
+        ('fused_loss', c_int32), ('_pad2', c_int32), ('row_loss', c_void_p), ('loss_out', c_void_p),
+        ('dpos', c_void_p), ('dneg', c_void_p),
     ]
 
 
@@ -63,6 +65,7 @@ SIGNATURES = {
     'rsa_fused_sample_gather_score': (c_int, [POINTER(FusedArgs), c_void_p]),
     'rsa_pairwise_loss': (c_int, [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p,
                                   c_void_p, c_void_p, c_void_p, c_void_p]),
+    'rsa_mean_rows': (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
     'rsa_row_lse': (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_float, c_void_p]),
     'rsa_fused_backward': (c_int, [POINTER(BackwardArgs), c_void_p]),
     'rsa_scatter_add_rows': (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_int64, c_void_p]),

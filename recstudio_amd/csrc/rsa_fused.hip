@@ -36,6 +36,9 @@ struct FwdParams {
   float* pos_logp;
   float* pos_score;
   float* neg_score;
+  float* row_loss;   // fused BPR epilogue (nullable): per-query loss, d loss/d pos, d loss/d neg
+  float* dpos;
+  float* dneg;
   int64_t n_items, n_query_rows, n_queries, numel;
   PhiloxCall pc;
   int32_t dim, num_neg, sampler, mask_pad_pos, guide_log2;
@@ -175,8 +178,11 @@ __device__ __forceinline__ float finish_score(bool cos, float dot, float inorm2,
   return cos ? (dot / sqrtf(inorm2)) / sqrtf(qnorm2) : dot;
 }
 
+#ifndef RSA_FWD_MIN_WAVES
+#define RSA_FWD_MIN_WAVES 1
+#endif
 template <int LPR, bool GENERIC, bool COS, bool QU, bool NT>
-__global__ __launch_bounds__(256) void fused_fwd_kernel(const FwdParams p) {
+__global__ __launch_bounds__(256, RSA_FWD_MIN_WAVES) void fused_fwd_kernel(const FwdParams p) {
   using F = Frag<LPR, GENERIC>;
   const int lane = lane_id();
   const int sub = lane % LPR;
@@ -189,6 +195,19 @@ __global__ __launch_bounds__(256) void fused_fwd_kernel(const FwdParams p) {
   for (int64_t tile = wave0; tile < n_tiles; tile += wstride) {
     const int64_t e = (tile << 6) + lane;
     const int act = e < p.numel;
+
+    // ---- 0. (query-uniform path) the two scalar loads everything else hangs off -- query row index and
+    // positive id -- are issued first so that their latency hides under the sampling chain below
+    int64_t m_lane = 0, qrow_u = 0, pid_u = 0;
+    bool want_pos = false, first = false, pad = false;
+    if constexpr (QU) {
+      m_lane = (tile << 6) / n;   // wave-uniform: n % 64 == 0
+      first = (tile << 6) % n == 0;
+      qrow_u = p.query_index ? p.query_index[m_lane] : m_lane;
+      want_pos = p.pos_ids != nullptr && (p.pos_score != nullptr || p.pos_logp != nullptr) &&
+                 (first || p.row_loss != nullptr);
+      if (want_pos) pid_u = p.pos_ids[m_lane];
+    }
 
     // ---- 1. the id of element e (lane-parallel: one Philox / one CDF search per lane)
     int32_t id = 0;
@@ -214,20 +233,22 @@ __global__ __launch_bounds__(256) void fused_fwd_kernel(const FwdParams p) {
       }
     }
 
-    // ---- 2. which query each element belongs to
-    F qf;
+    // ---- 2. query fragment (and, query-uniform path, the positive row): loads issued back to back here,
+    // consumed after the negative rows are in flight
+    F qf, px;
     int32_t qrow_lane = 0;
-    int64_t m_lane = 0;
     float qn2_u = 0.f;
     if constexpr (QU) {
-      m_lane = (tile << 6) / n;   // wave-uniform: n % 64 == 0
-      const int64_t qrow = p.query_index ? p.query_index[m_lane] : m_lane;
-      frag_load<LPR, GENERIC>(qf, p.query + (size_t)qrow * D, sub, D);
+      frag_load<LPR, GENERIC>(qf, p.query + (size_t)qrow_u * D, sub, D);
+      pad = pid_u == 0;
+      pid_u = pid_u < 0 ? 0 : (pid_u >= p.n_items ? p.n_items - 1 : pid_u);
+      frag_load<LPR, GENERIC>(px, p.item_table + (size_t)pid_u * D, sub, D);   // row 0 when there is no positive
       if constexpr (COS) qn2_u = group_sum<LPR>(frag_dot<LPR, GENERIC>(qf, qf));
     } else {
       m_lane = act ? e / n : 0;
       qrow_lane = (int32_t)(p.query_index ? (act ? p.query_index[m_lane] : 0) : m_lane);
       frag_load<LPR, GENERIC>(qf, p.query, sub, D);   // unused in this path
+      px = qf;
     }
 
     // ---- 3. negatives: gather + dot
@@ -236,24 +257,46 @@ __global__ __launch_bounds__(256) void fused_fwd_kernel(const FwdParams p) {
     if constexpr (COS && QU) qn2 = qn2_u;
     if (act) p.neg_score[e] = finish_score(COS, dot, in2, qn2);
 
-    // ---- 4. positives
+    // ---- 4. positives (+ the fused BPR epilogue: every tile of a query needs the positive score)
+    const float neg_s = finish_score(COS, dot, in2, qn2);
     if (p.pos_ids != nullptr && (p.pos_score != nullptr || p.pos_logp != nullptr)) {
       if constexpr (QU) {
-        if ((tile << 6) % n == 0) {   // first tile of the query (wave-uniform)
-          int64_t pid = p.pos_ids[m_lane];
-          const bool pad = pid == 0;
-          pid = pid < 0 ? 0 : (pid >= p.n_items ? p.n_items - 1 : pid);
+        const bool fuse = p.row_loss != nullptr;
+        if (want_pos) {
+          const int64_t pid = pid_u;
+          float s = 0.f;
           if (p.pos_score) {
-            F x;
-            frag_load<LPR, GENERIC>(x, p.item_table + (size_t)pid * D, sub, D);
+            const F& x = px;
             float pd = group_sum<LPR>(frag_dot<LPR, GENERIC>(x, qf));
             float pi2 = 1.f;
             if constexpr (COS) pi2 = group_sum<LPR>(frag_dot<LPR, GENERIC>(x, x));
-            float s = finish_score(COS, pd, pi2, qn2_u);
+            s = finish_score(COS, pd, pi2, qn2_u);
             if (p.mask_pad_pos && pad) s = -INFINITY;
-            if (lane == 0) p.pos_score[m_lane] = s;
+            if (first && lane == 0) p.pos_score[m_lane] = s;
           }
-          if (p.pos_logp && lane == 0) p.pos_logp[m_lane] = logf(p.pop_prob[pid]);
+          if (first && p.pos_logp && lane == 0) p.pos_logp[m_lane] = logf(p.pop_prob[pid]);
+          if (fuse) {
+            // BPRLoss (loss_func.py:55-59): -mean_m (1/n) sum_j logsigmoid(pos - neg_j), with its gradient
+            const float w = 1.f / (float)n, inv_m = 1.f / (float)p.n_queries;
+            // one hardware exp + one log per element: t = exp(-|x|) serves logsigmoid and sigmoid(-x)
+            // (absolute error ~1e-7 on terms of O(1), far inside the 1e-4 contract)
+            const float xd = s - neg_s;
+            const float t = __expf(-fabsf(xd));
+            const float r = __frcp_rn(1.f + t);
+            const float ls = fminf(xd, 0.f) - __logf(1.f + t);
+            const float sg = (xd >= 0.f ? t * r : r) * w * inv_m;
+            if (p.dneg) p.dneg[e] = sg;
+            const float tl = group_sum<64>(ls * w), tg = group_sum<64>(sg);
+            if (lane == 0) {
+              if (n == 64) {   // one tile per query: plain stores, deterministic
+                p.row_loss[m_lane] = -tl;
+                if (p.dpos) p.dpos[m_lane] = -tg;
+              } else {         // several tiles per query: accumulate (buffers zeroed by the host wrapper)
+                atomicAdd(p.row_loss + m_lane, -tl);
+                if (p.dpos) atomicAdd(p.dpos + m_lane, -tg);
+              }
+            }
+          }
         }
       } else {
         const int owner = act && (e - m_lane * n == 0);
@@ -350,6 +393,9 @@ extern "C" int rsa_fused_sample_gather_score(const rsa_fused_args* a, rsa_stream
   p.pos_logp = a->pos_logp;
   p.pos_score = a->pos_score;
   p.neg_score = a->neg_score;
+  p.row_loss = nullptr;
+  p.dpos = nullptr;
+  p.dneg = nullptr;
   p.n_items = a->n_items;
   p.n_query_rows = a->n_query_rows;
   p.n_queries = a->n_queries;
@@ -372,6 +418,25 @@ extern "C" int rsa_fused_sample_gather_score(const rsa_fused_args* a, rsa_stream
   }
   p.numel = numel;
   const bool qu = (a->num_neg % 64) == 0;
+  if (a->fused_loss == RSA_LOSS_BPR + 1) {
+    RSA_CHECK_ARG(qu && a->pos_ids && a->pos_score && a->row_loss,
+                  "rsa_fused_sample_gather_score: the fused BPR epilogue needs num_neg %% 64 == 0, pos_ids, pos_score "
+                  "and row_loss");
+    p.row_loss = a->row_loss;
+    p.dpos = a->dpos;
+    p.dneg = a->dneg;
+    if (a->num_neg != 64) {
+      hipError_t e1 = hipMemsetAsync(a->row_loss, 0, sizeof(float) * a->n_queries, s);
+      hipError_t e2 = a->dpos ? hipMemsetAsync(a->dpos, 0, sizeof(float) * a->n_queries, s) : hipSuccess;
+      if (e1 != hipSuccess || e2 != hipSuccess) {
+        rsa::set_error("rsa_fused_sample_gather_score: memset failed");
+        return RSA_ERR_HIP;
+      }
+    }
+  } else if (a->fused_loss != 0) {
+    rsa::set_error("rsa_fused_sample_gather_score: fused_loss=%d not supported (0 = none, 1 = BPR)", a->fused_loss);
+    return RSA_ERR_UNSUPPORTED;
+  }
   switch (a->dim) {
     case 32: rc = launch_fwd<8, false>(p, cos, qu, s); break;
     case 64: rc = launch_fwd<16, false>(p, cos, qu, s); break;
@@ -379,5 +444,6 @@ extern "C" int rsa_fused_sample_gather_score(const rsa_fused_args* a, rsa_stream
     case 256: rc = launch_fwd<64, false>(p, cos, qu, s); break;
     default: rc = launch_fwd<64, true>(p, cos, qu, s); break;
   }
+  if (rc == RSA_OK && p.row_loss != nullptr && a->loss_out != nullptr) rc = rsa_mean_rows(a->row_loss, a->n_queries, a->loss_out, stream);
   return rc;
 }

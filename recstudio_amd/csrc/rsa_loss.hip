@@ -84,20 +84,30 @@ __global__ __launch_bounds__(256) void pairwise_loss_kernel(int kind, const floa
   }
 }
 
-// loss_out[0] = sum(row_loss) / M, fixed summation order.
-__global__ __launch_bounds__(1024) void mean_rows_kernel(const float* __restrict__ row_loss, int64_t M,
-                                                         float* __restrict__ out) {
-  __shared__ float part[16];
+// loss_out[0] = sum(row_loss) / M in a fixed order: up to 256 workgroups each sum one contiguous chunk
+// (kernel 1), one workgroup sums the partials (kernel 2).
+__global__ __launch_bounds__(256) void mean_rows_stage1(const float* __restrict__ row_loss, int64_t M, int64_t chunk,
+                                                        float* __restrict__ partial) {
+  __shared__ float part[4];
+  const int64_t lo = (int64_t)blockIdx.x * chunk;
+  int64_t hi = lo + chunk;
+  if (hi > M) hi = M;
   float acc = 0.f;
-  for (int64_t i = threadIdx.x; i < M; i += 1024) acc += row_loss[i];
+  for (int64_t i = lo + threadIdx.x; i < hi; i += 256) acc += row_loss[i];
   acc = group_sum<64>(acc);
   if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
   __syncthreads();
-  if (threadIdx.x < 64) {
-    float v = threadIdx.x < 16 ? part[threadIdx.x] : 0.f;
-    v = group_sum<64>(v);
-    if (threadIdx.x == 0) out[0] = v / (float)M;
-  }
+  if (threadIdx.x == 0) partial[blockIdx.x] = (part[0] + part[1]) + (part[2] + part[3]);
+}
+
+__global__ __launch_bounds__(256) void mean_rows_stage2(const float* __restrict__ partial, int n_part, int64_t M,
+                                                        float* __restrict__ out) {
+  __shared__ float part[4];
+  float acc = threadIdx.x < n_part ? partial[threadIdx.x] : 0.f;
+  acc = group_sum<64>(acc);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) out[0] = ((part[0] + part[1]) + (part[2] + part[3])) / (float)M;
 }
 
 // lse[m] = logsumexp(x[m, :]); optionally grad[m, :] = softmax(x[m, :]) * scale.  One workgroup per row.
@@ -142,6 +152,29 @@ extern "C" int rsa_row_lse(const float* x, int64_t n_rows, int64_t n_cols, float
   return RSA_OK;
 }
 
+// Deterministic mean of n_rows floats.  The <= 256 stage-1 partials live in a 1 KB device scratch the
+// library allocates once (the ABI passes no workspace for this); calls on different streams must
+// not overlap (the Python binding issues everything on torch's current stream).
+static float* g_partials = nullptr;
+
+extern "C" int rsa_mean_rows(const float* row_loss, int64_t n_rows, float* out, rsa_stream_t stream) {
+  RSA_CHECK_ARG(row_loss && out && n_rows >= 1, "rsa_mean_rows: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  if (g_partials == nullptr) {   // one-time 1 KB scratch (the only allocation the library ever makes)
+    if (hipMalloc(&g_partials, 256 * sizeof(float)) != hipSuccess) {
+      rsa::set_error("rsa_mean_rows: could not allocate the 1 KB partial-sum scratch");
+      return RSA_ERR_HIP;
+    }
+  }
+  int blocks = (int)((n_rows + 1023) / 1024);
+  if (blocks > 256) blocks = 256;
+  const int64_t chunk = (n_rows + blocks - 1) / blocks;
+  hipLaunchKernelGGL(mean_rows_stage1, dim3(blocks), dim3(256), 0, s, row_loss, n_rows, chunk, g_partials);
+  hipLaunchKernelGGL(mean_rows_stage2, dim3(1), dim3(256), 0, s, g_partials, blocks, n_rows, out);
+  RSA_CHECK_LAUNCH("rsa_mean_rows");
+  return RSA_OK;
+}
+
 extern "C" int rsa_pairwise_loss(int32_t loss_kind, const float* pos_score, const float* neg_score,
                                  const float* pos_logp, const float* neg_logp, int64_t n_rows, int32_t num_neg,
                                  float* row_loss, float* loss_out, float* dpos, float* dneg, rsa_stream_t stream) {
@@ -165,7 +198,5 @@ extern "C" int rsa_pairwise_loss(int32_t loss_kind, const float* pos_score, cons
   }
 #undef RSA_LAUNCH_LOSS
   RSA_CHECK_LAUNCH("rsa_pairwise_loss");
-  hipLaunchKernelGGL(mean_rows_kernel, dim3(1), dim3(1024), 0, s, row_loss, n_rows, loss_out);
-  RSA_CHECK_LAUNCH("rsa_pairwise_loss(mean)");
-  return RSA_OK;
+  return rsa_mean_rows(row_loss, n_rows, loss_out, stream);
 }

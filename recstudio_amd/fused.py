@@ -115,6 +115,71 @@ def retriever_scores(item_weight, query_src, num_neg, *, query_index=None, pos_i
     return score, out['neg_ids']
 
 
+class _FusedBPRFn(torch.autograd.Function):
+    """forward + BPRLoss in ONE kernel launch (loss evaluated in the epilogue, d loss/d score kept),
+    backward = one rsa_fused_backward launch.  == BaseRetriever.training_step with BPRLoss
+    (baseretriever.py:399-404, loss_func.py:55-59)."""
+
+    @staticmethod
+    def forward(ctx, item_weight, query_src, cfg):
+        out = ops.fused_forward(item_weight, query_src, cfg['num_neg'], query_index=cfg.get('query_index'),
+                                pos_ids=cfg['pos_ids'], sampler=cfg['sampler'], neg_ids=cfg.get('neg_ids'),
+                                table=cfg.get('table'), pop_prob=cfg.get('pop_prob'), guide=cfg.get('guide'),
+                                guide_log2=cfg.get('guide_log2', 0), table_prob=cfg.get('table_prob'),
+                                n_queries=cfg['n_queries'], want_logp=False, fused_bpr=True)
+        cfg['out'] = out
+        ctx.cfg = cfg
+        ctx.save_for_backward(item_weight, query_src, out['neg_ids'], out['dpos'], out['dneg'])
+        return out['loss']
+
+    @staticmethod
+    def backward(ctx, g):
+        cfg = ctx.cfg
+        item_weight, query_src, neg_ids, dpos, dneg = ctx.saved_tensors
+        qi, pos_ids, sparse = cfg.get('query_index'), cfg['pos_ids'], cfg.get('sparse_grad', False)
+        need_item, need_q = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        item_grad, rows, qgrad = ops.fused_backward(
+            item_weight, query_src, neg_ids, dneg, query_index=qi, pos_ids=pos_ids, dpos=dpos,
+            upstream=g.reshape(1).contiguous(), dense_item_grad=need_item and not sparse,
+            row_item_grad=need_item and sparse, want_query_grad=need_q)
+        g_item = g_q = None
+        if need_item:
+            if sparse:
+                M, n = neg_ids.shape
+                idx = torch.cat([pos_ids.view(M, 1), neg_ids], 1).reshape(1, -1)
+                g_item = torch.sparse_coo_tensor(idx, rows, item_weight.shape)
+            else:
+                g_item = item_grad
+        if need_q:
+            if qi is None:
+                g_q = qgrad
+            elif sparse:
+                g_q = torch.sparse_coo_tensor(qi.view(1, -1), qgrad, query_src.shape)
+            else:
+                g_q = ops.scatter_add_rows(qgrad, qi, query_src.shape[0])
+        return g_item, g_q, None
+
+
+def fused_bpr_loss(item_weight, query_src, num_neg, *, query_index=None, pos_ids, sampler=None, neg_ids=None,
+                   sparse_grad=False):
+    """BPR training loss through the single-launch fused path (num_neg % 64 == 0).  Returns
+    (loss, neg_ids)."""
+    M = query_index.numel() if query_index is not None else query_src.shape[0]
+    cfg = {'num_neg': int(num_neg), 'query_index': query_index, 'pos_ids': pos_ids, 'sparse_grad': sparse_grad,
+           'n_queries': M}
+    kind = _sampler_kind(sampler) if sampler is not None else nat.SAMPLER_GIVEN
+    if kind is None:
+        raise TypeError(f'fused path does not cover sampler {type(sampler).__name__}')
+    cfg['sampler'] = kind
+    if kind == nat.SAMPLER_GIVEN:
+        cfg['neg_ids'] = neg_ids.reshape(M, -1)
+    elif kind == nat.SAMPLER_POPULAR:
+        cfg.update(table=sampler.table, pop_prob=sampler.pop_prob, guide=sampler.guide, guide_log2=sampler.guide_log2,
+                   table_prob=getattr(sampler, 'table_prob', None))
+    loss = _FusedBPRFn.apply(item_weight, query_src, cfg)
+    return loss, cfg['out']['neg_ids']
+
+
 def train_step_no_autograd(item_weight, query_src, num_neg, loss_kind, *, query_index, pos_ids, sampler=None,
                            neg_ids=None, sparse_grad=True, want_user_grad=True):
     """sample+gather+score -> loss(+dscore) -> scatter-add, three launches, no autograd graph.

@@ -123,13 +123,15 @@ def seg_gather(item_table, flat_item_ids, seg_start, seg_end, max_len, want_rows
 def fused_forward(item_table, query, num_neg, *, query_index=None, pos_ids=None, neg_ids=None,
                   sampler=nat.SAMPLER_GIVEN, cosine=False, mask_pad_pos=False,
                   table=None, pop_prob=None, guide=None, guide_log2=0, generator=None, n_queries=None,
-                  out=None, want_logp=True, table_prob=None):
+                  out=None, want_logp=True, table_prob=None, fused_bpr=False, want_mean=True):
     """One launch of rsa_fused_sample_gather_score.  Returns a dict with
     neg_ids [M,n] int64, neg_score [M,n], pos_score [M] (if pos_ids), and for the
     popularity sampler neg_logp [M,n], pos_logp [M].  ``out``: a dict returned by an earlier
     call with the same shapes, whose buffers are overwritten instead of allocating.
     ``want_logp=False`` skips the log-probability outputs of the popularity sampler (BPR ignores
-    them, loss_func.py:55-59)."""
+    them, loss_func.py:55-59).  ``fused_bpr=True`` (needs num_neg % 64 == 0 and pos_ids) evaluates
+    BPRLoss in the kernel's epilogue: adds ``loss`` (scalar), ``row_loss [M]``, ``dpos [M]``,
+    ``dneg [M, n]`` to the result."""
     item_table = _need(item_table, torch.float32, 'item_table')
     query = _need(query, torch.float32, 'query')
     dev = item_table.device
@@ -176,6 +178,15 @@ def fused_forward(item_table, query, num_neg, *, query_index=None, pos_ids=None,
     a.table_prob = ptr(_need_opt(table_prob, torch.float32, 'table_prob'))
     a.neg_ids, a.neg_logp, a.pos_logp = ptr(neg_ids), ptr(out.get('neg_logp')), ptr(out.get('pos_logp'))
     a.pos_score, a.neg_score = ptr(out.get('pos_score')), ptr(out['neg_score'])
+    if fused_bpr:
+        if 'loss' not in out:
+            out['loss'] = torch.empty((), dtype=torch.float32, device=dev)
+            out['row_loss'] = torch.empty(M, dtype=torch.float32, device=dev)
+            out['dpos'] = torch.empty(M, dtype=torch.float32, device=dev)
+            out['dneg'] = torch.empty(M, n, dtype=torch.float32, device=dev)
+        a.fused_loss = nat.LOSS_BPR + 1
+        a.row_loss, a.loss_out = ptr(out['row_loss']), ptr(out['loss'] if want_mean else None)
+        a.dpos, a.dneg = ptr(out['dpos']), ptr(out['dneg'])
     nat.check(nat.lib().rsa_fused_sample_gather_score(ctypes.byref(a), _stream()), 'rsa_fused_sample_gather_score')
     return out
 

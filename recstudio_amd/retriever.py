@@ -30,7 +30,7 @@ from . import _native as nat
 from . import eval as rs_eval
 from . import ops
 from .dataset import SeqDataset, TripletDataset
-from .fused import retriever_scores
+from .fused import fused_bpr_loss, retriever_scores
 from .loss_func import BPRLoss, FullScoreLoss, PairwiseLoss, PointwiseLoss, SampledSoftmaxLoss, SoftmaxLoss
 from .sampler import PopularSamplerModel, Sampler, UniformSampler
 from .scorer import CosineScorer, InnerProductScorer
@@ -341,6 +341,19 @@ class BaseRetriever(torch.nn.Module):
 
     # ------------------------------------------------------------------ steps
     def training_step(self, batch):
+        # single-launch path: stock BPRLoss on the fused kernels with a whole number of 64-negative tiles
+        if (type(self.loss_fn) is BPRLoss and self.sampler is not None and self._fused_ok()
+                and type(self.score_func) is InnerProductScorer and self.neg_count and self.neg_count % 64 == 0
+                and batch[self.fiid].dim() == 1):
+            qfeat = self._get_query_feat(batch)
+            if isinstance(self.query_encoder, torch.nn.Embedding) and isinstance(qfeat, torch.Tensor) and qfeat.dim() == 1:
+                qsrc, qidx = self.query_encoder.weight, qfeat
+            else:
+                qsrc, qidx = self.query_encoder(qfeat), None
+            loss, _ = fused_bpr_loss(self.item_encoder.weight, qsrc, self.neg_count, query_index=qidx,
+                                     pos_ids=batch[self.fiid], sampler=self.sampler,
+                                     sparse_grad=self.config['train'].get('sparse_grad', False))
+            return loss
         output = self.forward(batch, isinstance(self.loss_fn, FullScoreLoss))
         score = output['score']
         score['label'] = batch[self.frating]

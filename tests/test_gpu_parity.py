@@ -427,3 +427,35 @@ def test_full_size_properties(ra):
     tot = rows_g.view(B, n + 1, d).sum(1)
     keep = (ids != 0).all(1)                      # a sampled padding id contributes no gradient row
     assert float(tot[keep].abs().max()) < 1e-6
+
+
+@pytest.mark.parametrize('n', [64, 128, 320])
+@pytest.mark.parametrize('kind', ['given', 'uniform', 'popular'])
+def test_fused_bpr_epilogue_matches_separate_loss_and_oracle(ra, n, kind):
+    """One-launch forward+BPR (value and gradient) == separate kernels == oracle autograd."""
+    from recstudio_amd.fused import fused_bpr_loss
+    N, U, d, B = 2003, 97, 128, 41
+    iw, uw = _tables(N, U, d, n)
+    g = torch.Generator().manual_seed(n)
+    uid = torch.randint(1, U, (B,), generator=g)
+    pos = torch.randint(1, N, (B,), generator=g)
+    counts = (torch.rand(N, generator=g) ** 3 * 100).long()
+    sampler = {'given': None, 'uniform': ra.UniformSampler(N), 'popular': ra.PopularSamplerModel(counts).to(DEV)}[kind]
+    neg_given = torch.randint(0, N, (B, n), generator=g).to(DEV) if kind == 'given' else None
+    for sparse in (False, True):
+        iwd, uwd = iw.to(DEV).requires_grad_(True), uw.to(DEV).requires_grad_(True)
+        torch.manual_seed(77)
+        loss, ids = fused_bpr_loss(iwd, uwd, n, query_index=uid.to(DEV), pos_ids=pos.to(DEV), sampler=sampler,
+                                   neg_ids=neg_given, sparse_grad=sparse)
+        (loss * 3.0).backward()                       # non-trivial upstream gradient
+        val, ps, ns, gi, gu = oracle.dense_grads(iw, uw, uid, pos, ids.cpu(), loss='bpr')
+        rel_close(loss.detach().cpu(), val, rtol=1e-5)
+        gi_got = iwd.grad.to_dense() if sparse else iwd.grad
+        gu_got = uwd.grad.to_dense() if sparse else uwd.grad
+        rel_close(gi_got.cpu(), gi * 3, rtol=2e-4, atol=1e-7)
+        rel_close(gu_got.cpu(), gu * 3, rtol=2e-4, atol=1e-7)
+        # the sampler stream is the same as the unfused path's
+        torch.manual_seed(77)
+        _, ids2 = ra.retriever_scores(iw.to(DEV), uw.to(DEV), n, query_index=uid.to(DEV), pos_ids=pos.to(DEV),
+                                      sampler=sampler, neg_ids=neg_given)
+        assert torch.equal(ids, ids2)
