@@ -173,7 +173,7 @@ def main():
         kw = dict(query_index=uid, pos_ids=pos, sampler=kind)
         if popular:
             kw.update(table=sampler.table, pop_prob=sampler.pop_prob, guide=sampler.guide, guide_log2=sampler.guide_log2,
-                      table_prob=sampler.table_prob)
+                      table_prob=sampler.table_prob, cdf_lut=sampler.cdf_lut)
         bufs = {}
 
         def fwd(b=B, u=uid, p=pos, key='main'):

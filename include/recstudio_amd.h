@@ -138,6 +138,10 @@ typedef struct rsa_fused_args {
   float* loss_out;             /* nullable [1] out: mean over queries (deterministic; rsa_mean_rows) */
   float* dpos;                 /* nullable [M] out: d loss_out / d pos_score */
   float* dneg;                 /* nullable [M, n] out: d loss_out / d neg_score */
+  const float* cdf_lut;        /* nullable [2^guide_log2 + 1][4] fp32: {guide[b] (int32 bits), table[g], pop_prob[g], 0},
+                                  g = min(guide[b], n_items-1).  Direct-lookup form of the inverse CDF: one 32-byte
+                                  read resolves id and probability for every bucket holding <= 1 CDF boundary
+                                  (one memory round trip instead of three); identical results. */
 } rsa_fused_args;
 
 int rsa_fused_sample_gather_score(const rsa_fused_args* args, rsa_stream_t stream);

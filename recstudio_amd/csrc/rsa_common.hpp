@@ -115,6 +115,36 @@ __device__ __forceinline__ int32_t cdf_lower_bound(const float* __restrict__ tab
   return lo > (int32_t)(n_items - 1) ? (int32_t)(n_items - 1) : lo;
 }
 
+// Direct-lookup form of the same search.  lut[b] = {guide[b] (int bits), table[g], pop_prob[g], 0} with
+// g = min(guide[b], n_items-1): one 32-byte read (entries b and b+1) resolves every bucket that holds at
+// most one CDF boundary -- the common case with a fine guide -- INCLUDING the probability needed for the
+// log-prob, i.e. one memory round trip instead of three dependent ones (guide -> table -> pop_prob).
+// Buckets with more boundaries fall back to the binary search.  Same comparisons, same index.
+template <int STRIDE>
+__device__ __forceinline__ int32_t cdf_lookup_lut(const float4* __restrict__ lut, const float* __restrict__ cdf,
+                                                  const float* __restrict__ prob, int prob_stride, int64_t n_items,
+                                                  int guide_log2, float u, float& pr) {
+  const int32_t K = 1 << guide_log2;
+  int32_t b = (int32_t)(u * (float)K);
+  b = b < 0 ? 0 : (b > K - 1 ? K - 1 : b);
+  const float4 e0 = lut[b], e1 = lut[b + 1];
+  int32_t lo = __float_as_int(e0.x), hi = __float_as_int(e1.x);
+  const int32_t last = (int32_t)(n_items - 1);
+  if (hi - lo <= 1) {
+    const bool take_lo = (hi == lo) || !(e0.y < u);
+    pr = take_lo ? e0.z : e1.z;
+    const int32_t id = take_lo ? lo : hi;
+    return id > last ? last : id;
+  }
+  while (lo < hi) {
+    const int32_t mid = lo + ((hi - lo) >> 1);
+    if (cdf[(size_t)mid * STRIDE] < u) lo = mid + 1; else hi = mid;
+  }
+  lo = lo > last ? last : lo;
+  pr = prob[(size_t)lo * prob_stride];
+  return lo;
+}
+
 // ---------------------------------------------------------------- wave helpers
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 

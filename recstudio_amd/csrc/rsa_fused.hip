@@ -30,6 +30,7 @@ struct FwdParams {
   const float* table;
   const float* pop_prob;
   const float* table_prob;
+  const float* lut;
   const int32_t* guide;
   int64_t* neg_ids;
   float* neg_logp;
@@ -217,7 +218,17 @@ __global__ __launch_bounds__(256, RSA_FWD_MIN_WAVES) void fused_fwd_kernel(const
         p.neg_ids[e] = id;
       } else if (p.sampler == RSA_SAMPLER_POPULAR) {
         const float u = torch_rand_element(p.pc, (uint64_t)e);
-        if (p.table_prob) {   // interleaved {cdf, prob}: the search and the log-prob share cache lines
+        if (p.lut) {          // direct lookup: one round trip for id AND probability in the common case
+          float pr;
+          if (p.table_prob)
+            id = cdf_lookup_lut<2>(reinterpret_cast<const float4*>(p.lut), p.table_prob, p.table_prob + 1, 2,
+                                   p.n_items, p.guide_log2, u, pr);
+          else
+            id = cdf_lookup_lut<1>(reinterpret_cast<const float4*>(p.lut), p.table, p.pop_prob, 1, p.n_items,
+                                   p.guide_log2, u, pr);
+          p.neg_ids[e] = id;
+          if (p.neg_logp) p.neg_logp[e] = logf(pr);
+        } else if (p.table_prob) {   // interleaved {cdf, prob}: the search and the log-prob share cache lines
           id = cdf_lower_bound<2>(p.table_prob, p.guide, p.n_items, p.guide_log2, u);
           p.neg_ids[e] = id;
           if (p.neg_logp) p.neg_logp[e] = logf(p.table_prob[2 * (size_t)id + 1]);
@@ -387,6 +398,7 @@ extern "C" int rsa_fused_sample_gather_score(const rsa_fused_args* a, rsa_stream
   p.table = a->table;
   p.pop_prob = a->pop_prob;
   p.table_prob = a->table_prob;
+  p.lut = a->cdf_lut;
   p.guide = a->guide;
   p.neg_ids = a->neg_ids;
   p.neg_logp = a->neg_logp;

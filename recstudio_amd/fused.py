@@ -33,7 +33,7 @@ class _ScoreFn(torch.autograd.Function):
                                 pos_ids=cfg.get('pos_ids'), neg_ids=cfg.get('neg_ids'), sampler=cfg['sampler'],
                                 cosine=cfg.get('cosine', False), mask_pad_pos=cfg.get('mask_pad_pos', False),
                                 table=cfg.get('table'), pop_prob=cfg.get('pop_prob'), guide=cfg.get('guide'),
-                                table_prob=cfg.get('table_prob'),
+                                table_prob=cfg.get('table_prob'), cdf_lut=cfg.get('cdf_lut'),
                                 guide_log2=cfg.get('guide_log2', 0), n_queries=cfg.get('n_queries'))
         cfg['out'] = out
         ctx.cfg = cfg
@@ -101,7 +101,8 @@ def retriever_scores(item_weight, query_src, num_neg, *, query_index=None, pos_i
         cfg['neg_ids'] = neg_ids.reshape(M, -1)
     elif kind == nat.SAMPLER_POPULAR:
         cfg.update(table=sampler.table, pop_prob=sampler.pop_prob, guide=sampler.guide,
-                   guide_log2=sampler.guide_log2, table_prob=getattr(sampler, 'table_prob', None))
+                   guide_log2=sampler.guide_log2, table_prob=getattr(sampler, 'table_prob', None),
+                   cdf_lut=getattr(sampler, 'cdf_lut', None))
     pos_score, neg_score = _ScoreFn.apply(item_weight, query_src, cfg)
     out = cfg['out']
     score = {'pos_score': pos_score if pos_ids is not None else None, 'neg_score': neg_score}
@@ -125,7 +126,7 @@ class _FusedBPRFn(torch.autograd.Function):
         out = ops.fused_forward(item_weight, query_src, cfg['num_neg'], query_index=cfg.get('query_index'),
                                 pos_ids=cfg['pos_ids'], sampler=cfg['sampler'], neg_ids=cfg.get('neg_ids'),
                                 table=cfg.get('table'), pop_prob=cfg.get('pop_prob'), guide=cfg.get('guide'),
-                                guide_log2=cfg.get('guide_log2', 0), table_prob=cfg.get('table_prob'),
+                                guide_log2=cfg.get('guide_log2', 0), table_prob=cfg.get('table_prob'), cdf_lut=cfg.get('cdf_lut'),
                                 n_queries=cfg['n_queries'], want_logp=False, fused_bpr=True)
         cfg['out'] = out
         ctx.cfg = cfg
@@ -175,7 +176,7 @@ def fused_bpr_loss(item_weight, query_src, num_neg, *, query_index=None, pos_ids
         cfg['neg_ids'] = neg_ids.reshape(M, -1)
     elif kind == nat.SAMPLER_POPULAR:
         cfg.update(table=sampler.table, pop_prob=sampler.pop_prob, guide=sampler.guide, guide_log2=sampler.guide_log2,
-                   table_prob=getattr(sampler, 'table_prob', None))
+                   table_prob=getattr(sampler, 'table_prob', None), cdf_lut=getattr(sampler, 'cdf_lut', None))
     loss = _FusedBPRFn.apply(item_weight, query_src, cfg)
     return loss, cfg['out']['neg_ids']
 

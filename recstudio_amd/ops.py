@@ -123,7 +123,7 @@ def seg_gather(item_table, flat_item_ids, seg_start, seg_end, max_len, want_rows
 def fused_forward(item_table, query, num_neg, *, query_index=None, pos_ids=None, neg_ids=None,
                   sampler=nat.SAMPLER_GIVEN, cosine=False, mask_pad_pos=False,
                   table=None, pop_prob=None, guide=None, guide_log2=0, generator=None, n_queries=None,
-                  out=None, want_logp=True, table_prob=None, fused_bpr=False, want_mean=True):
+                  out=None, want_logp=True, table_prob=None, fused_bpr=False, want_mean=True, cdf_lut=None):
     """One launch of rsa_fused_sample_gather_score.  Returns a dict with
     neg_ids [M,n] int64, neg_score [M,n], pos_score [M] (if pos_ids), and for the
     popularity sampler neg_logp [M,n], pos_logp [M].  ``out``: a dict returned by an earlier
@@ -176,6 +176,7 @@ def fused_forward(item_table, query, num_neg, *, query_index=None, pos_ids=None,
     a.sampler, a.mask_pad_pos, a.guide_log2 = int(sampler), int(bool(mask_pad_pos)), int(guide_log2)
     a.table, a.pop_prob, a.guide = ptr(table), ptr(pop_prob), ptr(guide)
     a.table_prob = ptr(_need_opt(table_prob, torch.float32, 'table_prob'))
+    a.cdf_lut = ptr(_need_opt(cdf_lut, torch.float32, 'cdf_lut'))
     a.neg_ids, a.neg_logp, a.pos_logp = ptr(neg_ids), ptr(out.get('neg_logp')), ptr(out.get('pos_logp'))
     a.pos_score, a.neg_score = ptr(out.get('pos_score')), ptr(out['neg_score'])
     if fused_bpr:

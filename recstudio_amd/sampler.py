@@ -68,7 +68,7 @@ def build_guide_table(table: Tensor, guide_log2: Optional[int] = None):
     (sampler.py:247) because j/K and u*K are exact in fp32 for K <= 2**24."""
     n = table.numel()
     if guide_log2 is None:
-        guide_log2 = int(min(24, max(4, int(np.ceil(np.log2(max(n, 2)))) + 1)))
+        guide_log2 = int(min(23, max(4, int(np.ceil(np.log2(max(n, 2)))) - 1)))   # ~1 item per bucket; LUT <= 134 MB
     K = 1 << guide_log2
     cuts = torch.arange(K + 1, dtype=torch.float64) / K
     guide = torch.searchsorted(table.detach().cpu().contiguous(), cuts.to(torch.float32))
@@ -102,6 +102,12 @@ class PopularSamplerModel(Sampler):
     def _register_pairs(self):
         # interleaved {table[i], pop_prob[i]} copy for the fused kernel (not part of the reference's state)
         self.register_buffer('table_prob', torch.stack([self.table, self.pop_prob], 1).contiguous(), persistent=False)
+        # direct-lookup table {guide[b] as int bits, table[g], pop_prob[g], 0}, g = min(guide[b], N-1):
+        # 16 B per guide bucket (268 MB at 2^24 buckets) buys one memory round trip per id instead of three
+        g = self.guide.to(torch.int64).clamp(max=self.table.numel() - 1)
+        lut = torch.stack([self.guide.view(torch.float32), self.table[g], self.pop_prob[g],
+                           torch.zeros_like(self.table[g])], 1).contiguous()
+        self.register_buffer('cdf_lut', lut, persistent=False)
 
     @classmethod
     def from_tables(cls, pop_prob, table, guide_log2=None):

@@ -85,7 +85,7 @@ def test_popular_sampler_tables_equal_reference_buffers(golden):
         assert np.array_equal(ps.pop_prob.numpy(), g[f'm{mode}_pop_prob'])
         assert np.array_equal(ps.table.numpy(), g[f'm{mode}_table'])
         assert ps.num_items == len(g['counts']) - 1
-        assert set(dict(ps.named_buffers())) == {'pop_prob', 'table', 'guide', 'table_prob'}
+        assert set(dict(ps.named_buffers())) == {'pop_prob', 'table', 'guide', 'table_prob', 'cdf_lut'}
         assert set(ps.state_dict()) == {'pop_prob', 'table', 'guide'}
 
 

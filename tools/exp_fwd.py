@@ -40,16 +40,17 @@ us = ra.UniformSampler(N)
 def f_uni():
     buf['u'] = ra.ops.fused_forward(item, user, n, query_index=uid, pos_ids=pos, sampler=nat.SAMPLER_UNIFORM, out=buf.get('u'))
 report('uniform sampler', timeit(f_uni), bytes_per_triplet(d, n, False) * B * n)
-for glog in (20, 22, 24):
+for glog in (22, 23, 24):
     ps = ra.PopularSamplerModel(counts, guide_log2=glog).to(dev)
-    for logp, pairs in ((True, False), (True, True), (False, False), (False, True)):
-        key = f'p{glog}{logp}{pairs}'
+    for logp, pairs, lut in ((True, True, False), (True, True, True), (True, False, True), (False, True, True)):
+        key = f'p{glog}{logp}{pairs}{lut}'
         def f_pop():
             o = buf.get(key)
             buf[key] = ra.ops.fused_forward(item, user, n, query_index=uid, pos_ids=pos, sampler=nat.SAMPLER_POPULAR,
                                             table=ps.table, pop_prob=ps.pop_prob, guide=ps.guide, guide_log2=ps.guide_log2,
-                                            out=o, want_logp=logp, table_prob=ps.table_prob if pairs else None)
-        report(f'popular guide_log2={glog} logp={logp} pairs={pairs}', timeit(f_pop), bytes_per_triplet(d, n, True) * B * n)
+                                            out=o, want_logp=logp, table_prob=ps.table_prob if pairs else None,
+                                            cdf_lut=ps.cdf_lut if lut else None)
+        report(f'popular guide_log2={glog} logp={logp} pairs={pairs} lut={lut}', timeit(f_pop), bytes_per_triplet(d, n, True) * B * n)
     # stand-alone sampler kernel
     def f_s():
         ra.ops.sample_popular(ps.table, ps.pop_prob, ps.guide, ps.guide_log2, B * n)
