@@ -15,8 +15,16 @@
 // through LDS (row stride D+4 floats: conflict-free ds_read_b128) and shared by the 4 waves; the
 // query operand lives in registers for the whole item range.  Exact fp32 (fmaf chain), 157 TFLOP/s peak.
 //
-// Top-k.  Scores go to HBM (caller's `scores` or the workspace) and a per-row 3-pass radix select
-// (11/11/10 bits) finds the exact k-th key, collects the k winners and bitonic-sorts them.
+// Top-k without materialising [B, N] (default when the caller does not ask for `scores`):
+//   A. the same GEMM over an evenly spread SAMPLE of 32-item tiles (<= 65 536 items) -> per-query
+//      threshold T = the j-th largest sampled score, j sized so that ~3k (+ margin) catalog items beat T;
+//   B. the full GEMM with a filter epilogue: a lane appends (score, item) to its query's candidate
+//      list only when score > T -- 16 compares per lane per tile, a rare atomic;
+//   C. exact radix select (11/11/10 bits) + bitonic sort over the few hundred candidates of each query.
+// A query whose candidate count ends up outside [k, CAP] (threshold too tight / too loose: a catalog whose
+// scores are far from exchangeable across the sampled tiles) is flagged and recomputed exactly by
+// D. a per-row radix select that evaluates the dot products on the fly.  The result is always the exact
+// top-k (ties -> smaller id).  With `scores` given, the radix select runs on the materialised rows.
 #include "rsa_common.hpp"
 
 namespace rsa {
@@ -26,11 +34,24 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int QB = 128;   // queries per workgroup (4 waves x 32)
 constexpr int TI = 32;    // items per tile
 
+struct FilterArgs {
+  const float* thr;     // [n_query] per-query threshold (null: no filtering)
+  int32_t* cnt;         // [n_query] candidate counters (zeroed)
+  float* cand_val;      // [n_query, cap]
+  int32_t* cand_idx;    // [n_query, cap] item ids
+  int32_t cap;
+};
+
+// tile_stride == 1: the workgroup walks the contiguous item range [1 + bx*items_per_split, ...).
+// tile_stride  > 1: SAMPLE mode -- "item" positions are sample positions; sample tile s reads catalog tile
+// s*tile_stride, and scores are written to a dense [n_query, score_ld] sample matrix.
 template <int D>
 __global__ __launch_bounds__(256) void fullscore_kernel(const float* __restrict__ item_table, int64_t n_items,
                                                         const float* __restrict__ query, int64_t n_query,
-                                                        float* __restrict__ scores, float2* __restrict__ lse_part,
-                                                        int splits, int64_t items_per_split) {
+                                                        float* __restrict__ scores, int64_t score_ld,
+                                                        float2* __restrict__ lse_part, int splits,
+                                                        int64_t items_per_split, int64_t tile_stride,
+                                                        int64_t n_positions, FilterArgs flt) {
   constexpr int KH = D / 2;         // k values per lane half
   constexpr int LD = D + 4;         // padded LDS row stride (floats)
   constexpr int V4 = D / 4;         // float4 per row
@@ -40,7 +61,6 @@ __global__ __launch_bounds__(256) void fullscore_kernel(const float* __restrict_
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j = lane & 31, h = lane >> 5;
   const int64_t q = (int64_t)blockIdx.y * QB + wave * 32 + j;
-  const int64_t n_cols = n_items - 1;
 
   float bq[KH];
   {
@@ -54,10 +74,15 @@ __global__ __launch_bounds__(256) void fullscore_kernel(const float* __restrict_
     }
   }
 
+  // positions are 1-based like item ids: position p of a contiguous walk IS item p; in sample mode
+  // position p maps to item 1 + ((p-1)/TI)*tile_stride*TI + (p-1)%TI
+  const int64_t p_limit = n_positions + 1;
   const int64_t i_begin = 1 + (int64_t)blockIdx.x * items_per_split;
   int64_t i_end = i_begin + items_per_split;
-  if (i_end > n_items) i_end = n_items;
+  if (i_end > p_limit) i_end = p_limit;
   const int n_tiles = i_begin < i_end ? (int)((i_end - i_begin + TI - 1) / TI) : 0;
+  float thr = INFINITY;
+  if (flt.thr != nullptr && q < n_query) thr = flt.thr[q];
 
   constexpr int LOADS = (TI * V4) / 256;    // float4 per thread per tile (D=128: 4)
   static_assert((TI * V4) % 256 == 0, "tile must split evenly over the workgroup");
@@ -67,9 +92,10 @@ __global__ __launch_bounds__(256) void fullscore_kernel(const float* __restrict_
     for (int f = 0; f < LOADS; ++f) {
       const int idx = f * 256 + tid;
       const int row = idx / V4, c4 = idx - row * V4;
-      const int64_t item = i_begin + (int64_t)t * TI + row;
-      stage[f] = item < i_end ? reinterpret_cast<const float4*>(item_table + (size_t)item * D)[c4]
-                              : make_float4(0.f, 0.f, 0.f, 0.f);
+      const int64_t pos = i_begin + (int64_t)t * TI + row;
+      const int64_t item = tile_stride == 1 ? pos : 1 + ((pos - 1) / TI) * tile_stride * TI + (pos - 1) % TI;
+      stage[f] = (pos < i_end && item < n_items) ? reinterpret_cast<const float4*>(item_table + (size_t)item * D)[c4]
+                                                 : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
   auto commit = [&](int buf) {
@@ -132,7 +158,21 @@ __global__ __launch_bounds__(256) void fullscore_kernel(const float* __restrict_
         const int qq = 2 * tt + h;
         const int64_t qg = (int64_t)blockIdx.y * QB + wave * 32 + qq;
         const int64_t item = i0 + j;
-        if (qg < n_query && item < i_end) scores[(size_t)qg * n_cols + (item - 1)] = tpose[wave][qq][j];
+        if (qg < n_query && item < i_end) scores[(size_t)qg * score_ld + (item - 1)] = tpose[wave][qq][j];
+      }
+    }
+    if (flt.thr != nullptr) {
+      // candidate filter: almost never taken once the threshold is in place
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (acc[r] > thr && i0 + row < i_end) {
+          const int32_t slot = atomicAdd(flt.cnt + q, 1);
+          if (slot < flt.cap) {
+            flt.cand_val[(size_t)q * flt.cap + slot] = acc[r];
+            flt.cand_idx[(size_t)q * flt.cap + slot] = (int32_t)(i0 + row);
+          }
+        }
       }
     }
     if (t + 1 < n_tiles) commit(cur ^ 1);
@@ -171,14 +211,57 @@ __device__ __forceinline__ float key_value(uint32_t k) {
   return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
 }
 
-__global__ __launch_bounds__(1024) void topk_row_kernel(const float* __restrict__ scores, int64_t n_cols, int k,
-                                                        float* __restrict__ topk_val, int64_t* __restrict__ topk_idx) {
+enum { SEL_DENSE = 0, SEL_CAND = 1, SEL_RECOMPUTE = 2, SEL_THRESHOLD = 3 };
+
+struct SelectArgs {
+  const float* values;      // DENSE/THRESHOLD: [n_rows, ld] score rows;  CAND: [n_rows, cap] candidate scores
+  const int32_t* cand_idx;  // CAND: [n_rows, cap] item ids
+  int32_t* cnt;             // CAND: [n_rows] candidate counts
+  int32_t* flags;           // CAND: out, 1 = row must be recomputed;  RECOMPUTE: in
+  int64_t ld;               // row stride of `values`
+  int64_t n_cols;           // DENSE/THRESHOLD/RECOMPUTE: elements per row
+  int32_t cap;
+  const float* item_table;  // RECOMPUTE: item rows 1..n_cols, query rows
+  const float* query;
+  int32_t dim;
+  float* thr_out;           // THRESHOLD: [n_rows] the k-th largest value of each row
+};
+
+// Exact top-k of one row (one 1024-thread workgroup per row): 3-pass radix select on the order-preserving
+// key finds the k-th key, one more pass collects the winners, a bitonic sort orders them.
+template <int MODE>
+__global__ __launch_bounds__(1024) void topk_row_kernel(SelectArgs a, int k, float* __restrict__ topk_val,
+                                                        int64_t* __restrict__ topk_idx) {
   __shared__ uint32_t hist[2048];
-  __shared__ uint32_t s_digit, s_krem, s_cnt_gt, s_cnt_eq;
+  __shared__ uint32_t s_digit, s_krem, s_cnt_gt;
   __shared__ uint32_t okey[1024];
   __shared__ int32_t oidx[1024];
+  __shared__ float qrow[MODE == SEL_RECOMPUTE ? 128 : 1];
   const int tid = threadIdx.x;
-  const float* row = scores + (size_t)blockIdx.x * n_cols;
+  const int64_t r = blockIdx.x;
+  int64_t n = a.n_cols;
+  if (MODE == SEL_CAND) {
+    const int32_t c = a.cnt[r];
+    const bool bad = c < k || c > a.cap;
+    if (tid == 0) a.flags[r] = bad ? 1 : 0;
+    if (bad) return;                       // recomputed exactly by the SEL_RECOMPUTE pass
+    n = c;
+  }
+  if (MODE == SEL_RECOMPUTE) {
+    if (a.flags[r] == 0) return;
+    for (int c = tid; c < a.dim; c += 1024) qrow[c] = a.query[(size_t)r * a.dim + c];
+    __syncthreads();
+  }
+  const float* row = a.values + (size_t)r * a.ld;
+  auto value_at = [&](int64_t i) -> float {
+    if (MODE == SEL_RECOMPUTE) {
+      const float* it = a.item_table + (size_t)(i + 1) * a.dim;
+      float acc = 0.f;
+      for (int c = 0; c < a.dim; ++c) acc = __fmaf_rn(it[c], qrow[c], acc);
+      return acc;
+    }
+    return row[i];
+  };
   uint32_t prefix = 0, pmask = 0;
   uint32_t k_rem = (uint32_t)k;
   const int shifts[3] = {21, 10, 0}, nbits[3] = {11, 11, 10};
@@ -186,8 +269,8 @@ __global__ __launch_bounds__(1024) void topk_row_kernel(const float* __restrict_
     const int shift = shifts[pass], nb = 1 << nbits[pass];
     for (int b = tid; b < 2048; b += 1024) hist[b] = 0;
     __syncthreads();
-    for (int64_t i = tid; i < n_cols; i += 1024) {
-      const uint32_t key = order_key(row[i]);
+    for (int64_t i = tid; i < n; i += 1024) {
+      const uint32_t key = order_key(value_at(i));
       if ((key & pmask) == prefix) atomicAdd(&hist[(key >> shift) & (nb - 1)], 1u);
     }
     __syncthreads();
@@ -217,30 +300,56 @@ __global__ __launch_bounds__(1024) void topk_row_kernel(const float* __restrict_
     __syncthreads();
   }
   // prefix = key of the k-th largest; k_rem of the keys equal to it are needed
+  if (MODE == SEL_THRESHOLD) {
+    if (tid == 0) a.thr_out[r] = key_value(prefix);
+    return;
+  }
+  // Winners: every key above the k-th key, plus the k_rem SMALLEST ids among the keys equal to it
+  // (deterministic tie rule).  The tie slots [n_gt, k) start as sentinels and are filled by
+  // "replace the current largest id if mine is smaller"; s_tie_max lets the (possibly very many)
+  // remaining ties bail out with one LDS read.
+  __shared__ int32_t s_tie_max;
+  const uint32_t n_gt = (uint32_t)k - k_rem;
   if (tid == 0) {
     s_cnt_gt = 0;
-    s_cnt_eq = 0;
+    s_tie_max = 0x7fffffff;
   }
-  okey[tid] = 0;
+  okey[tid] = (tid >= (int)n_gt && tid < k) ? prefix : 0u;
   oidx[tid] = 0x7fffffff;
   __syncthreads();
-  const uint32_t n_gt = (uint32_t)k - k_rem;
-  for (int64_t i = tid; i < n_cols; i += 1024) {
-    const uint32_t key = order_key(row[i]);
+  for (int64_t i = tid; i < n; i += 1024) {
+    const uint32_t key = order_key(value_at(i));
+    const int32_t id = MODE == SEL_CAND ? a.cand_idx[(size_t)r * a.cap + i] : (int32_t)i + 1;   // item id
     if (key > prefix) {
       const uint32_t p = atomicAdd(&s_cnt_gt, 1u);
       okey[p] = key;
-      oidx[p] = (int32_t)i;
+      oidx[p] = id;
     } else if (key == prefix) {
-      const uint32_t p = atomicAdd(&s_cnt_eq, 1u);
-      if (p < k_rem) {
-        okey[n_gt + p] = key;
-        oidx[n_gt + p] = (int32_t)i;
+      while (id < *(volatile int32_t*)&s_tie_max) {
+        uint32_t worst = n_gt;
+        int32_t wv = *(volatile int32_t*)&oidx[n_gt];
+        for (uint32_t t = n_gt + 1; t < (uint32_t)k; ++t) {
+          const int32_t v = *(volatile int32_t*)&oidx[t];
+          if (v > wv) {
+            wv = v;
+            worst = t;
+          }
+        }
+        if (id >= wv) break;
+        if (atomicCAS(&oidx[worst], wv, id) == wv) {
+          int32_t mx = 0;
+          for (uint32_t t = n_gt; t < (uint32_t)k; ++t) {
+            const int32_t v = *(volatile int32_t*)&oidx[t];
+            mx = v > mx ? v : mx;
+          }
+          atomicMin(&s_tie_max, mx);   // stale-high is harmless (extra work), never too low:
+          break;                       // mx is the max of a superset-or-equal of the final kept ids
+        }
       }
     }
   }
   __syncthreads();
-  // bitonic sort, descending by key, ascending index among equal keys
+  // bitonic sort, descending by key, ascending id among equal keys
   for (int size = 2; size <= 1024; size <<= 1) {
     for (int stride = size >> 1; stride > 0; stride >>= 1) {
       const int partner = tid ^ stride;
@@ -258,8 +367,8 @@ __global__ __launch_bounds__(1024) void topk_row_kernel(const float* __restrict_
     }
   }
   if (tid < k) {
-    topk_val[(size_t)blockIdx.x * k + tid] = key_value(okey[tid]);
-    topk_idx[(size_t)blockIdx.x * k + tid] = (int64_t)oidx[tid] + 1;   // item id (baseretriever.py:385)
+    topk_val[(size_t)r * k + tid] = key_value(okey[tid]);
+    topk_idx[(size_t)r * k + tid] = (int64_t)oidx[tid];   // item id (baseretriever.py:385)
   }
 }
 
@@ -315,20 +424,78 @@ __global__ __launch_bounds__(256) void mask_history_kernel(const float* __restri
 
 using namespace rsa;
 
-static int64_t fullscore_splits(int64_t n_query, int64_t n_items) {
+static int64_t fullscore_splits(int64_t n_query, int64_t n_positions) {
   const int64_t groups = (n_query + QB - 1) / QB;
   int64_t splits = (1024 + groups - 1) / groups;   // ~4 workgroups per CU in flight
-  const int64_t max_splits = (n_items - 1 + TI - 1) / TI;
+  const int64_t max_splits = (n_positions + TI - 1) / TI;
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
   return splits;
 }
 
+constexpr int32_t CAND_CAP = 8192;          // candidates kept per query by the filter epilogue
+constexpr int64_t SAMPLE_TILES_MAX = 2048;  // 65 536 sampled items
+constexpr int64_t FILTER_MIN_ITEMS = 32768; // below this the dense radix select is cheaper
+
+struct TopkPlan {
+  bool filter;
+  int64_t sample_tiles, tile_stride, sample_items;
+  int32_t j;   // threshold rank inside the sample
+};
+
+static TopkPlan plan_topk(int64_t n_items, int32_t k, bool scores_given) {
+  TopkPlan pl{};
+  const int64_t n_cols = n_items - 1;
+  const int64_t tiles = (n_cols + TI - 1) / TI;
+  pl.filter = !scores_given && k > 0 && n_cols >= FILTER_MIN_ITEMS;
+  if (!pl.filter) return pl;
+  pl.sample_tiles = tiles / 4 < SAMPLE_TILES_MAX ? tiles / 4 : SAMPLE_TILES_MAX;
+  pl.tile_stride = tiles / pl.sample_tiles;
+  pl.sample_items = pl.sample_tiles * TI;
+  // expected catalog items above the j-th sampled score ~ j * n_cols / sample_items: aim at 3k + margin
+  const double ratio = (double)pl.sample_items / (double)n_cols;
+  int64_t j = (int64_t)(3.0 * k * ratio) + 16;
+  if (j > 1024) j = 1024;
+  if (j > pl.sample_items) j = pl.sample_items;
+  pl.j = (int32_t)j;
+  if ((double)j / ratio > 0.6 * CAND_CAP) pl.filter = false;   // would crowd the candidate lists
+  return pl;
+}
+
+static inline int64_t align256(int64_t b) { return (b + 255) / 256 * 256; }
+
 extern "C" int64_t rsa_fullscore_workspace_bytes(int64_t n_query, int64_t n_items, int32_t k) {
   if (n_query <= 0 || n_items <= 1) return 0;
-  int64_t bytes = n_query * fullscore_splits(n_query, n_items) * (int64_t)sizeof(float2);   // lse partials
-  if (k > 0) bytes += n_query * (n_items - 1) * (int64_t)sizeof(float);                     // score rows
+  int64_t bytes = align256(n_query * fullscore_splits(n_query, n_items - 1) * (int64_t)sizeof(float2));   // lse partials
+  if (k > 0) {
+    const TopkPlan pl = plan_topk(n_items, k, false);
+    if (pl.filter) {
+      bytes += align256(n_query * pl.sample_items * 4);        // sample scores
+      bytes += 3 * align256(n_query * 4);                       // thresholds, counters, flags
+      bytes += 2 * align256(n_query * (int64_t)CAND_CAP * 4);   // candidate values + ids
+    } else {
+      bytes += align256(n_query * (n_items - 1) * (int64_t)sizeof(float));   // dense score rows
+    }
+  }
   return bytes + 256;
+}
+
+template <int D>
+static void launch_gemm(dim3 grid, hipStream_t s, const float* item_table, int64_t n_items, const float* query,
+                        int64_t n_query, float* scores, int64_t score_ld, float2* lse_part, int splits, int64_t per,
+                        int64_t tile_stride, int64_t n_positions, FilterArgs flt) {
+  hipLaunchKernelGGL(fullscore_kernel<D>, grid, dim3(256), 0, s, item_table, n_items, query, n_query, scores, score_ld,
+                     lse_part, splits, per, tile_stride, n_positions, flt);
+}
+
+static void gemm_dispatch(int dim, dim3 grid, hipStream_t s, const float* item_table, int64_t n_items,
+                          const float* query, int64_t n_query, float* scores, int64_t score_ld, float2* lse_part,
+                          int splits, int64_t per, int64_t tile_stride, int64_t n_positions, FilterArgs flt) {
+  switch (dim) {
+    case 32: launch_gemm<32>(grid, s, item_table, n_items, query, n_query, scores, score_ld, lse_part, splits, per, tile_stride, n_positions, flt); break;
+    case 64: launch_gemm<64>(grid, s, item_table, n_items, query, n_query, scores, score_ld, lse_part, splits, per, tile_stride, n_positions, flt); break;
+    default: launch_gemm<128>(grid, s, item_table, n_items, query, n_query, scores, score_ld, lse_part, splits, per, tile_stride, n_positions, flt); break;
+  }
 }
 
 extern "C" int rsa_fullscore(const float* item_table, int64_t n_items, int32_t dim, const float* query,
@@ -348,31 +515,74 @@ extern "C" int rsa_fullscore(const float* item_table, int64_t n_items, int32_t d
   RSA_CHECK_ARG(workspace != nullptr && workspace_bytes >= need, "rsa_fullscore: workspace too small (%lld < %lld)",
                 (long long)workspace_bytes, (long long)need);
   hipStream_t s = (hipStream_t)stream;
-  const int64_t splits = fullscore_splits(n_query, n_items);
-  const int64_t per = (((n_items - 1) + splits - 1) / splits + TI - 1) / TI * TI;
-  const int64_t splits_used = ((n_items - 1) + per - 1) / per;
-  float2* part = reinterpret_cast<float2*>(workspace);
-  float* score_rows = scores;
-  if (k > 0 && scores == nullptr)
-    score_rows = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) +
-                                          ((n_query * splits * (int64_t)sizeof(float2) + 255) / 256) * 256);
-  dim3 grid((unsigned)splits_used, (unsigned)((n_query + QB - 1) / QB)), block(256);
+  const int64_t n_cols = n_items - 1;
+  const unsigned groups = (unsigned)((n_query + QB - 1) / QB);
+  const int64_t splits = fullscore_splits(n_query, n_cols);
+  const int64_t per = ((n_cols + splits - 1) / splits + TI - 1) / TI * TI;
+  const int64_t splits_used = (n_cols + per - 1) / per;
+  char* ws = reinterpret_cast<char*>(workspace);
+  float2* part = reinterpret_cast<float2*>(ws);
+  ws += align256(n_query * splits * (int64_t)sizeof(float2));
   float2* lp = lse ? part : nullptr;
-  switch (dim) {
-    case 32: hipLaunchKernelGGL(fullscore_kernel<32>, grid, block, 0, s, item_table, n_items, query, n_query, score_rows, lp, (int)splits_used, per); break;
-    case 64: hipLaunchKernelGGL(fullscore_kernel<64>, grid, block, 0, s, item_table, n_items, query, n_query, score_rows, lp, (int)splits_used, per); break;
-    default: hipLaunchKernelGGL(fullscore_kernel<128>, grid, block, 0, s, item_table, n_items, query, n_query, score_rows, lp, (int)splits_used, per); break;
+  const TopkPlan pl = plan_topk(n_items, k, scores != nullptr);
+  const FilterArgs no_filter{nullptr, nullptr, nullptr, nullptr, 0};
+
+  if (pl.filter) {
+    float* sample = reinterpret_cast<float*>(ws);      ws += align256(n_query * pl.sample_items * 4);
+    float* thr = reinterpret_cast<float*>(ws);         ws += align256(n_query * 4);
+    int32_t* cnt = reinterpret_cast<int32_t*>(ws);     ws += align256(n_query * 4);
+    int32_t* flags = reinterpret_cast<int32_t*>(ws);   ws += align256(n_query * 4);
+    float* cand_val = reinterpret_cast<float*>(ws);    ws += align256(n_query * (int64_t)CAND_CAP * 4);
+    int32_t* cand_idx = reinterpret_cast<int32_t*>(ws);
+    if (hipMemsetAsync(cnt, 0, n_query * 4, s) != hipSuccess) {
+      rsa::set_error("rsa_fullscore: memset failed");
+      return RSA_ERR_HIP;
+    }
+    // A. sample GEMM + per-query threshold
+    const int64_t ssplits = fullscore_splits(n_query, pl.sample_items);
+    const int64_t sper = ((pl.sample_items + ssplits - 1) / ssplits + TI - 1) / TI * TI;
+    const int64_t ssplits_used = (pl.sample_items + sper - 1) / sper;
+    gemm_dispatch(dim, dim3((unsigned)ssplits_used, groups), s, item_table, n_items, query, n_query, sample,
+                  pl.sample_items, nullptr, (int)ssplits_used, sper, pl.tile_stride, pl.sample_items, no_filter);
+    RSA_CHECK_LAUNCH("rsa_fullscore(sample gemm)");
+    SelectArgs sa{};
+    sa.values = sample; sa.ld = pl.sample_items; sa.n_cols = pl.sample_items; sa.thr_out = thr;
+    hipLaunchKernelGGL(topk_row_kernel<SEL_THRESHOLD>, dim3((unsigned)n_query), dim3(1024), 0, s, sa, (int)pl.j,
+                       (float*)nullptr, (int64_t*)nullptr);
+    RSA_CHECK_LAUNCH("rsa_fullscore(threshold)");
+    // B. full GEMM with the filter epilogue (+ fused logsumexp)
+    const FilterArgs flt{thr, cnt, cand_val, cand_idx, CAND_CAP};
+    gemm_dispatch(dim, dim3((unsigned)splits_used, groups), s, item_table, n_items, query, n_query, nullptr, n_cols, lp,
+                  (int)splits_used, per, 1, n_cols, flt);
+    RSA_CHECK_LAUNCH("rsa_fullscore(gemm+filter)");
+    // C. exact select over the candidates;  D. exact recompute of flagged rows
+    SelectArgs ca{};
+    ca.values = cand_val; ca.cand_idx = cand_idx; ca.cnt = cnt; ca.flags = flags; ca.ld = CAND_CAP; ca.cap = CAND_CAP;
+    hipLaunchKernelGGL(topk_row_kernel<SEL_CAND>, dim3((unsigned)n_query), dim3(1024), 0, s, ca, (int)k, topk_val,
+                       topk_idx);
+    SelectArgs ra{};
+    ra.flags = flags; ra.n_cols = n_cols; ra.item_table = item_table; ra.query = query; ra.dim = dim; ra.values = query;
+    hipLaunchKernelGGL(topk_row_kernel<SEL_RECOMPUTE>, dim3((unsigned)n_query), dim3(1024), 0, s, ra, (int)k, topk_val,
+                       topk_idx);
+    RSA_CHECK_LAUNCH("rsa_fullscore(select)");
+  } else {
+    float* score_rows = scores;
+    if (k > 0 && scores == nullptr) score_rows = reinterpret_cast<float*>(ws);
+    gemm_dispatch(dim, dim3((unsigned)splits_used, groups), s, item_table, n_items, query, n_query, score_rows, n_cols,
+                  lp, (int)splits_used, per, 1, n_cols, no_filter);
+    RSA_CHECK_LAUNCH("rsa_fullscore(gemm)");
+    if (k > 0) {
+      SelectArgs da{};
+      da.values = score_rows; da.ld = n_cols; da.n_cols = n_cols;
+      hipLaunchKernelGGL(topk_row_kernel<SEL_DENSE>, dim3((unsigned)n_query), dim3(1024), 0, s, da, (int)k, topk_val,
+                         topk_idx);
+      RSA_CHECK_LAUNCH("rsa_fullscore(topk)");
+    }
   }
-  RSA_CHECK_LAUNCH("rsa_fullscore(gemm)");
   if (lse) {
     hipLaunchKernelGGL(lse_merge_kernel, dim3((unsigned)((n_query + 255) / 256)), dim3(256), 0, s, part, n_query,
                        (int)splits_used, lse);
     RSA_CHECK_LAUNCH("rsa_fullscore(lse)");
-  }
-  if (k > 0) {
-    hipLaunchKernelGGL(topk_row_kernel, dim3((unsigned)n_query), dim3(1024), 0, s, score_rows, n_items - 1, (int)k,
-                       topk_val, topk_idx);
-    RSA_CHECK_LAUNCH("rsa_fullscore(topk)");
   }
   return RSA_OK;
 }

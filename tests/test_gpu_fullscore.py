@@ -138,3 +138,34 @@ def test_fullscore_config5_shape_properties(ra):
     # linearity: scaling the queries scales the top-k scores and shifts nothing
     _, _, tv2, ti2 = ra.ops.fullscore(iw, q * 2, k=k)
     assert torch.equal(ti2, ti) and torch.equal(tv2, tv * 2)
+
+
+def test_topk_filter_path_adversarial_catalogs(ra):
+    """The threshold-filter top-k must stay exact when the sampled tiles are NOT representative:
+    scores increasing with the item id, a few huge outliers hidden between sampled tiles, all-equal
+    scores (everything ties), and a zero query."""
+    N, d, k = 200_001, 64, 100
+    g = torch.Generator().manual_seed(3)
+    base = torch.randn(N, d, generator=g) * 0.1
+    q = torch.randn(4, d, generator=g)
+    cases = {}
+    trend = base.clone()
+    trend[:, 0] += torch.linspace(-3, 3, N)                  # strong trend along the id axis
+    cases['trend'] = (trend, q.clone())
+    spikes = base.clone()
+    spikes[torch.arange(50, N, 1999)] *= 40.0                 # ~100 outliers
+    cases['spikes'] = (spikes, q.clone())
+    flat = torch.zeros(N, d)
+    flat[:, 0] = 1.0                                          # every item scores the same
+    cases['flat'] = (flat, q.clone())
+    cases['zero_query'] = (base.clone(), torch.zeros(4, d))
+    for name, (iw, qq) in cases.items():
+        _, lse, tv, ti = ra.ops.fullscore(iw.to(DEV), qq.to(DEV), want_lse=True, k=k)
+        ref = qq.double() @ iw[1:].double().T
+        wv, wi = torch.topk(ref, k)
+        close(tv.cpu(), wv.float(), rtol=1e-4, atol=1e-5)
+        got = ref.gather(1, ti.cpu() - 1)                     # the returned ids carry the returned scores
+        close(got.float(), tv.cpu(), rtol=1e-4, atol=1e-5)
+        if name in ('flat', 'zero_query'):                    # all ties: the k smallest ids, in order
+            assert torch.equal(ti.cpu(), torch.arange(1, k + 1).expand(4, k)), name
+        close(lse.cpu(), torch.logsumexp(ref, -1).float(), rtol=1e-5)
