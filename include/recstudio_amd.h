@@ -75,13 +75,15 @@ int rsa_sample_uniform(int64_t* neg_ids, int64_t numel, int64_t low, int64_t hig
 int rsa_sample_popular(const float* table, const float* pop_prob, const int32_t* guide,
                        int64_t n_items, int32_t guide_log2,
                        int64_t* neg_ids, float* neg_logp, float* u_out, int64_t numel,
-                       uint64_t seed, uint64_t offset, uint32_t grid_threads, rsa_stream_t stream);
+                       uint64_t seed, uint64_t offset, uint32_t grid_threads,
+                       const float* cdf_lut /* nullable, see rsa_fused_args.cdf_lut */, rsa_stream_t stream);
 
 /* The same inverse-CDF lookup for caller-supplied uniforms u[numel] (used by the
  * parity tests to hit exact table edges). */
 int rsa_popular_lookup(const float* table, const float* pop_prob, const int32_t* guide,
                        int64_t n_items, int32_t guide_log2, const float* u,
-                       int64_t* ids, float* logp, int64_t numel, rsa_stream_t stream);
+                       int64_t* ids, float* logp, int64_t numel, const float* cdf_lut /* nullable */,
+                       rsa_stream_t stream);
 
 /* PopularSamplerModel.compute_item_p -- recstudio/ann/sampler.py:257-258:
  * logp[i] = log(pop_prob[ids[i]]). */

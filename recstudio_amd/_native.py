@@ -57,9 +57,9 @@ SIGNATURES = {
     'rsa_device_info': (c_int, [c_int, POINTER(c_int32), POINTER(c_int32), POINTER(c_int32)]),
     'rsa_sample_uniform': (c_int, [c_void_p, c_int64, c_int64, c_int64, c_uint64, c_uint64, c_uint32, c_void_p]),
     'rsa_sample_popular': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p,
-                                   c_int64, c_uint64, c_uint64, c_uint32, c_void_p]),
+                                   c_int64, c_uint64, c_uint64, c_uint32, c_void_p, c_void_p]),
     'rsa_popular_lookup': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p,
-                                   c_int64, c_void_p]),
+                                   c_int64, c_void_p, c_void_p]),
     'rsa_item_logp': (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p]),
     'rsa_embedding_gather': (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_int64, c_void_p, c_void_p]),
     'rsa_fused_sample_gather_score': (c_int, [POINTER(FusedArgs), c_void_p]),

@@ -42,41 +42,47 @@ __global__ __launch_bounds__(256) void shard_count_kernel(const int64_t* __restr
   if (threadIdx.x < G && h[threadIdx.x]) atomicAdd(&counts[threadIdx.x], h[threadIdx.x]);
 }
 
+// Counting-sort scatter.  Each workgroup owns a contiguous chunk of elements: pass 1 counts the chunk's
+// elements per owner in LDS, ONE global atomic per (workgroup, owner) reserves a contiguous slot range,
+// pass 2 hands out the slots from LDS counters.  (A first version did one global atomic per wave and
+// owner on the same few cursor words and spent 0.8 ms there for 4 M elements.)
 __global__ __launch_bounds__(256) void shard_route_kernel(const int64_t* __restrict__ pos_ids,
                                                           const int64_t* __restrict__ neg_ids, int64_t n_queries,
                                                           int n, int64_t rows_per_shard, int G, int64_t query_base,
-                                                          int32_t* __restrict__ cursor, int64_t* __restrict__ keys,
-                                                          int64_t* __restrict__ pos_out) {
+                                                          int64_t chunk, int32_t* __restrict__ cursor,
+                                                          int64_t* __restrict__ keys, int64_t* __restrict__ pos_out) {
+  __shared__ int32_t cnt[64], base[64];
   const int64_t numel = n_queries * (n + 1);
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  const int64_t e_end = ((numel + stride - 1) / stride) * stride;   // whole waves take every trip (ballots)
-  const int lane = lane_id();
-  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < e_end; e += stride) {
-    const bool act = e < numel;
-    int64_t m = 0, id = 0;
-    int c = 0, g = -1;
-    if (act) {
-      id = element_id(pos_ids, neg_ids, e, n, m, c);
-      g = (int)(id / rows_per_shard);
-      g = g < 0 ? 0 : (g >= G ? G - 1 : g);
-    }
-    // one atomic per (wave, owner): the lanes of an owner take consecutive slots
-    int32_t slot = 0;
-    for (int o = 0; o < G; ++o) {
-      const unsigned long long mask = __ballot(g == o);
-      if (mask == 0ull) continue;
-      const int leader = __ffsll((long long)mask) - 1;
-      int32_t base = 0;
-      if (lane == leader) base = atomicAdd(&cursor[o], (int32_t)__popcll(mask));
-      base = __shfl(base, leader, 64);
-      if (g == o) slot = base + (int32_t)__popcll(mask & ((1ull << lane) - 1ull));
-    }
-    if (act) {
-      const int64_t local = id - (int64_t)g * rows_per_shard;
-      keys[slot] = ((query_base + m) << 32) | (local & 0xffffffffll);
-      // destination of this element's score in the home buffer [pos_score (n_queries) | neg_score (n_queries x n)]
-      pos_out[slot] = c == 0 ? m : n_queries + m * n + (c - 1);
-    }
+  const int64_t e_lo = (int64_t)blockIdx.x * chunk;
+  int64_t e_hi = e_lo + chunk;
+  if (e_hi > numel) e_hi = numel;
+  if (threadIdx.x < 64) cnt[threadIdx.x] = 0;
+  __syncthreads();
+  for (int64_t e = e_lo + threadIdx.x; e < e_hi; e += 256) {
+    int64_t m;
+    int c;
+    const int64_t id = element_id(pos_ids, neg_ids, e, n, m, c);
+    int g = (int)(id / rows_per_shard);
+    g = g < 0 ? 0 : (g >= G ? G - 1 : g);
+    atomicAdd(&cnt[g], 1);
+  }
+  __syncthreads();
+  if (threadIdx.x < G) {
+    base[threadIdx.x] = cnt[threadIdx.x] ? atomicAdd(&cursor[threadIdx.x], cnt[threadIdx.x]) : 0;
+    cnt[threadIdx.x] = 0;
+  }
+  __syncthreads();
+  for (int64_t e = e_lo + threadIdx.x; e < e_hi; e += 256) {
+    int64_t m;
+    int c;
+    const int64_t id = element_id(pos_ids, neg_ids, e, n, m, c);
+    int g = (int)(id / rows_per_shard);
+    g = g < 0 ? 0 : (g >= G ? G - 1 : g);
+    const int32_t slot = base[g] + atomicAdd(&cnt[g], 1);
+    const int64_t local = id - (int64_t)g * rows_per_shard;
+    keys[slot] = ((query_base + m) << 32) | (local & 0xffffffffll);
+    // destination of this element's score in the home buffer [pos_score (n_queries) | neg_score (n_queries x n)]
+    pos_out[slot] = c == 0 ? m : n_queries + m * n + (c - 1);
   }
 }
 
@@ -134,9 +140,12 @@ extern "C" int rsa_shard_route(const int64_t* pos_ids, const int64_t* neg_ids, i
   RSA_CHECK_ARG(query_base >= 0 && query_base + n_queries < (1ll << 31), "rsa_shard_route: query index overflow");
   if (n_queries == 0) return RSA_OK;
   RSA_CHECK_ARG(pos_ids && (neg_ids || num_neg == 0) && cursor && keys && positions, "rsa_shard_route: null pointer");
-  hipLaunchKernelGGL(shard_route_kernel, dim3(grid1d(n_queries * (num_neg + 1))), dim3(256), 0, (hipStream_t)stream,
-                     pos_ids, neg_ids, n_queries, (int)num_neg, rows_per_shard, (int)n_shards, query_base, cursor, keys,
-                     positions);
+  const int64_t numel = n_queries * (num_neg + 1);
+  int64_t blocks = (numel + 16383) / 16384;            // >= 16 K elements per workgroup ...
+  if (blocks < 512 && numel > 512 * 1024) blocks = 512;   // ... but keep the chip busy on mid-size batches
+  const int64_t chunk = (numel + blocks - 1) / blocks;
+  hipLaunchKernelGGL(shard_route_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, pos_ids, neg_ids,
+                     n_queries, (int)num_neg, rows_per_shard, (int)n_shards, query_base, chunk, cursor, keys, positions);
   RSA_CHECK_LAUNCH("rsa_shard_route");
   return RSA_OK;
 }

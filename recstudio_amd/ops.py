@@ -44,7 +44,7 @@ def sample_uniform(numel, low, high, device, generator=None):
     return out
 
 
-def sample_popular(table, pop_prob, guide, guide_log2, numel, generator=None, want_u=False):
+def sample_popular(table, pop_prob, guide, guide_log2, numel, generator=None, want_u=False, cdf_lut=None):
     table = _need(table, torch.float32, 'table')
     pop_prob = _need(pop_prob, torch.float32, 'pop_prob')
     guide = _need(guide, torch.int32, 'guide')
@@ -56,11 +56,12 @@ def sample_popular(table, pop_prob, guide, guide_log2, numel, generator=None, wa
         pc = rng.reserve(numel, 4, dev, generator)
         nat.check(nat.lib().rsa_sample_popular(ptr(table), ptr(pop_prob), ptr(guide), table.numel(), int(guide_log2),
                                                ptr(ids), ptr(logp), ptr(u), int(numel), pc.seed, pc.offset,
-                                               pc.grid_threads, _stream()), 'rsa_sample_popular')
+                                               pc.grid_threads, ptr(_need_opt(cdf_lut, torch.float32, 'cdf_lut')),
+                                               _stream()), 'rsa_sample_popular')
     return (ids, logp, u) if want_u else (ids, logp)
 
 
-def popular_lookup(table, pop_prob, guide, guide_log2, u):
+def popular_lookup(table, pop_prob, guide, guide_log2, u, cdf_lut=None):
     table = _need(table, torch.float32, 'table')
     pop_prob = _need(pop_prob, torch.float32, 'pop_prob')
     guide = _need(guide, torch.int32, 'guide')
@@ -68,7 +69,9 @@ def popular_lookup(table, pop_prob, guide, guide_log2, u):
     ids = torch.empty(u.numel(), dtype=torch.int64, device=u.device)
     logp = torch.empty(u.numel(), dtype=torch.float32, device=u.device)
     nat.check(nat.lib().rsa_popular_lookup(ptr(table), ptr(pop_prob), ptr(guide), table.numel(), int(guide_log2),
-                                           ptr(u), ptr(ids), ptr(logp), u.numel(), _stream()), 'rsa_popular_lookup')
+                                           ptr(u), ptr(ids), ptr(logp), u.numel(),
+                                           ptr(_need_opt(cdf_lut, torch.float32, 'cdf_lut')), _stream()),
+              'rsa_popular_lookup')
     return ids.view(u.shape), logp.view(u.shape)
 
 

@@ -126,7 +126,8 @@ class PopularSamplerModel(Sampler):
         with torch.no_grad():
             shape = tuple(query.shape[:-1])
             nq = int(np.prod(shape))
-            neg, neg_prob = ops.sample_popular(self.table, self.pop_prob, self.guide, self.guide_log2, nq * num_neg)
+            neg, neg_prob = ops.sample_popular(self.table, self.pop_prob, self.guide, self.guide_log2, nq * num_neg,
+                                               cdf_lut=getattr(self, 'cdf_lut', None))
             neg = neg.view(*shape, num_neg)
             neg_prob = neg_prob.view(*shape, num_neg)
             if pos_items is not None:

@@ -88,10 +88,12 @@ def test_popular_lookup_golden(ra, golden):
         rel_close(built.table.numpy(), g[f'm{mode}_table'], rtol=2e-6, atol=0)
         for glog in (None, 4, 9, 16):
             ps = ra.PopularSamplerModel.from_tables(T(g[f'm{mode}_pop_prob']), T(g[f'm{mode}_table']), glog).to(DEV)
-            ids, logp = ra.ops.popular_lookup(ps.table, ps.pop_prob, ps.guide, ps.guide_log2, T(g[f'm{mode}_u']).to(DEV))
             want = np.minimum(g[f'm{mode}_ids'], len(counts) - 1)
-            assert np.array_equal(ids.cpu().numpy(), want)
-            rel_close(logp.cpu(), g[f'm{mode}_logp'], rtol=1e-6, atol=1e-7)
+            for lut in (None, ps.cdf_lut):        # binary search inside the guide bucket / direct lookup table
+                ids, logp = ra.ops.popular_lookup(ps.table, ps.pop_prob, ps.guide, ps.guide_log2,
+                                                  T(g[f'm{mode}_u']).to(DEV), cdf_lut=lut)
+                assert np.array_equal(ids.cpu().numpy(), want)
+                rel_close(logp.cpu(), g[f'm{mode}_logp'], rtol=1e-6, atol=1e-7)
     # larger table: ids from this host's build of the table == torch.searchsorted on the same table
     ps = ra.PopularSamplerModel(T(g['big_counts']), mode=0)
     rel_close(ps.table[-64:].numpy(), g['big_table_tail'], rtol=2e-6, atol=0)
