@@ -169,7 +169,7 @@ int rsa_row_lse(const float* x, int64_t n_rows, int64_t n_cols, float* lse, floa
 
 /* Backward of the fused forward for the inner-product scorer == what autograd
  * produces at recommender.py:636-639 (embedding_dense_backward + bmm backward):
- *   item_grad[neg_ids[m,j]] += up * dneg[m,j] * q_m     (skipped for id 0: padding_idx)
+ *   item_grad[neg_ids[m,j]] += up * dneg[m,j] * q_m     (skipped for id == item_pad_row: padding_idx)
  *   item_grad[pos_ids[m]]   += up * dpos[m]   * q_m
  *   query_grad[m]            = up * (dpos[m] * item[pos] + sum_j dneg[m,j] * item[neg_j])
  * item_grad: dense [n_items, dim], accumulated with atomics, caller zero-fills
@@ -194,6 +194,13 @@ typedef struct rsa_backward_args {
   float* item_grad;
   float* item_grad_rows;
   float* query_grad;
+  float* query_table_grad;     /* nullable [n_query_rows, dim], atomics, caller-zeroed: the query gradient accumulated
+                                  at row query_index[m] -- the dense grad of a user-embedding query
+                                  tower in the same launch; also the per-query accumulation of the sharded backward */
+  int32_t query_table_pad_row; /* row of query_table_grad that receives no gradient (padding_idx; 0 for a RecStudio
+                                  user table), -1 = none */
+  int32_t item_pad_row;        /* item row that receives no gradient (padding_idx = 0 in RecStudio); -1 = none (an
+                                  item-table shard that does not hold the global row 0) */
 } rsa_backward_args;
 
 int rsa_fused_backward(const rsa_backward_args* args, rsa_stream_t stream);
@@ -257,6 +264,8 @@ int rsa_shard_route(const int64_t* pos_ids, const int64_t* neg_ids, int64_t n_qu
 int rsa_shard_unpack(const int64_t* keys, int64_t numel, int64_t* local_rows, int64_t* query_index,
                      rsa_stream_t stream);
 int rsa_scatter_f32(const float* src, const int64_t* positions, int64_t numel, float* dst, rsa_stream_t stream);
+/* dst[i] = src[positions[i]]: d loss/d score in routed order for the gradient exchange. */
+int rsa_gather_f32(const float* src, const int64_t* positions, int64_t numel, float* dst, rsa_stream_t stream);
 
 #ifdef __cplusplus
 }

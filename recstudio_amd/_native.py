@@ -47,6 +47,7 @@ class BackwardArgs(Structure):
         ('pos_ids', c_void_p), ('neg_ids', c_void_p), ('n_queries', c_int64),
         ('dpos', c_void_p), ('dneg', c_void_p), ('upstream', c_void_p),
         ('item_grad', c_void_p), ('item_grad_rows', c_void_p), ('query_grad', c_void_p),
+        ('query_table_grad', c_void_p), ('query_table_pad_row', c_int32), ('item_pad_row', c_int32),
     ]
 
 
@@ -78,6 +79,7 @@ SIGNATURES = {
                                 c_void_p, c_void_p]),
     'rsa_shard_unpack': (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     'rsa_scatter_f32': (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
+    'rsa_gather_f32': (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     'rsa_fullscore_workspace_bytes': (c_int64, [c_int64, c_int64, c_int32]),
     'rsa_fullscore': (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
                               c_int32, c_void_p, c_int64, c_void_p]),

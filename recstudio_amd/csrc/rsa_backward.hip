@@ -32,8 +32,9 @@ struct BwdParams {
   float* item_grad;
   float* item_grad_rows;
   float* query_grad;
+  float* query_table_grad;
   int64_t n_items, n_query_rows, n_queries;
-  int32_t dim, num_neg;
+  int32_t dim, num_neg, qpad, ipad;
 };
 
 __device__ __forceinline__ int64_t clamp_id(int64_t id, int64_t n) { return id < 0 ? 0 : (id >= n ? n - 1 : id); }
@@ -65,10 +66,11 @@ __device__ __forceinline__ void tile_bwd_general(const BwdParams& p, int D, int3
       if (GENERIC && col >= D) break;
       const float qa = qrow[col];
       const float xa = irow[col];
-      const float gi = rid != 0 ? rd * qa : 0.f;
-      if (p.item_grad && rid != 0) atomicAdd(p.item_grad + (size_t)rid * D + col, gi);
+      const float gi = rid != p.ipad ? rd * qa : 0.f;
+      if (p.item_grad && rid != p.ipad) atomicAdd(p.item_grad + (size_t)rid * D + col, gi);
       if (p.item_grad_rows) p.item_grad_rows[(size_t)outrow * D + col] = gi;
       if (p.query_grad) atomicAdd(p.query_grad + (size_t)mr * D + col, rd * xa);
+      if (p.query_table_grad && qr != p.qpad) atomicAdd(p.query_table_grad + (size_t)qr * D + col, rd * xa);
     }
   }
 }
@@ -166,7 +168,7 @@ __global__ __launch_bounds__(256) void bwd_qu_kernel(const BwdParams p) {
         const int r = gbase + t0 + u;
         if (p.item_grad_rows) {
           float* orow = p.item_grad_rows + (size_t)(m * (n + 1) + 1 + ((int64_t)tq << 6) + r) * D;
-          const float s = rid[u] != 0 ? rd[u] : 0.f;
+          const float s = rid[u] != p.ipad ? rd[u] : 0.f;
 #pragma unroll
           for (int c = 0; c < CH; ++c) {
             const int col = (c * LPR + sub) * 4;
@@ -175,7 +177,7 @@ __global__ __launch_bounds__(256) void bwd_qu_kernel(const BwdParams p) {
                   make_float4(s * qf[c].x, s * qf[c].y, s * qf[c].z, s * qf[c].w);
           }
         }
-        if (p.item_grad && rid[u] != 0) {
+        if (p.item_grad && rid[u] != p.ipad) {
           float* grow = p.item_grad + (size_t)rid[u] * D;
           for (int c = 0; c < ndw; ++c) {
             const int col = c * LPR + sub;
@@ -221,17 +223,21 @@ __global__ __launch_bounds__(256) void bwd_qu_kernel(const BwdParams p) {
           const float4 x = *reinterpret_cast<const float4*>(p.item_table + (size_t)pid * D + col);
           s.x = __fmaf_rn(dp, x.x, s.x); s.y = __fmaf_rn(dp, x.y, s.y);
           s.z = __fmaf_rn(dp, x.z, s.z); s.w = __fmaf_rn(dp, x.w, s.w);
-          const float sp = pid != 0 ? dp : 0.f;
+          const float sp = pid != p.ipad ? dp : 0.f;
           if (p.item_grad_rows)
             *reinterpret_cast<float4*>(p.item_grad_rows + (size_t)(m * (n + 1)) * D + col) =
                 make_float4(sp * qf[c].x, sp * qf[c].y, sp * qf[c].z, sp * qf[c].w);
-          if (p.item_grad && pid != 0) {
+          if (p.item_grad && pid != p.ipad) {
             float* grow = p.item_grad + (size_t)pid * D + col;
             atomicAdd(grow + 0, dp * qf[c].x); atomicAdd(grow + 1, dp * qf[c].y);
             atomicAdd(grow + 2, dp * qf[c].z); atomicAdd(grow + 3, dp * qf[c].w);
           }
         }
         if (p.query_grad) *reinterpret_cast<float4*>(p.query_grad + (size_t)m * D + col) = s;
+        if (p.query_table_grad && qrow != p.qpad) {   // embedding_dense_backward of the query table, padding row skipped
+          float* g = p.query_table_grad + (size_t)qrow * D + col;
+          atomicAdd(g + 0, s.x); atomicAdd(g + 1, s.y); atomicAdd(g + 2, s.z); atomicAdd(g + 3, s.w);
+        }
       }
     }
   }
@@ -289,7 +295,8 @@ extern "C" int rsa_fused_backward(const rsa_backward_args* a, rsa_stream_t strea
                 "rsa_fused_backward: sizes out of range");
   RSA_CHECK_ARG(a->item_table && a->query && a->neg_ids && a->dneg, "rsa_fused_backward: null input pointer");
   RSA_CHECK_ARG(a->pos_ids == nullptr || a->dpos != nullptr, "rsa_fused_backward: pos_ids without dpos");
-  RSA_CHECK_ARG(a->item_grad || a->item_grad_rows || a->query_grad, "rsa_fused_backward: no output requested");
+  RSA_CHECK_ARG(a->item_grad || a->item_grad_rows || a->query_grad || a->query_table_grad,
+                "rsa_fused_backward: no output requested");
   BwdParams p;
   p.item_table = a->item_table;
   p.query = a->query;
@@ -302,11 +309,14 @@ extern "C" int rsa_fused_backward(const rsa_backward_args* a, rsa_stream_t strea
   p.item_grad = a->item_grad;
   p.item_grad_rows = a->item_grad_rows;
   p.query_grad = a->query_grad;
+  p.query_table_grad = a->query_table_grad;
   p.n_items = a->n_items;
   p.n_query_rows = a->n_query_rows;
   p.n_queries = a->n_queries;
   p.dim = a->dim;
   p.num_neg = a->num_neg;
+  p.qpad = a->query_table_pad_row;
+  p.ipad = a->item_pad_row;
   hipStream_t s = (hipStream_t)stream;
   switch (a->dim) {
     case 32: return launch_bwd<8, false>(p, s);

@@ -104,6 +104,13 @@ __global__ __launch_bounds__(256) void scatter_f32_kernel(const float* __restric
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < numel; i += stride) dst[pos[i]] = src[i];
 }
 
+__global__ __launch_bounds__(256) void gather_f32_kernel(const float* __restrict__ src,
+                                                         const int64_t* __restrict__ pos, int64_t numel,
+                                                         float* __restrict__ dst) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < numel; i += stride) dst[i] = src[pos[i]];
+}
+
 static inline int grid1d(int64_t numel) {
   int64_t b = (numel + 255) / 256;
   return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
@@ -169,5 +176,16 @@ extern "C" int rsa_scatter_f32(const float* src, const int64_t* positions, int64
   hipLaunchKernelGGL(scatter_f32_kernel, dim3(grid1d(numel)), dim3(256), 0, (hipStream_t)stream, src, positions, numel,
                      dst);
   RSA_CHECK_LAUNCH("rsa_scatter_f32");
+  return RSA_OK;
+}
+
+extern "C" int rsa_gather_f32(const float* src, const int64_t* positions, int64_t numel, float* dst,
+                              rsa_stream_t stream) {
+  RSA_CHECK_ARG(numel >= 0, "rsa_gather_f32: numel < 0");
+  if (numel == 0) return RSA_OK;
+  RSA_CHECK_ARG(src && positions && dst, "rsa_gather_f32: null pointer");
+  hipLaunchKernelGGL(gather_f32_kernel, dim3(grid1d(numel)), dim3(256), 0, (hipStream_t)stream, src, positions, numel,
+                     dst);
+  RSA_CHECK_LAUNCH("rsa_gather_f32");
   return RSA_OK;
 }

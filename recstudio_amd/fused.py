@@ -57,10 +57,13 @@ class _ScoreFn(torch.autograd.Function):
             gneg = torch.zeros_like(cfg['out']['neg_score'])
         if pos_ids is not None and (gpos is None or gpos.numel() == 0):
             gpos = torch.zeros(pos_ids.numel(), dtype=torch.float32, device=item_weight.device)
+        # dense user-table gradient straight from the kernel (no [M, d] intermediate, no second launch)
+        qtab = torch.zeros_like(query_src) if (need_q and qi is not None and not sparse) else None
         item_grad, rows, qgrad = ops.fused_backward(
             item_weight, query_src, neg_ids, gneg.contiguous(), query_index=qi, pos_ids=pos_ids,
             dpos=None if pos_ids is None else gpos.contiguous(),
-            dense_item_grad=need_item and not sparse, row_item_grad=need_item and sparse, want_query_grad=need_q)
+            dense_item_grad=need_item and not sparse, row_item_grad=need_item and sparse,
+            want_query_grad=need_q and qtab is None, query_table_grad=qtab)
         g_item = None
         if need_item:
             if sparse:
@@ -76,7 +79,7 @@ class _ScoreFn(torch.autograd.Function):
                 if sparse:
                     g_q = torch.sparse_coo_tensor(qi.view(1, -1), qgrad, query_src.shape)
                 else:
-                    g_q = ops.scatter_add_rows(qgrad, qi, query_src.shape[0])
+                    g_q = qtab
             else:
                 g_q = qgrad
         return g_item, g_q, None
@@ -139,10 +142,11 @@ class _FusedBPRFn(torch.autograd.Function):
         item_weight, query_src, neg_ids, dpos, dneg = ctx.saved_tensors
         qi, pos_ids, sparse = cfg.get('query_index'), cfg['pos_ids'], cfg.get('sparse_grad', False)
         need_item, need_q = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        qtab = torch.zeros_like(query_src) if (need_q and qi is not None and not sparse) else None
         item_grad, rows, qgrad = ops.fused_backward(
             item_weight, query_src, neg_ids, dneg, query_index=qi, pos_ids=pos_ids, dpos=dpos,
             upstream=g.reshape(1).contiguous(), dense_item_grad=need_item and not sparse,
-            row_item_grad=need_item and sparse, want_query_grad=need_q)
+            row_item_grad=need_item and sparse, want_query_grad=need_q and qtab is None, query_table_grad=qtab)
         g_item = g_q = None
         if need_item:
             if sparse:
@@ -157,7 +161,7 @@ class _FusedBPRFn(torch.autograd.Function):
             elif sparse:
                 g_q = torch.sparse_coo_tensor(qi.view(1, -1), qgrad, query_src.shape)
             else:
-                g_q = ops.scatter_add_rows(qgrad, qi, query_src.shape[0])
+                g_q = qtab
         return g_item, g_q, None
 
 

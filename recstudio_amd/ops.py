@@ -217,7 +217,8 @@ def pairwise_loss(kind, pos_score, neg_score, pos_logp=None, neg_logp=None, want
 
 
 def fused_backward(item_table, query, neg_ids, dneg, *, query_index=None, pos_ids=None, dpos=None, upstream=None,
-                   dense_item_grad=True, row_item_grad=False, want_query_grad=True):
+                   dense_item_grad=True, row_item_grad=False, want_query_grad=True, query_table_grad=None,
+                   item_grad_out=None, query_table_pad_row=0, item_pad_row=0):
     """rsa_fused_backward.  Returns (item_grad [N,d] | None, item_grad_rows [M*(n+1), d] | None,
     query_grad [M,d] | None)."""
     item_table = _need(item_table, torch.float32, 'item_table')
@@ -232,7 +233,10 @@ def fused_backward(item_table, query, neg_ids, dneg, *, query_index=None, pos_id
     n_items, dim = item_table.shape
     M = query_index.numel() if query_index is not None else query.shape[0]
     n = neg_ids.numel() // M
-    item_grad = torch.zeros(n_items, dim, dtype=torch.float32, device=dev) if dense_item_grad else None
+    if item_grad_out is not None:          # accumulate into a caller-provided (zeroed or running) dense buffer
+        item_grad = _need(item_grad_out, torch.float32, 'item_grad_out')
+    else:
+        item_grad = torch.zeros(n_items, dim, dtype=torch.float32, device=dev) if dense_item_grad else None
     rows = torch.empty(M * (n + 1), dim, dtype=torch.float32, device=dev) if row_item_grad else None
     if rows is not None and pos_ids is None:
         rows.zero_()
@@ -243,6 +247,9 @@ def fused_backward(item_table, query, neg_ids, dneg, *, query_index=None, pos_id
     a.pos_ids, a.neg_ids, a.n_queries = ptr(pos_ids), ptr(neg_ids), M
     a.dpos, a.dneg, a.upstream = ptr(dpos), ptr(dneg), ptr(upstream)
     a.item_grad, a.item_grad_rows, a.query_grad = ptr(item_grad), ptr(rows), ptr(qgrad)
+    a.query_table_grad = ptr(_need_opt(query_table_grad, torch.float32, 'query_table_grad'))
+    a.query_table_pad_row = int(query_table_pad_row)
+    a.item_pad_row = int(item_pad_row)
     nat.check(nat.lib().rsa_fused_backward(ctypes.byref(a), _stream()), 'rsa_fused_backward')
     return item_grad, rows, qgrad
 

@@ -88,6 +88,24 @@ class HipBackend:
                   'rsa_scatter_f32')
         return dst
 
+    def gather(self, src, positions):
+        dst = torch.empty(positions.numel(), dtype=torch.float32, device=src.device)
+        nat.check(nat.lib().rsa_gather_f32(ptr(src), ptr(positions), positions.numel(), ptr(dst), ops._stream()),
+                  'rsa_gather_f32')
+        return dst
+
+    def backward_keys(self, item_local, q_all, keys, dscore, item_grad_local, qgrad_all, item_pad_row=-1):
+        """Owner side of the backward: item_grad_local[row] += d * q_all[qidx]; qgrad_all[qidx] += d * item_local[row]."""
+        m = keys.numel()
+        if m == 0:
+            return
+        rows = torch.empty(m, dtype=torch.int64, device=keys.device)
+        qidx = torch.empty(m, dtype=torch.int64, device=keys.device)
+        nat.check(nat.lib().rsa_shard_unpack(ptr(keys), m, ptr(rows), ptr(qidx), ops._stream()), 'rsa_shard_unpack')
+        ops.fused_backward(item_local, q_all, rows.view(m, 1), dscore.view(m, 1), query_index=qidx,
+                           dense_item_grad=False, want_query_grad=False, item_grad_out=item_grad_local,
+                           query_table_grad=qgrad_all, query_table_pad_row=-1, item_pad_row=item_pad_row)
+
 
 class ShardedItemTable:
     def __init__(self, item_local, plan, rank, dist, backend=None, group=None):
@@ -117,7 +135,29 @@ class ShardedItemTable:
         return out
 
     # -- the step ---------------------------------------------------------------------------------
-    def score_ids(self, q, pos, neg):
+    def _reduce_scatter_rows(self, x, rows_per_rank):
+        out = torch.empty(rows_per_rank, *x.shape[1:], dtype=x.dtype, device=x.device)
+        self.dist.reduce_scatter_tensor(out, x.contiguous(), group=self.group)
+        return out
+
+    def backward(self, route, dpos, dneg, item_grad_local):
+        """Gradient exchange for one step.  ``route`` comes from
+        ``score_ids(..., keep_route=True)``; ``dpos [B]`` / ``dneg [B, n]`` = d loss / d score on the home
+        rank.  Accumulates this shard's dense item gradient into ``item_grad_local [rows_local, d]`` (no
+        communication: rows never leave their owner) and returns d loss / d q for the own queries [B, d]
+        (reduce-scatter of the per-owner partial sums)."""
+        B = route['B']
+        dflat = torch.cat([dpos.reshape(-1), dneg.reshape(-1)])
+        d_sorted = self.backend.gather(dflat, route['positions'])
+        d_owner = self._all_to_all(d_sorted, route['recv_counts'], route['send_counts'])
+        q_all = route['q_all']
+        qgrad_all = torch.zeros_like(q_all)
+        # only shard 0 holds the global padding row (item id 0), which never receives gradient
+        self.backend.backward_keys(self.item_local, q_all, route['recv_keys'], d_owner, item_grad_local, qgrad_all,
+                                   item_pad_row=0 if self.rank == 0 else -1)
+        return self._reduce_scatter_rows(qgrad_all, B)
+
+    def score_ids(self, q, pos, neg, keep_route=False):
         """q [B, d] own queries, pos [B], neg [B, n] GLOBAL item ids -> (pos_score [B], neg_score [B, n])."""
         B, n = neg.shape
         plan = self.plan
@@ -130,13 +170,20 @@ class ShardedItemTable:
         scores_owner = self.backend.score_keys(self.item_local, q_all, recv_keys)
         scores_home = self._all_to_all(scores_owner, send_counts, recv_counts)
         flat = self.backend.scatter(scores_home, positions, B * (n + 1))
+        if keep_route:
+            route = {'B': B, 'n': n, 'q_all': q_all, 'positions': positions, 'recv_keys': recv_keys,
+                     'send_counts': send_counts, 'recv_counts': recv_counts}
+            return flat[:B], flat[B:].view(B, n), route
         return flat[:B], flat[B:].view(B, n)
 
-    def sample_and_score(self, user_table, uid, pos, n, sampler):
+    def sample_and_score(self, user_table, uid, pos, n, sampler, keep_route=False):
         """BaseRetriever.forward for a user-embedding query tower against the sharded item table."""
         B = uid.numel()
         q = self.backend.gather_rows(user_table, uid)
         log_pos, neg, log_neg = self.backend.sample(sampler, B, n, uid.device, pos)
-        pos_score, neg_score = self.score_ids(q, pos, neg)
-        return {'pos_score': pos_score, 'neg_score': neg_score, 'neg_ids': neg, 'log_pos_prob': log_pos,
-                'log_neg_prob': log_neg, 'query': q}
+        res = self.score_ids(q, pos, neg, keep_route)
+        out = {'pos_score': res[0], 'neg_score': res[1], 'neg_ids': neg, 'log_pos_prob': log_pos,
+               'log_neg_prob': log_neg, 'query': q}
+        if keep_route:
+            out['route'] = res[2]
+        return out

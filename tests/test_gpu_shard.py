@@ -67,5 +67,14 @@ def test_world1_rccl_step_equals_unsharded():
             np.testing.assert_allclose(out['pos_score'].cpu(), score['pos_score'].cpu(), rtol=1e-5, atol=1e-6)
             want_p, want_n = oracle.retriever_forward(item.cpu(), user.cpu()[uid.cpu()], pos.cpu(), ids.cpu())
             np.testing.assert_allclose(out['neg_score'].cpu(), want_n, rtol=1e-4, atol=1e-6)
+            # gradient exchange == the unsharded backward
+            torch.manual_seed(11)
+            out = table.sample_and_score(user, uid, pos, n, sampler, keep_route=True)
+            loss, dpos, dneg, _ = ra.ops.pairwise_loss(ra._native.LOSS_BPR, out['pos_score'], out['neg_score'])
+            ig = torch.zeros_like(item)
+            qg = table.backward(out['route'], dpos, dneg, ig)
+            ig2, _, qg2 = ra.ops.fused_backward(item, user, out['neg_ids'], dneg, query_index=uid, pos_ids=pos, dpos=dpos)
+            np.testing.assert_allclose(qg.cpu(), qg2.cpu(), rtol=2e-4, atol=1e-8)
+            np.testing.assert_allclose(ig.cpu(), ig2.cpu(), rtol=2e-4, atol=1e-8)
     finally:
         dist.destroy_process_group()

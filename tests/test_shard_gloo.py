@@ -48,6 +48,15 @@ class CheckerBackend:
         out[positions] = scores
         return out
 
+    def gather(self, src, positions):
+        return src[positions]
+
+    def backward_keys(self, item_local, q_all, keys, dscore, item_grad_local, qgrad_all, item_pad_row=-1):
+        rows, qidx = keys & 0xffffffff, keys >> 32
+        live = rows != item_pad_row
+        item_grad_local.index_add_(0, rows[live], dscore[live].unsqueeze(1) * q_all[qidx[live]])
+        qgrad_all.index_add_(0, qidx, dscore.unsqueeze(1) * item_local[rows])
+
 
 def _free_port():
     s = socket.socket()
@@ -79,6 +88,23 @@ def _worker(rank, world, port, n_items, d, B, n, result_dir):
         want_pos, want_neg = oracle.retriever_forward(item, user[uid], pos, out['neg_ids'])
         np.testing.assert_allclose(out['pos_score'].numpy(), want_pos.numpy(), rtol=1e-6, atol=1e-6)
         np.testing.assert_allclose(out['neg_score'].numpy(), want_neg.numpy(), rtol=1e-6, atol=1e-6)
+        # gradient exchange: item grads stay on the owner, query grads come home by reduce-scatter
+        out = table.sample_and_score(user, uid, pos, n, sampler, keep_route=True)
+        gg = torch.Generator().manual_seed(500 + rank)
+        dpos, dneg = torch.randn(B, generator=gg), torch.randn(B, n, generator=gg)
+        item_grad_local = torch.zeros(hi - lo, d)
+        qgrad = table.backward(out['route'], dpos, dneg, item_grad_local)
+        neg_ids = out['neg_ids']
+        want_q = dpos.unsqueeze(1) * item[pos] + (dneg.unsqueeze(-1) * item[neg_ids]).sum(1)
+        np.testing.assert_allclose(qgrad.numpy(), want_q.numpy(), rtol=1e-5, atol=1e-5)
+        # the dense item gradient summed over ALL ranks' contributions == single-process scatter-add
+        contrib = torch.zeros(n_items, d)
+        qv = user[uid]
+        contrib.index_add_(0, pos, dpos.unsqueeze(1) * qv)
+        contrib.index_add_(0, neg_ids.reshape(-1), (dneg.unsqueeze(-1) * qv.unsqueeze(1)).reshape(-1, d))
+        dist.all_reduce(contrib)                        # what every rank contributed, anywhere
+        contrib[0] = 0                                  # padding row: no gradient
+        np.testing.assert_allclose(item_grad_local.numpy(), contrib[lo:hi].numpy(), rtol=1e-5, atol=1e-5)
         # skewed ids: everything owned by the last rank, and an empty segment for rank 0
         neg2 = torch.full((B, n), n_items - 1, dtype=torch.int64)
         pos2 = torch.full((B,), n_items - 2, dtype=torch.int64)
