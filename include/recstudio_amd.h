@@ -167,7 +167,8 @@ int rsa_mean_rows(const float* row_loss, int64_t n_rows, float* out, rsa_stream_
 int rsa_row_lse(const float* x, int64_t n_rows, int64_t n_cols, float* lse, float* softmax_scaled,
                 float scale, rsa_stream_t stream);
 
-/* Backward of the fused forward for the inner-product scorer == what autograd
+/* Backward of the fused forward (shown for the inner-product scorer; RSA_SCORE_COS applies the cosine
+ * chain rule instead) == what autograd
  * produces at recommender.py:636-639 (embedding_dense_backward + bmm backward):
  *   item_grad[neg_ids[m,j]] += up * dneg[m,j] * q_m     (skipped for id == item_pad_row: padding_idx)
  *   item_grad[pos_ids[m]]   += up * dpos[m]   * q_m
@@ -201,6 +202,8 @@ typedef struct rsa_backward_args {
                                   user table), -1 = none */
   int32_t item_pad_row;        /* item row that receives no gradient (padding_idx = 0 in RecStudio); -1 = none (an
                                   item-table shard that does not hold the global row 0) */
+  int32_t score_mode;          /* rsa_score_mode: RSA_SCORE_IP (tuned kernels) or RSA_SCORE_COS (plain kernel) */
+  int32_t _pad;
 } rsa_backward_args;
 
 int rsa_fused_backward(const rsa_backward_args* args, rsa_stream_t stream);

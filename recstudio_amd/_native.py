@@ -48,6 +48,7 @@ class BackwardArgs(Structure):
         ('dpos', c_void_p), ('dneg', c_void_p), ('upstream', c_void_p),
         ('item_grad', c_void_p), ('item_grad_rows', c_void_p), ('query_grad', c_void_p),
         ('query_table_grad', c_void_p), ('query_table_pad_row', c_int32), ('item_pad_row', c_int32),
+        ('score_mode', c_int32), ('_pad', c_int32),
     ]
 
 

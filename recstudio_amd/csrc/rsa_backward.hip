@@ -243,6 +243,54 @@ __global__ __launch_bounds__(256) void bwd_qu_kernel(const BwdParams p) {
   }
 }
 
+// ------------------------------------------------------------------ cosine scorer
+// score = <q, x> / (|x| |q|)  (scorer.py:19-25, no epsilon):
+//   d score / d x = q / (|x||q|) - score * x / |x|^2        d score / d q = x / (|x||q|) - score * q / |q|^2
+// One wave per (query, item) element, positives included as column 0; a plain kernel -- cosine training
+// is not the path the byte model is built around.
+__global__ __launch_bounds__(256) void bwd_cos_kernel(const BwdParams p) {
+  const int lane = lane_id();
+  const int D = p.dim;
+  const int64_t n = p.num_neg, w = p.pos_ids ? n + 1 : n;
+  const int64_t numel = p.n_queries * w;
+  const float up = p.upstream ? p.upstream[0] : 1.f;
+  const int64_t wave0 = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int64_t wstride = (int64_t)gridDim.x * (blockDim.x >> 6);
+  for (int64_t e = wave0; e < numel; e += wstride) {
+    const int64_t m = e / w;
+    const int c = (int)(e - m * w);
+    const bool is_pos = p.pos_ids != nullptr && c == 0;
+    const int64_t j = p.pos_ids ? c - 1 : c;
+    const int64_t id = clamp_id(is_pos ? p.pos_ids[m] : p.neg_ids[m * n + j], p.n_items);
+    const float d = (is_pos ? p.dpos[m] : p.dneg[m * n + j]) * up;
+    const int64_t qrow = p.query_index ? p.query_index[m] : m;
+    const float* x = p.item_table + (size_t)id * D;
+    const float* q = p.query + (size_t)qrow * D;
+    float dot = 0.f, nx2 = 0.f, nq2 = 0.f;
+    for (int col = lane; col < D; col += 64) {
+      const float xv = x[col], qv = q[col];
+      dot = __fmaf_rn(xv, qv, dot);
+      nx2 = __fmaf_rn(xv, xv, nx2);
+      nq2 = __fmaf_rn(qv, qv, nq2);
+    }
+    dot = group_sum<64>(dot);
+    nx2 = group_sum<64>(nx2);
+    nq2 = group_sum<64>(nq2);
+    const float inv = 1.f / (sqrtf(nx2) * sqrtf(nq2));
+    const float sc = dot * inv;
+    const int64_t outrow = m * (n + 1) + (is_pos ? 0 : 1 + j);
+    for (int col = lane; col < D; col += 64) {
+      const float xv = x[col], qv = q[col];
+      const float gx = id != p.ipad ? d * (qv * inv - sc * xv / nx2) : 0.f;
+      const float gq = d * (xv * inv - sc * qv / nq2);
+      if (p.item_grad && id != p.ipad) atomicAdd(p.item_grad + (size_t)id * D + col, gx);
+      if (p.item_grad_rows) p.item_grad_rows[(size_t)outrow * D + col] = gx;
+      if (p.query_grad) atomicAdd(p.query_grad + (size_t)m * D + col, gq);
+      if (p.query_table_grad && qrow != p.qpad) atomicAdd(p.query_table_grad + (size_t)qrow * D + col, gq);
+    }
+  }
+}
+
 // ------------------------------------------------------------------ embedding_dense_backward
 __global__ __launch_bounds__(256) void scatter_add_rows_kernel(const float* __restrict__ src,
                                                                const int64_t* __restrict__ ids, int64_t numel,
@@ -318,6 +366,21 @@ extern "C" int rsa_fused_backward(const rsa_backward_args* a, rsa_stream_t strea
   p.qpad = a->query_table_pad_row;
   p.ipad = a->item_pad_row;
   hipStream_t s = (hipStream_t)stream;
+  if (a->score_mode == RSA_SCORE_COS) {
+    if (p.query_grad) {
+      if (hipMemsetAsync(p.query_grad, 0, (size_t)p.n_queries * p.dim * sizeof(float), s) != hipSuccess) {
+        rsa::set_error("rsa_fused_backward: memset failed");
+        return RSA_ERR_HIP;
+      }
+    }
+    const int64_t numel = p.n_queries * (p.num_neg + (p.pos_ids ? 1 : 0));
+    int64_t blocks = (numel + 3) / 4;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(bwd_cos_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p);
+    RSA_CHECK_LAUNCH("rsa_fused_backward(cosine)");
+    return RSA_OK;
+  }
+  RSA_CHECK_ARG(a->score_mode == RSA_SCORE_IP, "rsa_fused_backward: unknown score_mode %d", a->score_mode);
   switch (a->dim) {
     case 32: return launch_bwd<8, false>(p, s);
     case 64: return launch_bwd<16, false>(p, s);

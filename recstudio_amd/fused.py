@@ -46,8 +46,6 @@ class _ScoreFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gpos, gneg):
         cfg = ctx.cfg
-        if cfg.get('cosine', False):
-            raise NotImplementedError('backward of the cosine scorer is not implemented in this build')
         item_weight, query_src, neg_ids = ctx.saved_tensors
         qi, pos_ids = cfg.get('query_index'), cfg.get('pos_ids')
         sparse = cfg.get('sparse_grad', False)
@@ -63,7 +61,7 @@ class _ScoreFn(torch.autograd.Function):
             item_weight, query_src, neg_ids, gneg.contiguous(), query_index=qi, pos_ids=pos_ids,
             dpos=None if pos_ids is None else gpos.contiguous(),
             dense_item_grad=need_item and not sparse, row_item_grad=need_item and sparse,
-            want_query_grad=need_q and qtab is None, query_table_grad=qtab)
+            want_query_grad=need_q and qtab is None, query_table_grad=qtab, cosine=cfg.get('cosine', False))
         g_item = None
         if need_item:
             if sparse:

@@ -218,7 +218,7 @@ def pairwise_loss(kind, pos_score, neg_score, pos_logp=None, neg_logp=None, want
 
 def fused_backward(item_table, query, neg_ids, dneg, *, query_index=None, pos_ids=None, dpos=None, upstream=None,
                    dense_item_grad=True, row_item_grad=False, want_query_grad=True, query_table_grad=None,
-                   item_grad_out=None, query_table_pad_row=0, item_pad_row=0):
+                   item_grad_out=None, query_table_pad_row=0, item_pad_row=0, cosine=False):
     """rsa_fused_backward.  Returns (item_grad [N,d] | None, item_grad_rows [M*(n+1), d] | None,
     query_grad [M,d] | None)."""
     item_table = _need(item_table, torch.float32, 'item_table')
@@ -250,6 +250,7 @@ def fused_backward(item_table, query, neg_ids, dneg, *, query_index=None, pos_id
     a.query_table_grad = ptr(_need_opt(query_table_grad, torch.float32, 'query_table_grad'))
     a.query_table_pad_row = int(query_table_pad_row)
     a.item_pad_row = int(item_pad_row)
+    a.score_mode = nat.SCORE_COS if cosine else nat.SCORE_IP
     nat.check(nat.lib().rsa_fused_backward(ctypes.byref(a), _stream()), 'rsa_fused_backward')
     return item_grad, rows, qgrad
 

@@ -30,14 +30,15 @@ class _RowScoreFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        if ctx.cosine:
-            raise NotImplementedError('backward of the cosine scorer is not implemented in this build')
         q2, rows = ctx.saved_tensors
         M, d = q2.shape
-        r3 = rows.view(M, ctx.n, d)
-        gq = (g.unsqueeze(-1) * r3).sum(1) if ctx.needs_input_grad[0] else None
-        gr = (g.unsqueeze(-1) * q2.unsqueeze(1)).reshape(-1, d) if ctx.needs_input_grad[1] else None
-        return gq, gr, None, None
+        ids = torch.arange(rows.shape[0], device=rows.device, dtype=torch.int64).view(M, ctx.n)
+        _, grows, gq = ops.fused_backward(rows, q2, ids, g.reshape(M, ctx.n).contiguous(), dense_item_grad=False,
+                                          row_item_grad=True, want_query_grad=True, item_pad_row=-1,
+                                          cosine=ctx.cosine)
+        # row-sparse layout is [M, 1 + n, d] with an (unused) positive slot per query
+        gr = grows.view(M, ctx.n + 1, d)[:, 1:].reshape(-1, d)
+        return (gq if ctx.needs_input_grad[0] else None), (gr if ctx.needs_input_grad[1] else None), None, None
 
 
 class InnerProductScorer(torch.nn.Module):

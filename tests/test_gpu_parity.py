@@ -461,3 +461,33 @@ def test_fused_bpr_epilogue_matches_separate_loss_and_oracle(ra, n, kind):
         _, ids2 = ra.retriever_scores(iw.to(DEV), uw.to(DEV), n, query_index=uid.to(DEV), pos_ids=pos.to(DEV),
                                       sampler=sampler, neg_ids=neg_given)
         assert torch.equal(ids, ids2)
+
+
+@pytest.mark.parametrize('d,n', [(64, 5), (128, 64), (100, 3)])
+def test_cosine_backward_vs_oracle(ra, d, n):
+    N, U, B = 301, 40, 17
+    iw, uw = _tables(N, U, d, d + n)
+    iw[0] = 0
+    g = torch.Generator().manual_seed(n)
+    uid = torch.randint(1, U, (B,), generator=g)
+    pos = torch.randint(1, N, (B,), generator=g)
+    neg = torch.randint(1, N, (B, n), generator=g)        # no padding ids: the reference yields NaN for them
+    val, ps, ns, gi, gu = oracle.dense_grads(iw, uw, uid, pos, neg, loss='bpr', cosine=True)
+    iwd, uwd = iw.to(DEV).requires_grad_(True), uw.to(DEV).requires_grad_(True)
+    score, _ = ra.retriever_scores(iwd, uwd, n, query_index=uid.to(DEV), pos_ids=pos.to(DEV), neg_ids=neg.to(DEV),
+                                   cosine=True)
+    loss = ra.BPRLoss()(None, score['pos_score'], None, score['neg_score'], None)
+    rel_close(loss.detach().cpu(), val, rtol=1e-5)
+    loss.backward()
+    rel_close(iwd.grad.cpu(), gi, rtol=3e-4, atol=1e-7)
+    rel_close(uwd.grad.cpu(), gu, rtol=3e-4, atol=1e-7)
+    # the scorer plugin on materialised vectors is differentiable too (both scorers)
+    for cls, ofn in ((ra.CosineScorer, oracle.cosine_score), (ra.InnerProductScorer, oracle.inner_product_score)):
+        q = uw[uid].clone().requires_grad_(True)
+        it = iw[neg].clone().requires_grad_(True)
+        ofn(q, it).square().sum().backward()
+        qd = uw[uid].to(DEV).requires_grad_(True)
+        itd = iw[neg].to(DEV).requires_grad_(True)
+        cls()(qd, itd).square().sum().backward()
+        rel_close(qd.grad.cpu(), q.grad, rtol=3e-4, atol=1e-6)
+        rel_close(itd.grad.cpu(), it.grad, rtol=3e-4, atol=1e-6)
