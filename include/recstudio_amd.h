@@ -40,7 +40,7 @@ enum rsa_status {
 
 enum rsa_score_mode { RSA_SCORE_IP = 0, RSA_SCORE_COS = 1 };
 enum rsa_sampler_kind { RSA_SAMPLER_GIVEN = 0, RSA_SAMPLER_UNIFORM = 1, RSA_SAMPLER_POPULAR = 2 };
-enum rsa_loss_kind { RSA_LOSS_BPR = 0, RSA_LOSS_SSM = 1 };
+enum rsa_loss_kind { RSA_LOSS_BPR = 0, RSA_LOSS_SSM = 1, RSA_LOSS_BCE = 2 };
 
 const char* rsa_last_error(void);
 int rsa_abi_version(void);
@@ -63,6 +63,15 @@ int rsa_device_info(int device, int32_t* cu_count, int32_t* max_threads_per_cu, 
  * neg_ids[numel] <- low + philox % (high - low). */
 int rsa_sample_uniform(int64_t* neg_ids, int64_t numel, int64_t low, int64_t high,
                        uint64_t seed, uint64_t offset, uint32_t grid_threads, rsa_stream_t stream);
+
+/* MaskedUniformSampler.forward / uniform_sample_masked_hist -- recstudio/ann/sampler.py:117-147, :187-214:
+ * rejection-free uniform negatives over the items NOT in each user's 0-padded history
+ * user_hist [n_rows, hist_len] (hist_len <= 2048).  num_items excludes the padding id.  neg_ids
+ * [n_rows, per_row] (per_row = queries-per-user x num_neg); u = torch.rand(n_rows, per_row) on the
+ * device stream. */
+int rsa_sample_masked_uniform(const int64_t* user_hist, int64_t n_rows, int32_t hist_len, int64_t num_items,
+                              int32_t per_row, int64_t* neg_ids, uint64_t seed, uint64_t offset,
+                              uint32_t grid_threads, rsa_stream_t stream);
 
 /* PopularSamplerModel.forward -- recstudio/ann/sampler.py:243-258
  * (u = torch.rand; ids = torch.searchsorted(table, u); logp = log(pop_prob[ids])).
@@ -149,7 +158,7 @@ typedef struct rsa_fused_args {
 int rsa_fused_sample_gather_score(const rsa_fused_args* args, rsa_stream_t stream);
 
 /* BPRLoss.forward (recstudio/model/loss_func.py:55-59) / SampledSoftmaxLoss.forward
- * (:80-90) on pos_score [M], neg_score [M, n] (each positive with its own n
+ * (:80-90) / BinaryCrossEntropyLoss.forward (:105-127, dns=False) on pos_score [M], neg_score [M, n] (each positive with its own n
  * negatives), value AND gradient in one pass.  pos_logp / neg_logp are nullable
  * (treated as 0; the reference's UniformSampler hands int64 zeros).  loss_out[1]
  * = mean over rows; row_loss [M] scratch/out; dpos [M] and dneg [M, n] (nullable)
@@ -157,6 +166,13 @@ int rsa_fused_sample_gather_score(const rsa_fused_args* args, rsa_stream_t strea
 int rsa_pairwise_loss(int32_t loss_kind, const float* pos_score, const float* neg_score,
                       const float* pos_logp, const float* neg_logp, int64_t n_rows, int32_t num_neg,
                       float* row_loss, float* loss_out, float* dpos, float* dneg, rsa_stream_t stream);
+
+/* SampledSoftmaxLoss.forward when pos_score [B, L] and neg_score [B, n] have the SAME rank
+ * (recstudio/model/loss_func.py:84-89): the L positives of a row share its n negatives; padded
+ * positives (+-inf) contribute nothing and are not counted.  Value + gradients in one pass. */
+int rsa_ssm_shared_loss(const float* pos_score, const float* pos_logp, const float* neg_score,
+                        const float* neg_logp, int64_t n_rows, int32_t n_pos, int32_t num_neg,
+                        float* row_loss, float* loss_out, float* dpos, float* dneg, rsa_stream_t stream);
 
 /* out[0] = mean(row_loss[0..n_rows)) in a fixed summation order (two tiny launches). */
 int rsa_mean_rows(const float* row_loss, int64_t n_rows, float* out, rsa_stream_t stream);

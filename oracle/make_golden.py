@@ -125,6 +125,12 @@ def gen_loss(loss_func):
     # large magnitudes (stability of logsigmoid / logsumexp)
     run('bpr_big', loss_func.BPRLoss(), pos_score=pos * 30, log_pos_prob=lpp, neg_score=neg * 30, log_neg_prob=lnp)
     run('ssm_big', loss_func.SampledSoftmaxLoss(), pos_score=pos * 30, log_pos_prob=lpp, neg_score=neg * 30, log_neg_prob=lnp)
+    # BinaryCrossEntropyLoss (SASRec's default, seq/sasrec.py:117-119), incl. padded (-inf) positives
+    run('bce_1d', loss_func.BinaryCrossEntropyLoss(), pos_score=pos, log_pos_prob=lpp, neg_score=neg, log_neg_prob=lnp)
+    pos4 = pos2.clone()
+    pos4[0, 1] = -float('inf')
+    pos4[5, 2] = -float('inf')
+    run('bce_2d_pad', loss_func.BinaryCrossEntropyLoss(), pos_score=pos4, log_pos_prob=lpp2, neg_score=neg2, log_neg_prob=lnp2)
     alls = torch.randn(B, 50, generator=g)
     run('softmax_full', loss_func.SoftmaxLoss(), pos_score=pos, all_score=alls)
     np.savez_compressed(os.path.join(OUT, 'loss.npz'), **out)
@@ -151,6 +157,27 @@ def gen_uniform(sampler):
     torch.manual_seed(9)
     neg, npb = us(15, 7, device=torch.device('cpu'))
     out['qint_neg'] = np_(neg)
+    # MaskedUniformSampler / uniform_sample_masked_hist (sampler.py:117-147, :187-214)
+    g = torch.Generator().manual_seed(31)
+    Nm, Bm, Lh, nm = 60, 9, 12, 40
+    hist = torch.zeros(Bm, Lh, dtype=torch.int64)
+    for b in range(Bm):
+        m = int(torch.randint(0, Lh + 1, (1,), generator=g))
+        hist[b, :m] = torch.randperm(Nm - 1, generator=g)[:m] + 1
+    hist[3] = hist[3][torch.randperm(Lh, generator=g)]        # padding not at the end
+    torch.manual_seed(77)
+    u = torch.rand(Bm, nm)
+    torch.manual_seed(77)
+    neg = sampler.uniform_sample_masked_hist(num_items=Nm - 1, num_neg=nm, user_hist=hist)
+    torch.manual_seed(78)
+    u3 = torch.rand(Bm, 3 * 5)
+    torch.manual_seed(78)
+    neg3 = sampler.uniform_sample_masked_hist(num_items=Nm - 1, num_neg=5, user_hist=hist, num_query_per_user=3)
+    out.update(mask_N=Nm, mask_hist=np_(hist), mask_u=np_(u), mask_neg=np_(neg), mask_u3=np_(u3), mask_neg3=np_(neg3))
+    ms = sampler.MaskedUniformSampler(Nm)
+    torch.manual_seed(79)
+    pp, ng, npb = ms(torch.zeros(Bm, 4), nm, torch.ones(Bm, dtype=torch.int64), hist)
+    out.update(mask_fw_neg=np_(ng), mask_fw_negprob=np_(npb), mask_fw_posprob=np_(pp))
     np.savez_compressed(os.path.join(OUT, 'uniform.npz'), **out)
 
 

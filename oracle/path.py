@@ -116,6 +116,25 @@ class PopularSamplerModel:
         return neg, neg_prob
 
 
+def masked_uniform_from_u(num_items, num_neg, user_hist, u, num_query_per_user=None):
+    """recstudio/ann/sampler.py:117-147 with the uniforms given: rejection-free uniform sampling over the
+    items NOT in each user's (0-padded) history.  ``num_items`` excludes the padding id."""
+    n_q = 1 if num_query_per_user is None else num_query_per_user
+    num_user, hist_len = user_hist.shape
+    u = torch.as_tensor(u, dtype=torch.float32).view(num_user, n_q * num_neg)
+    nz = torch.count_nonzero(user_hist, dim=-1)
+    neg = torch.floor(u * (num_items - nz).view(-1, 1)).long() + 1                 # :133
+    sorted_hist, _ = user_hist.sort(dim=-1)
+    offset = torch.arange(hist_len).repeat(num_user, 1) - (hist_len - nz).view(-1, 1)
+    offset[offset < 0] = 0
+    sorted_hist = sorted_hist - offset                                             # :134-138
+    masked_offset = torch.searchsorted(sorted_hist, neg, right=True)               # :139
+    neg = neg + (masked_offset - (hist_len - nz).view(-1, 1))                      # :140-141
+    if num_query_per_user is not None:
+        neg = neg.reshape(num_user, num_query_per_user, num_neg)
+    return neg
+
+
 # --------------------------------------------------------------------------- scorers
 def inner_product_score(query, items):
     """recstudio/model/scorer.py:5-17 -- dispatch on shapes exactly as the reference."""
@@ -158,6 +177,19 @@ def sampled_softmax_loss(pos_score, log_pos_prob, neg_score, log_neg_prob):
     notpad = torch.logical_not(torch.isinf(new_pos)).float().sum(-1)
     out = torch.nan_to_num(out, posinf=0).sum(-1) / notpad
     return out.mean()
+
+
+def bce_loss(pos_score, neg_score):
+    """recstudio/model/loss_func.py:105-127 (dns=False; weight = 1/n, :129-130)."""
+    weight = torch.ones_like(neg_score) / neg_score.size(-1)
+    pad = torch.isinf(pos_score)
+    pos_loss = torch.nn.functional.logsigmoid(pos_score).masked_fill(pad, 0.0).sum() / (~pad).sum()
+    neg_loss = (torch.nn.functional.softplus(neg_score) * weight).sum(-1)
+    if pos_score.dim() == neg_score.dim() - 1:
+        neg_loss = neg_loss.masked_fill(pad, 0.0).sum() / (~pad).sum()
+    else:
+        neg_loss = neg_loss.mean()
+    return -pos_loss + neg_loss
 
 
 def softmax_loss(pos_score, all_score):

@@ -7,10 +7,10 @@ computation on the path runs in hand-written HIP kernels reached through the C A
 fallback: calling an op without the built library or with CPU tensors raises.
 """
 from . import _native, ops, rng                                  # noqa: F401
-from .sampler import Sampler, UniformSampler, PopularSamplerModel    # noqa: F401
+from .sampler import Sampler, UniformSampler, MaskedUniformSampler, PopularSamplerModel    # noqa: F401
 from .scorer import InnerProductScorer, CosineScorer              # noqa: F401
 from .loss_func import (FullScoreLoss, PairwiseLoss, PointwiseLoss, BPRLoss,   # noqa: F401
-                        SampledSoftmaxLoss, SoftmaxLoss)
+                        SampledSoftmaxLoss, SoftmaxLoss, BinaryCrossEntropyLoss)
 from .fused import retriever_scores                               # noqa: F401
 from .dataset import TripletDataset, SeqDataset, DataSampler, SortedDataSampler   # noqa: F401
 from .retriever import (BaseRetriever, TwoTowerRecommender, ItemTowerRecommender, BPR, SASRec,   # noqa: F401

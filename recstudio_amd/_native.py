@@ -16,7 +16,7 @@ CSRC = os.path.join(HERE, 'csrc')
 RSA_OK = 0
 SCORE_IP, SCORE_COS = 0, 1
 SAMPLER_GIVEN, SAMPLER_UNIFORM, SAMPLER_POPULAR = 0, 1, 2
-LOSS_BPR, LOSS_SSM = 0, 1
+LOSS_BPR, LOSS_SSM, LOSS_BCE = 0, 1, 2
 
 
 class NativeError(RuntimeError):
@@ -58,6 +58,8 @@ SIGNATURES = {
     'rsa_abi_version': (c_int, []),
     'rsa_device_info': (c_int, [c_int, POINTER(c_int32), POINTER(c_int32), POINTER(c_int32)]),
     'rsa_sample_uniform': (c_int, [c_void_p, c_int64, c_int64, c_int64, c_uint64, c_uint64, c_uint32, c_void_p]),
+    'rsa_sample_masked_uniform': (c_int, [c_void_p, c_int64, c_int32, c_int64, c_int32, c_void_p, c_uint64, c_uint64,
+                                          c_uint32, c_void_p]),
     'rsa_sample_popular': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p,
                                    c_int64, c_uint64, c_uint64, c_uint32, c_void_p, c_void_p]),
     'rsa_popular_lookup': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p,
@@ -67,6 +69,8 @@ SIGNATURES = {
     'rsa_fused_sample_gather_score': (c_int, [POINTER(FusedArgs), c_void_p]),
     'rsa_pairwise_loss': (c_int, [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p,
                                   c_void_p, c_void_p, c_void_p, c_void_p]),
+    'rsa_ssm_shared_loss': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p,
+                                    c_void_p, c_void_p, c_void_p, c_void_p]),
     'rsa_mean_rows': (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
     'rsa_row_lse': (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_float, c_void_p]),
     'rsa_fused_backward': (c_int, [POINTER(BackwardArgs), c_void_p]),

@@ -101,13 +101,105 @@ __global__ __launch_bounds__(256) void mean_rows_stage1(const float* __restrict_
 }
 
 __global__ __launch_bounds__(256) void mean_rows_stage2(const float* __restrict__ partial, int n_part, int64_t M,
-                                                        float* __restrict__ out) {
+                                                        const int32_t* __restrict__ denom, float* __restrict__ out) {
   __shared__ float part[4];
   float acc = threadIdx.x < n_part ? partial[threadIdx.x] : 0.f;
   acc = group_sum<64>(acc);
   if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
   __syncthreads();
-  if (threadIdx.x == 0) out[0] = ((part[0] + part[1]) + (part[2] + part[3])) / (float)M;
+  if (threadIdx.x == 0) out[0] = ((part[0] + part[1]) + (part[2] + part[3])) / (denom ? (float)denom[0] : (float)M);
+}
+
+// BinaryCrossEntropyLoss (loss_func.py:100-132, dns=False, one negative set per positive):
+//   loss = -sum_valid logsigmoid(pos) / V + sum_valid (1/n) sum_j softplus(neg_j) / V,  V = #non-padded positives.
+__global__ __launch_bounds__(256) void count_valid_kernel(const float* __restrict__ pos, int64_t M,
+                                                          int32_t* __restrict__ count) {
+  int c = 0;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < M; i += stride) c += isinf(pos[i]) ? 0 : 1;
+  c = (int)group_sum<64>((float)c);   // exact up to 2^24 per wave-iteration sum; counts here are tiny per lane
+  if ((threadIdx.x & 63) == 0 && c) atomicAdd(count, c);
+}
+
+__device__ __forceinline__ float softplus_f(float x) {   // == F.softplus (beta 1, threshold 20)
+  return x > 20.f ? x : log1pf(expf(x));
+}
+
+template <int RL>
+__global__ __launch_bounds__(256) void bce_loss_kernel(const float* __restrict__ pos, const float* __restrict__ neg,
+                                                       int64_t M, int n, const int32_t* __restrict__ count,
+                                                       float* __restrict__ row_loss, float* __restrict__ dpos,
+                                                       float* __restrict__ dneg) {
+  const int sub = threadIdx.x % RL;
+  const int64_t g0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / RL;
+  const int64_t gstride = ((int64_t)gridDim.x * blockDim.x) / RL;
+  const float inv_v = 1.f / (float)count[0];
+  const float w = 1.f / (float)n;
+  const int64_t m_end = ((M + gstride - 1) / gstride) * gstride;
+  for (int64_t m = g0; m < m_end; m += gstride) {
+    const bool rv = m < M;
+    const float ps = rv ? pos[m] : 0.f;
+    const bool valid = rv && !isinf(ps);
+    const float* nrow = neg + (rv ? m : 0) * (int64_t)n;
+    float acc = 0.f;
+    if (rv)
+      for (int j = sub; j < n; j += RL) {
+        const float x = nrow[j];
+        acc += softplus_f(x) * w;
+        if (dneg) dneg[m * (int64_t)n + j] = valid ? (1.f / (1.f + expf(-x))) * w * inv_v : 0.f;
+      }
+    acc = group_sum<RL>(acc);
+    if (rv && sub == 0) {
+      row_loss[m] = valid ? (acc - log_sigmoid(ps)) : 0.f;
+      if (dpos) dpos[m] = valid ? -sigmoid_neg(ps) * inv_v : 0.f;
+    }
+  }
+}
+
+// SampledSoftmaxLoss with SEVERAL positives per row sharing one negative set -- loss_func.py:84-89 when
+// pos_score [B, L] and neg_score [B, n] have the same rank: z = cat(pos - logQ_pos, neg - logQ_neg),
+// out_l = logsumexp(z) - z_pos_l, padded positives (+-inf) contribute 0 and are not counted, row = sum / count.
+// One wave per row.
+__global__ __launch_bounds__(256) void ssm_shared_kernel(const float* __restrict__ pos, const float* __restrict__ pos_lp,
+                                                         const float* __restrict__ neg, const float* __restrict__ neg_lp,
+                                                         int64_t B, int L, int n, float* __restrict__ row_loss,
+                                                         float* __restrict__ dpos, float* __restrict__ dneg) {
+  const int lane = lane_id();
+  const int64_t w0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), ws = (int64_t)gridDim.x * 4;
+  const float inv_b = 1.f / (float)B;
+  for (int64_t b = w0; b < B; b += ws) {
+    const float* pr = pos + b * L;
+    const float* nr = neg + b * n;
+    const float* plp = pos_lp ? pos_lp + b * L : nullptr;
+    const float* nlp = neg_lp ? neg_lp + b * n : nullptr;
+    float mx = -INFINITY;
+    for (int l = lane; l < L; l += 64) mx = fmaxf(mx, pr[l] - (plp ? plp[l] : 0.f));
+    for (int j = lane; j < n; j += 64) mx = fmaxf(mx, nr[j] - (nlp ? nlp[j] : 0.f));
+#pragma unroll
+    for (int k = 32; k >= 1; k >>= 1) mx = fmaxf(mx, __shfl_xor(mx, k, 64));
+    float se = 0.f, zsum = 0.f, cnt = 0.f;
+    for (int l = lane; l < L; l += 64) {
+      const float z = pr[l] - (plp ? plp[l] : 0.f);
+      se += expf(z - mx);
+      if (!isinf(z)) {
+        zsum += z;
+        cnt += 1.f;
+      }
+    }
+    for (int j = lane; j < n; j += 64) se += expf(nr[j] - (nlp ? nlp[j] : 0.f) - mx);
+    se = group_sum<64>(se);
+    zsum = group_sum<64>(zsum);
+    cnt = group_sum<64>(cnt);
+    const float lse = mx + logf(se);
+    if (lane == 0) row_loss[b] = (cnt * lse - zsum) / cnt;     // 0/0 = NaN like the reference when all padded
+    if (dpos)
+      for (int l = lane; l < L; l += 64) {
+        const float z = pr[l] - (plp ? plp[l] : 0.f);
+        dpos[b * L + l] = (expf(z - lse) - (isinf(z) ? 0.f : 1.f / cnt)) * inv_b;
+      }
+    if (dneg)
+      for (int j = lane; j < n; j += 64) dneg[b * n + j] = expf(nr[j] - (nlp ? nlp[j] : 0.f) - lse) * inv_b;
+  }
 }
 
 // lse[m] = logsumexp(x[m, :]); optionally grad[m, :] = softmax(x[m, :]) * scale.  One workgroup per row.
@@ -157,7 +249,13 @@ extern "C" int rsa_row_lse(const float* x, int64_t n_rows, int64_t n_cols, float
 // not overlap (the Python binding issues everything on torch's current stream).
 static float* g_partials = nullptr;
 
+static int mean_rows_impl(const float* row_loss, int64_t n_rows, const int32_t* denom, float* out, rsa_stream_t stream);
+
 extern "C" int rsa_mean_rows(const float* row_loss, int64_t n_rows, float* out, rsa_stream_t stream) {
+  return mean_rows_impl(row_loss, n_rows, nullptr, out, stream);
+}
+
+static int mean_rows_impl(const float* row_loss, int64_t n_rows, const int32_t* denom, float* out, rsa_stream_t stream) {
   RSA_CHECK_ARG(row_loss && out && n_rows >= 1, "rsa_mean_rows: bad arguments");
   hipStream_t s = (hipStream_t)stream;
   if (g_partials == nullptr) {   // one-time 1 KB scratch (the only allocation the library ever makes)
@@ -170,16 +268,18 @@ extern "C" int rsa_mean_rows(const float* row_loss, int64_t n_rows, float* out, 
   if (blocks > 256) blocks = 256;
   const int64_t chunk = (n_rows + blocks - 1) / blocks;
   hipLaunchKernelGGL(mean_rows_stage1, dim3(blocks), dim3(256), 0, s, row_loss, n_rows, chunk, g_partials);
-  hipLaunchKernelGGL(mean_rows_stage2, dim3(1), dim3(256), 0, s, g_partials, blocks, n_rows, out);
+  hipLaunchKernelGGL(mean_rows_stage2, dim3(1), dim3(256), 0, s, g_partials, blocks, n_rows, denom, out);
   RSA_CHECK_LAUNCH("rsa_mean_rows");
   return RSA_OK;
 }
 
+static int32_t* g_count = nullptr;   // device word for the BCE valid-row count (allocated once, like g_partials)
+
 extern "C" int rsa_pairwise_loss(int32_t loss_kind, const float* pos_score, const float* neg_score,
                                  const float* pos_logp, const float* neg_logp, int64_t n_rows, int32_t num_neg,
                                  float* row_loss, float* loss_out, float* dpos, float* dneg, rsa_stream_t stream) {
-  RSA_CHECK_ARG(loss_kind == RSA_LOSS_BPR || loss_kind == RSA_LOSS_SSM, "rsa_pairwise_loss: unknown loss %d",
-                loss_kind);
+  RSA_CHECK_ARG(loss_kind == RSA_LOSS_BPR || loss_kind == RSA_LOSS_SSM || loss_kind == RSA_LOSS_BCE,
+                "rsa_pairwise_loss: unknown loss %d", loss_kind);
   RSA_CHECK_ARG(n_rows >= 1 && num_neg >= 1, "rsa_pairwise_loss: need n_rows >= 1 and num_neg >= 1");
   RSA_CHECK_ARG(pos_score && neg_score && row_loss && loss_out, "rsa_pairwise_loss: null pointer");
   hipStream_t s = (hipStream_t)stream;
@@ -187,6 +287,30 @@ extern "C" int rsa_pairwise_loss(int32_t loss_kind, const float* pos_score, cons
   int64_t blocks = (n_rows * rl + 255) / 256;
   if (blocks > 4096) blocks = 4096;
   dim3 grid((unsigned)blocks), block(256);
+  if (loss_kind == RSA_LOSS_BCE) {
+    if (g_count == nullptr && hipMalloc(&g_count, 256) != hipSuccess) {
+      rsa::set_error("rsa_pairwise_loss: could not allocate the counter scratch");
+      return RSA_ERR_HIP;
+    }
+    if (hipMemsetAsync(g_count, 0, sizeof(int32_t), s) != hipSuccess) {
+      rsa::set_error("rsa_pairwise_loss: memset failed");
+      return RSA_ERR_HIP;
+    }
+    int64_t cb = (n_rows + 255) / 256;
+    if (cb > 1024) cb = 1024;
+    hipLaunchKernelGGL(count_valid_kernel, dim3((unsigned)cb), dim3(256), 0, s, pos_score, n_rows, g_count);
+#define RSA_LAUNCH_BCE(RL) \
+  hipLaunchKernelGGL(bce_loss_kernel<RL>, grid, block, 0, s, pos_score, neg_score, n_rows, (int)num_neg, g_count, row_loss, dpos, dneg)
+    switch (rl) {
+      case 1: RSA_LAUNCH_BCE(1); break;
+      case 4: RSA_LAUNCH_BCE(4); break;
+      case 16: RSA_LAUNCH_BCE(16); break;
+      default: RSA_LAUNCH_BCE(64); break;
+    }
+#undef RSA_LAUNCH_BCE
+    RSA_CHECK_LAUNCH("rsa_pairwise_loss(bce)");
+    return mean_rows_impl(row_loss, n_rows, g_count, loss_out, stream);
+  }
 #define RSA_LAUNCH_LOSS(RL)                                                                                      \
   hipLaunchKernelGGL(pairwise_loss_kernel<RL>, grid, block, 0, s, (int)loss_kind, pos_score, neg_score, pos_logp, \
                      neg_logp, n_rows, (int)num_neg, row_loss, dpos, dneg)
@@ -198,5 +322,18 @@ extern "C" int rsa_pairwise_loss(int32_t loss_kind, const float* pos_score, cons
   }
 #undef RSA_LAUNCH_LOSS
   RSA_CHECK_LAUNCH("rsa_pairwise_loss");
+  return rsa_mean_rows(row_loss, n_rows, loss_out, stream);
+}
+
+extern "C" int rsa_ssm_shared_loss(const float* pos_score, const float* pos_logp, const float* neg_score,
+                                   const float* neg_logp, int64_t n_rows, int32_t n_pos, int32_t num_neg,
+                                   float* row_loss, float* loss_out, float* dpos, float* dneg, rsa_stream_t stream) {
+  RSA_CHECK_ARG(n_rows >= 1 && n_pos >= 1 && num_neg >= 1, "rsa_ssm_shared_loss: bad sizes");
+  RSA_CHECK_ARG(pos_score && neg_score && row_loss && loss_out, "rsa_ssm_shared_loss: null pointer");
+  int64_t blocks = (n_rows + 3) / 4;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(ssm_shared_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, pos_score, pos_logp,
+                     neg_score, neg_logp, n_rows, (int)n_pos, (int)num_neg, row_loss, dpos, dneg);
+  RSA_CHECK_LAUNCH("rsa_ssm_shared_loss");
   return rsa_mean_rows(row_loss, n_rows, loss_out, stream);
 }

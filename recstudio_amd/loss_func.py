@@ -11,7 +11,8 @@ import torch
 from . import _native as nat
 from . import ops
 
-__all__ = ['FullScoreLoss', 'PairwiseLoss', 'PointwiseLoss', 'BPRLoss', 'SampledSoftmaxLoss', 'SoftmaxLoss']
+__all__ = ['FullScoreLoss', 'PairwiseLoss', 'PointwiseLoss', 'BPRLoss', 'SampledSoftmaxLoss', 'SoftmaxLoss',
+           'BinaryCrossEntropyLoss']
 
 
 class FullScoreLoss(torch.nn.Module):
@@ -73,10 +74,40 @@ class BPRLoss(PairwiseLoss):
         return _PairwiseFn.apply(nat.LOSS_BPR, pos_score, neg_score, None, None)
 
 
+class BinaryCrossEntropyLoss(PairwiseLoss):
+    """recstudio/model/loss_func.py:100-132 (dns=False): SASRec's default loss (seq/sasrec.py:117-119)."""
+
+    def __init__(self, dns=False):
+        super().__init__()
+        if dns:
+            raise NotImplementedError('BinaryCrossEntropyLoss(dns=True) is outside the path this package covers')
+        self.dns = dns
+
+    def forward(self, label, pos_score, log_pos_prob, neg_score, log_neg_prob):
+        _check_shapes(pos_score, neg_score)
+        return _PairwiseFn.apply(nat.LOSS_BCE, pos_score, neg_score, None, None)
+
+
+class _SharedSSMFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pos_score, neg_score, pos_logp, neg_logp):
+        loss, dpos, dneg = ops.ssm_shared_loss(pos_score, neg_score, pos_logp, neg_logp)
+        ctx.save_for_backward(dpos, dneg)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        dpos, dneg = ctx.saved_tensors
+        return dpos * g, dneg * g, None, None
+
+
 class SampledSoftmaxLoss(PairwiseLoss):
     """recstudio/model/loss_func.py:80-90."""
 
     def forward(self, label, pos_score, log_pos_prob, neg_score, log_neg_prob):
+        if pos_score.dim() == neg_score.dim() == 2:      # several positives sharing one negative set (:84-89)
+            return _SharedSSMFn.apply(pos_score, neg_score, _as_f32_or_none(log_pos_prob),
+                                      _as_f32_or_none(log_neg_prob))
         _check_shapes(pos_score, neg_score)
         return _PairwiseFn.apply(nat.LOSS_SSM, pos_score, neg_score, _as_f32_or_none(log_pos_prob),
                                  _as_f32_or_none(log_neg_prob))

@@ -44,6 +44,19 @@ def sample_uniform(numel, low, high, device, generator=None):
     return out
 
 
+def sample_masked_uniform(user_hist, num_items, per_row, generator=None):
+    """int64 [B, per_row]: uniform over [1, num_items] minus each row's history (sampler.py:117-147)."""
+    user_hist = _need(user_hist, torch.int64, 'user_hist')
+    B, Lh = user_hist.shape
+    out = torch.empty(B, int(per_row), dtype=torch.int64, device=user_hist.device)
+    if B * per_row:
+        pc = rng.reserve(B * per_row, 4, user_hist.device, generator)
+        nat.check(nat.lib().rsa_sample_masked_uniform(ptr(user_hist), B, Lh, int(num_items), int(per_row), ptr(out),
+                                                      pc.seed, pc.offset, pc.grid_threads, _stream()),
+                  'rsa_sample_masked_uniform')
+    return out
+
+
 def sample_popular(table, pop_prob, guide, guide_log2, numel, generator=None, want_u=False, cdf_lut=None):
     table = _need(table, torch.float32, 'table')
     pop_prob = _need(pop_prob, torch.float32, 'pop_prob')
@@ -214,6 +227,23 @@ def pairwise_loss(kind, pos_score, neg_score, pos_logp=None, neg_logp=None, want
                                           M, n, ptr(row), ptr(loss), ptr(dpos), ptr(dneg), _stream()),
               'rsa_pairwise_loss')
     return loss, dpos, dneg, row
+
+
+def ssm_shared_loss(pos_score, neg_score, pos_logp=None, neg_logp=None):
+    """rsa_ssm_shared_loss: pos_score [B, L], neg_score [B, n].  Returns (loss, dpos, dneg)."""
+    pos_score = _need(pos_score, torch.float32, 'pos_score')
+    neg_score = _need(neg_score, torch.float32, 'neg_score')
+    pos_logp = _need_opt(pos_logp, torch.float32, 'pos_logp')
+    neg_logp = _need_opt(neg_logp, torch.float32, 'neg_logp')
+    B, L = pos_score.shape
+    n = neg_score.shape[1]
+    dev = pos_score.device
+    row = torch.empty(B, dtype=torch.float32, device=dev)
+    loss = torch.empty((), dtype=torch.float32, device=dev)
+    dpos, dneg = torch.empty_like(pos_score), torch.empty_like(neg_score)
+    nat.check(nat.lib().rsa_ssm_shared_loss(ptr(pos_score), ptr(pos_logp), ptr(neg_score), ptr(neg_logp), B, L, n,
+                                            ptr(row), ptr(loss), ptr(dpos), ptr(dneg), _stream()), 'rsa_ssm_shared_loss')
+    return loss, dpos, dneg
 
 
 def fused_backward(item_table, query, neg_ids, dneg, *, query_index=None, pos_ids=None, dpos=None, upstream=None,

@@ -15,7 +15,7 @@ from torch import Tensor
 
 from . import ops
 
-__all__ = ['Sampler', 'UniformSampler', 'PopularSamplerModel', 'build_guide_table']
+__all__ = ['Sampler', 'UniformSampler', 'MaskedUniformSampler', 'PopularSamplerModel', 'build_guide_table']
 
 
 class Sampler(torch.nn.Module):
@@ -59,6 +59,28 @@ class UniformSampler(Sampler):
 
     def compute_item_p(self, query, pos_items):
         return torch.zeros_like(pos_items)          # sampler.py:113-114
+
+
+class MaskedUniformSampler(Sampler):
+    """recstudio/ann/sampler.py:187-214: uniform negatives excluding each user's history (rejection-free).
+    BaseRetriever passes ``user_hist`` because the parameter is named in ``forward`` (baseretriever.py:225-228)."""
+
+    def forward(self, query, num_neg, pos_items=None, user_hist=None):
+        with torch.no_grad():
+            if query.dim() == 2:
+                neg = ops.sample_masked_uniform(user_hist, self.num_items, num_neg)
+            elif query.dim() == 3:
+                nq = query.size(1)
+                neg = ops.sample_masked_uniform(user_hist, self.num_items, nq * num_neg).view(query.size(0), nq, num_neg)
+            else:
+                raise ValueError('`query` need to be 2-dimensional or 3-dimensional.')
+            neg_prob = self.compute_item_p(query, neg)
+            if pos_items is not None:
+                return self.compute_item_p(query, pos_items), neg, neg_prob
+            return neg, neg_prob
+
+    def compute_item_p(self, query, pos_items):
+        return torch.zeros_like(pos_items)              # -log(1), int64 like the reference (sampler.py:213-214)
 
 
 def build_guide_table(table: Tensor, guide_log2: Optional[int] = None):

@@ -234,7 +234,8 @@ def test_losses_golden(ra, golden):
     g = golden('loss')
     for name, cls in (('bpr_1d', 'BPRLoss'), ('bpr_2d', 'BPRLoss'), ('bpr_big', 'BPRLoss'),
                       ('ssm_1d_f32', 'SampledSoftmaxLoss'), ('ssm_1d_i64', 'SampledSoftmaxLoss'),
-                      ('ssm_2d', 'SampledSoftmaxLoss'), ('ssm_big', 'SampledSoftmaxLoss')):
+                      ('ssm_2d', 'SampledSoftmaxLoss'), ('ssm_big', 'SampledSoftmaxLoss'),
+                      ('bce_1d', 'BinaryCrossEntropyLoss'), ('bce_2d_pad', 'BinaryCrossEntropyLoss')):
         pos = T(g[name + '_pos_score']).to(DEV).requires_grad_(True)
         neg = T(g[name + '_neg_score']).to(DEV).requires_grad_(True)
         lpp, lnp = T(g[name + '_log_pos_prob']).to(DEV), T(g[name + '_log_neg_prob']).to(DEV)
@@ -243,6 +244,19 @@ def test_losses_golden(ra, golden):
         (loss * 1.0).backward()
         rel_close(pos.grad.cpu(), g[name + '_grad_pos_score'], rtol=1e-4, atol=1e-7)
         rel_close(neg.grad.cpu(), g[name + '_grad_neg_score'], rtol=1e-4, atol=1e-7)
+
+
+def test_ssm_shared_negatives_golden(ra, golden):
+    """loss_func.py:84-89: multi-positive rows sharing one negative set, with -inf padded positives."""
+    g = golden('loss')
+    name = 'ssm_shared_pad'
+    pos = T(g[name + '_pos_score']).to(DEV).requires_grad_(True)
+    neg = T(g[name + '_neg_score']).to(DEV).requires_grad_(True)
+    loss = ra.SampledSoftmaxLoss()(None, pos, T(g[name + '_log_pos_prob']).to(DEV), neg, T(g[name + '_log_neg_prob']).to(DEV))
+    rel_close(loss.detach().cpu(), g[name + '_loss'], rtol=1e-5)
+    loss.backward()
+    rel_close(pos.grad.cpu(), g[name + '_grad_pos_score'], rtol=1e-4, atol=1e-7)
+    rel_close(neg.grad.cpu(), g[name + '_grad_neg_score'], rtol=1e-4, atol=1e-7)
 
 
 @pytest.mark.parametrize('n', [1, 2, 7, 33, 64, 256, 1000])
@@ -491,3 +505,37 @@ def test_cosine_backward_vs_oracle(ra, d, n):
         cls()(qd, itd).square().sum().backward()
         rel_close(qd.grad.cpu(), q.grad, rtol=3e-4, atol=1e-6)
         rel_close(itd.grad.cpu(), it.grad, rtol=3e-4, atol=1e-6)
+
+
+def test_masked_uniform_sampler(ra, golden):
+    """MaskedUniformSampler (sampler.py:117-147): same ids as the reference's op sequence on this device's
+    random stream, and the recorded reference outputs for recorded uniforms (through the oracle)."""
+    g = golden('uniform')
+    N, hist = int(g['mask_N']), T(g['mask_hist'])
+    cu, mt = props(ra)
+    gen = torch.cuda.default_generators[torch.cuda.current_device()]
+    ms = ra.MaskedUniformSampler(N)
+    for qdim, n in ((2, 40), (3, 5)):
+        query = torch.zeros(hist.shape[0], 4, device=DEV) if qdim == 2 else torch.zeros(hist.shape[0], 3, 4, device=DEV)
+        per_row = n if qdim == 2 else 3 * n
+        torch.manual_seed(123)
+        off0 = gen.get_offset()
+        pp, neg, npb = ms(query, n, torch.ones(hist.shape[0], dtype=torch.int64, device=DEV), hist.to(DEV))
+        torch.manual_seed(123)
+        u = torch.rand(hist.shape[0], per_row, device=DEV)            # what the reference would draw here
+        want = oracle.masked_uniform_from_u(N - 1, n, hist, u.cpu(), None if qdim == 2 else 3)
+        assert torch.equal(neg.cpu(), want)
+        rest = philox.device_rand(123, off0, hist.shape[0] * per_row, philox.rng_grid_threads(hist.shape[0] * per_row, cu, mt))
+        assert np.array_equal(rest.reshape(u.shape), u.cpu().numpy())
+        assert npb.dtype == torch.int64 and not npb.any() and npb.shape == neg.shape
+    # bigger, random histories: never a history item, always in [1, N-1], roughly uniform
+    N2, B2, L2, n2 = 500, 64, 300, 2000
+    gg = torch.Generator().manual_seed(4)
+    h2 = torch.zeros(B2, L2, dtype=torch.int64)
+    for b in range(B2):
+        m = int(torch.randint(0, L2 + 1, (1,), generator=gg))
+        h2[b, torch.randperm(L2, generator=gg)[:m]] = torch.randperm(N2 - 1, generator=gg)[:m] + 1
+    neg = ra.ops.sample_masked_uniform(h2.to(DEV), N2 - 1, n2).cpu()
+    for b in range(B2):
+        assert not set(neg[b].tolist()) & set(h2[b].tolist())
+    assert int(neg.min()) >= 1 and int(neg.max()) <= N2 - 1

@@ -96,6 +96,8 @@ def test_plugin_signatures_match_reference():
     assert list(inspect.signature(ra.UniformSampler.forward).parameters) == ['self', 'query', 'num_neg', 'pos_items', 'device']
     assert list(inspect.signature(ra.PopularSamplerModel.forward).parameters) == ['self', 'query', 'num_neg', 'pos_items']
     assert list(inspect.signature(ra.PopularSamplerModel.__init__).parameters)[:4] == ['self', 'pop_count', 'scorer', 'mode']
+    assert list(inspect.signature(ra.MaskedUniformSampler.forward).parameters) == ['self', 'query', 'num_neg', 'pos_items', 'user_hist']
+    assert list(inspect.signature(ra.BinaryCrossEntropyLoss.forward).parameters) == ['self', 'label', 'pos_score', 'log_pos_prob', 'neg_score', 'log_neg_prob']
     assert list(inspect.signature(ra.Sampler.__init__).parameters) == ['self', 'num_items', 'scorer_fn']
     assert list(inspect.signature(ra.Sampler.update).parameters) == ['self', 'item_embs', 'max_iter']
     for cls in (ra.BPRLoss, ra.SampledSoftmaxLoss):

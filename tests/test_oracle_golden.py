@@ -69,6 +69,11 @@ def test_losses(golden):
         if name + '_grad_pos_score' in g:
             np.testing.assert_allclose(gp.numpy(), g[name + '_grad_pos_score'], rtol=1e-5, atol=1e-8)
             np.testing.assert_allclose(gn.numpy(), g[name + '_grad_neg_score'], rtol=1e-5, atol=1e-8)
+    for name in ('bce_1d', 'bce_2d_pad'):
+        val, (gp, gn) = grads(oracle.bce_loss, (T(g[name + '_pos_score']), True), (T(g[name + '_neg_score']), True))
+        np.testing.assert_allclose(val.detach().numpy(), g[name + '_loss'], rtol=1e-6)
+        np.testing.assert_allclose(gp.numpy(), g[name + '_grad_pos_score'], rtol=1e-5, atol=1e-8)
+        np.testing.assert_allclose(gn.numpy(), g[name + '_grad_neg_score'], rtol=1e-5, atol=1e-8)
     val, (gp, ga) = grads(oracle.softmax_loss, (T(g['softmax_full_pos_score']), True), (T(g['softmax_full_all_score']), True))
     np.testing.assert_allclose(val.detach().numpy(), g['softmax_full_loss'], rtol=1e-6)
     np.testing.assert_allclose(ga.numpy(), g['softmax_full_grad_all_score'], rtol=1e-5, atol=1e-8)
@@ -91,6 +96,22 @@ def test_uniform_sampler_cpu_stream(golden):
     torch.manual_seed(9)
     neg, _ = us.forward(15, 7)
     assert np.array_equal(neg.numpy(), g['qint_neg'])
+
+
+def test_masked_uniform_sampler(golden):
+    g = golden('uniform')
+    N, hist = int(g['mask_N']), T(g['mask_hist'])
+    neg = oracle.masked_uniform_from_u(N - 1, g['mask_neg'].shape[1], hist, g['mask_u'])
+    assert np.array_equal(neg.numpy(), g['mask_neg'])
+    neg3 = oracle.masked_uniform_from_u(N - 1, 5, hist, g['mask_u3'], num_query_per_user=3)
+    assert np.array_equal(neg3.numpy(), g['mask_neg3'])
+    for b in range(hist.shape[0]):          # never a history item, never padding, always in range
+        assert not set(neg[b].tolist()) & set(hist[b].tolist())
+        assert neg[b].min() >= 1 and neg[b].max() <= N - 1
+    torch.manual_seed(79)
+    u = torch.rand(hist.shape[0], g['mask_fw_neg'].shape[1])
+    assert np.array_equal(oracle.masked_uniform_from_u(N - 1, u.shape[1], hist, u).numpy(), g['mask_fw_neg'])
+    assert not g['mask_fw_negprob'].any() and not g['mask_fw_posprob'].any()    # -log(1) = 0, int64
 
 
 def test_popular_sampler(golden):
