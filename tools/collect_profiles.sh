@@ -12,6 +12,8 @@ BENCH="python $REPO/bench.py --no-cpu-baseline --no-sweep"
 rocprofv3 --kernel-trace --stats -d $OUT/trace -o bench -- $BENCH --steps 100 --warmup 10 > $OUT/trace.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch -o bench -- $BENCH --steps 10 --warmup 2 > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write -o bench -- $BENCH --steps 10 --warmup 2 > $OUT/pmc_write.log 2>&1
+# MFMA utilisation of the full-score GEMM: busy cycles of the matrix pipes vs elapsed GPU cycles
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -d $OUT/pmc_mfma -o bench -- $BENCH --steps 4 --warmup 1 > $OUT/pmc_mfma.log 2>&1
 cd $REPO
 python tools/summarize_profiles.py $OUT $TAG > $OUT/summary.log 2>&1
 tail -40 $OUT/summary.log

@@ -68,6 +68,27 @@ for sub, counter in (('pmc_fetch', 'FETCH_SIZE'), ('pmc_write', 'WRITE_SIZE')):
         vals = vals[2:] if len(vals) > 4 else vals       # drop the cold first launches
         out[counter + '_KB_per_launch'] = sum(vals) / len(vals)
 
+c = db('pmc_mfma')
+if c is not None:
+    lines.append('# rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE')
+    lines.append('# per-dispatch: mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (elapsed_cycles x 1024 SIMDs), elapsed_cycles = '
+                 'GRBM_GUI_ACTIVE / 8 (the counter is summed over the 8 XCDs; check: it equals duration x ~2.0 GHz)')
+    disp = {}
+    for did, name, grid, counter, value, dur in c.execute(
+            "select dispatch_id, kernel_name, grid_size, counter_name, value, duration from counters_collection"):
+        d = disp.setdefault(did, {'name': name, 'grid': grid, 'dur': dur})
+        d[counter] = value
+    full = [d for d in disp.values() if 'fullscore_kernel' in d['name']]
+    if full:
+        dmax = max(d['dur'] for d in full)       # the full-catalog launches (the sample GEMM is ~15x shorter)
+        big = [d for d in full if d['dur'] > 0.5 * dmax and d.get('GRBM_GUI_ACTIVE')]
+        utils = [d['SQ_VALU_MFMA_BUSY_CYCLES'] / (d['GRBM_GUI_ACTIVE'] / 8.0 * 1024.0) for d in big]
+        clocks = [d['GRBM_GUI_ACTIVE'] / 8.0 / d['dur'] for d in big]      # cycles per ns = GHz
+        out['fullscore_mfma_util'] = sum(utils) / len(utils)
+        out['fullscore_clock_ghz'] = sum(clocks) / len(clocks)
+        out['fullscore_mfma_busy_cycles'] = sum(d['SQ_VALU_MFMA_BUSY_CYCLES'] for d in big) / len(big)
+        lines.append(f'fullscore_kernel<128> (full catalog launches, n={len(big)}): mfma_busy={out["fullscore_mfma_busy_cycles"]:.4g} '
+                     f'cycles, effective clock {out["fullscore_clock_ghz"]:.2f} GHz, MFMA utilisation {out["fullscore_mfma_util"]:.3f}')
 if 'FETCH_SIZE_KB_per_launch' in out:
     # MI355X_MICROARCH.md section HBM: on gfx950 FETCH_SIZE reports exactly 1/2 of the bytes of a wide
     # (16 B/lane) coalesced read stream -> doubled here; WRITE_SIZE is taken as is (uncalibrated).
