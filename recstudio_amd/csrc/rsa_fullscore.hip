@@ -45,7 +45,7 @@ struct FilterArgs {
 // tile_stride == 1: the workgroup walks the contiguous item range [1 + bx*items_per_split, ...).
 // tile_stride  > 1: SAMPLE mode -- "item" positions are sample positions; sample tile s reads catalog tile
 // s*tile_stride, and scores are written to a dense [n_query, score_ld] sample matrix.
-template <int D>
+template <int D, bool LSE, bool SCORES, bool FILTER>
 __global__ __launch_bounds__(256) void fullscore_kernel(const float* __restrict__ item_table, int64_t n_items,
                                                         const float* __restrict__ query, int64_t n_query,
                                                         float* __restrict__ scores, int64_t score_ld,
@@ -93,9 +93,11 @@ __global__ __launch_bounds__(256) void fullscore_kernel(const float* __restrict_
       const int idx = f * 256 + tid;
       const int row = idx / V4, c4 = idx - row * V4;
       const int64_t pos = i_begin + (int64_t)t * TI + row;
-      const int64_t item = tile_stride == 1 ? pos : 1 + ((pos - 1) / TI) * tile_stride * TI + (pos - 1) % TI;
-      stage[f] = (pos < i_end && item < n_items) ? reinterpret_cast<const float4*>(item_table + (size_t)item * D)[c4]
-                                                 : make_float4(0.f, 0.f, 0.f, 0.f);
+      int64_t item = tile_stride == 1 ? pos : 1 + ((pos - 1) / TI) * tile_stride * TI + (pos - 1) % TI;
+      const bool ok = pos < i_end && item < n_items;
+      item = item < n_items ? item : n_items - 1;          // unconditional load from a valid row, zeroed by select
+      const float4 v = reinterpret_cast<const float4*>(item_table + (size_t)item * D)[c4];
+      stage[f] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
   auto commit = [&](int buf) {
@@ -108,46 +110,31 @@ __global__ __launch_bounds__(256) void fullscore_kernel(const float* __restrict_
   };
 
   float run_m = -INFINITY, run_s = 0.f;
-  if (n_tiles > 0) {
-    fetch(0);
-    commit(0);
-  }
-  __syncthreads();
-  for (int t = 0; t < n_tiles; ++t) {
-    const int cur = t & 1;
-    if (t + 1 < n_tiles) fetch(t + 1);          // global loads fly under the MFMA chain
-    f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    const float* arow = &tile[cur][j][h * KH];   // lane's item row of this tile, its k half
+
+  // ---- per-tile epilogue pieces.  They are applied to the PREVIOUS tile's accumulators while the current
+  // tile's MFMA chain (64 dependent 64-cycle instructions) is in flight.
+  // (a) branch-free online logsumexp: pure VALU, interleaved with the MFMAs by the sched_group_barriers below
+  auto lse_update = [&](const f32x16& acc, int64_t i0) {
+    const bool full = i0 + TI <= i_end;      // only the last tile of a range can be partial
+    float v[16];
+    float tmax = -INFINITY;
 #pragma unroll
-    for (int c = 0; c < KH / 4; ++c) {
-      const float4 a = *reinterpret_cast<const float4*>(arow + 4 * c);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bq[4 * c + 0], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bq[4 * c + 1], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bq[4 * c + 2], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bq[4 * c + 3], acc, 0, 0, 0);
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+      v[r] = (full || i0 + row < i_end) ? acc[r] : -INFINITY;
+      tmax = fmaxf(tmax, v[r]);
     }
-    // acc[r] = <item (i0 + row(r)), query q>, row(r) = (r & 3) + 8 * (r >> 2) + 4 * h
-    const int64_t i0 = i_begin + (int64_t)t * TI;
-    if (lse_part != nullptr) {
-      float tmax = -INFINITY;
+    const float m_new = fmaxf(run_m, tmax);
+    const float m_safe = m_new == -INFINITY ? 0.f : m_new;   // nothing seen yet: exp(-inf - 0) = 0 everywhere
+    float sum = run_s * __expf(run_m - m_safe);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (i0 + row < i_end) tmax = fmaxf(tmax, acc[r]);
-      }
-      if (tmax > -INFINITY) {
-        const float m_new = fmaxf(run_m, tmax);
-        float s = run_s * __expf(run_m - m_new);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-          if (i0 + row < i_end) s += __expf(acc[r] - m_new);
-        }
-        run_m = m_new;
-        run_s = s;
-      }
-    }
-    if (scores != nullptr) {
+    for (int r = 0; r < 16; ++r) sum += __expf(v[r] - m_safe);
+    run_m = m_new;
+    run_s = sum;
+  };
+  // (b) the parts with memory side effects (score rows, candidate lists)
+  auto emit = [&](const f32x16& acc, int64_t i0) {
+    if constexpr (SCORES) {
       // transpose the wave's 32 (items) x 32 (queries) tile through LDS so that every half-wave
       // writes 128 contiguous bytes of one query's score row
 #pragma unroll
@@ -161,24 +148,73 @@ __global__ __launch_bounds__(256) void fullscore_kernel(const float* __restrict_
         if (qg < n_query && item < i_end) scores[(size_t)qg * score_ld + (item - 1)] = tpose[wave][qq][j];
       }
     }
-    if (flt.thr != nullptr) {
+    if constexpr (FILTER) {
       // candidate filter: almost never taken once the threshold is in place
+      float best = -INFINITY;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (acc[r] > thr && i0 + row < i_end) {
-          const int32_t slot = atomicAdd(flt.cnt + q, 1);
-          if (slot < flt.cap) {
-            flt.cand_val[(size_t)q * flt.cap + slot] = acc[r];
-            flt.cand_idx[(size_t)q * flt.cap + slot] = (int32_t)(i0 + row);
+      for (int r = 0; r < 16; ++r) best = fmaxf(best, acc[r]);
+      if (best > thr) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+          if (acc[r] > thr && i0 + row < i_end) {
+            const int32_t slot = atomicAdd(flt.cnt + q, 1);
+            if (slot < flt.cap) {
+              flt.cand_val[(size_t)q * flt.cap + slot] = acc[r];
+              flt.cand_idx[(size_t)q * flt.cap + slot] = (int32_t)(i0 + row);
+            }
           }
         }
       }
     }
-    if (t + 1 < n_tiles) commit(cur ^ 1);
-    __syncthreads();
+  };
+  auto mfma_tile = [&](int buf) -> f32x16 {
+    f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const float* arow = &tile[buf][j][h * KH];   // lane's item row of this tile, its k half
+#pragma unroll
+    for (int c = 0; c < KH / 4; ++c) {
+      const float4 a = *reinterpret_cast<const float4*>(arow + 4 * c);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bq[4 * c + 0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bq[4 * c + 1], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bq[4 * c + 2], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bq[4 * c + 3], acc, 0, 0, 0);
+    }
+    return acc;   // acc[r] = <item (i0 + row(r)), query q>, row(r) = (r & 3) + 8 * (r >> 2) + 4 * h
+  };
+
+  if (n_tiles == 0) {
+    if (LSE && h == 0 && q < n_query) lse_part[(size_t)q * splits + blockIdx.x] = make_float2(-INFINITY, 0.f);
+    return;
   }
-  if (lse_part != nullptr) {
+  fetch(0);
+  commit(0);
+  __syncthreads();
+  // tile 0 (peeled so that the loop body is branch-free up to the rare filter hit)
+  fetch(1);                               // out-of-range tiles load a valid row and are zeroed
+  f32x16 acc_prev = mfma_tile(0);
+  commit(1);
+  __syncthreads();
+  for (int t = 1; t < n_tiles; ++t) {
+    const int cur = t & 1;
+    fetch(t + 1);                         // global loads fly under the MFMA chain
+    const f32x16 acc = mfma_tile(cur);
+    if constexpr (LSE) {
+      lse_update(acc_prev, i_begin + (int64_t)(t - 1) * TI);
+      // one MFMA of this tile, then a couple of the previous tile's epilogue VALU ops, and so on
+#pragma unroll
+      for (int g = 0; g < KH; ++g) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+      }
+    }
+    emit(acc_prev, i_begin + (int64_t)(t - 1) * TI);
+    commit(cur ^ 1);
+    __syncthreads();
+    acc_prev = acc;
+  }
+  if constexpr (LSE) lse_update(acc_prev, i_begin + (int64_t)(n_tiles - 1) * TI);
+  emit(acc_prev, i_begin + (int64_t)(n_tiles - 1) * TI);
+  if constexpr (LSE) {
     // fold the two k-halves' item subsets (lanes j and j+32 hold the same query)
     const float om = __shfl_xor(run_m, 32, 64), os = __shfl_xor(run_s, 32, 64);
     const float m = fmaxf(run_m, om);
@@ -484,8 +520,17 @@ template <int D>
 static void launch_gemm(dim3 grid, hipStream_t s, const float* item_table, int64_t n_items, const float* query,
                         int64_t n_query, float* scores, int64_t score_ld, float2* lse_part, int splits, int64_t per,
                         int64_t tile_stride, int64_t n_positions, FilterArgs flt) {
-  hipLaunchKernelGGL(fullscore_kernel<D>, grid, dim3(256), 0, s, item_table, n_items, query, n_query, scores, score_ld,
-                     lse_part, splits, per, tile_stride, n_positions, flt);
+  const bool L = lse_part != nullptr, S = scores != nullptr, F = flt.thr != nullptr;
+#define RSA_GEMM(LL, SS, FF)                                                                                       \
+  hipLaunchKernelGGL((fullscore_kernel<D, LL, SS, FF>), grid, dim3(256), 0, s, item_table, n_items, query, n_query, \
+                     scores, score_ld, lse_part, splits, per, tile_stride, n_positions, flt)
+  if (L && !S && !F) RSA_GEMM(true, false, false);        // training: logsumexp only
+  else if (L && !S && F) RSA_GEMM(true, false, true);     // eval: logsumexp + candidate filter
+  else if (!L && !S && F) RSA_GEMM(false, false, true);   // eval: candidate filter
+  else if (!L && S && !F) RSA_GEMM(false, true, false);   // materialised scores / threshold sample
+  else if (L && S && !F) RSA_GEMM(true, true, false);     // materialised scores + logsumexp
+  else RSA_GEMM(true, true, true);
+#undef RSA_GEMM
 }
 
 static void gemm_dispatch(int dim, dim3 grid, hipStream_t s, const float* item_table, int64_t n_items,
