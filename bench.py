@@ -27,10 +27,11 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 measured copy)
 
 
-def bytes_per_triplet(d, n, popular):
+def bytes_per_triplet(d, n, popular, fused_loss=False):
     """negative row + (user row + positive row + two ids) / n + id/score/logp
-    written + sampler probe."""
-    return 4 * d + 2 * 4 * d / n + 16.0 / n + 16 + (8 if popular else 0)
+    written + sampler probe; the fused BPR epilogue additionally writes d loss/d score (4 B per triplet) and
+    the per-query loss and d loss/d pos (8 B per query)."""
+    return 4 * d + 2 * 4 * d / n + 16.0 / n + 16 + (8 if popular else 0) + ((4 + 8.0 / n) if fused_loss else 0)
 
 
 def make_workload(dev, n_items, n_users, d, seed=1):
@@ -201,7 +202,7 @@ def main():
         torch.cuda.synchronize()
         k_ms = sorted(a.elapsed_time(b) for a, b in evs)
         k_avg = sum(k_ms) / len(k_ms)
-        alg = bytes_per_triplet(d, n, popular) * B * n
+        alg = bytes_per_triplet(d, n, popular, fused_loss=True) * B * n
         achieved = alg / (k_avg * 1e-3) / 1e9
         roofline = {'bound': 'hbm', 'kernel': 'rsa::fused_fwd_kernel<32,false,false,true,true> (sample+gather+score+BPR epilogue)',
                     'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
@@ -209,7 +210,7 @@ def main():
                     'alg_bytes_per_launch': int(alg), 'avg_kernel_ms': round(k_avg, 4),
                     'median_kernel_ms': round(k_ms[len(k_ms) // 2], 4)}
         pmc = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')
-        if os.path.exists(pmc):
+        if os.path.exists(pmc) and (args.items, args.batch, args.neg, args.dim, popular) == (10_000_001, 65536, 64, 128, True):
             try:
                 roofline['traffic'] = json.load(open(pmc)).get('fused_fwd_bytes_per_launch')
             except Exception:
@@ -254,6 +255,37 @@ def main():
                                   'frac_of_peak': round(flops / t_lse / 1e9 / 157.3, 3)}
         except Exception as e:
             extra['fullscore'] = {'error': repr(e)[:200]}
+        # configs[2] shape: SASRec tail -- ragged history gather [B, L<=50, d] + sampled softmax, n = 256
+        try:
+            b3, L3, n3, n_it3 = 8192, 50, 256, 1_000_001
+            g3 = torch.Generator(device=dev).manual_seed(3)
+            lens = torch.randint(1, L3 + 1, (b3,), device=dev, generator=g3)
+            end = torch.cumsum(lens, 0)
+            start = end - lens
+            flat = torch.randint(1, n_it3, (int(end[-1]),), device=dev, generator=g3)
+            it3 = item[:n_it3]
+            t_seg = time_gpu(lambda: ra.ops.seg_gather(it3, flat, start, end, L3), 50, 5) * 1e3
+            seg_bytes = float(end[-1]) * (4 * d + 8) + b3 * L3 * 4 * d + b3 * L3 * 8
+            q3 = user[1:b3 + 1].contiguous()
+            pos3 = torch.randint(1, n_it3, (b3,), device=dev, generator=g3)
+            ps3 = ra.PopularSamplerModel(counts[:n_it3]).to(dev)
+            kw3 = dict(pos_ids=pos3, sampler=nat.SAMPLER_POPULAR, table=ps3.table, pop_prob=ps3.pop_prob, guide=ps3.guide,
+                       guide_log2=ps3.guide_log2, table_prob=ps3.table_prob, cdf_lut=ps3.cdf_lut)
+            buf3 = {}
+
+            def step3():
+                buf3['o'] = ra.ops.fused_forward(it3, q3, n3, out=buf3.get('o'), **kw3)
+                o = buf3['o']
+                return ra.ops.pairwise_loss(nat.LOSS_SSM, o['pos_score'], o['neg_score'], o['pos_logp'], o['neg_logp'])
+            t3 = time_gpu(step3, 50, 5) * 1e3
+            extra['seq_softmax'] = {
+                'workload': f'B={b3} prefixes, L<={L3}, N={n_it3}, d={d}, popularity sampler n={n3}, SampledSoftmax '
+                            '(BASELINE.json configs[2] tail; the Transformer is stock PyTorch and not timed)',
+                'seg_gather_ms': round(t_seg, 4), 'seg_gather_GBs': round(seg_bytes / t_seg / 1e6, 1),
+                'sample_gather_score_ssm_ms': round(t3, 4), 'M_triplets_s': round(b3 * n3 / t3 / 1e3, 1),
+                'alg_GBs': round(bytes_per_triplet(d, n3, True) * b3 * n3 / t3 / 1e6, 1)}
+        except Exception as e:
+            extra['seq_softmax'] = {'error': repr(e)[:200]}
         value = B * n / ms_step / 1e3
         parallelism = 'single'
         workload = (f'BPR two-tower d={d}, synthetic {args.items} items / {args.users} users / 1e8-interaction Zipf '
