@@ -133,6 +133,7 @@ def main():
     ap.add_argument('--batch', type=int, default=65536, help='queries per step per GPU')
     ap.add_argument('--neg', type=int, default=64)
     ap.add_argument('--sampler', default='popular', choices=['popular', 'uniform'])
+    ap.add_argument('--guide-log2', type=int, default=None, help='override the sampler guide-table size (experiments)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-sweep', action='store_true')
     args = ap.parse_args()
@@ -169,7 +170,8 @@ def main():
         dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
     if world == 1 and not force_shard:
         item, user = make_workload(dev, args.items, args.users, d)
-        sampler = (ra.PopularSamplerModel(counts) if popular else ra.UniformSampler(args.items)).to(dev)
+        sampler = (ra.PopularSamplerModel(counts, guide_log2=args.guide_log2) if popular
+                   else ra.UniformSampler(args.items)).to(dev)
         kind = nat.SAMPLER_POPULAR if popular else nat.SAMPLER_UNIFORM
         kw = dict(query_index=uid, pos_ids=pos, sampler=kind)
         if popular:
