@@ -16,12 +16,12 @@
 // query operand lives in registers for the whole item range.  Exact fp32 (fmaf chain), 157 TFLOP/s peak.
 //
 // Top-k without materialising [B, N] (default when the caller does not ask for `scores`):
-//   A. the same GEMM over an evenly spread SAMPLE of 32-item tiles (<= 65 536 items) -> per-query
+//   A. the same GEMM over an evenly spread SAMPLE of 32-item tiles (<= 32 768 items) -> per-query
 //      threshold T = the j-th largest sampled score, j sized so that ~3k (+ margin) catalog items beat T;
 //   B. the full GEMM with a filter epilogue: a lane appends (score, item) to its query's candidate
 //      list only when score > T -- 16 compares per lane per tile, a rare atomic;
 //   C. exact radix select (11/11/10 bits) + bitonic sort over the few hundred candidates of each query.
-// A query whose candidate count ends up outside [k, CAP] (threshold too tight / too loose: a catalog whose
+// A query whose candidate count ends up outside [k, 4096] (or that overflows a 32-slot segment) (threshold too tight / too loose: a catalog whose
 // scores are far from exchangeable across the sampled tiles) is flagged and recomputed exactly by
 // D. a per-row radix select that evaluates the dot products on the fly.  The result is always the exact
 // top-k (ties -> smaller id).  With `scores` given, the radix select runs on the materialised rows.
@@ -34,12 +34,15 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int QB = 128;   // queries per workgroup (4 waves x 32)
 constexpr int TI = 32;    // items per tile
 
+// Candidate lists of the filter epilogue.  Every (query, item-range split, lane half) owns a private
+// segment of SEG slots and counts in a register: plain fire-and-forget stores, no atomics (a returning
+// global atomic inside the tile loop stalls the wave for a memory round trip and cost 25 % of the GEMM).
+constexpr int SEG = 32;
 struct FilterArgs {
   const float* thr;     // [n_query] per-query threshold (null: no filtering)
-  int32_t* cnt;         // [n_query] candidate counters (zeroed)
-  float* cand_val;      // [n_query, cap]
-  int32_t* cand_idx;    // [n_query, cap] item ids
-  int32_t cap;
+  int32_t* seg_cnt;     // [n_query, splits, 2] candidates seen per segment (may exceed SEG: overflow marker)
+  float* cand_val;      // [n_query, splits, 2, SEG]
+  int32_t* cand_idx;    // [n_query, splits, 2, SEG] item ids
 };
 
 // tile_stride == 1: the workgroup walks the contiguous item range [1 + bx*items_per_split, ...).
@@ -83,6 +86,8 @@ __global__ __launch_bounds__(256) void fullscore_kernel(const float* __restrict_
   const int n_tiles = i_begin < i_end ? (int)((i_end - i_begin + TI - 1) / TI) : 0;
   float thr = INFINITY;
   if (flt.thr != nullptr && q < n_query) thr = flt.thr[q];
+  int32_t my_cnt = 0;
+  const size_t seg = ((size_t)(q < n_query ? q : 0) * splits + blockIdx.x) * 2 + h;
 
   constexpr int LOADS = (TI * V4) / 256;    // float4 per thread per tile (D=128: 4)
   static_assert((TI * V4) % 256 == 0, "tile must split evenly over the workgroup");
@@ -158,11 +163,11 @@ __global__ __launch_bounds__(256) void fullscore_kernel(const float* __restrict_
         for (int r = 0; r < 16; ++r) {
           const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
           if (acc[r] > thr && i0 + row < i_end) {
-            const int32_t slot = atomicAdd(flt.cnt + q, 1);
-            if (slot < flt.cap) {
-              flt.cand_val[(size_t)q * flt.cap + slot] = acc[r];
-              flt.cand_idx[(size_t)q * flt.cap + slot] = (int32_t)(i0 + row);
+            if (my_cnt < SEG) {
+              flt.cand_val[seg * SEG + my_cnt] = acc[r];
+              flt.cand_idx[seg * SEG + my_cnt] = (int32_t)(i0 + row);
             }
+            ++my_cnt;
           }
         }
       }
@@ -184,6 +189,7 @@ __global__ __launch_bounds__(256) void fullscore_kernel(const float* __restrict_
 
   if (n_tiles == 0) {
     if (LSE && h == 0 && q < n_query) lse_part[(size_t)q * splits + blockIdx.x] = make_float2(-INFINITY, 0.f);
+    if (FILTER && q < n_query) flt.seg_cnt[seg] = 0;
     return;
   }
   fetch(0);
@@ -214,6 +220,7 @@ __global__ __launch_bounds__(256) void fullscore_kernel(const float* __restrict_
   }
   if constexpr (LSE) lse_update(acc_prev, i_begin + (int64_t)(n_tiles - 1) * TI);
   emit(acc_prev, i_begin + (int64_t)(n_tiles - 1) * TI);
+  if (FILTER && q < n_query) flt.seg_cnt[seg] = my_cnt;
   if constexpr (LSE) {
     // fold the two k-halves' item subsets (lanes j and j+32 hold the same query)
     const float om = __shfl_xor(run_m, 32, 64), os = __shfl_xor(run_s, 32, 64);
@@ -249,14 +256,15 @@ __device__ __forceinline__ float key_value(uint32_t k) {
 
 enum { SEL_DENSE = 0, SEL_CAND = 1, SEL_RECOMPUTE = 2, SEL_THRESHOLD = 3 };
 
+constexpr int CAND_MAX = 4096;   // candidates of one query that the select kernel compacts into LDS
 struct SelectArgs {
-  const float* values;      // DENSE/THRESHOLD: [n_rows, ld] score rows;  CAND: [n_rows, cap] candidate scores
-  const int32_t* cand_idx;  // CAND: [n_rows, cap] item ids
-  int32_t* cnt;             // CAND: [n_rows] candidate counts
+  const float* values;      // DENSE/THRESHOLD: [n_rows, ld] score rows;  CAND: [n_rows, n_seg, SEG] candidate scores
+  const int32_t* cand_idx;  // CAND: [n_rows, n_seg, SEG] item ids
+  const int32_t* seg_cnt;   // CAND: [n_rows, n_seg] candidates seen per segment
+  int32_t n_seg;            // CAND: segments per row (splits x 2)
   int32_t* flags;           // CAND: out, 1 = row must be recomputed;  RECOMPUTE: in
   int64_t ld;               // row stride of `values`
   int64_t n_cols;           // DENSE/THRESHOLD/RECOMPUTE: elements per row
-  int32_t cap;
   const float* item_table;  // RECOMPUTE: item rows 1..n_cols, query rows
   const float* query;
   int32_t dim;
@@ -273,15 +281,50 @@ __global__ __launch_bounds__(1024) void topk_row_kernel(SelectArgs a, int k, flo
   __shared__ uint32_t okey[1024];
   __shared__ int32_t oidx[1024];
   __shared__ float qrow[MODE == SEL_RECOMPUTE ? 128 : 1];
+  __shared__ float cval[MODE == SEL_CAND ? CAND_MAX : 1];
+  __shared__ int32_t cidx[MODE == SEL_CAND ? CAND_MAX : 1];
+  __shared__ int32_t s_total, s_over;
   const int tid = threadIdx.x;
   const int64_t r = blockIdx.x;
   int64_t n = a.n_cols;
   if (MODE == SEL_CAND) {
-    const int32_t c = a.cnt[r];
-    const bool bad = c < k || c > a.cap;
+    // compact the row's private segments into LDS: exclusive prefix of the segment counts (n_seg <= 2048)
+    if (tid == 0) s_over = 0;
+    for (int b = tid; b < 2048; b += 1024) {
+      int32_t c = b < a.n_seg ? a.seg_cnt[(size_t)r * a.n_seg + b] : 0;
+      if (c > SEG) {
+        s_over = 1;
+        c = SEG;
+      }
+      hist[b] = (uint32_t)c;
+    }
+    __syncthreads();
+    for (int off = 1; off < 2048; off <<= 1) {      // inclusive prefix sums (Hillis-Steele)
+      uint32_t v0 = 0, v1 = 0;
+      const int b0 = tid, b1 = tid + 1024;
+      if (b0 >= off) v0 = hist[b0 - off];
+      if (b1 >= off) v1 = hist[b1 - off];
+      __syncthreads();
+      hist[b0] += v0;
+      hist[b1] += v1;
+      __syncthreads();
+    }
+    if (tid == 0) s_total = (int32_t)hist[2047];
+    __syncthreads();
+    const int32_t total = s_total;
+    const bool bad = s_over != 0 || total < k || total > CAND_MAX;
     if (tid == 0) a.flags[r] = bad ? 1 : 0;
     if (bad) return;                       // recomputed exactly by the SEL_RECOMPUTE pass
-    n = c;
+    for (int b = tid; b < a.n_seg; b += 1024) {
+      const int32_t end = (int32_t)hist[b], beg = b ? (int32_t)hist[b - 1] : 0;
+      const size_t src = ((size_t)r * a.n_seg + b) * SEG;
+      for (int32_t e = beg; e < end; ++e) {
+        cval[e] = a.values[src + (e - beg)];
+        cidx[e] = a.cand_idx[src + (e - beg)];
+      }
+    }
+    __syncthreads();
+    n = total;
   }
   if (MODE == SEL_RECOMPUTE) {
     if (a.flags[r] == 0) return;
@@ -296,6 +339,7 @@ __global__ __launch_bounds__(1024) void topk_row_kernel(SelectArgs a, int k, flo
       for (int c = 0; c < a.dim; ++c) acc = __fmaf_rn(it[c], qrow[c], acc);
       return acc;
     }
+    if (MODE == SEL_CAND) return cval[i];
     return row[i];
   };
   uint32_t prefix = 0, pmask = 0;
@@ -355,7 +399,7 @@ __global__ __launch_bounds__(1024) void topk_row_kernel(SelectArgs a, int k, flo
   __syncthreads();
   for (int64_t i = tid; i < n; i += 1024) {
     const uint32_t key = order_key(value_at(i));
-    const int32_t id = MODE == SEL_CAND ? a.cand_idx[(size_t)r * a.cap + i] : (int32_t)i + 1;   // item id
+    const int32_t id = MODE == SEL_CAND ? cidx[i] : (int32_t)i + 1;   // item id
     if (key > prefix) {
       const uint32_t p = atomicAdd(&s_cnt_gt, 1u);
       okey[p] = key;
@@ -469,8 +513,7 @@ static int64_t fullscore_splits(int64_t n_query, int64_t n_positions) {
   return splits;
 }
 
-constexpr int32_t CAND_CAP = 8192;          // candidates kept per query by the filter epilogue
-constexpr int64_t SAMPLE_TILES_MAX = 2048;  // 65 536 sampled items
+constexpr int64_t SAMPLE_TILES_MAX = 1024;  // 32 768 sampled items
 constexpr int64_t FILTER_MIN_ITEMS = 32768; // below this the dense radix select is cheaper
 
 struct TopkPlan {
@@ -494,7 +537,7 @@ static TopkPlan plan_topk(int64_t n_items, int32_t k, bool scores_given) {
   if (j > 1024) j = 1024;
   if (j > pl.sample_items) j = pl.sample_items;
   pl.j = (int32_t)j;
-  if ((double)j / ratio > 0.6 * CAND_CAP) pl.filter = false;   // would crowd the candidate lists
+  if ((double)j / ratio > 0.6 * CAND_MAX) pl.filter = false;   // would crowd the candidate lists
   return pl;
 }
 
@@ -507,8 +550,10 @@ extern "C" int64_t rsa_fullscore_workspace_bytes(int64_t n_query, int64_t n_item
     const TopkPlan pl = plan_topk(n_items, k, false);
     if (pl.filter) {
       bytes += align256(n_query * pl.sample_items * 4);        // sample scores
-      bytes += 3 * align256(n_query * 4);                       // thresholds, counters, flags
-      bytes += 2 * align256(n_query * (int64_t)CAND_CAP * 4);   // candidate values + ids
+      const int64_t n_seg = fullscore_splits(n_query, n_items - 1) * 2;
+      bytes += 2 * align256(n_query * 4);                       // thresholds, flags
+      bytes += align256(n_query * n_seg * 4);                   // per-segment counts
+      bytes += 2 * align256(n_query * n_seg * (int64_t)SEG * 4);   // candidate values + ids
     } else {
       bytes += align256(n_query * (n_items - 1) * (int64_t)sizeof(float));   // dense score rows
     }
@@ -570,19 +615,16 @@ extern "C" int rsa_fullscore(const float* item_table, int64_t n_items, int32_t d
   ws += align256(n_query * splits * (int64_t)sizeof(float2));
   float2* lp = lse ? part : nullptr;
   const TopkPlan pl = plan_topk(n_items, k, scores != nullptr);
-  const FilterArgs no_filter{nullptr, nullptr, nullptr, nullptr, 0};
+  const FilterArgs no_filter{nullptr, nullptr, nullptr, nullptr};
 
   if (pl.filter) {
     float* sample = reinterpret_cast<float*>(ws);      ws += align256(n_query * pl.sample_items * 4);
+    const int64_t n_seg = splits_used * 2;
     float* thr = reinterpret_cast<float*>(ws);         ws += align256(n_query * 4);
-    int32_t* cnt = reinterpret_cast<int32_t*>(ws);     ws += align256(n_query * 4);
     int32_t* flags = reinterpret_cast<int32_t*>(ws);   ws += align256(n_query * 4);
-    float* cand_val = reinterpret_cast<float*>(ws);    ws += align256(n_query * (int64_t)CAND_CAP * 4);
+    int32_t* seg_cnt = reinterpret_cast<int32_t*>(ws); ws += align256(n_query * splits * 2 * 4);
+    float* cand_val = reinterpret_cast<float*>(ws);    ws += align256(n_query * splits * 2 * (int64_t)SEG * 4);
     int32_t* cand_idx = reinterpret_cast<int32_t*>(ws);
-    if (hipMemsetAsync(cnt, 0, n_query * 4, s) != hipSuccess) {
-      rsa::set_error("rsa_fullscore: memset failed");
-      return RSA_ERR_HIP;
-    }
     // A. sample GEMM + per-query threshold
     const int64_t ssplits = fullscore_splits(n_query, pl.sample_items);
     const int64_t sper = ((pl.sample_items + ssplits - 1) / ssplits + TI - 1) / TI * TI;
@@ -596,13 +638,13 @@ extern "C" int rsa_fullscore(const float* item_table, int64_t n_items, int32_t d
                        (float*)nullptr, (int64_t*)nullptr);
     RSA_CHECK_LAUNCH("rsa_fullscore(threshold)");
     // B. full GEMM with the filter epilogue (+ fused logsumexp)
-    const FilterArgs flt{thr, cnt, cand_val, cand_idx, CAND_CAP};
+    const FilterArgs flt{thr, seg_cnt, cand_val, cand_idx};
     gemm_dispatch(dim, dim3((unsigned)splits_used, groups), s, item_table, n_items, query, n_query, nullptr, n_cols, lp,
                   (int)splits_used, per, 1, n_cols, flt);
     RSA_CHECK_LAUNCH("rsa_fullscore(gemm+filter)");
     // C. exact select over the candidates;  D. exact recompute of flagged rows
     SelectArgs ca{};
-    ca.values = cand_val; ca.cand_idx = cand_idx; ca.cnt = cnt; ca.flags = flags; ca.ld = CAND_CAP; ca.cap = CAND_CAP;
+    ca.values = cand_val; ca.cand_idx = cand_idx; ca.seg_cnt = seg_cnt; ca.n_seg = (int32_t)n_seg; ca.flags = flags;
     hipLaunchKernelGGL(topk_row_kernel<SEL_CAND>, dim3((unsigned)n_query), dim3(1024), 0, s, ca, (int)k, topk_val,
                        topk_idx);
     SelectArgs ra{};
