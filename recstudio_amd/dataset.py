@@ -103,6 +103,66 @@ class _Loader:
         return len(self.sampler)
 
 
+class _DeviceLoader:
+    """Loader fast path: the interaction columns and the sample index live on the GPU, an
+    epoch's permutation is drawn there, and a batch dict is assembled without touching the host -- for
+    SeqDataset the ragged ``[start, end)`` history slices go through ``rsa_seg_gather`` (ids only) instead of
+    the per-batch Python ``torch.cat([arange ...])`` + ``pad_sequence`` (dataset.py:1428-1434).  Batches have
+    the same keys, dtypes and values as the host loader's."""
+
+    def __init__(self, dataset, batch_size, shuffle, drop_last, device):
+        from . import ops                                   # device work only; imported lazily (host-only users)
+        self.ops = ops
+        self.ds, self.batch_size, self.shuffle, self.drop_last = dataset, batch_size, shuffle, drop_last
+        self.device = torch.device(device)
+        self.cols = {k: v.to(self.device) for k, v in dataset.inter_feat.items()
+                     if k in dataset.use_field or k == dataset.frating}
+        self.index = dataset.data_index.to(self.device)
+        self.seq = isinstance(dataset, SeqDataset)
+        if self.seq:
+            self.max_len = int(dataset.sample_length.max())
+
+    def __len__(self):
+        n = self.index.shape[0]
+        return n // self.batch_size if self.drop_last else (n + self.batch_size - 1) // self.batch_size
+
+    def __iter__(self):
+        n = self.index.shape[0]
+        if self.seq:      # SortedDataSampler (dataset.py:1767-1780): batches of similar history length
+            length = self.index[:, 2] - self.index[:, 1]
+            key = length
+            if self.shuffle:
+                bucket = torch.div(torch.randperm(n, device=self.device), self.batch_size * 10, rounding_mode='floor')
+                key = length + bucket * (length.max() + 1)
+            order = torch.sort(key, stable=True).indices
+        else:
+            order = torch.randperm(n, device=self.device) if self.shuffle else torch.arange(n, device=self.device)
+        ds = self.ds
+        for lo in range(0, n, self.batch_size):
+            sel = order[lo:lo + self.batch_size]
+            if self.drop_last and sel.numel() < self.batch_size:
+                break
+            rows = self.index[sel]
+            if not self.seq:
+                yield {k: v[rows] for k, v in self.cols.items()}
+                continue
+            start, end = rows[:, 1].contiguous(), rows[:, 2].contiguous()
+            lens = end - start
+            L = int(lens.max())
+            batch = {ds.fuid: rows[:, 0], 'seqlen': lens}
+            ids, _, _ = self.ops.seg_gather(None, self.cols[ds.fiid], start, end, L, want_rows=False)
+            batch['in_' + ds.fiid] = ids
+            batch[ds.fiid] = self.cols[ds.fiid][end]
+            if ds.frating in self.cols:
+                # ratings of the history positions: same [start, end) windows, right-padded with 0
+                r = self.cols[ds.frating]
+                pos = torch.arange(L, device=self.device).view(1, -1) + start.view(-1, 1)
+                valid = pos < end.view(-1, 1)
+                batch['in_' + ds.frating] = torch.where(valid, r[pos.clamp(max=r.numel() - 1)], torch.zeros((), device=self.device))
+                batch[ds.frating] = r[end]
+            yield batch
+
+
 class TripletDataset:
     def __init__(self, name: str = 'ml-100k', config: Optional[Dict] = None, _interactions=None):
         self.name = name
@@ -378,6 +438,13 @@ class TripletDataset:
     def eval_loader(self, batch_size, num_workers=0, ddp=False, device=None):
         self.eval_mode = True
         return _Loader(self, SortedDataSampler(self, batch_size), device)
+
+    def device_train_loader(self, batch_size, shuffle=True, drop_last=False, device='cuda'):
+        """Training loader whose data never leaves the GPU (see _DeviceLoader)."""
+        if self.data_index.dim() > 1 and not isinstance(self, SeqDataset):
+            raise ValueError('device_train_loader is for training splits')
+        self.eval_mode = False
+        return _DeviceLoader(self, batch_size, shuffle, drop_last, device)
 
 
 class SeqDataset(TripletDataset):

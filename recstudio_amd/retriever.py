@@ -50,7 +50,7 @@ def default_config():
                   'init_method': 'xavier_normal', 'item_batch_size': 1024, 'learner': 'adam', 'learning_rate': 0.001,
                   'num_threads': 10, 'sampling_method': 'none', 'sampler': 'uniform', 'negative_count': 0,
                   'excluding_hist': False, 'scheduler': None, 'seed': 2022, 'weight_decay': 0.0,
-                  'tensorboard_path': None, 'sparse_grad': False},
+                  'tensorboard_path': None, 'sparse_grad': False, 'device_loader': True},
         'eval': {'batch_size': 128, 'cutoff': [5, 10, 20], 'val_metrics': ['ndcg', 'recall'], 'val_n_epoch': 1,
                  'test_metrics': ['ndcg', 'recall', 'precision', 'map', 'mrr', 'hit'], 'topk': 100,
                  'save_path': './saved/'},
@@ -429,7 +429,11 @@ class BaseRetriever(torch.nn.Module):
             if self.sampler is not None:
                 self.sampler.update(item_embs=self.item_vector)                 # recommender.py:564-570
             losses = []
-            for batch in train_data.train_loader(batch_size=tr['batch_size'], shuffle=True, drop_last=False):
+            if tr.get('device_loader', True) and hasattr(train_data, 'device_train_loader'):
+                loader = train_data.device_train_loader(tr['batch_size'], shuffle=True, drop_last=False, device=device)
+            else:
+                loader = train_data.train_loader(batch_size=tr['batch_size'], shuffle=True, drop_last=False)
+            for batch in loader:
                 batch = self._to_device(batch, device)
                 optimizer.zero_grad()
                 loss = self.training_step(batch)

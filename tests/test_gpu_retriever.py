@@ -157,3 +157,31 @@ def test_sasrec_fit_ml100k(ra, golden):
     best = model.fit(trn, val)
     res = model.evaluate(tst)
     assert np.isfinite(model.logged_metrics['train_loss']) and res['recall@20'] > 0.02
+
+
+def test_device_loaders_match_host_loaders(ra, golden):
+    """Loader fast path: batches assembled on the GPU (SeqDataset through rsa_seg_gather) equal the host
+    loader's batches (which are pinned to the reference in tests/test_dataset_golden.py)."""
+    g = golden('data_ml100k')
+    ds = make(ra.TripletDataset, g)
+    trn, _, _ = ds.build(split_ratio=[0.8, 0.1, 0.1], shuffle=True)
+    trn.drop_feat(trn.use_field)
+    host = list(trn.train_loader(512, shuffle=False))
+    dev = list(trn.device_train_loader(512, shuffle=False, device=DEV))
+    assert len(host) == len(dev) == 131
+    for hb, db in zip(host[:3] + host[-1:], dev[:3] + dev[-1:]):
+        assert sorted(hb) == sorted(db)
+        for k in hb:
+            assert db[k].is_cuda and torch.equal(hb[k], db[k].cpu()) and hb[k].dtype == db[k].dtype
+    sq = make(ra.SeqDataset, g, max_seq_len=50)
+    strn, _, _ = sq.build(split_ratio=2)
+    strn.drop_feat(strn.use_field)
+    host = list(zip(range(4), strn.train_loader(64, shuffle=False)))
+    dev = list(zip(range(4), strn.device_train_loader(64, shuffle=False, device=DEV)))
+    for (_, hb), (_, db) in zip(host, dev):
+        assert sorted(hb) == sorted(db)
+        for k in hb:
+            assert torch.equal(hb[k], db[k].cpu()), k
+    # shuffled epochs cover every sample exactly once
+    seen = torch.cat([b['user_id'] * 0 + 1 for b in trn.device_train_loader(4096, shuffle=True, device=DEV)])
+    assert int(seen.sum()) == len(trn)
