@@ -38,7 +38,7 @@ enum rsa_status {
   RSA_ERR_UNSUPPORTED = -3  /* valid request this build does not implement */
 };
 
-enum rsa_score_mode { RSA_SCORE_IP = 0, RSA_SCORE_COS = 1 };
+enum rsa_score_mode { RSA_SCORE_IP = 0, RSA_SCORE_COS = 1, RSA_SCORE_EUC = 2 /* EuclideanScorer, scorer.py:28-34 */ };
 enum rsa_sampler_kind { RSA_SAMPLER_GIVEN = 0, RSA_SAMPLER_UNIFORM = 1, RSA_SAMPLER_POPULAR = 2 };
 enum rsa_loss_kind { RSA_LOSS_BPR = 0, RSA_LOSS_SSM = 1, RSA_LOSS_BCE = 2 };
 
@@ -218,7 +218,7 @@ typedef struct rsa_backward_args {
                                   user table), -1 = none */
   int32_t item_pad_row;        /* item row that receives no gradient (padding_idx = 0 in RecStudio); -1 = none (an
                                   item-table shard that does not hold the global row 0) */
-  int32_t score_mode;          /* rsa_score_mode: RSA_SCORE_IP (tuned kernels) or RSA_SCORE_COS (plain kernel) */
+  int32_t score_mode;          /* rsa_score_mode: RSA_SCORE_IP (tuned kernels) or RSA_SCORE_COS / RSA_SCORE_EUC (plain kernel) */
   int32_t _pad;
 } rsa_backward_args;
 
@@ -256,6 +256,12 @@ int rsa_fullscore(const float* item_table, int64_t n_items, int32_t dim,
                   const float* query, int64_t n_query,
                   float* scores, float* lse, float* topk_val, int64_t* topk_idx, int32_t k,
                   void* workspace, int64_t workspace_bytes, rsa_stream_t stream);
+
+/* torch.topk(values, k) over the last dim of a [n_rows, n_cols] matrix (k <= 1024): values in descending
+ * order and their COLUMN indices (equal values -> smaller column first).  Used by the 'dns' sampling method
+ * (baseretriever.py:343-347: the hardest num_neg[1] of a sampled pool of num_neg[0] negatives). */
+int rsa_row_topk(const float* values, int64_t n_rows, int64_t n_cols, int32_t k, float* out_val,
+                 int64_t* out_col, rsa_stream_t stream);
 
 /* History exclusion of BaseRetriever.topk -- baseretriever.py:386-392: candidates (sorted
  * descending, [n_query, n_cand], item ids) that appear in user_hist [n_query, hist_len] (0-padded)

@@ -18,7 +18,7 @@ pinned by the Random123 known-answer vectors on CPU and by ``torch.randint`` /
 from .philox import (philox4x32_10, rng_grid_threads, rng_counter_offset,
                      device_randint, device_rand)
 from .path import (UniformSampler, PopularSamplerModel, popular_tables,
-                   searchsorted_left, masked_uniform_from_u, inner_product_score, cosine_score,
+                   searchsorted_left, masked_uniform_from_u, inner_product_score, cosine_score, euclidean_score,
                    bpr_loss, sampled_softmax_loss, softmax_loss, bce_loss,
                    retriever_forward, dense_grads, topk_with_history,
                    rank_metrics, seq_gather, test_step_hits)

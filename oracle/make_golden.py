@@ -63,7 +63,7 @@ def np_(t):
 def gen_score(scorer):
     out = {}
     g = torch.Generator().manual_seed(11)
-    ip, cos = scorer.InnerProductScorer(), scorer.CosineScorer()
+    ip, cos, euc = scorer.InnerProductScorer(), scorer.CosineScorer(), scorer.EuclideanScorer()
     for d in (64, 128):
         B, n, L, N = 6, 5, 4, 9
         cases = {
@@ -79,6 +79,7 @@ def gen_score(scorer):
             out[k + '_items'] = np_(it)
             out[k + '_ip'] = np_(ip(q.clone(), it.clone()))
             out[k + '_cos'] = np_(cos(q.clone(), it.clone()))
+            out[k + '_euc'] = np_(euc(q.clone(), it.clone()))
     np.savez_compressed(os.path.join(OUT, 'score.npz'), **out)
 
 

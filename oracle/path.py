@@ -157,6 +157,15 @@ def cosine_score(query, items):
     return out
 
 
+def euclidean_score(query, items):
+    """recstudio/model/scorer.py:28-34: -(-2 <q, x> + |x|^2 + |q|^2)."""
+    out = -2 * inner_product_score(query, items)
+    out = out + torch.sum(torch.square(items), dim=-1)
+    keep = (query.dim() != items.dim()) or (query.size(0) != items.size(0))
+    out = out + torch.sum(torch.square(query), dim=-1, keepdim=keep)
+    return -out
+
+
 # --------------------------------------------------------------------------- losses
 def bpr_loss(pos_score, neg_score):
     """recstudio/model/loss_func.py:55-59 (dns=False)."""

@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(HERE, 'librecstudio_amd.so')
 CSRC = os.path.join(HERE, 'csrc')
 
 RSA_OK = 0
-SCORE_IP, SCORE_COS = 0, 1
+SCORE_IP, SCORE_COS, SCORE_EUC = 0, 1, 2
 SAMPLER_GIVEN, SAMPLER_UNIFORM, SAMPLER_POPULAR = 0, 1, 2
 LOSS_BPR, LOSS_SSM, LOSS_BCE = 0, 1, 2
 
@@ -77,6 +77,7 @@ SIGNATURES = {
     'rsa_scatter_add_rows': (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_int64, c_void_p]),
     'rsa_seg_gather': (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int32,
                                c_void_p, c_void_p, c_void_p, c_void_p]),
+    'rsa_row_topk': (c_int, [c_void_p, c_int64, c_int64, c_int32, c_void_p, c_void_p, c_void_p]),
     'rsa_topk_mask_history': (c_int, [c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_int64, c_int32, c_void_p,
                                       c_void_p, c_void_p]),
     'rsa_shard_count': (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_int64, c_int32, c_void_p, c_void_p]),

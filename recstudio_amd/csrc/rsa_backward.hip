@@ -34,7 +34,7 @@ struct BwdParams {
   float* query_grad;
   float* query_table_grad;
   int64_t n_items, n_query_rows, n_queries;
-  int32_t dim, num_neg, qpad, ipad;
+  int32_t dim, num_neg, qpad, ipad, score_mode;
 };
 
 __device__ __forceinline__ int64_t clamp_id(int64_t id, int64_t n) { return id < 0 ? 0 : (id >= n ? n - 1 : id); }
@@ -243,7 +243,7 @@ __global__ __launch_bounds__(256) void bwd_qu_kernel(const BwdParams p) {
   }
 }
 
-// ------------------------------------------------------------------ cosine scorer
+// ------------------------------------------------------------------ cosine / Euclidean scorers
 // score = <q, x> / (|x| |q|)  (scorer.py:19-25, no epsilon):
 //   d score / d x = q / (|x||q|) - score * x / |x|^2        d score / d q = x / (|x||q|) - score * q / |q|^2
 // One wave per (query, item) element, positives included as column 0; a plain kernel -- cosine training
@@ -276,13 +276,14 @@ __global__ __launch_bounds__(256) void bwd_cos_kernel(const BwdParams p) {
     dot = group_sum<64>(dot);
     nx2 = group_sum<64>(nx2);
     nq2 = group_sum<64>(nq2);
+    const bool euc = p.score_mode == RSA_SCORE_EUC;   // score = -|x - q|^2: d/dx = 2(q - x), d/dq = 2(x - q)
     const float inv = 1.f / (sqrtf(nx2) * sqrtf(nq2));
     const float sc = dot * inv;
     const int64_t outrow = m * (n + 1) + (is_pos ? 0 : 1 + j);
     for (int col = lane; col < D; col += 64) {
       const float xv = x[col], qv = q[col];
-      const float gx = id != p.ipad ? d * (qv * inv - sc * xv / nx2) : 0.f;
-      const float gq = d * (xv * inv - sc * qv / nq2);
+      const float gx = id != p.ipad ? (euc ? 2.f * d * (qv - xv) : d * (qv * inv - sc * xv / nx2)) : 0.f;
+      const float gq = euc ? 2.f * d * (xv - qv) : d * (xv * inv - sc * qv / nq2);
       if (p.item_grad && id != p.ipad) atomicAdd(p.item_grad + (size_t)id * D + col, gx);
       if (p.item_grad_rows) p.item_grad_rows[(size_t)outrow * D + col] = gx;
       if (p.query_grad) atomicAdd(p.query_grad + (size_t)m * D + col, gq);
@@ -366,7 +367,8 @@ extern "C" int rsa_fused_backward(const rsa_backward_args* a, rsa_stream_t strea
   p.qpad = a->query_table_pad_row;
   p.ipad = a->item_pad_row;
   hipStream_t s = (hipStream_t)stream;
-  if (a->score_mode == RSA_SCORE_COS) {
+  p.score_mode = a->score_mode;
+  if (a->score_mode == RSA_SCORE_COS || a->score_mode == RSA_SCORE_EUC) {
     if (p.query_grad) {
       if (hipMemsetAsync(p.query_grad, 0, (size_t)p.n_queries * p.dim * sizeof(float), s) != hipSuccess) {
         rsa::set_error("rsa_fused_backward: memset failed");

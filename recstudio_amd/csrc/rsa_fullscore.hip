@@ -269,6 +269,7 @@ struct SelectArgs {
   const float* query;
   int32_t dim;
   float* thr_out;           // THRESHOLD: [n_rows] the k-th largest value of each row
+  int32_t idx_base;         // DENSE: reported index = column + idx_base (1: item ids of a catalog row, 0: columns)
 };
 
 // Exact top-k of one row (one 1024-thread workgroup per row): 3-pass radix select on the order-preserving
@@ -399,7 +400,7 @@ __global__ __launch_bounds__(1024) void topk_row_kernel(SelectArgs a, int k, flo
   __syncthreads();
   for (int64_t i = tid; i < n; i += 1024) {
     const uint32_t key = order_key(value_at(i));
-    const int32_t id = MODE == SEL_CAND ? cidx[i] : (int32_t)i + 1;   // item id
+    const int32_t id = MODE == SEL_CAND ? cidx[i] : (int32_t)i + (MODE == SEL_DENSE ? a.idx_base : 1);   // item id
     if (key > prefix) {
       const uint32_t p = atomicAdd(&s_cnt_gt, 1u);
       okey[p] = key;
@@ -660,7 +661,7 @@ extern "C" int rsa_fullscore(const float* item_table, int64_t n_items, int32_t d
     RSA_CHECK_LAUNCH("rsa_fullscore(gemm)");
     if (k > 0) {
       SelectArgs da{};
-      da.values = score_rows; da.ld = n_cols; da.n_cols = n_cols;
+      da.values = score_rows; da.ld = n_cols; da.n_cols = n_cols; da.idx_base = 1;
       hipLaunchKernelGGL(topk_row_kernel<SEL_DENSE>, dim3((unsigned)n_query), dim3(1024), 0, s, da, (int)k, topk_val,
                          topk_idx);
       RSA_CHECK_LAUNCH("rsa_fullscore(topk)");
@@ -671,6 +672,20 @@ extern "C" int rsa_fullscore(const float* item_table, int64_t n_items, int32_t d
                        (int)splits_used, lse);
     RSA_CHECK_LAUNCH("rsa_fullscore(lse)");
   }
+  return RSA_OK;
+}
+
+extern "C" int rsa_row_topk(const float* values, int64_t n_rows, int64_t n_cols, int32_t k, float* out_val,
+                            int64_t* out_col, rsa_stream_t stream) {
+  RSA_CHECK_ARG(n_rows >= 0 && n_cols >= 1 && k >= 1 && k <= 1024 && (int64_t)k <= n_cols,
+                "rsa_row_topk: need 1 <= k <= min(1024, n_cols)");
+  if (n_rows == 0) return RSA_OK;
+  RSA_CHECK_ARG(values && out_val && out_col, "rsa_row_topk: null pointer");
+  SelectArgs da{};
+  da.values = values; da.ld = n_cols; da.n_cols = n_cols; da.idx_base = 0;
+  hipLaunchKernelGGL(topk_row_kernel<SEL_DENSE>, dim3((unsigned)n_rows), dim3(1024), 0, (hipStream_t)stream, da, (int)k,
+                     out_val, out_col);
+  RSA_CHECK_LAUNCH("rsa_row_topk");
   return RSA_OK;
 }
 

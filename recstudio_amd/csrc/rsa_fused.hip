@@ -42,7 +42,7 @@ struct FwdParams {
   float* dneg;
   int64_t n_items, n_query_rows, n_queries, numel;
   PhiloxCall pc;
-  int32_t dim, num_neg, sampler, mask_pad_pos, guide_log2;
+  int32_t dim, num_neg, sampler, mask_pad_pos, guide_log2, score_mode;
 };
 
 template <int LPR, bool GENERIC>
@@ -174,9 +174,12 @@ __device__ __forceinline__ void tile_rows(const float* __restrict__ table, int D
   }
 }
 
-__device__ __forceinline__ float finish_score(bool cos, float dot, float inorm2, float qnorm2) {
+__device__ __forceinline__ float finish_score(int mode, float dot, float inorm2, float qnorm2) {
   // CosineScorer: dot / ||item|| / ||query||, two divisions, no epsilon (scorer.py:21-24)
-  return cos ? (dot / sqrtf(inorm2)) / sqrtf(qnorm2) : dot;
+  // EuclideanScorer: -(-2 dot + ||item||^2 + ||query||^2)                (scorer.py:28-34)
+  if (mode == RSA_SCORE_COS) return (dot / sqrtf(inorm2)) / sqrtf(qnorm2);
+  if (mode == RSA_SCORE_EUC) return -((-2.f * dot + inorm2) + qnorm2);
+  return dot;
 }
 
 #ifndef RSA_FWD_MIN_WAVES
@@ -266,10 +269,10 @@ __global__ __launch_bounds__(256, RSA_FWD_MIN_WAVES) void fused_fwd_kernel(const
     float dot = 0.f, in2 = 1.f, qn2 = 1.f;
     tile_rows<LPR, GENERIC, COS, QU, NT>(p.item_table, D, id, p.query, qrow_lane, qf, dot, in2, qn2);
     if constexpr (COS && QU) qn2 = qn2_u;
-    if (act) p.neg_score[e] = finish_score(COS, dot, in2, qn2);
+    if (act) p.neg_score[e] = finish_score(COS ? p.score_mode : RSA_SCORE_IP, dot, in2, qn2);
 
     // ---- 4. positives (+ the fused BPR epilogue: every tile of a query needs the positive score)
-    const float neg_s = finish_score(COS, dot, in2, qn2);
+    const float neg_s = finish_score(COS ? p.score_mode : RSA_SCORE_IP, dot, in2, qn2);
     if (p.pos_ids != nullptr && (p.pos_score != nullptr || p.pos_logp != nullptr)) {
       if constexpr (QU) {
         const bool fuse = p.row_loss != nullptr;
@@ -281,7 +284,7 @@ __global__ __launch_bounds__(256, RSA_FWD_MIN_WAVES) void fused_fwd_kernel(const
             float pd = group_sum<LPR>(frag_dot<LPR, GENERIC>(x, qf));
             float pi2 = 1.f;
             if constexpr (COS) pi2 = group_sum<LPR>(frag_dot<LPR, GENERIC>(x, x));
-            s = finish_score(COS, pd, pi2, qn2_u);
+            s = finish_score(COS ? p.score_mode : RSA_SCORE_IP, pd, pi2, qn2_u);
             if (p.mask_pad_pos && pad) s = -INFINITY;
             if (first && lane == 0) p.pos_score[m_lane] = s;
           }
@@ -319,7 +322,7 @@ __global__ __launch_bounds__(256, RSA_FWD_MIN_WAVES) void fused_fwd_kernel(const
             float pd = 0.f, pi2 = 1.f, pq2 = 1.f;
             tile_rows<LPR, GENERIC, COS, false, false>(p.item_table, D, (int32_t)pid64, p.query, qrow_lane, qf, pd,
                                                        pi2, pq2);
-            float s = finish_score(COS, pd, pi2, pq2);
+            float s = finish_score(COS ? p.score_mode : RSA_SCORE_IP, pd, pi2, pq2);
             if (p.mask_pad_pos && pad) s = -INFINITY;
             if (owner) p.pos_score[m_lane] = s;
           }
@@ -369,7 +372,7 @@ extern "C" int rsa_fused_sample_gather_score(const rsa_fused_args* a, rsa_stream
   RSA_CHECK_ARG(a->n_items >= 2 && a->n_items < (1ll << 31), "rsa_fused_sample_gather_score: n_items out of range");
   RSA_CHECK_ARG(a->n_query_rows >= 1 && a->n_query_rows < (1ll << 31),
                 "rsa_fused_sample_gather_score: n_query_rows out of range");
-  RSA_CHECK_ARG(a->score_mode == RSA_SCORE_IP || a->score_mode == RSA_SCORE_COS,
+  RSA_CHECK_ARG(a->score_mode >= RSA_SCORE_IP && a->score_mode <= RSA_SCORE_EUC,
                 "rsa_fused_sample_gather_score: unknown score_mode %d", a->score_mode);
   RSA_CHECK_ARG(a->sampler >= RSA_SAMPLER_GIVEN && a->sampler <= RSA_SAMPLER_POPULAR,
                 "rsa_fused_sample_gather_score: unknown sampler %d", a->sampler);
@@ -417,8 +420,9 @@ extern "C" int rsa_fused_sample_gather_score(const rsa_fused_args* a, rsa_stream
   p.sampler = a->sampler;
   p.mask_pad_pos = a->mask_pad_pos;
   p.guide_log2 = a->guide_log2;
+  p.score_mode = a->score_mode;
 
-  const bool cos = a->score_mode == RSA_SCORE_COS;
+  const bool cos = a->score_mode != RSA_SCORE_IP;   // cosine and Euclidean both need the squared norms
   hipStream_t s = (hipStream_t)stream;
   int rc = RSA_OK;
   if (numel == 0) {

@@ -186,7 +186,7 @@ def fused_forward(item_table, query, num_neg, *, query_index=None, pos_ids=None,
             if pos_ids is not None:
                 out['pos_logp'] = torch.empty(M, dtype=torch.float32, device=dev)
     a.item_table, a.n_items, a.dim = ptr(item_table), n_items, dim
-    a.score_mode = nat.SCORE_COS if cosine else nat.SCORE_IP
+    a.score_mode = int(cosine) if not isinstance(cosine, bool) else (nat.SCORE_COS if cosine else nat.SCORE_IP)
     a.query, a.query_index, a.n_query_rows = ptr(query), ptr(query_index), query.shape[0]
     a.pos_ids, a.n_queries, a.num_neg = ptr(pos_ids), M, n
     a.sampler, a.mask_pad_pos, a.guide_log2 = int(sampler), int(bool(mask_pad_pos)), int(guide_log2)
@@ -280,7 +280,7 @@ def fused_backward(item_table, query, neg_ids, dneg, *, query_index=None, pos_id
     a.query_table_grad = ptr(_need_opt(query_table_grad, torch.float32, 'query_table_grad'))
     a.query_table_pad_row = int(query_table_pad_row)
     a.item_pad_row = int(item_pad_row)
-    a.score_mode = nat.SCORE_COS if cosine else nat.SCORE_IP
+    a.score_mode = int(cosine) if not isinstance(cosine, bool) else (nat.SCORE_COS if cosine else nat.SCORE_IP)
     nat.check(nat.lib().rsa_fused_backward(ctypes.byref(a), _stream()), 'rsa_fused_backward')
     return item_grad, rows, qgrad
 
@@ -339,3 +339,14 @@ def topk_mask_history(cand_val, cand_idx, user_hist, k):
     nat.check(nat.lib().rsa_topk_mask_history(ptr(cand_val), ptr(cand_idx), kc, ptr(user_hist), user_hist.shape[1], B,
                                               int(k), ptr(out_v), ptr(out_i), _stream()), 'rsa_topk_mask_history')
     return out_v, out_i
+
+
+def row_topk(values, k):
+    """torch.topk(values, k) over the last dim (k <= 1024) -> (values, column indices)."""
+    values = _need(values, torch.float32, 'values')
+    lead, n = values.shape[:-1], values.shape[-1]
+    v2 = values.reshape(-1, n)
+    out_v = torch.empty(v2.shape[0], k, dtype=torch.float32, device=values.device)
+    out_i = torch.empty(v2.shape[0], k, dtype=torch.int64, device=values.device)
+    nat.check(nat.lib().rsa_row_topk(ptr(v2), v2.shape[0], n, int(k), ptr(out_v), ptr(out_i), _stream()), 'rsa_row_topk')
+    return out_v.view(*lead, k), out_i.view(*lead, k)

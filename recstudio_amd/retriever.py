@@ -33,7 +33,7 @@ from .dataset import SeqDataset, TripletDataset
 from .fused import fused_bpr_loss, retriever_scores
 from .loss_func import BPRLoss, FullScoreLoss, PairwiseLoss, PointwiseLoss, SampledSoftmaxLoss, SoftmaxLoss
 from .sampler import PopularSamplerModel, Sampler, UniformSampler
-from .scorer import CosineScorer, InnerProductScorer
+from .scorer import CosineScorer, EuclideanScorer, InnerProductScorer
 
 __all__ = ['BaseRetriever', 'TwoTowerRecommender', 'ItemTowerRecommender', 'BPR', 'SASRec', 'default_config',
            'seed_everything']
@@ -211,9 +211,10 @@ class BaseRetriever(torch.nn.Module):
     # ------------------------------------------------------------------ forward
     def _fused_ok(self):
         return (isinstance(self.item_encoder, torch.nn.Embedding) and len(self.item_fields) == 1
-                and type(self.score_func) in (InnerProductScorer, CosineScorer)
+                and type(self.score_func) in (InnerProductScorer, CosineScorer, EuclideanScorer)
                 and (self.sampler is None or type(self.sampler) in (UniformSampler, PopularSamplerModel))
-                and self.config['train'].get('sampling_method', 'none') == 'none')
+                and self.config['train'].get('sampling_method', 'none') == 'none'
+                and not isinstance(getattr(self, 'neg_count', None), (list, tuple)))
 
     def forward(self, batch: Dict, full_score: bool = False, return_query: bool = False, return_item: bool = False,
                 return_neg_item: bool = False, return_neg_id: bool = False):
@@ -221,7 +222,7 @@ class BaseRetriever(torch.nn.Module):
             return self._forward_plugins(batch, full_score, return_query, return_item, return_neg_item, return_neg_id)
         output = {}
         pos_items = self._get_item_feat(batch)
-        cosine = isinstance(self.score_func, CosineScorer)
+        cosine = self.score_func.cosine      # False / True / rsa_score_mode of the Euclidean scorer
         query = None
         if self.sampler is not None:
             if self.neg_count is None:
@@ -312,11 +313,32 @@ class BaseRetriever(torch.nn.Module):
         return (pos_prob, neg_id, neg_prob, query) if return_query else (pos_prob, neg_id, neg_prob)
 
     def sampling(self, batch, num_neg, method='none', excluding_hist=False, t=1, return_query=False, query=None):
-        if method != 'none':
-            raise NotImplementedError("only sampling_method='none' (the reference default) is covered")
+        """baseretriever.py:248-369 for ``method`` in ('none', 'dns').  'dns' (dynamic negative sampling,
+        :330-347): draw a pool of num_neg[0] negatives, score it with the gather+score kernel (no [B, n0, d]
+        tensor), keep the num_neg[1] highest-scoring ones."""
+        if method not in ('none', 'dns'):
+            raise NotImplementedError("sampling_method: only 'none' (the reference default) and 'dns' are covered")
         assert self.sampler is not None, 'excepted sampler of retriever to be Sampler, but get None.'
-        n = num_neg[1] if isinstance(num_neg, (list, tuple)) else num_neg
-        log_pos_prob, neg_id, log_neg_prob, query = self._sample(batch, n, excluding_hist, True)
+        if isinstance(num_neg, int):
+            num_neg = [num_neg, num_neg]
+        assert len(num_neg) == 2 and num_neg[0] >= num_neg[1], 'negative_count must be [pool, kept] with pool >= kept'
+        if method == 'none':
+            log_pos_prob, neg_id, log_neg_prob, query = self._sample(batch, num_neg[1], excluding_hist, True)
+        else:
+            log_pos_prob, pool, _, query = self._sample(batch, num_neg[0], excluding_hist, True)
+            if not (isinstance(self.item_encoder, torch.nn.Embedding)
+                    and type(self.score_func) in (InnerProductScorer, CosineScorer, EuclideanScorer)):
+                raise NotImplementedError("'dns' needs an nn.Embedding item tower and a stock scorer")
+            lead = pool.shape[:-1]
+            with torch.no_grad():
+                q2 = query.reshape(-1, query.shape[-1])
+                scores = ops.fused_forward(self.item_encoder.weight, q2, num_neg[0],
+                                           neg_ids=pool.reshape(-1, num_neg[0]).contiguous(),
+                                           cosine=self.score_func.cosine)['neg_score']
+                _, cols = ops.row_topk(scores, num_neg[1])
+                neg_id = torch.gather(pool.reshape(-1, num_neg[0]), -1, cols).view(*lead, num_neg[1])
+            log_neg_prob = torch.zeros_like(neg_id)
+            log_pos_prob = torch.zeros_like(batch.get(self.fiid))
         log_pos_prob = log_pos_prob.view_as(batch.get(self.fiid))
         result = (log_pos_prob.detach(), neg_id, log_neg_prob.detach())
         return (result, query) if return_query else (result, None)

@@ -11,7 +11,7 @@ import torch
 from . import _native as nat
 from . import ops
 
-__all__ = ['InnerProductScorer', 'CosineScorer']
+__all__ = ['InnerProductScorer', 'CosineScorer', 'EuclideanScorer']
 
 
 class _RowScoreFn(torch.autograd.Function):
@@ -64,6 +64,11 @@ class CosineScorer(InnerProductScorer):
     cosine = True
 
 
+class EuclideanScorer(InnerProductScorer):
+    """recstudio/model/scorer.py:28-34: -(|items|^2 + |query|^2 - 2 <query, items>)."""
+    cosine = nat.SCORE_EUC      # the `cosine` slot carries the rsa_score_mode
+
+
 class _FullScoreFn(torch.autograd.Function):
     """[B, N] = query @ items.T with the fp32-MFMA kernel; the backward GEMMs are plain library
     GEMMs (rocBLAS through torch.matmul)."""
@@ -84,5 +89,5 @@ class _FullScoreFn(torch.autograd.Function):
 def full_scores(query, items, cosine=False):
     """([B,D],[N,D]) case of the scorers (scorer.py:16): items has no padding row here."""
     if cosine:
-        raise NotImplementedError('CosineScorer over the full catalog is not implemented in this build')
+        raise NotImplementedError('Cosine / Euclidean scorers over the full catalog are not implemented in this build')
     return _FullScoreFn.apply(query, items.contiguous())

@@ -185,3 +185,36 @@ def test_device_loaders_match_host_loaders(ra, golden):
     # shuffled epochs cover every sample exactly once
     seen = torch.cat([b['user_id'] * 0 + 1 for b in trn.device_train_loader(4096, shuffle=True, device=DEV)])
     assert int(seen.sum()) == len(trn)
+
+
+def test_dns_sampling_method(ra):
+    """sampling_method='dns' (baseretriever.py:330-347): the reference's op sequence on this device --
+    randint pool -> embedding -> matmul -> topk -> gather -- against the kernel path, same seed."""
+    N, U, d, B, n0, n1 = 4001, 100, 64, 70, 32, 4
+    m = ra.BaseRetriever({'model': {'embed_dim': d}, 'train': {'negative_count': [n0, n1], 'sampling_method': 'dns'}},
+                         item_encoder=torch.nn.Embedding(N, d, padding_idx=0),
+                         query_encoder=torch.nn.Embedding(U, d, padding_idx=0), sampler=ra.UniformSampler(N),
+                         loss=ra.BPRLoss())
+    m.fiid, m.fuid, m.frating = 'item_id', 'user_id', 'rating'
+    m.item_fields, m.query_fields, m.neg_count = {'item_id'}, {'user_id'}, [n0, n1]
+    m._init_parameter()
+    m.to(DEV)
+    assert not m._fused_ok()
+    batch = {'user_id': torch.randint(1, U, (B,), device=DEV), 'item_id': torch.randint(1, N, (B,), device=DEV),
+             'rating': torch.ones(B, device=DEV)}
+    torch.manual_seed(9)
+    out = m.forward(batch, return_neg_id=True)
+    torch.manual_seed(9)
+    pool = torch.randint(1, N, (B, n0), device=DEV)
+    q = m.query_encoder(batch['user_id'])
+    s = torch.matmul(m.item_encoder(pool), q.unsqueeze(-1)).squeeze(-1)
+    want = torch.gather(pool, -1, torch.topk(s, n1).indices)
+    assert torch.equal(out['neg_id'], want)
+    np.testing.assert_allclose(out['score']['neg_score'].detach().cpu(), torch.topk(s, n1).values.detach().cpu(),
+                               rtol=1e-4, atol=1e-6)
+    loss = m.training_step(batch)
+    loss.backward()
+    assert torch.isfinite(loss) and m.item_encoder.weight.grad is not None and not m.item_encoder.weight.grad[0].any()
+    v, c = ra.ops.row_topk(s.detach(), 7)
+    wv, wc = torch.topk(s.detach(), 7)
+    assert torch.equal(v, wv) and torch.equal(c, wc)

@@ -45,6 +45,7 @@ def test_scorers(golden):
             q, it = T(g[k + '_q']), T(g[k + '_items'])
             np.testing.assert_allclose(oracle.inner_product_score(q, it).numpy(), g[k + '_ip'], rtol=1e-6, atol=1e-6)
             np.testing.assert_allclose(oracle.cosine_score(q, it).numpy(), g[k + '_cos'], rtol=1e-6, atol=1e-6)
+            np.testing.assert_allclose(oracle.euclidean_score(q, it).numpy(), g[k + '_euc'], rtol=1e-5, atol=1e-4)
 
 
 def test_losses(golden):
