@@ -257,6 +257,15 @@ int rsa_fullscore(const float* item_table, int64_t n_items, int32_t dim,
                   float* scores, float* lse, float* topk_val, int64_t* topk_idx, int32_t k,
                   void* workspace, int64_t workspace_bytes, rsa_stream_t stream);
 
+/* Backward of logsumexp over the full catalog (SoftmaxLoss, loss_func.py:39-47, when the forward was
+ * rsa_fullscore(..., lse) and [B, N-1] was never written):  probs[b, i-1] = row_scale[b] * exp(<q_b, item_i> - lse[b])
+ * = row_scale[b] * softmax_i, recomputed by the same MFMA kernel.  d lse/d query = probs @ items[1:],
+ * d lse/d items[1:] = probs^T @ query are then plain library GEMMs on the caller's side.
+ * row_scale may be null (1).  probs: [n_query, n_items-1]. */
+int rsa_fullscore_softmax(const float* item_table, int64_t n_items, int32_t dim, const float* query,
+                          int64_t n_query, const float* lse, const float* row_scale, float* probs,
+                          rsa_stream_t stream);
+
 /* torch.topk(values, k) over the last dim of a [n_rows, n_cols] matrix (k <= 1024): values in descending
  * order and their COLUMN indices (equal values -> smaller column first).  Used by the 'dns' sampling method
  * (baseretriever.py:343-347: the hardest num_neg[1] of a sampled pool of num_neg[0] negatives). */

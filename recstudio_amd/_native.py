@@ -77,6 +77,8 @@ SIGNATURES = {
     'rsa_scatter_add_rows': (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_int64, c_void_p]),
     'rsa_seg_gather': (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int32,
                                c_void_p, c_void_p, c_void_p, c_void_p]),
+    'rsa_fullscore_softmax': (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_int64, c_void_p, c_void_p, c_void_p,
+                                      c_void_p]),
     'rsa_row_topk': (c_int, [c_void_p, c_int64, c_int64, c_int32, c_void_p, c_void_p, c_void_p]),
     'rsa_topk_mask_history': (c_int, [c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_int64, c_int32, c_void_p,
                                       c_void_p, c_void_p]),

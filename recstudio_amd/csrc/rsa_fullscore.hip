@@ -43,6 +43,10 @@ struct FilterArgs {
   int32_t* seg_cnt;     // [n_query, splits, 2] candidates seen per segment (may exceed SEG: overflow marker)
   float* cand_val;      // [n_query, splits, 2, SEG]
   int32_t* cand_idx;    // [n_query, splits, 2, SEG] item ids
+  // SCORES epilogue transform (backward of the full softmax): with sm_lse set the stored value is
+  // sm_scale[q] * exp(score - sm_lse[q]) instead of the raw score
+  const float* sm_lse;    // [n_query] or null
+  const float* sm_scale;  // [n_query] or null (1)
 };
 
 // tile_stride == 1: the workgroup walks the contiguous item range [1 + bx*items_per_split, ...).
@@ -86,6 +90,12 @@ __global__ __launch_bounds__(256) void fullscore_kernel(const float* __restrict_
   const int n_tiles = i_begin < i_end ? (int)((i_end - i_begin + TI - 1) / TI) : 0;
   float thr = INFINITY;
   if (flt.thr != nullptr && q < n_query) thr = flt.thr[q];
+  float my_lse = 0.f, my_scale = 1.f;
+  const bool softmax_out = SCORES && flt.sm_lse != nullptr;
+  if (softmax_out && q < n_query) {
+    my_lse = flt.sm_lse[q];
+    if (flt.sm_scale != nullptr) my_scale = flt.sm_scale[q];
+  }
   int32_t my_cnt = 0;
   const size_t seg = ((size_t)(q < n_query ? q : 0) * splits + blockIdx.x) * 2 + h;
 
@@ -143,7 +153,8 @@ __global__ __launch_bounds__(256) void fullscore_kernel(const float* __restrict_
       // transpose the wave's 32 (items) x 32 (queries) tile through LDS so that every half-wave
       // writes 128 contiguous bytes of one query's score row
 #pragma unroll
-      for (int r = 0; r < 16; ++r) tpose[wave][j][(r & 3) + 8 * (r >> 2) + 4 * h] = acc[r];
+      for (int r = 0; r < 16; ++r)
+        tpose[wave][j][(r & 3) + 8 * (r >> 2) + 4 * h] = softmax_out ? my_scale * __expf(acc[r] - my_lse) : acc[r];
       __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the wave's own LDS writes have landed
 #pragma unroll
       for (int tt = 0; tt < 16; ++tt) {
@@ -616,7 +627,7 @@ extern "C" int rsa_fullscore(const float* item_table, int64_t n_items, int32_t d
   ws += align256(n_query * splits * (int64_t)sizeof(float2));
   float2* lp = lse ? part : nullptr;
   const TopkPlan pl = plan_topk(n_items, k, scores != nullptr);
-  const FilterArgs no_filter{nullptr, nullptr, nullptr, nullptr};
+  const FilterArgs no_filter{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 
   if (pl.filter) {
     float* sample = reinterpret_cast<float*>(ws);      ws += align256(n_query * pl.sample_items * 4);
@@ -639,7 +650,7 @@ extern "C" int rsa_fullscore(const float* item_table, int64_t n_items, int32_t d
                        (float*)nullptr, (int64_t*)nullptr);
     RSA_CHECK_LAUNCH("rsa_fullscore(threshold)");
     // B. full GEMM with the filter epilogue (+ fused logsumexp)
-    const FilterArgs flt{thr, seg_cnt, cand_val, cand_idx};
+    const FilterArgs flt{thr, seg_cnt, cand_val, cand_idx, nullptr, nullptr};
     gemm_dispatch(dim, dim3((unsigned)splits_used, groups), s, item_table, n_items, query, n_query, nullptr, n_cols, lp,
                   (int)splits_used, per, 1, n_cols, flt);
     RSA_CHECK_LAUNCH("rsa_fullscore(gemm+filter)");
@@ -672,6 +683,28 @@ extern "C" int rsa_fullscore(const float* item_table, int64_t n_items, int32_t d
                        (int)splits_used, lse);
     RSA_CHECK_LAUNCH("rsa_fullscore(lse)");
   }
+  return RSA_OK;
+}
+
+extern "C" int rsa_fullscore_softmax(const float* item_table, int64_t n_items, int32_t dim, const float* query,
+                                     int64_t n_query, const float* lse, const float* row_scale, float* probs,
+                                     rsa_stream_t stream) {
+  RSA_CHECK_ARG(n_query >= 0 && n_items >= 2, "rsa_fullscore_softmax: need n_items >= 2");
+  if (n_query == 0) return RSA_OK;
+  RSA_CHECK_ARG(item_table && query && lse && probs, "rsa_fullscore_softmax: null pointer");
+  if (dim != 32 && dim != 64 && dim != 128) {
+    rsa::set_error("rsa_fullscore_softmax: dim=%d: the MFMA full-score kernel is built for dim in {32, 64, 128}", dim);
+    return RSA_ERR_UNSUPPORTED;
+  }
+  const int64_t n_cols = n_items - 1;
+  const unsigned groups = (unsigned)((n_query + QB - 1) / QB);
+  const int64_t splits = fullscore_splits(n_query, n_cols);
+  const int64_t per = ((n_cols + splits - 1) / splits + TI - 1) / TI * TI;
+  const int64_t splits_used = (n_cols + per - 1) / per;
+  const FilterArgs ep{nullptr, nullptr, nullptr, nullptr, lse, row_scale};
+  gemm_dispatch(dim, dim3((unsigned)splits_used, groups), (hipStream_t)stream, item_table, n_items, query, n_query, probs,
+                n_cols, nullptr, (int)splits_used, per, 1, n_cols, ep);
+  RSA_CHECK_LAUNCH("rsa_fullscore_softmax");
   return RSA_OK;
 }
 

@@ -295,6 +295,18 @@ def row_lse(x, want_softmax=False, scale=1.0):
     return lse, sm
 
 
+def _pad_k(item_table, query):
+    """The MFMA kernel is built for d in {32, 64, 128}: zero-pad the k dimension otherwise (a copy -- only for
+    unusual dims; the dot products are unchanged)."""
+    dim = item_table.shape[1]
+    if dim in (32, 64, 128):
+        return item_table, query, dim
+    if dim > 128:
+        raise NotImplementedError(f'full-catalog scoring supports embed_dim <= 128, got {dim}')
+    pad = (32 if dim < 32 else 64 if dim < 64 else 128) - dim
+    return torch.nn.functional.pad(item_table, (0, pad)), torch.nn.functional.pad(query, (0, pad)), dim + pad
+
+
 def fullscore(item_table, query, *, want_scores=False, want_lse=False, k=0, items_without_pad=False):
     """rsa_fullscore: scores of query [B,d] against rows 1.. of item_table [N,d].
     ``items_without_pad``: ``item_table`` is the reference's ``item_vector`` (= weight[1:], no padding
@@ -303,15 +315,7 @@ def fullscore(item_table, query, *, want_scores=False, want_lse=False, k=0, item
     query = _need(query, torch.float32, 'query')
     dev = item_table.device
     n_items, dim = item_table.shape
-    if dim not in (32, 64, 128):
-        # the MFMA kernel is built for d in {32, 64, 128}: zero-pad the k dimension (a copy -- only
-        # for unusual dims; the dot products are unchanged)
-        if dim > 128:
-            raise NotImplementedError(f'full-catalog scoring supports embed_dim <= 128, got {dim}')
-        pad = (32 if dim < 32 else 64 if dim < 64 else 128) - dim
-        item_table = torch.nn.functional.pad(item_table, (0, pad))
-        query = torch.nn.functional.pad(query, (0, pad))
-        dim += pad
+    item_table, query, dim = _pad_k(item_table, query)
     table_ptr = ptr(item_table)
     if items_without_pad:
         n_items += 1
@@ -326,6 +330,22 @@ def fullscore(item_table, query, *, want_scores=False, want_lse=False, k=0, item
     nat.check(nat.lib().rsa_fullscore(table_ptr, n_items, dim, ptr(query), B, ptr(scores), ptr(lse), ptr(tv),
                                       ptr(ti), int(k), ptr(ws), ws_bytes, _stream()), 'rsa_fullscore')
     return scores, lse, tv, ti
+
+
+def fullscore_softmax(item_table, query, lse, row_scale=None):
+    """rsa_fullscore_softmax: probs[b, i-1] = row_scale[b] * exp(<query_b, item_i> - lse[b]) over rows 1.. of
+    ``item_table`` (dims in {32, 64, 128})."""
+    item_table = _need(item_table, torch.float32, 'item_table')
+    query = _need(query, torch.float32, 'query')
+    lse = _need(lse, torch.float32, 'lse')
+    item_table, query, dim = _pad_k(item_table, query)
+    n_items = item_table.shape[0]
+    B = query.shape[0]
+    probs = torch.empty(B, n_items - 1, dtype=torch.float32, device=item_table.device)
+    nat.check(nat.lib().rsa_fullscore_softmax(ptr(item_table), n_items, dim, ptr(query), B, ptr(lse),
+                                              ptr(_need_opt(row_scale, torch.float32, 'row_scale')), ptr(probs),
+                                              _stream()), 'rsa_fullscore_softmax')
+    return probs
 
 
 def topk_mask_history(cand_val, cand_idx, user_hist, k):

@@ -33,7 +33,7 @@ from .dataset import SeqDataset, TripletDataset
 from .fused import fused_bpr_loss, retriever_scores
 from .loss_func import BPRLoss, FullScoreLoss, PairwiseLoss, PointwiseLoss, SampledSoftmaxLoss, SoftmaxLoss
 from .sampler import PopularSamplerModel, Sampler, UniformSampler
-from .scorer import CosineScorer, EuclideanScorer, InnerProductScorer
+from .scorer import CosineScorer, EuclideanScorer, InnerProductScorer, full_lse
 
 __all__ = ['BaseRetriever', 'TwoTowerRecommender', 'ItemTowerRecommender', 'BPR', 'SASRec', 'default_config',
            'seed_everything']
@@ -376,6 +376,14 @@ class BaseRetriever(torch.nn.Module):
                                      pos_ids=batch[self.fiid], sampler=self.sampler,
                                      sparse_grad=self.config['train'].get('sparse_grad', False))
             return loss
+        # full softmax without the [B, N] score matrix: stock SoftmaxLoss over an nn.Embedding catalog
+        if (type(self.loss_fn) is SoftmaxLoss and self.sampler is None and type(self.score_func) is InnerProductScorer
+                and isinstance(self.item_encoder, torch.nn.Embedding) and len(self.item_fields) == 1
+                and self.item_encoder.weight.shape[1] <= 128 and batch[self.fiid].dim() == 1
+                and self.config['train'].get('fused_full_softmax', True)):
+            output = self.forward(batch, False, return_query=True)
+            lse = full_lse(output['query'], self.item_encoder.weight)
+            return (lse - output['score']['pos_score']).mean()       # loss_func.py:39-47, first branch
         output = self.forward(batch, isinstance(self.loss_fn, FullScoreLoss))
         score = output['score']
         score['label'] = batch[self.frating]

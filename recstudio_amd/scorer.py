@@ -91,3 +91,32 @@ def full_scores(query, items, cosine=False):
     if cosine:
         raise NotImplementedError('Cosine / Euclidean scorers over the full catalog are not implemented in this build')
     return _FullScoreFn.apply(query, items.contiguous())
+
+
+class _FullLseFn(torch.autograd.Function):
+    """logsumexp_i <query_b, weight_i> over item rows 1..N-1 WITHOUT writing [B, N]: the forward is the MFMA
+    kernel's in-register online logsumexp; the backward recomputes the scaled softmax with the same kernel
+    (one [B, N-1] write) and finishes with two library GEMMs."""
+
+    @staticmethod
+    def forward(ctx, query, weight):
+        lse = ops.fullscore(weight, query, want_lse=True)[1]
+        ctx.save_for_backward(query, weight, lse)
+        return lse
+
+    @staticmethod
+    def backward(ctx, g):
+        query, weight, lse = ctx.saved_tensors
+        probs = ops.fullscore_softmax(weight, query, lse, g.contiguous())
+        gq = probs @ weight[1:] if ctx.needs_input_grad[0] else None
+        gw = None
+        if ctx.needs_input_grad[1]:
+            gw = torch.empty_like(weight)
+            gw[0].zero_()
+            torch.matmul(probs.t(), query, out=gw[1:])
+        return gq, gw
+
+
+def full_lse(query, item_weight):
+    """logsumexp over the whole catalog of <query, item> (padding row 0 excluded), differentiable."""
+    return _FullLseFn.apply(query.contiguous(), item_weight)

@@ -107,6 +107,23 @@ class HipBackend:
                            query_table_grad=qgrad_all, query_table_pad_row=-1, item_pad_row=item_pad_row)
 
 
+    def full_partial(self, item_local, q_all, k, want_lse, has_pad_row):
+        """This shard's part of the full-catalog pass (BASELINE.json configs[4] sharded):
+        logsumexp over the local rows and the local top-k as (values, 1-based LOCAL row numbers, i.e.
+        row r of ``item_local`` -> r + 1 without a padding row, r with one)."""
+        _, lse, tv, ti = ops.fullscore(item_local, q_all, want_lse=want_lse, k=k, items_without_pad=not has_pad_row)
+        return lse, tv, ti
+
+    def merge_lse(self, parts):
+        """parts [B, G] per-shard logsumexp -> [B]."""
+        return ops.row_lse(parts.contiguous())[0]
+
+    def merge_topk(self, vals, ids, k):
+        """vals/ids [B, G*k] (shard-major, each shard's list sorted) -> exact global top-k, ties -> smaller id."""
+        v, cols = ops.row_topk(vals.contiguous(), k)
+        return v, torch.gather(ids, 1, cols)
+
+
 class ShardedItemTable:
     def __init__(self, item_local, plan, rank, dist, backend=None, group=None):
         self.item_local, self.plan, self.rank, self.dist = item_local, plan, int(rank), dist
@@ -187,3 +204,42 @@ class ShardedItemTable:
         if keep_route:
             out['route'] = res[2]
         return out
+
+    # -- full-catalog pass (eval top-k / full softmax), sharded the same way --------------------------
+    def _exchange_partials(self, x, B):
+        """x [G*B, ...] (this shard's partial for EVERY query) -> [G, B, ...] (every shard's partial for the
+        own queries): an equal-split all-to-all."""
+        out = torch.empty_like(x)
+        self.dist.all_to_all_single(out, x.contiguous(), group=self.group)
+        return out.view(self.plan.world, B, *x.shape[1:])
+
+    def full_lse_topk(self, q, k=0, want_lse=True):
+        """q [B, d] own queries -> (lse [B] or None, top-k values [B, k], GLOBAL item ids [B, k]) over the
+        whole sharded catalog (padding row 0 excluded), equal to the single-GPU rsa_fullscore result.
+        Per shard: one MFMA pass over the local rows for all G*B gathered queries; across shards only
+        (8k + 4) bytes per query per shard travel."""
+        B, G = q.shape[0], self.plan.world
+        lo, hi = self.plan.bounds(self.rank)
+        has_pad = self.rank == 0
+        real_rows = (hi - lo) - (1 if has_pad else 0)
+        q_all = self._all_gather_rows(q)
+        k_local = min(int(k), real_rows)
+        if real_rows <= 0 or (not want_lse and k_local == 0):
+            lse_p = torch.full((G * B,), float('-inf'), dtype=torch.float32, device=q.device) if want_lse else None
+            tv = ti = None
+        else:
+            lse_p, tv, ti = self.backend.full_partial(self.item_local, q_all, k_local, want_lse, has_pad)
+        lse = None
+        if want_lse:
+            lse = self.backend.merge_lse(self._exchange_partials(lse_p, B).transpose(0, 1))
+        if not k:
+            return lse, None, None
+        vals = torch.full((G * B, k), float('-inf'), dtype=torch.float32, device=q.device)
+        ids = torch.zeros(G * B, k, dtype=torch.int64, device=q.device)
+        if k_local:
+            vals[:, :k_local] = tv
+            ids[:, :k_local] = ti + (lo if has_pad else lo - 1)          # local 1-based row number -> global id
+        vals = self._exchange_partials(vals, B).transpose(0, 1).reshape(B, G * k)
+        ids = self._exchange_partials(ids, B).transpose(0, 1).reshape(B, G * k)
+        tv, ti = self.backend.merge_topk(vals, ids, k)
+        return lse, tv, ti

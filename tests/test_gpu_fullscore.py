@@ -116,6 +116,60 @@ def test_softmax_loss_full_catalog_golden(ra, golden):
     close(uw.grad.cpu(), g[tag + '_user_grad'], rtol=1e-4, atol=1e-7)
 
 
+def test_full_softmax_without_score_matrix_golden(ra, golden):
+    """full_lse (forward never writes [B, N]) + BaseRetriever.training_step dispatch == the reference's
+    SoftmaxLoss value and dense gradients."""
+    g = golden('forward')
+    tag = 'softmax_ip'
+    iw = T(g[tag + '_item_w']).to(DEV).requires_grad_(True)
+    uw = T(g[tag + '_user_w']).to(DEV).requires_grad_(True)
+    uid, pos = T(g[tag + '_uid']).to(DEV), T(g[tag + '_pos']).to(DEV)
+    q = torch.nn.functional.embedding(uid, uw)
+    loss = (ra.scorer.full_lse(q, iw) - (q * iw[pos]).sum(-1)).mean()
+    close(loss.detach().cpu(), g[tag + '_loss'], rtol=1e-5)
+    loss.backward()
+    close(iw.grad.cpu(), g[tag + '_item_grad'], rtol=1e-4, atol=1e-7)
+    close(uw.grad.cpu(), g[tag + '_user_grad'], rtol=1e-4, atol=1e-7)
+    # through the retriever
+    N, d = iw.shape
+    item = torch.nn.Embedding(N, d, padding_idx=0)
+    user = torch.nn.Embedding(uw.shape[0], d, padding_idx=0)
+    with torch.no_grad():
+        item.weight.copy_(T(g[tag + '_item_w']))
+        user.weight.copy_(T(g[tag + '_user_w']))
+    m = ra.BaseRetriever(None, item_encoder=item, query_encoder=user, scorer=ra.InnerProductScorer(),
+                         loss=ra.SoftmaxLoss())
+    m.fiid, m.fuid, m.frating = 'item_id', 'user_id', 'rating'
+    m.item_fields, m.query_fields = {'item_id'}, {'user_id'}
+    m.to(DEV)
+    batch = {'user_id': uid, 'item_id': pos, 'rating': torch.ones(len(uid), device=DEV)}
+    for fused in (True, False):
+        m.zero_grad()
+        m.config['train']['fused_full_softmax'] = fused
+        l2 = m.training_step(batch)
+        close(l2.detach().cpu(), g[tag + '_loss'], rtol=1e-5)
+        l2.backward()
+        close(m.item_encoder.weight.grad.cpu(), g[tag + '_item_grad'], rtol=1e-4, atol=1e-7)
+        close(m.query_encoder.weight.grad.cpu(), g[tag + '_user_grad'], rtol=1e-4, atol=1e-7)
+
+
+def test_full_softmax_grad_d128(ra):
+    """d = 128, N = 5001, B = 300 (ragged vs the 128-query / 32-item tiles): full_lse gradients against
+    torch autograd of logsumexp(q @ W[1:].T) on the same device."""
+    torch.manual_seed(3)
+    N, d, B = 5001, 128, 300
+    w = (torch.randn(N, d, device=DEV) * 0.3).requires_grad_(True)
+    q = (torch.randn(B, d, device=DEV) * 0.3).requires_grad_(True)
+    coef = torch.rand(B, device=DEV)
+    (ra.scorer.full_lse(q, w) * coef).sum().backward()
+    gw, gq = w.grad.clone(), q.grad.clone()
+    w.grad = q.grad = None
+    (torch.logsumexp(q.double() @ w[1:].double().t(), -1) * coef.double()).sum().backward()
+    assert not gw[0].any()
+    close(gq.cpu(), q.grad.cpu(), rtol=1e-4, atol=1e-7)
+    close(gw.cpu(), w.grad.cpu(), rtol=1e-4, atol=1e-7)
+
+
 def test_fullscore_config5_shape_properties(ra):
     """BASELINE.json configs[4]: N = 1e6, d = 128, B = 512, k = 100: properties + oracle spot checks."""
     N, d, B, k = 1_000_001, 128, 512, 100

@@ -78,3 +78,57 @@ def test_world1_rccl_step_equals_unsharded():
             np.testing.assert_allclose(ig.cpu(), ig2.cpu(), rtol=2e-4, atol=1e-8)
     finally:
         dist.destroy_process_group()
+
+
+def test_full_partials_of_two_shards_merge_to_the_unsharded_result():
+    """HipBackend.full_partial on the two row blocks of a 2-way plan (block 1 has no padding row: base
+    pointer trick) + merge kernels == rsa_fullscore over the whole table."""
+    import recstudio_amd as ra
+    from recstudio_amd.shard import HipBackend, RowShardPlan
+    torch.manual_seed(0)
+    N, d, B, k = 40_001, 128, 130, 50
+    item = torch.randn(N, d, device=DEV) * 0.2
+    item[0] = 0
+    q = torch.randn(B, d, device=DEV) * 0.2
+    plan = RowShardPlan(N, 2)
+    hb = HipBackend()
+    lses, vals, ids = [], [], []
+    for r in range(2):
+        lo, hi = plan.bounds(r)
+        lse, tv, ti = hb.full_partial(item[lo:hi].contiguous(), q, k, True, r == 0)
+        lses.append(lse)
+        vals.append(tv)
+        ids.append(ti + (lo if r == 0 else lo - 1))
+    lse = hb.merge_lse(torch.stack(lses, 1))
+    tv, ti = hb.merge_topk(torch.cat(vals, 1), torch.cat(ids, 1), k)
+    _, wl, wv, wi = ra.ops.fullscore(item, q, want_lse=True, k=k)
+    assert torch.equal(ti, wi)
+    np.testing.assert_allclose(tv.cpu(), wv.cpu(), rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(lse.cpu(), wl.cpu(), rtol=1e-6)
+    sc = q.double() @ item[1:].double().t()
+    np.testing.assert_allclose(lse.cpu(), torch.logsumexp(sc, -1).cpu(), rtol=1e-5)
+    # fp64 ordering can swap fp32 near-ties: compare the values, and the ids where they agree on rank
+    w64 = torch.topk(sc, k)
+    np.testing.assert_allclose(tv.cpu(), w64.values.float().cpu(), rtol=1e-5, atol=1e-6)
+    assert (ti == w64.indices + 1).float().mean() > 0.99
+
+
+def test_world1_rccl_full_catalog_pass():
+    import torch.distributed as dist
+    import recstudio_amd as ra
+    from recstudio_amd.shard import RowShardPlan, ShardedItemTable
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(_free_port())
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+    try:
+        torch.manual_seed(1)
+        N, d, B, k = 50_001, 64, 70, 20
+        item = torch.randn(N, d, device=DEV) * 0.2
+        q = torch.randn(B, d, device=DEV) * 0.2
+        table = ShardedItemTable(item, RowShardPlan(N, 1), 0, dist)
+        lse, tv, ti = table.full_lse_topk(q, k)
+        _, wl, wv, wi = ra.ops.fullscore(item, q, want_lse=True, k=k)
+        assert torch.equal(ti, wi) and torch.equal(tv, wv)
+        np.testing.assert_allclose(lse.cpu(), wl.cpu(), rtol=1e-6)
+    finally:
+        dist.destroy_process_group()

@@ -58,6 +58,23 @@ class CheckerBackend:
         qgrad_all.index_add_(0, qidx, dscore.unsqueeze(1) * item_local[rows])
 
 
+    def full_partial(self, item_local, q_all, k, want_lse, has_pad_row):
+        rows = item_local[1:] if has_pad_row else item_local
+        sc = q_all @ rows.t()
+        lse = torch.logsumexp(sc, -1) if want_lse else None
+        if not k:
+            return lse, None, None
+        order = torch.argsort(-sc, dim=1, stable=True)[:, :k]           # ties -> smaller row first
+        return lse, torch.gather(sc, 1, order), order + 1
+
+    def merge_lse(self, parts):
+        return torch.logsumexp(parts, -1)
+
+    def merge_topk(self, vals, ids, k):
+        order = torch.argsort(-vals, dim=1, stable=True)[:, :k]
+        return torch.gather(vals, 1, order), torch.gather(ids, 1, order)
+
+
 def _free_port():
     s = socket.socket()
     s.bind(('127.0.0.1', 0))
@@ -115,6 +132,43 @@ def _worker(rank, world, port, n_items, d, B, n, result_dir):
         open(os.path.join(result_dir, f'ok{rank}'), 'w').write('ok')
     finally:
         dist.destroy_process_group()
+
+
+def _full_worker(rank, world, port, n_items, d, B, k, result_dir):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from recstudio_amd.shard import RowShardPlan, ShardedItemTable
+        g = torch.Generator().manual_seed(11)
+        item = torch.randn(n_items, d, generator=g)
+        item[0] = 0
+        plan = RowShardPlan(n_items, world)
+        lo, hi = plan.bounds(rank)
+        table = ShardedItemTable(item[lo:hi].clone(), plan, rank, dist, backend=CheckerBackend())
+        q = torch.randn(B, d, generator=torch.Generator().manual_seed(200 + rank))
+        lse, tv, ti = table.full_lse_topk(q, k)
+        sc = q @ item[1:].t()
+        np.testing.assert_allclose(lse.numpy(), torch.logsumexp(sc, -1).numpy(), rtol=1e-6, atol=1e-6)
+        wv, wi = torch.topk(sc, k)
+        assert torch.equal(ti, wi + 1)
+        np.testing.assert_allclose(tv.numpy(), wv.numpy(), rtol=1e-6, atol=1e-6)
+        lse2, _, _ = table.full_lse_topk(q, 0)
+        np.testing.assert_allclose(lse2.numpy(), lse.numpy())
+        _, tv2, ti2 = table.full_lse_topk(q, k, want_lse=False)
+        assert torch.equal(ti2, ti)
+        open(os.path.join(result_dir, f'ok{rank}'), 'w').write('ok')
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('n_items,k', [(101, 10), (7, 3), (3, 1)])
+def test_sharded_full_catalog_pass_equals_single_process(tmp_path, n_items, k):
+    """k larger than one shard's row count ((7, 3): shard 0 holds 3 real rows, shard 1 holds 3) and a last
+    shard with a single row ((3, 1): rows_per_shard = 2 -> shard 1 = {2})."""
+    world = 2
+    mp.spawn(_full_worker, args=(world, _free_port(), n_items, 16, 5, k, str(tmp_path)), nprocs=world, join=True)
+    assert all(os.path.exists(tmp_path / f'ok{r}') for r in range(world))
 
 
 @pytest.mark.parametrize('n_items,n', [(101, 5), (64, 1)])
