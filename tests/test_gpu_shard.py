@@ -132,3 +132,40 @@ def test_world1_rccl_full_catalog_pass():
         np.testing.assert_allclose(lse.cpu(), wl.cpu(), rtol=1e-6)
     finally:
         dist.destroy_process_group()
+
+
+def test_world1_rccl_sharded_training_step():
+    """ShardedRetriever.training_step through the HIP kernels (world_size 1 over RCCL) == torch autograd of
+    the same BPR loss with the same sampled negatives."""
+    import torch.distributed as dist
+    import recstudio_amd as ra
+    from recstudio_amd.shard import RowShardPlan, ShardedItemTable, ShardedRetriever
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(_free_port())
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+    try:
+        torch.manual_seed(2)
+        N, U, d, B, n = 20_011, 300, 128, 200, 16
+        item = torch.randn(N, d, device=DEV) * 0.2
+        item[0] = 0
+        tower = torch.nn.Embedding(U, d).to(DEV)
+        uid = torch.randint(1, U, (B,), device=DEV)
+        pos = torch.randint(1, N, (B,), device=DEV)
+        table = ShardedItemTable(item, RowShardPlan(N, 1), 0, dist)
+        trainer = ShardedRetriever(table, tower, ra.UniformSampler(N), ra.BPRLoss(), n)
+        loss = trainer.training_step(uid, pos)
+        neg = trainer.last_neg
+        item_ref = item.clone().requires_grad_(True)
+        w_ref = tower.weight.detach().clone().requires_grad_(True)
+        q = w_ref[uid]
+        ps = (q * item_ref[pos]).sum(-1)
+        ns = (q.unsqueeze(1) * item_ref[neg]).sum(-1)
+        ref = -torch.nn.functional.logsigmoid(ps.view(-1, 1) - ns).mean(-1).mean()
+        ref.backward()
+        np.testing.assert_allclose(loss.item(), ref.item(), rtol=1e-5)
+        want = item_ref.grad.clone()
+        want[0] = 0
+        np.testing.assert_allclose(trainer.item_grad_local.cpu(), want.cpu(), rtol=2e-4, atol=1e-7)
+        np.testing.assert_allclose(tower.weight.grad.cpu(), w_ref.grad.cpu(), rtol=2e-4, atol=1e-7)
+    finally:
+        dist.destroy_process_group()

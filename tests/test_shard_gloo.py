@@ -162,6 +162,69 @@ def _full_worker(rank, world, port, n_items, d, B, k, result_dir):
         dist.destroy_process_group()
 
 
+def _train_worker(rank, world, port, n_items, d, B, n, result_dir):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from recstudio_amd.shard import RowShardPlan, ShardedItemTable, ShardedRetriever
+        g = torch.Generator().manual_seed(21)
+        item = torch.randn(n_items, d, generator=g) * 0.3
+        item[0] = 0
+        tower_w = torch.randn(d, 8, generator=g) * 0.3
+        plan = RowShardPlan(n_items, world)
+        lo, hi = plan.bounds(rank)
+        table = ShardedItemTable(item[lo:hi].clone(), plan, rank, dist, backend=CheckerBackend())
+        tower = torch.nn.Linear(8, d)
+        with torch.no_grad():
+            tower.weight.copy_(tower_w)
+            tower.bias.zero_()
+        feats, poss = [], []
+        for r in range(world):          # every rank can rebuild every rank's batch for the reference
+            gr = torch.Generator().manual_seed(300 + r)
+            feats.append(torch.randn(B, 8, generator=gr))
+            poss.append(torch.randint(1, n_items, (B,), generator=gr))
+        torch.manual_seed(40 + rank)
+
+        def bpr(label, pos_score, log_pos_prob, neg_score, log_neg_prob):      # loss_func.py:50-59
+            return -torch.mean(torch.nn.functional.logsigmoid(pos_score.view(-1, 1) - neg_score).mean(-1))
+        trainer = ShardedRetriever(table, tower, oracle.UniformSampler(n_items), bpr, n)
+        loss = trainer.training_step(feats[rank], poss[rank])
+        # single-process reference on the concatenated batch with the SAME negatives
+        negs = [torch.zeros(B, n, dtype=torch.int64) for _ in range(world)]
+        dist.all_gather(negs, trainer.last_neg)
+        item_ref = item.clone().requires_grad_(True)
+        tower_ref = torch.nn.Linear(8, d)
+        with torch.no_grad():
+            tower_ref.weight.copy_(tower_w)
+            tower_ref.bias.zero_()
+        q = tower_ref(torch.cat(feats))
+        pos, neg = torch.cat(poss), torch.cat(negs)
+        ps = (q * item_ref[pos]).sum(-1)
+        ns = (q.unsqueeze(1) * item_ref[neg]).sum(-1)
+        ref = bpr(None, ps, None, ns, None)
+        ref.backward()
+        total = loss.clone()
+        dist.all_reduce(total)
+        np.testing.assert_allclose(total.item(), ref.item(), rtol=1e-6)
+        np.testing.assert_allclose(tower.weight.grad.numpy(), tower_ref.weight.grad.numpy(), rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(tower.bias.grad.numpy(), tower_ref.bias.grad.numpy(), rtol=1e-4, atol=1e-6)
+        want = item_ref.grad.clone()
+        want[0] = 0
+        np.testing.assert_allclose(trainer.item_grad_local.numpy(), want[lo:hi].numpy(), rtol=1e-4, atol=1e-6)
+        open(os.path.join(result_dir, f'ok{rank}'), 'w').write('ok')
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_training_step_equals_single_process_autograd(tmp_path):
+    """ShardedRetriever.training_step on 2 ranks (item rows sharded, query tower replicated + bucketed
+    all-reduce) == autograd of the global-mean BPR loss in one process."""
+    world = 2
+    mp.spawn(_train_worker, args=(world, _free_port(), 61, 16, 7, 4, str(tmp_path)), nprocs=world, join=True)
+    assert all(os.path.exists(tmp_path / f'ok{r}') for r in range(world))
+
+
 @pytest.mark.parametrize('n_items,k', [(101, 10), (7, 3), (3, 1)])
 def test_sharded_full_catalog_pass_equals_single_process(tmp_path, n_items, k):
     """k larger than one shard's row count ((7, 3): shard 0 holds 3 real rows, shard 1 holds 3) and a last
