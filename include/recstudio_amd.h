@@ -78,7 +78,7 @@ int rsa_sample_masked_uniform(const int64_t* user_hist, int64_t n_rows, int32_t 
  * table/pop_prob: fp32 [n_items] exactly as the reference's registered buffers
  * (:239-241).  guide: int32 [2^guide_log2 + 1], guide[j] = first index with
  * table[i] >= j / 2^guide_log2, guide[2^guide_log2] = n_items (cut-point
- * acceleration; returns the same index searchsorted does).  An id that would be
+ * acceleration, guide_log2 <= 28; returns the same index searchsorted does).  An id that would be
  * n_items (u above table[-1]) is clamped to n_items-1.  neg_logp / u_out may be
  * null. */
 int rsa_sample_popular(const float* table, const float* pop_prob, const int32_t* guide,
@@ -149,10 +149,12 @@ typedef struct rsa_fused_args {
   float* loss_out;             /* nullable [1] out: mean over queries (deterministic; rsa_mean_rows) */
   float* dpos;                 /* nullable [M] out: d loss_out / d pos_score */
   float* dneg;                 /* nullable [M, n] out: d loss_out / d neg_score */
-  const float* cdf_lut;        /* nullable [2^guide_log2 + 1][4] fp32: {guide[b] (int32 bits), table[g], pop_prob[g], 0},
-                                  g = min(guide[b], n_items-1).  Direct-lookup form of the inverse CDF: one 32-byte
+  const float* cdf_lut;        /* nullable [2^guide_log2 + 1][4] fp32, one self-contained entry per guide bucket b with
+                                  lo = guide[b], hi = guide[b+1]: {lo as int32 bits, bit 31 set when hi - lo >= 2;
+                                  table[lo] (+inf when hi == lo); pop_prob[min(lo, n_items-1)];
+                                  pop_prob[min(lo+1, n_items-1)]}.  Direct-lookup form of the inverse CDF: one 16-byte
                                   read resolves id and probability for every bucket holding <= 1 CDF boundary
-                                  (one memory round trip instead of three); identical results. */
+                                  (one HBM line instead of three dependent round trips); identical results. */
 } rsa_fused_args;
 
 int rsa_fused_sample_gather_score(const rsa_fused_args* args, rsa_stream_t stream);

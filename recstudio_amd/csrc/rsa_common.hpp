@@ -115,11 +115,15 @@ __device__ __forceinline__ int32_t cdf_lower_bound(const float* __restrict__ tab
   return lo > (int32_t)(n_items - 1) ? (int32_t)(n_items - 1) : lo;
 }
 
-// Direct-lookup form of the same search.  lut[b] = {guide[b] (int bits), table[g], pop_prob[g], 0} with
-// g = min(guide[b], n_items-1): one 32-byte read (entries b and b+1) resolves every bucket that holds at
-// most one CDF boundary -- the common case with a fine guide -- INCLUDING the probability needed for the
-// log-prob, i.e. one memory round trip instead of three dependent ones (guide -> table -> pop_prob).
-// Buckets with more boundaries fall back to the binary search.  Same comparisons, same index.
+// Direct-lookup form of the same search.  One self-contained 16-byte entry per guide bucket b, with
+// lo = guide[b], hi = guide[b+1] (so the answer lies in [lo, hi]):
+//   x = lo, sign bit set when hi - lo >= 2 (bucket holds two or more CDF boundaries: binary search needed)
+//   y = table[lo], or +inf when hi == lo          z = pop_prob[min(lo, N-1)]       w = pop_prob[min(lo+1, N-1)]
+// Direct buckets (hi - lo <= 1, the common case with a fine guide) resolve id AND probability from this
+// single read -- one HBM line per sampled id instead of three dependent round trips (guide -> table ->
+// pop_prob): id = lo + (y < u).  Same comparisons as the binary search, same index.
+constexpr uint32_t LUT_SEARCH_BIT = 0x80000000u;
+
 template <int STRIDE>
 __device__ __forceinline__ int32_t cdf_lookup_lut(const float4* __restrict__ lut, const float* __restrict__ cdf,
                                                   const float* __restrict__ prob, int prob_stride, int64_t n_items,
@@ -127,15 +131,17 @@ __device__ __forceinline__ int32_t cdf_lookup_lut(const float4* __restrict__ lut
   const int32_t K = 1 << guide_log2;
   int32_t b = (int32_t)(u * (float)K);
   b = b < 0 ? 0 : (b > K - 1 ? K - 1 : b);
-  const float4 e0 = lut[b], e1 = lut[b + 1];
-  int32_t lo = __float_as_int(e0.x), hi = __float_as_int(e1.x);
+  const float4 e0 = lut[b];
+  const uint32_t x = __float_as_uint(e0.x);
+  int32_t lo = (int32_t)(x & ~LUT_SEARCH_BIT);
   const int32_t last = (int32_t)(n_items - 1);
-  if (hi - lo <= 1) {
-    const bool take_lo = (hi == lo) || !(e0.y < u);
-    pr = take_lo ? e0.z : e1.z;
-    const int32_t id = take_lo ? lo : hi;
+  if (!(x & LUT_SEARCH_BIT)) {
+    const bool up = e0.y < u;
+    pr = up ? e0.w : e0.z;
+    const int32_t id = lo + (up ? 1 : 0);
     return id > last ? last : id;
   }
+  int32_t hi = (int32_t)(__float_as_uint(lut[b + 1].x) & ~LUT_SEARCH_BIT);
   while (lo < hi) {
     const int32_t mid = lo + ((hi - lo) >> 1);
     if (cdf[(size_t)mid * STRIDE] < u) lo = mid + 1; else hi = mid;

@@ -385,7 +385,7 @@ extern "C" int rsa_fused_sample_gather_score(const rsa_fused_args* a, rsa_stream
     if (a->sampler != RSA_SAMPLER_GIVEN)
       RSA_CHECK_ARG(a->grid_threads > 0 && (a->offset & 3) == 0, "rsa_fused_sample_gather_score: bad philox state");
     if (a->sampler == RSA_SAMPLER_POPULAR)
-      RSA_CHECK_ARG(a->table && a->pop_prob && a->guide && a->guide_log2 >= 0 && a->guide_log2 <= 24,
+      RSA_CHECK_ARG(a->table && a->pop_prob && a->guide && a->guide_log2 >= 0 && a->guide_log2 <= 28,
                     "rsa_fused_sample_gather_score: popularity tables missing");
   }
   RSA_CHECK_ARG(a->pos_logp == nullptr || a->pop_prob != nullptr,

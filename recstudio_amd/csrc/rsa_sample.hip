@@ -61,28 +61,39 @@ __global__ __launch_bounds__(256) void sample_popular_lut_kernel(const float* __
   float u[E], pr[E];
   int32_t lo[E], hi[E];
   bool have_pr[E];
-  float4 e0[E], e1[E];
+  float4 e0[E];
+  int32_t bk[E];
 #pragma unroll
   for (int k = 0; k < E; ++k) {
     const int64_t e = base + k * 256;
     const int64_t ee = e < numel ? e : numel - 1;          // tail lanes repeat the last element (never stored)
     u[k] = FROM_U ? u_in[ee] : torch_rand_element(pc, (uint64_t)ee);
     int32_t b = (int32_t)(u[k] * (float)K);
-    b = b < 0 ? 0 : (b > K - 1 ? K - 1 : b);
-    e0[k] = lut[b];
-    e1[k] = lut[b + 1];
+    bk[k] = b < 0 ? 0 : (b > K - 1 ? K - 1 : b);
+    e0[k] = lut[bk[k]];
   }
+  bool any_search = false;
 #pragma unroll
   for (int k = 0; k < E; ++k) {
-    lo[k] = __float_as_int(e0[k].x);
-    hi[k] = __float_as_int(e1[k].x);
-    have_pr[k] = false;
-    if (hi[k] - lo[k] <= 1) {                               // same decision as cdf_lookup_lut
-      const bool take_lo = (hi[k] == lo[k]) || !(e0[k].y < u[k]);
-      pr[k] = take_lo ? e0[k].z : e1[k].z;
-      lo[k] = hi[k] = take_lo ? lo[k] : hi[k];
-      have_pr[k] = true;
+    const uint32_t x = __float_as_uint(e0[k].x);
+    lo[k] = (int32_t)(x & ~LUT_SEARCH_BIT);
+    have_pr[k] = !(x & LUT_SEARCH_BIT);
+    if (have_pr[k]) {                                       // same decision as cdf_lookup_lut
+      const bool up = e0[k].y < u[k];
+      pr[k] = up ? e0[k].w : e0[k].z;
+      lo[k] += up ? 1 : 0;
+      hi[k] = lo[k];
+    } else {
+      any_search = true;
     }
+  }
+  if (any_search) {
+    float hx[E];
+#pragma unroll
+    for (int k = 0; k < E; ++k) hx[k] = lut[bk[k] + 1].x;   // adjacent entry: almost always the same line
+#pragma unroll
+    for (int k = 0; k < E; ++k)
+      if (!have_pr[k]) hi[k] = (int32_t)(__float_as_uint(hx[k]) & ~LUT_SEARCH_BIT);
   }
   for (;;) {                                                // lock-step lower_bound over the open ranges
     bool any = false;
@@ -95,7 +106,8 @@ __global__ __launch_bounds__(256) void sample_popular_lut_kernel(const float* __
     }
     if (!any) break;
 #pragma unroll
-    for (int k = 0; k < E; ++k) c[k] = table[mid[k] > last ? last : mid[k]];   // unconditional: loads stay batched
+    for (int k = 0; k < E; ++k)     // unconditional so the loads stay batched; closed chains re-read the cached table[0]
+      c[k] = table[lo[k] < hi[k] ? (mid[k] > last ? last : mid[k]) : 0];
 #pragma unroll
     for (int k = 0; k < E; ++k)
       if (lo[k] < hi[k]) {
@@ -221,7 +233,7 @@ static int check_popular(const char* fn, const float* table, const float* pop_pr
                          int64_t n_items, int32_t guide_log2) {
   RSA_CHECK_ARG(table && pop_prob && guide, "%s: table/pop_prob/guide is null", fn);
   RSA_CHECK_ARG(n_items >= 1 && n_items < (1ll << 31), "%s: n_items out of range", fn);
-  RSA_CHECK_ARG(guide_log2 >= 0 && guide_log2 <= 24, "%s: guide_log2 must be in [0, 24]", fn);
+  RSA_CHECK_ARG(guide_log2 >= 0 && guide_log2 <= 28, "%s: guide_log2 must be in [0, 28]", fn);
   return RSA_OK;
 }
 

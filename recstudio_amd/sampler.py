@@ -87,13 +87,16 @@ def build_guide_table(table: Tensor, guide_log2: Optional[int] = None):
     """Cut-point ("guide") table for the fp32 CDF ``table``: guide[j] = first index i with
     table[i] >= j / K, K = 2**guide_log2, guide[K] = N.  Searching only inside
     [guide[b], guide[b+1]] for b = floor(u*K) returns exactly torch.searchsorted(table, u)
-    (sampler.py:247) because j/K and u*K are exact in fp32 for K <= 2**24."""
+    (sampler.py:247): u*K is exact in fp32 (power-of-two scale) and the cut points j/K are compared with the
+    fp32 CDF in float64, where both are exact."""
     n = table.numel()
     if guide_log2 is None:
-        guide_log2 = int(min(23, max(4, int(np.ceil(np.log2(max(n, 2)))) - 1)))   # ~1 item per bucket; LUT <= 134 MB
+        # ~1 item per bucket; LUT = 16 B per bucket: 134 MB at N = 1e7, 537 MB (the cap) at N = 1e8 -- measured best
+        # of 2^23..2^26 there; 2^24 at N = 1e7 is slower than 2^23 (fewer searches but a wider random footprint)
+        guide_log2 = int(min(25, max(4, int(np.ceil(np.log2(max(n, 2)))) - 1)))
     K = 1 << guide_log2
     cuts = torch.arange(K + 1, dtype=torch.float64) / K
-    guide = torch.searchsorted(table.detach().cpu().contiguous(), cuts.to(torch.float32))
+    guide = torch.searchsorted(table.detach().cpu().to(torch.float64).contiguous(), cuts)
     guide[K] = n
     return guide.to(torch.int32), guide_log2
 
@@ -124,11 +127,17 @@ class PopularSamplerModel(Sampler):
     def _register_pairs(self):
         # interleaved {table[i], pop_prob[i]} copy for the fused kernel (not part of the reference's state)
         self.register_buffer('table_prob', torch.stack([self.table, self.pop_prob], 1).contiguous(), persistent=False)
-        # direct-lookup table {guide[b] as int bits, table[g], pop_prob[g], 0}, g = min(guide[b], N-1):
-        # 16 B per guide bucket (268 MB at 2^24 buckets) buys one memory round trip per id instead of three
-        g = self.guide.to(torch.int64).clamp(max=self.table.numel() - 1)
-        lut = torch.stack([self.guide.view(torch.float32), self.table[g], self.pop_prob[g],
-                           torch.zeros_like(self.table[g])], 1).contiguous()
+        # direct-lookup table, one self-contained 16-B entry per guide bucket (layout: rsa_common.hpp,
+        # cdf_lookup_lut): {lo | search bit, table[lo] or +inf, pop_prob[lo], pop_prob[lo+1]} -- one HBM line
+        # per sampled id instead of three dependent round trips (134 MB at 2^23 buckets)
+        last = self.table.numel() - 1
+        lo = self.guide.to(torch.int64)
+        hi = torch.cat([lo[1:], lo[-1:]])
+        span = hi - lo
+        g0, g1 = lo.clamp(max=last), (lo + 1).clamp(max=last)
+        x = (lo - (span >= 2).to(torch.int64) * (1 << 31)).to(torch.int32)
+        y = torch.where(span == 0, torch.full_like(self.table[g0], float('inf')), self.table[g0])
+        lut = torch.stack([x.view(torch.float32), y, self.pop_prob[g0], self.pop_prob[g1]], 1).contiguous()
         self.register_buffer('cdf_lut', lut, persistent=False)
 
     @classmethod
