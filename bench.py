@@ -288,6 +288,47 @@ def main():
                 'alg_GBs': round(bytes_per_triplet(d, n3, True) * b3 * n3 / t3 / 1e6, 1)}
         except Exception as e:
             extra['seq_softmax'] = {'error': repr(e)[:200]}
+        # full softmax training step on configs[4] (forward never writes [B, N]; backward = one softmax write + 2 GEMMs)
+        try:
+            from recstudio_amd.scorer import full_lse
+            w5 = item[:n5].detach().clone().requires_grad_(True)
+            qq5 = q5.detach().clone().requires_grad_(True)
+
+            def softmax_step():
+                w5.grad = qq5.grad = None
+                full_lse(qq5, w5).mean().backward()
+            t_sm = time_gpu(softmax_step, 5, 2) * 1e3
+            extra['fullscore']['softmax_train_step_ms'] = round(t_sm, 3)
+            extra['fullscore']['softmax_train_step_tflops'] = round(4 * flops / t_sm / 1e9, 1)   # lse GEMM + softmax recompute + 2 gradient GEMMs
+            del w5, qq5
+        except Exception as e:
+            extra['fullscore']['softmax_train_step_error'] = repr(e)[:200]
+        # north_star target: the fused gather+sample+score(+BPR) on a 100 M-item table (51.2 GB) at d = 128
+        if not args.no_sweep and args.dim == 128:
+            try:
+                del item
+                torch.cuda.empty_cache()
+                n8 = 100_000_001
+                item8 = torch.empty(n8, d, device=dev).normal_(0, 0.02, generator=torch.Generator(device=dev).manual_seed(8))
+                item8[0] = 0
+                pos8 = torch.randint(1, n8, (B,), device=dev, generator=gen)
+                res8 = {}
+                for name, n_neg, b_q in (('n=64,B=65536', 64, B), ('n=1024,B=4096', 1024, 4096)):
+                    u8, p8 = uid[:b_q].contiguous(), pos8[:b_q].contiguous()
+                    b8 = {}
+
+                    def st8(n_neg=n_neg, u8=u8, p8=p8, b8=b8):
+                        b8['o'] = ra.ops.fused_forward(item8, user, n_neg, out=b8.get('o'), fused_bpr=True, want_mean=False,
+                                                       query_index=u8, pos_ids=p8, sampler=nat.SAMPLER_UNIFORM)
+                    t8 = time_gpu(st8, 50, 5) * 1e3
+                    alg8 = bytes_per_triplet(d, n_neg, False, fused_loss=True) * b_q * n_neg
+                    res8[name] = {'ms': round(t8, 4), 'M_triplets_s': round(b_q * n_neg / t8 / 1e3, 1),
+                                  'alg_GBs': round(alg8 / t8 / 1e6, 1), 'frac_of_hbm_peak': round(alg8 / t8 / 1e6 / HBM_PEAK_GBS, 4)}
+                extra['table_100M'] = {'workload': f'uniform sampler + gather + score + fused BPR, N={n8} items (51.2 GB table), d={d} '
+                                       '(north_star target; BASELINE.json configs[3] per-GPU shape for n=1024)', **res8}
+                del item8
+            except Exception as e:
+                extra['table_100M'] = {'error': repr(e)[:200]}
         value = B * n / ms_step / 1e3
         parallelism = 'single'
         workload = (f'BPR two-tower d={d}, synthetic {args.items} items / {args.users} users / 1e8-interaction Zipf '

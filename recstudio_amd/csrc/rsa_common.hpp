@@ -141,6 +141,33 @@ __device__ __forceinline__ int32_t cdf_lookup_lut(const float4* __restrict__ lut
     const int32_t id = lo + (up ? 1 : 0);
     return id > last ? last : id;
   }
+  // Bucket with >= 2 boundaries.  The answer is lo + #{i : cdf[lo+i] < u} (the CDF is non-decreasing, so the
+  // predicate holds on a prefix): probe the next PROBE entries with loads issued together -- one more round
+  // trip instead of a chain of dependent binary-search probes -- and only buckets with more than PROBE
+  // boundaries below u (rare with ~1 item per bucket) continue with the binary search in [lo+PROBE, hi].
+  constexpr int PROBE = 4;
+  float c[PROBE], q[PROBE];
+#pragma unroll
+  for (int i = 0; i < PROBE; ++i) {
+    const int32_t j = lo + i > last ? last : lo + i;
+    c[i] = cdf[(size_t)j * STRIDE];
+    q[i] = STRIDE == 2 ? cdf[(size_t)j * STRIDE + 1] : 0.f;     // interleaved {cdf, prob}: the same 8-byte load
+  }
+  int cnt = 0;
+#pragma unroll
+  for (int i = 0; i < PROBE; ++i) cnt += (lo + i <= last && c[i] < u) ? 1 : 0;   // prefix count
+  if (cnt < PROBE) {
+    lo += cnt;
+    lo = lo > last ? last : lo;
+    if (STRIDE == 2 && prob == cdf + 1) {
+      pr = cnt == 0 ? q[0] : cnt == 1 ? q[1] : cnt == 2 ? q[2] : q[3];
+      if (lo == last) pr = prob[(size_t)last * prob_stride];    // clamped index: re-read (edge only)
+    } else {
+      pr = prob[(size_t)lo * prob_stride];
+    }
+    return lo;
+  }
+  lo += PROBE;
   int32_t hi = (int32_t)(__float_as_uint(lut[b + 1].x) & ~LUT_SEARCH_BIT);
   while (lo < hi) {
     const int32_t mid = lo + ((hi - lo) >> 1);

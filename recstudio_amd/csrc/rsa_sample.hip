@@ -72,7 +72,8 @@ __global__ __launch_bounds__(256) void sample_popular_lut_kernel(const float* __
     bk[k] = b < 0 ? 0 : (b > K - 1 ? K - 1 : b);
     e0[k] = lut[bk[k]];
   }
-  bool any_search = false;
+  constexpr int PROBE = 4;
+  float c[E][PROBE];
 #pragma unroll
   for (int k = 0; k < E; ++k) {
     const uint32_t x = __float_as_uint(e0[k].x);
@@ -82,37 +83,32 @@ __global__ __launch_bounds__(256) void sample_popular_lut_kernel(const float* __
       const bool up = e0[k].y < u[k];
       pr[k] = up ? e0[k].w : e0[k].z;
       lo[k] += up ? 1 : 0;
+    }
+    // buckets with >= 2 boundaries: probe the next PROBE CDF entries at once (see cdf_lookup_lut); resolved
+    // chains re-read the cached table[0] so that the loads stay unconditional and batched
+#pragma unroll
+    for (int i = 0; i < PROBE; ++i) {
+      const int32_t j = lo[k] + i > last ? last : lo[k] + i;
+      c[k][i] = table[have_pr[k] ? 0 : j];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < E; ++k) {
+    hi[k] = lo[k];
+    if (!have_pr[k]) {
+      int cnt = 0;
+#pragma unroll
+      for (int i = 0; i < PROBE; ++i) cnt += (lo[k] + i <= last && c[k][i] < u[k]) ? 1 : 0;
+      lo[k] += cnt;
       hi[k] = lo[k];
-    } else {
-      any_search = true;
-    }
-  }
-  if (any_search) {
-    float hx[E];
-#pragma unroll
-    for (int k = 0; k < E; ++k) hx[k] = lut[bk[k] + 1].x;   // adjacent entry: almost always the same line
-#pragma unroll
-    for (int k = 0; k < E; ++k)
-      if (!have_pr[k]) hi[k] = (int32_t)(__float_as_uint(hx[k]) & ~LUT_SEARCH_BIT);
-  }
-  for (;;) {                                                // lock-step lower_bound over the open ranges
-    bool any = false;
-    int32_t mid[E];
-    float c[E];
-#pragma unroll
-    for (int k = 0; k < E; ++k) {
-      mid[k] = lo[k] + ((hi[k] - lo[k]) >> 1);
-      any |= lo[k] < hi[k];
-    }
-    if (!any) break;
-#pragma unroll
-    for (int k = 0; k < E; ++k)     // unconditional so the loads stay batched; closed chains re-read the cached table[0]
-      c[k] = table[lo[k] < hi[k] ? (mid[k] > last ? last : mid[k]) : 0];
-#pragma unroll
-    for (int k = 0; k < E; ++k)
-      if (lo[k] < hi[k]) {
-        if (c[k] < u[k]) lo[k] = mid[k] + 1; else hi[k] = mid[k];
+      if (cnt == PROBE) {                                   // rare: more than PROBE boundaries below u
+        hi[k] = (int32_t)(__float_as_uint(lut[bk[k] + 1].x) & ~LUT_SEARCH_BIT);
+        while (lo[k] < hi[k]) {
+          const int32_t mid = lo[k] + ((hi[k] - lo[k]) >> 1);
+          if (table[mid] < u[k]) lo[k] = mid + 1; else hi[k] = mid;
+        }
       }
+    }
   }
 #pragma unroll
   for (int k = 0; k < E; ++k) lo[k] = lo[k] > last ? last : lo[k];
