@@ -124,14 +124,19 @@ __device__ __forceinline__ int32_t cdf_lower_bound(const float* __restrict__ tab
 // pop_prob): id = lo + (y < u).  Same comparisons as the binary search, same index.
 constexpr uint32_t LUT_SEARCH_BIT = 0x80000000u;
 
-template <int STRIDE>
-__device__ __forceinline__ int32_t cdf_lookup_lut(const float4* __restrict__ lut, const float* __restrict__ cdf,
-                                                  const float* __restrict__ prob, int prob_stride, int64_t n_items,
-                                                  int guide_log2, float u, float& pr) {
+__device__ __forceinline__ int32_t lut_bucket(int guide_log2, float u) {
   const int32_t K = 1 << guide_log2;
-  int32_t b = (int32_t)(u * (float)K);
-  b = b < 0 ? 0 : (b > K - 1 ? K - 1 : b);
-  const float4 e0 = lut[b];
+  const int32_t b = (int32_t)(u * (float)K);     // exact: power-of-two scale
+  return b < 0 ? 0 : (b > K - 1 ? K - 1 : b);
+}
+
+// resolve a draw u given its (already loaded) bucket entry e0 = lut[lut_bucket(u)]
+template <int STRIDE>
+__device__ __forceinline__ int32_t cdf_resolve_lut(const float4 e0, const float4* __restrict__ lut,
+                                                   const float* __restrict__ cdf, const float* __restrict__ prob,
+                                                   int prob_stride, int64_t n_items, int guide_log2, float u,
+                                                   float& pr) {
+  const int32_t b = lut_bucket(guide_log2, u);
   const uint32_t x = __float_as_uint(e0.x);
   int32_t lo = (int32_t)(x & ~LUT_SEARCH_BIT);
   const int32_t last = (int32_t)(n_items - 1);
@@ -176,6 +181,14 @@ __device__ __forceinline__ int32_t cdf_lookup_lut(const float4* __restrict__ lut
   lo = lo > last ? last : lo;
   pr = prob[(size_t)lo * prob_stride];
   return lo;
+}
+
+template <int STRIDE>
+__device__ __forceinline__ int32_t cdf_lookup_lut(const float4* __restrict__ lut, const float* __restrict__ cdf,
+                                                  const float* __restrict__ prob, int prob_stride, int64_t n_items,
+                                                  int guide_log2, float u, float& pr) {
+  return cdf_resolve_lut<STRIDE>(lut[lut_bucket(guide_log2, u)], lut, cdf, prob, prob_stride, n_items, guide_log2, u,
+                                 pr);
 }
 
 // ---------------------------------------------------------------- wave helpers

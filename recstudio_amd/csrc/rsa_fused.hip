@@ -182,6 +182,9 @@ __device__ __forceinline__ float finish_score(int mode, float dot, float inorm2,
   return dot;
 }
 
+#ifndef RSA_FWD_LUT_AHEAD
+#define RSA_FWD_LUT_AHEAD 1
+#endif
 #ifndef RSA_FWD_MIN_WAVES
 #define RSA_FWD_MIN_WAVES 1
 #endif
@@ -196,9 +199,25 @@ __global__ __launch_bounds__(256, RSA_FWD_MIN_WAVES) void fused_fwd_kernel(const
   const int64_t wave0 = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const int64_t wstride = (int64_t)gridDim.x * (blockDim.x >> 6);
 
+  // Popularity sampler with the direct-lookup table: the draw and the LUT entry of the wave's NEXT tile are
+  // fetched one tile ahead (5 VGPRs), so that a tile's row loads no longer wait behind the LUT round trip.
+  const bool ahead = RSA_FWD_LUT_AHEAD && QU && p.sampler == RSA_SAMPLER_POPULAR && p.lut != nullptr;
+  float u_next = 0.f;
+  float4 lut_next = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto fetch_ahead = [&](int64_t t) {
+    const int64_t e2 = (t << 6) + lane;
+    if (e2 < p.numel) {
+      u_next = torch_rand_element(p.pc, (uint64_t)e2);
+      lut_next = reinterpret_cast<const float4*>(p.lut)[lut_bucket(p.guide_log2, u_next)];
+    }
+  };
+  if (ahead && wave0 < n_tiles) fetch_ahead(wave0);
+
   for (int64_t tile = wave0; tile < n_tiles; tile += wstride) {
     const int64_t e = (tile << 6) + lane;
     const int act = e < p.numel;
+    const float u_cur = u_next;
+    const float4 lut_cur = lut_next;
 
     // ---- 0. (query-uniform path) the two scalar loads everything else hangs off -- query row index and
     // positive id -- are issued first so that their latency hides under the sampling chain below
@@ -220,8 +239,18 @@ __global__ __launch_bounds__(256, RSA_FWD_MIN_WAVES) void fused_fwd_kernel(const
         id = (int32_t)torch_randint_element(p.pc, (uint64_t)e, (uint64_t)(p.n_items - 1), 1);
         p.neg_ids[e] = id;
       } else if (p.sampler == RSA_SAMPLER_POPULAR) {
-        const float u = torch_rand_element(p.pc, (uint64_t)e);
-        if (p.lut) {          // direct lookup: one round trip for id AND probability in the common case
+        const float u = ahead ? u_cur : torch_rand_element(p.pc, (uint64_t)e);
+        if (ahead) {
+          float pr;
+          if (p.table_prob)
+            id = cdf_resolve_lut<2>(lut_cur, reinterpret_cast<const float4*>(p.lut), p.table_prob, p.table_prob + 1, 2,
+                                    p.n_items, p.guide_log2, u, pr);
+          else
+            id = cdf_resolve_lut<1>(lut_cur, reinterpret_cast<const float4*>(p.lut), p.table, p.pop_prob, 1,
+                                    p.n_items, p.guide_log2, u, pr);
+          p.neg_ids[e] = id;
+          if (p.neg_logp) p.neg_logp[e] = logf(pr);
+        } else if (p.lut) {   // direct lookup: one round trip for id AND probability in the common case
           float pr;
           if (p.table_prob)
             id = cdf_lookup_lut<2>(reinterpret_cast<const float4*>(p.lut), p.table_prob, p.table_prob + 1, 2,
@@ -246,6 +275,8 @@ __global__ __launch_bounds__(256, RSA_FWD_MIN_WAVES) void fused_fwd_kernel(const
         id = (int32_t)g;
       }
     }
+
+    if (ahead && tile + wstride < n_tiles) fetch_ahead(tile + wstride);
 
     // ---- 2. query fragment (and, query-uniform path, the positive row): loads issued back to back here,
     // consumed after the negative rows are in flight
