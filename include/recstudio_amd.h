@@ -155,6 +155,10 @@ typedef struct rsa_fused_args {
                                   pop_prob[min(lo+1, n_items-1)]}.  Direct-lookup form of the inverse CDF: one 16-byte
                                   read resolves id and probability for every bucket holding <= 1 CDF boundary
                                   (one HBM line instead of three dependent round trips); identical results. */
+  float* query_grad;           /* nullable [M, dim] out, fused_loss = 1 only (inner product, dim in {32,64,128,256}):
+                                  d loss_out / d query row m = sum_j dneg[m,j] * item[neg_ids[m,j]] + dpos[m] * item[pos],
+                                  accumulated while the rows are in registers, so that rsa_fused_backward can be
+                                  called without query_grad / query_table_grad and then never reads an item row. */
 } rsa_fused_args;
 
 int rsa_fused_sample_gather_score(const rsa_fused_args* args, rsa_stream_t stream);

@@ -132,6 +132,9 @@ __global__ __launch_bounds__(256) void bwd_qu_kernel(const BwdParams p) {
     qacc[c] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
 
+  // the query gradient may already have been produced by the forward (rsa_fused_args.query_grad): then the
+  // negative rows are not read at all and this kernel only writes dneg * q rows (or their atomics)
+  const bool need_q = p.query_grad != nullptr || p.query_table_grad != nullptr;
   const int tiles = (int)(n >> 6);
   for (int tq = wave; tq < tiles; tq += nwave) {
     const int64_t j = ((int64_t)tq << 6) + lane;
@@ -152,8 +155,8 @@ __global__ __launch_bounds__(256) void bwd_qu_kernel(const BwdParams p) {
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
           const int col = (c * LPR + sub) * 4;
-          x[u][c] = (!GENERIC || col < D) ? *reinterpret_cast<const float4*>(irow + col)
-                                          : make_float4(0.f, 0.f, 0.f, 0.f);
+          x[u][c] = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (need_q && (!GENERIC || col < D)) x[u][c] = *reinterpret_cast<const float4*>(irow + col);
         }
       }
 #pragma unroll
@@ -202,7 +205,7 @@ __global__ __launch_bounds__(256) void bwd_qu_kernel(const BwdParams p) {
     red[(wave * CH + c) * 64 + lane] = qacc[c];
   }
   __syncthreads();
-  if (wave == 0) {
+  if (wave == 0 && (need_q || p.pos_ids != nullptr)) {
     float dp = 0.f;
     int64_t pid = 0;
     if (p.pos_ids) {

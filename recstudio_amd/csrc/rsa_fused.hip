@@ -40,6 +40,7 @@ struct FwdParams {
   float* row_loss;   // fused BPR epilogue (nullable): per-query loss, d loss/d pos, d loss/d neg
   float* dpos;
   float* dneg;
+  float* qgrad;      // fused BPR epilogue (nullable): [M, dim] d loss / d query row, accumulated from the rows in flight
   int64_t n_items, n_query_rows, n_queries, numel;
   PhiloxCall pc;
   int32_t dim, num_neg, sampler, mask_pad_pos, guide_log2, score_mode;
@@ -85,6 +86,15 @@ __device__ __forceinline__ float frag_dot(const Frag<LPR, GENERIC>& a, const Fra
 #pragma unroll
   for (int c = 1; c < Frag<LPR, GENERIC>::CH; ++c) s += dot4(a.v[c], b.v[c]);
   return s;
+}
+
+// d / d neg of  -w * inv_m * logsigmoid(pos - neg)  =  w * inv_m * sigmoid(neg - pos), written so that the
+// in-loop (query gradient) and epilogue (dneg output) evaluations are the same float operations
+__device__ __forceinline__ float bpr_dneg(float pos, float neg, float w, float inv_m) {
+  const float xd = pos - neg;
+  const float t = __expf(-fabsf(xd));
+  const float r = __frcp_rn(1.f + t);
+  return (xd >= 0.f ? t * r : r) * w * inv_m;
 }
 
 // In-place partial transpose-reduce over the lane-mask bits {step, 2*step, ..., step*L/2}:
@@ -174,6 +184,47 @@ __device__ __forceinline__ void tile_rows(const float* __restrict__ table, int D
   }
 }
 
+// Training variant of tile_rows (query-uniform, inner product, BPR): while a batch's row fragments are still
+// in registers every lane of the group gets the batch's complete dot products (plain butterfly sums -- no
+// transpose tree, whose long-lived select masks cost > 100 extra VGPRs here), turns them into d loss/d neg and
+// accumulates the query-gradient fragment qacc += dneg_row * row.  The backward pass then never re-reads the
+// negative rows.  On return lane r holds the dot of row r, as in tile_rows.
+template <int LPR, bool NT>
+__device__ __forceinline__ void tile_rows_qg(const float* __restrict__ table, int32_t id_lane,
+                                             const Frag<LPR, false>& qf, float pos_s, float bw, float binv, float& dot,
+                                             float4& qacc) {
+  using F = Frag<LPR, false>;
+  constexpr int D = LPR * 4;
+  constexpr int BATCH = LPR < 8 ? LPR : 8;
+  constexpr int NB = LPR / BATCH;
+  const int lane = lane_id();
+  const int sub = lane % LPR;
+  const int gbase = lane - sub;
+  dot = 0.f;
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    F x[BATCH];
+#pragma unroll
+    for (int k = 0; k < BATCH; ++k) {
+      const int32_t rid = __shfl(id_lane, gbase + b * BATCH + k, 64);     // rows b*BATCH .. of the lane group
+      frag_load<LPR, false, NT>(x[k], table + (size_t)rid * D, sub, D);
+    }
+#pragma unroll
+    for (int k = 0; k < BATCH; ++k) {
+      const float dk = group_sum<LPR>(frag_dot<LPR, false>(x[k], qf));    // all LPR lanes hold the row's dot
+      const float g = bpr_dneg(pos_s, dk, bw, binv);
+      const float4 xv = x[k].v[0];
+      qacc.x = __fmaf_rn(g, xv.x, qacc.x);
+      qacc.y = __fmaf_rn(g, xv.y, qacc.y);
+      qacc.z = __fmaf_rn(g, xv.z, qacc.z);
+      qacc.w = __fmaf_rn(g, xv.w, qacc.w);
+      dot = sub == b * BATCH + k ? dk : dot;
+    }
+    // keep the batches sequential: otherwise the scheduler hoists all LPR row loads to the top (222 VGPRs)
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 __device__ __forceinline__ float finish_score(int mode, float dot, float inorm2, float qnorm2) {
   // CosineScorer: dot / ||item|| / ||query||, two divisions, no epsilon (scorer.py:21-24)
   // EuclideanScorer: -(-2 dot + ||item||^2 + ||query||^2)                (scorer.py:28-34)
@@ -182,14 +233,17 @@ __device__ __forceinline__ float finish_score(int mode, float dot, float inorm2,
   return dot;
 }
 
+#ifndef RSA_QG_MIN_WAVES
+#define RSA_QG_MIN_WAVES 1
+#endif
 #ifndef RSA_FWD_LUT_AHEAD
 #define RSA_FWD_LUT_AHEAD 1
 #endif
 #ifndef RSA_FWD_MIN_WAVES
 #define RSA_FWD_MIN_WAVES 1
 #endif
-template <int LPR, bool GENERIC, bool COS, bool QU, bool NT>
-__global__ __launch_bounds__(256, RSA_FWD_MIN_WAVES) void fused_fwd_kernel(const FwdParams p) {
+template <int LPR, bool GENERIC, bool COS, bool QU, bool NT, bool QG = false>
+__global__ __launch_bounds__(256, QG ? RSA_QG_MIN_WAVES : RSA_FWD_MIN_WAVES) void fused_fwd_kernel(const FwdParams p) {
   using F = Frag<LPR, GENERIC>;
   const int lane = lane_id();
   const int sub = lane % LPR;
@@ -298,7 +352,39 @@ __global__ __launch_bounds__(256, RSA_FWD_MIN_WAVES) void fused_fwd_kernel(const
 
     // ---- 3. negatives: gather + dot
     float dot = 0.f, in2 = 1.f, qn2 = 1.f;
-    tile_rows<LPR, GENERIC, COS, QU, NT>(p.item_table, D, id, p.query, qrow_lane, qf, dot, in2, qn2);
+    float pos_early = 0.f;
+    float4 qacc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if constexpr (QG) {
+      // the positive score first (its loads were issued before everything else): the negatives' d loss/d score
+      // is needed while their rows are in registers
+      pos_early = group_sum<LPR>(frag_dot<LPR, GENERIC>(px, qf));
+      if (p.mask_pad_pos && pad) pos_early = -INFINITY;
+      const float bw = 1.f / (float)n, binv = 1.f / (float)p.n_queries;
+      tile_rows_qg<LPR, NT>(p.item_table, id, qf, pos_early, bw, binv, dot, qacc);
+      // d loss/d query row = sum_j dneg_j * item_j + dpos * item_pos, dpos = -sum_j dneg_j (this tile's share).
+      // Written right here, unconditionally (the host only selects this variant with the BPR epilogue on):
+      // under the epilogue's run-time conditions the compiler sinks the whole accumulation below the row
+      // loads and keeps all LPR row fragments alive (> 220 VGPRs).
+      const float tg = group_sum<64>(bpr_dneg(pos_early, dot, bw, binv));
+#pragma unroll
+      for (int mk = LPR; mk < 64; mk <<= 1) {
+        qacc.x += __shfl_xor(qacc.x, mk, 64); qacc.y += __shfl_xor(qacc.y, mk, 64);
+        qacc.z += __shfl_xor(qacc.z, mk, 64); qacc.w += __shfl_xor(qacc.w, mk, 64);
+      }
+      const float4 pv = px.v[0];
+      qacc.x = __fmaf_rn(-tg, pv.x, qacc.x); qacc.y = __fmaf_rn(-tg, pv.y, qacc.y);
+      qacc.z = __fmaf_rn(-tg, pv.z, qacc.z); qacc.w = __fmaf_rn(-tg, pv.w, qacc.w);
+      if (lane < LPR) {
+        float* g = p.qgrad + (size_t)m_lane * D + sub * 4;
+        if (n == 64) {
+          *reinterpret_cast<float4*>(g) = qacc;
+        } else {
+          atomicAdd(g + 0, qacc.x); atomicAdd(g + 1, qacc.y); atomicAdd(g + 2, qacc.z); atomicAdd(g + 3, qacc.w);
+        }
+      }
+    } else {
+      tile_rows<LPR, GENERIC, COS, QU, NT>(p.item_table, D, id, p.query, qrow_lane, qf, dot, in2, qn2);
+    }
     if constexpr (COS && QU) qn2 = qn2_u;
     if (act) p.neg_score[e] = finish_score(COS ? p.score_mode : RSA_SCORE_IP, dot, in2, qn2);
 
@@ -327,9 +413,8 @@ __global__ __launch_bounds__(256, RSA_FWD_MIN_WAVES) void fused_fwd_kernel(const
             // (absolute error ~1e-7 on terms of O(1), far inside the 1e-4 contract)
             const float xd = s - neg_s;
             const float t = __expf(-fabsf(xd));
-            const float r = __frcp_rn(1.f + t);
             const float ls = fminf(xd, 0.f) - __logf(1.f + t);
-            const float sg = (xd >= 0.f ? t * r : r) * w * inv_m;
+            const float sg = bpr_dneg(s, neg_s, w, inv_m);
             if (p.dneg) p.dneg[e] = sg;
             const float tl = group_sum<64>(ls * w), tg = group_sum<64>(sg);
             if (lane == 0) {
@@ -368,6 +453,13 @@ template <int LPR, bool GENERIC, bool COS, bool QU>
 static void launch_fwd2(const FwdParams& p, dim3 grid, dim3 block, hipStream_t stream) {
   // streaming (nontemporal) row loads once the table cannot live in the 256 MB Infinity Cache
   const bool nt = !GENERIC && (size_t)p.n_items * p.dim * sizeof(float) > (512ull << 20);
+  if constexpr (QU && !COS && !GENERIC) {
+    if (p.qgrad != nullptr) {     // training forward: query gradient accumulated from the rows in flight
+      if (nt) hipLaunchKernelGGL((fused_fwd_kernel<LPR, GENERIC, COS, QU, true, true>), grid, block, 0, stream, p);
+      else hipLaunchKernelGGL((fused_fwd_kernel<LPR, GENERIC, COS, QU, false, true>), grid, block, 0, stream, p);
+      return;
+    }
+  }
   if (nt) hipLaunchKernelGGL((fused_fwd_kernel<LPR, GENERIC, COS, QU, !GENERIC>), grid, block, 0, stream, p);
   else hipLaunchKernelGGL((fused_fwd_kernel<LPR, GENERIC, COS, QU, false>), grid, block, 0, stream, p);
 }
@@ -442,6 +534,7 @@ extern "C" int rsa_fused_sample_gather_score(const rsa_fused_args* a, rsa_stream
   p.row_loss = nullptr;
   p.dpos = nullptr;
   p.dneg = nullptr;
+  p.qgrad = nullptr;
   p.n_items = a->n_items;
   p.n_query_rows = a->n_query_rows;
   p.n_queries = a->n_queries;
@@ -465,6 +558,8 @@ extern "C" int rsa_fused_sample_gather_score(const rsa_fused_args* a, rsa_stream
   }
   p.numel = numel;
   const bool qu = (a->num_neg % 64) == 0;
+  RSA_CHECK_ARG(a->query_grad == nullptr || a->fused_loss == RSA_LOSS_BPR + 1,
+                "rsa_fused_sample_gather_score: query_grad is an output of the fused BPR epilogue (fused_loss = 1)");
   if (a->fused_loss == RSA_LOSS_BPR + 1) {
     RSA_CHECK_ARG(qu && a->pos_ids && a->pos_score && a->row_loss,
                   "rsa_fused_sample_gather_score: the fused BPR epilogue needs num_neg %% 64 == 0, pos_ids, pos_score "
@@ -472,9 +567,17 @@ extern "C" int rsa_fused_sample_gather_score(const rsa_fused_args* a, rsa_stream
     p.row_loss = a->row_loss;
     p.dpos = a->dpos;
     p.dneg = a->dneg;
+    if (a->query_grad != nullptr) {
+      RSA_CHECK_ARG(!cos && (a->dim == 32 || a->dim == 64 || a->dim == 128 || a->dim == 256),
+                    "rsa_fused_sample_gather_score: query_grad needs the inner-product scorer and dim in "
+                    "{32, 64, 128, 256}");
+      p.qgrad = a->query_grad;
+    }
     if (a->num_neg != 64) {
       hipError_t e1 = hipMemsetAsync(a->row_loss, 0, sizeof(float) * a->n_queries, s);
       hipError_t e2 = a->dpos ? hipMemsetAsync(a->dpos, 0, sizeof(float) * a->n_queries, s) : hipSuccess;
+      if (e1 == hipSuccess && e2 == hipSuccess && p.qgrad)
+        e1 = hipMemsetAsync(p.qgrad, 0, sizeof(float) * a->n_queries * a->dim, s);
       if (e1 != hipSuccess || e2 != hipSuccess) {
         rsa::set_error("rsa_fused_sample_gather_score: memset failed");
         return RSA_ERR_HIP;

@@ -124,13 +124,17 @@ class _FusedBPRFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, item_weight, query_src, cfg):
+        # d loss/d query is accumulated by the forward itself while the negative rows are in registers
+        # (inner product, stock dims): the backward launch then only writes item-gradient rows
+        fwd_qgrad = ctx.needs_input_grad[1] and item_weight.shape[1] in (32, 64, 128, 256)
         out = ops.fused_forward(item_weight, query_src, cfg['num_neg'], query_index=cfg.get('query_index'),
                                 pos_ids=cfg['pos_ids'], sampler=cfg['sampler'], neg_ids=cfg.get('neg_ids'),
                                 table=cfg.get('table'), pop_prob=cfg.get('pop_prob'), guide=cfg.get('guide'),
                                 guide_log2=cfg.get('guide_log2', 0), table_prob=cfg.get('table_prob'), cdf_lut=cfg.get('cdf_lut'),
-                                n_queries=cfg['n_queries'], want_logp=False, fused_bpr=True)
+                                n_queries=cfg['n_queries'], want_logp=False, fused_bpr=True, want_query_grad=fwd_qgrad)
         cfg['out'] = out
         ctx.cfg = cfg
+        ctx.fwd_qgrad = fwd_qgrad
         ctx.save_for_backward(item_weight, query_src, out['neg_ids'], out['dpos'], out['dneg'])
         return out['loss']
 
@@ -140,11 +144,17 @@ class _FusedBPRFn(torch.autograd.Function):
         item_weight, query_src, neg_ids, dpos, dneg = ctx.saved_tensors
         qi, pos_ids, sparse = cfg.get('query_index'), cfg['pos_ids'], cfg.get('sparse_grad', False)
         need_item, need_q = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
-        qtab = torch.zeros_like(query_src) if (need_q and qi is not None and not sparse) else None
-        item_grad, rows, qgrad = ops.fused_backward(
-            item_weight, query_src, neg_ids, dneg, query_index=qi, pos_ids=pos_ids, dpos=dpos,
-            upstream=g.reshape(1).contiguous(), dense_item_grad=need_item and not sparse,
-            row_item_grad=need_item and sparse, want_query_grad=need_q and qtab is None, query_table_grad=qtab)
+        have_q = need_q and ctx.fwd_qgrad
+        qtab = torch.zeros_like(query_src) if (need_q and not have_q and qi is not None and not sparse) else None
+        item_grad = rows = qgrad = None
+        if need_item or (need_q and not have_q):
+            item_grad, rows, qgrad = ops.fused_backward(
+                item_weight, query_src, neg_ids, dneg, query_index=qi, pos_ids=pos_ids, dpos=dpos,
+                upstream=g.reshape(1).contiguous(), dense_item_grad=need_item and not sparse,
+                row_item_grad=need_item and sparse, want_query_grad=need_q and not have_q and qtab is None,
+                query_table_grad=qtab)
+        if have_q:
+            qgrad = cfg['out']['query_grad'] * g
         g_item = g_q = None
         if need_item:
             if sparse:
@@ -158,6 +168,8 @@ class _FusedBPRFn(torch.autograd.Function):
                 g_q = qgrad
             elif sparse:
                 g_q = torch.sparse_coo_tensor(qi.view(1, -1), qgrad, query_src.shape)
+            elif have_q:
+                g_q = ops.scatter_add_rows(qgrad, qi, query_src.shape[0])     # embedding_dense_backward, row 0 skipped
             else:
                 g_q = qtab
         return g_item, g_q, None

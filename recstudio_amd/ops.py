@@ -139,7 +139,8 @@ def seg_gather(item_table, flat_item_ids, seg_start, seg_end, max_len, want_rows
 def fused_forward(item_table, query, num_neg, *, query_index=None, pos_ids=None, neg_ids=None,
                   sampler=nat.SAMPLER_GIVEN, cosine=False, mask_pad_pos=False,
                   table=None, pop_prob=None, guide=None, guide_log2=0, generator=None, n_queries=None,
-                  out=None, want_logp=True, table_prob=None, fused_bpr=False, want_mean=True, cdf_lut=None):
+                  out=None, want_logp=True, table_prob=None, fused_bpr=False, want_mean=True, cdf_lut=None,
+                  want_query_grad=False):
     """One launch of rsa_fused_sample_gather_score.  Returns a dict with
     neg_ids [M,n] int64, neg_score [M,n], pos_score [M] (if pos_ids), and for the
     popularity sampler neg_logp [M,n], pos_logp [M].  ``out``: a dict returned by an earlier
@@ -147,7 +148,8 @@ def fused_forward(item_table, query, num_neg, *, query_index=None, pos_ids=None,
     ``want_logp=False`` skips the log-probability outputs of the popularity sampler (BPR ignores
     them, loss_func.py:55-59).  ``fused_bpr=True`` (needs num_neg % 64 == 0 and pos_ids) evaluates
     BPRLoss in the kernel's epilogue: adds ``loss`` (scalar), ``row_loss [M]``, ``dpos [M]``,
-    ``dneg [M, n]`` to the result."""
+    ``dneg [M, n]`` to the result; with ``want_query_grad`` (inner product, dim in {32, 64, 128, 256}) also
+    ``query_grad [M, d]`` = d loss / d query row, accumulated while the rows are in registers."""
     item_table = _need(item_table, torch.float32, 'item_table')
     query = _need(query, torch.float32, 'query')
     dev = item_table.device
@@ -204,6 +206,12 @@ def fused_forward(item_table, query, num_neg, *, query_index=None, pos_ids=None,
         a.fused_loss = nat.LOSS_BPR + 1
         a.row_loss, a.loss_out = ptr(out['row_loss']), ptr(out['loss'] if want_mean else None)
         a.dpos, a.dneg = ptr(out['dpos']), ptr(out['dneg'])
+        if want_query_grad:
+            if 'query_grad' not in out:
+                out['query_grad'] = torch.empty(M, dim, dtype=torch.float32, device=dev)
+            a.query_grad = ptr(out['query_grad'])
+    elif want_query_grad:
+        raise ValueError('want_query_grad needs fused_bpr=True')
     nat.check(nat.lib().rsa_fused_sample_gather_score(ctypes.byref(a), _stream()), 'rsa_fused_sample_gather_score')
     return out
 

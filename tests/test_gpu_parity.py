@@ -542,3 +542,60 @@ def test_masked_uniform_sampler(ra, golden):
     for b in range(B2):
         assert not set(neg[b].tolist()) & set(h2[b].tolist())
     assert int(neg.min()) >= 1 and int(neg.max()) <= N2 - 1
+
+
+@pytest.mark.parametrize('d,n,sampler', [(128, 64, 'uniform'), (64, 128, 'popular'), (32, 64, 'given'), (256, 64, 'uniform')])
+def test_forward_query_grad_matches_backward_kernel(ra, d, n, sampler):
+    """rsa_fused_args.query_grad (accumulated in the forward while the rows are in registers) == the query
+    gradient of rsa_fused_backward, and the backward without query outputs still writes the same item rows."""
+    torch.manual_seed(4)
+    N, U, M = 5003, 301, 97
+    item = torch.randn(N, d, device=DEV) * 0.3
+    item[0] = 0
+    user = torch.randn(U, d, device=DEV) * 0.3
+    uid = torch.randint(1, U, (M,), device=DEV)
+    pos = torch.randint(1, N, (M,), device=DEV)
+    kw = {}
+    if sampler == 'given':
+        kw = dict(neg_ids=torch.randint(0, N, (M, n), device=DEV))
+    elif sampler == 'uniform':
+        kw = dict(sampler=ra._native.SAMPLER_UNIFORM)
+    else:
+        ps = ra.PopularSamplerModel((torch.rand(N) ** 3 * 50).long()).to(DEV)
+        kw = dict(sampler=ra._native.SAMPLER_POPULAR, table=ps.table, pop_prob=ps.pop_prob, guide=ps.guide,
+                  guide_log2=ps.guide_log2, table_prob=ps.table_prob, cdf_lut=ps.cdf_lut)
+    torch.manual_seed(9)
+    a = ra.ops.fused_forward(item, user, n, query_index=uid, pos_ids=pos, fused_bpr=True, want_query_grad=True, **kw)
+    torch.manual_seed(9)
+    b = ra.ops.fused_forward(item, user, n, query_index=uid, pos_ids=pos, fused_bpr=True, **kw)
+    assert torch.equal(a['neg_ids'], b['neg_ids'])
+    rel_close(a['neg_score'].cpu(), b['neg_score'].cpu(), rtol=1e-5, atol=1e-6)
+    rel_close(a['dneg'].cpu(), b['dneg'].cpu(), rtol=1e-4, atol=1e-9)
+    rel_close(a['loss'].cpu(), b['loss'].cpu(), rtol=1e-6)
+    _, rows_ref, qg_ref = ra.ops.fused_backward(item, user, b['neg_ids'], b['dneg'], query_index=uid, pos_ids=pos,
+                                                dpos=b['dpos'], dense_item_grad=False, row_item_grad=True)
+    rel_close(a['query_grad'].cpu(), qg_ref.cpu(), rtol=2e-4, atol=1e-8)
+    ig, rows, qg = ra.ops.fused_backward(item, user, a['neg_ids'], a['dneg'], query_index=uid, pos_ids=pos,
+                                         dpos=a['dpos'], dense_item_grad=True, row_item_grad=True, want_query_grad=False)
+    assert qg is None
+    rel_close(rows.cpu(), rows_ref.cpu(), rtol=1e-4, atol=1e-9)
+    ig_ref = ra.ops.fused_backward(item, user, b['neg_ids'], b['dneg'], query_index=uid, pos_ids=pos, dpos=b['dpos'])[0]
+    rel_close(ig.cpu(), ig_ref.cpu(), rtol=2e-4, atol=1e-8)
+    # through autograd: the fused BPR loss's gradients against torch autograd of the same loss
+    iw = item.clone().requires_grad_(True)
+    uw = user.clone().requires_grad_(True)
+    torch.manual_seed(9)
+    loss, neg = ra.fused.fused_bpr_loss(iw, uw, n, query_index=uid, pos_ids=pos,
+                                        sampler=None if sampler == 'given' else (ra.UniformSampler(N) if sampler == 'uniform' else ps),
+                                        neg_ids=kw.get('neg_ids'))
+    loss.backward()
+    iw2 = item.clone().requires_grad_(True)
+    uw2 = user.clone().requires_grad_(True)
+    q = uw2[uid]
+    ref = -torch.nn.functional.logsigmoid((q * iw2[pos]).sum(-1, keepdim=True) - (q.unsqueeze(1) * iw2[neg]).sum(-1)).mean(-1).mean()
+    ref.backward()
+    rel_close(loss.detach().cpu(), ref.detach().cpu(), rtol=1e-5)
+    rel_close(uw.grad.cpu(), uw2.grad.cpu(), rtol=3e-4, atol=1e-8)
+    g2 = iw2.grad.clone()
+    g2[0] = 0
+    rel_close(iw.grad.cpu(), g2.cpu(), rtol=3e-4, atol=1e-8)
