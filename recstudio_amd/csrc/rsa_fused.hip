@@ -46,6 +46,20 @@ struct FwdParams {
   int32_t dim, num_neg, sampler, mask_pad_pos, guide_log2, score_mode;
 };
 
+#ifndef RSA_FWD_NT_STORE
+#define RSA_FWD_NT_STORE 1
+#endif
+// per-element outputs (ids, scores, log-probs, d loss/d score) are written once and consumed by a later kernel:
+// streaming stores keep them from displacing table lines in L2
+template <typename T>
+__device__ __forceinline__ void st_out(T* p, T v) {
+#if RSA_FWD_NT_STORE
+  __builtin_nontemporal_store(v, p);
+#else
+  *p = v;
+#endif
+}
+
 template <int LPR, bool GENERIC>
 struct Frag {
   static constexpr int CH = GENERIC ? 4 : 1;
@@ -291,7 +305,7 @@ __global__ __launch_bounds__(256, QG ? RSA_QG_MIN_WAVES : RSA_FWD_MIN_WAVES) voi
     if (act) {
       if (p.sampler == RSA_SAMPLER_UNIFORM) {
         id = (int32_t)torch_randint_element(p.pc, (uint64_t)e, (uint64_t)(p.n_items - 1), 1);
-        p.neg_ids[e] = id;
+        st_out(&p.neg_ids[e], (int64_t)id);
       } else if (p.sampler == RSA_SAMPLER_POPULAR) {
         const float u = ahead ? u_cur : torch_rand_element(p.pc, (uint64_t)e);
         if (ahead) {
@@ -302,8 +316,8 @@ __global__ __launch_bounds__(256, QG ? RSA_QG_MIN_WAVES : RSA_FWD_MIN_WAVES) voi
           else
             id = cdf_resolve_lut<1>(lut_cur, reinterpret_cast<const float4*>(p.lut), p.table, p.pop_prob, 1,
                                     p.n_items, p.guide_log2, u, pr);
-          p.neg_ids[e] = id;
-          if (p.neg_logp) p.neg_logp[e] = logf(pr);
+          st_out(&p.neg_ids[e], (int64_t)id);
+          if (p.neg_logp) st_out(&p.neg_logp[e], logf(pr));
         } else if (p.lut) {   // direct lookup: one round trip for id AND probability in the common case
           float pr;
           if (p.table_prob)
@@ -312,16 +326,16 @@ __global__ __launch_bounds__(256, QG ? RSA_QG_MIN_WAVES : RSA_FWD_MIN_WAVES) voi
           else
             id = cdf_lookup_lut<1>(reinterpret_cast<const float4*>(p.lut), p.table, p.pop_prob, 1, p.n_items,
                                    p.guide_log2, u, pr);
-          p.neg_ids[e] = id;
-          if (p.neg_logp) p.neg_logp[e] = logf(pr);
+          st_out(&p.neg_ids[e], (int64_t)id);
+          if (p.neg_logp) st_out(&p.neg_logp[e], logf(pr));
         } else if (p.table_prob) {   // interleaved {cdf, prob}: the search and the log-prob share cache lines
           id = cdf_lower_bound<2>(p.table_prob, p.guide, p.n_items, p.guide_log2, u);
-          p.neg_ids[e] = id;
-          if (p.neg_logp) p.neg_logp[e] = logf(p.table_prob[2 * (size_t)id + 1]);
+          st_out(&p.neg_ids[e], (int64_t)id);
+          if (p.neg_logp) st_out(&p.neg_logp[e], logf(p.table_prob[2 * (size_t)id + 1]));
         } else {
           id = cdf_lower_bound<1>(p.table, p.guide, p.n_items, p.guide_log2, u);
-          p.neg_ids[e] = id;
-          if (p.neg_logp) p.neg_logp[e] = logf(p.pop_prob[id]);
+          st_out(&p.neg_ids[e], (int64_t)id);
+          if (p.neg_logp) st_out(&p.neg_logp[e], logf(p.pop_prob[id]));
         }
       } else {
         int64_t g = p.neg_ids[e];
@@ -386,7 +400,7 @@ __global__ __launch_bounds__(256, QG ? RSA_QG_MIN_WAVES : RSA_FWD_MIN_WAVES) voi
       tile_rows<LPR, GENERIC, COS, QU, NT>(p.item_table, D, id, p.query, qrow_lane, qf, dot, in2, qn2);
     }
     if constexpr (COS && QU) qn2 = qn2_u;
-    if (act) p.neg_score[e] = finish_score(COS ? p.score_mode : RSA_SCORE_IP, dot, in2, qn2);
+    if (act) st_out(&p.neg_score[e], finish_score(COS ? p.score_mode : RSA_SCORE_IP, dot, in2, qn2));
 
     // ---- 4. positives (+ the fused BPR epilogue: every tile of a query needs the positive score)
     const float neg_s = finish_score(COS ? p.score_mode : RSA_SCORE_IP, dot, in2, qn2);
@@ -415,7 +429,7 @@ __global__ __launch_bounds__(256, QG ? RSA_QG_MIN_WAVES : RSA_FWD_MIN_WAVES) voi
             const float t = __expf(-fabsf(xd));
             const float ls = fminf(xd, 0.f) - __logf(1.f + t);
             const float sg = bpr_dneg(s, neg_s, w, inv_m);
-            if (p.dneg) p.dneg[e] = sg;
+            if (p.dneg) st_out(&p.dneg[e], sg);
             const float tl = group_sum<64>(ls * w), tg = group_sum<64>(sg);
             if (lane == 0) {
               if (n == 64) {   // one tile per query: plain stores, deterministic
