@@ -27,6 +27,10 @@
 // top-k (ties -> smaller id).  With `scores` given, the radix select runs on the materialised rows.
 #include "rsa_common.hpp"
 
+#ifndef RSA_FS_MIN_BLOCKS
+#define RSA_FS_MIN_BLOCKS 1
+#endif
+
 namespace rsa {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -53,7 +57,7 @@ struct FilterArgs {
 // tile_stride  > 1: SAMPLE mode -- "item" positions are sample positions; sample tile s reads catalog tile
 // s*tile_stride, and scores are written to a dense [n_query, score_ld] sample matrix.
 template <int D, bool LSE, bool SCORES, bool FILTER>
-__global__ __launch_bounds__(256) void fullscore_kernel(const float* __restrict__ item_table, int64_t n_items,
+__global__ __launch_bounds__(256, RSA_FS_MIN_BLOCKS) void fullscore_kernel(const float* __restrict__ item_table, int64_t n_items,
                                                         const float* __restrict__ query, int64_t n_query,
                                                         float* __restrict__ scores, int64_t score_ld,
                                                         float2* __restrict__ lse_part, int splits,

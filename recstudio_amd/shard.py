@@ -129,6 +129,10 @@ class ShardedItemTable:
         self.item_local, self.plan, self.rank, self.dist = item_local, plan, int(rank), dist
         self.backend = backend if backend is not None else HipBackend()
         self.group = group
+        # the query all-gather runs on its OWN communicator: collectives of one communicator execute in issue
+        # order on one stream, so on the main group the small count / key exchanges (and the host read-back of
+        # the counts) would queue behind the 33.5 MB-per-rank gather instead of overlapping with it
+        self.gather_group = dist.new_group() if (group is None and plan.world > 1) else group
         lo, hi = plan.bounds(rank)
         if item_local.shape[0] != hi - lo:
             raise ValueError(f'rank {rank} must hold rows [{lo}, {hi}) of the item table, got {item_local.shape[0]}')
@@ -144,7 +148,7 @@ class ShardedItemTable:
         nothing before the owner-side scoring needs it, so it flies under sampling, counting and routing."""
         out = torch.empty(self.plan.world * x.shape[0], *x.shape[1:], dtype=x.dtype, device=x.device)
         x = x.contiguous()
-        work = self.dist.all_gather_into_tensor(out, x, group=self.group, async_op=True)
+        work = self.dist.all_gather_into_tensor(out, x, group=self.gather_group, async_op=True)
 
         def wait():
             work.wait()
