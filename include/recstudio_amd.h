@@ -159,6 +159,9 @@ typedef struct rsa_fused_args {
                                   d loss_out / d query row m = sum_j dneg[m,j] * item[neg_ids[m,j]] + dpos[m] * item[pos],
                                   accumulated while the rows are in registers, so that rsa_fused_backward can be
                                   called without query_grad / query_table_grad and then never reads an item row. */
+  const int64_t* packed_keys;  /* nullable [M]: sampler GIVEN, num_neg == 1, no positives: element m scores query row
+                                  (key >> 32) against item row (key & 0xffffffff) -- the owner side of the sharded
+                                  exchange (rsa_shard_route keys) without unpacking; neg_ids / query_index unused. */
 } rsa_fused_args;
 
 int rsa_fused_sample_gather_score(const rsa_fused_args* args, rsa_stream_t stream);

@@ -201,23 +201,6 @@ __device__ __forceinline__ float group_sum(float v) {   // all lanes of each WID
   return v;
 }
 
-// Transpose-reduce: each lane of an L-lane group holds v[0..L-1]; afterwards lane s of the
-// group holds sum over the group's lanes of v[s].  L-1 shuffles for L sums.
-template <int L>
-__device__ __forceinline__ float transpose_reduce(float (&v)[L], int sub_lane) {
-#pragma unroll
-  for (int m = L / 2; m >= 1; m >>= 1) {
-    const bool upper = (sub_lane & m) != 0;
-#pragma unroll
-    for (int t = 0; t < m; ++t) {
-      const float send = upper ? v[t] : v[t + m];
-      const float keep = upper ? v[t + m] : v[t];
-      v[t] = keep + __shfl_xor(send, m, 64);
-    }
-  }
-  return v[0];
-}
-
 __device__ __forceinline__ float dot4(const float4& a, const float4& b) {
   return __fmaf_rn(a.w, b.w, __fmaf_rn(a.z, b.z, __fmaf_rn(a.y, b.y, a.x * b.x)));
 }

@@ -40,6 +40,7 @@ struct FwdParams {
   float* row_loss;   // fused BPR epilogue (nullable): per-query loss, d loss/d pos, d loss/d neg
   float* dpos;
   float* dneg;
+  const int64_t* packed_keys;   // num_neg == 1, GIVEN: element e = (query row << 32) | item row (sharded owner side)
   float* qgrad;      // fused BPR epilogue (nullable): [M, dim] d loss / d query row, accumulated from the rows in flight
   int64_t n_items, n_query_rows, n_queries, numel;
   PhiloxCall pc;
@@ -338,7 +339,7 @@ __global__ __launch_bounds__(256, QG ? RSA_QG_MIN_WAVES : RSA_FWD_MIN_WAVES) voi
           if (p.neg_logp) st_out(&p.neg_logp[e], logf(p.pop_prob[id]));
         }
       } else {
-        int64_t g = p.neg_ids[e];
+        int64_t g = p.packed_keys ? (p.packed_keys[e] & 0xffffffffll) : p.neg_ids[e];
         g = g < 0 ? 0 : (g >= p.n_items ? p.n_items - 1 : g);   // clamp: never fault on a bad id
         id = (int32_t)g;
       }
@@ -360,6 +361,7 @@ __global__ __launch_bounds__(256, QG ? RSA_QG_MIN_WAVES : RSA_FWD_MIN_WAVES) voi
     } else {
       m_lane = act ? e / n : 0;
       qrow_lane = (int32_t)(p.query_index ? (act ? p.query_index[m_lane] : 0) : m_lane);
+      if (p.packed_keys) qrow_lane = act ? (int32_t)(p.packed_keys[e] >> 32) : 0;
       frag_load<LPR, GENERIC>(qf, p.query, sub, D);   // unused in this path
       px = qf;
     }
@@ -515,10 +517,13 @@ extern "C" int rsa_fused_sample_gather_score(const rsa_fused_args* a, rsa_stream
                 "rsa_fused_sample_gather_score: unknown sampler %d", a->sampler);
   if (a->n_queries == 0) return RSA_OK;
   RSA_CHECK_ARG(a->item_table && a->query, "rsa_fused_sample_gather_score: item_table/query is null");
-  RSA_CHECK_ARG(a->query_index != nullptr || a->n_query_rows >= a->n_queries,
+  RSA_CHECK_ARG(a->query_index != nullptr || a->packed_keys != nullptr || a->n_query_rows >= a->n_queries,
                 "rsa_fused_sample_gather_score: query has fewer rows than n_queries");
   if (numel > 0) {
-    RSA_CHECK_ARG(a->neg_ids && a->neg_score, "rsa_fused_sample_gather_score: neg_ids/neg_score is null");
+    RSA_CHECK_ARG((a->neg_ids || a->packed_keys) && a->neg_score,
+                  "rsa_fused_sample_gather_score: neg_ids/neg_score is null");
+    RSA_CHECK_ARG(a->packed_keys == nullptr || (a->sampler == RSA_SAMPLER_GIVEN && a->num_neg == 1 && !a->pos_ids),
+                  "rsa_fused_sample_gather_score: packed_keys needs sampler GIVEN, num_neg == 1 and no positives");
     if (a->sampler != RSA_SAMPLER_GIVEN)
       RSA_CHECK_ARG(a->grid_threads > 0 && (a->offset & 3) == 0, "rsa_fused_sample_gather_score: bad philox state");
     if (a->sampler == RSA_SAMPLER_POPULAR)
@@ -549,6 +554,7 @@ extern "C" int rsa_fused_sample_gather_score(const rsa_fused_args* a, rsa_stream
   p.dpos = nullptr;
   p.dneg = nullptr;
   p.qgrad = nullptr;
+  p.packed_keys = a->packed_keys;
   p.n_items = a->n_items;
   p.n_query_rows = a->n_query_rows;
   p.n_queries = a->n_queries;

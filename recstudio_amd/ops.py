@@ -216,6 +216,25 @@ def fused_forward(item_table, query, num_neg, *, query_index=None, pos_ids=None,
     return out
 
 
+def score_packed_keys(item_table, query, keys):
+    """Scores of (query row, item row) pairs packed as (qrow << 32) | irow (rsa_shard_route's keys): the fused
+    gather+score kernel reading the pairs directly."""
+    item_table = _need(item_table, torch.float32, 'item_table')
+    query = _need(query, torch.float32, 'query')
+    keys = _need(keys, torch.int64, 'keys')
+    m = keys.numel()
+    out = torch.empty(m, dtype=torch.float32, device=keys.device)
+    if m == 0:
+        return out
+    a = nat.FusedArgs()
+    a.item_table, a.n_items, a.dim = ptr(item_table), item_table.shape[0], item_table.shape[1]
+    a.query, a.n_query_rows = ptr(query), query.shape[0]
+    a.n_queries, a.num_neg, a.sampler = m, 1, nat.SAMPLER_GIVEN
+    a.packed_keys, a.neg_score = ptr(keys), ptr(out)
+    nat.check(nat.lib().rsa_fused_sample_gather_score(ctypes.byref(a), _stream()), 'rsa_fused_sample_gather_score')
+    return out
+
+
 def pairwise_loss(kind, pos_score, neg_score, pos_logp=None, neg_logp=None, want_grad=True):
     """(loss [scalar tensor], dpos [M] | None, dneg [M,n] | None, row_loss [M])."""
     pos_score = _need(pos_score, torch.float32, 'pos_score')

@@ -72,15 +72,7 @@ class HipBackend:
         return keys, positions
 
     def score_keys(self, item_local, q_all, keys):
-        m = keys.numel()
-        rows = torch.empty(m, dtype=torch.int64, device=keys.device)
-        qidx = torch.empty(m, dtype=torch.int64, device=keys.device)
-        if m == 0:
-            return torch.empty(0, dtype=torch.float32, device=keys.device)
-        nat.check(nat.lib().rsa_shard_unpack(ptr(keys), m, ptr(rows), ptr(qidx), ops._stream()), 'rsa_shard_unpack')
-        out = ops.fused_forward(item_local, q_all, 1, query_index=qidx, neg_ids=rows.view(m, 1),
-                                sampler=nat.SAMPLER_GIVEN)
-        return out['neg_score'].view(m)
+        return ops.score_packed_keys(item_local, q_all, keys)
 
     def scatter(self, scores, positions, numel):
         dst = torch.empty(numel, dtype=torch.float32, device=scores.device)
