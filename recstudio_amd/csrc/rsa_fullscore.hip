@@ -42,6 +42,7 @@ constexpr int TI = 32;    // items per tile
 // segment of SEG slots and counts in a register: plain fire-and-forget stores, no atomics (a returning
 // global atomic inside the tile loop stalls the wave for a memory round trip and cost 25 % of the GEMM).
 constexpr int SEG = 32;
+constexpr int OVF = 1024;
 struct FilterArgs {
   const float* thr;     // [n_query] per-query threshold (null: no filtering)
   int32_t* seg_cnt;     // [n_query, splits, 2] candidates seen per segment (may exceed SEG: overflow marker)
@@ -51,6 +52,13 @@ struct FilterArgs {
   // sm_scale[q] * exp(score - sm_lse[q]) instead of the raw score
   const float* sm_lse;    // [n_query] or null
   const float* sm_scale;  // [n_query] or null (1)
+  // Overflow list of a query (OVF slots): a candidate that finds its private segment full is appended here
+  // with a returning atomic -- paid only on that rare path.  Scores that trend along the id axis (ids sorted
+  // by popularity, say) put most of a query's candidates into a few item ranges; without this list every such
+  // row fell back to the exact single-workgroup recompute (17 ms per row at N = 1e6).
+  int32_t* ovf_cnt;     // [n_query], zeroed by the host
+  float* ovf_val;       // [n_query, OVF]
+  int32_t* ovf_idx;     // [n_query, OVF]
 };
 
 // tile_stride == 1: the workgroup walks the contiguous item range [1 + bx*items_per_split, ...).
@@ -181,8 +189,14 @@ __global__ __launch_bounds__(256, RSA_FS_MIN_BLOCKS) void fullscore_kernel(const
             if (my_cnt < SEG) {
               flt.cand_val[seg * SEG + my_cnt] = acc[r];
               flt.cand_idx[seg * SEG + my_cnt] = (int32_t)(i0 + row);
+              ++my_cnt;
+            } else {
+              const int pos = atomicAdd(&flt.ovf_cnt[q], 1);
+              if (pos < OVF) {
+                flt.ovf_val[(size_t)q * OVF + pos] = acc[r];
+                flt.ovf_idx[(size_t)q * OVF + pos] = (int32_t)(i0 + row);
+              }
             }
-            ++my_cnt;
           }
         }
       }
@@ -277,6 +291,9 @@ struct SelectArgs {
   const int32_t* cand_idx;  // CAND: [n_rows, n_seg, SEG] item ids
   const int32_t* seg_cnt;   // CAND: [n_rows, n_seg] candidates seen per segment
   int32_t n_seg;            // CAND: segments per row (splits x 2)
+  const int32_t* ovf_cnt;   // CAND: [n_rows] entries appended to the row's overflow list (may exceed OVF)
+  const float* ovf_val;     // CAND: [n_rows, OVF]
+  const int32_t* ovf_idx;   // CAND: [n_rows, OVF]
   int32_t* flags;           // CAND: out, 1 = row must be recomputed;  RECOMPUTE: in
   int64_t ld;               // row stride of `values`
   int64_t n_cols;           // DENSE/THRESHOLD/RECOMPUTE: elements per row
@@ -325,10 +342,12 @@ __global__ __launch_bounds__(1024) void topk_row_kernel(SelectArgs a, int k, flo
       hist[b1] += v1;
       __syncthreads();
     }
+    const int32_t n_ovf = a.ovf_cnt[r];
     if (tid == 0) s_total = (int32_t)hist[2047];
     __syncthreads();
-    const int32_t total = s_total;
-    const bool bad = s_over != 0 || total < k || total > CAND_MAX;
+    const int32_t seg_total = s_total;
+    const int32_t total = seg_total + (n_ovf < OVF ? n_ovf : OVF);
+    const bool bad = s_over != 0 || n_ovf > OVF || total < k || total > CAND_MAX;
     if (tid == 0) a.flags[r] = bad ? 1 : 0;
     if (bad) return;                       // recomputed exactly by the SEL_RECOMPUTE pass
     for (int b = tid; b < a.n_seg; b += 1024) {
@@ -338,6 +357,10 @@ __global__ __launch_bounds__(1024) void topk_row_kernel(SelectArgs a, int k, flo
         cval[e] = a.values[src + (e - beg)];
         cidx[e] = a.cand_idx[src + (e - beg)];
       }
+    }
+    for (int32_t e = tid; e < total - seg_total; e += 1024) {
+      cval[seg_total + e] = a.ovf_val[(size_t)r * OVF + e];
+      cidx[seg_total + e] = a.ovf_idx[(size_t)r * OVF + e];
     }
     __syncthreads();
     n = total;
@@ -520,9 +543,10 @@ __global__ __launch_bounds__(256) void mask_history_kernel(const float* __restri
 
 using namespace rsa;
 
-static int64_t fullscore_splits(int64_t n_query, int64_t n_positions) {
+static int64_t fullscore_splits(int64_t n_query, int64_t n_positions, int64_t min_splits = 1) {
   const int64_t groups = (n_query + QB - 1) / QB;
   int64_t splits = (1024 + groups - 1) / groups;   // ~4 workgroups per CU in flight
+  if (splits < min_splits) splits = min_splits;
   const int64_t max_splits = (n_positions + TI - 1) / TI;
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
@@ -536,6 +560,7 @@ struct TopkPlan {
   bool filter;
   int64_t sample_tiles, tile_stride, sample_items;
   int32_t j;   // threshold rank inside the sample
+  int64_t min_splits;   // item-range splits needed to keep the per-segment candidate count far below SEG
 };
 
 static TopkPlan plan_topk(int64_t n_items, int32_t k, bool scores_given) {
@@ -554,6 +579,11 @@ static TopkPlan plan_topk(int64_t n_items, int32_t k, bool scores_given) {
   if (j > pl.sample_items) j = pl.sample_items;
   pl.j = (int32_t)j;
   if ((double)j / ratio > 0.6 * CAND_MAX) pl.filter = false;   // would crowd the candidate lists
+  // a (query, split, lane half) segment holds SEG = 32 candidates; with ~6 expected per segment an overflow
+  // (-> the slow exact recompute of that row) has probability ~1e-14 for exchangeable scores.  Large k at
+  // large B (few default splits) used to sit at ~16 per segment: a handful of overflowing rows per call, each
+  // costing a full single-workgroup pass over the catalog (460 ms instead of 5 ms at B = 2048, k = 500).
+  pl.min_splits = (int64_t)((double)j / ratio / (2.0 * 6.0)) + 1;
   return pl;
 }
 
@@ -561,15 +591,17 @@ static inline int64_t align256(int64_t b) { return (b + 255) / 256 * 256; }
 
 extern "C" int64_t rsa_fullscore_workspace_bytes(int64_t n_query, int64_t n_items, int32_t k) {
   if (n_query <= 0 || n_items <= 1) return 0;
-  int64_t bytes = align256(n_query * fullscore_splits(n_query, n_items - 1) * (int64_t)sizeof(float2));   // lse partials
+  const TopkPlan pl = plan_topk(n_items, k, k <= 0);
+  int64_t bytes = align256(n_query * fullscore_splits(n_query, n_items - 1, pl.filter ? pl.min_splits : 1) *
+                           (int64_t)sizeof(float2));   // lse partials
   if (k > 0) {
-    const TopkPlan pl = plan_topk(n_items, k, false);
     if (pl.filter) {
       bytes += align256(n_query * pl.sample_items * 4);        // sample scores
-      const int64_t n_seg = fullscore_splits(n_query, n_items - 1) * 2;
+      const int64_t n_seg = fullscore_splits(n_query, n_items - 1, pl.min_splits) * 2;
       bytes += 2 * align256(n_query * 4);                       // thresholds, flags
       bytes += align256(n_query * n_seg * 4);                   // per-segment counts
       bytes += 2 * align256(n_query * n_seg * (int64_t)SEG * 4);   // candidate values + ids
+      bytes += align256(n_query * 4) + 2 * align256(n_query * (int64_t)OVF * 4);   // overflow lists
     } else {
       bytes += align256(n_query * (n_items - 1) * (int64_t)sizeof(float));   // dense score rows
     }
@@ -623,15 +655,15 @@ extern "C" int rsa_fullscore(const float* item_table, int64_t n_items, int32_t d
   hipStream_t s = (hipStream_t)stream;
   const int64_t n_cols = n_items - 1;
   const unsigned groups = (unsigned)((n_query + QB - 1) / QB);
-  const int64_t splits = fullscore_splits(n_query, n_cols);
+  const TopkPlan pl = plan_topk(n_items, k, scores != nullptr);
+  const int64_t splits = fullscore_splits(n_query, n_cols, pl.filter ? pl.min_splits : 1);
   const int64_t per = ((n_cols + splits - 1) / splits + TI - 1) / TI * TI;
   const int64_t splits_used = (n_cols + per - 1) / per;
   char* ws = reinterpret_cast<char*>(workspace);
   float2* part = reinterpret_cast<float2*>(ws);
   ws += align256(n_query * splits * (int64_t)sizeof(float2));
   float2* lp = lse ? part : nullptr;
-  const TopkPlan pl = plan_topk(n_items, k, scores != nullptr);
-  const FilterArgs no_filter{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  const FilterArgs no_filter{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 
   if (pl.filter) {
     float* sample = reinterpret_cast<float*>(ws);      ws += align256(n_query * pl.sample_items * 4);
@@ -640,7 +672,10 @@ extern "C" int rsa_fullscore(const float* item_table, int64_t n_items, int32_t d
     int32_t* flags = reinterpret_cast<int32_t*>(ws);   ws += align256(n_query * 4);
     int32_t* seg_cnt = reinterpret_cast<int32_t*>(ws); ws += align256(n_query * splits * 2 * 4);
     float* cand_val = reinterpret_cast<float*>(ws);    ws += align256(n_query * splits * 2 * (int64_t)SEG * 4);
-    int32_t* cand_idx = reinterpret_cast<int32_t*>(ws);
+    int32_t* cand_idx = reinterpret_cast<int32_t*>(ws); ws += align256(n_query * splits * 2 * (int64_t)SEG * 4);
+    int32_t* ovf_cnt = reinterpret_cast<int32_t*>(ws);  ws += align256(n_query * 4);
+    float* ovf_val = reinterpret_cast<float*>(ws);      ws += align256(n_query * (int64_t)OVF * 4);
+    int32_t* ovf_idx = reinterpret_cast<int32_t*>(ws);
     // A. sample GEMM + per-query threshold
     const int64_t ssplits = fullscore_splits(n_query, pl.sample_items);
     const int64_t sper = ((pl.sample_items + ssplits - 1) / ssplits + TI - 1) / TI * TI;
@@ -654,13 +689,18 @@ extern "C" int rsa_fullscore(const float* item_table, int64_t n_items, int32_t d
                        (float*)nullptr, (int64_t*)nullptr);
     RSA_CHECK_LAUNCH("rsa_fullscore(threshold)");
     // B. full GEMM with the filter epilogue (+ fused logsumexp)
-    const FilterArgs flt{thr, seg_cnt, cand_val, cand_idx, nullptr, nullptr};
+    if (hipMemsetAsync(ovf_cnt, 0, (size_t)n_query * 4, s) != hipSuccess) {
+      rsa::set_error("rsa_fullscore: memset failed");
+      return RSA_ERR_HIP;
+    }
+    const FilterArgs flt{thr, seg_cnt, cand_val, cand_idx, nullptr, nullptr, ovf_cnt, ovf_val, ovf_idx};
     gemm_dispatch(dim, dim3((unsigned)splits_used, groups), s, item_table, n_items, query, n_query, nullptr, n_cols, lp,
                   (int)splits_used, per, 1, n_cols, flt);
     RSA_CHECK_LAUNCH("rsa_fullscore(gemm+filter)");
     // C. exact select over the candidates;  D. exact recompute of flagged rows
     SelectArgs ca{};
     ca.values = cand_val; ca.cand_idx = cand_idx; ca.seg_cnt = seg_cnt; ca.n_seg = (int32_t)n_seg; ca.flags = flags;
+    ca.ovf_cnt = ovf_cnt; ca.ovf_val = ovf_val; ca.ovf_idx = ovf_idx;
     hipLaunchKernelGGL(topk_row_kernel<SEL_CAND>, dim3((unsigned)n_query), dim3(1024), 0, s, ca, (int)k, topk_val,
                        topk_idx);
     SelectArgs ra{};
@@ -705,7 +745,7 @@ extern "C" int rsa_fullscore_softmax(const float* item_table, int64_t n_items, i
   const int64_t splits = fullscore_splits(n_query, n_cols);
   const int64_t per = ((n_cols + splits - 1) / splits + TI - 1) / TI * TI;
   const int64_t splits_used = (n_cols + per - 1) / per;
-  const FilterArgs ep{nullptr, nullptr, nullptr, nullptr, lse, row_scale};
+  const FilterArgs ep{nullptr, nullptr, nullptr, nullptr, lse, row_scale, nullptr, nullptr, nullptr};
   gemm_dispatch(dim, dim3((unsigned)splits_used, groups), (hipStream_t)stream, item_table, n_items, query, n_query, probs,
                 n_cols, nullptr, (int)splits_used, per, 1, n_cols, ep);
   RSA_CHECK_LAUNCH("rsa_fullscore_softmax");

@@ -223,3 +223,29 @@ def test_topk_filter_path_adversarial_catalogs(ra):
         if name in ('flat', 'zero_query'):                    # all ties: the k smallest ids, in order
             assert torch.equal(ti.cpu(), torch.arange(1, k + 1).expand(4, k)), name
         close(lse.cpu(), torch.logsumexp(ref, -1).float(), rtol=1e-5)
+
+
+def test_topk_large_k_large_batch_trending_scores(ra):
+    """B = 2048, k = 500 on a catalog whose scores trend along the id axis (ids sorted by popularity, say):
+    most of a query's candidates fall into a few item ranges.  The per-segment lists overflow into the
+    query's overflow list instead of sending every row to the exact single-workgroup recompute (which used
+    to turn this call from milliseconds into tens of seconds)."""
+    import time
+    torch.manual_seed(5)
+    N, d, B, k = 300_001, 128, 2048, 500
+    item = torch.randn(N, d, device=DEV) * 0.1
+    item[:, 0] += torch.linspace(3, -3, N, device=DEV)
+    q = torch.randn(B, d, device=DEV) * 0.3
+    q[:, 0] = q[:, 0].abs() + 0.5                      # every query prefers small ids
+    ra.ops.fullscore(item, q, k=k)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    _, lse, tv, ti = ra.ops.fullscore(item, q, want_lse=True, k=k)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    ref = q @ item[1:].T
+    wv, wi = torch.topk(ref, k)
+    close(tv.cpu(), wv.cpu(), rtol=1e-4, atol=1e-5)
+    assert (ti == wi + 1).float().mean() > 0.99       # fp32 near-ties may swap neighbours
+    close(lse.cpu(), torch.logsumexp(ref.double(), -1).float().cpu(), rtol=1e-5)
+    assert elapsed < 0.5, f'top-k fell off the fast path: {elapsed * 1e3:.0f} ms'
