@@ -31,7 +31,8 @@ from . import eval as rs_eval
 from . import ops
 from .dataset import SeqDataset, TripletDataset
 from .fused import fused_bpr_loss, retriever_scores
-from .loss_func import BPRLoss, FullScoreLoss, PairwiseLoss, PointwiseLoss, SampledSoftmaxLoss, SoftmaxLoss
+from .loss_func import (BinaryCrossEntropyLoss, BPRLoss, FullScoreLoss, PairwiseLoss, PointwiseLoss, SampledSoftmaxLoss,
+                        SoftmaxLoss)
 from .sampler import PopularSamplerModel, Sampler, UniformSampler
 from .scorer import CosineScorer, EuclideanScorer, InnerProductScorer, full_lse
 
@@ -582,11 +583,16 @@ class SASRec(BaseRetriever):
     """recstudio/model/seq/sasrec.py:70-123 with the retriever tail on the fused path."""
 
     def __init__(self, config=None, **kwargs):
+        # recstudio/model/seq/config/sasrec.yaml on top of basemodel.yaml; the caller's config wins
+        user = config or {}
         super().__init__(config, **kwargs)
         m = self.config['model']
         for k, v in (('hidden_size', 128), ('layer_num', 2), ('head_num', 2), ('dropout_rate', 0.5),
                      ('activation', 'gelu'), ('layer_norm_eps', 1e-12)):
             m.setdefault(k, v)
+        for k, v in (('negative_count', 1), ('init_method', 'normal')):
+            if k not in user.get('train', {}):
+                self.config['train'][k] = v
 
     def _get_dataset_class():
         return SeqDataset
@@ -601,7 +607,7 @@ class SASRec(BaseRetriever):
         return data if isinstance(data, dict) else super()._get_query_feat(data)
 
     def _get_loss_func(self):
-        return SampledSoftmaxLoss()
+        return BinaryCrossEntropyLoss()         # sasrec.py:117-119
 
     def _get_sampler(self, train_data):
         return UniformSampler(train_data.num_items)

@@ -159,6 +159,20 @@ def test_sasrec_fit_ml100k(ra, golden):
     assert np.isfinite(model.logged_metrics['train_loss']) and res['recall@20'] > 0.02
 
 
+def test_sasrec_stock_defaults_fit_ml100k(ra, golden):
+    """Stock SASRec as the reference configures it (sasrec.py:117-123, seq/config/sasrec.yaml): BinaryCrossEntropyLoss,
+    UniformSampler, negative_count = 1, normal init -- no plugin kwargs."""
+    g = golden('data_ml100k')
+    sq = make(ra.SeqDataset, g, max_seq_len=50)
+    trn, val, tst = sq.build(split_ratio=2)
+    model = ra.SASRec({'model': {'embed_dim': 64}, 'train': {'epochs': 2, 'batch_size': 512}, 'eval': {'batch_size': 256}})
+    model.fit(trn, val)
+    assert type(model.loss_fn) is ra.BinaryCrossEntropyLoss and model.neg_count == 1
+    assert model.config['train']['init_method'] == 'normal'
+    res = model.evaluate(tst)
+    assert np.isfinite(model.logged_metrics['train_loss']) and res['recall@20'] > 0.02
+
+
 def test_device_loaders_match_host_loaders(ra, golden):
     """Loader fast path: batches assembled on the GPU (SeqDataset through rsa_seg_gather) equal the host
     loader's batches (which are pinned to the reference in tests/test_dataset_golden.py)."""
