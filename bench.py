@@ -239,6 +239,17 @@ def main():
                                    'unit': 'M triplets/s', 'what': 'forward + BPR loss + user-gradient rows (accumulated '
                                    'in the forward) + row-sparse item-gradient rows (no optimizer)',
                                    'forward_ms': round(t_f, 4), 'two_pass_ms_per_step': round(ms_two, 4)}
+            # complete SGD step without gradient tensors (updates applied by the kernels); the tables are restored after
+            from recstudio_amd.fused import bpr_sgd_step
+            iw0, uw0 = item.clone(), user.clone()
+            t_sgd = time_gpu(lambda: bpr_sgd_step(item, user, n, 1e-3, user_ids=uid, pos_ids=pos, sampler=sampler),
+                             max(10, args.steps // 4), 3) * 1e3
+            item.copy_(iw0)
+            user.copy_(uw0)
+            del iw0, uw0
+            extra['train_step']['sgd_step_ms'] = round(t_sgd, 4)
+            extra['train_step']['sgd_step_what'] = ('forward + BPR loss + SGD update of the touched item and user rows '
+                                                    'applied in place by the kernels (no [N, d] gradient tensor)')
         except Exception as e:      # never let the secondary figure kill the bench line
             extra['train_step'] = {'error': repr(e)[:200]}
         if not args.no_sweep:

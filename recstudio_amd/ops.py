@@ -108,11 +108,14 @@ def embedding_gather(table, ids):
     return out
 
 
-def scatter_add_rows(src, ids, n_rows):
+def scatter_add_rows(src, ids, n_rows, out=None):
+    """dst[ids[i]] += src[i] for ids != 0 (embedding_dense_backward with padding_idx = 0).  ``out``: accumulate
+    into an existing [n_rows, dim] tensor instead of a fresh zero one."""
     src = _need(src, torch.float32, 'src')
     ids = _need(ids, torch.int64, 'ids')
     dim = src.shape[-1]
-    dst = torch.zeros(n_rows, dim, dtype=torch.float32, device=src.device)
+    dst = _need(out, torch.float32, 'out') if out is not None else torch.zeros(n_rows, dim, dtype=torch.float32,
+                                                                                device=src.device)
     nat.check(nat.lib().rsa_scatter_add_rows(ptr(src), ptr(ids), ids.numel(), dim, ptr(dst), n_rows, _stream()),
               'rsa_scatter_add_rows')
     return dst

@@ -515,7 +515,12 @@ ItemTowerRecommender = BaseRetriever
 
 
 class BPR(BaseRetriever):
-    """recstudio/model/mf/bpr.py:7-25."""
+    """recstudio/model/mf/bpr.py:7-25, recstudio/model/mf/config/bpr.yaml (negative_count: 1)."""
+
+    def __init__(self, config=None, **kwargs):
+        super().__init__(config, **kwargs)
+        if 'negative_count' not in (config or {}).get('train', {}):
+            self.config['train']['negative_count'] = 1
 
     def _get_dataset_class():
         return TripletDataset

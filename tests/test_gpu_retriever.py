@@ -232,3 +232,31 @@ def test_dns_sampling_method(ra):
     v, c = ra.ops.row_topk(s.detach(), 7)
     wv, wc = torch.topk(s.detach(), 7)
     assert torch.equal(v, wv) and torch.equal(c, wc)
+
+
+def test_bpr_sgd_step_equals_autograd_plus_torch_sgd(ra):
+    """fused.bpr_sgd_step (no gradient tensors: updates applied by the kernels) == loss.backward() +
+    torch.optim.SGD.step() on dense gradients, same sampled negatives."""
+    torch.manual_seed(6)
+    N, U, d, B, n, lr = 4001, 301, 64, 257, 64, 0.05
+    item = torch.nn.Embedding(N, d, padding_idx=0).to(DEV)
+    user = torch.nn.Embedding(U, d, padding_idx=0).to(DEV)
+    item2 = torch.nn.Embedding(N, d, padding_idx=0).to(DEV)
+    user2 = torch.nn.Embedding(U, d, padding_idx=0).to(DEV)
+    item2.load_state_dict(item.state_dict())
+    user2.load_state_dict(user.state_dict())
+    uid = torch.randint(1, U, (B,), device=DEV)
+    pos = torch.randint(1, N, (B,), device=DEV)
+    torch.manual_seed(8)
+    loss, neg = ra.fused.bpr_sgd_step(item.weight, user.weight, n, lr, user_ids=uid, pos_ids=pos,
+                                      sampler=ra.UniformSampler(N))
+    opt = torch.optim.SGD(list(item2.parameters()) + list(user2.parameters()), lr=lr)
+    q = user2(uid)
+    ref = -torch.nn.functional.logsigmoid((q * item2(pos)).sum(-1, keepdim=True)
+                                          - (q.unsqueeze(1) * item2(neg)).sum(-1)).mean(-1).mean()
+    ref.backward()
+    opt.step()
+    np.testing.assert_allclose(loss.item(), ref.item(), rtol=1e-5)
+    np.testing.assert_allclose(item.weight.detach().cpu(), item2.weight.detach().cpu(), rtol=1e-4, atol=1e-7)
+    np.testing.assert_allclose(user.weight.detach().cpu(), user2.weight.detach().cpu(), rtol=1e-4, atol=1e-7)
+    assert not item.weight[0].any() and not user.weight[0].any()
