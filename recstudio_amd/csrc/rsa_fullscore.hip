@@ -27,6 +27,9 @@
 // top-k (ties -> smaller id).  With `scores` given, the radix select runs on the materialised rows.
 #include "rsa_common.hpp"
 
+#ifndef RSA_FS_EXP_NOEPI
+#define RSA_FS_EXP_NOEPI 0
+#endif
 #ifndef RSA_FS_MIN_BLOCKS
 #define RSA_FS_MIN_BLOCKS 1
 #endif
@@ -36,7 +39,16 @@ namespace rsa {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int QB = 128;   // queries per workgroup (4 waves x 32)
-constexpr int TI = 32;    // items per tile
+constexpr int TI = 32;    // items per MFMA tile
+#ifndef RSA_FS_STG
+#define RSA_FS_STG 1
+#endif
+constexpr int STG = RSA_FS_STG;   // MFMA tiles per LDS stage: one workgroup barrier per STG * TI items.  Measured at
+                                  // B = 2048, N = 1e6: STG = 2 (half the barriers, 67 KB LDS) 115.1 vs 115.8 TFLOP/s for
+                                  // STG = 1, and the score-writing variants lose a wave per SIMD -- the barrier is not
+                                  // what limits the MFMA pipe; neither are a second accumulation chain (111 vs 117) nor
+                                  // 3 waves/SIMD via launch bounds (+2 %, spills in the other variants) nor the epilogue
+                                  // (GEMM core alone: same time)
 
 // Candidate lists of the filter epilogue.  Every (query, item-range split, lane half) owns a private
 // segment of SEG slots and counts in a register: plain fire-and-forget stores, no atomics (a returning
@@ -74,7 +86,7 @@ __global__ __launch_bounds__(256, RSA_FS_MIN_BLOCKS) void fullscore_kernel(const
   constexpr int KH = D / 2;         // k values per lane half
   constexpr int LD = D + 4;         // padded LDS row stride (floats)
   constexpr int V4 = D / 4;         // float4 per row
-  __shared__ float tile[2][TI][LD];
+  __shared__ float tile[2][TI * STG][LD];
   __shared__ float tpose[4][32][33];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -111,15 +123,15 @@ __global__ __launch_bounds__(256, RSA_FS_MIN_BLOCKS) void fullscore_kernel(const
   int32_t my_cnt = 0;
   const size_t seg = ((size_t)(q < n_query ? q : 0) * splits + blockIdx.x) * 2 + h;
 
-  constexpr int LOADS = (TI * V4) / 256;    // float4 per thread per tile (D=128: 4)
-  static_assert((TI * V4) % 256 == 0, "tile must split evenly over the workgroup");
+  constexpr int LOADS = (TI * STG * V4) / 256;    // float4 per thread per stage (D=128, STG=2: 8)
+  static_assert((TI * STG * V4) % 256 == 0, "stage must split evenly over the workgroup");
   float4 stage[LOADS];
   auto fetch = [&](int t) {
 #pragma unroll
     for (int f = 0; f < LOADS; ++f) {
       const int idx = f * 256 + tid;
       const int row = idx / V4, c4 = idx - row * V4;
-      const int64_t pos = i_begin + (int64_t)t * TI + row;
+      const int64_t pos = i_begin + (int64_t)t * (TI * STG) + row;
       int64_t item = tile_stride == 1 ? pos : 1 + ((pos - 1) / TI) * tile_stride * TI + (pos - 1) % TI;
       const bool ok = pos < i_end && item < n_items;
       item = item < n_items ? item : n_items - 1;          // unconditional load from a valid row, zeroed by select
@@ -142,6 +154,11 @@ __global__ __launch_bounds__(256, RSA_FS_MIN_BLOCKS) void fullscore_kernel(const
   // tile's MFMA chain (64 dependent 64-cycle instructions) is in flight.
   // (a) branch-free online logsumexp: pure VALU, interleaved with the MFMAs by the sched_group_barriers below
   auto lse_update = [&](const f32x16& acc, int64_t i0) {
+#if RSA_FS_EXP_NOEPI
+    run_s += acc[0] + acc[5] + acc[10] + acc[15];   // experiment: GEMM core without the logsumexp epilogue
+    run_m = 0.f;
+    return;
+#endif
     const bool full = i0 + TI <= i_end;      // only the last tile of a range can be partial
     float v[16];
     float tmax = -INFINITY;
@@ -202,9 +219,9 @@ __global__ __launch_bounds__(256, RSA_FS_MIN_BLOCKS) void fullscore_kernel(const
       }
     }
   };
-  auto mfma_tile = [&](int buf) -> f32x16 {
+  auto mfma_tile = [&](int buf, int sub) -> f32x16 {
     f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    const float* arow = &tile[buf][j][h * KH];   // lane's item row of this tile, its k half
+    const float* arow = &tile[buf][sub * TI + j][h * KH];   // lane's item row of this tile, its k half
 #pragma unroll
     for (int c = 0; c < KH / 4; ++c) {
       const float4 a = *reinterpret_cast<const float4*>(arow + 4 * c);
@@ -221,20 +238,24 @@ __global__ __launch_bounds__(256, RSA_FS_MIN_BLOCKS) void fullscore_kernel(const
     if (FILTER && q < n_query) flt.seg_cnt[seg] = 0;
     return;
   }
+  // Stage s = MFMA tiles s*STG .. s*STG+STG-1 staged together in LDS (double-buffered): one workgroup barrier
+  // per STG tiles.  Tiles past n_tiles inside the last stage are all-masked (zero rows, results ignored).
+  const int n_stages = (n_tiles + STG - 1) / STG;
   fetch(0);
   commit(0);
   __syncthreads();
-  // tile 0 (peeled so that the loop body is branch-free up to the rare filter hit)
-  fetch(1);                               // out-of-range tiles load a valid row and are zeroed
-  f32x16 acc_prev = mfma_tile(0);
-  commit(1);
-  __syncthreads();
-  for (int t = 1; t < n_tiles; ++t) {
-    const int cur = t & 1;
-    fetch(t + 1);                         // global loads fly under the MFMA chain
-    const f32x16 acc = mfma_tile(cur);
+  fetch(1);                               // out-of-range stages load a valid row and are zeroed
+  f32x16 acc_prev = mfma_tile(0, 0);      // tile 0 peeled: the loop body is branch-free up to the rare filter hit
+  if (STG == 1) {
+    commit(1);
+    __syncthreads();
+  }
+  for (int u = 1; u < n_stages * STG; ++u) {
+    const int st = u / STG, sub = u - st * STG, cur = st & 1;
+    if (sub == 0) fetch(st + 1);          // global loads fly under this stage's MFMA chains
+    const f32x16 acc = mfma_tile(cur, sub);
     if constexpr (LSE) {
-      lse_update(acc_prev, i_begin + (int64_t)(t - 1) * TI);
+      lse_update(acc_prev, i_begin + (int64_t)(u - 1) * TI);
       // one MFMA of this tile, then a couple of the previous tile's epilogue VALU ops, and so on
 #pragma unroll
       for (int g = 0; g < KH; ++g) {
@@ -242,13 +263,15 @@ __global__ __launch_bounds__(256, RSA_FS_MIN_BLOCKS) void fullscore_kernel(const
         __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
       }
     }
-    emit(acc_prev, i_begin + (int64_t)(t - 1) * TI);
-    commit(cur ^ 1);
-    __syncthreads();
+    emit(acc_prev, i_begin + (int64_t)(u - 1) * TI);
+    if (sub == STG - 1) {
+      commit(cur ^ 1);
+      __syncthreads();
+    }
     acc_prev = acc;
   }
-  if constexpr (LSE) lse_update(acc_prev, i_begin + (int64_t)(n_tiles - 1) * TI);
-  emit(acc_prev, i_begin + (int64_t)(n_tiles - 1) * TI);
+  if constexpr (LSE) lse_update(acc_prev, i_begin + (int64_t)(n_stages * STG - 1) * TI);
+  emit(acc_prev, i_begin + (int64_t)(n_stages * STG - 1) * TI);
   if (FILTER && q < n_query) flt.seg_cnt[seg] = my_cnt;
   if constexpr (LSE) {
     // fold the two k-halves' item subsets (lanes j and j+32 hold the same query)
