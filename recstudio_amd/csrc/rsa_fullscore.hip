@@ -26,7 +26,11 @@
 // D. a per-row radix select that evaluates the dot products on the fly.  The result is always the exact
 // top-k (ties -> smaller id).  With `scores` given, the radix select runs on the materialised rows.
 #include "rsa_common.hpp"
+#include <type_traits>
 
+#ifndef RSA_FS_EXP
+#define RSA_FS_EXP 0
+#endif
 #ifndef RSA_FS_EXP_NOEPI
 #define RSA_FS_EXP_NOEPI 0
 #endif
@@ -126,7 +130,26 @@ __global__ __launch_bounds__(256, RSA_FS_MIN_BLOCKS) void fullscore_kernel(const
   constexpr int LOADS = (TI * STG * V4) / 256;    // float4 per thread per stage (D=128, STG=2: 8)
   static_assert((TI * STG * V4) % 256 == 0, "stage must split evenly over the workgroup");
   float4 stage[LOADS];
-  auto fetch = [&](int t) {
+  // Stages that lie completely inside the item range of a contiguous walk (all but the last one or two) are
+  // loaded through per-thread pointers that advance by a constant: no index arithmetic, range checks or
+  // zero-selects in the main loop -- VALU instructions there compete with the MFMA chain for issue slots
+  // (measured: the same loop without its loads/epilogue VALU runs at 148 instead of 119 TFLOP/s).
+  const int64_t n_full_tiles = tile_stride == 1 && i_begin < i_end ? (i_end - i_begin) / TI : 0;
+  const int n_full_stages = (int)(n_full_tiles / STG);
+  const float4* fast_src[LOADS];
+#pragma unroll
+  for (int f = 0; f < LOADS; ++f) {
+    const int idx = f * 256 + tid;
+    const int row = idx / V4, c4 = idx - row * V4;
+    fast_src[f] = reinterpret_cast<const float4*>(item_table + (size_t)(n_full_stages > 0 ? i_begin + row : 0) * D) + c4;
+  }
+  constexpr int64_t STAGE_F4 = (int64_t)TI * STG * V4;     // float4 per stage
+  auto fetch = [&](int t) __attribute__((always_inline)) {
+    if (t < n_full_stages) {
+#pragma unroll
+      for (int f = 0; f < LOADS; ++f) stage[f] = fast_src[f][(int64_t)t * STAGE_F4];
+      return;
+    }
 #pragma unroll
     for (int f = 0; f < LOADS; ++f) {
       const int idx = f * 256 + tid;
@@ -139,7 +162,7 @@ __global__ __launch_bounds__(256, RSA_FS_MIN_BLOCKS) void fullscore_kernel(const
       stage[f] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
-  auto commit = [&](int buf) {
+  auto commit = [&](int buf) __attribute__((always_inline)) {
 #pragma unroll
     for (int f = 0; f < LOADS; ++f) {
       const int idx = f * 256 + tid;
@@ -153,21 +176,25 @@ __global__ __launch_bounds__(256, RSA_FS_MIN_BLOCKS) void fullscore_kernel(const
   // ---- per-tile epilogue pieces.  They are applied to the PREVIOUS tile's accumulators while the current
   // tile's MFMA chain (64 dependent 64-cycle instructions) is in flight.
   // (a) branch-free online logsumexp: pure VALU, interleaved with the MFMAs by the sched_group_barriers below
-  auto lse_update = [&](const f32x16& acc, int64_t i0) {
-#if RSA_FS_EXP_NOEPI
+  auto lse_update = [&](const f32x16& acc, int64_t i0, auto masked) __attribute__((always_inline)) {
+#if RSA_FS_EXP_NOEPI || (RSA_FS_EXP & 4)
     run_s += acc[0] + acc[5] + acc[10] + acc[15];   // experiment: GEMM core without the logsumexp epilogue
     run_m = 0.f;
     return;
 #endif
-    const bool full = i0 + TI <= i_end;      // only the last tile of a range can be partial
     float v[16];
-    float tmax = -INFINITY;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-      v[r] = (full || i0 + row < i_end) ? acc[r] : -INFINITY;
-      tmax = fmaxf(tmax, v[r]);
+      v[r] = acc[r];
+      if constexpr (decltype(masked)::value) {     // only the last tiles of a range can be partial
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (!(i0 + row < i_end)) v[r] = -INFINITY;
+      }
     }
+    float tmax = fmaxf(fmaxf(v[0], v[1]), v[2]);
+#pragma unroll
+    for (int r = 3; r < 15; r += 2) tmax = fmaxf(fmaxf(tmax, v[r]), v[r + 1]);    // v_max3_f32
+    tmax = fmaxf(tmax, v[15]);
     const float m_new = fmaxf(run_m, tmax);
     const float m_safe = m_new == -INFINITY ? 0.f : m_new;   // nothing seen yet: exp(-inf - 0) = 0 everywhere
     float sum = run_s * __expf(run_m - m_safe);
@@ -177,7 +204,7 @@ __global__ __launch_bounds__(256, RSA_FS_MIN_BLOCKS) void fullscore_kernel(const
     run_s = sum;
   };
   // (b) the parts with memory side effects (score rows, candidate lists)
-  auto emit = [&](const f32x16& acc, int64_t i0) {
+  auto emit = [&](const f32x16& acc, int64_t i0) __attribute__((always_inline)) {
     if constexpr (SCORES) {
       // transpose the wave's 32 (items) x 32 (queries) tile through LDS so that every half-wave
       // writes 128 contiguous bytes of one query's score row
@@ -219,12 +246,16 @@ __global__ __launch_bounds__(256, RSA_FS_MIN_BLOCKS) void fullscore_kernel(const
       }
     }
   };
-  auto mfma_tile = [&](int buf, int sub) -> f32x16 {
+  auto mfma_tile = [&](int buf, int sub) __attribute__((always_inline)) -> f32x16 {
     f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     const float* arow = &tile[buf][sub * TI + j][h * KH];   // lane's item row of this tile, its k half
 #pragma unroll
     for (int c = 0; c < KH / 4; ++c) {
+#if RSA_FS_EXP & 1
+      const float4 a = make_float4(bq[4 * c + 1], bq[4 * c + 2], bq[4 * c + 3], bq[4 * c]);   // experiment: no LDS reads
+#else
       const float4 a = *reinterpret_cast<const float4*>(arow + 4 * c);
+#endif
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bq[4 * c + 0], acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bq[4 * c + 1], acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bq[4 * c + 2], acc, 0, 0, 0);
@@ -250,12 +281,15 @@ __global__ __launch_bounds__(256, RSA_FS_MIN_BLOCKS) void fullscore_kernel(const
     commit(1);
     __syncthreads();
   }
-  for (int u = 1; u < n_stages * STG; ++u) {
+  // iteration u: MFMA chain of tile u with the epilogue of tile u-1 interleaved under it
+  auto iteration = [&](int u, auto masked) __attribute__((always_inline)) {
     const int st = u / STG, sub = u - st * STG, cur = st & 1;
+#if !(RSA_FS_EXP & 2)
     if (sub == 0) fetch(st + 1);          // global loads fly under this stage's MFMA chains
+#endif
     const f32x16 acc = mfma_tile(cur, sub);
     if constexpr (LSE) {
-      lse_update(acc_prev, i_begin + (int64_t)(u - 1) * TI);
+      lse_update(acc_prev, i_begin + (int64_t)(u - 1) * TI, masked);
       // one MFMA of this tile, then a couple of the previous tile's epilogue VALU ops, and so on
 #pragma unroll
       for (int g = 0; g < KH; ++g) {
@@ -264,14 +298,21 @@ __global__ __launch_bounds__(256, RSA_FS_MIN_BLOCKS) void fullscore_kernel(const
       }
     }
     emit(acc_prev, i_begin + (int64_t)(u - 1) * TI);
+#if !(RSA_FS_EXP & 2)
     if (sub == STG - 1) {
       commit(cur ^ 1);
       __syncthreads();
     }
+#endif
     acc_prev = acc;
-  }
-  if constexpr (LSE) lse_update(acc_prev, i_begin + (int64_t)(n_stages * STG - 1) * TI);
-  emit(acc_prev, i_begin + (int64_t)(n_stages * STG - 1) * TI);
+  };
+  const int total_tiles = n_stages * STG;
+  const int fast_end = (int)(n_full_tiles < total_tiles - 1 ? n_full_tiles : total_tiles - 1);   // tiles 0..fast_end-1 are full
+  int u = 1;
+  for (; u <= fast_end; ++u) iteration(u, std::false_type{});
+  for (; u < total_tiles; ++u) iteration(u, std::true_type{});
+  if constexpr (LSE) lse_update(acc_prev, i_begin + (int64_t)(total_tiles - 1) * TI, std::true_type{});
+  emit(acc_prev, i_begin + (int64_t)(total_tiles - 1) * TI);
   if (FILTER && q < n_query) flt.seg_cnt[seg] = my_cnt;
   if constexpr (LSE) {
     // fold the two k-halves' item subsets (lanes j and j+32 hold the same query)
