@@ -197,9 +197,13 @@ __global__ __launch_bounds__(256, RSA_FS_MIN_BLOCKS) void fullscore_kernel(const
     tmax = fmaxf(tmax, v[15]);
     const float m_new = fmaxf(run_m, tmax);
     const float m_safe = m_new == -INFINITY ? 0.f : m_new;   // nothing seen yet: exp(-inf - 0) = 0 everywhere
-    float sum = run_s * __expf(run_m - m_safe);
+    // exp(x - m) = 2^(x * log2(e) - m * log2(e)): one fma + one v_exp per element (VALU slots are what the
+    // epilogue costs: they are stolen from the MFMA chain's issue)
+    constexpr float LOG2E = 1.4426950408889634f;
+    const float c = m_safe * LOG2E;
+    float sum = run_s * __builtin_amdgcn_exp2f(__fmaf_rn(run_m, LOG2E, -c));
 #pragma unroll
-    for (int r = 0; r < 16; ++r) sum += __expf(v[r] - m_safe);
+    for (int r = 0; r < 16; ++r) sum += __builtin_amdgcn_exp2f(__fmaf_rn(v[r], LOG2E, -c));
     run_m = m_new;
     run_s = sum;
   };
