@@ -86,7 +86,7 @@ def test_popular_lookup_golden(ra, golden):
         built = ra.PopularSamplerModel(counts.clone(), mode=mode)
         rel_close(built.pop_prob.numpy(), g[f'm{mode}_pop_prob'], rtol=2e-6, atol=0)
         rel_close(built.table.numpy(), g[f'm{mode}_table'], rtol=2e-6, atol=0)
-        for glog in (None, 4, 9, 16):
+        for glog in (None, 4, 9, 16, 25):      # 25: finer than fp32's 2^-24 grid (float64 cut points)
             ps = ra.PopularSamplerModel.from_tables(T(g[f'm{mode}_pop_prob']), T(g[f'm{mode}_table']), glog).to(DEV)
             want = np.minimum(g[f'm{mode}_ids'], len(counts) - 1)
             for lut in (None, ps.cdf_lut):        # binary search inside the guide bucket / direct lookup table
@@ -102,6 +102,16 @@ def test_popular_lookup_golden(ra, golden):
     ps = ps.to(DEV)
     ids, _ = ra.ops.popular_lookup(ps.table, ps.pop_prob, ps.guide, ps.guide_log2, u.to(DEV))
     assert torch.equal(ids.cpu(), want)
+    # buckets holding many CDF boundaries (coarse guide): the 4-wide probe and its binary-search tail, both the
+    # fused kernel's pair layout and the stand-alone kernel's separate arrays, on dense random uniforms
+    coarse = ra.PopularSamplerModel.from_tables(ps.pop_prob.cpu(), ps.table.cpu(), 6).to(DEV)
+    torch.manual_seed(3)
+    uu = torch.rand(200_000, device=DEV)
+    want = torch.searchsorted(coarse.table, uu).clamp_(max=coarse.table.numel() - 1)
+    ids, logp = ra.ops.popular_lookup(coarse.table, coarse.pop_prob, coarse.guide, coarse.guide_log2, uu,
+                                      cdf_lut=coarse.cdf_lut)
+    assert torch.equal(ids, want)
+    rel_close(logp.cpu(), torch.log(coarse.pop_prob[want]).cpu(), rtol=1e-6, atol=1e-7)
 
 
 def test_sampler_plugin_surface(ra):
@@ -162,7 +172,7 @@ def test_fused_forward_given_ids(ra, d, n, cosine):
 
 
 @pytest.mark.parametrize('n,B', [(1, 512), (64, 100), (256, 9), (100, 33), (1024, 3)])
-@pytest.mark.parametrize('kind', ['uniform', 'popular'])
+@pytest.mark.parametrize('kind', ['uniform', 'popular', 'popular_coarse'])
 def test_fused_forward_sampled(ra, n, B, kind):
     N, U, d = 20011, 300, 128
     iw, uw = _tables(N, U, d, 5)
@@ -177,8 +187,11 @@ def test_fused_forward_sampled(ra, n, B, kind):
         sampler = ra.UniformSampler(N)
         ref = oracle.UniformSampler(N)
     else:
-        sampler = ra.PopularSamplerModel(counts).to(DEV)
+        # 'popular_coarse': 2^5 guide buckets over 20 k items -> every draw takes the wide probe and its
+        # binary-search tail instead of the direct LUT hit
+        sampler = ra.PopularSamplerModel(counts, guide_log2=5 if kind == 'popular_coarse' else None).to(DEV)
         ref = oracle.PopularSamplerModel(counts)
+        kind = 'popular'
     torch.manual_seed(seed)
     off0 = gen.get_offset()
     score, ids = ra.retriever_scores(iw.to(DEV), uw.to(DEV), n, query_index=uid.to(DEV), pos_ids=pos.to(DEV),
