@@ -28,11 +28,11 @@
 #include "rsa_common.hpp"
 #include <type_traits>
 
+// Ablation switches for tools/exp_fs.sh (bit mask; results are WRONG when set -- timing experiments only, never
+// a product build): 1 = A operand from registers instead of LDS, 2 = no stage loads / LDS writes / barrier,
+// 4 = no logsumexp epilogue.
 #ifndef RSA_FS_EXP
 #define RSA_FS_EXP 0
-#endif
-#ifndef RSA_FS_EXP_NOEPI
-#define RSA_FS_EXP_NOEPI 0
 #endif
 #ifndef RSA_FS_MIN_BLOCKS
 #define RSA_FS_MIN_BLOCKS 1
@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256, RSA_FS_MIN_BLOCKS) void fullscore_kernel(const
   // tile's MFMA chain (64 dependent 64-cycle instructions) is in flight.
   // (a) branch-free online logsumexp: pure VALU, interleaved with the MFMAs by the sched_group_barriers below
   auto lse_update = [&](const f32x16& acc, int64_t i0, auto masked) __attribute__((always_inline)) {
-#if RSA_FS_EXP_NOEPI || (RSA_FS_EXP & 4)
+#if RSA_FS_EXP & 4
     run_s += acc[0] + acc[5] + acc[10] + acc[15];   // experiment: GEMM core without the logsumexp epilogue
     run_m = 0.f;
     return;
