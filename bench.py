@@ -382,6 +382,24 @@ def main():
         achieved = alg / (ms_step * 1e-3) / 1e9
         roofline = {'bound': 'hbm', 'kernel': 'whole sharded step (per GPU)', 'achieved': round(achieved, 1),
                     'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': None}
+        # the same sharded table at BASELINE.json configs[3]'s per-GPU shape (n = 1024, B = 4096: the same 4.2 M
+        # triplets per GPU per step, but a 16x smaller query all-gather -- at n = 64 that gather is the largest
+        # message of the step)
+        try:
+            n4, b4 = 1024, 4096
+            uid4, pos4 = uid[:b4].contiguous(), pos[:b4].contiguous()
+
+            def step4():
+                o = table.sample_and_score(user, uid4, pos4, n4, sampler)
+                return ra.ops.pairwise_loss(nat.LOSS_BPR, o['pos_score'], o['neg_score'], want_grad=True)
+            ms4 = time_gpu(step4, max(10, args.steps // 4), 5, dist) * 1e3
+            t4 = torch.tensor([ms4], device=dev)
+            dist.all_reduce(t4, op=dist.ReduceOp.MAX)
+            ms4 = float(t4.item())
+            extra['sharded_n1024'] = {'workload': f'same sharded table, neg={n4}, B={b4} queries/step/GPU (configs[3] shape)',
+                                      'ms_per_step': round(ms4, 4), 'M_triplets_s': round(world * b4 * n4 / ms4 / 1e3, 2)}
+        except Exception as e:
+            extra['sharded_n1024'] = {'error': repr(e)[:200]}
         parallelism = f'item-table row-sharded x{world} + RCCL all-to-all (ids out, scores back)'
         workload = (f'two-tower d={d}, {args.items}-item table row-sharded over {world} GPUs, {args.sampler} sampler '
                     f'neg={n}, InnerProduct + BPR loss, B={B} queries/step/GPU (BASELINE.json configs[3] layout)')
