@@ -146,7 +146,8 @@ typedef struct rsa_fused_args {
                                   needs num_neg % 64 == 0, pos_ids, pos_score.  Outputs below. */
   int32_t _pad2;
   float* row_loss;             /* [M] out: per-query loss */
-  float* loss_out;             /* nullable [1] out: mean over queries (deterministic; rsa_mean_rows) */
+  float* loss_out;             /* nullable [1] out: mean over queries, reduced in the same launch by the last workgroup
+                                  to finish (fixed summation order: reproducible run to run) */
   float* dpos;                 /* nullable [M] out: d loss_out / d pos_score */
   float* dneg;                 /* nullable [M, n] out: d loss_out / d neg_score */
   const float* cdf_lut;        /* nullable [2^guide_log2 + 1][4] fp32, one self-contained entry per guide bucket b with
