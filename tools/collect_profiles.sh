@@ -15,5 +15,8 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write -o bench -- $BENCH -
 # MFMA utilisation of the full-score GEMM: busy cycles of the matrix pipes vs elapsed GPU cycles
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -d $OUT/pmc_mfma -o bench -- $BENCH --steps 4 --warmup 1 > $OUT/pmc_mfma.log 2>&1
 cd $REPO
-python tools/summarize_profiles.py $OUT $TAG > $OUT/summary.log 2>&1
+# the rocpd databases are 15-20 MB each (gpurun merges at most 64 MiB back): summarise on the box, keep the summaries
+mkdir -p $REPO/gpurun_out/profiles_$TAG
+python tools/summarize_profiles.py $OUT $TAG $REPO/gpurun_out/profiles_$TAG > $OUT/summary.log 2>&1
 tail -40 $OUT/summary.log
+rm -rf $OUT/trace $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_mfma
