@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define RSA_ABI_VERSION 1
+#define RSA_ABI_VERSION 2   /* 2: rsa_fused_args grew query_grad + packed_keys; rsa_row_topk, rsa_fullscore_softmax */
 
 typedef void* rsa_stream_t; /* hipStream_t */
 

@@ -109,6 +109,9 @@ def build(verbose=False):
     return LIB_PATH
 
 
+ABI_VERSION = 2      # RSA_ABI_VERSION of include/recstudio_amd.h this binding was written against
+
+
 def lib():
     """The loaded library with typed entry points.  Raises if it is not built."""
     global _lib
@@ -122,7 +125,7 @@ def lib():
             fn = getattr(handle, name)       # AttributeError if the symbol is not exported
             fn.restype = res
             fn.argtypes = args
-        if handle.rsa_abi_version() != 1:
+        if handle.rsa_abi_version() != ABI_VERSION:
             raise RuntimeError('recstudio_amd: ABI version mismatch between header and library')
         _lib = handle
     return _lib

@@ -34,7 +34,7 @@ def test_header_symbols_all_exported(nat):
 
 def test_abi_version_and_error_channel(nat):
     lib = nat.lib()
-    assert lib.rsa_abi_version() == 1
+    assert lib.rsa_abi_version() == nat.ABI_VERSION == 2
     # argument validation happens before any HIP call, so it can be exercised without a GPU
     rc = lib.rsa_sample_uniform(None, 10, 1, 5, 0, 0, 256, None)
     assert rc == -1 and b'neg_ids is null' in lib.rsa_last_error()
