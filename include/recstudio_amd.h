@@ -163,9 +163,17 @@ typedef struct rsa_fused_args {
   const int64_t* packed_keys;  /* nullable [M]: sampler GIVEN, num_neg == 1, no positives: element m scores query row
                                   (key >> 32) against item row (key & 0xffffffff) -- the owner side of the sharded
                                   exchange (rsa_shard_route keys) without unpacking; neg_ids / query_index unused. */
+  const uint64_t* offset_dev;  /* nullable device word: when set, the Philox offset is read from it at run time instead
+                                  of `offset` (a multiple of 4, like torch's) -- lets a captured HIP graph draw fresh
+                                  numbers on every replay; advance it with rsa_rng_advance in the same graph. */
 } rsa_fused_args;
 
 int rsa_fused_sample_gather_score(const rsa_fused_args* args, rsa_stream_t stream);
+
+/* *offset_dev += increment (one thread).  Together with rsa_fused_args.offset_dev this keeps the device copy of the
+ * torch generator offset moving inside a captured graph; `increment` is what torch's distribution call would
+ * consume ((numel-1)/(grid_threads*unroll)+1)*4, see "Philox state"). */
+int rsa_rng_advance(uint64_t* offset_dev, uint64_t increment, rsa_stream_t stream);
 
 /* BPRLoss.forward (recstudio/model/loss_func.py:55-59) / SampledSoftmaxLoss.forward
  * (:80-90) / BinaryCrossEntropyLoss.forward (:105-127, dns=False) on pos_score [M], neg_score [M, n] (each positive with its own n

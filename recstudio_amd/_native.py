@@ -35,7 +35,7 @@ class FusedArgs(Structure):
         ('neg_ids', c_void_p), ('neg_logp', c_void_p), ('pos_logp', c_void_p),
         ('pos_score', c_void_p), ('neg_score', c_void_p), ('table_prob', c_void_p),
         ('fused_loss', c_int32), ('_pad2', c_int32), ('row_loss', c_void_p), ('loss_out', c_void_p),
-        ('dpos', c_void_p), ('dneg', c_void_p), ('cdf_lut', c_void_p), ('query_grad', c_void_p), ('packed_keys', c_void_p),
+        ('dpos', c_void_p), ('dneg', c_void_p), ('cdf_lut', c_void_p), ('query_grad', c_void_p), ('packed_keys', c_void_p), ('offset_dev', c_void_p),
     ]
 
 
@@ -79,6 +79,7 @@ SIGNATURES = {
                                c_void_p, c_void_p, c_void_p, c_void_p]),
     'rsa_fullscore_softmax': (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_int64, c_void_p, c_void_p, c_void_p,
                                       c_void_p]),
+    'rsa_rng_advance': (c_int, [c_void_p, c_uint64, c_void_p]),
     'rsa_row_topk': (c_int, [c_void_p, c_int64, c_int64, c_int32, c_void_p, c_void_p, c_void_p]),
     'rsa_topk_mask_history': (c_int, [c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_int64, c_int32, c_void_p,
                                       c_void_p, c_void_p]),

@@ -615,6 +615,10 @@ static int64_t fullscore_splits(int64_t n_query, int64_t n_positions, int64_t mi
   const int64_t groups = (n_query + QB - 1) / QB;
   int64_t splits = (1024 + groups - 1) / groups;   // ~4 workgroups per CU in flight
   if (splits < min_splits) splits = min_splits;
+  // XCD-aware launch: workgroups are dealt round-robin to the 8 XCDs by linear id = blockIdx.y * gridDim.x +
+  // blockIdx.x.  With gridDim.x (= splits) a multiple of 8, all query groups of one item range (same blockIdx.x)
+  // land on the same XCD and share its L2: the range is fetched from HBM once, not once per query group.
+  if (splits >= 8) splits = (splits + 7) / 8 * 8;
   const int64_t max_splits = (n_positions + TI - 1) / TI;
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;

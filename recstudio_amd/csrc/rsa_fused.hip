@@ -43,6 +43,7 @@ struct FwdParams {
   float* loss_out;              // fused BPR epilogue: mean of row_loss, reduced by the last workgroup to finish
   unsigned int* done_counter;   //   (self-resetting arrival counter + one partial sum per workgroup, owned by the library)
   float* loss_partials;
+  const uint64_t* offset_dev;   // nullable: Philox offset read at run time (graph replays)
   const int64_t* packed_keys;   // num_neg == 1, GIVEN: element e = (query row << 32) | item row (sharded owner side)
   float* qgrad;      // fused BPR epilogue (nullable): [M, dim] d loss / d query row, accumulated from the rows in flight
   int64_t n_items, n_query_rows, n_queries, numel;
@@ -268,6 +269,8 @@ __global__ __launch_bounds__(256, QG ? RSA_QG_MIN_WAVES : RSA_FWD_MIN_WAVES) voi
   const int D = GENERIC ? p.dim : LPR * 4;
   const int64_t n = p.num_neg;
   const int64_t n_tiles = (p.numel + 63) >> 6;
+  PhiloxCall pc = p.pc;
+  if (p.offset_dev != nullptr) pc.offset4 = *p.offset_dev >> 2;     // graph replay: the offset lives on the device
   const int64_t wave0 = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const int64_t wstride = (int64_t)gridDim.x * (blockDim.x >> 6);
 
@@ -279,7 +282,7 @@ __global__ __launch_bounds__(256, QG ? RSA_QG_MIN_WAVES : RSA_FWD_MIN_WAVES) voi
   auto fetch_ahead = [&](int64_t t) {
     const int64_t e2 = (t << 6) + lane;
     if (e2 < p.numel) {
-      u_next = torch_rand_element(p.pc, (uint64_t)e2);
+      u_next = torch_rand_element(pc, (uint64_t)e2);
       lut_next = reinterpret_cast<const float4*>(p.lut)[lut_bucket(p.guide_log2, u_next)];
     }
   };
@@ -309,10 +312,10 @@ __global__ __launch_bounds__(256, QG ? RSA_QG_MIN_WAVES : RSA_FWD_MIN_WAVES) voi
     int32_t id = 0;
     if (act) {
       if (p.sampler == RSA_SAMPLER_UNIFORM) {
-        id = (int32_t)torch_randint_element(p.pc, (uint64_t)e, (uint64_t)(p.n_items - 1), 1);
+        id = (int32_t)torch_randint_element(pc, (uint64_t)e, (uint64_t)(p.n_items - 1), 1);
         st_out(&p.neg_ids[e], (int64_t)id);
       } else if (p.sampler == RSA_SAMPLER_POPULAR) {
-        const float u = ahead ? u_cur : torch_rand_element(p.pc, (uint64_t)e);
+        const float u = ahead ? u_cur : torch_rand_element(pc, (uint64_t)e);
         if (ahead) {
           float pr;
           if (p.table_prob)
@@ -546,9 +549,18 @@ static int launch_fwd(const FwdParams& p, bool cos, bool qu, hipStream_t stream)
   return RSA_OK;
 }
 
+__global__ void rng_advance_kernel(uint64_t* offset_dev, uint64_t increment) { *offset_dev += increment; }
+
 }  // namespace rsa
 
 using namespace rsa;
+
+extern "C" int rsa_rng_advance(uint64_t* offset_dev, uint64_t increment, rsa_stream_t stream) {
+  RSA_CHECK_ARG(offset_dev != nullptr && (increment & 3) == 0, "rsa_rng_advance: null pointer / increment not a multiple of 4");
+  hipLaunchKernelGGL(rng_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, offset_dev, increment);
+  RSA_CHECK_LAUNCH("rsa_rng_advance");
+  return RSA_OK;
+}
 
 // arrival counter of the in-kernel loss reduction.  One word for the process: launches that request loss_out must
 // not run concurrently on different streams (same rule as rsa_mean_rows' scratch).
@@ -608,6 +620,7 @@ extern "C" int rsa_fused_sample_gather_score(const rsa_fused_args* a, rsa_stream
   p.qgrad = nullptr;
   p.loss_out = nullptr;
   p.done_counter = nullptr;
+  p.offset_dev = a->offset_dev;
   p.loss_partials = nullptr;
   p.packed_keys = a->packed_keys;
   p.n_items = a->n_items;

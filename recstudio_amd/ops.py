@@ -143,7 +143,7 @@ def fused_forward(item_table, query, num_neg, *, query_index=None, pos_ids=None,
                   sampler=nat.SAMPLER_GIVEN, cosine=False, mask_pad_pos=False,
                   table=None, pop_prob=None, guide=None, guide_log2=0, generator=None, n_queries=None,
                   out=None, want_logp=True, table_prob=None, fused_bpr=False, want_mean=True, cdf_lut=None,
-                  want_query_grad=False):
+                  want_query_grad=False, rng_state=None):
     """One launch of rsa_fused_sample_gather_score.  Returns a dict with
     neg_ids [M,n] int64, neg_score [M,n], pos_score [M] (if pos_ids), and for the
     popularity sampler neg_logp [M,n], pos_logp [M].  ``out``: a dict returned by an earlier
@@ -174,8 +174,16 @@ def fused_forward(item_table, query, num_neg, *, query_index=None, pos_ids=None,
     else:
         neg_ids = out['neg_ids'] if out is not None else torch.empty(M, n, dtype=torch.int64, device=dev)
         unroll = 4 if sampler == nat.SAMPLER_POPULAR else rng.randint_unroll(1, n_items)
-        pc = rng.reserve(M * n, unroll, dev, generator)
-        a.seed, a.offset, a.grid_threads = pc.seed, pc.offset, pc.grid_threads
+        if rng_state is not None:
+            # graph-capturable form: (seed, device int64 tensor holding the offset); the caller advances it
+            # (rsa_rng_advance) and mirrors the consumption into the torch generator afterwards
+            seed, offset_dev = rng_state
+            cu, mt = rng.device_props(dev)
+            a.seed, a.offset, a.grid_threads = int(seed) & 0xFFFFFFFFFFFFFFFF, 0, rng.grid_threads(M * n, cu, mt)
+            a.offset_dev = ptr(offset_dev)
+        else:
+            pc = rng.reserve(M * n, unroll, dev, generator)
+            a.seed, a.offset, a.grid_threads = pc.seed, pc.offset, pc.grid_threads
     reuse = out is not None        # caller-provided output buffers (same keys/shapes as returned)
     if not reuse:
         out = {'neg_score': torch.empty(M, n, dtype=torch.float32, device=dev)}
@@ -400,3 +408,8 @@ def row_topk(values, k):
     out_i = torch.empty(v2.shape[0], k, dtype=torch.int64, device=values.device)
     nat.check(nat.lib().rsa_row_topk(ptr(v2), v2.shape[0], n, int(k), ptr(out_v), ptr(out_i), _stream()), 'rsa_row_topk')
     return out_v.view(*lead, k), out_i.view(*lead, k)
+
+
+def rng_advance(offset_dev, increment):
+    """*offset_dev += increment on the stream (rsa_rng_advance): the device copy of the generator offset."""
+    nat.check(nat.lib().rsa_rng_advance(ptr(offset_dev), int(increment), _stream()), 'rsa_rng_advance')

@@ -260,3 +260,57 @@ def test_bpr_sgd_step_equals_autograd_plus_torch_sgd(ra):
     np.testing.assert_allclose(item.weight.detach().cpu(), item2.weight.detach().cpu(), rtol=1e-4, atol=1e-7)
     np.testing.assert_allclose(user.weight.detach().cpu(), user2.weight.detach().cpu(), rtol=1e-4, atol=1e-7)
     assert not item.weight[0].any() and not user.weight[0].any()
+
+
+@pytest.mark.parametrize('kind', ['uniform', 'popular'])
+def test_graphed_step_replays_draw_the_same_stream_as_eager(ra, kind):
+    """GraphedBPRStep (hipGraph replay, Philox offset on the device) == the eager single-launch step, batch after
+    batch, and leaves the torch generator where the eager run leaves it."""
+    torch.manual_seed(1)
+    N, U, d, B, n = 6001, 401, 128, 192, 64
+    item = (torch.randn(N, d, device=DEV) * 0.2)
+    item[0] = 0
+    user = torch.randn(U, d, device=DEV) * 0.2
+    sampler = ra.UniformSampler(N) if kind == 'uniform' else ra.PopularSamplerModel((torch.rand(N) ** 2 * 90).long()).to(DEV)
+    batches = [(torch.randint(1, U, (B,), device=DEV), torch.randint(1, N, (B,), device=DEV)) for _ in range(3)]
+    gen = torch.cuda.default_generators[torch.cuda.current_device()]
+    torch.manual_seed(77)
+    eager = []
+    for uid, pos in batches:
+        loss, neg = ra.fused.fused_bpr_loss(item, user, n, query_index=uid, pos_ids=pos, sampler=sampler)
+        eager.append((float(loss), neg.clone()))
+    end_offset = gen.get_offset()
+    torch.manual_seed(77)
+    g = ra.graph.GraphedBPRStep(item, user, n, B, sampler, mode='grads')
+    for (uid, pos), (want_loss, want_neg) in zip(batches, eager):
+        loss = g.step(uid, pos)
+        assert torch.equal(g.out['neg_ids'], want_neg)
+        np.testing.assert_allclose(float(loss), want_loss, rtol=1e-6)
+    g.sync_generator()
+    assert gen.get_offset() == end_offset
+    # the captured backward wrote the row-sparse item gradient of the LAST batch
+    uid, pos = batches[-1]
+    o = g.out
+    _, rows, _ = ra.ops.fused_backward(item, user, o['neg_ids'], o['dneg'], query_index=uid, pos_ids=pos,
+                                       dpos=o['dpos'], dense_item_grad=False, row_item_grad=True, want_query_grad=False)
+    assert torch.equal(o['rows'], rows)
+
+
+def test_graphed_sgd_step_equals_eager_sgd_step(ra):
+    torch.manual_seed(2)
+    N, U, d, B, n, lr = 3001, 201, 64, 128, 64, 0.05
+    item = torch.randn(N, d, device=DEV) * 0.2
+    item[0] = 0
+    user = torch.randn(U, d, device=DEV) * 0.2
+    item2, user2 = item.clone(), user.clone()
+    sampler = ra.UniformSampler(N)
+    batches = [(torch.randint(1, U, (B,), device=DEV), torch.randint(1, N, (B,), device=DEV)) for _ in range(3)]
+    torch.manual_seed(5)
+    for uid, pos in batches:
+        ra.fused.bpr_sgd_step(item2, user2, n, lr, user_ids=uid, pos_ids=pos, sampler=sampler)
+    torch.manual_seed(5)
+    g = ra.graph.GraphedBPRStep(item, user, n, B, sampler, mode='sgd', lr=lr)
+    for uid, pos in batches:
+        g.step(uid, pos)
+    np.testing.assert_allclose(item.cpu(), item2.cpu(), rtol=1e-5, atol=1e-7)      # atomics: order may differ
+    np.testing.assert_allclose(user.cpu(), user2.cpu(), rtol=1e-5, atol=1e-7)

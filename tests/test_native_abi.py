@@ -50,7 +50,7 @@ def test_abi_version_and_error_channel(nat):
 
 def test_struct_layout_matches_header(nat):
     # natural alignment on LP64: 8-byte pointers/int64, 4-byte int32
-    assert ctypes.sizeof(nat.FusedArgs) == 8 * 3 + 8 * 2 + 8 + 8 * 2 + 16 + 16 + 8 + 8 * 3 + 8 * 5 + 8 + 8 + 8 * 4 + 8 + 8 + 8
+    assert ctypes.sizeof(nat.FusedArgs) == 8 * 3 + 8 * 2 + 8 + 8 * 2 + 16 + 16 + 8 + 8 * 3 + 8 * 5 + 8 + 8 + 8 * 4 + 8 + 8 + 8 + 8
     assert nat.FusedArgs.seed.offset == 80 and nat.FusedArgs.table.offset == 104
     assert ctypes.sizeof(nat.BackwardArgs) == 8 * 18
     assert nat.BackwardArgs.query.offset == 24 and nat.BackwardArgs.item_grad.offset == 96
