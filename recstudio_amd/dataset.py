@@ -190,6 +190,45 @@ class TripletDataset:
         ratings = np.ones(n, dtype=np.float32) if ratings is None else np.asarray(ratings, dtype=np.float64)
         return cls(name, config, _interactions=(users, items, ratings, timestamps))
 
+    # ------------------------------------------------------------------ flat binary cache
+    def save_cache(self, path):
+        """The preprocessed dataset as ONE flat binary file (numpy .npz: mapped id columns, ratings, timestamps,
+        token tables, config) -- the replacement of the reference's pickled-object cache
+        (recstudio/data/dataset.py:95-100, `_save_cache`): loading it skips text parsing, filtering and id
+        mapping, and the id columns can be handed to the device loaders as they are."""
+        import json
+        arrays = {'user': self.inter_feat[self.fuid].numpy(), 'item': self.inter_feat[self.fiid].numpy(),
+                  'rating': self.inter_feat[self.frating].numpy(),
+                  'user_tokens': self.field2tokens[self.fuid].astype('U'),
+                  'item_tokens': self.field2tokens[self.fiid].astype('U'),
+                  'meta': np.frombuffer(json.dumps({'name': self.name, 'config': self.config, 'cls': type(self).__name__,
+                                                    'n_users': self._n_users, 'n_items': self._n_items}).encode(),
+                                        dtype=np.uint8)}
+        if self.ftime in self.inter_feat:
+            arrays['time'] = self.inter_feat[self.ftime].numpy()
+        np.savez(path, **arrays)
+
+    @classmethod
+    def load_cache(cls, path):
+        import json
+        z = np.load(path if str(path).endswith('.npz') else str(path) + '.npz', allow_pickle=False)
+        meta = json.loads(bytes(z['meta']).decode())
+        self = cls.__new__(cls)
+        self.name, self.config = meta['name'], meta['config']
+        self.fuid = self.config['user_id_field'].split(':')[0]
+        self.fiid = self.config['item_id_field'].split(':')[0]
+        self.frating = self.config['rating_field'].split(':')[0]
+        self.ftime = self.config['time_field'].split(':')[0] if self.config['time_field'] else None
+        self._n_users, self._n_items = meta['n_users'], meta['n_items']
+        self.field2tokens = {self.fuid: z['user_tokens'], self.fiid: z['item_tokens']}
+        self.inter_feat = {self.fuid: torch.from_numpy(z['user']), self.fiid: torch.from_numpy(z['item']),
+                           self.frating: torch.from_numpy(z['rating'])}
+        if 'time' in z.files:
+            self.inter_feat[self.ftime] = torch.from_numpy(z['time'])
+        self._use_field = {self.fuid, self.fiid, self.frating}
+        self.eval_mode = False
+        return self
+
     def _read_atomic_files(self):
         import pandas as pd
         cfg = self.config

@@ -102,3 +102,28 @@ def test_samplers_and_synthetic_stream():
     trn, val, tst = ds.build()
     assert len(trn) + sum(int(x) for x in (val.data_index[:, 2] - val.data_index[:, 1])) + \
         sum(int(x) for x in (tst.data_index[:, 2] - tst.data_index[:, 1])) == ds.num_inters
+
+
+def test_flat_cache_round_trip(golden, tmp_path):
+    """save_cache / load_cache (one flat .npz instead of the reference's pickled object): the reloaded dataset
+    builds the same splits and batches."""
+    g = golden('data_ml100k')
+    for cls, cfg, kw in ((TripletDataset, {}, dict(split_ratio=[0.8, 0.1, 0.1], shuffle=True)),
+                         (SeqDataset, {'max_seq_len': 50}, dict(split_ratio=2))):
+        ds = make(cls, g, **cfg)
+        path = tmp_path / f'{cls.__name__}.npz'
+        ds.save_cache(path)
+        ds2 = cls.load_cache(path)
+        assert type(ds2) is cls and ds2.num_users == ds.num_users and ds2.num_items == ds.num_items
+        for k in ds.inter_feat:
+            assert torch.equal(ds.inter_feat[k], ds2.inter_feat[k]) and ds.inter_feat[k].dtype == ds2.inter_feat[k].dtype
+        assert list(ds.field2tokens[ds.fiid][:5]) == list(ds2.field2tokens[ds2.fiid][:5])
+        seed_everything(2022)
+        a = ds.build(**kw)
+        seed_everything(2022)
+        b = ds2.build(**kw)
+        for x, y in zip(a, b):
+            assert torch.equal(x.data_index, y.data_index)
+        ba = next(iter(a[0].train_loader(64, shuffle=False)))
+        bb = next(iter(b[0].train_loader(64, shuffle=False)))
+        assert sorted(ba) == sorted(bb) and all(torch.equal(ba[k], bb[k]) for k in ba)
