@@ -313,38 +313,87 @@ class BaseRetriever(torch.nn.Module):
         pos_prob, neg_id, neg_prob = self.sampler(**kwargs)
         return (pos_prob, neg_id, neg_prob, query) if return_query else (pos_prob, neg_id, neg_prob)
 
+    def _pool_scores(self, query, pool):
+        """Scores of every query against its own pool of item ids [.., n0] with the gather+score kernel (ids
+        given, no [B, n0, d] tensor) -- no autograd, as in the reference's sampling() (which detaches)."""
+        if not (isinstance(self.item_encoder, torch.nn.Embedding)
+                and type(self.score_func) in (InnerProductScorer, CosineScorer, EuclideanScorer)):
+            raise NotImplementedError("this sampling_method needs an nn.Embedding item tower and a stock scorer")
+        n0 = pool.shape[-1]
+        with torch.no_grad():
+            q2 = query.reshape(-1, query.shape[-1]).contiguous()
+            s = ops.fused_forward(self.item_encoder.weight, q2, n0, neg_ids=pool.reshape(-1, n0).contiguous(),
+                                  cosine=self.score_func.cosine)['neg_score']
+        return s.view(*pool.shape)
+
     def sampling(self, batch, num_neg, method='none', excluding_hist=False, t=1, return_query=False, query=None):
-        """baseretriever.py:248-369 for ``method`` in ('none', 'dns').  'dns' (dynamic negative sampling,
-        :330-347): draw a pool of num_neg[0] negatives, score it with the gather+score kernel (no [B, n0, d]
-        tensor), keep the num_neg[1] highest-scoring ones."""
-        if method not in ('none', 'dns'):
-            raise NotImplementedError("sampling_method: only 'none' (the reference default) and 'dns' are covered")
-        assert self.sampler is not None, 'excepted sampler of retriever to be Sampler, but get None.'
+        """baseretriever.py:248-369, all six methods.  'none' is the sampler plugin; 'dns' / 'sir' (:330-355) draw a
+        pool of num_neg[0] ids, score it with the gather+score kernel and keep the num_neg[1] best (`rsa_row_topk`) /
+        resample by softmax weight; 'toprand' / 'top&rand' (:280-298) start from the full-catalog top-k (MFMA
+        kernel); 'brute' (:300-328) samples from the softmax over the whole catalog.  The random draws of the
+        non-default methods are the reference's own torch ops on the device (torch.randint / torch.multinomial),
+        so they consume the generator exactly as the reference does."""
+        if method not in ('none', 'dns', 'sir', 'toprand', 'top&rand', 'brute'):
+            raise NotImplementedError('sampling method only support one of none/brute/sir/dns/toprand/top&rand')
         if isinstance(num_neg, int):
             num_neg = [num_neg, num_neg]
+        elif not isinstance(num_neg, (list, tuple)):
+            raise TypeError('num_neg only support int and List/Tuple type.')
         assert len(num_neg) == 2 and num_neg[0] >= num_neg[1], 'negative_count must be [pool, kept] with pool >= kept'
+        fiid_val = batch.get(self.fiid)
+        user_hist = batch.get('user_hist', fiid_val)
+        if user_hist is not None and user_hist.dim() == 1:
+            user_hist = user_hist.view(-1, 1)          # the positives play the history's role (:259-261)
         if method == 'none':
+            assert self.sampler is not None, 'excepted sampler of retriever to be Sampler, but get None.'
             log_pos_prob, neg_id, log_neg_prob, query = self._sample(batch, num_neg[1], excluding_hist, True)
-        else:
-            log_pos_prob, pool, _, query = self._sample(batch, num_neg[0], excluding_hist, True)
-            if not (isinstance(self.item_encoder, torch.nn.Embedding)
-                    and type(self.score_func) in (InnerProductScorer, CosineScorer, EuclideanScorer)):
-                raise NotImplementedError("'dns' needs an nn.Embedding item tower and a stock scorer")
-            lead = pool.shape[:-1]
-            with torch.no_grad():
-                q2 = query.reshape(-1, query.shape[-1])
-                scores = ops.fused_forward(self.item_encoder.weight, q2, num_neg[0],
-                                           neg_ids=pool.reshape(-1, num_neg[0]).contiguous(),
-                                           cosine=self.score_func.cosine)['neg_score']
+        elif method in ('dns', 'sir'):
+            assert self.sampler is not None, 'excepted sampler of retriever to be Sampler, but get None.'
+            _, pool, _, query = self._sample(batch, num_neg[0], excluding_hist, True)
+            scores = self._pool_scores(query, pool)
+            if method == 'dns':
                 _, cols = ops.row_topk(scores, num_neg[1])
-                neg_id = torch.gather(pool.reshape(-1, num_neg[0]), -1, cols).view(*lead, num_neg[1])
+                neg_id = torch.gather(pool, -1, cols)
+                log_neg_prob = torch.zeros_like(neg_id)
+                log_pos_prob = torch.zeros_like(fiid_val)
+            else:
+                with torch.no_grad():
+                    log_pos_prob = self.score_func(query, self.item_encoder(self._get_item_feat(batch)))      # :349-351
+                    probs = torch.softmax(scores + torch.finfo(torch.float32).eps, dim=-1)
+                    resampled = torch.multinomial(probs.reshape(-1, probs.shape[-1]), num_neg[1],
+                                                  replacement=True).view(*probs.shape[:-1], num_neg[1])
+                neg_id = torch.gather(pool, -1, resampled)
+                log_neg_prob = torch.gather(scores, -1, resampled)
+        elif method == 'toprand':
+            _, topk_items, query = self.topk(batch, k=num_neg[0], user_h=user_hist, return_query=True)
+            rand_idx = torch.randint(0, num_neg[0], (topk_items.size(0), num_neg[1]), device=topk_items.device)
+            neg_id = torch.gather(topk_items, -1, rand_idx)
             log_neg_prob = torch.zeros_like(neg_id)
-            log_pos_prob = torch.zeros_like(batch.get(self.fiid))
-        log_pos_prob = log_pos_prob.view_as(batch.get(self.fiid))
+            log_pos_prob = torch.zeros_like(fiid_val)
+        elif method == 'top&rand':
+            k0 = num_neg[1] // 2
+            _, neg_id, query = self.topk(batch, k=k0, user_h=user_hist, return_query=True)
+            n_q = int(np.prod(query.shape[:-1]))
+            rand_ids = torch.randint(1, self.item_vector.size(0) + 1, size=(n_q, num_neg[1] - k0), device=query.device)
+            neg_id = torch.cat((neg_id, rand_ids), dim=-1)
+            log_neg_prob = torch.zeros_like(neg_id)
+            log_pos_prob = torch.zeros_like(fiid_val)
+        else:                                                        # 'brute': softmax over the whole catalog
+            query = self.query_encoder(self._get_query_feat(batch)) if query is None else query
+            pos2 = fiid_val.view(-1, 1) if fiid_val.dim() == 1 else fiid_val
+            with torch.no_grad():
+                all_score = self.score_func(query, self.item_vector) / t
+                all_prob = torch.nn.functional.pad(torch.softmax(all_score, dim=-1), pad=(1, 0))
+                log_pos_prob = torch.log(torch.gather(all_prob, dim=-1, index=pos2))
+                sampling_prob = all_prob
+                if excluding_hist:
+                    sampling_prob = all_prob.scatter(-1, user_hist, 0.0)        # utils.mask_with_hist(dist, hist, 0)
+                neg_id = torch.multinomial(sampling_prob, num_neg[1] * pos2.size(-1), replacement=True)
+                log_neg_prob = torch.log(torch.gather(sampling_prob, dim=-1, index=neg_id))
+        log_pos_prob = log_pos_prob.view_as(fiid_val)
         result = (log_pos_prob.detach(), neg_id, log_neg_prob.detach())
         return (result, query) if return_query else (result, None)
 
-    # ------------------------------------------------------------------ retrieval
     def topk(self, batch, k, user_h=None, return_query=False):
         """baseretriever.py:374-397: full-catalog scores -> top (k + |hist|) -> drop history -> top k."""
         query = self.query_encoder(self._get_query_feat(batch))

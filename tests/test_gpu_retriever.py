@@ -314,3 +314,70 @@ def test_graphed_sgd_step_equals_eager_sgd_step(ra):
         g.step(uid, pos)
     np.testing.assert_allclose(item.cpu(), item2.cpu(), rtol=1e-5, atol=1e-7)      # atomics: order may differ
     np.testing.assert_allclose(user.cpu(), user2.cpu(), rtol=1e-5, atol=1e-7)
+
+
+def _sampling_model(ra, N, U, d, n0, n1, method):
+    m = ra.BaseRetriever({'model': {'embed_dim': d}, 'train': {'negative_count': [n0, n1], 'sampling_method': method}},
+                         item_encoder=torch.nn.Embedding(N, d, padding_idx=0),
+                         query_encoder=torch.nn.Embedding(U, d, padding_idx=0), sampler=ra.UniformSampler(N),
+                         loss=ra.BPRLoss())
+    m.fiid, m.fuid, m.frating = 'item_id', 'user_id', 'rating'
+    m.item_fields, m.query_fields, m.neg_count = {'item_id'}, {'user_id'}, [n0, n1]
+    m._init_parameter()
+    m.to(DEV)
+    with torch.no_grad():
+        m.item_encoder.weight.mul_(30)          # spread the scores so that softmax / top-k are not degenerate
+        m.item_encoder.weight[0] = 0
+    m._update_item_vector()
+    return m
+
+
+@pytest.mark.parametrize('method', ['sir', 'toprand', 'top&rand', 'brute'])
+def test_other_sampling_methods_follow_the_reference_op_sequence(ra, method):
+    """baseretriever.py:280-355 restated with stock torch ops on this device (F.embedding, matmul, topk,
+    softmax, multinomial, randint) under the same seed == BaseRetriever.sampling(method=...)."""
+    N, U, d, B, n0, n1 = 3001, 100, 64, 50, 24, 6
+    m = _sampling_model(ra, N, U, d, n0, n1, method)
+    uid = torch.randint(1, U, (B,), device=DEV)
+    pos = torch.randint(1, N, (B,), device=DEV)
+    batch = {'user_id': uid, 'item_id': pos, 'rating': torch.ones(B, device=DEV)}
+    torch.manual_seed(21)
+    (lpp, neg, lnp), query = m.sampling(batch, [n0, n1], method=method, return_query=True)
+    W = m.item_encoder.weight.detach()
+    q = m.query_encoder(uid).detach()
+    torch.manual_seed(21)
+    if method == 'sir':
+        pool = torch.randint(1, N, (B, n0), device=DEV)
+        s = torch.matmul(W[pool], q.unsqueeze(-1)).squeeze(-1)
+        probs = torch.softmax(s + torch.finfo(torch.float32).eps, -1)
+        # the kernel's scores differ from matmul's in the last bits; feed multinomial the kernel's probabilities
+        kernel_probs = torch.softmax(m._pool_scores(q, pool) + torch.finfo(torch.float32).eps, -1)
+        np.testing.assert_allclose(kernel_probs.cpu(), probs.cpu(), rtol=2e-4, atol=1e-7)
+        res = torch.multinomial(kernel_probs, n1, replacement=True)
+        assert torch.equal(neg, torch.gather(pool, -1, res))
+        np.testing.assert_allclose(lnp.cpu(), torch.gather(s, -1, res).cpu(), rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(lpp.cpu(), (q * W[pos]).sum(-1).cpu(), rtol=1e-4, atol=1e-5)
+    elif method in ('toprand', 'top&rand'):
+        k = n0 if method == 'toprand' else n1 // 2
+        full = q @ W[1:].T
+        sc, it = torch.topk(full, k + 1)
+        it = it + 1
+        keep = it != pos.view(-1, 1)                       # the positive plays the history's role
+        top = torch.stack([row[kp][:k] for row, kp in zip(it, keep)])
+        if method == 'toprand':
+            idx = torch.randint(0, n0, (B, n1), device=DEV)
+            assert torch.equal(neg, torch.gather(top, -1, idx))
+        else:
+            rnd = torch.randint(1, N, size=(B, n1 - k), device=DEV)
+            assert torch.equal(neg, torch.cat((top, rnd), -1))
+        assert not lnp.any() and not lpp.any()
+    else:
+        all_prob = torch.nn.functional.pad(torch.softmax(m.score_func(q, m.item_vector), -1), (1, 0))
+        want = torch.multinomial(all_prob, n1, replacement=True)
+        assert torch.equal(neg, want)
+        np.testing.assert_allclose(lnp.cpu(), torch.log(torch.gather(all_prob, -1, want)).cpu(), rtol=1e-5)
+        np.testing.assert_allclose(lpp.cpu(), torch.log(torch.gather(all_prob, -1, pos.view(-1, 1))).view(-1).cpu(), rtol=1e-5)
+    # and the training step runs through it
+    loss = m.training_step(batch)
+    loss.backward()
+    assert torch.isfinite(loss)
