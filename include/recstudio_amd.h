@@ -40,7 +40,9 @@ enum rsa_status {
 
 enum rsa_score_mode { RSA_SCORE_IP = 0, RSA_SCORE_COS = 1, RSA_SCORE_EUC = 2 /* EuclideanScorer, scorer.py:28-34 */ };
 enum rsa_sampler_kind { RSA_SAMPLER_GIVEN = 0, RSA_SAMPLER_UNIFORM = 1, RSA_SAMPLER_POPULAR = 2 };
-enum rsa_loss_kind { RSA_LOSS_BPR = 0, RSA_LOSS_SSM = 1, RSA_LOSS_BCE = 2 };
+enum rsa_loss_kind { RSA_LOSS_BPR = 0, RSA_LOSS_SSM = 1, RSA_LOSS_BCE = 2,
+                     /* rsa_pairwise_loss_ex: */ RSA_LOSS_WBPR = 3, RSA_LOSS_WBCE = 4, RSA_LOSS_HINGE = 5, RSA_LOSS_NCE = 6,
+                     RSA_LOSS_CCL = 7 };
 
 const char* rsa_last_error(void);
 int rsa_abi_version(void);
@@ -184,6 +186,18 @@ int rsa_rng_advance(uint64_t* offset_dev, uint64_t increment, rsa_stream_t strea
 int rsa_pairwise_loss(int32_t loss_kind, const float* pos_score, const float* neg_score,
                       const float* pos_logp, const float* neg_logp, int64_t n_rows, int32_t num_neg,
                       float* row_loss, float* loss_out, float* dpos, float* dneg, rsa_stream_t stream);
+
+/* The other PairwiseLoss classes of recstudio/model/loss_func.py, value + d loss/d score in one pass like
+ * rsa_pairwise_loss:  RSA_LOSS_WBPR WeightedBPRLoss (:93-97; the softmax(neg - logQ) weights are differentiated
+ * through, as in the reference), RSA_LOSS_WBCE WeightedBinaryCrossEntropyLoss (:135-137 on :105-127, padded -inf
+ * positives dropped), RSA_LOSS_HINGE HingeLoss (:140-154, num_items=None; param0 = margin), RSA_LOSS_NCE NCELoss
+ * (:163-168), RSA_LOSS_CCL CCLLoss (:171-186; param0 = margin, param1 = neg_weight).  InfoNCELoss (:157-160) is
+ * rsa_pairwise_loss(RSA_LOSS_SSM) with null log-probabilities.  Top1Loss (:66-78) is not offered: the reference's
+ * forward modifies a sigmoid output in place and cannot be back-propagated. */
+int rsa_pairwise_loss_ex(int32_t loss_kind, const float* pos_score, const float* neg_score,
+                         const float* pos_logp, const float* neg_logp, int64_t n_rows, int32_t num_neg,
+                         float param0, float param1, float* row_loss, float* loss_out, float* dpos, float* dneg,
+                         rsa_stream_t stream);
 
 /* SampledSoftmaxLoss.forward when pos_score [B, L] and neg_score [B, n] have the SAME rank
  * (recstudio/model/loss_func.py:84-89): the L positives of a row share its n negatives; padded

@@ -134,6 +134,21 @@ def gen_loss(loss_func):
     run('bce_2d_pad', loss_func.BinaryCrossEntropyLoss(), pos_score=pos4, log_pos_prob=lpp2, neg_score=neg2, log_neg_prob=lnp2)
     alls = torch.randn(B, 50, generator=g)
     run('softmax_full', loss_func.SoftmaxLoss(), pos_score=pos, all_score=alls)
+    # the other PairwiseLoss classes of loss_func.py (:93-97, :135-193).  Top1Loss (:66-78) is left out: its forward
+    # modifies a sigmoid output in place, so the reference itself cannot back-propagate through it.
+    for tag, (p_, lp_, n_, ln_) in (('1d', (pos, lpp, neg, lnp)), ('2d', (pos2, lpp2, neg2, lnp2))):
+        run(f'wbpr_{tag}', loss_func.WeightedBPRLoss(), pos_score=p_, log_pos_prob=lp_, neg_score=n_, log_neg_prob=ln_)
+        run(f'wbce_{tag}', loss_func.WeightedBinaryCrossEntropyLoss(), pos_score=p_, log_pos_prob=lp_, neg_score=n_,
+            log_neg_prob=ln_)
+        run(f'hinge_{tag}', loss_func.HingeLoss(margin=2), pos_score=p_, log_pos_prob=lp_, neg_score=n_, log_neg_prob=ln_)
+        run(f'infonce_{tag}', loss_func.InfoNCELoss(), pos_score=p_, log_pos_prob=lp_, neg_score=n_, log_neg_prob=ln_)
+        run(f'ccl_{tag}', loss_func.CCLLoss(margin=0.6, neg_weight=0.3), pos_score=p_, log_pos_prob=lp_, neg_score=n_,
+            log_neg_prob=ln_)
+    run('nce_1d', loss_func.NCELoss(), pos_score=pos, log_pos_prob=lpp, neg_score=neg, log_neg_prob=lnp)
+    run('wbce_2d_pad', loss_func.WeightedBinaryCrossEntropyLoss(), pos_score=pos4, log_pos_prob=lpp2, neg_score=neg2,
+        log_neg_prob=lnp2)
+    run('wbpr_big', loss_func.WeightedBPRLoss(), pos_score=pos * 30, log_pos_prob=lpp, neg_score=neg * 30, log_neg_prob=lnp)
+    run('hinge_inactive', loss_func.HingeLoss(margin=0.5), pos_score=pos + 5, log_pos_prob=lpp, neg_score=neg, log_neg_prob=lnp)
     np.savez_compressed(os.path.join(OUT, 'loss.npz'), **out)
 
 

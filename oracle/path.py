@@ -201,6 +201,58 @@ def bce_loss(pos_score, neg_score):
     return -pos_loss + neg_loss
 
 
+def _neg_weights(neg_score, log_neg_prob):
+    """softmax over the negatives of (score - log q): the importance weights of the "Weighted" losses
+    (recstudio/model/loss_func.py:96, :136-137).  Part of the autograd graph, as in the reference."""
+    return torch.softmax(neg_score - log_neg_prob, dim=-1)
+
+
+def weighted_bpr_loss(pos_score, neg_score, log_neg_prob):
+    """recstudio/model/loss_func.py:93-97."""
+    ls = torch.nn.functional.logsigmoid(pos_score.unsqueeze(-1) - neg_score)
+    return -(ls * _neg_weights(neg_score, log_neg_prob)).sum(-1).mean()
+
+
+def weighted_bce_loss(pos_score, neg_score, log_neg_prob):
+    """recstudio/model/loss_func.py:135-137 on top of :105-127 (dns=False)."""
+    pad = torch.isinf(pos_score)
+    n_valid = (~pad).sum()
+    pos_term = torch.nn.functional.logsigmoid(pos_score).masked_fill(pad, 0.0).sum() / n_valid
+    neg_rows = (torch.nn.functional.softplus(neg_score) * _neg_weights(neg_score, log_neg_prob)).sum(-1)
+    if pos_score.dim() == neg_score.dim() - 1:
+        neg_term = neg_rows.masked_fill(pad, 0.0).sum() / n_valid
+    else:
+        neg_term = neg_rows.mean()
+    return neg_term - pos_term
+
+
+def hinge_loss(pos_score, neg_score, margin=2.0):
+    """recstudio/model/loss_func.py:140-154 with num_items=None (the num_items branch takes the mean of a bool
+    tensor, which torch rejects)."""
+    hardest = neg_score.max(dim=-1).values
+    return torch.clamp(hardest - pos_score + margin, min=0).mean()
+
+
+def info_nce_loss(pos_score, neg_score):
+    """recstudio/model/loss_func.py:157-160: sampled softmax with the proposal log-probabilities zeroed."""
+    return sampled_softmax_loss(pos_score, torch.zeros_like(pos_score), neg_score, torch.zeros_like(neg_score))
+
+
+def nce_loss(pos_score, log_pos_prob, neg_score, log_neg_prob):
+    """recstudio/model/loss_func.py:163-168 (x - softplus(x) written as logsigmoid(x) -- the same function)."""
+    zp, zn = pos_score - log_pos_prob, neg_score - log_neg_prob
+    per_row = torch.nn.functional.logsigmoid(zp) + (zn - torch.nn.functional.softplus(zn)).sum(1)
+    return -per_row.mean()
+
+
+def ccl_loss(pos_score, neg_score, margin=0.8, neg_weight=0.3):
+    """recstudio/model/loss_func.py:171-186."""
+    p, q = torch.sigmoid(pos_score), torch.sigmoid(neg_score)
+    pushed = torch.relu(q - margin).mean(dim=-1)
+    n_valid = torch.logical_not(torch.isinf(p)).float().sum()
+    return torch.nan_to_num((1 - p) + neg_weight * pushed, posinf=0.0).sum() / n_valid
+
+
 def softmax_loss(pos_score, all_score):
     """recstudio/model/loss_func.py:39-47."""
     if all_score.dim() > pos_score.dim():

@@ -10,7 +10,8 @@ from . import _native, ops, rng                                  # noqa: F401
 from .sampler import Sampler, UniformSampler, MaskedUniformSampler, PopularSamplerModel    # noqa: F401
 from .scorer import InnerProductScorer, CosineScorer, EuclideanScorer   # noqa: F401
 from .loss_func import (FullScoreLoss, PairwiseLoss, PointwiseLoss, BPRLoss,   # noqa: F401
-                        SampledSoftmaxLoss, SoftmaxLoss, BinaryCrossEntropyLoss)
+                        SampledSoftmaxLoss, SoftmaxLoss, BinaryCrossEntropyLoss, WeightedBPRLoss,
+                        WeightedBinaryCrossEntropyLoss, HingeLoss, NCELoss, CCLLoss, InfoNCELoss)
 from .fused import retriever_scores                               # noqa: F401
 from .dataset import TripletDataset, SeqDataset, DataSampler, SortedDataSampler   # noqa: F401
 from .retriever import (BaseRetriever, TwoTowerRecommender, ItemTowerRecommender, BPR, SASRec,   # noqa: F401

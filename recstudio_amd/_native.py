@@ -17,6 +17,7 @@ RSA_OK = 0
 SCORE_IP, SCORE_COS, SCORE_EUC = 0, 1, 2
 SAMPLER_GIVEN, SAMPLER_UNIFORM, SAMPLER_POPULAR = 0, 1, 2
 LOSS_BPR, LOSS_SSM, LOSS_BCE = 0, 1, 2
+LOSS_WBPR, LOSS_WBCE, LOSS_HINGE, LOSS_NCE, LOSS_CCL = 3, 4, 5, 6, 7
 
 
 class NativeError(RuntimeError):
@@ -69,6 +70,8 @@ SIGNATURES = {
     'rsa_fused_sample_gather_score': (c_int, [POINTER(FusedArgs), c_void_p]),
     'rsa_pairwise_loss': (c_int, [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p,
                                   c_void_p, c_void_p, c_void_p, c_void_p]),
+    'rsa_pairwise_loss_ex': (c_int, [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_float, c_float,
+                                     c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'rsa_ssm_shared_loss': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p,
                                     c_void_p, c_void_p, c_void_p, c_void_p]),
     'rsa_mean_rows': (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),

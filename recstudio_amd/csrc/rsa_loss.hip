@@ -156,6 +156,131 @@ __global__ __launch_bounds__(256) void bce_loss_kernel(const float* __restrict__
   }
 }
 
+// The other PairwiseLoss classes of recstudio/model/loss_func.py on the same [M, n] tile, value + gradient:
+//   RSA_LOSS_WBPR  WeightedBPRLoss :93-97                 w = softmax(neg - logQ) is part of the graph
+//   RSA_LOSS_WBCE  WeightedBinaryCrossEntropyLoss :135-137 (on :105-127, dns=False)
+//   RSA_LOSS_HINGE HingeLoss :140-154 (num_items=None)     p0 = margin
+//   RSA_LOSS_NCE   NCELoss :163-168
+//   RSA_LOSS_CCL   CCLLoss :171-186                        p0 = margin, p1 = neg_weight
+// RL lanes per row as above; the weighted losses need the row's softmax statistics first (max, sum of
+// exponentials, weighted sums), hence up to three sweeps over the row's n scores (they stay in L1/L2).
+template <int RL>
+__global__ __launch_bounds__(256) void pairwise_loss_ex_kernel(int kind, const float* __restrict__ pos,
+                                                               const float* __restrict__ neg,
+                                                               const float* __restrict__ pos_lp,
+                                                               const float* __restrict__ neg_lp, int64_t M, int n,
+                                                               float p0, float p1, const int32_t* __restrict__ count,
+                                                               float* __restrict__ row_loss, float* __restrict__ dpos,
+                                                               float* __restrict__ dneg) {
+  const int sub = threadIdx.x % RL;
+  const int64_t g0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / RL;
+  const int64_t gstride = ((int64_t)gridDim.x * blockDim.x) / RL;
+  const float inv = kind == RSA_LOSS_WBCE ? 1.f / (float)count[0] : 1.f / (float)M;
+  const int64_t m_end = ((M + gstride - 1) / gstride) * gstride;
+  for (int64_t m = g0; m < m_end; m += gstride) {
+    const bool rv = m < M;
+    const float* nrow = neg + (rv ? m : 0) * (int64_t)n;
+    const float* lrow = neg_lp ? neg_lp + (rv ? m : 0) * (int64_t)n : nullptr;
+    float* drow = dneg ? dneg + (rv ? m : 0) * (int64_t)n : nullptr;
+    const float ps = rv ? pos[m] : 0.f;
+    float rl = 0.f, dp = 0.f;
+    if (kind == RSA_LOSS_WBPR || kind == RSA_LOSS_WBCE) {
+      const bool valid = kind == RSA_LOSS_WBPR || !isinf(ps);       // BCE: padded (-inf) positives drop out
+      float mx = -INFINITY;
+      if (rv)
+        for (int j = sub; j < n; j += RL) mx = fmaxf(mx, nrow[j] - (lrow ? lrow[j] : 0.f));
+#pragma unroll
+      for (int k = RL / 2; k >= 1; k >>= 1) mx = fmaxf(mx, __shfl_xor(mx, k, 64));
+      float se = 0.f, a = 0.f, gsum = 0.f;     // sum e, sum e * f_j, sum e * f'_j  (e = exp(z - mx))
+      if (rv)
+        for (int j = sub; j < n; j += RL) {
+          const float e = expf(nrow[j] - (lrow ? lrow[j] : 0.f) - mx);
+          se += e;
+          if (kind == RSA_LOSS_WBPR) {
+            a += e * log_sigmoid(ps - nrow[j]);
+            gsum += e * sigmoid_neg(ps - nrow[j]);
+          } else {
+            a += e * softplus_f(nrow[j]);
+          }
+        }
+      se = group_sum<RL>(se);
+      a = group_sum<RL>(a);
+      gsum = group_sum<RL>(gsum);
+      const float bar = a / se;                 // sum_j w_j f_j
+      if (kind == RSA_LOSS_WBPR) {
+        rl = -bar;
+        dp = -(gsum / se) * inv;
+      } else {
+        rl = valid ? bar - log_sigmoid(ps) : 0.f;
+        dp = valid ? -sigmoid_neg(ps) * inv : 0.f;
+      }
+      if (rv && drow)
+        for (int j = sub; j < n; j += RL) {
+          const float w = expf(nrow[j] - (lrow ? lrow[j] : 0.f) - mx) / se;
+          float g;
+          if (kind == RSA_LOSS_WBPR)           // -(w f' + f dw): f = logsigmoid(pos - neg), df/dneg = -sigmoid(neg - pos)
+            g = w * sigmoid_neg(ps - nrow[j]) - w * (log_sigmoid(ps - nrow[j]) - bar);
+          else                                 // w f' + f dw:   f = softplus(neg), f' = sigmoid(neg)
+            g = w * (1.f / (1.f + expf(-nrow[j]))) + w * (softplus_f(nrow[j]) - bar);
+          drow[j] = valid ? g * inv : 0.f;
+        }
+    } else if (kind == RSA_LOSS_HINGE) {
+      float mx = -INFINITY;
+      int arg = 0x7fffffff;
+      if (rv)
+        for (int j = sub; j < n; j += RL)
+          if (nrow[j] > mx) {
+            mx = nrow[j];
+            arg = j;
+          }
+#pragma unroll
+      for (int k = RL / 2; k >= 1; k >>= 1) {            // (max, smallest index among equals)
+        const float om = __shfl_xor(mx, k, 64);
+        const int oa = __shfl_xor(arg, k, 64);
+        if (om > mx || (om == mx && oa < arg)) {
+          mx = om;
+          arg = oa;
+        }
+      }
+      const bool active = mx - ps + p0 > 0.f;
+      rl = active ? mx - ps + p0 : 0.f;
+      dp = active ? -inv : 0.f;
+      if (rv && drow)
+        for (int j = sub; j < n; j += RL) drow[j] = (active && j == arg) ? inv : 0.f;
+    } else if (kind == RSA_LOSS_NCE) {
+      const float zp = ps - ((rv && pos_lp) ? pos_lp[m] : 0.f);
+      float acc = 0.f;
+      if (rv)
+        for (int j = sub; j < n; j += RL) {
+          const float z = nrow[j] - (lrow ? lrow[j] : 0.f);
+          acc += z - softplus_f(z);
+          if (drow) drow[j] = -(z > 20.f ? 0.f : sigmoid_neg(z)) * inv;     // d/dz (z - softplus(z)), threshold 20
+        }
+      acc = group_sum<RL>(acc);
+      rl = -(log_sigmoid(zp) + acc);
+      dp = -sigmoid_neg(zp) * inv;
+    } else {                                                               // RSA_LOSS_CCL
+      const float pp = 1.f / (1.f + expf(-ps));
+      const float wn = p1 / (float)n;
+      float acc = 0.f;
+      if (rv)
+        for (int j = sub; j < n; j += RL) {
+          const float q = 1.f / (1.f + expf(-nrow[j]));
+          const bool on = q - p0 > 0.f;
+          acc += on ? q - p0 : 0.f;
+          if (drow) drow[j] = on ? wn * q * (1.f - q) * inv : 0.f;
+        }
+      acc = group_sum<RL>(acc);
+      rl = (1.f - pp) + wn * acc;
+      dp = -pp * (1.f - pp) * inv;
+    }
+    if (rv && sub == 0) {
+      row_loss[m] = rl;
+      if (dpos) dpos[m] = dp;
+    }
+  }
+}
+
 // SampledSoftmaxLoss with SEVERAL positives per row sharing one negative set -- loss_func.py:84-89 when
 // pos_score [B, L] and neg_score [B, n] have the same rank: z = cat(pos - logQ_pos, neg - logQ_neg),
 // out_l = logsumexp(z) - z_pos_l, padded positives (+-inf) contribute 0 and are not counted, row = sum / count.
@@ -323,6 +448,48 @@ extern "C" int rsa_pairwise_loss(int32_t loss_kind, const float* pos_score, cons
 #undef RSA_LAUNCH_LOSS
   RSA_CHECK_LAUNCH("rsa_pairwise_loss");
   return rsa_mean_rows(row_loss, n_rows, loss_out, stream);
+}
+
+extern "C" int rsa_pairwise_loss_ex(int32_t loss_kind, const float* pos_score, const float* neg_score,
+                                    const float* pos_logp, const float* neg_logp, int64_t n_rows, int32_t num_neg,
+                                    float param0, float param1, float* row_loss, float* loss_out, float* dpos,
+                                    float* dneg, rsa_stream_t stream) {
+  RSA_CHECK_ARG(loss_kind >= RSA_LOSS_WBPR && loss_kind <= RSA_LOSS_CCL, "rsa_pairwise_loss_ex: unknown loss %d",
+                loss_kind);
+  RSA_CHECK_ARG(n_rows >= 1 && num_neg >= 1, "rsa_pairwise_loss_ex: need n_rows >= 1 and num_neg >= 1");
+  RSA_CHECK_ARG(pos_score && neg_score && row_loss && loss_out, "rsa_pairwise_loss_ex: null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  const int rl = num_neg <= 2 ? 1 : num_neg <= 8 ? 4 : num_neg <= 32 ? 16 : 64;
+  int64_t blocks = (n_rows * rl + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  dim3 grid((unsigned)blocks), block(256);
+  const int32_t* count = nullptr;
+  if (loss_kind == RSA_LOSS_WBCE) {
+    if (g_count == nullptr && hipMalloc(&g_count, 256) != hipSuccess) {
+      rsa::set_error("rsa_pairwise_loss_ex: could not allocate the counter scratch");
+      return RSA_ERR_HIP;
+    }
+    if (hipMemsetAsync(g_count, 0, sizeof(int32_t), s) != hipSuccess) {
+      rsa::set_error("rsa_pairwise_loss_ex: memset failed");
+      return RSA_ERR_HIP;
+    }
+    int64_t cb = (n_rows + 255) / 256;
+    if (cb > 1024) cb = 1024;
+    hipLaunchKernelGGL(count_valid_kernel, dim3((unsigned)cb), dim3(256), 0, s, pos_score, n_rows, g_count);
+    count = g_count;
+  }
+#define RSA_LAUNCH_EX(RL)                                                                                         \
+  hipLaunchKernelGGL(pairwise_loss_ex_kernel<RL>, grid, block, 0, s, (int)loss_kind, pos_score, neg_score, pos_logp, \
+                     neg_logp, n_rows, (int)num_neg, param0, param1, count, row_loss, dpos, dneg)
+  switch (rl) {
+    case 1: RSA_LAUNCH_EX(1); break;
+    case 4: RSA_LAUNCH_EX(4); break;
+    case 16: RSA_LAUNCH_EX(16); break;
+    default: RSA_LAUNCH_EX(64); break;
+  }
+#undef RSA_LAUNCH_EX
+  RSA_CHECK_LAUNCH("rsa_pairwise_loss_ex");
+  return mean_rows_impl(row_loss, n_rows, count, loss_out, stream);
 }
 
 extern "C" int rsa_ssm_shared_loss(const float* pos_score, const float* pos_logp, const float* neg_score,

@@ -88,6 +88,74 @@ class BinaryCrossEntropyLoss(PairwiseLoss):
         return _PairwiseFn.apply(nat.LOSS_BCE, pos_score, neg_score, None, None)
 
 
+class _PairwiseExFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, kind, pos_score, neg_score, pos_logp, neg_logp, p0, p1):
+        loss, dpos, dneg = ops.pairwise_loss_ex(kind, pos_score, neg_score, pos_logp, neg_logp, p0, p1)
+        ctx.save_for_backward(dpos, dneg)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        dpos, dneg = ctx.saved_tensors
+        return None, dpos * g, dneg * g, None, None, None, None
+
+
+class WeightedBPRLoss(PairwiseLoss):
+    """recstudio/model/loss_func.py:93-97: BPR with importance weights softmax(neg_score - log_neg_prob)."""
+
+    def forward(self, label, pos_score, log_pos_prob, neg_score, log_neg_prob):
+        _check_shapes(pos_score, neg_score)
+        return _PairwiseExFn.apply(nat.LOSS_WBPR, pos_score, neg_score, None, _as_f32_or_none(log_neg_prob), 0.0, 0.0)
+
+
+class WeightedBinaryCrossEntropyLoss(BinaryCrossEntropyLoss):
+    """recstudio/model/loss_func.py:135-137."""
+
+    def forward(self, label, pos_score, log_pos_prob, neg_score, log_neg_prob):
+        _check_shapes(pos_score, neg_score)
+        return _PairwiseExFn.apply(nat.LOSS_WBCE, pos_score, neg_score, None, _as_f32_or_none(log_neg_prob), 0.0, 0.0)
+
+
+class HingeLoss(PairwiseLoss):
+    """recstudio/model/loss_func.py:140-154 with num_items=None (the num_items branch of the reference takes the mean
+    of a bool tensor, which torch rejects)."""
+
+    def __init__(self, margin=2, num_items=None):
+        super().__init__()
+        if num_items is not None:
+            raise NotImplementedError('HingeLoss(num_items=...) does not run in the reference either (mean of a bool tensor)')
+        self.margin, self.n_items = margin, num_items
+
+    def forward(self, label, pos_score, log_pos_prob, neg_score, log_neg_prob):
+        _check_shapes(pos_score, neg_score)
+        return _PairwiseExFn.apply(nat.LOSS_HINGE, pos_score, neg_score, None, None, float(self.margin), 0.0)
+
+
+class NCELoss(PairwiseLoss):
+    """recstudio/model/loss_func.py:163-168 (pos_score [B], neg_score [B, n])."""
+
+    def forward(self, label, pos_score, log_pos_prob, neg_score, log_neg_prob):
+        if pos_score.dim() != 1 or neg_score.dim() != 2:
+            raise NotImplementedError('NCELoss: the reference sums the negatives over dim 1, i.e. expects [B] and [B, n]')
+        _check_shapes(pos_score, neg_score)
+        return _PairwiseExFn.apply(nat.LOSS_NCE, pos_score, neg_score, _as_f32_or_none(log_pos_prob),
+                                   _as_f32_or_none(log_neg_prob), 0.0, 0.0)
+
+
+class CCLLoss(PairwiseLoss):
+    """recstudio/model/loss_func.py:171-186."""
+
+    def __init__(self, margin=0.8, neg_weight=0.3):
+        super().__init__()
+        self.margin, self.neg_weight = margin, neg_weight
+
+    def forward(self, label, pos_score, log_pos_prob, neg_score, log_neg_prob):
+        _check_shapes(pos_score, neg_score)
+        return _PairwiseExFn.apply(nat.LOSS_CCL, pos_score, neg_score, None, None, float(self.margin),
+                                   float(self.neg_weight))
+
+
 class _SharedSSMFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, pos_score, neg_score, pos_logp, neg_logp):
@@ -111,6 +179,13 @@ class SampledSoftmaxLoss(PairwiseLoss):
         _check_shapes(pos_score, neg_score)
         return _PairwiseFn.apply(nat.LOSS_SSM, pos_score, neg_score, _as_f32_or_none(log_pos_prob),
                                  _as_f32_or_none(log_neg_prob))
+
+
+class InfoNCELoss(SampledSoftmaxLoss):
+    """recstudio/model/loss_func.py:157-160: sampled softmax with the proposal log-probabilities zeroed."""
+
+    def forward(self, label, pos_score, log_pos_prob, neg_score, log_neg_prob):
+        return super().forward(label, pos_score, None, neg_score, None)
 
 
 class _MeanLseFn(torch.autograd.Function):

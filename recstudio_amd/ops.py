@@ -267,6 +267,26 @@ def pairwise_loss(kind, pos_score, neg_score, pos_logp=None, neg_logp=None, want
     return loss, dpos, dneg, row
 
 
+def pairwise_loss_ex(kind, pos_score, neg_score, pos_logp=None, neg_logp=None, param0=0.0, param1=0.0):
+    """rsa_pairwise_loss_ex (WeightedBPR / WeightedBCE / Hinge / NCE / CCL): (loss, dpos, dneg)."""
+    pos_score = _need(pos_score, torch.float32, 'pos_score')
+    neg_score = _need(neg_score, torch.float32, 'neg_score')
+    M = pos_score.numel()
+    n = neg_score.numel() // max(M, 1)
+    if neg_score.numel() != M * n or M == 0 or n == 0:
+        raise ValueError(f'pairwise_loss_ex: pos {tuple(pos_score.shape)} vs neg {tuple(neg_score.shape)}')
+    pos_logp = _need_opt(pos_logp, torch.float32, 'pos_logp')
+    neg_logp = _need_opt(neg_logp, torch.float32, 'neg_logp')
+    dev = pos_score.device
+    row = torch.empty(M, dtype=torch.float32, device=dev)
+    loss = torch.empty((), dtype=torch.float32, device=dev)
+    dpos, dneg = torch.empty_like(pos_score), torch.empty_like(neg_score)
+    nat.check(nat.lib().rsa_pairwise_loss_ex(int(kind), ptr(pos_score), ptr(neg_score), ptr(pos_logp), ptr(neg_logp), M, n,
+                                             float(param0), float(param1), ptr(row), ptr(loss), ptr(dpos), ptr(dneg),
+                                             _stream()), 'rsa_pairwise_loss_ex')
+    return loss, dpos, dneg
+
+
 def ssm_shared_loss(pos_score, neg_score, pos_logp=None, neg_logp=None):
     """rsa_ssm_shared_loss: pos_score [B, L], neg_score [B, n].  Returns (loss, dpos, dneg)."""
     pos_score = _need(pos_score, torch.float32, 'pos_score')

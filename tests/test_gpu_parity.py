@@ -260,6 +260,51 @@ def test_losses_golden(ra, golden):
         rel_close(neg.grad.cpu(), g[name + '_grad_neg_score'], rtol=1e-4, atol=1e-7)
 
 
+def test_other_pairwise_losses_golden(ra, golden):
+    """WeightedBPR / WeightedBCE / Hinge / InfoNCE / NCE / CCL (loss_func.py:93-97, :135-193): value and gradients
+    recorded from the reference."""
+    g = golden('loss')
+    make = {'wbpr': lambda n: ra.WeightedBPRLoss(), 'wbce': lambda n: ra.WeightedBinaryCrossEntropyLoss(),
+            'hinge': lambda n: ra.HingeLoss(margin=0.5 if n == 'hinge_inactive' else 2), 'infonce': lambda n: ra.InfoNCELoss(),
+            'ccl': lambda n: ra.CCLLoss(margin=0.6, neg_weight=0.3), 'nce': lambda n: ra.NCELoss()}
+    for name in ('wbpr_1d', 'wbpr_2d', 'wbpr_big', 'wbce_1d', 'wbce_2d', 'wbce_2d_pad', 'hinge_1d', 'hinge_2d',
+                 'hinge_inactive', 'infonce_1d', 'infonce_2d', 'ccl_1d', 'ccl_2d', 'nce_1d'):
+        pos = T(g[name + '_pos_score']).to(DEV).requires_grad_(True)
+        neg = T(g[name + '_neg_score']).to(DEV).requires_grad_(True)
+        lpp, lnp = T(g[name + '_log_pos_prob']).to(DEV), T(g[name + '_log_neg_prob']).to(DEV)
+        loss = make[name.split('_')[0]](name)(label=None, pos_score=pos, log_pos_prob=lpp, neg_score=neg, log_neg_prob=lnp)
+        rel_close(loss.detach().cpu(), g[name + '_loss'], rtol=1e-5, atol=1e-7)
+        (loss * 1.0).backward()
+        rel_close(pos.grad.cpu(), g[name + '_grad_pos_score'], rtol=1e-4, atol=1e-7)
+        rel_close(neg.grad.cpu(), g[name + '_grad_neg_score'], rtol=1e-4, atol=1e-7)
+
+
+@pytest.mark.parametrize('n', [1, 3, 20, 64, 300])
+def test_other_pairwise_losses_vs_oracle(ra, n):
+    """The same losses at other row lengths (1 / 4 / 16 / 64 lanes per row) against the oracle's autograd."""
+    M = 77
+    g = torch.Generator().manual_seed(n)
+    pos, neg = torch.randn(M, generator=g) * 2, torch.randn(M, n, generator=g) * 2
+    lpp, lnp = torch.log(torch.rand(M, generator=g)), torch.log(torch.rand(M, n, generator=g))
+    pos_pad = pos.clone()
+    pos_pad[5] = -float('inf')
+    cases = (('wbpr', ra.WeightedBPRLoss(), lambda p, q: oracle.weighted_bpr_loss(p, q, lnp), pos),
+             ('wbce', ra.WeightedBinaryCrossEntropyLoss(), lambda p, q: oracle.weighted_bce_loss(p, q, lnp), pos_pad),
+             ('hinge', ra.HingeLoss(margin=1.5), lambda p, q: oracle.hinge_loss(p, q, 1.5), pos),
+             ('nce', ra.NCELoss(), lambda p, q: oracle.nce_loss(p, lpp, q, lnp), pos),
+             ('ccl', ra.CCLLoss(0.55, 0.4), lambda p, q: oracle.ccl_loss(p, q, 0.55, 0.4), pos))
+    for name, mod, ref, pp in cases:
+        p, q = pp.clone().requires_grad_(True), neg.clone().requires_grad_(True)
+        want = ref(p, q)
+        want.backward()
+        pd, qd = pp.to(DEV).requires_grad_(True), neg.to(DEV).requires_grad_(True)
+        got = mod(None, pd, lpp.to(DEV), qd, lnp.to(DEV))
+        rel_close(got.detach().cpu(), want.detach(), rtol=1e-5, atol=1e-7)
+        got.backward()
+        rel_close(pd.grad.cpu(), torch.nan_to_num(p.grad), rtol=1e-4, atol=1e-7)
+        rel_close(qd.grad.cpu(), q.grad, rtol=1e-4, atol=1e-7)
+
+
 def test_ssm_shared_negatives_golden(ra, golden):
     """loss_func.py:84-89: multi-positive rows sharing one negative set, with -inf padded positives."""
     g = golden('loss')

@@ -75,6 +75,22 @@ def test_losses(golden):
         np.testing.assert_allclose(val.detach().numpy(), g[name + '_loss'], rtol=1e-6)
         np.testing.assert_allclose(gp.numpy(), g[name + '_grad_pos_score'], rtol=1e-5, atol=1e-8)
         np.testing.assert_allclose(gn.numpy(), g[name + '_grad_neg_score'], rtol=1e-5, atol=1e-8)
+    # the other PairwiseLoss classes (loss_func.py:93-97, :135-193)
+    others = {
+        'wbpr': lambda name: (lambda p, n: oracle.weighted_bpr_loss(p, n, T(g[name + '_log_neg_prob']))),
+        'wbce': lambda name: (lambda p, n: oracle.weighted_bce_loss(p, n, T(g[name + '_log_neg_prob']))),
+        'hinge': lambda name: (lambda p, n: oracle.hinge_loss(p, n, 0.5 if name == 'hinge_inactive' else 2.0)),
+        'infonce': lambda name: oracle.info_nce_loss,
+        'ccl': lambda name: (lambda p, n: oracle.ccl_loss(p, n, 0.6, 0.3)),
+        'nce': lambda name: (lambda p, n: oracle.nce_loss(p, T(g[name + '_log_pos_prob']), n, T(g[name + '_log_neg_prob']))),
+    }
+    for name in ('wbpr_1d', 'wbpr_2d', 'wbpr_big', 'wbce_1d', 'wbce_2d', 'wbce_2d_pad', 'hinge_1d', 'hinge_2d',
+                 'hinge_inactive', 'infonce_1d', 'infonce_2d', 'ccl_1d', 'ccl_2d', 'nce_1d'):
+        fn = others[name.split('_')[0]](name)
+        val, (gp, gn) = grads(fn, (T(g[name + '_pos_score']), True), (T(g[name + '_neg_score']), True))
+        np.testing.assert_allclose(val.detach().numpy(), g[name + '_loss'], rtol=1e-6, err_msg=name)
+        np.testing.assert_allclose(gp.numpy(), g[name + '_grad_pos_score'], rtol=1e-5, atol=1e-8, err_msg=name)
+        np.testing.assert_allclose(gn.numpy(), g[name + '_grad_neg_score'], rtol=1e-5, atol=1e-8, err_msg=name)
     val, (gp, ga) = grads(oracle.softmax_loss, (T(g['softmax_full_pos_score']), True), (T(g['softmax_full_all_score']), True))
     np.testing.assert_allclose(val.detach().numpy(), g['softmax_full_loss'], rtol=1e-6)
     np.testing.assert_allclose(ga.numpy(), g['softmax_full_grad_all_score'], rtol=1e-5, atol=1e-8)
