@@ -19,6 +19,7 @@ from .philox import (philox4x32_10, rng_grid_threads, rng_counter_offset,
                      device_randint, device_rand)
 from .path import (UniformSampler, PopularSamplerModel, popular_tables,
                    searchsorted_left, masked_uniform_from_u, inner_product_score, cosine_score, euclidean_score,
+                   norm_score, gmf_score,
                    bpr_loss, sampled_softmax_loss, softmax_loss, bce_loss, weighted_bpr_loss, weighted_bce_loss,
                    hinge_loss, info_nce_loss, nce_loss, ccl_loss,
                    retriever_forward, dense_grads, topk_with_history,

@@ -80,6 +80,15 @@ def gen_score(scorer):
             out[k + '_ip'] = np_(ip(q.clone(), it.clone()))
             out[k + '_cos'] = np_(cos(q.clone(), it.clone()))
             out[k + '_euc'] = np_(euc(q.clone(), it.clone()))
+            out[k + '_norm2'] = np_(scorer.NormScorer(p=2)(q.clone(), it.clone()))              # scorer.py:56-66
+            torch.manual_seed(100 + d)
+            gmf = scorer.GMFScorer(d, bias=True, activation='relu')                              # scorer.py:69-86
+            try:                      # the reference's GMF handles 2-D queries only (its unsqueeze(1) is wrong for [B, L, D])
+                out[k + '_gmf'] = np_(gmf(q.clone(), it.clone()))
+                out[k + '_gmf_w'] = np_(gmf.W.weight)
+                out[k + '_gmf_b'] = np_(gmf.W.bias)
+            except RuntimeError:
+                pass
     np.savez_compressed(os.path.join(OUT, 'score.npz'), **out)
 
 

@@ -167,6 +167,22 @@ def euclidean_score(query, items):
 
 
 # --------------------------------------------------------------------------- losses
+def norm_score(query, items, p=2):
+    """recstudio/model/scorer.py:56-66 (NormScorer): minus the p-norm of (query - items)."""
+    if query.dim() < items.dim() or query.size(0) != items.size(0):
+        query = query.unsqueeze(-2)
+    return -torch.norm(query - items, p=p, dim=-1)
+
+
+def gmf_score(query, items, weight, bias=None, activation=torch.relu):
+    """recstudio/model/scorer.py:69-86 (GMFScorer): act(Linear(query * item)); 2-D queries as in the reference."""
+    if query.dim() < items.dim():
+        query = query.unsqueeze(1)
+    elif query.size(0) != items.size(0):
+        query, items = query.unsqueeze(1), items.unsqueeze(0)
+    return activation(torch.nn.functional.linear(query * items, weight, bias)).squeeze(-1)
+
+
 def bpr_loss(pos_score, neg_score):
     """recstudio/model/loss_func.py:55-59 (dns=False)."""
     diff = pos_score.unsqueeze(-1) - neg_score

@@ -8,7 +8,7 @@ fallback: calling an op without the built library or with CPU tensors raises.
 """
 from . import _native, ops, rng                                  # noqa: F401
 from .sampler import Sampler, UniformSampler, MaskedUniformSampler, PopularSamplerModel    # noqa: F401
-from .scorer import InnerProductScorer, CosineScorer, EuclideanScorer   # noqa: F401
+from .scorer import InnerProductScorer, CosineScorer, EuclideanScorer, NormScorer, GMFScorer   # noqa: F401
 from .loss_func import (FullScoreLoss, PairwiseLoss, PointwiseLoss, BPRLoss,   # noqa: F401
                         SampledSoftmaxLoss, SoftmaxLoss, BinaryCrossEntropyLoss, WeightedBPRLoss,
                         WeightedBinaryCrossEntropyLoss, HingeLoss, NCELoss, CCLLoss, InfoNCELoss)

@@ -69,6 +69,44 @@ class EuclideanScorer(InnerProductScorer):
     cosine = nat.SCORE_EUC      # the `cosine` slot carries the rsa_score_mode
 
 
+class NormScorer(EuclideanScorer):
+    """recstudio/model/scorer.py:56-66 for p = 2: -||query - items||_2, evaluated as -sqrt of the Euclidean mode of
+    the gather+score kernel (|q|^2 + |x|^2 - 2 <q, x>, clamped at 0); gradients flow through that kernel's backward."""
+
+    def __init__(self, p=2):
+        super().__init__()
+        if p != 2:
+            raise NotImplementedError('NormScorer: only p = 2 maps onto the dot-product kernels')
+        self.p = p
+
+    def forward(self, query, items):
+        if query.size(0) != items.size(0):
+            raise NotImplementedError('NormScorer over the full catalog is not implemented in this build')
+        return -torch.sqrt(torch.clamp(-super().forward(query, items), min=0.0))
+
+
+class GMFScorer(InnerProductScorer):
+    """recstudio/model/scorer.py:69-86: act(W (query * item) + b) = act(<query * w, item> + b) -- the learned
+    weights fold into the query, so scoring (and its backward) is the inner-product kernel."""
+
+    def __init__(self, emb_dim, bias=False, activation='relu'):
+        super().__init__()
+        self.emb_dim = emb_dim
+        self.W = torch.nn.Linear(emb_dim, 1, bias=bias)
+        acts = {'relu': torch.relu, 'sigmoid': torch.sigmoid, 'tanh': torch.tanh, 'identity': lambda x: x,
+                'gelu': torch.nn.functional.gelu, 'leakyrelu': torch.nn.functional.leaky_relu}
+        if activation not in acts:
+            raise ValueError(f'GMFScorer: unknown activation {activation!r}')
+        self.activation = acts[activation]
+
+    def forward(self, query, key):
+        assert query.dim() <= key.dim(), 'query dim must be smaller than or euqal to key dim'
+        s = super().forward(query * self.W.weight.view(-1), key)
+        if self.W.bias is not None:
+            s = s + self.W.bias
+        return self.activation(s)
+
+
 class _FullScoreFn(torch.autograd.Function):
     """[B, N] = query @ items.T with the fp32-MFMA kernel; the backward GEMMs are plain library
     GEMMs (rocBLAS through torch.matmul)."""

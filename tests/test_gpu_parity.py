@@ -241,6 +241,29 @@ def test_scorer_plugin_golden(ra, golden):
             rel_close(ra.InnerProductScorer()(q, it).cpu(), g[k + '_ip'], atol=1e-5)
             rel_close(ra.CosineScorer()(q, it).cpu(), g[k + '_cos'], atol=1e-5)
             rel_close(ra.EuclideanScorer()(q, it).cpu(), g[k + '_euc'], atol=1e-3)
+            rel_close(ra.NormScorer(p=2)(q, it).cpu(), g[k + '_norm2'], rtol=1e-4, atol=1e-4)
+            if k + '_gmf' in g and case != 'bld_bld':        # the reference's GMF handles 2-D queries only
+                gmf = ra.GMFScorer(d, bias=True).to(DEV)
+                with torch.no_grad():
+                    gmf.W.weight.copy_(T(g[k + '_gmf_w']))
+                    gmf.W.bias.copy_(T(g[k + '_gmf_b']))
+                rel_close(gmf(q, it).detach().cpu(), g[k + '_gmf'], rtol=1e-4, atol=1e-5)
+    # GMF / Norm gradients against torch autograd of the oracle's op sequence
+    torch.manual_seed(0)
+    q = torch.randn(9, 64, device=DEV, requires_grad=True)
+    it = torch.randn(9, 5, 64, device=DEV, requires_grad=True)
+    gmf = ra.GMFScorer(64, bias=True, activation='tanh').to(DEV)
+    for fn, ref in ((gmf, lambda a, b: oracle.gmf_score(a, b, gmf.W.weight, gmf.W.bias, torch.tanh)),
+                    (ra.NormScorer(), oracle.norm_score)):
+        grads = []
+        for f in (fn, ref):
+            q.grad = it.grad = None
+            gmf.zero_grad()
+            f(q, it).square().sum().backward()
+            grads.append((q.grad.clone(), it.grad.clone(), gmf.W.weight.grad.clone() if gmf.W.weight.grad is not None else None))
+        for a, b in zip(*grads):
+            if a is not None:
+                rel_close(a.cpu(), b.cpu(), rtol=3e-4, atol=1e-5)
 
 
 # --------------------------------------------------------------------------- losses

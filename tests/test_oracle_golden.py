@@ -46,6 +46,10 @@ def test_scorers(golden):
             np.testing.assert_allclose(oracle.inner_product_score(q, it).numpy(), g[k + '_ip'], rtol=1e-6, atol=1e-6)
             np.testing.assert_allclose(oracle.cosine_score(q, it).numpy(), g[k + '_cos'], rtol=1e-6, atol=1e-6)
             np.testing.assert_allclose(oracle.euclidean_score(q, it).numpy(), g[k + '_euc'], rtol=1e-5, atol=1e-4)
+            np.testing.assert_allclose(oracle.norm_score(q, it).numpy(), g[k + '_norm2'], rtol=1e-6, atol=1e-6)
+            if k + '_gmf' in g:
+                got = oracle.gmf_score(q, it, T(g[k + '_gmf_w']), T(g[k + '_gmf_b']))
+                np.testing.assert_allclose(got.numpy(), g[k + '_gmf'], rtol=1e-5, atol=1e-6)
 
 
 def test_losses(golden):
