@@ -7,7 +7,8 @@ computation on the path runs in hand-written HIP kernels reached through the C A
 fallback: calling an op without the built library or with CPU tensors raises.
 """
 from . import _native, ops, rng                                  # noqa: F401
-from .sampler import Sampler, UniformSampler, MaskedUniformSampler, PopularSamplerModel    # noqa: F401
+from .sampler import (Sampler, UniformSampler, MaskedUniformSampler, PopularSamplerModel,    # noqa: F401
+                      RetrieverSampler)
 from .scorer import InnerProductScorer, CosineScorer, EuclideanScorer, NormScorer, GMFScorer   # noqa: F401
 from .loss_func import (FullScoreLoss, PairwiseLoss, PointwiseLoss, BPRLoss,   # noqa: F401
                         SampledSoftmaxLoss, SoftmaxLoss, BinaryCrossEntropyLoss, WeightedBPRLoss,

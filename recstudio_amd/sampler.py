@@ -167,3 +167,20 @@ class PopularSamplerModel(Sampler):
 
     def compute_item_p(self, query, pos_items):
         return ops.item_logp(self.pop_prob, pos_items)                    # sampler.py:257-258
+
+
+class RetrieverSampler(Sampler):
+    """recstudio/ann/sampler.py:61-78 (IRGAN): negatives drawn by ANOTHER retriever's ``sampling(method=...)`` --
+    by default from its softmax over the whole catalog ('brute'), scored on the full-score kernels."""
+
+    def __init__(self, num_items, retriever=None, method='brute', t=1):
+        super().__init__(num_items)
+        self.retriever, self.method, self.T = retriever, method, t
+
+    def update(self, item_embs, max_iter=30):
+        self.retriever._update_item_vector()
+
+    def forward(self, batch, num_neg, pos_items=None, excluding_hist=False):
+        (log_pos_prob, neg_id, log_neg_prob), _ = self.retriever.sampling(
+            batch=batch, num_neg=num_neg, excluding_hist=excluding_hist, method=self.method, return_query=False, t=self.T)
+        return log_pos_prob.detach(), neg_id.detach(), log_neg_prob.detach()

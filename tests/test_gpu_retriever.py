@@ -381,3 +381,18 @@ def test_other_sampling_methods_follow_the_reference_op_sequence(ra, method):
     loss = m.training_step(batch)
     loss.backward()
     assert torch.isfinite(loss)
+
+
+def test_retriever_sampler_wraps_another_retrievers_sampling(ra):
+    """sampler.py:61-78: the generator retriever's brute-force softmax sampling behind the Sampler interface."""
+    N, U, d, B = 2001, 80, 64, 30
+    gen = _sampling_model(ra, N, U, d, 8, 5, 'brute')
+    rs = ra.RetrieverSampler(N, retriever=gen, method='brute', t=1)
+    assert isinstance(rs, ra.Sampler)
+    batch = {'user_id': torch.randint(1, U, (B,), device=DEV), 'item_id': torch.randint(1, N, (B,), device=DEV)}
+    torch.manual_seed(3)
+    lpp, neg, lnp = rs(batch, 5)
+    torch.manual_seed(3)
+    (lpp2, neg2, lnp2), _ = gen.sampling(batch, 5, method='brute')
+    assert torch.equal(neg, neg2) and torch.equal(lnp, lnp2) and torch.equal(lpp, lpp2)
+    assert neg.shape == (B, 5) and int(neg.min()) >= 1 and int(neg.max()) < N
