@@ -256,6 +256,21 @@ typedef struct rsa_backward_args {
 
 int rsa_fused_backward(const rsa_backward_args* args, rsa_stream_t stream);
 
+/* Atomics-free, bit-reproducible form of the item-side scatter-add of a step:
+ *     target[id] += upstream * sum_{e : id_e = id} d_e * query[qrow_e]      (rows id != pad_row)
+ * over the n_queries * (1 + num_neg) elements (positive of query m first, then its negatives; d = dpos / dneg).
+ * The (id, element) pairs are radix-sorted (rocPRIM, stable) and every run of equal ids is summed by one wave in
+ * element order, then the row is read-modified-written once.  `target` [n_items, dim] is a zeroed dense gradient
+ * (== the reference's weight.grad, recommender.py:636-639) or the weight table itself with upstream = -lr (plain
+ * SGD in place).  dim in {64, 128, 256}; pos_ids / dpos nullable; query_index nullable (query row m);
+ * upstream: nullable device scalar; pad_row < 0: none.  Workspace from the _workspace_bytes call. */
+int64_t rsa_scatter_rows_sorted_workspace_bytes(int64_t n_queries, int32_t num_neg, int64_t n_items);
+int rsa_scatter_rows_sorted(const float* query, const int64_t* query_index, int64_t n_query_rows, int32_t dim,
+                            const int64_t* pos_ids, const int64_t* neg_ids, int64_t n_queries, int32_t num_neg,
+                            const float* dpos, const float* dneg, const float* upstream, int64_t n_items,
+                            int64_t pad_row, float* target, void* workspace, int64_t workspace_bytes,
+                            rsa_stream_t stream);
+
 /* embedding_dense_backward: dst[ids[i]] += src[i] for ids != 0 (padding_idx=0).
  * Used for the user-table gradient.  dst [n_rows, dim] caller-zeroed. */
 int rsa_scatter_add_rows(const float* src, const int64_t* ids, int64_t numel, int32_t dim,

@@ -147,7 +147,12 @@ class _FusedBPRFn(torch.autograd.Function):
         have_q = need_q and ctx.fwd_qgrad
         qtab = torch.zeros_like(query_src) if (need_q and not have_q and qi is not None and not sparse) else None
         item_grad = rows = qgrad = None
-        if need_item or (need_q and not have_q):
+        sorted_dense = (need_item and not sparse and (have_q or not need_q) and item_weight.shape[1] in (64, 128, 256))
+        if sorted_dense:
+            # dense weight.grad without atomics: elements sorted by item id, one read-modify-write per touched row
+            item_grad = ops.scatter_rows_sorted(torch.zeros_like(item_weight), query_src, neg_ids, dneg, query_index=qi,
+                                                pos_ids=pos_ids, dpos=dpos, upstream=g.reshape(1).contiguous(), pad_row=0)
+        elif need_item or (need_q and not have_q):
             item_grad, rows, qgrad = ops.fused_backward(
                 item_weight, query_src, neg_ids, dneg, query_index=qi, pos_ids=pos_ids, dpos=dpos,
                 upstream=g.reshape(1).contiguous(), dense_item_grad=need_item and not sparse,
@@ -211,11 +216,12 @@ def train_step_no_autograd(item_weight, query_src, num_neg, loss_kind, *, query_
     return loss, score, grads
 
 
-def bpr_sgd_step(item_weight, user_weight, num_neg, lr, *, user_ids, pos_ids, sampler=None, neg_ids=None):
+def bpr_sgd_step(item_weight, user_weight, num_neg, lr, *, user_ids, pos_ids, sampler=None, neg_ids=None, atomics=False):
     """One complete SGD training step of a BPR two-tower model (nn.Embedding user and item tables) in three
     launches and WITHOUT gradient tensors: the forward samples, scores, evaluates BPRLoss and accumulates the
-    user-row gradients; the backward kernel adds ``-lr * dneg * q`` straight into the touched ITEM rows of the
-    weight table (atomics; dword-contiguous lines) and a row scatter applies ``-lr * q.grad`` to the touched USER
+    user-row gradients; ``rsa_scatter_rows_sorted`` adds ``-lr * dneg * q`` straight into the touched ITEM rows of the
+    weight table (elements sorted by item id, one read-modify-write per row, bit-reproducible; ``atomics=True``: the
+    backward kernel's float atomics instead) and a row scatter applies ``-lr * q.grad`` to the touched USER
     rows.  Equal to ``loss.backward(); torch.optim.SGD(lr).step()`` on the dense gradients (no momentum /
     weight decay) up to fp32 summation order -- without the [N, d] gradient zero-fill, scatter and dense update
     that dominate that path (5.12 GB each at N = 1e7).  Returns (loss, neg_ids).  num_neg % 64 == 0."""
@@ -236,7 +242,12 @@ def bpr_sgd_step(item_weight, user_weight, num_neg, lr, *, user_ids, pos_ids, sa
         step = torch.full((1,), -float(lr), dtype=torch.float32, device=iw.device)
         # the user-row gradient is complete BEFORE any weight changes (it was accumulated by the forward); the
         # item-row update needs the pre-update user rows, so it runs first
-        ops.fused_backward(iw, uw, out['neg_ids'], out['dneg'], query_index=user_ids, pos_ids=pos_ids, dpos=out['dpos'],
-                           upstream=step, dense_item_grad=True, item_grad_out=iw, want_query_grad=False)
+        if iw.shape[1] in (64, 128, 256) and not atomics:
+            # sorted by item id: every touched row is read-modified-written once, in a fixed order
+            ops.scatter_rows_sorted(iw, uw, out['neg_ids'], out['dneg'], query_index=user_ids, pos_ids=pos_ids,
+                                    dpos=out['dpos'], upstream=step, pad_row=0)
+        else:
+            ops.fused_backward(iw, uw, out['neg_ids'], out['dneg'], query_index=user_ids, pos_ids=pos_ids, dpos=out['dpos'],
+                               upstream=step, dense_item_grad=True, item_grad_out=iw, want_query_grad=False)
         ops.scatter_add_rows(out['query_grad'] * step, user_ids, uw.shape[0], out=uw)
     return out['loss'], out['neg_ids']

@@ -433,3 +433,26 @@ def row_topk(values, k):
 def rng_advance(offset_dev, increment):
     """*offset_dev += increment on the stream (rsa_rng_advance): the device copy of the generator offset."""
     nat.check(nat.lib().rsa_rng_advance(ptr(offset_dev), int(increment), _stream()), 'rsa_rng_advance')
+
+
+def scatter_rows_sorted(target, query, neg_ids, dneg, *, query_index=None, pos_ids=None, dpos=None, upstream=None,
+                        pad_row=0):
+    """rsa_scatter_rows_sorted: target[id] += upstream * sum_e d_e * query[qrow_e], sorted by id, no atomics.
+    ``target``: [n_items, d] (a zeroed dense gradient, or the weight table with upstream = -lr)."""
+    target = _need(target, torch.float32, 'target')
+    query = _need(query, torch.float32, 'query')
+    neg_ids = _need(neg_ids, torch.int64, 'neg_ids')
+    dneg = _need(dneg, torch.float32, 'dneg')
+    query_index = _need_opt(query_index, torch.int64, 'query_index')
+    pos_ids = _need_opt(pos_ids, torch.int64, 'pos_ids')
+    dpos = _need_opt(dpos, torch.float32, 'dpos')
+    upstream = _need_opt(upstream, torch.float32, 'upstream')
+    n_items, dim = target.shape
+    M = query_index.numel() if query_index is not None else query.shape[0]
+    n = neg_ids.numel() // M
+    ws_bytes = int(nat.lib().rsa_scatter_rows_sorted_workspace_bytes(M, n, n_items))
+    ws = torch.empty(max(ws_bytes, 8), dtype=torch.uint8, device=target.device)
+    nat.check(nat.lib().rsa_scatter_rows_sorted(ptr(query), ptr(query_index), query.shape[0], dim, ptr(pos_ids), ptr(neg_ids),
+                                                M, n, ptr(dpos), ptr(dneg), ptr(upstream), n_items, int(pad_row), ptr(target),
+                                                ptr(ws), ws_bytes, _stream()), 'rsa_scatter_rows_sorted')
+    return target

@@ -396,3 +396,33 @@ def test_retriever_sampler_wraps_another_retrievers_sampling(ra):
     (lpp2, neg2, lnp2), _ = gen.sampling(batch, 5, method='brute')
     assert torch.equal(neg, neg2) and torch.equal(lnp, lnp2) and torch.equal(lpp, lpp2)
     assert neg.shape == (B, 5) and int(neg.min()) >= 1 and int(neg.max()) < N
+
+
+@pytest.mark.parametrize('d', [64, 128, 256])
+def test_sorted_scatter_equals_atomic_backward_and_is_reproducible(ra, d):
+    """rsa_scatter_rows_sorted (radix sort by item id + one RMW per row) == the dense atomic scatter of
+    rsa_fused_backward, twice bit-identical, padding row untouched, heavy duplication included."""
+    torch.manual_seed(d)
+    N, U, M, n = 3001, 500, 777, 64
+    item = torch.randn(N, d, device=DEV)
+    user = torch.randn(U, d, device=DEV)
+    uid = torch.randint(1, U, (M,), device=DEV)
+    pos = torch.randint(0, N, (M,), device=DEV)
+    neg = torch.randint(0, 40, (M, n), device=DEV)             # ~1200 copies of each id: long runs crossing chunks
+    neg[:, ::2] = torch.randint(0, N, (M, n // 2), device=DEV)
+    dpos, dneg = torch.randn(M, device=DEV), torch.randn(M, n, device=DEV)
+    up = torch.tensor([0.37], device=DEV)
+    ref = ra.ops.fused_backward(item, user, neg, dneg, query_index=uid, pos_ids=pos, dpos=dpos, upstream=up,
+                                want_query_grad=False)[0]
+    a = ra.ops.scatter_rows_sorted(torch.zeros(N, d, device=DEV), user, neg, dneg, query_index=uid, pos_ids=pos,
+                                   dpos=dpos, upstream=up)
+    b = ra.ops.scatter_rows_sorted(torch.zeros(N, d, device=DEV), user, neg, dneg, query_index=uid, pos_ids=pos,
+                                   dpos=dpos, upstream=up)
+    assert torch.equal(a, b) and not a[0].any()
+    np.testing.assert_allclose(a.cpu(), ref.cpu(), rtol=2e-4, atol=2e-4)
+    q = user[uid].double()
+    want = torch.zeros(N, d, dtype=torch.float64, device=DEV)
+    want.index_add_(0, pos, dpos.double().unsqueeze(1) * q)
+    want.index_add_(0, neg.reshape(-1), (dneg.double().unsqueeze(-1) * q.unsqueeze(1)).reshape(-1, d))
+    want[0] = 0
+    np.testing.assert_allclose(a.cpu(), (want * 0.37).float().cpu(), rtol=1e-4, atol=1e-4)
