@@ -258,7 +258,8 @@ int rsa_fused_backward(const rsa_backward_args* args, rsa_stream_t stream);
 
 /* Atomics-free, bit-reproducible form of the item-side scatter-add of a step:
  *     target[id] += upstream * sum_{e : id_e = id} d_e * query[qrow_e]      (rows id != pad_row)
- * over the n_queries * (1 + num_neg) elements (positive of query m first, then its negatives; d = dpos / dneg).
+ * over the elements of the step (with pos_ids: the positive of query m first, then its num_neg negatives; without: the
+ * negatives only; d = dpos / dneg).
  * The (id, element) pairs are radix-sorted (rocPRIM, stable) and every run of equal ids is summed by one wave in
  * element order, then the row is read-modified-written once.  `target` [n_items, dim] is a zeroed dense gradient
  * (== the reference's weight.grad, recommender.py:636-639) or the weight table itself with upstream = -lr (plain

@@ -19,12 +19,14 @@ __global__ __launch_bounds__(256) void sorted_keys_kernel(const int64_t* __restr
                                                           const int64_t* __restrict__ neg_ids, int64_t n_queries, int n,
                                                           int64_t n_items, int32_t* __restrict__ keys,
                                                           int32_t* __restrict__ vals) {
-  const int64_t total = n_queries * (int64_t)(n + 1);
+  const int w = pos_ids ? n + 1 : n;          // elements per query: positive slot only when positives are given
+  const int off = pos_ids ? 1 : 0;
+  const int64_t total = n_queries * (int64_t)w;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
-    const int64_t m = e / (n + 1);
-    const int c = (int)(e - m * (n + 1));
-    int64_t id = c == 0 ? (pos_ids ? pos_ids[m] : 0) : neg_ids[m * (int64_t)n + (c - 1)];
+    const int64_t m = e / w;
+    const int c = (int)(e - m * w);
+    int64_t id = (off && c == 0) ? pos_ids[m] : neg_ids[m * (int64_t)n + (c - off)];
     id = id < 0 ? 0 : (id >= n_items ? n_items - 1 : id);
     keys[e] = (int32_t)id;
     vals[e] = (int32_t)e;
@@ -35,7 +37,7 @@ __global__ __launch_bounds__(256) void sorted_keys_kernel(const int64_t* __restr
 template <int NDW>   // dwords per lane per row: D = 64 * NDW
 __global__ __launch_bounds__(256) void sorted_apply_kernel(const int32_t* __restrict__ keys, const int32_t* __restrict__ vals,
                                                            int64_t total, const float* __restrict__ query,
-                                                           const int64_t* __restrict__ query_index, int n,
+                                                           const int64_t* __restrict__ query_index, int n, int has_pos,
                                                            const float* __restrict__ dpos, const float* __restrict__ dneg,
                                                            const float* __restrict__ upstream, int32_t pad_row,
                                                            float* __restrict__ target) {
@@ -45,6 +47,7 @@ __global__ __launch_bounds__(256) void sorted_apply_kernel(const int32_t* __rest
   const int64_t begin = chunk * 64;
   if (begin >= total) return;
   const float scale = upstream ? upstream[0] : 1.f;
+  const int w = n + has_pos;
   // this lane's element of the chunk: key, query row, coefficient (all lanes in parallel)
   const int64_t i = begin + lane;
   const bool in = i < total;
@@ -53,10 +56,10 @@ __global__ __launch_bounds__(256) void sorted_apply_kernel(const int32_t* __rest
   float coef = 0.f;
   if (in) {
     const int64_t e = vals[i];
-    const int64_t m = e / (n + 1);
-    const int c = (int)(e - m * (n + 1));
+    const int64_t m = e / w;
+    const int c = (int)(e - m * w);
     qrow = (int32_t)(query_index ? query_index[m] : m);
-    coef = c == 0 ? (dpos ? dpos[m] : 0.f) : dneg[m * (int64_t)n + (c - 1)];
+    coef = (has_pos && c == 0) ? dpos[m] : dneg[m * (int64_t)n + (c - has_pos)];
   }
   const int32_t prev = begin > 0 ? keys[begin - 1] : -1;     // a run continuing from the previous chunk is not ours
   float acc[NDW];
@@ -94,10 +97,10 @@ __global__ __launch_bounds__(256) void sorted_apply_kernel(const int32_t* __rest
   // the last run may continue into the following chunks: finish it here (rare, short)
   for (int64_t j = begin + cnt; j < total && keys[j] == cur; ++j) {
     const int64_t e = vals[j];
-    const int64_t m = e / (n + 1);
-    const int c = (int)(e - m * (n + 1));
+    const int64_t m = e / w;
+    const int c = (int)(e - m * w);
     const int64_t qr = query_index ? query_index[m] : m;
-    const float cf = c == 0 ? (dpos ? dpos[m] : 0.f) : dneg[m * (int64_t)n + (c - 1)];
+    const float cf = (has_pos && c == 0) ? dpos[m] : dneg[m * (int64_t)n + (c - has_pos)];
     const float* qp = query + (size_t)qr * D;
 #pragma unroll
     for (int k = 0; k < NDW; ++k) acc[k] = __fmaf_rn(cf, qp[k * 64 + lane], acc[k]);
@@ -126,7 +129,7 @@ using namespace rsa;
 
 extern "C" int64_t rsa_scatter_rows_sorted_workspace_bytes(int64_t n_queries, int32_t num_neg, int64_t n_items) {
   if (n_queries <= 0 || num_neg < 0 || n_items < 1) return 0;
-  const int64_t total = n_queries * (int64_t)(num_neg + 1);
+  const int64_t total = n_queries * (int64_t)(num_neg + 1);     // sized for the with-positives layout
   return 4 * align256s(total * 4) + align256s((int64_t)sort_temp_bytes(total, key_bits(n_items))) + 256;
 }
 
@@ -144,14 +147,15 @@ extern "C" int rsa_scatter_rows_sorted(const float* query, const int64_t* query_
     rsa::set_error("rsa_scatter_rows_sorted: dim=%d: built for dim in {64, 128, 256}", dim);
     return RSA_ERR_UNSUPPORTED;
   }
-  const int64_t total = n_queries * (int64_t)(num_neg + 1);
+  const int has_pos = pos_ids != nullptr ? 1 : 0;
+  const int64_t total = n_queries * (int64_t)(num_neg + has_pos);
   RSA_CHECK_ARG(total < (1ll << 31), "rsa_scatter_rows_sorted: more than 2^31 elements");
   const int64_t need = rsa_scatter_rows_sorted_workspace_bytes(n_queries, num_neg, n_items);
   RSA_CHECK_ARG(workspace && workspace_bytes >= need, "rsa_scatter_rows_sorted: workspace too small (%lld < %lld)",
                 (long long)workspace_bytes, (long long)need);
   hipStream_t s = (hipStream_t)stream;
   char* ws = reinterpret_cast<char*>(workspace);
-  const int64_t seg = align256s(total * 4);
+  const int64_t seg = align256s(n_queries * (int64_t)(num_neg + 1) * 4);     // layout of the workspace_bytes call
   int32_t* k_in = reinterpret_cast<int32_t*>(ws);
   int32_t* v_in = reinterpret_cast<int32_t*>(ws + seg);
   int32_t* k_out = reinterpret_cast<int32_t*>(ws + 2 * seg);
@@ -172,9 +176,9 @@ extern "C" int rsa_scatter_rows_sorted(const float* query, const int64_t* query_
   dim3 grid((chunks + 3) / 4), block(256);
   const int32_t pad = (int32_t)(pad_row < 0 || pad_row >= (1ll << 31) ? -2 : pad_row);
   switch (dim) {
-    case 64: hipLaunchKernelGGL(sorted_apply_kernel<1>, grid, block, 0, s, k_out, v_out, total, query, query_index, (int)num_neg, dpos, dneg, upstream, pad, target); break;
-    case 128: hipLaunchKernelGGL(sorted_apply_kernel<2>, grid, block, 0, s, k_out, v_out, total, query, query_index, (int)num_neg, dpos, dneg, upstream, pad, target); break;
-    default: hipLaunchKernelGGL(sorted_apply_kernel<4>, grid, block, 0, s, k_out, v_out, total, query, query_index, (int)num_neg, dpos, dneg, upstream, pad, target); break;
+    case 64: hipLaunchKernelGGL(sorted_apply_kernel<1>, grid, block, 0, s, k_out, v_out, total, query, query_index, (int)num_neg, has_pos, dpos, dneg, upstream, pad, target); break;
+    case 128: hipLaunchKernelGGL(sorted_apply_kernel<2>, grid, block, 0, s, k_out, v_out, total, query, query_index, (int)num_neg, has_pos, dpos, dneg, upstream, pad, target); break;
+    default: hipLaunchKernelGGL(sorted_apply_kernel<4>, grid, block, 0, s, k_out, v_out, total, query, query_index, (int)num_neg, has_pos, dpos, dneg, upstream, pad, target); break;
   }
   RSA_CHECK_LAUNCH("rsa_scatter_rows_sorted(apply)");
   return RSA_OK;

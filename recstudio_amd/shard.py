@@ -94,6 +94,12 @@ class HipBackend:
         rows = torch.empty(m, dtype=torch.int64, device=keys.device)
         qidx = torch.empty(m, dtype=torch.int64, device=keys.device)
         nat.check(nat.lib().rsa_shard_unpack(ptr(keys), m, ptr(rows), ptr(qidx), ops._stream()), 'rsa_shard_unpack')
+        if item_local.shape[1] in (64, 128, 256):
+            # two atomics-free sorted scatters (by item row, then by query): reproducible, ~2x faster than atomics
+            ops.scatter_rows_sorted(item_grad_local, q_all, rows.view(m, 1), dscore.view(m, 1), query_index=qidx,
+                                    pad_row=item_pad_row)
+            ops.scatter_rows_sorted(qgrad_all, item_local, qidx.view(m, 1), dscore.view(m, 1), query_index=rows, pad_row=-1)
+            return
         ops.fused_backward(item_local, q_all, rows.view(m, 1), dscore.view(m, 1), query_index=qidx,
                            dense_item_grad=False, want_query_grad=False, item_grad_out=item_grad_local,
                            query_table_grad=qgrad_all, query_table_pad_row=-1, item_pad_row=item_pad_row)
