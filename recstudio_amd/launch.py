@@ -56,7 +56,9 @@ def main(argv=None):
             user.weight[0] = 0
         torch.manual_seed(args.seed + rank)               # each rank draws its own negatives
         table = ShardedItemTable(item_local, plan, rank, dist)
-        trainer = ShardedRetriever(table, user, ra.UniformSampler(args.items), ra.BPRLoss(), args.neg)
+        inplace = args.dim in (64, 128, 256)       # item rows updated inside the backward exchange (no dense gradient block)
+        trainer = ShardedRetriever(table, user, ra.UniformSampler(args.items), ra.BPRLoss(), args.neg,
+                                   item_sgd_lr=args.lr if inplace else None)
         data = torch.Generator(device=dev).manual_seed(args.seed + 1000 + rank)
         t0, losses = None, []
         for step in range(args.steps):
@@ -67,11 +69,13 @@ def main(argv=None):
             uid = torch.randint(1, args.users, (args.batch,), device=dev, generator=data)
             # every user keeps consuming the same handful of items: something for the model to learn
             pos = 1 + (uid * 2654435761 + torch.randint(0, 4, (args.batch,), device=dev, generator=data)) % (args.items - 1)
-            trainer.item_grad_local.zero_()
+            if not inplace:
+                trainer.item_grad_local.zero_()
             user.weight.grad = None
             loss = trainer.training_step(uid, pos)        # this rank's share of the global mean loss
             with torch.no_grad():                         # plain SGD on the owned item rows and the replica
-                item_local.add_(trainer.item_grad_local, alpha=-args.lr)
+                if not inplace:
+                    item_local.add_(trainer.item_grad_local, alpha=-args.lr)
                 user.weight.add_(user.weight.grad, alpha=-args.lr)
             if step % 10 == 0 or step == args.steps - 1:
                 total = loss.clone()
@@ -84,7 +88,7 @@ def main(argv=None):
         if rank == 0 and t0 is not None and args.steps - s0 > 0:
             dt = (time.perf_counter() - t0) / (args.steps - s0)
             print(f'{world} GPU(s): {dt * 1e3:.3f} ms/step, {world * args.batch * args.neg / dt / 1e6:.1f} M triplets/s '
-                  f'(forward + backward + SGD; dense per-shard gradient buffer)', flush=True)
+                  f'(forward + backward + SGD)', flush=True)
         return losses
     finally:
         dist.destroy_process_group()

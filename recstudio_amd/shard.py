@@ -86,8 +86,11 @@ class HipBackend:
                   'rsa_gather_f32')
         return dst
 
-    def backward_keys(self, item_local, q_all, keys, dscore, item_grad_local, qgrad_all, item_pad_row=-1):
-        """Owner side of the backward: item_grad_local[row] += d * q_all[qidx]; qgrad_all[qidx] += d * item_local[row]."""
+    def backward_keys(self, item_local, q_all, keys, dscore, item_grad_local, qgrad_all, item_pad_row=-1, item_scale=None):
+        """Owner side of the backward: item_grad_local[row] += d * q_all[qidx]; qgrad_all[qidx] += d * item_local[row].
+        ``item_scale`` (device scalar): multiply the item-side update by it -- with ``item_grad_local is item_local``
+        and item_scale = -lr this is plain SGD applied in place (the query-side pass, which reads the rows, runs
+        first)."""
         m = keys.numel()
         if m == 0:
             return
@@ -96,10 +99,12 @@ class HipBackend:
         nat.check(nat.lib().rsa_shard_unpack(ptr(keys), m, ptr(rows), ptr(qidx), ops._stream()), 'rsa_shard_unpack')
         if item_local.shape[1] in (64, 128, 256):
             # two atomics-free sorted scatters (by item row, then by query): reproducible, ~2x faster than atomics
-            ops.scatter_rows_sorted(item_grad_local, q_all, rows.view(m, 1), dscore.view(m, 1), query_index=qidx,
-                                    pad_row=item_pad_row)
             ops.scatter_rows_sorted(qgrad_all, item_local, qidx.view(m, 1), dscore.view(m, 1), query_index=rows, pad_row=-1)
+            ops.scatter_rows_sorted(item_grad_local, q_all, rows.view(m, 1), dscore.view(m, 1), query_index=qidx,
+                                    upstream=item_scale, pad_row=item_pad_row)
             return
+        if item_scale is not None:
+            raise NotImplementedError('in-place item update needs embed_dim in {64, 128, 256}')
         ops.fused_backward(item_local, q_all, rows.view(m, 1), dscore.view(m, 1), query_index=qidx,
                            dense_item_grad=False, want_query_grad=False, item_grad_out=item_grad_local,
                            query_table_grad=qgrad_all, query_table_pad_row=-1, item_pad_row=item_pad_row)
@@ -172,7 +177,7 @@ class ShardedItemTable:
         self.dist.reduce_scatter_tensor(out, x.contiguous(), group=self.group)
         return out
 
-    def backward(self, route, dpos, dneg, item_grad_local):
+    def backward(self, route, dpos, dneg, item_grad_local, item_scale=None):
         """Gradient exchange for one step.  ``route`` comes from
         ``score_ids(..., keep_route=True)``; ``dpos [B]`` / ``dneg [B, n]`` = d loss / d score on the home
         rank.  Accumulates this shard's dense item gradient into ``item_grad_local [rows_local, d]`` (no
@@ -185,8 +190,9 @@ class ShardedItemTable:
         q_all = route['q_all']
         qgrad_all = torch.zeros_like(q_all)
         # only shard 0 holds the global padding row (item id 0), which never receives gradient
+        extra = {} if item_scale is None else {'item_scale': item_scale}
         self.backend.backward_keys(self.item_local, q_all, route['recv_keys'], d_owner, item_grad_local, qgrad_all,
-                                   item_pad_row=0 if self.rank == 0 else -1)
+                                   item_pad_row=0 if self.rank == 0 else -1, **extra)
         return self._reduce_scatter_rows(qgrad_all, B)
 
     def score_ids(self, q, pos, neg, keep_route=False, q_gather=None):
@@ -272,20 +278,20 @@ class _ShardedScoreFn(torch.autograd.Function):
     ``item_grad_local`` (this rank's [rows_local, d] block of the dense table gradient)."""
 
     @staticmethod
-    def forward(ctx, q, table, pos, neg, item_grad_local):
+    def forward(ctx, q, table, pos, neg, item_grad_local, item_scale=None):
         pos_score, neg_score, route = table.score_ids(q, pos, neg, keep_route=True)
-        ctx.table, ctx.route, ctx.item_grad_local = table, route, item_grad_local
+        ctx.table, ctx.route, ctx.item_grad_local, ctx.item_scale = table, route, item_grad_local, item_scale
         ctx.mark_non_differentiable(pos, neg)
         return pos_score, neg_score
 
     @staticmethod
     def backward(ctx, gpos, gneg):
-        dq = ctx.table.backward(ctx.route, gpos.contiguous(), gneg.contiguous(), ctx.item_grad_local)
-        return dq, None, None, None, None
+        dq = ctx.table.backward(ctx.route, gpos.contiguous(), gneg.contiguous(), ctx.item_grad_local, ctx.item_scale)
+        return dq, None, None, None, None, None
 
 
-def sharded_scores(table, q, pos, neg, item_grad_local):
-    return _ShardedScoreFn.apply(q, table, pos, neg, item_grad_local)
+def sharded_scores(table, q, pos, neg, item_grad_local, item_scale=None):
+    return _ShardedScoreFn.apply(q, table, pos, neg, item_grad_local, item_scale)
 
 
 def allreduce_grads(params, dist, group=None, bucket_bytes=64 << 20):
@@ -323,10 +329,18 @@ class ShardedRetriever:
     (Sampler / PairwiseLoss); the item block ``table.item_local`` and its gradient block are plain tensors
     owned by this rank, updated by the caller's optimizer."""
 
-    def __init__(self, table, query_encoder, sampler, loss_fn, neg_count):
+    def __init__(self, table, query_encoder, sampler, loss_fn, neg_count, item_sgd_lr=None):
+        """``item_sgd_lr``: apply plain SGD with this learning rate to the owned item rows INSIDE the backward
+        exchange (sorted scatter straight into the weight block, no [rows_local, d] gradient buffer to zero, fill
+        and add); the caller then only steps the query tower."""
         self.table, self.query_encoder, self.sampler, self.loss_fn = table, query_encoder, sampler, loss_fn
         self.neg_count = int(neg_count)
-        self.item_grad_local = torch.zeros_like(table.item_local)
+        self.item_scale = None
+        if item_sgd_lr is None:
+            self.item_grad_local = torch.zeros_like(table.item_local)
+        else:
+            self.item_grad_local = table.item_local
+            self.item_scale = torch.full((1,), -float(item_sgd_lr), dtype=torch.float32, device=table.item_local.device)
 
     def training_step(self, query_feat, pos_items, label=None):
         """Returns this rank's share of the global mean loss (local mean / world size) after running backward:
@@ -337,7 +351,7 @@ class ShardedRetriever:
         q = self.query_encoder(query_feat)
         B = pos_items.numel()
         log_pos, neg, log_neg = table.backend.sample(self.sampler, B, self.neg_count, q.device, pos_items)
-        pos_score, neg_score = sharded_scores(table, q, pos_items, neg, self.item_grad_local)
+        pos_score, neg_score = sharded_scores(table, q, pos_items, neg, self.item_grad_local, self.item_scale)
         loss = self.loss_fn(label, pos_score, log_pos, neg_score, log_neg) / world
         loss.backward()
         allreduce_grads(self.query_encoder.parameters(), table.dist, table.group)

@@ -181,3 +181,37 @@ def test_launch_entry_point_world1_loss_decreases():
     losses = launch.main(['--items', '2001', '--users', '301', '--dim', '64', '--neg', '16', '--batch', '512',
                           '--steps', '61', '--lr', '100.0'])
     assert losses[0] == pytest.approx(0.6931, abs=2e-3) and losses[-1] < losses[0] - 0.05
+
+
+def test_world1_rccl_inplace_item_sgd_equals_dense_gradient_step():
+    """ShardedRetriever(item_sgd_lr=lr): the item rows updated inside the backward exchange == weights minus lr
+    times the dense item gradient of the same step (same seed, hence the same negatives)."""
+    import torch.distributed as dist
+    import recstudio_amd as ra
+    from recstudio_amd.shard import RowShardPlan, ShardedItemTable, ShardedRetriever
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(_free_port())
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+    try:
+        torch.manual_seed(4)
+        N, U, d, B, n, lr = 9001, 200, 64, 150, 8, 0.3
+        item0 = torch.randn(N, d, device=DEV) * 0.2
+        item0[0] = 0
+        uid = torch.randint(1, U, (B,), device=DEV)
+        pos = torch.randint(1, N, (B,), device=DEV)
+        results = []
+        for inplace in (False, True):
+            item = item0.clone()
+            tower = torch.nn.Embedding(U, d).to(DEV)
+            with torch.no_grad():
+                tower.weight.copy_(torch.linspace(-1, 1, U * d, device=DEV).view(U, d))
+            table = ShardedItemTable(item, RowShardPlan(N, 1), 0, dist)
+            trainer = ShardedRetriever(table, tower, ra.UniformSampler(N), ra.BPRLoss(), n, item_sgd_lr=lr if inplace else None)
+            torch.manual_seed(99)
+            trainer.training_step(uid, pos)
+            results.append(item if inplace else item - lr * trainer.item_grad_local)
+            results.append(tower.weight.grad.clone())
+        np.testing.assert_allclose(results[2].cpu(), results[0].cpu(), rtol=1e-5, atol=1e-7)
+        np.testing.assert_allclose(results[3].cpu(), results[1].cpu(), rtol=1e-5, atol=1e-7)
+    finally:
+        dist.destroy_process_group()
