@@ -57,11 +57,24 @@ class _ScoreFn(torch.autograd.Function):
             gpos = torch.zeros(pos_ids.numel(), dtype=torch.float32, device=item_weight.device)
         # dense user-table gradient straight from the kernel (no [M, d] intermediate, no second launch)
         qtab = torch.zeros_like(query_src) if (need_q and qi is not None and not sparse) else None
-        item_grad, rows, qgrad = ops.fused_backward(
-            item_weight, query_src, neg_ids, gneg.contiguous(), query_index=qi, pos_ids=pos_ids,
-            dpos=None if pos_ids is None else gpos.contiguous(),
-            dense_item_grad=need_item and not sparse, row_item_grad=need_item and sparse,
-            want_query_grad=need_q and qtab is None, query_table_grad=qtab, cosine=cfg.get('cosine', False))
+        # dense item gradient of the inner-product scorer: sorted atomics-free scatter (rsa_scatter_rows_sorted) next to
+        # a backward launch that only produces the query gradient; other cases: the backward kernel's own scatter
+        cos = cfg.get('cosine', False)
+        sorted_dense = (need_item and not sparse and (cos is False or cos == nat.SCORE_IP)
+                        and item_weight.shape[1] in (64, 128, 256) and neg_ids.shape[1] % 64 == 0)
+        item_grad = rows = qgrad = None
+        gneg_c = gneg.contiguous()
+        gpos_c = None if pos_ids is None else gpos.contiguous()
+        if sorted_dense:
+            item_grad = ops.scatter_rows_sorted(torch.zeros_like(item_weight), query_src, neg_ids, gneg_c, query_index=qi,
+                                                pos_ids=pos_ids, dpos=gpos_c, pad_row=0)
+        if not sorted_dense or need_q:
+            ig, rows, qgrad = ops.fused_backward(
+                item_weight, query_src, neg_ids, gneg_c, query_index=qi, pos_ids=pos_ids, dpos=gpos_c,
+                dense_item_grad=need_item and not sparse and not sorted_dense, row_item_grad=need_item and sparse,
+                want_query_grad=need_q and qtab is None, query_table_grad=qtab, cosine=cos)
+            if not sorted_dense:
+                item_grad = ig
         g_item = None
         if need_item:
             if sparse:
