@@ -426,3 +426,23 @@ def test_sorted_scatter_equals_atomic_backward_and_is_reproducible(ra, d):
     want.index_add_(0, neg.reshape(-1), (dneg.double().unsqueeze(-1) * q.unsqueeze(1)).reshape(-1, d))
     want[0] = 0
     np.testing.assert_allclose(a.cpu(), (want * 0.37).float().cpu(), rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize('M,n,with_pos', [(1, 1, True), (3, 5, False), (130, 7, True), (64, 1, False)])
+def test_sorted_scatter_small_and_ragged_shapes(ra, M, n, with_pos):
+    torch.manual_seed(M * 10 + n)
+    N, U, d = 37, 20, 128
+    user = torch.randn(U, d, device=DEV)
+    uid = torch.randint(0, U, (M,), device=DEV)
+    pos = torch.randint(0, N, (M,), device=DEV) if with_pos else None
+    neg = torch.randint(0, N, (M, n), device=DEV)
+    dpos = torch.randn(M, device=DEV) if with_pos else None
+    dneg = torch.randn(M, n, device=DEV)
+    got = ra.ops.scatter_rows_sorted(torch.ones(N, d, device=DEV), user, neg, dneg, query_index=uid, pos_ids=pos, dpos=dpos,
+                                     pad_row=-1)
+    q = user[uid].double()
+    want = torch.ones(N, d, dtype=torch.float64, device=DEV)
+    if with_pos:
+        want.index_add_(0, pos, dpos.double().unsqueeze(1) * q)
+    want.index_add_(0, neg.reshape(-1), (dneg.double().unsqueeze(-1) * q.unsqueeze(1)).reshape(-1, d))
+    np.testing.assert_allclose(got.cpu(), want.float().cpu(), rtol=1e-5, atol=1e-5)
