@@ -132,7 +132,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=200)
-    ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=50)
     ap.add_argument('--items', type=int, default=10_000_001)
     ap.add_argument('--users', type=int, default=1_000_001)
     ap.add_argument('--dim', type=int, default=128)

@@ -252,6 +252,9 @@ __device__ __forceinline__ float finish_score(int mode, float dot, float inorm2,
   return dot;
 }
 
+#ifndef RSA_FWD_GRID_CAP
+#define RSA_FWD_GRID_CAP (256 * 8)
+#endif
 #ifndef RSA_QG_MIN_WAVES
 #define RSA_QG_MIN_WAVES 1
 #endif
@@ -535,7 +538,7 @@ template <int LPR, bool GENERIC>
 static int launch_fwd(const FwdParams& p, bool cos, bool qu, hipStream_t stream) {
   const int64_t n_tiles = (p.numel + 63) >> 6;
   int64_t blocks = (n_tiles + 3) / 4;
-  if (blocks > 256 * 8) blocks = 256 * 8;
+  if (blocks > RSA_FWD_GRID_CAP) blocks = RSA_FWD_GRID_CAP;
   if (blocks < 1) blocks = 1;
   dim3 grid((unsigned)blocks), block(256);
   if (cos) {
