@@ -77,6 +77,58 @@ def test_guide_table_returns_searchsorted_index(golden, glog):
     assert np.array_equal(got, np.minimum(oracle.searchsorted_left(t, u), len(t) - 1))
 
 
+def lookup_with_lut(lut, table, pop_prob, glog, u):
+    """numpy model of rsa::cdf_lookup_lut (rsa_common.hpp): one self-contained entry per bucket, a 4-wide probe for
+    buckets with two or more boundaries, binary search beyond that.  Returns (ids, probabilities)."""
+    K = 1 << glog
+    last = len(table) - 1
+    x = lut[:, 0].view(np.uint32)
+    ids = np.empty(len(u), dtype=np.int64)
+    pr = np.empty(len(u), dtype=np.float32)
+    for i, ui in enumerate(u):
+        b = int(np.clip(np.int64(ui * np.float32(K)), 0, K - 1))
+        lo = int(x[b] & 0x7fffffff)
+        if not (x[b] & 0x80000000):
+            up = bool(lut[b, 1] < ui)
+            ids[i], pr[i] = min(lo + up, last), (lut[b, 3] if up else lut[b, 2])
+            continue
+        cnt = sum(1 for k in range(4) if lo + k <= last and table[lo + k] < ui)
+        if cnt < 4:
+            lo = min(lo + cnt, last)
+        else:
+            lo, hi = lo + 4, int(x[b + 1] & 0x7fffffff)
+            while lo < hi:
+                mid = lo + ((hi - lo) >> 1)
+                if table[mid] < ui:
+                    lo = mid + 1
+                else:
+                    hi = mid
+            lo = min(lo, last)
+        ids[i], pr[i] = lo, pop_prob[lo]
+    return ids, pr
+
+
+@pytest.mark.parametrize('glog', [2, 6, 11, 16])
+def test_direct_lookup_table_returns_searchsorted_index_and_probability(golden, glog):
+    """The host-built LUT (sampler._register_pairs) through a numpy model of the device lookup: fine guides hit
+    the direct entries, coarse ones the probe and the binary-search tail; ids == searchsorted, probabilities ==
+    pop_prob[id], incl. uniforms on and next to every CDF value."""
+    from recstudio_amd import PopularSamplerModel
+    g = golden('popular')
+    for mode in (0, 2):
+        ps = PopularSamplerModel.from_tables(T(g[f'm{mode}_pop_prob']), T(g[f'm{mode}_table']), glog)
+        t, p = ps.table.numpy(), ps.pop_prob.numpy()
+        lut = ps.cdf_lut.numpy()
+        assert lut.shape == ((1 << glog) + 1, 4)
+        u = np.concatenate([g[f'm{mode}_u'], t, np.nextafter(t, np.float32(0)), np.nextafter(t, np.float32(2)),
+                            np.random.default_rng(glog).random(4000, dtype=np.float32)]).astype(np.float32)
+        u = u[(u >= 0) & (u < 1)]
+        ids, pr = lookup_with_lut(lut, t, p, glog, u)
+        want = np.minimum(oracle.searchsorted_left(t, u), len(t) - 1)
+        assert np.array_equal(ids, want)
+        assert np.array_equal(pr, p[want])
+
+
 def test_popular_sampler_tables_equal_reference_buffers(golden):
     from recstudio_amd import PopularSamplerModel
     g = golden('popular')
@@ -109,6 +161,18 @@ def test_plugin_signatures_match_reference():
         assert list(inspect.signature(cls.forward).parameters) == ['self', 'query', 'items']
     assert issubclass(ra.CosineScorer, ra.InnerProductScorer)
     assert ra.UniformSampler(1575).num_items == 1574
+    for cls in (ra.WeightedBPRLoss, ra.WeightedBinaryCrossEntropyLoss, ra.HingeLoss, ra.NCELoss, ra.CCLLoss, ra.InfoNCELoss):
+        assert issubclass(cls, ra.PairwiseLoss)
+        assert list(inspect.signature(cls.forward).parameters) == ['self', 'label', 'pos_score', 'log_pos_prob', 'neg_score', 'log_neg_prob']
+    assert issubclass(ra.InfoNCELoss, ra.SampledSoftmaxLoss) and issubclass(ra.WeightedBinaryCrossEntropyLoss, ra.BinaryCrossEntropyLoss)
+    assert list(inspect.signature(ra.HingeLoss.__init__).parameters) == ['self', 'margin', 'num_items']
+    assert list(inspect.signature(ra.CCLLoss.__init__).parameters) == ['self', 'margin', 'neg_weight']
+    for cls in (ra.EuclideanScorer, ra.NormScorer, ra.GMFScorer):
+        assert issubclass(cls, ra.InnerProductScorer)
+    assert list(inspect.signature(ra.GMFScorer.__init__).parameters) == ['self', 'emb_dim', 'bias', 'activation']
+    assert list(inspect.signature(ra.RetrieverSampler.__init__).parameters) == ['self', 'num_items', 'retriever', 'method', 't']
+    assert list(inspect.signature(ra.RetrieverSampler.forward).parameters) == ['self', 'batch', 'num_neg', 'pos_items', 'excluding_hist']
+    assert list(inspect.signature(ra.BaseRetriever.sampling).parameters) == ['self', 'batch', 'num_neg', 'method', 'excluding_hist', 't', 'return_query', 'query']
 
 
 def test_cpu_tensors_are_rejected():

@@ -51,11 +51,12 @@ class CheckerBackend:
     def gather(self, src, positions):
         return src[positions]
 
-    def backward_keys(self, item_local, q_all, keys, dscore, item_grad_local, qgrad_all, item_pad_row=-1):
+    def backward_keys(self, item_local, q_all, keys, dscore, item_grad_local, qgrad_all, item_pad_row=-1, item_scale=None):
         rows, qidx = keys & 0xffffffff, keys >> 32
         live = rows != item_pad_row
-        item_grad_local.index_add_(0, rows[live], dscore[live].unsqueeze(1) * q_all[qidx[live]])
-        qgrad_all.index_add_(0, qidx, dscore.unsqueeze(1) * item_local[rows])
+        qgrad_all.index_add_(0, qidx, dscore.unsqueeze(1) * item_local[rows])       # reads the rows: first
+        scale = 1.0 if item_scale is None else float(item_scale)
+        item_grad_local.index_add_(0, rows[live], scale * dscore[live].unsqueeze(1) * q_all[qidx[live]])
 
 
     def full_partial(self, item_local, q_all, k, want_lse, has_pad_row):
@@ -190,6 +191,18 @@ def _train_worker(rank, world, port, n_items, d, B, n, result_dir):
             return -torch.mean(torch.nn.functional.logsigmoid(pos_score.view(-1, 1) - neg_score).mean(-1))
         trainer = ShardedRetriever(table, tower, oracle.UniformSampler(n_items), bpr, n)
         loss = trainer.training_step(feats[rank], poss[rank])
+        # the same step with the item rows updated in place inside the exchange (item_sgd_lr)
+        table2 = ShardedItemTable(item[lo:hi].clone(), plan, rank, dist, backend=CheckerBackend())
+        tower2 = torch.nn.Linear(8, d)
+        with torch.no_grad():
+            tower2.weight.copy_(tower_w)
+            tower2.bias.zero_()
+        torch.manual_seed(40 + rank)
+        trainer2 = ShardedRetriever(table2, tower2, oracle.UniformSampler(n_items), bpr, n, item_sgd_lr=0.7)
+        trainer2.training_step(feats[rank], poss[rank])
+        np.testing.assert_allclose(table2.item_local.numpy(), (item[lo:hi] - 0.7 * trainer.item_grad_local).numpy(),
+                                   rtol=1e-5, atol=1e-7)
+        np.testing.assert_allclose(tower2.weight.grad.numpy(), tower.weight.grad.numpy(), rtol=1e-5, atol=1e-7)
         # single-process reference on the concatenated batch with the SAME negatives
         negs = [torch.zeros(B, n, dtype=torch.int64) for _ in range(world)]
         dist.all_gather(negs, trainer.last_neg)
