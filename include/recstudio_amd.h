@@ -6,8 +6,10 @@
  * is a DEVICE pointer unless stated otherwise, `stream` is a hipStream_t
  * passed as void*.  Every entry point returns 0 on success or a negative
  * rsa_status; rsa_last_error() returns the thread-local message of the last
- * failure.  No entry point synchronises or allocates caller-visible memory (the library keeps one
- * 1 KB device scratch for deterministic partial sums, allocated on first use).
+ * failure.  No entry point synchronises or allocates caller-visible memory (the library keeps three tiny
+ * device scratch blocks of its own, allocated on first use: partial sums of rsa_mean_rows, the valid-row
+ * counter of the BCE losses, the arrival counter + per-workgroup partials of the fused loss reduction --
+ * calls that use them must not run concurrently on different streams).
  *
  * The reference (ustcml/RecStudio) is pure Python on PyTorch; it has no native
  * boundary of its own.  Each entry point below therefore replaces a SEQUENCE
@@ -27,7 +29,9 @@
 extern "C" {
 #endif
 
-#define RSA_ABI_VERSION 2   /* 2: rsa_fused_args grew query_grad + packed_keys; rsa_row_topk, rsa_fullscore_softmax */
+#define RSA_ABI_VERSION 2   /* 2: rsa_fused_args grew query_grad, packed_keys, offset_dev; new entry points
+                               (rsa_row_topk, rsa_fullscore_softmax, rsa_pairwise_loss_ex, rsa_scatter_rows_sorted,
+                               rsa_rng_advance) */
 
 typedef void* rsa_stream_t; /* hipStream_t */
 

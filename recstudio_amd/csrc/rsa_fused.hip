@@ -214,7 +214,7 @@ __device__ __forceinline__ void tile_rows_qg(const float* __restrict__ table, in
                                              float4& qacc) {
   using F = Frag<LPR, false>;
   constexpr int D = LPR * 4;
-  constexpr int BATCH = LPR < 8 ? LPR : 8;
+  constexpr int BATCH = LPR < RSA_QG_BATCH ? LPR : RSA_QG_BATCH;
   constexpr int NB = LPR / BATCH;
   const int lane = lane_id();
   const int sub = lane % LPR;
@@ -252,6 +252,9 @@ __device__ __forceinline__ float finish_score(int mode, float dot, float inorm2,
   return dot;
 }
 
+#ifndef RSA_QG_BATCH
+#define RSA_QG_BATCH 8
+#endif
 #ifndef RSA_FWD_GRID_CAP
 #define RSA_FWD_GRID_CAP (256 * 8)
 #endif
