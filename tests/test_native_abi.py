@@ -61,3 +61,10 @@ def test_missing_library_fails_loudly(nat, monkeypatch):
     monkeypatch.setattr(nat, '_lib', None)
     with pytest.raises(RuntimeError, match='no CPU fallback'):
         nat.lib()
+
+
+def test_graft_entry_build_runs():
+    """The driver's build check: __graft_entry__.build() compiles (a no-op when up to date), loads the library and
+    imports the package."""
+    import __graft_entry__ as g
+    g.build()
