@@ -254,6 +254,18 @@ def main():
             user.copy_(uw0)
             del iw0, uw0
             extra['train_step']['sgd_step_ms'] = round(t_sgd, 4)
+            # complete lazy-Adam step (torch.optim.SparseAdam's rule) on the same machinery
+            from recstudio_amd.fused import FusedBPRAdam
+            iw0, uw0 = item.clone(), user.clone()
+            fa = FusedBPRAdam(item, user, lr=1e-3)
+            t_adam = time_gpu(lambda: fa.step(n, user_ids=uid, pos_ids=pos, sampler=sampler), max(10, args.steps // 4), 3) * 1e3
+            item.copy_(iw0)
+            user.copy_(uw0)
+            del iw0, uw0, fa
+            torch.cuda.empty_cache()
+            extra['train_step']['adam_step_ms'] = round(t_adam, 4)
+            extra['train_step']['adam_step_what'] = ('forward + BPR loss + lazy Adam (SparseAdam rule) on the touched item '
+                                                     'and user rows, gradient sums kept in registers (no gradient tensor)')
             extra['train_step']['sgd_step_what'] = ('forward + BPR loss + SGD update of the touched item and user rows '
                                                     'applied in place by the kernels (no [N, d] gradient tensor)')
         except Exception as e:      # never let the secondary figure kill the bench line

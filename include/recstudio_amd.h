@@ -276,6 +276,18 @@ int rsa_scatter_rows_sorted(const float* query, const int64_t* query_index, int6
                             int64_t pad_row, float* target, void* workspace, int64_t workspace_bytes,
                             rsa_stream_t stream);
 
+/* The same sorted pass with a LAZY ADAM update of every touched row instead of the accumulate (the update rule of
+ * torch.optim.SparseAdam on the coalesced gradient g[id] = upstream * sum_e d_e * query[qrow_e]):
+ *     m += (g - m)(1 - beta1);  v += (g^2 - v)(1 - beta2);  weight -= lr * sqrt(1 - beta2^step) / (1 - beta1^step) * m / (sqrt(v) + eps)
+ * exp_avg / exp_avg_sq: [n_items, dim] optimizer state, updated in place; rows not in the step are untouched (lazy).
+ * The row sums never leave registers: no gradient tensor, no coalesce pass.  step >= 1 is the 1-based step count. */
+int rsa_adam_rows_sorted(const float* query, const int64_t* query_index, int64_t n_query_rows, int32_t dim,
+                         const int64_t* pos_ids, const int64_t* neg_ids, int64_t n_queries, int32_t num_neg,
+                         const float* dpos, const float* dneg, const float* upstream, int64_t n_items,
+                         int64_t pad_row, float* weight, float* exp_avg, float* exp_avg_sq, float lr, float beta1,
+                         float beta2, float eps, int64_t step, void* workspace, int64_t workspace_bytes,
+                         rsa_stream_t stream);
+
 /* embedding_dense_backward: dst[ids[i]] += src[i] for ids != 0 (padding_idx=0).
  * Used for the user-table gradient.  dst [n_rows, dim] caller-zeroed. */
 int rsa_scatter_add_rows(const float* src, const int64_t* ids, int64_t numel, int32_t dim,

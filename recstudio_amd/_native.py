@@ -85,6 +85,9 @@ SIGNATURES = {
     'rsa_scatter_rows_sorted_workspace_bytes': (c_int64, [c_int64, c_int32, c_int64]),
     'rsa_scatter_rows_sorted': (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_int64, c_int32, c_void_p,
                                         c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_void_p]),
+    'rsa_adam_rows_sorted': (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_int64, c_int32, c_void_p,
+                                     c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_float, c_float,
+                                     c_float, c_float, c_int64, c_void_p, c_int64, c_void_p]),
     'rsa_rng_advance': (c_int, [c_void_p, c_uint64, c_void_p]),
     'rsa_row_topk': (c_int, [c_void_p, c_int64, c_int64, c_int32, c_void_p, c_void_p, c_void_p]),
     'rsa_topk_mask_history': (c_int, [c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_int64, c_int32, c_void_p,

@@ -33,6 +33,12 @@ __global__ __launch_bounds__(256) void sorted_keys_kernel(const int64_t* __restr
   }
 }
 
+struct AdamArgs {            // exp_avg == nullptr: plain accumulate (target[id] += scale * sum)
+  float* exp_avg;
+  float* exp_avg_sq;
+  float one_minus_beta1, one_minus_beta2, eps, step_size;
+};
+
 // One wave per chunk of 64 sorted elements; a run of equal ids belongs to the wave that holds its first element.
 template <int NDW>   // dwords per lane per row: D = 64 * NDW
 __global__ __launch_bounds__(256) void sorted_apply_kernel(const int32_t* __restrict__ keys, const int32_t* __restrict__ vals,
@@ -40,7 +46,7 @@ __global__ __launch_bounds__(256) void sorted_apply_kernel(const int32_t* __rest
                                                            const int64_t* __restrict__ query_index, int n, int has_pos,
                                                            const float* __restrict__ dpos, const float* __restrict__ dneg,
                                                            const float* __restrict__ upstream, int32_t pad_row,
-                                                           float* __restrict__ target) {
+                                                           float* __restrict__ target, AdamArgs adam) {
   constexpr int D = 64 * NDW;
   const int lane = lane_id();
   const int64_t chunk = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -69,8 +75,26 @@ __global__ __launch_bounds__(256) void sorted_apply_kernel(const int32_t* __rest
   auto flush = [&]() {
     if (cur >= 0 && cur != pad_row) {
       float* row = target + (size_t)cur * D;
+      if (adam.exp_avg == nullptr) {
 #pragma unroll
-      for (int k = 0; k < NDW; ++k) row[k * 64 + lane] += scale * acc[k];
+        for (int k = 0; k < NDW; ++k) row[k * 64 + lane] += scale * acc[k];
+      } else {
+        // lazy Adam on the touched row (torch.optim.SparseAdam's update, torch/optim/_functional.py sparse_adam):
+        // m += (g - m)(1 - b1); v += (g^2 - v)(1 - b2); w -= step_size * m / (sqrt(v) + eps)
+        float* mrow = adam.exp_avg + (size_t)cur * D;
+        float* vrow = adam.exp_avg_sq + (size_t)cur * D;
+#pragma unroll
+        for (int k = 0; k < NDW; ++k) {
+          const int c = k * 64 + lane;
+          const float g = scale * acc[k];
+          const float m0 = mrow[c], v0 = vrow[c];
+          const float m1 = m0 + (g - m0) * adam.one_minus_beta1;
+          const float v1 = v0 + (g * g - v0) * adam.one_minus_beta2;
+          mrow[c] = m1;
+          vrow[c] = v1;
+          row[c] -= adam.step_size * (m1 / (sqrtf(v1) + adam.eps));
+        }
+      }
     }
 #pragma unroll
     for (int k = 0; k < NDW; ++k) acc[k] = 0.f;
@@ -133,11 +157,11 @@ extern "C" int64_t rsa_scatter_rows_sorted_workspace_bytes(int64_t n_queries, in
   return 4 * align256s(total * 4) + align256s((int64_t)sort_temp_bytes(total, key_bits(n_items))) + 256;
 }
 
-extern "C" int rsa_scatter_rows_sorted(const float* query, const int64_t* query_index, int64_t n_query_rows, int32_t dim,
-                                       const int64_t* pos_ids, const int64_t* neg_ids, int64_t n_queries,
-                                       int32_t num_neg, const float* dpos, const float* dneg, const float* upstream,
-                                       int64_t n_items, int64_t pad_row, float* target, void* workspace,
-                                       int64_t workspace_bytes, rsa_stream_t stream) {
+static int scatter_sorted_impl(const float* query, const int64_t* query_index, int64_t n_query_rows, int32_t dim,
+                               const int64_t* pos_ids, const int64_t* neg_ids, int64_t n_queries, int32_t num_neg,
+                               const float* dpos, const float* dneg, const float* upstream, int64_t n_items,
+                               int64_t pad_row, float* target, AdamArgs adam, void* workspace, int64_t workspace_bytes,
+                               rsa_stream_t stream) {
   RSA_CHECK_ARG(n_queries >= 0 && num_neg >= 1 && n_items >= 1 && n_items < (1ll << 31), "rsa_scatter_rows_sorted: bad sizes");
   if (n_queries == 0) return RSA_OK;
   RSA_CHECK_ARG(query && neg_ids && dneg && target, "rsa_scatter_rows_sorted: null pointer");
@@ -176,10 +200,34 @@ extern "C" int rsa_scatter_rows_sorted(const float* query, const int64_t* query_
   dim3 grid((chunks + 3) / 4), block(256);
   const int32_t pad = (int32_t)(pad_row < 0 || pad_row >= (1ll << 31) ? -2 : pad_row);
   switch (dim) {
-    case 64: hipLaunchKernelGGL(sorted_apply_kernel<1>, grid, block, 0, s, k_out, v_out, total, query, query_index, (int)num_neg, has_pos, dpos, dneg, upstream, pad, target); break;
-    case 128: hipLaunchKernelGGL(sorted_apply_kernel<2>, grid, block, 0, s, k_out, v_out, total, query, query_index, (int)num_neg, has_pos, dpos, dneg, upstream, pad, target); break;
-    default: hipLaunchKernelGGL(sorted_apply_kernel<4>, grid, block, 0, s, k_out, v_out, total, query, query_index, (int)num_neg, has_pos, dpos, dneg, upstream, pad, target); break;
+    case 64: hipLaunchKernelGGL(sorted_apply_kernel<1>, grid, block, 0, s, k_out, v_out, total, query, query_index, (int)num_neg, has_pos, dpos, dneg, upstream, pad, target, adam); break;
+    case 128: hipLaunchKernelGGL(sorted_apply_kernel<2>, grid, block, 0, s, k_out, v_out, total, query, query_index, (int)num_neg, has_pos, dpos, dneg, upstream, pad, target, adam); break;
+    default: hipLaunchKernelGGL(sorted_apply_kernel<4>, grid, block, 0, s, k_out, v_out, total, query, query_index, (int)num_neg, has_pos, dpos, dneg, upstream, pad, target, adam); break;
   }
   RSA_CHECK_LAUNCH("rsa_scatter_rows_sorted(apply)");
   return RSA_OK;
+}
+
+extern "C" int rsa_scatter_rows_sorted(const float* query, const int64_t* query_index, int64_t n_query_rows, int32_t dim,
+                                       const int64_t* pos_ids, const int64_t* neg_ids, int64_t n_queries,
+                                       int32_t num_neg, const float* dpos, const float* dneg, const float* upstream,
+                                       int64_t n_items, int64_t pad_row, float* target, void* workspace,
+                                       int64_t workspace_bytes, rsa_stream_t stream) {
+  const AdamArgs none{nullptr, nullptr, 0.f, 0.f, 0.f, 0.f};
+  return scatter_sorted_impl(query, query_index, n_query_rows, dim, pos_ids, neg_ids, n_queries, num_neg, dpos, dneg,
+                             upstream, n_items, pad_row, target, none, workspace, workspace_bytes, stream);
+}
+
+extern "C" int rsa_adam_rows_sorted(const float* query, const int64_t* query_index, int64_t n_query_rows, int32_t dim,
+                                    const int64_t* pos_ids, const int64_t* neg_ids, int64_t n_queries, int32_t num_neg,
+                                    const float* dpos, const float* dneg, const float* upstream, int64_t n_items,
+                                    int64_t pad_row, float* weight, float* exp_avg, float* exp_avg_sq, float lr,
+                                    float beta1, float beta2, float eps, int64_t step, void* workspace,
+                                    int64_t workspace_bytes, rsa_stream_t stream) {
+  RSA_CHECK_ARG(exp_avg && exp_avg_sq && step >= 1 && beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f,
+                "rsa_adam_rows_sorted: bad optimizer state / hyper-parameters");
+  const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+  const AdamArgs adam{exp_avg, exp_avg_sq, 1.f - beta1, 1.f - beta2, eps, (float)((double)lr * sqrt(bc2) / bc1)};
+  return scatter_sorted_impl(query, query_index, n_query_rows, dim, pos_ids, neg_ids, n_queries, num_neg, dpos, dneg,
+                             upstream, n_items, pad_row, weight, adam, workspace, workspace_bytes, stream);
 }

@@ -264,3 +264,45 @@ def bpr_sgd_step(item_weight, user_weight, num_neg, lr, *, user_ids, pos_ids, sa
                                upstream=step, dense_item_grad=True, item_grad_out=iw, want_query_grad=False)
         ops.scatter_add_rows(out['query_grad'] * step, user_ids, uw.shape[0], out=uw)
     return out['loss'], out['neg_ids']
+
+
+class FusedBPRAdam:
+    """Complete lazy-Adam training step of a BPR two-tower model (nn.Embedding user and item tables) without
+    gradient tensors: the forward samples, scores, evaluates BPRLoss and accumulates the user-row gradients;
+    ``rsa_adam_rows_sorted`` sorts the step's (item id, element) pairs, sums every touched row's gradient in
+    registers and applies torch.optim.SparseAdam's update to that row of (weight, exp_avg, exp_avg_sq); the user
+    rows go through the same kernel with the accumulated row gradients.  Equal (up to fp32 summation order) to
+    ``loss.backward()`` with sparse embeddings + ``torch.optim.SparseAdam.step()`` -- whose coalesce pass alone
+    takes 16 ms at B = 65 536, n = 64 -- and untouched rows keep their state (lazy)."""
+
+    def __init__(self, item_weight, user_weight, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+        self.iw, self.uw = item_weight.data, user_weight.data
+        if self.iw.shape[1] not in (64, 128, 256):
+            raise NotImplementedError('FusedBPRAdam: embed_dim must be 64, 128 or 256')
+        self.lr, self.betas, self.eps, self.t = float(lr), betas, float(eps), 0
+        self.state = {k: torch.zeros_like(w) for k, w in (('im', self.iw), ('iv', self.iw), ('um', self.uw), ('uv', self.uw))}
+
+    def step(self, num_neg, *, user_ids, pos_ids, sampler=None, neg_ids=None):
+        """One step; returns (loss, neg_ids).  num_neg % 64 == 0."""
+        M = user_ids.numel()
+        kind = _sampler_kind(sampler) if sampler is not None else nat.SAMPLER_GIVEN
+        if kind is None:
+            raise TypeError(f'fused path does not cover sampler {type(sampler).__name__}')
+        kw = {}
+        if kind == nat.SAMPLER_GIVEN:
+            kw['neg_ids'] = neg_ids.reshape(M, -1)
+        elif kind == nat.SAMPLER_POPULAR:
+            kw.update(table=sampler.table, pop_prob=sampler.pop_prob, guide=sampler.guide, guide_log2=sampler.guide_log2,
+                      table_prob=getattr(sampler, 'table_prob', None), cdf_lut=getattr(sampler, 'cdf_lut', None))
+        self.t += 1
+        st = self.state
+        with torch.no_grad():
+            out = ops.fused_forward(self.iw, self.uw, num_neg, query_index=user_ids, pos_ids=pos_ids, sampler=kind,
+                                    want_logp=False, fused_bpr=True, want_query_grad=True, **kw)
+            hp = dict(lr=self.lr, betas=self.betas, eps=self.eps, step=self.t)
+            # item rows first: their gradient needs the pre-update user rows (the user gradient is already complete)
+            ops.adam_rows_sorted(self.iw, st['im'], st['iv'], self.uw, out['neg_ids'], out['dneg'], query_index=user_ids,
+                                 pos_ids=pos_ids, dpos=out['dpos'], pad_row=0, **hp)
+            ones = torch.ones(M, 1, dtype=torch.float32, device=self.iw.device)
+            ops.adam_rows_sorted(self.uw, st['um'], st['uv'], out['query_grad'], user_ids.view(M, 1), ones, pad_row=0, **hp)
+        return out['loss'], out['neg_ids']

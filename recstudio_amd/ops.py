@@ -456,3 +456,29 @@ def scatter_rows_sorted(target, query, neg_ids, dneg, *, query_index=None, pos_i
                                                 M, n, ptr(dpos), ptr(dneg), ptr(upstream), n_items, int(pad_row), ptr(target),
                                                 ptr(ws), ws_bytes, _stream()), 'rsa_scatter_rows_sorted')
     return target
+
+
+def adam_rows_sorted(weight, exp_avg, exp_avg_sq, query, neg_ids, dneg, *, lr, betas=(0.9, 0.999), eps=1e-8, step=1,
+                     query_index=None, pos_ids=None, dpos=None, upstream=None, pad_row=0):
+    """rsa_adam_rows_sorted: lazy Adam (torch.optim.SparseAdam's rule) on the rows touched by the step, from the
+    factored gradient (ids, coefficients, query rows) -- no gradient tensor."""
+    weight = _need(weight, torch.float32, 'weight')
+    exp_avg = _need(exp_avg, torch.float32, 'exp_avg')
+    exp_avg_sq = _need(exp_avg_sq, torch.float32, 'exp_avg_sq')
+    query = _need(query, torch.float32, 'query')
+    neg_ids = _need(neg_ids, torch.int64, 'neg_ids')
+    dneg = _need(dneg, torch.float32, 'dneg')
+    query_index = _need_opt(query_index, torch.int64, 'query_index')
+    pos_ids = _need_opt(pos_ids, torch.int64, 'pos_ids')
+    dpos = _need_opt(dpos, torch.float32, 'dpos')
+    upstream = _need_opt(upstream, torch.float32, 'upstream')
+    n_items, dim = weight.shape
+    M = query_index.numel() if query_index is not None else query.shape[0]
+    n = neg_ids.numel() // M
+    ws_bytes = int(nat.lib().rsa_scatter_rows_sorted_workspace_bytes(M, n, n_items))
+    ws = torch.empty(max(ws_bytes, 8), dtype=torch.uint8, device=weight.device)
+    nat.check(nat.lib().rsa_adam_rows_sorted(ptr(query), ptr(query_index), query.shape[0], dim, ptr(pos_ids), ptr(neg_ids), M, n,
+                                             ptr(dpos), ptr(dneg), ptr(upstream), n_items, int(pad_row), ptr(weight),
+                                             ptr(exp_avg), ptr(exp_avg_sq), float(lr), float(betas[0]), float(betas[1]),
+                                             float(eps), int(step), ptr(ws), ws_bytes, _stream()), 'rsa_adam_rows_sorted')
+    return weight

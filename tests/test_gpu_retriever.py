@@ -446,3 +446,36 @@ def test_sorted_scatter_small_and_ragged_shapes(ra, M, n, with_pos):
         want.index_add_(0, pos, dpos.double().unsqueeze(1) * q)
     want.index_add_(0, neg.reshape(-1), (dneg.double().unsqueeze(-1) * q.unsqueeze(1)).reshape(-1, d))
     np.testing.assert_allclose(got.cpu(), want.float().cpu(), rtol=1e-5, atol=1e-5)
+
+
+def test_fused_adam_step_equals_sparse_grads_plus_torch_sparse_adam(ra):
+    """fused.FusedBPRAdam (no gradient tensors; lazy Adam applied by rsa_adam_rows_sorted) == loss.backward() with
+    COO gradients + torch.optim.SparseAdam.step(), three steps, same sampled negatives."""
+    torch.manual_seed(7)
+    N, U, d, B, n, lr = 4001, 301, 64, 200, 64, 0.01
+    item = torch.nn.Embedding(N, d, padding_idx=0).to(DEV)
+    user = torch.nn.Embedding(U, d, padding_idx=0).to(DEV)
+    with torch.no_grad():
+        item.weight.mul_(0.3)
+        user.weight.mul_(0.3)
+    item2 = torch.nn.Embedding(N, d, padding_idx=0).to(DEV)
+    user2 = torch.nn.Embedding(U, d, padding_idx=0).to(DEV)
+    item2.load_state_dict(item.state_dict())
+    user2.load_state_dict(user.state_dict())
+    opt = torch.optim.SparseAdam(list(item2.parameters()) + list(user2.parameters()), lr=lr)
+    fa = ra.fused.FusedBPRAdam(item.weight, user.weight, lr=lr)
+    sampler = ra.UniformSampler(N)
+    batches = [(torch.randint(1, U, (B,), device=DEV), torch.randint(1, N, (B,), device=DEV)) for _ in range(3)]
+    batches[1] = (batches[0][0], batches[0][1])                  # repeated rows: state carried over
+    for step, (uid, pos) in enumerate(batches):
+        torch.manual_seed(50 + step)
+        loss, neg = fa.step(n, user_ids=uid, pos_ids=pos, sampler=sampler)
+        opt.zero_grad()
+        ref, _ = ra.fused.fused_bpr_loss(item2.weight, user2.weight, n, query_index=uid, pos_ids=pos, neg_ids=neg,
+                                         sparse_grad=True)
+        ref.backward()
+        opt.step()
+        np.testing.assert_allclose(float(loss), float(ref.detach()), rtol=1e-5)
+    np.testing.assert_allclose(item.weight.detach().cpu(), item2.weight.detach().cpu(), rtol=2e-4, atol=2e-6)
+    np.testing.assert_allclose(user.weight.detach().cpu(), user2.weight.detach().cpu(), rtol=2e-4, atol=2e-6)
+    assert not item.weight[0].any()
