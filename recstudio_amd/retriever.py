@@ -51,7 +51,7 @@ def default_config():
                   'init_method': 'xavier_normal', 'item_batch_size': 1024, 'learner': 'adam', 'learning_rate': 0.001,
                   'num_threads': 10, 'sampling_method': 'none', 'sampler': 'uniform', 'negative_count': 0,
                   'excluding_hist': False, 'scheduler': None, 'seed': 2022, 'weight_decay': 0.0,
-                  'tensorboard_path': None, 'sparse_grad': False, 'device_loader': True},
+                  'tensorboard_path': None, 'sparse_grad': False, 'device_loader': True, 'fused_optimizer': None},
         'eval': {'batch_size': 128, 'cutoff': [5, 10, 20], 'val_metrics': ['ndcg', 'recall'], 'val_n_epoch': 1,
                  'test_metrics': ['ndcg', 'recall', 'precision', 'map', 'mrr', 'hit'], 'topk': 100,
                  'save_path': './saved/'},
@@ -497,6 +497,7 @@ class BaseRetriever(torch.nn.Module):
             val_data.use_field = train_data.use_field
         optimizer = self._get_optimizer()
         tr = self.config['train']
+        fused_step = self._fused_optimizer_step(tr)
         val_metrics = self.config['eval']['val_metrics']
         cutoff = self.config['eval']['cutoff']
         cutoff0 = cutoff[0] if isinstance(cutoff, list) else cutoff
@@ -515,6 +516,9 @@ class BaseRetriever(torch.nn.Module):
                 loader = train_data.train_loader(batch_size=tr['batch_size'], shuffle=True, drop_last=False)
             for batch in loader:
                 batch = self._to_device(batch, device)
+                if fused_step is not None and batch[self.fiid].dim() == 1:
+                    losses.append(fused_step(batch))        # forward + loss + optimizer update in the kernels
+                    continue
                 optimizer.zero_grad()
                 loss = self.training_step(batch)
                 loss.backward()
@@ -538,6 +542,33 @@ class BaseRetriever(torch.nn.Module):
         if best_state is not None:
             self.load_state_dict(best_state)
         return best
+
+    def _fused_optimizer_step(self, tr):
+        """``train.fused_optimizer: 'sgd' | 'adam'`` (default None = the reference's torch optimizer on autograd
+        gradients): for the stock BPR two-tower configuration (nn.Embedding towers, InnerProductScorer, BPRLoss,
+        Uniform / Popular sampler, negative_count % 64 == 0, embed_dim in {64, 128, 256}) run the whole step --
+        sampling, scoring, loss, and the SGD / lazy-Adam update of the touched rows -- in the kernels, with no gradient
+        tensors (fused.bpr_sgd_step / fused.FusedBPRAdam).  'adam' follows torch.optim.SparseAdam (rows outside the
+        batch keep their state), which differs from the dense Adam the reference runs by default."""
+        kind = tr.get('fused_optimizer')
+        if not kind:
+            return None
+        ok = (type(self.loss_fn) is BPRLoss and self.sampler is not None and self._fused_ok()
+              and type(self.score_func) is InnerProductScorer and isinstance(self.neg_count, int) and self.neg_count % 64 == 0
+              and isinstance(self.query_encoder, torch.nn.Embedding) and self.item_encoder.weight.shape[1] in (64, 128, 256)
+              and not tr.get('weight_decay') and tr.get('grad_clip_norm') is None)
+        if not ok:
+            raise NotImplementedError("train.fused_optimizer needs the stock BPR two-tower configuration "
+                                      "(see BaseRetriever._fused_optimizer_step)")
+        from .fused import FusedBPRAdam, bpr_sgd_step
+        iw, uw, lr = self.item_encoder.weight, self.query_encoder.weight, tr['learning_rate']
+        if kind == 'sgd':
+            return lambda b: bpr_sgd_step(iw, uw, self.neg_count, lr, user_ids=b[self.fuid], pos_ids=b[self.fiid],
+                                          sampler=self.sampler)[0]
+        if kind == 'adam':
+            opt = FusedBPRAdam(iw, uw, lr=lr)
+            return lambda b: opt.step(self.neg_count, user_ids=b[self.fuid], pos_ids=b[self.fiid], sampler=self.sampler)[0]
+        raise ValueError(f"train.fused_optimizer must be 'sgd' or 'adam', got {kind!r}")
 
     @torch.no_grad()
     def _eval_epoch(self, data, step, device):

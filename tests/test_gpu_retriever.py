@@ -479,3 +479,20 @@ def test_fused_adam_step_equals_sparse_grads_plus_torch_sparse_adam(ra):
     np.testing.assert_allclose(item.weight.detach().cpu(), item2.weight.detach().cpu(), rtol=2e-4, atol=2e-6)
     np.testing.assert_allclose(user.weight.detach().cpu(), user2.weight.detach().cpu(), rtol=2e-4, atol=2e-6)
     assert not item.weight[0].any()
+
+
+@pytest.mark.parametrize('kind', ['adam', 'sgd'])
+def test_bpr_fit_with_fused_optimizer(ra, golden, kind):
+    """BaseRetriever.fit with train.fused_optimizer: the whole step (sampling, scoring, loss, optimizer update) in the
+    kernels; BPR on the ml-100k fixture still learns."""
+    g = golden('data_ml100k')
+    ds = make(ra.TripletDataset, g)
+    trn, val, tst = ds.build(split_ratio=[0.8, 0.1, 0.1], shuffle=True)
+    lr = 0.003 if kind == 'adam' else 30.0            # plain SGD on a mean-reduced loss needs a batch-sized rate
+    cfg = {'model': {'embed_dim': 64}, 'train': {'epochs': 6, 'negative_count': 64, 'batch_size': 512, 'learning_rate': lr,
+           'fused_optimizer': kind, 'init_method': 'normal'}, 'eval': {'batch_size': 256}}
+    model = ra.BPR(cfg)
+    model.fit(trn, val)
+    res = model.evaluate(tst)
+    assert np.isfinite(model.logged_metrics['train_loss']) and model.logged_metrics['train_loss'] < 0.68
+    assert res['recall@20'] > 0.05
