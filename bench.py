@@ -197,33 +197,6 @@ def main():
             o = fwd()
             return ra.ops.pairwise_loss(nat.LOSS_BPR, o['pos_score'], o['neg_score'], want_grad=True)
 
-        ms_step = time_gpu(step, args.steps, args.warmup) * 1e3
-        extra['unfused_loss_ms_per_step'] = round(time_gpu(step_unfused, args.steps, args.warmup) * 1e3, 4)
-
-        # dominant kernel alone, timed with events on the launch stream
-        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-        torch.cuda.synchronize()
-        for a, b in evs:      # exactly one launch between the events: the fused kernel (no mean reduction)
-            a.record()
-            bufs['step'] = ra.ops.fused_forward(item, user, n, out=bufs['step'], fused_bpr=True, want_mean=False, **kw)
-            b.record()
-        torch.cuda.synchronize()
-        k_ms = sorted(a.elapsed_time(b) for a, b in evs)
-        k_avg = sum(k_ms) / len(k_ms)
-        alg = bytes_per_triplet(d, n, popular, fused_loss=True) * B * n
-        achieved = alg / (k_avg * 1e-3) / 1e9
-        roofline = {'bound': 'hbm', 'kernel': 'rsa::fused_fwd_kernel<32,false,false,true,true> (sample+gather+score+BPR epilogue)',
-                    'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                    'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': None,
-                    'alg_bytes_per_launch': int(alg), 'avg_kernel_ms': round(k_avg, 4),
-                    'median_kernel_ms': round(k_ms[len(k_ms) // 2], 4)}
-        pmc = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')
-        if os.path.exists(pmc) and (args.items, args.batch, args.neg, args.dim, popular) == (10_000_001, 65536, 64, 128, True):
-            try:
-                roofline['traffic'] = json.load(open(pmc)).get('fused_fwd_bytes_per_launch')
-            except Exception:
-                pass
-
         # training step: forward + loss + row-sparse gradient scatter (+ user-row gradient)
         def train_two_pass():      # backward re-reads the negative rows for the user gradient
             o = step()
@@ -344,6 +317,46 @@ def main():
             del w5, qq5
         except Exception as e:
             extra['fullscore']['softmax_train_step_error'] = repr(e)[:200]
+        # ---- the headline line: exactly K steps after W warm-up steps, measured after the secondary figures so that the
+        # GPU is at steady-state clocks (boxes of the pool differ by several per cent either way)
+        hb = {}
+
+        def step():          # sample + gather + score + BPR loss (value, d loss/d score, mean): ONE kernel
+            hb['step'] = ra.ops.fused_forward(item, user, n, out=hb.get('step'), fused_bpr=True, **kw)
+            return hb['step']
+
+        def step_unfused():  # the same with the loss as its own kernel
+            hb['fwd'] = ra.ops.fused_forward(item, user, n, out=hb.get('fwd'), **kw)
+            o = hb['fwd']
+            return ra.ops.pairwise_loss(nat.LOSS_BPR, o['pos_score'], o['neg_score'], want_grad=True)
+
+        ms_step = time_gpu(step, args.steps, args.warmup) * 1e3
+        extra['unfused_loss_ms_per_step'] = round(time_gpu(step_unfused, args.steps, args.warmup) * 1e3, 4)
+
+        # dominant kernel alone, timed with events on the launch stream
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+        torch.cuda.synchronize()
+        for a, b in evs:      # exactly one launch between the events: the fused kernel (no mean reduction)
+            a.record()
+            hb['step'] = ra.ops.fused_forward(item, user, n, out=hb['step'], fused_bpr=True, want_mean=False, **kw)
+            b.record()
+        torch.cuda.synchronize()
+        k_ms = sorted(a.elapsed_time(b) for a, b in evs)
+        k_avg = sum(k_ms) / len(k_ms)
+        alg = bytes_per_triplet(d, n, popular, fused_loss=True) * B * n
+        achieved = alg / (k_avg * 1e-3) / 1e9
+        roofline = {'bound': 'hbm', 'kernel': 'rsa::fused_fwd_kernel<32,false,false,true,true> (sample+gather+score+BPR epilogue)',
+                    'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                    'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': None,
+                    'alg_bytes_per_launch': int(alg), 'avg_kernel_ms': round(k_avg, 4),
+                    'median_kernel_ms': round(k_ms[len(k_ms) // 2], 4)}
+        pmc = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')
+        if os.path.exists(pmc) and (args.items, args.batch, args.neg, args.dim, popular) == (10_000_001, 65536, 64, 128, True):
+            try:
+                roofline['traffic'] = json.load(open(pmc)).get('fused_fwd_bytes_per_launch')
+            except Exception:
+                pass
+
         # north_star target: the fused gather+sample+score(+BPR) on a 100 M-item table (51.2 GB) at d = 128
         if not args.no_sweep and args.dim == 128:
             try:
