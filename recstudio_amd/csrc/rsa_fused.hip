@@ -577,6 +577,7 @@ extern "C" int rsa_fused_sample_gather_score(const rsa_fused_args* a, rsa_stream
   RSA_CHECK_ARG(a != nullptr, "rsa_fused_sample_gather_score: args is null");
   RSA_CHECK_ARG(a->n_queries >= 0 && a->num_neg >= 0, "rsa_fused_sample_gather_score: negative sizes");
   const int64_t numel = a->n_queries * (int64_t)a->num_neg;
+  if (a->n_queries == 0) return RSA_OK;       // nothing to do (empty batch): before the table-shape checks
   RSA_CHECK_ARG(a->dim >= 4 && a->dim <= 1024 && a->dim % 4 == 0,
                 "rsa_fused_sample_gather_score: dim=%d must be a multiple of 4 in [4, 1024]", a->dim);
   RSA_CHECK_ARG(a->n_items >= 2 && a->n_items < (1ll << 31), "rsa_fused_sample_gather_score: n_items out of range");

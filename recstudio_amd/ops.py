@@ -449,6 +449,8 @@ def scatter_rows_sorted(target, query, neg_ids, dneg, *, query_index=None, pos_i
     upstream = _need_opt(upstream, torch.float32, 'upstream')
     n_items, dim = target.shape
     M = query_index.numel() if query_index is not None else query.shape[0]
+    if M == 0:
+        return target
     n = neg_ids.numel() // M
     ws_bytes = int(nat.lib().rsa_scatter_rows_sorted_workspace_bytes(M, n, n_items))
     ws = torch.empty(max(ws_bytes, 8), dtype=torch.uint8, device=target.device)
@@ -474,6 +476,8 @@ def adam_rows_sorted(weight, exp_avg, exp_avg_sq, query, neg_ids, dneg, *, lr, b
     upstream = _need_opt(upstream, torch.float32, 'upstream')
     n_items, dim = weight.shape
     M = query_index.numel() if query_index is not None else query.shape[0]
+    if M == 0:
+        return weight
     n = neg_ids.numel() // M
     ws_bytes = int(nat.lib().rsa_scatter_rows_sorted_workspace_bytes(M, n, n_items))
     ws = torch.empty(max(ws_bytes, 8), dtype=torch.uint8, device=weight.device)

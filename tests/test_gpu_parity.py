@@ -680,3 +680,24 @@ def test_forward_query_grad_matches_backward_kernel(ra, d, n, sampler):
     g2 = iw2.grad.clone()
     g2[0] = 0
     rel_close(iw.grad.cpu(), g2.cpu(), rtol=3e-4, atol=1e-8)
+
+
+def test_empty_inputs_are_no_ops(ra):
+    """Zero queries / zero ids: every entry point returns cleanly with empty outputs (the reference's torch ops do the
+    same on empty tensors)."""
+    N, d = 101, 64
+    item = torch.randn(N, d, device=DEV)
+    e64 = torch.empty(0, dtype=torch.int64, device=DEV)
+    assert ra.ops.sample_uniform(0, 1, N, DEV).numel() == 0
+    assert ra.ops.embedding_gather(item, e64).shape == (0, d)
+    out = ra.ops.fused_forward(item, torch.empty(0, d, device=DEV), 4, pos_ids=e64, neg_ids=torch.empty(0, 4, dtype=torch.int64, device=DEV))
+    assert out['neg_score'].shape == (0, 4) and out['pos_score'].shape == (0,)
+    neg, lp = ra.UniformSampler(N)(torch.empty(0, d, device=DEV), 5)
+    assert neg.shape == (0, 5)
+    _, lse, tv, ti = ra.ops.fullscore(item, torch.empty(0, d, device=DEV), want_lse=True, k=3)
+    assert lse.shape == (0,) and tv.shape == (0, 3)
+    res = ra.ops.seg_gather(item, torch.randint(1, N, (10,), device=DEV), e64, e64, 7)
+    assert sorted(tuple(t.shape) for t in res) == [(0,), (0, 7), (0, 7, d)]
+    g = ra.ops.scatter_rows_sorted(torch.zeros(N, d, device=DEV), torch.empty(0, d, device=DEV),
+                                   torch.empty(0, 4, dtype=torch.int64, device=DEV), torch.empty(0, 4, device=DEV))
+    assert not g.any()
