@@ -701,3 +701,55 @@ def test_empty_inputs_are_no_ops(ra):
     g = ra.ops.scatter_rows_sorted(torch.zeros(N, d, device=DEV), torch.empty(0, d, device=DEV),
                                    torch.empty(0, 4, dtype=torch.int64, device=DEV), torch.empty(0, 4, device=DEV))
     assert not g.any()
+
+
+def test_fused_forward_fuzz_against_device_reference_ops(ra):
+    """40 random configurations (dim incl. non-power-of-two / generic dims, 1..300 negatives, ragged batch sizes, all
+    three samplers, all three scorers): ids == the reference's torch.randint / searchsorted(rand) on this device under
+    the same seed, scores == F.embedding + the scorer's formula in float64."""
+    rs = np.random.RandomState(1234)
+    gen = torch.cuda.default_generators[torch.cuda.current_device()]
+    for it in range(40):
+        d = int(rs.choice([32, 64, 100, 128, 256, 36, 512]))
+        n = int(rs.choice([1, 2, 5, 33, 64, 100, 128, 300]))
+        B = int(rs.randint(1, 150))
+        N = int(rs.choice([50, 1000, 20011]))
+        mode = int(rs.randint(0, 3))
+        kind = ['given', 'uniform', 'popular'][int(rs.randint(0, 3))]
+        torch.manual_seed(it)
+        item = torch.randn(N, d, device=DEV) * 0.3
+        q = torch.randn(B, d, device=DEV) * 0.3
+        pos = torch.randint(0, N, (B,), device=DEV)
+        seed = 1000 + it
+        kw = {}
+        if kind == 'given':
+            want_ids = torch.randint(0, N, (B, n), device=DEV)
+            kw['neg_ids'] = want_ids
+        elif kind == 'uniform':
+            kw['sampler'] = ra._native.SAMPLER_UNIFORM
+            torch.manual_seed(seed)
+            want_ids = torch.randint(1, N, (B, n), device=DEV)
+        else:
+            ps = ra.PopularSamplerModel((torch.rand(N) ** 3 * 60).long()).to(DEV)
+            kw.update(sampler=ra._native.SAMPLER_POPULAR, table=ps.table, pop_prob=ps.pop_prob, guide=ps.guide,
+                      guide_log2=ps.guide_log2, table_prob=ps.table_prob, cdf_lut=ps.cdf_lut)
+            torch.manual_seed(seed)
+            want_ids = torch.searchsorted(ps.table, torch.rand(B, n, device=DEV)).clamp_(max=N - 1)
+        torch.manual_seed(seed)
+        out = ra.ops.fused_forward(item, q, n, pos_ids=pos, cosine=mode, **kw)
+        tag = f'it={it} d={d} n={n} B={B} N={N} mode={mode} {kind}'
+        assert torch.equal(out['neg_ids'], want_ids), tag
+        qd, xd, pd = q.double(), item.double()[want_ids], item.double()[pos]
+        dot_n, dot_p = (qd.unsqueeze(1) * xd).sum(-1), (qd * pd).sum(-1)
+        if mode == 0:
+            wn, wp = dot_n, dot_p
+        elif mode == 1:
+            wn = dot_n / xd.norm(dim=-1) / qd.norm(dim=-1, keepdim=True)
+            wp = dot_p / pd.norm(dim=-1) / qd.norm(dim=-1)
+        else:
+            wn = -(xd.square().sum(-1) + qd.square().sum(-1, keepdim=True) - 2 * dot_n)
+            wp = -(pd.square().sum(-1) + qd.square().sum(-1) - 2 * dot_p)
+        ok = torch.isfinite(wn)
+        np.testing.assert_allclose(out['neg_score'][ok].cpu(), wn[ok].float().cpu(), rtol=2e-4, atol=2e-5, err_msg=tag)
+        okp = torch.isfinite(wp)
+        np.testing.assert_allclose(out['pos_score'][okp].cpu(), wp[okp].float().cpu(), rtol=2e-4, atol=2e-5, err_msg=tag)
