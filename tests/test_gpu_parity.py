@@ -753,3 +753,48 @@ def test_fused_forward_fuzz_against_device_reference_ops(ra):
         np.testing.assert_allclose(out['neg_score'][ok].cpu(), wn[ok].float().cpu(), rtol=2e-4, atol=2e-5, err_msg=tag)
         okp = torch.isfinite(wp)
         np.testing.assert_allclose(out['pos_score'][okp].cpu(), wp[okp].float().cpu(), rtol=2e-4, atol=2e-5, err_msg=tag)
+
+
+def test_backward_fuzz_against_torch_autograd(ra):
+    """24 random configurations: gradients of a random scalar functional of (pos_score, neg_score) through the fused
+    score node (dense item gradient, user-table gradient; the sorted / atomic / cosine / Euclidean backward paths)
+    == torch autograd of the same functional over F.embedding + the scorer's formula."""
+    rs = np.random.RandomState(99)
+    for it in range(24):
+        d = int(rs.choice([32, 64, 128, 256, 48]))
+        n = int(rs.choice([1, 3, 64, 128, 70]))
+        B = int(rs.randint(1, 90))
+        N, U = int(rs.choice([40, 3001])), 57
+        mode = int(rs.randint(0, 3))
+        torch.manual_seed(300 + it)
+        iw = (torch.randn(N, d, device=DEV) * 0.4)
+        iw[0] = 0
+        uw = torch.randn(U, d, device=DEV) * 0.4
+        uid = torch.randint(1, U, (B,), device=DEV)
+        pos = torch.randint(1, N, (B,), device=DEV)
+        neg = torch.randint(0, N, (B, n), device=DEV)
+        cp, cn = torch.randn(B, device=DEV), torch.randn(B, n, device=DEV)
+        a, b = iw.clone().requires_grad_(True), uw.clone().requires_grad_(True)
+        score, _ = ra.retriever_scores(a, b, n, query_index=uid, pos_ids=pos, neg_ids=neg, cosine=mode)
+        ((score['pos_score'] * cp).sum() + (score['neg_score'] * cn).sum()).backward()
+        a2, b2 = iw.clone().double().requires_grad_(True), uw.clone().double().requires_grad_(True)
+        q, xp, xn = b2[uid], a2[pos], a2[neg]
+        dp, dn = (q * xp).sum(-1), (q.unsqueeze(1) * xn).sum(-1)
+        if mode == 1:
+            dp = dp / xp.norm(dim=-1) / q.norm(dim=-1)
+            dn = dn / xn.norm(dim=-1) / q.norm(dim=-1, keepdim=True)
+        elif mode == 2:
+            dp = -(xp.square().sum(-1) + q.square().sum(-1) - 2 * dp)
+            dn = -(xn.square().sum(-1) + q.square().sum(-1, keepdim=True) - 2 * dn)
+        live = neg != 0 if mode == 1 else torch.ones_like(neg, dtype=torch.bool)      # cosine of the zero padding row: NaN
+        ((dp * cp.double()).sum() + (dn * cn.double())[live].sum()).backward()
+        tag = f'it={it} d={d} n={n} B={B} N={N} mode={mode}'
+        want_i = a2.grad.clone()
+        want_i[0] = 0                                             # the padding row never receives gradient
+        if mode == 1 and not bool(live.all()):
+            continue                                              # reference semantics there are NaN: not compared
+        scale = float(want_i.abs().max()) + 1e-6
+        np.testing.assert_allclose(a.grad.cpu(), want_i.float().cpu(), rtol=3e-4, atol=3e-6 * scale, err_msg=tag)
+        want_u = b2.grad.clone()
+        np.testing.assert_allclose(b.grad.cpu(), want_u.float().cpu(), rtol=3e-4, atol=3e-6 * (float(want_u.abs().max()) + 1e-6),
+                                   err_msg=tag)
