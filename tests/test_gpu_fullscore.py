@@ -249,3 +249,27 @@ def test_topk_large_k_large_batch_trending_scores(ra):
     assert (ti == wi + 1).float().mean() > 0.99       # fp32 near-ties may swap neighbours
     close(lse.cpu(), torch.logsumexp(ref.double(), -1).float().cpu(), rtol=1e-5)
     assert elapsed < 0.5, f'top-k fell off the fast path: {elapsed * 1e3:.0f} ms'
+
+
+def test_fullscore_topk_fuzz(ra):
+    """18 random (B, N, d, k) around the dense / filter switch-over (32 768 items) and the tile sizes: logsumexp and
+    exact top-k (values; ids wherever fp32 near-ties do not swap neighbours) against a float64 matmul on the device."""
+    rs = np.random.RandomState(7)
+    for it in range(18):
+        d = int(rs.choice([32, 64, 128, 100]))
+        N = int(rs.choice([33, 1000, 32768, 32769, 32800, 70001, 200003]))
+        B = int(rs.choice([1, 31, 128, 129, 300]))
+        k = int(min(N - 1, rs.choice([1, 10, 100, 300])))
+        torch.manual_seed(it)
+        item = torch.randn(N, d, device=DEV) * 0.3
+        q = torch.randn(B, d, device=DEV) * 0.3
+        _, lse, tv, ti = ra.ops.fullscore(item, q, want_lse=True, k=k)
+        ref = q.double() @ item[1:].double().T
+        tag = f'it={it} B={B} N={N} d={d} k={k}'
+        np.testing.assert_allclose(lse.cpu(), torch.logsumexp(ref, -1).float().cpu(), rtol=2e-5, err_msg=tag)
+        wv, wi = torch.topk(ref, k)
+        np.testing.assert_allclose(tv.cpu(), wv.float().cpu(), rtol=1e-4, atol=1e-5, err_msg=tag)
+        assert (ti == wi + 1).float().mean() > 0.98, tag
+        got = ref.gather(1, ti - 1)                                  # the ids carry the returned values
+        np.testing.assert_allclose(got.float().cpu(), tv.cpu(), rtol=1e-4, atol=1e-5, err_msg=tag)
+        assert bool((tv[:, :-1] >= tv[:, 1:]).all()), tag            # sorted, descending
