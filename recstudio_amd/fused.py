@@ -125,8 +125,8 @@ def retriever_scores(item_weight, query_src, num_neg, *, query_index=None, pos_i
         score['log_neg_prob'] = out['neg_logp']
     else:
         # UniformSampler.compute_item_p: int64 zeros (sampler.py:113-114)
-        score['log_pos_prob'] = None if pos_ids is None else torch.zeros_like(pos_ids)
-        score['log_neg_prob'] = torch.zeros_like(out['neg_ids'])
+        score['log_pos_prob'] = None if pos_ids is None else ops.zero_logp_like(pos_ids)
+        score['log_neg_prob'] = ops.zero_logp_like(out['neg_ids'])
     return score, out['neg_ids']
 
 

@@ -49,7 +49,8 @@ def _as_f32_or_none(t):
     if t is None:
         return None
     if not t.is_floating_point():
-        return None if not bool(t.any()) else t.to(torch.float32)
+        # zeros created by this package are recognised by identity; anything else is cast (no host sync either way)
+        return None if ops.is_known_zero(t) else t.to(torch.float32)
     return t
 
 

@@ -13,6 +13,31 @@ from . import rng
 from ._native import ptr
 
 
+# Integer all-zero log-probabilities (what the reference's UniformSampler hands out, sampler.py:113-114) come from a
+# small cache of persistent zero buffers (one per element count and device) and are recognised by address, not by
+# reading them back: the losses would otherwise need a host sync per step to learn that there is nothing to subtract
+# (and the sampler a memset per step).  They are constants: nothing in the package or in the reference writes to them.
+_ZERO_LOGP = {}
+
+
+def zero_logp_like(ids):
+    """An int64 all-zero tensor shaped like ``ids`` (a view of a cached constant buffer)."""
+    key = (ids.numel(), ids.device)
+    z = _ZERO_LOGP.get(key)
+    if z is None:
+        if len(_ZERO_LOGP) >= 16:              # a handful of batch shapes at most; do not grow without bound
+            _ZERO_LOGP.clear()
+        z = _ZERO_LOGP[key] = torch.zeros(ids.numel(), dtype=torch.int64, device=ids.device)
+    return z.view(ids.shape)
+
+
+def is_known_zero(t):
+    if t.is_floating_point():
+        return False
+    z = _ZERO_LOGP.get((t.numel(), t.device))
+    return z is not None and z.data_ptr() == t.data_ptr()
+
+
 def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 

@@ -58,7 +58,7 @@ class UniformSampler(Sampler):
             return neg, neg_prob
 
     def compute_item_p(self, query, pos_items):
-        return torch.zeros_like(pos_items)          # sampler.py:113-114
+        return ops.zero_logp_like(pos_items)        # sampler.py:113-114
 
 
 class MaskedUniformSampler(Sampler):
@@ -80,7 +80,7 @@ class MaskedUniformSampler(Sampler):
             return neg, neg_prob
 
     def compute_item_p(self, query, pos_items):
-        return torch.zeros_like(pos_items)              # -log(1), int64 like the reference (sampler.py:213-214)
+        return ops.zero_logp_like(pos_items)            # -log(1), int64 like the reference (sampler.py:213-214)
 
 
 def build_guide_table(table: Tensor, guide_log2: Optional[int] = None):
