@@ -54,15 +54,16 @@ __global__ __launch_bounds__(256) void seg_gather_kernel(const float* __restrict
     const int vec = D >> 2;
     const int total = max_len * vec;
     float4* orow = reinterpret_cast<float4*>(out_rows + (size_t)b * max_len * D);
+    const int64_t last_flat = n_flat > 0 ? n_flat - 1 : 0;
     for (int i = threadIdx.x; i < total; i += blockDim.x) {
       const int l = i / vec, c = i - l * vec;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (l < len) {
-        int64_t id = flat[s + l];
-        id = id < 0 ? 0 : (id >= n_items ? n_items - 1 : id);
-        v = reinterpret_cast<const float4*>(table + (size_t)id * D)[c];
-      }
-      orow[i] = v;
+      // unconditional loads (a load under a lane predicate becomes a branch + vmcnt(0)): padded positions read a
+      // valid address and are zeroed by a select
+      const int64_t fi = s + l < last_flat ? s + l : last_flat;
+      int64_t id = n_flat > 0 ? flat[fi] : 0;
+      id = id < 0 ? 0 : (id >= n_items ? n_items - 1 : id);
+      const float4 x = reinterpret_cast<const float4*>(table + (size_t)id * D)[c];
+      orow[i] = l < len ? x : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   }
 }
