@@ -378,7 +378,24 @@ def main():
                     alg8 = bytes_per_triplet(d, n_neg, False, fused_loss=True) * b_q * n_neg
                     res8[name] = {'ms': round(t8, 4), 'M_triplets_s': round(b_q * n_neg / t8 / 1e3, 1),
                                   'alg_GBs': round(alg8 / t8 / 1e6, 1), 'frac_of_hbm_peak': round(alg8 / t8 / 1e6 / HBM_PEAK_GBS, 4)}
-                extra['table_100M'] = {'workload': f'uniform sampler + gather + score + fused BPR, N={n8} items (51.2 GB table), d={d} '
+                try:          # the popularity sampler on the same table (2^25-bucket lookup table, 537 MB)
+                    ps8 = ra.PopularSamplerModel(zipf_counts(n8, 100_000_000)).to(dev)
+                    b8p = {}
+
+                    def st8p():
+                        b8p['o'] = ra.ops.fused_forward(item8, user, n, out=b8p.get('o'), fused_bpr=True, want_mean=False,
+                                                       query_index=uid, pos_ids=pos8, sampler=nat.SAMPLER_POPULAR,
+                                                       table=ps8.table, pop_prob=ps8.pop_prob, guide=ps8.guide,
+                                                       guide_log2=ps8.guide_log2, table_prob=ps8.table_prob, cdf_lut=ps8.cdf_lut)
+                    t8p = time_gpu(st8p, 50, 5) * 1e3
+                    alg8p = bytes_per_triplet(d, n, True, fused_loss=True) * B * n
+                    res8['popular,n=64,B=65536'] = {'ms': round(t8p, 4), 'M_triplets_s': round(B * n / t8p / 1e3, 1),
+                                                     'alg_GBs': round(alg8p / t8p / 1e6, 1),
+                                                     'frac_of_hbm_peak': round(alg8p / t8p / 1e6 / HBM_PEAK_GBS, 4)}
+                    del ps8, b8p
+                except Exception as e:
+                    res8['popular,n=64,B=65536'] = {'error': repr(e)[:200]}
+                extra['table_100M'] = {'workload': f'uniform (and popularity) sampler + gather + score + fused BPR, N={n8} items (51.2 GB table), d={d} '
                                        '(north_star target; BASELINE.json configs[3] per-GPU shape for n=1024)', **res8}
                 del item8
             except Exception as e:
