@@ -20,6 +20,9 @@
 // ~2*D flops; see DESIGN.md for the byte model.
 #include "rsa_common.hpp"
 
+#ifndef RSA_LUT_NT
+#define RSA_LUT_NT 0
+#endif
 #ifndef RSA_QG_BATCH
 #define RSA_QG_BATCH 8     // rows per load batch of the training forward (4 / 2 measured: same register count)
 #endif
@@ -290,7 +293,15 @@ __global__ __launch_bounds__(256, QG ? RSA_QG_MIN_WAVES : RSA_FWD_MIN_WAVES) voi
     const int64_t e2 = (t << 6) + lane;
     if (e2 < p.numel) {
       u_next = torch_rand_element(pc, (uint64_t)e2);
+#if RSA_LUT_NT
+      {   // the 134 MB table is read at random and an entry is never reused within a step: streaming hint
+        typedef float v4f __attribute__((ext_vector_type(4)));
+        const v4f v = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(p.lut) + lut_bucket(p.guide_log2, u_next));
+        lut_next = make_float4(v.x, v.y, v.z, v.w);
+      }
+#else
       lut_next = reinterpret_cast<const float4*>(p.lut)[lut_bucket(p.guide_log2, u_next)];
+#endif
     }
   };
   if (ahead && wave0 < n_tiles) fetch_ahead(wave0);
