@@ -6,10 +6,11 @@
  * is a DEVICE pointer unless stated otherwise, `stream` is a hipStream_t
  * passed as void*.  Every entry point returns 0 on success or a negative
  * rsa_status; rsa_last_error() returns the thread-local message of the last
- * failure.  No entry point synchronises or allocates caller-visible memory (the library keeps three tiny
- * device scratch blocks of its own, allocated on first use: partial sums of rsa_mean_rows, the valid-row
- * counter of the BCE losses, the arrival counter + per-workgroup partials of the fused loss reduction --
- * calls that use them must not run concurrently on different streams).
+ * failure.  No entry point synchronises or allocates: the few reductions that need device scratch (mean of the
+ * row losses, valid-row count of the BCE losses, arrival counter + per-workgroup partials of the in-kernel loss
+ * reduction) take a caller-owned block of rsa_scratch_bytes() bytes, zero-filled ONCE by the caller and then
+ * left alone (the kernels restore the words they use); one block per device and stream -- calls sharing a block
+ * must be stream-ordered.
  *
  * The reference (ustcml/RecStudio) is pure Python on PyTorch; it has no native
  * boundary of its own.  Each entry point below therefore replaces a SEQUENCE
@@ -29,7 +30,12 @@
 extern "C" {
 #endif
 
-#define RSA_ABI_VERSION 2   /* 2: rsa_fused_args grew query_grad, packed_keys, offset_dev; new entry points
+#define RSA_ABI_VERSION 3   /* 3: caller-owned reduction scratch (rsa_scratch_bytes; the library allocates nothing);
+                               Philox element base (G-invariant sampling across ranks); bucket-line inverse CDF
+                               (cdf_lines); SampledSoftmax epilogue (fused_loss = 2); cosine / Euclidean full-catalog
+                               scores (rsa_row_sqnorm, rsa_fullscore score_mode); fixed-capacity shard routing
+                               (rsa_shard_route_fixed, negative keys / positions = empty slot).
+                               2: rsa_fused_args grew query_grad, packed_keys, offset_dev; new entry points
                                (rsa_row_topk, rsa_fullscore_softmax, rsa_pairwise_loss_ex, rsa_scatter_rows_sorted,
                                rsa_rng_advance) */
 
@@ -50,6 +56,8 @@ enum rsa_loss_kind { RSA_LOSS_BPR = 0, RSA_LOSS_SSM = 1, RSA_LOSS_BCE = 2,
 
 const char* rsa_last_error(void);
 int rsa_abi_version(void);
+/* Size of the caller-owned reduction scratch (see above). */
+int64_t rsa_scratch_bytes(void);
 
 /* Device properties torch's distribution kernels size their grid from
  * (multiProcessorCount, maxThreadsPerMultiProcessor) -- needed to reproduce
@@ -62,13 +70,16 @@ int rsa_device_info(int device, int32_t* cu_count, int32_t* max_threads_per_cu, 
  * grid_threads is the thread count of torch's distribution grid for `numel`
  * outputs (256 * min(CUs * maxThreadsPerCU/256, ceil(numel/256))).  With
  * these, element i of the output is bit-identical to element i of
- * torch.randint(low, high, (numel,), device='cuda') / torch.rand(numel). */
+ * torch.randint(low, high, (numel,), device='cuda') / torch.rand(numel).
+ * elem_base: output element i draws what element elem_base + i of the torch call would -- a rank that owns
+ * rows [r*B, (r+1)*B) of a global [G*B, n] id tensor passes elem_base = r*B*n and the grid_threads of the GLOBAL
+ * call, so that the negatives of a run do not depend on the number of GPUs; 0 otherwise. */
 
 /* UniformSampler.forward -- recstudio/ann/sampler.py:86-111
  * (torch.randint(1, num_items+1, (num_queries, num_neg)), :102-104).
  * neg_ids[numel] <- low + philox % (high - low). */
 int rsa_sample_uniform(int64_t* neg_ids, int64_t numel, int64_t low, int64_t high,
-                       uint64_t seed, uint64_t offset, uint32_t grid_threads, rsa_stream_t stream);
+                       uint64_t seed, uint64_t offset, uint32_t grid_threads, uint64_t elem_base, rsa_stream_t stream);
 
 /* MaskedUniformSampler.forward / uniform_sample_masked_hist -- recstudio/ann/sampler.py:117-147, :187-214:
  * rejection-free uniform negatives over the items NOT in each user's 0-padded history
@@ -86,19 +97,20 @@ int rsa_sample_masked_uniform(const int64_t* user_hist, int64_t n_rows, int32_t 
  * table[i] >= j / 2^guide_log2, guide[2^guide_log2] = n_items (cut-point
  * acceleration, guide_log2 <= 28; returns the same index searchsorted does).  An id that would be
  * n_items (u above table[-1]) is clamped to n_items-1.  neg_logp / u_out may be
- * null. */
+ * null.  cdf_lut / cdf_lines (nullable, see rsa_fused_args) are faster forms of the same lookup; with
+ * cdf_lines the guide may be null. */
 int rsa_sample_popular(const float* table, const float* pop_prob, const int32_t* guide,
                        int64_t n_items, int32_t guide_log2,
                        int64_t* neg_ids, float* neg_logp, float* u_out, int64_t numel,
-                       uint64_t seed, uint64_t offset, uint32_t grid_threads,
-                       const float* cdf_lut /* nullable, see rsa_fused_args.cdf_lut */, rsa_stream_t stream);
+                       uint64_t seed, uint64_t offset, uint32_t grid_threads, uint64_t elem_base,
+                       const float* cdf_lut, const float* cdf_lines, int32_t lines_log2, rsa_stream_t stream);
 
 /* The same inverse-CDF lookup for caller-supplied uniforms u[numel] (used by the
  * parity tests to hit exact table edges). */
 int rsa_popular_lookup(const float* table, const float* pop_prob, const int32_t* guide,
                        int64_t n_items, int32_t guide_log2, const float* u,
                        int64_t* ids, float* logp, int64_t numel, const float* cdf_lut /* nullable */,
-                       rsa_stream_t stream);
+                       const float* cdf_lines /* nullable */, int32_t lines_log2, rsa_stream_t stream);
 
 /* PopularSamplerModel.compute_item_p -- recstudio/ann/sampler.py:257-258:
  * logp[i] = log(pop_prob[ids[i]]). */
@@ -148,7 +160,10 @@ typedef struct rsa_fused_args {
   const float* table_prob;     /* nullable [n_items][2]: interleaved copy {table[i], pop_prob[i]}.  When given,
                                   the CDF probes and the log-prob read share cache lines (one Infinity-Cache
                                   round trip fewer per sampled id); results are identical. */
-  int32_t fused_loss;          /* 0 = none; 1 = BPRLoss (loss_func.py:55-59) evaluated in the kernel's epilogue:
+  int32_t fused_loss;          /* 0 = none; 1 = BPRLoss (loss_func.py:55-59); 2 = SampledSoftmaxLoss (loss_func.py:80-90,
+                                  one positive per row; logsumexp over the positive and all num_neg negatives of a query
+                                  carried across its num_neg/64 tiles by ONE wave; inner product, dim in {32,64,128,256};
+                                  a -inf positive yields NaN like the reference).  Evaluated in the kernel's epilogue:
                                   needs num_neg % 64 == 0, pos_ids, pos_score.  Outputs below. */
   int32_t _pad2;
   float* row_loss;             /* [M] out: per-query loss */
@@ -162,16 +177,34 @@ typedef struct rsa_fused_args {
                                   pop_prob[min(lo+1, n_items-1)]}.  Direct-lookup form of the inverse CDF: one 16-byte
                                   read resolves id and probability for every bucket holding <= 1 CDF boundary
                                   (one HBM line instead of three dependent round trips); identical results. */
-  float* query_grad;           /* nullable [M, dim] out, fused_loss = 1 only (inner product, dim in {32,64,128,256}):
+  float* query_grad;           /* nullable [M, dim] out, fused_loss != 0 only (inner product, dim in {32,64,128,256}):
                                   d loss_out / d query row m = sum_j dneg[m,j] * item[neg_ids[m,j]] + dpos[m] * item[pos],
                                   accumulated while the rows are in registers, so that rsa_fused_backward can be
                                   called without query_grad / query_table_grad and then never reads an item row. */
   const int64_t* packed_keys;  /* nullable [M]: sampler GIVEN, num_neg == 1, no positives: element m scores query row
                                   (key >> 32) against item row (key & 0xffffffff) -- the owner side of the sharded
-                                  exchange (rsa_shard_route keys) without unpacking; neg_ids / query_index unused. */
+                                  exchange (rsa_shard_route keys) without unpacking; neg_ids / query_index unused.
+                                  A negative key is an empty slot: its score is 0. */
   const uint64_t* offset_dev;  /* nullable device word: when set, the Philox offset is read from it at run time instead
                                   of `offset` (a multiple of 4, like torch's) -- lets a captured HIP graph draw fresh
                                   numbers on every replay; advance it with rsa_rng_advance in the same graph. */
+  uint64_t elem_base;          /* Philox element index of flat element 0 (see "Philox state"); 0 on one GPU */
+  void* reduce_scratch;        /* loss_out != null: caller-owned scratch of rsa_scratch_bytes() bytes (zeroed once) */
+  const float* cdf_lines;      /* nullable [2^lines_log2][32] fp32 (128-byte aligned): BUCKET LINES, the one-HBM-line form of
+                                  the inverse CDF.  Line b describes u in [b, b+1) / 2^lines_log2 through the DISTINCT CDF
+                                  values inside it (items whose CDF equals their predecessor's can never be returned by
+                                  searchsorted and are left out):
+                                    [0] c = number of distinct values in the bucket (int32 bits)
+                                    [1] id, [2] pop_prob of the first distinct entry ABOVE the bucket (the answer when u
+                                        exceeds every value in it; n_items-1 past the end)
+                                    [3] lo, [28] hi: search range in `table` for the fallback (int32 bits)
+                                    [4..11]  the first min(c, 8) values, padded with +inf
+                                    [12..27] {id (int32 bits), pop_prob} of those entries
+                                  id = entry[#{values < u}] -- the same comparisons torch.searchsorted makes; only a
+                                  bucket with more than 8 distinct values whose first 8 are all below u falls back to the
+                                  binary search in [lo, hi].  Takes precedence over cdf_lut / guide. */
+  int32_t lines_log2;
+  int32_t _pad3;
 } rsa_fused_args;
 
 int rsa_fused_sample_gather_score(const rsa_fused_args* args, rsa_stream_t stream);
@@ -189,7 +222,7 @@ int rsa_rng_advance(uint64_t* offset_dev, uint64_t increment, rsa_stream_t strea
  * = d loss_out / d score. */
 int rsa_pairwise_loss(int32_t loss_kind, const float* pos_score, const float* neg_score,
                       const float* pos_logp, const float* neg_logp, int64_t n_rows, int32_t num_neg,
-                      float* row_loss, float* loss_out, float* dpos, float* dneg, rsa_stream_t stream);
+                      float* row_loss, float* loss_out, float* dpos, float* dneg, void* scratch, rsa_stream_t stream);
 
 /* The other PairwiseLoss classes of recstudio/model/loss_func.py, value + d loss/d score in one pass like
  * rsa_pairwise_loss:  RSA_LOSS_WBPR WeightedBPRLoss (:93-97; the softmax(neg - logQ) weights are differentiated
@@ -201,17 +234,18 @@ int rsa_pairwise_loss(int32_t loss_kind, const float* pos_score, const float* ne
 int rsa_pairwise_loss_ex(int32_t loss_kind, const float* pos_score, const float* neg_score,
                          const float* pos_logp, const float* neg_logp, int64_t n_rows, int32_t num_neg,
                          float param0, float param1, float* row_loss, float* loss_out, float* dpos, float* dneg,
-                         rsa_stream_t stream);
+                         void* scratch, rsa_stream_t stream);
 
 /* SampledSoftmaxLoss.forward when pos_score [B, L] and neg_score [B, n] have the SAME rank
  * (recstudio/model/loss_func.py:84-89): the L positives of a row share its n negatives; padded
  * positives (+-inf) contribute nothing and are not counted.  Value + gradients in one pass. */
 int rsa_ssm_shared_loss(const float* pos_score, const float* pos_logp, const float* neg_score,
                         const float* neg_logp, int64_t n_rows, int32_t n_pos, int32_t num_neg,
-                        float* row_loss, float* loss_out, float* dpos, float* dneg, rsa_stream_t stream);
+                        float* row_loss, float* loss_out, float* dpos, float* dneg, void* scratch,
+                        rsa_stream_t stream);
 
 /* out[0] = mean(row_loss[0..n_rows)) in a fixed summation order (two tiny launches). */
-int rsa_mean_rows(const float* row_loss, int64_t n_rows, float* out, rsa_stream_t stream);
+int rsa_mean_rows(const float* row_loss, int64_t n_rows, float* out, void* scratch, rsa_stream_t stream);
 
 /* SoftmaxLoss.forward on a MATERIALISED score matrix -- recstudio/model/loss_func.py:41:
  * lse[m] = logsumexp(x[m, :]); softmax_scaled (nullable) [n_rows, n_cols] = softmax(x) * scale
@@ -268,7 +302,8 @@ int rsa_fused_backward(const rsa_backward_args* args, rsa_stream_t stream);
  * element order, then the row is read-modified-written once.  `target` [n_items, dim] is a zeroed dense gradient
  * (== the reference's weight.grad, recommender.py:636-639) or the weight table itself with upstream = -lr (plain
  * SGD in place).  dim in {64, 128, 256}; pos_ids / dpos nullable; query_index nullable (query row m);
- * upstream: nullable device scalar; pad_row < 0: none.  Workspace from the _workspace_bytes call. */
+ * upstream: nullable device scalar; pad_row < 0: none.  Elements whose id is NEGATIVE are dropped (empty slots of
+ * the fixed-capacity shard exchange): nothing is read or written for them.  Workspace from the _workspace_bytes call. */
 int64_t rsa_scatter_rows_sorted_workspace_bytes(int64_t n_queries, int32_t num_neg, int64_t n_items);
 int rsa_scatter_rows_sorted(const float* query, const int64_t* query_index, int64_t n_query_rows, int32_t dim,
                             const int64_t* pos_ids, const int64_t* neg_ids, int64_t n_queries, int32_t num_neg,
@@ -304,7 +339,12 @@ int rsa_seg_gather(const float* item_table, int64_t n_items, int32_t dim,
                    const int64_t* seg_start, const int64_t* seg_end, int64_t n_seg, int32_t max_len,
                    int64_t* out_ids, float* out_rows, int64_t* out_len, rsa_stream_t stream);
 
-/* Full-catalog scoring -- InnerProductScorer ([B,d],[N,d]) case, scorer.py:16,
+/* aux[r] of every row of a [n_rows, dim] table, the per-row operand of the cosine / Euclidean full-catalog scores:
+ * RSA_SCORE_COS -> 1 / ||row||_2 (inf for a zero row: the reference divides by zero too, scorer.py:21-24),
+ * RSA_SCORE_EUC -> ||row||_2^2 (scorer.py:28-34).  dim % 4 == 0. */
+int rsa_row_sqnorm(const float* table, int64_t n_rows, int32_t dim, int32_t score_mode, float* out, rsa_stream_t stream);
+
+/* Full-catalog scoring -- InnerProductScorer / CosineScorer / EuclideanScorer ([B,d],[N,d]) case, scorer.py:16, :19-34,
  * called from baseretriever.py:183-186 (training, FullScoreLoss) and :384 (topk).
  * Scores query [B, dim] against item_table rows [1, n_items) (item_vector =
  * weight[1:], baseretriever.py:122-123) with the fp32 MFMA
@@ -314,11 +354,16 @@ int rsa_seg_gather(const float* item_table, int64_t n_items, int32_t dim,
  *   topk_val / topk_idx : nullable [B, k] out, k <= 1024: largest k scores in descending order,
  *     ids are ITEM ids (1-based, baseretriever.py:385); equal scores -> smaller id first.
  *   dim must be 32, 64 or 128 (RSA_ERR_UNSUPPORTED otherwise).
+ *   score_mode RSA_SCORE_COS / RSA_SCORE_EUC: the dot products of a tile are turned into cosine / negative squared
+ *     distance in the tile epilogue, before logsumexp / filter / store:  cos = dot * item_aux * query_aux,
+ *     euc = 2 dot - item_aux - query_aux, with item_aux [n_items - 1] (entry i-1 belongs to item row i; 16-byte
+ *     aligned) and query_aux [B] from rsa_row_sqnorm of the same mode; both null for RSA_SCORE_IP.
  *   workspace: device scratch of rsa_fullscore_workspace_bytes(B, n_items, k) bytes. */
 int64_t rsa_fullscore_workspace_bytes(int64_t n_query, int64_t n_items, int32_t k);
 int rsa_fullscore(const float* item_table, int64_t n_items, int32_t dim,
                   const float* query, int64_t n_query,
                   float* scores, float* lse, float* topk_val, int64_t* topk_idx, int32_t k,
+                  int32_t score_mode, const float* item_aux, const float* query_aux,
                   void* workspace, int64_t workspace_bytes, rsa_stream_t stream);
 
 /* Backward of logsumexp over the full catalog (SoftmaxLoss, loss_func.py:39-47, when the forward was
@@ -359,10 +404,22 @@ int rsa_shard_count(const int64_t* pos_ids, const int64_t* neg_ids, int64_t n_qu
 int rsa_shard_route(const int64_t* pos_ids, const int64_t* neg_ids, int64_t n_queries, int32_t num_neg,
                     int64_t rows_per_shard, int32_t n_shards, int64_t query_base, int32_t* cursor,
                     int64_t* keys, int64_t* positions, rsa_stream_t stream);
+/* FIXED-CAPACITY form of the routing (no owner histogram, no split sizes on the host): owner g's segment is
+ * slots [g*capacity, (g+1)*capacity) of keys / positions [n_shards*capacity].  Both arrays are filled with -1
+ * ("empty slot") by this call first; empty slots travel through the equal-split all-to-all as they are and
+ * every consumer skips them: rsa_fused_sample_gather_score (packed_keys < 0 -> score 0), rsa_shard_unpack
+ * (-> row -1, query -1), rsa_scatter_rows_sorted (negative ids dropped), rsa_scatter_f32 / rsa_gather_f32
+ * (negative position -> nothing written / 0).  An element that finds its owner's segment full is NOT routed and
+ * is counted in *overflow (device word, zeroed by the caller once, sticky): the caller sizes `capacity` from a
+ * calibration step and checks the word off the critical path.  cursor: [n_shards] int32 device scratch. */
+int rsa_shard_route_fixed(const int64_t* pos_ids, const int64_t* neg_ids, int64_t n_queries, int32_t num_neg,
+                          int64_t rows_per_shard, int32_t n_shards, int64_t query_base, int64_t capacity,
+                          int32_t* cursor, int64_t* keys, int64_t* positions, int32_t* overflow, rsa_stream_t stream);
 int rsa_shard_unpack(const int64_t* keys, int64_t numel, int64_t* local_rows, int64_t* query_index,
                      rsa_stream_t stream);
+/* dst[positions[i]] = src[i] for positions[i] >= 0 */
 int rsa_scatter_f32(const float* src, const int64_t* positions, int64_t numel, float* dst, rsa_stream_t stream);
-/* dst[i] = src[positions[i]]: d loss/d score in routed order for the gradient exchange. */
+/* dst[i] = positions[i] >= 0 ? src[positions[i]] : 0: d loss/d score in routed order for the gradient exchange. */
 int rsa_gather_f32(const float* src, const int64_t* positions, int64_t numel, float* dst, rsa_stream_t stream);
 
 #ifdef __cplusplus

@@ -10,7 +10,9 @@ import subprocess
 from ctypes import (POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_uint32, c_uint64, c_void_p)
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, 'librecstudio_amd.so')
+# RSA_LIB: load another build of the same sources (tools/build_variant.sh writes librecstudio_amd_<name>.so next to the
+# default one for A/B measurements of compile-time switches); the ABI check below still applies
+LIB_PATH = os.environ.get('RSA_LIB') or os.path.join(HERE, 'librecstudio_amd.so')
 CSRC = os.path.join(HERE, 'csrc')
 
 RSA_OK = 0
@@ -37,6 +39,7 @@ class FusedArgs(Structure):
         ('pos_score', c_void_p), ('neg_score', c_void_p), ('table_prob', c_void_p),
         ('fused_loss', c_int32), ('_pad2', c_int32), ('row_loss', c_void_p), ('loss_out', c_void_p),
         ('dpos', c_void_p), ('dneg', c_void_p), ('cdf_lut', c_void_p), ('query_grad', c_void_p), ('packed_keys', c_void_p), ('offset_dev', c_void_p),
+        ('elem_base', c_uint64), ('reduce_scratch', c_void_p), ('cdf_lines', c_void_p), ('lines_log2', c_int32), ('_pad3', c_int32),
     ]
 
 
@@ -57,24 +60,25 @@ class BackwardArgs(Structure):
 SIGNATURES = {
     'rsa_last_error': (c_char_p, []),
     'rsa_abi_version': (c_int, []),
+    'rsa_scratch_bytes': (c_int64, []),
     'rsa_device_info': (c_int, [c_int, POINTER(c_int32), POINTER(c_int32), POINTER(c_int32)]),
-    'rsa_sample_uniform': (c_int, [c_void_p, c_int64, c_int64, c_int64, c_uint64, c_uint64, c_uint32, c_void_p]),
+    'rsa_sample_uniform': (c_int, [c_void_p, c_int64, c_int64, c_int64, c_uint64, c_uint64, c_uint32, c_uint64, c_void_p]),
     'rsa_sample_masked_uniform': (c_int, [c_void_p, c_int64, c_int32, c_int64, c_int32, c_void_p, c_uint64, c_uint64,
                                           c_uint32, c_void_p]),
     'rsa_sample_popular': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p,
-                                   c_int64, c_uint64, c_uint64, c_uint32, c_void_p, c_void_p]),
+                                   c_int64, c_uint64, c_uint64, c_uint32, c_uint64, c_void_p, c_void_p, c_int32, c_void_p]),
     'rsa_popular_lookup': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p,
-                                   c_int64, c_void_p, c_void_p]),
+                                   c_int64, c_void_p, c_void_p, c_int32, c_void_p]),
     'rsa_item_logp': (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p]),
     'rsa_embedding_gather': (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_int64, c_void_p, c_void_p]),
     'rsa_fused_sample_gather_score': (c_int, [POINTER(FusedArgs), c_void_p]),
     'rsa_pairwise_loss': (c_int, [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p,
-                                  c_void_p, c_void_p, c_void_p, c_void_p]),
+                                  c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'rsa_pairwise_loss_ex': (c_int, [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_float, c_float,
-                                     c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+                                     c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'rsa_ssm_shared_loss': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p,
-                                    c_void_p, c_void_p, c_void_p, c_void_p]),
-    'rsa_mean_rows': (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
+                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'rsa_mean_rows': (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     'rsa_row_lse': (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_float, c_void_p]),
     'rsa_fused_backward': (c_int, [POINTER(BackwardArgs), c_void_p]),
     'rsa_scatter_add_rows': (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_int64, c_void_p]),
@@ -95,12 +99,15 @@ SIGNATURES = {
     'rsa_shard_count': (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_int64, c_int32, c_void_p, c_void_p]),
     'rsa_shard_route': (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_int64, c_int32, c_int64, c_void_p, c_void_p,
                                 c_void_p, c_void_p]),
+    'rsa_shard_route_fixed': (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_int64, c_int32, c_int64, c_int64, c_void_p,
+                                      c_void_p, c_void_p, c_void_p, c_void_p]),
     'rsa_shard_unpack': (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     'rsa_scatter_f32': (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     'rsa_gather_f32': (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     'rsa_fullscore_workspace_bytes': (c_int64, [c_int64, c_int64, c_int32]),
     'rsa_fullscore': (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
-                              c_int32, c_void_p, c_int64, c_void_p]),
+                              c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    'rsa_row_sqnorm': (c_int, [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p]),
 }
 
 _lib = None
@@ -119,7 +126,7 @@ def build(verbose=False):
     return LIB_PATH
 
 
-ABI_VERSION = 2      # RSA_ABI_VERSION of include/recstudio_amd.h this binding was written against
+ABI_VERSION = 3      # RSA_ABI_VERSION of include/recstudio_amd.h this binding was written against
 
 
 def lib():

@@ -48,13 +48,25 @@ struct PhiloxCall {
   uint64_t seed;
   uint64_t offset4;        // generator offset / 4 (torch offsets are multiples of 4)
   uint32_t grid_threads;   // G
+  uint64_t elem_base;      // element index of this launch's element 0 inside the (global) torch call
 };
+
+// ---------------------------------------------------------------- caller-owned reduction scratch
+// Layout of the rsa_scratch_bytes() block (zero-filled once by the caller):
+//   [0]     arrival counter of the in-kernel loss reduction (self-resetting)
+//   [64]    valid-row counter of the BCE losses (reset by a memset before each use)
+//   [256]   one float per workgroup of the fused forward (grid <= SCRATCH_MAX_GRID)
+//   [256 + 4 * SCRATCH_MAX_GRID]   256 stage-1 partials of rsa_mean_rows
+constexpr int SCRATCH_MAX_GRID = 4096;
+constexpr int64_t SCRATCH_COUNTER = 0, SCRATCH_BCE_COUNT = 64, SCRATCH_FUSED_PARTIALS = 256,
+                  SCRATCH_MEAN_PARTIALS = 256 + 4 * SCRATCH_MAX_GRID, SCRATCH_BYTES = SCRATCH_MEAN_PARTIALS + 4 * 256;
 
 // Raw philox draw for output element li of a call whose per-draw unroll is UNROLL
 // (4: 32-bit ints and floats, 2: 64-bit ints).  Returns the 4 words and the
 // component index the element owns.
 template <int UNROLL>
 __device__ __forceinline__ uint4 philox_for_element(const PhiloxCall& pc, uint64_t li, int& comp) {
+  li += pc.elem_base;
   uint64_t idx, j;
   if (li < pc.grid_threads) {   // common case: every element on its own subsequence, first draw
     idx = li;
@@ -189,6 +201,50 @@ __device__ __forceinline__ int32_t cdf_lookup_lut(const float4* __restrict__ lut
                                                   int guide_log2, float u, float& pr) {
   return cdf_resolve_lut<STRIDE>(lut[lut_bucket(guide_log2, u)], lut, cdf, prob, prob_stride, n_items, guide_log2, u,
                                  pr);
+}
+
+// Bucket-line form (layout: include/recstudio_amd.h, rsa_fused_args.cdf_lines): one 128-byte line per bucket holds
+// the bucket's first 8 DISTINCT CDF values with their {id, probability}; hdr = line[0..3], c0 = line[4..7],
+// c1 = line[8..11] (three 16-byte loads of the same line, issued together).  Same comparisons as
+// torch.searchsorted, same index; one HBM line per draw.
+constexpr int LINE_K = 8;
+__device__ __forceinline__ int32_t lines_bucket(int lines_log2, float u) { return lut_bucket(lines_log2, u); }
+
+__device__ __forceinline__ int32_t cdf_resolve_line(const float4 hdr, const float4 c0, const float4 c1,
+                                                    const float* __restrict__ line, const float* __restrict__ cdf,
+                                                    int cdf_stride, const float* __restrict__ prob, int prob_stride,
+                                                    int64_t n_items, float u, float& pr) {
+  const int c = __float_as_int(hdr.x);
+  const int k = (c0.x < u) + (c0.y < u) + (c0.z < u) + (c0.w < u) + (c1.x < u) + (c1.y < u) + (c1.z < u) + (c1.w < u);
+  if (k < LINE_K || c <= LINE_K) {          // the padding is +inf, so k <= min(c, 8)
+    if (k < c) {
+      const float2 e = *reinterpret_cast<const float2*>(line + 12 + 2 * k);
+      pr = e.y;
+      return __float_as_int(e.x);
+    }
+    pr = hdr.z;
+    return __float_as_int(hdr.y);
+  }
+  // more than 8 distinct values in the bucket and u above the first 8: binary search in the full table
+  int32_t lo = __float_as_int(hdr.w), hi = __float_as_int(line[28]);
+  while (lo < hi) {
+    const int32_t mid = lo + ((hi - lo) >> 1);
+    if (cdf[(size_t)mid * cdf_stride] < u) lo = mid + 1; else hi = mid;
+  }
+  const int32_t last = (int32_t)(n_items - 1);
+  lo = lo > last ? last : lo;
+  pr = prob[(size_t)lo * prob_stride];
+  return lo;
+}
+
+__device__ __forceinline__ int32_t cdf_lookup_line(const float* __restrict__ lines, int lines_log2,
+                                                   const float* __restrict__ cdf, int cdf_stride,
+                                                   const float* __restrict__ prob, int prob_stride, int64_t n_items,
+                                                   float u, float& pr) {
+  const float* line = lines + (size_t)lines_bucket(lines_log2, u) * 32;
+  const float4* l4 = reinterpret_cast<const float4*>(line);
+  const float4 hdr = l4[0], c0 = l4[1], c1 = l4[2];
+  return cdf_resolve_line(hdr, c0, c1, line, cdf, cdf_stride, prob, prob_stride, n_items, u, pr);
 }
 
 // ---------------------------------------------------------------- wave helpers

@@ -75,12 +75,18 @@ struct FilterArgs {
   int32_t* ovf_cnt;     // [n_query], zeroed by the host
   float* ovf_val;       // [n_query, OVF]
   int32_t* ovf_idx;     // [n_query, OVF]
+  // Cosine / Euclidean scores (MODE != 0): per-item and per-query operands from rsa_row_sqnorm
+  const float* item_aux;   // [n_items - 1], entry i-1 for item row i
+  const float* query_aux;  // [n_query]
 };
 
 // tile_stride == 1: the workgroup walks the contiguous item range [1 + bx*items_per_split, ...).
 // tile_stride  > 1: SAMPLE mode -- "item" positions are sample positions; sample tile s reads catalog tile
 // s*tile_stride, and scores are written to a dense [n_query, score_ld] sample matrix.
-template <int D, bool LSE, bool SCORES, bool FILTER>
+// MODE: rsa_score_mode.  For RSA_SCORE_COS / RSA_SCORE_EUC the tile's dot products are turned into the score in the
+// epilogue (cos = dot * item_aux * query_aux, euc = 2 dot - item_aux - query_aux) before logsumexp / filter / store; the
+// inner-product instantiation is unchanged.
+template <int D, bool LSE, bool SCORES, bool FILTER, int MODE = 0>
 __global__ __launch_bounds__(256, RSA_FS_MIN_BLOCKS) void fullscore_kernel(const float* __restrict__ item_table, int64_t n_items,
                                                         const float* __restrict__ query, int64_t n_query,
                                                         float* __restrict__ scores, int64_t score_ld,
@@ -118,6 +124,31 @@ __global__ __launch_bounds__(256, RSA_FS_MIN_BLOCKS) void fullscore_kernel(const
   const int n_tiles = i_begin < i_end ? (int)((i_end - i_begin + TI - 1) / TI) : 0;
   float thr = INFINITY;
   if (flt.thr != nullptr && q < n_query) thr = flt.thr[q];
+  float q_aux = 0.f;
+  if constexpr (MODE != 0) q_aux = flt.query_aux[q < n_query ? q : 0];
+  // the lane's 16 rows of a tile are 4 runs of 4 consecutive items: 4 aligned 16-byte loads of item_aux per tile
+  auto to_score = [&](const f32x16& acc, int64_t i0) __attribute__((always_inline)) -> f32x16 {
+    if constexpr (MODE == 0) {
+      return acc;
+    } else {
+      const int64_t item0 = tile_stride == 1 ? i0 : 1 + ((i0 - 1) / TI) * tile_stride * TI;
+      f32x16 out;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        // (the last tile of a range may reach up to TI - 1 rows past the table: item_aux is allocated with 64 floats
+        // of padding, those rows are masked by the callers)
+        const int64_t a0 = item0 - 1 + 8 * g + 4 * h;
+        const float4 xa = *reinterpret_cast<const float4*>(flt.item_aux + a0);
+        const float xs[4] = {xa.x, xa.y, xa.z, xa.w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float d = acc[4 * g + r];
+          out[4 * g + r] = MODE == RSA_SCORE_COS ? d * xs[r] * q_aux : __fmaf_rn(2.f, d, -xs[r]) - q_aux;
+        }
+      }
+      return out;
+    }
+  };
   float my_lse = 0.f, my_scale = 1.f;
   const bool softmax_out = SCORES && flt.sm_lse != nullptr;
   if (softmax_out && q < n_query) {
@@ -292,6 +323,7 @@ __global__ __launch_bounds__(256, RSA_FS_MIN_BLOCKS) void fullscore_kernel(const
     if (sub == 0) fetch(st + 1);          // global loads fly under this stage's MFMA chains
 #endif
     const f32x16 acc = mfma_tile(cur, sub);
+    if constexpr (MODE != 0) acc_prev = to_score(acc_prev, i_begin + (int64_t)(u - 1) * TI);
     if constexpr (LSE) {
       lse_update(acc_prev, i_begin + (int64_t)(u - 1) * TI, masked);
       // one MFMA of this tile, then a couple of the previous tile's epilogue VALU ops, and so on
@@ -315,6 +347,7 @@ __global__ __launch_bounds__(256, RSA_FS_MIN_BLOCKS) void fullscore_kernel(const
   int u = 1;
   for (; u <= fast_end; ++u) iteration(u, std::false_type{});
   for (; u < total_tiles; ++u) iteration(u, std::true_type{});
+  if constexpr (MODE != 0) acc_prev = to_score(acc_prev, i_begin + (int64_t)(total_tiles - 1) * TI);
   if constexpr (LSE) lse_update(acc_prev, i_begin + (int64_t)(total_tiles - 1) * TI, std::true_type{});
   emit(acc_prev, i_begin + (int64_t)(total_tiles - 1) * TI);
   if (FILTER && q < n_query) flt.seg_cnt[seg] = my_cnt;
@@ -370,6 +403,9 @@ struct SelectArgs {
   int32_t dim;
   float* thr_out;           // THRESHOLD: [n_rows] the k-th largest value of each row
   int32_t idx_base;         // DENSE: reported index = column + idx_base (1: item ids of a catalog row, 0: columns)
+  int32_t score_mode;       // RECOMPUTE: rsa_score_mode with item_aux [n_cols] / query_aux [n_rows]
+  const float* item_aux;
+  const float* query_aux;
 };
 
 // Exact top-k of one row (one 1024-thread workgroup per row): 3-pass radix select on the order-preserving
@@ -444,6 +480,8 @@ __global__ __launch_bounds__(1024) void topk_row_kernel(SelectArgs a, int k, flo
       const float* it = a.item_table + (size_t)(i + 1) * a.dim;
       float acc = 0.f;
       for (int c = 0; c < a.dim; ++c) acc = __fmaf_rn(it[c], qrow[c], acc);
+      if (a.score_mode == RSA_SCORE_COS) acc = acc * a.item_aux[i] * a.query_aux[r];
+      else if (a.score_mode == RSA_SCORE_EUC) acc = __fmaf_rn(2.f, acc, -a.item_aux[i]) - a.query_aux[r];
       return acc;
     }
     if (MODE == SEL_CAND) return cval[i];
@@ -681,13 +719,13 @@ extern "C" int64_t rsa_fullscore_workspace_bytes(int64_t n_query, int64_t n_item
   return bytes + 256;
 }
 
-template <int D>
+template <int D, int MODE>
 static void launch_gemm(dim3 grid, hipStream_t s, const float* item_table, int64_t n_items, const float* query,
                         int64_t n_query, float* scores, int64_t score_ld, float2* lse_part, int splits, int64_t per,
                         int64_t tile_stride, int64_t n_positions, FilterArgs flt) {
   const bool L = lse_part != nullptr, S = scores != nullptr, F = flt.thr != nullptr;
-#define RSA_GEMM(LL, SS, FF)                                                                                       \
-  hipLaunchKernelGGL((fullscore_kernel<D, LL, SS, FF>), grid, dim3(256), 0, s, item_table, n_items, query, n_query, \
+#define RSA_GEMM(LL, SS, FF)                                                                                             \
+  hipLaunchKernelGGL((fullscore_kernel<D, LL, SS, FF, MODE>), grid, dim3(256), 0, s, item_table, n_items, query, n_query, \
                      scores, score_ld, lse_part, splits, per, tile_stride, n_positions, flt)
   if (L && !S && !F) RSA_GEMM(true, false, false);        // training: logsumexp only
   else if (L && !S && F) RSA_GEMM(true, false, true);     // eval: logsumexp + candidate filter
@@ -698,18 +736,26 @@ static void launch_gemm(dim3 grid, hipStream_t s, const float* item_table, int64
 #undef RSA_GEMM
 }
 
-static void gemm_dispatch(int dim, dim3 grid, hipStream_t s, const float* item_table, int64_t n_items,
+static void gemm_dispatch(int dim, int mode, dim3 grid, hipStream_t s, const float* item_table, int64_t n_items,
                           const float* query, int64_t n_query, float* scores, int64_t score_ld, float2* lse_part,
                           int splits, int64_t per, int64_t tile_stride, int64_t n_positions, FilterArgs flt) {
+#define RSA_DIM(DD, MM) launch_gemm<DD, MM>(grid, s, item_table, n_items, query, n_query, scores, score_ld, lse_part, splits, per, tile_stride, n_positions, flt)
+#define RSA_MODE(DD)                       \
+  if (mode == RSA_SCORE_COS) RSA_DIM(DD, 1); \
+  else if (mode == RSA_SCORE_EUC) RSA_DIM(DD, 2); \
+  else RSA_DIM(DD, 0)
   switch (dim) {
-    case 32: launch_gemm<32>(grid, s, item_table, n_items, query, n_query, scores, score_ld, lse_part, splits, per, tile_stride, n_positions, flt); break;
-    case 64: launch_gemm<64>(grid, s, item_table, n_items, query, n_query, scores, score_ld, lse_part, splits, per, tile_stride, n_positions, flt); break;
-    default: launch_gemm<128>(grid, s, item_table, n_items, query, n_query, scores, score_ld, lse_part, splits, per, tile_stride, n_positions, flt); break;
+    case 32: RSA_MODE(32); break;
+    case 64: RSA_MODE(64); break;
+    default: RSA_MODE(128); break;
   }
+#undef RSA_MODE
+#undef RSA_DIM
 }
 
 extern "C" int rsa_fullscore(const float* item_table, int64_t n_items, int32_t dim, const float* query,
                              int64_t n_query, float* scores, float* lse, float* topk_val, int64_t* topk_idx, int32_t k,
+                             int32_t score_mode, const float* item_aux, const float* query_aux,
                              void* workspace, int64_t workspace_bytes, rsa_stream_t stream) {
   RSA_CHECK_ARG(n_query >= 0 && n_items >= 2, "rsa_fullscore: need n_items >= 2");
   if (n_query == 0) return RSA_OK;
@@ -717,6 +763,9 @@ extern "C" int rsa_fullscore(const float* item_table, int64_t n_items, int32_t d
   RSA_CHECK_ARG(scores || lse || k > 0, "rsa_fullscore: no output requested");
   RSA_CHECK_ARG(k >= 0 && k <= 1024 && (int64_t)k <= n_items - 1, "rsa_fullscore: k must be in [0, min(1024, n_items-1)]");
   RSA_CHECK_ARG(k == 0 || (topk_val && topk_idx), "rsa_fullscore: topk outputs are null");
+  RSA_CHECK_ARG(score_mode >= RSA_SCORE_IP && score_mode <= RSA_SCORE_EUC, "rsa_fullscore: unknown score_mode %d", score_mode);
+  RSA_CHECK_ARG(score_mode == RSA_SCORE_IP || (item_aux && query_aux && ((uintptr_t)item_aux & 15) == 0),
+                "rsa_fullscore: cosine / Euclidean scores need item_aux (16-byte aligned) and query_aux");
   if (dim != 32 && dim != 64 && dim != 128) {
     rsa::set_error("rsa_fullscore: dim=%d: the MFMA full-score kernel is built for dim in {32, 64, 128}", dim);
     return RSA_ERR_UNSUPPORTED;
@@ -735,7 +784,7 @@ extern "C" int rsa_fullscore(const float* item_table, int64_t n_items, int32_t d
   float2* part = reinterpret_cast<float2*>(ws);
   ws += align256(n_query * splits * (int64_t)sizeof(float2));
   float2* lp = lse ? part : nullptr;
-  const FilterArgs no_filter{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  const FilterArgs no_filter{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, item_aux, query_aux};
 
   if (pl.filter) {
     float* sample = reinterpret_cast<float*>(ws);      ws += align256(n_query * pl.sample_items * 4);
@@ -752,7 +801,7 @@ extern "C" int rsa_fullscore(const float* item_table, int64_t n_items, int32_t d
     const int64_t ssplits = fullscore_splits(n_query, pl.sample_items);
     const int64_t sper = ((pl.sample_items + ssplits - 1) / ssplits + TI - 1) / TI * TI;
     const int64_t ssplits_used = (pl.sample_items + sper - 1) / sper;
-    gemm_dispatch(dim, dim3((unsigned)ssplits_used, groups), s, item_table, n_items, query, n_query, sample,
+    gemm_dispatch(dim, score_mode, dim3((unsigned)ssplits_used, groups), s, item_table, n_items, query, n_query, sample,
                   pl.sample_items, nullptr, (int)ssplits_used, sper, pl.tile_stride, pl.sample_items, no_filter);
     RSA_CHECK_LAUNCH("rsa_fullscore(sample gemm)");
     SelectArgs sa{};
@@ -765,8 +814,8 @@ extern "C" int rsa_fullscore(const float* item_table, int64_t n_items, int32_t d
       rsa::set_error("rsa_fullscore: memset failed");
       return RSA_ERR_HIP;
     }
-    const FilterArgs flt{thr, seg_cnt, cand_val, cand_idx, nullptr, nullptr, ovf_cnt, ovf_val, ovf_idx};
-    gemm_dispatch(dim, dim3((unsigned)splits_used, groups), s, item_table, n_items, query, n_query, nullptr, n_cols, lp,
+    const FilterArgs flt{thr, seg_cnt, cand_val, cand_idx, nullptr, nullptr, ovf_cnt, ovf_val, ovf_idx, item_aux, query_aux};
+    gemm_dispatch(dim, score_mode, dim3((unsigned)splits_used, groups), s, item_table, n_items, query, n_query, nullptr, n_cols, lp,
                   (int)splits_used, per, 1, n_cols, flt);
     RSA_CHECK_LAUNCH("rsa_fullscore(gemm+filter)");
     // C. exact select over the candidates;  D. exact recompute of flagged rows
@@ -777,14 +826,15 @@ extern "C" int rsa_fullscore(const float* item_table, int64_t n_items, int32_t d
                        topk_idx);
     SelectArgs ra{};
     ra.flags = flags; ra.n_cols = n_cols; ra.item_table = item_table; ra.query = query; ra.dim = dim; ra.values = query;
+    ra.score_mode = score_mode; ra.item_aux = item_aux; ra.query_aux = query_aux;
     hipLaunchKernelGGL(topk_row_kernel<SEL_RECOMPUTE>, dim3((unsigned)n_query), dim3(1024), 0, s, ra, (int)k, topk_val,
                        topk_idx);
     RSA_CHECK_LAUNCH("rsa_fullscore(select)");
   } else {
     float* score_rows = scores;
     if (k > 0 && scores == nullptr) score_rows = reinterpret_cast<float*>(ws);
-    gemm_dispatch(dim, dim3((unsigned)splits_used, groups), s, item_table, n_items, query, n_query, score_rows, n_cols,
-                  lp, (int)splits_used, per, 1, n_cols, no_filter);
+    gemm_dispatch(dim, score_mode, dim3((unsigned)splits_used, groups), s, item_table, n_items, query, n_query, score_rows,
+                  n_cols, lp, (int)splits_used, per, 1, n_cols, no_filter);
     RSA_CHECK_LAUNCH("rsa_fullscore(gemm)");
     if (k > 0) {
       SelectArgs da{};
@@ -817,8 +867,8 @@ extern "C" int rsa_fullscore_softmax(const float* item_table, int64_t n_items, i
   const int64_t splits = fullscore_splits(n_query, n_cols);
   const int64_t per = ((n_cols + splits - 1) / splits + TI - 1) / TI * TI;
   const int64_t splits_used = (n_cols + per - 1) / per;
-  const FilterArgs ep{nullptr, nullptr, nullptr, nullptr, lse, row_scale, nullptr, nullptr, nullptr};
-  gemm_dispatch(dim, dim3((unsigned)splits_used, groups), (hipStream_t)stream, item_table, n_items, query, n_query, probs,
+  const FilterArgs ep{nullptr, nullptr, nullptr, nullptr, lse, row_scale, nullptr, nullptr, nullptr, nullptr, nullptr};
+  gemm_dispatch(dim, RSA_SCORE_IP, dim3((unsigned)splits_used, groups), (hipStream_t)stream, item_table, n_items, query, n_query, probs,
                 n_cols, nullptr, (int)splits_used, per, 1, n_cols, ep);
   RSA_CHECK_LAUNCH("rsa_fullscore_softmax");
   return RSA_OK;

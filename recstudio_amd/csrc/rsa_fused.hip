@@ -26,6 +26,9 @@
 #ifndef RSA_QG_BATCH
 #define RSA_QG_BATCH 8     // rows per load batch of the training forward (4 / 2 measured: same register count)
 #endif
+#ifndef RSA_QG_PIPELINE
+#define RSA_QG_PIPELINE 0  // 1: double-buffered batches pinned by data dependences (A/B on the GPU before switching)
+#endif
 
 namespace rsa {
 
@@ -38,6 +41,7 @@ struct FwdParams {
   const float* pop_prob;
   const float* table_prob;
   const float* lut;
+  const float* lines;          // bucket lines [2^lines_log2][32] (nullable)
   const int32_t* guide;
   int64_t* neg_ids;
   float* neg_logp;
@@ -55,8 +59,33 @@ struct FwdParams {
   float* qgrad;      // fused BPR epilogue (nullable): [M, dim] d loss / d query row, accumulated from the rows in flight
   int64_t n_items, n_query_rows, n_queries, numel;
   PhiloxCall pc;
-  int32_t dim, num_neg, sampler, mask_pad_pos, guide_log2, score_mode;
+  int32_t dim, num_neg, sampler, mask_pad_pos, guide_log2, score_mode, lines_log2;
 };
+
+// Inverse CDF of the popularity sampler for a draw u, by the best structure the caller supplied: bucket lines
+// (one HBM line), direct-lookup table (+ one 4-wide probe), or the guide table + binary search.  All return
+// torch.searchsorted(table, u) clamped to n_items-1 and the id's probability.
+__device__ __forceinline__ int32_t lookup_popular(const FwdParams& p, float u, float& pr) {
+  if (p.lines != nullptr) {
+    if (p.table_prob) return cdf_lookup_line(p.lines, p.lines_log2, p.table_prob, 2, p.table_prob + 1, 2, p.n_items, u, pr);
+    return cdf_lookup_line(p.lines, p.lines_log2, p.table, 1, p.pop_prob, 1, p.n_items, u, pr);
+  }
+  if (p.lut != nullptr) {   // direct lookup: one round trip for id AND probability in the common case
+    if (p.table_prob)
+      return cdf_lookup_lut<2>(reinterpret_cast<const float4*>(p.lut), p.table_prob, p.table_prob + 1, 2, p.n_items,
+                               p.guide_log2, u, pr);
+    return cdf_lookup_lut<1>(reinterpret_cast<const float4*>(p.lut), p.table, p.pop_prob, 1, p.n_items, p.guide_log2, u, pr);
+  }
+  int32_t id;
+  if (p.table_prob) {       // interleaved {cdf, prob}: the search and the probability share cache lines
+    id = cdf_lower_bound<2>(p.table_prob, p.guide, p.n_items, p.guide_log2, u);
+    pr = p.table_prob[2 * (size_t)id + 1];
+  } else {
+    id = cdf_lower_bound<1>(p.table, p.guide, p.n_items, p.guide_log2, u);
+    pr = p.pop_prob[id];
+  }
+  return id;
+}
 
 #ifndef RSA_FWD_NT_STORE
 #define RSA_FWD_NT_STORE 1
@@ -227,6 +256,35 @@ __device__ __forceinline__ void tile_rows_qg(const float* __restrict__ table, in
   const int sub = lane % LPR;
   const int gbase = lane - sub;
   dot = 0.f;
+#if RSA_QG_PIPELINE
+  // batch b+1 requested while batch b is consumed; order pinned by data dependences (see tile_rows_ssm)
+  F x[2][BATCH];
+  int gb = gbase;
+  auto request = [&](int b) __attribute__((always_inline)) {
+#pragma unroll
+    for (int k = 0; k < BATCH; ++k) {
+      const int32_t rid = __shfl(id_lane, gb + b * BATCH + k, 64);
+      frag_load<LPR, false, NT>(x[b & 1][k], table + (size_t)rid * D, sub, D);
+    }
+  };
+  request(0);
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    if (b + 1 < NB) request(b + 1);
+#pragma unroll
+    for (int k = 0; k < BATCH; ++k) {
+      const float dk = group_sum<LPR>(frag_dot<LPR, false>(x[b & 1][k], qf));
+      const float g = bpr_dneg(pos_s, dk, bw, binv);
+      const float4 xv = x[b & 1][k].v[0];
+      qacc.x = __fmaf_rn(g, xv.x, qacc.x);
+      qacc.y = __fmaf_rn(g, xv.y, qacc.y);
+      qacc.z = __fmaf_rn(g, xv.z, qacc.z);
+      qacc.w = __fmaf_rn(g, xv.w, qacc.w);
+      dot = sub == b * BATCH + k ? dk : dot;
+    }
+    asm volatile("" : "+v"(gb), "+v"(qacc.x), "+v"(qacc.y), "+v"(qacc.z), "+v"(qacc.w));
+  }
+#else
 #pragma unroll
   for (int b = 0; b < NB; ++b) {
     F x[BATCH];
@@ -249,6 +307,7 @@ __device__ __forceinline__ void tile_rows_qg(const float* __restrict__ table, in
     // keep the batches sequential: otherwise the scheduler hoists all LPR row loads to the top (222 VGPRs)
     __builtin_amdgcn_sched_barrier(0);
   }
+#endif
 }
 
 __device__ __forceinline__ float finish_score(int mode, float dot, float inorm2, float qnorm2) {
@@ -271,6 +330,55 @@ __device__ __forceinline__ float finish_score(int mode, float dot, float inorm2,
 #ifndef RSA_FWD_MIN_WAVES
 #define RSA_FWD_MIN_WAVES 1
 #endif
+#ifndef RSA_SSM_BATCH
+#define RSA_SSM_BATCH 4     // double-buffered: 2 * 4 row loads in flight per wave, 141 VGPRs at d = 128 (8: 180)
+#endif
+#ifndef RSA_FWD_LINES_AHEAD
+#define RSA_FWD_LINES_AHEAD 1     // bucket line of a wave's next tile fetched one tile ahead (12 more VGPRs than the LUT form)
+#endif
+
+// loss = mean of the per-query losses, in the SAME launch.  Every workgroup publishes the sum of its own waves'
+// losses (the unit -> wave assignment is static, so the partial is reproducible); the last workgroup to arrive adds
+// the partials in index order.  Saves two tiny launches per step (a quarter of the step at B = 4096).
+// Device-scope atomics only, no fences: a release/acquire fence here writes back / invalidates the whole XCD L2 on
+// every workgroup exit (measured: +90 us per launch).  The partial is published with a RETURNING exchange performed at
+// the memory side, and the arrival is counted only after that value has come back: the increment is made to depend on
+// it through an opaque asm, so neither the compiler nor the hardware can count the arrival before the partial is out.
+__device__ __forceinline__ void reduce_mean_loss(float wave_loss, float* __restrict__ loss_out,
+                                                 unsigned int* __restrict__ done_counter,
+                                                 float* __restrict__ loss_partials, int64_t n_queries) {
+  __shared__ int s_last;
+  __shared__ float s_red[256];
+  const int lane = lane_id();
+  const int wave = threadIdx.x >> 6;
+  if (lane == 0) s_red[wave] = wave_loss;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float part = 0.f;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) part += s_red[w];
+    const float prev = __hip_atomic_exchange(loss_partials + blockIdx.x, part, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned one = 1u;
+    asm volatile("; arrival waits for the partial" : "+v"(one) : "v"(prev));
+    const unsigned arrived = __hip_atomic_fetch_add(done_counter, one, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = arrived == gridDim.x - 1;
+    if (s_last) __hip_atomic_store(done_counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // reset
+  }
+  __syncthreads();
+  if (s_last) {
+    float acc = 0.f;
+    for (unsigned i = threadIdx.x; i < gridDim.x; i += 256)
+      acc += __hip_atomic_load(loss_partials + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    s_red[threadIdx.x] = acc;
+    __syncthreads();
+#pragma unroll
+    for (int w = 128; w >= 1; w >>= 1) {
+      if ((int)threadIdx.x < w) s_red[threadIdx.x] += s_red[threadIdx.x + w];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) loss_out[0] = s_red[0] / (float)n_queries;
+  }
+}
 template <int LPR, bool GENERIC, bool COS, bool QU, bool NT, bool QG = false>
 __global__ __launch_bounds__(256, QG ? RSA_QG_MIN_WAVES : RSA_FWD_MIN_WAVES) void fused_fwd_kernel(const FwdParams p) {
   using F = Frag<LPR, GENERIC>;
@@ -286,21 +394,38 @@ __global__ __launch_bounds__(256, QG ? RSA_QG_MIN_WAVES : RSA_FWD_MIN_WAVES) voi
 
   // Popularity sampler with the direct-lookup table: the draw and the LUT entry of the wave's NEXT tile are
   // fetched one tile ahead (5 VGPRs), so that a tile's row loads no longer wait behind the LUT round trip.
-  const bool ahead = RSA_FWD_LUT_AHEAD && QU && p.sampler == RSA_SAMPLER_POPULAR && p.lut != nullptr;
+  // (not in the training forward: 12 more live registers there cost a wave per SIMD)
+  const bool ahead_lines = RSA_FWD_LINES_AHEAD && !QG && QU && p.sampler == RSA_SAMPLER_POPULAR && p.lines != nullptr;
+  const bool ahead = ahead_lines || (RSA_FWD_LUT_AHEAD && QU && p.sampler == RSA_SAMPLER_POPULAR && p.lut != nullptr);
   float u_next = 0.f;
   float4 lut_next = make_float4(0.f, 0.f, 0.f, 0.f);
+#if RSA_FWD_LINES_AHEAD
+  float4 c0_next = make_float4(0.f, 0.f, 0.f, 0.f), c1_next = make_float4(0.f, 0.f, 0.f, 0.f);
+#endif
   auto fetch_ahead = [&](int64_t t) {
     const int64_t e2 = (t << 6) + lane;
     if (e2 < p.numel) {
       u_next = torch_rand_element(pc, (uint64_t)e2);
+      // one source pointer for both forms (the first 16 bytes of a bucket line play the LUT entry's role): separate
+      // if/else assignments of the carried registers made the compiler merge the stores through a pointer select
+      // and park the values in scratch
+      const float4* src = ahead_lines
+                              ? reinterpret_cast<const float4*>(p.lines + (size_t)lines_bucket(p.lines_log2, u_next) * 32)
+                              : reinterpret_cast<const float4*>(p.lut) + lut_bucket(p.guide_log2, u_next);
 #if RSA_LUT_NT
-      {   // the 134 MB table is read at random and an entry is never reused within a step: streaming hint
+      {   // the table is read at random and an entry is never reused within a step: streaming hint
         typedef float v4f __attribute__((ext_vector_type(4)));
-        const v4f v = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(p.lut) + lut_bucket(p.guide_log2, u_next));
+        const v4f v = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(src));
         lut_next = make_float4(v.x, v.y, v.z, v.w);
       }
 #else
-      lut_next = reinterpret_cast<const float4*>(p.lut)[lut_bucket(p.guide_log2, u_next)];
+      lut_next = src[0];
+#endif
+#if RSA_FWD_LINES_AHEAD
+      if (ahead_lines) {      // + the 8 values of the draw's bucket: two more 16-byte loads of the SAME line
+        c0_next = src[1];
+        c1_next = src[2];
+      }
 #endif
     }
   };
@@ -312,6 +437,9 @@ __global__ __launch_bounds__(256, QG ? RSA_QG_MIN_WAVES : RSA_FWD_MIN_WAVES) voi
     const int act = e < p.numel;
     const float u_cur = u_next;
     const float4 lut_cur = lut_next;
+#if RSA_FWD_LINES_AHEAD
+    const float4 c0_cur = c0_next, c1_cur = c1_next;
+#endif
 
     // ---- 0. (query-uniform path) the two scalar loads everything else hangs off -- query row index and
     // positive id -- are issued first so that their latency hides under the sampling chain below
@@ -334,37 +462,31 @@ __global__ __launch_bounds__(256, QG ? RSA_QG_MIN_WAVES : RSA_FWD_MIN_WAVES) voi
         st_out(&p.neg_ids[e], (int64_t)id);
       } else if (p.sampler == RSA_SAMPLER_POPULAR) {
         const float u = ahead ? u_cur : torch_rand_element(pc, (uint64_t)e);
+        float pr;
         if (ahead) {
-          float pr;
+#if RSA_FWD_LINES_AHEAD
+          if (ahead_lines) {
+            const float* line = p.lines + (size_t)lines_bucket(p.lines_log2, u) * 32;
+            if (p.table_prob)
+              id = cdf_resolve_line(lut_cur, c0_cur, c1_cur, line, p.table_prob, 2, p.table_prob + 1, 2, p.n_items, u, pr);
+            else
+              id = cdf_resolve_line(lut_cur, c0_cur, c1_cur, line, p.table, 1, p.pop_prob, 1, p.n_items, u, pr);
+          } else
+#endif
           if (p.table_prob)
             id = cdf_resolve_lut<2>(lut_cur, reinterpret_cast<const float4*>(p.lut), p.table_prob, p.table_prob + 1, 2,
                                     p.n_items, p.guide_log2, u, pr);
           else
             id = cdf_resolve_lut<1>(lut_cur, reinterpret_cast<const float4*>(p.lut), p.table, p.pop_prob, 1,
                                     p.n_items, p.guide_log2, u, pr);
-          st_out(&p.neg_ids[e], (int64_t)id);
-          if (p.neg_logp) st_out(&p.neg_logp[e], logf(pr));
-        } else if (p.lut) {   // direct lookup: one round trip for id AND probability in the common case
-          float pr;
-          if (p.table_prob)
-            id = cdf_lookup_lut<2>(reinterpret_cast<const float4*>(p.lut), p.table_prob, p.table_prob + 1, 2,
-                                   p.n_items, p.guide_log2, u, pr);
-          else
-            id = cdf_lookup_lut<1>(reinterpret_cast<const float4*>(p.lut), p.table, p.pop_prob, 1, p.n_items,
-                                   p.guide_log2, u, pr);
-          st_out(&p.neg_ids[e], (int64_t)id);
-          if (p.neg_logp) st_out(&p.neg_logp[e], logf(pr));
-        } else if (p.table_prob) {   // interleaved {cdf, prob}: the search and the log-prob share cache lines
-          id = cdf_lower_bound<2>(p.table_prob, p.guide, p.n_items, p.guide_log2, u);
-          st_out(&p.neg_ids[e], (int64_t)id);
-          if (p.neg_logp) st_out(&p.neg_logp[e], logf(p.table_prob[2 * (size_t)id + 1]));
         } else {
-          id = cdf_lower_bound<1>(p.table, p.guide, p.n_items, p.guide_log2, u);
-          st_out(&p.neg_ids[e], (int64_t)id);
-          if (p.neg_logp) st_out(&p.neg_logp[e], logf(p.pop_prob[id]));
+          id = lookup_popular(p, u, pr);
         }
+        st_out(&p.neg_ids[e], (int64_t)id);
+        if (p.neg_logp) st_out(&p.neg_logp[e], logf(pr));
       } else {
-        int64_t g = p.packed_keys ? (p.packed_keys[e] & 0xffffffffll) : p.neg_ids[e];
+        int64_t g = p.packed_keys ? p.packed_keys[e] : p.neg_ids[e];
+        if (p.packed_keys) g = g < 0 ? 0 : (g & 0xffffffffll);   // a negative key is an empty slot (row 0, query 0)
         g = g < 0 ? 0 : (g >= p.n_items ? p.n_items - 1 : g);   // clamp: never fault on a bad id
         id = (int32_t)g;
       }
@@ -377,6 +499,7 @@ __global__ __launch_bounds__(256, QG ? RSA_QG_MIN_WAVES : RSA_FWD_MIN_WAVES) voi
     F qf, px;
     int32_t qrow_lane = 0;
     float qn2_u = 0.f;
+    bool empty_slot = false;     // packed_keys < 0: the slot's score is 0
     if constexpr (QU) {
       frag_load<LPR, GENERIC>(qf, p.query + (size_t)qrow_u * D, sub, D);
       pad = pid_u == 0;
@@ -386,7 +509,11 @@ __global__ __launch_bounds__(256, QG ? RSA_QG_MIN_WAVES : RSA_FWD_MIN_WAVES) voi
     } else {
       m_lane = act ? e / n : 0;
       qrow_lane = (int32_t)(p.query_index ? (act ? p.query_index[m_lane] : 0) : m_lane);
-      if (p.packed_keys) qrow_lane = act ? (int32_t)(p.packed_keys[e] >> 32) : 0;
+      if (p.packed_keys) {
+        const int64_t key = act ? p.packed_keys[e] : 0;
+        qrow_lane = key < 0 ? 0 : (int32_t)(key >> 32);
+        if (key < 0) empty_slot = true;
+      }
       frag_load<LPR, GENERIC>(qf, p.query, sub, D);   // unused in this path
       px = qf;
     }
@@ -427,7 +554,7 @@ __global__ __launch_bounds__(256, QG ? RSA_QG_MIN_WAVES : RSA_FWD_MIN_WAVES) voi
       tile_rows<LPR, GENERIC, COS, QU, NT>(p.item_table, D, id, p.query, qrow_lane, qf, dot, in2, qn2);
     }
     if constexpr (COS && QU) qn2 = qn2_u;
-    if (act) st_out(&p.neg_score[e], finish_score(COS ? p.score_mode : RSA_SCORE_IP, dot, in2, qn2));
+    if (act) st_out(&p.neg_score[e], empty_slot ? 0.f : finish_score(COS ? p.score_mode : RSA_SCORE_IP, dot, in2, qn2));
 
     // ---- 4. positives (+ the fused BPR epilogue: every tile of a query needs the positive score)
     const float neg_s = finish_score(COS ? p.score_mode : RSA_SCORE_IP, dot, in2, qn2);
@@ -490,48 +617,207 @@ __global__ __launch_bounds__(256, QG ? RSA_QG_MIN_WAVES : RSA_FWD_MIN_WAVES) voi
     }
   }
 
-  // ---- 5. (fused BPR epilogue) loss = mean of the per-query losses, in the SAME launch.  Every workgroup
-  // publishes the sum of its own tiles' losses (tile -> wave assignment is static, so the partial is
-  // reproducible); the last workgroup to arrive adds the partials in index order.  Saves two tiny launches per
-  // step (a quarter of the step at B = 4096).
+  // ---- 5. (fused BPR epilogue) loss = mean of the per-query losses, in the same launch
   if constexpr (QU) {
-    if (p.loss_out != nullptr) {
-      __shared__ int s_last;
-      __shared__ float s_red[256];
-      const int wave = threadIdx.x >> 6;
-      if (lane == 0) s_red[wave] = wave_loss;
-      __syncthreads();
-      if (threadIdx.x == 0) {
-        float part = 0.f;
-        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) part += s_red[w];
-        // Device-scope atomics only, no fences: a release/acquire fence here writes back / invalidates the
-        // whole XCD L2 on every workgroup exit (measured: +90 us per launch).  The exchange is performed at the
-        // memory side and awaited before the arrival is counted.
-        const float prev = __hip_atomic_exchange(p.loss_partials + blockIdx.x, part, __ATOMIC_RELAXED,
-                                                 __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned bump = prev != prev ? 2u : 1u;        // data dependence: the counter waits for the exchange
-        unsigned arrived = __hip_atomic_fetch_add(p.done_counter, bump > 1u ? 1u : bump, __ATOMIC_RELAXED,
-                                                  __HIP_MEMORY_SCOPE_AGENT);
-        s_last = arrived == gridDim.x - 1;
-        if (s_last) __hip_atomic_store(p.done_counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // reset
-      }
-      __syncthreads();
-      if (s_last) {
-        float acc = 0.f;
-        for (unsigned i = threadIdx.x; i < gridDim.x; i += 256)
-          acc += __hip_atomic_load(p.loss_partials + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __syncthreads();
-        s_red[threadIdx.x] = acc;
-        __syncthreads();
+    if (p.loss_out != nullptr) reduce_mean_loss(wave_loss, p.loss_out, p.done_counter, p.loss_partials, p.n_queries);
+  }
+}
+
+// ------------------------------------------------------------------ SampledSoftmax epilogue (fused_loss = 2)
+// SampledSoftmaxLoss.forward (recstudio/model/loss_func.py:80-90) for pos_score [M], neg_score [M, n], n % 64 == 0:
+//   z_pos = pos - logQ_pos, z_j = neg_j - logQ_j;  row = logsumexp(z_pos, z_1..z_n) - z_pos;  loss = mean_m row
+//   d loss/d neg_j = softmax_j / M,  d loss/d pos = (softmax_pos - 1) / M   (NaN for a -inf positive, like the reference)
+// The logsumexp spans the n/64 tiles of a query, so ONE wave owns a query and walks its tiles in order, carrying the
+// running (max, sum) -- no cross-wave exchange, no atomics, bit-reproducible.  z is staged in the dneg buffer and
+// rewritten as the gradient once the query's logsumexp is known (same lane, same address).
+// QG: d loss/d query = (1/M) sum_j softmax_j item_j + dpos * item_pos is accumulated flash-style while a batch's rows
+// are in registers: every lane group keeps sum_j exp(z_j - g) row_j with its own running reference g (rescaled when
+// g moves, once per batch of 8 rows) and the groups are merged with the final logsumexp -- the backward of configs[2]
+// then never reads an item row.
+
+template <int LPR, bool NT>
+__device__ __forceinline__ void tile_rows_ssm(const float* __restrict__ table, int32_t id_lane, float lq_lane, bool has_lq,
+                                              const Frag<LPR, false>& qf, float& dot, float& gm, float4& qacc) {
+  using F = Frag<LPR, false>;
+  constexpr int D = LPR * 4;
+  constexpr int BATCH = LPR < RSA_SSM_BATCH ? LPR : RSA_SSM_BATCH;
+  constexpr int NB = LPR / BATCH;
+  const int lane = lane_id();
+  const int sub = lane % LPR;
+  const int gbase = lane - sub;
+  dot = 0.f;
+  // Batch b+1's rows are requested while batch b is being consumed (two batches of fragments live, 2 * BATCH row
+  // loads in flight per wave).  The order is pinned through DATA dependences -- an empty asm ties the source-lane
+  // number of batch b+2's shuffles to the accumulator after batch b: sched_barrier alone does not hold, the
+  // selection DAG moved every batch's accumulation behind the last batch and kept all LPR row fragments alive
+  // (277 VGPRs at d = 128).
+  F x[2][BATCH];
+  float lqk[2][BATCH];
+  int gb = gbase;
+  auto request = [&](int b) __attribute__((always_inline)) {
 #pragma unroll
-        for (int w = 128; w >= 1; w >>= 1) {
-          if ((int)threadIdx.x < w) s_red[threadIdx.x] += s_red[threadIdx.x + w];
-          __syncthreads();
-        }
-        if (threadIdx.x == 0) p.loss_out[0] = s_red[0] / (float)p.n_queries;
+    for (int k = 0; k < BATCH; ++k) {
+      const int32_t rid = __shfl(id_lane, gb + b * BATCH + k, 64);
+      frag_load<LPR, false, NT>(x[b & 1][k], table + (size_t)rid * D, sub, D);
+      lqk[b & 1][k] = has_lq ? __shfl(lq_lane, gb + b * BATCH + k, 64) : 0.f;
+    }
+  };
+  request(0);
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    if (b + 1 < NB) request(b + 1);
+#pragma unroll
+    for (int k = 0; k < BATCH; ++k) {
+      const float dk = group_sum<LPR>(frag_dot<LPR, false>(x[b & 1][k], qf));     // all LPR lanes hold the row's dot
+      dot = sub == b * BATCH + k ? dk : dot;
+      // online softmax accumulation: move the group's reference to max(gm, z), rescale, add this row
+      const float z = dk - lqk[b & 1][k];
+      const float g_new = fmaxf(gm, z);
+      const float r = __expf(gm - g_new);      // gm = -inf on the first row: r = 0, qacc is 0 anyway
+      const float w = __expf(z - g_new);
+      const float4 xv = x[b & 1][k].v[0];
+      qacc.x = __fmaf_rn(w, xv.x, qacc.x * r);
+      qacc.y = __fmaf_rn(w, xv.y, qacc.y * r);
+      qacc.z = __fmaf_rn(w, xv.z, qacc.z * r);
+      qacc.w = __fmaf_rn(w, xv.w, qacc.w * r);
+      gm = g_new;
+    }
+    asm volatile("" : "+v"(gb), "+v"(qacc.x), "+v"(qacc.y), "+v"(qacc.z), "+v"(qacc.w));
+  }
+}
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m, 64));
+  return v;
+}
+
+#ifndef RSA_SSM_MIN_WAVES
+#define RSA_SSM_MIN_WAVES 3
+#endif
+template <int LPR, bool NT, bool QG>
+__global__ __launch_bounds__(256) void fused_ssm_kernel(const FwdParams p) {
+  using F = Frag<LPR, false>;
+  constexpr int D = LPR * 4;
+  const int lane = lane_id();
+  const int sub = lane % LPR;
+  const int64_t n = p.num_neg;
+  const int T = (int)(n >> 6);
+  PhiloxCall pc = p.pc;
+  if (p.offset_dev != nullptr) pc.offset4 = *p.offset_dev >> 2;
+  const int64_t wave0 = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int64_t wstride = (int64_t)gridDim.x * (blockDim.x >> 6);
+  const float inv_m = 1.f / (float)p.n_queries;
+  const bool popular = p.sampler == RSA_SAMPLER_POPULAR;
+  const bool has_lq = popular || (p.sampler == RSA_SAMPLER_GIVEN && p.neg_logp != nullptr);
+  float wave_loss = 0.f;
+
+  for (int64_t m = wave0; m < p.n_queries; m += wstride) {
+    const int64_t qrow = p.query_index ? p.query_index[m] : m;
+    int64_t pid = p.pos_ids[m];
+    const bool pad = pid == 0;
+    pid = pid < 0 ? 0 : (pid >= p.n_items ? p.n_items - 1 : pid);
+    F qf, px;
+    frag_load<LPR, false>(qf, p.query + (size_t)qrow * D, sub, D);
+    frag_load<LPR, false>(px, p.item_table + (size_t)pid * D, sub, D);
+    float lq_pos = 0.f;
+    if (popular) lq_pos = logf(p.pop_prob[pid]);
+    else if (p.sampler == RSA_SAMPLER_GIVEN && p.pos_logp != nullptr) lq_pos = p.pos_logp[m];
+    float pos_s = group_sum<LPR>(frag_dot<LPR, false>(px, qf));
+    if (p.mask_pad_pos && pad) pos_s = -INFINITY;
+    const float z_pos = pos_s - lq_pos;
+
+    float run_m = -INFINITY, run_s = 0.f;      // wave-uniform running logsumexp state over the negatives
+    float gm = -INFINITY;                      // lane-group reference of qacc
+    float4 qacc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 1
+    for (int t = 0; t < T; ++t) {
+      const int64_t e = m * n + ((int64_t)t << 6) + lane;
+      int32_t id;
+      float lq = 0.f;
+      if (p.sampler == RSA_SAMPLER_UNIFORM) {
+        id = (int32_t)torch_randint_element(pc, (uint64_t)e, (uint64_t)(p.n_items - 1), 1);
+        st_out(&p.neg_ids[e], (int64_t)id);
+      } else if (popular) {
+        float pr;
+        id = lookup_popular(p, torch_rand_element(pc, (uint64_t)e), pr);
+        lq = logf(pr);
+        st_out(&p.neg_ids[e], (int64_t)id);
+        if (p.neg_logp) st_out(&p.neg_logp[e], lq);
+      } else {
+        int64_t g = p.neg_ids[e];
+        g = g < 0 ? 0 : (g >= p.n_items ? p.n_items - 1 : g);
+        id = (int32_t)g;
+        if (p.neg_logp) lq = p.neg_logp[e];
+      }
+      float dot;
+      if constexpr (QG) {
+        tile_rows_ssm<LPR, NT>(p.item_table, id, lq, has_lq, qf, dot, gm, qacc);
+      } else {
+        float u1, u2;
+        tile_rows<LPR, false, false, true, NT>(p.item_table, D, id, p.query, 0, qf, dot, u1, u2);
+      }
+      st_out(&p.neg_score[e], dot);
+      const float z = dot - lq;
+      if (p.dneg) p.dneg[e] = z;               // staged; rewritten below once the logsumexp is known
+      const float m_new = fmaxf(run_m, wave_max(z));
+      run_s = run_s * __expf(run_m - m_new) + group_sum<64>(__expf(z - m_new));
+      run_m = m_new;
+    }
+
+    // ---- the query's logsumexp, loss and gradients
+    const float top = fmaxf(run_m, z_pos);
+    const float lse = top + logf(run_s * expf(run_m - top) + expf(z_pos - top));
+    const bool bad = isinf(z_pos);             // padded positive: the reference divides 0 by 0 (loss_func.py:88-89)
+    const float row = bad ? NAN : lse - z_pos;
+    const float dp = bad ? NAN : (expf(z_pos - lse) - 1.f) * inv_m;
+    wave_loss += row;
+    if (lane == 0) {
+      p.pos_score[m] = pos_s;
+      if (popular && p.pos_logp) p.pos_logp[m] = lq_pos;
+      p.row_loss[m] = row;
+      if (p.dpos) p.dpos[m] = dp;
+    }
+    if (p.dneg) {
+#pragma unroll 2
+      for (int t = 0; t < T; ++t) {
+        const int64_t e = m * n + ((int64_t)t << 6) + lane;
+        const float z = p.dneg[e];
+        st_out(&p.dneg[e], bad ? NAN : __expf(z - lse) * inv_m);
       }
     }
+    if constexpr (QG) {
+      const float sc = bad ? NAN : __expf(gm - lse) * inv_m;     // this group's weights relative to the final lse
+      qacc.x *= sc; qacc.y *= sc; qacc.z *= sc; qacc.w *= sc;
+#pragma unroll
+      for (int mk = LPR; mk < 64; mk <<= 1) {
+        qacc.x += __shfl_xor(qacc.x, mk, 64); qacc.y += __shfl_xor(qacc.y, mk, 64);
+        qacc.z += __shfl_xor(qacc.z, mk, 64); qacc.w += __shfl_xor(qacc.w, mk, 64);
+      }
+      const float4 pv = px.v[0];
+      qacc.x = __fmaf_rn(dp, pv.x, qacc.x); qacc.y = __fmaf_rn(dp, pv.y, qacc.y);
+      qacc.z = __fmaf_rn(dp, pv.z, qacc.z); qacc.w = __fmaf_rn(dp, pv.w, qacc.w);
+      if (lane < LPR) *reinterpret_cast<float4*>(p.qgrad + (size_t)m * D + sub * 4) = qacc;
+    }
   }
+  if (p.loss_out != nullptr) reduce_mean_loss(wave_loss, p.loss_out, p.done_counter, p.loss_partials, p.n_queries);
+}
+
+template <int LPR>
+static int launch_ssm(const FwdParams& p, hipStream_t stream) {
+  const bool nt = (size_t)p.n_items * p.dim * sizeof(float) > (512ull << 20);
+  int64_t blocks = (p.n_queries + 3) / 4;      // one wave per query
+  if (blocks > RSA_FWD_GRID_CAP) blocks = RSA_FWD_GRID_CAP;
+  dim3 grid((unsigned)blocks), block(256);
+  if (p.qgrad != nullptr) {
+    if (nt) hipLaunchKernelGGL((fused_ssm_kernel<LPR, true, true>), grid, block, 0, stream, p);
+    else hipLaunchKernelGGL((fused_ssm_kernel<LPR, false, true>), grid, block, 0, stream, p);
+  } else {
+    if (nt) hipLaunchKernelGGL((fused_ssm_kernel<LPR, true, false>), grid, block, 0, stream, p);
+    else hipLaunchKernelGGL((fused_ssm_kernel<LPR, false, false>), grid, block, 0, stream, p);
+  }
+  RSA_CHECK_LAUNCH("rsa_fused_sample_gather_score(ssm)");
+  return RSA_OK;
 }
 
 template <int LPR, bool GENERIC, bool COS, bool QU>
@@ -580,9 +866,7 @@ extern "C" int rsa_rng_advance(uint64_t* offset_dev, uint64_t increment, rsa_str
   return RSA_OK;
 }
 
-// arrival counter of the in-kernel loss reduction.  One word for the process: launches that request loss_out must
-// not run concurrently on different streams (same rule as rsa_mean_rows' scratch).
-static unsigned int* g_done_counter = nullptr;
+extern "C" int64_t rsa_scratch_bytes(void) { return SCRATCH_BYTES; }
 
 extern "C" int rsa_fused_sample_gather_score(const rsa_fused_args* a, rsa_stream_t stream) {
   RSA_CHECK_ARG(a != nullptr, "rsa_fused_sample_gather_score: args is null");
@@ -609,9 +893,15 @@ extern "C" int rsa_fused_sample_gather_score(const rsa_fused_args* a, rsa_stream
                   "rsa_fused_sample_gather_score: packed_keys needs sampler GIVEN, num_neg == 1 and no positives");
     if (a->sampler != RSA_SAMPLER_GIVEN)
       RSA_CHECK_ARG(a->grid_threads > 0 && (a->offset & 3) == 0, "rsa_fused_sample_gather_score: bad philox state");
-    if (a->sampler == RSA_SAMPLER_POPULAR)
-      RSA_CHECK_ARG(a->table && a->pop_prob && a->guide && a->guide_log2 >= 0 && a->guide_log2 <= 28,
-                    "rsa_fused_sample_gather_score: popularity tables missing");
+    if (a->sampler == RSA_SAMPLER_POPULAR) {
+      RSA_CHECK_ARG(a->table && a->pop_prob, "rsa_fused_sample_gather_score: popularity tables missing");
+      if (a->cdf_lines != nullptr)
+        RSA_CHECK_ARG(a->lines_log2 >= 0 && a->lines_log2 <= 28 && ((uintptr_t)a->cdf_lines & 127) == 0,
+                      "rsa_fused_sample_gather_score: cdf_lines must be 128-byte aligned with lines_log2 in [0, 28]");
+      else
+        RSA_CHECK_ARG(a->guide && a->guide_log2 >= 0 && a->guide_log2 <= 28,
+                      "rsa_fused_sample_gather_score: guide table missing");
+    }
   }
   RSA_CHECK_ARG(a->pos_logp == nullptr || a->pop_prob != nullptr,
                 "rsa_fused_sample_gather_score: pos_logp needs pop_prob");
@@ -627,6 +917,8 @@ extern "C" int rsa_fused_sample_gather_score(const rsa_fused_args* a, rsa_stream
   p.pop_prob = a->pop_prob;
   p.table_prob = a->table_prob;
   p.lut = a->cdf_lut;
+  p.lines = a->cdf_lines;
+  p.lines_log2 = a->lines_log2;
   p.guide = a->guide;
   p.neg_ids = a->neg_ids;
   p.neg_logp = a->neg_logp;
@@ -645,7 +937,7 @@ extern "C" int rsa_fused_sample_gather_score(const rsa_fused_args* a, rsa_stream
   p.n_items = a->n_items;
   p.n_query_rows = a->n_query_rows;
   p.n_queries = a->n_queries;
-  p.pc = PhiloxCall{a->seed, a->offset >> 2, a->grid_threads};
+  p.pc = PhiloxCall{a->seed, a->offset >> 2, a->grid_threads, a->elem_base};
   p.dim = a->dim;
   p.num_neg = a->num_neg;
   p.sampler = a->sampler;
@@ -665,26 +957,26 @@ extern "C" int rsa_fused_sample_gather_score(const rsa_fused_args* a, rsa_stream
   }
   p.numel = numel;
   const bool qu = (a->num_neg % 64) == 0;
-  RSA_CHECK_ARG(a->query_grad == nullptr || a->fused_loss == RSA_LOSS_BPR + 1,
-                "rsa_fused_sample_gather_score: query_grad is an output of the fused BPR epilogue (fused_loss = 1)");
-  if (a->fused_loss == RSA_LOSS_BPR + 1) {
+  const bool bpr = a->fused_loss == RSA_LOSS_BPR + 1, ssm = a->fused_loss == RSA_LOSS_SSM + 1;
+  RSA_CHECK_ARG(a->fused_loss == 0 || bpr || ssm,
+                "rsa_fused_sample_gather_score: fused_loss=%d not supported (0 = none, 1 = BPR, 2 = SampledSoftmax)",
+                a->fused_loss);
+  RSA_CHECK_ARG(a->query_grad == nullptr || bpr || ssm,
+                "rsa_fused_sample_gather_score: query_grad is an output of the fused loss epilogue (fused_loss != 0)");
+  if (bpr || ssm) {
     RSA_CHECK_ARG(qu && a->pos_ids && a->pos_score && a->row_loss,
-                  "rsa_fused_sample_gather_score: the fused BPR epilogue needs num_neg %% 64 == 0, pos_ids, pos_score "
+                  "rsa_fused_sample_gather_score: the fused loss epilogue needs num_neg %% 64 == 0, pos_ids, pos_score "
                   "and row_loss");
     p.row_loss = a->row_loss;
     p.dpos = a->dpos;
     p.dneg = a->dneg;
     if (a->loss_out != nullptr) {
-      if (g_done_counter == nullptr) {   // one device word, allocated and zeroed once; the kernel leaves it at zero
-        // [0, 256): the counter word;  [256, 256 + 4 * 2048): one float per workgroup (grid <= 2048)
-        if (hipMalloc(&g_done_counter, 256 + 4 * 2048) != hipSuccess || hipMemset(g_done_counter, 0, 256) != hipSuccess) {
-          rsa::set_error("rsa_fused_sample_gather_score: could not allocate the arrival counter");
-          return RSA_ERR_HIP;
-        }
-      }
+      RSA_CHECK_ARG(a->reduce_scratch != nullptr,
+                    "rsa_fused_sample_gather_score: loss_out needs reduce_scratch (rsa_scratch_bytes() bytes, zeroed once)");
+      char* sc = reinterpret_cast<char*>(a->reduce_scratch);
       p.loss_out = a->loss_out;
-      p.done_counter = g_done_counter;
-      p.loss_partials = reinterpret_cast<float*>(reinterpret_cast<char*>(g_done_counter) + 256);
+      p.done_counter = reinterpret_cast<unsigned int*>(sc + SCRATCH_COUNTER);
+      p.loss_partials = reinterpret_cast<float*>(sc + SCRATCH_FUSED_PARTIALS);
     }
     if (a->query_grad != nullptr) {
       RSA_CHECK_ARG(!cos && (a->dim == 32 || a->dim == 64 || a->dim == 128 || a->dim == 256),
@@ -692,19 +984,27 @@ extern "C" int rsa_fused_sample_gather_score(const rsa_fused_args* a, rsa_stream
                     "{32, 64, 128, 256}");
       p.qgrad = a->query_grad;
     }
-    if (a->num_neg != 64) {
-      hipError_t e1 = hipMemsetAsync(a->row_loss, 0, sizeof(float) * a->n_queries, s);
-      hipError_t e2 = a->dpos ? hipMemsetAsync(a->dpos, 0, sizeof(float) * a->n_queries, s) : hipSuccess;
-      if (e1 == hipSuccess && e2 == hipSuccess && p.qgrad)
-        e1 = hipMemsetAsync(p.qgrad, 0, sizeof(float) * a->n_queries * a->dim, s);
-      if (e1 != hipSuccess || e2 != hipSuccess) {
-        rsa::set_error("rsa_fused_sample_gather_score: memset failed");
-        return RSA_ERR_HIP;
-      }
+  }
+  if (ssm) {
+    RSA_CHECK_ARG(!cos && (a->dim == 32 || a->dim == 64 || a->dim == 128 || a->dim == 256) && a->packed_keys == nullptr,
+                  "rsa_fused_sample_gather_score: the SampledSoftmax epilogue needs the inner-product scorer and dim in "
+                  "{32, 64, 128, 256}");
+    switch (a->dim) {
+      case 32: return launch_ssm<8>(p, s);
+      case 64: return launch_ssm<16>(p, s);
+      case 128: return launch_ssm<32>(p, s);
+      default: return launch_ssm<64>(p, s);
     }
-  } else if (a->fused_loss != 0) {
-    rsa::set_error("rsa_fused_sample_gather_score: fused_loss=%d not supported (0 = none, 1 = BPR)", a->fused_loss);
-    return RSA_ERR_UNSUPPORTED;
+  }
+  if (bpr && a->num_neg != 64) {
+    hipError_t e1 = hipMemsetAsync(a->row_loss, 0, sizeof(float) * a->n_queries, s);
+    hipError_t e2 = a->dpos ? hipMemsetAsync(a->dpos, 0, sizeof(float) * a->n_queries, s) : hipSuccess;
+    if (e1 == hipSuccess && e2 == hipSuccess && p.qgrad)
+      e1 = hipMemsetAsync(p.qgrad, 0, sizeof(float) * a->n_queries * a->dim, s);
+    if (e1 != hipSuccess || e2 != hipSuccess) {
+      rsa::set_error("rsa_fused_sample_gather_score: memset failed");
+      return RSA_ERR_HIP;
+    }
   }
   switch (a->dim) {
     case 32: rc = launch_fwd<8, false>(p, cos, qu, s); break;

@@ -369,26 +369,21 @@ extern "C" int rsa_row_lse(const float* x, int64_t n_rows, int64_t n_cols, float
   return RSA_OK;
 }
 
-// Deterministic mean of n_rows floats.  The <= 256 stage-1 partials live in a 1 KB device scratch the
-// library allocates once (the ABI passes no workspace for this); calls on different streams must
-// not overlap (the Python binding issues everything on torch's current stream).
-static float* g_partials = nullptr;
+// Deterministic mean of n_rows floats.  The <= 256 stage-1 partials live in the caller-owned scratch block
+// (rsa_scratch_bytes(), include/recstudio_amd.h): calls sharing a block must be stream-ordered.
+static int mean_rows_impl(const float* row_loss, int64_t n_rows, const int32_t* denom, float* out, void* scratch,
+                          rsa_stream_t stream);
 
-static int mean_rows_impl(const float* row_loss, int64_t n_rows, const int32_t* denom, float* out, rsa_stream_t stream);
-
-extern "C" int rsa_mean_rows(const float* row_loss, int64_t n_rows, float* out, rsa_stream_t stream) {
-  return mean_rows_impl(row_loss, n_rows, nullptr, out, stream);
+extern "C" int rsa_mean_rows(const float* row_loss, int64_t n_rows, float* out, void* scratch, rsa_stream_t stream) {
+  return mean_rows_impl(row_loss, n_rows, nullptr, out, scratch, stream);
 }
 
-static int mean_rows_impl(const float* row_loss, int64_t n_rows, const int32_t* denom, float* out, rsa_stream_t stream) {
+static int mean_rows_impl(const float* row_loss, int64_t n_rows, const int32_t* denom, float* out, void* scratch,
+                          rsa_stream_t stream) {
   RSA_CHECK_ARG(row_loss && out && n_rows >= 1, "rsa_mean_rows: bad arguments");
+  RSA_CHECK_ARG(scratch != nullptr, "rsa_mean_rows: scratch is null (rsa_scratch_bytes() bytes, zeroed once by the caller)");
   hipStream_t s = (hipStream_t)stream;
-  if (g_partials == nullptr) {   // one-time 1 KB scratch (the only allocation the library ever makes)
-    if (hipMalloc(&g_partials, 256 * sizeof(float)) != hipSuccess) {
-      rsa::set_error("rsa_mean_rows: could not allocate the 1 KB partial-sum scratch");
-      return RSA_ERR_HIP;
-    }
-  }
+  float* g_partials = reinterpret_cast<float*>(reinterpret_cast<char*>(scratch) + SCRATCH_MEAN_PARTIALS);
   int blocks = (int)((n_rows + 1023) / 1024);
   if (blocks > 256) blocks = 256;
   const int64_t chunk = (n_rows + blocks - 1) / blocks;
@@ -398,11 +393,12 @@ static int mean_rows_impl(const float* row_loss, int64_t n_rows, const int32_t* 
   return RSA_OK;
 }
 
-static int32_t* g_count = nullptr;   // device word for the BCE valid-row count (allocated once, like g_partials)
-
 extern "C" int rsa_pairwise_loss(int32_t loss_kind, const float* pos_score, const float* neg_score,
                                  const float* pos_logp, const float* neg_logp, int64_t n_rows, int32_t num_neg,
-                                 float* row_loss, float* loss_out, float* dpos, float* dneg, rsa_stream_t stream) {
+                                 float* row_loss, float* loss_out, float* dpos, float* dneg, void* scratch,
+                                 rsa_stream_t stream) {
+  RSA_CHECK_ARG(scratch != nullptr, "rsa_pairwise_loss: scratch is null");
+  int32_t* g_count = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(scratch) + SCRATCH_BCE_COUNT);
   RSA_CHECK_ARG(loss_kind == RSA_LOSS_BPR || loss_kind == RSA_LOSS_SSM || loss_kind == RSA_LOSS_BCE,
                 "rsa_pairwise_loss: unknown loss %d", loss_kind);
   RSA_CHECK_ARG(n_rows >= 1 && num_neg >= 1, "rsa_pairwise_loss: need n_rows >= 1 and num_neg >= 1");
@@ -413,10 +409,6 @@ extern "C" int rsa_pairwise_loss(int32_t loss_kind, const float* pos_score, cons
   if (blocks > 4096) blocks = 4096;
   dim3 grid((unsigned)blocks), block(256);
   if (loss_kind == RSA_LOSS_BCE) {
-    if (g_count == nullptr && hipMalloc(&g_count, 256) != hipSuccess) {
-      rsa::set_error("rsa_pairwise_loss: could not allocate the counter scratch");
-      return RSA_ERR_HIP;
-    }
     if (hipMemsetAsync(g_count, 0, sizeof(int32_t), s) != hipSuccess) {
       rsa::set_error("rsa_pairwise_loss: memset failed");
       return RSA_ERR_HIP;
@@ -434,7 +426,7 @@ extern "C" int rsa_pairwise_loss(int32_t loss_kind, const float* pos_score, cons
     }
 #undef RSA_LAUNCH_BCE
     RSA_CHECK_LAUNCH("rsa_pairwise_loss(bce)");
-    return mean_rows_impl(row_loss, n_rows, g_count, loss_out, stream);
+    return mean_rows_impl(row_loss, n_rows, g_count, loss_out, scratch, stream);
   }
 #define RSA_LAUNCH_LOSS(RL)                                                                                      \
   hipLaunchKernelGGL(pairwise_loss_kernel<RL>, grid, block, 0, s, (int)loss_kind, pos_score, neg_score, pos_logp, \
@@ -447,13 +439,15 @@ extern "C" int rsa_pairwise_loss(int32_t loss_kind, const float* pos_score, cons
   }
 #undef RSA_LAUNCH_LOSS
   RSA_CHECK_LAUNCH("rsa_pairwise_loss");
-  return rsa_mean_rows(row_loss, n_rows, loss_out, stream);
+  return rsa_mean_rows(row_loss, n_rows, loss_out, scratch, stream);
 }
 
 extern "C" int rsa_pairwise_loss_ex(int32_t loss_kind, const float* pos_score, const float* neg_score,
                                     const float* pos_logp, const float* neg_logp, int64_t n_rows, int32_t num_neg,
                                     float param0, float param1, float* row_loss, float* loss_out, float* dpos,
-                                    float* dneg, rsa_stream_t stream) {
+                                    float* dneg, void* scratch, rsa_stream_t stream) {
+  RSA_CHECK_ARG(scratch != nullptr, "rsa_pairwise_loss_ex: scratch is null");
+  int32_t* g_count = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(scratch) + SCRATCH_BCE_COUNT);
   RSA_CHECK_ARG(loss_kind >= RSA_LOSS_WBPR && loss_kind <= RSA_LOSS_CCL, "rsa_pairwise_loss_ex: unknown loss %d",
                 loss_kind);
   RSA_CHECK_ARG(n_rows >= 1 && num_neg >= 1, "rsa_pairwise_loss_ex: need n_rows >= 1 and num_neg >= 1");
@@ -465,10 +459,6 @@ extern "C" int rsa_pairwise_loss_ex(int32_t loss_kind, const float* pos_score, c
   dim3 grid((unsigned)blocks), block(256);
   const int32_t* count = nullptr;
   if (loss_kind == RSA_LOSS_WBCE) {
-    if (g_count == nullptr && hipMalloc(&g_count, 256) != hipSuccess) {
-      rsa::set_error("rsa_pairwise_loss_ex: could not allocate the counter scratch");
-      return RSA_ERR_HIP;
-    }
     if (hipMemsetAsync(g_count, 0, sizeof(int32_t), s) != hipSuccess) {
       rsa::set_error("rsa_pairwise_loss_ex: memset failed");
       return RSA_ERR_HIP;
@@ -489,12 +479,13 @@ extern "C" int rsa_pairwise_loss_ex(int32_t loss_kind, const float* pos_score, c
   }
 #undef RSA_LAUNCH_EX
   RSA_CHECK_LAUNCH("rsa_pairwise_loss_ex");
-  return mean_rows_impl(row_loss, n_rows, count, loss_out, stream);
+  return mean_rows_impl(row_loss, n_rows, count, loss_out, scratch, stream);
 }
 
 extern "C" int rsa_ssm_shared_loss(const float* pos_score, const float* pos_logp, const float* neg_score,
                                    const float* neg_logp, int64_t n_rows, int32_t n_pos, int32_t num_neg,
-                                   float* row_loss, float* loss_out, float* dpos, float* dneg, rsa_stream_t stream) {
+                                   float* row_loss, float* loss_out, float* dpos, float* dneg, void* scratch,
+                                   rsa_stream_t stream) {
   RSA_CHECK_ARG(n_rows >= 1 && n_pos >= 1 && num_neg >= 1, "rsa_ssm_shared_loss: bad sizes");
   RSA_CHECK_ARG(pos_score && neg_score && row_loss && loss_out, "rsa_ssm_shared_loss: null pointer");
   int64_t blocks = (n_rows + 3) / 4;
@@ -502,5 +493,5 @@ extern "C" int rsa_ssm_shared_loss(const float* pos_score, const float* pos_logp
   hipLaunchKernelGGL(ssm_shared_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, pos_score, pos_logp,
                      neg_score, neg_logp, n_rows, (int)n_pos, (int)num_neg, row_loss, dpos, dneg);
   RSA_CHECK_LAUNCH("rsa_ssm_shared_loss");
-  return rsa_mean_rows(row_loss, n_rows, loss_out, stream);
+  return rsa_mean_rows(row_loss, n_rows, loss_out, scratch, stream);
 }

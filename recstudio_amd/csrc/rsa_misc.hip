@@ -68,6 +68,24 @@ __global__ __launch_bounds__(256) void seg_gather_kernel(const float* __restrict
   }
 }
 
+// aux[r] = 1 / ||row r|| (cosine) or ||row r||^2 (Euclidean): one lane group of D/4 lanes per row, 16-byte loads.
+__global__ __launch_bounds__(256) void row_sqnorm_kernel(const float* __restrict__ table, int64_t n_rows, int D, int mode,
+                                                         float* __restrict__ out) {
+  const int lane = lane_id();
+  const int64_t w0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), ws = (int64_t)gridDim.x * 4;
+  const int v4 = D >> 2;
+  for (int64_t r = w0; r < n_rows; r += ws) {
+    const float4* row = reinterpret_cast<const float4*>(table + (size_t)r * D);
+    float acc = 0.f;
+    for (int c = lane; c < v4; c += 64) {
+      const float4 v = row[c];
+      acc += dot4(v, v);
+    }
+    acc = group_sum<64>(acc);
+    if (lane == 0) out[r] = mode == RSA_SCORE_COS ? 1.f / sqrtf(acc) : acc;
+  }
+}
+
 }  // namespace rsa
 
 using namespace rsa;
@@ -115,5 +133,19 @@ extern "C" int rsa_seg_gather(const float* item_table, int64_t n_items, int32_t 
   hipLaunchKernelGGL(seg_gather_kernel, dim3((unsigned)n_seg), dim3(256), 0, (hipStream_t)stream, item_table, n_items,
                      (int)dim, flat_item_ids, n_flat, seg_start, seg_end, (int)max_len, out_ids, out_rows, out_len);
   RSA_CHECK_LAUNCH("rsa_seg_gather");
+  return RSA_OK;
+}
+
+extern "C" int rsa_row_sqnorm(const float* table, int64_t n_rows, int32_t dim, int32_t score_mode, float* out,
+                              rsa_stream_t stream) {
+  RSA_CHECK_ARG(n_rows >= 0 && dim >= 4 && dim % 4 == 0, "rsa_row_sqnorm: bad sizes");
+  RSA_CHECK_ARG(score_mode == RSA_SCORE_COS || score_mode == RSA_SCORE_EUC, "rsa_row_sqnorm: score_mode must be COS or EUC");
+  if (n_rows == 0) return RSA_OK;
+  RSA_CHECK_ARG(table && out, "rsa_row_sqnorm: null pointer");
+  int64_t blocks = (n_rows + 3) / 4;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(rsa::row_sqnorm_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, table, n_rows,
+                     (int)dim, (int)score_mode, out);
+  RSA_CHECK_LAUNCH("rsa_row_sqnorm");
   return RSA_OK;
 }

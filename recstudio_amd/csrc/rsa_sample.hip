@@ -22,7 +22,9 @@ template <bool FROM_U>
 __global__ __launch_bounds__(256) void sample_popular_kernel(const float* __restrict__ table,
                                                              const float* __restrict__ pop_prob,
                                                              const int32_t* __restrict__ guide,
-                                                             const float* __restrict__ lut, int64_t n_items,
+                                                             const float* __restrict__ lut,
+                                                             const float* __restrict__ lines, int lines_log2,
+                                                             int64_t n_items,
                                                              int guide_log2, const float* __restrict__ u_in,
                                                              int64_t* __restrict__ ids, float* __restrict__ logp,
                                                              float* __restrict__ u_out, int64_t numel,
@@ -32,7 +34,9 @@ __global__ __launch_bounds__(256) void sample_popular_kernel(const float* __rest
     const float u = FROM_U ? u_in[e] : torch_rand_element(pc, (uint64_t)e);
     int32_t id;
     float pr;
-    if (lut != nullptr) {   // direct lookup: id and probability in one round trip (see rsa_common.hpp)
+    if (lines != nullptr) {   // bucket lines: one 128-byte line resolves id and probability
+      id = cdf_lookup_line(lines, lines_log2, table, 1, pop_prob, 1, n_items, u, pr);
+    } else if (lut != nullptr) {   // direct lookup: id and probability in one round trip (see rsa_common.hpp)
       id = cdf_lookup_lut<1>(reinterpret_cast<const float4*>(lut), table, pop_prob, 1, n_items, guide_log2, u, pr);
     } else {
       id = cdf_lower_bound(table, guide, n_items, guide_log2, u);
@@ -212,13 +216,13 @@ static inline int grid_for(int64_t numel) {
 using namespace rsa;
 
 extern "C" int rsa_sample_uniform(int64_t* neg_ids, int64_t numel, int64_t low, int64_t high, uint64_t seed,
-                                  uint64_t offset, uint32_t grid_threads, rsa_stream_t stream) {
+                                  uint64_t offset, uint32_t grid_threads, uint64_t elem_base, rsa_stream_t stream) {
   RSA_CHECK_ARG(numel >= 0, "rsa_sample_uniform: numel < 0");
   if (numel == 0) return RSA_OK;
   RSA_CHECK_ARG(neg_ids != nullptr, "rsa_sample_uniform: neg_ids is null");
   RSA_CHECK_ARG(high > low, "rsa_sample_uniform: empty range [%lld, %lld)", (long long)low, (long long)high);
   RSA_CHECK_ARG(grid_threads > 0 && (offset & 3) == 0, "rsa_sample_uniform: bad philox state");
-  PhiloxCall pc{seed, offset >> 2, grid_threads};
+  PhiloxCall pc{seed, offset >> 2, grid_threads, elem_base};
   hipLaunchKernelGGL(sample_uniform_kernel, dim3(grid_for(numel)), dim3(256), 0, (hipStream_t)stream, neg_ids, numel,
                      (uint64_t)(high - low), low, pc);
   RSA_CHECK_LAUNCH("rsa_sample_uniform");
@@ -226,24 +230,31 @@ extern "C" int rsa_sample_uniform(int64_t* neg_ids, int64_t numel, int64_t low, 
 }
 
 static int check_popular(const char* fn, const float* table, const float* pop_prob, const int32_t* guide,
-                         int64_t n_items, int32_t guide_log2) {
-  RSA_CHECK_ARG(table && pop_prob && guide, "%s: table/pop_prob/guide is null", fn);
+                         int64_t n_items, int32_t guide_log2, const float* lines, int32_t lines_log2) {
+  RSA_CHECK_ARG(table && pop_prob, "%s: table/pop_prob is null", fn);
   RSA_CHECK_ARG(n_items >= 1 && n_items < (1ll << 31), "%s: n_items out of range", fn);
-  RSA_CHECK_ARG(guide_log2 >= 0 && guide_log2 <= 28, "%s: guide_log2 must be in [0, 28]", fn);
+  if (lines != nullptr) {
+    RSA_CHECK_ARG(lines_log2 >= 0 && lines_log2 <= 28 && ((uintptr_t)lines & 127) == 0,
+                  "%s: cdf_lines must be 128-byte aligned with lines_log2 in [0, 28]", fn);
+  } else {
+    RSA_CHECK_ARG(guide != nullptr, "%s: guide is null", fn);
+    RSA_CHECK_ARG(guide_log2 >= 0 && guide_log2 <= 28, "%s: guide_log2 must be in [0, 28]", fn);
+  }
   return RSA_OK;
 }
 
 extern "C" int rsa_sample_popular(const float* table, const float* pop_prob, const int32_t* guide, int64_t n_items,
                                   int32_t guide_log2, int64_t* neg_ids, float* neg_logp, float* u_out, int64_t numel,
-                                  uint64_t seed, uint64_t offset, uint32_t grid_threads, const float* cdf_lut,
+                                  uint64_t seed, uint64_t offset, uint32_t grid_threads, uint64_t elem_base,
+                                  const float* cdf_lut, const float* cdf_lines, int32_t lines_log2,
                                   rsa_stream_t stream) {
   RSA_CHECK_ARG(numel >= 0, "rsa_sample_popular: numel < 0");
   if (numel == 0) return RSA_OK;
-  if (int rc = check_popular("rsa_sample_popular", table, pop_prob, guide, n_items, guide_log2)) return rc;
+  if (int rc = check_popular("rsa_sample_popular", table, pop_prob, guide, n_items, guide_log2, cdf_lines, lines_log2)) return rc;
   RSA_CHECK_ARG(neg_ids != nullptr, "rsa_sample_popular: neg_ids is null");
   RSA_CHECK_ARG(grid_threads > 0 && (offset & 3) == 0, "rsa_sample_popular: bad philox state");
-  PhiloxCall pc{seed, offset >> 2, grid_threads};
-  if (cdf_lut != nullptr) {
+  PhiloxCall pc{seed, offset >> 2, grid_threads, elem_base};
+  if (cdf_lut != nullptr && cdf_lines == nullptr) {
     hipLaunchKernelGGL((sample_popular_lut_kernel<false, LUT_BATCH>), dim3((unsigned)((numel + 256 * LUT_BATCH - 1) / (256 * LUT_BATCH))),
                        dim3(256), 0, (hipStream_t)stream, table, pop_prob, reinterpret_cast<const float4*>(cdf_lut),
                        n_items, guide_log2, (const float*)nullptr, neg_ids, neg_logp, u_out, numel, pc);
@@ -251,21 +262,22 @@ extern "C" int rsa_sample_popular(const float* table, const float* pop_prob, con
     return RSA_OK;
   }
   hipLaunchKernelGGL(sample_popular_kernel<false>, dim3(grid_for(numel)), dim3(256), 0, (hipStream_t)stream, table,
-                     pop_prob, guide, cdf_lut, n_items, guide_log2, (const float*)nullptr, neg_ids, neg_logp, u_out,
-                     numel, pc);
+                     pop_prob, guide, cdf_lut, cdf_lines, (int)lines_log2, n_items, guide_log2, (const float*)nullptr,
+                     neg_ids, neg_logp, u_out, numel, pc);
   RSA_CHECK_LAUNCH("rsa_sample_popular");
   return RSA_OK;
 }
 
 extern "C" int rsa_popular_lookup(const float* table, const float* pop_prob, const int32_t* guide, int64_t n_items,
                                   int32_t guide_log2, const float* u, int64_t* ids, float* logp, int64_t numel,
-                                  const float* cdf_lut, rsa_stream_t stream) {
+                                  const float* cdf_lut, const float* cdf_lines, int32_t lines_log2,
+                                  rsa_stream_t stream) {
   RSA_CHECK_ARG(numel >= 0, "rsa_popular_lookup: numel < 0");
   if (numel == 0) return RSA_OK;
-  if (int rc = check_popular("rsa_popular_lookup", table, pop_prob, guide, n_items, guide_log2)) return rc;
+  if (int rc = check_popular("rsa_popular_lookup", table, pop_prob, guide, n_items, guide_log2, cdf_lines, lines_log2)) return rc;
   RSA_CHECK_ARG(u && ids, "rsa_popular_lookup: u/ids is null");
-  PhiloxCall pc{0, 0, 1};
-  if (cdf_lut != nullptr) {
+  PhiloxCall pc{0, 0, 1, 0};
+  if (cdf_lut != nullptr && cdf_lines == nullptr) {
     hipLaunchKernelGGL((sample_popular_lut_kernel<true, LUT_BATCH>), dim3((unsigned)((numel + 256 * LUT_BATCH - 1) / (256 * LUT_BATCH))),
                        dim3(256), 0, (hipStream_t)stream, table, pop_prob, reinterpret_cast<const float4*>(cdf_lut),
                        n_items, guide_log2, u, ids, logp, (float*)nullptr, numel, pc);
@@ -273,7 +285,8 @@ extern "C" int rsa_popular_lookup(const float* table, const float* pop_prob, con
     return RSA_OK;
   }
   hipLaunchKernelGGL(sample_popular_kernel<true>, dim3(grid_for(numel)), dim3(256), 0, (hipStream_t)stream, table,
-                     pop_prob, guide, cdf_lut, n_items, guide_log2, u, ids, logp, (float*)nullptr, numel, pc);
+                     pop_prob, guide, cdf_lut, cdf_lines, (int)lines_log2, n_items, guide_log2, u, ids, logp,
+                     (float*)nullptr, numel, pc);
   RSA_CHECK_LAUNCH("rsa_popular_lookup");
   return RSA_OK;
 }
@@ -298,7 +311,7 @@ extern "C" int rsa_sample_masked_uniform(const int64_t* user_hist, int64_t n_row
   RSA_CHECK_ARG(hist_len >= 1 && hist_len <= MASK_MAX_HIST, "rsa_sample_masked_uniform: hist_len must be in [1, %d]",
                 MASK_MAX_HIST);
   RSA_CHECK_ARG(grid_threads > 0 && (offset & 3) == 0, "rsa_sample_masked_uniform: bad philox state");
-  PhiloxCall pc{seed, offset >> 2, grid_threads};
+  PhiloxCall pc{seed, offset >> 2, grid_threads, 0};
   hipLaunchKernelGGL(sample_masked_kernel, dim3((unsigned)n_rows), dim3(256), 0, (hipStream_t)stream, user_hist,
                      (int)hist_len, num_items, (int)per_row, neg_ids, pc);
   RSA_CHECK_LAUNCH("rsa_sample_masked_uniform");

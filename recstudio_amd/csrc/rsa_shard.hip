@@ -86,14 +86,62 @@ __global__ __launch_bounds__(256) void shard_route_kernel(const int64_t* __restr
   }
 }
 
+// Fixed-capacity variant of shard_route_kernel: owner g's segment is slots [g*capacity, (g+1)*capacity); the
+// per-owner cursor counts from 0 and an element that does not fit is dropped and counted in *overflow.
+__global__ __launch_bounds__(256) void shard_route_fixed_kernel(const int64_t* __restrict__ pos_ids,
+                                                                const int64_t* __restrict__ neg_ids, int64_t n_queries,
+                                                                int n, int64_t rows_per_shard, int G, int64_t query_base,
+                                                                int64_t chunk, int64_t capacity, int32_t* __restrict__ cursor,
+                                                                int64_t* __restrict__ keys, int64_t* __restrict__ pos_out,
+                                                                int32_t* __restrict__ overflow) {
+  __shared__ int32_t cnt[64], base[64];
+  const int64_t numel = n_queries * (n + 1);
+  const int64_t e_lo = (int64_t)blockIdx.x * chunk;
+  int64_t e_hi = e_lo + chunk;
+  if (e_hi > numel) e_hi = numel;
+  if (threadIdx.x < 64) cnt[threadIdx.x] = 0;
+  __syncthreads();
+  for (int64_t e = e_lo + threadIdx.x; e < e_hi; e += 256) {
+    int64_t m;
+    int c;
+    const int64_t id = element_id(pos_ids, neg_ids, e, n, m, c);
+    int g = (int)(id / rows_per_shard);
+    g = g < 0 ? 0 : (g >= G ? G - 1 : g);
+    atomicAdd(&cnt[g], 1);
+  }
+  __syncthreads();
+  if (threadIdx.x < G) {
+    base[threadIdx.x] = cnt[threadIdx.x] ? atomicAdd(&cursor[threadIdx.x], cnt[threadIdx.x]) : 0;
+    cnt[threadIdx.x] = 0;
+  }
+  __syncthreads();
+  int dropped = 0;
+  for (int64_t e = e_lo + threadIdx.x; e < e_hi; e += 256) {
+    int64_t m;
+    int c;
+    const int64_t id = element_id(pos_ids, neg_ids, e, n, m, c);
+    int g = (int)(id / rows_per_shard);
+    g = g < 0 ? 0 : (g >= G ? G - 1 : g);
+    const int64_t slot = (int64_t)base[g] + atomicAdd(&cnt[g], 1);
+    if (slot >= capacity) {
+      ++dropped;
+      continue;
+    }
+    const int64_t local = id - (int64_t)g * rows_per_shard;
+    keys[g * capacity + slot] = ((query_base + m) << 32) | (local & 0xffffffffll);
+    pos_out[g * capacity + slot] = c == 0 ? m : n_queries + m * n + (c - 1);
+  }
+  if (dropped) atomicAdd(overflow, dropped);
+}
+
 __global__ __launch_bounds__(256) void shard_unpack_kernel(const int64_t* __restrict__ keys, int64_t numel,
                                                            int64_t* __restrict__ local_rows,
                                                            int64_t* __restrict__ qidx) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < numel; i += stride) {
     const int64_t k = keys[i];
-    local_rows[i] = k & 0xffffffffll;
-    qidx[i] = (k >> 32) & 0x7fffffffll;
+    local_rows[i] = k < 0 ? -1 : (k & 0xffffffffll);      // empty slot of the fixed-capacity exchange
+    qidx[i] = k < 0 ? -1 : ((k >> 32) & 0x7fffffffll);
   }
 }
 
@@ -101,14 +149,20 @@ __global__ __launch_bounds__(256) void scatter_f32_kernel(const float* __restric
                                                           const int64_t* __restrict__ pos, int64_t numel,
                                                           float* __restrict__ dst) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < numel; i += stride) dst[pos[i]] = src[i];
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < numel; i += stride) {
+    const int64_t q = pos[i];
+    if (q >= 0) dst[q] = src[i];
+  }
 }
 
 __global__ __launch_bounds__(256) void gather_f32_kernel(const float* __restrict__ src,
                                                          const int64_t* __restrict__ pos, int64_t numel,
                                                          float* __restrict__ dst) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < numel; i += stride) dst[i] = src[pos[i]];
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < numel; i += stride) {
+    const int64_t q = pos[i];
+    dst[i] = q >= 0 ? src[q] : 0.f;
+  }
 }
 
 static inline int grid1d(int64_t numel) {
@@ -154,6 +208,37 @@ extern "C" int rsa_shard_route(const int64_t* pos_ids, const int64_t* neg_ids, i
   hipLaunchKernelGGL(shard_route_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, pos_ids, neg_ids,
                      n_queries, (int)num_neg, rows_per_shard, (int)n_shards, query_base, chunk, cursor, keys, positions);
   RSA_CHECK_LAUNCH("rsa_shard_route");
+  return RSA_OK;
+}
+
+extern "C" int rsa_shard_route_fixed(const int64_t* pos_ids, const int64_t* neg_ids, int64_t n_queries, int32_t num_neg,
+                                     int64_t rows_per_shard, int32_t n_shards, int64_t query_base, int64_t capacity,
+                                     int32_t* cursor, int64_t* keys, int64_t* positions, int32_t* overflow,
+                                     rsa_stream_t stream) {
+  RSA_CHECK_ARG(n_queries >= 0 && num_neg >= 0 && rows_per_shard >= 1 && rows_per_shard < (1ll << 32),
+                "rsa_shard_route_fixed: bad sizes");
+  RSA_CHECK_ARG(n_shards >= 1 && n_shards <= 64, "rsa_shard_route_fixed: n_shards must be in [1, 64]");
+  RSA_CHECK_ARG(query_base >= 0 && query_base + n_queries < (1ll << 31), "rsa_shard_route_fixed: query index overflow");
+  RSA_CHECK_ARG(capacity >= 1 && capacity * n_shards < (1ll << 31), "rsa_shard_route_fixed: capacity out of range");
+  RSA_CHECK_ARG(cursor && keys && positions && overflow, "rsa_shard_route_fixed: null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  const size_t slots = (size_t)capacity * n_shards;
+  if (hipMemsetAsync(cursor, 0, sizeof(int32_t) * n_shards, s) != hipSuccess ||
+      hipMemsetAsync(keys, 0xff, sizeof(int64_t) * slots, s) != hipSuccess ||
+      hipMemsetAsync(positions, 0xff, sizeof(int64_t) * slots, s) != hipSuccess) {
+    rsa::set_error("rsa_shard_route_fixed: memset failed");
+    return RSA_ERR_HIP;
+  }
+  if (n_queries == 0) return RSA_OK;
+  RSA_CHECK_ARG(pos_ids && (neg_ids || num_neg == 0), "rsa_shard_route_fixed: null ids");
+  const int64_t numel = n_queries * (num_neg + 1);
+  int64_t blocks = (numel + 16383) / 16384;
+  if (blocks < 512 && numel > 512 * 1024) blocks = 512;
+  const int64_t chunk = (numel + blocks - 1) / blocks;
+  hipLaunchKernelGGL(shard_route_fixed_kernel, dim3((unsigned)blocks), dim3(256), 0, s, pos_ids, neg_ids, n_queries,
+                     (int)num_neg, rows_per_shard, (int)n_shards, query_base, chunk, capacity, cursor, keys, positions,
+                     overflow);
+  RSA_CHECK_LAUNCH("rsa_shard_route_fixed");
   return RSA_OK;
 }
 

@@ -27,7 +27,8 @@ __global__ __launch_bounds__(256) void sorted_keys_kernel(const int64_t* __restr
     const int64_t m = e / w;
     const int c = (int)(e - m * w);
     int64_t id = (off && c == 0) ? pos_ids[m] : neg_ids[m * (int64_t)n + (c - off)];
-    id = id < 0 ? 0 : (id >= n_items ? n_items - 1 : id);
+    // a negative id is an empty slot: key n_items sorts behind every real row and its run is skipped
+    id = id < 0 ? n_items : (id >= n_items ? n_items - 1 : id);
     keys[e] = (int32_t)id;
     vals[e] = (int32_t)e;
   }
@@ -46,7 +47,7 @@ __global__ __launch_bounds__(256) void sorted_apply_kernel(const int32_t* __rest
                                                            const int64_t* __restrict__ query_index, int n, int has_pos,
                                                            const float* __restrict__ dpos, const float* __restrict__ dneg,
                                                            const float* __restrict__ upstream, int32_t pad_row,
-                                                           float* __restrict__ target, AdamArgs adam) {
+                                                           int32_t drop_key, float* __restrict__ target, AdamArgs adam) {
   constexpr int D = 64 * NDW;
   const int lane = lane_id();
   const int64_t chunk = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -60,7 +61,7 @@ __global__ __launch_bounds__(256) void sorted_apply_kernel(const int32_t* __rest
   const int32_t key = in ? keys[i] : -1;
   int32_t qrow = 0;
   float coef = 0.f;
-  if (in) {
+  if (in && key != drop_key) {        // empty slots: nothing is read for them (their query index is -1)
     const int64_t e = vals[i];
     const int64_t m = e / w;
     const int c = (int)(e - m * w);
@@ -111,13 +112,14 @@ __global__ __launch_bounds__(256) void sorted_apply_kernel(const int32_t* __rest
       flush();
       cur = kt;
     }
+    if (cur == drop_key) break;       // the dropped run is the last one (largest key): nothing follows
     const int32_t qr = __builtin_amdgcn_readlane(qrow, t);
     const float cf = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(coef), t));   // bit pattern, not a value cast
     const float* qp = query + (size_t)qr * D;
 #pragma unroll
     for (int k = 0; k < NDW; ++k) acc[k] = __fmaf_rn(cf, qp[k * 64 + lane], acc[k]);
   }
-  if (skipping) return;       // the whole chunk continues a run owned by an earlier wave
+  if (skipping || cur == drop_key) return;       // the whole chunk continues a run owned by an earlier wave / empty slots
   // the last run may continue into the following chunks: finish it here (rare, short)
   for (int64_t j = begin + cnt; j < total && keys[j] == cur; ++j) {
     const int64_t e = vals[j];
@@ -154,7 +156,7 @@ using namespace rsa;
 extern "C" int64_t rsa_scatter_rows_sorted_workspace_bytes(int64_t n_queries, int32_t num_neg, int64_t n_items) {
   if (n_queries <= 0 || num_neg < 0 || n_items < 1) return 0;
   const int64_t total = n_queries * (int64_t)(num_neg + 1);     // sized for the with-positives layout
-  return 4 * align256s(total * 4) + align256s((int64_t)sort_temp_bytes(total, key_bits(n_items))) + 256;
+  return 4 * align256s(total * 4) + align256s((int64_t)sort_temp_bytes(total, key_bits(n_items + 1))) + 256;
 }
 
 static int scatter_sorted_impl(const float* query, const int64_t* query_index, int64_t n_query_rows, int32_t dim,
@@ -190,7 +192,7 @@ static int scatter_sorted_impl(const float* query, const int64_t* query_index, i
   hipLaunchKernelGGL(sorted_keys_kernel, dim3((unsigned)blocks), dim3(256), 0, s, pos_ids, neg_ids, n_queries, (int)num_neg,
                      n_items, k_in, v_in);
   RSA_CHECK_LAUNCH("rsa_scatter_rows_sorted(keys)");
-  const unsigned bits = key_bits(n_items);
+  const unsigned bits = key_bits(n_items + 1);      // ids 0 .. n_items-1 and the drop key n_items
   size_t temp_bytes = sort_temp_bytes(total, bits);
   if (rocprim::radix_sort_pairs(temp, temp_bytes, k_in, k_out, v_in, v_out, (size_t)total, 0u, bits, s) != hipSuccess) {
     rsa::set_error("rsa_scatter_rows_sorted: radix sort failed: %s", hipGetErrorString(hipGetLastError()));
@@ -200,9 +202,9 @@ static int scatter_sorted_impl(const float* query, const int64_t* query_index, i
   dim3 grid((chunks + 3) / 4), block(256);
   const int32_t pad = (int32_t)(pad_row < 0 || pad_row >= (1ll << 31) ? -2 : pad_row);
   switch (dim) {
-    case 64: hipLaunchKernelGGL(sorted_apply_kernel<1>, grid, block, 0, s, k_out, v_out, total, query, query_index, (int)num_neg, has_pos, dpos, dneg, upstream, pad, target, adam); break;
-    case 128: hipLaunchKernelGGL(sorted_apply_kernel<2>, grid, block, 0, s, k_out, v_out, total, query, query_index, (int)num_neg, has_pos, dpos, dneg, upstream, pad, target, adam); break;
-    default: hipLaunchKernelGGL(sorted_apply_kernel<4>, grid, block, 0, s, k_out, v_out, total, query, query_index, (int)num_neg, has_pos, dpos, dneg, upstream, pad, target, adam); break;
+    case 64: hipLaunchKernelGGL(sorted_apply_kernel<1>, grid, block, 0, s, k_out, v_out, total, query, query_index, (int)num_neg, has_pos, dpos, dneg, upstream, pad, (int32_t)n_items, target, adam); break;
+    case 128: hipLaunchKernelGGL(sorted_apply_kernel<2>, grid, block, 0, s, k_out, v_out, total, query, query_index, (int)num_neg, has_pos, dpos, dneg, upstream, pad, (int32_t)n_items, target, adam); break;
+    default: hipLaunchKernelGGL(sorted_apply_kernel<4>, grid, block, 0, s, k_out, v_out, total, query, query_index, (int)num_neg, has_pos, dpos, dneg, upstream, pad, (int32_t)n_items, target, adam); break;
   }
   RSA_CHECK_LAUNCH("rsa_scatter_rows_sorted(apply)");
   return RSA_OK;

@@ -24,6 +24,14 @@ def _sampler_kind(sampler):
     return None
 
 
+_POP_KEYS = ('table', 'pop_prob', 'guide', 'guide_log2', 'table_prob', 'cdf_lut', 'cdf_lines', 'lines_log2')
+
+
+def _pop_kw(cfg):
+    """the popularity sampler's tables out of a cfg dict, as ops.fused_forward keyword arguments"""
+    return {k: cfg[k] for k in _POP_KEYS if cfg.get(k) is not None}
+
+
 class _ScoreFn(torch.autograd.Function):
     """(item_weight, query_src) -> (pos_score, neg_score); non-differentiable extras ride in ctx.extras."""
 
@@ -32,9 +40,7 @@ class _ScoreFn(torch.autograd.Function):
         out = ops.fused_forward(item_weight, query_src, cfg['num_neg'], query_index=cfg.get('query_index'),
                                 pos_ids=cfg.get('pos_ids'), neg_ids=cfg.get('neg_ids'), sampler=cfg['sampler'],
                                 cosine=cfg.get('cosine', False), mask_pad_pos=cfg.get('mask_pad_pos', False),
-                                table=cfg.get('table'), pop_prob=cfg.get('pop_prob'), guide=cfg.get('guide'),
-                                table_prob=cfg.get('table_prob'), cdf_lut=cfg.get('cdf_lut'),
-                                guide_log2=cfg.get('guide_log2', 0), n_queries=cfg.get('n_queries'))
+                                n_queries=cfg.get('n_queries'), **_pop_kw(cfg))
         cfg['out'] = out
         ctx.cfg = cfg
         ctx.save_for_backward(item_weight, query_src, out['neg_ids'])
@@ -114,9 +120,7 @@ def retriever_scores(item_weight, query_src, num_neg, *, query_index=None, pos_i
             raise ValueError('neg_ids is required when no sampler is given')
         cfg['neg_ids'] = neg_ids.reshape(M, -1)
     elif kind == nat.SAMPLER_POPULAR:
-        cfg.update(table=sampler.table, pop_prob=sampler.pop_prob, guide=sampler.guide,
-                   guide_log2=sampler.guide_log2, table_prob=getattr(sampler, 'table_prob', None),
-                   cdf_lut=getattr(sampler, 'cdf_lut', None))
+        cfg.update(sampler.lookup_kwargs())
     pos_score, neg_score = _ScoreFn.apply(item_weight, query_src, cfg)
     out = cfg['out']
     score = {'pos_score': pos_score if pos_ids is not None else None, 'neg_score': neg_score}
@@ -131,20 +135,20 @@ def retriever_scores(item_weight, query_src, num_neg, *, query_index=None, pos_i
 
 
 class _FusedBPRFn(torch.autograd.Function):
-    """forward + BPRLoss in ONE kernel launch (loss evaluated in the epilogue, d loss/d score kept),
-    backward = one rsa_fused_backward launch.  == BaseRetriever.training_step with BPRLoss
-    (baseretriever.py:399-404, loss_func.py:55-59)."""
+    """forward + BPRLoss (or SampledSoftmaxLoss, cfg['loss'] = 'ssm') in ONE kernel launch (loss evaluated in the
+    epilogue, d loss/d score kept), backward = one write-only launch.  == BaseRetriever.training_step with BPRLoss /
+    SampledSoftmaxLoss (baseretriever.py:399-404, loss_func.py:55-59, :80-90)."""
 
     @staticmethod
     def forward(ctx, item_weight, query_src, cfg):
         # d loss/d query is accumulated by the forward itself while the negative rows are in registers
         # (inner product, stock dims): the backward launch then only writes item-gradient rows
         fwd_qgrad = ctx.needs_input_grad[1] and item_weight.shape[1] in (32, 64, 128, 256)
+        loss = cfg.get('loss', 'bpr')
         out = ops.fused_forward(item_weight, query_src, cfg['num_neg'], query_index=cfg.get('query_index'),
                                 pos_ids=cfg['pos_ids'], sampler=cfg['sampler'], neg_ids=cfg.get('neg_ids'),
-                                table=cfg.get('table'), pop_prob=cfg.get('pop_prob'), guide=cfg.get('guide'),
-                                guide_log2=cfg.get('guide_log2', 0), table_prob=cfg.get('table_prob'), cdf_lut=cfg.get('cdf_lut'),
-                                n_queries=cfg['n_queries'], want_logp=False, fused_bpr=True, want_query_grad=fwd_qgrad)
+                                n_queries=cfg['n_queries'], want_logp=False, fused_loss=loss, want_query_grad=fwd_qgrad,
+                                pos_logp=cfg.get('pos_logp'), neg_logp=cfg.get('neg_logp'), **_pop_kw(cfg))
         cfg['out'] = out
         ctx.cfg = cfg
         ctx.fwd_qgrad = fwd_qgrad
@@ -193,13 +197,24 @@ class _FusedBPRFn(torch.autograd.Function):
         return g_item, g_q, None
 
 
+def fused_ssm_loss(item_weight, query_src, num_neg, *, query_index=None, pos_ids, sampler=None, neg_ids=None,
+                   pos_logp=None, neg_logp=None, sparse_grad=False):
+    """SampledSoftmaxLoss (loss_func.py:80-90, one positive per row) through the single-launch fused path:
+    sampling, gather, scores, the logsumexp over a query's positive and num_neg negatives, the loss and d loss/d query
+    in one kernel (num_neg % 64 == 0, inner product, embed_dim in {32, 64, 128, 256}); the backward only writes the
+    item-gradient rows.  With ``neg_ids`` given, ``pos_logp`` / ``neg_logp`` are the sampler's log-probabilities
+    (None = 0).  Returns (loss, neg_ids)."""
+    return fused_bpr_loss(item_weight, query_src, num_neg, query_index=query_index, pos_ids=pos_ids, sampler=sampler,
+                          neg_ids=neg_ids, sparse_grad=sparse_grad, loss='ssm', pos_logp=pos_logp, neg_logp=neg_logp)
+
+
 def fused_bpr_loss(item_weight, query_src, num_neg, *, query_index=None, pos_ids, sampler=None, neg_ids=None,
-                   sparse_grad=False):
-    """BPR training loss through the single-launch fused path (num_neg % 64 == 0).  Returns
-    (loss, neg_ids)."""
+                   sparse_grad=False, loss='bpr', pos_logp=None, neg_logp=None):
+    """BPR (``loss='ssm'``: sampled softmax) training loss through the single-launch fused path
+    (num_neg % 64 == 0).  Returns (loss, neg_ids)."""
     M = query_index.numel() if query_index is not None else query_src.shape[0]
     cfg = {'num_neg': int(num_neg), 'query_index': query_index, 'pos_ids': pos_ids, 'sparse_grad': sparse_grad,
-           'n_queries': M}
+           'n_queries': M, 'loss': loss, 'pos_logp': pos_logp, 'neg_logp': neg_logp}
     kind = _sampler_kind(sampler) if sampler is not None else nat.SAMPLER_GIVEN
     if kind is None:
         raise TypeError(f'fused path does not cover sampler {type(sampler).__name__}')
@@ -207,8 +222,7 @@ def fused_bpr_loss(item_weight, query_src, num_neg, *, query_index=None, pos_ids
     if kind == nat.SAMPLER_GIVEN:
         cfg['neg_ids'] = neg_ids.reshape(M, -1)
     elif kind == nat.SAMPLER_POPULAR:
-        cfg.update(table=sampler.table, pop_prob=sampler.pop_prob, guide=sampler.guide, guide_log2=sampler.guide_log2,
-                   table_prob=getattr(sampler, 'table_prob', None), cdf_lut=getattr(sampler, 'cdf_lut', None))
+        cfg.update(sampler.lookup_kwargs())
     loss = _FusedBPRFn.apply(item_weight, query_src, cfg)
     return loss, cfg['out']['neg_ids']
 
@@ -246,8 +260,7 @@ def bpr_sgd_step(item_weight, user_weight, num_neg, lr, *, user_ids, pos_ids, sa
     if kind == nat.SAMPLER_GIVEN:
         kw['neg_ids'] = neg_ids.reshape(M, -1)
     elif kind == nat.SAMPLER_POPULAR:
-        kw.update(table=sampler.table, pop_prob=sampler.pop_prob, guide=sampler.guide, guide_log2=sampler.guide_log2,
-                  table_prob=getattr(sampler, 'table_prob', None), cdf_lut=getattr(sampler, 'cdf_lut', None))
+        kw.update(sampler.lookup_kwargs())
     with torch.no_grad():
         iw, uw = item_weight.data, user_weight.data
         out = ops.fused_forward(iw, uw, num_neg, query_index=user_ids, pos_ids=pos_ids, sampler=kind, want_logp=False,
@@ -292,8 +305,7 @@ class FusedBPRAdam:
         if kind == nat.SAMPLER_GIVEN:
             kw['neg_ids'] = neg_ids.reshape(M, -1)
         elif kind == nat.SAMPLER_POPULAR:
-            kw.update(table=sampler.table, pop_prob=sampler.pop_prob, guide=sampler.guide, guide_log2=sampler.guide_log2,
-                      table_prob=getattr(sampler, 'table_prob', None), cdf_lut=getattr(sampler, 'cdf_lut', None))
+            kw.update(sampler.lookup_kwargs())
         self.t += 1
         st = self.state
         with torch.no_grad():

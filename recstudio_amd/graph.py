@@ -34,9 +34,7 @@ class GraphedBPRStep:
         self.n, self.B, self.mode, self.lr = int(num_neg), int(batch_size), mode, float(lr)
         self.kw = {'sampler': kind}
         if kind == nat.SAMPLER_POPULAR:
-            self.kw.update(table=sampler.table, pop_prob=sampler.pop_prob, guide=sampler.guide,
-                           guide_log2=sampler.guide_log2, table_prob=getattr(sampler, 'table_prob', None),
-                           cdf_lut=getattr(sampler, 'cdf_lut', None))
+            self.kw.update(sampler.lookup_kwargs())
         unroll = 4 if kind == nat.SAMPLER_POPULAR else rng.randint_unroll(1, self.iw.shape[0])
         cu, mt = rng.device_props(dev)
         self.increment = rng.counter_offset(self.B * self.n, rng.grid_threads(self.B * self.n, cu, mt), unroll)

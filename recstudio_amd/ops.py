@@ -5,6 +5,7 @@ computation below happens in the HIP kernels of librecstudio_amd.so.  All
 tensors must live on a ROCm device -- there is no CPU path.
 """
 import ctypes
+import functools
 
 import torch
 
@@ -38,8 +39,67 @@ def is_known_zero(t):
     return z is not None and z.data_ptr() == t.data_ptr()
 
 
+# Every native launch runs on the CURRENT STREAM OF THE DEVICE ITS TENSORS LIVE ON, with that device made current
+# for the duration of the call (torch.cuda.device guard): a model on cuda:1 while cuda:0 is the process's current
+# device (BaseRetriever honours train.gpu = [1] without calling set_device) must not launch on device 0's stream
+# against device-1 pointers.  All tensor arguments of one call must share the device.
+_LAUNCH_DEV = []
+
+
 def _stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    dev = _LAUNCH_DEV[-1] if _LAUNCH_DEV else None
+    return ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+
+def _tensor_device(args, kwargs):
+    dev = None
+    for a in list(args) + list(kwargs.values()):
+        if isinstance(a, torch.Tensor) and a.is_cuda:
+            if dev is None:
+                dev = a.device
+            elif a.device != dev:
+                raise RuntimeError(f'recstudio_amd: tensors of one call live on different devices ({dev} and {a.device})')
+    return dev
+
+
+def _on_device(fn):
+    """Run ``fn`` under the device guard of its tensor arguments (see above)."""
+    @functools.wraps(fn)
+    def wrapped(*args, **kwargs):
+        dev = _tensor_device(args, kwargs)
+        if dev is None:
+            d = kwargs.get('device')
+            if d is None:
+                d = next((a for a in args if isinstance(a, (torch.device, str))), None)
+            dev = torch.device(d) if d is not None else None
+            if dev is not None and dev.type == 'cuda' and dev.index is None:
+                dev = torch.device('cuda', torch.cuda.current_device())
+        if dev is None or dev.type != 'cuda':
+            return fn(*args, **kwargs)       # CPU tensors: the op's own _need() raises the "GPU only" error
+        _LAUNCH_DEV.append(dev)
+        try:
+            if dev.index == torch.cuda.current_device():
+                return fn(*args, **kwargs)
+            with torch.cuda.device(dev):
+                return fn(*args, **kwargs)
+        finally:
+            _LAUNCH_DEV.pop()
+    return wrapped
+
+
+# Caller-owned reduction scratch of the C ABI (rsa_scratch_bytes(): arrival counter + partial sums of the in-kernel
+# loss reduction, rsa_mean_rows' partials, the BCE valid-row counter): one zero-filled block per (device, stream),
+# so that launches on different streams or devices never share words.
+_SCRATCH = {}
+
+
+def _scratch():
+    dev = _LAUNCH_DEV[-1] if _LAUNCH_DEV else torch.device('cuda', torch.cuda.current_device())
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    t = _SCRATCH.get(key)
+    if t is None:
+        t = _SCRATCH[key] = torch.zeros(int(nat.lib().rsa_scratch_bytes()), dtype=torch.uint8, device=dev)
+    return t
 
 
 def _need(t, dtype, name):
@@ -58,6 +118,7 @@ def _need_opt(t, dtype, name):
 
 
 # ------------------------------------------------------------------ samplers
+@_on_device
 def sample_uniform(numel, low, high, device, generator=None):
     """int64 [numel], == torch.randint(low, high, (numel,), device=device) incl. generator advance."""
     out = torch.empty(int(numel), dtype=torch.int64, device=device)
@@ -65,10 +126,11 @@ def sample_uniform(numel, low, high, device, generator=None):
         return out
     pc = rng.reserve(numel, rng.randint_unroll(low, high), device, generator)
     nat.check(nat.lib().rsa_sample_uniform(ptr(out), int(numel), int(low), int(high), pc.seed, pc.offset,
-                                           pc.grid_threads, _stream()), 'rsa_sample_uniform')
+                                           pc.grid_threads, pc.elem_base, _stream()), 'rsa_sample_uniform')
     return out
 
 
+@_on_device
 def sample_masked_uniform(user_hist, num_items, per_row, generator=None):
     """int64 [B, per_row]: uniform over [1, num_items] minus each row's history (sampler.py:117-147)."""
     user_hist = _need(user_hist, torch.int64, 'user_hist')
@@ -82,10 +144,12 @@ def sample_masked_uniform(user_hist, num_items, per_row, generator=None):
     return out
 
 
-def sample_popular(table, pop_prob, guide, guide_log2, numel, generator=None, want_u=False, cdf_lut=None):
+@_on_device
+def sample_popular(table, pop_prob, guide, guide_log2, numel, generator=None, want_u=False, cdf_lut=None,
+                   cdf_lines=None, lines_log2=0):
     table = _need(table, torch.float32, 'table')
     pop_prob = _need(pop_prob, torch.float32, 'pop_prob')
-    guide = _need(guide, torch.int32, 'guide')
+    guide = _need_opt(guide, torch.int32, 'guide')
     dev = table.device
     ids = torch.empty(int(numel), dtype=torch.int64, device=dev)
     logp = torch.empty(int(numel), dtype=torch.float32, device=dev)
@@ -94,25 +158,31 @@ def sample_popular(table, pop_prob, guide, guide_log2, numel, generator=None, wa
         pc = rng.reserve(numel, 4, dev, generator)
         nat.check(nat.lib().rsa_sample_popular(ptr(table), ptr(pop_prob), ptr(guide), table.numel(), int(guide_log2),
                                                ptr(ids), ptr(logp), ptr(u), int(numel), pc.seed, pc.offset,
-                                               pc.grid_threads, ptr(_need_opt(cdf_lut, torch.float32, 'cdf_lut')),
+                                               pc.grid_threads, pc.elem_base,
+                                               ptr(_need_opt(cdf_lut, torch.float32, 'cdf_lut')),
+                                               ptr(_need_opt(cdf_lines, torch.float32, 'cdf_lines')), int(lines_log2),
                                                _stream()), 'rsa_sample_popular')
     return (ids, logp, u) if want_u else (ids, logp)
 
 
-def popular_lookup(table, pop_prob, guide, guide_log2, u, cdf_lut=None):
+@_on_device
+def popular_lookup(table, pop_prob, guide, guide_log2, u, cdf_lut=None, cdf_lines=None, lines_log2=0):
     table = _need(table, torch.float32, 'table')
     pop_prob = _need(pop_prob, torch.float32, 'pop_prob')
-    guide = _need(guide, torch.int32, 'guide')
+    guide = _need_opt(guide, torch.int32, 'guide')
     u = _need(u, torch.float32, 'u')
     ids = torch.empty(u.numel(), dtype=torch.int64, device=u.device)
     logp = torch.empty(u.numel(), dtype=torch.float32, device=u.device)
     nat.check(nat.lib().rsa_popular_lookup(ptr(table), ptr(pop_prob), ptr(guide), table.numel(), int(guide_log2),
                                            ptr(u), ptr(ids), ptr(logp), u.numel(),
-                                           ptr(_need_opt(cdf_lut, torch.float32, 'cdf_lut')), _stream()),
+                                           ptr(_need_opt(cdf_lut, torch.float32, 'cdf_lut')),
+                                           ptr(_need_opt(cdf_lines, torch.float32, 'cdf_lines')), int(lines_log2),
+                                           _stream()),
               'rsa_popular_lookup')
     return ids.view(u.shape), logp.view(u.shape)
 
 
+@_on_device
 def item_logp(pop_prob, ids):
     pop_prob = _need(pop_prob, torch.float32, 'pop_prob')
     ids = _need(ids, torch.int64, 'ids')
@@ -123,6 +193,7 @@ def item_logp(pop_prob, ids):
 
 
 # ------------------------------------------------------------------ gathers
+@_on_device
 def embedding_gather(table, ids):
     table = _need(table, torch.float32, 'table')
     ids = _need(ids, torch.int64, 'ids')
@@ -133,6 +204,7 @@ def embedding_gather(table, ids):
     return out
 
 
+@_on_device
 def scatter_add_rows(src, ids, n_rows, out=None):
     """dst[ids[i]] += src[i] for ids != 0 (embedding_dense_backward with padding_idx = 0).  ``out``: accumulate
     into an existing [n_rows, dim] tensor instead of a fresh zero one."""
@@ -146,6 +218,7 @@ def scatter_add_rows(src, ids, n_rows, out=None):
     return dst
 
 
+@_on_device
 def seg_gather(item_table, flat_item_ids, seg_start, seg_end, max_len, want_rows=True, want_ids=True):
     flat = _need(flat_item_ids, torch.int64, 'flat_item_ids')
     s = _need(seg_start, torch.int64, 'seg_start')
@@ -164,11 +237,13 @@ def seg_gather(item_table, flat_item_ids, seg_start, seg_end, max_len, want_rows
 
 
 # ------------------------------------------------------------------ fused forward / backward
+@_on_device
 def fused_forward(item_table, query, num_neg, *, query_index=None, pos_ids=None, neg_ids=None,
                   sampler=nat.SAMPLER_GIVEN, cosine=False, mask_pad_pos=False,
                   table=None, pop_prob=None, guide=None, guide_log2=0, generator=None, n_queries=None,
                   out=None, want_logp=True, table_prob=None, fused_bpr=False, want_mean=True, cdf_lut=None,
-                  want_query_grad=False, rng_state=None):
+                  want_query_grad=False, rng_state=None, cdf_lines=None, lines_log2=0, fused_loss=None,
+                  pos_logp=None, neg_logp=None):
     """One launch of rsa_fused_sample_gather_score.  Returns a dict with
     neg_ids [M,n] int64, neg_score [M,n], pos_score [M] (if pos_ids), and for the
     popularity sampler neg_logp [M,n], pos_logp [M].  ``out``: a dict returned by an earlier
@@ -177,7 +252,11 @@ def fused_forward(item_table, query, num_neg, *, query_index=None, pos_ids=None,
     them, loss_func.py:55-59).  ``fused_bpr=True`` (needs num_neg % 64 == 0 and pos_ids) evaluates
     BPRLoss in the kernel's epilogue: adds ``loss`` (scalar), ``row_loss [M]``, ``dpos [M]``,
     ``dneg [M, n]`` to the result; with ``want_query_grad`` (inner product, dim in {32, 64, 128, 256}) also
-    ``query_grad [M, d]`` = d loss / d query row, accumulated while the rows are in registers."""
+    ``query_grad [M, d]`` = d loss / d query row, accumulated while the rows are in registers.
+    ``fused_loss='ssm'`` (same conditions, inner product, dim in {32, 64, 128, 256}): SampledSoftmaxLoss in the
+    epilogue instead (one wave per query carries the logsumexp over its num_neg / 64 tiles); with ids given,
+    ``pos_logp`` / ``neg_logp`` are the INPUT log-probabilities.  ``cdf_lines`` / ``lines_log2``: the bucket-line
+    form of the popularity sampler's inverse CDF (PopularSamplerModel.cdf_lines)."""
     item_table = _need(item_table, torch.float32, 'item_table')
     query = _need(query, torch.float32, 'query')
     dev = item_table.device
@@ -208,7 +287,7 @@ def fused_forward(item_table, query, num_neg, *, query_index=None, pos_ids=None,
             a.offset_dev = ptr(offset_dev)
         else:
             pc = rng.reserve(M * n, unroll, dev, generator)
-            a.seed, a.offset, a.grid_threads = pc.seed, pc.offset, pc.grid_threads
+            a.seed, a.offset, a.grid_threads, a.elem_base = pc.seed, pc.offset, pc.grid_threads, pc.elem_base
     reuse = out is not None        # caller-provided output buffers (same keys/shapes as returned)
     if not reuse:
         out = {'neg_score': torch.empty(M, n, dtype=torch.float32, device=dev)}
@@ -218,7 +297,7 @@ def fused_forward(item_table, query, num_neg, *, query_index=None, pos_ids=None,
     if sampler == nat.SAMPLER_POPULAR:
         table = _need(table, torch.float32, 'table')
         pop_prob = _need(pop_prob, torch.float32, 'pop_prob')
-        guide = _need(guide, torch.int32, 'guide')
+        guide = _need_opt(guide, torch.int32, 'guide')
         if not reuse and want_logp:
             out['neg_logp'] = torch.empty(M, n, dtype=torch.float32, device=dev)
             if pos_ids is not None:
@@ -231,27 +310,40 @@ def fused_forward(item_table, query, num_neg, *, query_index=None, pos_ids=None,
     a.table, a.pop_prob, a.guide = ptr(table), ptr(pop_prob), ptr(guide)
     a.table_prob = ptr(_need_opt(table_prob, torch.float32, 'table_prob'))
     a.cdf_lut = ptr(_need_opt(cdf_lut, torch.float32, 'cdf_lut'))
-    a.neg_ids, a.neg_logp, a.pos_logp = ptr(neg_ids), ptr(out.get('neg_logp')), ptr(out.get('pos_logp'))
+    a.cdf_lines, a.lines_log2 = ptr(_need_opt(cdf_lines, torch.float32, 'cdf_lines')), int(lines_log2)
+    if sampler == nat.SAMPLER_GIVEN and (pos_logp is not None or neg_logp is not None):
+        # ids given: the log-probabilities are INPUTS of the SampledSoftmax epilogue
+        a.neg_logp, a.pos_logp = ptr(_need_opt(neg_logp, torch.float32, 'neg_logp')), ptr(_need_opt(pos_logp, torch.float32, 'pos_logp'))
+        a.neg_ids = ptr(neg_ids)
+    else:
+        a.neg_ids, a.neg_logp, a.pos_logp = ptr(neg_ids), ptr(out.get('neg_logp')), ptr(out.get('pos_logp'))
     a.pos_score, a.neg_score = ptr(out.get('pos_score')), ptr(out['neg_score'])
-    if fused_bpr:
+    if fused_loss is None and fused_bpr:
+        fused_loss = 'bpr'
+    if fused_loss is not None:
+        if fused_loss not in ('bpr', 'ssm'):
+            raise ValueError("fused_loss must be None, 'bpr' or 'ssm'")
         if 'loss' not in out:
             out['loss'] = torch.empty((), dtype=torch.float32, device=dev)
             out['row_loss'] = torch.empty(M, dtype=torch.float32, device=dev)
             out['dpos'] = torch.empty(M, dtype=torch.float32, device=dev)
             out['dneg'] = torch.empty(M, n, dtype=torch.float32, device=dev)
-        a.fused_loss = nat.LOSS_BPR + 1
+        a.fused_loss = (nat.LOSS_BPR if fused_loss == 'bpr' else nat.LOSS_SSM) + 1
         a.row_loss, a.loss_out = ptr(out['row_loss']), ptr(out['loss'] if want_mean else None)
+        if want_mean:
+            a.reduce_scratch = ptr(_scratch())
         a.dpos, a.dneg = ptr(out['dpos']), ptr(out['dneg'])
         if want_query_grad:
             if 'query_grad' not in out:
                 out['query_grad'] = torch.empty(M, dim, dtype=torch.float32, device=dev)
             a.query_grad = ptr(out['query_grad'])
     elif want_query_grad:
-        raise ValueError('want_query_grad needs fused_bpr=True')
+        raise ValueError('want_query_grad needs a fused loss (fused_bpr=True / fused_loss=...)')
     nat.check(nat.lib().rsa_fused_sample_gather_score(ctypes.byref(a), _stream()), 'rsa_fused_sample_gather_score')
     return out
 
 
+@_on_device
 def score_packed_keys(item_table, query, keys):
     """Scores of (query row, item row) pairs packed as (qrow << 32) | irow (rsa_shard_route's keys): the fused
     gather+score kernel reading the pairs directly."""
@@ -271,6 +363,7 @@ def score_packed_keys(item_table, query, keys):
     return out
 
 
+@_on_device
 def pairwise_loss(kind, pos_score, neg_score, pos_logp=None, neg_logp=None, want_grad=True):
     """(loss [scalar tensor], dpos [M] | None, dneg [M,n] | None, row_loss [M])."""
     pos_score = _need(pos_score, torch.float32, 'pos_score')
@@ -287,11 +380,12 @@ def pairwise_loss(kind, pos_score, neg_score, pos_logp=None, neg_logp=None, want
     dpos = torch.empty(pos_score.shape, dtype=torch.float32, device=dev) if want_grad else None
     dneg = torch.empty(neg_score.shape, dtype=torch.float32, device=dev) if want_grad else None
     nat.check(nat.lib().rsa_pairwise_loss(int(kind), ptr(pos_score), ptr(neg_score), ptr(pos_logp), ptr(neg_logp),
-                                          M, n, ptr(row), ptr(loss), ptr(dpos), ptr(dneg), _stream()),
+                                          M, n, ptr(row), ptr(loss), ptr(dpos), ptr(dneg), ptr(_scratch()), _stream()),
               'rsa_pairwise_loss')
     return loss, dpos, dneg, row
 
 
+@_on_device
 def pairwise_loss_ex(kind, pos_score, neg_score, pos_logp=None, neg_logp=None, param0=0.0, param1=0.0):
     """rsa_pairwise_loss_ex (WeightedBPR / WeightedBCE / Hinge / NCE / CCL): (loss, dpos, dneg)."""
     pos_score = _need(pos_score, torch.float32, 'pos_score')
@@ -308,10 +402,11 @@ def pairwise_loss_ex(kind, pos_score, neg_score, pos_logp=None, neg_logp=None, p
     dpos, dneg = torch.empty_like(pos_score), torch.empty_like(neg_score)
     nat.check(nat.lib().rsa_pairwise_loss_ex(int(kind), ptr(pos_score), ptr(neg_score), ptr(pos_logp), ptr(neg_logp), M, n,
                                              float(param0), float(param1), ptr(row), ptr(loss), ptr(dpos), ptr(dneg),
-                                             _stream()), 'rsa_pairwise_loss_ex')
+                                             ptr(_scratch()), _stream()), 'rsa_pairwise_loss_ex')
     return loss, dpos, dneg
 
 
+@_on_device
 def ssm_shared_loss(pos_score, neg_score, pos_logp=None, neg_logp=None):
     """rsa_ssm_shared_loss: pos_score [B, L], neg_score [B, n].  Returns (loss, dpos, dneg)."""
     pos_score = _need(pos_score, torch.float32, 'pos_score')
@@ -325,10 +420,12 @@ def ssm_shared_loss(pos_score, neg_score, pos_logp=None, neg_logp=None):
     loss = torch.empty((), dtype=torch.float32, device=dev)
     dpos, dneg = torch.empty_like(pos_score), torch.empty_like(neg_score)
     nat.check(nat.lib().rsa_ssm_shared_loss(ptr(pos_score), ptr(pos_logp), ptr(neg_score), ptr(neg_logp), B, L, n,
-                                            ptr(row), ptr(loss), ptr(dpos), ptr(dneg), _stream()), 'rsa_ssm_shared_loss')
+                                            ptr(row), ptr(loss), ptr(dpos), ptr(dneg), ptr(_scratch()), _stream()),
+              'rsa_ssm_shared_loss')
     return loss, dpos, dneg
 
 
+@_on_device
 def fused_backward(item_table, query, neg_ids, dneg, *, query_index=None, pos_ids=None, dpos=None, upstream=None,
                    dense_item_grad=True, row_item_grad=False, want_query_grad=True, query_table_grad=None,
                    item_grad_out=None, query_table_pad_row=0, item_pad_row=0, cosine=False):
@@ -369,6 +466,7 @@ def fused_backward(item_table, query, neg_ids, dneg, *, query_index=None, pos_id
 
 
 # ------------------------------------------------------------------ full catalog
+@_on_device
 def row_lse(x, want_softmax=False, scale=1.0):
     x = _need(x, torch.float32, 'x')
     M, n = x.shape
@@ -379,25 +477,57 @@ def row_lse(x, want_softmax=False, scale=1.0):
 
 
 def _pad_k(item_table, query):
-    """The MFMA kernel is built for d in {32, 64, 128}: zero-pad the k dimension otherwise (a copy -- only for
-    unusual dims; the dot products are unchanged)."""
+    """The MFMA kernel is built for d in {32, 64, 128}: zero-pad the k dimension of smaller dims (a copy -- only for
+    unusual dims; the dot products are unchanged).  d > 128 is handled by the callers (k split into chunks)."""
     dim = item_table.shape[1]
     if dim in (32, 64, 128):
         return item_table, query, dim
     if dim > 128:
-        raise NotImplementedError(f'full-catalog scoring supports embed_dim <= 128, got {dim}')
+        raise NotImplementedError(f'one MFMA pass covers embed_dim <= 128, got {dim} (ops.fullscore splits it)')
     pad = (32 if dim < 32 else 64 if dim < 64 else 128) - dim
     return torch.nn.functional.pad(item_table, (0, pad)), torch.nn.functional.pad(query, (0, pad)), dim + pad
 
 
-def fullscore(item_table, query, *, want_scores=False, want_lse=False, k=0, items_without_pad=False):
+@_on_device
+def row_sqnorm(table, score_mode, pad=0):
+    """rsa_row_sqnorm: per-row operand of the cosine (1 / ||row||) or Euclidean (||row||^2) full-catalog scores.
+    ``pad`` extra (zero) entries are appended (the MFMA kernel reads up to a tile past the last item)."""
+    table = _need(table, torch.float32, 'table')
+    n, d = table.shape
+    out = torch.zeros(n + pad, dtype=torch.float32, device=table.device) if pad else \
+        torch.empty(n, dtype=torch.float32, device=table.device)
+    nat.check(nat.lib().rsa_row_sqnorm(ptr(table), n, d, int(score_mode), ptr(out), _stream()), 'rsa_row_sqnorm')
+    return out
+
+
+def _score_mode(cosine):
+    return int(cosine) if not isinstance(cosine, bool) else (nat.SCORE_COS if cosine else nat.SCORE_IP)
+
+
+FULLSCORE_MAX_K = 1024
+
+
+@_on_device
+def fullscore(item_table, query, *, want_scores=False, want_lse=False, k=0, items_without_pad=False, score_mode=0):
     """rsa_fullscore: scores of query [B,d] against rows 1.. of item_table [N,d].
     ``items_without_pad``: ``item_table`` is the reference's ``item_vector`` (= weight[1:], no padding
-    row); the kernel never touches row 0, so the base pointer is simply moved one row back."""
+    row); the kernel never touches row 0, so the base pointer is simply moved one row back.
+    ``score_mode``: rsa_score_mode (inner product / cosine / Euclidean, scorer.py:5-34).
+    Shapes outside the single-pass kernel are composed from it: embed_dim > 128 accumulates materialised scores
+    over 128-wide slices of k; top-k beyond 1024 runs on materialised scores (torch.topk)."""
     item_table = _need(item_table, torch.float32, 'item_table')
     query = _need(query, torch.float32, 'query')
+    score_mode = _score_mode(score_mode)
+    dim0 = item_table.shape[1]
+    if dim0 > 128 or k > FULLSCORE_MAX_K:
+        return _fullscore_composed(item_table, query, want_scores, want_lse, k, items_without_pad, score_mode)
     dev = item_table.device
     n_items, dim = item_table.shape
+    ia = qa = None
+    if score_mode != nat.SCORE_IP:       # per-item / per-query operands from the UNPADDED rows
+        rows = item_table if items_without_pad else item_table[1:]
+        ia = row_sqnorm(rows, score_mode, pad=64)
+        qa = row_sqnorm(query, score_mode)
     item_table, query, dim = _pad_k(item_table, query)
     table_ptr = ptr(item_table)
     if items_without_pad:
@@ -411,10 +541,39 @@ def fullscore(item_table, query, *, want_scores=False, want_lse=False, k=0, item
     ws_bytes = int(nat.lib().rsa_fullscore_workspace_bytes(B, n_items, int(k)))
     ws = torch.empty(max(ws_bytes, 8), dtype=torch.uint8, device=dev)
     nat.check(nat.lib().rsa_fullscore(table_ptr, n_items, dim, ptr(query), B, ptr(scores), ptr(lse), ptr(tv),
-                                      ptr(ti), int(k), ptr(ws), ws_bytes, _stream()), 'rsa_fullscore')
+                                      ptr(ti), int(k), score_mode, ptr(ia), ptr(qa), ptr(ws), ws_bytes, _stream()),
+              'rsa_fullscore')
     return scores, lse, tv, ti
 
 
+def _fullscore_composed(item_table, query, want_scores, want_lse, k, items_without_pad, score_mode):
+    """embed_dim > 128 and / or k > 1024 (the reference has neither limit, scorer.py:16, baseretriever.py:385):
+    inner products accumulated over <= 128-wide column slices through the MFMA kernel into one materialised
+    [B, N-1] matrix, the cosine / Euclidean operands applied to it, then logsumexp (rsa_row_lse) and top-k
+    (rsa_row_topk up to 1024, torch.topk beyond)."""
+    rows = item_table if items_without_pad else item_table[1:]
+    d = rows.shape[1]
+    scores = None
+    for c0 in range(0, d, 128):
+        part = fullscore(rows[:, c0:c0 + 128].contiguous(), query[:, c0:c0 + 128].contiguous(), want_scores=True,
+                         items_without_pad=True)[0]
+        scores = part if scores is None else scores.add_(part)
+    if score_mode == nat.SCORE_COS:
+        scores.mul_(row_sqnorm(rows, score_mode)).mul_(row_sqnorm(query, score_mode).view(-1, 1))
+    elif score_mode == nat.SCORE_EUC:
+        scores.mul_(2.0).sub_(row_sqnorm(rows, score_mode)).sub_(row_sqnorm(query, score_mode).view(-1, 1))
+    lse = row_lse(scores)[0] if want_lse else None
+    tv = ti = None
+    if k:
+        if k <= FULLSCORE_MAX_K:
+            tv, ti = row_topk(scores, k)
+        else:
+            tv, ti = torch.topk(scores, k, dim=-1)
+        ti = ti + 1
+    return (scores if want_scores else None), lse, tv, ti
+
+
+@_on_device
 def fullscore_softmax(item_table, query, lse, row_scale=None):
     """rsa_fullscore_softmax: probs[b, i-1] = row_scale[b] * exp(<query_b, item_i> - lse[b]) over rows 1.. of
     ``item_table`` (dims in {32, 64, 128})."""
@@ -431,6 +590,7 @@ def fullscore_softmax(item_table, query, lse, row_scale=None):
     return probs
 
 
+@_on_device
 def topk_mask_history(cand_val, cand_idx, user_hist, k):
     """baseretriever.py:386-392 on sorted candidates: drop history items, keep the k best."""
     cand_val = _need(cand_val, torch.float32, 'cand_val')
@@ -444,6 +604,7 @@ def topk_mask_history(cand_val, cand_idx, user_hist, k):
     return out_v, out_i
 
 
+@_on_device
 def row_topk(values, k):
     """torch.topk(values, k) over the last dim (k <= 1024) -> (values, column indices)."""
     values = _need(values, torch.float32, 'values')
@@ -455,11 +616,13 @@ def row_topk(values, k):
     return out_v.view(*lead, k), out_i.view(*lead, k)
 
 
+@_on_device
 def rng_advance(offset_dev, increment):
     """*offset_dev += increment on the stream (rsa_rng_advance): the device copy of the generator offset."""
     nat.check(nat.lib().rsa_rng_advance(ptr(offset_dev), int(increment), _stream()), 'rsa_rng_advance')
 
 
+@_on_device
 def scatter_rows_sorted(target, query, neg_ids, dneg, *, query_index=None, pos_ids=None, dpos=None, upstream=None,
                         pad_row=0):
     """rsa_scatter_rows_sorted: target[id] += upstream * sum_e d_e * query[qrow_e], sorted by id, no atomics.
@@ -485,6 +648,7 @@ def scatter_rows_sorted(target, query, neg_ids, dneg, *, query_index=None, pos_i
     return target
 
 
+@_on_device
 def adam_rows_sorted(weight, exp_avg, exp_avg_sq, query, neg_ids, dneg, *, lr, betas=(0.9, 0.999), eps=1e-8, step=1,
                      query_index=None, pos_ids=None, dpos=None, upstream=None, pad_row=0):
     """rsa_adam_rows_sorted: lazy Adam (torch.optim.SparseAdam's rule) on the rows touched by the step, from the

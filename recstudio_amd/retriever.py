@@ -30,7 +30,7 @@ from . import _native as nat
 from . import eval as rs_eval
 from . import ops
 from .dataset import SeqDataset, TripletDataset
-from .fused import fused_bpr_loss, retriever_scores
+from .fused import fused_bpr_loss, fused_ssm_loss, retriever_scores
 from .loss_func import (BinaryCrossEntropyLoss, BPRLoss, FullScoreLoss, PairwiseLoss, PointwiseLoss, SampledSoftmaxLoss,
                         SoftmaxLoss)
 from .sampler import PopularSamplerModel, Sampler, UniformSampler
@@ -398,12 +398,16 @@ class BaseRetriever(torch.nn.Module):
         """baseretriever.py:374-397: full-catalog scores -> top (k + |hist|) -> drop history -> top k."""
         query = self.query_encoder(self._get_query_feat(batch))
         more = user_h.size(1) if user_h is not None else 0
-        if type(self.score_func) is InnerProductScorer and isinstance(self.item_encoder, torch.nn.Embedding):
+        if type(self.score_func) in (InnerProductScorer, CosineScorer, EuclideanScorer) \
+                and isinstance(self.item_encoder, torch.nn.Embedding):
+            # the MFMA kernel: scores + exact top-(k + more) without the [B, N] matrix (cosine / Euclidean: the tile
+            # epilogue applies the norms, scorer.py:19-34); embed_dim > 128 or k + more > 1024 (a user whose history
+            # is longer than that, e.g. ml-1m) are composed from the same kernel on materialised scores (ops.fullscore)
             n_items = self.item_encoder.weight.shape[0]
             kc = min(k + more, n_items - 1)
             table = self.item_vector if hasattr(self, 'item_vector') else self._get_item_vector()
             _, _, score, topk_items = ops.fullscore(table.detach(), query.detach().contiguous(), k=kc,
-                                                    items_without_pad=True)
+                                                    items_without_pad=True, score_mode=self.score_func.cosine)
         else:
             score, topk_items = torch.topk(self.score_func(query, self.item_vector), k + more)
             topk_items = topk_items + 1
@@ -423,6 +427,21 @@ class BaseRetriever(torch.nn.Module):
             else:
                 qsrc, qidx = self.query_encoder(qfeat), None
             loss, _ = fused_bpr_loss(self.item_encoder.weight, qsrc, self.neg_count, query_index=qidx,
+                                     pos_ids=batch[self.fiid], sampler=self.sampler,
+                                     sparse_grad=self.config['train'].get('sparse_grad', False))
+            return loss
+        # the same for stock SampledSoftmaxLoss (configs[2]): the logsumexp over the positive and the negatives of a
+        # query is carried through its tiles by one wave, the query gradient is accumulated in the forward
+        if (type(self.loss_fn) is SampledSoftmaxLoss and self.sampler is not None and self._fused_ok()
+                and type(self.score_func) is InnerProductScorer and self.neg_count and self.neg_count % 64 == 0
+                and batch[self.fiid].dim() == 1 and self.item_encoder.weight.shape[1] in (32, 64, 128, 256)
+                and self.config['train'].get('fused_ssm', True)):
+            qfeat = self._get_query_feat(batch)
+            if isinstance(self.query_encoder, torch.nn.Embedding) and isinstance(qfeat, torch.Tensor) and qfeat.dim() == 1:
+                qsrc, qidx = self.query_encoder.weight, qfeat
+            else:
+                qsrc, qidx = self.query_encoder(qfeat), None
+            loss, _ = fused_ssm_loss(self.item_encoder.weight, qsrc, self.neg_count, query_index=qidx,
                                      pos_ids=batch[self.fiid], sampler=self.sampler,
                                      sparse_grad=self.config['train'].get('sparse_grad', False))
             return loss

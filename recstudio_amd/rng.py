@@ -21,6 +21,7 @@ class PhiloxCall:
     seed: int
     offset: int
     grid_threads: int
+    elem_base: int = 0          # element index of this rank's element 0 inside the global call (sharded_stream)
 
 
 def grid_threads(numel, cu_count, max_threads_per_cu):
@@ -38,6 +39,15 @@ def randint_unroll(low, high):
     return 2 if (int(high) - int(low)) >= (1 << 28) else 4
 
 
+class _no_shard:
+    def __enter__(self):
+        self.saved = list(_SHARD)
+        _SHARD.clear()
+
+    def __exit__(self, *exc):
+        _SHARD.extend(self.saved)
+
+
 _PROPS = {}
 
 
@@ -51,10 +61,36 @@ def device_props(device):
     return _PROPS[idx]
 
 
+_SHARD = []          # stack of (rank, world, generator) set by sharded_stream
+
+
+class sharded_stream:
+    """``with rng.sharded_stream(rank, world, generator):`` -- inside, a sampler call over ``numel`` outputs draws
+    elements [rank*numel, (rank+1)*numel) of ONE torch call over world*numel outputs (grid sized for the global
+    call, generator advanced by what the global call consumes).  With ``generator`` in the same state on every rank
+    the negatives of a run are those of a single-GPU run on the concatenated batch, whatever the number of GPUs
+    ("global element index so results are G-invariant")."""
+
+    def __init__(self, rank, world, generator):
+        self.item = (int(rank), int(world), generator)
+
+    def __enter__(self):
+        _SHARD.append(self.item)
+        return self
+
+    def __exit__(self, *exc):
+        _SHARD.pop()
+
+
 def reserve(numel, unroll, device, generator=None, props=None):
     """Consume the generator state one torch distribution call over ``numel`` outputs would."""
     if numel <= 0:
         return PhiloxCall(0, 0, BLOCK)
+    if _SHARD:
+        rank, world, gen = _SHARD[-1]
+        with _no_shard():
+            pc = reserve(numel * world, unroll, device, gen if gen is not None else generator, props)
+        return PhiloxCall(pc.seed, pc.offset, pc.grid_threads, rank * int(numel))
     if generator is None:
         idx = torch.device(device).index
         if idx is None:

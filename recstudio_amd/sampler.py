@@ -15,7 +15,8 @@ from torch import Tensor
 
 from . import ops
 
-__all__ = ['Sampler', 'UniformSampler', 'MaskedUniformSampler', 'PopularSamplerModel', 'build_guide_table']
+__all__ = ['Sampler', 'UniformSampler', 'MaskedUniformSampler', 'PopularSamplerModel', 'build_guide_table',
+           'build_cdf_lines']
 
 
 class Sampler(torch.nn.Module):
@@ -101,13 +102,92 @@ def build_guide_table(table: Tensor, guide_log2: Optional[int] = None):
     return guide.to(torch.int32), guide_log2
 
 
+LINE_K = 8          # distinct CDF values held by one bucket line (rsa_common.hpp)
+
+
+def build_cdf_lines(table: Tensor, pop_prob: Tensor, lines_log2: Optional[int] = None, max_bytes: int = 2 << 30,
+                    overflow_target: float = 2e-4):
+    """BUCKET LINES: the one-HBM-line form of ``torch.searchsorted(table, u)`` (layout: include/recstudio_amd.h,
+    ``rsa_fused_args.cdf_lines``).  Bucket b covers u in [b, b+1) / 2**lines_log2 and its 128-byte line lists the
+    first LINE_K DISTINCT values of the CDF inside it with their {id, probability}, plus the first distinct entry
+    above the bucket.  Items whose CDF value equals their predecessor's (zero probability, or a probability the fp32
+    cumsum absorbed) can never be returned by a lower-bound search and are left out, so a catalog where most items
+    were never seen does not crowd the lines.  Cut points are compared in float64, where the fp32 CDF and b / 2**g
+    are both exact -- same argument as ``build_guide_table``.
+
+    ``lines_log2`` None: the smallest size (>= 2**4 buckets) for which at most ``overflow_target`` of the buckets
+    (= of the draws, u being uniform) hold more than LINE_K distinct values AND would need the binary-search
+    fallback, capped at ``max_bytes``.  Returns (lines [2**g, 32] float32, g)."""
+    t = table.detach().cpu().to(torch.float32).contiguous()
+    pp = pop_prob.detach().cpu().to(torch.float32).contiguous()
+    n = t.numel()
+    distinct = torch.ones(n, dtype=torch.bool)
+    distinct[1:] = t[1:] > t[:-1]
+    ids = torch.nonzero(distinct).flatten()                    # first index of every run of equal CDF values
+    cdf = t[ids]
+    nd = ids.numel()
+    cdf64 = cdf.to(torch.float64)
+
+    def cuts_of(g):
+        K = 1 << g
+        gd = torch.searchsorted(cdf64, torch.arange(K + 1, dtype=torch.float64) / K)     # first entry >= b / K
+        gd[K] = nd
+        return gd
+
+    if lines_log2 is None:
+        g_max = max(4, int(np.floor(np.log2(max_bytes / 128))))
+        g = int(min(g_max, max(4, int(np.ceil(np.log2(max(nd, 2) / 2.0))))))            # ~2 entries per bucket
+        while g > 4:                                              # as small as the overflow target allows
+            c = cuts_of(g - 1)
+            if float(((c[1:] - c[:-1]) > LINE_K).double().mean()) > overflow_target:
+                break
+            g -= 1
+        while g < g_max:
+            c = cuts_of(g)
+            if float(((c[1:] - c[:-1]) > LINE_K).double().mean()) <= overflow_target:
+                break
+            g += 1
+        lines_log2 = g
+    gd = cuts_of(lines_log2)
+    K = 1 << lines_log2
+    lo, hi = gd[:-1], gd[1:]
+    cnt = hi - lo
+    last = n - 1
+    lines = torch.zeros(K, 32, dtype=torch.float32)
+    as_f = lambda x: x.to(torch.int32).view(torch.float32)       # noqa: E731  int32 bit patterns in a float tensor
+    lines[:, 0] = as_f(cnt)
+    nxt = hi.clamp(max=nd - 1)
+    past = hi >= nd                                               # nothing above the bucket: searchsorted returns n -> clamped
+    nxt_id = torch.where(past, torch.full_like(hi, last), ids[nxt])
+    lines[:, 1] = as_f(nxt_id)
+    lines[:, 2] = pp[nxt_id]
+    lines[:, 3] = as_f(torch.where(lo < nd, ids[lo.clamp(max=nd - 1)], torch.full_like(lo, n)))   # fallback range in `table`
+    lines[:, 28] = as_f(torch.where(past, torch.full_like(hi, n), ids[nxt]))
+    for k in range(LINE_K):
+        e = lo + k
+        ok = e < hi
+        e = e.clamp(max=nd - 1)
+        lines[:, 4 + k] = torch.where(ok, cdf[e], torch.full((K,), float('inf')))
+        lines[:, 12 + 2 * k] = as_f(torch.where(ok, ids[e], torch.zeros_like(e)))
+        lines[:, 13 + 2 * k] = torch.where(ok, pp[ids[e]], torch.zeros(K))
+    return lines, lines_log2
+
+
 class PopularSamplerModel(Sampler):
     """recstudio/ann/sampler.py:224-258.  The fp32 tables are built with the very same torch
     CPU ops as the reference's constructor (so they are bit-identical to its registered
     buffers) and uploaded with the module; a guide table accelerates the inverse-CDF search."""
 
-    def __init__(self, pop_count, scorer=None, mode=0, guide_log2=None):
+    # derived lookup structures: rebuilt from pop_prob / table, never part of the state dict (the reference's
+    # checkpoint holds exactly `pop_prob` and `table`, sampler.py:239-241)
+    LINES_MIN_ITEMS = 1 << 16        # below this the tables live in L2 and every form costs the same
+
+    def __init__(self, pop_count, scorer=None, mode=0, guide_log2=None, lookup='auto', lines_log2=None):
+        """``lookup``: 'lines' (bucket lines, one HBM line per draw), 'lut' (16-byte direct-lookup table + 4-wide
+        probe), 'guide' (guide table + binary search) or 'auto' (lines for catalogs of LINES_MIN_ITEMS items or
+        more).  All return torch.searchsorted's index."""
         super().__init__(pop_count.shape[0], scorer)
+        self.lookup, self._guide_log2_arg, self._lines_log2_arg = lookup, guide_log2, lines_log2
         with torch.no_grad():
             pop_count = torch.as_tensor(pop_count).detach().to('cpu', torch.float)
             if mode == 0:
@@ -120,45 +200,70 @@ class PopularSamplerModel(Sampler):
             self.register_buffer('pop_prob', pop_count / pop_count.sum())
             self.register_buffer('table', torch.cumsum(self.pop_prob, dim=0))
             self.pop_prob[-1] = 1.0                                       # sampler.py:241
-            guide, self.guide_log2 = build_guide_table(self.table, guide_log2)
-            self.register_buffer('guide', guide)
             self._register_pairs()
+        self.register_load_state_dict_post_hook(lambda module, incompatible: module._register_pairs())
 
+    def _use_lines(self):
+        if self.lookup == 'auto':
+            return self.table.numel() >= self.LINES_MIN_ITEMS
+        return self.lookup == 'lines'
+
+    @torch.no_grad()
     def _register_pairs(self):
-        # interleaved {table[i], pop_prob[i]} copy for the fused kernel (not part of the reference's state)
-        self.register_buffer('table_prob', torch.stack([self.table, self.pop_prob], 1).contiguous(), persistent=False)
-        # direct-lookup table, one self-contained 16-B entry per guide bucket (layout: rsa_common.hpp,
-        # cdf_lookup_lut): {lo | search bit, table[lo] or +inf, pop_prob[lo], pop_prob[lo+1]} -- one HBM line
-        # per sampled id instead of three dependent round trips (134 MB at 2^23 buckets)
-        last = self.table.numel() - 1
-        lo = self.guide.to(torch.int64)
-        hi = torch.cat([lo[1:], lo[-1:]])
-        span = hi - lo
-        g0, g1 = lo.clamp(max=last), (lo + 1).clamp(max=last)
-        x = (lo - (span >= 2).to(torch.int64) * (1 << 31)).to(torch.int32)
-        y = torch.where(span == 0, torch.full_like(self.table[g0], float('inf')), self.table[g0])
-        lut = torch.stack([x.view(torch.float32), y, self.pop_prob[g0], self.pop_prob[g1]], 1).contiguous()
-        self.register_buffer('cdf_lut', lut, persistent=False)
+        """(Re)build every derived buffer from ``table`` / ``pop_prob`` -- also after ``load_state_dict`` replaced them,
+        so that the kernels never sample from a stale structure while ``compute_item_p`` reads the new ``pop_prob``.
+        None of them is persistent: the state dict is the reference's (``pop_prob``, ``table``)."""
+        dev = self.table.device
+        table, prob = self.table.detach().cpu(), self.pop_prob.detach().cpu()
+        # interleaved {table[i], pop_prob[i]} copy (binary-search fallbacks share cache lines with the probability)
+        self.register_buffer('table_prob', torch.stack([table, prob], 1).contiguous().to(dev), persistent=False)
+        guide = lut = lines = None
+        self.guide_log2 = self.lines_log2 = 0
+        if self._use_lines():
+            lines, self.lines_log2 = build_cdf_lines(table, prob, self._lines_log2_arg)
+        else:
+            guide, self.guide_log2 = build_guide_table(table, self._guide_log2_arg)
+            if self.lookup in ('auto', 'lut'):
+                # direct-lookup table, one self-contained 16-B entry per guide bucket (layout: rsa_common.hpp,
+                # cdf_lookup_lut): {lo | search bit, table[lo] or +inf, pop_prob[lo], pop_prob[lo+1]}
+                last = table.numel() - 1
+                lo = guide.to(torch.int64)
+                hi = torch.cat([lo[1:], lo[-1:]])
+                span = hi - lo
+                g0, g1 = lo.clamp(max=last), (lo + 1).clamp(max=last)
+                x = (lo - (span >= 2).to(torch.int64) * (1 << 31)).to(torch.int32)
+                y = torch.where(span == 0, torch.full_like(table[g0], float('inf')), table[g0])
+                lut = torch.stack([x.view(torch.float32), y, prob[g0], prob[g1]], 1).contiguous()
+        for name, t in (('guide', guide), ('cdf_lut', lut), ('cdf_lines', lines)):
+            self.register_buffer(name, None if t is None else t.to(dev), persistent=False)
 
     @classmethod
-    def from_tables(cls, pop_prob, table, guide_log2=None):
+    def from_tables(cls, pop_prob, table, guide_log2=None, lookup='auto', lines_log2=None):
         """Build from already-computed reference buffers (e.g. a loaded RecStudio checkpoint's
         ``sampler.pop_prob`` / ``sampler.table``) instead of recomputing them from counts."""
         self = cls.__new__(cls)
         Sampler.__init__(self, table.numel(), None)
+        self.lookup, self._guide_log2_arg, self._lines_log2_arg = lookup, guide_log2, lines_log2
         self.register_buffer('pop_prob', pop_prob.detach().clone().to(torch.float32))
         self.register_buffer('table', table.detach().clone().to(torch.float32))
-        guide, self.guide_log2 = build_guide_table(self.table, guide_log2)
-        self.register_buffer('guide', guide.to(self.table.device))
         self._register_pairs()
+        self.register_load_state_dict_post_hook(lambda module, incompatible: module._register_pairs())
         return self
+
+    def lookup_kwargs(self):
+        """The popularity tables as keyword arguments of ``ops.fused_forward`` / ``ops.sample_popular``."""
+        return dict(table=self.table, pop_prob=self.pop_prob, guide=self.guide, guide_log2=self.guide_log2,
+                    table_prob=getattr(self, 'table_prob', None), cdf_lut=getattr(self, 'cdf_lut', None),
+                    cdf_lines=getattr(self, 'cdf_lines', None), lines_log2=getattr(self, 'lines_log2', 0))
 
     def forward(self, query, num_neg, pos_items=None):
         with torch.no_grad():
             shape = tuple(query.shape[:-1])
             nq = int(np.prod(shape))
             neg, neg_prob = ops.sample_popular(self.table, self.pop_prob, self.guide, self.guide_log2, nq * num_neg,
-                                               cdf_lut=getattr(self, 'cdf_lut', None))
+                                               cdf_lut=getattr(self, 'cdf_lut', None),
+                                               cdf_lines=getattr(self, 'cdf_lines', None),
+                                               lines_log2=getattr(self, 'lines_log2', 0))
             neg = neg.view(*shape, num_neg)
             neg_prob = neg_prob.view(*shape, num_neg)
             if pos_items is not None:

@@ -80,8 +80,6 @@ class NormScorer(EuclideanScorer):
         self.p = p
 
     def forward(self, query, items):
-        if query.size(0) != items.size(0):
-            raise NotImplementedError('NormScorer over the full catalog is not implemented in this build')
         return -torch.sqrt(torch.clamp(-super().forward(query, items), min=0.0))
 
 
@@ -108,27 +106,39 @@ class GMFScorer(InnerProductScorer):
 
 
 class _FullScoreFn(torch.autograd.Function):
-    """[B, N] = query @ items.T with the fp32-MFMA kernel; the backward GEMMs are plain library
-    GEMMs (rocBLAS through torch.matmul)."""
+    """[B, N] scores of every query against every item with the fp32-MFMA kernel (inner product, or cosine /
+    Euclidean applied in the tile epilogue); the backward GEMMs of this MATERIALISED compatibility path are plain
+    library GEMMs (rocBLAS through torch.matmul) plus, for cosine / Euclidean, the chain rule of the norms."""
 
     @staticmethod
-    def forward(ctx, query, items):
-        ctx.save_for_backward(query, items)
-        return ops.fullscore(items, query, want_scores=True, items_without_pad=True)[0]
+    def forward(ctx, query, items, mode):
+        ctx.mode = mode
+        out = ops.fullscore(items, query, want_scores=True, items_without_pad=True, score_mode=mode)[0]
+        ctx.save_for_backward(query, items, out if mode == nat.SCORE_COS else None)
+        return out
 
     @staticmethod
     def backward(ctx, g):
-        query, items = ctx.saved_tensors
-        gq = g @ items if ctx.needs_input_grad[0] else None
-        gi = g.t() @ query if ctx.needs_input_grad[1] else None
-        return gq, gi
+        query, items, out = ctx.saved_tensors
+        need_q, need_i = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        if ctx.mode == nat.SCORE_IP:
+            return (g @ items if need_q else None), (g.t() @ query if need_i else None), None
+        if ctx.mode == nat.SCORE_EUC:        # s = 2 q.x - |x|^2 - |q|^2
+            gq = 2.0 * (g @ items - g.sum(1, keepdim=True) * query) if need_q else None
+            gi = 2.0 * (g.t() @ query - g.sum(0).unsqueeze(1) * items) if need_i else None
+            return gq, gi, None
+        # cosine: s = q.x / (|q||x|);  ds/dq = x / (|q||x|) - s q / |q|^2  (and symmetrically for x)
+        qn, xn = query.norm(dim=1, keepdim=True), items.norm(dim=1, keepdim=True)
+        gs = g * out
+        gq = ((g / xn.t()) @ items / qn - gs.sum(1, keepdim=True) * query / (qn * qn)) if need_q else None
+        gi = ((g / qn).t() @ query / xn - gs.sum(0).unsqueeze(1) * items / (xn * xn)) if need_i else None
+        return gq, gi, None
 
 
 def full_scores(query, items, cosine=False):
-    """([B,D],[N,D]) case of the scorers (scorer.py:16): items has no padding row here."""
-    if cosine:
-        raise NotImplementedError('Cosine / Euclidean scorers over the full catalog are not implemented in this build')
-    return _FullScoreFn.apply(query, items.contiguous())
+    """([B,D],[N,D]) case of the scorers (scorer.py:16, :19-25, :28-34): items has no padding row here."""
+    mode = int(cosine) if not isinstance(cosine, bool) else (nat.SCORE_COS if cosine else nat.SCORE_IP)
+    return _FullScoreFn.apply(query, items.contiguous(), mode)
 
 
 class _FullLseFn(torch.autograd.Function):

@@ -138,7 +138,76 @@ def test_popular_sampler_tables_equal_reference_buffers(golden):
         assert np.array_equal(ps.table.numpy(), g[f'm{mode}_table'])
         assert ps.num_items == len(g['counts']) - 1
         assert set(dict(ps.named_buffers())) == {'pop_prob', 'table', 'guide', 'table_prob', 'cdf_lut'}
-        assert set(ps.state_dict()) == {'pop_prob', 'table', 'guide'}
+        # the checkpoint is the reference's: exactly its two registered buffers (sampler.py:239-241)
+        assert set(ps.state_dict()) == {'pop_prob', 'table'}
+
+
+def lookup_with_lines(lines, g, table, prob, u):
+    """numpy restatement of rsa_common.hpp cdf_resolve_line (layout: include/recstudio_amd.h, cdf_lines)."""
+    K = 1 << g
+    b = np.clip((u * np.float32(K)).astype(np.int64), 0, K - 1)
+    li = lines.view(np.int32)
+    ids, pr = np.empty(u.shape, np.int64), np.empty(u.shape, np.float32)
+    n = len(table)
+    for i, (bb, uu) in enumerate(zip(b, u)):
+        c, k = li[bb, 0], int((lines[bb, 4:12] < uu).sum())
+        if k < 8 or c <= 8:
+            if k < c:
+                ids[i], pr[i] = li[bb, 12 + 2 * k], lines[bb, 13 + 2 * k]
+            else:
+                ids[i], pr[i] = li[bb, 1], lines[bb, 2]
+        else:
+            lo, hi = li[bb, 3], li[bb, 28]
+            while lo < hi:
+                mid = lo + ((hi - lo) >> 1)
+                if table[mid] < uu:
+                    lo = mid + 1
+                else:
+                    hi = mid
+            lo = min(lo, n - 1)
+            ids[i], pr[i] = lo, prob[lo]
+    return ids, pr
+
+
+def test_bucket_lines_return_searchsorted_index(golden):
+    """The bucket-line table (one 128-byte line per draw on the GPU) resolves to exactly torch.searchsorted's index
+    and that item's probability: reference fixture tables (edge uniforms included) and synthetic catalogs where half
+    the items have zero probability, with forced tiny tables so that the > 8-entries fallback is exercised."""
+    from recstudio_amd import PopularSamplerModel
+    g = golden('popular')
+    gen = torch.Generator().manual_seed(0)
+    cases = [(T(g['counts']), mode, glog, g[f'm{mode}_u']) for mode in (0, 1, 2) for glog in (None, 4)]
+    for n, mode, glog in ((2000, 0, None), (5000, 2, 4), (5000, 2, None), (300, 1, 6)):
+        cnt = (torch.rand(n, generator=gen) ** 6 * 500).long()
+        cnt[torch.rand(n, generator=gen) < 0.5] = 0
+        cases.append((cnt, mode, glog, np.zeros(0, np.float32)))
+    for cnt, mode, glog, u_fix in cases:
+        ps = PopularSamplerModel(cnt, mode=mode, lookup='lines', lines_log2=glog)
+        assert ps.guide is None and ps.cdf_lut is None and ps.cdf_lines.shape == (1 << ps.lines_log2, 32)
+        t, p = ps.table.numpy(), ps.pop_prob.numpy()
+        u = np.concatenate([u_fix, t, np.nextafter(t, np.float32(0)), np.nextafter(t, np.float32(2)),
+                            np.random.default_rng(mode).random(4000, dtype=np.float32),
+                            np.array([0.0, 1 - 2 ** -24], np.float32)]).astype(np.float32)
+        u = u[(u >= 0) & (u < 1)]
+        ids, pr = lookup_with_lines(ps.cdf_lines.numpy(), ps.lines_log2, t, p, u)
+        want = np.minimum(oracle.searchsorted_left(t, u), len(t) - 1)
+        assert np.array_equal(ids, want)
+        assert np.array_equal(pr, p[want])
+
+
+def test_popular_sampler_checkpoint_is_the_references(golden):
+    """state_dict holds the reference's two buffers only, loads strictly in both directions, and loading REBUILDS
+    the derived lookup structures (a stale table would sample one distribution and report another's log-probs)."""
+    from recstudio_amd import PopularSamplerModel
+    g = golden('popular')
+    a = PopularSamplerModel(T(g['counts']), mode=0)
+    b = PopularSamplerModel(torch.flip(T(g['counts']), [0]), mode=2, lookup='lines')
+    ref_like = {'pop_prob': a.pop_prob.clone(), 'table': a.table.clone()}      # what a RecStudio checkpoint holds
+    b.load_state_dict(ref_like, strict=True)
+    assert torch.equal(b.table, a.table) and torch.equal(b.table_prob[:, 0], a.table) and torch.equal(b.table_prob[:, 1], a.pop_prob)
+    fresh = PopularSamplerModel(T(g['counts']), mode=0, lookup='lines')
+    assert torch.equal(b.cdf_lines.view(torch.int32), fresh.cdf_lines.view(torch.int32)) and b.lines_log2 == fresh.lines_log2
+    a.load_state_dict(b.state_dict(), strict=True)
 
 
 def test_plugin_signatures_match_reference():

@@ -7,6 +7,7 @@ import re
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, 'include', 'recstudio_amd.h')
 
 
 @pytest.fixture(scope='module')
@@ -34,11 +35,12 @@ def test_header_symbols_all_exported(nat):
 
 def test_abi_version_and_error_channel(nat):
     lib = nat.lib()
-    assert lib.rsa_abi_version() == nat.ABI_VERSION == 2
+    assert lib.rsa_abi_version() == nat.ABI_VERSION == 3
+    assert lib.rsa_scratch_bytes() >= 256 + 4 * 2048
     # argument validation happens before any HIP call, so it can be exercised without a GPU
-    rc = lib.rsa_sample_uniform(None, 10, 1, 5, 0, 0, 256, None)
+    rc = lib.rsa_sample_uniform(None, 10, 1, 5, 0, 0, 256, 0, None)
     assert rc == -1 and b'neg_ids is null' in lib.rsa_last_error()
-    rc = lib.rsa_sample_uniform(ctypes.c_void_p(8), 10, 5, 5, 0, 0, 256, None)
+    rc = lib.rsa_sample_uniform(ctypes.c_void_p(8), 10, 5, 5, 0, 0, 256, 0, None)
     assert rc == -1 and b'empty range' in lib.rsa_last_error()
     a = nat.FusedArgs()
     a.dim, a.n_items, a.n_queries, a.num_neg, a.n_query_rows = 6, 10, 2, 1, 2
@@ -48,12 +50,39 @@ def test_abi_version_and_error_channel(nat):
         nat.check(-1, 'x')
 
 
-def test_struct_layout_matches_header(nat):
-    # natural alignment on LP64: 8-byte pointers/int64, 4-byte int32
-    assert ctypes.sizeof(nat.FusedArgs) == 8 * 3 + 8 * 2 + 8 + 8 * 2 + 16 + 16 + 8 + 8 * 3 + 8 * 5 + 8 + 8 + 8 * 4 + 8 + 8 + 8 + 8
-    assert nat.FusedArgs.seed.offset == 80 and nat.FusedArgs.table.offset == 104
-    assert ctypes.sizeof(nat.BackwardArgs) == 8 * 18
-    assert nat.BackwardArgs.query.offset == 24 and nat.BackwardArgs.item_grad.offset == 96
+def test_struct_layout_matches_header(nat, tmp_path):
+    """Field offsets of the ctypes mirrors == offsetof() in the C header, asked of the C compiler itself."""
+    import re
+    import shutil
+    import subprocess
+    hdr = open(HEADER).read()
+    prog = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{HEADER}"', 'int main(void) {']
+    fields = {}
+    for struct, cls in (('rsa_fused_args', nat.FusedArgs), ('rsa_backward_args', nat.BackwardArgs)):
+        body = hdr[hdr.index(f'typedef struct {struct} {{'):hdr.index(f'}} {struct};')]
+        body = re.sub(r'/\*.*?\*/', '', body, flags=re.S)
+        names = []
+        for decl in body.split('{', 1)[1].split(';'):
+            for part in decl.split(','):
+                m = re.search(r'(\w+)\s*$', part.strip())
+                if m and part.strip():
+                    names.append(m.group(1))
+        fields[struct] = names
+        assert names == [f[0] for f in cls._fields_], f'{struct}: field order differs from the header'
+        prog.append(f'  printf("{struct} %zu\\n", sizeof({struct}));')
+        prog += [f'  printf("{struct}.{n} %zu\\n", offsetof({struct}, {n}));' for n in names]
+    prog += ['  return 0;', '}']
+    if shutil.which('gcc') is None:
+        pytest.skip('no C compiler')
+    src = tmp_path / 'layout.c'
+    src.write_text('\n'.join(prog))
+    exe = tmp_path / 'layout'
+    subprocess.run(['gcc', '-std=c99', '-o', str(exe), str(src)], check=True)
+    out = dict(line.split() for line in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.splitlines())
+    for struct, cls in (('rsa_fused_args', nat.FusedArgs), ('rsa_backward_args', nat.BackwardArgs)):
+        assert ctypes.sizeof(cls) == int(out[struct])
+        for n in fields[struct]:
+            assert getattr(cls, n).offset == int(out[f'{struct}.{n}']), f'{struct}.{n}'
 
 
 def test_missing_library_fails_loudly(nat, monkeypatch):
