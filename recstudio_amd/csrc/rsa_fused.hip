@@ -24,10 +24,11 @@
 #define RSA_LUT_NT 0
 #endif
 #ifndef RSA_QG_BATCH
-#define RSA_QG_BATCH 8     // rows per load batch of the training forward (4 / 2 measured: same register count)
+#define RSA_QG_BATCH 4     // rows per load batch of the training forward (double-buffered when RSA_QG_PIPELINE)
 #endif
 #ifndef RSA_QG_PIPELINE
-#define RSA_QG_PIPELINE 0  // 1: double-buffered batches pinned by data dependences (A/B on the GPU before switching)
+#define RSA_QG_PIPELINE 1  // double-buffered batches pinned by data dependences: 120 VGPRs (4 waves/SIMD) instead of 171;
+                           // measured: the training forward costs +0-3 % over the plain one instead of +4-10 %
 #endif
 
 namespace rsa {
@@ -334,21 +335,27 @@ __device__ __forceinline__ float finish_score(int mode, float dot, float inorm2,
 #define RSA_SSM_BATCH 4     // double-buffered: 2 * 4 row loads in flight per wave, 141 VGPRs at d = 128 (8: 180)
 #endif
 #ifndef RSA_FWD_LINES_AHEAD
-#define RSA_FWD_LINES_AHEAD 1     // bucket line of a wave's next tile fetched one tile ahead (12 more VGPRs than the LUT form)
+#define RSA_FWD_LINES_AHEAD 0     // 1: bucket line of a wave's next tile fetched one tile ahead -- 12 more live VGPRs (128), measured 2-4 % SLOWER
 #endif
 
-// loss = mean of the per-query losses, in the SAME launch.  Every workgroup publishes the sum of its own waves'
-// losses (the unit -> wave assignment is static, so the partial is reproducible); the last workgroup to arrive adds
-// the partials in index order.  Saves two tiny launches per step (a quarter of the step at B = 4096).
-// Device-scope atomics only, no fences: a release/acquire fence here writes back / invalidates the whole XCD L2 on
-// every workgroup exit (measured: +90 us per launch).  The partial is published with a RETURNING exchange performed at
-// the memory side, and the arrival is counted only after that value has come back: the increment is made to depend on
-// it through an opaque asm, so neither the compiler nor the hardware can count the arrival before the partial is out.
+// loss = mean of the per-query losses, in the SAME launch, with ONE device-scope atomic per workgroup and no
+// second phase: every workgroup adds {its waves' loss sum as a 2^-30 fixed-point integer, 1 arrival} to one 64-bit
+// word (bits 0..49 sum, bits 50..63 arrivals); integer addition is associative, so the total is bit-reproducible
+// whatever the arrival order.  The workgroup whose add returns gridDim.x - 1 earlier arrivals holds the complete sum
+// (returned value + its own share), writes the mean and resets the word.  A NaN / inf partial (SampledSoftmax with a
+// padded positive, loss_func.py:88-89) first sets a sticky flag word with a RETURNING atomic and only then arrives
+// (the arrival is made to depend on the returned value), and the last workgroup reads the flags through a pointer
+// that depends on its own returned arrival count -- so the flag is visible whenever the arrival is.  No fences: a
+// release / acquire pair at workgroup exit writes back / invalidates the whole XCD L2 (measured: +90 us per launch);
+// the first version exchanged float partials and counted arrivals with a second, dependent atomic -- two memory
+// round trips in every workgroup's tail, 7.5 us of a 43 us launch at B = 4096.
+// Range: |partial| < 2^19 at 2^-30 resolution (a batch of 10^5 queries with row losses up to ~5); beyond that the
+// result saturates to +inf through the flag word.  Totals must be >= 0 (every loss on this path is).
+constexpr int LOSS_FRAC_BITS = 30, LOSS_COUNT_SHIFT = 50;
 __device__ __forceinline__ void reduce_mean_loss(float wave_loss, float* __restrict__ loss_out,
-                                                 unsigned int* __restrict__ done_counter,
+                                                 unsigned int* __restrict__ flag_word,
                                                  float* __restrict__ loss_partials, int64_t n_queries) {
-  __shared__ int s_last;
-  __shared__ float s_red[256];
+  __shared__ float s_red[16];
   const int lane = lane_id();
   const int wave = threadIdx.x >> 6;
   if (lane == 0) s_red[wave] = wave_loss;
@@ -356,29 +363,33 @@ __device__ __forceinline__ void reduce_mean_loss(float wave_loss, float* __restr
   if (threadIdx.x == 0) {
     float part = 0.f;
     for (int w = 0; w < (int)(blockDim.x >> 6); ++w) part += s_red[w];
-    const float prev = __hip_atomic_exchange(loss_partials + blockIdx.x, part, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    unsigned one = 1u;
-    asm volatile("; arrival waits for the partial" : "+v"(one) : "v"(prev));
-    const unsigned arrived = __hip_atomic_fetch_add(done_counter, one, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    s_last = arrived == gridDim.x - 1;
-    if (s_last) __hip_atomic_store(done_counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // reset
-  }
-  __syncthreads();
-  if (s_last) {
-    float acc = 0.f;
-    for (unsigned i = threadIdx.x; i < gridDim.x; i += 256)
-      acc += __hip_atomic_load(loss_partials + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
-    s_red[threadIdx.x] = acc;
-    __syncthreads();
-#pragma unroll
-    for (int w = 128; w >= 1; w >>= 1) {
-      if ((int)threadIdx.x < w) s_red[threadIdx.x] += s_red[threadIdx.x + w];
-      __syncthreads();
+    unsigned long long* word = reinterpret_cast<unsigned long long*>(loss_partials);     // 8-byte aligned (offset 256)
+    const bool bad = !(fabsf(part) < 524288.f);          // NaN, inf or out of the fixed-point range
+    const long long fixed = bad ? 0ll : __double2ll_rn((double)part * (double)(1ll << LOSS_FRAC_BITS));
+    unsigned long long add = ((unsigned long long)fixed & ((1ull << LOSS_COUNT_SHIFT) - 1)) + (1ull << LOSS_COUNT_SHIFT);
+    if (bad) {
+      const unsigned int old = __hip_atomic_fetch_or(flag_word, part != part ? 1u : 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("; the arrival waits for the flag" : "+v"(add) : "v"(old));
     }
-    if (threadIdx.x == 0) loss_out[0] = s_red[0] / (float)n_queries;
+    const unsigned long long prev = __hip_atomic_fetch_add(word, add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((prev >> LOSS_COUNT_SHIFT) == (unsigned long long)(gridDim.x - 1)) {
+      const unsigned long long total = (prev + add) & ((1ull << LOSS_COUNT_SHIFT) - 1);
+      float loss = (float)((double)total / (double)(1ll << LOSS_FRAC_BITS) / (double)n_queries);
+      unsigned int* fw = flag_word;
+      asm volatile("; the flags are read after the last arrival" : "+v"(fw) : "v"(prev));
+      const unsigned int flags = __hip_atomic_load(fw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (flags & 1u) loss = NAN;
+      else if (flags & 2u) loss = INFINITY;
+      loss_out[0] = loss;
+      __hip_atomic_store(word, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // leave the scratch zeroed
+      if (flags) __hip_atomic_store(fw, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
 }
+
+#ifndef RSA_FWD_GRID_CAP
+#define RSA_FWD_GRID_CAP (256 * 8)
+#endif
 template <int LPR, bool GENERIC, bool COS, bool QU, bool NT, bool QG = false>
 __global__ __launch_bounds__(256, QG ? RSA_QG_MIN_WAVES : RSA_FWD_MIN_WAVES) void fused_fwd_kernel(const FwdParams p) {
   using F = Frag<LPR, GENERIC>;

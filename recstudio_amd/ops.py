@@ -311,15 +311,15 @@ def fused_forward(item_table, query, num_neg, *, query_index=None, pos_ids=None,
     a.table_prob = ptr(_need_opt(table_prob, torch.float32, 'table_prob'))
     a.cdf_lut = ptr(_need_opt(cdf_lut, torch.float32, 'cdf_lut'))
     a.cdf_lines, a.lines_log2 = ptr(_need_opt(cdf_lines, torch.float32, 'cdf_lines')), int(lines_log2)
-    if sampler == nat.SAMPLER_GIVEN and (pos_logp is not None or neg_logp is not None):
+    if fused_loss is None and fused_bpr:
+        fused_loss = 'bpr'
+    if sampler == nat.SAMPLER_GIVEN and fused_loss == 'ssm' and (pos_logp is not None or neg_logp is not None):
         # ids given: the log-probabilities are INPUTS of the SampledSoftmax epilogue
         a.neg_logp, a.pos_logp = ptr(_need_opt(neg_logp, torch.float32, 'neg_logp')), ptr(_need_opt(pos_logp, torch.float32, 'pos_logp'))
         a.neg_ids = ptr(neg_ids)
     else:
         a.neg_ids, a.neg_logp, a.pos_logp = ptr(neg_ids), ptr(out.get('neg_logp')), ptr(out.get('pos_logp'))
     a.pos_score, a.neg_score = ptr(out.get('pos_score')), ptr(out['neg_score'])
-    if fused_loss is None and fused_bpr:
-        fused_loss = 'bpr'
     if fused_loss is not None:
         if fused_loss not in ('bpr', 'ssm'):
             raise ValueError("fused_loss must be None, 'bpr' or 'ssm'")

@@ -14,6 +14,16 @@ rows [r*rows_per_shard, (r+1)*rows_per_shard) and B queries per step.  Per step:
 comparable: its only multi-device mode re-broadcasts every parameter each step
 (recstudio/utils/data_parallel.py:106-159) and DDP is dead code (recommender.py:731-740).
 
+No host round trip in the step (``exchange='fixed'``, the default): every owner gets a fixed-capacity segment of
+the key buffer, unused slots carry key -1 through an EQUAL-split all-to-all and are skipped by every consumer, so
+the split sizes never have to be read back; the capacity comes from one calibration step (exact counts, max over
+ranks, plus slack) and a sticky device-side overflow counter is checked off the critical path
+(``check_overflow``).  ``exchange='exact'`` is the variable-split form (counts exchanged and read back each step).
+
+G-invariant negatives: all ranks draw from ONE Philox stream (``sample_generator``, same seed everywhere) by global
+element index -- rank r owns rows [r*B, (r+1)*B) of a virtual [G*B, n] id tensor (``rng.sharded_stream``) -- so a
+run's negatives do not depend on the number of GPUs.
+
 All device work goes through ``backend`` (default: the HIP kernels).  The protocol itself --
 split sizes, exchange order, reassembly -- is backend-agnostic so that the world_size-2 ``gloo``
 tests can drive it on CPU with a checker backend supplied BY THE TEST; this module contains no
@@ -25,6 +35,7 @@ import torch
 
 from . import _native as nat
 from . import ops
+from . import rng
 from ._native import ptr
 
 
@@ -46,10 +57,39 @@ class RowShardPlan:
 class HipBackend:
     """Device work of the sharded step, all through the C ABI."""
 
-    def sample(self, sampler, n_queries, n, device, pos_ids):
-        # the stand-alone Sampler plugin: (log_pos_prob, neg_ids, log_neg_prob)
+    def make_generator(self, seed, device):
+        return torch.Generator(device=device).manual_seed(int(seed))
+
+    def sample(self, sampler, n_queries, n, device, pos_ids, shard=None):
+        """The stand-alone Sampler plugin: (log_pos_prob, neg_ids, log_neg_prob).  ``shard = (rank, world, generator)``:
+        this rank's rows of ONE global draw (rng.sharded_stream)."""
         q = torch.empty(n_queries, 1, device=device)
-        return sampler(q, n, pos_ids)
+        if shard is None:
+            return sampler(q, n, pos_ids)
+        with rng.sharded_stream(*shard):
+            return sampler(q, n, pos_ids)
+
+    def new_flag(self, device):
+        return torch.zeros(1, dtype=torch.int32, device=device)
+
+    def flag_read_async(self, flag):
+        """Start copying the overflow word to the host; returns poll() -> None while in flight, else the value."""
+        host = torch.empty(1, dtype=torch.int32).pin_memory()
+        host.copy_(flag, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        return lambda: int(host[0]) if ev.query() else None
+
+    def route_fixed(self, pos, neg, plan, query_base, capacity, overflow):
+        B, n = neg.shape
+        slots = plan.world * int(capacity)
+        keys = torch.empty(slots, dtype=torch.int64, device=pos.device)
+        positions = torch.empty(slots, dtype=torch.int64, device=pos.device)
+        cursor = torch.empty(plan.world, dtype=torch.int32, device=pos.device)
+        nat.check(nat.lib().rsa_shard_route_fixed(ptr(pos), ptr(neg), B, n, plan.rows_per_shard, plan.world, int(query_base),
+                                                  int(capacity), ptr(cursor), ptr(keys), ptr(positions), ptr(overflow),
+                                                  ops._stream()), 'rsa_shard_route_fixed')
+        return keys, positions
 
     def gather_rows(self, table, ids):
         return ops.embedding_gather(table, ids)
@@ -105,6 +145,7 @@ class HipBackend:
             return
         if item_scale is not None:
             raise NotImplementedError('in-place item update needs embed_dim in {64, 128, 256}')
+        rows, qidx = rows.clamp_(min=0), qidx.clamp_(min=0)      # empty slots (d = 0 there): any valid row
         ops.fused_backward(item_local, q_all, rows.view(m, 1), dscore.view(m, 1), query_index=qidx,
                            dense_item_grad=False, want_query_grad=False, item_grad_out=item_grad_local,
                            query_table_grad=qgrad_all, query_table_pad_row=-1, item_pad_row=item_pad_row)
@@ -128,13 +169,21 @@ class HipBackend:
 
 
 class ShardedItemTable:
-    def __init__(self, item_local, plan, rank, dist, backend=None, group=None):
+    def __init__(self, item_local, plan, rank, dist, backend=None, group=None, exchange='fixed', slack=1.08,
+                 margin=4096, check_every=64, sample_seed=2022):
         self.item_local, self.plan, self.rank, self.dist = item_local, plan, int(rank), dist
         self.backend = backend if backend is not None else HipBackend()
         self.group = group
+        if exchange not in ('fixed', 'exact'):
+            raise ValueError("exchange must be 'fixed' or 'exact'")
+        self.exchange, self.slack, self.margin, self.check_every = exchange, float(slack), int(margin), int(check_every)
+        self._cap, self._steps, self._poll = {}, 0, None
+        self._overflow = self.backend.new_flag(item_local.device)
+        # ONE sampler stream for the whole job: same seed on every rank, advanced in lock-step (see module docstring)
+        self.sample_generator = self.backend.make_generator(sample_seed, item_local.device)
         # the query all-gather runs on its OWN communicator: collectives of one communicator execute in issue
-        # order on one stream, so on the main group the small count / key exchanges (and the host read-back of
-        # the counts) would queue behind the 33.5 MB-per-rank gather instead of overlapping with it
+        # order on one stream, so on the main group the key / score exchanges would queue behind the (at n = 64)
+        # much larger gather instead of overlapping with it
         self.gather_group = dist.new_group() if (group is None and plan.world > 1) else group
         lo, hi = plan.bounds(rank)
         if item_local.shape[0] != hi - lo:
@@ -148,7 +197,7 @@ class ShardedItemTable:
         """Start the all-gather of the query block on the communicator's own stream and return a function
         that waits for it.  At B = 65536 queries/GPU the block is 33.5 MB per rank -- the largest message of
         the step (7 x 33.5 MB arrive per GPU over xGMI, vs 8 + 4 bytes per triplet for keys and scores) -- and
-        nothing before the owner-side scoring needs it, so it flies under sampling, counting and routing."""
+        nothing before the owner-side scoring needs it, so it flies under sampling and routing."""
         out = torch.empty(self.plan.world * x.shape[0], *x.shape[1:], dtype=x.dtype, device=x.device)
         x = x.contiguous()
         work = self.dist.all_gather_into_tensor(out, x, group=self.gather_group, async_op=True)
@@ -165,18 +214,60 @@ class ShardedItemTable:
         self.dist.all_to_all_single(recv, send, group=self.group)
         return [int(v) for v in send.tolist()], [int(v) for v in recv.tolist()]
 
-    def _all_to_all(self, x, recv_counts, send_counts):
+    def _all_to_all(self, x, recv_counts=None, send_counts=None):
+        """Variable split (host lists) or, with no counts, the equal split of the fixed-capacity exchange."""
+        if recv_counts is None:
+            out = torch.empty_like(x)
+            self.dist.all_to_all_single(out, x, group=self.group)
+            return out
         out = torch.empty(sum(recv_counts), dtype=x.dtype, device=x.device)
         self.dist.all_to_all_single(out, x, output_split_sizes=recv_counts, input_split_sizes=send_counts,
                                     group=self.group)
         return out
 
-    # -- the step ---------------------------------------------------------------------------------
     def _reduce_scatter_rows(self, x, rows_per_rank):
         out = torch.empty(rows_per_rank, *x.shape[1:], dtype=x.dtype, device=x.device)
         self.dist.reduce_scatter_tensor(out, x.contiguous(), group=self.group)
         return out
 
+    # -- fixed-capacity bookkeeping -------------------------------------------------------------------
+    def _calibrate(self, key, send_counts):
+        """Capacity of one owner segment from an exact step: the largest per-owner count of ANY rank (so that every
+        rank uses the same equal split) plus slack.  One small all-reduce + read-back, on the calibration step only."""
+        B, n = key
+        m = torch.tensor([max(send_counts)], dtype=torch.int64, device=self.item_local.device)
+        self.dist.all_reduce(m, op=self.dist.ReduceOp.MAX, group=self.group)
+        cap = int(int(m.item()) * self.slack) + self.margin
+        cap = min(B * (n + 1), (cap + 255) // 256 * 256)
+        self._cap[key] = max(cap, 1)
+
+    def check_overflow(self, block=True):
+        """Raise if any routed element ever found its owner's segment full (its score was lost).  ``block=False``:
+        only look at a read-back that has already completed (the per-step use: no stall)."""
+        if block:
+            self._poll = self._poll or self.backend.flag_read_async(self._overflow)
+            v = self._poll()
+            while v is None:
+                v = self._poll()
+        else:
+            v = self._poll() if self._poll is not None else None
+            if v is None:
+                return
+        self._poll = None
+        if v:
+            self._cap.clear()               # recalibrate on the next step
+            self._overflow.zero_()
+            raise RuntimeError(f'sharded exchange: {v} elements did not fit their owner segment (capacity slack '
+                               f'{self.slack}); the affected steps are invalid -- raise `slack` / `margin` or use '
+                               "exchange='exact' for id distributions that drift this fast")
+
+    def _after_fixed_step(self):
+        self._steps += 1
+        self.check_overflow(block=False)
+        if self._poll is None and self._steps % self.check_every == 0:
+            self._poll = self.backend.flag_read_async(self._overflow)
+
+    # -- the step ---------------------------------------------------------------------------------
     def backward(self, route, dpos, dneg, item_grad_local, item_scale=None):
         """Gradient exchange for one step.  ``route`` comes from
         ``score_ids(..., keep_route=True)``; ``dpos [B]`` / ``dneg [B, n]`` = d loss / d score on the home
@@ -185,8 +276,8 @@ class ShardedItemTable:
         (reduce-scatter of the per-owner partial sums)."""
         B = route['B']
         dflat = torch.cat([dpos.reshape(-1), dneg.reshape(-1)])
-        d_sorted = self.backend.gather(dflat, route['positions'])
-        d_owner = self._all_to_all(d_sorted, route['recv_counts'], route['send_counts'])
+        d_sorted = self.backend.gather(dflat, route['positions'])           # empty slots: 0
+        d_owner = self._all_to_all(d_sorted, route.get('recv_counts'), route.get('send_counts'))
         q_all = route['q_all']
         qgrad_all = torch.zeros_like(q_all)
         # only shard 0 holds the global padding row (item id 0), which never receives gradient
@@ -202,27 +293,46 @@ class ShardedItemTable:
         plan = self.plan
         if q_gather is None:
             q_gather = self._all_gather_rows_start(q)
-        counts = self.backend.count(pos, neg, plan)
-        send_counts, recv_counts = self._exchange_counts(counts)
-        starts = torch.tensor([0] + send_counts[:-1], dtype=torch.int64).cumsum(0)
-        keys, positions = self.backend.route(pos, neg, plan, self.rank * B, starts)
-        recv_keys = self._all_to_all(keys, recv_counts, send_counts)
+        cap = self._cap.get((B, n)) if self.exchange == 'fixed' else None
+        route = {'B': B, 'n': n}
+        if cap is None:
+            # exact split sizes: owner histogram, count exchange, host read-back (every step with exchange='exact',
+            # the calibration step otherwise)
+            counts = self.backend.count(pos, neg, plan)
+            send_counts, recv_counts = self._exchange_counts(counts)
+            starts = torch.tensor([0] + send_counts[:-1], dtype=torch.int64).cumsum(0)
+            keys, positions = self.backend.route(pos, neg, plan, self.rank * B, starts)
+            recv_keys = self._all_to_all(keys, recv_counts, send_counts)
+            route.update(send_counts=send_counts, recv_counts=recv_counts)
+            if self.exchange == 'fixed':
+                self._calibrate((B, n), send_counts)
+            back = (send_counts, recv_counts)
+        else:
+            keys, positions = self.backend.route_fixed(pos, neg, plan, self.rank * B, cap, self._overflow)
+            recv_keys = self._all_to_all(keys)
+            back = (None, None)
         q_all = q_gather()
         scores_owner = self.backend.score_keys(self.item_local, q_all, recv_keys)
-        scores_home = self._all_to_all(scores_owner, send_counts, recv_counts)
+        scores_home = self._all_to_all(scores_owner, *back)
         flat = self.backend.scatter(scores_home, positions, B * (n + 1))
+        if cap is not None:
+            self._after_fixed_step()
         if keep_route:
-            route = {'B': B, 'n': n, 'q_all': q_all, 'positions': positions, 'recv_keys': recv_keys,
-                     'send_counts': send_counts, 'recv_counts': recv_counts}
+            route.update(q_all=q_all, positions=positions, recv_keys=recv_keys)
             return flat[:B], flat[B:].view(B, n), route
         return flat[:B], flat[B:].view(B, n)
+
+    def sample(self, sampler, n_queries, n, device, pos):
+        """(log_pos_prob, neg_ids, log_neg_prob) for this rank's queries: its rows of the job-wide draw."""
+        return self.backend.sample(sampler, n_queries, n, device, pos,
+                                   shard=(self.rank, self.plan.world, self.sample_generator))
 
     def sample_and_score(self, user_table, uid, pos, n, sampler, keep_route=False):
         """BaseRetriever.forward for a user-embedding query tower against the sharded item table."""
         B = uid.numel()
         q = self.backend.gather_rows(user_table, uid)
         q_gather = self._all_gather_rows_start(q)
-        log_pos, neg, log_neg = self.backend.sample(sampler, B, n, uid.device, pos)
+        log_pos, neg, log_neg = self.sample(sampler, B, n, uid.device, pos)
         res = self.score_ids(q, pos, neg, keep_route, q_gather)
         out = {'pos_score': res[0], 'neg_score': res[1], 'neg_ids': neg, 'log_pos_prob': log_pos,
                'log_neg_prob': log_neg, 'query': q}
@@ -350,7 +460,7 @@ class ShardedRetriever:
         table, world = self.table, self.table.plan.world
         q = self.query_encoder(query_feat)
         B = pos_items.numel()
-        log_pos, neg, log_neg = table.backend.sample(self.sampler, B, self.neg_count, q.device, pos_items)
+        log_pos, neg, log_neg = table.sample(self.sampler, B, self.neg_count, q.device, pos_items)
         pos_score, neg_score = sharded_scores(table, q, pos_items, neg, self.item_grad_local, self.item_scale)
         loss = self.loss_fn(label, pos_score, log_pos, neg_score, log_neg) / world
         loss.backward()

@@ -51,6 +51,21 @@ def test_device_stream_matches_torch_randint(ra, numel, high, seed):
     g = philox.rng_grid_threads(numel, cu, mt)
     rest = philox.device_randint(seed, off0, numel, 1, high, g)
     assert np.array_equal(rest, want.cpu().numpy())  # oracle restatement == torch == kernel
+    # G ranks drawing their row blocks of the same global call (elem_base): identical ids, identical generator advance
+    for world in (2, 8):
+        per = numel // world
+        if per == 0:
+            continue
+        torch.manual_seed(seed)
+        want_g = torch.randint(1, high, (per * world,), device=DEV)
+        off_g = gen.get_offset()
+        parts = []
+        for r in range(world):
+            torch.manual_seed(seed)
+            with ra.rng.sharded_stream(r, world, None):
+                parts.append(ra.ops.sample_uniform(per, 1, high, DEV))
+            assert gen.get_offset() == off_g
+        assert torch.equal(torch.cat(parts), want_g)
 
 
 @pytest.mark.parametrize('numel,seed', [(3, 2022), (4096 * 64, 1), (2048 * 256 * 4 + 3, 2)])
@@ -66,6 +81,18 @@ def test_device_stream_matches_torch_rand(ra, golden, numel, seed):
     torch.manual_seed(seed)
     ids, logp, u = ra.ops.sample_popular(ps.table, ps.pop_prob, ps.guide, ps.guide_log2, numel, want_u=True)
     assert gen.get_offset() == off_torch
+    # G-invariant form: G ranks drawing their slices of ONE global call (rng.sharded_stream) == the single call
+    for world in (2, 8):
+        per = numel // world
+        if per == 0:
+            continue
+        parts = []
+        for r in range(world):
+            torch.manual_seed(seed)
+            with ra.rng.sharded_stream(r, world, None):
+                parts.append(ra.ops.sample_popular(ps.table, ps.pop_prob, ps.guide, ps.guide_log2, per)[0])
+            assert gen.get_offset() == off0 + ra.rng.counter_offset(per * world, ra.rng.grid_threads(per * world, *props(ra)), 4)
+        assert torch.equal(torch.cat(parts), want_ids_of(ps, seed, per * world))
     assert torch.equal(u, want_u)
     assert torch.equal(ids, want_ids)
     cu, mt = props(ra)
@@ -75,6 +102,11 @@ def test_device_stream_matches_torch_rand(ra, golden, numel, seed):
 
 
 # --------------------------------------------------------------------------- popularity sampler
+def want_ids_of(ps, seed, numel):
+    torch.manual_seed(seed)
+    return torch.searchsorted(ps.table, torch.rand(numel, device=DEV)).clamp_(max=ps.table.numel() - 1)
+
+
 def test_popular_lookup_golden(ra, golden):
     """ids / log-probs for the reference's own (pop_prob, table) buffers and recorded uniforms.
     (The buffers themselves come out of torch CPU ops whose last bit depends on the host's SIMD
@@ -95,7 +127,7 @@ def test_popular_lookup_golden(ra, golden):
                 assert np.array_equal(ids.cpu().numpy(), want)
                 rel_close(logp.cpu(), g[f'm{mode}_logp'], rtol=1e-6, atol=1e-7)
     # larger table: ids from this host's build of the table == torch.searchsorted on the same table
-    ps = ra.PopularSamplerModel(T(g['big_counts']), mode=0)
+    ps = ra.PopularSamplerModel(T(g['big_counts']), mode=0, lookup='lut')
     rel_close(ps.table[-64:].numpy(), g['big_table_tail'], rtol=2e-6, atol=0)
     u = T(g['big_u'])
     want = torch.searchsorted(ps.table, u).clamp_(max=ps.table.numel() - 1)

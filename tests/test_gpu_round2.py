@@ -1,0 +1,374 @@
+"""GPU parity tests (``-m gpu``) of the round-2 additions: the bucket-line inverse CDF, the SampledSoftmax epilogue of
+the fused forward (with the in-forward query gradient), cosine / Euclidean scores over the full catalog, the composed
+full-score shapes (embed_dim > 128, k > 1024), the device guard -- each against the CPU oracle (oracle/), the committed
+reference fixtures (tests/golden) or torch's own device ops."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+T = torch.from_numpy
+DEV = 'cuda'
+
+
+@pytest.fixture(scope='module')
+def ra():
+    import recstudio_amd
+    recstudio_amd._native.lib()          # fail loudly if the HIP extension is not there
+    assert torch.cuda.is_available()
+    torch.cuda.init()
+    return recstudio_amd
+
+
+def rel_close(a, b, rtol=1e-4, atol=1e-6):
+    np.testing.assert_allclose(np.asarray(a), np.asarray(b), rtol=rtol, atol=atol)
+
+
+def _tables(N, U, d, seed):
+    g = torch.Generator().manual_seed(seed)
+    iw = torch.randn(N, d, generator=g) * 0.3
+    iw[0] = 0
+    uw = torch.randn(U, d, generator=g) * 0.3
+    return iw, uw
+
+
+# --------------------------------------------------------------------------- bucket lines
+def test_bucket_lines_golden_and_searchsorted(ra, golden):
+    """cdf_lines lookup == the reference fixture ids (edge uniforms included), at the automatic size and at tiny
+    forced sizes where most draws take the > 8-entries fallback; and == torch.searchsorted on dense random uniforms
+    of a 120 000-item table."""
+    g = golden('popular')
+    for mode in (0, 1, 2):
+        want = np.minimum(g[f'm{mode}_ids'], len(g['counts']) - 1)
+        for glog in (None, 2, 4, 7, 12, 20):
+            ps = ra.PopularSamplerModel.from_tables(T(g[f'm{mode}_pop_prob']), T(g[f'm{mode}_table']), lookup='lines',
+                                                    lines_log2=glog).to(DEV)
+            assert ps.cdf_lines.data_ptr() % 128 == 0
+            ids, logp = ra.ops.popular_lookup(ps.table, ps.pop_prob, None, 0, T(g[f'm{mode}_u']).to(DEV),
+                                              cdf_lines=ps.cdf_lines, lines_log2=ps.lines_log2)
+            assert np.array_equal(ids.cpu().numpy(), want)
+            rel_close(logp.cpu(), g[f'm{mode}_logp'], rtol=1e-6, atol=1e-7)
+    big = ra.PopularSamplerModel(T(g['big_counts']), mode=0, lookup='lines').to(DEV)
+    torch.manual_seed(5)
+    uu = torch.rand(300_000, device=DEV)
+    want = torch.searchsorted(big.table, uu).clamp_(max=big.table.numel() - 1)
+    for glog in (None, 8):
+        ps = big if glog is None else ra.PopularSamplerModel(T(g['big_counts']), mode=0, lookup='lines', lines_log2=glog).to(DEV)
+        ids, logp = ra.ops.popular_lookup(ps.table, ps.pop_prob, None, 0, uu, cdf_lines=ps.cdf_lines, lines_log2=ps.lines_log2)
+        assert torch.equal(ids, want)
+        rel_close(logp.cpu(), torch.log(ps.pop_prob[want]).cpu(), rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize('n,B', [(64, 100), (256, 9), (100, 33), (1, 300)])
+@pytest.mark.parametrize('glog', [None, 6])
+def test_fused_forward_sampled_with_bucket_lines(ra, n, B, glog):
+    """The fused kernel with cdf_lines draws what torch.rand + torch.searchsorted draw on this device for the same
+    seed (one-tile-ahead prefetch for n % 64 == 0, plain lookup otherwise; BPR epilogue with and without the
+    in-forward query gradient), and reports log(pop_prob[id])."""
+    N, U, d = 50_021, 211, 128
+    iw, uw = _tables(N, U, d, n)
+    g = torch.Generator().manual_seed(n + B)
+    counts = (torch.rand(N, generator=g) ** 5 * 300).long()
+    counts[torch.rand(N, generator=g) < 0.4] = 0
+    ps = ra.PopularSamplerModel(counts, lookup='lines', lines_log2=glog).to(DEV)
+    uid = torch.randint(1, U, (B,), generator=g).to(DEV)
+    pos = torch.randint(1, N, (B,), generator=g).to(DEV)
+    iwd, uwd = iw.to(DEV), uw.to(DEV)
+    torch.manual_seed(11)
+    want = torch.searchsorted(ps.table, torch.rand(B, n, device=DEV)).clamp_(max=N - 1)
+    variants = [dict()]
+    if n % 64 == 0:
+        variants += [dict(fused_bpr=True), dict(fused_bpr=True, want_query_grad=True), dict(fused_loss='ssm'),
+                     dict(fused_loss='ssm', want_query_grad=True)]
+    for kw in variants:
+        torch.manual_seed(11)
+        o = ra.ops.fused_forward(iwd, uwd, n, query_index=uid, pos_ids=pos, sampler=ra._native.SAMPLER_POPULAR,
+                                 **ps.lookup_kwargs(), **kw)
+        assert torch.equal(o['neg_ids'], want), kw
+        rel_close(o['neg_logp'].cpu(), torch.log(ps.pop_prob[want]).cpu(), rtol=1e-6, atol=1e-7)
+        ref = (uwd[uid].unsqueeze(1) * iwd[want]).sum(-1)
+        rel_close(o['neg_score'].cpu(), ref.cpu(), rtol=1e-4, atol=1e-5)
+    # the Sampler plugin on its own draws the same stream
+    torch.manual_seed(11)
+    lp, ids, lnp = ps(torch.empty(B, 1, device=DEV), n, pos)
+    assert torch.equal(ids, want)
+    rel_close(lp.cpu(), torch.log(ps.pop_prob[pos]).cpu(), rtol=1e-6, atol=1e-7)
+
+
+# --------------------------------------------------------------------------- SampledSoftmax epilogue
+@pytest.mark.parametrize('d', [32, 64, 128, 256])
+@pytest.mark.parametrize('n', [64, 256, 1024])
+@pytest.mark.parametrize('kind', ['given', 'given_logp', 'uniform', 'popular'])
+def test_fused_ssm_epilogue_vs_oracle(ra, d, n, kind):
+    """fused_loss = 'ssm' (one launch: scores, logsumexp across the n / 64 tiles of a query, loss, d loss/d score,
+    d loss/d query) == oracle.sampled_softmax_loss + autograd on the same ids, == the separate loss kernel."""
+    if n == 1024 and d in (32, 256):
+        pytest.skip('covered by the other dims')
+    N, U, B = 3001, 97, 37
+    iw, uw = _tables(N, U, d, n + d)
+    g = torch.Generator().manual_seed(d + n)
+    uid = torch.randint(1, U, (B,), generator=g)
+    pos = torch.randint(1, N, (B,), generator=g)
+    counts = (torch.rand(N, generator=g) ** 3 * 100).long()
+    nat = ra._native
+    kw, lpp, lnp = {}, None, None
+    if kind.startswith('given'):
+        kw = dict(neg_ids=torch.randint(0, N, (B, n), generator=g).to(DEV))
+        if kind == 'given_logp':
+            lpp = -torch.rand(B, generator=g) * 9
+            lnp = -torch.rand(B, n, generator=g) * 9
+            kw.update(pos_logp=lpp.to(DEV), neg_logp=lnp.to(DEV))
+    elif kind == 'uniform':
+        kw = dict(sampler=nat.SAMPLER_UNIFORM)
+    else:
+        ps = ra.PopularSamplerModel(counts, lookup='lines' if n == 256 else 'auto').to(DEV)
+        kw = dict(sampler=nat.SAMPLER_POPULAR, **ps.lookup_kwargs())
+    iwd, uwd = iw.to(DEV), uw.to(DEV)
+    torch.manual_seed(21)
+    a = ra.ops.fused_forward(iwd, uwd, n, query_index=uid.to(DEV), pos_ids=pos.to(DEV), fused_loss='ssm',
+                             want_query_grad=True, **kw)
+    torch.manual_seed(21)
+    b = ra.ops.fused_forward(iwd, uwd, n, query_index=uid.to(DEV), pos_ids=pos.to(DEV), fused_loss='ssm', **kw)
+    torch.manual_seed(21)
+    c = ra.ops.fused_forward(iwd, uwd, n, query_index=uid.to(DEV), pos_ids=pos.to(DEV), **kw)      # no epilogue
+    ids = a['neg_ids']
+    assert torch.equal(ids, b['neg_ids']) and torch.equal(ids, c['neg_ids'])
+    if kind == 'popular':
+        lpp, lnp = c['pos_logp'].cpu(), c['neg_logp'].cpu()
+        rel_close(a['neg_logp'].cpu(), lnp, rtol=1e-6, atol=1e-7)
+        rel_close(a['pos_logp'].cpu(), lpp, rtol=1e-6, atol=1e-7)
+    # oracle: value + autograd w.r.t. the scores and the query
+    q = uw[uid].clone().requires_grad_(True)
+    psr = (q * iw[pos]).sum(-1)
+    nsr = (q.unsqueeze(1) * iw[ids.cpu()]).sum(-1)
+    psr.retain_grad()
+    nsr.retain_grad()
+    zero_p, zero_n = torch.zeros(B), torch.zeros(B, n)
+    val = oracle.sampled_softmax_loss(psr, lpp if lpp is not None else zero_p, nsr, lnp if lnp is not None else zero_n)
+    val.backward()
+    for o in (a, b):
+        rel_close(o['loss'].cpu(), val.detach(), rtol=1e-5)
+        rel_close(o['neg_score'].cpu(), nsr.detach(), rtol=1e-4, atol=1e-5)
+        rel_close(o['pos_score'].cpu(), psr.detach(), rtol=1e-4, atol=1e-5)
+        rel_close(o['dneg'].cpu(), nsr.grad, rtol=1e-4, atol=1e-9)
+        rel_close(o['dpos'].cpu(), psr.grad, rtol=1e-4, atol=1e-9)
+    rel_close(a['query_grad'].cpu(), q.grad, rtol=2e-4, atol=1e-8)
+    # == the stand-alone loss kernel on the unfused scores
+    lp_d = None if lpp is None else lpp.to(DEV)
+    ln_d = None if lnp is None else lnp.to(DEV)
+    loss2, dpos2, dneg2, _ = ra.ops.pairwise_loss(nat.LOSS_SSM, c['pos_score'], c['neg_score'], lp_d, ln_d)
+    rel_close(a['loss'].cpu(), loss2.cpu(), rtol=1e-5)
+    rel_close(a['dneg'].cpu(), dneg2.cpu(), rtol=1e-4, atol=1e-9)
+
+
+def test_fused_ssm_extreme_logits_and_padding(ra):
+    """Running-maximum rescaling: scores spread over +-60 with log-probabilities down to -18 stay finite and equal the
+    oracle; a -inf positive (masked padding) yields NaN loss and gradients for that row like the reference
+    (loss_func.py:88-89)."""
+    N, d, B, n = 999, 64, 8, 192
+    g = torch.Generator().manual_seed(0)
+    iw = torch.randn(N, d, generator=g)
+    iw[0] = 0
+    q = torch.randn(B, d, generator=g) * 3
+    pos = torch.randint(1, N, (B,), generator=g)
+    neg = torch.randint(1, N, (B, n), generator=g)
+    lnp = -torch.rand(B, n, generator=g) * 18
+    lpp = -torch.rand(B, generator=g) * 18
+    o = ra.ops.fused_forward(iw.to(DEV), q.to(DEV), n, pos_ids=pos.to(DEV), neg_ids=neg.to(DEV), fused_loss='ssm',
+                             want_query_grad=True, pos_logp=lpp.to(DEV), neg_logp=lnp.to(DEV))
+    qr = q.clone().requires_grad_(True)
+    val = oracle.sampled_softmax_loss((qr * iw[pos]).sum(-1), lpp, (qr.unsqueeze(1) * iw[neg]).sum(-1), lnp)
+    val.backward()
+    assert torch.isfinite(o['loss']).all() and float((qr.unsqueeze(1) * iw[neg]).sum(-1).abs().max()) > 40
+    rel_close(o['loss'].cpu(), val.detach(), rtol=1e-5)
+    rel_close(o['query_grad'].cpu(), qr.grad, rtol=2e-4, atol=1e-7)
+    pos2 = pos.clone()
+    pos2[3] = 0
+    o = ra.ops.fused_forward(iw.to(DEV), q.to(DEV), n, pos_ids=pos2.to(DEV), neg_ids=neg.to(DEV), fused_loss='ssm',
+                             want_query_grad=True, mask_pad_pos=True)
+    assert torch.isnan(o['loss']) and torch.isnan(o['row_loss'][3]) and torch.isnan(o['dneg'][3]).all()
+    assert torch.isnan(o['query_grad'][3]).all() and torch.isfinite(o['row_loss'][[0, 1, 2, 4]]).all()
+
+
+@pytest.mark.parametrize('kind', ['uniform', 'popular', 'given'])
+def test_fused_ssm_loss_autograd_vs_oracle(ra, kind):
+    """fused_ssm_loss through autograd (dense and row-sparse table gradients, write-only backward) == the oracle's
+    dense_grads on the drawn ids; the ids are those of the unfused path under the same seed."""
+    from recstudio_amd.fused import fused_ssm_loss
+    N, U, d, B, n = 2003, 97, 128, 41, 256
+    iw, uw = _tables(N, U, d, 5)
+    g = torch.Generator().manual_seed(3)
+    uid = torch.randint(1, U, (B,), generator=g)
+    pos = torch.randint(1, N, (B,), generator=g)
+    counts = (torch.rand(N, generator=g) ** 3 * 100).long()
+    sampler = {'given': None, 'uniform': ra.UniformSampler(N), 'popular': ra.PopularSamplerModel(counts).to(DEV)}[kind]
+    neg_given = torch.randint(0, N, (B, n), generator=g).to(DEV) if kind == 'given' else None
+    for sparse in (False, True):
+        iwd, uwd = iw.to(DEV).requires_grad_(True), uw.to(DEV).requires_grad_(True)
+        torch.manual_seed(77)
+        loss, ids = fused_ssm_loss(iwd, uwd, n, query_index=uid.to(DEV), pos_ids=pos.to(DEV), sampler=sampler,
+                                   neg_ids=neg_given, sparse_grad=sparse)
+        (loss * 2.0).backward()
+        lpp = lnp = None
+        if kind == 'popular':
+            ref = oracle.PopularSamplerModel(counts)
+            lpp, lnp = ref.compute_item_p(pos), ref.compute_item_p(ids.cpu())
+        val, _, _, gi, gu = oracle.dense_grads(iw, uw, uid, pos, ids.cpu(), loss='ssm',
+                                               log_pos_prob=lpp if lpp is not None else torch.zeros(B),
+                                               log_neg_prob=lnp if lnp is not None else torch.zeros(B, n))
+        rel_close(loss.detach().cpu(), val, rtol=1e-5)
+        gi_got = iwd.grad.to_dense() if sparse else iwd.grad
+        gu_got = uwd.grad.to_dense() if sparse else uwd.grad
+        rel_close(gi_got.cpu(), gi * 2, rtol=3e-4, atol=1e-7)
+        rel_close(gu_got.cpu(), gu * 2, rtol=3e-4, atol=1e-7)
+        torch.manual_seed(77)
+        _, ids2 = ra.retriever_scores(iw.to(DEV), uw.to(DEV), n, query_index=uid.to(DEV), pos_ids=pos.to(DEV),
+                                      sampler=sampler, neg_ids=neg_given)
+        assert torch.equal(ids, ids2)
+
+
+# --------------------------------------------------------------------------- cosine / Euclidean over the full catalog
+@pytest.mark.parametrize('d', [64, 128])
+@pytest.mark.parametrize('name', ['cos', 'euc', 'ip'])
+def test_full_catalog_scorers_golden(ra, golden, d, name):
+    """([B,D],[N,D]) case of Cosine / Euclidean / InnerProduct scorers (scorer.py:16-34) == the reference fixture."""
+    g = golden('score')
+    q, items = T(g[f'd{d}_bd_Nd_q']).to(DEV), T(g[f'd{d}_bd_Nd_items']).to(DEV)
+    scorer = {'cos': ra.CosineScorer(), 'euc': ra.EuclideanScorer(), 'ip': ra.InnerProductScorer()}[name]
+    out = scorer(q, items)
+    assert out.shape == (q.shape[0], items.shape[0])
+    rel_close(out.cpu(), g[f'd{d}_bd_Nd_{name}'], rtol=1e-4, atol=1e-5)
+    if name == 'euc':
+        rel_close(ra.NormScorer()(q, items).cpu(), g[f'd{d}_bd_Nd_norm2'], rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize('mode', ['cos', 'euc'])
+@pytest.mark.parametrize('d,N,B,k', [(128, 40_000, 200, 100), (64, 5_000, 33, 10), (100, 70_001, 130, 50)])
+def test_full_catalog_cos_euc_scores_lse_topk(ra, mode, d, N, B, k):
+    """rsa_fullscore with the cosine / Euclidean tile epilogue: materialised scores, logsumexp and exact top-k (the
+    filter path for large catalogs, the dense select for small ones) against the oracle's formulas; gradients of the
+    materialised path against torch autograd."""
+    g = torch.Generator().manual_seed(d + N)
+    iw = torch.randn(N, d, generator=g) * (0.5 + torch.rand(N, 1, generator=g) * 2)
+    iw[0] = 0
+    q = torch.randn(B, d, generator=g)
+    fn = oracle.cosine_score if mode == 'cos' else oracle.euclidean_score
+    want = fn(q, iw[1:])
+    sm = ra._native.SCORE_COS if mode == 'cos' else ra._native.SCORE_EUC
+    scores, lse, _, _ = ra.ops.fullscore(iw.to(DEV), q.to(DEV), want_scores=True, want_lse=True, score_mode=sm)
+    rel_close(scores.cpu(), want, rtol=1e-4, atol=1e-4 if mode == 'euc' else 1e-6)
+    rel_close(lse.cpu(), torch.logsumexp(want.double(), -1).float(), rtol=1e-5, atol=1e-5)
+    _, lse2, tv, ti = ra.ops.fullscore(iw.to(DEV), q.to(DEV), want_lse=True, k=k, score_mode=sm)
+    rel_close(lse2.cpu(), lse.cpu(), rtol=1e-6, atol=1e-6)
+    wv, wi = torch.topk(want, k)
+    rel_close(tv.cpu(), wv, rtol=1e-4, atol=1e-4 if mode == 'euc' else 1e-6)
+    # ids: equal wherever the k-th neighbourhood has no near-ties within the fp32 tolerance
+    got_scores = torch.gather(want, 1, (ti.cpu() - 1))
+    rel_close(got_scores, wv, rtol=1e-4, atol=1e-4 if mode == 'euc' else 1e-6)
+    assert (ti.cpu() - 1 == wi).float().mean() > 0.99
+    # autograd of the materialised scorer path
+    scorer = ra.CosineScorer() if mode == 'cos' else ra.EuclideanScorer()
+    qd, xd = q[:16].to(DEV).requires_grad_(True), iw[1:3000].to(DEV).requires_grad_(True)
+    w = torch.randn(16, 2999, generator=g).to(DEV)
+    (scorer(qd, xd) * w).sum().backward()
+    qr, xr = q[:16].clone().requires_grad_(True), iw[1:3000].clone().requires_grad_(True)
+    (fn(qr, xr) * w.cpu()).sum().backward()
+    rel_close(qd.grad.cpu(), qr.grad, rtol=2e-3, atol=2e-3 if mode == 'euc' else 2e-5)
+    rel_close(xd.grad.cpu(), xr.grad, rtol=2e-3, atol=2e-3 if mode == 'euc' else 2e-5)
+
+
+def test_full_catalog_wide_dim_and_large_k(ra):
+    """Shapes outside the single MFMA pass are composed from it: embed_dim 192 / 320 (k split into 128-wide slices)
+    and k = 1500 > 1024 (a user whose history + eval.topk exceeds the in-kernel select), incl. topk_mask_history."""
+    g = torch.Generator().manual_seed(7)
+    for d, N, B, k in ((192, 9_000, 40, 20), (320, 3_000, 17, 5), (64, 6_000, 12, 1500)):
+        iw = torch.randn(N, d, generator=g)
+        iw[0] = 0
+        q = torch.randn(B, d, generator=g)
+        want = q @ iw[1:].t()
+        scores, lse, tv, ti = ra.ops.fullscore(iw.to(DEV), q.to(DEV), want_scores=True, want_lse=True, k=k)
+        rel_close(scores.cpu(), want, rtol=1e-4, atol=1e-4)
+        rel_close(lse.cpu(), torch.logsumexp(want, -1), rtol=1e-5, atol=1e-4)
+        wv, wi = torch.topk(want, k)
+        rel_close(tv.cpu(), wv, rtol=1e-4, atol=1e-4)
+        assert (ti.cpu() - 1 == wi).float().mean() > 0.99
+        for mode, fn in ((ra._native.SCORE_COS, oracle.cosine_score), (ra._native.SCORE_EUC, oracle.euclidean_score)):
+            s2 = ra.ops.fullscore(iw.to(DEV), q.to(DEV), want_scores=True, score_mode=mode)[0]
+            rel_close(s2.cpu(), fn(q, iw[1:]), rtol=1e-4, atol=1e-3 if mode == 2 else 1e-6)
+
+
+def test_cosine_retriever_trains_and_evaluates(ra, golden):
+    """BaseRetriever(scorer=CosineScorer()) used to train and then fail at its first validation step: topk() now runs
+    on the MFMA kernel's cosine epilogue; ids == the oracle's topk_with_history(cosine=True) on the fixture."""
+    g = golden('topk')
+    iw, uw = T(g['item_w']), T(g['user_w'])
+    uid, hist = T(g['uid']), T(g['hist'])
+    for scorer, cos in ((ra.CosineScorer(), True), (ra.InnerProductScorer(), False)):
+        m = ra.BaseRetriever({'train': {'seed': 1}}, scorer=scorer,
+                             item_encoder=torch.nn.Embedding(iw.shape[0], iw.shape[1], padding_idx=0),
+                             query_encoder=torch.nn.Embedding(uw.shape[0], uw.shape[1], padding_idx=0))
+        m.fiid, m.fuid, m.frating = 'item_id', 'user_id', 'rating'
+        m.fields = {'item_id', 'user_id', 'rating'}
+        m.item_fields, m.query_fields = {'item_id'}, {'user_id'}
+        with torch.no_grad():
+            m.item_encoder.weight.copy_(iw)
+            m.query_encoder.weight.copy_(uw)
+        m.to(DEV)
+        m._update_item_vector()
+        score, items = m.topk({'user_id': uid.to(DEV)}, 10, hist.to(DEV))
+        ws, wi = oracle.topk_with_history(uw[uid], iw, 10, hist, cosine=cos)
+        rel_close(score.cpu(), ws, rtol=1e-4, atol=1e-6)
+        assert torch.equal(items.cpu(), wi)
+        if not cos:
+            assert torch.equal(items.cpu(), T(g['items']))
+
+
+# --------------------------------------------------------------------------- hygiene
+def test_reduce_scratch_is_per_stream_and_library_allocates_nothing(ra):
+    """The in-kernel loss reduction uses the caller's scratch: two streams get two blocks, repeated launches leave the
+    arrival counter at zero, and the loss equals the mean of the row losses."""
+    N, U, d, B, n = 2003, 97, 128, 300, 64
+    iw, uw = _tables(N, U, d, 1)
+    iwd, uwd = iw.to(DEV), uw.to(DEV)
+    uid = torch.randint(1, U, (B,), device=DEV)
+    pos = torch.randint(1, N, (B,), device=DEV)
+    neg = torch.randint(1, N, (B, n), device=DEV)
+    outs = []
+    streams = [torch.cuda.current_stream(), torch.cuda.Stream()]
+    for s in streams:
+        with torch.cuda.stream(s):
+            for _ in range(3):
+                o = ra.ops.fused_forward(iwd, uwd, n, query_index=uid, pos_ids=pos, neg_ids=neg, fused_bpr=True)
+            outs.append(o)
+    torch.cuda.synchronize()
+    keys = {k for k in ra.ops._SCRATCH if k[0] == torch.cuda.current_device()}
+    assert len({k[1] for k in keys}) >= 2
+    for o in outs:
+        rel_close(o['loss'].cpu(), o['row_loss'].mean().cpu(), rtol=1e-5)
+    for k in keys:
+        assert int(ra.ops._SCRATCH[k][:4].view(torch.int32)[0]) == 0
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason='needs two GPUs')
+def test_ops_follow_the_tensors_device(ra):
+    """Tensors on cuda:1 while cuda:0 is current: the launch runs on device 1's stream with device 1's scratch and
+    generator; mixing devices raises."""
+    torch.cuda.set_device(0)
+    N, U, d, B, n = 2003, 97, 128, 50, 64
+    iw, uw = _tables(N, U, d, 1)
+    d1 = torch.device('cuda', 1)
+    uid = torch.randint(1, U, (B,))
+    pos = torch.randint(1, N, (B,))
+    torch.manual_seed(5)
+    o1 = ra.ops.fused_forward(iw.to(d1), uw.to(d1), n, query_index=uid.to(d1), pos_ids=pos.to(d1),
+                              sampler=ra._native.SAMPLER_UNIFORM, fused_bpr=True)
+    torch.manual_seed(5)
+    o0 = ra.ops.fused_forward(iw.to(DEV), uw.to(DEV), n, query_index=uid.to(DEV), pos_ids=pos.to(DEV),
+                              sampler=ra._native.SAMPLER_UNIFORM, fused_bpr=True)
+    assert o1['neg_ids'].device == d1 and torch.equal(o1['neg_ids'].cpu(), o0['neg_ids'].cpu())
+    rel_close(o1['loss'].cpu(), o0['loss'].cpu(), rtol=1e-6)
+    with pytest.raises(RuntimeError, match='different devices'):
+        ra.ops.embedding_gather(iw.to(d1), uid.to(DEV))

@@ -41,6 +41,219 @@ def test_route_kernels_match_checker(world, B, n):
     assert torch.equal(out[positions], src)
 
 
+@pytest.mark.parametrize('world,B,n,cap_frac', [(4, 33, 7, 2.0), (8, 1000, 64, 1.1), (2, 5, 1, 1.0), (3, 17, 100, 0.5)])
+def test_route_fixed_kernel_matches_checker(world, B, n, cap_frac):
+    """rsa_shard_route_fixed: every owner segment holds the same multiset of (key, position) pairs as the checker's
+    (order inside a segment is free), unused slots are -1, elements beyond the capacity are dropped AND counted; the
+    consumers skip the empty slots (score 0, nothing scattered, zero gathered, unpack -> -1)."""
+    from recstudio_amd import _native as nat
+    from recstudio_amd.shard import HipBackend, RowShardPlan
+    from recstudio_amd._native import ptr
+    import recstudio_amd as ra
+    n_items = 10007
+    plan = RowShardPlan(n_items, world)
+    g = torch.Generator().manual_seed(B + n)
+    pos = torch.randint(0, n_items, (B,), generator=g)
+    neg = torch.randint(0, n_items, (B, n), generator=g)
+    hb, cb = HipBackend(), CheckerBackend()
+    counts = cb.count(pos, neg, plan)
+    cap = max(1, int(B * (n + 1) / world * cap_frac))
+    flag = hb.new_flag(DEV)
+    keys, positions = hb.route_fixed(pos.to(DEV), neg.to(DEV), plan, 1000, cap, flag)
+    wflag = cb.new_flag(None)
+    wkeys, wpos = cb.route_fixed(pos, neg, plan, 1000, cap, wflag)
+    keys, positions = keys.cpu(), positions.cpu()
+    assert int(flag.item()) == int(wflag.item()) == int((counts.long() - cap).clamp(min=0).sum())
+    for o in range(world):
+        seg = slice(o * cap, (o + 1) * cap)
+        kept = min(cap, int(counts[o]))
+        got = sorted(zip(keys[seg].tolist(), positions[seg].tolist()))
+        assert got[:cap - kept] == [(-1, -1)] * (cap - kept)
+        if kept == int(counts[o]):                       # no overflow: exactly the checker's pairs
+            assert got == sorted(zip(wkeys[seg].tolist(), wpos[seg].tolist()))
+        else:                                            # overflow: a subset of this owner's pairs, all distinct
+            fk, fp = cb.route(pos, neg, plan, 1000, None)
+            full = set(zip(fk.tolist(), fp.tolist()))
+            live = [p for p in got if p[0] >= 0]
+            assert len(set(live)) == kept and set(live) <= full
+    # consumers of a buffer with empty slots
+    item = torch.randn(plan.rows_per_shard, 64, device=DEV)
+    q_all = torch.randn(1000 + B, 64, device=DEV)
+    kd = keys.to(DEV)
+    sc = hb.score_keys(item, q_all, kd).cpu()
+    want = cb.score_keys(item.cpu(), q_all.cpu(), keys)
+    np.testing.assert_allclose(sc, want, rtol=1e-4, atol=1e-5)
+    assert (sc[keys < 0] == 0).all()
+    rows = torch.empty_like(kd)
+    qidx = torch.empty_like(kd)
+    nat.check(nat.lib().rsa_shard_unpack(ptr(kd), kd.numel(), ptr(rows), ptr(qidx), ra.ops._stream()), 'unpack')
+    assert ((rows.cpu() < 0) == (keys < 0)).all() and ((qidx.cpu() < 0) == (keys < 0)).all()
+    src = torch.randn(keys.numel())
+    out = hb.scatter(src.to(DEV), positions.to(DEV), B * (n + 1)).cpu()
+    live = positions >= 0
+    assert torch.equal(out[positions[live]], src[live])
+    back = hb.gather(out.to(DEV), positions.to(DEV)).cpu()
+    assert torch.equal(back[live], src[live]) and (back[~live] == 0).all()
+
+
+def test_sorted_scatter_drops_negative_ids():
+    """rsa_scatter_rows_sorted with ids < 0 (empty slots of the fixed-capacity exchange): nothing read or written for
+    them -- the rest equals the scatter of the live elements alone, also when the empty slots are a long run."""
+    import recstudio_amd as ra
+    torch.manual_seed(0)
+    N, d, m = 3001, 128, 5000
+    q = torch.randn(700, d, device=DEV)
+    ids = torch.randint(0, N, (m, 1), device=DEV)
+    qidx = torch.randint(0, 700, (m,), device=DEV)
+    coef = torch.randn(m, 1, device=DEV)
+    dead = torch.rand(m, device=DEV) < 0.4
+    ids_d, qidx_d = ids.clone(), qidx.clone()
+    ids_d[dead] = -1
+    qidx_d[dead] = -1
+    got = ra.ops.scatter_rows_sorted(torch.zeros(N, d, device=DEV), q, ids_d, coef, query_index=qidx_d, pad_row=-1)
+    live = ~dead
+    want = ra.ops.scatter_rows_sorted(torch.zeros(N, d, device=DEV), q, ids[live].contiguous(), coef[live].contiguous(),
+                                      query_index=qidx[live].contiguous(), pad_row=-1)
+    assert torch.equal(got, want)
+    ref = torch.zeros(N, d, device=DEV).index_add_(0, ids[live].view(-1), coef[live] * q[qidx[live]])
+    np.testing.assert_allclose(got.cpu(), ref.cpu(), rtol=1e-4, atol=1e-5)
+
+
+class StagedDist:
+    """torch.distributed look-alike whose collectives run over gloo through host staging: lets TWO ranks share ONE
+    GPU (RCCL refuses two ranks on one device), so the HIP side of the sharded step -- routing with non-trivial
+    split sizes, owner-side scoring of received keys, the sorted backward scatters -- runs at world size 2 on the
+    single-GPU test box.  The real RCCL path is the same ShardedItemTable code with torch.distributed itself
+    (test_two_gpus_rccl below, skipped without a second GPU)."""
+
+    def __init__(self, dist):
+        self.d = dist
+        self.ReduceOp = dist.ReduceOp
+
+    def new_group(self, *a, **k):
+        return None
+
+    class _Done:
+        def wait(self):
+            return True
+
+    def all_gather_into_tensor(self, out, x, group=None, async_op=False):
+        parts = [torch.empty(x.shape, dtype=x.dtype) for _ in range(self.d.get_world_size())]
+        self.d.all_gather(parts, x.cpu())
+        out.copy_(torch.cat(parts).view(out.shape))
+        return self._Done() if async_op else None
+
+    def all_to_all_single(self, out, x, output_split_sizes=None, input_split_sizes=None, group=None):
+        o = torch.empty(out.shape, dtype=out.dtype)
+        self.d.all_to_all_single(o, x.cpu().contiguous(), output_split_sizes, input_split_sizes)
+        out.copy_(o)
+
+    def reduce_scatter_tensor(self, out, x, group=None):
+        full = x.cpu().clone()
+        self.d.all_reduce(full)
+        r, per = self.d.get_rank(), out.shape[0]
+        out.copy_(full[r * per:(r + 1) * per])
+
+    def all_reduce(self, x, op=None, group=None):
+        c = x.cpu()
+        self.d.all_reduce(c, op=op if op is not None else self.d.ReduceOp.SUM)
+        x.copy_(c)
+
+
+def _two_rank_worker(rank, world, port, backend, result_dir):
+    import torch.distributed as dist
+    import recstudio_amd as ra
+    from recstudio_amd.shard import RowShardPlan, ShardedItemTable, ShardedRetriever
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dev = torch.device('cuda', rank if backend == 'nccl' else 0)
+    torch.cuda.set_device(dev)
+    if backend == 'nccl':
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        comm = dist
+    else:
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+        comm = StagedDist(dist)
+    try:
+        N, U, d, B, n = 30_011, 500, 128, 257, 64
+        g = torch.Generator().manual_seed(3)
+        item = (torch.randn(N, d, generator=g) * 0.1)
+        item[0] = 0
+        user = (torch.randn(U, d, generator=g) * 0.1).to(dev)
+        counts = (torch.rand(N, generator=g) ** 3 * 100).long()
+        gr = torch.Generator().manual_seed(50 + rank)
+        uid = torch.randint(1, U, (B,), generator=gr).to(dev)
+        pos = torch.randint(1, N, (B,), generator=gr).to(dev)
+        plan = RowShardPlan(N, world)
+        lo, hi = plan.bounds(rank)
+        item_d = item.to(dev)
+        for si, sampler in enumerate((ra.UniformSampler(N), ra.PopularSamplerModel(counts).to(dev))):
+            table = ShardedItemTable(item_d[lo:hi].contiguous(), plan, rank, comm, sample_seed=17 + si)
+            for step in range(3):                       # step 0: exact split + calibration; 1, 2: fixed capacity
+                out = table.sample_and_score(user, uid, pos, n, sampler, keep_route=True)
+                assert ('send_counts' in out['route']) == (step == 0)
+                ids = out['neg_ids']
+                want_p, want_n = oracle.retriever_forward(item, user.cpu()[uid.cpu()], pos.cpu(), ids.cpu())
+                np.testing.assert_allclose(out['neg_score'].cpu(), want_n, rtol=1e-4, atol=1e-6)
+                np.testing.assert_allclose(out['pos_score'].cpu(), want_p, rtol=1e-4, atol=1e-6)
+                # G-invariance on the device stream: the two ranks' blocks == one draw of [2B, n] from the same state
+                blocks = [torch.empty(B, n, dtype=torch.int64) for _ in range(world)]
+                dist.all_gather(blocks, ids.cpu())
+                gen1 = torch.Generator(device=dev).manual_seed(17 + si)
+                for _ in range(step + 1):
+                    with ra.rng.sharded_stream(0, 1, gen1):
+                        one = sampler(torch.empty(world * B, 1, device=dev), n, None)[0]
+                assert torch.equal(torch.cat(blocks), one.cpu())
+                # gradient exchange == the unsharded backward kernels on the full table
+                loss, dpos, dneg, _ = ra.ops.pairwise_loss(ra._native.LOSS_BPR, out['pos_score'], out['neg_score'])
+                ig = torch.zeros(hi - lo, d, device=dev)
+                qg = table.backward(out['route'], dpos, dneg, ig)
+                ig2, _, qg2 = ra.ops.fused_backward(item_d, user, ids, dneg, query_index=uid, pos_ids=pos, dpos=dpos)
+                np.testing.assert_allclose(qg.cpu(), qg2.cpu(), rtol=2e-4, atol=1e-8)
+                total = ig2.cpu()                        # this rank's contribution to every row ...
+                dist.all_reduce(total)                   # ... summed over the ranks
+                np.testing.assert_allclose(ig.cpu(), total[lo:hi], rtol=2e-4, atol=1e-8)
+            table.check_overflow()
+        # the sharded full-catalog pass
+        q = torch.randn(70, d, generator=gr).to(dev) * 0.2
+        table = ShardedItemTable(item_d[lo:hi].contiguous(), plan, rank, comm)
+        lse, tv, ti = table.full_lse_topk(q, 20)
+        _, wl, wv, wi = ra.ops.fullscore(item_d, q, want_lse=True, k=20)
+        assert torch.equal(ti, wi)
+        np.testing.assert_allclose(tv.cpu(), wv.cpu(), rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(lse.cpu(), wl.cpu(), rtol=1e-6)
+        # a training step: global-mean BPR loss, replicated tower summed over ranks, in-place item SGD
+        tower = torch.nn.Embedding(U, d).to(dev)
+        with torch.no_grad():
+            tower.weight.copy_(user)
+        tbl = ShardedItemTable(item_d[lo:hi].clone(), plan, rank, comm)
+        trainer = ShardedRetriever(tbl, tower, ra.UniformSampler(N), ra.BPRLoss(), 64, item_sgd_lr=0.5)
+        l0 = trainer.training_step(uid, pos)
+        tot = l0.detach().cpu().clone()
+        dist.all_reduce(tot)
+        assert abs(float(tot) - 0.6931) < 0.05 and torch.isfinite(tower.weight.grad).all()
+        open(os.path.join(result_dir, f'ok{rank}'), 'w').write('ok')
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_on_one_gpu_hip_backend(tmp_path):
+    """World size 2 with the HIP backend on the single test GPU (collectives staged over gloo): forward with exact and
+    fixed-capacity exchange, G-invariant negatives, gradient exchange, sharded full-catalog pass, training step."""
+    import torch.multiprocessing as mp
+    mp.spawn(_two_rank_worker, args=(2, _free_port(), 'gloo', str(tmp_path)), nprocs=2, join=True)
+    assert all(os.path.exists(tmp_path / f'ok{r}') for r in range(2))
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason='needs two GPUs')
+def test_two_gpus_rccl(tmp_path):
+    """The same worker over RCCL, one rank per GPU (all_gather_into_tensor / all_to_all_single with and without
+    split sizes / reduce_scatter_tensor / all_reduce on device buffers)."""
+    import torch.multiprocessing as mp
+    mp.spawn(_two_rank_worker, args=(2, _free_port(), 'nccl', str(tmp_path)), nprocs=2, join=True)
+    assert all(os.path.exists(tmp_path / f'ok{r}') for r in range(2))
+
+
 def test_world1_rccl_step_equals_unsharded():
     import torch.distributed as dist
     import recstudio_amd as ra
@@ -57,9 +270,9 @@ def test_world1_rccl_step_equals_unsharded():
         pos = torch.randint(1, N, (B,), generator=g).to(DEV)
         counts = (torch.rand(N, generator=g) ** 3 * 100).long()
         for sampler in (ra.UniformSampler(N), ra.PopularSamplerModel(counts).to(DEV)):
-            table = ShardedItemTable(item, RowShardPlan(N, 1), 0, dist)
-            torch.manual_seed(11)
-            out = table.sample_and_score(user, uid, pos, n, sampler)
+            # the table draws from its own job-wide stream (seed sample_seed, offset 0 on a fresh table)
+            table = ShardedItemTable(item, RowShardPlan(N, 1), 0, dist, sample_seed=11)
+            out = table.sample_and_score(user, uid, pos, n, sampler)         # exact split + calibration
             torch.manual_seed(11)
             score, ids = ra.retriever_scores(item, user, n, query_index=uid, pos_ids=pos, sampler=sampler)
             assert torch.equal(out['neg_ids'], ids)                     # same Philox stream either way
@@ -67,9 +280,12 @@ def test_world1_rccl_step_equals_unsharded():
             np.testing.assert_allclose(out['pos_score'].cpu(), score['pos_score'].cpu(), rtol=1e-5, atol=1e-6)
             want_p, want_n = oracle.retriever_forward(item.cpu(), user.cpu()[uid.cpu()], pos.cpu(), ids.cpu())
             np.testing.assert_allclose(out['neg_score'].cpu(), want_n, rtol=1e-4, atol=1e-6)
-            # gradient exchange == the unsharded backward
-            torch.manual_seed(11)
+            # gradient exchange == the unsharded backward (this step runs the fixed-capacity exchange)
             out = table.sample_and_score(user, uid, pos, n, sampler, keep_route=True)
+            assert 'send_counts' not in out['route']
+            want_p, want_n = oracle.retriever_forward(item.cpu(), user.cpu()[uid.cpu()], pos.cpu(), out['neg_ids'].cpu())
+            np.testing.assert_allclose(out['neg_score'].cpu(), want_n, rtol=1e-4, atol=1e-6)
+            np.testing.assert_allclose(out['pos_score'].cpu(), want_p, rtol=1e-4, atol=1e-6)
             loss, dpos, dneg, _ = ra.ops.pairwise_loss(ra._native.LOSS_BPR, out['pos_score'], out['neg_score'])
             ig = torch.zeros_like(item)
             qg = table.backward(out['route'], dpos, dneg, ig)

@@ -11,6 +11,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 import oracle
+from oracle import philox
 
 
 class CheckerBackend:
@@ -19,8 +20,52 @@ class CheckerBackend:
     def gather_rows(self, table, ids):
         return table[ids]
 
-    def sample(self, sampler, n_queries, n, device, pos_ids):
-        return sampler.forward(torch.zeros(n_queries, 1), n, pos_ids)
+    # the device generator's role is played by (seed, offset) of the oracle's Philox restatement: ONE stream for the
+    # job, rank r owns rows [r*B, (r+1)*B) of the global [G*B, n] draw
+    GRID = 256 * 1024
+
+    def make_generator(self, seed, device):
+        return {'seed': int(seed), 'offset': 0}
+
+    def sample(self, sampler, n_queries, n, device, pos_ids, shard=None):
+        if shard is None:
+            return sampler.forward(torch.zeros(n_queries, 1), n, pos_ids)
+        rank, world, gen = shard
+        numel = n_queries * world * n
+        grid = philox.rng_grid_threads(numel, 256, 2048)
+        res = sampler.forward_device_stream(torch.zeros(n_queries * world, 1), n, gen['seed'], gen['offset'], grid,
+                                            pos_items=None if pos_ids is None else pos_ids.repeat(world))
+        lp, ids, lnp = res if pos_ids is not None else (None, *res)
+        unroll = 4 if isinstance(sampler, oracle.PopularSamplerModel) or sampler.num_items < (1 << 28) else 2
+        gen['offset'] += ((numel - 1) // (grid * unroll) + 1) * 4
+        rows = slice(rank * n_queries, (rank + 1) * n_queries)
+        if pos_ids is None:
+            return ids[rows], lnp[rows]
+        return lp[rows], ids[rows], lnp[rows]
+
+    def new_flag(self, device):
+        return torch.zeros(1, dtype=torch.int32)
+
+    def flag_read_async(self, flag):
+        return lambda: int(flag[0])
+
+    def route_fixed(self, pos, neg, plan, query_base, capacity, overflow):
+        B, n = neg.shape
+        ids = self._elements(pos, neg)
+        owner = plan.owner(ids)
+        m = torch.arange(B).repeat_interleave(n + 1)
+        c = torch.arange(n + 1).repeat(B)
+        key = ((query_base + m) << 32) | (ids - owner * plan.rows_per_shard)
+        position = torch.where(c == 0, m, B + m * n + (c - 1))
+        keys = torch.full((plan.world * capacity,), -1, dtype=torch.int64)
+        positions = torch.full((plan.world * capacity,), -1, dtype=torch.int64)
+        for gdst in range(plan.world):
+            sel = torch.nonzero(owner == gdst).flatten()
+            overflow += max(0, sel.numel() - capacity)
+            sel = sel[:capacity]
+            keys[gdst * capacity:gdst * capacity + sel.numel()] = key[sel]
+            positions[gdst * capacity:gdst * capacity + sel.numel()] = position[sel]
+        return keys, positions
 
     def _elements(self, pos, neg):
         return torch.cat([pos.view(-1, 1), neg], 1).reshape(-1)
@@ -40,18 +85,22 @@ class CheckerBackend:
         return key[order], position[order]
 
     def score_keys(self, item_local, q_all, keys):
-        rows, qidx = keys & 0xffffffff, keys >> 32
-        return (item_local[rows] * q_all[qidx]).sum(-1)
+        live = keys >= 0                                       # negative key = empty slot: score 0
+        rows, qidx = keys.clamp(min=0) & 0xffffffff, keys.clamp(min=0) >> 32
+        return torch.where(live, (item_local[rows] * q_all[qidx]).sum(-1), torch.zeros(()))
 
     def scatter(self, scores, positions, numel):
         out = torch.empty(numel)
-        out[positions] = scores
+        live = positions >= 0
+        out[positions[live]] = scores[live]
         return out
 
     def gather(self, src, positions):
-        return src[positions]
+        return torch.where(positions >= 0, src[positions.clamp(min=0)], torch.zeros(()))
 
     def backward_keys(self, item_local, q_all, keys, dscore, item_grad_local, qgrad_all, item_pad_row=-1, item_scale=None):
+        keep = keys >= 0
+        keys, dscore = keys[keep], dscore[keep]
         rows, qidx = keys & 0xffffffff, keys >> 32
         live = rows != item_pad_row
         qgrad_all.index_add_(0, qidx, dscore.unsqueeze(1) * item_local[rows])       # reads the rows: first
@@ -100,14 +149,32 @@ def _worker(rank, world, port, n_items, d, B, n, result_dir):
         gr = torch.Generator().manual_seed(100 + rank)
         uid = torch.randint(1, 50, (B,), generator=gr)
         pos = torch.randint(1, n_items, (B,), generator=gr)
-        torch.manual_seed(7 + rank)
         sampler = oracle.UniformSampler(n_items)
-        out = table.sample_and_score(user, uid, pos, n, sampler)
+        assert table.exchange == 'fixed' and not table._cap
+        out = table.sample_and_score(user, uid, pos, n, sampler)           # exact split + calibration
+        assert table._cap[(B, n)] <= B * (n + 1)
         want_pos, want_neg = oracle.retriever_forward(item, user[uid], pos, out['neg_ids'])
         np.testing.assert_allclose(out['pos_score'].numpy(), want_pos.numpy(), rtol=1e-6, atol=1e-6)
         np.testing.assert_allclose(out['neg_score'].numpy(), want_neg.numpy(), rtol=1e-6, atol=1e-6)
-        # gradient exchange: item grads stay on the owner, query grads come home by reduce-scatter
+        # G-invariant negatives: the ranks' blocks, concatenated, are what ONE process draws for the whole batch from
+        # the same stream (same seed, same offset) -- the negatives of a run do not depend on the number of GPUs
+        blocks = [torch.zeros(B, n, dtype=torch.int64) for _ in range(world)]
+        dist.all_gather(blocks, out['neg_ids'])
+        solo = CheckerBackend()
+        ids1, _ = solo.sample(sampler, B * world, n, None, None, shard=(0, 1, solo.make_generator(2022, None)))
+        assert torch.equal(torch.cat(blocks), ids1)
+        # gradient exchange: item grads stay on the owner, query grads come home by reduce-scatter.  This step runs
+        # the FIXED-capacity exchange (equal split, -1 keys in the unused slots, no counts on the host)
         out = table.sample_and_score(user, uid, pos, n, sampler, keep_route=True)
+        assert 'send_counts' not in out['route'] and (out['route']['recv_keys'] < 0).any()
+        want_pos, want_neg = oracle.retriever_forward(item, user[uid], pos, out['neg_ids'])
+        np.testing.assert_allclose(out['pos_score'].numpy(), want_pos.numpy(), rtol=1e-6, atol=1e-6)
+        np.testing.assert_allclose(out['neg_score'].numpy(), want_neg.numpy(), rtol=1e-6, atol=1e-6)
+        blocks2 = [torch.zeros(B, n, dtype=torch.int64) for _ in range(world)]
+        dist.all_gather(blocks2, out['neg_ids'])
+        assert not torch.equal(torch.cat(blocks2), ids1)                    # the stream moved on ...
+        ids2, _ = solo.sample(sampler, B * world, n, None, None, shard=(0, 1, {'seed': 2022, 'offset': table.sample_generator['offset'] - 4}))
+        assert torch.equal(torch.cat(blocks2), ids2)                        # ... in lock-step with a single process
         gg = torch.Generator().manual_seed(500 + rank)
         dpos, dneg = torch.randn(B, generator=gg), torch.randn(B, n, generator=gg)
         item_grad_local = torch.zeros(hi - lo, d)
@@ -130,6 +197,22 @@ def _worker(rank, world, port, n_items, d, B, n, result_dir):
         w2p, w2n = oracle.retriever_forward(item, user[uid], pos2, neg2)
         np.testing.assert_allclose(p2.numpy(), w2p.numpy(), rtol=1e-6, atol=1e-6)
         np.testing.assert_allclose(s2.numpy(), w2n.numpy(), rtol=1e-6, atol=1e-6)
+        table.check_overflow()                                                # nothing was dropped so far
+        # the exact (variable-split) exchange gives the same scores
+        exact = ShardedItemTable(item[lo:hi].clone(), plan, rank, dist, backend=CheckerBackend(), exchange='exact')
+        p3, s3 = exact.score_ids(user[uid], pos2, neg2)
+        assert torch.equal(p3, p2) and torch.equal(s3, s2)
+        # an id distribution that outgrows a tight capacity is DETECTED: calibrate on uniform ids without slack, then
+        # send everything to one owner
+        tight = ShardedItemTable(item[lo:hi].clone(), plan, rank, dist, backend=CheckerBackend(), slack=1.0, margin=0)
+        negu = torch.randint(1, n_items, (B, n), generator=gr)
+        tight.score_ids(user[uid], pos, negu)
+        assert B < 100 or tight._cap[(B, n)] < B * (n + 1)
+        if tight._cap[(B, n)] < B * (n + 1):
+            tight.score_ids(user[uid], pos2, neg2)
+            with pytest.raises(RuntimeError, match='did not fit'):
+                tight.check_overflow()
+            assert not tight._cap                                             # recalibrates on the next step
         open(os.path.join(result_dir, f'ok{rank}'), 'w').write('ok')
     finally:
         dist.destroy_process_group()
@@ -185,8 +268,6 @@ def _train_worker(rank, world, port, n_items, d, B, n, result_dir):
             gr = torch.Generator().manual_seed(300 + r)
             feats.append(torch.randn(B, 8, generator=gr))
             poss.append(torch.randint(1, n_items, (B,), generator=gr))
-        torch.manual_seed(40 + rank)
-
         def bpr(label, pos_score, log_pos_prob, neg_score, log_neg_prob):      # loss_func.py:50-59
             return -torch.mean(torch.nn.functional.logsigmoid(pos_score.view(-1, 1) - neg_score).mean(-1))
         trainer = ShardedRetriever(table, tower, oracle.UniformSampler(n_items), bpr, n)
@@ -197,7 +278,6 @@ def _train_worker(rank, world, port, n_items, d, B, n, result_dir):
         with torch.no_grad():
             tower2.weight.copy_(tower_w)
             tower2.bias.zero_()
-        torch.manual_seed(40 + rank)
         trainer2 = ShardedRetriever(table2, tower2, oracle.UniformSampler(n_items), bpr, n, item_sgd_lr=0.7)
         trainer2.training_step(feats[rank], poss[rank])
         np.testing.assert_allclose(table2.item_local.numpy(), (item[lo:hi] - 0.7 * trainer.item_grad_local).numpy(),
@@ -247,10 +327,12 @@ def test_sharded_full_catalog_pass_equals_single_process(tmp_path, n_items, k):
     assert all(os.path.exists(tmp_path / f'ok{r}') for r in range(world))
 
 
-@pytest.mark.parametrize('n_items,n', [(101, 5), (64, 1)])
-def test_sharded_scores_equal_single_process(tmp_path, n_items, n):
+@pytest.mark.parametrize('n_items,n,B', [(101, 5, 9), (64, 1, 9), (1001, 7, 500)])
+def test_sharded_scores_equal_single_process(tmp_path, n_items, n, B):
+    """Forward + gradient exchange on 2 ranks == single process: exact-split calibration step, then the fixed-capacity
+    exchange; negatives identical to a world-1 draw (G-invariance); overflow of a tight capacity detected (B = 500)."""
     world = 2
-    mp.spawn(_worker, args=(world, _free_port(), n_items, 16, 9, n, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), n_items, 16, B, n, str(tmp_path)), nprocs=world, join=True)
     assert all(os.path.exists(tmp_path / f'ok{r}') for r in range(world))
 
 

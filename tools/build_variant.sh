@@ -1,0 +1,23 @@
+#!/bin/bash
+# Build another copy of the library with extra -D switches for A/B measurements on the GPU box:
+#   tools/build_variant.sh qgpipe -DRSA_QG_PIPELINE=1 -DRSA_QG_BATCH=4
+# writes recstudio_amd/librecstudio_amd_qgpipe.so (git-ignored, travels with gpurun); select it with
+#   RSA_LIB=$PWD/recstudio_amd/librecstudio_amd_qgpipe.so python bench.py ...
+set -e
+NAME=$1; shift
+ROOT=$(cd "$(dirname "$0")/.." && pwd)
+OUT=$ROOT/recstudio_amd/csrc/variant_$NAME
+mkdir -p $OUT
+FLAGS="-O3 -std=c++17 --offload-arch=gfx950 -fPIC -Wall -Wno-unused-function -ffp-contract=off $*"
+for f in rsa_misc rsa_sample rsa_fused rsa_loss rsa_backward rsa_fullscore rsa_shard rsa_sorted; do
+  # only the fused forward carries switches today; the other objects are reused from the default build
+  if [ "$f" = rsa_fused ] || [ ! -f $ROOT/recstudio_amd/csrc/$f.o ]; then
+    /opt/rocm/bin/hipcc $FLAGS -c $ROOT/recstudio_amd/csrc/$f.hip -o $OUT/$f.o &
+  else
+    cp $ROOT/recstudio_amd/csrc/$f.o $OUT/$f.o
+  fi
+done
+wait
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $OUT/*.o -o $ROOT/recstudio_amd/librecstudio_amd_$NAME.so
+rm -rf $OUT
+echo built $ROOT/recstudio_amd/librecstudio_amd_$NAME.so
