@@ -7,8 +7,12 @@ One *step* = one pass of the hot path over one batch of synthetic interactions:
 i.e. BaseRetriever.forward + loss_fn of the reference (baseretriever.py:142-171, loss_func.py:55-59)
 on BASELINE.json configs[1]: N = 10 000 001 items x d = 128 fp32, 1 000 001 users, popularity
 sampler, n = 64 negatives, inner product, BPR.  All inputs are resident in HBM before the timed
-region.  N > 1 GPUs: the item table is row-sharded over the ranks (configs[3] layout), ids /
-scores travel by RCCL all-to-all, each rank owns B queries per step (weak scaling).
+region.
+
+--gpus N > 1: BASELINE.json configs[3] -- a 100 000 001-item table row-sharded over the N ranks, n = 1024
+negatives, B = 4096 queries per GPU per step (weak scaling), ids out / scores back by RCCL all-to-all.  Started
+without a launcher (WORLD_SIZE unset) the script re-executes itself under torch.distributed.run with N ranks;
+under the driver's own torchrun it checks that the world size is N.
 
 Prints ONE JSON line (rank 0).  Extra keys beyond the driver contract: roofline, cpu_baseline,
 train_step (forward + loss + row-sparse gradient scatter), sweep.
@@ -82,6 +86,21 @@ def time_gpu_best(fn, steps, warmup, repeats=3):
     return min(time_gpu(fn, steps, warmup if r == 0 else 1) for r in range(repeats))
 
 
+def self_launch(n_gpus):
+    """`python bench.py --gpus N` without a launcher: become `python -m torch.distributed.run ... bench.py --gpus N`
+    (one rank per GPU over RCCL, rendezvous on 127.0.0.1)."""
+    import socket
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n_gpus}',
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    os.execvpe(cmd[0], cmd, env)
+
+
 def cpu_baseline(args, counts, d, B, n):
     """The oracle (a port, not the product) timed on this box's host cores on a bounded sample:
     the same N / d / B / n, a handful of steps."""
@@ -133,20 +152,35 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=200)
     ap.add_argument('--warmup', type=int, default=50)
-    ap.add_argument('--items', type=int, default=10_000_001)
+    ap.add_argument('--items', type=int, default=None, help='default: 10 000 001 on one GPU, 100 000 001 sharded')
     ap.add_argument('--users', type=int, default=1_000_001)
     ap.add_argument('--dim', type=int, default=128)
-    ap.add_argument('--batch', type=int, default=65536, help='queries per step per GPU')
-    ap.add_argument('--neg', type=int, default=64)
-    ap.add_argument('--sampler', default='popular', choices=['popular', 'uniform'])
+    ap.add_argument('--batch', type=int, default=None, help='queries per step per GPU (default 65536 / 4096 sharded)')
+    ap.add_argument('--neg', type=int, default=None, help='default 64 / 1024 sharded')
+    ap.add_argument('--sampler', default=None, choices=['popular', 'uniform'], help='default popular / uniform sharded')
     ap.add_argument('--guide-log2', type=int, default=None, help='override the sampler guide-table size (experiments)')
+    ap.add_argument('--pop-lookup', default='auto', choices=['auto', 'lines', 'lut', 'guide'],
+                    help='inverse-CDF structure of the popularity sampler (experiments)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-sweep', action='store_true')
     args = ap.parse_args()
 
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        self_launch(args.gpus)              # does not return
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        raise SystemExit(f'bench.py: --gpus {args.gpus} but the launcher started {world} rank(s)')
+    sharded_run = world > 1
+    if args.items is None:
+        args.items = 100_000_001 if sharded_run else 10_000_001
+    if args.batch is None:
+        args.batch = 4096 if sharded_run else 65536
+    if args.neg is None:
+        args.neg = 1024 if sharded_run else 64
+    if args.sampler is None:
+        args.sampler = 'uniform' if sharded_run else 'popular'
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     dist = None
@@ -154,14 +188,17 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('nccl', device_id=dev)
+        assert dist.get_world_size() == args.gpus and dist.get_backend() == 'nccl'
 
     import recstudio_amd as ra
     from recstudio_amd import _native as nat
     ra._native.lib()     # no extension, no benchmark
+    if world > 1:        # torchrun pins OMP_NUM_THREADS=1: give each rank its share of the host cores for table builds
+        torch.set_num_threads(max(1, (os.cpu_count() or 8) // world))
 
     d, B, n = args.dim, args.batch, args.neg
     popular = args.sampler == 'popular'
-    counts = zipf_counts(args.items, 100_000_000)
+    counts = zipf_counts(args.items, 100_000_000) if (popular or not sharded_run) else None
     gen = torch.Generator(device=dev).manual_seed(100 + rank)
     uid = torch.randint(1, args.users, (B,), device=dev, generator=gen)
     pos = torch.randint(1, args.items, (B,), device=dev, generator=gen)
@@ -176,13 +213,12 @@ def main():
         dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
     if world == 1 and not force_shard:
         item, user = make_workload(dev, args.items, args.users, d)
-        sampler = (ra.PopularSamplerModel(counts, guide_log2=args.guide_log2) if popular
+        sampler = (ra.PopularSamplerModel(counts, guide_log2=args.guide_log2, lookup=args.pop_lookup) if popular
                    else ra.UniformSampler(args.items)).to(dev)
         kind = nat.SAMPLER_POPULAR if popular else nat.SAMPLER_UNIFORM
         kw = dict(query_index=uid, pos_ids=pos, sampler=kind)
         if popular:
-            kw.update(table=sampler.table, pop_prob=sampler.pop_prob, guide=sampler.guide, guide_log2=sampler.guide_log2,
-                      table_prob=sampler.table_prob, cdf_lut=sampler.cdf_lut)
+            kw.update(sampler.lookup_kwargs())
         bufs = {}
 
         def fwd(b=B, u=uid, p=pos, key='main'):
@@ -285,21 +321,46 @@ def main():
             q3 = user[1:b3 + 1].contiguous()
             pos3 = torch.randint(1, n_it3, (b3,), device=dev, generator=g3)
             ps3 = ra.PopularSamplerModel(counts[:n_it3]).to(dev)
-            kw3 = dict(pos_ids=pos3, sampler=nat.SAMPLER_POPULAR, table=ps3.table, pop_prob=ps3.pop_prob, guide=ps3.guide,
-                       guide_log2=ps3.guide_log2, table_prob=ps3.table_prob, cdf_lut=ps3.cdf_lut)
+            kw3 = dict(pos_ids=pos3, sampler=nat.SAMPLER_POPULAR, **ps3.lookup_kwargs())
             buf3 = {}
 
-            def step3():
+            def step3_unfused():
                 buf3['o'] = ra.ops.fused_forward(it3, q3, n3, out=buf3.get('o'), **kw3)
                 o = buf3['o']
                 return ra.ops.pairwise_loss(nat.LOSS_SSM, o['pos_score'], o['neg_score'], o['pos_logp'], o['neg_logp'])
+
+            def step3():          # ONE launch: sampling, gather, scores, logsumexp over the query's tiles, loss, d loss/d score
+                buf3['f'] = ra.ops.fused_forward(it3, q3, n3, out=buf3.get('f'), fused_loss='ssm', **kw3)
+                return buf3['f']
+
+            def train3():         # + d loss/d query in the forward, write-only item-gradient rows in the backward
+                buf3['t'] = ra.ops.fused_forward(it3, q3, n3, out=buf3.get('t'), fused_loss='ssm', want_query_grad=True, **kw3)
+                o = buf3['t']
+                return ra.ops.fused_backward(it3, q3, o['neg_ids'], o['dneg'], pos_ids=pos3, dpos=o['dpos'],
+                                             dense_item_grad=False, row_item_grad=True, want_query_grad=False)
+
+            def train3_two_pass():     # round-1 form: separate loss kernel, backward re-reads the rows for d loss/d query
+                loss, dpos, dneg, _ = step3_unfused()
+                o = buf3['o']
+                return ra.ops.fused_backward(it3, q3, o['neg_ids'], dneg, pos_ids=pos3, dpos=dpos, dense_item_grad=False,
+                                             row_item_grad=True, want_query_grad=True)
             t3 = time_gpu_best(step3, 50, 5) * 1e3
+            t3u = time_gpu_best(step3_unfused, 50, 5) * 1e3
+            t3t = time_gpu_best(train3, 30, 3) * 1e3
+            t3t2 = time_gpu_best(train3_two_pass, 30, 3) * 1e3
             extra['seq_softmax'] = {
                 'workload': f'B={b3} prefixes, L<={L3}, N={n_it3}, d={d}, popularity sampler n={n3}, SampledSoftmax '
                             '(BASELINE.json configs[2] tail; the Transformer is stock PyTorch and not timed)',
                 'seg_gather_ms': round(t_seg, 4), 'seg_gather_GBs': round(seg_bytes / t_seg / 1e6, 1),
                 'sample_gather_score_ssm_ms': round(t3, 4), 'M_triplets_s': round(b3 * n3 / t3 / 1e3, 1),
-                'alg_GBs': round(bytes_per_triplet(d, n3, True) * b3 * n3 / t3 / 1e6, 1)}
+                'alg_GBs': round(bytes_per_triplet(d, n3, True) * b3 * n3 / t3 / 1e6, 1),
+                'frac_of_hbm_peak': round(bytes_per_triplet(d, n3, True) * b3 * n3 / t3 / 1e6 / HBM_PEAK_GBS, 4),
+                'what': 'sampling + gather + scores + SampledSoftmax (logsumexp across the 4 tiles of a query, loss, '
+                        'd loss/d score) in ONE launch',
+                'unfused_loss_ms': round(t3u, 4),
+                'train_step_ms': round(t3t, 4), 'train_step_two_pass_ms': round(t3t2, 4),
+                'train_step_what': 'forward as above + d loss/d query accumulated in the forward + write-only '
+                                   'row-sparse item-gradient rows (two_pass: separate loss kernel, backward re-reads the rows)'}
         except Exception as e:
             extra['seq_softmax'] = {'error': repr(e)[:200]}
         # full softmax training step on configs[4] (forward never writes [B, N]; backward = one softmax write + 2 GEMMs)
@@ -350,10 +411,18 @@ def main():
                     'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': None,
                     'alg_bytes_per_launch': int(alg), 'avg_kernel_ms': round(k_avg, 4),
                     'median_kernel_ms': round(k_ms[len(k_ms) // 2], 4)}
-        pmc = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')
-        if os.path.exists(pmc) and (args.items, args.batch, args.neg, args.dim, popular) == (10_000_001, 65536, 64, 128, True):
+        # HBM bytes per launch come from separate rocprofv3 --pmc passes (tools/collect_profiles.sh), not from this run:
+        # the committed figure is attached only together with the kernel time it was collected at, and dropped when
+        # that time is more than 15 % away from today's (a changed kernel must be re-profiled, not re-labelled)
+        pmc = os.path.join(ROOT, 'profiles', 'r02_pmc_traffic.json')
+        if os.path.exists(pmc) and (args.items, args.batch, args.neg, args.dim, popular, args.pop_lookup) == \
+                (10_000_001, 65536, 64, 128, True, 'auto'):
             try:
-                roofline['traffic'] = json.load(open(pmc)).get('fused_fwd_bytes_per_launch')
+                rec = json.load(open(pmc))
+                then = rec.get('fused_fwd_avg_us', 0.0) / 1e3
+                if then and abs(then - k_avg) / k_avg < 0.15:
+                    roofline['traffic'] = rec.get('fused_fwd_bytes_per_launch')
+                    roofline['traffic_source'] = f'profiles/r02_pmc_traffic.json (FETCH_SIZE x2 + WRITE_SIZE passes; kernel avg then {then:.4f} ms)'
             except Exception:
                 pass
 
@@ -379,19 +448,20 @@ def main():
                     res8[name] = {'ms': round(t8, 4), 'M_triplets_s': round(b_q * n_neg / t8 / 1e3, 1),
                                   'alg_GBs': round(alg8 / t8 / 1e6, 1), 'frac_of_hbm_peak': round(alg8 / t8 / 1e6 / HBM_PEAK_GBS, 4)}
                 try:          # the popularity sampler on the same table (2^25-bucket lookup table, 537 MB)
-                    ps8 = ra.PopularSamplerModel(zipf_counts(n8, 100_000_000)).to(dev)
+                    ps8 = ra.PopularSamplerModel(zipf_counts(n8, 100_000_000), lookup=args.pop_lookup).to(dev)
                     b8p = {}
 
                     def st8p():
                         b8p['o'] = ra.ops.fused_forward(item8, user, n, out=b8p.get('o'), fused_bpr=True, want_mean=False,
                                                        query_index=uid, pos_ids=pos8, sampler=nat.SAMPLER_POPULAR,
-                                                       table=ps8.table, pop_prob=ps8.pop_prob, guide=ps8.guide,
-                                                       guide_log2=ps8.guide_log2, table_prob=ps8.table_prob, cdf_lut=ps8.cdf_lut)
+                                                       **ps8.lookup_kwargs())
                     t8p = time_gpu(st8p, 50, 5) * 1e3
                     alg8p = bytes_per_triplet(d, n, True, fused_loss=True) * B * n
                     res8['popular,n=64,B=65536'] = {'ms': round(t8p, 4), 'M_triplets_s': round(B * n / t8p / 1e3, 1),
                                                      'alg_GBs': round(alg8p / t8p / 1e6, 1),
-                                                     'frac_of_hbm_peak': round(alg8p / t8p / 1e6 / HBM_PEAK_GBS, 4)}
+                                                     'frac_of_hbm_peak': round(alg8p / t8p / 1e6 / HBM_PEAK_GBS, 4),
+                                                     'lookup': 'bucket lines 2^%d x 128 B' % ps8.lines_log2 if ps8.lines_log2
+                                                     else 'lut 2^%d' % ps8.guide_log2}
                     del ps8, b8p
                 except Exception as e:
                     res8['popular,n=64,B=65536'] = {'error': repr(e)[:200]}
@@ -400,14 +470,48 @@ def main():
                 del item8
             except Exception as e:
                 extra['table_100M'] = {'error': repr(e)[:200]}
+        # the multi-GPU workload (configs[3]) on ONE rank: a 12.5 M-row block (1/8 of the 100 M-item table), n = 1024,
+        # B = 4096 through the sharded step with a world-size-1 RCCL group -- the N = 1 reference point of the
+        # `--gpus N` line (same code path, same per-GPU shape)
+        if not args.no_sweep and args.dim == 128:
+            try:
+                import torch.distributed as dist1
+                from recstudio_amd import shard
+                os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+                os.environ.setdefault('MASTER_PORT', '29541')
+                dist1.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
+                dist = dist1
+                n_blk, n1k, b1k = 12_500_001, 1024, 4096
+                blk = torch.empty(n_blk, d, device=dev).normal_(0, 0.02, generator=torch.Generator(device=dev).manual_seed(9))
+                blk[0] = 0
+                tbl = shard.ShardedItemTable(blk, shard.RowShardPlan(n_blk, 1), 0, dist1)
+                us = ra.UniformSampler(n_blk)
+                u1, p1 = uid[:b1k].contiguous(), torch.randint(1, n_blk, (b1k,), device=dev, generator=gen)
+
+                def st1():
+                    o = tbl.sample_and_score(user, u1, p1, n1k, us)
+                    return ra.ops.pairwise_loss(nat.LOSS_BPR, o['pos_score'], o['neg_score'], want_grad=True)
+                st1()
+                t1 = time_gpu(st1, 50, 5) * 1e3
+                tbl.check_overflow()
+                extra['sharded_world1'] = {'workload': f'configs[3] per-GPU shape on one rank: {n_blk}-row block, neg={n1k}, '
+                                           f'B={b1k}, uniform sampler, sharded step at world size 1 (RCCL)',
+                                           'ms_per_step': round(t1, 4), 'M_triplets_s': round(b1k * n1k / t1 / 1e3, 2),
+                                           'frac_of_hbm_peak': round(bytes_per_triplet(d, n1k, False) * b1k * n1k / t1 / 1e6 / HBM_PEAK_GBS, 4)}
+                del blk, tbl
+            except Exception as e:
+                extra['sharded_world1'] = {'error': repr(e)[:200]}
         value = B * n / ms_step / 1e3
         parallelism = 'single'
         workload = (f'BPR two-tower d={d}, synthetic {args.items} items / {args.users} users / 1e8-interaction Zipf '
                     f'popularity, {args.sampler} sampler neg={n}, InnerProduct + BPR loss, B={B} queries/step '
                     f'(BASELINE.json configs[1])')
         if rank == 0 and not args.no_cpu_baseline:
-            extra['cpu_baseline'] = cpu_baseline(args, counts, d, 4096, n)
+            extra['cpu_baseline'] = cpu_baseline(args, counts, d, min(B, 16384), n)
+            extra['cpu_baseline']['sample'] += (f'; NOTE the CPU sample runs B={min(B, 16384)} queries/step, the GPU headline '
+                                                f'B={B} (triplets/s is per-triplet work, the batch only bounds the sample)')
     else:
+        # BASELINE.json configs[3]: the item table row-sharded over the ranks, ids out / scores back by RCCL all-to-all
         from recstudio_amd import shard
         plan = shard.RowShardPlan(args.items, world)
         lo, hi = plan.bounds(rank)
@@ -416,42 +520,67 @@ def main():
         if rank == 0:
             item_local[0] = 0
         user = torch.empty(args.users, d, device=dev).normal_(0, 0.02, generator=torch.Generator(device=dev).manual_seed(3))
-        sampler = (ra.PopularSamplerModel(counts) if popular else ra.UniformSampler(args.items)).to(dev)
+        sampler = (ra.PopularSamplerModel(counts, lookup=args.pop_lookup) if popular else ra.UniformSampler(args.items)).to(dev)
         table = shard.ShardedItemTable(item_local, plan, rank, dist)
 
-        def step():
-            o = table.sample_and_score(user, uid, pos, n, sampler)
-            return ra.ops.pairwise_loss(nat.LOSS_BPR, o['pos_score'], o['neg_score'], want_grad=True)
+        def make_step(tbl, smp, u, p, nn):
+            def step():
+                o = tbl.sample_and_score(user, u, p, nn, smp)
+                return ra.ops.pairwise_loss(nat.LOSS_BPR, o['pos_score'], o['neg_score'], want_grad=True)
+            return step
+        step = make_step(table, sampler, uid, pos, n)
+        step()                       # calibration step of the fixed-capacity exchange (exact split sizes, once)
         ms_step = time_gpu(step, args.steps, args.warmup, dist) * 1e3
+        table.check_overflow()       # nothing was dropped during the timed steps
         t = torch.tensor([ms_step], device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         ms_step = float(t.item())
         value = world * B * n / ms_step / 1e3
         alg = bytes_per_triplet(d, n, popular) * B * n
         achieved = alg / (ms_step * 1e-3) / 1e9
-        roofline = {'bound': 'hbm', 'kernel': 'whole sharded step (per GPU)', 'achieved': round(achieved, 1),
+        roofline = {'bound': 'hbm', 'kernel': 'whole sharded step (per GPU): sample, route, key all-to-all, owner-side '
+                    'gather+score, score all-to-all, scatter, loss', 'achieved': round(achieved, 1),
                     'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': None}
-        # the same sharded table at BASELINE.json configs[3]'s per-GPU shape (n = 1024, B = 4096: the same 4.2 M
-        # triplets per GPU per step, but a 16x smaller query all-gather -- at n = 64 that gather is the largest
-        # message of the step)
-        try:
-            n4, b4 = 1024, 4096
-            uid4, pos4 = uid[:b4].contiguous(), pos[:b4].contiguous()
+        extra['exchange'] = {'mode': table.exchange, 'capacity_per_owner': table._cap.get((B, n)),
+                             'mean_per_owner': B * (n + 1) // world,
+                             'what': 'equal-split all-to-all of fixed-capacity segments, empty slots = -1 keys; no split '
+                                     'sizes on the host (one calibration step before the timed region)'}
 
-            def step4():
-                o = table.sample_and_score(user, uid4, pos4, n4, sampler)
-                return ra.ops.pairwise_loss(nat.LOSS_BPR, o['pos_score'], o['neg_score'], want_grad=True)
-            ms4 = time_gpu(step4, max(10, args.steps // 4), 5, dist) * 1e3
-            t4 = torch.tensor([ms4], device=dev)
-            dist.all_reduce(t4, op=dist.ReduceOp.MAX)
-            ms4 = float(t4.item())
-            extra['sharded_n1024'] = {'workload': f'same sharded table, neg={n4}, B={b4} queries/step/GPU (configs[3] shape)',
-                                      'ms_per_step': round(ms4, 4), 'M_triplets_s': round(world * b4 * n4 / ms4 / 1e3, 2)}
+        def timed_max(fn, steps, warm):
+            fn()
+            v = torch.tensor([time_gpu(fn, steps, warm, dist) * 1e3], device=dev)
+            dist.all_reduce(v, op=dist.ReduceOp.MAX)
+            return float(v.item())
+        # the other sampler on the same sharded table, and the exact (variable-split, host read-back) exchange
+        try:
+            other = ra.UniformSampler(args.items).to(dev) if popular else \
+                ra.PopularSamplerModel(zipf_counts(args.items, 100_000_000), lookup=args.pop_lookup).to(dev)
+            ms_o = timed_max(make_step(table, other, uid, pos, n), max(10, args.steps // 4), 5)
+            extra['other_sampler'] = {'sampler': 'uniform' if popular else 'popular', 'ms_per_step': round(ms_o, 4),
+                                      'M_triplets_s': round(world * B * n / ms_o / 1e3, 2)}
+            del other
         except Exception as e:
-            extra['sharded_n1024'] = {'error': repr(e)[:200]}
+            extra['other_sampler'] = {'error': repr(e)[:200]}
+        try:
+            exact = shard.ShardedItemTable(item_local, plan, rank, dist, exchange='exact')
+            ms_e = timed_max(make_step(exact, sampler, uid, pos, n), max(10, args.steps // 4), 5)
+            extra['exact_exchange_ms_per_step'] = round(ms_e, 4)
+        except Exception as e:
+            extra['exact_exchange_ms_per_step'] = repr(e)[:200]
+        # the single-GPU workload's shape (n = 64, B = 65536: same triplets per GPU per step, 16x larger query gather)
+        try:
+            n4, b4 = 64, 65536
+            g4 = torch.Generator(device=dev).manual_seed(200 + rank)
+            uid4 = torch.randint(1, args.users, (b4,), device=dev, generator=g4)
+            pos4 = torch.randint(1, args.items, (b4,), device=dev, generator=g4)
+            ms4 = timed_max(make_step(table, sampler, uid4, pos4, n4), max(10, args.steps // 4), 5)
+            extra['sharded_n64'] = {'workload': f'same sharded table, neg={n4}, B={b4} queries/step/GPU',
+                                    'ms_per_step': round(ms4, 4), 'M_triplets_s': round(world * b4 * n4 / ms4 / 1e3, 2)}
+        except Exception as e:
+            extra['sharded_n64'] = {'error': repr(e)[:200]}
         parallelism = f'item-table row-sharded x{world} + RCCL all-to-all (ids out, scores back)'
         workload = (f'two-tower d={d}, {args.items}-item table row-sharded over {world} GPUs, {args.sampler} sampler '
-                    f'neg={n}, InnerProduct + BPR loss, B={B} queries/step/GPU (BASELINE.json configs[3] layout)')
+                    f'neg={n}, InnerProduct + BPR loss, B={B} queries/step/GPU (BASELINE.json configs[3])')
 
     if rank == 0:
         line = {'metric': 'M scored (user,pos,neg) triplets/sec at d=128', 'value': round(value, 2),

@@ -54,8 +54,10 @@ def main(argv=None):
         with torch.no_grad():
             user.weight.normal_(0, 0.02, generator=torch.Generator(device=dev).manual_seed(args.seed))
             user.weight[0] = 0
-        torch.manual_seed(args.seed + rank)               # each rank draws its own negatives
-        table = ShardedItemTable(item_local, plan, rank, dist)
+        torch.manual_seed(args.seed + rank)
+        # negatives come from ONE job-wide Philox stream (same seed on every rank, global element index): the run's
+        # negatives do not depend on the number of GPUs
+        table = ShardedItemTable(item_local, plan, rank, dist, sample_seed=args.seed)
         inplace = args.dim in (64, 128, 256)       # item rows updated inside the backward exchange (no dense gradient block)
         trainer = ShardedRetriever(table, user, ra.UniformSampler(args.items), ra.BPRLoss(), args.neg,
                                    item_sgd_lr=args.lr if inplace else None)

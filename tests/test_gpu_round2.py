@@ -372,3 +372,108 @@ def test_ops_follow_the_tensors_device(ra):
     rel_close(o1['loss'].cpu(), o0['loss'].cpu(), rtol=1e-6)
     with pytest.raises(RuntimeError, match='different devices'):
         ra.ops.embedding_gather(iw.to(d1), uid.to(DEV))
+
+
+# --------------------------------------------------------------------------- BASELINE.json configs[2] / configs[3] as configs
+def test_config2_sasrec_d128_L50_ssm_n256_training_step(ra, golden):
+    """configs[2] composed: SASRec (SeqDataset, max_seq_len = 50) at d = 128 with SampledSoftmaxLoss + PopularSamplerModel,
+    n = 256.  One training_step on a fixed batch (single fused launch for sampling + scores + loss + d loss/d query)
+    against the reference's op sequence restated on the CPU (sasrec.py:37-67 query encoder with stock torch modules,
+    baseretriever.py:153-171 scores, loss_func.py:80-90): loss and the gradients of the item table (which also feeds the
+    history gather) and of the position embedding."""
+    import copy
+    from test_dataset_golden import make
+    g = golden('data_ml100k')
+    sq = make(ra.SeqDataset, g, max_seq_len=50)
+    trn, _, _ = sq.build(split_ratio=2)
+    n = 256
+    cfg = {'model': {'embed_dim': 128, 'dropout_rate': 0.0}, 'train': {'negative_count': n, 'batch_size': 512,
+                                                                       'init_method': 'normal', 'seed': 7}}
+    model = ra.SASRec(cfg, loss=ra.SampledSoftmaxLoss(), sampler=ra.PopularSamplerModel(trn.item_freq))
+    model._init_model(trn)
+    model._init_parameter()
+    with torch.no_grad():                       # the 0.02 init gives near-constant scores: spread them
+        model.item_encoder.weight.mul_(15.0)
+        model.item_encoder.weight[0] = 0
+    model.to(DEV)
+    model.train()
+    batch = next(iter(trn.train_loader(batch_size=512, shuffle=False)))
+    assert batch['in_item_id'].shape[1] <= 50 and model.item_encoder.weight.shape[1] == 128
+    ref = copy.deepcopy(model).cpu()
+    bd = {k: v.to(DEV) for k, v in batch.items()}
+    torch.manual_seed(123)
+    loss = model.training_step(bd)
+    loss.backward()
+    # the same negatives through the sampler plugin under the same seed (same device stream)
+    torch.manual_seed(123)
+    lpp, neg, lnp = model.sampler(torch.empty(len(batch['item_id']), 1, device=DEV), n, bd['item_id'])
+    # reference op sequence on the CPU
+    enc = ref.query_encoder
+    hist = batch['in_item_id']
+    B, L = hist.shape
+    positions = torch.arange(L).unsqueeze(0).expand(B, L)
+    seq = torch.nn.functional.embedding(hist, ref.item_encoder.weight, padding_idx=0) + enc.position_emb(positions)
+    causal = torch.triu(torch.ones(L, L, dtype=torch.bool), 1)
+    out = enc.transformer_layer(enc.dropout(seq), mask=causal, src_key_padding_mask=hist == 0)
+    last = (batch['seqlen'] - 1).clamp(min=0).view(-1, 1, 1).expand(-1, 1, out.shape[-1])
+    q = out.gather(1, last).squeeze(1)
+    w = ref.item_encoder.weight
+    pos_s = (q * torch.nn.functional.embedding(batch['item_id'], w, padding_idx=0)).sum(-1)
+    neg_s = (q.unsqueeze(1) * torch.nn.functional.embedding(neg.cpu(), w, padding_idx=0)).sum(-1)
+    want = oracle.sampled_softmax_loss(pos_s, lpp.cpu(), neg_s, lnp.cpu())
+    want.backward()
+    assert float(neg_s.std()) > 0.05
+    rel_close(loss.detach().cpu(), want.detach(), rtol=2e-4)
+    gi, gi_ref = model.item_encoder.weight.grad.cpu(), ref.item_encoder.weight.grad
+    assert not gi[0].any() and torch.isfinite(gi).all()
+    scale = float(gi_ref.abs().max())
+    rel_close(gi, gi_ref, rtol=2e-3, atol=2e-4 * scale)
+    gp, gp_ref = model.query_encoder.position_emb.weight.grad.cpu(), enc.position_emb.weight.grad
+    rel_close(gp, gp_ref, rtol=2e-3, atol=2e-4 * float(gp_ref.abs().max()))
+
+
+def test_config3_per_gpu_shape_properties(ra):
+    """configs[3] at the per-GPU shape of an 8-way shard: 12.5 M-row block (6.4 GB), n = 1024, B = 4096.
+    Sampled ids bit-exact vs torch.randint over the GLOBAL id range, fixed-capacity routing to 8 owners without
+    overflow at the default slack, packed-key scoring on the block spot-checked against gathered rows, score
+    round trip through scatter."""
+    from recstudio_amd.shard import HipBackend, RowShardPlan
+    n_global, world, B, n, d = 100_000_001, 8, 4096, 1024, 128
+    plan = RowShardPlan(n_global, world)
+    rows = plan.rows_per_shard
+    assert rows == 12_500_001
+    gen = torch.Generator(device=DEV).manual_seed(1)
+    block = torch.empty(rows, d, device=DEV).normal_(0, 0.02, generator=gen)
+    q_all = torch.empty(world * B, d, device=DEV).normal_(0, 0.02, generator=gen)
+    pos = torch.randint(1, n_global, (B,), device=DEV, generator=gen)
+    torch.manual_seed(31)
+    want = torch.randint(1, n_global, (B, n), device=DEV)
+    torch.manual_seed(31)
+    lp, neg, lnp = ra.UniformSampler(n_global)(torch.empty(B, 1, device=DEV), n, pos)
+    assert torch.equal(neg, want) and lnp.dtype == torch.int64
+    hb = HipBackend()
+    counts = hb.count(pos, neg, plan).cpu().long()
+    assert int(counts.sum()) == B * (n + 1)
+    assert torch.equal(counts, torch.bincount(plan.owner(torch.cat([pos.view(-1, 1), neg], 1).reshape(-1)).cpu(), minlength=world))
+    cap = (int(counts.max() * 1.08) + 4096 + 255) // 256 * 256
+    flag = hb.new_flag(DEV)
+    keys, positions = hb.route_fixed(pos, neg, plan, 3 * B, cap, flag)
+    assert int(flag.item()) == 0 and int((keys >= 0).sum()) == B * (n + 1)
+    for o in (0, 5, 7):                              # segment o holds exactly the elements owned by o
+        seg = keys[o * cap:(o + 1) * cap]
+        assert int((seg >= 0).sum()) == int(counts[o])
+    # owner side: this rank plays owner 5 (rows [5 * rows, 6 * rows)) and scores its segment against q_all
+    seg = keys[5 * cap:6 * cap].contiguous()
+    sc = hb.score_keys(block, q_all, seg)
+    live = torch.nonzero(seg >= 0).flatten()
+    pick = live[torch.randint(0, live.numel(), (2000,), device=DEV)]
+    k = seg[pick]
+    ref = (block[k & 0xffffffff] * q_all[k >> 32]).sum(-1)
+    rel_close(sc[pick].cpu(), ref.cpu(), rtol=1e-4, atol=1e-7)
+    assert (sc[seg < 0] == 0).all() and int((k >> 32).min()) >= 3 * B and int((k >> 32).max()) < 4 * B
+    # home side: scores of all owners scattered back land on the element they belong to
+    fake = (keys & 0xffffffff).float()               # stand-in score = local row number
+    home = hb.scatter(fake, positions, B * (n + 1))
+    ids_flat = torch.cat([pos.view(-1, 1), neg], 1)
+    want_home = torch.cat([ids_flat[:, 0], ids_flat[:, 1:].reshape(-1)]) % rows
+    assert torch.equal(home.long(), want_home.float().long())
