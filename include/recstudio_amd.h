@@ -153,8 +153,9 @@ typedef struct rsa_fused_args {
   const float* pop_prob;
   const int32_t* guide;
   int64_t* neg_ids;            /* [M, n]: INPUT if sampler == GIVEN, else OUTPUT */
-  float* neg_logp;             /* nullable [M, n] out (POPULAR) */
-  float* pos_logp;             /* nullable [M] out (POPULAR, needs pos_ids) */
+  float* neg_logp;             /* nullable [M, n] out (POPULAR); INPUT log-probabilities when sampler == GIVEN and
+                                  fused_loss == 2 (null = 0) */
+  float* pos_logp;             /* nullable [M] out (POPULAR, needs pos_ids); INPUT like neg_logp for GIVEN + fused_loss 2 */
   float* pos_score;            /* nullable [M] out (needs pos_ids) */
   float* neg_score;            /* [M, n] out */
   const float* table_prob;     /* nullable [n_items][2]: interleaved copy {table[i], pop_prob[i]}.  When given,

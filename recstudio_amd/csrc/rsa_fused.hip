@@ -914,7 +914,9 @@ extern "C" int rsa_fused_sample_gather_score(const rsa_fused_args* a, rsa_stream
                       "rsa_fused_sample_gather_score: guide table missing");
     }
   }
-  RSA_CHECK_ARG(a->pos_logp == nullptr || a->pop_prob != nullptr,
+  // (ids given + SampledSoftmax epilogue: pos_logp / neg_logp are INPUTS, no table needed)
+  RSA_CHECK_ARG(a->pos_logp == nullptr || a->pop_prob != nullptr ||
+                    (a->sampler == RSA_SAMPLER_GIVEN && a->fused_loss == RSA_LOSS_SSM + 1),
                 "rsa_fused_sample_gather_score: pos_logp needs pop_prob");
   RSA_CHECK_ARG((a->pos_score == nullptr && a->pos_logp == nullptr) || a->pos_ids != nullptr,
                 "rsa_fused_sample_gather_score: pos outputs need pos_ids");

@@ -136,7 +136,7 @@ def test_popular_lookup_golden(ra, golden):
     assert torch.equal(ids.cpu(), want)
     # buckets holding many CDF boundaries (coarse guide): the 4-wide probe and its binary-search tail, both the
     # fused kernel's pair layout and the stand-alone kernel's separate arrays, on dense random uniforms
-    coarse = ra.PopularSamplerModel.from_tables(ps.pop_prob.cpu(), ps.table.cpu(), 6).to(DEV)
+    coarse = ra.PopularSamplerModel.from_tables(ps.pop_prob.cpu(), ps.table.cpu(), 6, lookup='lut').to(DEV)
     torch.manual_seed(3)
     uu = torch.rand(200_000, device=DEV)
     want = torch.searchsorted(coarse.table, uu).clamp_(max=coarse.table.numel() - 1)

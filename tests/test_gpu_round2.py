@@ -184,7 +184,7 @@ def test_fused_ssm_extreme_logits_and_padding(ra):
     val.backward()
     assert torch.isfinite(o['loss']).all() and float((qr.unsqueeze(1) * iw[neg]).sum(-1).abs().max()) > 40
     rel_close(o['loss'].cpu(), val.detach(), rtol=1e-5)
-    rel_close(o['query_grad'].cpu(), qr.grad, rtol=2e-4, atol=1e-7)
+    rel_close(o['query_grad'].cpu(), qr.grad, rtol=2e-4, atol=2e-6)      # sums of +-O(1) terms: cancellation
     pos2 = pos.clone()
     pos2[3] = 0
     o = ra.ops.fused_forward(iw.to(DEV), q.to(DEV), n, pos_ids=pos2.to(DEV), neg_ids=neg.to(DEV), fused_loss='ssm',
