@@ -158,6 +158,9 @@ def gen_loss(loss_func):
         log_neg_prob=lnp2)
     run('wbpr_big', loss_func.WeightedBPRLoss(), pos_score=pos * 30, log_pos_prob=lpp, neg_score=neg * 30, log_neg_prob=lnp)
     run('hinge_inactive', loss_func.HingeLoss(margin=0.5), pos_score=pos + 5, log_pos_prob=lpp, neg_score=neg, log_neg_prob=lnp)
+    # SoftmaxLoss second branch (loss_func.py:43-47): several positives per row [B, L] against one [B, N] score row,
+    # padded (-inf) positives dropped from the row mean
+    run('softmax_multi_pad', loss_func.SoftmaxLoss(), pos_score=pos3, all_score=alls)
     np.savez_compressed(os.path.join(OUT, 'loss.npz'), **out)
 
 

@@ -177,43 +177,58 @@ __device__ __forceinline__ void fold(float (&d)[L], int sub, int step) {
 // Rows are visited BATCH at a time, batch b = rows {b, b+NB, b+2NB, ...} of the lane group, and
 // each batch is folded to one value right away (the depth-first order of the transpose-reduce
 // tree), so only BATCH row fragments + NB partials are live instead of LPR of each.
+#ifndef RSA_FWD_PIN
+#define RSA_FWD_PIN 0      // 0: batches ordered by sched heuristics (round 1);  1: batch b+1's loads pinned behind batch b's
+#endif                     // fold by a data dependence;  2: one batch requested ahead (two batches of fragments live)
+#ifndef RSA_FWD_BATCH
+#define RSA_FWD_BATCH 8
+#endif
 template <int LPR, bool GENERIC, bool COS, bool QU, bool NT>
 __device__ __forceinline__ void tile_rows(const float* __restrict__ table, int D, int32_t id_lane,
                                           const float* __restrict__ query, int32_t qrow_lane,
                                           const Frag<LPR, GENERIC>& qf_uniform, float& dot, float& inorm2,
                                           float& qnorm2) {
   using F = Frag<LPR, GENERIC>;
-  constexpr int BATCH = GENERIC ? 2 : (LPR < 8 ? LPR : 8);
+  constexpr int BATCH = GENERIC ? 2 : (LPR < RSA_FWD_BATCH ? LPR : RSA_FWD_BATCH);
   constexpr int NB = LPR / BATCH;
+  constexpr int NBUF = (RSA_FWD_PIN == 2) ? 2 : 1;
   const int lane = lane_id();
   const int sub = lane % LPR;
-  const int gbase = lane - sub;   // first tile row of this lane group
+  int gbase = lane - sub;   // first tile row of this lane group
   float top[NB];
   float top2[COS ? NB : 1];
   float top3[(COS && !QU) ? NB : 1];
-#pragma unroll
-  for (int b = 0; b < NB; ++b) {
-    F x[BATCH];
-    F qx[QU ? 1 : BATCH];
+  F x[NBUF][BATCH];
+  F qx[NBUF][QU ? 1 : BATCH];
+  auto request = [&](int b) __attribute__((always_inline)) {
 #pragma unroll
     for (int k = 0; k < BATCH; ++k) {
       const int r = gbase + b + k * NB;
       const int32_t rid = __shfl(id_lane, r, 64);
-      frag_load<LPR, GENERIC, NT>(x[k], table + (size_t)rid * D, sub, D);
+      frag_load<LPR, GENERIC, NT>(x[b % NBUF][k], table + (size_t)rid * D, sub, D);
       if constexpr (!QU) {
         const int32_t qr = __shfl(qrow_lane, r, 64);
-        frag_load<LPR, GENERIC>(qx[k], query + (size_t)qr * D, sub, D);
+        frag_load<LPR, GENERIC>(qx[b % NBUF][k], query + (size_t)qr * D, sub, D);
       }
+    }
+  };
+  if (RSA_FWD_PIN == 2) request(0);
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    if (RSA_FWD_PIN == 2) {
+      if (b + 1 < NB) request(b + 1);
+    } else {
+      request(b);
     }
     float d[BATCH];
     float d2[COS ? BATCH : 1];
     float d3[(COS && !QU) ? BATCH : 1];
 #pragma unroll
     for (int k = 0; k < BATCH; ++k) {
-      const F& q = QU ? qf_uniform : qx[QU ? 0 : k];
-      d[k] = frag_dot<LPR, GENERIC>(x[k], q);
+      const F& q = QU ? qf_uniform : qx[b % NBUF][QU ? 0 : k];
+      d[k] = frag_dot<LPR, GENERIC>(x[b % NBUF][k], q);
       if constexpr (COS) {
-        d2[k] = frag_dot<LPR, GENERIC>(x[k], x[k]);
+        d2[k] = frag_dot<LPR, GENERIC>(x[b % NBUF][k], x[b % NBUF][k]);
         if constexpr (!QU) d3[k] = frag_dot<LPR, GENERIC>(q, q);
       }
     }
@@ -227,6 +242,11 @@ __device__ __forceinline__ void tile_rows(const float* __restrict__ table, int D
         top3[b] = d3[0];
       }
     }
+#if RSA_FWD_PIN
+    // the source-lane base of the NEXT request depends on this batch's result: the selection DAG cannot move that
+    // request (and its LPR-row fragments) in front of this batch, nor this batch's fold behind the later ones
+    asm volatile("" : "+v"(gbase), "+v"(top[b]));
+#endif
   }
   fold<NB>(top, sub, 1);
   dot = top[0];
@@ -351,7 +371,11 @@ __device__ __forceinline__ float finish_score(int mode, float dot, float inorm2,
 // round trips in every workgroup's tail, 7.5 us of a 43 us launch at B = 4096.
 // Range: |partial| < 2^19 at 2^-30 resolution (a batch of 10^5 queries with row losses up to ~5); beyond that the
 // result saturates to +inf through the flag word.  Totals must be >= 0 (every loss on this path is).
-constexpr int LOSS_FRAC_BITS = 30, LOSS_COUNT_SHIFT = 50;
+// Two levels: workgroup b adds to sub-word b % 32 (the sub-words sit in different 128-byte lines), and the workgroup
+// that completes a sub-word forwards its total to the top word -- atomics on ONE address are performed one after the
+// other at the memory side (~8 ns each), and at B = 4096 all 1024 workgroups finish together: a single word cost an
+// 8 us tail on a 37 us launch.
+constexpr int LOSS_FRAC_BITS = 30, LOSS_COUNT_SHIFT = 50, LOSS_SUBWORDS = 32;
 __device__ __forceinline__ void reduce_mean_loss(float wave_loss, float* __restrict__ loss_out,
                                                  unsigned int* __restrict__ flag_word,
                                                  float* __restrict__ loss_partials, int64_t n_queries) {
@@ -363,26 +387,37 @@ __device__ __forceinline__ void reduce_mean_loss(float wave_loss, float* __restr
   if (threadIdx.x == 0) {
     float part = 0.f;
     for (int w = 0; w < (int)(blockDim.x >> 6); ++w) part += s_red[w];
-    unsigned long long* word = reinterpret_cast<unsigned long long*>(loss_partials);     // 8-byte aligned (offset 256)
+    unsigned long long* words = reinterpret_cast<unsigned long long*>(loss_partials);     // 8-byte aligned (offset 256)
+    constexpr unsigned long long FIELD = (1ull << LOSS_COUNT_SHIFT) - 1, ONE = 1ull << LOSS_COUNT_SHIFT;
     const bool bad = !(fabsf(part) < 524288.f);          // NaN, inf or out of the fixed-point range
     const long long fixed = bad ? 0ll : __double2ll_rn((double)part * (double)(1ll << LOSS_FRAC_BITS));
-    unsigned long long add = ((unsigned long long)fixed & ((1ull << LOSS_COUNT_SHIFT) - 1)) + (1ull << LOSS_COUNT_SHIFT);
+    unsigned long long add = ((unsigned long long)fixed & FIELD) + ONE;
     if (bad) {
       const unsigned int old = __hip_atomic_fetch_or(flag_word, part != part ? 1u : 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       asm volatile("; the arrival waits for the flag" : "+v"(add) : "v"(old));
     }
-    const unsigned long long prev = __hip_atomic_fetch_add(word, add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if ((prev >> LOSS_COUNT_SHIFT) == (unsigned long long)(gridDim.x - 1)) {
-      const unsigned long long total = (prev + add) & ((1ull << LOSS_COUNT_SHIFT) - 1);
-      float loss = (float)((double)total / (double)(1ll << LOSS_FRAC_BITS) / (double)n_queries);
-      unsigned int* fw = flag_word;
-      asm volatile("; the flags are read after the last arrival" : "+v"(fw) : "v"(prev));
-      const unsigned int flags = __hip_atomic_load(fw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (flags & 1u) loss = NAN;
-      else if (flags & 2u) loss = INFINITY;
-      loss_out[0] = loss;
-      __hip_atomic_store(word, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // leave the scratch zeroed
-      if (flags) __hip_atomic_store(fw, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned j = blockIdx.x % LOSS_SUBWORDS;
+    const unsigned members = (gridDim.x - j + LOSS_SUBWORDS - 1) / LOSS_SUBWORDS;
+    const unsigned n_sub = gridDim.x < LOSS_SUBWORDS ? gridDim.x : LOSS_SUBWORDS;
+    unsigned long long* sub = words + 16 * (1 + j);      // 128 bytes apart; words[0] is the top word
+    const unsigned long long prev = __hip_atomic_fetch_add(sub, add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((prev >> LOSS_COUNT_SHIFT) == (unsigned long long)(members - 1)) {
+      const unsigned long long sub_total = (prev + add) & FIELD;
+      __hip_atomic_store(sub, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);        // leave the scratch zeroed
+      const unsigned long long add2 = sub_total + ONE;
+      const unsigned long long prev2 = __hip_atomic_fetch_add(words, add2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if ((prev2 >> LOSS_COUNT_SHIFT) == (unsigned long long)(n_sub - 1)) {
+        const unsigned long long total = (prev2 + add2) & FIELD;
+        float loss = (float)((double)total / (double)(1ll << LOSS_FRAC_BITS) / (double)n_queries);
+        unsigned int* fw = flag_word;
+        asm volatile("; the flags are read after the last arrival" : "+v"(fw) : "v"(prev2));
+        const unsigned int flags = __hip_atomic_load(fw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (flags & 1u) loss = NAN;
+        else if (flags & 2u) loss = INFINITY;
+        loss_out[0] = loss;
+        __hip_atomic_store(words, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (flags) __hip_atomic_store(fw, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
     }
   }
 }

@@ -206,11 +206,33 @@ class _MeanLseFn(torch.autograd.Function):
         return (sm * g).view(ctx.shape)
 
 
+class _RowLseFn(torch.autograd.Function):
+    """logsumexp(all_score[m, :]) per row (rsa_row_lse), softmax kept for the backward."""
+
+    @staticmethod
+    def forward(ctx, all_score):
+        x = all_score.reshape(-1, all_score.shape[-1])
+        lse, sm = ops.row_lse(x, want_softmax=all_score.requires_grad, scale=1.0)
+        ctx.shape = all_score.shape
+        ctx.save_for_backward(sm)
+        return lse.view(all_score.shape[:-1])
+
+    @staticmethod
+    def backward(ctx, g):
+        (sm,) = ctx.saved_tensors
+        return (sm * g.reshape(-1, 1)).view(ctx.shape)
+
+
 class SoftmaxLoss(FullScoreLoss):
-    """recstudio/model/loss_func.py:39-47, first branch (all_score one dim more than pos_score):
-    mean(logsumexp(all_score, -1) - pos_score)."""
+    """recstudio/model/loss_func.py:39-47.  First branch (all_score one dim more than pos_score):
+    mean(logsumexp(all_score, -1) - pos_score).  Second branch (same rank: several positives [B, L] per score row
+    [B, N]): per row the mean over its non-padded positives of logsumexp - pos, padded (-inf) positives dropped."""
 
     def forward(self, label, pos_score, all_score):
-        if all_score.dim() != pos_score.dim() + 1:
-            raise NotImplementedError('SoftmaxLoss: only all_score [.., N] with pos_score [..] is implemented')
-        return _MeanLseFn.apply(all_score) - pos_score.mean()
+        if all_score.dim() > pos_score.dim():
+            return _MeanLseFn.apply(all_score) - pos_score.mean()
+        lse = _RowLseFn.apply(all_score)                                     # the [B, N] reduction runs in HIP
+        output = lse.unsqueeze(-1) - pos_score                               # [B, L]: a few elementwise torch ops
+        notpadnum = torch.logical_not(torch.isinf(pos_score)).float().sum(-1)
+        output = torch.nan_to_num(output, posinf=0).sum(-1) / notpadnum
+        return torch.mean(output)

@@ -127,3 +127,73 @@ def test_flat_cache_round_trip(golden, tmp_path):
         ba = next(iter(a[0].train_loader(64, shuffle=False)))
         bb = next(iter(b[0].train_loader(64, shuffle=False)))
         assert sorted(ba) == sorted(bb) and all(torch.equal(ba[k], bb[k]) for k in ba)
+
+
+def _write_atomic(tmp_path, g, rows=None, user_feat=True):
+    """The fixture's raw interaction columns written back in RecStudio's atomic-file layout (tab-separated,
+    one header row -- recstudio/data/config/ml-100k.yaml, dataset_demo/ml-100k/ml-100k.inter)."""
+    sel = slice(None) if rows is None else rows
+    u, i = g['raw_user'][sel], g['raw_item'][sel]
+    r, t = g['raw_rating'][sel], g['raw_time'][sel]
+    with open(tmp_path / 'demo.inter', 'w') as f:
+        f.write('user_id\titem_id\trating\ttimestamp\n')
+        for a, b, c, d in zip(u, i, r, t):
+            f.write(f'{a}\t{b}\t{int(c)}\t{int(d)}\n')
+    if user_feat:
+        with open(tmp_path / 'demo.user', 'w') as f:
+            f.write('user_id\tage\tgender\n')
+            for a in sorted(set(u.tolist()) | {99999}):        # one user without interactions
+                f.write(f'{a}\t30\tM\n')
+    return {'data_dir': str(tmp_path), 'inter_feat_name': 'demo.inter', 'inter_feat_header': 0, 'field_separator': '\t',
+            'user_feat_name': ['demo.user'] if user_feat else None, 'user_feat_header': 0, 'low_rating_thres': 3.0}
+
+
+def test_atomic_file_reader_equals_injected_interactions(golden, tmp_path):
+    """TripletDataset built by PARSING atomic files (recstudio/data/dataset.py:945-974 `build` <- `_load_all_data`) ==
+    the dataset built from the same columns handed over in memory, which the tests above pin to the reference: ids,
+    splits, item_freq, first batch."""
+    g = golden('data_ml100k')
+    cfg = _write_atomic(tmp_path, g, user_feat=False)
+    seed_everything(2022)
+    a = TripletDataset('demo', cfg)
+    seed_everything(2022)
+    b = make(TripletDataset, g)
+    assert (a.num_users, a.num_items) == (b.num_users, b.num_items) == (944, 1575)
+    for f in ('user_id', 'item_id', 'rating'):
+        assert torch.equal(a.inter_feat[f], b.inter_feat[f]), f
+    seed_everything(2022)
+    ta, va, _ = a.build(split_ratio=[0.8, 0.1, 0.1], shuffle=True)
+    seed_everything(2022)
+    tb, vb, _ = b.build(split_ratio=[0.8, 0.1, 0.1], shuffle=True)
+    assert torch.equal(ta.data_index, tb.data_index) and torch.equal(va.data_index, vb.data_index)
+    assert torch.equal(ta.item_freq, tb.item_freq) and np.array_equal(ta.item_freq.numpy(), g['t_item_freq'])
+    ba, bb = next(iter(ta.train_loader(512, shuffle=False))), next(iter(tb.train_loader(512, shuffle=False)))
+    assert all(torch.equal(ba[k], bb[k]) for k in bb)
+    # a user-feature file adds the users that never interacted to the id space (the reference maps ids over the
+    # union of the feature files); rows with missing values are dropped
+    cfg2 = _write_atomic(tmp_path, g, rows=slice(0, 3000), user_feat=True)
+    with open(tmp_path / 'demo.inter', 'a') as f:
+        f.write('7\t\t5\t1\n')
+    c = TripletDataset('demo', cfg2)
+    d = TripletDataset('demo', dict(cfg2, user_feat_name=None))
+    # (users whose only interactions fall below low_rating_thres stay in the id space through the feature file)
+    assert c.num_users == len(set(g['raw_user'][:3000].tolist())) + 1 + 1 and c.num_users > d.num_users
+    assert c.num_items == d.num_items
+    assert len(c.inter_feat['user_id']) == len(d.inter_feat['user_id'])
+
+
+@pytest.mark.skipif(not __import__('os').path.exists('/root/reference/recstudio/dataset_demo/ml-100k/ml-100k.inter'),
+                    reason='the reference checkout is only present in the build container')
+def test_atomic_file_reader_on_the_reference_demo_files(golden):
+    """The reference's own bundled ml-100k atomic files through the product reader == the recorded fixture."""
+    g = golden('data_ml100k')
+    cfg = {'data_dir': '/root/reference/recstudio/dataset_demo/ml-100k', 'inter_feat_name': 'ml-100k.inter',
+           'inter_feat_header': 0, 'field_separator': '\t', 'user_feat_name': ['ml-100k.user'], 'user_feat_header': 0,
+           'low_rating_thres': 3.0}
+    seed_everything(2022)
+    ds = TripletDataset('ml-100k', cfg)
+    assert (ds.num_users, ds.num_items) == (944, 1575)
+    trn, _, _ = ds.build(split_ratio=[0.8, 0.1, 0.1], shuffle=True)
+    assert np.array_equal(trn.inter_feat['user_id'].numpy(), g['t_inter_user'])
+    assert np.array_equal(trn.inter_feat['item_id'].numpy(), g['t_inter_item'])
+    assert np.array_equal(trn.item_freq.numpy(), g['t_item_freq'])

@@ -477,3 +477,23 @@ def test_config3_per_gpu_shape_properties(ra):
     ids_flat = torch.cat([pos.view(-1, 1), neg], 1)
     want_home = torch.cat([ids_flat[:, 0], ids_flat[:, 1:].reshape(-1)]) % rows
     assert torch.equal(home.long(), want_home.float().long())
+
+
+def test_softmax_loss_second_branch_golden(ra, golden):
+    """SoftmaxLoss with pos_score [B, L] and all_score [B, N] of the same rank (loss_func.py:43-47): value and both
+    gradients == the reference fixture (padded -inf positives dropped from the row mean)."""
+    g = golden('loss')
+    pos = T(g['softmax_multi_pad_pos_score']).to(DEV).requires_grad_(True)
+    alls = T(g['softmax_multi_pad_all_score']).to(DEV).requires_grad_(True)
+    val = ra.SoftmaxLoss()(None, pos, alls)
+    val.backward()
+    rel_close(val.detach().cpu(), g['softmax_multi_pad_loss'], rtol=1e-5)
+    rel_close(alls.grad.cpu(), g['softmax_multi_pad_grad_all_score'], rtol=1e-4, atol=1e-8)
+    rel_close(pos.grad.cpu(), g['softmax_multi_pad_grad_pos_score'], rtol=1e-4, atol=1e-8)
+    # first branch unchanged
+    pos1 = T(g['softmax_full_pos_score']).to(DEV).requires_grad_(True)
+    all1 = T(g['softmax_full_all_score']).to(DEV).requires_grad_(True)
+    v1 = ra.SoftmaxLoss()(None, pos1, all1)
+    v1.backward()
+    rel_close(v1.detach().cpu(), g['softmax_full_loss'], rtol=1e-5)
+    rel_close(all1.grad.cpu(), g['softmax_full_grad_all_score'], rtol=1e-4, atol=1e-8)

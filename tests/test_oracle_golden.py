@@ -98,6 +98,11 @@ def test_losses(golden):
     val, (gp, ga) = grads(oracle.softmax_loss, (T(g['softmax_full_pos_score']), True), (T(g['softmax_full_all_score']), True))
     np.testing.assert_allclose(val.detach().numpy(), g['softmax_full_loss'], rtol=1e-6)
     np.testing.assert_allclose(ga.numpy(), g['softmax_full_grad_all_score'], rtol=1e-5, atol=1e-8)
+    # second branch (several positives per row, -inf padding dropped)
+    val, (gp, ga) = grads(oracle.softmax_loss, (T(g['softmax_multi_pad_pos_score']), True), (T(g['softmax_multi_pad_all_score']), True))
+    np.testing.assert_allclose(val.detach().numpy(), g['softmax_multi_pad_loss'], rtol=1e-6)
+    np.testing.assert_allclose(ga.numpy(), g['softmax_multi_pad_grad_all_score'], rtol=1e-5, atol=1e-8)
+    np.testing.assert_allclose(gp.numpy(), g['softmax_multi_pad_grad_pos_score'], rtol=1e-5, atol=1e-8)
 
 
 def test_uniform_sampler_cpu_stream(golden):
