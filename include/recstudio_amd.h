@@ -406,8 +406,8 @@ int rsa_shard_route(const int64_t* pos_ids, const int64_t* neg_ids, int64_t n_qu
                     int64_t rows_per_shard, int32_t n_shards, int64_t query_base, int32_t* cursor,
                     int64_t* keys, int64_t* positions, rsa_stream_t stream);
 /* FIXED-CAPACITY form of the routing (no owner histogram, no split sizes on the host): owner g's segment is
- * slots [g*capacity, (g+1)*capacity) of keys / positions [n_shards*capacity].  Both arrays are filled with -1
- * ("empty slot") by this call first; empty slots travel through the equal-split all-to-all as they are and
+ * slots [g*capacity, (g+1)*capacity) of keys / positions [n_shards*capacity].  The unused tail of every segment is
+ * filled with -1 ("empty slot") by this call; empty slots travel through the equal-split all-to-all as they are and
  * every consumer skips them: rsa_fused_sample_gather_score (packed_keys < 0 -> score 0), rsa_shard_unpack
  * (-> row -1, query -1), rsa_scatter_rows_sorted (negative ids dropped), rsa_scatter_f32 / rsa_gather_f32
  * (negative position -> nothing written / 0).  An element that finds its owner's segment full is NOT routed and

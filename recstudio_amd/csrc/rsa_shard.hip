@@ -134,6 +134,19 @@ __global__ __launch_bounds__(256) void shard_route_fixed_kernel(const int64_t* _
   if (dropped) atomicAdd(overflow, dropped);
 }
 
+// keys / positions of the UNUSED tail of every owner segment <- -1 (cursor[g] = elements routed to g, possibly more
+// than the capacity).  Only the slack is written: filling both whole buffers first cost 5 % of the sharded step.
+__global__ __launch_bounds__(256) void shard_fill_tail_kernel(const int32_t* __restrict__ cursor, int64_t capacity,
+                                                              int64_t* __restrict__ keys, int64_t* __restrict__ pos_out) {
+  const int g = blockIdx.y;
+  const int64_t used = cursor[g] < capacity ? cursor[g] : capacity;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = used + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < capacity; i += stride) {
+    keys[g * capacity + i] = -1;
+    pos_out[g * capacity + i] = -1;
+  }
+}
+
 __global__ __launch_bounds__(256) void shard_unpack_kernel(const int64_t* __restrict__ keys, int64_t numel,
                                                            int64_t* __restrict__ local_rows,
                                                            int64_t* __restrict__ qidx) {
@@ -222,14 +235,18 @@ extern "C" int rsa_shard_route_fixed(const int64_t* pos_ids, const int64_t* neg_
   RSA_CHECK_ARG(capacity >= 1 && capacity * n_shards < (1ll << 31), "rsa_shard_route_fixed: capacity out of range");
   RSA_CHECK_ARG(cursor && keys && positions && overflow, "rsa_shard_route_fixed: null pointer");
   hipStream_t s = (hipStream_t)stream;
-  const size_t slots = (size_t)capacity * n_shards;
-  if (hipMemsetAsync(cursor, 0, sizeof(int32_t) * n_shards, s) != hipSuccess ||
-      hipMemsetAsync(keys, 0xff, sizeof(int64_t) * slots, s) != hipSuccess ||
-      hipMemsetAsync(positions, 0xff, sizeof(int64_t) * slots, s) != hipSuccess) {
+  if (hipMemsetAsync(cursor, 0, sizeof(int32_t) * n_shards, s) != hipSuccess) {
     rsa::set_error("rsa_shard_route_fixed: memset failed");
     return RSA_ERR_HIP;
   }
-  if (n_queries == 0) return RSA_OK;
+  int64_t tail_blocks = (capacity + 255) / 256;
+  if (tail_blocks > 256) tail_blocks = 256;
+  if (n_queries == 0) {
+    hipLaunchKernelGGL(shard_fill_tail_kernel, dim3((unsigned)tail_blocks, (unsigned)n_shards), dim3(256), 0, s, cursor,
+                       capacity, keys, positions);
+    RSA_CHECK_LAUNCH("rsa_shard_route_fixed(fill)");
+    return RSA_OK;
+  }
   RSA_CHECK_ARG(pos_ids && (neg_ids || num_neg == 0), "rsa_shard_route_fixed: null ids");
   const int64_t numel = n_queries * (num_neg + 1);
   int64_t blocks = (numel + 16383) / 16384;
@@ -238,6 +255,8 @@ extern "C" int rsa_shard_route_fixed(const int64_t* pos_ids, const int64_t* neg_
   hipLaunchKernelGGL(shard_route_fixed_kernel, dim3((unsigned)blocks), dim3(256), 0, s, pos_ids, neg_ids, n_queries,
                      (int)num_neg, rows_per_shard, (int)n_shards, query_base, chunk, capacity, cursor, keys, positions,
                      overflow);
+  hipLaunchKernelGGL(shard_fill_tail_kernel, dim3((unsigned)tail_blocks, (unsigned)n_shards), dim3(256), 0, s, cursor,
+                     capacity, keys, positions);
   RSA_CHECK_LAUNCH("rsa_shard_route_fixed");
   return RSA_OK;
 }
