@@ -191,19 +191,20 @@ typedef struct rsa_fused_args {
                                   numbers on every replay; advance it with rsa_rng_advance in the same graph. */
   uint64_t elem_base;          /* Philox element index of flat element 0 (see "Philox state"); 0 on one GPU */
   void* reduce_scratch;        /* loss_out != null: caller-owned scratch of rsa_scratch_bytes() bytes (zeroed once) */
-  const float* cdf_lines;      /* nullable [2^lines_log2][32] fp32 (128-byte aligned): BUCKET LINES, the one-HBM-line form of
-                                  the inverse CDF.  Line b describes u in [b, b+1) / 2^lines_log2 through the DISTINCT CDF
-                                  values inside it (items whose CDF equals their predecessor's can never be returned by
-                                  searchsorted and are left out):
-                                    [0] c = number of distinct values in the bucket (int32 bits)
-                                    [1] id, [2] pop_prob of the first distinct entry ABOVE the bucket (the answer when u
-                                        exceeds every value in it; n_items-1 past the end)
-                                    [3] lo, [28] hi: search range in `table` for the fallback (int32 bits)
-                                    [4..11]  the first min(c, 8) values, padded with +inf
-                                    [12..27] {id (int32 bits), pop_prob} of those entries
-                                  id = entry[#{values < u}] -- the same comparisons torch.searchsorted makes; only a
-                                  bucket with more than 8 distinct values whose first 8 are all below u falls back to the
-                                  binary search in [lo, hi].  Takes precedence over cdf_lut / guide. */
+  const float* cdf_lines;      /* nullable [2^lines_log2 + 1][32] fp32 (128-byte aligned): BUCKET LINES, the one-HBM-line form
+                                  of the inverse CDF.  Line b describes u in [b, b+1) / 2^lines_log2 through the DISTINCT
+                                  CDF values inside it (items whose CDF equals their predecessor's can never be returned
+                                  by searchsorted and are left out), 12 slots:
+                                    words 0..11   cdf of the bucket's first distinct values, then (if fewer than 12) of the
+                                                  first distinct entry ABOVE the bucket, then +inf
+                                    words 12..23  pop_prob of those entries
+                                    words 24..29  their ids as uint16 offsets from `base` (even slot in the low half)
+                                    word  30      base id (int32 bits);  word 31: number of distinct values in the bucket
+                                                  (int32; -1 = ids too far apart for 16-bit offsets)
+                                  id = base + delta[#{cdf[i] < u}] -- the same comparisons torch.searchsorted makes; a
+                                  draw above 12 in-bucket values (or a -1 line) is searched in `table` between this
+                                  line's and the next line's base (line 2^lines_log2 is a sentinel).  Takes precedence
+                                  over cdf_lut / guide. */
   int32_t lines_log2;
   int32_t _pad3;
 } rsa_fused_args;

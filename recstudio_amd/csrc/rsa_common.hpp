@@ -203,39 +203,18 @@ __device__ __forceinline__ int32_t cdf_lookup_lut(const float4* __restrict__ lut
                                  pr);
 }
 
-// Bucket-line form (layout: include/recstudio_amd.h, rsa_fused_args.cdf_lines): one 128-byte line per bucket holds
-// the bucket's first 8 DISTINCT CDF values with their {id, probability}; hdr = line[0..3], c0 = line[4..7],
-// c1 = line[8..11] (three 16-byte loads of the same line, issued together).  Same comparisons as
-// torch.searchsorted, same index; one HBM line per draw.
-constexpr int LINE_K = 8;
+// Bucket-line form (layout: include/recstudio_amd.h, rsa_fused_args.cdf_lines): one 128-byte line per bucket,
+//   words 0..11  cdf[12]     the bucket's first distinct CDF values, then (when fewer than 12) the first entry ABOVE the
+//                            bucket, then +inf
+//   words 12..23 prob[12]    pop_prob of those entries
+//   words 24..29 delta[12]   uint16 each: id = base + delta
+//   word  30     base        id of slot 0
+//   word  31     count       distinct values inside the bucket (may exceed 12); -1: ids too far apart for 16-bit deltas
+// k = #{cdf[i] < u} is the answer's slot: the entry above the bucket compares >= u, so k never points past it.  Only
+// k == 12 (more than 12 distinct values, all below u) and count == -1 fall back to a binary search of `table`
+// between this line's and the next line's base.  Same comparisons as torch.searchsorted, same index; one HBM line.
+constexpr int LINE_SLOTS = 12;
 __device__ __forceinline__ int32_t lines_bucket(int lines_log2, float u) { return lut_bucket(lines_log2, u); }
-
-__device__ __forceinline__ int32_t cdf_resolve_line(const float4 hdr, const float4 c0, const float4 c1,
-                                                    const float* __restrict__ line, const float* __restrict__ cdf,
-                                                    int cdf_stride, const float* __restrict__ prob, int prob_stride,
-                                                    int64_t n_items, float u, float& pr) {
-  const int c = __float_as_int(hdr.x);
-  const int k = (c0.x < u) + (c0.y < u) + (c0.z < u) + (c0.w < u) + (c1.x < u) + (c1.y < u) + (c1.z < u) + (c1.w < u);
-  if (k < LINE_K || c <= LINE_K) {          // the padding is +inf, so k <= min(c, 8)
-    if (k < c) {
-      const float2 e = *reinterpret_cast<const float2*>(line + 12 + 2 * k);
-      pr = e.y;
-      return __float_as_int(e.x);
-    }
-    pr = hdr.z;
-    return __float_as_int(hdr.y);
-  }
-  // more than 8 distinct values in the bucket and u above the first 8: binary search in the full table
-  int32_t lo = __float_as_int(hdr.w), hi = __float_as_int(line[28]);
-  while (lo < hi) {
-    const int32_t mid = lo + ((hi - lo) >> 1);
-    if (cdf[(size_t)mid * cdf_stride] < u) lo = mid + 1; else hi = mid;
-  }
-  const int32_t last = (int32_t)(n_items - 1);
-  lo = lo > last ? last : lo;
-  pr = prob[(size_t)lo * prob_stride];
-  return lo;
-}
 
 __device__ __forceinline__ int32_t cdf_lookup_line(const float* __restrict__ lines, int lines_log2,
                                                    const float* __restrict__ cdf, int cdf_stride,
@@ -243,8 +222,26 @@ __device__ __forceinline__ int32_t cdf_lookup_line(const float* __restrict__ lin
                                                    float u, float& pr) {
   const float* line = lines + (size_t)lines_bucket(lines_log2, u) * 32;
   const float4* l4 = reinterpret_cast<const float4*>(line);
-  const float4 hdr = l4[0], c0 = l4[1], c1 = l4[2];
-  return cdf_resolve_line(hdr, c0, c1, line, cdf, cdf_stride, prob, prob_stride, n_items, u, pr);
+  const float4 c0 = l4[0], c1 = l4[1], c2 = l4[2];                       // four loads of ONE line, issued together
+  const int2 tail = *reinterpret_cast<const int2*>(line + 30);
+  const int k = (c0.x < u) + (c0.y < u) + (c0.z < u) + (c0.w < u) + (c1.x < u) + (c1.y < u) + (c1.z < u) + (c1.w < u) +
+                (c2.x < u) + (c2.y < u) + (c2.z < u) + (c2.w < u);
+  if (tail.y >= 0 && k < LINE_SLOTS) {
+    pr = line[12 + k];
+    const uint32_t w = __float_as_uint(line[24 + (k >> 1)]);
+    return tail.x + (int32_t)((k & 1) ? (w >> 16) : (w & 0xffffu));
+  }
+  // rare: > 12 distinct values in the bucket and u above the first 12, or a line whose ids do not fit 16-bit deltas
+  int32_t lo = tail.x, hi = __float_as_int(line[32 + 30]);               // base of the next line (a sentinel line closes the table)
+  const int32_t last = (int32_t)(n_items - 1);
+  hi = hi > last ? last : hi;
+  while (lo < hi) {
+    const int32_t mid = lo + ((hi - lo) >> 1);
+    if (cdf[(size_t)mid * cdf_stride] < u) lo = mid + 1; else hi = mid;
+  }
+  lo = lo > last ? last : lo;
+  pr = prob[(size_t)lo * prob_stride];
+  return lo;
 }
 
 // ---------------------------------------------------------------- wave helpers

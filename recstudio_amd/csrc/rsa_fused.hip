@@ -354,9 +354,6 @@ __device__ __forceinline__ float finish_score(int mode, float dot, float inorm2,
 #ifndef RSA_SSM_BATCH
 #define RSA_SSM_BATCH 4     // double-buffered: 2 * 4 row loads in flight per wave, 141 VGPRs at d = 128 (8: 180)
 #endif
-#ifndef RSA_FWD_LINES_AHEAD
-#define RSA_FWD_LINES_AHEAD 0     // 1: bucket line of a wave's next tile fetched one tile ahead -- 12 more live VGPRs (128), measured 2-4 % SLOWER
-#endif
 
 // loss = mean of the per-query losses, in the SAME launch, with ONE device-scope atomic per workgroup and no
 // second phase: every workgroup adds {its waves' loss sum as a 2^-30 fixed-point integer, 1 arrival} to one 64-bit
@@ -440,38 +437,22 @@ __global__ __launch_bounds__(256, QG ? RSA_QG_MIN_WAVES : RSA_FWD_MIN_WAVES) voi
 
   // Popularity sampler with the direct-lookup table: the draw and the LUT entry of the wave's NEXT tile are
   // fetched one tile ahead (5 VGPRs), so that a tile's row loads no longer wait behind the LUT round trip.
-  // (not in the training forward: 12 more live registers there cost a wave per SIMD)
-  const bool ahead_lines = RSA_FWD_LINES_AHEAD && !QG && QU && p.sampler == RSA_SAMPLER_POPULAR && p.lines != nullptr;
-  const bool ahead = ahead_lines || (RSA_FWD_LUT_AHEAD && QU && p.sampler == RSA_SAMPLER_POPULAR && p.lut != nullptr);
+  // (bucket lines are NOT fetched ahead: carrying a line's 12 values across a tile measured 2-4 % slower)
+  const bool ahead = RSA_FWD_LUT_AHEAD && QU && p.sampler == RSA_SAMPLER_POPULAR && p.lut != nullptr && p.lines == nullptr;
   float u_next = 0.f;
   float4 lut_next = make_float4(0.f, 0.f, 0.f, 0.f);
-#if RSA_FWD_LINES_AHEAD
-  float4 c0_next = make_float4(0.f, 0.f, 0.f, 0.f), c1_next = make_float4(0.f, 0.f, 0.f, 0.f);
-#endif
   auto fetch_ahead = [&](int64_t t) {
     const int64_t e2 = (t << 6) + lane;
     if (e2 < p.numel) {
       u_next = torch_rand_element(pc, (uint64_t)e2);
-      // one source pointer for both forms (the first 16 bytes of a bucket line play the LUT entry's role): separate
-      // if/else assignments of the carried registers made the compiler merge the stores through a pointer select
-      // and park the values in scratch
-      const float4* src = ahead_lines
-                              ? reinterpret_cast<const float4*>(p.lines + (size_t)lines_bucket(p.lines_log2, u_next) * 32)
-                              : reinterpret_cast<const float4*>(p.lut) + lut_bucket(p.guide_log2, u_next);
 #if RSA_LUT_NT
       {   // the table is read at random and an entry is never reused within a step: streaming hint
         typedef float v4f __attribute__((ext_vector_type(4)));
-        const v4f v = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(src));
+        const v4f v = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(p.lut) + lut_bucket(p.guide_log2, u_next));
         lut_next = make_float4(v.x, v.y, v.z, v.w);
       }
 #else
-      lut_next = src[0];
-#endif
-#if RSA_FWD_LINES_AHEAD
-      if (ahead_lines) {      // + the 8 values of the draw's bucket: two more 16-byte loads of the SAME line
-        c0_next = src[1];
-        c1_next = src[2];
-      }
+      lut_next = reinterpret_cast<const float4*>(p.lut)[lut_bucket(p.guide_log2, u_next)];
 #endif
     }
   };
@@ -483,9 +464,6 @@ __global__ __launch_bounds__(256, QG ? RSA_QG_MIN_WAVES : RSA_FWD_MIN_WAVES) voi
     const int act = e < p.numel;
     const float u_cur = u_next;
     const float4 lut_cur = lut_next;
-#if RSA_FWD_LINES_AHEAD
-    const float4 c0_cur = c0_next, c1_cur = c1_next;
-#endif
 
     // ---- 0. (query-uniform path) the two scalar loads everything else hangs off -- query row index and
     // positive id -- are issued first so that their latency hides under the sampling chain below
@@ -510,15 +488,6 @@ __global__ __launch_bounds__(256, QG ? RSA_QG_MIN_WAVES : RSA_FWD_MIN_WAVES) voi
         const float u = ahead ? u_cur : torch_rand_element(pc, (uint64_t)e);
         float pr;
         if (ahead) {
-#if RSA_FWD_LINES_AHEAD
-          if (ahead_lines) {
-            const float* line = p.lines + (size_t)lines_bucket(p.lines_log2, u) * 32;
-            if (p.table_prob)
-              id = cdf_resolve_line(lut_cur, c0_cur, c1_cur, line, p.table_prob, 2, p.table_prob + 1, 2, p.n_items, u, pr);
-            else
-              id = cdf_resolve_line(lut_cur, c0_cur, c1_cur, line, p.table, 1, p.pop_prob, 1, p.n_items, u, pr);
-          } else
-#endif
           if (p.table_prob)
             id = cdf_resolve_lut<2>(lut_cur, reinterpret_cast<const float4*>(p.lut), p.table_prob, p.table_prob + 1, 2,
                                     p.n_items, p.guide_log2, u, pr);

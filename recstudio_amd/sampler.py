@@ -102,22 +102,24 @@ def build_guide_table(table: Tensor, guide_log2: Optional[int] = None):
     return guide.to(torch.int32), guide_log2
 
 
-LINE_K = 8          # distinct CDF values held by one bucket line (rsa_common.hpp)
+LINE_SLOTS = 12     # entry slots of one bucket line (rsa_common.hpp)
 
 
 def build_cdf_lines(table: Tensor, pop_prob: Tensor, lines_log2: Optional[int] = None, max_bytes: int = 2 << 30,
-                    overflow_target: float = 2e-4):
+                    overflow_target: float = 1e-2):
     """BUCKET LINES: the one-HBM-line form of ``torch.searchsorted(table, u)`` (layout: include/recstudio_amd.h,
-    ``rsa_fused_args.cdf_lines``).  Bucket b covers u in [b, b+1) / 2**lines_log2 and its 128-byte line lists the
-    first LINE_K DISTINCT values of the CDF inside it with their {id, probability}, plus the first distinct entry
-    above the bucket.  Items whose CDF value equals their predecessor's (zero probability, or a probability the fp32
-    cumsum absorbed) can never be returned by a lower-bound search and are left out, so a catalog where most items
-    were never seen does not crowd the lines.  Cut points are compared in float64, where the fp32 CDF and b / 2**g
-    are both exact -- same argument as ``build_guide_table``.
+    ``rsa_fused_args.cdf_lines``).  Bucket b covers u in [b, b+1) / 2**lines_log2; its 128-byte line lists the bucket's
+    first distinct CDF values, then -- when there is room -- the first distinct entry ABOVE the bucket, each with its
+    probability and its id as a 16-bit offset from the line's base id: 12 slots of {cdf fp32, prob fp32, delta u16} +
+    base + count = 128 bytes.  The slot of a draw is #{cdf[i] < u}.  Items whose CDF value equals their predecessor's
+    (zero probability, or a probability the fp32 cumsum absorbed) can never be returned by a lower-bound search and are
+    left out, so a catalog where most items were never seen does not crowd the lines.  Cut points are compared in
+    float64, where the fp32 CDF and b / 2**g are both exact -- same argument as ``build_guide_table``.
 
     ``lines_log2`` None: the smallest size (>= 2**4 buckets) for which at most ``overflow_target`` of the buckets
-    (= of the draws, u being uniform) hold more than LINE_K distinct values AND would need the binary-search
-    fallback, capped at ``max_bytes``.  Returns (lines [2**g, 32] float32, g)."""
+    (= of the draws, u being uniform) hold more than 11 distinct values (a 12th leaves no room for the entry above the
+    bucket; a draw beyond the 12th falls back to a binary search), capped at ``max_bytes``.
+    Returns (lines [2**g + 1, 32] float32 -- the last line is a sentinel closing the fallback ranges --, g)."""
     t = table.detach().cpu().to(torch.float32).contiguous()
     pp = pop_prob.detach().cpu().to(torch.float32).contiguous()
     n = t.numel()
@@ -134,18 +136,16 @@ def build_cdf_lines(table: Tensor, pop_prob: Tensor, lines_log2: Optional[int] =
         gd[K] = nd
         return gd
 
+    def crowded(g):
+        c = cuts_of(g)
+        return float(((c[1:] - c[:-1]) > LINE_SLOTS - 1).double().mean())
+
     if lines_log2 is None:
         g_max = max(4, int(np.floor(np.log2(max_bytes / 128))))
-        g = int(min(g_max, max(4, int(np.ceil(np.log2(max(nd, 2) / 2.0))))))            # ~2 entries per bucket
-        while g > 4:                                              # as small as the overflow target allows
-            c = cuts_of(g - 1)
-            if float(((c[1:] - c[:-1]) > LINE_K).double().mean()) > overflow_target:
-                break
+        g = int(min(g_max, max(4, int(np.ceil(np.log2(max(nd, 2) / 4.0))))))            # ~4 entries per bucket
+        while g > 4 and crowded(g - 1) <= overflow_target:       # as small as the overflow target allows
             g -= 1
-        while g < g_max:
-            c = cuts_of(g)
-            if float(((c[1:] - c[:-1]) > LINE_K).double().mean()) <= overflow_target:
-                break
+        while g < g_max and crowded(g) > overflow_target:
             g += 1
         lines_log2 = g
     gd = cuts_of(lines_log2)
@@ -153,23 +153,32 @@ def build_cdf_lines(table: Tensor, pop_prob: Tensor, lines_log2: Optional[int] =
     lo, hi = gd[:-1], gd[1:]
     cnt = hi - lo
     last = n - 1
-    lines = torch.zeros(K, 32, dtype=torch.float32)
     as_f = lambda x: x.to(torch.int32).view(torch.float32)       # noqa: E731  int32 bit patterns in a float tensor
-    lines[:, 0] = as_f(cnt)
-    nxt = hi.clamp(max=nd - 1)
-    past = hi >= nd                                               # nothing above the bucket: searchsorted returns n -> clamped
-    nxt_id = torch.where(past, torch.full_like(hi, last), ids[nxt])
-    lines[:, 1] = as_f(nxt_id)
-    lines[:, 2] = pp[nxt_id]
-    lines[:, 3] = as_f(torch.where(lo < nd, ids[lo.clamp(max=nd - 1)], torch.full_like(lo, n)))   # fallback range in `table`
-    lines[:, 28] = as_f(torch.where(past, torch.full_like(hi, n), ids[nxt]))
-    for k in range(LINE_K):
+    lines = torch.zeros(K + 1, 32, dtype=torch.float32)
+    slot_id = torch.zeros(K, LINE_SLOTS, dtype=torch.int64)
+    for k in range(LINE_SLOTS):
         e = lo + k
-        ok = e < hi
-        e = e.clamp(max=nd - 1)
-        lines[:, 4 + k] = torch.where(ok, cdf[e], torch.full((K,), float('inf')))
-        lines[:, 12 + 2 * k] = as_f(torch.where(ok, ids[e], torch.zeros_like(e)))
-        lines[:, 13 + 2 * k] = torch.where(ok, pp[ids[e]], torch.zeros(K))
+        used = e <= hi                                            # real entries (e < hi) and the one above the bucket (e == hi)
+        past = e >= nd                                            # nothing above: searchsorted returns n -> clamped to n - 1
+        ec = e.clamp(max=nd - 1)
+        idk = torch.where(past, torch.full_like(e, last), ids[ec])
+        slot_id[:, k] = torch.where(used, idk, torch.zeros_like(idk))
+        lines[:K, k] = torch.where(used & ~past, cdf[ec], torch.full((K,), float('inf')))
+        lines[:K, 12 + k] = torch.where(used, pp[idk], torch.zeros(K))
+    base = slot_id[:, 0]
+    used_cols = torch.arange(LINE_SLOTS).view(1, -1) <= cnt.view(-1, 1)
+    delta = torch.where(used_cols, slot_id - base.view(-1, 1), torch.zeros_like(slot_id))
+    wide = (delta > 0xffff).any(1)                                # ids too far apart for 16-bit offsets: searched instead
+    delta = delta.clamp(min=0, max=0xffff)
+    packed = (delta[:, 0::2] | (delta[:, 1::2] << 16))            # two uint16 per word, even slot in the low half
+    packed = torch.where(packed >= (1 << 31), packed - (1 << 32), packed)
+    lines[:K, 24:30] = packed.to(torch.int32).view(torch.float32)
+    # fallback range in `table`: [first id at or above the bucket's lower cut, the next line's]
+    first = torch.where(lo < nd, ids[lo.clamp(max=nd - 1)], torch.full_like(lo, last))
+    lines[:K, 30] = as_f(torch.where(wide, first, base))
+    lines[:K, 31] = as_f(torch.where(wide, torch.full_like(cnt, -1), cnt))
+    lines[K, 30] = as_f(torch.tensor([last]))[0]
+    lines[K, :12] = float('inf')
     return lines, lines_log2
 
 

@@ -38,7 +38,7 @@ def _tables(N, U, d, seed):
 # --------------------------------------------------------------------------- bucket lines
 def test_bucket_lines_golden_and_searchsorted(ra, golden):
     """cdf_lines lookup == the reference fixture ids (edge uniforms included), at the automatic size and at tiny
-    forced sizes where most draws take the > 8-entries fallback; and == torch.searchsorted on dense random uniforms
+    forced sizes where most draws take the > 12-entries fallback; and == torch.searchsorted on dense random uniforms
     of a 120 000-item table."""
     g = golden('popular')
     for mode in (0, 1, 2):

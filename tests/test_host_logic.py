@@ -143,21 +143,21 @@ def test_popular_sampler_tables_equal_reference_buffers(golden):
 
 
 def lookup_with_lines(lines, g, table, prob, u):
-    """numpy restatement of rsa_common.hpp cdf_resolve_line (layout: include/recstudio_amd.h, cdf_lines)."""
+    """numpy restatement of rsa_common.hpp cdf_lookup_line (layout: include/recstudio_amd.h, cdf_lines)."""
     K = 1 << g
     b = np.clip((u * np.float32(K)).astype(np.int64), 0, K - 1)
     li = lines.view(np.int32)
+    lu = lines.view(np.uint32)
     ids, pr = np.empty(u.shape, np.int64), np.empty(u.shape, np.float32)
     n = len(table)
     for i, (bb, uu) in enumerate(zip(b, u)):
-        c, k = li[bb, 0], int((lines[bb, 4:12] < uu).sum())
-        if k < 8 or c <= 8:
-            if k < c:
-                ids[i], pr[i] = li[bb, 12 + 2 * k], lines[bb, 13 + 2 * k]
-            else:
-                ids[i], pr[i] = li[bb, 1], lines[bb, 2]
+        k = int((lines[bb, :12] < uu).sum())
+        base, cnt = int(li[bb, 30]), int(li[bb, 31])
+        if cnt >= 0 and k < 12:
+            w = int(lu[bb, 24 + (k >> 1)])
+            ids[i], pr[i] = base + ((w >> 16) if k & 1 else (w & 0xffff)), lines[bb, 12 + k]
         else:
-            lo, hi = li[bb, 3], li[bb, 28]
+            lo, hi = base, min(int(li[bb + 1, 30]), n - 1)
             while lo < hi:
                 mid = lo + ((hi - lo) >> 1)
                 if table[mid] < uu:
@@ -172,7 +172,7 @@ def lookup_with_lines(lines, g, table, prob, u):
 def test_bucket_lines_return_searchsorted_index(golden):
     """The bucket-line table (one 128-byte line per draw on the GPU) resolves to exactly torch.searchsorted's index
     and that item's probability: reference fixture tables (edge uniforms included) and synthetic catalogs where half
-    the items have zero probability, with forced tiny tables so that the > 8-entries fallback is exercised."""
+    the items have zero probability, with forced tiny tables so that the > 12-entries fallback is exercised."""
     from recstudio_amd import PopularSamplerModel
     g = golden('popular')
     gen = torch.Generator().manual_seed(0)
@@ -181,9 +181,14 @@ def test_bucket_lines_return_searchsorted_index(golden):
         cnt = (torch.rand(n, generator=gen) ** 6 * 500).long()
         cnt[torch.rand(n, generator=gen) < 0.5] = 0
         cases.append((cnt, mode, glog, np.zeros(0, np.float32)))
+    sparse = torch.zeros(400_000, dtype=torch.long)              # seen items > 65535 ids apart: 16-bit offsets overflow
+    sparse[::70_001] = 5
+    sparse[1000:1040] = 3
+    cases.append((sparse, 0, 3, np.zeros(0, np.float32)))
+    cases.append((sparse, 0, None, np.zeros(0, np.float32)))
     for cnt, mode, glog, u_fix in cases:
         ps = PopularSamplerModel(cnt, mode=mode, lookup='lines', lines_log2=glog)
-        assert ps.guide is None and ps.cdf_lut is None and ps.cdf_lines.shape == (1 << ps.lines_log2, 32)
+        assert ps.guide is None and ps.cdf_lut is None and ps.cdf_lines.shape == ((1 << ps.lines_log2) + 1, 32)
         t, p = ps.table.numpy(), ps.pop_prob.numpy()
         u = np.concatenate([u_fix, t, np.nextafter(t, np.float32(0)), np.nextafter(t, np.float32(2)),
                             np.random.default_rng(mode).random(4000, dtype=np.float32),
