@@ -177,6 +177,12 @@ __device__ __forceinline__ void fold(float (&d)[L], int sub, int step) {
 // Rows are visited BATCH at a time, batch b = rows {b, b+NB, b+2NB, ...} of the lane group, and
 // each batch is folded to one value right away (the depth-first order of the transpose-reduce
 // tree), so only BATCH row fragments + NB partials are live instead of LPR of each.
+#ifndef RSA_FWD_PLAIN_PIPE
+#define RSA_FWD_PLAIN_PIPE 0
+#endif
+#ifndef RSA_FWD_QNT
+#define RSA_FWD_QNT 0      // 1: the query and positive rows of a big-table launch are streamed (nontemporal) too
+#endif
 #ifndef RSA_FWD_PIN
 #define RSA_FWD_PIN 0      // 0: batches ordered by sched heuristics (round 1);  1: batch b+1's loads pinned behind batch b's
 #endif                     // fold by a data dependence;  2: one batch requested ahead (two batches of fragments live)
@@ -329,6 +335,40 @@ __device__ __forceinline__ void tile_rows_qg(const float* __restrict__ table, in
     __builtin_amdgcn_sched_barrier(0);
   }
 #endif
+}
+
+// Plain (no loss) counterpart of the pipelined training tile: batches of RSA_QG_BATCH rows, batch b+1 requested while
+// batch b is reduced with butterfly sums, order pinned by data dependences.  Query-uniform inner product only.
+template <int LPR, bool NT>
+__device__ __forceinline__ void tile_rows_pipe(const float* __restrict__ table, int32_t id_lane,
+                                               const Frag<LPR, false>& qf, float& dot) {
+  using F = Frag<LPR, false>;
+  constexpr int D = LPR * 4;
+  constexpr int BATCH = LPR < RSA_QG_BATCH ? LPR : RSA_QG_BATCH;
+  constexpr int NB = LPR / BATCH;
+  const int lane = lane_id();
+  const int sub = lane % LPR;
+  dot = 0.f;
+  F x[2][BATCH];
+  int gb = lane - sub;
+  auto request = [&](int b) __attribute__((always_inline)) {
+#pragma unroll
+    for (int k = 0; k < BATCH; ++k) {
+      const int32_t rid = __shfl(id_lane, gb + b * BATCH + k, 64);
+      frag_load<LPR, false, NT>(x[b & 1][k], table + (size_t)rid * D, sub, D);
+    }
+  };
+  request(0);
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    if (b + 1 < NB) request(b + 1);
+#pragma unroll
+    for (int k = 0; k < BATCH; ++k) {
+      const float dk = group_sum<LPR>(frag_dot<LPR, false>(x[b & 1][k], qf));
+      dot = sub == b * BATCH + k ? dk : dot;
+    }
+    asm volatile("" : "+v"(gb), "+v"(dot));
+  }
 }
 
 __device__ __forceinline__ float finish_score(int mode, float dot, float inorm2, float qnorm2) {
@@ -516,10 +556,10 @@ __global__ __launch_bounds__(256, QG ? RSA_QG_MIN_WAVES : RSA_FWD_MIN_WAVES) voi
     float qn2_u = 0.f;
     bool empty_slot = false;     // packed_keys < 0: the slot's score is 0
     if constexpr (QU) {
-      frag_load<LPR, GENERIC>(qf, p.query + (size_t)qrow_u * D, sub, D);
+      frag_load<LPR, GENERIC, NT && RSA_FWD_QNT>(qf, p.query + (size_t)qrow_u * D, sub, D);
       pad = pid_u == 0;
       pid_u = pid_u < 0 ? 0 : (pid_u >= p.n_items ? p.n_items - 1 : pid_u);
-      frag_load<LPR, GENERIC>(px, p.item_table + (size_t)pid_u * D, sub, D);   // row 0 when there is no positive
+      frag_load<LPR, GENERIC, NT && RSA_FWD_QNT>(px, p.item_table + (size_t)pid_u * D, sub, D);   // row 0 when there is no positive
       if constexpr (COS) qn2_u = group_sum<LPR>(frag_dot<LPR, GENERIC>(qf, qf));
     } else {
       m_lane = act ? e / n : 0;
@@ -565,6 +605,8 @@ __global__ __launch_bounds__(256, QG ? RSA_QG_MIN_WAVES : RSA_FWD_MIN_WAVES) voi
           atomicAdd(g + 0, qacc.x); atomicAdd(g + 1, qacc.y); atomicAdd(g + 2, qacc.z); atomicAdd(g + 3, qacc.w);
         }
       }
+    } else if constexpr (RSA_FWD_PLAIN_PIPE && QU && !COS && !GENERIC) {
+      tile_rows_pipe<LPR, NT>(p.item_table, id, qf, dot);
     } else {
       tile_rows<LPR, GENERIC, COS, QU, NT>(p.item_table, D, id, p.query, qrow_lane, qf, dot, in2, qn2);
     }

@@ -41,7 +41,7 @@ def f_uni():
     buf['u'] = ra.ops.fused_forward(item, user, n, query_index=uid, pos_ids=pos, sampler=nat.SAMPLER_UNIFORM, out=buf.get('u'))
 report('uniform sampler', timeit(f_uni), bytes_per_triplet(d, n, False) * B * n)
 for glog in (22, 23, 24):
-    ps = ra.PopularSamplerModel(counts, guide_log2=glog).to(dev)
+    ps = ra.PopularSamplerModel(counts, guide_log2=glog, lookup='lut').to(dev)
     for logp, pairs, lut in ((True, True, False), (True, True, True), (True, False, True), (False, True, True)):
         key = f'p{glog}{logp}{pairs}{lut}'
         def f_pop():

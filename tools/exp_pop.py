@@ -31,7 +31,7 @@ for N, glogs in ((10_000_001, (23,)), (100_000_001, (25,))):
         buf['g'] = ra.ops.fused_forward(item, user, n, query_index=uid, pos_ids=pos, neg_ids=ids, out=buf.get('g'))
     print(f'N={N} given ids: {timeit(f_given) * 1e3:.1f} us', flush=True)
     for glog in glogs:
-        ps = ra.PopularSamplerModel(counts, guide_log2=glog).to(dev)
+        ps = ra.PopularSamplerModel(counts, guide_log2=glog, lookup='lut').to(dev)
         key = f'p{glog}'
         def f_pop():
             buf[key] = ra.ops.fused_forward(item, user, n, query_index=uid, pos_ids=pos, sampler=nat.SAMPLER_POPULAR,

@@ -10,8 +10,7 @@ q3 = torch.randn(b3, d, device=dev) * 0.02
 pos3 = torch.randint(1, N, (b3,), device=dev)
 counts = zipf_counts(10_000_001, 100_000_000)
 ps3 = ra.PopularSamplerModel(counts[:N]).to(dev)
-kw3 = dict(pos_ids=pos3, sampler=nat.SAMPLER_POPULAR, table=ps3.table, pop_prob=ps3.pop_prob, guide=ps3.guide,
-           guide_log2=ps3.guide_log2, table_prob=ps3.table_prob, cdf_lut=ps3.cdf_lut)
+kw3 = dict(pos_ids=pos3, sampler=nat.SAMPLER_POPULAR, **ps3.lookup_kwargs())
 def T(fn, reps=30, warm=5):
     for _ in range(warm): fn()
     torch.cuda.synchronize(); t0 = time.perf_counter()
@@ -20,7 +19,7 @@ def T(fn, reps=30, warm=5):
 buf = {}
 def fwd():
     buf['o'] = ra.ops.fused_forward(item, q3, n3, out=buf.get('o'), **kw3)
-print('guide_log2', ps3.guide_log2)
+print('lines_log2', ps3.lines_log2)
 print('fwd popular n=256: %.4f ms' % T(fwd))
 o = buf['o']
 print('ssm loss:          %.4f ms' % T(lambda: ra.ops.pairwise_loss(nat.LOSS_SSM, o['pos_score'], o['neg_score'], o['pos_logp'], o['neg_logp'])))
