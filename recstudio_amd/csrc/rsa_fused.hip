@@ -811,8 +811,7 @@ __global__ __launch_bounds__(256) void fused_ssm_kernel(const FwdParams p) {
       if constexpr (QG) {
         tile_rows_ssm<LPR, NT>(p.item_table, id, lq, has_lq, qf, dot, gm, qacc);
       } else {
-        float u1, u2;
-        tile_rows<LPR, false, false, true, NT>(p.item_table, D, id, p.query, 0, qf, dot, u1, u2);
+        tile_rows_pipe<LPR, NT>(p.item_table, id, qf, dot);      // (the transposed-fold tile needs 164 VGPRs in this frame)
       }
       st_out(&p.neg_score[e], dot);
       const float z = dot - lq;

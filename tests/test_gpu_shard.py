@@ -174,6 +174,15 @@ def _two_rank_worker(rank, world, port, backend, result_dir):
     else:
         dist.init_process_group('gloo', rank=rank, world_size=world)
         comm = StagedDist(dist)
+    def gather_cpu(t):          # every rank's `t` (NCCL moves device tensors only)
+        parts = [torch.empty_like(t if backend == 'nccl' else t.cpu()) for _ in range(world)]
+        dist.all_gather(parts, t if backend == 'nccl' else t.cpu())
+        return [p.cpu() for p in parts]
+
+    def sum_cpu(t):
+        x = t.clone() if backend == 'nccl' else t.cpu().clone()
+        dist.all_reduce(x)
+        return x.cpu()
     try:
         N, U, d, B, n = 30_011, 500, 128, 257, 64
         g = torch.Generator().manual_seed(3)
@@ -197,8 +206,7 @@ def _two_rank_worker(rank, world, port, backend, result_dir):
                 np.testing.assert_allclose(out['neg_score'].cpu(), want_n, rtol=1e-4, atol=1e-6)
                 np.testing.assert_allclose(out['pos_score'].cpu(), want_p, rtol=1e-4, atol=1e-6)
                 # G-invariance on the device stream: the two ranks' blocks == one draw of [2B, n] from the same state
-                blocks = [torch.empty(B, n, dtype=torch.int64) for _ in range(world)]
-                dist.all_gather(blocks, ids.cpu())
+                blocks = gather_cpu(ids)
                 gen1 = torch.Generator(device=dev).manual_seed(17 + si)
                 for _ in range(step + 1):
                     with ra.rng.sharded_stream(0, 1, gen1):
@@ -210,8 +218,7 @@ def _two_rank_worker(rank, world, port, backend, result_dir):
                 qg = table.backward(out['route'], dpos, dneg, ig)
                 ig2, _, qg2 = ra.ops.fused_backward(item_d, user, ids, dneg, query_index=uid, pos_ids=pos, dpos=dpos)
                 np.testing.assert_allclose(qg.cpu(), qg2.cpu(), rtol=2e-4, atol=1e-8)
-                total = ig2.cpu()                        # this rank's contribution to every row ...
-                dist.all_reduce(total)                   # ... summed over the ranks
+                total = sum_cpu(ig2)                     # this rank's contribution to every row, summed over the ranks
                 np.testing.assert_allclose(ig.cpu(), total[lo:hi], rtol=2e-4, atol=1e-8)
             table.check_overflow()
         # the sharded full-catalog pass
@@ -229,8 +236,7 @@ def _two_rank_worker(rank, world, port, backend, result_dir):
         tbl = ShardedItemTable(item_d[lo:hi].clone(), plan, rank, comm)
         trainer = ShardedRetriever(tbl, tower, ra.UniformSampler(N), ra.BPRLoss(), 64, item_sgd_lr=0.5)
         l0 = trainer.training_step(uid, pos)
-        tot = l0.detach().cpu().clone()
-        dist.all_reduce(tot)
+        tot = sum_cpu(l0.detach().reshape(1))
         assert abs(float(tot) - 0.6931) < 0.05 and torch.isfinite(tower.weight.grad).all()
         open(os.path.join(result_dir, f'ok{rank}'), 'w').write('ok')
     finally:
