@@ -358,8 +358,9 @@ int rsa_row_sqnorm(const float* table, int64_t n_rows, int32_t dim, int32_t scor
  *   dim must be 32, 64 or 128 (RSA_ERR_UNSUPPORTED otherwise).
  *   score_mode RSA_SCORE_COS / RSA_SCORE_EUC: the dot products of a tile are turned into cosine / negative squared
  *     distance in the tile epilogue, before logsumexp / filter / store:  cos = dot * item_aux * query_aux,
- *     euc = 2 dot - item_aux - query_aux, with item_aux [n_items - 1] (entry i-1 belongs to item row i; 16-byte
- *     aligned) and query_aux [B] from rsa_row_sqnorm of the same mode; both null for RSA_SCORE_IP.
+ *     euc = 2 dot - item_aux - query_aux, with item_aux [n_items - 1 + 64] (entry i-1 belongs to item row i; 16-byte
+ *     aligned; the 64 trailing floats are padding the last tile of an item range may read -- any values) and
+ *     query_aux [B] from rsa_row_sqnorm of the same mode; both null for RSA_SCORE_IP.
  *   workspace: device scratch of rsa_fullscore_workspace_bytes(B, n_items, k) bytes. */
 int64_t rsa_fullscore_workspace_bytes(int64_t n_query, int64_t n_items, int32_t k);
 int rsa_fullscore(const float* item_table, int64_t n_items, int32_t dim,
