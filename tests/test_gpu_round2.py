@@ -497,3 +497,84 @@ def test_softmax_loss_second_branch_golden(ra, golden):
     v1.backward()
     rel_close(v1.detach().cpu(), g['softmax_full_loss'], rtol=1e-5)
     rel_close(all1.grad.cpu(), g['softmax_full_grad_all_score'], rtol=1e-4, atol=1e-8)
+
+
+def test_config2_bench_shape_properties(ra):
+    """configs[2] at the bench's size (N = 1e6 + 1, d = 128, B = 8192 prefixes, n = 256, popularity sampler, fused
+    SampledSoftmax with the in-forward query gradient): size-independent properties + an oracle spot check."""
+    N, d, B, n = 1_000_001, 128, 8192, 256
+    g = torch.Generator(device=DEV).manual_seed(1)
+    iw = torch.empty(N, d, device=DEV).normal_(0, 0.3, generator=g)
+    iw[0] = 0
+    q = torch.empty(B, d, device=DEV).normal_(0, 0.3, generator=g)
+    counts = (torch.rand(N, generator=torch.Generator().manual_seed(2)) ** 8 * 1e4).long()
+    seen = torch.nonzero(counts[1:] > 0).flatten() + 1          # positives are items that occur (log-prob finite)
+    pos = seen[torch.randint(0, seen.numel(), (B,), generator=torch.Generator().manual_seed(3))].to(DEV)
+    ps = ra.PopularSamplerModel(counts).to(DEV)
+    assert ps.cdf_lines is not None
+    kw = dict(pos_ids=pos, sampler=ra._native.SAMPLER_POPULAR, **ps.lookup_kwargs())
+    torch.manual_seed(2022)
+    o = ra.ops.fused_forward(iw, q, n, fused_loss='ssm', want_query_grad=True, **kw)
+    # (1) ids == the reference's op sequence on this device; log-probs of those ids
+    torch.manual_seed(2022)
+    want = torch.searchsorted(ps.table, torch.rand(B, n, device=DEV)).clamp_(max=N - 1)
+    assert torch.equal(o['neg_ids'], want)
+    rel_close(o['neg_logp'].cpu(), torch.log(ps.pop_prob[want]).cpu(), rtol=1e-6, atol=1e-7)
+    # (2) the mean reduced in the kernel == mean of the row losses; softmax sums to one: sum_j dneg + dpos == 0
+    rel_close(o['loss'].cpu(), o['row_loss'].double().mean().float().cpu(), rtol=1e-6)
+    assert float((o['dneg'].double().sum(1) + o['dpos'].double()).abs().max()) < 1e-9
+    assert float(o['dneg'].min()) >= 0 and float(o['dpos'].max()) <= 0
+    # (3) idempotence: the same ids given (with their log-probs) reproduce loss and gradients bit for bit
+    again = ra.ops.fused_forward(iw, q, n, pos_ids=pos, neg_ids=o['neg_ids'], fused_loss='ssm', want_query_grad=True,
+                                 pos_logp=o['pos_logp'], neg_logp=o['neg_logp'])
+    assert torch.equal(again['loss'], o['loss']) and torch.equal(again['dneg'], o['dneg'])
+    assert torch.equal(again['query_grad'], o['query_grad'])
+    # (4) == the two-launch path (scores, then rsa_pairwise_loss)
+    torch.manual_seed(2022)
+    c = ra.ops.fused_forward(iw, q, n, **kw)
+    loss2, dpos2, dneg2, _ = ra.ops.pairwise_loss(ra._native.LOSS_SSM, c['pos_score'], c['neg_score'], c['pos_logp'], c['neg_logp'])
+    rel_close(o['loss'].cpu(), loss2.cpu(), rtol=1e-5)
+    rel_close(o['dneg'].cpu(), dneg2.cpu(), rtol=1e-4, atol=1e-12)
+    # (5) oracle spot check on 48 whole rows: loss terms and d loss/d query
+    sel = torch.randint(0, B, (48,))
+    qs = q[sel.to(DEV)].cpu().clone().requires_grad_(True)
+    ids = o['neg_ids'][sel.to(DEV)].cpu()
+    psr = (qs * iw[pos[sel.to(DEV)]].cpu()).sum(-1)
+    nsr = (qs.unsqueeze(1) * iw[ids.to(DEV)].cpu()).sum(-1)
+    z = torch.cat([(psr - o['pos_logp'][sel.to(DEV)].cpu()).unsqueeze(1), nsr - o['neg_logp'][sel.to(DEV)].cpu()], 1)
+    rows = torch.logsumexp(z, 1) - z[:, 0]
+    rel_close(o['row_loss'][sel.to(DEV)].cpu(), rows.detach(), rtol=1e-4, atol=1e-6)
+    (rows.sum() / B).backward()
+    rel_close(o['query_grad'][sel.to(DEV)].cpu(), qs.grad, rtol=3e-4, atol=1e-9)
+
+
+def test_config1_headline_shape_fused_bpr_properties(ra):
+    """configs[1] at the bench's batch (B = 65 536, n = 64, N = 1e7 + 1, popularity sampler through the bucket lines):
+    the single-launch step's ids == torch's, loss == the separate loss kernel's on the same scores, the in-kernel mean ==
+    mean(row_loss), and the in-forward query gradient == the backward kernel's."""
+    N, U, d, B, n = 10_000_001, 1_000_001, 128, 65536, 64
+    g = torch.Generator(device=DEV).manual_seed(1)
+    iw = torch.empty(N, d, device=DEV).normal_(0, 0.1, generator=g)
+    iw[0] = 0
+    uw = torch.empty(U, d, device=DEV).normal_(0, 0.1, generator=g)
+    counts = (torch.rand(N, generator=torch.Generator().manual_seed(2)) ** 8 * 1e4).long()
+    ps = ra.PopularSamplerModel(counts).to(DEV)
+    uid = torch.randint(1, U, (B,), device=DEV, generator=g)
+    pos = torch.randint(1, N, (B,), device=DEV, generator=g)
+    kw = dict(query_index=uid, pos_ids=pos, sampler=ra._native.SAMPLER_POPULAR, **ps.lookup_kwargs())
+    torch.manual_seed(5)
+    o = ra.ops.fused_forward(iw, uw, n, fused_bpr=True, want_query_grad=True, **kw)
+    torch.manual_seed(5)
+    want = torch.searchsorted(ps.table, torch.rand(B, n, device=DEV)).clamp_(max=N - 1)
+    assert torch.equal(o['neg_ids'], want)
+    rel_close(o['loss'].cpu(), o['row_loss'].double().mean().float().cpu(), rtol=1e-6)
+    loss2, dpos2, dneg2, _ = ra.ops.pairwise_loss(ra._native.LOSS_BPR, o['pos_score'], o['neg_score'])
+    rel_close(o['loss'].cpu(), loss2.cpu(), rtol=1e-5)
+    rel_close(o['dneg'].cpu(), dneg2.cpu(), rtol=1e-4, atol=1e-12)
+    _, _, qg = ra.ops.fused_backward(iw, uw, o['neg_ids'], o['dneg'], query_index=uid, pos_ids=pos, dpos=o['dpos'],
+                                     dense_item_grad=False, row_item_grad=False, want_query_grad=True)
+    rel_close(o['query_grad'].cpu(), qg.cpu(), rtol=3e-4, atol=1e-10)
+    # run-to-run reproducibility of the in-kernel reduction (fixed-point, order-independent)
+    torch.manual_seed(5)
+    o2 = ra.ops.fused_forward(iw, uw, n, fused_bpr=True, want_query_grad=True, **kw)
+    assert torch.equal(o2['loss'], o['loss'])
