@@ -53,9 +53,10 @@ struct PhiloxCall {
 
 // ---------------------------------------------------------------- caller-owned reduction scratch
 // Layout of the rsa_scratch_bytes() block (zero-filled once by the caller):
-//   [0]     arrival counter of the in-kernel loss reduction (self-resetting)
+//   [0]     NaN / inf flag word of the in-kernel loss reduction (cleared by the kernel that read it)
 //   [64]    valid-row counter of the BCE losses (reset by a memset before each use)
-//   [256]   one float per workgroup of the fused forward (grid <= SCRATCH_MAX_GRID)
+//   [256]   64-bit {arrivals, fixed-point loss sum} words of the in-kernel loss reduction: the top word, then 32
+//           sub-words 128 bytes apart (self-resetting; 4.2 KB of the 16 KB reserved here)
 //   [256 + 4 * SCRATCH_MAX_GRID]   256 stage-1 partials of rsa_mean_rows
 constexpr int SCRATCH_MAX_GRID = 4096;
 constexpr int64_t SCRATCH_COUNTER = 0, SCRATCH_BCE_COUNT = 64, SCRATCH_FUSED_PARTIALS = 256,

@@ -52,9 +52,9 @@ struct FwdParams {
   float* row_loss;   // fused BPR epilogue (nullable): per-query loss, d loss/d pos, d loss/d neg
   float* dpos;
   float* dneg;
-  float* loss_out;              // fused BPR epilogue: mean of row_loss, reduced by the last workgroup to finish
-  unsigned int* done_counter;   //   (self-resetting arrival counter + one partial sum per workgroup, owned by the library)
-  float* loss_partials;
+  float* loss_out;              // fused loss epilogue: mean of row_loss, reduced in the same launch (reduce_mean_loss)
+  unsigned int* done_counter;   //   NaN / inf flag word and the {arrivals, fixed-point sum} words, both in the CALLER's
+  float* loss_partials;         //   reduce_scratch (rsa_common.hpp, "caller-owned reduction scratch")
   const uint64_t* offset_dev;   // nullable: Philox offset read at run time (graph replays)
   const int64_t* packed_keys;   // num_neg == 1, GIVEN: element e = (query row << 32) | item row (sharded owner side)
   float* qgrad;      // fused BPR epilogue (nullable): [M, dim] d loss / d query row, accumulated from the rows in flight
