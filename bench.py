@@ -374,7 +374,19 @@ def main():
                 full_lse(qq5, w5).mean().backward()
             t_sm = time_gpu(softmax_step, 5, 2) * 1e3
             extra['fullscore']['softmax_train_step_ms'] = round(t_sm, 3)
-            extra['fullscore']['softmax_train_step_tflops'] = round(4 * flops / t_sm / 1e9, 1)   # lse GEMM + softmax recompute + 2 gradient GEMMs
+            # where the step goes: in-tree MFMA kernels (forward logsumexp, softmax recompute that writes [B, N-1] once)
+            # vs the two plain library GEMMs of the backward (rocBLAS through torch.matmul; DESIGN.md 4.4 for why they stay)
+            lse5 = ra.ops.fullscore(w5.detach(), qq5.detach(), want_lse=True)[1]
+            scale5 = torch.full((b5,), 1.0 / b5, device=dev)
+            t_rec = time_gpu(lambda: ra.ops.fullscore_softmax(w5.detach(), qq5.detach(), lse5, scale5), 5, 2) * 1e3
+            probs5 = ra.ops.fullscore_softmax(w5.detach(), qq5.detach(), lse5, scale5)
+            t_gq = time_gpu(lambda: probs5 @ w5.detach()[1:], 5, 2) * 1e3
+            t_gx = time_gpu(lambda: probs5.t() @ qq5.detach(), 5, 2) * 1e3
+            extra['fullscore']['softmax_train_step_parts_ms'] = {
+                'forward_lse_in_tree': round(t_lse, 3), 'softmax_recompute_write_in_tree': round(t_rec, 3),
+                'grad_query_gemm_rocblas': round(t_gq, 3), 'grad_items_gemm_rocblas': round(t_gx, 3),
+                'fp32_mfma_floor_of_the_step_ms': round(4 * flops / 157.3e12 * 1e3, 2)}
+            del probs5
             del w5, qq5
         except Exception as e:
             extra['fullscore']['softmax_train_step_error'] = repr(e)[:200]
