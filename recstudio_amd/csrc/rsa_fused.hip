@@ -396,7 +396,7 @@ __device__ __forceinline__ float finish_score(int mode, float dot, float inorm2,
 #endif
 
 // loss = mean of the per-query losses, in the SAME launch, with ONE device-scope atomic per workgroup and no
-// second phase: every workgroup adds {its waves' loss sum as a 2^-30 fixed-point integer, 1 arrival} to one 64-bit
+// second phase: every workgroup adds {its share of the mean as a 2^-38 fixed-point integer, 1 arrival} to one 64-bit
 // word (bits 0..49 sum, bits 50..63 arrivals); integer addition is associative, so the total is bit-reproducible
 // whatever the arrival order.  The workgroup whose add returns gridDim.x - 1 earlier arrivals holds the complete sum
 // (returned value + its own share), writes the mean and resets the word.  A NaN / inf partial (SampledSoftmax with a
@@ -406,13 +406,15 @@ __device__ __forceinline__ float finish_score(int mode, float dot, float inorm2,
 // release / acquire pair at workgroup exit writes back / invalidates the whole XCD L2 (measured: +90 us per launch);
 // the first version exchanged float partials and counted arrivals with a second, dependent atomic -- two memory
 // round trips in every workgroup's tail, 7.5 us of a 43 us launch at B = 4096.
-// Range: |partial| < 2^19 at 2^-30 resolution (a batch of 10^5 queries with row losses up to ~5); beyond that the
-// result saturates to +inf through the flag word.  Totals must be >= 0 (every loss on this path is).
+// The words hold each workgroup's share of the MEAN (its loss sum / n_queries) at 2^-38 resolution, so the range does
+// not depend on the batch size: a mean loss up to 2^11 fits the 50-bit field whatever B is (quantisation <= grid * 2^-39
+// ~ 4e-9 absolute); a share >= 2^10 (or NaN / inf) saturates to +inf / NaN through the flag word.  Totals must be >= 0
+// (every loss on this path is).
 // Two levels: workgroup b adds to sub-word b % 32 (the sub-words sit in different 128-byte lines), and the workgroup
 // that completes a sub-word forwards its total to the top word -- atomics on ONE address are performed one after the
 // other at the memory side (~8 ns each), and at B = 4096 all 1024 workgroups finish together: a single word cost an
 // 8 us tail on a 37 us launch.
-constexpr int LOSS_FRAC_BITS = 30, LOSS_COUNT_SHIFT = 50, LOSS_SUBWORDS = 32;
+constexpr int LOSS_FRAC_BITS = 38, LOSS_COUNT_SHIFT = 50, LOSS_SUBWORDS = 32;
 __device__ __forceinline__ void reduce_mean_loss(float wave_loss, float* __restrict__ loss_out,
                                                  unsigned int* __restrict__ flag_word,
                                                  float* __restrict__ loss_partials, int64_t n_queries) {
@@ -426,8 +428,9 @@ __device__ __forceinline__ void reduce_mean_loss(float wave_loss, float* __restr
     for (int w = 0; w < (int)(blockDim.x >> 6); ++w) part += s_red[w];
     unsigned long long* words = reinterpret_cast<unsigned long long*>(loss_partials);     // 8-byte aligned (offset 256)
     constexpr unsigned long long FIELD = (1ull << LOSS_COUNT_SHIFT) - 1, ONE = 1ull << LOSS_COUNT_SHIFT;
-    const bool bad = !(fabsf(part) < 524288.f);          // NaN, inf or out of the fixed-point range
-    const long long fixed = bad ? 0ll : __double2ll_rn((double)part * (double)(1ll << LOSS_FRAC_BITS));
+    const double share = (double)part / (double)n_queries;       // this workgroup's share of the mean
+    const bool bad = !(fabs(share) < 1024.0);                    // NaN, inf or out of the fixed-point range
+    const long long fixed = bad ? 0ll : __double2ll_rn(share * (double)(1ll << LOSS_FRAC_BITS));
     unsigned long long add = ((unsigned long long)fixed & FIELD) + ONE;
     if (bad) {
       const unsigned int old = __hip_atomic_fetch_or(flag_word, part != part ? 1u : 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -445,7 +448,7 @@ __device__ __forceinline__ void reduce_mean_loss(float wave_loss, float* __restr
       const unsigned long long prev2 = __hip_atomic_fetch_add(words, add2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if ((prev2 >> LOSS_COUNT_SHIFT) == (unsigned long long)(n_sub - 1)) {
         const unsigned long long total = (prev2 + add2) & FIELD;
-        float loss = (float)((double)total / (double)(1ll << LOSS_FRAC_BITS) / (double)n_queries);
+        float loss = (float)((double)total / (double)(1ll << LOSS_FRAC_BITS));
         unsigned int* fw = flag_word;
         asm volatile("; the flags are read after the last arrival" : "+v"(fw) : "v"(prev2));
         const unsigned int flags = __hip_atomic_load(fw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

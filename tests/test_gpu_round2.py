@@ -578,3 +578,25 @@ def test_config1_headline_shape_fused_bpr_properties(ra):
     torch.manual_seed(5)
     o2 = ra.ops.fused_forward(iw, uw, n, fused_bpr=True, want_query_grad=True, **kw)
     assert torch.equal(o2['loss'], o['loss'])
+
+
+def test_in_kernel_mean_is_batch_size_independent(ra):
+    """The fixed-point mean reduction holds each workgroup's share of the MEAN: large batches with large row losses
+    (SampledSoftmax over 1024 negatives: ~ln 1025 per row, 200 000 rows) neither overflow nor lose precision, and a
+    single -inf positive turns the mean into NaN like the reference."""
+    N, d, B, n = 20_001, 64, 200_000, 1024
+    g = torch.Generator(device=DEV).manual_seed(0)
+    iw = torch.empty(N, d, device=DEV).normal_(0, 0.05, generator=g)
+    q = torch.empty(B, d, device=DEV).normal_(0, 0.05, generator=g)
+    pos = torch.randint(1, N, (B,), device=DEV, generator=g)
+    torch.manual_seed(3)
+    o = ra.ops.fused_forward(iw, q, n, pos_ids=pos, sampler=ra._native.SAMPLER_UNIFORM, fused_loss='ssm')
+    want = o['row_loss'].double().mean()
+    assert 6.5 < float(want) < 7.5
+    rel_close(o['loss'].cpu(), want.float().cpu(), rtol=2e-7)
+    pos[12345] = 0
+    o = ra.ops.fused_forward(iw, q, n, pos_ids=pos, sampler=ra._native.SAMPLER_UNIFORM, fused_loss='ssm', mask_pad_pos=True)
+    assert torch.isnan(o['loss']) and int(torch.isnan(o['row_loss']).sum()) == 1
+    pos[12345] = 7
+    o = ra.ops.fused_forward(iw, q, n, pos_ids=pos, sampler=ra._native.SAMPLER_UNIFORM, fused_loss='ssm', mask_pad_pos=True)
+    assert torch.isfinite(o['loss'])                     # the flag word was cleared by the launch that read it
