@@ -177,7 +177,7 @@ class ShardedItemTable:
         if exchange not in ('fixed', 'exact'):
             raise ValueError("exchange must be 'fixed' or 'exact'")
         self.exchange, self.slack, self.margin, self.check_every = exchange, float(slack), int(margin), int(check_every)
-        self._cap, self._steps, self._poll = {}, 0, None
+        self._cap, self._steps, self._poll, self._poll_due = {}, 0, None, 0
         self._overflow = self.backend.new_flag(item_local.device)
         # ONE sampler stream for the whole job: same seed on every rank, advanced in lock-step (see module docstring)
         self.sample_generator = self.backend.make_generator(sample_seed, item_local.device)
@@ -241,31 +241,42 @@ class ShardedItemTable:
         cap = min(B * (n + 1), (cap + 255) // 256 * 256)
         self._cap[key] = max(cap, 1)
 
+    def _start_overflow_read(self):
+        """The overflow words of ALL ranks summed (one tiny all-reduce) and copied to the host asynchronously: every
+        rank sees the same value, so every rank raises at the same step -- a rank that raised alone would leave the
+        others waiting in their next collective."""
+        total = self._overflow.clone()
+        self.dist.all_reduce(total, group=self.group)
+        return self.backend.flag_read_async(total)
+
     def check_overflow(self, block=True):
-        """Raise if any routed element ever found its owner's segment full (its score was lost).  ``block=False``:
-        only look at a read-back that has already completed (the per-step use: no stall)."""
-        if block:
-            self._poll = self._poll or self.backend.flag_read_async(self._overflow)
+        """Raise if any routed element of ANY rank ever found its owner's segment full (its score was lost).
+        COLLECTIVE (call it on every rank at the same point)."""
+        self._poll = self._poll or self._start_overflow_read()
+        v = self._poll()
+        while v is None:
             v = self._poll()
-            while v is None:
-                v = self._poll()
-        else:
-            v = self._poll() if self._poll is not None else None
-            if v is None:
-                return
         self._poll = None
         if v:
             self._cap.clear()               # recalibrate on the next step
             self._overflow.zero_()
-            raise RuntimeError(f'sharded exchange: {v} elements did not fit their owner segment (capacity slack '
+            raise RuntimeError(f'sharded exchange: {v} elements (all ranks) did not fit their owner segment (capacity slack '
                                f'{self.slack}); the affected steps are invalid -- raise `slack` / `margin` or use '
                                "exchange='exact' for id distributions that drift this fast")
 
+    LAG = 8          # steps between starting the read-back of the overflow words and looking at it
+
     def _after_fixed_step(self):
+        """Every ``check_every`` steps the (all-reduced) overflow count starts its way to the host; LAG steps later --
+        long after the copy has landed, so without a stall -- every rank looks at it, at the SAME step."""
         self._steps += 1
-        self.check_overflow(block=False)
+        if self.check_every <= 0:
+            return
+        if self._poll is not None and self._steps >= self._poll_due:
+            self.check_overflow()
         if self._poll is None and self._steps % self.check_every == 0:
-            self._poll = self.backend.flag_read_async(self._overflow)
+            self._poll = self._start_overflow_read()
+            self._poll_due = self._steps + self.LAG
 
     # -- the step ---------------------------------------------------------------------------------
     def backward(self, route, dpos, dneg, item_grad_local, item_scale=None):
