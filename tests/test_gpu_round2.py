@@ -600,3 +600,34 @@ def test_in_kernel_mean_is_batch_size_independent(ra):
     pos[12345] = 7
     o = ra.ops.fused_forward(iw, q, n, pos_ids=pos, sampler=ra._native.SAMPLER_UNIFORM, fused_loss='ssm', mask_pad_pos=True)
     assert torch.isfinite(o['loss'])                     # the flag word was cleared by the launch that read it
+
+
+def test_retriever_topk_with_history_longer_than_1024(ra):
+    """BaseRetriever.topk asks the scorer for k + |history| candidates (baseretriever.py:384): a user whose train + val
+    history is longer than the in-kernel select's 1024 (ml-1m: ~1.8 k) used to fail; the composed path == the oracle."""
+    N, U, d, B, k, Lh = 6001, 50, 64, 9, 100, 1300
+    g = torch.Generator().manual_seed(0)
+    iw = torch.randn(N, d, generator=g)
+    iw[0] = 0
+    uw = torch.randn(U, d, generator=g)
+    hist = torch.zeros(B, Lh, dtype=torch.int64)
+    for b in range(B):
+        m = int(torch.randint(5, Lh + 1, (1,), generator=g))
+        hist[b, :m] = torch.randperm(N - 1, generator=g)[:m] + 1
+    uid = torch.randint(1, U, (B,), generator=g)
+    m = ra.BaseRetriever({'train': {'seed': 1}}, scorer=ra.InnerProductScorer(),
+                         item_encoder=torch.nn.Embedding(N, d, padding_idx=0),
+                         query_encoder=torch.nn.Embedding(U, d, padding_idx=0))
+    m.fiid, m.fuid, m.frating = 'item_id', 'user_id', 'rating'
+    m.item_fields, m.query_fields = {'item_id'}, {'user_id'}
+    with torch.no_grad():
+        m.item_encoder.weight.copy_(iw)
+        m.query_encoder.weight.copy_(uw)
+    m.to(DEV)
+    m._update_item_vector()
+    score, items = m.topk({'user_id': uid.to(DEV)}, k, hist.to(DEV))
+    ws, wi = oracle.topk_with_history(uw[uid], iw, k, hist)
+    rel_close(score.cpu(), ws, rtol=1e-4, atol=1e-5)
+    assert (items.cpu() == wi).float().mean() > 0.995          # fp32 near-ties may swap neighbours
+    for b in range(B):
+        assert not set(items[b].tolist()) & set(hist[b][hist[b] > 0].tolist())
