@@ -18,6 +18,7 @@ Prints ONE JSON line (rank 0).  Extra keys beyond the driver contract: roofline,
 train_step (forward + loss + row-sparse gradient scatter), sweep.
 """
 import argparse
+import threading
 import json
 import os
 import sys
@@ -205,6 +206,18 @@ def main():
     torch.manual_seed(2022 + rank)       # basemodel.yaml:63 seed
 
     extra = {}
+    emit_lock, emitted = threading.Lock(), []
+
+    def headline_line(value, ms_step, workload, parallelism, roofline, extra):
+        line = {'metric': 'M scored (user,pos,neg) triplets/sec at d=128', 'value': round(value, 2),
+                'unit': 'M triplets/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+                'ms_per_step': round(ms_step, 4), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+                'dtype': 'f32', 'data': 'synthetic',
+                'config': {'workload': workload, 'global_batch': B * world, 'num_neg': n, 'dim': d,
+                           'n_items': args.items, 'parallelism': parallelism},
+                'roofline': roofline}
+        line.update(extra)
+        return line
     force_shard = world == 1 and os.environ.get('RSA_BENCH_FORCE_SHARD') == '1'   # exercise the N>1 branch on one GPU
     if force_shard:
         import torch.distributed as dist
@@ -563,6 +576,28 @@ def main():
                              'what': 'equal-split all-to-all of fixed-capacity segments, empty slots = -1 keys; no split '
                                      'sizes on the host (one calibration step before the timed region)'}
 
+        parallelism = f'item-table row-sharded x{world} + RCCL all-to-all (ids out, scores back)'
+        workload = (f'two-tower d={d}, {args.items}-item table row-sharded over {world} GPUs, {args.sampler} sampler '
+                    f'neg={n}, InnerProduct + BPR loss, B={B} queries/step/GPU (BASELINE.json configs[3])')
+
+        def emit():
+            with emit_lock:
+                if emitted:
+                    return
+                emitted.append(1)
+                if rank == 0:
+                    print(json.dumps(headline_line(value, ms_step, workload, parallelism, roofline, extra)), flush=True)
+        # The side figures below run collectives: should one of them stall (a rank that failed alone leaves the others
+        # waiting), the measured headline must still come out -- a watchdog thread prints the line and ends the rank.
+
+        def give_up():
+            extra['extras_timed_out'] = True
+            emit()
+            os._exit(0)
+        watchdog = threading.Timer(float(os.environ.get('RSA_BENCH_EXTRAS_DEADLINE_S', '420')), give_up)
+        watchdog.daemon = True
+        watchdog.start()
+
         def timed_max(fn, steps, warm):
             fn()
             v = torch.tensor([time_gpu(fn, steps, warm, dist) * 1e3], device=dev)
@@ -597,20 +632,11 @@ def main():
                                     'ms_per_step': round(ms4, 4), 'M_triplets_s': round(world * b4 * n4 / ms4 / 1e3, 2)}
         except Exception as e:
             extra['sharded_n64'] = {'error': repr(e)[:200]}
-        parallelism = f'item-table row-sharded x{world} + RCCL all-to-all (ids out, scores back)'
-        workload = (f'two-tower d={d}, {args.items}-item table row-sharded over {world} GPUs, {args.sampler} sampler '
-                    f'neg={n}, InnerProduct + BPR loss, B={B} queries/step/GPU (BASELINE.json configs[3])')
+        watchdog.cancel()
+        emit()
 
-    if rank == 0:
-        line = {'metric': 'M scored (user,pos,neg) triplets/sec at d=128', 'value': round(value, 2),
-                'unit': 'M triplets/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-                'ms_per_step': round(ms_step, 4), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-                'dtype': 'f32', 'data': 'synthetic',
-                'config': {'workload': workload, 'global_batch': B * world, 'num_neg': n, 'dim': d,
-                           'n_items': args.items, 'parallelism': parallelism},
-                'roofline': roofline}
-        line.update(extra)
-        print(json.dumps(line))
+    if rank == 0 and not emitted:
+        print(json.dumps(headline_line(value, ms_step, workload, parallelism, roofline, extra)), flush=True)
     if dist is not None:
         dist.destroy_process_group()
 
