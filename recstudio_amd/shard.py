@@ -170,8 +170,12 @@ class HipBackend:
 
 class ShardedItemTable:
     def __init__(self, item_local, plan, rank, dist, backend=None, group=None, exchange='fixed', slack=1.08,
-                 margin=4096, check_every=64, sample_seed=2022):
+                 margin=4096, check_every=64, sample_seed=2022, chunks=1):
+        """``chunks`` > 1 (fixed-capacity exchange only): the step's queries are cut into that many contiguous
+        slices whose exchanges are issued asynchronously, so that slice c+1's key all-to-all and slice c-1's score
+        all-to-all travel over xGMI while slice c is being scored (see ``_score_ids_pipelined``)."""
         self.item_local, self.plan, self.rank, self.dist = item_local, plan, int(rank), dist
+        self.chunks = max(1, int(chunks))
         self.backend = backend if backend is not None else HipBackend()
         self.group = group
         if exchange not in ('fixed', 'exact'):
@@ -224,6 +228,20 @@ class ShardedItemTable:
         self.dist.all_to_all_single(out, x, output_split_sizes=recv_counts, input_split_sizes=send_counts,
                                     group=self.group)
         return out
+
+    def _all_to_all_start(self, x):
+        """Equal-split all-to-all issued asynchronously (it runs on the communicator's stream once everything queued
+        on the current stream so far has finished); returns wait() -> the received tensor, ordered after the transfer
+        on the current stream."""
+        out = torch.empty_like(x)
+        work = self.dist.all_to_all_single(out, x, group=self.group, async_op=True)
+
+        def wait():
+            if work is not None:
+                work.wait()
+            return out
+        wait.keep = x
+        return wait
 
     def _reduce_scatter_rows(self, x, rows_per_rank):
         out = torch.empty(rows_per_rank, *x.shape[1:], dtype=x.dtype, device=x.device)
@@ -286,16 +304,63 @@ class ShardedItemTable:
         communication: rows never leave their owner) and returns d loss / d q for the own queries [B, d]
         (reduce-scatter of the per-owner partial sums)."""
         B = route['B']
-        dflat = torch.cat([dpos.reshape(-1), dneg.reshape(-1)])
-        d_sorted = self.backend.gather(dflat, route['positions'])           # empty slots: 0
-        d_owner = self._all_to_all(d_sorted, route.get('recv_counts'), route.get('send_counts'))
         q_all = route['q_all']
         qgrad_all = torch.zeros_like(q_all)
         # only shard 0 holds the global padding row (item id 0), which never receives gradient
         extra = {} if item_scale is None else {'item_scale': item_scale}
+        pad_row = 0 if self.rank == 0 else -1
+        if 'slices' in route:
+            # pipelined step: all gradient exchanges are issued first, the owner-side scatters follow slice by slice
+            # (slice c's scatter runs while slice c+1's gradients are still on the wire)
+            dpos, dneg = dpos.reshape(-1), dneg.reshape(B, -1)
+            waits = []
+            for (b0, b1, positions, _) in route['slices']:
+                dflat = torch.cat([dpos[b0:b1], dneg[b0:b1].reshape(-1)])
+                waits.append(self._all_to_all_start(self.backend.gather(dflat, positions)))
+            for (_, _, _, recv_keys), wait in zip(route['slices'], waits):
+                self.backend.backward_keys(self.item_local, q_all, recv_keys, wait(), item_grad_local, qgrad_all,
+                                           item_pad_row=pad_row, **extra)
+            return self._reduce_scatter_rows(qgrad_all, B)
+        dflat = torch.cat([dpos.reshape(-1), dneg.reshape(-1)])
+        d_sorted = self.backend.gather(dflat, route['positions'])           # empty slots: 0
+        d_owner = self._all_to_all(d_sorted, route.get('recv_counts'), route.get('send_counts'))
         self.backend.backward_keys(self.item_local, q_all, route['recv_keys'], d_owner, item_grad_local, qgrad_all,
-                                   item_pad_row=0 if self.rank == 0 else -1, **extra)
+                                   item_pad_row=pad_row, **extra)
         return self._reduce_scatter_rows(qgrad_all, B)
+
+    def _score_ids_pipelined(self, q_gather, pos, neg, keep_route):
+        """The fixed-capacity step cut into ``self.chunks`` query slices.  Issue order on the current stream:
+        route(0), route(1), ... (each followed by its asynchronous key all-to-all on the communicator's stream),
+        then per slice: wait for its keys, score, start the score all-to-all; finally per slice: wait, scatter home.
+        Collectives of one communicator run in issue order, so slice c's keys arrive while slice c-1 is being scored
+        and its scores go back while slice c+1 is being scored.  Every rank issues the same sequence."""
+        B, n = neg.shape
+        C = self.chunks
+        Bc = B // C
+        cap = self._cap[(Bc, n)]
+        bounds = [(c * Bc, (c + 1) * Bc) for c in range(C)]
+        routed = []
+        for b0, b1 in bounds:
+            keys, positions = self.backend.route_fixed(pos[b0:b1], neg[b0:b1], self.plan, self.rank * B + b0, cap,
+                                                       self._overflow)
+            routed.append((positions, self._all_to_all_start(keys)))
+        q_all = q_gather()
+        scored = []
+        for positions, wait_keys in routed:
+            recv_keys = wait_keys()
+            scored.append((positions, recv_keys,
+                           self._all_to_all_start(self.backend.score_keys(self.item_local, q_all, recv_keys))))
+        pos_parts, neg_parts, slices = [], [], []
+        for (b0, b1), (positions, recv_keys, wait_scores) in zip(bounds, scored):
+            flat = self.backend.scatter(wait_scores(), positions, Bc * (n + 1))
+            pos_parts.append(flat[:Bc])
+            neg_parts.append(flat[Bc:].view(Bc, n))
+            slices.append((b0, b1, positions, recv_keys))
+        self._after_fixed_step()
+        pos_score, neg_score = torch.cat(pos_parts), torch.cat(neg_parts)
+        if keep_route:
+            return pos_score, neg_score, {'B': B, 'n': n, 'q_all': q_all, 'slices': slices}
+        return pos_score, neg_score
 
     def score_ids(self, q, pos, neg, keep_route=False, q_gather=None):
         """q [B, d] own queries, pos [B], neg [B, n] GLOBAL item ids -> (pos_score [B], neg_score [B, n]).
@@ -304,6 +369,13 @@ class ShardedItemTable:
         plan = self.plan
         if q_gather is None:
             q_gather = self._all_gather_rows_start(q)
+        if self.exchange == 'fixed' and self.chunks > 1 and B % self.chunks == 0:
+            Bc = B // self.chunks
+            if (Bc, n) not in self._cap:
+                # capacity of a slice's owner segments: exact owner counts of slice 0, max over ranks, plus slack
+                send_counts, _ = self._exchange_counts(self.backend.count(pos[:Bc], neg[:Bc], plan))
+                self._calibrate((Bc, n), send_counts)
+            return self._score_ids_pipelined(q_gather, pos, neg, keep_route)
         cap = self._cap.get((B, n)) if self.exchange == 'fixed' else None
         route = {'B': B, 'n': n}
         if cap is None:

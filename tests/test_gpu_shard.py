@@ -143,10 +143,11 @@ class StagedDist:
         out.copy_(torch.cat(parts).view(out.shape))
         return self._Done() if async_op else None
 
-    def all_to_all_single(self, out, x, output_split_sizes=None, input_split_sizes=None, group=None):
+    def all_to_all_single(self, out, x, output_split_sizes=None, input_split_sizes=None, group=None, async_op=False):
         o = torch.empty(out.shape, dtype=out.dtype)
         self.d.all_to_all_single(o, x.cpu().contiguous(), output_split_sizes, input_split_sizes)
         out.copy_(o)
+        return self._Done() if async_op else None
 
     def reduce_scatter_tensor(self, out, x, group=None):
         full = x.cpu().clone()
@@ -158,6 +159,27 @@ class StagedDist:
         c = x.cpu()
         self.d.all_reduce(c, op=op if op is not None else self.d.ReduceOp.SUM)
         x.copy_(c)
+
+
+def _check_pipelined_equals_whole(ra, ShardedItemTable, make_table, user, uid, pos, n, sampler, rows, d, dev):
+    """ShardedItemTable(chunks=C) against the whole step on the same job-wide stream: same negatives, bit-equal scores,
+    same gradients up to summation order; C slices in the route; per-slice capacity."""
+    B = uid.numel()
+    for chunks in (2, 4):
+        whole, piped = make_table(chunks=1), make_table(chunks=chunks)
+        for step in range(3):
+            a = whole.sample_and_score(user, uid, pos, n, sampler, keep_route=True)
+            b = piped.sample_and_score(user, uid, pos, n, sampler, keep_route=True)
+            assert torch.equal(a['neg_ids'], b['neg_ids'])
+            assert torch.equal(a['pos_score'], b['pos_score']) and torch.equal(a['neg_score'], b['neg_score'])
+            assert len(b['route']['slices']) == chunks and (B // chunks, n) in piped._cap
+            _, dpos, dneg, _ = ra.ops.pairwise_loss(ra._native.LOSS_BPR, a['pos_score'], a['neg_score'])
+            ga, gb = torch.zeros(rows, d, device=dev), torch.zeros(rows, d, device=dev)
+            qa = whole.backward(a['route'], dpos, dneg, ga)
+            qb = piped.backward(b['route'], dpos, dneg, gb)
+            np.testing.assert_allclose(qb.cpu(), qa.cpu(), rtol=2e-4, atol=1e-8)
+            np.testing.assert_allclose(gb.cpu(), ga.cpu(), rtol=2e-4, atol=1e-8)
+        piped.check_overflow()
 
 
 def _two_rank_worker(rank, world, port, backend, result_dir):
@@ -221,6 +243,12 @@ def _two_rank_worker(rank, world, port, backend, result_dir):
                 total = sum_cpu(ig2)                     # this rank's contribution to every row, summed over the ranks
                 np.testing.assert_allclose(ig.cpu(), total[lo:hi], rtol=2e-4, atol=1e-8)
             table.check_overflow()
+        # the step cut into query slices with asynchronously issued exchanges
+        _check_pipelined_equals_whole(ra, ShardedItemTable,
+                                      lambda chunks: ShardedItemTable(item_d[lo:hi].contiguous(), plan, rank, comm,
+                                                                      sample_seed=5, chunks=chunks),
+                                      user, uid[:256].contiguous(), pos[:256].contiguous(), n, ra.UniformSampler(N),
+                                      hi - lo, d, dev)
         # the sharded full-catalog pass
         q = torch.randn(70, d, generator=gr).to(dev) * 0.2
         table = ShardedItemTable(item_d[lo:hi].contiguous(), plan, rank, comm)
@@ -298,6 +326,12 @@ def test_world1_rccl_step_equals_unsharded():
             ig2, _, qg2 = ra.ops.fused_backward(item, user, out['neg_ids'], dneg, query_index=uid, pos_ids=pos, dpos=dpos)
             np.testing.assert_allclose(qg.cpu(), qg2.cpu(), rtol=2e-4, atol=1e-8)
             np.testing.assert_allclose(ig.cpu(), ig2.cpu(), rtol=2e-4, atol=1e-8)
+        # query slices with asynchronous RCCL exchanges (real work objects on the communicator's stream)
+        _check_pipelined_equals_whole(ra, ShardedItemTable,
+                                      lambda chunks: ShardedItemTable(item, RowShardPlan(N, 1), 0, dist, sample_seed=5,
+                                                                      chunks=chunks),
+                                      user, uid[:256].contiguous(), pos[:256].contiguous(), 128,
+                                      ra.PopularSamplerModel(counts).to(DEV), N, d, DEV)
     finally:
         dist.destroy_process_group()
 

@@ -218,6 +218,58 @@ def _worker(rank, world, port, n_items, d, B, n, result_dir):
         dist.destroy_process_group()
 
 
+def _chunk_worker(rank, world, port, n_items, d, B, n, chunks, result_dir):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from recstudio_amd.shard import RowShardPlan, ShardedItemTable
+        g = torch.Generator().manual_seed(5)
+        item = torch.randn(n_items, d, generator=g)
+        item[0] = 0
+        user = torch.randn(50, d, generator=g)
+        plan = RowShardPlan(n_items, world)
+        lo, hi = plan.bounds(rank)
+        gr = torch.Generator().manual_seed(100 + rank)
+        uid = torch.randint(1, 50, (B,), generator=gr)
+        pos = torch.randint(1, n_items, (B,), generator=gr)
+        sampler = oracle.UniformSampler(n_items)
+        whole = ShardedItemTable(item[lo:hi].clone(), plan, rank, dist, backend=CheckerBackend())
+        piped = ShardedItemTable(item[lo:hi].clone(), plan, rank, dist, backend=CheckerBackend(), chunks=chunks)
+        gg = torch.Generator().manual_seed(500 + rank)
+        dpos, dneg = torch.randn(B, generator=gg), torch.randn(B, n, generator=gg)
+        for step in range(3):                                  # step 0 calibrates (both tables), 1 and 2 run fixed
+            a = whole.sample_and_score(user, uid, pos, n, sampler, keep_route=True)
+            b = piped.sample_and_score(user, uid, pos, n, sampler, keep_route=True)
+            assert torch.equal(a['neg_ids'], b['neg_ids'])     # same job-wide stream, sliced or not
+            assert torch.equal(a['pos_score'], b['pos_score']) and torch.equal(a['neg_score'], b['neg_score'])
+            assert 'slices' in b['route'] and len(b['route']['slices']) == chunks
+            assert (B // chunks, n) in piped._cap and (B, n) not in piped._cap
+            ga, gb = torch.zeros(hi - lo, d), torch.zeros(hi - lo, d)
+            qa = whole.backward(a['route'], dpos, dneg, ga)
+            qb = piped.backward(b['route'], dpos, dneg, gb)
+            np.testing.assert_allclose(qb.numpy(), qa.numpy(), rtol=1e-5, atol=1e-5)
+            np.testing.assert_allclose(gb.numpy(), ga.numpy(), rtol=1e-5, atol=1e-5)
+        piped.check_overflow()
+        # a batch the slices do not divide runs whole
+        p1, s1 = piped.score_ids(user[uid[:B - 1]], pos[:B - 1], a['neg_ids'][:B - 1])
+        w1p, w1n = oracle.retriever_forward(item, user[uid[:B - 1]], pos[:B - 1], a['neg_ids'][:B - 1])
+        np.testing.assert_allclose(p1.numpy(), w1p.numpy(), rtol=1e-6, atol=1e-6)
+        np.testing.assert_allclose(s1.numpy(), w1n.numpy(), rtol=1e-6, atol=1e-6)
+        # overflow inside a slice is detected like in the whole step
+        tight = ShardedItemTable(item[lo:hi].clone(), plan, rank, dist, backend=CheckerBackend(), slack=1.0, margin=0,
+                                 chunks=chunks)
+        tight.score_ids(user[uid], pos, a['neg_ids'])
+        Bc = B // chunks
+        if tight._cap[(Bc, n)] < Bc * (n + 1):
+            tight.score_ids(user[uid], torch.full((B,), n_items - 2), torch.full((B, n), n_items - 1))
+            with pytest.raises(RuntimeError, match='did not fit'):
+                tight.check_overflow()
+        open(os.path.join(result_dir, f'ok{rank}'), 'w').write('ok')
+    finally:
+        dist.destroy_process_group()
+
+
 def _full_worker(rank, world, port, n_items, d, B, k, result_dir):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
@@ -333,6 +385,16 @@ def test_sharded_scores_equal_single_process(tmp_path, n_items, n, B):
     exchange; negatives identical to a world-1 draw (G-invariance); overflow of a tight capacity detected (B = 500)."""
     world = 2
     mp.spawn(_worker, args=(world, _free_port(), n_items, 16, B, n, str(tmp_path)), nprocs=world, join=True)
+    assert all(os.path.exists(tmp_path / f'ok{r}') for r in range(world))
+
+
+@pytest.mark.parametrize('B,n,chunks', [(8, 5, 2), (12, 3, 4), (400, 7, 2)])
+def test_pipelined_slices_equal_the_whole_step(tmp_path, B, n, chunks):
+    """ShardedItemTable(chunks=C): the step cut into C query slices with asynchronously issued exchanges gives the same
+    negatives and bit-equal scores as the whole step, the same gradients (summed in a different order), keeps its
+    own per-slice capacity, detects overflow, and falls back to the whole step for batches C does not divide."""
+    world = 2
+    mp.spawn(_chunk_worker, args=(world, _free_port(), 1001, 16, B, n, chunks, str(tmp_path)), nprocs=world, join=True)
     assert all(os.path.exists(tmp_path / f'ok{r}') for r in range(world))
 
 
