@@ -393,11 +393,16 @@ def main():
             scale5 = torch.full((b5,), 1.0 / b5, device=dev)
             t_rec = time_gpu(lambda: ra.ops.fullscore_softmax(w5.detach(), qq5.detach(), lse5, scale5), 5, 2) * 1e3
             probs5 = ra.ops.fullscore_softmax(w5.detach(), qq5.detach(), lse5, scale5)
+            t_rec_dq = time_gpu(lambda: ra.ops.fullscore_softmax(w5.detach(), qq5.detach(), lse5, scale5,
+                                                                 want_query_grad=True), 5, 2) * 1e3
             t_gq = time_gpu(lambda: probs5 @ w5.detach()[1:], 5, 2) * 1e3
             t_gx = time_gpu(lambda: probs5.t() @ qq5.detach(), 5, 2) * 1e3
             extra['fullscore']['softmax_train_step_parts_ms'] = {
-                'forward_lse_in_tree': round(t_lse, 3), 'softmax_recompute_write_in_tree': round(t_rec, 3),
-                'grad_query_gemm_rocblas': round(t_gq, 3), 'grad_items_gemm_rocblas': round(t_gx, 3),
+                'forward_lse_in_tree': round(t_lse, 3),
+                'softmax_recompute_write_and_grad_query_in_tree': round(t_rec_dq, 3),
+                'grad_items_gemm_rocblas': round(t_gx, 3),
+                'not_in_the_step_any_more': {'softmax_recompute_write_alone': round(t_rec, 3),
+                                             'grad_query_gemm_rocblas': round(t_gq, 3)},
                 'fp32_mfma_floor_of_the_step_ms': round(4 * flops / 157.3e12 * 1e3, 2)}
             del probs5
             del w5, qq5

@@ -30,7 +30,8 @@
 extern "C" {
 #endif
 
-#define RSA_ABI_VERSION 3   /* 3: caller-owned reduction scratch (rsa_scratch_bytes; the library allocates nothing);
+#define RSA_ABI_VERSION 4   /* 4: rsa_fullscore_softmax_dq (d/d query of the full softmax on the matrix cores, in the
+                               recompute pass); 3: caller-owned reduction scratch (rsa_scratch_bytes; the library allocates nothing);
                                Philox element base (G-invariant sampling across ranks); bucket-line inverse CDF
                                (cdf_lines); SampledSoftmax epilogue (fused_loss = 2); cosine / Euclidean full-catalog
                                scores (rsa_row_sqnorm, rsa_fullscore score_mode); fixed-capacity shard routing
@@ -377,6 +378,16 @@ int rsa_fullscore(const float* item_table, int64_t n_items, int32_t dim,
 int rsa_fullscore_softmax(const float* item_table, int64_t n_items, int32_t dim, const float* query,
                           int64_t n_query, const float* lse, const float* row_scale, float* probs,
                           rsa_stream_t stream);
+
+/* The same pass that ALSO leaves query_grad [n_query, dim] = probs @ items[1:] (d lse/d query times row_scale): the
+ * tile of probs the epilogue has just produced is multiplied with the item tile staged in LDS on the matrix cores, so
+ * one of the two backward GEMMs needs no second pass over the 4 * n_query * n_items bytes of probs.  The per-item-range
+ * partial sums go through `workspace` (rsa_fullscore_softmax_dq_workspace_bytes) and are added in range order
+ * (reproducible).  probs is still written (d lse/d items = probs^T @ query remains a library GEMM on the caller's side). */
+int64_t rsa_fullscore_softmax_dq_workspace_bytes(int64_t n_query, int64_t n_items, int32_t dim);
+int rsa_fullscore_softmax_dq(const float* item_table, int64_t n_items, int32_t dim, const float* query,
+                             int64_t n_query, const float* lse, const float* row_scale, float* probs,
+                             float* query_grad, void* workspace, int64_t workspace_bytes, rsa_stream_t stream);
 
 /* torch.topk(values, k) over the last dim of a [n_rows, n_cols] matrix (k <= 1024): values in descending
  * order and their COLUMN indices (equal values -> smaller column first).  Used by the 'dns' sampling method

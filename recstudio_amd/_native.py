@@ -86,6 +86,9 @@ SIGNATURES = {
                                c_void_p, c_void_p, c_void_p, c_void_p]),
     'rsa_fullscore_softmax': (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_int64, c_void_p, c_void_p, c_void_p,
                                       c_void_p]),
+    'rsa_fullscore_softmax_dq_workspace_bytes': (c_int64, [c_int64, c_int64, c_int32]),
+    'rsa_fullscore_softmax_dq': (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_int64, c_void_p, c_void_p, c_void_p,
+                                         c_void_p, c_void_p, c_int64, c_void_p]),
     'rsa_scatter_rows_sorted_workspace_bytes': (c_int64, [c_int64, c_int32, c_int64]),
     'rsa_scatter_rows_sorted': (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_int64, c_int32, c_void_p,
                                         c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_void_p]),
@@ -126,7 +129,7 @@ def build(verbose=False):
     return LIB_PATH
 
 
-ABI_VERSION = 3      # RSA_ABI_VERSION of include/recstudio_amd.h this binding was written against
+ABI_VERSION = 4      # RSA_ABI_VERSION of include/recstudio_amd.h this binding was written against
 
 
 def lib():

@@ -37,6 +37,9 @@
 #ifndef RSA_FS_MIN_BLOCKS
 #define RSA_FS_MIN_BLOCKS 1
 #endif
+#ifndef RSA_FS_DQ_MIN_BLOCKS
+#define RSA_FS_DQ_MIN_BLOCKS 2     // the dQ variant: at most 256 registers, two waves per SIMD
+#endif
 
 namespace rsa {
 
@@ -78,6 +81,8 @@ struct FilterArgs {
   // Cosine / Euclidean scores (MODE != 0): per-item and per-query operands from rsa_row_sqnorm
   const float* item_aux;   // [n_items - 1], entry i-1 for item row i
   const float* query_aux;  // [n_query]
+  // DQ variant (softmax backward): this item range's share of d/d query = sum_i P[q, i] * item_i, [splits, n_query, D]
+  float* dq_part;
 };
 
 // tile_stride == 1: the workgroup walks the contiguous item range [1 + bx*items_per_split, ...).
@@ -86,8 +91,14 @@ struct FilterArgs {
 // MODE: rsa_score_mode.  For RSA_SCORE_COS / RSA_SCORE_EUC the tile's dot products are turned into the score in the
 // epilogue (cos = dot * item_aux * query_aux, euc = 2 dot - item_aux - query_aux) before logsumexp / filter / store; the
 // inner-product instantiation is unchanged.
-template <int D, bool LSE, bool SCORES, bool FILTER, int MODE = 0>
-__global__ __launch_bounds__(256, RSA_FS_MIN_BLOCKS) void fullscore_kernel(const float* __restrict__ item_table, int64_t n_items,
+// DQ (with the softmax score transform only): the tile of P = row_scale * softmax the epilogue has just produced is fed
+// straight back into the matrix cores as the B operand of a second product, dQ^T[d, q] += X^T[d, item] * P[item, q] --
+// a lane's 16 accumulator registers ARE its B-operand values when the 32 items of the tile are taken as the K index in
+// the order the accumulator layout holds them (step r: items row(r, h = 0) and row(r, h = 1)), so nothing moves between
+// lanes; the A operand X[item(r, h)][32 db + j] is a conflict-free 4-byte LDS read of the staged item tile.  dQ stays in
+// 16 * D/32 accumulator registers for the whole item range and leaves the kernel once (per-range partials).
+template <int D, bool LSE, bool SCORES, bool FILTER, int MODE = 0, bool DQ = false>
+__global__ __launch_bounds__(256, DQ ? RSA_FS_DQ_MIN_BLOCKS : RSA_FS_MIN_BLOCKS) void fullscore_kernel(const float* __restrict__ item_table, int64_t n_items,
                                                         const float* __restrict__ query, int64_t n_query,
                                                         float* __restrict__ scores, int64_t score_ld,
                                                         float2* __restrict__ lse_part, int splits,
@@ -96,7 +107,9 @@ __global__ __launch_bounds__(256, RSA_FS_MIN_BLOCKS) void fullscore_kernel(const
   constexpr int KH = D / 2;         // k values per lane half
   constexpr int LD = D + 4;         // padded LDS row stride (floats)
   constexpr int V4 = D / 4;         // float4 per row
-  __shared__ float tile[2][TI * STG][LD];
+  // two stage buffers; the dQ variant reads tile u-1 again (second product) while tile u+1 is being committed: three
+  constexpr int NBUF = DQ ? 3 : 2;
+  __shared__ float tile[NBUF][TI * STG][LD];
   __shared__ float tpose[4][32][33];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -203,6 +216,13 @@ __global__ __launch_bounds__(256, RSA_FS_MIN_BLOCKS) void fullscore_kernel(const
   };
 
   float run_m = -INFINITY, run_s = 0.f;
+  static_assert(!DQ || (SCORES && !LSE && !FILTER && MODE == 0 && STG == 1 && D % 32 == 0), "DQ: softmax-backward variant only");
+  constexpr int DB = D / 32;
+  f32x16 dq[DQ ? DB : 1];
+  if constexpr (DQ) {
+#pragma unroll
+    for (int db = 0; db < DB; ++db) dq[db] = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  }
 
   // ---- per-tile epilogue pieces.  They are applied to the PREVIOUS tile's accumulators while the current
   // tile's MFMA chain (64 dependent 64-cycle instructions) is in flight.
@@ -239,13 +259,39 @@ __global__ __launch_bounds__(256, RSA_FS_MIN_BLOCKS) void fullscore_kernel(const
     run_s = sum;
   };
   // (b) the parts with memory side effects (score rows, candidate lists)
-  auto emit = [&](const f32x16& acc, int64_t i0) __attribute__((always_inline)) {
+  auto emit = [&](const f32x16& acc, int64_t i0, int pbuf) __attribute__((always_inline)) {
     if constexpr (SCORES) {
       // transpose the wave's 32 (items) x 32 (queries) tile through LDS so that every half-wave
       // writes 128 contiguous bytes of one query's score row
+      f32x16 pv;
 #pragma unroll
-      for (int r = 0; r < 16; ++r)
-        tpose[wave][j][(r & 3) + 8 * (r >> 2) + 4 * h] = softmax_out ? my_scale * __expf(acc[r] - my_lse) : acc[r];
+      for (int r = 0; r < 16; ++r) {
+        pv[r] = softmax_out ? my_scale * __expf(acc[r] - my_lse) : acc[r];
+        tpose[wave][j][(r & 3) + 8 * (r >> 2) + 4 * h] = pv[r];
+      }
+      if constexpr (DQ) {
+        // rows past the item range are zero in LDS (fetch), so their (finite) P values add nothing
+        // output column block db of lane j is d = DB * j + db: the DB A-operand values of a step are DB consecutive
+        // floats of the item row -- one 16-byte LDS read at D = 128 instead of four 4-byte ones
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float* xr = &tile[pbuf][(r & 3) + 8 * (r >> 2) + 4 * h][DB * j];
+          float xa[DB];
+          if constexpr (DB == 4) {
+            const float4 v = *reinterpret_cast<const float4*>(xr);
+            xa[0] = v.x; xa[1] = v.y; xa[2] = v.z; xa[3] = v.w;
+          } else if constexpr (DB == 2) {
+            const float2 v = *reinterpret_cast<const float2*>(xr);
+            xa[0] = v.x; xa[1] = v.y;
+          } else {
+#pragma unroll
+            for (int db = 0; db < DB; ++db) xa[db] = xr[db];
+          }
+#pragma unroll
+          for (int db = 0; db < DB; ++db)
+            dq[db] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[db], pv[r], dq[db], 0, 0, 0);
+        }
+      }
       __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the wave's own LDS writes have landed
 #pragma unroll
       for (int tt = 0; tt < 16; ++tt) {
@@ -299,7 +345,21 @@ __global__ __launch_bounds__(256, RSA_FS_MIN_BLOCKS) void fullscore_kernel(const
     return acc;   // acc[r] = <item (i0 + row(r)), query q>, row(r) = (r & 3) + 8 * (r >> 2) + 4 * h
   };
 
+  auto store_dq = [&]() __attribute__((always_inline)) {
+    if constexpr (DQ) {
+      if (q < n_query) {
+        float* dst = flt.dq_part + ((size_t)blockIdx.x * n_query + q) * D;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {      // dq[db][r] = dQ[q][DB * i + db], i = row(r) of the accumulator layout
+          const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
+#pragma unroll
+          for (int db = 0; db < DB; ++db) dst[DB * i + db] = dq[db][r];
+        }
+      }
+    }
+  };
   if (n_tiles == 0) {
+    store_dq();
     if (LSE && h == 0 && q < n_query) lse_part[(size_t)q * splits + blockIdx.x] = make_float2(-INFINITY, 0.f);
     if (FILTER && q < n_query) flt.seg_cnt[seg] = 0;
     return;
@@ -317,8 +377,10 @@ __global__ __launch_bounds__(256, RSA_FS_MIN_BLOCKS) void fullscore_kernel(const
     __syncthreads();
   }
   // iteration u: MFMA chain of tile u with the epilogue of tile u-1 interleaved under it
+  int rb_prv = 0, rb_cur = 1, rb_nxt = 2;    // dQ variant: buffers of tiles u-1, u, u+1 (rotating)
   auto iteration = [&](int u, auto masked) __attribute__((always_inline)) {
-    const int st = u / STG, sub = u - st * STG, cur = st & 1;
+    const int st = u / STG, sub = u - st * STG;
+    const int cur = DQ ? rb_cur : (st & 1), nxt = DQ ? rb_nxt : (cur ^ 1), prv = DQ ? rb_prv : (cur ^ 1);
 #if !(RSA_FS_EXP & 2)
     if (sub == 0) fetch(st + 1);          // global loads fly under this stage's MFMA chains
 #endif
@@ -333,13 +395,18 @@ __global__ __launch_bounds__(256, RSA_FS_MIN_BLOCKS) void fullscore_kernel(const
         __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
       }
     }
-    emit(acc_prev, i_begin + (int64_t)(u - 1) * TI);
+    emit(acc_prev, i_begin + (int64_t)(u - 1) * TI, prv);
 #if !(RSA_FS_EXP & 2)
     if (sub == STG - 1) {
-      commit(cur ^ 1);
+      commit(nxt);
       __syncthreads();
     }
 #endif
+    if constexpr (DQ) {
+      rb_prv = cur;
+      rb_cur = nxt;
+      rb_nxt = prv;
+    }
     acc_prev = acc;
   };
   const int total_tiles = n_stages * STG;
@@ -349,7 +416,8 @@ __global__ __launch_bounds__(256, RSA_FS_MIN_BLOCKS) void fullscore_kernel(const
   for (; u < total_tiles; ++u) iteration(u, std::true_type{});
   if constexpr (MODE != 0) acc_prev = to_score(acc_prev, i_begin + (int64_t)(total_tiles - 1) * TI);
   if constexpr (LSE) lse_update(acc_prev, i_begin + (int64_t)(total_tiles - 1) * TI, std::true_type{});
-  emit(acc_prev, i_begin + (int64_t)(total_tiles - 1) * TI);
+  emit(acc_prev, i_begin + (int64_t)(total_tiles - 1) * TI, DQ ? rb_prv : ((total_tiles - 1) & 1));
+  store_dq();
   if (FILTER && q < n_query) flt.seg_cnt[seg] = my_cnt;
   if constexpr (LSE) {
     // fold the two k-halves' item subsets (lanes j and j+32 hold the same query)
@@ -871,6 +939,70 @@ extern "C" int rsa_fullscore_softmax(const float* item_table, int64_t n_items, i
   gemm_dispatch(dim, RSA_SCORE_IP, dim3((unsigned)splits_used, groups), (hipStream_t)stream, item_table, n_items, query, n_query, probs,
                 n_cols, nullptr, (int)splits_used, per, 1, n_cols, ep);
   RSA_CHECK_LAUNCH("rsa_fullscore_softmax");
+  return RSA_OK;
+}
+
+// query_grad[i] = sum over the item-range partials, in range order (reproducible)
+__global__ __launch_bounds__(256) void dq_reduce_kernel(const float4* __restrict__ part, int splits, int64_t n4,
+                                                        float4* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  float4 a = part[i];
+  for (int s = 1; s < splits; ++s) {
+    const float4 v = part[(size_t)s * n4 + i];
+    a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+  }
+  out[i] = a;
+}
+
+static void softmax_plan(int64_t n_query, int64_t n_items, int64_t& per, int64_t& splits_used) {
+  const int64_t n_cols = n_items - 1;
+  const int64_t splits = fullscore_splits(n_query, n_cols);
+  per = ((n_cols + splits - 1) / splits + TI - 1) / TI * TI;
+  splits_used = (n_cols + per - 1) / per;
+}
+
+extern "C" int64_t rsa_fullscore_softmax_dq_workspace_bytes(int64_t n_query, int64_t n_items, int32_t dim) {
+  if (n_query <= 0 || n_items <= 1 || dim <= 0) return 0;
+  int64_t per, splits_used;
+  softmax_plan(n_query, n_items, per, splits_used);
+  return splits_used * n_query * (int64_t)dim * (int64_t)sizeof(float) + 256;
+}
+
+extern "C" int rsa_fullscore_softmax_dq(const float* item_table, int64_t n_items, int32_t dim, const float* query,
+                                        int64_t n_query, const float* lse, const float* row_scale, float* probs,
+                                        float* query_grad, void* workspace, int64_t workspace_bytes,
+                                        rsa_stream_t stream) {
+  RSA_CHECK_ARG(n_query >= 0 && n_items >= 2, "rsa_fullscore_softmax_dq: need n_items >= 2");
+  if (n_query == 0) return RSA_OK;
+  RSA_CHECK_ARG(item_table && query && lse && probs && query_grad, "rsa_fullscore_softmax_dq: null pointer");
+  if (dim != 32 && dim != 64 && dim != 128) {
+    rsa::set_error("rsa_fullscore_softmax_dq: dim=%d: the MFMA full-score kernel is built for dim in {32, 64, 128}", dim);
+    return RSA_ERR_UNSUPPORTED;
+  }
+  RSA_CHECK_ARG(workspace && workspace_bytes >= rsa_fullscore_softmax_dq_workspace_bytes(n_query, n_items, dim),
+                "rsa_fullscore_softmax_dq: workspace too small (rsa_fullscore_softmax_dq_workspace_bytes)");
+  const int64_t n_cols = n_items - 1;
+  const unsigned groups = (unsigned)((n_query + QB - 1) / QB);
+  int64_t per, splits_used;
+  softmax_plan(n_query, n_items, per, splits_used);
+  float* part = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
+  const FilterArgs ep{nullptr, nullptr, nullptr, nullptr, lse, row_scale, nullptr, nullptr, nullptr, nullptr, nullptr, part};
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 grid((unsigned)splits_used, groups);
+#define RSA_DQ(DD)                                                                                                        \
+  hipLaunchKernelGGL((fullscore_kernel<DD, false, true, false, 0, true>), grid, dim3(256), 0, s, item_table, n_items, query, \
+                     n_query, probs, n_cols, (float2*)nullptr, (int)splits_used, per, (int64_t)1, n_cols, ep)
+  switch (dim) {
+    case 32: RSA_DQ(32); break;
+    case 64: RSA_DQ(64); break;
+    default: RSA_DQ(128); break;
+  }
+#undef RSA_DQ
+  const int64_t n4 = n_query * dim / 4;
+  hipLaunchKernelGGL(dq_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s,
+                     reinterpret_cast<const float4*>(part), (int)splits_used, n4, reinterpret_cast<float4*>(query_grad));
+  RSA_CHECK_LAUNCH("rsa_fullscore_softmax_dq");
   return RSA_OK;
 }
 

@@ -574,16 +574,26 @@ def _fullscore_composed(item_table, query, want_scores, want_lse, k, items_witho
 
 
 @_on_device
-def fullscore_softmax(item_table, query, lse, row_scale=None):
+def fullscore_softmax(item_table, query, lse, row_scale=None, want_query_grad=False):
     """rsa_fullscore_softmax: probs[b, i-1] = row_scale[b] * exp(<query_b, item_i> - lse[b]) over rows 1.. of
-    ``item_table`` (dims in {32, 64, 128})."""
+    ``item_table`` (dims in {32, 64, 128}).  ``want_query_grad``: -> (probs, probs @ item_table[1:]), the product
+    accumulated on the matrix cores in the same pass (rsa_fullscore_softmax_dq)."""
     item_table = _need(item_table, torch.float32, 'item_table')
     query = _need(query, torch.float32, 'query')
     lse = _need(lse, torch.float32, 'lse')
+    d_in = query.shape[1]
     item_table, query, dim = _pad_k(item_table, query)
     n_items = item_table.shape[0]
     B = query.shape[0]
     probs = torch.empty(B, n_items - 1, dtype=torch.float32, device=item_table.device)
+    if want_query_grad:
+        qgrad = torch.empty(B, dim, dtype=torch.float32, device=item_table.device)
+        ws_bytes = int(nat.lib().rsa_fullscore_softmax_dq_workspace_bytes(B, n_items, dim))
+        ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=item_table.device)
+        nat.check(nat.lib().rsa_fullscore_softmax_dq(ptr(item_table), n_items, dim, ptr(query), B, ptr(lse),
+                                                     ptr(_need_opt(row_scale, torch.float32, 'row_scale')), ptr(probs),
+                                                     ptr(qgrad), ptr(ws), ws_bytes, _stream()), 'rsa_fullscore_softmax_dq')
+        return probs, (qgrad if dim == d_in else qgrad[:, :d_in].contiguous())
     nat.check(nat.lib().rsa_fullscore_softmax(ptr(item_table), n_items, dim, ptr(query), B, ptr(lse),
                                               ptr(_need_opt(row_scale, torch.float32, 'row_scale')), ptr(probs),
                                               _stream()), 'rsa_fullscore_softmax')

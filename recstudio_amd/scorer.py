@@ -155,8 +155,10 @@ class _FullLseFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         query, weight, lse = ctx.saved_tensors
-        probs = ops.fullscore_softmax(weight, query, lse, g.contiguous())
-        gq = probs @ weight[1:] if ctx.needs_input_grad[0] else None
+        if ctx.needs_input_grad[0]:     # d/d query leaves the recompute pass itself (second MFMA product per tile)
+            probs, gq = ops.fullscore_softmax(weight, query, lse, g.contiguous(), want_query_grad=True)
+        else:
+            probs, gq = ops.fullscore_softmax(weight, query, lse, g.contiguous()), None
         gw = None
         if ctx.needs_input_grad[1]:
             gw = torch.empty_like(weight)

@@ -170,6 +170,26 @@ def test_full_softmax_grad_d128(ra):
     close(gw.cpu(), w.grad.cpu(), rtol=1e-4, atol=1e-7)
 
 
+@pytest.mark.parametrize('N,d,B', [(5001, 128, 300), (777, 64, 33), (40_000, 32, 129), (2, 128, 5), (100_003, 128, 257),
+                                   (3000, 48, 40)])
+def test_softmax_recompute_with_query_grad(ra, N, d, B):
+    """rsa_fullscore_softmax_dq: the recompute pass that also accumulates d/d query on the matrix cores.  probs are
+    bit-equal to the plain recompute pass; query_grad == probs @ items[1:] in float64 (ragged B / N vs the 128-query
+    and 32-item tiles, a single item, a padded dim, item-range splits that end inside a tile)."""
+    g = torch.Generator(device=DEV).manual_seed(N + d)
+    w = torch.empty(N, d, device=DEV).normal_(0, 0.3, generator=g)
+    q = torch.empty(B, d, device=DEV).normal_(0, 0.3, generator=g)
+    scale = torch.empty(B, device=DEV).uniform_(-1, 1, generator=g)
+    lse = ra.ops.fullscore(w, q, want_lse=True)[1]
+    plain = ra.ops.fullscore_softmax(w, q, lse, scale)
+    probs, gq = ra.ops.fullscore_softmax(w, q, lse, scale, want_query_grad=True)
+    assert torch.equal(probs, plain) and gq.shape == (B, d)
+    want = plain.double() @ w[1:].double()
+    close(gq.cpu(), want.float().cpu(), rtol=1e-4, atol=1e-6)
+    # twice the same bits (partials are added in a fixed order)
+    assert torch.equal(ra.ops.fullscore_softmax(w, q, lse, scale, want_query_grad=True)[1], gq)
+
+
 def test_fullscore_config5_shape_properties(ra):
     """BASELINE.json configs[4]: N = 1e6, d = 128, B = 512, k = 100: properties + oracle spot checks."""
     N, d, B, k = 1_000_001, 128, 512, 100
