@@ -8,8 +8,9 @@ device on every step, :106-159) and the dead DDP branch (recommender.py:731-740)
 [r*rows_per_shard, ...) of the item table (and of its optimizer state), a data-parallel slice of the batch and a
 replica of the user tower.  Per step (`shard.ShardedRetriever.training_step`): sample -> route -> RCCL all-to-all
 of 8-byte keys -> owner-side gather+score -> all-to-all of scores -> loss -> the same exchange backwards; the
-item-gradient block never leaves its owner, the user tower's dense gradients are summed with one bucketed
-all-reduce.  Synthetic interactions (there is no dataset download in scope); the loop is plain SGD.
+item-gradient block never leaves its owner; the replicated user table's row-sparse gradient is all-gathered as
+(ids, rows) and applied in place on every replica (an MLP tower's dense gradients would be summed with one bucketed
+all-reduce).  Synthetic interactions (there is no dataset download in scope); the loop is plain SGD.
 """
 import argparse
 import os
@@ -59,8 +60,10 @@ def main(argv=None):
         # negatives do not depend on the number of GPUs
         table = ShardedItemTable(item_local, plan, rank, dist, sample_seed=args.seed)
         inplace = args.dim in (64, 128, 256)       # item rows updated inside the backward exchange (no dense gradient block)
+        # the user table is an nn.Embedding: its gradient travels as (ids, rows) -- two small all-gathers -- and is
+        # applied in place on every replica (ShardedRetriever, sparse_query_rows); no dense [users, d] gradient exists
         trainer = ShardedRetriever(table, user, ra.UniformSampler(args.items), ra.BPRLoss(), args.neg,
-                                   item_sgd_lr=args.lr if inplace else None)
+                                   item_sgd_lr=args.lr if inplace else None, query_sgd_lr=args.lr)
         data = torch.Generator(device=dev).manual_seed(args.seed + 1000 + rank)
         t0, losses = None, []
         for step in range(args.steps):
@@ -73,12 +76,10 @@ def main(argv=None):
             pos = 1 + (uid * 2654435761 + torch.randint(0, 4, (args.batch,), device=dev, generator=data)) % (args.items - 1)
             if not inplace:
                 trainer.item_grad_local.zero_()
-            user.weight.grad = None
             loss = trainer.training_step(uid, pos)        # this rank's share of the global mean loss
-            with torch.no_grad():                         # plain SGD on the owned item rows and the replica
-                if not inplace:
+            if not inplace:
+                with torch.no_grad():                     # plain SGD on the owned item rows
                     item_local.add_(trainer.item_grad_local, alpha=-args.lr)
-                user.weight.add_(user.weight.grad, alpha=-args.lr)
             if step % 10 == 0 or step == args.steps - 1:
                 total = loss.clone()
                 dist.all_reduce(total)

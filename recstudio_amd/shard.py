@@ -151,6 +151,19 @@ class HipBackend:
                            query_table_grad=qgrad_all, query_table_pad_row=-1, item_pad_row=item_pad_row)
 
 
+    def apply_rows(self, table, ids, rows, scale, pad_row=0):
+        """table[ids[e]] += scale * rows[e], duplicates summed in sorted order without atomics: every replica that
+        applies the same (ids, rows) ends up with the same bits."""
+        m = ids.numel()
+        if m == 0:
+            return
+        d = rows.shape[1]
+        if d in (64, 128, 256):
+            ops.scatter_rows_sorted(table, rows, ids.view(m, 1), torch.full((m, 1), float(scale), device=rows.device),
+                                    query_index=torch.arange(m, device=ids.device), pad_row=pad_row)
+        else:
+            ops.scatter_add_rows(rows * float(scale), ids, table.shape[0], out=table)
+
     def full_partial(self, item_local, q_all, k, want_lse, has_pad_row):
         """This shard's part of the full-catalog pass (BASELINE.json configs[4] sharded):
         logsumexp over the local rows and the local top-k as (values, 1-based LOCAL row numbers, i.e.
@@ -166,6 +179,20 @@ class HipBackend:
         """vals/ids [B, G*k] (shard-major, each shard's list sorted) -> exact global top-k, ties -> smaller id."""
         v, cols = ops.row_topk(vals.contiguous(), k)
         return v, torch.gather(ids, 1, cols)
+
+
+_GATHER_GROUPS = {}
+
+
+def _gather_group(dist):
+    """One extra communicator over all ranks per process (and per torch.distributed look-alike), shared by every
+    ShardedItemTable: a communicator costs device buffers and a collective set-up, tables are cheap."""
+    world = getattr(getattr(dist, 'group', None), 'WORLD', None)     # a re-initialised process group is a new object
+    key = (id(dist), id(world))
+    if key not in _GATHER_GROUPS:
+        _GATHER_GROUPS.clear()                                    # groups of an earlier initialisation are dead
+        _GATHER_GROUPS[key] = (dist, world, dist.new_group())     # (holds the objects so that the ids stay unique)
+    return _GATHER_GROUPS[key][2]
 
 
 class ShardedItemTable:
@@ -188,7 +215,7 @@ class ShardedItemTable:
         # the query all-gather runs on its OWN communicator: collectives of one communicator execute in issue
         # order on one stream, so on the main group the key / score exchanges would queue behind the (at n = 64)
         # much larger gather instead of overlapping with it
-        self.gather_group = dist.new_group() if (group is None and plan.world > 1) else group
+        self.gather_group = _gather_group(dist) if (group is None and plan.world > 1) else group
         lo, hi = plan.bounds(rank)
         if item_local.shape[0] != hi - lo:
             raise ValueError(f'rank {rank} must hold rows [{lo}, {hi}) of the item table, got {item_local.shape[0]}')
@@ -522,12 +549,27 @@ class ShardedRetriever:
     (Sampler / PairwiseLoss); the item block ``table.item_local`` and its gradient block are plain tensors
     owned by this rank, updated by the caller's optimizer."""
 
-    def __init__(self, table, query_encoder, sampler, loss_fn, neg_count, item_sgd_lr=None):
+    def __init__(self, table, query_encoder, sampler, loss_fn, neg_count, item_sgd_lr=None, sparse_query_rows=None,
+                 query_sgd_lr=None):
         """``item_sgd_lr``: apply plain SGD with this learning rate to the owned item rows INSIDE the backward
         exchange (sorted scatter straight into the weight block, no [rows_local, d] gradient buffer to zero, fill
-        and add); the caller then only steps the query tower."""
+        and add); the caller then only steps the query tower.
+
+        ``sparse_query_rows`` (default: True when ``query_encoder`` is a plain ``nn.Embedding``): the replicated
+        user table's gradient is row-sparse -- B rows per rank -- so the ranks exchange ``(ids, gradient rows)`` with
+        two all-gathers (B*(d+2)*4 bytes per rank: 2 MB at B = 4096, d = 128) instead of all-reducing the dense
+        ``[n_users, d]`` gradient (512 MB at 1 M users) that autograd would build, zero and add every step.  After a
+        step ``query_rows = (ids [G*B], rows [G*B, d])`` holds the gradient of the global mean loss, identical on
+        every rank; ``query_sgd_lr`` applies plain SGD with it in place (sorted, atomics-free: replicas stay bit-equal)."""
         self.table, self.query_encoder, self.sampler, self.loss_fn = table, query_encoder, sampler, loss_fn
         self.neg_count = int(neg_count)
+        if sparse_query_rows is None:
+            sparse_query_rows = type(query_encoder) is torch.nn.Embedding
+        if sparse_query_rows and not isinstance(query_encoder, torch.nn.Embedding):
+            raise TypeError('sparse_query_rows needs an nn.Embedding query encoder')
+        if query_sgd_lr is not None and not sparse_query_rows:
+            raise ValueError('query_sgd_lr applies the row-sparse gradient: it needs sparse_query_rows')
+        self.sparse_query_rows, self.query_sgd_lr, self.query_rows = bool(sparse_query_rows), query_sgd_lr, None
         self.item_scale = None
         if item_sgd_lr is None:
             self.item_grad_local = torch.zeros_like(table.item_local)
@@ -541,12 +583,35 @@ class ShardedRetriever:
         query tower's ``.grad`` is summed over ranks, i.e. every replica ends up with the same gradient a
         single process would compute on the concatenated batch."""
         table, world = self.table, self.table.plan.world
-        q = self.query_encoder(query_feat)
+        if self.sparse_query_rows:
+            weight = self.query_encoder.weight
+            q = table.backend.gather_rows(weight.detach(), query_feat).requires_grad_(True)
+        else:
+            q = self.query_encoder(query_feat)
         B = pos_items.numel()
         log_pos, neg, log_neg = table.sample(self.sampler, B, self.neg_count, q.device, pos_items)
         pos_score, neg_score = sharded_scores(table, q, pos_items, neg, self.item_grad_local, self.item_scale)
         loss = self.loss_fn(label, pos_score, log_pos, neg_score, log_neg) / world
         loss.backward()
-        allreduce_grads(self.query_encoder.parameters(), table.dist, table.group)
+        if self.sparse_query_rows:
+            ids_all = table._all_gather_rows(query_feat.reshape(-1).contiguous())
+            rows_all = table._all_gather_rows(q.grad)
+            pad = self.query_encoder.padding_idx
+            self.query_rows = (ids_all, rows_all)
+            if self.query_sgd_lr is not None:
+                table.backend.apply_rows(weight.data, ids_all, rows_all, -float(self.query_sgd_lr),
+                                         pad_row=-1 if pad is None else int(pad))
+        else:
+            allreduce_grads(self.query_encoder.parameters(), table.dist, table.group)
         self.last_neg = neg
         return loss.detach()
+
+    def query_grad_dense(self):
+        """The row-sparse query-table gradient of the last step as a dense ``[n_users, d]`` tensor (tests, small
+        tables): what the all-reduced autograd gradient would have been."""
+        ids, rows = self.query_rows
+        out = torch.zeros_like(self.query_encoder.weight)
+        out.index_add_(0, ids, rows)
+        if self.query_encoder.padding_idx is not None:
+            out[self.query_encoder.padding_idx] = 0
+        return out

@@ -265,7 +265,24 @@ def _two_rank_worker(rank, world, port, backend, result_dir):
         trainer = ShardedRetriever(tbl, tower, ra.UniformSampler(N), ra.BPRLoss(), 64, item_sgd_lr=0.5)
         l0 = trainer.training_step(uid, pos)
         tot = sum_cpu(l0.detach().reshape(1))
-        assert abs(float(tot) - 0.6931) < 0.05 and torch.isfinite(tower.weight.grad).all()
+        assert abs(float(tot) - 0.6931) < 0.05 and tower.weight.grad is None       # nn.Embedding tower: row-sparse gradient
+        ids_all, rows_all = trainer.query_rows
+        assert ids_all.shape == (world * B,) and rows_all.shape == (world * B, d) and torch.isfinite(rows_all).all()
+        assert torch.equal(ids_all[rank * B:(rank + 1) * B], uid)
+        # every rank holds the same rows (what it applies keeps the replicas bit-equal)
+        both = gather_cpu(rows_all)
+        assert torch.equal(both[0], both[1])
+        # the same step with the user rows updated in place: W - lr * dense(row-sparse gradient), identical on both ranks
+        tower2 = torch.nn.Embedding(U, d).to(dev)
+        with torch.no_grad():
+            tower2.weight.copy_(user)
+        tbl2 = ShardedItemTable(item_d[lo:hi].clone(), plan, rank, comm)
+        trainer2 = ShardedRetriever(tbl2, tower2, ra.UniformSampler(N), ra.BPRLoss(), 64, item_sgd_lr=0.5, query_sgd_lr=0.25)
+        trainer2.training_step(uid, pos)
+        np.testing.assert_allclose(tower2.weight.detach().cpu(), (user - 0.25 * trainer.query_grad_dense()).cpu(),
+                                   rtol=1e-5, atol=1e-7)
+        reps = gather_cpu(tower2.weight.detach())
+        assert torch.equal(reps[0], reps[1])
         open(os.path.join(result_dir, f'ok{rank}'), 'w').write('ok')
     finally:
         dist.destroy_process_group()
@@ -422,6 +439,13 @@ def test_world1_rccl_sharded_training_step():
         want = item_ref.grad.clone()
         want[0] = 0
         np.testing.assert_allclose(trainer.item_grad_local.cpu(), want.cpu(), rtol=2e-4, atol=1e-7)
+        assert tower.weight.grad is None               # an nn.Embedding tower's gradient stays row-sparse
+        np.testing.assert_allclose(trainer.query_grad_dense().cpu(), w_ref.grad.cpu(), rtol=2e-4, atol=1e-7)
+        # the dense (autograd + all-reduce) path on request
+        tower.weight.grad = None
+        table_d = ShardedItemTable(item, RowShardPlan(N, 1), 0, dist)
+        dense = ShardedRetriever(table_d, tower, ra.UniformSampler(N), ra.BPRLoss(), n, sparse_query_rows=False)
+        dense.training_step(uid, pos)
         np.testing.assert_allclose(tower.weight.grad.cpu(), w_ref.grad.cpu(), rtol=2e-4, atol=1e-7)
     finally:
         dist.destroy_process_group()
@@ -466,7 +490,7 @@ def test_world1_rccl_inplace_item_sgd_equals_dense_gradient_step():
             torch.manual_seed(99)
             trainer.training_step(uid, pos)
             results.append(item if inplace else item - lr * trainer.item_grad_local)
-            results.append(tower.weight.grad.clone())
+            results.append(trainer.query_grad_dense())
         np.testing.assert_allclose(results[2].cpu(), results[0].cpu(), rtol=1e-5, atol=1e-7)
         np.testing.assert_allclose(results[3].cpu(), results[1].cpu(), rtol=1e-5, atol=1e-7)
     finally:

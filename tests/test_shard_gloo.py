@@ -108,6 +108,10 @@ class CheckerBackend:
         item_grad_local.index_add_(0, rows[live], scale * dscore[live].unsqueeze(1) * q_all[qidx[live]])
 
 
+    def apply_rows(self, table, ids, rows, scale, pad_row=0):
+        keep = ids != pad_row
+        table.index_add_(0, ids[keep], rows[keep] * float(scale))
+
     def full_partial(self, item_local, q_all, k, want_lse, has_pad_row):
         rows = item_local[1:] if has_pad_row else item_local
         sc = q_all @ rows.t()
@@ -357,6 +361,35 @@ def _train_worker(rank, world, port, n_items, d, B, n, result_dir):
         want = item_ref.grad.clone()
         want[0] = 0
         np.testing.assert_allclose(trainer.item_grad_local.numpy(), want[lo:hi].numpy(), rtol=1e-4, atol=1e-6)
+        # a replicated nn.Embedding tower: the gradient is exchanged as (ids, rows), not as a dense all-reduce
+        U = 23
+        emb_w = torch.randn(U, d, generator=g) * 0.3
+        uids = [torch.randint(1, U, (B,), generator=torch.Generator().manual_seed(700 + r)) for r in range(world)]
+        emb = torch.nn.Embedding(U, d, padding_idx=0)
+        with torch.no_grad():
+            emb.weight.copy_(emb_w)
+        table3 = ShardedItemTable(item[lo:hi].clone(), plan, rank, dist, backend=CheckerBackend())
+        trainer3 = ShardedRetriever(table3, emb, oracle.UniformSampler(n_items), bpr, n)
+        assert trainer3.sparse_query_rows
+        trainer3.training_step(uids[rank], poss[rank])
+        assert emb.weight.grad is None
+        negs3 = [torch.zeros(B, n, dtype=torch.int64) for _ in range(world)]
+        dist.all_gather(negs3, trainer3.last_neg)
+        w_ref = emb_w.clone().requires_grad_(True)
+        q3 = w_ref[torch.cat(uids)]
+        ref3 = bpr(None, (q3 * item[torch.cat(poss)]).sum(-1), None, (q3.unsqueeze(1) * item[torch.cat(negs3)]).sum(-1), None)
+        ref3.backward()
+        np.testing.assert_allclose(trainer3.query_grad_dense().numpy(), w_ref.grad.numpy(), rtol=1e-4, atol=1e-6)
+        # applied in place: the same replica on every rank
+        emb4 = torch.nn.Embedding(U, d, padding_idx=0)
+        with torch.no_grad():
+            emb4.weight.copy_(emb_w)
+        table4 = ShardedItemTable(item[lo:hi].clone(), plan, rank, dist, backend=CheckerBackend())
+        ShardedRetriever(table4, emb4, oracle.UniformSampler(n_items), bpr, n, query_sgd_lr=0.3).training_step(uids[rank], poss[rank])
+        np.testing.assert_allclose(emb4.weight.detach().numpy(), (emb_w - 0.3 * w_ref.grad).numpy(), rtol=1e-4, atol=1e-6)
+        reps = [torch.zeros(U, d) for _ in range(world)]
+        dist.all_gather(reps, emb4.weight.detach().clone())
+        assert torch.equal(reps[0], reps[1])
         open(os.path.join(result_dir, f'ok{rank}'), 'w').write('ok')
     finally:
         dist.destroy_process_group()
