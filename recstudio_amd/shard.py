@@ -162,7 +162,8 @@ class HipBackend:
             ops.scatter_rows_sorted(table, rows, ids.view(m, 1), torch.full((m, 1), float(scale), device=rows.device),
                                     query_index=torch.arange(m, device=ids.device), pad_row=pad_row)
         else:
-            ops.scatter_add_rows(rows * float(scale), ids, table.shape[0], out=table)
+            keep = (ids != pad_row).to(rows.dtype).unsqueeze(1) * float(scale)     # the padding row takes no gradient
+            ops.scatter_add_rows(rows * keep, ids, table.shape[0], out=table)
 
     def full_partial(self, item_local, q_all, k, want_lse, has_pad_row):
         """This shard's part of the full-catalog pass (BASELINE.json configs[4] sharded):
