@@ -15,7 +15,8 @@ item = torch.empty(N, d, device=dev).normal_(0, 0.02, generator=g)
 user = torch.empty(U, d, device=dev).normal_(0, 0.02, generator=g)
 uid = torch.randint(1, U, (B,), device=dev, generator=g)
 pos = torch.randint(1, N, (B,), device=dev, generator=g)
-tbl = shard.ShardedItemTable(item, shard.RowShardPlan(N, 1), 0, dist, exchange=os.environ.get('EXCHANGE', 'fixed'))
+tbl = shard.ShardedItemTable(item, shard.RowShardPlan(N, 1), 0, dist, exchange=os.environ.get('EXCHANGE', 'fixed'),
+                             chunks=int(os.environ.get('CHUNKS', 1)))
 smp = ra.UniformSampler(N)
 def step():
     o = tbl.sample_and_score(user, uid, pos, n, smp)
