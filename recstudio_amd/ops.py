@@ -46,9 +46,15 @@ def is_known_zero(t):
 _LAUNCH_DEV = []
 
 
+def _raw_stream(dev=None):
+    """hipStream_t (as an int) of the current stream of ``dev``.  torch.cuda.current_stream() builds a Stream object
+    (6 us a call, seven calls per sharded step); the raw getter is a plain C call."""
+    index = dev.index if dev is not None and dev.index is not None else torch.cuda.current_device()
+    return torch._C._cuda_getCurrentRawStream(index)
+
+
 def _stream():
-    dev = _LAUNCH_DEV[-1] if _LAUNCH_DEV else None
-    return ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    return ctypes.c_void_p(_raw_stream(_LAUNCH_DEV[-1] if _LAUNCH_DEV else None))
 
 
 def _tensor_device(args, kwargs):
@@ -95,7 +101,7 @@ _SCRATCH = {}
 
 def _scratch():
     dev = _LAUNCH_DEV[-1] if _LAUNCH_DEV else torch.device('cuda', torch.cuda.current_device())
-    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    key = (dev.index, _raw_stream(dev))
     t = _SCRATCH.get(key)
     if t is None:
         t = _SCRATCH[key] = torch.zeros(int(nat.lib().rsa_scratch_bytes()), dtype=torch.uint8, device=dev)
