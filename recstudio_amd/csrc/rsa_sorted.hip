@@ -5,8 +5,11 @@
 // autograd) is an atomic scatter in ATen and in rsa_fused_backward's dense mode.  Float atomics from 8 XCDs to
 // one table are performed at the memory side, a dword at a time: 537 M of them cost 2.5 ms per step at
 // B = 65536, n = 64, d = 128.  Here the elements are sorted by item id first (rocPRIM radix sort of (id, element)
-// pairs, stable), every run of equal ids is summed by ONE wave in element order and the row is read-modified-
-// written once with full-line accesses: no atomics, bit-reproducible, ~2x faster.
+// pairs, stable), every wave sums its 64 sorted elements run by run in element order, and every row is read-modified-
+// written once with full-line accesses: no atomics, bit-reproducible, ~2x faster.  A run that crosses chunk
+// boundaries (rare and short for item ids; the RULE when the key is a query index -- the owner side of the sharded
+// backward sums ~1000 item rows per query) is not walked by one wave: each chunk leaves the partial sum of its
+// leading / trailing open segment in the workspace and a second kernel adds a run's partials in chunk order.
 // `target` may be a zeroed dense gradient (== the reference's weight.grad) or the weight table itself with
 // scale = -lr (plain SGD applied in place).
 #include "rsa_common.hpp"
@@ -44,14 +47,52 @@ struct AdamArgs {            // exp_avg == nullptr: plain accumulate (target[id]
   float one_minus_beta1, one_minus_beta2, eps, step_size;
 };
 
-// One wave per chunk of 64 sorted elements; a run of equal ids belongs to the wave that holds its first element.
+// target[cur] (+ lazy Adam state) <- one read-modify-write of the row with the run's sum `acc`; trow / mrow_v / vrow_v
+// are the row's current values (requested earlier, at the head of the run).
+template <int NDW>
+__device__ __forceinline__ void apply_run(float* __restrict__ target, const AdamArgs& adam, int32_t cur, float scale, int lane,
+                                          const float (&acc)[NDW], const float (&trow)[NDW], const float (&mrow_v)[NDW],
+                                          const float (&vrow_v)[NDW]) {
+  constexpr int D = 64 * NDW;
+  float* row = target + (size_t)cur * D;
+  if (adam.exp_avg == nullptr) {
+#pragma unroll
+    for (int k = 0; k < NDW; ++k) row[k * 64 + lane] = trow[k] + scale * acc[k];
+    return;
+  }
+  // lazy Adam on the touched row (torch.optim.SparseAdam's update, torch/optim/_functional.py sparse_adam):
+  // m += (g - m)(1 - b1); v += (g^2 - v)(1 - b2); w -= step_size * m / (sqrt(v) + eps)
+  float* mrow = adam.exp_avg + (size_t)cur * D;
+  float* vrow = adam.exp_avg_sq + (size_t)cur * D;
+#pragma unroll
+  for (int k = 0; k < NDW; ++k) {
+    const int c = k * 64 + lane;
+    const float g = scale * acc[k];
+    const float m0 = mrow_v[k], v0 = vrow_v[k];
+    const float m1 = m0 + (g - m0) * adam.one_minus_beta1;
+    const float v1 = v0 + (g * g - v0) * adam.one_minus_beta2;
+    mrow[c] = m1;
+    vrow[c] = v1;
+    row[c] = trow[k] - adam.step_size * (m1 / (sqrtf(v1) + adam.eps));
+  }
+}
+
+// Per-chunk record of the open segments: meta[4 c + 0] = key of the LEADING segment if it continues the previous chunk's
+// run (else -1), [1] = 1 if that segment is the whole chunk, [2] = key of the TRAILING segment if its run goes on into
+// the next chunk and started in this one (else -1).
+enum { META_LEAD_KEY = 0, META_LEAD_FULL = 1, META_TRAIL_KEY = 2, META_STRIDE = 4 };
+
+// One wave per chunk of 64 sorted elements.  Runs that begin and end inside the chunk are applied here; the open
+// leading / trailing segments leave their partial sums in lead_part / trail_part [chunk, D] for sorted_finish_kernel.
 template <int NDW>   // dwords per lane per row: D = 64 * NDW
 __global__ __launch_bounds__(256) void sorted_apply_kernel(const int32_t* __restrict__ keys, const int32_t* __restrict__ vals,
                                                            int64_t total, const float* __restrict__ query,
                                                            const int64_t* __restrict__ query_index, int n, int has_pos,
                                                            const float* __restrict__ dpos, const float* __restrict__ dneg,
                                                            const float* __restrict__ upstream, int32_t pad_row,
-                                                           int32_t drop_key, float* __restrict__ target, AdamArgs adam) {
+                                                           int32_t drop_key, float* __restrict__ target, AdamArgs adam,
+                                                           float* __restrict__ lead_part, float* __restrict__ trail_part,
+                                                           int32_t* __restrict__ meta) {
   constexpr int D = 64 * NDW;
   const int lane = lane_id();
   const int64_t chunk = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -72,48 +113,35 @@ __global__ __launch_bounds__(256) void sorted_apply_kernel(const int32_t* __rest
     qrow = (int32_t)(query_index ? query_index[m] : m);
     coef = (has_pos && c == 0) ? dpos[m] : dneg[m * (int64_t)n + (c - has_pos)];
   }
-  const int32_t prev = begin > 0 ? keys[begin - 1] : -1;     // a run continuing from the previous chunk is not ours
+  const int cnt = (int)(total - begin < 64 ? total - begin : 64);
+  const int32_t prev = begin > 0 ? keys[begin - 1] : -1;                     // key in front of the chunk
+  const int32_t next = begin + cnt < total ? keys[begin + cnt] : -1;         // key behind it
   float acc[NDW];
   float trow[NDW], mrow_v[NDW], vrow_v[NDW];     // the current run's target (and Adam state) row, requested at its head
 #pragma unroll
   for (int k = 0; k < NDW; ++k) acc[k] = trow[k] = mrow_v[k] = vrow_v[k] = 0.f;
   int32_t cur = -1;           // id of the run being accumulated (-1: none)
-  const bool is_adam = adam.exp_avg != nullptr;
-  auto flush = [&]() {
-    if (cur >= 0 && cur != pad_row) {
-      float* row = target + (size_t)cur * D;
-      if (!is_adam) {
+  bool leading = false;       // accumulating the segment that continues the previous chunk's run
+  int32_t lead_key = -1;
+  auto close_segment = [&]() {        // a new run begins (or the chunk ends closed): what has been summed so far is complete
+    if (leading) {
+      if (cur != drop_key) {
 #pragma unroll
-        for (int k = 0; k < NDW; ++k) row[k * 64 + lane] = trow[k] + scale * acc[k];
-      } else {
-        // lazy Adam on the touched row (torch.optim.SparseAdam's update, torch/optim/_functional.py sparse_adam):
-        // m += (g - m)(1 - b1); v += (g^2 - v)(1 - b2); w -= step_size * m / (sqrt(v) + eps)
-        float* mrow = adam.exp_avg + (size_t)cur * D;
-        float* vrow = adam.exp_avg_sq + (size_t)cur * D;
-#pragma unroll
-        for (int k = 0; k < NDW; ++k) {
-          const int c = k * 64 + lane;
-          const float g = scale * acc[k];
-          const float m0 = mrow_v[k], v0 = vrow_v[k];
-          const float m1 = m0 + (g - m0) * adam.one_minus_beta1;
-          const float v1 = v0 + (g * g - v0) * adam.one_minus_beta2;
-          mrow[c] = m1;
-          vrow[c] = v1;
-          row[c] = trow[k] - adam.step_size * (m1 / (sqrtf(v1) + adam.eps));
-        }
+        for (int k = 0; k < NDW; ++k) lead_part[(size_t)chunk * D + k * 64 + lane] = acc[k];
       }
+      leading = false;
+    } else if (cur >= 0 && cur != pad_row && cur != drop_key) {
+      apply_run<NDW>(target, adam, cur, scale, lane, acc, trow, mrow_v, vrow_v);
     }
 #pragma unroll
     for (int k = 0; k < NDW; ++k) acc[k] = 0.f;
   };
-  const int cnt = (int)(total - begin < 64 ? total - begin : 64);
-  bool skipping = true;       // until the first head inside the chunk
   bool done = false;
   // The query rows AND the target rows of U consecutive elements are requested together before the (serial) run logic
   // consumes them.  Round 1 loaded one query row per iteration and read-modified-wrote the target row inside flush():
   // every element waited for its own round trip and every run for an HBM read in the middle of the serial chain
-  // (0.9 ms of the 1.7 ms SGD step).  A target row belongs to exactly one run and a run to exactly one
-  // wave, so reading it at the head of the run instead of at its end sees the same value.  Lanes past the chunk's
+  // (0.9 ms of the 1.7 ms SGD step).  A target row belongs to exactly one run and a closed run to exactly
+  // one wave, so reading it at the head of the run instead of at its end sees the same value.  Lanes past the chunk's
   // end, dropped and padding elements request row 0, always readable.
   constexpr int U = RSA_SORTED_UNROLL;
   for (int t0 = 0; t0 < cnt && !done; t0 += U) {
@@ -131,7 +159,7 @@ __global__ __launch_bounds__(256) void sorted_apply_kernel(const int32_t* __rest
         qv[u][k] = qp[k * 64 + lane];
         tv[u][k] = tp[k * 64 + lane];
       }
-      if (is_adam) {
+      if (adam.exp_avg != nullptr) {
         const float* mp = adam.exp_avg + (size_t)kr * D;
         const float* vp = adam.exp_avg_sq + (size_t)kr * D;
 #pragma unroll
@@ -151,10 +179,8 @@ __global__ __launch_bounds__(256) void sorted_apply_kernel(const int32_t* __rest
       const int32_t kt = __builtin_amdgcn_readlane(key, t);
       const int32_t before = t == 0 ? prev : __builtin_amdgcn_readlane(key, t - 1);
       const bool head = kt != before;
-      if (skipping && !head) continue;
-      skipping = false;
       if (head) {
-        flush();
+        close_segment();
         cur = kt;
 #pragma unroll
         for (int k = 0; k < NDW; ++k) {
@@ -162,6 +188,9 @@ __global__ __launch_bounds__(256) void sorted_apply_kernel(const int32_t* __rest
           mrow_v[k] = mv[u][k];
           vrow_v[k] = vv[u][k];
         }
+      } else if (t == 0) {            // the chunk opens inside a run that began in an earlier chunk
+        leading = true;
+        cur = lead_key = kt;
       }
       if (cur == drop_key) {          // the dropped run is the last one (largest key): nothing follows
         done = true;
@@ -172,19 +201,56 @@ __global__ __launch_bounds__(256) void sorted_apply_kernel(const int32_t* __rest
       for (int k = 0; k < NDW; ++k) acc[k] = __fmaf_rn(cf, qv[u][k], acc[k]);
     }
   }
-  if (skipping || cur == drop_key) return;       // the whole chunk continues a run owned by an earlier wave / empty slots
-  // the last run may continue into the following chunks: finish it here (rare, short)
-  for (int64_t j = begin + cnt; j < total && keys[j] == cur; ++j) {
-    const int64_t e = vals[j];
-    const int64_t m = e / w;
-    const int c = (int)(e - m * w);
-    const int64_t qr = query_index ? query_index[m] : m;
-    const float cf = (has_pos && c == 0) ? dpos[m] : dneg[m * (int64_t)n + (c - has_pos)];
-    const float* qp = query + (size_t)qr * D;
+  // the chunk's last segment: still the leading one (the whole chunk lies inside one run), open towards the next chunk,
+  // or closed
+  const bool whole = leading;
+  int32_t trail_key = -1;
+  if (leading) {
+    close_segment();                                  // -> lead_part
+  } else if (cur >= 0 && cur != drop_key && next == cur) {
+    trail_key = cur;                                  // the run goes on: sorted_finish_kernel owns its row
 #pragma unroll
-    for (int k = 0; k < NDW; ++k) acc[k] = __fmaf_rn(cf, qp[k * 64 + lane], acc[k]);
+    for (int k = 0; k < NDW; ++k) trail_part[(size_t)chunk * D + k * 64 + lane] = acc[k];
+  } else {
+    close_segment();
   }
-  flush();
+  if (lane == 0) {
+    meta[chunk * META_STRIDE + META_LEAD_KEY] = lead_key;
+    meta[chunk * META_STRIDE + META_LEAD_FULL] = whole ? 1 : 0;
+    meta[chunk * META_STRIDE + META_TRAIL_KEY] = trail_key;
+  }
+}
+
+// One wave per chunk whose trailing segment opened a run: adds the leading partials of the following chunks in chunk
+// order (a chunk that lies wholly inside the run passes the walk on) and applies the row once.
+template <int NDW>
+__global__ __launch_bounds__(256) void sorted_finish_kernel(int64_t n_chunks, const float* __restrict__ upstream,
+                                                            int32_t pad_row, float* __restrict__ target, AdamArgs adam,
+                                                            const float* __restrict__ lead_part,
+                                                            const float* __restrict__ trail_part,
+                                                            const int32_t* __restrict__ meta) {
+  constexpr int D = 64 * NDW;
+  const int lane = lane_id();
+  const int64_t chunk = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (chunk >= n_chunks) return;
+  const int32_t cur = meta[chunk * META_STRIDE + META_TRAIL_KEY];
+  if (cur < 0 || cur == pad_row) return;
+  const float scale = upstream ? upstream[0] : 1.f;
+  float acc[NDW], trow[NDW], mrow_v[NDW], vrow_v[NDW];
+#pragma unroll
+  for (int k = 0; k < NDW; ++k) {
+    acc[k] = trail_part[(size_t)chunk * D + k * 64 + lane];
+    trow[k] = target[(size_t)cur * D + k * 64 + lane];
+    mrow_v[k] = adam.exp_avg ? adam.exp_avg[(size_t)cur * D + k * 64 + lane] : 0.f;
+    vrow_v[k] = adam.exp_avg ? adam.exp_avg_sq[(size_t)cur * D + k * 64 + lane] : 0.f;
+  }
+  for (int64_t c2 = chunk + 1; c2 < n_chunks; ++c2) {
+    if (meta[c2 * META_STRIDE + META_LEAD_KEY] != cur) break;
+#pragma unroll
+    for (int k = 0; k < NDW; ++k) acc[k] += lead_part[(size_t)c2 * D + k * 64 + lane];
+    if (!meta[c2 * META_STRIDE + META_LEAD_FULL]) break;
+  }
+  apply_run<NDW>(target, adam, cur, scale, lane, acc, trow, mrow_v, vrow_v);
 }
 
 static inline int64_t align256s(int64_t b) { return (b + 255) / 256 * 256; }
@@ -209,7 +275,10 @@ using namespace rsa;
 extern "C" int64_t rsa_scatter_rows_sorted_workspace_bytes(int64_t n_queries, int32_t num_neg, int64_t n_items) {
   if (n_queries <= 0 || num_neg < 0 || n_items < 1) return 0;
   const int64_t total = n_queries * (int64_t)(num_neg + 1);     // sized for the with-positives layout
-  return 4 * align256s(total * 4) + align256s((int64_t)sort_temp_bytes(total, key_bits(n_items + 1))) + 256;
+  const int64_t chunks = (total + 63) / 64;
+  // + per chunk: two partial rows (sized for dim = 256) and the segment record
+  return 4 * align256s(total * 4) + align256s((int64_t)sort_temp_bytes(total, key_bits(n_items + 1))) +
+         2 * align256s(chunks * 256 * 4) + align256s(chunks * META_STRIDE * 4) + 256;
 }
 
 static int scatter_sorted_impl(const float* query, const int64_t* query_index, int64_t n_query_rows, int32_t dim,
@@ -240,6 +309,12 @@ static int scatter_sorted_impl(const float* query, const int64_t* query_index, i
   int32_t* k_out = reinterpret_cast<int32_t*>(ws + 2 * seg);
   int32_t* v_out = reinterpret_cast<int32_t*>(ws + 3 * seg);
   void* temp = ws + 4 * seg;
+  const int64_t max_total = n_queries * (int64_t)(num_neg + 1);
+  const int64_t max_chunks = (max_total + 63) / 64;
+  char* tail = ws + 4 * seg + align256s((int64_t)sort_temp_bytes(max_total, key_bits(n_items + 1)));
+  float* lead_part = reinterpret_cast<float*>(tail);
+  float* trail_part = reinterpret_cast<float*>(tail + align256s(max_chunks * 256 * 4));
+  int32_t* meta = reinterpret_cast<int32_t*>(tail + 2 * align256s(max_chunks * 256 * 4));
   int64_t blocks = (total + 255) / 256;
   if (blocks > 65536) blocks = 65536;
   hipLaunchKernelGGL(sorted_keys_kernel, dim3((unsigned)blocks), dim3(256), 0, s, pos_ids, neg_ids, n_queries, (int)num_neg,
@@ -254,11 +329,17 @@ static int scatter_sorted_impl(const float* query, const int64_t* query_index, i
   const unsigned chunks = (unsigned)((total + 63) / 64);
   dim3 grid((chunks + 3) / 4), block(256);
   const int32_t pad = (int32_t)(pad_row < 0 || pad_row >= (1ll << 31) ? -2 : pad_row);
+#define RSA_SORTED_LAUNCH(NDW)                                                                                          \
+  hipLaunchKernelGGL(sorted_apply_kernel<NDW>, grid, block, 0, s, k_out, v_out, total, query, query_index, (int)num_neg,  \
+                     has_pos, dpos, dneg, upstream, pad, (int32_t)n_items, target, adam, lead_part, trail_part, meta);   \
+  hipLaunchKernelGGL(sorted_finish_kernel<NDW>, grid, block, 0, s, (int64_t)chunks, upstream, pad, target, adam,          \
+                     lead_part, trail_part, meta)
   switch (dim) {
-    case 64: hipLaunchKernelGGL(sorted_apply_kernel<1>, grid, block, 0, s, k_out, v_out, total, query, query_index, (int)num_neg, has_pos, dpos, dneg, upstream, pad, (int32_t)n_items, target, adam); break;
-    case 128: hipLaunchKernelGGL(sorted_apply_kernel<2>, grid, block, 0, s, k_out, v_out, total, query, query_index, (int)num_neg, has_pos, dpos, dneg, upstream, pad, (int32_t)n_items, target, adam); break;
-    default: hipLaunchKernelGGL(sorted_apply_kernel<4>, grid, block, 0, s, k_out, v_out, total, query, query_index, (int)num_neg, has_pos, dpos, dneg, upstream, pad, (int32_t)n_items, target, adam); break;
+    case 64: RSA_SORTED_LAUNCH(1); break;
+    case 128: RSA_SORTED_LAUNCH(2); break;
+    default: RSA_SORTED_LAUNCH(4); break;
   }
+#undef RSA_SORTED_LAUNCH
   RSA_CHECK_LAUNCH("rsa_scatter_rows_sorted(apply)");
   return RSA_OK;
 }

@@ -448,6 +448,33 @@ def test_sorted_scatter_small_and_ragged_shapes(ra, M, n, with_pos):
     np.testing.assert_allclose(got.cpu(), want.float().cpu(), rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize('N,M,n,d', [(5, 700, 64, 128), (3, 9000, 5, 64), (40, 3000, 33, 256), (2, 64, 1, 128), (1, 129, 1, 128)])
+def test_sorted_scatter_long_runs(ra, N, M, n, d):
+    """Few target rows, thousands of elements each (the owner side of the sharded backward sorts by QUERY index: runs of
+    ~1000): runs that span many 64-element chunks are summed from per-chunk partials in chunk order -- equal to a float64
+    index_add, bit-identical from call to call, empty slots (negative ids) dropped, with and without a padding row."""
+    g = torch.Generator(device=DEV).manual_seed(N * 1000 + M)
+    U = 50
+    src = torch.randn(U, d, device=DEV, generator=g)
+    uid = torch.randint(0, U, (M,), device=DEV, generator=g)
+    ids = torch.randint(0, N, (M, n), device=DEV, generator=g)
+    ids[torch.rand(M, n, device=DEV, generator=g) < 0.05] = -1                   # empty slots
+    dn = torch.randn(M, n, device=DEV, generator=g)
+    for pad_row in (-1, 0):
+        base = torch.randn(N, d, device=DEV, generator=g)
+        got = ra.ops.scatter_rows_sorted(base.clone(), src, ids, dn, query_index=uid, pad_row=pad_row)
+        keep = ids.reshape(-1) >= 0
+        want = base.double()
+        contrib = (dn.double().unsqueeze(-1) * src[uid].double().unsqueeze(1)).reshape(-1, d)
+        want.index_add_(0, ids.reshape(-1)[keep], contrib[keep])
+        if pad_row >= 0:
+            want[pad_row] = base[pad_row].double()
+        scale = float(contrib.abs().sum(0).max())
+        np.testing.assert_allclose(got.cpu(), want.float().cpu(), rtol=1e-5, atol=1e-6 * max(1.0, scale))
+        again = ra.ops.scatter_rows_sorted(base.clone(), src, ids, dn, query_index=uid, pad_row=pad_row)
+        assert torch.equal(got, again)
+
+
 def test_fused_adam_step_equals_sparse_grads_plus_torch_sparse_adam(ra):
     """fused.FusedBPRAdam (no gradient tensors; lazy Adam applied by rsa_adam_rows_sorted) == loss.backward() with
     COO gradients + torch.optim.SparseAdam.step(), three steps, same sampled negatives."""
