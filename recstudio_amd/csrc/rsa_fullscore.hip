@@ -710,6 +710,7 @@ __global__ __launch_bounds__(256) void mask_history_kernel(const float* __restri
     }
     kept += __popcll(keep_mask);
     dropped += __popcll(drop_mask);
+    if (kept >= k) break;       // (wave-uniform) the k best survivors are out; the rest of the list cannot matter
   }
 }
 

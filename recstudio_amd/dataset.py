@@ -135,6 +135,11 @@ class _DeviceLoader:
                 bucket = torch.div(torch.randperm(n, device=self.device), self.batch_size * 10, rounding_mode='floor')
                 key = length + bucket * (length.max() + 1)
             order = torch.sort(key, stable=True).indices
+            # padded width of every batch of the epoch (the longest history in it) in ONE read-back, instead of an
+            # int(lens.max()) per batch -- that sync stalled the stream once per step
+            pad = (-n) % self.batch_size
+            lens_epoch = torch.cat([length[order], length.new_zeros(pad)]).view(-1, self.batch_size)
+            widths = lens_epoch.max(1).values.tolist()
         else:
             order = torch.randperm(n, device=self.device) if self.shuffle else torch.arange(n, device=self.device)
         ds = self.ds
@@ -148,7 +153,7 @@ class _DeviceLoader:
                 continue
             start, end = rows[:, 1].contiguous(), rows[:, 2].contiguous()
             lens = end - start
-            L = int(lens.max())
+            L = int(widths[lo // self.batch_size])
             batch = {ds.fuid: rows[:, 0], 'seqlen': lens}
             ids, _, _ = self.ops.seg_gather(None, self.cols[ds.fiid], start, end, L, want_rows=False)
             batch['in_' + ds.fiid] = ids

@@ -615,6 +615,12 @@ def test_retriever_topk_with_history_longer_than_1024(ra):
         m = int(torch.randint(5, Lh + 1, (1,), generator=g))
         hist[b, :m] = torch.randperm(N - 1, generator=g)[:m] + 1
     uid = torch.randint(1, U, (B,), generator=g)
+    # adversarial rows: the history IS the head of the ranking (rows 0 and 1: their 1000 / 1290 best items), so fewer than
+    # k of the 1024 in-kernel candidates survive and the row takes the wide path
+    for b, m_top in ((0, 1000), (1, 1290)):
+        best = torch.topk(uw[uid[b]] @ iw[1:].t(), m_top).indices + 1
+        hist[b] = 0
+        hist[b, :m_top] = best
     m = ra.BaseRetriever({'train': {'seed': 1}}, scorer=ra.InnerProductScorer(),
                          item_encoder=torch.nn.Embedding(N, d, padding_idx=0),
                          query_encoder=torch.nn.Embedding(U, d, padding_idx=0))
