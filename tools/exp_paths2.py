@@ -45,7 +45,6 @@ try:
     end = torch.arange(n_inter2)
     keep = end > user_start
     ds.data_index = torch.stack([uu[keep], torch.maximum(user_start[keep], end[keep] - 50), end[keep]], 1)
-    ds.sample_length = ds.data_index[:, 2] - ds.data_index[:, 1]
     ld = ds.device_train_loader(8192, shuffle=True, device=dev)
     def epoch2():
         c = 0
