@@ -262,6 +262,7 @@ __global__ __launch_bounds__(256, DQ ? RSA_FS_DQ_MIN_BLOCKS : RSA_FS_MIN_BLOCKS)
   // ---- per-tile epilogue pieces.  They are applied to the PREVIOUS tile's accumulators while the current
   // tile's MFMA chain (64 dependent 64-cycle instructions) is in flight.
   // (a) branch-free online logsumexp: pure VALU, interleaved with the MFMAs by the sched_group_barriers below
+  float tile_max = -INFINITY;      // max of the tile's (in-range) scores, left by lse_update for the candidate filter
   auto lse_update = [&](const f32x16& acc, int64_t i0, auto masked) __attribute__((always_inline)) {
 #if RSA_FS_EXP & 4
     run_s += acc[0] + acc[5] + acc[10] + acc[15];   // experiment: GEMM core without the logsumexp epilogue
@@ -281,6 +282,7 @@ __global__ __launch_bounds__(256, DQ ? RSA_FS_DQ_MIN_BLOCKS : RSA_FS_MIN_BLOCKS)
 #pragma unroll
     for (int r = 3; r < 15; r += 2) tmax = fmaxf(fmaxf(tmax, v[r]), v[r + 1]);    // v_max3_f32
     tmax = fmaxf(tmax, v[15]);
+    tile_max = tmax;
     const float m_new = fmaxf(run_m, tmax);
     const float m_safe = m_new == -INFINITY ? 0.f : m_new;   // nothing seen yet: exp(-inf - 0) = 0 everywhere
     // exp(x - m) = 2^(x * log2(e) - m * log2(e)): one fma + one v_exp per element (VALU slots are what the
@@ -338,9 +340,14 @@ __global__ __launch_bounds__(256, DQ ? RSA_FS_DQ_MIN_BLOCKS : RSA_FS_MIN_BLOCKS)
     }
     if constexpr (FILTER) {
       // candidate filter: almost never taken once the threshold is in place
+      // with the logsumexp in the same pass the tile maximum is already there
       float best = -INFINITY;
+      if constexpr (LSE) {
+        best = tile_max;
+      } else {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) best = fmaxf(best, acc[r]);
+        for (int r = 0; r < 16; ++r) best = fmaxf(best, acc[r]);
+      }
       if (best > thr) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -431,6 +438,11 @@ __global__ __launch_bounds__(256, DQ ? RSA_FS_DQ_MIN_BLOCKS : RSA_FS_MIN_BLOCKS)
     if constexpr (MODE != 0) acc_prev = to_score(acc_prev, i_begin + (int64_t)(u - 1) * TI);
     if constexpr (LSE) {
       lse_update(acc_prev, i_begin + (int64_t)(u - 1) * TI, masked);
+      // Pin the logsumexp state in front of the filter's branch: its exps are only needed by the NEXT tile's update, so
+      // the compiler sank them past the branch into a block of their own at the loop head, outside the MFMA chain
+      // they are meant to be interleaved with.  (Measured: no change in kernel time -- the SIMD's other wave covers
+      // the gap -- but the loop now has the shape the sched_group_barriers describe.)
+      if constexpr (FILTER) asm volatile("" : "+v"(run_s), "+v"(run_m));
       // one MFMA of this tile, then a couple of the previous tile's epilogue VALU ops, and so on
 #pragma unroll
       for (int g = 0; g < KH; ++g) {
