@@ -30,6 +30,7 @@ tests can drive it on CPU with a checker backend supplied BY THE TEST; this modu
 CPU implementation of the compute.
 """
 import ctypes
+import weakref
 
 import torch
 
@@ -187,13 +188,22 @@ _GATHER_GROUPS = {}
 
 def _gather_group(dist):
     """One extra communicator over all ranks per process (and per torch.distributed look-alike), shared by every
-    ShardedItemTable: a communicator costs device buffers and a collective set-up, tables are cheap."""
+    ShardedItemTable: a communicator costs device buffers and a collective set-up, tables are cheap.  Only a WEAK
+    reference is kept: torch.distributed owns the group until destroy_process_group(); a strong reference here kept
+    the (gloo) backend's threads alive past that call and the process aborted at interpreter shutdown now and then."""
     world = getattr(getattr(dist, 'group', None), 'WORLD', None)     # a re-initialised process group is a new object
     key = (id(dist), id(world))
-    if key not in _GATHER_GROUPS:
-        _GATHER_GROUPS.clear()                                    # groups of an earlier initialisation are dead
-        _GATHER_GROUPS[key] = (dist, world, dist.new_group())     # (holds the objects so that the ids stay unique)
-    return _GATHER_GROUPS[key][2]
+    hit = _GATHER_GROUPS.get(key)
+    if hit is not None:
+        if hit == 'none':                      # a look-alike whose new_group() returns None
+            return None
+        group = hit()
+        if group is not None:
+            return group
+    _GATHER_GROUPS.clear()                     # groups of an earlier initialisation are dead
+    group = dist.new_group()
+    _GATHER_GROUPS[key] = 'none' if group is None else weakref.ref(group)
+    return group
 
 
 class ShardedItemTable:
