@@ -30,7 +30,11 @@
 extern "C" {
 #endif
 
-#define RSA_ABI_VERSION 4   /* 4: rsa_fullscore_softmax_dq (d/d query of the full softmax on the matrix cores, in the
+#define RSA_ABI_VERSION 5   /* 5: version 2 of the fixed-capacity shard exchange (rsa_shard_sample_route: sampling fused into the routing
+                               pass, self-describing segments with {count, dropped} headers, 32-bit slots; rsa_shard_score_segments;
+                               rsa_shard_home: scatter + loss + mean + routed-order gradient in one launch; rsa_shard_unpack_segments;
+                               rsa_shard_scatter_slots); rsa_sample_masked_uniform takes elem_base;
+                               4: rsa_fullscore_softmax_dq (d/d query of the full softmax on the matrix cores, in the
                                recompute pass); 3: caller-owned reduction scratch (rsa_scratch_bytes; the library allocates nothing);
                                Philox element base (G-invariant sampling across ranks); bucket-line inverse CDF
                                (cdf_lines); SampledSoftmax epilogue (fused_loss = 2); cosine / Euclidean full-catalog
@@ -86,10 +90,10 @@ int rsa_sample_uniform(int64_t* neg_ids, int64_t numel, int64_t low, int64_t hig
  * rejection-free uniform negatives over the items NOT in each user's 0-padded history
  * user_hist [n_rows, hist_len] (hist_len <= 2048).  num_items excludes the padding id.  neg_ids
  * [n_rows, per_row] (per_row = queries-per-user x num_neg); u = torch.rand(n_rows, per_row) on the
- * device stream. */
+ * device stream (elem_base as in "Philox state": a rank's rows of one job-wide call). */
 int rsa_sample_masked_uniform(const int64_t* user_hist, int64_t n_rows, int32_t hist_len, int64_t num_items,
                               int32_t per_row, int64_t* neg_ids, uint64_t seed, uint64_t offset,
-                              uint32_t grid_threads, rsa_stream_t stream);
+                              uint32_t grid_threads, uint64_t elem_base, rsa_stream_t stream);
 
 /* PopularSamplerModel.forward -- recstudio/ann/sampler.py:243-258
  * (u = torch.rand; ids = torch.searchsorted(table, u); logp = log(pop_prob[ids])).
@@ -418,23 +422,110 @@ int rsa_shard_count(const int64_t* pos_ids, const int64_t* neg_ids, int64_t n_qu
 int rsa_shard_route(const int64_t* pos_ids, const int64_t* neg_ids, int64_t n_queries, int32_t num_neg,
                     int64_t rows_per_shard, int32_t n_shards, int64_t query_base, int32_t* cursor,
                     int64_t* keys, int64_t* positions, rsa_stream_t stream);
-/* FIXED-CAPACITY form of the routing (no owner histogram, no split sizes on the host): owner g's segment is
- * slots [g*capacity, (g+1)*capacity) of keys / positions [n_shards*capacity].  The unused tail of every segment is
- * filled with -1 ("empty slot") by this call; empty slots travel through the equal-split all-to-all as they are and
- * every consumer skips them: rsa_fused_sample_gather_score (packed_keys < 0 -> score 0), rsa_shard_unpack
- * (-> row -1, query -1), rsa_scatter_rows_sorted (negative ids dropped), rsa_scatter_f32 / rsa_gather_f32
- * (negative position -> nothing written / 0).  An element that finds its owner's segment full is NOT routed and
- * is counted in *overflow (device word, zeroed by the caller once, sticky): the caller sizes `capacity` from a
- * calibration step and checks the word off the critical path.  cursor: [n_shards] int32 device scratch. */
-int rsa_shard_route_fixed(const int64_t* pos_ids, const int64_t* neg_ids, int64_t n_queries, int32_t num_neg,
-                          int64_t rows_per_shard, int32_t n_shards, int64_t query_base, int64_t capacity,
-                          int32_t* cursor, int64_t* keys, int64_t* positions, int32_t* overflow, rsa_stream_t stream);
 int rsa_shard_unpack(const int64_t* keys, int64_t numel, int64_t* local_rows, int64_t* query_index,
                      rsa_stream_t stream);
-/* dst[positions[i]] = src[i] for positions[i] >= 0 */
+/* dst[positions[i]] = src[i] for positions[i] >= 0 (exact exchange) */
 int rsa_scatter_f32(const float* src, const int64_t* positions, int64_t numel, float* dst, rsa_stream_t stream);
 /* dst[i] = positions[i] >= 0 ? src[positions[i]] : 0: d loss/d score in routed order for the gradient exchange. */
 int rsa_gather_f32(const float* src, const int64_t* positions, int64_t numel, float* dst, rsa_stream_t stream);
+
+/* ---- Version 2 of the fixed-capacity exchange (ABI v5).  What changed against rsa_shard_route_fixed + rsa_scatter_f32 +
+ * rsa_pairwise_loss: (a) the negatives are drawn INSIDE the routing pass (same Philox element mapping as
+ * rsa_sample_uniform / rsa_sample_popular, so the ids are the ones the stand-alone samplers -- and the reference's
+ * torch.randint / torch.rand + searchsorted, sampler.py:102-104, :246-258 -- produce); the [n_queries, num_neg] id tensor
+ * is written only on request; (b) a segment is SELF-DESCRIBING: RSA_SHARD_HDR 8-byte header words {live keys, elements
+ * the source rank dropped in this step} precede its keys, so the slack is never filled, owners skip the tiles past the
+ * count, and after the key all-to-all every rank knows the job-wide number of dropped elements of the step without a
+ * collective of its own; (c) the home side keeps ONE int32 per element (slot_of: where its key sits in the send buffer
+ * == where its score sits in the returned buffer; -1 = dropped) instead of an 8-byte position per slot, and gathers
+ * through it inside the loss kernel (rsa_shard_home) -- no scatter pass, no separate loss / mean launches; (d) one
+ * routing launch covers all pipelined query slices.
+ * A DROPPED element (its owner's segment was full) has a defined outcome: no key, no score (reads as 0 where scores are
+ * materialised), no term in a fused loss, d loss / d score = 0 (nothing is sent for it); and the owner-side update
+ * scale of a step in which ANY rank dropped anything is 0 (rsa_shard_unpack_segments), so such a step leaves every
+ * weight untouched. */
+#define RSA_SHARD_HDR 2   /* 8-byte header words per segment: [0] live keys, [1] the source's dropped total of the step */
+
+typedef struct rsa_shard_route_args {
+  const int64_t* pos_ids;      /* [n_queries] global item ids (column 0 of the element matrix) */
+  int64_t* neg_ids;            /* [n_queries, num_neg]: INPUT when sampler == RSA_SAMPLER_GIVEN, else nullable OUTPUT */
+  float* neg_logp;             /* nullable [n_queries, num_neg] out (POPULAR): log pop_prob[id] */
+  float* pos_logp;             /* nullable [n_queries] out: log pop_prob[pos_ids] (needs pop_prob) */
+  int64_t n_queries;
+  int32_t num_neg;
+  int32_t sampler;             /* rsa_sampler_kind */
+  int32_t n_slices;            /* pipelined query slices (>= 1, divides n_queries): slice c = queries [c*B/C, (c+1)*B/C) */
+  int32_t n_shards;            /* G <= 64 */
+  int64_t rows_per_shard;      /* owner(id) = min(id / rows_per_shard, G - 1) */
+  int64_t query_base;          /* global index of query 0 (rank * n_queries): goes into the keys */
+  int64_t capacity;            /* keys per (slice, owner) segment */
+  int64_t n_items;             /* catalog size: uniform ids are drawn from [1, n_items) */
+  uint64_t seed, offset;       /* Philox state, see "Philox state" (sampler != GIVEN) */
+  uint32_t grid_threads;
+  uint32_t _pad;
+  uint64_t elem_base;
+  const float* table;          /* POPULAR: as in rsa_fused_args */
+  const float* pop_prob;
+  const int32_t* guide;
+  const float* table_prob;
+  const float* cdf_lut;
+  const float* cdf_lines;
+  int32_t guide_log2;
+  int32_t lines_log2;
+  int64_t* send_keys;          /* [n_slices][n_shards][RSA_SHARD_HDR + capacity] out; key = (query_base + query) << 32 | local row.
+                                  NULL: count only (nothing is sampled into the outputs, only counts_out is written) */
+  int32_t* slot_of;            /* [n_queries * (1 + num_neg)] out, element e = query * (1 + num_neg) + column */
+  int32_t* cursors;            /* [n_slices * n_shards + 1] device scratch, zeroed ONCE by the caller (self-resetting) */
+  int32_t* counts_out;         /* nullable [n_slices * n_shards]: exact element counts per (slice, owner) -- calibration */
+} rsa_shard_route_args;
+int64_t rsa_shard_segment_stride(int64_t capacity);    /* RSA_SHARD_HDR + capacity: 8-byte words per segment */
+int rsa_shard_sample_route(const rsa_shard_route_args* args, rsa_stream_t stream);
+
+/* Owner side: scores[i] = <query[key_i >> 32], item_table[key_i & 0xffffffff]> for every live slot of the received
+ * segments keys [n_segments][stride] (the fused gather+score kernel of rsa_fused_sample_gather_score reading the
+ * segments directly; slots past a segment's count are not read and their score is not written; whole tiles past the
+ * count are skipped).  step_dropped (nullable int32 device word) <- sum over the segments of header word 1 (the job-wide
+ * dropped count of the step when the segments come from all ranks); overflow_sticky (nullable) += the same. */
+int rsa_shard_score_segments(const float* item_table, int64_t n_rows, int32_t dim, const float* query,
+                             int64_t n_query_rows, const int64_t* keys, int64_t n_segments, int64_t stride, float* scores,
+                             int32_t* step_dropped, int32_t* overflow_sticky, rsa_stream_t stream);
+
+/* Home side: gather the returned scores through slot_of and evaluate the loss in the same launch (one wave per query).
+ * loss 0: pos_score / neg_score only.  loss 1: BPRLoss (loss_func.py:55-59).  loss 2: SampledSoftmaxLoss (:80-90) with
+ * nullable log-probabilities.  loss_out = sum(row_loss) / mean_den (mean_den = n_queries for the local mean, the job-wide
+ * query count for this rank's share of the global mean); dpos / dneg / d_send = d loss_out / d score, d_send in routed
+ * order (index = slot) ready for the gradient all-to-all.  Every output is nullable except neg_score for loss 0. */
+typedef struct rsa_shard_home_args {
+  const float* scores;         /* returned score buffer, indexed by slot */
+  const int32_t* slot_of;      /* [n_queries * (1 + num_neg)] */
+  int64_t n_queries;
+  int32_t num_neg;
+  int32_t loss;
+  const float* pos_logp;       /* loss 2, nullable [n_queries] */
+  const float* neg_logp;       /* loss 2, nullable [n_queries, num_neg] */
+  int64_t mean_den;
+  float* pos_score;            /* nullable [n_queries] out */
+  float* neg_score;            /* nullable [n_queries, num_neg] out */
+  float* row_loss;             /* nullable [n_queries] out */
+  float* loss_out;             /* nullable [1] out (needs reduce_scratch) */
+  float* dpos;                 /* nullable [n_queries] out */
+  float* dneg;                 /* nullable [n_queries, num_neg] out */
+  float* d_send;               /* nullable, slot-indexed out */
+  void* reduce_scratch;        /* rsa_scratch_bytes() bytes, zeroed once */
+} rsa_shard_home_args;
+int rsa_shard_home(const rsa_shard_home_args* args, rsa_stream_t stream);
+
+/* d_send[slot_of[e]] = (dpos | dneg)[e] for a loss evaluated outside rsa_shard_home (dropped elements send nothing). */
+int rsa_shard_scatter_slots(const float* dpos, const float* dneg, const int32_t* slot_of, int64_t n_queries,
+                            int32_t num_neg, float* d_send, rsa_stream_t stream);
+
+/* Owner side of the backward: (local row, query index) per slot of the received segments, -1 past a segment's count
+ * (rsa_scatter_rows_sorted drops negative ids); scale_out (nullable, 2 floats) = {gate * (scale_in ? scale_in[0] : 1),
+ * gate} with gate = step_dropped[0] != 0 ? 0 : 1 -- the `upstream` scalars of the item-side and the query-side
+ * sorted scatter, so that a step in which any rank dropped an element updates nothing. */
+int rsa_shard_unpack_segments(const int64_t* keys, int64_t n_segments, int64_t stride, int64_t* local_rows,
+                              int64_t* query_index, const float* scale_in, const int32_t* step_dropped, float* scale_out,
+                              rsa_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -56,6 +56,29 @@ class BackwardArgs(Structure):
     ]
 
 
+class ShardRouteArgs(Structure):
+    """struct rsa_shard_route_args (include/recstudio_amd.h)."""
+    _fields_ = [
+        ('pos_ids', c_void_p), ('neg_ids', c_void_p), ('neg_logp', c_void_p), ('pos_logp', c_void_p),
+        ('n_queries', c_int64), ('num_neg', c_int32), ('sampler', c_int32), ('n_slices', c_int32), ('n_shards', c_int32),
+        ('rows_per_shard', c_int64), ('query_base', c_int64), ('capacity', c_int64), ('n_items', c_int64),
+        ('seed', c_uint64), ('offset', c_uint64), ('grid_threads', c_uint32), ('_pad', c_uint32), ('elem_base', c_uint64),
+        ('table', c_void_p), ('pop_prob', c_void_p), ('guide', c_void_p), ('table_prob', c_void_p), ('cdf_lut', c_void_p),
+        ('cdf_lines', c_void_p), ('guide_log2', c_int32), ('lines_log2', c_int32),
+        ('send_keys', c_void_p), ('slot_of', c_void_p), ('cursors', c_void_p), ('counts_out', c_void_p),
+    ]
+
+
+class ShardHomeArgs(Structure):
+    """struct rsa_shard_home_args (include/recstudio_amd.h)."""
+    _fields_ = [
+        ('scores', c_void_p), ('slot_of', c_void_p), ('n_queries', c_int64), ('num_neg', c_int32), ('loss', c_int32),
+        ('pos_logp', c_void_p), ('neg_logp', c_void_p), ('mean_den', c_int64),
+        ('pos_score', c_void_p), ('neg_score', c_void_p), ('row_loss', c_void_p), ('loss_out', c_void_p),
+        ('dpos', c_void_p), ('dneg', c_void_p), ('d_send', c_void_p), ('reduce_scratch', c_void_p),
+    ]
+
+
 # name -> (restype, argtypes); must list every symbol the header declares.
 SIGNATURES = {
     'rsa_last_error': (c_char_p, []),
@@ -64,7 +87,7 @@ SIGNATURES = {
     'rsa_device_info': (c_int, [c_int, POINTER(c_int32), POINTER(c_int32), POINTER(c_int32)]),
     'rsa_sample_uniform': (c_int, [c_void_p, c_int64, c_int64, c_int64, c_uint64, c_uint64, c_uint32, c_uint64, c_void_p]),
     'rsa_sample_masked_uniform': (c_int, [c_void_p, c_int64, c_int32, c_int64, c_int32, c_void_p, c_uint64, c_uint64,
-                                          c_uint32, c_void_p]),
+                                          c_uint32, c_uint64, c_void_p]),
     'rsa_sample_popular': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p,
                                    c_int64, c_uint64, c_uint64, c_uint32, c_uint64, c_void_p, c_void_p, c_int32, c_void_p]),
     'rsa_popular_lookup': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p,
@@ -102,8 +125,14 @@ SIGNATURES = {
     'rsa_shard_count': (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_int64, c_int32, c_void_p, c_void_p]),
     'rsa_shard_route': (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_int64, c_int32, c_int64, c_void_p, c_void_p,
                                 c_void_p, c_void_p]),
-    'rsa_shard_route_fixed': (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_int64, c_int32, c_int64, c_int64, c_void_p,
-                                      c_void_p, c_void_p, c_void_p, c_void_p]),
+    'rsa_shard_segment_stride': (c_int64, [c_int64]),
+    'rsa_shard_sample_route': (c_int, [POINTER(ShardRouteArgs), c_void_p]),
+    'rsa_shard_score_segments': (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_void_p,
+                                         c_void_p, c_void_p, c_void_p]),
+    'rsa_shard_home': (c_int, [POINTER(ShardHomeArgs), c_void_p]),
+    'rsa_shard_scatter_slots': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p]),
+    'rsa_shard_unpack_segments': (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                          c_void_p]),
     'rsa_shard_unpack': (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     'rsa_scatter_f32': (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     'rsa_gather_f32': (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
@@ -129,7 +158,7 @@ def build(verbose=False):
     return LIB_PATH
 
 
-ABI_VERSION = 4      # RSA_ABI_VERSION of include/recstudio_amd.h this binding was written against
+ABI_VERSION = 5      # RSA_ABI_VERSION of include/recstudio_amd.h this binding was written against
 
 
 def lib():

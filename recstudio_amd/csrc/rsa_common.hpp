@@ -259,4 +259,104 @@ __device__ __forceinline__ float dot4(const float4& a, const float4& b) {
   return __fmaf_rn(a.w, b.w, __fmaf_rn(a.z, b.z, __fmaf_rn(a.y, b.y, a.x * b.x)));
 }
 
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m, 64));
+  return v;
+}
+
+// Inverse CDF of the popularity sampler for a draw u, by the best structure the caller supplied (P: any parameter
+// struct with the fields table, pop_prob, table_prob, lut, lines, guide, n_items, guide_log2, lines_log2): bucket lines
+// (one HBM line), direct-lookup table (+ one 4-wide probe), or the guide table + binary search.  All return
+// torch.searchsorted(table, u) clamped to n_items-1 and the id's probability.
+template <typename P>
+__device__ __forceinline__ int32_t lookup_popular(const P& p, float u, float& pr) {
+  if (p.lines != nullptr) {
+    if (p.table_prob) return cdf_lookup_line(p.lines, p.lines_log2, p.table_prob, 2, p.table_prob + 1, 2, p.n_items, u, pr);
+    return cdf_lookup_line(p.lines, p.lines_log2, p.table, 1, p.pop_prob, 1, p.n_items, u, pr);
+  }
+  if (p.lut != nullptr) {   // direct lookup: one round trip for id AND probability in the common case
+    if (p.table_prob)
+      return cdf_lookup_lut<2>(reinterpret_cast<const float4*>(p.lut), p.table_prob, p.table_prob + 1, 2, p.n_items,
+                               p.guide_log2, u, pr);
+    return cdf_lookup_lut<1>(reinterpret_cast<const float4*>(p.lut), p.table, p.pop_prob, 1, p.n_items, p.guide_log2, u, pr);
+  }
+  int32_t id;
+  if (p.table_prob) {       // interleaved {cdf, prob}: the search and the probability share cache lines
+    id = cdf_lower_bound<2>(p.table_prob, p.guide, p.n_items, p.guide_log2, u);
+    pr = p.table_prob[2 * (size_t)id + 1];
+  } else {
+    id = cdf_lower_bound<1>(p.table, p.guide, p.n_items, p.guide_log2, u);
+    pr = p.pop_prob[id];
+  }
+  return id;
+}
+
+// loss = mean of the per-query losses, in the SAME launch, with ONE device-scope atomic per workgroup and no
+// second phase: every workgroup adds {its share of the mean as a 2^-38 fixed-point integer, 1 arrival} to one 64-bit
+// word (bits 0..49 sum, bits 50..63 arrivals); integer addition is associative, so the total is bit-reproducible
+// whatever the arrival order.  The workgroup whose add returns gridDim.x - 1 earlier arrivals holds the complete sum
+// (returned value + its own share), writes the mean and resets the word.  A NaN / inf partial (SampledSoftmax with a
+// padded positive, loss_func.py:88-89) first sets a sticky flag word with a RETURNING atomic and only then arrives
+// (the arrival is made to depend on the returned value), and the last workgroup reads the flags through a pointer
+// that depends on its own returned arrival count -- so the flag is visible whenever the arrival is.  No fences: a
+// release / acquire pair at workgroup exit writes back / invalidates the whole XCD L2 (measured: +90 us per launch);
+// the first version exchanged float partials and counted arrivals with a second, dependent atomic -- two memory
+// round trips in every workgroup's tail, 7.5 us of a 43 us launch at B = 4096.
+// The words hold each workgroup's share of the MEAN (its loss sum / n_queries) at 2^-38 resolution, so the range does
+// not depend on the batch size: a mean loss up to 2^11 fits the 50-bit field whatever B is (quantisation <= grid * 2^-39
+// ~ 4e-9 absolute); a share >= 2^10 (or NaN / inf) saturates to +inf / NaN through the flag word.  Totals must be >= 0
+// (every loss on this path is).
+// Two levels: workgroup b adds to sub-word b % 32 (the sub-words sit in different 128-byte lines), and the workgroup
+// that completes a sub-word forwards its total to the top word -- atomics on ONE address are performed one after the
+// other at the memory side (~8 ns each), and at B = 4096 all 1024 workgroups finish together: a single word cost an
+// 8 us tail on a 37 us launch.
+constexpr int LOSS_FRAC_BITS = 38, LOSS_COUNT_SHIFT = 50, LOSS_SUBWORDS = 32;
+__device__ __forceinline__ void reduce_mean_loss(float wave_loss, float* __restrict__ loss_out,
+                                                 unsigned int* __restrict__ flag_word,
+                                                 float* __restrict__ loss_partials, int64_t n_queries) {
+  __shared__ float s_red[16];
+  const int lane = lane_id();
+  const int wave = threadIdx.x >> 6;
+  if (lane == 0) s_red[wave] = wave_loss;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float part = 0.f;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) part += s_red[w];
+    unsigned long long* words = reinterpret_cast<unsigned long long*>(loss_partials);     // 8-byte aligned (offset 256)
+    constexpr unsigned long long FIELD = (1ull << LOSS_COUNT_SHIFT) - 1, ONE = 1ull << LOSS_COUNT_SHIFT;
+    const double share = (double)part / (double)n_queries;       // this workgroup's share of the mean
+    const bool bad = !(fabs(share) < 1024.0);                    // NaN, inf or out of the fixed-point range
+    const long long fixed = bad ? 0ll : __double2ll_rn(share * (double)(1ll << LOSS_FRAC_BITS));
+    unsigned long long add = ((unsigned long long)fixed & FIELD) + ONE;
+    if (bad) {
+      const unsigned int old = __hip_atomic_fetch_or(flag_word, part != part ? 1u : 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("; the arrival waits for the flag" : "+v"(add) : "v"(old));
+    }
+    const unsigned j = blockIdx.x % LOSS_SUBWORDS;
+    const unsigned members = (gridDim.x - j + LOSS_SUBWORDS - 1) / LOSS_SUBWORDS;
+    const unsigned n_sub = gridDim.x < LOSS_SUBWORDS ? gridDim.x : LOSS_SUBWORDS;
+    unsigned long long* sub = words + 16 * (1 + j);      // 128 bytes apart; words[0] is the top word
+    const unsigned long long prev = __hip_atomic_fetch_add(sub, add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((prev >> LOSS_COUNT_SHIFT) == (unsigned long long)(members - 1)) {
+      const unsigned long long sub_total = (prev + add) & FIELD;
+      __hip_atomic_store(sub, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);        // leave the scratch zeroed
+      const unsigned long long add2 = sub_total + ONE;
+      const unsigned long long prev2 = __hip_atomic_fetch_add(words, add2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if ((prev2 >> LOSS_COUNT_SHIFT) == (unsigned long long)(n_sub - 1)) {
+        const unsigned long long total = (prev2 + add2) & FIELD;
+        float loss = (float)((double)total / (double)(1ll << LOSS_FRAC_BITS));
+        unsigned int* fw = flag_word;
+        asm volatile("; the flags are read after the last arrival" : "+v"(fw) : "v"(prev2));
+        const unsigned int flags = __hip_atomic_load(fw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (flags & 1u) loss = NAN;
+        else if (flags & 2u) loss = INFINITY;
+        loss_out[0] = loss;
+        __hip_atomic_store(words, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (flags) __hip_atomic_store(fw, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  }
+}
+
 }  // namespace rsa

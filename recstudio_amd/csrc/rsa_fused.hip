@@ -57,36 +57,14 @@ struct FwdParams {
   float* loss_partials;         //   reduce_scratch (rsa_common.hpp, "caller-owned reduction scratch")
   const uint64_t* offset_dev;   // nullable: Philox offset read at run time (graph replays)
   const int64_t* packed_keys;   // num_neg == 1, GIVEN: element e = (query row << 32) | item row (sharded owner side)
+  int32_t* step_dropped;        // segment form (seg_stride != 0): <- sum of the segments' header word 1 (nullable)
+  int32_t* overflow_sticky;     //   += the same (nullable)
   float* qgrad;      // fused BPR epilogue (nullable): [M, dim] d loss / d query row, accumulated from the rows in flight
   int64_t n_items, n_query_rows, n_queries, numel;
   PhiloxCall pc;
   int32_t dim, num_neg, sampler, mask_pad_pos, guide_log2, score_mode, lines_log2;
+  int32_t seg_stride;           // != 0: packed_keys is [n_segments][seg_stride] with RSA_SHARD_HDR header words per segment
 };
-
-// Inverse CDF of the popularity sampler for a draw u, by the best structure the caller supplied: bucket lines
-// (one HBM line), direct-lookup table (+ one 4-wide probe), or the guide table + binary search.  All return
-// torch.searchsorted(table, u) clamped to n_items-1 and the id's probability.
-__device__ __forceinline__ int32_t lookup_popular(const FwdParams& p, float u, float& pr) {
-  if (p.lines != nullptr) {
-    if (p.table_prob) return cdf_lookup_line(p.lines, p.lines_log2, p.table_prob, 2, p.table_prob + 1, 2, p.n_items, u, pr);
-    return cdf_lookup_line(p.lines, p.lines_log2, p.table, 1, p.pop_prob, 1, p.n_items, u, pr);
-  }
-  if (p.lut != nullptr) {   // direct lookup: one round trip for id AND probability in the common case
-    if (p.table_prob)
-      return cdf_lookup_lut<2>(reinterpret_cast<const float4*>(p.lut), p.table_prob, p.table_prob + 1, 2, p.n_items,
-                               p.guide_log2, u, pr);
-    return cdf_lookup_lut<1>(reinterpret_cast<const float4*>(p.lut), p.table, p.pop_prob, 1, p.n_items, p.guide_log2, u, pr);
-  }
-  int32_t id;
-  if (p.table_prob) {       // interleaved {cdf, prob}: the search and the probability share cache lines
-    id = cdf_lower_bound<2>(p.table_prob, p.guide, p.n_items, p.guide_log2, u);
-    pr = p.table_prob[2 * (size_t)id + 1];
-  } else {
-    id = cdf_lower_bound<1>(p.table, p.guide, p.n_items, p.guide_log2, u);
-    pr = p.pop_prob[id];
-  }
-  return id;
-}
 
 #ifndef RSA_FWD_NT_STORE
 #define RSA_FWD_NT_STORE 1
@@ -395,73 +373,6 @@ __device__ __forceinline__ float finish_score(int mode, float dot, float inorm2,
 #define RSA_SSM_BATCH 4     // double-buffered: 2 * 4 row loads in flight per wave, 141 VGPRs at d = 128 (8: 180)
 #endif
 
-// loss = mean of the per-query losses, in the SAME launch, with ONE device-scope atomic per workgroup and no
-// second phase: every workgroup adds {its share of the mean as a 2^-38 fixed-point integer, 1 arrival} to one 64-bit
-// word (bits 0..49 sum, bits 50..63 arrivals); integer addition is associative, so the total is bit-reproducible
-// whatever the arrival order.  The workgroup whose add returns gridDim.x - 1 earlier arrivals holds the complete sum
-// (returned value + its own share), writes the mean and resets the word.  A NaN / inf partial (SampledSoftmax with a
-// padded positive, loss_func.py:88-89) first sets a sticky flag word with a RETURNING atomic and only then arrives
-// (the arrival is made to depend on the returned value), and the last workgroup reads the flags through a pointer
-// that depends on its own returned arrival count -- so the flag is visible whenever the arrival is.  No fences: a
-// release / acquire pair at workgroup exit writes back / invalidates the whole XCD L2 (measured: +90 us per launch);
-// the first version exchanged float partials and counted arrivals with a second, dependent atomic -- two memory
-// round trips in every workgroup's tail, 7.5 us of a 43 us launch at B = 4096.
-// The words hold each workgroup's share of the MEAN (its loss sum / n_queries) at 2^-38 resolution, so the range does
-// not depend on the batch size: a mean loss up to 2^11 fits the 50-bit field whatever B is (quantisation <= grid * 2^-39
-// ~ 4e-9 absolute); a share >= 2^10 (or NaN / inf) saturates to +inf / NaN through the flag word.  Totals must be >= 0
-// (every loss on this path is).
-// Two levels: workgroup b adds to sub-word b % 32 (the sub-words sit in different 128-byte lines), and the workgroup
-// that completes a sub-word forwards its total to the top word -- atomics on ONE address are performed one after the
-// other at the memory side (~8 ns each), and at B = 4096 all 1024 workgroups finish together: a single word cost an
-// 8 us tail on a 37 us launch.
-constexpr int LOSS_FRAC_BITS = 38, LOSS_COUNT_SHIFT = 50, LOSS_SUBWORDS = 32;
-__device__ __forceinline__ void reduce_mean_loss(float wave_loss, float* __restrict__ loss_out,
-                                                 unsigned int* __restrict__ flag_word,
-                                                 float* __restrict__ loss_partials, int64_t n_queries) {
-  __shared__ float s_red[16];
-  const int lane = lane_id();
-  const int wave = threadIdx.x >> 6;
-  if (lane == 0) s_red[wave] = wave_loss;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    float part = 0.f;
-    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) part += s_red[w];
-    unsigned long long* words = reinterpret_cast<unsigned long long*>(loss_partials);     // 8-byte aligned (offset 256)
-    constexpr unsigned long long FIELD = (1ull << LOSS_COUNT_SHIFT) - 1, ONE = 1ull << LOSS_COUNT_SHIFT;
-    const double share = (double)part / (double)n_queries;       // this workgroup's share of the mean
-    const bool bad = !(fabs(share) < 1024.0);                    // NaN, inf or out of the fixed-point range
-    const long long fixed = bad ? 0ll : __double2ll_rn(share * (double)(1ll << LOSS_FRAC_BITS));
-    unsigned long long add = ((unsigned long long)fixed & FIELD) + ONE;
-    if (bad) {
-      const unsigned int old = __hip_atomic_fetch_or(flag_word, part != part ? 1u : 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      asm volatile("; the arrival waits for the flag" : "+v"(add) : "v"(old));
-    }
-    const unsigned j = blockIdx.x % LOSS_SUBWORDS;
-    const unsigned members = (gridDim.x - j + LOSS_SUBWORDS - 1) / LOSS_SUBWORDS;
-    const unsigned n_sub = gridDim.x < LOSS_SUBWORDS ? gridDim.x : LOSS_SUBWORDS;
-    unsigned long long* sub = words + 16 * (1 + j);      // 128 bytes apart; words[0] is the top word
-    const unsigned long long prev = __hip_atomic_fetch_add(sub, add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if ((prev >> LOSS_COUNT_SHIFT) == (unsigned long long)(members - 1)) {
-      const unsigned long long sub_total = (prev + add) & FIELD;
-      __hip_atomic_store(sub, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);        // leave the scratch zeroed
-      const unsigned long long add2 = sub_total + ONE;
-      const unsigned long long prev2 = __hip_atomic_fetch_add(words, add2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if ((prev2 >> LOSS_COUNT_SHIFT) == (unsigned long long)(n_sub - 1)) {
-        const unsigned long long total = (prev2 + add2) & FIELD;
-        float loss = (float)((double)total / (double)(1ll << LOSS_FRAC_BITS));
-        unsigned int* fw = flag_word;
-        asm volatile("; the flags are read after the last arrival" : "+v"(fw) : "v"(prev2));
-        const unsigned int flags = __hip_atomic_load(fw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (flags & 1u) loss = NAN;
-        else if (flags & 2u) loss = INFINITY;
-        loss_out[0] = loss;
-        __hip_atomic_store(words, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (flags) __hip_atomic_store(fw, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-    }
-  }
-}
-
 #ifndef RSA_FWD_GRID_CAP
 #define RSA_FWD_GRID_CAP (256 * 8)
 #endif
@@ -501,6 +412,17 @@ __global__ __launch_bounds__(256, QG ? RSA_QG_MIN_WAVES : RSA_FWD_MIN_WAVES) voi
   };
   if (ahead && wave0 < n_tiles) fetch_ahead(wave0);
 
+  if constexpr (!QU) {
+    if (p.seg_stride && blockIdx.x == 0 && threadIdx.x == 0 && (p.step_dropped || p.overflow_sticky)) {
+      // header word 1 of every received segment = what its source could not place this step: the job-wide total
+      const int64_t n_seg = p.numel / p.seg_stride;
+      int64_t total = 0;
+      for (int64_t sgm = 0; sgm < n_seg; ++sgm) total += p.packed_keys[sgm * p.seg_stride + 1];
+      const int32_t t32 = total > 0x7fffffffll ? 0x7fffffff : (int32_t)total;
+      if (p.step_dropped) *p.step_dropped = t32;
+      if (p.overflow_sticky && t32) atomicAdd(p.overflow_sticky, t32);
+    }
+  }
   float wave_loss = 0.f;     // fused BPR epilogue: sum of this wave's tile losses (fixed tile order)
   for (int64_t tile = wave0; tile < n_tiles; tile += wstride) {
     const int64_t e = (tile << 6) + lane;
@@ -523,6 +445,7 @@ __global__ __launch_bounds__(256, QG ? RSA_QG_MIN_WAVES : RSA_FWD_MIN_WAVES) voi
 
     // ---- 1. the id of element e (lane-parallel: one Philox / one CDF search per lane)
     int32_t id = 0;
+    int64_t key_lane = -1;       // packed_keys: this lane's key, -1 = empty slot
     if (act) {
       if (p.sampler == RSA_SAMPLER_UNIFORM) {
         id = (int32_t)torch_randint_element(pc, (uint64_t)e, (uint64_t)(p.n_items - 1), 1);
@@ -544,10 +467,23 @@ __global__ __launch_bounds__(256, QG ? RSA_QG_MIN_WAVES : RSA_FWD_MIN_WAVES) voi
         if (p.neg_logp) st_out(&p.neg_logp[e], logf(pr));
       } else {
         int64_t g = p.packed_keys ? p.packed_keys[e] : p.neg_ids[e];
-        if (p.packed_keys) g = g < 0 ? 0 : (g & 0xffffffffll);   // a negative key is an empty slot (row 0, query 0)
+        if (p.packed_keys) {
+          if (p.seg_stride) {     // self-describing segments: live iff behind the header and below the segment's count
+            const uint32_t seg = (uint32_t)e / (uint32_t)p.seg_stride;
+            const uint32_t within = (uint32_t)e - seg * (uint32_t)p.seg_stride;
+            const int64_t live = p.packed_keys[(size_t)seg * p.seg_stride];
+            if (within < RSA_SHARD_HDR || (int64_t)(within - RSA_SHARD_HDR) >= live) g = -1;
+          }
+          key_lane = g;
+          g = g < 0 ? 0 : (g & 0xffffffffll);   // a negative key is an empty slot (row 0, query 0)
+        }
         g = g < 0 ? 0 : (g >= p.n_items ? p.n_items - 1 : g);   // clamp: never fault on a bad id
         id = (int32_t)g;
       }
+    }
+    if constexpr (!QU) {
+      // segment form: a tile that lies entirely in a segment's slack (or past the end) has nothing to score
+      if (p.seg_stride && __ballot(key_lane >= 0) == 0ull) continue;
     }
 
     if (ahead && tile + wstride < n_tiles) fetch_ahead(tile + wstride);
@@ -568,9 +504,9 @@ __global__ __launch_bounds__(256, QG ? RSA_QG_MIN_WAVES : RSA_FWD_MIN_WAVES) voi
       m_lane = act ? e / n : 0;
       qrow_lane = (int32_t)(p.query_index ? (act ? p.query_index[m_lane] : 0) : m_lane);
       if (p.packed_keys) {
-        const int64_t key = act ? p.packed_keys[e] : 0;
-        qrow_lane = key < 0 ? 0 : (int32_t)(key >> 32);
-        if (key < 0) empty_slot = true;
+        qrow_lane = key_lane < 0 ? 0 : (int32_t)(key_lane >> 32);
+        if (qrow_lane >= p.n_query_rows) qrow_lane = 0;      // never fault on a bad key
+        if (key_lane < 0) empty_slot = true;
       }
       frag_load<LPR, GENERIC>(qf, p.query, sub, D);   // unused in this path
       px = qf;
@@ -614,7 +550,8 @@ __global__ __launch_bounds__(256, QG ? RSA_QG_MIN_WAVES : RSA_FWD_MIN_WAVES) voi
       tile_rows<LPR, GENERIC, COS, QU, NT>(p.item_table, D, id, p.query, qrow_lane, qf, dot, in2, qn2);
     }
     if constexpr (COS && QU) qn2 = qn2_u;
-    if (act) st_out(&p.neg_score[e], empty_slot ? 0.f : finish_score(COS ? p.score_mode : RSA_SCORE_IP, dot, in2, qn2));
+    if (act && !(p.seg_stride && empty_slot))
+      st_out(&p.neg_score[e], empty_slot ? 0.f : finish_score(COS ? p.score_mode : RSA_SCORE_IP, dot, in2, qn2));
 
     // ---- 4. positives (+ the fused BPR epilogue: every tile of a query needs the positive score)
     const float neg_s = finish_score(COS ? p.score_mode : RSA_SCORE_IP, dot, in2, qn2);
@@ -744,12 +681,6 @@ __device__ __forceinline__ void tile_rows_ssm(const float* __restrict__ table, i
     }
     asm volatile("" : "+v"(gb), "+v"(qacc.x), "+v"(qacc.y), "+v"(qacc.z), "+v"(qacc.w));
   }
-}
-
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m, 64));
-  return v;
 }
 
 #ifndef RSA_SSM_MIN_WAVES
@@ -995,6 +926,9 @@ extern "C" int rsa_fused_sample_gather_score(const rsa_fused_args* a, rsa_stream
   p.offset_dev = a->offset_dev;
   p.loss_partials = nullptr;
   p.packed_keys = a->packed_keys;
+  p.step_dropped = nullptr;
+  p.overflow_sticky = nullptr;
+  p.seg_stride = 0;
   p.n_items = a->n_items;
   p.n_query_rows = a->n_query_rows;
   p.n_queries = a->n_queries;
@@ -1075,4 +1009,44 @@ extern "C" int rsa_fused_sample_gather_score(const rsa_fused_args* a, rsa_stream
     default: rc = launch_fwd<64, true>(p, cos, qu, s); break;
   }
   return rc;
+}
+
+
+// Owner side of the sharded exchange, segment form (include/recstudio_amd.h, "Version 2 of the fixed-capacity exchange")
+extern "C" int rsa_shard_score_segments(const float* item_table, int64_t n_rows, int32_t dim, const float* query,
+                                        int64_t n_query_rows, const int64_t* keys, int64_t n_segments, int64_t stride,
+                                        float* scores, int32_t* step_dropped, int32_t* overflow_sticky, rsa_stream_t stream) {
+  RSA_CHECK_ARG(n_segments >= 0 && stride > RSA_SHARD_HDR, "rsa_shard_score_segments: bad sizes");
+  const int64_t numel = n_segments * stride;
+  if (numel == 0) return RSA_OK;
+  RSA_CHECK_ARG(numel < (1ll << 31), "rsa_shard_score_segments: more than 2^31 slots");
+  RSA_CHECK_ARG(item_table && query && keys && scores, "rsa_shard_score_segments: null pointer");
+  RSA_CHECK_ARG(dim >= 4 && dim <= 1024 && dim % 4 == 0, "rsa_shard_score_segments: dim=%d must be a multiple of 4 in [4, 1024]", dim);
+  RSA_CHECK_ARG(n_rows >= 1 && n_rows < (1ll << 32) && n_query_rows >= 1 && n_query_rows < (1ll << 31),
+                "rsa_shard_score_segments: table sizes out of range");
+  FwdParams p = {};
+  p.item_table = item_table;
+  p.query = query;
+  p.packed_keys = keys;
+  p.neg_score = scores;
+  p.step_dropped = step_dropped;
+  p.overflow_sticky = overflow_sticky;
+  p.seg_stride = (int32_t)stride;
+  p.n_items = n_rows;
+  p.n_query_rows = n_query_rows;
+  p.n_queries = numel;
+  p.numel = numel;
+  p.pc = PhiloxCall{0, 0, 256, 0};
+  p.dim = dim;
+  p.num_neg = 1;
+  p.sampler = RSA_SAMPLER_GIVEN;
+  p.score_mode = RSA_SCORE_IP;
+  hipStream_t s = (hipStream_t)stream;
+  switch (dim) {
+    case 32: return launch_fwd<8, false>(p, false, false, s);
+    case 64: return launch_fwd<16, false>(p, false, false, s);
+    case 128: return launch_fwd<32, false>(p, false, false, s);
+    case 256: return launch_fwd<64, false>(p, false, false, s);
+    default: return launch_fwd<64, true>(p, false, false, s);
+  }
 }

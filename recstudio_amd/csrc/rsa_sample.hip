@@ -304,14 +304,14 @@ extern "C" int rsa_item_logp(const float* pop_prob, int64_t n_items, const int64
 
 extern "C" int rsa_sample_masked_uniform(const int64_t* user_hist, int64_t n_rows, int32_t hist_len, int64_t num_items,
                                          int32_t per_row, int64_t* neg_ids, uint64_t seed, uint64_t offset,
-                                         uint32_t grid_threads, rsa_stream_t stream) {
+                                         uint32_t grid_threads, uint64_t elem_base, rsa_stream_t stream) {
   RSA_CHECK_ARG(n_rows >= 0 && per_row >= 0 && num_items >= 1, "rsa_sample_masked_uniform: bad sizes");
   if (n_rows == 0 || per_row == 0) return RSA_OK;
   RSA_CHECK_ARG(user_hist && neg_ids, "rsa_sample_masked_uniform: null pointer");
   RSA_CHECK_ARG(hist_len >= 1 && hist_len <= MASK_MAX_HIST, "rsa_sample_masked_uniform: hist_len must be in [1, %d]",
                 MASK_MAX_HIST);
   RSA_CHECK_ARG(grid_threads > 0 && (offset & 3) == 0, "rsa_sample_masked_uniform: bad philox state");
-  PhiloxCall pc{seed, offset >> 2, grid_threads, 0};
+  PhiloxCall pc{seed, offset >> 2, grid_threads, elem_base};
   hipLaunchKernelGGL(sample_masked_kernel, dim3((unsigned)n_rows), dim3(256), 0, (hipStream_t)stream, user_hist,
                      (int)hist_len, num_items, (int)per_row, neg_ids, pc);
   RSA_CHECK_LAUNCH("rsa_sample_masked_uniform");

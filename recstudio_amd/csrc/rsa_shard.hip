@@ -5,10 +5,13 @@
 // rank that owns the item row as one packed 64-bit key, is scored there, and its fp32 score comes
 // back:  8 + 4 bytes per triplet over xGMI instead of a 512-byte row.
 //
+// Exact (variable-split) exchange:
 //   rsa_shard_count   : histogram of owners                     (-> all-to-all split sizes)
 //   rsa_shard_route   : counting-sort scatter into per-owner segments, key = qidx << 32 | local row
 //   rsa_shard_unpack  : owner side, key -> (local row int64, query index int64)
 //   rsa_scatter_f32   : home side, dst[pos[i]] = src[i]  (returned scores -> [pos_score | neg_score] buffer)
+// Fixed-capacity exchange, version 2 (the default; second half of this file):
+//   rsa_shard_sample_route / rsa_shard_score_segments (rsa_fused.hip) / rsa_shard_home / rsa_shard_unpack_segments
 #include "rsa_common.hpp"
 
 namespace rsa {
@@ -103,16 +106,13 @@ __global__ __launch_bounds__(256) void shard_count_kernel(RouteShape sh, int32_t
   if (threadIdx.x < sh.G && h[threadIdx.x]) atomicAdd(&counts[threadIdx.x], h[threadIdx.x]);
 }
 
-// Counting-sort scatter.  Each workgroup owns a contiguous chunk of ROUTE_CHUNK elements, held in registers as
-// (owner, local row): pass 1 counts the chunk's elements per owner in LDS, ONE global atomic per (workgroup, owner)
-// reserves a contiguous slot range, pass 2 hands out the slots from LDS counters.  (A first version did one global
-// atomic per wave and owner on the same few cursor words and spent 0.8 ms there for 4 M elements.)
-// FIXED: owner g's segment is slots [g*capacity, (g+1)*capacity), the per-owner cursor counts from 0, and an element
-// that does not fit is dropped and counted in *overflow.  Otherwise the cursors arrive holding the segment starts.
-template <bool FIXED>
-__global__ __launch_bounds__(256) void shard_route_kernel(RouteShape sh, int64_t query_base, int64_t capacity,
-                                                          int32_t* __restrict__ cursor, int64_t* __restrict__ keys,
-                                                          int64_t* __restrict__ pos_out, int32_t* __restrict__ overflow) {
+// Counting-sort scatter (exact exchange).  Each workgroup owns a contiguous chunk of ROUTE_CHUNK elements, held in
+// registers as (owner, local row): pass 1 counts the chunk's elements per owner in LDS, ONE global atomic per
+// (workgroup, owner) reserves a contiguous slot range, pass 2 hands out the slots from LDS counters.  (A first version
+// did one global atomic per wave and owner on the same few cursor words and spent 0.8 ms there for 4 M elements.)
+// The cursors arrive holding the segment starts (exclusive prefix sum of the exact counts).
+__global__ __launch_bounds__(256) void shard_route_kernel(RouteShape sh, int64_t query_base, int32_t* __restrict__ cursor,
+                                                          int64_t* __restrict__ keys, int64_t* __restrict__ pos_out) {
   __shared__ int32_t cnt[64], base[64];
   const int64_t numel = sh.n_queries * (sh.n + 1);
   const int64_t e_lo = (int64_t)blockIdx.x * ROUTE_CHUNK;
@@ -140,38 +140,18 @@ __global__ __launch_bounds__(256) void shard_route_kernel(RouteShape sh, int64_t
     cnt[threadIdx.x] = 0;
   }
   __syncthreads();
-  int dropped = 0;
 #pragma unroll
   for (int k = 0; k < ROUTE_EPT; ++k) {
     const bool valid = g[k] >= 0;
     const int gk = valid ? g[k] : 0;
-    const int64_t slot = (int64_t)base[gk] + wave_count<true>(cnt, valid, gk, sh.G == 1);
+    const int64_t at = (int64_t)base[gk] + wave_count<true>(cnt, valid, gk, sh.G == 1);
     if (!valid) continue;
-    if (FIXED && slot >= capacity) {
-      ++dropped;
-      continue;
-    }
     const int64_t e = e_lo + k * 256 + threadIdx.x;
     const int64_t m = (int64_t)sh.by_width.div((uint64_t)e);
     const int c = (int)(e - m * (sh.n + 1));
-    const int64_t at = FIXED ? gk * capacity + slot : slot;
     keys[at] = ((query_base + m) << 32) | (int64_t)local[k];
     // destination of this element's score in the home buffer [pos_score (n_queries) | neg_score (n_queries x n)]
     pos_out[at] = c == 0 ? m : sh.n_queries + m * sh.n + (c - 1);
-  }
-  if (FIXED && dropped) atomicAdd(overflow, dropped);
-}
-
-// keys / positions of the UNUSED tail of every owner segment <- -1 (cursor[g] = elements routed to g, possibly more
-// than the capacity).  Only the slack is written: filling both whole buffers first cost 5 % of the sharded step.
-__global__ __launch_bounds__(256) void shard_fill_tail_kernel(const int32_t* __restrict__ cursor, int64_t capacity,
-                                                              int64_t* __restrict__ keys, int64_t* __restrict__ pos_out) {
-  const int g = blockIdx.y;
-  const int64_t used = cursor[g] < capacity ? cursor[g] : capacity;
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = used + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < capacity; i += stride) {
-    keys[g * capacity + i] = -1;
-    pos_out[g * capacity + i] = -1;
   }
 }
 
@@ -203,6 +183,334 @@ __global__ __launch_bounds__(256) void gather_f32_kernel(const float* __restrict
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < numel; i += stride) {
     const int64_t q = pos[i];
     dst[i] = q >= 0 ? src[q] : 0.f;
+  }
+}
+
+
+// =====================================================================================================================
+// Version 2 of the fixed-capacity exchange (ABI v5): sampling fused into the routing pass, self-describing segments,
+// 32-bit slots, one home-side kernel for scatter + loss + mean (+ d loss/d score in routed order).
+//
+// Send buffer of a rank: [n_slices][n_shards] segments of stride = RSA_SHARD_HDR + capacity 8-byte words.  Word 0 of a
+// segment = number of keys in it (<= capacity), word 1 = elements of THIS STEP the source rank could not place anywhere
+// (its dropped total over all segments), then the keys.  The headers travel with the keys through the equal-split
+// all-to-all, so every owner learns (a) how many slots of each received segment are live -- no -1 fill of the slack,
+// tiles past the count are skipped -- and (b) the step's dropped totals of ALL sources: after the key exchange every
+// rank holds the job-wide overflow count without a collective of its own.
+//
+// slot_of[e] (element order: query-major, column 0 = positive) = index of the element's key in the send buffer == index
+// of its score in the returned score buffer (same geometry), or -1 when it was dropped.  The home kernel gathers through
+// it; nothing is scattered, no 8-byte position list exists.
+
+struct PopTables {
+  const float* table;
+  const float* pop_prob;
+  const float* table_prob;
+  const float* lut;
+  const float* lines;
+  const int32_t* guide;
+  int64_t n_items;
+  int32_t guide_log2, lines_log2;
+};
+
+struct RouteV2 {
+  const int64_t* pos_ids;
+  int64_t* neg_ids;
+  float* neg_logp;
+  float* pos_logp;
+  int64_t* send;
+  int32_t* slot_of;
+  int32_t* cursors;        // [n_slices * G] arrival cursors + [1] block ticket: zero between launches (self-resetting)
+  int32_t* counts_out;
+  int64_t n_queries, per_slice, capacity, stride, rows_per_shard, query_base;
+  PhiloxCall pc;
+  PopTables pop;
+  FastDiv by_width, by_rows;
+  int32_t n, G, sampler, n_slices, blocks_per_slice;
+};
+
+template <bool COUNT_ONLY>
+__global__ __launch_bounds__(256) void shard_sample_route_kernel(const RouteV2 a) {
+  __shared__ int32_t cnt[64], base[64];
+  __shared__ int s_last;
+  const int slice = blockIdx.x / a.blocks_per_slice;
+  const int64_t e_lo = (int64_t)(blockIdx.x - slice * a.blocks_per_slice) * ROUTE_CHUNK;     // within the slice
+  const int64_t slice_numel = a.per_slice * (a.n + 1);
+  const int64_t m0 = (int64_t)slice * a.per_slice;
+  if (threadIdx.x < 64) cnt[threadIdx.x] = 0;
+  int g[ROUTE_EPT];
+  uint32_t local[ROUTE_EPT];
+  const uint64_t range = (uint64_t)(a.pop.n_items - 1);
+#pragma unroll
+  for (int k = 0; k < ROUTE_EPT; ++k) {
+    const int64_t e = e_lo + k * 256 + threadIdx.x;
+    g[k] = -1;
+    local[k] = 0;
+    if (e < slice_numel) {
+      const int64_t ml = (int64_t)a.by_width.div((uint64_t)e);
+      const int c = (int)(e - ml * (a.n + 1));
+      const int64_t m = m0 + ml;
+      int64_t id;
+      if (c == 0) {
+        id = a.pos_ids[m];
+        if (!COUNT_ONLY && a.pos_logp != nullptr) {
+          const int64_t pc_ = id < 0 ? 0 : (id >= a.pop.n_items ? a.pop.n_items - 1 : id);
+          a.pos_logp[m] = logf(a.pop.pop_prob[pc_]);
+        }
+      } else {
+        const int64_t flat = m * a.n + (c - 1);
+        if (a.sampler == RSA_SAMPLER_UNIFORM) {
+          id = torch_randint_element(a.pc, (uint64_t)flat, range, 1);
+          if (!COUNT_ONLY && a.neg_ids != nullptr) a.neg_ids[flat] = id;
+        } else if (a.sampler == RSA_SAMPLER_POPULAR) {
+          float pr;
+          id = lookup_popular(a.pop, torch_rand_element(a.pc, (uint64_t)flat), pr);
+          if (!COUNT_ONLY) {
+            if (a.neg_ids != nullptr) a.neg_ids[flat] = id;
+            if (a.neg_logp != nullptr) a.neg_logp[flat] = logf(pr);
+          }
+        } else {
+          id = a.neg_ids[flat];
+        }
+      }
+      const int64_t q = id < 0 ? 0 : (int64_t)a.by_rows.div((uint64_t)id);
+      g[k] = q >= a.G ? a.G - 1 : (int)q;
+      const int64_t loc = id - (int64_t)g[k] * a.rows_per_shard;
+      local[k] = (uint32_t)(loc < 0 ? 0 : loc);
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < ROUTE_EPT; ++k) wave_count<false>(cnt, g[k] >= 0, g[k], a.G == 1);
+  __syncthreads();
+  if (threadIdx.x < a.G) {
+    base[threadIdx.x] = cnt[threadIdx.x] ? atomicAdd(&a.cursors[slice * a.G + threadIdx.x], cnt[threadIdx.x]) : 0;
+    cnt[threadIdx.x] = 0;
+  }
+  __syncthreads();      // the returning cursor atomics of this workgroup have been performed
+  if (!COUNT_ONLY) {
+    int64_t* seg0 = a.send + (int64_t)slice * a.G * a.stride;
+#pragma unroll
+    for (int k = 0; k < ROUTE_EPT; ++k) {
+      const bool valid = g[k] >= 0;
+      const int gk = valid ? g[k] : 0;
+      const int64_t slot = (int64_t)base[gk] + wave_count<true>(cnt, valid, gk, a.G == 1);
+      if (!valid) continue;
+      const int64_t e = e_lo + k * 256 + threadIdx.x;
+      const int64_t E = m0 * (a.n + 1) + e;
+      if (slot >= a.capacity) {        // no room: the element is dropped -- no key, no score, no gradient
+        a.slot_of[E] = -1;
+        continue;
+      }
+      const int64_t ml = (int64_t)a.by_width.div((uint64_t)e);
+      const int64_t at = (int64_t)gk * a.stride + RSA_SHARD_HDR + slot;
+      seg0[at] = ((a.query_base + m0 + ml) << 32) | (int64_t)local[k];
+      a.slot_of[E] = (int32_t)((int64_t)slice * a.G * a.stride + at);
+    }
+  }
+  // the workgroup that takes the last ticket sees every cursor final: it writes the segment headers (and the exact
+  // counts for the calibration step) and leaves the cursors and the ticket zeroed for the next launch
+  if (threadIdx.x == 0) {
+    const int t = __hip_atomic_fetch_add(&a.cursors[a.n_slices * a.G], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = t == (int)gridDim.x - 1;
+  }
+  __syncthreads();
+  if (s_last && threadIdx.x < 64) {
+    const int segs = a.n_slices * a.G;
+    int64_t dropped = 0;
+    for (int s = threadIdx.x; s < segs; s += 64) {
+      const int64_t c = __hip_atomic_load(&a.cursors[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (c > a.capacity) dropped += c - a.capacity;
+    }
+#pragma unroll
+    for (int mk = 32; mk >= 1; mk >>= 1) dropped += __shfl_xor((long long)dropped, mk, 64);
+    for (int s = threadIdx.x; s < segs; s += 64) {
+      const int64_t c = __hip_atomic_load(&a.cursors[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (a.counts_out != nullptr) a.counts_out[s] = (int32_t)c;
+      if (!COUNT_ONLY) {
+        a.send[(int64_t)s * a.stride] = c < a.capacity ? c : a.capacity;
+        a.send[(int64_t)s * a.stride + 1] = dropped;
+      }
+      __hip_atomic_store(&a.cursors[s], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (threadIdx.x == 0) __hip_atomic_store(&a.cursors[segs], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+// Owner side of the backward: received segments -> (local row, query index) per slot, -1 for slots past a segment's
+// count (the sorted scatters drop negative ids), and the step's update scales scale_out[2] = {gate * scale_in (1 when
+// null), gate}: gate = 0 when ANY rank dropped an element in this step (the step then changes no weight anywhere).
+__global__ __launch_bounds__(256) void shard_unpack_segments_kernel(const int64_t* __restrict__ keys, int64_t numel,
+                                                                    int64_t stride, int64_t* __restrict__ local_rows,
+                                                                    int64_t* __restrict__ qidx,
+                                                                    const float* __restrict__ scale_in,
+                                                                    const int32_t* __restrict__ step_dropped,
+                                                                    float* __restrict__ scale_out) {
+  if (scale_out != nullptr && blockIdx.x == 0 && threadIdx.x == 0) {
+    const float gate = (step_dropped != nullptr && step_dropped[0] != 0) ? 0.f : 1.f;
+    scale_out[0] = gate * (scale_in ? scale_in[0] : 1.f);
+    scale_out[1] = gate;
+  }
+  const int64_t step = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < numel; i += step) {
+    const int64_t seg = i / stride, within = i - seg * stride;
+    const int64_t count = keys[seg * stride];
+    const bool live = within >= RSA_SHARD_HDR && within - RSA_SHARD_HDR < count;
+    const int64_t k = keys[i];
+    local_rows[i] = live ? (k & 0xffffffffll) : -1;
+    qidx[i] = live ? ((k >> 32) & 0x7fffffffll) : -1;
+  }
+}
+
+// d_send[slot_of[e]] = d[e] (d = [dpos | dneg] of a loss evaluated outside): d loss/d score in routed order
+__global__ __launch_bounds__(256) void shard_scatter_slots_kernel(const float* __restrict__ dpos,
+                                                                  const float* __restrict__ dneg,
+                                                                  const int32_t* __restrict__ slot_of, int64_t n_queries,
+                                                                  int n, FastDiv by_width, float* __restrict__ d_send) {
+  const int64_t numel = n_queries * (n + 1);
+  const int64_t step = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < numel; e += step) {
+    const int32_t s = slot_of[e];
+    if (s < 0) continue;
+    const int64_t m = (int64_t)by_width.div((uint64_t)e);
+    const int c = (int)(e - m * (n + 1));
+    d_send[s] = c == 0 ? dpos[m] : dneg[m * n + (c - 1)];
+  }
+}
+
+// Home side of the forward: ONE wave per query walks the query's (1 + n) elements in tiles of 64, gathers their
+// scores from the returned buffer through slot_of and evaluates the loss in place:
+//   LOSS 0: scores only (pos_score / neg_score; a dropped element reads 0)
+//   LOSS 1: BPRLoss (loss_func.py:55-59)    row = -(1/n) sum_j logsigmoid(pos - neg_j)
+//   LOSS 2: SampledSoftmaxLoss (:80-90)     row = logsumexp(z_pos, z_1..z_n) - z_pos, z = score - logQ
+// with d loss/d score written per element (dpos / dneg) and / or straight into the routed-order gradient buffer d_send
+// (the gather + concatenation of the first version).  A dropped negative contributes nothing to the sums (the 1/n of
+// BPR stays); a dropped positive zeroes the query's loss and every gradient of the query.  The mean over queries
+// (divided by mean_den: the local or the job-wide query count) is reduced in the same launch (reduce_mean_loss).
+struct HomeArgs {
+  const float* scores;
+  const int32_t* slot_of;
+  const float* pos_logp;
+  const float* neg_logp;
+  float* pos_score;
+  float* neg_score;
+  float* row_loss;
+  float* loss_out;
+  float* dpos;
+  float* dneg;
+  float* d_send;
+  unsigned int* flag_word;
+  float* loss_partials;
+  int64_t n_queries, mean_den;
+  int32_t n;
+};
+
+template <int LOSS>
+__global__ __launch_bounds__(256) void shard_home_kernel(const HomeArgs a) {
+  const int lane = lane_id();
+  const int64_t wave0 = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int64_t wstride = (int64_t)gridDim.x * (blockDim.x >> 6);
+  const int n = a.n;
+  const int T = (n + 63) >> 6;
+  const float w = 1.f / (float)n, inv_m = 1.f / (float)a.mean_den;
+  float wave_loss = 0.f;
+  for (int64_t m = wave0; m < a.n_queries; m += wstride) {
+    const int64_t E0 = m * (n + 1);
+    const int32_t sp = a.slot_of[E0];
+    const float pos = sp >= 0 ? a.scores[sp] : 0.f;
+    if (lane == 0 && a.pos_score != nullptr) a.pos_score[m] = pos;
+    if constexpr (LOSS == 0) {
+      for (int t = 0; t < T; ++t) {
+        const int j = (t << 6) + lane;
+        if (j < n) {
+          const int32_t s = a.slot_of[E0 + 1 + j];
+          a.neg_score[m * n + j] = s >= 0 ? a.scores[s] : 0.f;
+        }
+      }
+    } else if constexpr (LOSS == 1) {
+      float lsum = 0.f, gsum = 0.f;
+      for (int t = 0; t < T; ++t) {
+        const int j = (t << 6) + lane;
+        int32_t s = -1;
+        float neg = 0.f;
+        if (j < n) {
+          s = a.slot_of[E0 + 1 + j];
+          if (s >= 0) neg = a.scores[s];
+          if (a.neg_score != nullptr) a.neg_score[m * n + j] = neg;
+        }
+        const bool live = s >= 0 && sp >= 0;
+        const float xd = pos - neg;
+        const float tt = __expf(-fabsf(xd));
+        const float ls = live ? fminf(xd, 0.f) - __logf(1.f + tt) : 0.f;
+        const float r = __frcp_rn(1.f + tt);
+        const float sg = live ? (xd >= 0.f ? tt * r : r) * w * inv_m : 0.f;
+        if (j < n && a.dneg != nullptr) a.dneg[m * n + j] = sg;
+        if (s >= 0 && a.d_send != nullptr) a.d_send[s] = sg;
+        lsum += ls;
+        gsum += sg;
+      }
+      lsum = group_sum<64>(lsum);
+      gsum = group_sum<64>(gsum);
+      const float row = -lsum * w;
+      wave_loss += row;
+      if (lane == 0) {
+        if (a.row_loss != nullptr) a.row_loss[m] = row;
+        if (a.dpos != nullptr) a.dpos[m] = -gsum;
+        if (sp >= 0 && a.d_send != nullptr) a.d_send[sp] = -gsum;
+      }
+    } else {
+      const float lq_pos = a.pos_logp ? a.pos_logp[m] : 0.f;
+      const float z_pos = pos - lq_pos;
+      float run_m = -INFINITY, run_s = 0.f;
+      for (int t = 0; t < T; ++t) {
+        const int j = (t << 6) + lane;
+        int32_t s = -1;
+        float neg = 0.f, z = -INFINITY;
+        if (j < n) {
+          s = a.slot_of[E0 + 1 + j];
+          if (s >= 0) {
+            neg = a.scores[s];
+            z = neg - (a.neg_logp ? a.neg_logp[m * n + j] : 0.f);
+          }
+          if (a.neg_score != nullptr) a.neg_score[m * n + j] = neg;
+        }
+        const float tm = wave_max(z);
+        const float m_new = fmaxf(run_m, tm);
+        if (m_new > -INFINITY) {
+          run_s = run_s * __expf(run_m - m_new) + group_sum<64>(s >= 0 ? __expf(z - m_new) : 0.f);
+          run_m = m_new;
+        }
+      }
+      const bool gone = sp < 0;                   // dropped positive: the query leaves the step
+      const float top = fmaxf(run_m, z_pos);
+      const float lse = top + logf((run_m > -INFINITY ? run_s * expf(run_m - top) : 0.f) + expf(z_pos - top));
+      const bool bad = isinf(z_pos);              // padded positive: NaN like the reference (loss_func.py:88-89)
+      const float row = gone ? 0.f : (bad ? NAN : lse - z_pos);
+      const float dp = gone ? 0.f : (bad ? NAN : (expf(z_pos - lse) - 1.f) * inv_m);
+      wave_loss += row;
+      if (lane == 0) {
+        if (a.row_loss != nullptr) a.row_loss[m] = row;
+        if (a.dpos != nullptr) a.dpos[m] = dp;
+        if (sp >= 0 && a.d_send != nullptr) a.d_send[sp] = dp;
+      }
+      if (a.dneg != nullptr || a.d_send != nullptr) {
+        for (int t = 0; t < T; ++t) {
+          const int j = (t << 6) + lane;
+          if (j >= n) continue;
+          const int32_t s = a.slot_of[E0 + 1 + j];
+          float dv = 0.f;
+          if (s >= 0 && !gone) {
+            const float z = a.scores[s] - (a.neg_logp ? a.neg_logp[m * n + j] : 0.f);
+            dv = bad ? NAN : __expf(z - lse) * inv_m;
+          }
+          if (a.dneg != nullptr) a.dneg[m * n + j] = dv;
+          if (s >= 0 && a.d_send != nullptr) a.d_send[s] = dv;
+        }
+      }
+    }
+  }
+  if constexpr (LOSS != 0) {
+    if (a.loss_out != nullptr) reduce_mean_loss(wave_loss, a.loss_out, a.flag_word, a.loss_partials, a.mean_den);
   }
 }
 
@@ -251,46 +559,9 @@ extern "C" int rsa_shard_route(const int64_t* pos_ids, const int64_t* neg_ids, i
   RSA_CHECK_ARG(numel < (1ll << 31), "rsa_shard_route: more than 2^31 elements");
   const RouteShape sh{pos_ids, neg_ids, n_queries, (int)num_neg, (int)n_shards, rows_per_shard,
                       make_fastdiv((uint64_t)num_neg + 1), make_fastdiv((uint64_t)rows_per_shard)};
-  hipLaunchKernelGGL(shard_route_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, sh, query_base,
-                     (int64_t)0, cursor, keys, positions, (int32_t*)nullptr);
+  hipLaunchKernelGGL(shard_route_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, sh, query_base, cursor, keys,
+                     positions);
   RSA_CHECK_LAUNCH("rsa_shard_route");
-  return RSA_OK;
-}
-
-extern "C" int rsa_shard_route_fixed(const int64_t* pos_ids, const int64_t* neg_ids, int64_t n_queries, int32_t num_neg,
-                                     int64_t rows_per_shard, int32_t n_shards, int64_t query_base, int64_t capacity,
-                                     int32_t* cursor, int64_t* keys, int64_t* positions, int32_t* overflow,
-                                     rsa_stream_t stream) {
-  RSA_CHECK_ARG(n_queries >= 0 && num_neg >= 0 && rows_per_shard >= 1 && rows_per_shard < (1ll << 32),
-                "rsa_shard_route_fixed: bad sizes");
-  RSA_CHECK_ARG(n_shards >= 1 && n_shards <= 64, "rsa_shard_route_fixed: n_shards must be in [1, 64]");
-  RSA_CHECK_ARG(query_base >= 0 && query_base + n_queries < (1ll << 31), "rsa_shard_route_fixed: query index overflow");
-  RSA_CHECK_ARG(capacity >= 1 && capacity * n_shards < (1ll << 31), "rsa_shard_route_fixed: capacity out of range");
-  RSA_CHECK_ARG(cursor && keys && positions && overflow, "rsa_shard_route_fixed: null pointer");
-  hipStream_t s = (hipStream_t)stream;
-  if (hipMemsetAsync(cursor, 0, sizeof(int32_t) * n_shards, s) != hipSuccess) {
-    rsa::set_error("rsa_shard_route_fixed: memset failed");
-    return RSA_ERR_HIP;
-  }
-  int64_t tail_blocks = (capacity + 255) / 256;
-  if (tail_blocks > 256) tail_blocks = 256;
-  if (n_queries == 0) {
-    hipLaunchKernelGGL(shard_fill_tail_kernel, dim3((unsigned)tail_blocks, (unsigned)n_shards), dim3(256), 0, s, cursor,
-                       capacity, keys, positions);
-    RSA_CHECK_LAUNCH("rsa_shard_route_fixed(fill)");
-    return RSA_OK;
-  }
-  RSA_CHECK_ARG(pos_ids && (neg_ids || num_neg == 0), "rsa_shard_route_fixed: null ids");
-  const int64_t numel = n_queries * (num_neg + 1);
-  const int64_t blocks = (numel + ROUTE_CHUNK - 1) / ROUTE_CHUNK;
-  RSA_CHECK_ARG(numel < (1ll << 31), "rsa_shard_route_fixed: more than 2^31 elements");
-  const RouteShape sh{pos_ids, neg_ids, n_queries, (int)num_neg, (int)n_shards, rows_per_shard,
-                      make_fastdiv((uint64_t)num_neg + 1), make_fastdiv((uint64_t)rows_per_shard)};
-  hipLaunchKernelGGL(shard_route_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, sh, query_base, capacity, cursor,
-                     keys, positions, overflow);
-  hipLaunchKernelGGL(shard_fill_tail_kernel, dim3((unsigned)tail_blocks, (unsigned)n_shards), dim3(256), 0, s, cursor,
-                     capacity, keys, positions);
-  RSA_CHECK_LAUNCH("rsa_shard_route_fixed");
   return RSA_OK;
 }
 
@@ -324,5 +595,163 @@ extern "C" int rsa_gather_f32(const float* src, const int64_t* positions, int64_
   hipLaunchKernelGGL(gather_f32_kernel, dim3(grid1d(numel)), dim3(256), 0, (hipStream_t)stream, src, positions, numel,
                      dst);
   RSA_CHECK_LAUNCH("rsa_gather_f32");
+  return RSA_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ ABI v5 entry points
+extern "C" int64_t rsa_shard_segment_stride(int64_t capacity) { return capacity + RSA_SHARD_HDR; }
+
+extern "C" int rsa_shard_sample_route(const rsa_shard_route_args* a, rsa_stream_t stream) {
+  RSA_CHECK_ARG(a != nullptr, "rsa_shard_sample_route: args is null");
+  RSA_CHECK_ARG(a->n_queries >= 0 && a->num_neg >= 0 && a->rows_per_shard >= 1 && a->rows_per_shard < (1ll << 32),
+                "rsa_shard_sample_route: bad sizes");
+  RSA_CHECK_ARG(a->n_shards >= 1 && a->n_shards <= 64, "rsa_shard_sample_route: n_shards must be in [1, 64]");
+  RSA_CHECK_ARG(a->n_slices >= 1 && a->n_slices * a->n_shards <= 4096 && a->n_queries % a->n_slices == 0,
+                "rsa_shard_sample_route: n_slices must divide n_queries (and n_slices * n_shards <= 4096)");
+  RSA_CHECK_ARG(a->query_base >= 0 && a->query_base + a->n_queries < (1ll << 31), "rsa_shard_sample_route: query index overflow");
+  RSA_CHECK_ARG(a->sampler >= RSA_SAMPLER_GIVEN && a->sampler <= RSA_SAMPLER_POPULAR, "rsa_shard_sample_route: unknown sampler %d",
+                a->sampler);
+  RSA_CHECK_ARG(a->cursors != nullptr, "rsa_shard_sample_route: cursors is null");
+  const bool count_only = a->send_keys == nullptr;
+  RSA_CHECK_ARG(!count_only || a->counts_out != nullptr, "rsa_shard_sample_route: nothing to do (send_keys and counts_out null)");
+  if (a->n_queries == 0) {
+    if (a->counts_out) {
+      if (hipMemsetAsync(a->counts_out, 0, sizeof(int32_t) * a->n_slices * a->n_shards, (hipStream_t)stream) != hipSuccess) {
+        rsa::set_error("rsa_shard_sample_route: memset failed");
+        return RSA_ERR_HIP;
+      }
+    }
+    if (!count_only) {     // empty segments still carry their headers
+      const int64_t stride = a->capacity + RSA_SHARD_HDR;
+      if (hipMemset2DAsync(a->send_keys, sizeof(int64_t) * stride, 0, sizeof(int64_t) * RSA_SHARD_HDR,
+                           (size_t)a->n_slices * a->n_shards, (hipStream_t)stream) != hipSuccess) {
+        rsa::set_error("rsa_shard_sample_route: memset failed");
+        return RSA_ERR_HIP;
+      }
+    }
+    return RSA_OK;
+  }
+  RSA_CHECK_ARG(a->pos_ids != nullptr, "rsa_shard_sample_route: pos_ids is null");
+  RSA_CHECK_ARG(a->num_neg == 0 || a->sampler != RSA_SAMPLER_GIVEN || a->neg_ids != nullptr,
+                "rsa_shard_sample_route: sampler GIVEN needs neg_ids");
+  RSA_CHECK_ARG(a->n_items >= 2 && a->n_items < (1ll << 31), "rsa_shard_sample_route: n_items out of range");
+  if (a->sampler != RSA_SAMPLER_GIVEN && a->num_neg > 0)
+    RSA_CHECK_ARG(a->grid_threads > 0 && (a->offset & 3) == 0, "rsa_shard_sample_route: bad philox state");
+  if (a->sampler == RSA_SAMPLER_POPULAR && a->num_neg > 0) {
+    RSA_CHECK_ARG(a->table && a->pop_prob, "rsa_shard_sample_route: popularity tables missing");
+    if (a->cdf_lines != nullptr)
+      RSA_CHECK_ARG(a->lines_log2 >= 0 && a->lines_log2 <= 28 && ((uintptr_t)a->cdf_lines & 127) == 0,
+                    "rsa_shard_sample_route: cdf_lines must be 128-byte aligned with lines_log2 in [0, 28]");
+    else
+      RSA_CHECK_ARG(a->guide && a->guide_log2 >= 0 && a->guide_log2 <= 28, "rsa_shard_sample_route: guide table missing");
+  }
+  RSA_CHECK_ARG(a->pos_logp == nullptr || a->pop_prob != nullptr, "rsa_shard_sample_route: pos_logp needs pop_prob");
+  if (!count_only) {
+    RSA_CHECK_ARG(a->slot_of != nullptr, "rsa_shard_sample_route: slot_of is null");
+    RSA_CHECK_ARG(a->capacity >= 1 && (a->capacity + RSA_SHARD_HDR) * a->n_shards * a->n_slices < (1ll << 31),
+                  "rsa_shard_sample_route: capacity out of range");
+  }
+  const int64_t per_slice = a->n_queries / a->n_slices;
+  const int64_t slice_numel = per_slice * (a->num_neg + 1);
+  RSA_CHECK_ARG(a->n_queries * (a->num_neg + 1) < (1ll << 31), "rsa_shard_sample_route: more than 2^31 elements");
+  const int64_t bps = (slice_numel + ROUTE_CHUNK - 1) / ROUTE_CHUNK;
+  RSA_CHECK_ARG(bps * a->n_slices < (1ll << 31), "rsa_shard_sample_route: grid too large");
+  RouteV2 r;
+  r.pos_ids = a->pos_ids;
+  r.neg_ids = a->neg_ids;
+  r.neg_logp = a->neg_logp;
+  r.pos_logp = a->pos_logp;
+  r.send = a->send_keys;
+  r.slot_of = a->slot_of;
+  r.cursors = a->cursors;
+  r.counts_out = a->counts_out;
+  r.n_queries = a->n_queries;
+  r.per_slice = per_slice;
+  r.capacity = count_only ? (1ll << 40) : a->capacity;
+  r.stride = a->capacity + RSA_SHARD_HDR;
+  r.rows_per_shard = a->rows_per_shard;
+  r.query_base = a->query_base;
+  r.pc = PhiloxCall{a->seed, a->offset >> 2, a->grid_threads, a->elem_base};
+  r.pop = PopTables{a->table, a->pop_prob, a->table_prob, a->cdf_lut, a->cdf_lines, a->guide, a->n_items, a->guide_log2,
+                    a->lines_log2};
+  r.by_width = make_fastdiv((uint64_t)a->num_neg + 1);
+  r.by_rows = make_fastdiv((uint64_t)a->rows_per_shard);
+  r.n = a->num_neg;
+  r.G = a->n_shards;
+  r.sampler = a->sampler;
+  r.n_slices = a->n_slices;
+  r.blocks_per_slice = (int32_t)bps;
+  const dim3 grid((unsigned)(bps * a->n_slices)), block(256);
+  if (count_only) hipLaunchKernelGGL(shard_sample_route_kernel<true>, grid, block, 0, (hipStream_t)stream, r);
+  else hipLaunchKernelGGL(shard_sample_route_kernel<false>, grid, block, 0, (hipStream_t)stream, r);
+  RSA_CHECK_LAUNCH("rsa_shard_sample_route");
+  return RSA_OK;
+}
+
+extern "C" int rsa_shard_home(const rsa_shard_home_args* a, rsa_stream_t stream) {
+  RSA_CHECK_ARG(a != nullptr, "rsa_shard_home: args is null");
+  RSA_CHECK_ARG(a->n_queries >= 0 && a->num_neg >= 0, "rsa_shard_home: negative sizes");
+  RSA_CHECK_ARG(a->loss >= 0 && a->loss <= 2, "rsa_shard_home: loss must be 0 (none), 1 (BPR) or 2 (SampledSoftmax)");
+  if (a->n_queries == 0) return RSA_OK;
+  RSA_CHECK_ARG(a->scores && a->slot_of, "rsa_shard_home: scores / slot_of is null");
+  RSA_CHECK_ARG(a->loss != 0 || (a->neg_score != nullptr || a->num_neg == 0), "rsa_shard_home: loss 0 needs neg_score");
+  RSA_CHECK_ARG(a->loss == 0 || a->num_neg >= 1, "rsa_shard_home: a loss needs num_neg >= 1");
+  RSA_CHECK_ARG(a->loss == 0 || a->mean_den >= 1, "rsa_shard_home: mean_den must be >= 1");
+  HomeArgs h;
+  h.scores = a->scores;
+  h.slot_of = a->slot_of;
+  h.pos_logp = a->pos_logp;
+  h.neg_logp = a->neg_logp;
+  h.pos_score = a->pos_score;
+  h.neg_score = a->neg_score;
+  h.row_loss = a->row_loss;
+  h.loss_out = a->loss_out;
+  h.dpos = a->dpos;
+  h.dneg = a->dneg;
+  h.d_send = a->d_send;
+  h.flag_word = nullptr;
+  h.loss_partials = nullptr;
+  h.n_queries = a->n_queries;
+  h.mean_den = a->mean_den;
+  h.n = a->num_neg;
+  if (a->loss != 0 && a->loss_out != nullptr) {
+    RSA_CHECK_ARG(a->reduce_scratch != nullptr, "rsa_shard_home: loss_out needs reduce_scratch (rsa_scratch_bytes() bytes, zeroed once)");
+    char* sc = reinterpret_cast<char*>(a->reduce_scratch);
+    h.flag_word = reinterpret_cast<unsigned int*>(sc + SCRATCH_COUNTER);
+    h.loss_partials = reinterpret_cast<float*>(sc + SCRATCH_FUSED_PARTIALS);
+  }
+  int64_t blocks = (a->n_queries + 3) / 4;
+  if (blocks > 2048) blocks = 2048;
+  const dim3 grid((unsigned)blocks), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  if (a->loss == 0) hipLaunchKernelGGL(shard_home_kernel<0>, grid, block, 0, s, h);
+  else if (a->loss == 1) hipLaunchKernelGGL(shard_home_kernel<1>, grid, block, 0, s, h);
+  else hipLaunchKernelGGL(shard_home_kernel<2>, grid, block, 0, s, h);
+  RSA_CHECK_LAUNCH("rsa_shard_home");
+  return RSA_OK;
+}
+
+extern "C" int rsa_shard_scatter_slots(const float* dpos, const float* dneg, const int32_t* slot_of, int64_t n_queries,
+                                       int32_t num_neg, float* d_send, rsa_stream_t stream) {
+  RSA_CHECK_ARG(n_queries >= 0 && num_neg >= 0, "rsa_shard_scatter_slots: negative sizes");
+  if (n_queries == 0) return RSA_OK;
+  RSA_CHECK_ARG(dpos && (dneg || num_neg == 0) && slot_of && d_send, "rsa_shard_scatter_slots: null pointer");
+  RSA_CHECK_ARG(n_queries * (num_neg + 1) < (1ll << 31), "rsa_shard_scatter_slots: more than 2^31 elements");
+  hipLaunchKernelGGL(shard_scatter_slots_kernel, dim3(grid1d(n_queries * (num_neg + 1))), dim3(256), 0, (hipStream_t)stream,
+                     dpos, dneg, slot_of, n_queries, (int)num_neg, make_fastdiv((uint64_t)num_neg + 1), d_send);
+  RSA_CHECK_LAUNCH("rsa_shard_scatter_slots");
+  return RSA_OK;
+}
+
+extern "C" int rsa_shard_unpack_segments(const int64_t* keys, int64_t n_segments, int64_t stride, int64_t* local_rows,
+                                         int64_t* query_index, const float* scale_in, const int32_t* step_dropped,
+                                         float* scale_out, rsa_stream_t stream) {
+  RSA_CHECK_ARG(n_segments >= 0 && stride > RSA_SHARD_HDR, "rsa_shard_unpack_segments: bad sizes");
+  const int64_t numel = n_segments * stride;
+  if (numel == 0) return RSA_OK;
+  RSA_CHECK_ARG(keys && local_rows && query_index, "rsa_shard_unpack_segments: null pointer");
+  hipLaunchKernelGGL(shard_unpack_segments_kernel, dim3(grid1d(numel)), dim3(256), 0, (hipStream_t)stream, keys, numel, stride,
+                     local_rows, query_index, scale_in, step_dropped, scale_out);
+  RSA_CHECK_LAUNCH("rsa_shard_unpack_segments");
   return RSA_OK;
 }

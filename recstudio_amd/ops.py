@@ -32,6 +32,24 @@ def zero_logp_like(ids):
     return z.view(ids.shape)
 
 
+def zero_logp(shape, device):
+    """The same constant for a shape / device instead of a template tensor."""
+    shape = tuple(int(x) for x in shape)
+    numel = 1
+    for x in shape:
+        numel *= x
+    device = torch.device(device)
+    if device.type == 'cuda' and device.index is None:
+        device = torch.device('cuda', torch.cuda.current_device())
+    key = (numel, device)
+    z = _ZERO_LOGP.get(key)
+    if z is None:
+        if len(_ZERO_LOGP) >= 16:
+            _ZERO_LOGP.clear()
+        z = _ZERO_LOGP[key] = torch.zeros(numel, dtype=torch.int64, device=device)
+    return z.view(shape)
+
+
 def is_known_zero(t):
     if t.is_floating_point():
         return False
@@ -145,7 +163,7 @@ def sample_masked_uniform(user_hist, num_items, per_row, generator=None):
     if B * per_row:
         pc = rng.reserve(B * per_row, 4, user_hist.device, generator)
         nat.check(nat.lib().rsa_sample_masked_uniform(ptr(user_hist), B, Lh, int(num_items), int(per_row), ptr(out),
-                                                      pc.seed, pc.offset, pc.grid_threads, _stream()),
+                                                      pc.seed, pc.offset, pc.grid_threads, pc.elem_base, _stream()),
                   'rsa_sample_masked_uniform')
     return out
 

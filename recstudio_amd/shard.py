@@ -1,24 +1,32 @@
 """Row-sharded item table over the GPUs of one node (BASELINE.json configs[3]).
 
 One process per GPU (``torch.distributed``; backend "nccl" is RCCL on ROCm).  Rank r owns item
-rows [r*rows_per_shard, (r+1)*rows_per_shard) and B queries per step.  Per step:
+rows [r*rows_per_shard, (r+1)*rows_per_shard) and B queries per step.  Per step (``exchange='fixed'``, the default):
 
-  1. all_gather of the [B, d] query block                        (RCCL all-gather)
-  2. sample negatives for the own queries (replicated sampler tables, own Philox stream)
-  3. count + counting-sort the B*(1+n) (query, item) elements by owning rank   (HIP)
-  4. all_to_all of 8-byte packed keys (query index << 32 | local row)          (RCCL all-to-all)
-  5. local gather + score on the owner against the gathered queries            (HIP fused kernel)
-  6. all_to_all of the fp32 scores back, scatter into [pos_score | neg_score]  (RCCL + HIP)
+  1. all_gather of the [B, d] query block                                      (RCCL all-gather, own communicator)
+  2. ONE launch draws the negatives of the own queries (in-kernel Philox / inverse CDF, one job-wide stream) and
+     counting-sorts the B*(1+n) (query, item) elements by owning rank into fixed-capacity, self-describing
+     segments: {live count, dropped count} header + 8-byte keys (query index << 32 | local row); each element keeps
+     ONE int32: the slot of its key == the slot of its score on the way back              (rsa_shard_sample_route)
+  3. equal-split all_to_all of the segments                                     (RCCL all-to-all)
+  4. local gather + score on the owner against the gathered queries, straight from the received segments; tiles past
+     a segment's count are skipped                                               (rsa_shard_score_segments)
+  5. equal-split all_to_all of the fp32 scores back                             (RCCL all-to-all)
+  6. ONE launch gathers the scores through the slots and evaluates BPR / SampledSoftmax, its mean and d loss/d score
+     (written in routed order for the gradient exchange)                         (rsa_shard_home)
 
 12 bytes per triplet cross xGMI instead of a 512-byte row.  The reference has nothing
 comparable: its only multi-device mode re-broadcasts every parameter each step
 (recstudio/utils/data_parallel.py:106-159) and DDP is dead code (recommender.py:731-740).
 
-No host round trip in the step (``exchange='fixed'``, the default): every owner gets a fixed-capacity segment of
-the key buffer, unused slots carry key -1 through an EQUAL-split all-to-all and are skipped by every consumer, so
-the split sizes never have to be read back; the capacity comes from one calibration step (exact counts, max over
-ranks, plus slack) and a sticky device-side overflow counter is checked off the critical path
-(``check_overflow``).  ``exchange='exact'`` is the variable-split form (counts exchanged and read back each step).
+No host round trip in the step: the split is equal, the headers say what is live, and the capacity comes from one
+calibration launch (exact counts of the very draw the first step routes, max over slices, owners and ranks, plus
+slack).  An element that finds its segment full is DROPPED with a defined outcome -- no key, no score, no loss term,
+zero gradient -- and counted in the header; the headers of all sources reach every rank with the keys, so every rank
+knows the job-wide dropped count of the step and scales that step's weight updates by 0 on the device: an overflowed
+step changes nothing anywhere.  The count is also kept in a sticky device word that ``check_overflow`` reads off the
+critical path (same value on every rank, no collective).  ``exchange='exact'`` is the variable-split form (counts
+exchanged and read back each step, ids materialised, separate scatter and loss kernels).
 
 G-invariant negatives: all ranks draw from ONE Philox stream (``sample_generator``, same seed everywhere) by global
 element index -- rank r owns rows [r*B, (r+1)*B) of a virtual [G*B, n] id tensor (``rng.sharded_stream``) -- so a
@@ -58,8 +66,28 @@ class RowShardPlan:
 class HipBackend:
     """Device work of the sharded step, all through the C ABI."""
 
+    HDR = 2          # RSA_SHARD_HDR: 8-byte header words {live keys, dropped by the source this step} per segment
+
     def make_generator(self, seed, device):
         return torch.Generator(device=device).manual_seed(int(seed))
+
+    def new_state(self, device):
+        """Per-table device words: routing cursors (zeroed once, self-resetting), the sticky job-wide dropped count,
+        the dropped count of the last step, and the gated update scales {item scale, gate} the backward multiplies by."""
+        return {'cursors': torch.zeros(4097, dtype=torch.int32, device=device),
+                'overflow': torch.zeros(1, dtype=torch.int32, device=device),
+                'step_dropped': torch.zeros(1, dtype=torch.int32, device=device),
+                'scale': torch.ones(2, dtype=torch.float32, device=device)}
+
+    def sampler_spec(self, sampler):
+        """The in-kernel form of a Sampler plugin (drawn inside the routing pass), or None: then the plugin itself is
+        called and its ids are routed as given.  Exact types only -- a subclass may override ``forward``."""
+        from .sampler import PopularSamplerModel, UniformSampler
+        if type(sampler) is UniformSampler:
+            return {'kind': nat.SAMPLER_UNIFORM, 'n_items': sampler.num_items + 1}
+        if type(sampler) is PopularSamplerModel:
+            return {'kind': nat.SAMPLER_POPULAR, 'n_items': sampler.table.numel(), 'tables': sampler.lookup_kwargs()}
+        return None
 
     def sample(self, sampler, n_queries, n, device, pos_ids, shard=None):
         """The stand-alone Sampler plugin: (log_pos_prob, neg_ids, log_neg_prob).  ``shard = (rank, world, generator)``:
@@ -70,28 +98,152 @@ class HipBackend:
         with rng.sharded_stream(*shard):
             return sampler(q, n, pos_ids)
 
-    def new_flag(self, device):
-        return torch.zeros(1, dtype=torch.int32, device=device)
-
     def flag_read_async(self, flag):
-        """Start copying the overflow word to the host; returns poll() -> None while in flight, else the value."""
+        """Start copying a device word to the host; returns poll() -> None while in flight, else the value."""
         host = torch.empty(1, dtype=torch.int32).pin_memory()
         host.copy_(flag, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
         return lambda: int(host[0]) if ev.query() else None
 
-    def route_fixed(self, pos, neg, plan, query_base, capacity, overflow):
-        B, n = neg.shape
-        slots = plan.world * int(capacity)
-        keys = torch.empty(slots, dtype=torch.int64, device=pos.device)
-        positions = torch.empty(slots, dtype=torch.int64, device=pos.device)
-        cursor = torch.empty(plan.world, dtype=torch.int32, device=pos.device)
-        nat.check(nat.lib().rsa_shard_route_fixed(ptr(pos), ptr(neg), B, n, plan.rows_per_shard, plan.world, int(query_base),
-                                                  int(capacity), ptr(cursor), ptr(keys), ptr(positions), ptr(overflow),
-                                                  ops._stream()), 'rsa_shard_route_fixed')
-        return keys, positions
+    # -- version 2 of the fixed-capacity exchange (rsa_shard_sample_route / _score_segments / _home) -------------------
+    @ops._on_device
+    def sample_route(self, state, plan, rank, pos, n, chunks, capacity, spec, generator, neg=None, want_ids=False,
+                     want_logp=False, count_only=False):
+        """One launch: draw (or read) the negatives, route every (query, item) element of all ``chunks`` query slices.
+        -> dict(send [C*G*stride] int64, slot_of [B*(1+n)] int32, stride, neg_ids / log_neg_prob / log_pos_prob when
+        asked for), or the exact per-(slice, owner) counts [C*G] int32 with ``count_only`` (the generator is not
+        advanced: the next call routes the very draw that was counted)."""
+        B, dev, G = pos.numel(), pos.device, plan.world
+        a = nat.ShardRouteArgs()
+        kind = spec['kind'] if spec is not None else nat.SAMPLER_GIVEN
+        a.pos_ids, a.n_queries, a.num_neg, a.sampler = ptr(ops._need(pos, torch.int64, 'pos')), B, int(n), int(kind)
+        a.n_slices, a.n_shards, a.rows_per_shard = int(chunks), G, plan.rows_per_shard
+        a.query_base, a.capacity = rank * B, int(capacity)
+        a.n_items = spec['n_items'] if spec is not None else plan.n_items
+        out = {}
+        keep = []
+        if kind == nat.SAMPLER_GIVEN:
+            neg = ops._need(neg, torch.int64, 'neg')
+            a.neg_ids = ptr(neg)
+            out['neg_ids'] = neg.view(B, n)
+        elif B * n:
+            unroll = 4 if kind == nat.SAMPLER_POPULAR else rng.randint_unroll(1, a.n_items)
+            off0 = generator.get_offset() if count_only else None
+            with rng.sharded_stream(rank, G, generator):
+                pc = rng.reserve(B * n, unroll, dev)
+            if count_only:
+                generator.set_offset(off0)
+            a.seed, a.offset, a.grid_threads, a.elem_base = pc.seed, pc.offset, pc.grid_threads, pc.elem_base
+            if kind == nat.SAMPLER_POPULAR:
+                t = spec['tables']
+                keep = [ops._need(t['table'], torch.float32, 'table'), ops._need(t['pop_prob'], torch.float32, 'pop_prob')]
+                a.table, a.pop_prob = ptr(keep[0]), ptr(keep[1])
+                a.guide, a.guide_log2 = ptr(t.get('guide')), int(t.get('guide_log2') or 0)
+                a.table_prob, a.cdf_lut = ptr(t.get('table_prob')), ptr(t.get('cdf_lut'))
+                a.cdf_lines, a.lines_log2 = ptr(t.get('cdf_lines')), int(t.get('lines_log2') or 0)
+            if want_ids and not count_only:
+                out['neg_ids'] = torch.empty(B, n, dtype=torch.int64, device=dev)
+                a.neg_ids = ptr(out['neg_ids'])
+        if kind == nat.SAMPLER_POPULAR and want_logp and not count_only:
+            out['log_neg_prob'] = torch.empty(B, n, dtype=torch.float32, device=dev)
+            out['log_pos_prob'] = torch.empty(B, dtype=torch.float32, device=dev)
+            a.neg_logp, a.pos_logp = ptr(out['log_neg_prob']), ptr(out['log_pos_prob'])
+        a.cursors = ptr(state['cursors'])
+        if count_only:
+            counts = torch.empty(chunks * G, dtype=torch.int32, device=dev)
+            a.counts_out = ptr(counts)
+            nat.check(nat.lib().rsa_shard_sample_route(ctypes.byref(a), ops._stream()), 'rsa_shard_sample_route')
+            return counts
+        stride = int(capacity) + self.HDR
+        out['send'] = torch.empty(chunks * G * stride, dtype=torch.int64, device=dev)
+        out['slot_of'] = torch.empty(B * (n + 1), dtype=torch.int32, device=dev)
+        out['stride'] = stride
+        a.send_keys, a.slot_of = ptr(out['send']), ptr(out['slot_of'])
+        nat.check(nat.lib().rsa_shard_sample_route(ctypes.byref(a), ops._stream()), 'rsa_shard_sample_route')
+        return out
 
+    @ops._on_device
+    def score_segments(self, state, item_local, q_all, recv_keys, n_seg, stride, first=True, out=None):
+        """Owner side: fp32 scores of the live slots of ``recv_keys`` [n_seg, stride]; ``first``: also publish the
+        step's job-wide dropped count (sum of the received headers) into the state words."""
+        scores = out if out is not None else torch.empty(n_seg * stride, dtype=torch.float32, device=recv_keys.device)
+        nat.check(nat.lib().rsa_shard_score_segments(
+            ptr(item_local), item_local.shape[0], item_local.shape[1], ptr(q_all), q_all.shape[0], ptr(recv_keys), n_seg,
+            stride, ptr(scores), ptr(state['step_dropped']) if first else None, ptr(state['overflow']) if first else None,
+            ops._stream()), 'rsa_shard_score_segments')
+        return scores
+
+    @ops._on_device
+    def home(self, scores_home, slot_of, B, n, loss=None, pos_logp=None, neg_logp=None, mean_den=None,
+             want_scores=True, want_grad=False, want_dsend=False):
+        """Home side: gather through the slots + loss + mean (+ gradients) in one launch.  -> dict."""
+        dev = scores_home.device
+        a = nat.ShardHomeArgs()
+        a.scores, a.slot_of, a.n_queries, a.num_neg = ptr(scores_home), ptr(slot_of), int(B), int(n)
+        a.loss = {None: 0, 'bpr': 1, 'ssm': 2}[loss]
+        out = {}
+        if want_scores or loss is None:
+            out['pos_score'] = torch.empty(B, dtype=torch.float32, device=dev)
+            out['neg_score'] = torch.empty(B, n, dtype=torch.float32, device=dev)
+            a.pos_score, a.neg_score = ptr(out['pos_score']), ptr(out['neg_score'])
+        if loss is not None:
+            a.mean_den = int(mean_den if mean_den is not None else B)
+            a.pos_logp, a.neg_logp = ptr(ops._need_opt(pos_logp, torch.float32, 'pos_logp')), ptr(ops._need_opt(neg_logp, torch.float32, 'neg_logp'))
+            out['loss'] = torch.empty((), dtype=torch.float32, device=dev)
+            out['row_loss'] = torch.empty(B, dtype=torch.float32, device=dev)
+            a.loss_out, a.row_loss, a.reduce_scratch = ptr(out['loss']), ptr(out['row_loss']), ptr(ops._scratch())
+            if want_grad:
+                out['dpos'] = torch.empty(B, dtype=torch.float32, device=dev)
+                out['dneg'] = torch.empty(B, n, dtype=torch.float32, device=dev)
+                a.dpos, a.dneg = ptr(out['dpos']), ptr(out['dneg'])
+            if want_dsend:
+                out['d_send'] = torch.empty(scores_home.numel(), dtype=torch.float32, device=dev)
+                a.d_send = ptr(out['d_send'])
+        nat.check(nat.lib().rsa_shard_home(ctypes.byref(a), ops._stream()), 'rsa_shard_home')
+        return out
+
+    @ops._on_device
+    def scatter_slots(self, dpos, dneg, slot_of, n_slots):
+        """d loss/d score of a loss evaluated outside ``home`` -> routed order (dropped elements send nothing)."""
+        B = dpos.numel()
+        n = dneg.numel() // max(B, 1)
+        d_send = torch.empty(n_slots, dtype=torch.float32, device=dpos.device)
+        nat.check(nat.lib().rsa_shard_scatter_slots(ptr(ops._need(dpos, torch.float32, 'dpos')), ptr(ops._need(dneg, torch.float32, 'dneg')),
+                                                    ptr(slot_of), B, n, ptr(d_send), ops._stream()), 'rsa_shard_scatter_slots')
+        return d_send
+
+    @ops._on_device
+    def backward_segments(self, state, item_local, q_all, recv_keys, n_seg, stride, d_owner, item_grad_local, qgrad_all,
+                          item_pad_row=-1, item_scale=None):
+        """Owner side of the backward on received segments: item_grad_local[row] += s * d * q_all[qidx];
+        qgrad_all[qidx] += g * d * item_local[row], with g = 0 when any rank dropped an element in this step (else 1)
+        and s = g * item_scale (item_scale: device scalar, -lr for in-place SGD; default 1)."""
+        m = n_seg * stride
+        if m == 0:
+            return
+        rows = torch.empty(m, dtype=torch.int64, device=recv_keys.device)
+        qidx = torch.empty(m, dtype=torch.int64, device=recv_keys.device)
+        scale = state['scale']
+        nat.check(nat.lib().rsa_shard_unpack_segments(ptr(recv_keys), n_seg, stride, ptr(rows), ptr(qidx), ptr(item_scale),
+                                                      ptr(state['step_dropped']), ptr(scale), ops._stream()),
+                  'rsa_shard_unpack_segments')
+        if item_local.shape[1] in (64, 128, 256):
+            # two atomics-free sorted scatters (by query -- it reads the item rows, so it runs first -- then by item row)
+            ops.scatter_rows_sorted(qgrad_all, item_local, qidx.view(m, 1), d_owner.view(m, 1), query_index=rows,
+                                    upstream=scale[1:2], pad_row=-1)
+            ops.scatter_rows_sorted(item_grad_local, q_all, rows.view(m, 1), d_owner.view(m, 1), query_index=qidx,
+                                    upstream=scale[0:1], pad_row=item_pad_row)
+            return
+        if item_scale is not None:
+            raise NotImplementedError('in-place item update needs embed_dim in {64, 128, 256}')
+        d_owner = torch.where(rows >= 0, d_owner * scale[1], torch.zeros((), device=d_owner.device))
+        rows, qidx = rows.clamp_(min=0), qidx.clamp_(min=0)      # empty slots (d = 0 there): any valid row
+        ops.fused_backward(item_local, q_all, rows.view(m, 1), d_owner.view(m, 1), query_index=qidx,
+                           dense_item_grad=False, want_query_grad=False, item_grad_out=item_grad_local,
+                           query_table_grad=qgrad_all, query_table_pad_row=-1, item_pad_row=item_pad_row)
+
+    # -- exact (variable-split) exchange ------------------------------------------------------------------------------
     def gather_rows(self, table, ids):
         return ops.embedding_gather(table, ids)
 
@@ -116,7 +268,7 @@ class HipBackend:
         return ops.score_packed_keys(item_local, q_all, keys)
 
     def scatter(self, scores, positions, numel):
-        dst = torch.empty(numel, dtype=torch.float32, device=scores.device)
+        dst = torch.zeros(numel, dtype=torch.float32, device=scores.device)
         nat.check(nat.lib().rsa_scatter_f32(ptr(scores), ptr(positions), scores.numel(), ptr(dst), ops._stream()),
                   'rsa_scatter_f32')
         return dst
@@ -128,10 +280,10 @@ class HipBackend:
         return dst
 
     def backward_keys(self, item_local, q_all, keys, dscore, item_grad_local, qgrad_all, item_pad_row=-1, item_scale=None):
-        """Owner side of the backward: item_grad_local[row] += d * q_all[qidx]; qgrad_all[qidx] += d * item_local[row].
-        ``item_scale`` (device scalar): multiply the item-side update by it -- with ``item_grad_local is item_local``
-        and item_scale = -lr this is plain SGD applied in place (the query-side pass, which reads the rows, runs
-        first)."""
+        """Owner side of the backward (exact exchange): item_grad_local[row] += d * q_all[qidx]; qgrad_all[qidx] += d *
+        item_local[row].  ``item_scale`` (device scalar): multiply the item-side update by it -- with
+        ``item_grad_local is item_local`` and item_scale = -lr this is plain SGD applied in place (the query-side pass,
+        which reads the rows, runs first)."""
         m = keys.numel()
         if m == 0:
             return
@@ -139,22 +291,21 @@ class HipBackend:
         qidx = torch.empty(m, dtype=torch.int64, device=keys.device)
         nat.check(nat.lib().rsa_shard_unpack(ptr(keys), m, ptr(rows), ptr(qidx), ops._stream()), 'rsa_shard_unpack')
         if item_local.shape[1] in (64, 128, 256):
-            # two atomics-free sorted scatters (by item row, then by query): reproducible, ~2x faster than atomics
             ops.scatter_rows_sorted(qgrad_all, item_local, qidx.view(m, 1), dscore.view(m, 1), query_index=rows, pad_row=-1)
             ops.scatter_rows_sorted(item_grad_local, q_all, rows.view(m, 1), dscore.view(m, 1), query_index=qidx,
                                     upstream=item_scale, pad_row=item_pad_row)
             return
         if item_scale is not None:
             raise NotImplementedError('in-place item update needs embed_dim in {64, 128, 256}')
-        rows, qidx = rows.clamp_(min=0), qidx.clamp_(min=0)      # empty slots (d = 0 there): any valid row
+        rows, qidx = rows.clamp_(min=0), qidx.clamp_(min=0)
         ops.fused_backward(item_local, q_all, rows.view(m, 1), dscore.view(m, 1), query_index=qidx,
                            dense_item_grad=False, want_query_grad=False, item_grad_out=item_grad_local,
                            query_table_grad=qgrad_all, query_table_pad_row=-1, item_pad_row=item_pad_row)
 
-
     def apply_rows(self, table, ids, rows, scale, pad_row=0):
-        """table[ids[e]] += scale * rows[e], duplicates summed in sorted order without atomics: every replica that
-        applies the same (ids, rows) ends up with the same bits."""
+        """table[ids[e]] += scale * rows[e] for ids != pad_row (pad_row < 0: every row), duplicates summed in sorted
+        order without atomics for embed_dim in {64, 128, 256}: every replica that applies the same (ids, rows) ends up
+        with the same bits.  Other dims: ``index_add_`` (float atomics: equal up to summation order)."""
         m = ids.numel()
         if m == 0:
             return
@@ -163,8 +314,8 @@ class HipBackend:
             ops.scatter_rows_sorted(table, rows, ids.view(m, 1), torch.full((m, 1), float(scale), device=rows.device),
                                     query_index=torch.arange(m, device=ids.device), pad_row=pad_row)
         else:
-            keep = (ids != pad_row).to(rows.dtype).unsqueeze(1) * float(scale)     # the padding row takes no gradient
-            ops.scatter_add_rows(rows * keep, ids, table.shape[0], out=table)
+            keep = ids != pad_row
+            table.index_add_(0, ids[keep], rows[keep] * float(scale))
 
     def full_partial(self, item_local, q_all, k, want_lse, has_pad_row):
         """This shard's part of the full-catalog pass (BASELINE.json configs[4] sharded):
@@ -208,10 +359,10 @@ def _gather_group(dist):
 
 class ShardedItemTable:
     def __init__(self, item_local, plan, rank, dist, backend=None, group=None, exchange='fixed', slack=1.08,
-                 margin=4096, check_every=64, sample_seed=2022, chunks=1):
+                 margin=4096, check_every=16, sample_seed=2022, chunks=1):
         """``chunks`` > 1 (fixed-capacity exchange only): the step's queries are cut into that many contiguous
-        slices whose exchanges are issued asynchronously, so that slice c+1's key all-to-all and slice c-1's score
-        all-to-all travel over xGMI while slice c is being scored (see ``_score_ids_pipelined``)."""
+        slices, routed by ONE launch, whose exchanges are issued asynchronously, so that slice c+1's key all-to-all and
+        slice c-1's score all-to-all travel over xGMI while slice c is being scored (see ``_fixed_step``)."""
         self.item_local, self.plan, self.rank, self.dist = item_local, plan, int(rank), dist
         self.chunks = max(1, int(chunks))
         self.backend = backend if backend is not None else HipBackend()
@@ -220,7 +371,7 @@ class ShardedItemTable:
             raise ValueError("exchange must be 'fixed' or 'exact'")
         self.exchange, self.slack, self.margin, self.check_every = exchange, float(slack), int(margin), int(check_every)
         self._cap, self._steps, self._poll, self._poll_due = {}, 0, None, 0
-        self._overflow = self.backend.new_flag(item_local.device)
+        self.state = self.backend.new_state(item_local.device)
         # ONE sampler stream for the whole job: same seed on every rank, advanced in lock-step (see module docstring)
         self.sample_generator = self.backend.make_generator(sample_seed, item_local.device)
         # the query all-gather runs on its OWN communicator: collectives of one communicator execute in issue
@@ -256,10 +407,10 @@ class ShardedItemTable:
         self.dist.all_to_all_single(recv, send, group=self.group)
         return [int(v) for v in send.tolist()], [int(v) for v in recv.tolist()]
 
-    def _all_to_all(self, x, recv_counts=None, send_counts=None):
+    def _all_to_all(self, x, recv_counts=None, send_counts=None, out=None):
         """Variable split (host lists) or, with no counts, the equal split of the fixed-capacity exchange."""
         if recv_counts is None:
-            out = torch.empty_like(x)
+            out = torch.empty_like(x) if out is None else out
             self.dist.all_to_all_single(out, x, group=self.group)
             return out
         out = torch.empty(sum(recv_counts), dtype=x.dtype, device=x.device)
@@ -267,11 +418,11 @@ class ShardedItemTable:
                                     group=self.group)
         return out
 
-    def _all_to_all_start(self, x):
+    def _all_to_all_start(self, x, out=None):
         """Equal-split all-to-all issued asynchronously (it runs on the communicator's stream once everything queued
         on the current stream so far has finished); returns wait() -> the received tensor, ordered after the transfer
         on the current stream."""
-        out = torch.empty_like(x)
+        out = torch.empty_like(x) if out is None else out
         work = self.dist.all_to_all_single(out, x, group=self.group, async_op=True)
 
         def wait():
@@ -287,179 +438,213 @@ class ShardedItemTable:
         return out
 
     # -- fixed-capacity bookkeeping -------------------------------------------------------------------
-    def _calibrate(self, key, send_counts):
-        """Capacity of one owner segment from an exact step: the largest per-owner count of ANY rank (so that every
-        rank uses the same equal split) plus slack.  One small all-reduce + read-back, on the calibration step only."""
-        B, n = key
-        m = torch.tensor([max(send_counts)], dtype=torch.int64, device=self.item_local.device)
+    def _capacity(self, key, largest):
+        """Capacity of one (slice, owner) segment from the exact counts of a step: the largest count of ANY rank (so
+        that every rank uses the same equal split) plus slack.  One small all-reduce + read-back, on the calibration
+        step only."""
+        B, n, C = key
+        m = torch.tensor([int(largest)], dtype=torch.int64, device=self.item_local.device)
         self.dist.all_reduce(m, op=self.dist.ReduceOp.MAX, group=self.group)
         cap = int(int(m.item()) * self.slack) + self.margin
-        cap = min(B * (n + 1), (cap + 255) // 256 * 256)
+        cap = min((B // C) * (n + 1), (cap + 255) // 256 * 256)
         self._cap[key] = max(cap, 1)
-
-    def _start_overflow_read(self):
-        """The overflow words of ALL ranks summed (one tiny all-reduce) and copied to the host asynchronously: every
-        rank sees the same value, so every rank raises at the same step -- a rank that raised alone would leave the
-        others waiting in their next collective."""
-        total = self._overflow.clone()
-        self.dist.all_reduce(total, group=self.group)
-        return self.backend.flag_read_async(total)
+        return self._cap[key]
 
     def check_overflow(self, block=True):
-        """Raise if any routed element of ANY rank ever found its owner's segment full (its score was lost).
-        COLLECTIVE (call it on every rank at the same point)."""
-        self._poll = self._poll or self._start_overflow_read()
+        """Raise if any routed element of ANY rank found its owner's segment full since the last check.  The sticky
+        count is job-wide on every rank (the segment headers carry every source's dropped count to every owner), so
+        all ranks raise at the same step without a collective.  The steps in which it happened changed no weight
+        (their update scale was 0 on the device)."""
+        self._poll = self._poll or self.backend.flag_read_async(self.state['overflow'])
         v = self._poll()
         while v is None:
             v = self._poll()
         self._poll = None
         if v:
             self._cap.clear()               # recalibrate on the next step
-            self._overflow.zero_()
+            self.state['overflow'].zero_()
             raise RuntimeError(f'sharded exchange: {v} elements (all ranks) did not fit their owner segment (capacity slack '
-                               f'{self.slack}); the affected steps are invalid -- raise `slack` / `margin` or use '
-                               "exchange='exact' for id distributions that drift this fast")
+                               f'{self.slack}); the affected steps were skipped (their weight updates were scaled by 0) '
+                               "-- raise `slack` / `margin` or use exchange='exact' for id distributions that drift this fast")
 
-    LAG = 8          # steps between starting the read-back of the overflow words and looking at it
+    LAG = 4          # steps between starting the read-back of the overflow word and looking at it
 
     def _after_fixed_step(self):
-        """Every ``check_every`` steps the (all-reduced) overflow count starts its way to the host; LAG steps later --
-        long after the copy has landed, so without a stall -- every rank looks at it, at the SAME step."""
+        """Every ``check_every`` steps the overflow count starts its way to the host; LAG steps later -- long after
+        the copy has landed, so without a stall -- every rank looks at it, at the SAME step."""
         self._steps += 1
         if self.check_every <= 0:
             return
         if self._poll is not None and self._steps >= self._poll_due:
             self.check_overflow()
         if self._poll is None and self._steps % self.check_every == 0:
-            self._poll = self._start_overflow_read()
+            self._poll = self.backend.flag_read_async(self.state['overflow'])
             self._poll_due = self._steps + self.LAG
 
     # -- the step ---------------------------------------------------------------------------------
+    def _fixed_step(self, q_gather, pos, n, spec, neg=None, keep_route=False, fused_loss=None, mean_den=None,
+                    log_pos=None, log_neg=None, want_ids=True, want_logp=True, want_scores=True, want_grad=False):
+        """Version 2 of the fixed-capacity step.  Issue order on the current stream: ONE routing launch for all
+        ``chunks`` query slices (each slice's key all-to-all follows on the communicator's stream), then per slice:
+        wait for its keys, score, start the score all-to-all; finally wait for all scores and run the home kernel
+        once.  Collectives of one communicator run in issue order, so slice c's keys arrive while slice c-1 is being
+        scored and its scores go back while slice c+1 is being scored.  Every rank issues the same sequence."""
+        be, st, plan = self.backend, self.state, self.plan
+        B, G = pos.numel(), plan.world
+        C = self.chunks if (self.chunks > 1 and B % self.chunks == 0) else 1
+        key = (B, n, C)
+        cap = self._cap.get(key)
+        if cap is None:
+            # calibration: exact per-(slice, owner) counts of the very draw this step routes (the generator is not
+            # advanced), largest over slices, owners and ranks
+            counts = be.sample_route(st, plan, self.rank, pos, n, C, 0, spec, self.sample_generator, neg=neg, count_only=True)
+            cap = self._capacity(key, int(counts.max()))
+        # the sampler's log-probabilities: BPRLoss ignores them (loss_func.py:55-59), everything else gets them
+        r = be.sample_route(st, plan, self.rank, pos, n, C, cap, spec, self.sample_generator, neg=neg,
+                            want_ids=want_ids, want_logp=want_logp and fused_loss != 'bpr')
+        stride, per = r['stride'], G * r['stride']
+        send = r['send']
+        scores_home = torch.empty(C * per, dtype=torch.float32, device=send.device)
+        recv_keys = []
+        if C == 1:
+            q_all = q_gather()
+            rk = self._all_to_all(send)
+            recv_keys.append(rk)
+            self._all_to_all(be.score_segments(st, self.item_local, q_all, rk, G, stride, first=True), out=scores_home)
+        else:
+            waits = [self._all_to_all_start(send[c * per:(c + 1) * per]) for c in range(C)]
+            q_all = q_gather()
+            back = []
+            for c, w in enumerate(waits):
+                rk = w()
+                recv_keys.append(rk)
+                sc = be.score_segments(st, self.item_local, q_all, rk, G, stride, first=c == 0)
+                back.append(self._all_to_all_start(sc, out=scores_home[c * per:(c + 1) * per]))
+            for w in back:
+                w()
+        if log_pos is None:
+            log_pos, log_neg = r.get('log_pos_prob'), r.get('log_neg_prob')
+        out = be.home(scores_home, r['slot_of'], B, n, loss=fused_loss, pos_logp=log_pos if fused_loss == 'ssm' else None,
+                      neg_logp=log_neg if fused_loss == 'ssm' else None, mean_den=mean_den, want_scores=want_scores,
+                      want_grad=want_grad, want_dsend=keep_route and fused_loss is not None)
+        self._after_fixed_step()
+        out['neg_ids'], out['log_pos_prob'], out['log_neg_prob'] = r.get('neg_ids'), log_pos, log_neg
+        if keep_route:
+            out['route'] = {'B': B, 'n': n, 'C': C, 'stride': stride, 'q_all': q_all, 'slot_of': r['slot_of'],
+                            'recv_keys': recv_keys, 'd_send': out.pop('d_send', None)}
+        return out
+
     def backward(self, route, dpos, dneg, item_grad_local, item_scale=None):
-        """Gradient exchange for one step.  ``route`` comes from
-        ``score_ids(..., keep_route=True)``; ``dpos [B]`` / ``dneg [B, n]`` = d loss / d score on the home
-        rank.  Accumulates this shard's dense item gradient into ``item_grad_local [rows_local, d]`` (no
-        communication: rows never leave their owner) and returns d loss / d q for the own queries [B, d]
-        (reduce-scatter of the per-owner partial sums)."""
+        """Gradient exchange for one step.  ``route`` comes from a forward with
+        ``keep_route=True``; ``dpos [B]`` / ``dneg [B, n]`` = d loss / d score on the home rank (None: the
+        routed-order gradient the fused loss of the forward left in the route).  Accumulates this shard's dense item
+        gradient into ``item_grad_local [rows_local, d]`` (no communication: rows never leave their owner) and returns
+        d loss / d q for the own queries [B, d] (reduce-scatter of the per-owner partial sums)."""
         B = route['B']
         q_all = route['q_all']
         qgrad_all = torch.zeros_like(q_all)
         # only shard 0 holds the global padding row (item id 0), which never receives gradient
         extra = {} if item_scale is None else {'item_scale': item_scale}
         pad_row = 0 if self.rank == 0 else -1
-        if 'slices' in route:
-            # pipelined step: all gradient exchanges are issued first, the owner-side scatters follow slice by slice
-            # (slice c's scatter runs while slice c+1's gradients are still on the wire)
-            dpos, dneg = dpos.reshape(-1), dneg.reshape(B, -1)
-            waits = []
-            for (b0, b1, positions, _) in route['slices']:
-                dflat = torch.cat([dpos[b0:b1], dneg[b0:b1].reshape(-1)])
-                waits.append(self._all_to_all_start(self.backend.gather(dflat, positions)))
-            for (_, _, _, recv_keys), wait in zip(route['slices'], waits):
-                self.backend.backward_keys(self.item_local, q_all, recv_keys, wait(), item_grad_local, qgrad_all,
-                                           item_pad_row=pad_row, **extra)
+        if 'slot_of' in route:
+            G, C, stride = self.plan.world, route['C'], route['stride']
+            per = G * stride
+            if dpos is None:
+                d_send = route['d_send']
+                if d_send is None:
+                    raise ValueError('backward(route, None, None): the forward did not evaluate a fused loss')
+            else:
+                d_send = self.backend.scatter_slots(dpos.reshape(-1), dneg.reshape(B, -1), route['slot_of'], C * per)
+            if C == 1:
+                self.backend.backward_segments(self.state, self.item_local, q_all, route['recv_keys'][0], G, stride,
+                                               self._all_to_all(d_send), item_grad_local, qgrad_all, item_pad_row=pad_row, **extra)
+            else:
+                # all gradient exchanges are issued first, the owner-side scatters follow slice by slice (slice c's
+                # scatter runs while slice c+1's gradients are still on the wire)
+                waits = [self._all_to_all_start(d_send[c * per:(c + 1) * per]) for c in range(C)]
+                for rk, w in zip(route['recv_keys'], waits):
+                    self.backend.backward_segments(self.state, self.item_local, q_all, rk, G, stride, w(), item_grad_local,
+                                                   qgrad_all, item_pad_row=pad_row, **extra)
             return self._reduce_scatter_rows(qgrad_all, B)
         dflat = torch.cat([dpos.reshape(-1), dneg.reshape(-1)])
-        d_sorted = self.backend.gather(dflat, route['positions'])           # empty slots: 0
-        d_owner = self._all_to_all(d_sorted, route.get('recv_counts'), route.get('send_counts'))
+        d_sorted = self.backend.gather(dflat, route['positions'])
+        d_owner = self._all_to_all(d_sorted, route['recv_counts'], route['send_counts'])
         self.backend.backward_keys(self.item_local, q_all, route['recv_keys'], d_owner, item_grad_local, qgrad_all,
                                    item_pad_row=pad_row, **extra)
         return self._reduce_scatter_rows(qgrad_all, B)
 
-    def _score_ids_pipelined(self, q_gather, pos, neg, keep_route):
-        """The fixed-capacity step cut into ``self.chunks`` query slices.  Issue order on the current stream:
-        route(0), route(1), ... (each followed by its asynchronous key all-to-all on the communicator's stream),
-        then per slice: wait for its keys, score, start the score all-to-all; finally per slice: wait, scatter home.
-        Collectives of one communicator run in issue order, so slice c's keys arrive while slice c-1 is being scored
-        and its scores go back while slice c+1 is being scored.  Every rank issues the same sequence."""
+    def _exact_step(self, q_gather, pos, neg, keep_route):
+        """Variable-split exchange: owner histogram, count exchange, host read-back, every step."""
         B, n = neg.shape
-        C = self.chunks
-        Bc = B // C
-        cap = self._cap[(Bc, n)]
-        bounds = [(c * Bc, (c + 1) * Bc) for c in range(C)]
-        routed = []
-        for b0, b1 in bounds:
-            keys, positions = self.backend.route_fixed(pos[b0:b1], neg[b0:b1], self.plan, self.rank * B + b0, cap,
-                                                       self._overflow)
-            routed.append((positions, self._all_to_all_start(keys)))
+        counts = self.backend.count(pos, neg, self.plan)
+        send_counts, recv_counts = self._exchange_counts(counts)
+        starts = torch.tensor([0] + send_counts[:-1], dtype=torch.int64).cumsum(0)
+        keys, positions = self.backend.route(pos, neg, self.plan, self.rank * B, starts)
+        recv_keys = self._all_to_all(keys, recv_counts, send_counts)
         q_all = q_gather()
-        scored = []
-        for positions, wait_keys in routed:
-            recv_keys = wait_keys()
-            scored.append((positions, recv_keys,
-                           self._all_to_all_start(self.backend.score_keys(self.item_local, q_all, recv_keys))))
-        pos_parts, neg_parts, slices = [], [], []
-        for (b0, b1), (positions, recv_keys, wait_scores) in zip(bounds, scored):
-            flat = self.backend.scatter(wait_scores(), positions, Bc * (n + 1))
-            pos_parts.append(flat[:Bc])
-            neg_parts.append(flat[Bc:].view(Bc, n))
-            slices.append((b0, b1, positions, recv_keys))
-        self._after_fixed_step()
-        pos_score, neg_score = torch.cat(pos_parts), torch.cat(neg_parts)
+        scores_owner = self.backend.score_keys(self.item_local, q_all, recv_keys)
+        scores_home = self._all_to_all(scores_owner, send_counts, recv_counts)
+        flat = self.backend.scatter(scores_home, positions, B * (n + 1))
+        out = {'pos_score': flat[:B], 'neg_score': flat[B:].view(B, n)}
         if keep_route:
-            return pos_score, neg_score, {'B': B, 'n': n, 'q_all': q_all, 'slices': slices}
-        return pos_score, neg_score
+            out['route'] = {'B': B, 'n': n, 'q_all': q_all, 'positions': positions, 'recv_keys': recv_keys,
+                            'send_counts': send_counts, 'recv_counts': recv_counts}
+        return out
 
     def score_ids(self, q, pos, neg, keep_route=False, q_gather=None):
         """q [B, d] own queries, pos [B], neg [B, n] GLOBAL item ids -> (pos_score [B], neg_score [B, n]).
         ``q_gather``: the wait function of an all-gather of ``q`` the caller has already started."""
-        B, n = neg.shape
-        plan = self.plan
         if q_gather is None:
             q_gather = self._all_gather_rows_start(q)
-        if self.exchange == 'fixed' and self.chunks > 1 and B % self.chunks == 0:
-            Bc = B // self.chunks
-            if (Bc, n) not in self._cap:
-                # capacity of a slice's owner segments: exact owner counts of slice 0, max over ranks, plus slack
-                send_counts, _ = self._exchange_counts(self.backend.count(pos[:Bc], neg[:Bc], plan))
-                self._calibrate((Bc, n), send_counts)
-            return self._score_ids_pipelined(q_gather, pos, neg, keep_route)
-        cap = self._cap.get((B, n)) if self.exchange == 'fixed' else None
-        route = {'B': B, 'n': n}
-        if cap is None:
-            # exact split sizes: owner histogram, count exchange, host read-back (every step with exchange='exact',
-            # the calibration step otherwise)
-            counts = self.backend.count(pos, neg, plan)
-            send_counts, recv_counts = self._exchange_counts(counts)
-            starts = torch.tensor([0] + send_counts[:-1], dtype=torch.int64).cumsum(0)
-            keys, positions = self.backend.route(pos, neg, plan, self.rank * B, starts)
-            recv_keys = self._all_to_all(keys, recv_counts, send_counts)
-            route.update(send_counts=send_counts, recv_counts=recv_counts)
-            if self.exchange == 'fixed':
-                self._calibrate((B, n), send_counts)
-            back = (send_counts, recv_counts)
+        if self.exchange == 'fixed':
+            out = self._fixed_step(q_gather, pos, neg.shape[1], None, neg=neg.contiguous(), keep_route=keep_route)
         else:
-            keys, positions = self.backend.route_fixed(pos, neg, plan, self.rank * B, cap, self._overflow)
-            recv_keys = self._all_to_all(keys)
-            back = (None, None)
-        q_all = q_gather()
-        scores_owner = self.backend.score_keys(self.item_local, q_all, recv_keys)
-        scores_home = self._all_to_all(scores_owner, *back)
-        flat = self.backend.scatter(scores_home, positions, B * (n + 1))
-        if cap is not None:
-            self._after_fixed_step()
+            out = self._exact_step(q_gather, pos, neg, keep_route)
         if keep_route:
-            route.update(q_all=q_all, positions=positions, recv_keys=recv_keys)
-            return flat[:B], flat[B:].view(B, n), route
-        return flat[:B], flat[B:].view(B, n)
+            return out['pos_score'], out['neg_score'], out['route']
+        return out['pos_score'], out['neg_score']
 
     def sample(self, sampler, n_queries, n, device, pos):
         """(log_pos_prob, neg_ids, log_neg_prob) for this rank's queries: its rows of the job-wide draw."""
         return self.backend.sample(sampler, n_queries, n, device, pos,
                                    shard=(self.rank, self.plan.world, self.sample_generator))
 
-    def sample_and_score(self, user_table, uid, pos, n, sampler, keep_route=False):
-        """BaseRetriever.forward for a user-embedding query tower against the sharded item table."""
-        B = uid.numel()
-        q = self.backend.gather_rows(user_table, uid)
+    def forward_queries(self, q, pos, n, sampler, keep_route=False, fused_loss=None, mean_den=None, want_ids=True,
+                        want_scores=True, want_grad=False):
+        """BaseRetriever.forward (+ optionally the loss) for the own query vectors ``q [B, d]`` against the sharded
+        table.  With one of this package's in-kernel samplers and the fixed exchange the negatives are drawn inside
+        the routing launch (``neg_ids`` only with ``want_ids``); any other Sampler plugin is called and its ids are
+        routed as given.  ``fused_loss`` ('bpr' | 'ssm', fixed exchange): the home kernel evaluates the loss --
+        ``loss`` = sum of the row losses / ``mean_den`` (default B) -- and, with ``keep_route``, leaves d loss/d score
+        in routed order in the route for ``backward(route, None, None, ...)``."""
+        B = pos.numel()
         q_gather = self._all_gather_rows_start(q)
-        log_pos, neg, log_neg = self.sample(sampler, B, n, uid.device, pos)
-        res = self.score_ids(q, pos, neg, keep_route, q_gather)
-        out = {'pos_score': res[0], 'neg_score': res[1], 'neg_ids': neg, 'log_pos_prob': log_pos,
-               'log_neg_prob': log_neg, 'query': q}
-        if keep_route:
-            out['route'] = res[2]
+        spec = self.backend.sampler_spec(sampler) if self.exchange == 'fixed' else None
+        if spec is not None:
+            out = self._fixed_step(q_gather, pos, n, spec, keep_route=keep_route, fused_loss=fused_loss, mean_den=mean_den,
+                                   want_ids=want_ids, want_scores=want_scores, want_grad=want_grad)
+            if out['log_neg_prob'] is None:          # UniformSampler: int64 zeros (sampler.py:113-114), cached constants
+                out['log_pos_prob'] = ops.zero_logp(pos.shape, pos.device)
+                out['log_neg_prob'] = ops.zero_logp((B, n), pos.device)
+        else:
+            log_pos, neg, log_neg = self.sample(sampler, B, n, q.device, pos)
+            if self.exchange == 'fixed':
+                lp = log_pos if log_pos is not None and log_pos.is_floating_point() else None
+                ln = log_neg if log_neg is not None and log_neg.is_floating_point() else None
+                out = self._fixed_step(q_gather, pos, n, None, neg=neg.contiguous(), keep_route=keep_route, fused_loss=fused_loss,
+                                       mean_den=mean_den, log_pos=lp, log_neg=ln, want_scores=want_scores, want_grad=want_grad)
+            else:
+                if fused_loss is not None:
+                    raise ValueError("fused_loss needs exchange='fixed'")
+                out = self._exact_step(q_gather, pos, neg, keep_route)
+            out['neg_ids'], out['log_pos_prob'], out['log_neg_prob'] = neg, log_pos, log_neg
+        out['query'] = q
         return out
+
+    def sample_and_score(self, user_table, uid, pos, n, sampler, keep_route=False, **kw):
+        """BaseRetriever.forward for a user-embedding query tower against the sharded item table (see
+        ``forward_queries`` for the keyword arguments)."""
+        return self.forward_queries(self.backend.gather_rows(user_table, uid), pos, n, sampler, keep_route=keep_route, **kw)
 
     # -- full-catalog pass (eval top-k / full softmax), sharded the same way --------------------------
     def _exchange_partials(self, x, B):
@@ -558,29 +743,42 @@ class ShardedRetriever:
     """Two-tower training step with the item table row-sharded over the ranks and the query tower replicated
     (data parallel).  ``query_encoder(batch_feat) -> [B, d]``; ``sampler`` / ``loss_fn`` are the usual plugins
     (Sampler / PairwiseLoss); the item block ``table.item_local`` and its gradient block are plain tensors
-    owned by this rank, updated by the caller's optimizer."""
+    owned by this rank, updated by the caller's optimizer.
+
+    Gradients of the query tower: by default autograd fills ``query_encoder``'s ``.grad`` and the ranks sum them with
+    a bucketed all-reduce, i.e. every replica ends up with the gradient a single process would compute on the
+    concatenated batch.  ``sparse_query_rows`` (see ``__init__``) replaces that for a plain ``nn.Embedding`` tower."""
 
     def __init__(self, table, query_encoder, sampler, loss_fn, neg_count, item_sgd_lr=None, sparse_query_rows=None,
-                 query_sgd_lr=None):
+                 query_sgd_lr=None, keep_neg_ids=False):
         """``item_sgd_lr``: apply plain SGD with this learning rate to the owned item rows INSIDE the backward
         exchange (sorted scatter straight into the weight block, no [rows_local, d] gradient buffer to zero, fill
         and add); the caller then only steps the query tower.
 
-        ``sparse_query_rows`` (default: True when ``query_encoder`` is a plain ``nn.Embedding``): the replicated
-        user table's gradient is row-sparse -- B rows per rank -- so the ranks exchange ``(ids, gradient rows)`` with
-        two all-gathers (B*(d+2)*4 bytes per rank: 2 MB at B = 4096, d = 128) instead of all-reducing the dense
+        ``sparse_query_rows`` (opt-in; default: on exactly when ``query_sgd_lr`` is given): the replicated user
+        table's gradient is row-sparse -- B rows per rank -- so the ranks exchange ``(ids, gradient rows)`` with two
+        all-gathers (B*(d+2)*4 bytes per rank: 2 MB at B = 4096, d = 128) instead of all-reducing the dense
         ``[n_users, d]`` gradient (512 MB at 1 M users) that autograd would build, zero and add every step.  After a
         step ``query_rows = (ids [G*B], rows [G*B, d])`` holds the gradient of the global mean loss, identical on
-        every rank; ``query_sgd_lr`` applies plain SGD with it in place (sorted, atomics-free: replicas stay bit-equal)."""
+        every rank, and ``query_encoder.weight.grad`` is NOT populated: the caller applies ``query_rows`` itself or
+        passes ``query_sgd_lr`` (plain SGD in place; sorted, atomics-free: replicas stay bit-equal).  The path reads
+        the weight rows directly, so Embedding options that act inside ``forward`` / ``backward`` are refused.
+
+        ``keep_neg_ids``: keep the step's sampled ids in ``last_neg`` (the fused step does not write them otherwise)."""
         self.table, self.query_encoder, self.sampler, self.loss_fn = table, query_encoder, sampler, loss_fn
         self.neg_count = int(neg_count)
         if sparse_query_rows is None:
-            sparse_query_rows = type(query_encoder) is torch.nn.Embedding
-        if sparse_query_rows and not isinstance(query_encoder, torch.nn.Embedding):
-            raise TypeError('sparse_query_rows needs an nn.Embedding query encoder')
+            sparse_query_rows = query_sgd_lr is not None
+        if sparse_query_rows:
+            if not isinstance(query_encoder, torch.nn.Embedding):
+                raise TypeError('sparse_query_rows needs an nn.Embedding query encoder')
+            if query_encoder.max_norm is not None or query_encoder.scale_grad_by_freq or query_encoder.sparse:
+                raise ValueError('sparse_query_rows reads the weight rows directly: max_norm / scale_grad_by_freq / '
+                                 'sparse=True are not honoured on this path')
         if query_sgd_lr is not None and not sparse_query_rows:
             raise ValueError('query_sgd_lr applies the row-sparse gradient: it needs sparse_query_rows')
         self.sparse_query_rows, self.query_sgd_lr, self.query_rows = bool(sparse_query_rows), query_sgd_lr, None
+        self.keep_neg_ids, self.last_neg = bool(keep_neg_ids), None
         self.item_scale = None
         if item_sgd_lr is None:
             self.item_grad_local = torch.zeros_like(table.item_local)
@@ -588,25 +786,54 @@ class ShardedRetriever:
             self.item_grad_local = table.item_local
             self.item_scale = torch.full((1,), -float(item_sgd_lr), dtype=torch.float32, device=table.item_local.device)
 
+    def _fused_loss_kind(self):
+        """'bpr' / 'ssm' when the loss can be evaluated by the home kernel of the fixed exchange (this package's stock
+        BPRLoss / SampledSoftmaxLoss, exact types), else None (the loss plugin runs under autograd)."""
+        from .loss_func import BPRLoss, SampledSoftmaxLoss
+        if self.table.exchange != 'fixed' or not hasattr(self.table.backend, 'home'):
+            return None
+        if type(self.loss_fn) is BPRLoss:
+            return 'bpr'
+        if type(self.loss_fn) is SampledSoftmaxLoss:
+            return 'ssm'
+        return None
+
     def training_step(self, query_feat, pos_items, label=None):
         """Returns this rank's share of the global mean loss (local mean / world size) after running backward:
-        ``item_grad_local`` holds the gradient of the GLOBAL mean loss for the rows this rank owns, and the
-        query tower's ``.grad`` is summed over ranks, i.e. every replica ends up with the same gradient a
-        single process would compute on the concatenated batch."""
+        ``item_grad_local`` holds the gradient of the GLOBAL mean loss for the rows this rank owns (or the rows have
+        been updated in place, ``item_sgd_lr``), and the query tower's gradient is the one a single process would
+        compute on the concatenated batch -- in ``.grad`` (summed over ranks), or in ``query_rows`` with
+        ``sparse_query_rows``."""
         table, world = self.table, self.table.plan.world
         if self.sparse_query_rows:
             weight = self.query_encoder.weight
-            q = table.backend.gather_rows(weight.detach(), query_feat).requires_grad_(True)
+            q = table.backend.gather_rows(weight.detach(), query_feat)
         else:
             q = self.query_encoder(query_feat)
         B = pos_items.numel()
-        log_pos, neg, log_neg = table.sample(self.sampler, B, self.neg_count, q.device, pos_items)
-        pos_score, neg_score = sharded_scores(table, q, pos_items, neg, self.item_grad_local, self.item_scale)
-        loss = self.loss_fn(label, pos_score, log_pos, neg_score, log_neg) / world
-        loss.backward()
+        kind = self._fused_loss_kind()
+        if kind is not None:
+            # forward + loss in the exchange's own kernels; d loss/d score leaves the home kernel in routed order
+            out = table.forward_queries(q.detach(), pos_items, self.neg_count, self.sampler, keep_route=True, fused_loss=kind,
+                                        mean_den=B * world, want_ids=self.keep_neg_ids, want_scores=False)
+            loss = out['loss']
+            dq = table.backward(out['route'], None, None, self.item_grad_local, self.item_scale)
+            self.last_neg = out['neg_ids']
+            if not self.sparse_query_rows:
+                q.backward(dq)
+        else:
+            if self.sparse_query_rows:
+                q.requires_grad_(True)
+            log_pos, neg, log_neg = table.sample(self.sampler, B, self.neg_count, q.device, pos_items)
+            pos_score, neg_score = sharded_scores(table, q, pos_items, neg, self.item_grad_local, self.item_scale)
+            loss = self.loss_fn(label, pos_score, log_pos, neg_score, log_neg) / world
+            loss.backward()
+            dq = q.grad if self.sparse_query_rows else None
+            self.last_neg = neg
+            loss = loss.detach()
         if self.sparse_query_rows:
             ids_all = table._all_gather_rows(query_feat.reshape(-1).contiguous())
-            rows_all = table._all_gather_rows(q.grad)
+            rows_all = table._all_gather_rows(dq)
             pad = self.query_encoder.padding_idx
             self.query_rows = (ids_all, rows_all)
             if self.query_sgd_lr is not None:
@@ -614,8 +841,7 @@ class ShardedRetriever:
                                          pad_row=-1 if pad is None else int(pad))
         else:
             allreduce_grads(self.query_encoder.parameters(), table.dist, table.group)
-        self.last_neg = neg
-        return loss.detach()
+        return loss
 
     def query_grad_dense(self):
         """The row-sparse query-table gradient of the last step as a dense ``[n_users, d]`` tensor (tests, small

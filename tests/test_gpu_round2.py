@@ -434,11 +434,12 @@ def test_config2_sasrec_d128_L50_ssm_n256_training_step(ra, golden):
 
 def test_config3_per_gpu_shape_properties(ra):
     """configs[3] at the per-GPU shape of an 8-way shard: 12.5 M-row block (6.4 GB), n = 1024, B = 4096.
-    Sampled ids bit-exact vs torch.randint over the GLOBAL id range, fixed-capacity routing to 8 owners without
-    overflow at the default slack, packed-key scoring on the block spot-checked against gathered rows, score
-    round trip through scatter."""
+    The negatives drawn INSIDE the routing launch are bit-exact vs torch.randint over the GLOBAL id range (this rank's
+    rows of the job-wide call), every element lands once in its owner's fixed-capacity segment without overflow at the
+    default slack, the segment form of the scoring kernel on the block is spot-checked against gathered rows, and the
+    scores find their way home through the slots (BPR loss of the home kernel == the stand-alone loss kernel)."""
     from recstudio_amd.shard import HipBackend, RowShardPlan
-    n_global, world, B, n, d = 100_000_001, 8, 4096, 1024, 128
+    n_global, world, B, n, d, rank = 100_000_001, 8, 4096, 1024, 128, 3
     plan = RowShardPlan(n_global, world)
     rows = plan.rows_per_shard
     assert rows == 12_500_001
@@ -446,37 +447,56 @@ def test_config3_per_gpu_shape_properties(ra):
     block = torch.empty(rows, d, device=DEV).normal_(0, 0.02, generator=gen)
     q_all = torch.empty(world * B, d, device=DEV).normal_(0, 0.02, generator=gen)
     pos = torch.randint(1, n_global, (B,), device=DEV, generator=gen)
-    torch.manual_seed(31)
-    want = torch.randint(1, n_global, (B, n), device=DEV)
-    torch.manual_seed(31)
-    lp, neg, lnp = ra.UniformSampler(n_global)(torch.empty(B, 1, device=DEV), n, pos)
-    assert torch.equal(neg, want) and lnp.dtype == torch.int64
     hb = HipBackend()
-    counts = hb.count(pos, neg, plan).cpu().long()
-    assert int(counts.sum()) == B * (n + 1)
-    assert torch.equal(counts, torch.bincount(plan.owner(torch.cat([pos.view(-1, 1), neg], 1).reshape(-1)).cpu(), minlength=world))
+    st = hb.new_state(DEV)
+    spec = hb.sampler_spec(ra.UniformSampler(n_global))
+    g1 = torch.Generator(device=DEV).manual_seed(31)
+    counts = hb.sample_route(st, plan, rank, pos, n, 1, 0, spec, g1, count_only=True).cpu().long()
+    assert g1.get_offset() == 0 and int(counts.sum()) == B * (n + 1)
     cap = (int(counts.max() * 1.08) + 4096 + 255) // 256 * 256
-    flag = hb.new_flag(DEV)
-    keys, positions = hb.route_fixed(pos, neg, plan, 3 * B, cap, flag)
-    assert int(flag.item()) == 0 and int((keys >= 0).sum()) == B * (n + 1)
-    for o in (0, 5, 7):                              # segment o holds exactly the elements owned by o
-        seg = keys[o * cap:(o + 1) * cap]
-        assert int((seg >= 0).sum()) == int(counts[o])
-    # owner side: this rank plays owner 5 (rows [5 * rows, 6 * rows)) and scores its segment against q_all
-    seg = keys[5 * cap:6 * cap].contiguous()
-    sc = hb.score_keys(block, q_all, seg)
-    live = torch.nonzero(seg >= 0).flatten()
-    pick = live[torch.randint(0, live.numel(), (2000,), device=DEV)]
+    r = hb.sample_route(st, plan, rank, pos, n, 1, cap, spec, g1, want_ids=True)
+    # the ids: rows [rank*B, (rank+1)*B) of ONE torch.randint call over [world*B, n] from the same generator state
+    g2 = torch.Generator(device=DEV).manual_seed(31)
+    want = torch.randint(1, n_global, (world * B, n), device=DEV, generator=g2)[rank * B:(rank + 1) * B]
+    assert torch.equal(r['neg_ids'], want) and g1.get_offset() == g2.get_offset()
+    ids_flat = torch.cat([pos.view(-1, 1), r['neg_ids']], 1).reshape(-1)
+    assert torch.equal(counts, torch.bincount(plan.owner(ids_flat).cpu(), minlength=world))
+    stride = r['stride']
+    assert stride == cap + hb.HDR
+    send, slot_of = r['send'].view(world, stride), r['slot_of'].long()
+    assert torch.equal(send[:, 0].cpu(), counts) and int(send[:, 1].sum()) == 0        # headers: live counts, nothing dropped
+    assert (slot_of >= 0).all() and slot_of.unique().numel() == B * (n + 1)
+    keys = r['send'][slot_of]
+    assert torch.equal(keys & 0xffffffff, ids_flat % rows) and torch.equal(slot_of // stride, ids_flat // rows)
+    assert torch.equal(keys >> 32, (rank * B + torch.arange(B, device=DEV)).repeat_interleave(n + 1))
+    # owner side: this rank plays owner 5 (rows [5 * rows, 6 * rows)); as if all 8 sources had sent this same segment
+    seg = send[5].contiguous()
+    recv = seg.repeat(world)
+    flags = hb.new_state(DEV)
+    sc = hb.score_segments(flags, block, q_all, recv, world, stride).view(world, stride)
+    assert int(flags['step_dropped']) == 0 and int(flags['overflow']) == 0
+    live = int(counts[5])
+    pick = hb.HDR + torch.randint(0, live, (2000,), device=DEV)
     k = seg[pick]
     ref = (block[k & 0xffffffff] * q_all[k >> 32]).sum(-1)
-    rel_close(sc[pick].cpu(), ref.cpu(), rtol=1e-4, atol=1e-7)
-    assert (sc[seg < 0] == 0).all() and int((k >> 32).min()) >= 3 * B and int((k >> 32).max()) < 4 * B
-    # home side: scores of all owners scattered back land on the element they belong to
-    fake = (keys & 0xffffffff).float()               # stand-in score = local row number
-    home = hb.scatter(fake, positions, B * (n + 1))
-    ids_flat = torch.cat([pos.view(-1, 1), neg], 1)
-    want_home = torch.cat([ids_flat[:, 0], ids_flat[:, 1:].reshape(-1)]) % rows
-    assert torch.equal(home.long(), want_home.float().long())
+    rel_close(sc[0][pick].cpu(), ref.cpu(), rtol=1e-4, atol=1e-7)
+    assert torch.equal(sc[0][hb.HDR:hb.HDR + live], sc[7][hb.HDR:hb.HDR + live])
+    # home side: stand-in scores (local row number, exact in fp32 below 2^24) come home through the slots; the fused
+    # BPR loss + gradients == the stand-alone loss kernel on the gathered scores
+    fake = (r['send'] & 0xffffffff).float()
+    out = hb.home(fake, r['slot_of'], B, n)
+    want_home = (ids_flat % rows).view(B, n + 1).float()
+    assert torch.equal(out['pos_score'], want_home[:, 0]) and torch.equal(out['neg_score'], want_home[:, 1:])
+    sc_rand = torch.randn(world * stride, device=DEV)
+    o1 = hb.home(sc_rand, r['slot_of'], B, n)
+    o2 = hb.home(sc_rand, r['slot_of'], B, n, loss='bpr', want_grad=True, want_dsend=True)
+    loss, dpos, dneg, _ = ra.ops.pairwise_loss(ra._native.LOSS_BPR, o1['pos_score'], o1['neg_score'])
+    rel_close(o2['loss'].cpu(), loss.cpu(), rtol=1e-5)
+    rel_close(o2['dneg'].cpu(), dneg.cpu(), rtol=1e-4, atol=1e-12)
+    rel_close(o2['dpos'].cpu(), dpos.cpu(), rtol=1e-4, atol=1e-12)
+    d_flat = torch.cat([o2['dpos'].view(-1, 1), o2['dneg']], 1).reshape(-1)
+    assert torch.equal(o2['d_send'][slot_of], d_flat)
+    assert torch.equal(hb.scatter_slots(o2['dpos'], o2['dneg'], r['slot_of'], world * stride)[slot_of], d_flat)
 
 
 def test_softmax_loss_second_branch_golden(ra, golden):

@@ -41,59 +41,99 @@ def test_route_kernels_match_checker(world, B, n):
     assert torch.equal(out[positions], src)
 
 
-@pytest.mark.parametrize('world,B,n,cap_frac', [(4, 33, 7, 2.0), (8, 1000, 64, 1.1), (2, 5, 1, 1.0), (3, 17, 100, 0.5)])
-def test_route_fixed_kernel_matches_checker(world, B, n, cap_frac):
-    """rsa_shard_route_fixed: every owner segment holds the same multiset of (key, position) pairs as the checker's
-    (order inside a segment is free), unused slots are -1, elements beyond the capacity are dropped AND counted; the
-    consumers skip the empty slots (score 0, nothing scattered, zero gathered, unpack -> -1)."""
+@pytest.mark.parametrize('world,B,n,chunks,cap_frac', [(4, 33, 7, 1, 2.0), (8, 1000, 64, 1, 1.1), (2, 6, 1, 2, 1.0),
+                                                       (3, 16, 100, 4, 0.5), (1, 64, 64, 1, 0.7)])
+def test_sample_route_kernel_matches_checker(world, B, n, chunks, cap_frac):
+    """rsa_shard_sample_route on given ids: every (slice, owner) segment holds the same multiset of keys as the
+    checker's (order inside a segment is free), its header says how many are live and how many elements the rank
+    dropped in the whole step; slot_of points every kept element at its own key and is -1 for a dropped one; the exact
+    counts of the count-only mode are the checker's.  Then the consumers of such segments: the segment form of the
+    scoring kernel, the unpack kernel, the home kernel (scores, BPR / SampledSoftmax with dropped elements left out,
+    routed-order gradient) against the checker."""
     from recstudio_amd import _native as nat
     from recstudio_amd.shard import HipBackend, RowShardPlan
     from recstudio_amd._native import ptr
     import recstudio_amd as ra
-    n_items = 10007
+    n_items, rank = 10007, 1 if world > 1 else 0
     plan = RowShardPlan(n_items, world)
     g = torch.Generator().manual_seed(B + n)
     pos = torch.randint(0, n_items, (B,), generator=g)
     neg = torch.randint(0, n_items, (B, n), generator=g)
     hb, cb = HipBackend(), CheckerBackend()
-    counts = cb.count(pos, neg, plan)
-    cap = max(1, int(B * (n + 1) / world * cap_frac))
-    flag = hb.new_flag(DEV)
-    keys, positions = hb.route_fixed(pos.to(DEV), neg.to(DEV), plan, 1000, cap, flag)
-    wflag = cb.new_flag(None)
-    wkeys, wpos = cb.route_fixed(pos, neg, plan, 1000, cap, wflag)
-    keys, positions = keys.cpu(), positions.cpu()
-    assert int(flag.item()) == int(wflag.item()) == int((counts.long() - cap).clamp(min=0).sum())
-    for o in range(world):
-        seg = slice(o * cap, (o + 1) * cap)
-        kept = min(cap, int(counts[o]))
-        got = sorted(zip(keys[seg].tolist(), positions[seg].tolist()))
-        assert got[:cap - kept] == [(-1, -1)] * (cap - kept)
-        if kept == int(counts[o]):                       # no overflow: exactly the checker's pairs
-            assert got == sorted(zip(wkeys[seg].tolist(), wpos[seg].tolist()))
-        else:                                            # overflow: a subset of this owner's pairs, all distinct
-            fk, fp = cb.route(pos, neg, plan, 1000, None)
-            full = set(zip(fk.tolist(), fp.tolist()))
-            live = [p for p in got if p[0] >= 0]
-            assert len(set(live)) == kept and set(live) <= full
-    # consumers of a buffer with empty slots
+    st, wst = hb.new_state(DEV), cb.new_state(None)
+    counts = hb.sample_route(st, plan, rank, pos.to(DEV), n, chunks, 0, None, None, neg=neg.to(DEV), count_only=True).cpu()
+    wcounts = cb.sample_route(wst, plan, rank, pos, n, chunks, 0, None, None, neg=neg, count_only=True)
+    assert torch.equal(counts, wcounts)
+    cap = max(1, int((B // chunks) * (n + 1) / world * cap_frac))
+    r = hb.sample_route(st, plan, rank, pos.to(DEV), n, chunks, cap, None, None, neg=neg.to(DEV))
+    w = cb.sample_route(wst, plan, rank, pos, n, chunks, cap, None, None, neg=neg)
+    stride, segs = r['stride'], chunks * world
+    assert stride == w['stride'] == cap + hb.HDR
+    send, slot_of = r['send'].cpu().view(segs, stride), r['slot_of'].cpu().long()
+    wsend, wslot = w['send'].view(segs, stride), w['slot_of'].long()
+    dropped = int((counts.long() - cap).clamp(min=0).sum())
+    assert torch.equal(send[:, 0], counts.long().clamp(max=cap)) and torch.equal(send[:, 0], wsend[:, 0])
+    assert (send[:, 1] == dropped).all() and (wsend[:, 1] == dropped).all()
+    for sgm in range(segs):
+        live = int(send[sgm, 0])
+        got = sorted(send[sgm, hb.HDR:hb.HDR + live].tolist())
+        if int(counts[sgm]) <= cap:                   # no overflow here: exactly the checker's keys
+            assert got == sorted(wsend[sgm, hb.HDR:hb.HDR + live].tolist())
+    kept = slot_of >= 0
+    assert int((~kept).sum()) == dropped == int((wslot < 0).sum())
+    assert slot_of[kept].unique().numel() == int(kept.sum())
+    ids_flat = torch.cat([pos.view(-1, 1), neg], 1).reshape(-1)
+    m = torch.arange(B).repeat_interleave(n + 1)
+    want_key = ((rank * B + m) << 32) | (ids_flat - plan.owner(ids_flat) * plan.rows_per_shard)
+    assert torch.equal(r['send'].cpu()[slot_of[kept]], want_key[kept])
+    seg_of = (m // (B // chunks)) * world + plan.owner(ids_flat)
+    assert torch.equal(slot_of[kept] // stride, seg_of[kept])
+    # the cursors reset themselves: a second launch gives the same headers
+    r2 = hb.sample_route(st, plan, rank, pos.to(DEV), n, chunks, cap, None, None, neg=neg.to(DEV))
+    assert torch.equal(r2['send'].cpu().view(segs, stride)[:, :2], send[:, :2])
+    # ---- consumers.  Owner side: the received buffer of one slice = its `world` segments
     item = torch.randn(plan.rows_per_shard, 64, device=DEV)
-    q_all = torch.randn(1000 + B, 64, device=DEV)
-    kd = keys.to(DEV)
-    sc = hb.score_keys(item, q_all, kd).cpu()
-    want = cb.score_keys(item.cpu(), q_all.cpu(), keys)
-    np.testing.assert_allclose(sc, want, rtol=1e-4, atol=1e-5)
-    assert (sc[keys < 0] == 0).all()
-    rows = torch.empty_like(kd)
-    qidx = torch.empty_like(kd)
-    nat.check(nat.lib().rsa_shard_unpack(ptr(kd), kd.numel(), ptr(rows), ptr(qidx), ra.ops._stream()), 'unpack')
-    assert ((rows.cpu() < 0) == (keys < 0)).all() and ((qidx.cpu() < 0) == (keys < 0)).all()
-    src = torch.randn(keys.numel())
-    out = hb.scatter(src.to(DEV), positions.to(DEV), B * (n + 1)).cpu()
-    live = positions >= 0
-    assert torch.equal(out[positions[live]], src[live])
-    back = hb.gather(out.to(DEV), positions.to(DEV)).cpu()
-    assert torch.equal(back[live], src[live]) and (back[~live] == 0).all()
+    q_all = torch.randn(rank * B + B, 64, device=DEV)
+    per = world * stride
+    fl, wfl = hb.new_state(DEV), cb.new_state(None)
+    kd = r['send'][:per].contiguous()
+    sc = hb.score_segments(fl, item, q_all, kd, world, stride).cpu()
+    want = cb.score_segments(wfl, item.cpu(), q_all.cpu(), kd.cpu(), world, stride)
+    livem = cb._live(kd.cpu(), world, stride)
+    np.testing.assert_allclose(sc[livem], want[livem], rtol=1e-4, atol=1e-5)
+    assert int(fl['step_dropped']) == int(wfl['step_dropped']) == world * dropped == int(fl['overflow'])
+    rows, qidx = torch.empty_like(kd), torch.empty_like(kd)
+    scale = torch.full((2,), 7.0, device=DEV)
+    lr = torch.tensor([-0.25], device=DEV)
+    nat.check(nat.lib().rsa_shard_unpack_segments(ptr(kd), world, stride, ptr(rows), ptr(qidx), ptr(lr), ptr(fl['step_dropped']),
+                                                  ptr(scale), ra.ops._stream()), 'unpack')
+    assert ((rows.cpu() < 0) == ~livem).all() and ((qidx.cpu() < 0) == ~livem).all()
+    assert torch.equal(rows.cpu()[livem], kd.cpu()[livem] & 0xffffffff) and torch.equal(qidx.cpu()[livem], kd.cpu()[livem] >> 32)
+    assert scale.tolist() == ([0.0, 0.0] if dropped else [-0.25, 1.0])
+    # Home side: stand-in scores in the geometry of the send buffer
+    sc_home = torch.randn(segs * stride, generator=g)
+    lpp, lnp = torch.randn(B, generator=g), torch.randn(B, n, generator=g)
+    o = hb.home(sc_home.to(DEV), r['slot_of'], B, n)
+    so = slot_of.view(B, n + 1)
+    wsc = torch.where(so >= 0, sc_home[so.clamp(min=0)], torch.zeros(()))
+    assert torch.equal(o['pos_score'].cpu(), wsc[:, 0]) and torch.equal(o['neg_score'].cpu(), wsc[:, 1:])
+    for loss in ('bpr', 'ssm'):
+        kw = dict(loss=loss, pos_logp=lpp if loss == 'ssm' else None, neg_logp=lnp if loss == 'ssm' else None, mean_den=3 * B,
+                  want_grad=True, want_dsend=True)
+        got = hb.home(sc_home.to(DEV), r['slot_of'], B, n, **{k: (v.to(DEV) if isinstance(v, torch.Tensor) else v) for k, v in kw.items()})
+        ref = cb.home(sc_home, r['slot_of'].cpu(), B, n, **kw)
+        np.testing.assert_allclose(got['loss'].cpu(), ref['loss'], rtol=2e-5, atol=1e-7)
+        np.testing.assert_allclose(got['row_loss'].cpu(), ref['row_loss'], rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(got['dpos'].cpu(), ref['dpos'], rtol=1e-4, atol=1e-8)
+        np.testing.assert_allclose(got['dneg'].cpu(), ref['dneg'], rtol=1e-4, atol=1e-8)
+        ds, wds = got['d_send'].cpu(), ref['d_send']
+        assert torch.equal(torch.isnan(wds), ~torch.zeros_like(wds, dtype=torch.bool).index_fill_(0, slot_of[kept], True))
+        np.testing.assert_allclose(ds[slot_of[kept]], wds[slot_of[kept]], rtol=1e-4, atol=1e-8)
+        # a dropped element sends nothing and has zero gradient; a query whose positive was dropped leaves the step
+        dflat = torch.cat([got['dpos'].cpu().view(-1, 1), got['dneg'].cpu()], 1).reshape(-1)
+        assert not dflat[~kept].any()
+        gone = so[:, 0] < 0
+        assert not got['row_loss'].cpu()[gone].any() and not got['dneg'].cpu()[gone].any()
 
 
 def test_sorted_scatter_drops_negative_ids():
@@ -172,7 +212,7 @@ def _check_pipelined_equals_whole(ra, ShardedItemTable, make_table, user, uid, p
             b = piped.sample_and_score(user, uid, pos, n, sampler, keep_route=True)
             assert torch.equal(a['neg_ids'], b['neg_ids'])
             assert torch.equal(a['pos_score'], b['pos_score']) and torch.equal(a['neg_score'], b['neg_score'])
-            assert len(b['route']['slices']) == chunks and (B // chunks, n) in piped._cap
+            assert b['route']['C'] == chunks and len(b['route']['recv_keys']) == chunks and (B, n, chunks) in piped._cap
             _, dpos, dneg, _ = ra.ops.pairwise_loss(ra._native.LOSS_BPR, a['pos_score'], a['neg_score'])
             ga, gb = torch.zeros(rows, d, device=dev), torch.zeros(rows, d, device=dev)
             qa = whole.backward(a['route'], dpos, dneg, ga)
@@ -222,7 +262,7 @@ def _two_rank_worker(rank, world, port, backend, result_dir):
             table = ShardedItemTable(item_d[lo:hi].contiguous(), plan, rank, comm, sample_seed=17 + si)
             for step in range(3):                       # step 0: exact split + calibration; 1, 2: fixed capacity
                 out = table.sample_and_score(user, uid, pos, n, sampler, keep_route=True)
-                assert ('send_counts' in out['route']) == (step == 0)
+                assert 'send_counts' not in out['route'] and (B, n, 1) in table._cap      # fixed exchange from the first step on
                 ids = out['neg_ids']
                 want_p, want_n = oracle.retriever_forward(item, user.cpu()[uid.cpu()], pos.cpu(), ids.cpu())
                 np.testing.assert_allclose(out['neg_score'].cpu(), want_n, rtol=1e-4, atol=1e-6)
@@ -262,7 +302,8 @@ def _two_rank_worker(rank, world, port, backend, result_dir):
         with torch.no_grad():
             tower.weight.copy_(user)
         tbl = ShardedItemTable(item_d[lo:hi].clone(), plan, rank, comm)
-        trainer = ShardedRetriever(tbl, tower, ra.UniformSampler(N), ra.BPRLoss(), 64, item_sgd_lr=0.5)
+        trainer = ShardedRetriever(tbl, tower, ra.UniformSampler(N), ra.BPRLoss(), 64, item_sgd_lr=0.5, sparse_query_rows=True)
+        assert trainer._fused_loss_kind() == 'bpr'           # loss + routed-order gradient inside the home kernel
         l0 = trainer.training_step(uid, pos)
         tot = sum_cpu(l0.detach().reshape(1))
         assert abs(float(tot) - 0.6931) < 0.05 and tower.weight.grad is None       # nn.Embedding tower: row-sparse gradient
@@ -425,7 +466,7 @@ def test_world1_rccl_sharded_training_step():
         uid = torch.randint(1, U, (B,), device=DEV)
         pos = torch.randint(1, N, (B,), device=DEV)
         table = ShardedItemTable(item, RowShardPlan(N, 1), 0, dist)
-        trainer = ShardedRetriever(table, tower, ra.UniformSampler(N), ra.BPRLoss(), n)
+        trainer = ShardedRetriever(table, tower, ra.UniformSampler(N), ra.BPRLoss(), n, sparse_query_rows=True, keep_neg_ids=True)
         loss = trainer.training_step(uid, pos)
         neg = trainer.last_neg
         item_ref = item.clone().requires_grad_(True)
@@ -444,9 +485,23 @@ def test_world1_rccl_sharded_training_step():
         # the dense (autograd + all-reduce) path on request
         tower.weight.grad = None
         table_d = ShardedItemTable(item, RowShardPlan(N, 1), 0, dist)
-        dense = ShardedRetriever(table_d, tower, ra.UniformSampler(N), ra.BPRLoss(), n, sparse_query_rows=False)
+        dense = ShardedRetriever(table_d, tower, ra.UniformSampler(N), ra.BPRLoss(), n)
+        assert not dense.sparse_query_rows                   # the default: autograd fills .grad, summed over the ranks
+        torch.manual_seed(77)
         dense.training_step(uid, pos)
-        np.testing.assert_allclose(tower.weight.grad.cpu(), w_ref.grad.cpu(), rtol=2e-4, atol=1e-7)
+        g_fused = tower.weight.grad.clone()
+        assert torch.isfinite(g_fused).all() and g_fused.abs().sum() > 0
+        # a loss plugin the home kernel does not know runs under autograd over the exchanged scores: same negatives
+        # (same job-wide stream state), same gradient for the same loss
+        class MyBPR(ra.BPRLoss):
+            pass
+        tower.weight.grad = None
+        table_p = ShardedItemTable(item, RowShardPlan(N, 1), 0, dist)
+        plug = ShardedRetriever(table_p, tower, ra.UniformSampler(N), MyBPR(), n)
+        assert plug._fused_loss_kind() is None
+        plug.training_step(uid, pos)
+        np.testing.assert_allclose(tower.weight.grad.cpu(), g_fused.cpu(), rtol=2e-4, atol=1e-8)
+        np.testing.assert_allclose(plug.item_grad_local.cpu(), dense.item_grad_local.cpu(), rtol=2e-4, atol=1e-8)
     finally:
         dist.destroy_process_group()
 
@@ -486,12 +541,54 @@ def test_world1_rccl_inplace_item_sgd_equals_dense_gradient_step():
             with torch.no_grad():
                 tower.weight.copy_(torch.linspace(-1, 1, U * d, device=DEV).view(U, d))
             table = ShardedItemTable(item, RowShardPlan(N, 1), 0, dist)
-            trainer = ShardedRetriever(table, tower, ra.UniformSampler(N), ra.BPRLoss(), n, item_sgd_lr=lr if inplace else None)
+            trainer = ShardedRetriever(table, tower, ra.UniformSampler(N), ra.BPRLoss(), n, item_sgd_lr=lr if inplace else None,
+                                       sparse_query_rows=True)
             torch.manual_seed(99)
             trainer.training_step(uid, pos)
             results.append(item if inplace else item - lr * trainer.item_grad_local)
             results.append(trainer.query_grad_dense())
         np.testing.assert_allclose(results[2].cpu(), results[0].cpu(), rtol=1e-5, atol=1e-7)
         np.testing.assert_allclose(results[3].cpu(), results[1].cpu(), rtol=1e-5, atol=1e-7)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world1_rccl_overflow_step_is_harmless():
+    """A step whose ids outgrow the calibrated capacity: the dropped elements have no score, no
+    loss term and no gradient -- the loss stays finite -- and because every rank learns from the segment headers that
+    something was dropped, the step's in-place SGD updates (item rows AND user rows) are scaled by 0 on the device:
+    the weights are bit-identical afterwards.  The sticky count then makes check_overflow raise, and the next step
+    recalibrates and trains again."""
+    import torch.distributed as dist
+    import recstudio_amd as ra
+    from recstudio_amd.shard import RowShardPlan, ShardedItemTable, ShardedRetriever
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(_free_port())
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+    try:
+        torch.manual_seed(5)
+        N, U, d, B, n = 20_011, 300, 128, 256, 64
+        item = torch.randn(N, d, device=DEV) * 0.2
+        item[0] = 0
+        tower = torch.nn.Embedding(U, d).to(DEV)
+        uid = torch.randint(1, U, (B,), device=DEV)
+        pos = torch.randint(1, N, (B,), device=DEV)
+        for loss_fn in (ra.BPRLoss(), ra.SampledSoftmaxLoss()):
+            table = ShardedItemTable(item, RowShardPlan(N, 1), 0, dist, check_every=0)
+            trainer = ShardedRetriever(table, tower, ra.UniformSampler(N), loss_fn, n, item_sgd_lr=0.3, query_sgd_lr=0.3)
+            l0 = trainer.training_step(uid, pos)                           # calibrates, trains
+            assert torch.isfinite(l0) and int(table.state['step_dropped']) == 0
+            key = (B, n, 1)
+            table._cap[key] = table._cap[key] // 2                         # force an overflow: half the elements fit
+            w_item, w_user = item.clone(), tower.weight.detach().clone()
+            l1 = trainer.training_step(uid, pos)
+            assert torch.isfinite(l1) and float(l1) > 0
+            assert int(table.state['step_dropped']) == B * (n + 1) - table._cap[key]
+            assert torch.equal(item, w_item) and torch.equal(tower.weight.detach(), w_user)      # untouched
+            with pytest.raises(RuntimeError, match='did not fit'):
+                table.check_overflow()
+            l2 = trainer.training_step(uid, pos)                           # recalibrated: a normal step again
+            assert int(table.state['step_dropped']) == 0 and not torch.equal(item, w_item)
+            table.check_overflow()
     finally:
         dist.destroy_process_group()

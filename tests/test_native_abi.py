@@ -35,7 +35,7 @@ def test_header_symbols_all_exported(nat):
 
 def test_abi_version_and_error_channel(nat):
     lib = nat.lib()
-    assert lib.rsa_abi_version() == nat.ABI_VERSION == 4
+    assert lib.rsa_abi_version() == nat.ABI_VERSION == 5
     assert lib.rsa_scratch_bytes() >= 256 + 4 * 2048
     # argument validation happens before any HIP call, so it can be exercised without a GPU
     rc = lib.rsa_sample_uniform(None, 10, 1, 5, 0, 0, 256, 0, None)
@@ -58,7 +58,9 @@ def test_struct_layout_matches_header(nat, tmp_path):
     hdr = open(HEADER).read()
     prog = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{HEADER}"', 'int main(void) {']
     fields = {}
-    for struct, cls in (('rsa_fused_args', nat.FusedArgs), ('rsa_backward_args', nat.BackwardArgs)):
+    structs = (('rsa_fused_args', nat.FusedArgs), ('rsa_backward_args', nat.BackwardArgs),
+               ('rsa_shard_route_args', nat.ShardRouteArgs), ('rsa_shard_home_args', nat.ShardHomeArgs))
+    for struct, cls in structs:
         body = hdr[hdr.index(f'typedef struct {struct} {{'):hdr.index(f'}} {struct};')]
         body = re.sub(r'/\*.*?\*/', '', body, flags=re.S)
         names = []
@@ -79,7 +81,7 @@ def test_struct_layout_matches_header(nat, tmp_path):
     exe = tmp_path / 'layout'
     subprocess.run(['gcc', '-std=c99', '-o', str(exe), str(src)], check=True)
     out = dict(line.split() for line in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.splitlines())
-    for struct, cls in (('rsa_fused_args', nat.FusedArgs), ('rsa_backward_args', nat.BackwardArgs)):
+    for struct, cls in structs:
         assert ctypes.sizeof(cls) == int(out[struct])
         for n in fields[struct]:
             assert getattr(cls, n).offset == int(out[f'{struct}.{n}']), f'{struct}.{n}'
