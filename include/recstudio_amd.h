@@ -454,7 +454,8 @@ typedef struct rsa_shard_route_args {
   int64_t n_queries;
   int32_t num_neg;
   int32_t sampler;             /* rsa_sampler_kind */
-  int32_t n_slices;            /* pipelined query slices (>= 1, divides n_queries): slice c = queries [c*B/C, (c+1)*B/C) */
+  int32_t n_slices;            /* pipelined slices (>= 1): slice c = the c-th of n_slices contiguous ranges of the launch's
+                                  workgroups -- an arbitrary, run-independent partition of the step's elements */
   int32_t n_shards;            /* G <= 64 */
   int64_t rows_per_shard;      /* owner(id) = min(id / rows_per_shard, G - 1) */
   int64_t query_base;          /* global index of query 0 (rank * n_queries): goes into the keys */
@@ -475,7 +476,8 @@ typedef struct rsa_shard_route_args {
   int64_t* send_keys;          /* [n_slices][n_shards][RSA_SHARD_HDR + capacity] out; key = (query_base + query) << 32 | local row.
                                   NULL: count only (nothing is sampled into the outputs, only counts_out is written) */
   int32_t* slot_of;            /* [n_queries * (1 + num_neg)] out, element e = query * (1 + num_neg) + column */
-  int32_t* cursors;            /* [n_slices * n_shards + 1] device scratch, zeroed ONCE by the caller (self-resetting) */
+  int32_t* cursors;            /* [(n_slices * n_shards + 1) * 32] device scratch (one 128-byte line per cursor), zeroed
+                                  ONCE by the caller (self-resetting) */
   int32_t* counts_out;         /* nullable [n_slices * n_shards]: exact element counts per (slice, owner) -- calibration */
 } rsa_shard_route_args;
 int64_t rsa_shard_segment_stride(int64_t capacity);    /* RSA_SHARD_HDR + capacity: 8-byte words per segment */

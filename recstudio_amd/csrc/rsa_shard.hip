@@ -213,6 +213,20 @@ struct PopTables {
   int32_t guide_log2, lines_log2;
 };
 
+// Which elements a workgroup routes is free (an element only needs SOME slot in its owner's segment), so the
+// enumeration follows the random stream instead of the id matrix: torch's element li of a distribution call over
+// grid_threads T draws component (li / T) % U of the Philox block with counter offset/4 + (li / T) / U on subsequence
+// li % T (U = 4 outputs per block, 2 for 64-bit integers) -- the U elements li, li + T, ..., li + (U-1) T share ONE
+// block.  A WORK ITEM is such a block: the thread evaluates Philox once (40 quarter-rate 32-bit multiplies -- 20 us of
+// the first version's 48 were spent recomputing every block four times) and routes its U elements.  Consecutive
+// threads own consecutive subsequences, i.e. consecutive elements of the id matrix (coalesced id / slot stores).
+// Given ids use the same enumeration with a made-up T (numel / 4).  The positives are the work items behind the last
+// block.  A pipelined SLICE is a contiguous range of workgroups (any partition of the elements will do: the home
+// kernel gathers across all slices, the owner handles each slice's segments on their own).
+constexpr int ROUTE_ITEMS = 4;                       // work items per thread
+constexpr int ROUTE_ITEMS_PER_BLOCK = 256 * ROUTE_ITEMS;
+constexpr int CURSOR_PAD = 32;                       // one 128-byte line per cursor: atomics on one line are served in turn
+
 struct RouteV2 {
   const int64_t* pos_ids;
   int64_t* neg_ids;
@@ -220,51 +234,66 @@ struct RouteV2 {
   float* pos_logp;
   int64_t* send;
   int32_t* slot_of;
-  int32_t* cursors;        // [n_slices * G] arrival cursors + [1] block ticket: zero between launches (self-resetting)
+  int32_t* cursors;        // [n_slices * G] arrival cursors + [1] block ticket, CURSOR_PAD ints apart: zero between launches
   int32_t* counts_out;
-  int64_t n_queries, per_slice, capacity, stride, rows_per_shard, query_base;
+  int64_t n_queries, capacity, stride, rows_per_shard, query_base;
+  int64_t n_neg;           // n_queries * n
+  int64_t n_groups;        // work items that are Philox blocks (the positives follow)
+  uint64_t k_lo;           // first Philox counter step (li / T / U) this rank's elements touch
   PhiloxCall pc;
   PopTables pop;
-  FastDiv by_width, by_rows;
-  int32_t n, G, sampler, n_slices, blocks_per_slice;
+  FastDiv by_width, by_rows, by_n, by_gt;
+  int32_t n, G, sampler, n_slices, unroll;
 };
 
 template <bool COUNT_ONLY>
 __global__ __launch_bounds__(256) void shard_sample_route_kernel(const RouteV2 a) {
   __shared__ int32_t cnt[64], base[64];
   __shared__ int s_last;
-  const int slice = blockIdx.x / a.blocks_per_slice;
-  const int64_t e_lo = (int64_t)(blockIdx.x - slice * a.blocks_per_slice) * ROUTE_CHUNK;     // within the slice
-  const int64_t slice_numel = a.per_slice * (a.n + 1);
-  const int64_t m0 = (int64_t)slice * a.per_slice;
+  const int slice = (int)(((int64_t)blockIdx.x * a.n_slices) / gridDim.x);
   if (threadIdx.x < 64) cnt[threadIdx.x] = 0;
-  int g[ROUTE_EPT];
-  uint32_t local[ROUTE_EPT];
+  constexpr int EPT = ROUTE_ITEMS * 4;
+  int32_t gl[EPT];         // owner << 16 | slot inside this workgroup's range; -1: no element
+  uint32_t local[EPT];     // row inside the owner's block
+  int32_t el[EPT];         // element index in the [n_queries, 1 + n] matrix
   const uint64_t range = (uint64_t)(a.pop.n_items - 1);
+  const uint32_t T = a.pc.grid_threads;
 #pragma unroll
-  for (int k = 0; k < ROUTE_EPT; ++k) {
-    const int64_t e = e_lo + k * 256 + threadIdx.x;
-    g[k] = -1;
-    local[k] = 0;
-    if (e < slice_numel) {
-      const int64_t ml = (int64_t)a.by_width.div((uint64_t)e);
-      const int c = (int)(e - ml * (a.n + 1));
-      const int64_t m = m0 + ml;
-      int64_t id;
-      if (c == 0) {
-        id = a.pos_ids[m];
-        if (!COUNT_ONLY && a.pos_logp != nullptr) {
-          const int64_t pc_ = id < 0 ? 0 : (id >= a.pop.n_items ? a.pop.n_items - 1 : id);
-          a.pos_logp[m] = logf(a.pop.pop_prob[pc_]);
-        }
-      } else {
-        const int64_t flat = m * a.n + (c - 1);
+  for (int r = 0; r < ROUTE_ITEMS; ++r) {
+    const int64_t w = (int64_t)blockIdx.x * ROUTE_ITEMS_PER_BLOCK + r * 256 + threadIdx.x;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) gl[r * 4 + c] = -1;
+    if (w < a.n_groups) {
+      const uint64_t kq = a.by_gt.div((uint64_t)w);
+      const uint64_t idx = (uint64_t)w - kq * T;
+      const uint64_t kk = a.k_lo + kq;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (a.sampler != RSA_SAMPLER_GIVEN) {
+        const uint64_t ctr = a.pc.offset4 + kk;
+        v = philox4x32_10(make_uint4((uint32_t)ctr, (uint32_t)(ctr >> 32), (uint32_t)idx, (uint32_t)(idx >> 32)),
+                          make_uint2((uint32_t)a.pc.seed, (uint32_t)(a.pc.seed >> 32)));
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        if (c >= a.unroll) break;
+        const uint64_t li = (kk * a.unroll + c) * T + idx;
+        if (li < a.pc.elem_base || li - a.pc.elem_base >= (uint64_t)a.n_neg) continue;
+        const int64_t flat = (int64_t)(li - a.pc.elem_base);
+        int64_t id;
         if (a.sampler == RSA_SAMPLER_UNIFORM) {
-          id = torch_randint_element(a.pc, (uint64_t)flat, range, 1);
+          if (a.unroll == 2) {
+            const uint64_t r64 = c == 0 ? (((uint64_t)v.x << 32) | v.y) : (((uint64_t)v.z << 32) | v.w);
+            id = (int64_t)(r64 % range) + 1;
+          } else {
+            id = (int64_t)((uint64_t)pick(v, c) % range) + 1;
+          }
           if (!COUNT_ONLY && a.neg_ids != nullptr) a.neg_ids[flat] = id;
         } else if (a.sampler == RSA_SAMPLER_POPULAR) {
+          const float inv = 2.3283064e-10f;
+          float u = __fmaf_rn((float)pick(v, c), inv, inv);
+          u = u == 1.0f ? 0.0f : u;
           float pr;
-          id = lookup_popular(a.pop, torch_rand_element(a.pc, (uint64_t)flat), pr);
+          id = lookup_popular(a.pop, u, pr);
           if (!COUNT_ONLY) {
             if (a.neg_ids != nullptr) a.neg_ids[flat] = id;
             if (a.neg_logp != nullptr) a.neg_logp[flat] = logf(pr);
@@ -272,68 +301,92 @@ __global__ __launch_bounds__(256) void shard_sample_route_kernel(const RouteV2 a
         } else {
           id = a.neg_ids[flat];
         }
+        const int64_t m = (int64_t)a.by_n.div((uint64_t)flat);
+        el[r * 4 + c] = (int32_t)(flat + m + 1);               // = m * (n + 1) + 1 + (flat - m * n)
+        int g = 0;
+        if (a.G > 1) {
+          const int64_t q = id < 0 ? 0 : (int64_t)a.by_rows.div((uint64_t)id);
+          g = q >= a.G ? a.G - 1 : (int)q;
+        }
+        const int64_t loc = id - (int64_t)g * a.rows_per_shard;
+        local[r * 4 + c] = (uint32_t)(loc < 0 ? 0 : loc);
+        gl[r * 4 + c] = g << 16;
       }
-      const int64_t q = id < 0 ? 0 : (int64_t)a.by_rows.div((uint64_t)id);
-      g[k] = q >= a.G ? a.G - 1 : (int)q;
-      const int64_t loc = id - (int64_t)g[k] * a.rows_per_shard;
-      local[k] = (uint32_t)(loc < 0 ? 0 : loc);
+    } else if (w - a.n_groups < a.n_queries) {
+      const int64_t m = w - a.n_groups;
+      const int64_t id = a.pos_ids[m];
+      if (!COUNT_ONLY && a.pos_logp != nullptr) {
+        const int64_t pc_ = id < 0 ? 0 : (id >= a.pop.n_items ? a.pop.n_items - 1 : id);
+        a.pos_logp[m] = logf(a.pop.pop_prob[pc_]);
+      }
+      el[r * 4] = (int32_t)(m * (a.n + 1));
+      int g = 0;
+      if (a.G > 1) {
+        const int64_t q = id < 0 ? 0 : (int64_t)a.by_rows.div((uint64_t)id);
+        g = q >= a.G ? a.G - 1 : (int)q;
+      }
+      const int64_t loc = id - (int64_t)g * a.rows_per_shard;
+      local[r * 4] = (uint32_t)(loc < 0 ? 0 : loc);
+      gl[r * 4] = g << 16;
     }
   }
   __syncthreads();
+  // one pass of RETURNING LDS atomics: an element's slot inside this workgroup's share of its owner's segment
 #pragma unroll
-  for (int k = 0; k < ROUTE_EPT; ++k) wave_count<false>(cnt, g[k] >= 0, g[k], a.G == 1);
+  for (int k = 0; k < EPT; ++k) {
+    const bool valid = gl[k] >= 0;
+    const int32_t ls = wave_count<true>(cnt, valid, valid ? gl[k] >> 16 : 0, a.G == 1);
+    if (valid) gl[k] |= ls;
+  }
   __syncthreads();
   if (threadIdx.x < a.G) {
-    base[threadIdx.x] = cnt[threadIdx.x] ? atomicAdd(&a.cursors[slice * a.G + threadIdx.x], cnt[threadIdx.x]) : 0;
-    cnt[threadIdx.x] = 0;
+    const int32_t c = cnt[threadIdx.x];
+    base[threadIdx.x] = c ? atomicAdd(&a.cursors[(slice * a.G + threadIdx.x) * CURSOR_PAD], c) : 0;
   }
   __syncthreads();      // the returning cursor atomics of this workgroup have been performed
   if (!COUNT_ONLY) {
     int64_t* seg0 = a.send + (int64_t)slice * a.G * a.stride;
 #pragma unroll
-    for (int k = 0; k < ROUTE_EPT; ++k) {
-      const bool valid = g[k] >= 0;
-      const int gk = valid ? g[k] : 0;
-      const int64_t slot = (int64_t)base[gk] + wave_count<true>(cnt, valid, gk, a.G == 1);
-      if (!valid) continue;
-      const int64_t e = e_lo + k * 256 + threadIdx.x;
-      const int64_t E = m0 * (a.n + 1) + e;
+    for (int k = 0; k < EPT; ++k) {
+      if (gl[k] < 0) continue;
+      const int gk = gl[k] >> 16;
+      const int64_t slot = (int64_t)base[gk] + (gl[k] & 0xffff);
       if (slot >= a.capacity) {        // no room: the element is dropped -- no key, no score, no gradient
-        a.slot_of[E] = -1;
+        a.slot_of[el[k]] = -1;
         continue;
       }
-      const int64_t ml = (int64_t)a.by_width.div((uint64_t)e);
+      const int64_t m = (int64_t)a.by_width.div((uint64_t)el[k]);
       const int64_t at = (int64_t)gk * a.stride + RSA_SHARD_HDR + slot;
-      seg0[at] = ((a.query_base + m0 + ml) << 32) | (int64_t)local[k];
-      a.slot_of[E] = (int32_t)((int64_t)slice * a.G * a.stride + at);
+      seg0[at] = ((a.query_base + m) << 32) | (int64_t)local[k];
+      a.slot_of[el[k]] = (int32_t)((int64_t)slice * a.G * a.stride + at);
     }
   }
   // the workgroup that takes the last ticket sees every cursor final: it writes the segment headers (and the exact
   // counts for the calibration step) and leaves the cursors and the ticket zeroed for the next launch
+  const int segs = a.n_slices * a.G;
   if (threadIdx.x == 0) {
-    const int t = __hip_atomic_fetch_add(&a.cursors[a.n_slices * a.G], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int t = __hip_atomic_fetch_add(&a.cursors[segs * CURSOR_PAD], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     s_last = t == (int)gridDim.x - 1;
   }
   __syncthreads();
   if (s_last && threadIdx.x < 64) {
-    const int segs = a.n_slices * a.G;
     int64_t dropped = 0;
-    for (int s = threadIdx.x; s < segs; s += 64) {
-      const int64_t c = __hip_atomic_load(&a.cursors[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int sg = threadIdx.x; sg < segs; sg += 64) {
+      const int64_t c = __hip_atomic_load(&a.cursors[sg * CURSOR_PAD], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (c > a.capacity) dropped += c - a.capacity;
     }
 #pragma unroll
     for (int mk = 32; mk >= 1; mk >>= 1) dropped += __shfl_xor((long long)dropped, mk, 64);
-    for (int s = threadIdx.x; s < segs; s += 64) {
-      const int64_t c = __hip_atomic_load(&a.cursors[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (a.counts_out != nullptr) a.counts_out[s] = (int32_t)c;
+    for (int sg = threadIdx.x; sg < segs; sg += 64) {
+      const int64_t c = __hip_atomic_load(&a.cursors[sg * CURSOR_PAD], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (a.counts_out != nullptr) a.counts_out[sg] = (int32_t)c;
       if (!COUNT_ONLY) {
-        a.send[(int64_t)s * a.stride] = c < a.capacity ? c : a.capacity;
-        a.send[(int64_t)s * a.stride + 1] = dropped;
+        a.send[(int64_t)sg * a.stride] = c < a.capacity ? c : a.capacity;
+        a.send[(int64_t)sg * a.stride + 1] = dropped;
       }
-      __hip_atomic_store(&a.cursors[s], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&a.cursors[sg * CURSOR_PAD], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (threadIdx.x == 0) __hip_atomic_store(&a.cursors[segs], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0) __hip_atomic_store(&a.cursors[segs * CURSOR_PAD], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
@@ -405,6 +458,10 @@ struct HomeArgs {
   int32_t n;
 };
 
+// Tiles are handled HOME_TB at a time with the loads of a batch issued together (slots, then the scores they point
+// at): one tile at a time the kernel was a chain of 2 dependent memory round trips per tile (27 us for 4 M elements).
+constexpr int HOME_TB = 8;
+
 template <int LOSS>
 __global__ __launch_bounds__(256) void shard_home_kernel(const HomeArgs a) {
   const int lane = lane_id();
@@ -416,38 +473,55 @@ __global__ __launch_bounds__(256) void shard_home_kernel(const HomeArgs a) {
   float wave_loss = 0.f;
   for (int64_t m = wave0; m < a.n_queries; m += wstride) {
     const int64_t E0 = m * (n + 1);
+    const int32_t* so = a.slot_of + E0 + 1;
     const int32_t sp = a.slot_of[E0];
     const float pos = sp >= 0 ? a.scores[sp] : 0.f;
     if (lane == 0 && a.pos_score != nullptr) a.pos_score[m] = pos;
+    // a batch of tiles: slots and scores of this lane's element of each tile
+    auto fetch = [&](int t0, int32_t (&s)[HOME_TB], float (&sc)[HOME_TB]) __attribute__((always_inline)) {
+#pragma unroll
+      for (int i = 0; i < HOME_TB; ++i) {
+        const int j = ((t0 + i) << 6) + lane;
+        s[i] = (t0 + i < T && j < n) ? so[j] : -1;
+      }
+#pragma unroll
+      for (int i = 0; i < HOME_TB; ++i) sc[i] = s[i] >= 0 ? a.scores[s[i]] : 0.f;
+    };
     if constexpr (LOSS == 0) {
-      for (int t = 0; t < T; ++t) {
-        const int j = (t << 6) + lane;
-        if (j < n) {
-          const int32_t s = a.slot_of[E0 + 1 + j];
-          a.neg_score[m * n + j] = s >= 0 ? a.scores[s] : 0.f;
+      for (int t0 = 0; t0 < T; t0 += HOME_TB) {
+        int32_t s[HOME_TB];
+        float sc[HOME_TB];
+        fetch(t0, s, sc);
+#pragma unroll
+        for (int i = 0; i < HOME_TB; ++i) {
+          const int j = ((t0 + i) << 6) + lane;
+          if (t0 + i < T && j < n) a.neg_score[m * n + j] = sc[i];
         }
       }
     } else if constexpr (LOSS == 1) {
       float lsum = 0.f, gsum = 0.f;
-      for (int t = 0; t < T; ++t) {
-        const int j = (t << 6) + lane;
-        int32_t s = -1;
-        float neg = 0.f;
-        if (j < n) {
-          s = a.slot_of[E0 + 1 + j];
-          if (s >= 0) neg = a.scores[s];
-          if (a.neg_score != nullptr) a.neg_score[m * n + j] = neg;
+      for (int t0 = 0; t0 < T; t0 += HOME_TB) {
+        int32_t s[HOME_TB];
+        float sc[HOME_TB];
+        fetch(t0, s, sc);
+#pragma unroll
+        for (int i = 0; i < HOME_TB; ++i) {
+          const int j = ((t0 + i) << 6) + lane;
+          const bool in = t0 + i < T && j < n;
+          const bool live = s[i] >= 0 && sp >= 0;
+          const float xd = pos - sc[i];
+          const float tt = __expf(-fabsf(xd));
+          const float ls = live ? fminf(xd, 0.f) - __logf(1.f + tt) : 0.f;
+          const float r = __frcp_rn(1.f + tt);
+          const float sg = live ? (xd >= 0.f ? tt * r : r) * w * inv_m : 0.f;
+          if (in) {
+            if (a.neg_score != nullptr) a.neg_score[m * n + j] = sc[i];
+            if (a.dneg != nullptr) a.dneg[m * n + j] = sg;
+          }
+          if (s[i] >= 0 && a.d_send != nullptr) a.d_send[s[i]] = sg;
+          lsum += ls;
+          gsum += sg;
         }
-        const bool live = s >= 0 && sp >= 0;
-        const float xd = pos - neg;
-        const float tt = __expf(-fabsf(xd));
-        const float ls = live ? fminf(xd, 0.f) - __logf(1.f + tt) : 0.f;
-        const float r = __frcp_rn(1.f + tt);
-        const float sg = live ? (xd >= 0.f ? tt * r : r) * w * inv_m : 0.f;
-        if (j < n && a.dneg != nullptr) a.dneg[m * n + j] = sg;
-        if (s >= 0 && a.d_send != nullptr) a.d_send[s] = sg;
-        lsum += ls;
-        gsum += sg;
       }
       lsum = group_sum<64>(lsum);
       gsum = group_sum<64>(gsum);
@@ -461,23 +535,27 @@ __global__ __launch_bounds__(256) void shard_home_kernel(const HomeArgs a) {
     } else {
       const float lq_pos = a.pos_logp ? a.pos_logp[m] : 0.f;
       const float z_pos = pos - lq_pos;
+      const float* lq = a.neg_logp ? a.neg_logp + m * n : nullptr;
       float run_m = -INFINITY, run_s = 0.f;
-      for (int t = 0; t < T; ++t) {
-        const int j = (t << 6) + lane;
-        int32_t s = -1;
-        float neg = 0.f, z = -INFINITY;
-        if (j < n) {
-          s = a.slot_of[E0 + 1 + j];
-          if (s >= 0) {
-            neg = a.scores[s];
-            z = neg - (a.neg_logp ? a.neg_logp[m * n + j] : 0.f);
-          }
-          if (a.neg_score != nullptr) a.neg_score[m * n + j] = neg;
+      for (int t0 = 0; t0 < T; t0 += HOME_TB) {
+        int32_t s[HOME_TB];
+        float sc[HOME_TB], z[HOME_TB];
+        fetch(t0, s, sc);
+        float bm = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < HOME_TB; ++i) {
+          const int j = ((t0 + i) << 6) + lane;
+          const bool in = t0 + i < T && j < n;
+          z[i] = s[i] >= 0 ? sc[i] - (lq ? lq[j] : 0.f) : -INFINITY;
+          if (in && a.neg_score != nullptr) a.neg_score[m * n + j] = sc[i];
+          bm = fmaxf(bm, z[i]);
         }
-        const float tm = wave_max(z);
-        const float m_new = fmaxf(run_m, tm);
+        const float m_new = fmaxf(run_m, wave_max(bm));
         if (m_new > -INFINITY) {
-          run_s = run_s * __expf(run_m - m_new) + group_sum<64>(s >= 0 ? __expf(z - m_new) : 0.f);
+          float part = 0.f;
+#pragma unroll
+          for (int i = 0; i < HOME_TB; ++i) part += s[i] >= 0 ? __expf(z[i] - m_new) : 0.f;
+          run_s = run_s * __expf(run_m - m_new) + group_sum<64>(part);
           run_m = m_new;
         }
       }
@@ -494,17 +572,19 @@ __global__ __launch_bounds__(256) void shard_home_kernel(const HomeArgs a) {
         if (sp >= 0 && a.d_send != nullptr) a.d_send[sp] = dp;
       }
       if (a.dneg != nullptr || a.d_send != nullptr) {
-        for (int t = 0; t < T; ++t) {
-          const int j = (t << 6) + lane;
-          if (j >= n) continue;
-          const int32_t s = a.slot_of[E0 + 1 + j];
-          float dv = 0.f;
-          if (s >= 0 && !gone) {
-            const float z = a.scores[s] - (a.neg_logp ? a.neg_logp[m * n + j] : 0.f);
-            dv = bad ? NAN : __expf(z - lse) * inv_m;
+        for (int t0 = 0; t0 < T; t0 += HOME_TB) {
+          int32_t s[HOME_TB];
+          float sc[HOME_TB];
+          fetch(t0, s, sc);
+#pragma unroll
+          for (int i = 0; i < HOME_TB; ++i) {
+            const int j = ((t0 + i) << 6) + lane;
+            const bool in = t0 + i < T && j < n;
+            float dv = 0.f;
+            if (s[i] >= 0 && !gone) dv = bad ? NAN : __expf(sc[i] - (lq ? lq[j] : 0.f) - lse) * inv_m;
+            if (in && a.dneg != nullptr) a.dneg[m * n + j] = dv;
+            if (s[i] >= 0 && a.d_send != nullptr) a.d_send[s[i]] = dv;
           }
-          if (a.dneg != nullptr) a.dneg[m * n + j] = dv;
-          if (s >= 0 && a.d_send != nullptr) a.d_send[s] = dv;
         }
       }
     }
@@ -606,8 +686,8 @@ extern "C" int rsa_shard_sample_route(const rsa_shard_route_args* a, rsa_stream_
   RSA_CHECK_ARG(a->n_queries >= 0 && a->num_neg >= 0 && a->rows_per_shard >= 1 && a->rows_per_shard < (1ll << 32),
                 "rsa_shard_sample_route: bad sizes");
   RSA_CHECK_ARG(a->n_shards >= 1 && a->n_shards <= 64, "rsa_shard_sample_route: n_shards must be in [1, 64]");
-  RSA_CHECK_ARG(a->n_slices >= 1 && a->n_slices * a->n_shards <= 4096 && a->n_queries % a->n_slices == 0,
-                "rsa_shard_sample_route: n_slices must divide n_queries (and n_slices * n_shards <= 4096)");
+  RSA_CHECK_ARG(a->n_slices >= 1 && a->n_slices * a->n_shards <= 4096,
+                "rsa_shard_sample_route: n_slices must be >= 1 with n_slices * n_shards <= 4096");
   RSA_CHECK_ARG(a->query_base >= 0 && a->query_base + a->n_queries < (1ll << 31), "rsa_shard_sample_route: query index overflow");
   RSA_CHECK_ARG(a->sampler >= RSA_SAMPLER_GIVEN && a->sampler <= RSA_SAMPLER_POPULAR, "rsa_shard_sample_route: unknown sampler %d",
                 a->sampler);
@@ -651,11 +731,8 @@ extern "C" int rsa_shard_sample_route(const rsa_shard_route_args* a, rsa_stream_
     RSA_CHECK_ARG(a->capacity >= 1 && (a->capacity + RSA_SHARD_HDR) * a->n_shards * a->n_slices < (1ll << 31),
                   "rsa_shard_sample_route: capacity out of range");
   }
-  const int64_t per_slice = a->n_queries / a->n_slices;
-  const int64_t slice_numel = per_slice * (a->num_neg + 1);
   RSA_CHECK_ARG(a->n_queries * (a->num_neg + 1) < (1ll << 31), "rsa_shard_sample_route: more than 2^31 elements");
-  const int64_t bps = (slice_numel + ROUTE_CHUNK - 1) / ROUTE_CHUNK;
-  RSA_CHECK_ARG(bps * a->n_slices < (1ll << 31), "rsa_shard_sample_route: grid too large");
+  const int64_t n_neg = a->n_queries * a->num_neg;
   RouteV2 r;
   r.pos_ids = a->pos_ids;
   r.neg_ids = a->neg_ids;
@@ -666,22 +743,45 @@ extern "C" int rsa_shard_sample_route(const rsa_shard_route_args* a, rsa_stream_
   r.cursors = a->cursors;
   r.counts_out = a->counts_out;
   r.n_queries = a->n_queries;
-  r.per_slice = per_slice;
   r.capacity = count_only ? (1ll << 40) : a->capacity;
   r.stride = a->capacity + RSA_SHARD_HDR;
   r.rows_per_shard = a->rows_per_shard;
   r.query_base = a->query_base;
-  r.pc = PhiloxCall{a->seed, a->offset >> 2, a->grid_threads, a->elem_base};
+  r.n_neg = n_neg;
   r.pop = PopTables{a->table, a->pop_prob, a->table_prob, a->cdf_lut, a->cdf_lines, a->guide, a->n_items, a->guide_log2,
                     a->lines_log2};
-  r.by_width = make_fastdiv((uint64_t)a->num_neg + 1);
-  r.by_rows = make_fastdiv((uint64_t)a->rows_per_shard);
   r.n = a->num_neg;
   r.G = a->n_shards;
   r.sampler = a->sampler;
   r.n_slices = a->n_slices;
-  r.blocks_per_slice = (int32_t)bps;
-  const dim3 grid((unsigned)(bps * a->n_slices)), block(256);
+  // the enumeration of the negatives: Philox blocks of the torch call (see the kernel), or the same shape made up for
+  // given ids (four interleaved quarters)
+  if (a->sampler == RSA_SAMPLER_GIVEN || n_neg == 0) {
+    int64_t quarter = ((n_neg + 3) / 4 + 255) / 256 * 256;
+    if (quarter < 256) quarter = 256;
+    r.pc = PhiloxCall{0, 0, (uint32_t)quarter, 0};
+    r.unroll = 4;
+  } else {
+    r.pc = PhiloxCall{a->seed, a->offset >> 2, a->grid_threads, a->elem_base};
+    r.unroll = (a->sampler == RSA_SAMPLER_UNIFORM && (uint64_t)(a->n_items - 1) >= (1ull << 28)) ? 2 : 4;   // ATen: 64-bit draws
+  }
+  const uint64_t T = r.pc.grid_threads;
+  uint64_t k_lo = 0, k_hi = 0;
+  if (n_neg > 0) {
+    k_lo = (r.pc.elem_base / T) / r.unroll;
+    k_hi = ((r.pc.elem_base + (uint64_t)n_neg - 1) / T) / r.unroll;
+  }
+  r.k_lo = k_lo;
+  r.n_groups = n_neg > 0 ? (int64_t)((k_hi - k_lo + 1) * T) : 0;
+  RSA_CHECK_ARG(r.n_groups + a->n_queries < (1ll << 32), "rsa_shard_sample_route: too many work items");
+  r.by_width = make_fastdiv((uint64_t)a->num_neg + 1);
+  r.by_rows = make_fastdiv((uint64_t)a->rows_per_shard);
+  r.by_n = make_fastdiv((uint64_t)(a->num_neg > 0 ? a->num_neg : 1));
+  r.by_gt = make_fastdiv(T);
+  int64_t blocks = (r.n_groups + a->n_queries + ROUTE_ITEMS_PER_BLOCK - 1) / ROUTE_ITEMS_PER_BLOCK;
+  if (blocks < a->n_slices) blocks = a->n_slices;         // every slice owns at least one workgroup
+  RSA_CHECK_ARG(blocks < (1ll << 31), "rsa_shard_sample_route: grid too large");
+  const dim3 grid((unsigned)blocks), block(256);
   if (count_only) hipLaunchKernelGGL(shard_sample_route_kernel<true>, grid, block, 0, (hipStream_t)stream, r);
   else hipLaunchKernelGGL(shard_sample_route_kernel<false>, grid, block, 0, (hipStream_t)stream, r);
   RSA_CHECK_LAUNCH("rsa_shard_sample_route");

@@ -74,7 +74,7 @@ class HipBackend:
     def new_state(self, device):
         """Per-table device words: routing cursors (zeroed once, self-resetting), the sticky job-wide dropped count,
         the dropped count of the last step, and the gated update scales {item scale, gate} the backward multiplies by."""
-        return {'cursors': torch.zeros(4097, dtype=torch.int32, device=device),
+        return {'cursors': torch.zeros(4097 * 32, dtype=torch.int32, device=device),
                 'overflow': torch.zeros(1, dtype=torch.int32, device=device),
                 'step_dropped': torch.zeros(1, dtype=torch.int32, device=device),
                 'scale': torch.ones(2, dtype=torch.float32, device=device)}
@@ -359,12 +359,13 @@ def _gather_group(dist):
 
 class ShardedItemTable:
     def __init__(self, item_local, plan, rank, dist, backend=None, group=None, exchange='fixed', slack=1.08,
-                 margin=4096, check_every=16, sample_seed=2022, chunks=1):
+                 margin=4096, check_every=16, sample_seed=2022, chunks=1, force_collectives=False):
         """``chunks`` > 1 (fixed-capacity exchange only): the step's queries are cut into that many contiguous
         slices, routed by ONE launch, whose exchanges are issued asynchronously, so that slice c+1's key all-to-all and
         slice c-1's score all-to-all travel over xGMI while slice c is being scored (see ``_fixed_step``)."""
         self.item_local, self.plan, self.rank, self.dist = item_local, plan, int(rank), dist
         self.chunks = max(1, int(chunks))
+        self._solo = plan.world == 1 and not force_collectives
         self.backend = backend if backend is not None else HipBackend()
         self.group = group
         if exchange not in ('fixed', 'exact'):
@@ -383,6 +384,13 @@ class ShardedItemTable:
             raise ValueError(f'rank {rank} must hold rows [{lo}, {hi}) of the item table, got {item_local.shape[0]}')
 
     # -- collectives (RCCL through torch.distributed) -------------------------------------------
+    # With ONE rank every collective of the step is the identity (the all-gather of one block, an all-to-all with
+    # itself, a reduce-scatter of one part): unless ``force_collectives`` asks for the calls anyway (tests, and the
+    # bench's protocol-cost figure) they are skipped -- no copy through the communicator, no launch.
+    def _all_reduce_max(self, t):
+        if not self._solo:
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.group)
+
     def _all_gather_rows(self, x):
         return self._all_gather_rows_start(x)()
 
@@ -391,8 +399,10 @@ class ShardedItemTable:
         that waits for it.  At B = 65536 queries/GPU the block is 33.5 MB per rank -- the largest message of
         the step (7 x 33.5 MB arrive per GPU over xGMI, vs 8 + 4 bytes per triplet for keys and scores) -- and
         nothing before the owner-side scoring needs it, so it flies under sampling and routing."""
-        out = torch.empty(self.plan.world * x.shape[0], *x.shape[1:], dtype=x.dtype, device=x.device)
         x = x.contiguous()
+        if self._solo:
+            return lambda: x
+        out = torch.empty(self.plan.world * x.shape[0], *x.shape[1:], dtype=x.dtype, device=x.device)
         work = self.dist.all_gather_into_tensor(out, x, group=self.gather_group, async_op=True)
 
         def wait():
@@ -404,11 +414,16 @@ class ShardedItemTable:
     def _exchange_counts(self, counts):
         send = counts.to(torch.int64)
         recv = torch.empty_like(send)
-        self.dist.all_to_all_single(recv, send, group=self.group)
+        if self._solo:
+            recv = send
+        else:
+            self.dist.all_to_all_single(recv, send, group=self.group)
         return [int(v) for v in send.tolist()], [int(v) for v in recv.tolist()]
 
     def _all_to_all(self, x, recv_counts=None, send_counts=None, out=None):
         """Variable split (host lists) or, with no counts, the equal split of the fixed-capacity exchange."""
+        if self._solo:
+            return x if out is None else out.copy_(x)
         if recv_counts is None:
             out = torch.empty_like(x) if out is None else out
             self.dist.all_to_all_single(out, x, group=self.group)
@@ -422,6 +437,9 @@ class ShardedItemTable:
         """Equal-split all-to-all issued asynchronously (it runs on the communicator's stream once everything queued
         on the current stream so far has finished); returns wait() -> the received tensor, ordered after the transfer
         on the current stream."""
+        if self._solo:
+            res = x if out is None else out.copy_(x)
+            return lambda: res
         out = torch.empty_like(x) if out is None else out
         work = self.dist.all_to_all_single(out, x, group=self.group, async_op=True)
 
@@ -433,6 +451,8 @@ class ShardedItemTable:
         return wait
 
     def _reduce_scatter_rows(self, x, rows_per_rank):
+        if self._solo:
+            return x
         out = torch.empty(rows_per_rank, *x.shape[1:], dtype=x.dtype, device=x.device)
         self.dist.reduce_scatter_tensor(out, x.contiguous(), group=self.group)
         return out
@@ -444,9 +464,9 @@ class ShardedItemTable:
         step only."""
         B, n, C = key
         m = torch.tensor([int(largest)], dtype=torch.int64, device=self.item_local.device)
-        self.dist.all_reduce(m, op=self.dist.ReduceOp.MAX, group=self.group)
+        self._all_reduce_max(m)
         cap = int(int(m.item()) * self.slack) + self.margin
-        cap = min((B // C) * (n + 1), (cap + 255) // 256 * 256)
+        cap = min(B * (n + 1), (cap + 255) // 256 * 256)
         self._cap[key] = max(cap, 1)
         return self._cap[key]
 
@@ -510,7 +530,10 @@ class ShardedItemTable:
             q_all = q_gather()
             rk = self._all_to_all(send)
             recv_keys.append(rk)
-            self._all_to_all(be.score_segments(st, self.item_local, q_all, rk, G, stride, first=True), out=scores_home)
+            if self._solo:
+                be.score_segments(st, self.item_local, q_all, rk, G, stride, first=True, out=scores_home)
+            else:
+                self._all_to_all(be.score_segments(st, self.item_local, q_all, rk, G, stride, first=True), out=scores_home)
         else:
             waits = [self._all_to_all_start(send[c * per:(c + 1) * per]) for c in range(C)]
             q_all = q_gather()
@@ -518,8 +541,12 @@ class ShardedItemTable:
             for c, w in enumerate(waits):
                 rk = w()
                 recv_keys.append(rk)
-                sc = be.score_segments(st, self.item_local, q_all, rk, G, stride, first=c == 0)
-                back.append(self._all_to_all_start(sc, out=scores_home[c * per:(c + 1) * per]))
+                home_c = scores_home[c * per:(c + 1) * per]
+                if self._solo:
+                    be.score_segments(st, self.item_local, q_all, rk, G, stride, first=c == 0, out=home_c)
+                else:
+                    sc = be.score_segments(st, self.item_local, q_all, rk, G, stride, first=c == 0)
+                    back.append(self._all_to_all_start(sc, out=home_c))
             for w in back:
                 w()
         if log_pos is None:
@@ -650,6 +677,8 @@ class ShardedItemTable:
     def _exchange_partials(self, x, B):
         """x [G*B, ...] (this shard's partial for EVERY query) -> [G, B, ...] (every shard's partial for the
         own queries): an equal-split all-to-all."""
+        if self._solo:
+            return x.view(1, B, *x.shape[1:])
         out = torch.empty_like(x)
         self.dist.all_to_all_single(out, x.contiguous(), group=self.group)
         return out.view(self.plan.world, B, *x.shape[1:])
@@ -819,7 +848,7 @@ class ShardedRetriever:
             loss = out['loss']
             dq = table.backward(out['route'], None, None, self.item_grad_local, self.item_scale)
             self.last_neg = out['neg_ids']
-            if not self.sparse_query_rows:
+            if not self.sparse_query_rows and q.requires_grad:
                 q.backward(dq)
         else:
             if self.sparse_query_rows:
@@ -839,7 +868,7 @@ class ShardedRetriever:
             if self.query_sgd_lr is not None:
                 table.backend.apply_rows(weight.data, ids_all, rows_all, -float(self.query_sgd_lr),
                                          pad_row=-1 if pad is None else int(pad))
-        else:
+        elif not table._solo:
             allreduce_grads(self.query_encoder.parameters(), table.dist, table.group)
         return loss
 
