@@ -102,15 +102,41 @@ def self_launch(n_gpus):
     os.execvpe(cmd[0], cmd, env)
 
 
+def _cpu_model():
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
+
+
+def _median_time(step, budget_s, min_steps=3, max_steps=30, warm=1):
+    for _ in range(warm):
+        step()
+    times = []
+    t_end = time.perf_counter() + budget_s
+    while len(times) < min_steps or (time.perf_counter() < t_end and len(times) < max_steps):
+        t0 = time.perf_counter()
+        step()
+        times.append(time.perf_counter() - t0)
+    times.sort()
+    return times[len(times) // 2], len(times)
+
+
 def cpu_baseline(args, counts, d, B, n):
-    """The oracle (a port, not the product) timed on this box's host cores on a bounded sample:
-    the same N / d / B / n, a handful of steps."""
+    """SURVEY.md 8(d), CPU leg: the oracle (a port of the reference's PyTorch path, golden-checked against it; not the
+    product) timed on this box's host cores.  (i) forward-only sample + gather + score + loss under no_grad at the
+    headline's N / d / B / n, for 8 threads and for all cores (torch-CPU gathers do not scale to hundreds of threads: both
+    are reported, `value` is the better one); (ii) the full training step with the reference's dense backward
+    (autograd -> [N, d] gradients) at N = 1e6, the largest size where that is feasible, 3 warm-up + >= 5 timed steps."""
     import oracle
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
+    nproc = os.cpu_count() or 1
     n_items = counts.numel()
     g = torch.Generator().manual_seed(1)
     t0 = time.perf_counter()
+    torch.set_num_threads(nproc)
     item = torch.empty(n_items, d).uniform_(-0.035, 0.035, generator=g)
     item[0] = 0
     user = torch.empty(args.users, d).uniform_(-0.035, 0.035, generator=g)
@@ -125,27 +151,72 @@ def cpu_baseline(args, counts, d, B, n):
             lpp, neg, lnp = ps.forward(q, n, pos)
             p, s = oracle.retriever_forward(item, q, pos, neg)
             return oracle.bpr_loss(p, s)
-    # torch-CPU gathers do not scale to hundreds of threads: try a few thread counts, keep the best
-    best = None
-    for thr in sorted({min(cores, t) for t in (8, 32, 64, cores)}):
+    by_threads = {}
+    for thr in sorted({min(nproc, t) for t in (8, 32, nproc)}):
         torch.set_num_threads(thr)
-        step()
-        times = []
-        t_end = time.perf_counter() + 5.0
-        while len(times) < 3 or (time.perf_counter() < t_end and len(times) < 30):
-            t0 = time.perf_counter()
-            step()
-            times.append(time.perf_counter() - t0)
-        times.sort()
-        m = times[len(times) // 2]
-        if best is None or m < best[0]:
-            best = (m, thr, len(times))
-    med, cores, ntimes = best
-    times = [0] * ntimes
-    return {'value': round(B * n / med / 1e6, 3), 'unit': 'M triplets/s', 'cores': cores, 'kind': 'port',
-            'sample': f'oracle forward (popular sample + gather + inner product + BPR) on torch-CPU, '
-                      f'N={n_items} d={d} B={B} n={n}, median of {len(times)} steps, {cores} threads, '
-                      f'{med * 1e3:.1f} ms/step (table setup {setup:.1f}s untimed)'}
+        med, cnt = _median_time(step, 6.0)
+        by_threads[thr] = (med, cnt)
+    best_thr = min(by_threads, key=lambda t: by_threads[t][0])
+    med, cnt = by_threads[best_thr]
+    res = {'value': round(B * n / med / 1e6, 3), 'unit': 'M triplets/s', 'cores': best_thr, 'kind': 'port',
+           'nproc': nproc, 'cpu_model': _cpu_model(), 'torch': torch.__version__,
+           'forward_ms_by_threads': {str(t): round(v[0] * 1e3, 1) for t, v in by_threads.items()},
+           'sample': f'(i) oracle forward (popular sample + gather + inner product + BPR, no_grad) on torch-CPU, N={n_items} d={d} '
+                     f'B={B} n={n} (the headline shape), median of {cnt} steps at {best_thr} threads = {med * 1e3:.1f} ms/step '
+                     f'(table setup {setup:.1f}s untimed)'}
+    # (ii) full step, dense backward, N = 1e6 (dense gradients are infeasible beyond)
+    try:
+        n2, b2 = 1_000_001, 4096
+        item2 = item[:n2].clone()
+        ps2 = oracle.PopularSamplerModel(counts[:n2])
+        uid2, pos2 = uid[:b2], pos[:b2] % (n2 - 1) + 1
+        torch.set_num_threads(best_thr)
+
+        iw2, uw2 = item2.requires_grad_(True), user.clone().requires_grad_(True)
+        emb = torch.nn.functional.embedding
+
+        def train():          # recommender.py:636-639 on the oracle's ops: zero_grad (set to None), forward, loss, backward
+            iw2.grad = uw2.grad = None
+            q = emb(uid2, uw2, padding_idx=0)
+            with torch.no_grad():
+                _, neg, _ = ps2.forward(q, n, pos2)
+            p_s = oracle.inner_product_score(q, emb(pos2, iw2, padding_idx=0))
+            n_s = oracle.inner_product_score(q, emb(neg, iw2, padding_idx=0))
+            oracle.bpr_loss(p_s, n_s).backward()
+        for _ in range(2):
+            train()
+        med2, cnt2 = _median_time(train, 8.0, min_steps=5, max_steps=12, warm=1)
+        res['train_step_dense_backward'] = {
+            'ms_per_step': round(med2 * 1e3, 1), 'M_triplets_s': round(b2 * n / med2 / 1e6, 3), 'threads': best_thr,
+            'what': f'(ii) sample + forward + BPR + autograd dense backward ([N, d] item and user gradients), N={n2} B={b2} '
+                    f'n={n}, 3 warm-up + {cnt2} timed steps, median'}
+    except Exception as e:
+        res['train_step_dense_backward'] = {'error': repr(e)[:200]}
+    torch.set_num_threads(nproc)
+    return res
+
+
+def profile_record(name):
+    """The committed rocprofv3 record of a bench figure (profiles/r03_kernel_profiles.json, written by
+    tools/collect_profiles_r3.sh on a GPU box): kernel average from --kernel-trace --stats and the FETCH_SIZE / WRITE_SIZE
+    passes.  bench.py prints `profile_frac` next to every live fraction that has one, so that a reader sees the tracked
+    number and the live one side by side (boxes of the pool differ by several per cent)."""
+    path = os.path.join(ROOT, 'profiles', 'r03_kernel_profiles.json')
+    try:
+        return json.load(open(path)).get(name)
+    except (OSError, ValueError):
+        return None
+
+
+def with_profile(entry, name, alg_bytes):
+    rec = profile_record(name)
+    if rec and rec.get('avg_us'):
+        entry['profile_frac'] = round(alg_bytes / (rec['avg_us'] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
+        entry['profile_avg_kernel_ms'] = round(rec['avg_us'] / 1e3, 4)
+        if rec.get('hbm_bytes_per_launch'):
+            entry['profile_traffic_over_alg'] = round(rec['hbm_bytes_per_launch'] / alg_bytes, 3)
+        entry['profile_source'] = f'profiles/r03_kernel_profiles.json["{name}"]'
+    return entry
 
 
 def main():
@@ -182,14 +253,26 @@ def main():
         args.neg = 1024 if sharded_run else 64
     if args.sampler is None:
         args.sampler = 'uniform' if sharded_run else 'popular'
+    # RSA_BENCH_STAGED=1: the multi-rank branch on a single-GPU box -- all ranks share GPU 0 and their collectives are staged
+    # over gloo (tools/staged_dist.py, the tests' harness).  Exercises the code path and the JSON keys; not a measurement.
+    staged = world > 1 and os.environ.get('RSA_BENCH_STAGED') == '1'
+    if staged:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=dev)
-        assert dist.get_world_size() == args.gpus and dist.get_backend() == 'nccl'
+        if staged:
+            sys.path.insert(0, os.path.join(ROOT, 'tools'))
+            from staged_dist import StagedDist
+            dist.init_process_group('gloo')
+            dist = StagedDist(dist)
+        else:
+            dist.init_process_group('nccl', device_id=dev)
+            assert dist.get_backend() == 'nccl'
+        assert dist.get_world_size() == args.gpus
 
     import recstudio_amd as ra
     from recstudio_amd import _native as nat
@@ -361,7 +444,9 @@ def main():
             t3u = time_gpu_best(step3_unfused, 50, 5) * 1e3
             t3t = time_gpu_best(train3, 30, 3) * 1e3
             t3t2 = time_gpu_best(train3_two_pass, 30, 3) * 1e3
-            extra['seq_softmax'] = {
+            alg3 = bytes_per_triplet(d, n3, True) * b3 * n3
+            extra['seq_softmax'] = with_profile({}, 'ssm_N1e6_popular_n256_B8192', alg3)
+            extra['seq_softmax'].update({
                 'workload': f'B={b3} prefixes, L<={L3}, N={n_it3}, d={d}, popularity sampler n={n3}, SampledSoftmax '
                             '(BASELINE.json configs[2] tail; the Transformer is stock PyTorch and not timed)',
                 'seg_gather_ms': round(t_seg, 4), 'seg_gather_GBs': round(seg_bytes / t_seg / 1e6, 1),
@@ -373,7 +458,7 @@ def main():
                 'unfused_loss_ms': round(t3u, 4),
                 'train_step_ms': round(t3t, 4), 'train_step_two_pass_ms': round(t3t2, 4),
                 'train_step_what': 'forward as above + d loss/d query accumulated in the forward + write-only '
-                                   'row-sparse item-gradient rows (two_pass: separate loss kernel, backward re-reads the rows)'}
+                                   'row-sparse item-gradient rows (two_pass: separate loss kernel, backward re-reads the rows)'})
         except Exception as e:
             extra['seq_softmax'] = {'error': repr(e)[:200]}
         # full softmax training step on configs[4] (forward never writes [B, N]; backward = one softmax write + 2 GEMMs)
@@ -441,20 +526,20 @@ def main():
                     'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': None,
                     'alg_bytes_per_launch': int(alg), 'avg_kernel_ms': round(k_avg, 4),
                     'median_kernel_ms': round(k_ms[len(k_ms) // 2], 4)}
-        # HBM bytes per launch come from separate rocprofv3 --pmc passes (tools/collect_profiles.sh), not from this run:
-        # the committed figure is attached only together with the kernel time it was collected at, and dropped when
-        # that time is more than 15 % away from today's (a changed kernel must be re-profiled, not re-labelled)
-        pmc = os.path.join(ROOT, 'profiles', 'r02_pmc_traffic.json')
-        if os.path.exists(pmc) and (args.items, args.batch, args.neg, args.dim, popular, args.pop_lookup) == \
-                (10_000_001, 65536, 64, 128, True, 'auto'):
-            try:
-                rec = json.load(open(pmc))
-                then = rec.get('fused_fwd_avg_us', 0.0) / 1e3
-                if then and abs(then - k_avg) / k_avg < 0.15:
-                    roofline['traffic'] = rec.get('fused_fwd_bytes_per_launch')
-                    roofline['traffic_source'] = f'profiles/r02_pmc_traffic.json (FETCH_SIZE x2 + WRITE_SIZE passes; kernel avg then {then:.4f} ms)'
-            except Exception:
-                pass
+        # The tracked profile of this very kernel and shape (profiles/r03_kernel_profiles.json: rocprofv3 --kernel-trace --stats
+        # average and the FETCH_SIZE / WRITE_SIZE passes, collected by tools/collect_profiles_r3.sh on another box of the
+        # pool): `profile_frac` is the same algorithmic bytes over THAT average, printed next to the live `frac`; the PMC
+        # traffic is attached only while the two kernel times are within 15 % (a changed kernel must be re-profiled)
+        if (args.items, args.batch, args.neg, args.dim, popular, args.pop_lookup) == (10_000_001, 65536, 64, 128, True, 'auto'):
+            rec = profile_record('headline_N1e7_popular_n64_B65536')
+            if rec and rec.get('avg_us'):
+                roofline['profile_frac'] = round(alg / (rec['avg_us'] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
+                roofline['profile_avg_kernel_ms'] = round(rec['avg_us'] / 1e3, 4)
+                roofline['profile_source'] = 'profiles/r03_kernel_profiles.json["headline_N1e7_popular_n64_B65536"] (rocprofv3 --kernel-trace --stats)'
+                if rec.get('hbm_bytes_per_launch') and abs(rec['avg_us'] / 1e3 - k_avg) / k_avg < 0.15:
+                    roofline['traffic'] = int(rec['hbm_bytes_per_launch'])
+                    roofline['traffic_source'] = ('same file: FETCH_SIZE + WRITE_SIZE passes, units and gfx950 correction as in '
+                                                  'MI355X_MICROARCH.md (see tools/collect_profiles_r3.sh)')
 
         # north_star target: the fused gather+sample+score(+BPR) on a 100 M-item table (51.2 GB) at d = 128
         if not args.no_sweep and args.dim == 128:
@@ -475,8 +560,10 @@ def main():
                                                        query_index=u8, pos_ids=p8, sampler=nat.SAMPLER_UNIFORM)
                     t8 = time_gpu_best(st8, 50, 5) * 1e3
                     alg8 = bytes_per_triplet(d, n_neg, False, fused_loss=True) * b_q * n_neg
-                    res8[name] = {'ms': round(t8, 4), 'M_triplets_s': round(b_q * n_neg / t8 / 1e3, 1),
-                                  'alg_GBs': round(alg8 / t8 / 1e6, 1), 'frac_of_hbm_peak': round(alg8 / t8 / 1e6 / HBM_PEAK_GBS, 4)}
+                    res8[name] = with_profile({'ms': round(t8, 4), 'M_triplets_s': round(b_q * n_neg / t8 / 1e3, 1),
+                                               'alg_GBs': round(alg8 / t8 / 1e6, 1),
+                                               'frac_of_hbm_peak': round(alg8 / t8 / 1e6 / HBM_PEAK_GBS, 4)},
+                                              f'N1e8_uniform_n{n_neg}_B{b_q}', alg8)
                 try:          # the popularity sampler on the same table (2^25-bucket lookup table, 537 MB)
                     ps8 = ra.PopularSamplerModel(zipf_counts(n8, 100_000_000), lookup=args.pop_lookup).to(dev)
                     b8p = {}
@@ -487,11 +574,11 @@ def main():
                                                        **ps8.lookup_kwargs())
                     t8p = time_gpu_best(st8p, 50, 5) * 1e3
                     alg8p = bytes_per_triplet(d, n, True, fused_loss=True) * B * n
-                    res8['popular,n=64,B=65536'] = {'ms': round(t8p, 4), 'M_triplets_s': round(B * n / t8p / 1e3, 1),
-                                                     'alg_GBs': round(alg8p / t8p / 1e6, 1),
-                                                     'frac_of_hbm_peak': round(alg8p / t8p / 1e6 / HBM_PEAK_GBS, 4),
-                                                     'lookup': 'bucket lines 2^%d x 128 B' % ps8.lines_log2 if ps8.lines_log2
-                                                     else 'lut 2^%d' % ps8.guide_log2}
+                    res8['popular,n=64,B=65536'] = with_profile(
+                        {'ms': round(t8p, 4), 'M_triplets_s': round(B * n / t8p / 1e3, 1), 'alg_GBs': round(alg8p / t8p / 1e6, 1),
+                         'frac_of_hbm_peak': round(alg8p / t8p / 1e6 / HBM_PEAK_GBS, 4),
+                         'lookup': 'bucket lines 2^%d x 128 B' % ps8.lines_log2 if ps8.lines_log2 else 'lut 2^%d' % ps8.guide_log2},
+                        'N1e8_popular_n64_B65536', alg8p)
                     del ps8, b8p
                 except Exception as e:
                     res8['popular,n=64,B=65536'] = {'error': repr(e)[:200]}
@@ -503,8 +590,9 @@ def main():
             except Exception as e:
                 extra['table_100M'] = {'error': repr(e)[:200]}
         # the multi-GPU workload (configs[3]) on ONE rank: a 12.5 M-row block (1/8 of the 100 M-item table), n = 1024,
-        # B = 4096 through the sharded step with a world-size-1 RCCL group -- the N = 1 reference point of the
-        # `--gpus N` line (same code path, same per-GPU shape)
+        # B = 4096 through the sharded step -- the N = 1 reference point of the `--gpus N` line (same code path, same per-GPU
+        # shape).  With one rank every collective of the step is the identity and is skipped; `with_collectives_ms` forces
+        # them through a world-size-1 RCCL group (what the step's own all-gather / all-to-all launches cost without a wire)
         if not args.no_sweep and args.dim == 128:
             try:
                 import torch.distributed as dist1
@@ -516,20 +604,27 @@ def main():
                 n_blk, n1k, b1k = 12_500_001, 1024, 4096
                 blk = torch.empty(n_blk, d, device=dev).normal_(0, 0.02, generator=torch.Generator(device=dev).manual_seed(9))
                 blk[0] = 0
-                tbl = shard.ShardedItemTable(blk, shard.RowShardPlan(n_blk, 1), 0, dist1, check_every=0)
                 us = ra.UniformSampler(n_blk)
                 u1, p1 = uid[:b1k].contiguous(), torch.randint(1, n_blk, (b1k,), device=dev, generator=gen)
+                res1 = {}
+                for key, force in (('ms_per_step', False), ('with_collectives_ms', True)):
+                    tbl = shard.ShardedItemTable(blk, shard.RowShardPlan(n_blk, 1), 0, dist1, check_every=0, force_collectives=force)
 
-                def st1():
-                    o = tbl.sample_and_score(user, u1, p1, n1k, us)
-                    return ra.ops.pairwise_loss(nat.LOSS_BPR, o['pos_score'], o['neg_score'], want_grad=True)
-                st1()
-                t1 = time_gpu(st1, 50, 5) * 1e3
-                tbl.check_overflow()
-                extra['sharded_world1'] = {'workload': f'configs[3] per-GPU shape on one rank: {n_blk}-row block, neg={n1k}, '
-                                           f'B={b1k}, uniform sampler, sharded step at world size 1 (RCCL)',
-                                           'ms_per_step': round(t1, 4), 'M_triplets_s': round(b1k * n1k / t1 / 1e3, 2),
-                                           'frac_of_hbm_peak': round(bytes_per_triplet(d, n1k, False) * b1k * n1k / t1 / 1e6 / HBM_PEAK_GBS, 4)}
+                    def st1(tbl=tbl):     # sample + route + (exchange) + owner-side score + (exchange) + gather home + BPR loss + gradient
+                        return tbl.sample_and_score(user, u1, p1, n1k, us, fused_loss='bpr', want_ids=False, want_grad=True)
+                    st1()
+                    res1[key] = time_gpu(st1, 50, 5) * 1e3
+                    tbl.check_overflow()
+                t1 = res1['ms_per_step']
+                alg1 = bytes_per_triplet(d, n1k, False) * b1k * n1k
+                extra['sharded_world1'] = with_profile(
+                    {'workload': f'configs[3] per-GPU shape on one rank: {n_blk}-row block, neg={n1k}, B={b1k}, uniform sampler drawn in '
+                                 'the routing launch, fixed-capacity exchange v2, fused home kernel (scores, BPR loss, d loss/d score)',
+                     'ms_per_step': round(t1, 4), 'M_triplets_s': round(b1k * n1k / t1 / 1e3, 2),
+                     'frac_of_hbm_peak': round(alg1 / t1 / 1e6 / HBM_PEAK_GBS, 4),
+                     'with_collectives_ms': round(res1['with_collectives_ms'], 4),
+                     'kernels_per_step': 'embedding_gather, shard_sample_route, fused_fwd_kernel (segment form), shard_home'},
+                    'sharded_world1_scoring_kernel', alg1)
                 del blk, tbl
             except Exception as e:
                 extra['sharded_world1'] = {'error': repr(e)[:200]}
@@ -539,11 +634,13 @@ def main():
                     f'popularity, {args.sampler} sampler neg={n}, InnerProduct + BPR loss, B={B} queries/step '
                     f'(BASELINE.json configs[1])')
         if rank == 0 and not args.no_cpu_baseline:
-            extra['cpu_baseline'] = cpu_baseline(args, counts, d, min(B, 16384), n)
-            extra['cpu_baseline']['sample'] += (f'; NOTE the CPU sample runs B={min(B, 16384)} queries/step, the GPU headline '
-                                                f'B={B} (triplets/s is per-triplet work, the batch only bounds the sample)')
+            extra['cpu_baseline'] = cpu_baseline(args, counts, d, B, n)
     else:
-        # BASELINE.json configs[3]: the item table row-sharded over the ranks, ids out / scores back by RCCL all-to-all
+        # BASELINE.json configs[3]: the item table row-sharded over the ranks, ids out / scores back by RCCL all-to-all.
+        # How to read the line: `value` = world * B * n / ms_per_step of the SINGLE-slice step (K steps, barrier-bracketed,
+        # MAX over ranks); `world1_reference` = the identical per-GPU shape (same row block, same B, same n) timed IN THIS
+        # JOB on every rank alone (a one-rank table: no collectives), MAX over ranks; `efficiency_vs_world1` = that time /
+        # ms_per_step, i.e. the weak-scaling efficiency of the exchange itself, independent of the configs[1] N = 1 line.
         from recstudio_amd import shard
         plan = shard.RowShardPlan(args.items, world)
         lo, hi = plan.bounds(rank)
@@ -553,45 +650,70 @@ def main():
             item_local[0] = 0
         user = torch.empty(args.users, d, device=dev).normal_(0, 0.02, generator=torch.Generator(device=dev).manual_seed(3))
         sampler = (ra.PopularSamplerModel(counts, lookup=args.pop_lookup) if popular else ra.UniformSampler(args.items)).to(dev)
+
         def make_step(tbl, smp, u, p, nn):
-            def step():
-                o = tbl.sample_and_score(user, u, p, nn, smp)
-                return ra.ops.pairwise_loss(nat.LOSS_BPR, o['pos_score'], o['neg_score'], want_grad=True)
+            def step():      # sample + route, key exchange, owner-side score, score exchange, gather home + BPR loss + gradient
+                return tbl.sample_and_score(user, u, p, nn, smp, fused_loss='bpr', want_ids=False, want_grad=True)
             return step
+
+        def max_over_ranks(ms):
+            t = torch.tensor([ms], device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.item())
+
+        # ---- the world-1 reference, in this job: every rank alone on its own block (rows re-based to a one-rank plan)
+        solo_plan = shard.RowShardPlan(hi - lo, 1)
+        solo_pos = (pos % (hi - lo - 1)) + 1
+        solo_sampler = (ra.PopularSamplerModel(counts[lo:hi], lookup=args.pop_lookup) if popular else ra.UniformSampler(hi - lo)).to(dev)
+        solo_tbl = shard.ShardedItemTable(item_local, solo_plan, 0, dist, check_every=0)
+        solo_step = make_step(solo_tbl, solo_sampler, uid, solo_pos, n)
+        solo_step()
+        ms_solo = max_over_ranks(time_gpu(solo_step, args.steps, args.warmup, dist) * 1e3)
+        solo_tbl.check_overflow()
+        del solo_tbl, solo_sampler
+
         def measure(chunks):
-            """K timed steps (barrier + synchronize on both sides, MAX over ranks) of the sharded step with the queries
-            cut into `chunks` pipelined slices; collectively checked for dropped elements, retried with more slack."""
+            """K timed steps (barrier + synchronize on both sides, MAX over ranks) of the sharded step with the step's
+            elements cut into `chunks` pipelined slices; checked for dropped elements (the count is job-wide on every
+            rank), retried with more slack."""
             for slack in (1.08, 1.3, 2.0):
-                # check_every=0: no overflow check inside the timed region; the collective check below covers all of it
-                tbl = shard.ShardedItemTable(item_local, plan, rank, dist, slack=slack, check_every=0, chunks=chunks)
+                # check_every=0: no overflow check inside the timed region; the check below covers all of it
+                tbl = shard.ShardedItemTable(item_local, plan, rank, dist, slack=slack, check_every=0, chunks=chunks,
+                                             force_collectives=True)
                 step = make_step(tbl, sampler, uid, pos, n)
-                step()                   # calibration step of the fixed-capacity exchange (exact split sizes, once)
+                step()                   # calibration launch of the fixed-capacity exchange (exact counts, once) + first step
                 ms = time_gpu(step, args.steps, args.warmup, dist) * 1e3
                 try:
-                    tbl.check_overflow() # collective: nothing was dropped on any rank during the timed steps
+                    tbl.check_overflow() # nothing was dropped on any rank during the timed steps (same value everywhere)
                     break
                 except RuntimeError:     # raised on every rank alike: time again with more slack
                     continue
-            t = torch.tensor([ms], device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            return float(t.item()), tbl
+            return max_over_ranks(ms), tbl
 
-        def set_headline(ms, chunks):
-            alg = bytes_per_triplet(d, n, popular) * B * n
-            achieved = alg / (ms * 1e-3) / 1e9
-            what = ('whole sharded step (per GPU): sample, route, key all-to-all, owner-side gather+score, score '
-                    'all-to-all, scatter, loss' + (f'; queries in {chunks} pipelined slices' if chunks > 1 else ''))
-            return world * B * n / ms / 1e3, {'bound': 'hbm', 'kernel': what, 'achieved': round(achieved, 1),
-                                              'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                                              'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': None}
         ms_step, table = measure(1)
-        value, roofline = set_headline(ms_step, 1)
-        slices_used = 1
-        extra['exchange'] = {'mode': table.exchange, 'slack': table.slack, 'capacity_per_owner': table._cap.get((B, n)),
-                             'mean_per_owner': B * (n + 1) // world,
-                             'what': 'equal-split all-to-all of fixed-capacity segments, empty slots = -1 keys; no split '
-                                     'sizes on the host (one calibration step before the timed region)'}
-
+        alg = bytes_per_triplet(d, n, popular) * B * n
+        achieved = alg / (ms_step * 1e-3) / 1e9
+        value = world * B * n / ms_step / 1e3
+        roofline = {'bound': 'hbm', 'kernel': 'whole sharded step (per GPU): embedding_gather + all-gather, shard_sample_route, key '
+                    'all-to-all, fused_fwd_kernel on the received segments, score all-to-all, shard_home (scores + BPR + gradient)',
+                    'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4),
+                    'traffic': None}
+        try:
+            rccl = '.'.join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:
+            rccl = 'unknown'
+        extra.update({
+            'per_gpu_M_triplets_s': round(B * n / ms_step / 1e3, 2),
+            'world1_reference': {'ms_per_step': round(ms_solo, 4), 'per_gpu_M_triplets_s': round(B * n / ms_solo / 1e3, 2),
+                                 'what': 'the same per-GPU shape (own row block, same B and n, same step) on every rank ALONE, '
+                                         'timed in this job before the N-rank measurement, MAX over ranks'},
+            'efficiency_vs_world1': round(ms_solo / ms_step, 4),
+            'ranks_seen': int(dist.get_world_size()), 'backend': 'staged-gloo (test harness)' if staged else 'nccl (RCCL)',
+            'rccl_version': rccl,
+            'exchange': {'mode': table.exchange, 'slack': table.slack, 'capacity_per_segment': table._cap.get((B, n, 1)),
+                         'mean_per_owner': B * (n + 1) // world,
+                         'what': 'equal-split all-to-all of fixed-capacity, self-describing segments ({live, dropped} header + '
+                                 '8-byte keys); no split sizes on the host (one calibration launch before the timed region)'}})
         parallelism = f'item-table row-sharded x{world} + RCCL all-to-all (ids out, scores back)'
         workload = (f'two-tower d={d}, {args.items}-item table row-sharded over {world} GPUs, {args.sampler} sampler '
                     f'neg={n}, InnerProduct + BPR loss, B={B} queries/step/GPU (BASELINE.json configs[3])')
@@ -616,30 +738,26 @@ def main():
 
         def timed_max(fn, steps, warm):
             fn()
-            v = torch.tensor([time_gpu(fn, steps, warm, dist) * 1e3], device=dev)
-            dist.all_reduce(v, op=dist.ReduceOp.MAX)
-            return float(v.item())
-        # The same K steps with the queries cut into 2 / 4 slices whose exchanges overlap the scoring of the neighbouring
-        # slices (ShardedItemTable(chunks=...)): the line reports the fastest of the complete, checked measurements.
+            return max_over_ranks(time_gpu(fn, steps, warm, dist) * 1e3)
+        # The same K steps with the step cut into 2 / 4 slices whose exchanges overlap the scoring of the neighbouring
+        # slices (ShardedItemTable(chunks=...)): reported BESIDE the headline, which stays the single-slice time
         try:
             tried = {'1': round(ms_step, 4)}
             for c in (2, 4):
-                if B % c:
-                    continue
-                ms_c, tbl_c = measure(c)
+                ms_c, _ = measure(c)
                 tried[str(c)] = round(ms_c, 4)
-                if ms_c < ms_step:                  # same value on every rank (all-reduced)
-                    ms_step, slices_used, table, (value, roofline) = ms_c, c, tbl_c, set_headline(ms_c, c)
-            extra['pipelined_slices'] = {'ms_per_step_by_slices': tried, 'used': slices_used}
-            if slices_used > 1:
-                parallelism += f', queries in {slices_used} pipelined slices'
+            extra['pipelined_slices'] = {'ms_per_step_by_slices': tried,
+                                         'what': 'side figure: the headline is the 1-slice time whatever these say'}
         except Exception as e:
             extra['pipelined_slices'] = {'error': repr(e)[:200]}
         # the exact (variable-split, host read-back) exchange
         try:
-            exact = shard.ShardedItemTable(item_local, plan, rank, dist, exchange='exact', check_every=0)
-            ms_e = timed_max(make_step(exact, sampler, uid, pos, n), max(10, args.steps // 4), 5)
-            extra['exact_exchange_ms_per_step'] = round(ms_e, 4)
+            exact = shard.ShardedItemTable(item_local, plan, rank, dist, exchange='exact', check_every=0, force_collectives=True)
+
+            def exact_step():
+                o = exact.sample_and_score(user, uid, pos, n, sampler)
+                return ra.ops.pairwise_loss(nat.LOSS_BPR, o['pos_score'], o['neg_score'], want_grad=True)
+            extra['exact_exchange_ms_per_step'] = round(timed_max(exact_step, max(10, args.steps // 4), 5), 4)
         except Exception as e:
             extra['exact_exchange_ms_per_step'] = repr(e)[:200]
         # the single-GPU workload's shape (n = 64, B = 65536: same triplets per GPU per step, 16x larger query gather)
@@ -672,7 +790,7 @@ def main():
     if rank == 0 and not emitted:
         print(json.dumps(headline_line(value, ms_step, workload, parallelism, roofline, extra)), flush=True)
     if dist is not None:
-        dist.destroy_process_group()
+        getattr(dist, 'd', dist).destroy_process_group()
 
 
 if __name__ == '__main__':

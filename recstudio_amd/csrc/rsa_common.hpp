@@ -72,6 +72,9 @@ __device__ __forceinline__ uint4 philox_for_element(const PhiloxCall& pc, uint64
   if (li < pc.grid_threads) {   // common case: every element on its own subsequence, first draw
     idx = li;
     j = 0;
+  } else if ((li >> 32) == 0) {  // 32-bit quotient (the 64-bit one is a ~100-instruction subroutine, once per element)
+    j = (uint32_t)li / pc.grid_threads;
+    idx = li - j * pc.grid_threads;
   } else {
     j = li / pc.grid_threads;
     idx = li - j * pc.grid_threads;
@@ -98,7 +101,7 @@ __device__ __forceinline__ int64_t torch_randint_element(const PhiloxCall& pc, u
     return (int64_t)(r % range) + low;
   }
   const uint4 v = philox_for_element<4>(pc, li, comp);
-  return (int64_t)((uint64_t)pick(v, comp) % range) + low;
+  return (int64_t)(pick(v, comp) % (uint32_t)range) + low;      // range < 2^28 here: a 32-bit remainder, not the 64-bit subroutine
 }
 
 // == element li of torch.rand(..., device='cuda', dtype=float32)

@@ -536,14 +536,7 @@ __global__ __launch_bounds__(256, QG ? RSA_QG_MIN_WAVES : RSA_FWD_MIN_WAVES) voi
       const float4 pv = px.v[0];
       qacc.x = __fmaf_rn(-tg, pv.x, qacc.x); qacc.y = __fmaf_rn(-tg, pv.y, qacc.y);
       qacc.z = __fmaf_rn(-tg, pv.z, qacc.z); qacc.w = __fmaf_rn(-tg, pv.w, qacc.w);
-      if (lane < LPR) {
-        float* g = p.qgrad + (size_t)m_lane * D + sub * 4;
-        if (n == 64) {
-          *reinterpret_cast<float4*>(g) = qacc;
-        } else {
-          atomicAdd(g + 0, qacc.x); atomicAdd(g + 1, qacc.y); atomicAdd(g + 2, qacc.z); atomicAdd(g + 3, qacc.w);
-        }
-      }
+      if (lane < LPR) *reinterpret_cast<float4*>(p.qgrad + (size_t)m_lane * D + sub * 4) = qacc;    // n == 64: one tile per query
     } else if constexpr (RSA_FWD_PLAIN_PIPE && QU && !COS && !GENERIC) {
       tile_rows_pipe<LPR, NT>(p.item_table, id, qf, dot);
     } else {
@@ -583,14 +576,9 @@ __global__ __launch_bounds__(256, QG ? RSA_QG_MIN_WAVES : RSA_FWD_MIN_WAVES) voi
             if (p.dneg) st_out(&p.dneg[e], sg);
             const float tl = group_sum<64>(ls * w), tg = group_sum<64>(sg);
             wave_loss -= tl;
-            if (lane == 0) {
-              if (n == 64) {   // one tile per query: plain stores, deterministic
-                p.row_loss[m_lane] = -tl;
-                if (p.dpos) p.dpos[m_lane] = -tg;
-              } else {         // several tiles per query: accumulate (buffers zeroed by the host wrapper)
-                atomicAdd(p.row_loss + m_lane, -tl);
-                if (p.dpos) atomicAdd(p.dpos + m_lane, -tg);
-              }
+            if (lane == 0) {   // one tile per query (n == 64; longer queries run fused_bpr_walk_kernel): plain stores
+              p.row_loss[m_lane] = -tl;
+              if (p.dpos) p.dpos[m_lane] = -tg;
             }
           }
         }
@@ -793,6 +781,159 @@ __global__ __launch_bounds__(256) void fused_ssm_kernel(const FwdParams p) {
   if (p.loss_out != nullptr) reduce_mean_loss(wave_loss, p.loss_out, p.done_counter, p.loss_partials, p.n_queries);
 }
 
+// ------------------------------------------------------------------ BPR epilogue for queries longer than one tile
+// fused_loss = 1 with num_neg = 64 * T, T > 1.  The first version ran the tile-parallel kernel above and let the T tiles
+// of a query meet in float atomics on row_loss / dpos / query_grad (plus three memsets): not reproducible.  Here a
+// query belongs to ONE workgroup: WPQ = min(4, largest power of two <= T) of its waves share the query's tiles
+// round-robin, each carrying its sums in registers, and wave 0 of the query adds the partials in wave order through
+// LDS -- fixed order, no atomics, nothing to zero.  BPR needs no second pass over the tiles (the positive score is known
+// before the first negative): d loss/d neg is final when it is written.
+#ifndef RSA_WALK_TRANSPOSE
+#define RSA_WALK_TRANSPOSE 0     // 1: forward-only tiles through the transposed fold of tile_rows instead of butterfly sums
+#endif
+template <int LPR, bool NT, bool QG>
+__global__ __launch_bounds__(256) void fused_bpr_walk_kernel(const FwdParams p, const int wpq_log2) {
+  using F = Frag<LPR, false>;
+  constexpr int D = LPR * 4;
+  __shared__ float s_sum[4][2];
+  __shared__ float s_q[QG ? 4 : 1][QG ? D : 1];
+  const int lane = lane_id();
+  const int sub = lane % LPR;
+  const int wave = threadIdx.x >> 6;
+  const int64_t n = p.num_neg;
+  const int T = (int)(n >> 6);
+  const int wpq = 1 << wpq_log2, qpb = 4 >> wpq_log2;
+  const int qslot = wave >> wpq_log2, part = wave & (wpq - 1);
+  PhiloxCall pc = p.pc;
+  if (p.offset_dev != nullptr) pc.offset4 = *p.offset_dev >> 2;
+  const float w = 1.f / (float)n, inv_m = 1.f / (float)p.n_queries;
+  const bool popular = p.sampler == RSA_SAMPLER_POPULAR;
+  const int64_t groups = (p.n_queries + qpb - 1) / qpb;
+  float wave_loss = 0.f;
+  for (int64_t grp = blockIdx.x; grp < groups; grp += gridDim.x) {
+    const int64_t m = grp * qpb + qslot;
+    const bool valid = m < p.n_queries;                      // wave-uniform
+    float lsum = 0.f, gsum = 0.f, pos_s = 0.f;
+    float4 qacc = make_float4(0.f, 0.f, 0.f, 0.f);
+    F qf, px;
+    int64_t pid = 0;
+    if (valid) {
+      const int64_t qrow = p.query_index ? p.query_index[m] : m;
+      pid = p.pos_ids[m];
+      const bool pad = pid == 0;
+      pid = pid < 0 ? 0 : (pid >= p.n_items ? p.n_items - 1 : pid);
+      frag_load<LPR, false>(qf, p.query + (size_t)qrow * D, sub, D);
+      frag_load<LPR, false>(px, p.item_table + (size_t)pid * D, sub, D);
+      pos_s = group_sum<LPR>(frag_dot<LPR, false>(px, qf));
+      if (p.mask_pad_pos && pad) pos_s = -INFINITY;
+#pragma unroll 1
+      for (int t = part; t < T; t += wpq) {
+        const int64_t e = m * n + ((int64_t)t << 6) + lane;
+        int32_t id;
+        if (p.sampler == RSA_SAMPLER_UNIFORM) {
+          id = (int32_t)torch_randint_element(pc, (uint64_t)e, (uint64_t)(p.n_items - 1), 1);
+          st_out(&p.neg_ids[e], (int64_t)id);
+        } else if (popular) {
+          float pr;
+          id = lookup_popular(p, torch_rand_element(pc, (uint64_t)e), pr);
+          st_out(&p.neg_ids[e], (int64_t)id);
+          if (p.neg_logp) st_out(&p.neg_logp[e], logf(pr));
+        } else {
+          int64_t g = p.neg_ids[e];
+          g = g < 0 ? 0 : (g >= p.n_items ? p.n_items - 1 : g);
+          id = (int32_t)g;
+        }
+        float dot;
+        if constexpr (QG) {
+          tile_rows_qg<LPR, NT>(p.item_table, id, qf, pos_s, w, inv_m, dot, qacc);
+        } else if constexpr (RSA_WALK_TRANSPOSE) {
+          float in2, qn2;
+          tile_rows<LPR, false, false, true, NT>(p.item_table, D, id, p.query, 0, qf, dot, in2, qn2);
+        } else {
+          tile_rows_pipe<LPR, NT>(p.item_table, id, qf, dot);
+        }
+        st_out(&p.neg_score[e], dot);
+        const float xd = pos_s - dot;
+        const float tt = __expf(-fabsf(xd));
+        lsum += (fminf(xd, 0.f) - __logf(1.f + tt)) * w;
+        const float sg = bpr_dneg(pos_s, dot, w, inv_m);
+        if (p.dneg) st_out(&p.dneg[e], sg);
+        gsum += sg;
+      }
+      lsum = group_sum<64>(lsum);
+      gsum = group_sum<64>(gsum);
+      if constexpr (QG) {
+#pragma unroll
+        for (int mk = LPR; mk < 64; mk <<= 1) {
+          qacc.x += __shfl_xor(qacc.x, mk, 64); qacc.y += __shfl_xor(qacc.y, mk, 64);
+          qacc.z += __shfl_xor(qacc.z, mk, 64); qacc.w += __shfl_xor(qacc.w, mk, 64);
+        }
+      }
+    }
+    if (wpq > 1) {         // block-uniform: the partials of a query's waves meet in LDS, added in wave order
+      if (part != 0) {
+        if (lane == 0) {
+          s_sum[wave][0] = lsum;
+          s_sum[wave][1] = gsum;
+        }
+        if constexpr (QG) {
+          if (lane < LPR) *reinterpret_cast<float4*>(&s_q[wave][sub * 4]) = qacc;
+        }
+      }
+      __syncthreads();
+      if (part == 0) {
+        for (int k = 1; k < wpq; ++k) {
+          lsum += s_sum[wave + k][0];
+          gsum += s_sum[wave + k][1];
+          if constexpr (QG) {
+            if (lane < LPR) {
+              const float4 o = *reinterpret_cast<const float4*>(&s_q[wave + k][sub * 4]);
+              qacc.x += o.x; qacc.y += o.y; qacc.z += o.z; qacc.w += o.w;
+            }
+          }
+        }
+      }
+      __syncthreads();     // the slots are rewritten in the next iteration
+    }
+    if (valid && part == 0) {
+      wave_loss -= lsum;
+      if (lane == 0) {
+        p.pos_score[m] = pos_s;
+        if (popular && p.pos_logp) p.pos_logp[m] = logf(p.pop_prob[pid]);
+        p.row_loss[m] = -lsum;
+        if (p.dpos) p.dpos[m] = -gsum;
+      }
+      if constexpr (QG) {
+        const float4 pv = px.v[0];        // d loss/d query = sum_j dneg_j item_j + dpos item_pos, dpos = -sum_j dneg_j
+        qacc.x = __fmaf_rn(-gsum, pv.x, qacc.x); qacc.y = __fmaf_rn(-gsum, pv.y, qacc.y);
+        qacc.z = __fmaf_rn(-gsum, pv.z, qacc.z); qacc.w = __fmaf_rn(-gsum, pv.w, qacc.w);
+        if (lane < LPR) *reinterpret_cast<float4*>(p.qgrad + (size_t)m * D + sub * 4) = qacc;
+      }
+    }
+  }
+  if (p.loss_out != nullptr) reduce_mean_loss(wave_loss, p.loss_out, p.done_counter, p.loss_partials, p.n_queries);
+}
+
+template <int LPR>
+static int launch_bpr_walk(const FwdParams& p, hipStream_t stream) {
+  const bool nt = (size_t)p.n_items * p.dim * sizeof(float) > (512ull << 20);
+  const int T = p.num_neg >> 6;
+  const int wpq_log2 = T >= 4 ? 2 : (T >= 2 ? 1 : 0);
+  const int qpb = 4 >> wpq_log2;
+  int64_t blocks = (p.n_queries + qpb - 1) / qpb;
+  if (blocks > RSA_FWD_GRID_CAP) blocks = RSA_FWD_GRID_CAP;
+  dim3 grid((unsigned)blocks), block(256);
+  if (p.qgrad != nullptr) {
+    if (nt) hipLaunchKernelGGL((fused_bpr_walk_kernel<LPR, true, true>), grid, block, 0, stream, p, wpq_log2);
+    else hipLaunchKernelGGL((fused_bpr_walk_kernel<LPR, false, true>), grid, block, 0, stream, p, wpq_log2);
+  } else {
+    if (nt) hipLaunchKernelGGL((fused_bpr_walk_kernel<LPR, true, false>), grid, block, 0, stream, p, wpq_log2);
+    else hipLaunchKernelGGL((fused_bpr_walk_kernel<LPR, false, false>), grid, block, 0, stream, p, wpq_log2);
+  }
+  RSA_CHECK_LAUNCH("rsa_fused_sample_gather_score(bpr walk)");
+  return RSA_OK;
+}
+
 template <int LPR>
 static int launch_ssm(const FwdParams& p, hipStream_t stream) {
   const bool nt = (size_t)p.n_items * p.dim * sizeof(float) > (512ull << 20);
@@ -991,16 +1132,19 @@ extern "C" int rsa_fused_sample_gather_score(const rsa_fused_args* a, rsa_stream
       default: return launch_ssm<64>(p, s);
     }
   }
-  if (bpr && a->num_neg != 64) {
-    hipError_t e1 = hipMemsetAsync(a->row_loss, 0, sizeof(float) * a->n_queries, s);
-    hipError_t e2 = a->dpos ? hipMemsetAsync(a->dpos, 0, sizeof(float) * a->n_queries, s) : hipSuccess;
-    if (e1 == hipSuccess && e2 == hipSuccess && p.qgrad)
-      e1 = hipMemsetAsync(p.qgrad, 0, sizeof(float) * a->n_queries * a->dim, s);
-    if (e1 != hipSuccess || e2 != hipSuccess) {
-      rsa::set_error("rsa_fused_sample_gather_score: memset failed");
-      return RSA_ERR_HIP;
+  if (bpr && a->num_neg != 64 && !cos && a->packed_keys == nullptr &&
+      (a->dim == 32 || a->dim == 64 || a->dim == 128 || a->dim == 256)) {
+    // queries longer than one tile: the workgroup-per-query walk (deterministic, no atomics, nothing to zero)
+    switch (a->dim) {
+      case 32: return launch_bpr_walk<8>(p, s);
+      case 64: return launch_bpr_walk<16>(p, s);
+      case 128: return launch_bpr_walk<32>(p, s);
+      default: return launch_bpr_walk<64>(p, s);
     }
   }
+  RSA_CHECK_ARG(!bpr || a->num_neg == 64,
+                "rsa_fused_sample_gather_score: the BPR epilogue with num_neg > 64 needs the inner-product scorer and dim in "
+                "{32, 64, 128, 256}");
   switch (a->dim) {
     case 32: rc = launch_fwd<8, false>(p, cos, qu, s); break;
     case 64: rc = launch_fwd<16, false>(p, cos, qu, s); break;

@@ -29,6 +29,26 @@ static inline FastDiv make_fastdiv(uint64_t d) {
   return f;
 }
 
+// x / d for 32-bit x by ONE 32-bit multiply-high and a correction: with magic = floor(2^32 / d) the estimate
+// floor(x * magic / 2^32) is the quotient or one below it (x * magic / 2^32 > x / d - x / 2^32 > x / d - 1).  The
+// routing kernel divides four times per element (query of an element, owner of an id, modulo of the uniform draw): the
+// 64-bit forms (a 64 x 64 multiply-high is four quarter-rate multiplies, a 64-bit % a ~150-instruction subroutine)
+// were most of its time.
+struct Div32 {
+  uint32_t d, magic;
+  __device__ __forceinline__ uint32_t div(uint32_t x) const {
+    const uint32_t q = __umulhi(x, magic);
+    return (x - q * d >= d) ? q + 1 : q;
+  }
+  __device__ __forceinline__ uint32_t mod(uint32_t x) const { return x - div(x) * d; }
+};
+static inline Div32 make_div32(uint64_t d) {
+  Div32 v;
+  v.d = (uint32_t)d;
+  v.magic = d <= 1 ? 0xffffffffu : (uint32_t)((1ull << 32) / d);
+  return v;
+}
+
 struct RouteShape {
   const int64_t* pos_ids;
   const int64_t* neg_ids;
@@ -242,7 +262,7 @@ struct RouteV2 {
   uint64_t k_lo;           // first Philox counter step (li / T / U) this rank's elements touch
   PhiloxCall pc;
   PopTables pop;
-  FastDiv by_width, by_rows, by_n, by_gt;
+  Div32 by_width, by_rows, by_n, by_gt, by_range;
   int32_t n, G, sampler, n_slices, unroll;
 };
 
@@ -264,7 +284,7 @@ __global__ __launch_bounds__(256) void shard_sample_route_kernel(const RouteV2 a
 #pragma unroll
     for (int c = 0; c < 4; ++c) gl[r * 4 + c] = -1;
     if (w < a.n_groups) {
-      const uint64_t kq = a.by_gt.div((uint64_t)w);
+      const uint64_t kq = a.by_gt.div((uint32_t)w);
       const uint64_t idx = (uint64_t)w - kq * T;
       const uint64_t kk = a.k_lo + kq;
       uint4 v = make_uint4(0, 0, 0, 0);
@@ -285,7 +305,7 @@ __global__ __launch_bounds__(256) void shard_sample_route_kernel(const RouteV2 a
             const uint64_t r64 = c == 0 ? (((uint64_t)v.x << 32) | v.y) : (((uint64_t)v.z << 32) | v.w);
             id = (int64_t)(r64 % range) + 1;
           } else {
-            id = (int64_t)((uint64_t)pick(v, c) % range) + 1;
+            id = (int64_t)a.by_range.mod(pick(v, c)) + 1;
           }
           if (!COUNT_ONLY && a.neg_ids != nullptr) a.neg_ids[flat] = id;
         } else if (a.sampler == RSA_SAMPLER_POPULAR) {
@@ -301,11 +321,11 @@ __global__ __launch_bounds__(256) void shard_sample_route_kernel(const RouteV2 a
         } else {
           id = a.neg_ids[flat];
         }
-        const int64_t m = (int64_t)a.by_n.div((uint64_t)flat);
+        const int64_t m = (int64_t)a.by_n.div((uint32_t)flat);
         el[r * 4 + c] = (int32_t)(flat + m + 1);               // = m * (n + 1) + 1 + (flat - m * n)
         int g = 0;
         if (a.G > 1) {
-          const int64_t q = id < 0 ? 0 : (int64_t)a.by_rows.div((uint64_t)id);
+          const int64_t q = id < 0 ? 0 : (int64_t)a.by_rows.div((uint32_t)id);
           g = q >= a.G ? a.G - 1 : (int)q;
         }
         const int64_t loc = id - (int64_t)g * a.rows_per_shard;
@@ -322,7 +342,7 @@ __global__ __launch_bounds__(256) void shard_sample_route_kernel(const RouteV2 a
       el[r * 4] = (int32_t)(m * (a.n + 1));
       int g = 0;
       if (a.G > 1) {
-        const int64_t q = id < 0 ? 0 : (int64_t)a.by_rows.div((uint64_t)id);
+        const int64_t q = id < 0 ? 0 : (int64_t)a.by_rows.div((uint32_t)id);
         g = q >= a.G ? a.G - 1 : (int)q;
       }
       const int64_t loc = id - (int64_t)g * a.rows_per_shard;
@@ -355,7 +375,7 @@ __global__ __launch_bounds__(256) void shard_sample_route_kernel(const RouteV2 a
         a.slot_of[el[k]] = -1;
         continue;
       }
-      const int64_t m = (int64_t)a.by_width.div((uint64_t)el[k]);
+      const int64_t m = (int64_t)a.by_width.div((uint32_t)el[k]);
       const int64_t at = (int64_t)gk * a.stride + RSA_SHARD_HDR + slot;
       seg0[at] = ((a.query_base + m) << 32) | (int64_t)local[k];
       a.slot_of[el[k]] = (int32_t)((int64_t)slice * a.G * a.stride + at);
@@ -774,10 +794,11 @@ extern "C" int rsa_shard_sample_route(const rsa_shard_route_args* a, rsa_stream_
   r.k_lo = k_lo;
   r.n_groups = n_neg > 0 ? (int64_t)((k_hi - k_lo + 1) * T) : 0;
   RSA_CHECK_ARG(r.n_groups + a->n_queries < (1ll << 32), "rsa_shard_sample_route: too many work items");
-  r.by_width = make_fastdiv((uint64_t)a->num_neg + 1);
-  r.by_rows = make_fastdiv((uint64_t)a->rows_per_shard);
-  r.by_n = make_fastdiv((uint64_t)(a->num_neg > 0 ? a->num_neg : 1));
-  r.by_gt = make_fastdiv(T);
+  r.by_width = make_div32((uint64_t)a->num_neg + 1);
+  r.by_rows = make_div32((uint64_t)a->rows_per_shard);
+  r.by_n = make_div32((uint64_t)(a->num_neg > 0 ? a->num_neg : 1));
+  r.by_gt = make_div32(T);
+  r.by_range = make_div32((uint64_t)(a->n_items - 1));        // 32-bit draws only (ranges below 2^28)
   int64_t blocks = (r.n_groups + a->n_queries + ROUTE_ITEMS_PER_BLOCK - 1) / ROUTE_ITEMS_PER_BLOCK;
   if (blocks < a->n_slices) blocks = a->n_slices;         // every slice owns at least one workgroup
   RSA_CHECK_ARG(blocks < (1ll << 31), "rsa_shard_sample_route: grid too large");

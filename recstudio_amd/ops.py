@@ -344,6 +344,14 @@ def fused_forward(item_table, query, num_neg, *, query_index=None, pos_ids=None,
     else:
         a.neg_ids, a.neg_logp, a.pos_logp = ptr(neg_ids), ptr(out.get('neg_logp')), ptr(out.get('pos_logp'))
     a.pos_score, a.neg_score = ptr(out.get('pos_score')), ptr(out['neg_score'])
+    if fused_loss == 'bpr' and n != 64 and (dim not in (32, 64, 128, 256) or a.score_mode != nat.SCORE_IP):
+        # queries longer than one tile are walked by one workgroup (no atomics): that kernel covers the stock dims and
+        # the inner product; anything else runs the loss as its own (equally deterministic) launch
+        if want_query_grad:
+            raise ValueError('want_query_grad needs the inner-product scorer and dim in {32, 64, 128, 256}')
+        nat.check(nat.lib().rsa_fused_sample_gather_score(ctypes.byref(a), _stream()), 'rsa_fused_sample_gather_score')
+        out['loss'], out['dpos'], out['dneg'], out['row_loss'] = pairwise_loss(nat.LOSS_BPR, out['pos_score'], out['neg_score'])
+        return out
     if fused_loss is not None:
         if fused_loss not in ('bpr', 'ssm'):
             raise ValueError("fused_loss must be None, 'bpr' or 'ssm'")

@@ -182,6 +182,12 @@ def build_cdf_lines(table: Tensor, pop_prob: Tensor, lines_log2: Optional[int] =
     return lines, lines_log2
 
 
+def _rebuild_derived(module, incompatible_keys):
+    """load_state_dict post-hook of PopularSamplerModel (a module-level function: a lambda in the hook dict would make the
+    module unpicklable -- torch.save(model), mp.spawn arguments)."""
+    module._register_pairs()
+
+
 class PopularSamplerModel(Sampler):
     """recstudio/ann/sampler.py:224-258.  The fp32 tables are built with the very same torch
     CPU ops as the reference's constructor (so they are bit-identical to its registered
@@ -210,7 +216,12 @@ class PopularSamplerModel(Sampler):
             self.register_buffer('table', torch.cumsum(self.pop_prob, dim=0))
             self.pop_prob[-1] = 1.0                                       # sampler.py:241
             self._register_pairs()
-        self.register_load_state_dict_post_hook(lambda module, incompatible: module._register_pairs())
+        self.register_load_state_dict_post_hook(_rebuild_derived)
+
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        # checkpoints of an earlier revision carried the derived `guide` buffer: not part of the state any more
+        state_dict.pop(prefix + 'guide', None)
+        super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
 
     def _use_lines(self):
         if self.lookup == 'auto':
@@ -256,7 +267,7 @@ class PopularSamplerModel(Sampler):
         self.register_buffer('pop_prob', pop_prob.detach().clone().to(torch.float32))
         self.register_buffer('table', table.detach().clone().to(torch.float32))
         self._register_pairs()
-        self.register_load_state_dict_post_hook(lambda module, incompatible: module._register_pairs())
+        self.register_load_state_dict_post_hook(_rebuild_derived)
         return self
 
     def lookup_kwargs(self):

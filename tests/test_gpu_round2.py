@@ -657,3 +657,53 @@ def test_retriever_topk_with_history_longer_than_1024(ra):
     assert (items.cpu() == wi).float().mean() > 0.995          # fp32 near-ties may swap neighbours
     for b in range(B):
         assert not set(items[b].tolist()) & set(hist[b][hist[b] > 0].tolist())
+
+
+# --------------------------------------------------------------------------- BPR epilogue, queries longer than one tile
+@pytest.mark.parametrize('d', [32, 64, 128, 256, 48])
+@pytest.mark.parametrize('n,B', [(128, 301), (192, 64), (1024, 70), (448, 3)])
+def test_fused_bpr_long_queries_deterministic_and_exact(ra, d, n, B):
+    """fused_loss = BPR with num_neg = 64 * T, T > 1: a query's tiles are walked by the waves of ONE
+    workgroup and their partial sums meet in LDS in wave order -- no float atomics, no memsets -- so row_loss, dpos, the
+    in-forward query gradient and the loss are bit-equal run to run, and equal the separate loss kernel / the oracle.
+    d = 48 is outside the walk kernel's dims: the wrapper runs the loss as its own launch (same contract)."""
+    N, U = 20_011, 97
+    iw, uw = _tables(N, U, d, n + d)
+    iwd, uwd = iw.to(DEV), uw.to(DEV)
+    g = torch.Generator().manual_seed(B)
+    uid = torch.randint(1, U, (B,), generator=g).to(DEV)
+    pos = torch.randint(0, N, (B,), generator=g).to(DEV)           # a few padded positives (id 0)
+    neg = torch.randint(1, N, (B, n), generator=g).to(DEV)
+    qg = d != 48
+    runs = [ra.ops.fused_forward(iwd, uwd, n, query_index=uid, pos_ids=pos, neg_ids=neg, fused_bpr=True,
+                                 want_query_grad=qg) for _ in range(3)]
+    keys = ['loss', 'row_loss', 'dpos', 'dneg', 'neg_score', 'pos_score'] + (['query_grad'] if qg else [])
+    for o in runs[1:]:
+        for k in keys:
+            assert torch.equal(o[k], runs[0][k]), k
+    o = runs[0]
+    ps, ns = oracle.retriever_forward(iw, uw[uid.cpu()], pos.cpu(), neg.cpu())
+    rel_close(o['pos_score'].cpu(), ps, rtol=1e-4, atol=1e-5)
+    rel_close(o['neg_score'].cpu(), ns, rtol=1e-4, atol=1e-5)
+    psr, nsr = ps.clone().requires_grad_(True), ns.clone().requires_grad_(True)
+    want = oracle.bpr_loss(psr, nsr)
+    want.backward()
+    rel_close(o['loss'].cpu(), want.detach(), rtol=1e-5)
+    rel_close(o['dneg'].cpu(), nsr.grad, rtol=1e-4, atol=1e-9)
+    rel_close(o['dpos'].cpu(), psr.grad, rtol=1e-4, atol=1e-9)
+    rel_close(o['row_loss'].mean().cpu(), want.detach(), rtol=1e-5)
+    if qg:
+        want_q = psr.grad.unsqueeze(1) * iw[pos.cpu()] + (nsr.grad.unsqueeze(-1) * iw[neg.cpu()]).sum(1)
+        rel_close(o['query_grad'].cpu(), want_q, rtol=2e-4, atol=1e-8)
+    # in-kernel samplers through the same walk: same ids as the one-tile kernel's stream, forward-only == training forward
+    if d == 128:
+        torch.manual_seed(3)
+        a = ra.ops.fused_forward(iwd, uwd, n, query_index=uid, pos_ids=pos, sampler=ra._native.SAMPLER_UNIFORM, fused_bpr=True)
+        torch.manual_seed(3)
+        b = ra.ops.fused_forward(iwd, uwd, n, query_index=uid, pos_ids=pos, sampler=ra._native.SAMPLER_UNIFORM, fused_bpr=True,
+                                 want_query_grad=True)
+        torch.manual_seed(3)
+        want_ids = torch.randint(1, N, (B, n), device=DEV)
+        assert torch.equal(a['neg_ids'], want_ids) and torch.equal(b['neg_ids'], want_ids)
+        rel_close(a['loss'].cpu(), b['loss'].cpu(), rtol=1e-6)
+        rel_close(a['neg_score'].cpu(), b['neg_score'].cpu(), rtol=1e-5, atol=1e-6)

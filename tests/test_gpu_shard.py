@@ -1,6 +1,7 @@
 """GPU: the HIP routing kernels of the sharded path against the checker backend used by the gloo
 test, and a world_size-1 RCCL run of the whole sharded step against the unsharded fused forward."""
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -8,6 +9,8 @@ import torch
 
 import oracle
 from test_shard_gloo import CheckerBackend, _free_port
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools'))
 
 pytestmark = pytest.mark.gpu
 DEV = 'cuda'
@@ -162,46 +165,7 @@ def test_sorted_scatter_drops_negative_ids():
     np.testing.assert_allclose(got.cpu(), ref.cpu(), rtol=1e-4, atol=1e-5)
 
 
-class StagedDist:
-    """torch.distributed look-alike whose collectives run over gloo through host staging: lets TWO ranks share ONE
-    GPU (RCCL refuses two ranks on one device), so the HIP side of the sharded step -- routing with non-trivial
-    split sizes, owner-side scoring of received keys, the sorted backward scatters -- runs at world size 2 on the
-    single-GPU test box.  The real RCCL path is the same ShardedItemTable code with torch.distributed itself
-    (test_two_gpus_rccl below, skipped without a second GPU)."""
-
-    def __init__(self, dist):
-        self.d = dist
-        self.ReduceOp = dist.ReduceOp
-
-    def new_group(self, *a, **k):
-        return None
-
-    class _Done:
-        def wait(self):
-            return True
-
-    def all_gather_into_tensor(self, out, x, group=None, async_op=False):
-        parts = [torch.empty(x.shape, dtype=x.dtype) for _ in range(self.d.get_world_size())]
-        self.d.all_gather(parts, x.cpu())
-        out.copy_(torch.cat(parts).view(out.shape))
-        return self._Done() if async_op else None
-
-    def all_to_all_single(self, out, x, output_split_sizes=None, input_split_sizes=None, group=None, async_op=False):
-        o = torch.empty(out.shape, dtype=out.dtype)
-        self.d.all_to_all_single(o, x.cpu().contiguous(), output_split_sizes, input_split_sizes)
-        out.copy_(o)
-        return self._Done() if async_op else None
-
-    def reduce_scatter_tensor(self, out, x, group=None):
-        full = x.cpu().clone()
-        self.d.all_reduce(full)
-        r, per = self.d.get_rank(), out.shape[0]
-        out.copy_(full[r * per:(r + 1) * per])
-
-    def all_reduce(self, x, op=None, group=None):
-        c = x.cpu()
-        self.d.all_reduce(c, op=op if op is not None else self.d.ReduceOp.SUM)
-        x.copy_(c)
+from staged_dist import StagedDist       # noqa: E402  (tools/staged_dist.py)
 
 
 def _check_pipelined_equals_whole(ra, ShardedItemTable, make_table, user, uid, pos, n, sampler, rows, d, dev):

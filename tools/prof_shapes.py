@@ -1,0 +1,125 @@
+"""One bench figure, alone, for rocprofv3 (tools/collect_profiles_r3.sh): builds the shape, runs K launches of its step
+and prints {"shape", "steps"} so that the summariser can turn totals into per-step figures.
+usage: python tools/prof_shapes.py SHAPE [K]"""
+import json
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import recstudio_amd as ra                      # noqa: E402
+from recstudio_amd import _native as nat        # noqa: E402
+from bench import zipf_counts                   # noqa: E402
+
+shape = sys.argv[1]
+K = int(sys.argv[2]) if len(sys.argv) > 2 else 30
+dev = torch.device('cuda', 0)
+torch.cuda.set_device(0)
+d, U = 128, 1_000_001
+gen = torch.Generator(device=dev).manual_seed(100)
+
+
+def popular_sampler(n_items, tag):
+    """The popularity tables of an N-item Zipf catalog; cached under /tmp across the passes of one collection run (the
+    host-side build of the 1e8-item tables takes minutes)."""
+    path = f'/tmp/rsa_ps_{tag}.pt'
+    if os.path.exists(path):
+        return torch.load(path, weights_only=False).to(dev)
+    ps = ra.PopularSamplerModel(zipf_counts(n_items, 100_000_000))
+    torch.save(ps, path)
+    return ps.to(dev)
+
+
+def table(n_items, seed):
+    t = torch.empty(n_items, d, device=dev).normal_(0, 0.02, generator=torch.Generator(device=dev).manual_seed(seed))
+    t[0] = 0
+    return t
+
+
+user = torch.empty(U, d, device=dev).normal_(0, 0.02, generator=torch.Generator(device=dev).manual_seed(3))
+torch.manual_seed(2022)
+buf = {}
+if shape in ('headline_N1e7_popular_n64_B65536', 'N1e7_popular_n64_B4096', 'N1e7_popular_n64_B16384'):
+    B = int(shape.rsplit('_B', 1)[1])
+    item = table(10_000_001, 1)
+    ps = popular_sampler(10_000_001, '1e7')
+    uid = torch.randint(1, U, (B,), device=dev, generator=gen)
+    pos = torch.randint(1, 10_000_001, (B,), device=dev, generator=gen)
+    kw = dict(query_index=uid, pos_ids=pos, sampler=nat.SAMPLER_POPULAR, **ps.lookup_kwargs())
+
+    def step():
+        buf['o'] = ra.ops.fused_forward(item, user, 64, out=buf.get('o'), fused_bpr=True, **kw)
+elif shape.startswith('N1e8_'):
+    n8 = 100_000_001
+    item = table(n8, 8)
+    _, smp, nn, bb = shape.split('_')
+    n_neg, B = int(nn[1:]), int(bb[1:])
+    uid = torch.randint(1, U, (B,), device=dev, generator=gen)
+    pos = torch.randint(1, n8, (B,), device=dev, generator=gen)
+    if smp == 'popular':
+        ps = popular_sampler(n8, '1e8')
+        kw = dict(query_index=uid, pos_ids=pos, sampler=nat.SAMPLER_POPULAR, **ps.lookup_kwargs())
+    else:
+        kw = dict(query_index=uid, pos_ids=pos, sampler=nat.SAMPLER_UNIFORM)
+
+    def step():
+        buf['o'] = ra.ops.fused_forward(item, user, n_neg, out=buf.get('o'), fused_bpr=True, want_mean=False, **kw)
+elif shape == 'ssm_N1e6_popular_n256_B8192':
+    n6, B, n_neg = 1_000_001, 8192, 256
+    item = table(n6, 1)
+    ps = popular_sampler(n6, '1e6')
+    q = user[1:B + 1].contiguous()
+    pos = torch.randint(1, n6, (B,), device=dev, generator=gen)
+    kw = dict(pos_ids=pos, sampler=nat.SAMPLER_POPULAR, **ps.lookup_kwargs())
+
+    def step():
+        buf['o'] = ra.ops.fused_forward(item, q, n_neg, out=buf.get('o'), fused_loss='ssm', **kw)
+elif shape in ('sharded_world1_step', 'sharded_world1_train'):
+    import torch.distributed as dist
+    from recstudio_amd import shard
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29578')
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
+    n_blk, n_neg, B = 12_500_001, 1024, 4096
+    item = table(n_blk, 9)
+    tbl = shard.ShardedItemTable(item, shard.RowShardPlan(n_blk, 1), 0, dist, check_every=0)
+    us = ra.UniformSampler(n_blk)
+    uid = torch.randint(1, U, (B,), device=dev, generator=gen)
+    pos = torch.randint(1, n_blk, (B,), device=dev, generator=gen)
+    if shape == 'sharded_world1_step':
+        def step():
+            tbl.sample_and_score(user, uid, pos, n_neg, us, fused_loss='bpr', want_ids=False, want_grad=True)
+    else:
+        tower = torch.nn.Embedding(U, d).to(dev)
+        trainer = shard.ShardedRetriever(tbl, tower, us, ra.BPRLoss(), n_neg, item_sgd_lr=0.05, query_sgd_lr=0.05)
+
+        def step():
+            trainer.training_step(uid, pos)
+elif shape in ('sgd_step_N1e7_popular_n64_B65536', 'adam_step_N1e7_popular_n64_B65536'):
+    from recstudio_amd.fused import FusedBPRAdam, bpr_sgd_step
+    B = 65536
+    item = table(10_000_001, 1)
+    ps = popular_sampler(10_000_001, '1e7')
+    uid = torch.randint(1, U, (B,), device=dev, generator=gen)
+    pos = torch.randint(1, 10_000_001, (B,), device=dev, generator=gen)
+    if shape.startswith('sgd'):
+        def step():
+            bpr_sgd_step(item, user, 64, 1e-3, user_ids=uid, pos_ids=pos, sampler=ps)
+    else:
+        fa = FusedBPRAdam(item, user, lr=1e-3)
+
+        def step():
+            fa.step(64, user_ids=uid, pos_ids=pos, sampler=ps)
+else:
+    raise SystemExit(f'unknown shape {shape}')
+
+WARM = 3
+for _ in range(WARM):
+    step()
+torch.cuda.synchronize()
+for _ in range(K):
+    step()
+torch.cuda.synchronize()
+print(json.dumps({'shape': shape, 'steps': K, 'warmup': WARM}))
