@@ -21,7 +21,8 @@ import numpy as np
 import torch
 from torch.nn.utils.rnn import pad_sequence
 
-__all__ = ['TripletDataset', 'SeqDataset', 'DataSampler', 'SortedDataSampler', 'synthetic_interactions']
+__all__ = ['TripletDataset', 'SeqDataset', 'DataSampler', 'SortedDataSampler', 'RankSlice', 'rank_part',
+           'synthetic_interactions']
 
 DEFAULT_CONFIG = {
     'user_id_field': 'user_id:token', 'item_id_field': 'item_id:token', 'rating_field': 'rating:float',
@@ -86,17 +87,68 @@ class SortedDataSampler(DataSampler):
         yield from out
 
 
+def _rank_world(rank, world):
+    """(rank, world) of this process: the arguments, else torch.distributed, else the launcher's environment."""
+    if rank is not None and world is not None:
+        return int(rank), int(world)
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return int(os.environ.get('RANK', '0')), int(os.environ.get('WORLD_SIZE', '1'))
+
+
+def rank_part(index, rank, world):
+    """Rank ``rank``'s CONTIGUOUS 1/world of a global index batch -> (part, n_valid).  A batch the world size does not
+    divide is padded by wrapping around to its own first entries (torch's DistributedSampler rule), so that every rank
+    gets the same number of rows -- the sharded step's collectives need equal parts; ``n_valid`` says how many rows of
+    the part are real (the padding repeats samples: training sees them twice in that one batch, evaluation weighs them
+    out)."""
+    n = index.shape[0]
+    per = (n + world - 1) // world
+    if per * world != n:
+        index = torch.cat([index, index[:per * world - n]])
+    lo = rank * per
+    return index[lo:lo + per], max(0, min(per, n - lo))
+
+
+class RankSlice:
+    """recstudio/data/dataset.py:1113-1114, :1141-1142 (``DistributedSamplerWrapper`` around the index-batch sampler) for
+    the row-sharded trainer: the wrapped sampler draws GLOBAL index batches -- the same on every rank: it shuffles from
+    torch's global CPU stream, which ``seed_everything`` put into the same state everywhere (recommender.py:34-35) -- and
+    rank r keeps rows [r * B, (r + 1) * B) of each, so that the ranks' parts concatenated are exactly what ONE process
+    running the global batch sees, in that order (together with the job-wide negative stream this makes a G-rank run
+    reproduce the single-process run).  The reference deals out whole batches (rank r gets batches r, r + G, ...); a
+    contiguous slice of every batch keeps the step's global batch well defined instead.  Yields (index part, n_valid)."""
+
+    def __init__(self, sampler, rank=None, world=None):
+        self.sampler = sampler
+        self.rank, self.world = _rank_world(rank, world)
+
+    def __iter__(self):
+        for index in self.sampler:
+            yield rank_part(index, self.rank, self.world)
+
+    def __len__(self):
+        return len(self.sampler)
+
+
 class _Loader:
-    """DataLoader(dataset, sampler=index-batch sampler, batch_size=None) equivalent."""
+    """DataLoader(dataset, sampler=index-batch sampler, batch_size=None) equivalent.  With a ``RankSlice`` sampler the
+    batch additionally carries ``'_n_valid'`` (a Python int: rows of this rank's part that are not padding)."""
 
     def __init__(self, dataset, sampler, device=None):
         self.dataset, self.sampler, self.device = dataset, sampler, device
 
     def __iter__(self):
         for index in self.sampler:
+            n_valid = None
+            if isinstance(index, tuple):
+                index, n_valid = index
             batch = self.dataset[index]
             if self.device is not None:
                 batch = {k: v.to(self.device, non_blocking=True) for k, v in batch.items()}
+            if n_valid is not None:
+                batch['_n_valid'] = n_valid
             yield batch
 
     def __len__(self):
@@ -110,10 +162,15 @@ class _DeviceLoader:
     the per-batch Python ``torch.cat([arange ...])`` + ``pad_sequence`` (dataset.py:1428-1434).  Batches have
     the same keys, dtypes and values as the host loader's."""
 
-    def __init__(self, dataset, batch_size, shuffle, drop_last, device):
+    def __init__(self, dataset, batch_size, shuffle, drop_last, device, rank=0, world=1):
+        """``world`` > 1: ``batch_size`` is per rank; the epoch's order is drawn for the GLOBAL batches of
+        ``batch_size * world`` samples from the device generator (the same state on every rank after ``seed_everything``)
+        and this rank keeps its contiguous part of each (see ``RankSlice``); batches carry ``'_n_valid'``."""
         from . import ops                                   # device work only; imported lazily (host-only users)
         self.ops = ops
-        self.ds, self.batch_size, self.shuffle, self.drop_last = dataset, batch_size, shuffle, drop_last
+        self.ds, self.shuffle, self.drop_last = dataset, shuffle, drop_last
+        self.rank, self.world, self.per_rank = int(rank), int(world), int(batch_size)
+        self.batch_size = int(batch_size) * self.world      # the global batch
         self.device = torch.device(device)
         self.cols = {k: v.to(self.device) for k, v in dataset.inter_feat.items()
                      if k in dataset.use_field or k == dataset.frating}
@@ -147,9 +204,15 @@ class _DeviceLoader:
             sel = order[lo:lo + self.batch_size]
             if self.drop_last and sel.numel() < self.batch_size:
                 break
+            n_valid = None
+            if self.world > 1:
+                sel, n_valid = rank_part(sel, self.rank, self.world)
             rows = self.index[sel]
             if not self.seq:
-                yield {k: v[rows] for k, v in self.cols.items()}
+                batch = {k: v[rows] for k, v in self.cols.items()}
+                if n_valid is not None:
+                    batch['_n_valid'] = n_valid
+                yield batch
                 continue
             start, end = rows[:, 1].contiguous(), rows[:, 2].contiguous()
             lens = end - start
@@ -165,6 +228,8 @@ class _DeviceLoader:
                 valid = pos < end.view(-1, 1)
                 batch['in_' + ds.frating] = torch.where(valid, r[pos.clamp(max=r.numel() - 1)], torch.zeros((), device=self.device))
                 batch[ds.frating] = r[end]
+            if n_valid is not None:
+                batch['_n_valid'] = n_valid
             yield batch
 
 
@@ -468,27 +533,41 @@ class TripletDataset:
             data['user_hist'] = self.user_hist[data[self.fuid]][:, 0:user_count]
         return data
 
-    def loader(self, batch_size, shuffle=True, num_workers=0, drop_last=False, ddp=False, device=None):
+    def loader(self, batch_size, shuffle=True, num_workers=0, drop_last=False, ddp=False, device=None, rank=None, world=None):
+        """``ddp=True`` (recstudio/data/dataset.py:1113-1114): ``batch_size`` is per rank; every rank draws the same GLOBAL
+        index batches of ``batch_size * world`` samples and keeps its contiguous 1/world of each (``RankSlice``; rank and
+        world size from the arguments, torch.distributed or the launcher's environment)."""
+        r, w = _rank_world(rank, world) if ddp else (0, 1)
         if self.data_index.dim() > 1:
-            sampler = SortedDataSampler(self, batch_size, shuffle, drop_last)
+            sampler = SortedDataSampler(self, batch_size * w, shuffle, drop_last)
         else:
-            sampler = DataSampler(self, batch_size, shuffle, drop_last)
+            sampler = DataSampler(self, batch_size * w, shuffle, drop_last)
+        if ddp:
+            sampler = RankSlice(sampler, r, w)
         return _Loader(self, sampler, device)
 
-    def train_loader(self, batch_size, shuffle=True, num_workers=0, drop_last=False, ddp=False, device=None):
+    def train_loader(self, batch_size, shuffle=True, num_workers=0, drop_last=False, ddp=False, device=None, rank=None,
+                     world=None):
         self.eval_mode = False
-        return self.loader(batch_size, shuffle, num_workers, drop_last, ddp, device)
+        return self.loader(batch_size, shuffle, num_workers, drop_last, ddp, device, rank, world)
 
-    def eval_loader(self, batch_size, num_workers=0, ddp=False, device=None):
+    def eval_loader(self, batch_size, num_workers=0, ddp=False, device=None, rank=None, world=None):
+        """``ddp=True`` (dataset.py:1141-1142): this rank's contiguous part of every (length-sorted) global evaluation
+        batch of ``batch_size * world`` users; ``batch['_n_valid']`` rows of it are real."""
         self.eval_mode = True
-        return _Loader(self, SortedDataSampler(self, batch_size), device)
+        r, w = _rank_world(rank, world) if ddp else (0, 1)
+        sampler = SortedDataSampler(self, batch_size * w)
+        if ddp:
+            sampler = RankSlice(sampler, r, w)
+        return _Loader(self, sampler, device)
 
-    def device_train_loader(self, batch_size, shuffle=True, drop_last=False, device='cuda'):
-        """Training loader whose data never leaves the GPU (see _DeviceLoader)."""
+    def device_train_loader(self, batch_size, shuffle=True, drop_last=False, device='cuda', ddp=False, rank=None, world=None):
+        """Training loader whose data never leaves the GPU (see _DeviceLoader); ``ddp`` as in ``loader``."""
         if self.data_index.dim() > 1 and not isinstance(self, SeqDataset):
             raise ValueError('device_train_loader is for training splits')
         self.eval_mode = False
-        return _DeviceLoader(self, batch_size, shuffle, drop_last, device)
+        r, w = _rank_world(rank, world) if ddp else (0, 1)
+        return _DeviceLoader(self, batch_size, shuffle, drop_last, device, r, w)
 
 
 class SeqDataset(TripletDataset):
