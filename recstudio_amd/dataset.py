@@ -220,6 +220,8 @@ class _DeviceLoader:
             batch = {ds.fuid: rows[:, 0], 'seqlen': lens}
             ids, _, _ = self.ops.seg_gather(None, self.cols[ds.fiid], start, end, L, want_rows=False)
             batch['in_' + ds.fiid] = ids
+            # the CSR view itself, for towers that gather rows straight from it (SASRecQueryEncoder: rsa_seg_gather, rows form)
+            batch['_seg'] = (self.cols[ds.fiid], start, end)
             batch[ds.fiid] = self.cols[ds.fiid][end]
             if ds.frating in self.cols:
                 # ratings of the history positions: same [start, end) windows, right-padded with 0

@@ -20,6 +20,7 @@ path (sampler / scorer / loss objects called one by one, like the reference does
 import copy
 import inspect
 import logging
+import os
 import time
 from typing import Dict
 
@@ -51,7 +52,8 @@ def default_config():
                   'init_method': 'xavier_normal', 'item_batch_size': 1024, 'learner': 'adam', 'learning_rate': 0.001,
                   'num_threads': 10, 'sampling_method': 'none', 'sampler': 'uniform', 'negative_count': 0,
                   'excluding_hist': False, 'scheduler': None, 'seed': 2022, 'weight_decay': 0.0,
-                  'tensorboard_path': None, 'sparse_grad': False, 'device_loader': True, 'fused_optimizer': None},
+                  'tensorboard_path': None, 'sparse_grad': False, 'device_loader': True, 'fused_optimizer': None,
+                  'shard_slices': 1},
         'eval': {'batch_size': 128, 'cutoff': [5, 10, 20], 'val_metrics': ['ndcg', 'recall'], 'val_n_epoch': 1,
                  'test_metrics': ['ndcg', 'recall', 'precision', 'map', 'mrr', 'hit'], 'topk': 100,
                  'save_path': './saved/'},
@@ -415,6 +417,8 @@ class BaseRetriever(torch.nn.Module):
     def topk(self, batch, k, user_h=None, return_query=False):
         """baseretriever.py:374-397: full-catalog scores -> top (k + |hist|) -> drop history -> top k."""
         query = self.query_encoder(self._get_query_feat(batch))
+        if getattr(self, '_shard', None) is not None:
+            return self._topk_sharded(query, k, user_h, return_query)
         more = user_h.size(1) if user_h is not None else 0
         if type(self.score_func) in (InnerProductScorer, CosineScorer, EuclideanScorer) \
                 and isinstance(self.item_encoder, torch.nn.Embedding):
@@ -509,6 +513,15 @@ class BaseRetriever(torch.nn.Module):
         bs = batch[self.frating].size(0)
         assert len(rank_m) > 0
         score, topk_items = self.topk(batch, topk, batch['user_hist'])
+        n_valid = batch.get('_n_valid')
+        if n_valid is not None and n_valid < bs:
+            # this rank's part of a global evaluation batch the world size did not divide: the trailing rows are padding
+            # (dataset.rank_part) -- they took part in the (collective) top-k above and are dropped from the metrics
+            if n_valid == 0:
+                return {f'{name}@{cutoff}': 0.0 for cutoff in cutoffs for name, _ in rank_m}, 0
+            bs = n_valid
+            topk_items = topk_items[:bs]
+            batch = dict(batch, **{self.fiid: batch[self.fiid][:bs], self.frating: batch[self.frating][:bs]})
         if batch[self.fiid].dim() > 1:
             target, _ = batch[self.fiid].sort()
             idx_ = torch.searchsorted(target, topk_items)
@@ -539,11 +552,190 @@ class BaseRetriever(torch.nn.Module):
         return table.get(name, torch.optim.Adam)(params, lr=lr, weight_decay=wd)
 
     def _to_device(self, batch, device):
-        return {k: (v.to(device, non_blocking=True) if isinstance(v, torch.Tensor) else v) for k, v in batch.items()}
+        def move(v):
+            if isinstance(v, torch.Tensor):
+                return v.to(device, non_blocking=True)
+            if isinstance(v, tuple):
+                return tuple(move(x) for x in v)
+            return v
+        return {k: move(v) for k, v in batch.items()}
+
+    # ------------------------------------------------------------------ multi-GPU fit / evaluate (row-sharded item table)
+    def _dist_context(self, kwargs):
+        """The process group this ``fit`` runs in when it is ONE RANK of a multi-process job: ``fit(..., dist=...)`` (a
+        torch.distributed look-alike; forces the sharded path at any world size), an initialised torch.distributed
+        with more than one rank, or a launcher environment (WORLD_SIZE > 1: the group is created here, RCCL, one rank
+        per GPU).  None: single-process training.  Replaces recommender.py:608-612, :716-742 (``data_parallel`` /
+        ``_accelerate``: every parameter re-broadcast to a gpu list each step; the ddp branch raises)."""
+        dist = kwargs.get('dist')
+        if dist is not None:
+            return dist
+        import torch.distributed as td
+        if not td.is_available():
+            return None
+        if not td.is_initialized() and int(os.environ.get('WORLD_SIZE', '1')) > 1:
+            local = int(os.environ.get('LOCAL_RANK', '0'))
+            os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+            torch.cuda.set_device(local)
+            td.init_process_group('nccl', device_id=torch.device('cuda', local))
+        if td.is_initialized() and td.get_world_size() > 1:
+            return td
+        return None
+
+    def _setup_shard(self, train_data, dist, backend=None, device=None):
+        """Row-shard the item table over the ranks of ``dist``: rank r keeps rows [lo, hi) of ``item_encoder.weight`` (and,
+        through the optimizer, of its Adam state) as an ``nn.Embedding`` of its own block; sampler and query tower are
+        replicated.  Every rank initialises the full model from the same seed first (recommender.py:34-35), so the
+        shards are the rows of the very table a single process would train."""
+        from . import shard
+        rank, world = dist.get_rank(), dist.get_world_size()
+        if not (isinstance(self.item_encoder, torch.nn.Embedding) and len(self.item_fields) == 1
+                and type(self.score_func) is InnerProductScorer and isinstance(self.loss_fn, PairwiseLoss)
+                and self.sampler is not None and self.config['train'].get('sampling_method', 'none') == 'none'
+                and isinstance(self.neg_count, int) and self.neg_count > 0):
+            raise NotImplementedError('multi-GPU fit covers the two-tower configuration: nn.Embedding item tower over the item '
+                                      'id, InnerProductScorer, a PairwiseLoss, a Sampler with sampling_method "none"')
+        if device is None:
+            if backend is not None:
+                raise ValueError('a non-default shard backend needs an explicit device')
+            device = torch.device('cuda', int(os.environ.get('LOCAL_RANK', torch.cuda.current_device())))
+        device = torch.device(device)
+        n_items, d = self.item_encoder.weight.shape
+        plan = shard.RowShardPlan(n_items, world)
+        lo, hi = plan.bounds(rank)
+        block = torch.nn.Embedding(hi - lo, d, padding_idx=0 if rank == 0 else None,
+                                   _weight=self.item_encoder.weight.detach()[lo:hi].clone())
+        self.item_encoder = block                      # the full table is dropped: this rank owns rows [lo, hi)
+        if hasattr(self, 'item_vector'):
+            del self.item_vector
+        self.to(device)
+        table = shard.ShardedItemTable(self.item_encoder.weight.data, plan, rank, dist, backend=backend,
+                                       sample_seed=self.config['train']['seed'] or 2022,
+                                       chunks=int(self.config['train'].get('shard_slices', 1)))
+        self._shard = {'table': table, 'dist': dist, 'rank': rank, 'world': world, 'lo': lo, 'hi': hi, 'device': device,
+                       'n_items': n_items}
+        return self._shard
+
+    def _topk_sharded(self, query, k, user_h, return_query):
+        """``topk`` over the sharded catalog: per-shard MFMA pass + exchange of the (value, id) partials
+        (ShardedItemTable.full_lse_topk), then the history exclusion of baseretriever.py:386-392.  The candidate count is
+        k + the width of the WHOLE history table (the same on every rank: the collectives need equal shapes) -- at least
+        as many candidates as the single-process path keeps, so the k survivors are the same."""
+        sh = self._shard
+        table, be = sh['table'], sh['table'].backend
+        more = sh.get('hist_width', user_h.size(1) if user_h is not None else 0)
+        kc = min(k + more, sh['n_items'] - 1)
+        if kc > ops.FULLSCORE_MAX_K:
+            raise NotImplementedError(f'sharded topk: k + |history| = {kc} exceeds {ops.FULLSCORE_MAX_K}')
+        _, score, topk_items = table.full_lse_topk(query.detach().contiguous(), kc, want_lse=False)
+        if user_h is not None:
+            if hasattr(be, 'mask_history'):
+                score, topk_items = be.mask_history(score, topk_items, user_h, min(k, score.shape[1]))
+            else:
+                score, topk_items = ops.topk_mask_history(score, topk_items, user_h, min(k, score.shape[1]))
+        else:
+            score, topk_items = score[:, :k], topk_items[:, :k]
+        return (score, topk_items, query) if return_query else (score, topk_items)
+
+    def _fit_sharded(self, train_data, val_data, dist, backend=None, device=None):
+        """One process per GPU, item table row-sharded, query tower replicated (``shard.ShardedRetriever``): rank r trains on
+        its contiguous 1/G of every global batch (``train.batch_size`` is per rank), the negatives come from one job-wide
+        stream, the loss is the global mean -- a G-rank run reproduces the single-process run on the global batch up to
+        fp32 summation order.  The optimizer is the reference's (``train.learner``) on this rank's parameters: its own
+        row block (with its block of the optimizer state) and its replica of the tower, whose gradients are summed over
+        the ranks first; ``train.fused_optimizer: 'sgd'`` applies plain SGD inside the exchange instead."""
+        from . import shard
+        self._init_model(train_data)
+        self._init_parameter()
+        sh = self._setup_shard(train_data, dist, backend, device)
+        table, rank, world, device = sh['table'], sh['rank'], sh['world'], sh['device']
+        if hasattr(self.sampler, 'to'):
+            self.sampler.to(device)
+        if getattr(type(self.sampler), 'update', Sampler.update) is not Sampler.update:
+            raise NotImplementedError('multi-GPU fit: samplers with a per-epoch update() are not covered')
+        if val_data is not None:
+            val_data.use_field = train_data.use_field
+        tr = self.config['train']
+        if hasattr(train_data, 'user_hist') and train_data.user_hist is not None:
+            sh['hist_width'] = int(max(train_data.user_hist.shape[1], getattr(val_data, 'user_hist', train_data.user_hist).shape[1]))
+        fused = tr.get('fused_optimizer')
+        if fused not in (None, 'sgd'):
+            raise NotImplementedError("multi-GPU fit: train.fused_optimizer must be None or 'sgd'")
+        lr = tr['learning_rate']
+        embed_tower = isinstance(self.query_encoder, torch.nn.Embedding)
+        trainer = shard.ShardedRetriever(table, self.query_encoder, self.sampler, self.loss_fn, self.neg_count,
+                                         item_sgd_lr=lr if fused else None,
+                                         query_sgd_lr=lr if (fused and embed_tower) else None)
+        optimizer = None
+        if not fused or not embed_tower:
+            params = [p for p in self.parameters() if p.requires_grad and not (fused and p is self.item_encoder.weight)]
+            optimizer = self._make_optimizer(params) if params else None
+        if not fused:
+            self.item_encoder.weight.grad = trainer.item_grad_local       # the exchange accumulates into the block's .grad
+        sh['trainer'] = trainer
+        val_metrics = self.config['eval']['val_metrics']
+        cutoff = self.config['eval']['cutoff']
+        cutoff0 = cutoff[0] if isinstance(cutoff, list) else cutoff
+        self.val_metric = f"{(val_metrics[0] if isinstance(val_metrics, list) else val_metrics)}@{cutoff0}"
+        on_gpu = device.type == 'cuda'
+        best, best_state, bad = None, None, 0
+        self.train_losses = []
+        for epoch in range(tr['epochs']):
+            t0 = time.time()
+            self.train()
+            losses = []
+            if on_gpu and tr.get('device_loader', True) and hasattr(train_data, 'device_train_loader'):
+                loader = train_data.device_train_loader(tr['batch_size'], shuffle=True, drop_last=False, device=device, ddp=True,
+                                                        rank=rank, world=world)
+            else:
+                loader = train_data.train_loader(batch_size=tr['batch_size'], shuffle=True, drop_last=False, ddp=True,
+                                                 rank=rank, world=world)
+            for batch in loader:
+                batch = self._to_device(batch, device)
+                batch.pop('_n_valid', None)
+                if optimizer is not None:
+                    optimizer.zero_grad(set_to_none=False)
+                loss = trainer.training_step(self._get_query_feat(batch), batch[self.fiid], batch[self.frating])
+                if optimizer is not None:
+                    if tr['grad_clip_norm'] is not None:
+                        raise NotImplementedError('multi-GPU fit: grad_clip_norm needs a norm over all shards')
+                    optimizer.step()
+                losses.append(loss.detach().reshape(1))
+            step_losses = torch.cat(losses)                     # this rank's shares of the global mean losses
+            dist.all_reduce(step_losses)
+            self.train_losses.append(step_losses.cpu())
+            log = {'epoch': epoch, 'train_loss': float(step_losses.mean()), 'train_time': time.time() - t0}
+            if val_data is not None and (epoch + 1) % self.config['eval']['val_n_epoch'] == 0:
+                log.update(self._eval_epoch(val_data, self.validation_step, device))
+                cur = log[self.val_metric]
+                better = best is None or (cur > best if tr['early_stop_mode'] == 'max' else cur < best)
+                if better:
+                    best, best_state, bad = cur, copy.deepcopy(self.state_dict()), 0
+                else:
+                    bad += 1
+            self.logged_metrics = log
+            if rank == 0:
+                self.logger.info(' '.join(f'{k}={v:.4f}' if isinstance(v, float) else f'{k}={v}' for k, v in log.items()))
+            if val_data is not None and bad >= tr['early_stop_patience']:
+                break
+        if best_state is not None:
+            self.load_state_dict(best_state)
+            table.item_local = self.item_encoder.weight.data
+        return best
+
+    def _make_optimizer(self, params):
+        tr = self.config['train']
+        name, lr, wd = tr['learner'].lower(), tr['learning_rate'], tr['weight_decay']
+        table = {'adam': torch.optim.Adam, 'sgd': torch.optim.SGD, 'adagrad': torch.optim.Adagrad,
+                 'rmsprop': torch.optim.RMSprop}
+        return table.get(name, torch.optim.Adam)(params, lr=lr, weight_decay=wd)
 
     def fit(self, train_data, val_data=None, run_mode='light', config: Dict = None, **kwargs):
         if config is not None:
             self.config.update(config)
+        dist = self._dist_context(kwargs)
+        if dist is not None:
+            return self._fit_sharded(train_data, val_data, dist, kwargs.get('shard_backend'), kwargs.get('device'))
         self._init_model(train_data)
         self._init_parameter()
         device = self._device()
@@ -628,17 +820,32 @@ class BaseRetriever(torch.nn.Module):
     @torch.no_grad()
     def _eval_epoch(self, data, step, device):
         self.eval()
-        self._update_item_vector()
+        sh = getattr(self, '_shard', None)
+        if sh is None:
+            self._update_item_vector()
+            loader = data.eval_loader(batch_size=self.config['eval']['batch_size'])
+        else:       # this rank's contiguous part of every global evaluation batch (dataset.py:1141-1142)
+            loader = data.eval_loader(batch_size=self.config['eval']['batch_size'], ddp=True, rank=sh['rank'], world=sh['world'])
         total, acc = 0, {}
-        for batch in data.eval_loader(batch_size=self.config['eval']['batch_size']):
+        for batch in loader:
             metrics, bs = step(self._to_device(batch, device))
             for k, v in metrics.items():
                 acc[k] = acc.get(k, 0.0) + float(v) * bs                       # weighted mean, recommender.py:308-324
             total += bs
+        if sh is not None:                                                     # sums over the ranks' parts
+            keys = sorted(acc)
+            t = torch.tensor([acc[k] for k in keys] + [float(total)], dtype=torch.float64, device=device)
+            if t.device.type == 'cuda':
+                t = t.float()
+            sh['dist'].all_reduce(t)
+            acc, total = {k: float(v) for k, v in zip(keys, t[:-1])}, float(t[-1])
         return {k: v / max(total, 1) for k, v in acc.items()}
 
     def evaluate(self, test_data, verbose=True, **kwargs):
         test_data.use_field = self.fields
+        sh = getattr(self, '_shard', None)
+        if sh is not None and getattr(test_data, 'user_hist', None) is not None:
+            sh['hist_width'] = max(sh.get('hist_width', 0), int(test_data.user_hist.shape[1]))
         out = self._eval_epoch(test_data, self.test_step, next(self.parameters()).device)
         if verbose:
             self.logger.info(str(out))
@@ -688,8 +895,37 @@ class _EmbedFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (ids,) = ctx.saved_tensors
-        d = g.shape[-1]
-        return ops.scatter_add_rows(g.reshape(-1, d).contiguous(), ids.reshape(-1), ctx.n_rows), None
+        return _embedding_grad(g, ids, ctx.n_rows), None
+
+
+def _embedding_grad(g, ids, n_rows):
+    """Dense ``weight.grad`` of an item-row gather (embedding_dense_backward with padding_idx = 0): rows sorted by item id
+    and summed run by run without atomics (``rsa_scatter_rows_sorted``; bit-reproducible) for the stock dims, the
+    float-atomic scatter otherwise."""
+    d = g.shape[-1]
+    rows = g.reshape(-1, d).contiguous()
+    flat_ids = ids.reshape(-1, 1).contiguous()
+    if d in (64, 128, 256) and rows.shape[0] > 0:
+        ones = torch.ones(rows.shape[0], 1, dtype=torch.float32, device=g.device)
+        return ops.scatter_rows_sorted(torch.zeros(n_rows, d, dtype=torch.float32, device=g.device), rows, flat_ids, ones, pad_row=0)
+    return ops.scatter_add_rows(rows, flat_ids.view(-1), n_rows)
+
+
+class _SegEmbedFn(torch.autograd.Function):
+    """item_encoder(in_item_id) straight from the CSR view of the interaction column (dataset.py:1418-1439 +
+    seq/sasrec.py:42): ``rsa_seg_gather`` reads ``[start, end)`` of the flat item column and writes the right-padded
+    ``[B, L, d]`` rows -- no ``[B, L]`` id tensor is re-read; the backward is the sorted, atomics-free row scatter."""
+
+    @staticmethod
+    def forward(ctx, weight, flat, start, end, max_len, ids):
+        ctx.save_for_backward(ids)
+        ctx.n_rows = weight.shape[0]
+        return ops.seg_gather(weight, flat, start, end, int(max_len), want_rows=True, want_ids=False)[1]
+
+    @staticmethod
+    def backward(ctx, g):
+        (ids,) = ctx.saved_tensors
+        return _embedding_grad(g, ids, ctx.n_rows), None, None, None, None, None
 
 
 class SASRecQueryEncoder(torch.nn.Module):
@@ -712,7 +948,15 @@ class SASRecQueryEncoder(torch.nn.Module):
         user_hist = batch['in_' + self.fiid]
         B, L = user_hist.shape
         positions = torch.arange(L, dtype=torch.long, device=user_hist.device).unsqueeze(0).expand(B, L)
-        seq = _EmbedFn.apply(self.item_encoder.weight, user_hist) + self.position_emb(positions)
+        seg = batch.get('_seg')
+        if seg is not None and user_hist.is_cuda:
+            # the device loader handed over the CSR view (flat item column, start, end): the fused segment gather emits
+            # [B, L, d] directly; ``in_item_id`` only serves the padding mask and the backward
+            flat, start, end = seg
+            rows = _SegEmbedFn.apply(self.item_encoder.weight, flat, start, end, L, user_hist)
+        else:
+            rows = _EmbedFn.apply(self.item_encoder.weight, user_hist)
+        seq = rows + self.position_emb(positions)
         causal = torch.triu(torch.ones(L, L, dtype=torch.bool, device=user_hist.device), 1)
         out = self.transformer_layer(self.dropout(seq), mask=causal, src_key_padding_mask=user_hist == 0)
         last = (batch['seqlen'] - 1).clamp(min=0).view(-1, 1, 1).expand(-1, 1, out.shape[-1])

@@ -559,3 +559,73 @@ def test_world1_rccl_overflow_step_is_harmless():
             table.check_overflow()
     finally:
         dist.destroy_process_group()
+
+
+def _fit_gpu_worker(rank, world, port, result_dir):
+    import torch.distributed as dist
+    import recstudio_amd as ra
+    from recstudio_amd.dataset import TripletDataset
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'data_ml100k.npz'))
+        conf = {'train': {'epochs': 2, 'batch_size': 2048 // world, 'negative_count': 64, 'seed': 2022, 'learning_rate': 0.01,
+                          'early_stop_patience': 100},
+                'eval': {'batch_size': 128 // world, 'cutoff': [10], 'val_metrics': ['ndcg', 'recall'], 'topk': 50,
+                         'test_metrics': ['ndcg', 'recall']},
+                'model': {'embed_dim': 64}}
+        model = ra.BPR(conf)
+        ds = TripletDataset('ml-100k', {'low_rating_thres': 3.0},
+                            _interactions=(g['raw_user'].astype(str), g['raw_item'].astype(str),
+                                           g['raw_rating'].astype(np.float64), g['raw_time'].astype(np.float64)))
+        trn, val, tst = ds.build(split_ratio=[0.8, 0.1, 0.1], shuffle=True, split_mode='user_entry')
+        torch.cuda.manual_seed_all(2022)               # the device loader's permutation comes from the device generator
+        best = model.fit(trn, val, dist=StagedDist(dist), device='cuda:0')
+        test = model.evaluate(tst, verbose=False)
+        torch.save({'best': best, 'val': dict(model.logged_metrics), 'test': test, 'losses': torch.cat(model.train_losses),
+                    'item': model.item_encoder.weight.detach().cpu(), 'lo': model._shard['lo'],
+                    'tower': model.query_encoder.weight.detach().cpu()}, os.path.join(result_dir, f'w{world}r{rank}.pt'))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_fit_two_staged_ranks_equals_one_rank_hip(tmp_path):
+    """``BaseRetriever.fit`` / ``evaluate`` with the HIP backend as two ranks on the test GPU (collectives staged over gloo;
+    over RCCL the same code runs one rank per GPU): ml-100k BPR, n = 64 drawn inside the routing launch, fused BPR home
+    kernel, dense Adam on the row blocks and the replicated tower, device loader with rank parts, sharded top-k with
+    history masking -- losses, ndcg@10 / recall@10 and weights equal the one-rank run of the same global batch."""
+    import torch.multiprocessing as mp
+    for world in (1, 2):
+        mp.spawn(_fit_gpu_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    one = torch.load(tmp_path / 'w1r0.pt', weights_only=False)
+    two = [torch.load(tmp_path / f'w2r{r}.pt', weights_only=False) for r in range(2)]
+    assert abs(float(one['losses'][0]) - 0.6931) < 2e-3 and float(one['losses'][-1]) < float(one['losses'][0]) - 0.05
+    for t in two:
+        np.testing.assert_allclose(t['losses'].numpy(), one['losses'].numpy(), rtol=2e-5, atol=1e-6)
+        for k in ('ndcg@10', 'recall@10'):
+            assert abs(t['val'][k] - one['val'][k]) < 1e-4 and abs(t['test'][k] - one['test'][k]) < 1e-4
+        np.testing.assert_allclose(t['tower'].numpy(), one['tower'].numpy(), rtol=1e-3, atol=1e-5)
+    items = torch.cat([two[0]['item'], two[1]['item']])
+    np.testing.assert_allclose(items.numpy(), one['item'].numpy(), rtol=1e-3, atol=1e-5)
+    assert one['val']['ndcg@10'] > 0.01 and not items[0].any()
+
+
+@pytest.mark.parametrize('d', [32, 128])
+def test_apply_rows_pad_row_semantics_do_not_depend_on_dim(d):
+    """HipBackend.apply_rows(pad_row=-1) updates EVERY row, row 0 included, for the stock dims (sorted scatter) and
+    for the others alike; pad_row=0 skips row 0 in both."""
+    from recstudio_amd.shard import HipBackend
+    torch.manual_seed(d)
+    U, m = 50, 400
+    ids = torch.randint(0, U, (m,), device=DEV)
+    ids[:7] = 0
+    rows = torch.randn(m, d, device=DEV)
+    for pad in (-1, 0):
+        table = torch.zeros(U, d, device=DEV)
+        HipBackend().apply_rows(table, ids, rows, -0.5, pad_row=pad)
+        keep = ids != pad
+        want = torch.zeros(U, d, device=DEV).index_add_(0, ids[keep], -0.5 * rows[keep])
+        np.testing.assert_allclose(table.cpu(), want.cpu(), rtol=1e-5, atol=1e-6)
+        assert bool(table[0].any()) == (pad == -1)

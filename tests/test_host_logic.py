@@ -255,3 +255,56 @@ def test_cpu_tensors_are_rejected():
         ra.ops.embedding_gather(torch.zeros(4, 8), torch.zeros(2, dtype=torch.int64))
     with pytest.raises(RuntimeError, match='GPU only'):
         ra.BPRLoss()(None, torch.zeros(3), None, torch.zeros(3, 2), None)
+
+
+def test_popular_sampler_is_picklable_and_drops_legacy_guide_key():
+    """the load_state_dict post-hook is a module-level function (a lambda made torch.save(model) and mp.spawn
+    arguments fail), and a checkpoint of the revision that kept `guide` in the state dict still loads strictly."""
+    import io
+    import recstudio_amd as ra
+    ps = ra.PopularSamplerModel(torch.arange(3000) % 17)
+    buf = io.BytesIO()
+    torch.save(ps, buf)
+    buf.seek(0)
+    ps2 = torch.load(buf, weights_only=False)
+    assert torch.equal(ps2.table, ps.table) and sorted(ps.state_dict()) == ['pop_prob', 'table']
+
+    class Model(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.sampler = ra.PopularSamplerModel(torch.arange(3000) % 17)
+    m = Model()
+    sd = m.state_dict()
+    sd['sampler.guide'] = torch.zeros(5, dtype=torch.int32)
+    m.load_state_dict(sd)                       # strict: the legacy key is discarded, not "unexpected"
+
+
+def test_rank_slices_tile_every_global_batch():
+    """dataset.RankSlice (recstudio/data/dataset.py:1113-1114 for the row-sharded trainer): the ranks' parts of a global
+    batch, concatenated in rank order, are the single-process batch; a batch the world does not divide is padded by
+    wrapping around and says how many rows are real; train and eval loaders alike."""
+    from recstudio_amd.dataset import TripletDataset, rank_part, synthetic_interactions
+    idx = torch.arange(10)
+    parts = [rank_part(idx, r, 4) for r in range(4)]
+    assert [p[0].tolist() for p in parts] == [[0, 1, 2], [3, 4, 5], [6, 7, 8], [9, 0, 1]] and [p[1] for p in parts] == [3, 3, 3, 1]
+    assert [rank_part(torch.arange(2), r, 4)[1] for r in range(4)] == [1, 1, 0, 0]
+    u, i = synthetic_interactions(60, 300, 4000)
+    ds = TripletDataset.from_interactions(u, i)
+    trn, val, _ = ds.build(split_ratio=[0.8, 0.1, 0.1])
+    for world in (2, 3):
+        torch.manual_seed(5)
+        whole = list(trn.train_loader(32 * world, shuffle=True))
+        per_rank = []
+        for r in range(world):
+            torch.manual_seed(5)                 # seed_everything: the same host stream on every rank
+            per_rank.append(list(trn.train_loader(32, shuffle=True, ddp=True, rank=r, world=world)))
+        assert all(len(p) == len(whole) for p in per_rank)
+        for step, w in enumerate(whole):
+            got = torch.cat([p[step][trn.fiid][:p[step]['_n_valid']] for p in per_rank])
+            assert torch.equal(got, w[trn.fiid])
+            assert len({p[step][trn.fiid].numel() for p in per_rank}) == 1          # equal parts: the collectives need them
+        ev = list(val.eval_loader(20 * world))
+        ev_r = [list(val.eval_loader(20, ddp=True, rank=r, world=world)) for r in range(world)]
+        for step, w in enumerate(ev):
+            got = torch.cat([p[step][val.fuid][:p[step]['_n_valid']] for p in ev_r])
+            assert torch.equal(got, w[val.fuid]) and all('user_hist' in p[step] for p in ev_r)

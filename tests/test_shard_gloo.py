@@ -225,6 +225,13 @@ class CheckerBackend:
     def merge_lse(self, parts):
         return torch.logsumexp(parts, -1)
 
+    def mask_history(self, score, ids, user_hist, k):
+        """baseretriever.py:386-392 on sorted candidates: history items get -inf, then the k best in order."""
+        hit = (ids.unsqueeze(-1) == user_hist.unsqueeze(1)).any(-1) & (ids > 0)
+        score = torch.where(hit, torch.full((), float('-inf')), score)
+        order = torch.argsort(-score, dim=1, stable=True)[:, :k]
+        return torch.gather(score, 1, order), torch.gather(ids, 1, order)
+
     def merge_topk(self, vals, ids, k):
         order = torch.argsort(-vals, dim=1, stable=True)[:, :k]
         return torch.gather(vals, 1, order), torch.gather(ids, 1, order)
@@ -592,3 +599,65 @@ def test_plan_partitions_all_rows():
         for i, o in zip(ids.tolist(), own.tolist()):
             lo, hi = plan.bounds(o)
             assert lo <= i < hi
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# BaseRetriever.fit / evaluate as one rank of a multi-process job (VERDICT r2 missing #1 / #2)
+def _fit_worker(rank, world, port, result_dir, epochs, batch_global):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        import recstudio_amd as ra
+        from recstudio_amd.dataset import TripletDataset
+        g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'data_ml100k.npz'))
+        conf = {'train': {'epochs': epochs, 'batch_size': batch_global // world, 'negative_count': 5, 'seed': 2022,
+                          'learning_rate': 0.01, 'early_stop_patience': 100},
+                'eval': {'batch_size': 64 // world, 'cutoff': [10], 'val_metrics': ['ndcg', 'recall'], 'topk': 50,
+                         'test_metrics': ['ndcg', 'recall']},
+                'model': {'embed_dim': 16}}
+        model = ra.BPR(conf)                                       # seeds everything (recommender.py:34-35) ...
+        ds = TripletDataset('ml-100k', {'low_rating_thres': 3.0},
+                            _interactions=(g['raw_user'].astype(str), g['raw_item'].astype(str),
+                                           g['raw_rating'].astype(np.float64), g['raw_time'].astype(np.float64)))
+        trn, val, tst = ds.build(split_ratio=[0.8, 0.1, 0.1], shuffle=True, split_mode='user_entry')    # ... then the data
+        model.sampler = oracle.UniformSampler(trn.num_items)       # the checker's stand-in for the in-kernel sampler
+        best = model.fit(trn, val, dist=dist, shard_backend=CheckerBackend(), device='cpu')
+        test = model.evaluate(tst, verbose=False)
+        losses = torch.cat(model.train_losses)
+        sh = model._shard
+        assert tuple(model.item_encoder.weight.shape) == (sh['hi'] - sh['lo'], 16)     # this rank holds its row block only
+        # replicas of the tower are bit-equal; the item blocks tile the table
+        tower = [torch.zeros_like(model.query_encoder.weight) for _ in range(world)]
+        dist.all_gather(tower, model.query_encoder.weight.detach())
+        assert all(torch.equal(tower[0], t) for t in tower)
+        torch.save({'best': best, 'val': dict(model.logged_metrics), 'test': test, 'losses': losses,
+                    'item': model.item_encoder.weight.detach().clone(), 'lo': sh['lo'], 'tower': tower[0]},
+                   os.path.join(result_dir, f'w{world}r{rank}.pt'))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_fit_two_ranks_equals_one_rank_on_ml100k(tmp_path):
+    """BPR on the ml-100k fixture through ``BaseRetriever.fit`` / ``evaluate``: two ranks (rows of the item table and of its
+    Adam state sharded, tower replicated, every rank on its half of each global batch, one job-wide negative stream) give
+    the losses, ndcg@10 / recall@10 and weights of the one-rank run of the same global batch to 1e-5; the loss starts at
+    ln 2 (xavier-initialised towers) and falls, the ranking beats chance after two epochs."""
+    epochs, batch_global = 2, 1024
+    for world in (1, 2):
+        mp.spawn(_fit_worker, args=(world, _free_port(), str(tmp_path), epochs, batch_global), nprocs=world, join=True)
+    one = torch.load(tmp_path / 'w1r0.pt', weights_only=False)
+    two = [torch.load(tmp_path / f'w2r{r}.pt', weights_only=False) for r in range(2)]
+    assert one['losses'].numel() == epochs * ((66868 + batch_global - 1) // batch_global)
+    assert abs(float(one['losses'][0]) - 0.6931) < 2e-3 and float(one['losses'][-1]) < float(one['losses'][0]) - 0.05
+    for t in two:
+        np.testing.assert_allclose(t['losses'].numpy(), one['losses'].numpy(), rtol=1e-5, atol=1e-6)
+        for k in ('ndcg@10', 'recall@10'):
+            assert abs(t['val'][k] - one['val'][k]) < 1e-5 and abs(t['test'][k] - one['test'][k]) < 1e-5
+        assert t['best'] == pytest.approx(one['best'], abs=1e-5)
+        np.testing.assert_allclose(t['tower'].numpy(), one['tower'].numpy(), rtol=1e-4, atol=1e-6)
+    assert one['val']['ndcg@10'] > 0.01                              # two epochs already rank better than chance
+    items = torch.cat([two[0]['item'], two[1]['item']])
+    assert two[0]['lo'] == 0 and two[1]['lo'] == two[0]['item'].shape[0]
+    np.testing.assert_allclose(items.numpy(), one['item'].numpy(), rtol=1e-4, atol=1e-6)
+    assert not items[0].any()                                        # the padding row never moves
