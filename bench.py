@@ -379,13 +379,15 @@ def main():
             sweep = {}
             for b2 in (4096, 16384):
                 u2, p2 = uid[:b2].contiguous(), pos[:b2].contiguous()
-
-                def st(u2=u2, p2=p2, b2=b2):      # the same single-launch step as the headline line
-                    bufs[b2] = ra.ops.fused_forward(item, user, n, out=bufs.get(b2), fused_bpr=True,
-                                                    **dict(kw, query_index=u2, pos_ids=p2))
-                    return bufs[b2]
+                # the same single-launch step as the headline line, through ops.FusedStep (the call frozen into its argument
+                # block: at B = 4096 the ~35 us of Python per fused_forward call exceed the kernel's run time)
+                st = ra.ops.FusedStep(item, user, n, fused_bpr=True, **dict(kw, query_index=u2, pos_ids=p2))
                 t = time_gpu(st, args.steps, 10) * 1e3
-                sweep[f'B={b2}'] = {'ms_per_step': round(t, 4), 'M_triplets_s': round(b2 * n / t / 1e3, 2)}
+                alg2 = bytes_per_triplet(d, n, popular, fused_loss=True) * b2 * n
+                sweep[f'B={b2}'] = with_profile({'ms_per_step': round(t, 4), 'M_triplets_s': round(b2 * n / t / 1e3, 2),
+                                                 'frac_of_hbm_peak': round(alg2 / t / 1e6 / HBM_PEAK_GBS, 4)},
+                                                f'N1e7_popular_n64_B{b2}', alg2)
+                del st
             extra['sweep'] = sweep
         # configs[4]: full-catalog scores on the fp32 MFMA (N = 1e6, d = 128), logsumexp fused, + exact top-100
         try:

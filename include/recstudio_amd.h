@@ -434,7 +434,7 @@ int rsa_gather_f32(const float* src, const int64_t* positions, int64_t numel, fl
  * rsa_sample_uniform / rsa_sample_popular, so the ids are the ones the stand-alone samplers -- and the reference's
  * torch.randint / torch.rand + searchsorted, sampler.py:102-104, :246-258 -- produce); the [n_queries, num_neg] id tensor
  * is written only on request; (b) a segment is SELF-DESCRIBING: RSA_SHARD_HDR 8-byte header words {live keys, elements
- * the source rank dropped in this step} precede its keys, so the slack is never filled, owners skip the tiles past the
+ * the source rank dropped in this step -- in bank 0 of every (slice, owner), 0 elsewhere} precede its keys, so the slack is never filled, owners skip the tiles past the
  * count, and after the key all-to-all every rank knows the job-wide number of dropped elements of the step without a
  * collective of its own; (c) the home side keeps ONE int32 per element (slot_of: where its key sits in the send buffer
  * == where its score sits in the returned buffer; -1 = dropped) instead of an 8-byte position per slot, and gathers
@@ -457,9 +457,13 @@ typedef struct rsa_shard_route_args {
   int32_t n_slices;            /* pipelined slices (>= 1): slice c = the c-th of n_slices contiguous ranges of the launch's
                                   workgroups -- an arbitrary, run-independent partition of the step's elements */
   int32_t n_shards;            /* G <= 64 */
+  int32_t n_banks;             /* >= 1: what goes to one owner in one slice is split over n_banks segments, each filled through its
+                                  own cursor by its own share of the launch's workgroups (one cursor per owner makes every
+                                  workgroup queue up on one atomic address); n_slices * n_shards * n_banks <= 4096 */
+  int32_t _pad0;
   int64_t rows_per_shard;      /* owner(id) = min(id / rows_per_shard, G - 1) */
   int64_t query_base;          /* global index of query 0 (rank * n_queries): goes into the keys */
-  int64_t capacity;            /* keys per (slice, owner) segment */
+  int64_t capacity;            /* keys per (slice, owner, bank) segment */
   int64_t n_items;             /* catalog size: uniform ids are drawn from [1, n_items) */
   uint64_t seed, offset;       /* Philox state, see "Philox state" (sampler != GIVEN) */
   uint32_t grid_threads;
@@ -473,12 +477,12 @@ typedef struct rsa_shard_route_args {
   const float* cdf_lines;
   int32_t guide_log2;
   int32_t lines_log2;
-  int64_t* send_keys;          /* [n_slices][n_shards][RSA_SHARD_HDR + capacity] out; key = (query_base + query) << 32 | local row.
+  int64_t* send_keys;          /* [n_slices][n_shards][n_banks][RSA_SHARD_HDR + capacity] out; key = (query_base + query) << 32 | local row.
                                   NULL: count only (nothing is sampled into the outputs, only counts_out is written) */
   int32_t* slot_of;            /* [n_queries * (1 + num_neg)] out, element e = query * (1 + num_neg) + column */
-  int32_t* cursors;            /* [(n_slices * n_shards + 1) * 32] device scratch (one 128-byte line per cursor), zeroed
-                                  ONCE by the caller (self-resetting) */
-  int32_t* counts_out;         /* nullable [n_slices * n_shards]: exact element counts per (slice, owner) -- calibration */
+  int32_t* cursors;            /* [(n_slices * n_shards * n_banks + 33) * 32] int32 device scratch (one 128-byte line per cursor
+                                  and ticket), zeroed ONCE by the caller (self-resetting) */
+  int32_t* counts_out;         /* nullable [n_slices * n_shards * n_banks]: exact element counts per segment -- calibration */
 } rsa_shard_route_args;
 int64_t rsa_shard_segment_stride(int64_t capacity);    /* RSA_SHARD_HDR + capacity: 8-byte words per segment */
 int rsa_shard_sample_route(const rsa_shard_route_args* args, rsa_stream_t stream);

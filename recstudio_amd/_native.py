@@ -61,7 +61,7 @@ class ShardRouteArgs(Structure):
     _fields_ = [
         ('pos_ids', c_void_p), ('neg_ids', c_void_p), ('neg_logp', c_void_p), ('pos_logp', c_void_p),
         ('n_queries', c_int64), ('num_neg', c_int32), ('sampler', c_int32), ('n_slices', c_int32), ('n_shards', c_int32),
-        ('rows_per_shard', c_int64), ('query_base', c_int64), ('capacity', c_int64), ('n_items', c_int64),
+        ('n_banks', c_int32), ('_pad0', c_int32), ('rows_per_shard', c_int64), ('query_base', c_int64), ('capacity', c_int64), ('n_items', c_int64),
         ('seed', c_uint64), ('offset', c_uint64), ('grid_threads', c_uint32), ('_pad', c_uint32), ('elem_base', c_uint64),
         ('table', c_void_p), ('pop_prob', c_void_p), ('guide', c_void_p), ('table_prob', c_void_p), ('cdf_lut', c_void_p),
         ('cdf_lines', c_void_p), ('guide_log2', c_int32), ('lines_log2', c_int32),

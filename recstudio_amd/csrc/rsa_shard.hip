@@ -211,9 +211,12 @@ __global__ __launch_bounds__(256) void gather_f32_kernel(const float* __restrict
 // Version 2 of the fixed-capacity exchange (ABI v5): sampling fused into the routing pass, self-describing segments,
 // 32-bit slots, one home-side kernel for scatter + loss + mean (+ d loss/d score in routed order).
 //
-// Send buffer of a rank: [n_slices][n_shards] segments of stride = RSA_SHARD_HDR + capacity 8-byte words.  Word 0 of a
-// segment = number of keys in it (<= capacity), word 1 = elements of THIS STEP the source rank could not place anywhere
-// (its dropped total over all segments), then the keys.  The headers travel with the keys through the equal-split
+// Send buffer of a rank: [n_slices][n_shards][n_banks] segments of stride = RSA_SHARD_HDR + capacity 8-byte words.  Word 0
+// of a segment = number of keys in it (<= capacity), word 1 = elements of THIS STEP the source rank could not place
+// anywhere (its dropped total over all segments; carried by bank 0 of every (slice, owner), 0 in the other banks), then
+// the keys.  BANKS: what goes from one rank to one owner in one slice is split over n_banks segments, each filled by its
+// own share of the workgroups through its own cursor -- one cursor per (slice, owner) made every workgroup of the
+// launch queue up on one address (~10 ns per atomic: 10 us for 1028 workgroups at one owner).  The headers travel with the keys through the equal-split
 // all-to-all, so every owner learns (a) how many slots of each received segment are live -- no -1 fill of the slack,
 // tiles past the count are skipped -- and (b) the step's dropped totals of ALL sources: after the key exchange every
 // rank holds the job-wide overflow count without a collective of its own.
@@ -254,7 +257,7 @@ struct RouteV2 {
   float* pos_logp;
   int64_t* send;
   int32_t* slot_of;
-  int32_t* cursors;        // [n_slices * G] arrival cursors + [1] block ticket, CURSOR_PAD ints apart: zero between launches
+  int32_t* cursors;        // [n_slices * G * n_banks] arrival cursors + [1 + TICKET_SUB] tickets, CURSOR_PAD ints apart: zero between launches
   int32_t* counts_out;
   int64_t n_queries, capacity, stride, rows_per_shard, query_base;
   int64_t n_neg;           // n_queries * n
@@ -263,14 +266,18 @@ struct RouteV2 {
   PhiloxCall pc;
   PopTables pop;
   Div32 by_width, by_rows, by_n, by_gt, by_range;
-  int32_t n, G, sampler, n_slices, unroll;
+  int32_t n, G, sampler, n_slices, unroll, n_banks;
 };
+
+constexpr int TICKET_SUB = 32;      // two-level completion ticket: 32 sub-words, then one top word
 
 template <bool COUNT_ONLY>
 __global__ __launch_bounds__(256) void shard_sample_route_kernel(const RouteV2 a) {
   __shared__ int32_t cnt[64], base[64];
   __shared__ int s_last;
-  const int slice = (int)(((int64_t)blockIdx.x * a.n_slices) / gridDim.x);
+  // contiguous ranges of workgroups: n_slices slices, each cut into n_banks banks
+  const int micro = (int)(((int64_t)blockIdx.x * a.n_slices * a.n_banks) / gridDim.x);
+  const int slice = micro / a.n_banks, bank = micro - slice * a.n_banks;
   if (threadIdx.x < 64) cnt[threadIdx.x] = 0;
   constexpr int EPT = ROUTE_ITEMS * 4;
   int32_t gl[EPT];         // owner << 16 | slot inside this workgroup's range; -1: no element
@@ -361,11 +368,11 @@ __global__ __launch_bounds__(256) void shard_sample_route_kernel(const RouteV2 a
   __syncthreads();
   if (threadIdx.x < a.G) {
     const int32_t c = cnt[threadIdx.x];
-    base[threadIdx.x] = c ? atomicAdd(&a.cursors[(slice * a.G + threadIdx.x) * CURSOR_PAD], c) : 0;
+    base[threadIdx.x] = c ? atomicAdd(&a.cursors[((slice * a.G + threadIdx.x) * a.n_banks + bank) * CURSOR_PAD], c) : 0;
   }
   __syncthreads();      // the returning cursor atomics of this workgroup have been performed
   if (!COUNT_ONLY) {
-    int64_t* seg0 = a.send + (int64_t)slice * a.G * a.stride;
+    const int64_t seg_base = (int64_t)slice * a.G * a.n_banks;     // first segment of the slice
 #pragma unroll
     for (int k = 0; k < EPT; ++k) {
       if (gl[k] < 0) continue;
@@ -376,17 +383,32 @@ __global__ __launch_bounds__(256) void shard_sample_route_kernel(const RouteV2 a
         continue;
       }
       const int64_t m = (int64_t)a.by_width.div((uint32_t)el[k]);
-      const int64_t at = (int64_t)gk * a.stride + RSA_SHARD_HDR + slot;
-      seg0[at] = ((a.query_base + m) << 32) | (int64_t)local[k];
-      a.slot_of[el[k]] = (int32_t)((int64_t)slice * a.G * a.stride + at);
+      const int64_t at = (seg_base + (int64_t)gk * a.n_banks + bank) * a.stride + RSA_SHARD_HDR + slot;
+      a.send[at] = ((a.query_base + m) << 32) | (int64_t)local[k];
+      a.slot_of[el[k]] = (int32_t)at;
     }
   }
-  // the workgroup that takes the last ticket sees every cursor final: it writes the segment headers (and the exact
-  // counts for the calibration step) and leaves the cursors and the ticket zeroed for the next launch
-  const int segs = a.n_slices * a.G;
+  // The workgroup that takes the last ticket sees every cursor final: it writes the segment headers (and the exact
+  // counts for the calibration step) and leaves the cursors and the tickets zeroed for the next launch.  Two levels
+  // (workgroup b -> sub-ticket b % 32, the last arrival of a sub-ticket -> the top ticket), like the loss reduction of
+  // the fused kernels: one ticket word made the tail of every workgroup wait in a queue of gridDim.x atomics.
+  const int segs = a.n_slices * a.G * a.n_banks;
   if (threadIdx.x == 0) {
-    const int t = __hip_atomic_fetch_add(&a.cursors[segs * CURSOR_PAD], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    s_last = t == (int)gridDim.x - 1;
+    int32_t* tick = a.cursors + (int64_t)segs * CURSOR_PAD;
+    const unsigned j = blockIdx.x % TICKET_SUB;
+    const unsigned members = (gridDim.x - j + TICKET_SUB - 1) / TICKET_SUB;
+    const unsigned n_sub = gridDim.x < TICKET_SUB ? gridDim.x : TICKET_SUB;
+    int last = 0;
+    const int t = __hip_atomic_fetch_add(&tick[(1 + j) * CURSOR_PAD], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (t == (int)members - 1) {
+      __hip_atomic_store(&tick[(1 + j) * CURSOR_PAD], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int t2 = __hip_atomic_fetch_add(&tick[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (t2 == (int)n_sub - 1) {
+        __hip_atomic_store(&tick[0], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last = 1;
+      }
+    }
+    s_last = last;
   }
   __syncthreads();
   if (s_last && threadIdx.x < 64) {
@@ -402,11 +424,10 @@ __global__ __launch_bounds__(256) void shard_sample_route_kernel(const RouteV2 a
       if (a.counts_out != nullptr) a.counts_out[sg] = (int32_t)c;
       if (!COUNT_ONLY) {
         a.send[(int64_t)sg * a.stride] = c < a.capacity ? c : a.capacity;
-        a.send[(int64_t)sg * a.stride + 1] = dropped;
+        a.send[(int64_t)sg * a.stride + 1] = (sg % a.n_banks) == 0 ? dropped : 0;
       }
       __hip_atomic_store(&a.cursors[sg * CURSOR_PAD], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (threadIdx.x == 0) __hip_atomic_store(&a.cursors[segs * CURSOR_PAD], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
@@ -706,8 +727,8 @@ extern "C" int rsa_shard_sample_route(const rsa_shard_route_args* a, rsa_stream_
   RSA_CHECK_ARG(a->n_queries >= 0 && a->num_neg >= 0 && a->rows_per_shard >= 1 && a->rows_per_shard < (1ll << 32),
                 "rsa_shard_sample_route: bad sizes");
   RSA_CHECK_ARG(a->n_shards >= 1 && a->n_shards <= 64, "rsa_shard_sample_route: n_shards must be in [1, 64]");
-  RSA_CHECK_ARG(a->n_slices >= 1 && a->n_slices * a->n_shards <= 4096,
-                "rsa_shard_sample_route: n_slices must be >= 1 with n_slices * n_shards <= 4096");
+  RSA_CHECK_ARG(a->n_slices >= 1 && a->n_banks >= 1 && (int64_t)a->n_slices * a->n_shards * a->n_banks <= 4096,
+                "rsa_shard_sample_route: n_slices, n_banks must be >= 1 with n_slices * n_shards * n_banks <= 4096");
   RSA_CHECK_ARG(a->query_base >= 0 && a->query_base + a->n_queries < (1ll << 31), "rsa_shard_sample_route: query index overflow");
   RSA_CHECK_ARG(a->sampler >= RSA_SAMPLER_GIVEN && a->sampler <= RSA_SAMPLER_POPULAR, "rsa_shard_sample_route: unknown sampler %d",
                 a->sampler);
@@ -716,7 +737,7 @@ extern "C" int rsa_shard_sample_route(const rsa_shard_route_args* a, rsa_stream_
   RSA_CHECK_ARG(!count_only || a->counts_out != nullptr, "rsa_shard_sample_route: nothing to do (send_keys and counts_out null)");
   if (a->n_queries == 0) {
     if (a->counts_out) {
-      if (hipMemsetAsync(a->counts_out, 0, sizeof(int32_t) * a->n_slices * a->n_shards, (hipStream_t)stream) != hipSuccess) {
+      if (hipMemsetAsync(a->counts_out, 0, sizeof(int32_t) * a->n_slices * a->n_shards * a->n_banks, (hipStream_t)stream) != hipSuccess) {
         rsa::set_error("rsa_shard_sample_route: memset failed");
         return RSA_ERR_HIP;
       }
@@ -724,7 +745,7 @@ extern "C" int rsa_shard_sample_route(const rsa_shard_route_args* a, rsa_stream_
     if (!count_only) {     // empty segments still carry their headers
       const int64_t stride = a->capacity + RSA_SHARD_HDR;
       if (hipMemset2DAsync(a->send_keys, sizeof(int64_t) * stride, 0, sizeof(int64_t) * RSA_SHARD_HDR,
-                           (size_t)a->n_slices * a->n_shards, (hipStream_t)stream) != hipSuccess) {
+                           (size_t)a->n_slices * a->n_shards * a->n_banks, (hipStream_t)stream) != hipSuccess) {
         rsa::set_error("rsa_shard_sample_route: memset failed");
         return RSA_ERR_HIP;
       }
@@ -748,7 +769,7 @@ extern "C" int rsa_shard_sample_route(const rsa_shard_route_args* a, rsa_stream_
   RSA_CHECK_ARG(a->pos_logp == nullptr || a->pop_prob != nullptr, "rsa_shard_sample_route: pos_logp needs pop_prob");
   if (!count_only) {
     RSA_CHECK_ARG(a->slot_of != nullptr, "rsa_shard_sample_route: slot_of is null");
-    RSA_CHECK_ARG(a->capacity >= 1 && (a->capacity + RSA_SHARD_HDR) * a->n_shards * a->n_slices < (1ll << 31),
+    RSA_CHECK_ARG(a->capacity >= 1 && (a->capacity + RSA_SHARD_HDR) * a->n_shards * a->n_slices * a->n_banks < (1ll << 31),
                   "rsa_shard_sample_route: capacity out of range");
   }
   RSA_CHECK_ARG(a->n_queries * (a->num_neg + 1) < (1ll << 31), "rsa_shard_sample_route: more than 2^31 elements");
@@ -774,6 +795,7 @@ extern "C" int rsa_shard_sample_route(const rsa_shard_route_args* a, rsa_stream_
   r.G = a->n_shards;
   r.sampler = a->sampler;
   r.n_slices = a->n_slices;
+  r.n_banks = a->n_banks;
   // the enumeration of the negatives: Philox blocks of the torch call (see the kernel), or the same shape made up for
   // given ids (four interleaved quarters)
   if (a->sampler == RSA_SAMPLER_GIVEN || n_neg == 0) {
@@ -800,7 +822,7 @@ extern "C" int rsa_shard_sample_route(const rsa_shard_route_args* a, rsa_stream_
   r.by_gt = make_div32(T);
   r.by_range = make_div32((uint64_t)(a->n_items - 1));        // 32-bit draws only (ranges below 2^28)
   int64_t blocks = (r.n_groups + a->n_queries + ROUTE_ITEMS_PER_BLOCK - 1) / ROUTE_ITEMS_PER_BLOCK;
-  if (blocks < a->n_slices) blocks = a->n_slices;         // every slice owns at least one workgroup
+  if (blocks < (int64_t)a->n_slices * a->n_banks) blocks = (int64_t)a->n_slices * a->n_banks;     // every bank owns at least one workgroup
   RSA_CHECK_ARG(blocks < (1ll << 31), "rsa_shard_sample_route: grid too large");
   const dim3 grid((unsigned)blocks), block(256);
   if (count_only) hipLaunchKernelGGL(shard_sample_route_kernel<true>, grid, block, 0, (hipStream_t)stream, r);

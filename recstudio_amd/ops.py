@@ -267,7 +267,7 @@ def fused_forward(item_table, query, num_neg, *, query_index=None, pos_ids=None,
                   table=None, pop_prob=None, guide=None, guide_log2=0, generator=None, n_queries=None,
                   out=None, want_logp=True, table_prob=None, fused_bpr=False, want_mean=True, cdf_lut=None,
                   want_query_grad=False, rng_state=None, cdf_lines=None, lines_log2=0, fused_loss=None,
-                  pos_logp=None, neg_logp=None):
+                  pos_logp=None, neg_logp=None, _plan=None):
     """One launch of rsa_fused_sample_gather_score.  Returns a dict with
     neg_ids [M,n] int64, neg_score [M,n], pos_score [M] (if pos_ids), and for the
     popularity sampler neg_logp [M,n], pos_logp [M].  ``out``: a dict returned by an earlier
@@ -372,7 +372,40 @@ def fused_forward(item_table, query, num_neg, *, query_index=None, pos_ids=None,
     elif want_query_grad:
         raise ValueError('want_query_grad needs a fused loss (fused_bpr=True / fused_loss=...)')
     nat.check(nat.lib().rsa_fused_sample_gather_score(ctypes.byref(a), _stream()), 'rsa_fused_sample_gather_score')
+    if _plan is not None:
+        _plan.update(args=a, out=out, device=dev, generator=generator, numel=M * n, keep=(item_table, query, query_index, pos_ids,
+                                                                                         neg_ids, table, pop_prob, guide))
+        _plan['unroll'] = None if sampler == nat.SAMPLER_GIVEN or rng_state is not None else \
+            (4 if sampler == nat.SAMPLER_POPULAR else rng.randint_unroll(1, n_items))
     return out
+
+
+class FusedStep:
+    """A ``fused_forward`` call frozen into its argument block: ``step()`` re-launches the same kernel on the same
+    buffers, drawing fresh negatives (the generator is advanced exactly as a ``fused_forward`` call would).  What it
+    saves is host time only -- tensor checks, the ctypes struct fill: ~35 us of Python per call, more than a B = 4096
+    launch runs on the GPU.  The outputs are the dict of the first call (overwritten in place by every step)."""
+
+    def __init__(self, item_table, query, num_neg, **kw):
+        if kw.get('out') is not None or kw.get('rng_state') is not None:
+            raise ValueError('FusedStep owns its output buffers and reads the torch generator')
+        self._p = {}
+        self.out = fused_forward(item_table, query, num_neg, _plan=self._p, **kw)
+        if 'args' not in self._p:
+            raise ValueError('this configuration is composed of several launches: call fused_forward')
+        self._fn = nat.lib().rsa_fused_sample_gather_score
+        self._ref = ctypes.byref(self._p['args'])
+
+    def __call__(self):
+        p = self._p
+        if p['unroll'] is not None:
+            pc = rng.reserve(p['numel'], p['unroll'], p['device'], p['generator'])
+            a = p['args']
+            a.seed, a.offset, a.grid_threads, a.elem_base = pc.seed, pc.offset, pc.grid_threads, pc.elem_base
+        rc = self._fn(self._ref, ctypes.c_void_p(_raw_stream(p['device'])))
+        if rc != 0:
+            nat.check(rc, 'rsa_fused_sample_gather_score')
+        return self.out
 
 
 @_on_device

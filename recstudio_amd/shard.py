@@ -67,6 +67,7 @@ class HipBackend:
     """Device work of the sharded step, all through the C ABI."""
 
     HDR = 2          # RSA_SHARD_HDR: 8-byte header words {live keys, dropped by the source this step} per segment
+    BANKS = 8        # segments per (slice, owner), each filled through its own cursor (rsa_shard_route_args.n_banks)
 
     def make_generator(self, seed, device):
         return torch.Generator(device=device).manual_seed(int(seed))
@@ -74,7 +75,7 @@ class HipBackend:
     def new_state(self, device):
         """Per-table device words: routing cursors (zeroed once, self-resetting), the sticky job-wide dropped count,
         the dropped count of the last step, and the gated update scales {item scale, gate} the backward multiplies by."""
-        return {'cursors': torch.zeros(4097 * 32, dtype=torch.int32, device=device),
+        return {'cursors': torch.zeros((4096 + 33) * 32, dtype=torch.int32, device=device),
                 'overflow': torch.zeros(1, dtype=torch.int32, device=device),
                 'step_dropped': torch.zeros(1, dtype=torch.int32, device=device),
                 'scale': torch.ones(2, dtype=torch.float32, device=device)}
@@ -109,16 +110,16 @@ class HipBackend:
     # -- version 2 of the fixed-capacity exchange (rsa_shard_sample_route / _score_segments / _home) -------------------
     @ops._on_device
     def sample_route(self, state, plan, rank, pos, n, chunks, capacity, spec, generator, neg=None, want_ids=False,
-                     want_logp=False, count_only=False):
-        """One launch: draw (or read) the negatives, route every (query, item) element of all ``chunks`` query slices.
-        -> dict(send [C*G*stride] int64, slot_of [B*(1+n)] int32, stride, neg_ids / log_neg_prob / log_pos_prob when
-        asked for), or the exact per-(slice, owner) counts [C*G] int32 with ``count_only`` (the generator is not
+                     want_logp=False, count_only=False, banks=1):
+        """One launch: draw (or read) the negatives, route every (query, item) element of all ``chunks`` slices.
+        -> dict(send [C*G*banks*stride] int64, slot_of [B*(1+n)] int32, stride, neg_ids / log_neg_prob / log_pos_prob when
+        asked for), or the exact per-segment counts [C*G*banks] int32 with ``count_only`` (the generator is not
         advanced: the next call routes the very draw that was counted)."""
         B, dev, G = pos.numel(), pos.device, plan.world
         a = nat.ShardRouteArgs()
         kind = spec['kind'] if spec is not None else nat.SAMPLER_GIVEN
         a.pos_ids, a.n_queries, a.num_neg, a.sampler = ptr(ops._need(pos, torch.int64, 'pos')), B, int(n), int(kind)
-        a.n_slices, a.n_shards, a.rows_per_shard = int(chunks), G, plan.rows_per_shard
+        a.n_slices, a.n_shards, a.n_banks, a.rows_per_shard = int(chunks), G, int(banks), plan.rows_per_shard
         a.query_base, a.capacity = rank * B, int(capacity)
         a.n_items = spec['n_items'] if spec is not None else plan.n_items
         out = {}
@@ -151,12 +152,12 @@ class HipBackend:
             a.neg_logp, a.pos_logp = ptr(out['log_neg_prob']), ptr(out['log_pos_prob'])
         a.cursors = ptr(state['cursors'])
         if count_only:
-            counts = torch.empty(chunks * G, dtype=torch.int32, device=dev)
+            counts = torch.empty(chunks * G * banks, dtype=torch.int32, device=dev)
             a.counts_out = ptr(counts)
             nat.check(nat.lib().rsa_shard_sample_route(ctypes.byref(a), ops._stream()), 'rsa_shard_sample_route')
             return counts
         stride = int(capacity) + self.HDR
-        out['send'] = torch.empty(chunks * G * stride, dtype=torch.int64, device=dev)
+        out['send'] = torch.empty(chunks * G * banks * stride, dtype=torch.int64, device=dev)
         out['slot_of'] = torch.empty(B * (n + 1), dtype=torch.int32, device=dev)
         out['stride'] = stride
         a.send_keys, a.slot_of = ptr(out['send']), ptr(out['slot_of'])
@@ -465,7 +466,8 @@ class ShardedItemTable:
         B, n, C = key
         m = torch.tensor([int(largest)], dtype=torch.int64, device=self.item_local.device)
         self._all_reduce_max(m)
-        cap = int(int(m.item()) * self.slack) + self.margin
+        S = int(getattr(self.backend, 'BANKS', 1))
+        cap = int(int(m.item()) * self.slack) + (self.margin + S - 1) // S
         cap = min(B * (n + 1), (cap + 255) // 256 * 256)
         self._cap[key] = max(cap, 1)
         return self._cap[key]
@@ -512,17 +514,20 @@ class ShardedItemTable:
         be, st, plan = self.backend, self.state, self.plan
         B, G = pos.numel(), plan.world
         C = self.chunks if (self.chunks > 1 and B % self.chunks == 0) else 1
+        S = int(getattr(be, 'BANKS', 1))           # segments per (slice, owner): every consumer just sees G * S segments
         key = (B, n, C)
         cap = self._cap.get(key)
         if cap is None:
-            # calibration: exact per-(slice, owner) counts of the very draw this step routes (the generator is not
-            # advanced), largest over slices, owners and ranks
-            counts = be.sample_route(st, plan, self.rank, pos, n, C, 0, spec, self.sample_generator, neg=neg, count_only=True)
+            # calibration: exact per-segment counts of the very draw this step routes (the generator is not advanced),
+            # largest over slices, owners, banks and ranks
+            counts = be.sample_route(st, plan, self.rank, pos, n, C, 0, spec, self.sample_generator, neg=neg, count_only=True,
+                                     banks=S)
             cap = self._capacity(key, int(counts.max()))
         # the sampler's log-probabilities: BPRLoss ignores them (loss_func.py:55-59), everything else gets them
         r = be.sample_route(st, plan, self.rank, pos, n, C, cap, spec, self.sample_generator, neg=neg,
-                            want_ids=want_ids, want_logp=want_logp and fused_loss != 'bpr')
-        stride, per = r['stride'], G * r['stride']
+                            want_ids=want_ids, want_logp=want_logp and fused_loss != 'bpr', banks=S)
+        GS = G * S
+        stride, per = r['stride'], GS * r['stride']
         send = r['send']
         scores_home = torch.empty(C * per, dtype=torch.float32, device=send.device)
         recv_keys = []
@@ -531,9 +536,9 @@ class ShardedItemTable:
             rk = self._all_to_all(send)
             recv_keys.append(rk)
             if self._solo:
-                be.score_segments(st, self.item_local, q_all, rk, G, stride, first=True, out=scores_home)
+                be.score_segments(st, self.item_local, q_all, rk, GS, stride, first=True, out=scores_home)
             else:
-                self._all_to_all(be.score_segments(st, self.item_local, q_all, rk, G, stride, first=True), out=scores_home)
+                self._all_to_all(be.score_segments(st, self.item_local, q_all, rk, GS, stride, first=True), out=scores_home)
         else:
             waits = [self._all_to_all_start(send[c * per:(c + 1) * per]) for c in range(C)]
             q_all = q_gather()
@@ -543,9 +548,9 @@ class ShardedItemTable:
                 recv_keys.append(rk)
                 home_c = scores_home[c * per:(c + 1) * per]
                 if self._solo:
-                    be.score_segments(st, self.item_local, q_all, rk, G, stride, first=c == 0, out=home_c)
+                    be.score_segments(st, self.item_local, q_all, rk, GS, stride, first=c == 0, out=home_c)
                 else:
-                    sc = be.score_segments(st, self.item_local, q_all, rk, G, stride, first=c == 0)
+                    sc = be.score_segments(st, self.item_local, q_all, rk, GS, stride, first=c == 0)
                     back.append(self._all_to_all_start(sc, out=home_c))
             for w in back:
                 w()
@@ -557,7 +562,7 @@ class ShardedItemTable:
         self._after_fixed_step()
         out['neg_ids'], out['log_pos_prob'], out['log_neg_prob'] = r.get('neg_ids'), log_pos, log_neg
         if keep_route:
-            out['route'] = {'B': B, 'n': n, 'C': C, 'stride': stride, 'q_all': q_all, 'slot_of': r['slot_of'],
+            out['route'] = {'B': B, 'n': n, 'C': C, 'GS': GS, 'stride': stride, 'q_all': q_all, 'slot_of': r['slot_of'],
                             'recv_keys': recv_keys, 'd_send': out.pop('d_send', None)}
         return out
 
@@ -574,7 +579,7 @@ class ShardedItemTable:
         extra = {} if item_scale is None else {'item_scale': item_scale}
         pad_row = 0 if self.rank == 0 else -1
         if 'slot_of' in route:
-            G, C, stride = self.plan.world, route['C'], route['stride']
+            G, C, stride = route['GS'], route['C'], route['stride']     # G: segments per slice (owners x banks)
             per = G * stride
             if dpos is None:
                 d_send = route['d_send']

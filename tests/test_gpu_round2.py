@@ -733,3 +733,23 @@ def test_fused_bpr_long_queries_deterministic_and_exact(ra, d, n, B):
         assert torch.equal(a['neg_ids'], want_ids) and torch.equal(b['neg_ids'], want_ids)
         rel_close(a['loss'].cpu(), b['loss'].cpu(), rtol=1e-6)
         rel_close(a['neg_score'].cpu(), b['neg_score'].cpu(), rtol=1e-5, atol=1e-6)
+
+
+def test_fused_step_object_replays_the_call_with_fresh_draws(ra):
+    """ops.FusedStep: the frozen call draws what successive fused_forward calls draw (generator advanced alike) and
+    writes the same outputs into its own buffers."""
+    N, U, d, B, n = 5003, 97, 128, 70, 64
+    iw, uw = _tables(N, U, d, 3)
+    iwd, uwd = iw.to(DEV), uw.to(DEV)
+    uid = torch.randint(1, U, (B,), device=DEV)
+    pos = torch.randint(1, N, (B,), device=DEV)
+    kw = dict(query_index=uid, pos_ids=pos, sampler=ra._native.SAMPLER_UNIFORM, fused_bpr=True)
+    torch.manual_seed(9)
+    want = [ra.ops.fused_forward(iwd, uwd, n, **kw) for _ in range(3)]
+    torch.manual_seed(9)
+    step = ra.ops.FusedStep(iwd, uwd, n, **kw)
+    for k in range(3):
+        o = step() if k else step.out
+        assert torch.equal(o['neg_ids'], want[k]['neg_ids']) and torch.equal(o['loss'], want[k]['loss'])
+        assert torch.equal(o['dneg'], want[k]['dneg'])
+    assert torch.cuda.default_generators[0].get_offset() == 3 * ra.rng.counter_offset(B * n, ra.rng.grid_threads(B * n, *ra.rng.device_props(DEV)), 4)

@@ -60,7 +60,8 @@ class CheckerBackend:
         return None
 
     def sample_route(self, state, plan, rank, pos, n, chunks, capacity, spec, generator, neg=None, want_ids=False,
-                     want_logp=False, count_only=False):
+                     want_logp=False, count_only=False, banks=1):
+        assert banks == 1                                      # (the checker has no BANKS attribute: one segment per owner)
         B, G, C = pos.numel(), plan.world, chunks
         out = {}
         if spec is not None:
