@@ -635,6 +635,134 @@ __global__ __launch_bounds__(256) void shard_home_kernel(const HomeArgs a) {
   }
 }
 
+// Short queries (n <= 256): a wave handles QPW queries per iteration -- QPW * TPQ = 8 tiles in flight, the loads of all of
+// them issued together -- and keeps every score in registers, so the SampledSoftmax gradient needs no second pass.
+// One query per iteration was a chain of four dependent round trips per query (52 us for 65536 queries of n = 64).
+template <int LOSS, int QPW>
+__global__ __launch_bounds__(256) void shard_home_small_kernel(const HomeArgs a) {
+  constexpr int TPQ = HOME_TB / QPW;
+  const int lane = lane_id();
+  const int64_t wave0 = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int64_t wstride = (int64_t)gridDim.x * (blockDim.x >> 6);
+  const int n = a.n;
+  const float w = 1.f / (float)n, inv_m = 1.f / (float)a.mean_den;
+  float wave_loss = 0.f;
+  for (int64_t m0 = wave0 * QPW; m0 < a.n_queries; m0 += wstride * QPW) {
+    int32_t sp[QPW], s[QPW][TPQ];
+    float pos[QPW], sc[QPW][TPQ], lq[QPW][TPQ], lqp[QPW];
+#pragma unroll
+    for (int q = 0; q < QPW; ++q) {
+      const int64_t m = m0 + q;
+      const bool mv = m < a.n_queries;
+      sp[q] = mv ? a.slot_of[m * (n + 1)] : -1;
+#pragma unroll
+      for (int t = 0; t < TPQ; ++t) {
+        const int j = (t << 6) + lane;
+        s[q][t] = (mv && j < n) ? a.slot_of[m * (n + 1) + 1 + j] : -1;
+        lq[q][t] = (LOSS == 2 && mv && j < n && a.neg_logp) ? a.neg_logp[m * n + j] : 0.f;
+      }
+      lqp[q] = (LOSS == 2 && mv && a.pos_logp) ? a.pos_logp[m] : 0.f;
+    }
+#pragma unroll
+    for (int q = 0; q < QPW; ++q) {
+      pos[q] = sp[q] >= 0 ? a.scores[sp[q]] : 0.f;
+#pragma unroll
+      for (int t = 0; t < TPQ; ++t) sc[q][t] = s[q][t] >= 0 ? a.scores[s[q][t]] : 0.f;
+    }
+#pragma unroll
+    for (int q = 0; q < QPW; ++q) {
+      const int64_t m = m0 + q;
+      if (m >= a.n_queries) break;                 // wave-uniform
+      if (lane == 0 && a.pos_score != nullptr) a.pos_score[m] = pos[q];
+      if (a.neg_score != nullptr) {
+#pragma unroll
+        for (int t = 0; t < TPQ; ++t) {
+          const int j = (t << 6) + lane;
+          if (j < n) a.neg_score[m * n + j] = sc[q][t];
+        }
+      }
+      if constexpr (LOSS == 1) {
+        float lsum = 0.f, gsum = 0.f;
+#pragma unroll
+        for (int t = 0; t < TPQ; ++t) {
+          const int j = (t << 6) + lane;
+          const bool live = s[q][t] >= 0 && sp[q] >= 0;
+          const float xd = pos[q] - sc[q][t];
+          const float tt = __expf(-fabsf(xd));
+          const float ls = live ? fminf(xd, 0.f) - __logf(1.f + tt) : 0.f;
+          const float r = __frcp_rn(1.f + tt);
+          const float sg = live ? (xd >= 0.f ? tt * r : r) * w * inv_m : 0.f;
+          if (j < n && a.dneg != nullptr) a.dneg[m * n + j] = sg;
+          if (s[q][t] >= 0 && a.d_send != nullptr) a.d_send[s[q][t]] = sg;
+          lsum += ls;
+          gsum += sg;
+        }
+        lsum = group_sum<64>(lsum);
+        gsum = group_sum<64>(gsum);
+        const float row = -lsum * w;
+        wave_loss += row;
+        if (lane == 0) {
+          if (a.row_loss != nullptr) a.row_loss[m] = row;
+          if (a.dpos != nullptr) a.dpos[m] = -gsum;
+          if (sp[q] >= 0 && a.d_send != nullptr) a.d_send[sp[q]] = -gsum;
+        }
+      } else if constexpr (LOSS == 2) {
+        const float z_pos = pos[q] - lqp[q];
+        float z[TPQ], bm = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < TPQ; ++t) {
+          z[t] = s[q][t] >= 0 ? sc[q][t] - lq[q][t] : -INFINITY;
+          bm = fmaxf(bm, z[t]);
+        }
+        const float run_m = wave_max(bm);
+        float part = 0.f;
+        if (run_m > -INFINITY) {
+#pragma unroll
+          for (int t = 0; t < TPQ; ++t) part += s[q][t] >= 0 ? __expf(z[t] - run_m) : 0.f;
+        }
+        const float run_s = group_sum<64>(part);
+        const bool gone = sp[q] < 0;
+        const float top = fmaxf(run_m, z_pos);
+        const float lse = top + logf((run_m > -INFINITY ? run_s * expf(run_m - top) : 0.f) + expf(z_pos - top));
+        const bool bad = isinf(z_pos);
+        const float row = gone ? 0.f : (bad ? NAN : lse - z_pos);
+        const float dp = gone ? 0.f : (bad ? NAN : (expf(z_pos - lse) - 1.f) * inv_m);
+        wave_loss += row;
+        if (lane == 0) {
+          if (a.row_loss != nullptr) a.row_loss[m] = row;
+          if (a.dpos != nullptr) a.dpos[m] = dp;
+          if (sp[q] >= 0 && a.d_send != nullptr) a.d_send[sp[q]] = dp;
+        }
+#pragma unroll
+        for (int t = 0; t < TPQ; ++t) {
+          const int j = (t << 6) + lane;
+          float dv = 0.f;
+          if (s[q][t] >= 0 && !gone) dv = bad ? NAN : __expf(z[t] - lse) * inv_m;
+          if (j < n && a.dneg != nullptr) a.dneg[m * n + j] = dv;
+          if (s[q][t] >= 0 && a.d_send != nullptr) a.d_send[s[q][t]] = dv;
+        }
+      }
+    }
+  }
+  if constexpr (LOSS != 0) {
+    if (a.loss_out != nullptr) reduce_mean_loss(wave_loss, a.loss_out, a.flag_word, a.loss_partials, a.mean_den);
+  }
+}
+
+template <int LOSS>
+static void launch_home(const HomeArgs& h, hipStream_t s) {
+  const int n = h.n;
+  const int qpw = n <= 64 ? 8 : (n <= 128 ? 4 : (n <= 256 ? 2 : 1));
+  int64_t blocks = (h.n_queries + 4 * qpw - 1) / (4 * qpw);
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  const dim3 grid((unsigned)blocks), block(256);
+  if (qpw == 8) hipLaunchKernelGGL((shard_home_small_kernel<LOSS, 8>), grid, block, 0, s, h);
+  else if (qpw == 4) hipLaunchKernelGGL((shard_home_small_kernel<LOSS, 4>), grid, block, 0, s, h);
+  else if (qpw == 2) hipLaunchKernelGGL((shard_home_small_kernel<LOSS, 2>), grid, block, 0, s, h);
+  else hipLaunchKernelGGL(shard_home_kernel<LOSS>, grid, block, 0, s, h);
+}
+
 static inline int grid1d(int64_t numel) {
   int64_t b = (numel + 255) / 256;
   return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
@@ -863,13 +991,10 @@ extern "C" int rsa_shard_home(const rsa_shard_home_args* a, rsa_stream_t stream)
     h.flag_word = reinterpret_cast<unsigned int*>(sc + SCRATCH_COUNTER);
     h.loss_partials = reinterpret_cast<float*>(sc + SCRATCH_FUSED_PARTIALS);
   }
-  int64_t blocks = (a->n_queries + 3) / 4;
-  if (blocks > 2048) blocks = 2048;
-  const dim3 grid((unsigned)blocks), block(256);
   hipStream_t s = (hipStream_t)stream;
-  if (a->loss == 0) hipLaunchKernelGGL(shard_home_kernel<0>, grid, block, 0, s, h);
-  else if (a->loss == 1) hipLaunchKernelGGL(shard_home_kernel<1>, grid, block, 0, s, h);
-  else hipLaunchKernelGGL(shard_home_kernel<2>, grid, block, 0, s, h);
+  if (a->loss == 0) launch_home<0>(h, s);
+  else if (a->loss == 1) launch_home<1>(h, s);
+  else launch_home<2>(h, s);
   RSA_CHECK_LAUNCH("rsa_shard_home");
   return RSA_OK;
 }

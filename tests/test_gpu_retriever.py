@@ -193,9 +193,11 @@ def test_device_loaders_match_host_loaders(ra, golden):
     host = list(zip(range(4), strn.train_loader(64, shuffle=False)))
     dev = list(zip(range(4), strn.device_train_loader(64, shuffle=False, device=DEV)))
     for (_, hb), (_, db) in zip(host, dev):
-        assert sorted(hb) == sorted(db)
+        flat, st, en = db['_seg']                              # the CSR view rides along (for towers that gather from it)
+        assert sorted(hb) == sorted(k for k in db if not k.startswith('_'))
         for k in hb:
             assert torch.equal(hb[k], db[k].cpu()), k
+        assert torch.equal(en - st, db['seqlen']) and torch.equal(flat[en], db['item_id'])
     # shuffled epochs cover every sample exactly once
     seen = torch.cat([b['user_id'] * 0 + 1 for b in trn.device_train_loader(4096, shuffle=True, device=DEV)])
     assert int(seen.sum()) == len(trn)

@@ -46,7 +46,8 @@ def test_route_kernels_match_checker(world, B, n):
 
 @pytest.mark.parametrize('world,B,n,chunks,cap_frac,banks', [(4, 33, 7, 1, 2.0, 1), (8, 1000, 64, 1, 1.1, 1), (2, 6, 1, 2, 1.0, 1),
                                                              (3, 16, 100, 4, 0.5, 1), (1, 64, 64, 1, 0.7, 1),
-                                                             (8, 1000, 64, 1, 1.3, 8), (2, 700, 128, 2, 0.6, 4), (1, 300, 64, 1, 4.0, 8)])
+                                                             (8, 1000, 64, 1, 1.3, 8), (2, 700, 128, 2, 0.6, 4), (1, 300, 64, 1, 4.0, 8),
+                                                             (2, 41, 200, 1, 0.8, 2), (3, 9, 600, 1, 1.5, 1)])
 def test_sample_route_kernel_matches_checker(world, B, n, chunks, cap_frac, banks):
     """rsa_shard_sample_route on given ids: every (slice, owner) segment holds the same multiset of keys as the
     checker's (order inside a segment is free), its header says how many are live and how many elements the rank
