@@ -208,12 +208,20 @@ def profile_record(name):
         return None
 
 
-def with_profile(entry, name, alg_bytes):
+def with_profile(entry, name, alg_bytes, whole_step=False, flops=None):
+    """Attach the tracked profile of figure `name`: `profile_frac` = the same algorithmic bytes (or flops) over the tracked
+    rocprofv3 time -- the dominant kernel's average, or with `whole_step` the sum of the step's kernels."""
     rec = profile_record(name)
-    if rec and rec.get('avg_us'):
-        entry['profile_frac'] = round(alg_bytes / (rec['avg_us'] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
-        entry['profile_avg_kernel_ms'] = round(rec['avg_us'] / 1e3, 4)
-        if rec.get('hbm_bytes_per_launch'):
+    us = rec and rec.get('step_kernel_us' if whole_step else 'avg_us')
+    if us:
+        if flops is not None:
+            entry['profile_frac'] = round(flops / (us * 1e-6) / 1e12 / 157.3, 4)
+        else:
+            entry['profile_frac'] = round(alg_bytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
+        entry['profile_step_kernel_ms' if whole_step else 'profile_avg_kernel_ms'] = round(us / 1e3, 4)
+        if whole_step:
+            entry['profile_dominant_kernel_share'] = rec.get('dominant_share_of_step')
+        elif rec.get('hbm_bytes_per_launch') and alg_bytes:
             entry['profile_traffic_over_alg'] = round(rec['hbm_bytes_per_launch'] / alg_bytes, 3)
         entry['profile_source'] = f'profiles/r03_kernel_profiles.json["{name}"]'
     return entry
@@ -346,7 +354,9 @@ def main():
             ms_train = time_gpu(train, max(10, args.steps // 4), 5) * 1e3
             t_f = time_gpu(lambda: ra.ops.fused_forward(item, user, n, out=bufs['train'], fused_bpr=True,
                                                         want_query_grad=True, **kw), max(10, args.steps // 4), 5) * 1e3
-            extra['train_step'] = {'ms_per_step': round(ms_train, 4), 'value': round(B * n / ms_train / 1e3, 2),
+            extra['train_step'] = {'profile_step_kernel_ms': (profile_record('train_step_N1e7_popular_n64_B65536') or {}).get('step_kernel_us'),
+                                   'profile_sgd_step_kernel_ms': (profile_record('sgd_step_N1e7_popular_n64_B65536') or {}).get('step_kernel_us'),
+                                   'ms_per_step': round(ms_train, 4), 'value': round(B * n / ms_train / 1e3, 2),
                                    'unit': 'M triplets/s', 'what': 'forward + BPR loss + user-gradient rows (accumulated '
                                    'in the forward) + row-sparse item-gradient rows (no optimizer)',
                                    'forward_ms': round(t_f, 4), 'two_pass_ms_per_step': round(ms_two, 4)}
@@ -399,10 +409,11 @@ def main():
             t_lse = time_gpu(lambda: ra.ops.fullscore(it5, q5, want_lse=True), 10, 3) * 1e3
             t_topk = time_gpu(lambda: ra.ops.fullscore(it5, q5, want_lse=True, k=k5), 5, 2) * 1e3
             flops = 2.0 * b5 * d * (n5 - 1)
-            extra['fullscore'] = {'workload': f'B={b5} queries x N={n5} items, d={d}, fp32 MFMA (BASELINE.json configs[4])',
-                                  'gemm_lse_ms': round(t_lse, 3), 'gemm_lse_tflops': round(flops / t_lse / 1e9, 1),
-                                  'with_top100_ms': round(t_topk, 3), 'peak_tflops_fp32_matrix': 157.3,
-                                  'frac_of_peak': round(flops / t_lse / 1e9 / 157.3, 3)}
+            extra['fullscore'] = with_profile(
+                {'workload': f'B={b5} queries x N={n5} items, d={d}, fp32 MFMA (BASELINE.json configs[4])',
+                 'gemm_lse_ms': round(t_lse, 3), 'gemm_lse_tflops': round(flops / t_lse / 1e9, 1),
+                 'with_top100_ms': round(t_topk, 3), 'peak_tflops_fp32_matrix': 157.3,
+                 'frac_of_peak': round(flops / t_lse / 1e9 / 157.3, 3)}, 'fullscore_lse_B2048_N1e6', 0, flops=flops)
         except Exception as e:
             extra['fullscore'] = {'error': repr(e)[:200]}
         # configs[2] shape: SASRec tail -- ragged history gather [B, L<=50, d] + sampled softmax, n = 256
@@ -626,7 +637,7 @@ def main():
                      'frac_of_hbm_peak': round(alg1 / t1 / 1e6 / HBM_PEAK_GBS, 4),
                      'with_collectives_ms': round(res1['with_collectives_ms'], 4),
                      'kernels_per_step': 'embedding_gather, shard_sample_route, fused_fwd_kernel (segment form), shard_home'},
-                    'sharded_world1_scoring_kernel', alg1)
+                    'sharded_world1_step', alg1, whole_step=True)
                 del blk, tbl
             except Exception as e:
                 extra['sharded_world1'] = {'error': repr(e)[:200]}

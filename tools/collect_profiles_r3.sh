@@ -4,7 +4,7 @@
 # --pmc WRITE_SIZE (separate passes: the two counters do not fit one) -- summarised into
 # gpurun_out/profiles_r03/r03_kernel_profiles.{json,txt} (copy those to profiles/).  tools/summarize_shapes.py deletes
 # the rocpd databases of a shape once it has read them.
-SHAPES=${SHAPES:-"headline_N1e7_popular_n64_B65536 N1e7_popular_n64_B4096 N1e7_popular_n64_B16384 N1e8_uniform_n64_B65536 N1e8_uniform_n1024_B4096 N1e8_popular_n64_B65536 ssm_N1e6_popular_n256_B8192 sharded_world1_step sharded_world1_train sgd_step_N1e7_popular_n64_B65536"}
+SHAPES=${SHAPES:-"headline_N1e7_popular_n64_B65536 N1e7_popular_n64_B4096 N1e7_popular_n64_B16384 N1e8_uniform_n64_B65536 N1e8_uniform_n1024_B4096 N1e8_popular_n64_B65536 ssm_N1e6_popular_n256_B8192 sharded_world1_step sharded_world1_train sgd_step_N1e7_popular_n64_B65536 train_step_N1e7_popular_n64_B65536 fullscore_lse_B2048_N1e6 fullscore_top100_B2048_N1e6 seg_gather_B8192_L50"}
 REPO=$(pwd)
 OUT=$REPO/gpurun_out/prof_r03
 DST=$REPO/gpurun_out/profiles_r03

@@ -112,6 +112,36 @@ elif shape in ('sgd_step_N1e7_popular_n64_B65536', 'adam_step_N1e7_popular_n64_B
 
         def step():
             fa.step(64, user_ids=uid, pos_ids=pos, sampler=ps)
+elif shape == 'train_step_N1e7_popular_n64_B65536':
+    B = 65536
+    item = table(10_000_001, 1)
+    ps = popular_sampler(10_000_001, '1e7')
+    uid = torch.randint(1, U, (B,), device=dev, generator=gen)
+    pos = torch.randint(1, 10_000_001, (B,), device=dev, generator=gen)
+    kw = dict(query_index=uid, pos_ids=pos, sampler=nat.SAMPLER_POPULAR, **ps.lookup_kwargs())
+
+    def step():       # forward with the user gradient + write-only row-sparse item-gradient rows (bench.py train_step)
+        buf['o'] = ra.ops.fused_forward(item, user, 64, out=buf.get('o'), fused_bpr=True, want_query_grad=True, **kw)
+        o = buf['o']
+        ra.ops.fused_backward(item, user, o['neg_ids'], o['dneg'], query_index=uid, pos_ids=pos, dpos=o['dpos'],
+                              dense_item_grad=False, row_item_grad=True, want_query_grad=False)
+elif shape in ('fullscore_lse_B2048_N1e6', 'fullscore_top100_B2048_N1e6'):
+    item = table(1_000_001, 1)
+    q = user[1:2049].contiguous()
+    k = 100 if 'top100' in shape else 0
+
+    def step():
+        ra.ops.fullscore(item, q, want_lse=True, k=k)
+elif shape == 'seg_gather_B8192_L50':
+    n6, B, L = 1_000_001, 8192, 50
+    item = table(n6, 1)
+    lens = torch.randint(1, L + 1, (B,), device=dev, generator=gen)
+    end = torch.cumsum(lens, 0)
+    start = end - lens
+    flat = torch.randint(1, n6, (int(end[-1]),), device=dev, generator=gen)
+
+    def step():       # the call SASRecQueryEncoder makes on the device loader's CSR view: rows only
+        ra.ops.seg_gather(item, flat, start, end, L, want_rows=True, want_ids=False)
 else:
     raise SystemExit(f'unknown shape {shape}')
 
