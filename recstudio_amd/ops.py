@@ -122,6 +122,9 @@ def _scratch():
     key = (dev.index, _raw_stream(dev))
     t = _SCRATCH.get(key)
     if t is None:
+        if len(_SCRATCH) >= 64:          # short-lived streams: forget the oldest blocks (a block is only ever used on its stream)
+            for old in list(_SCRATCH)[:32]:
+                del _SCRATCH[old]
         t = _SCRATCH[key] = torch.zeros(int(nat.lib().rsa_scratch_bytes()), dtype=torch.uint8, device=dev)
     return t
 
