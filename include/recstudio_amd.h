@@ -212,6 +212,17 @@ typedef struct rsa_fused_args {
                                   over cdf_lut / guide. */
   int32_t lines_log2;
   int32_t _pad3;
+  /* In-forward SGD (fused_loss = 1, num_neg == 64, query_grad given; ABI v5).  dup_bits: the step's id census from
+   * rsa_mark_ids (bit i set <=> item i is touched by MORE than one element of the step, positives included).  A row that
+   * exactly one element touches is rewritten by the wave that has it in registers: item[id] += upd_scale[0] * d * q
+   * (d = d loss/d score of that element; upd_scale = -lr is plain SGD) -- nothing else reads or writes that row in the
+   * step, so the result is the one a separate update pass would give, bit for bit in any order.  Elements on shared rows
+   * (and the padding row 0) are NOT applied: apply_neg_ids [M, n] / apply_pos_ids [M] receive their ids (-1 for the
+   * elements already applied) and go to rsa_scatter_rows_sorted, which drops negative ids.  item_table is written. */
+  const uint32_t* dup_bits;    /* nullable [(n_items + 31) / 32] */
+  const float* upd_scale;      /* device scalar */
+  int64_t* apply_neg_ids;      /* [M, n] out */
+  int64_t* apply_pos_ids;      /* [M] out */
 } rsa_fused_args;
 
 int rsa_fused_sample_gather_score(const rsa_fused_args* args, rsa_stream_t stream);
@@ -329,6 +340,12 @@ int rsa_adam_rows_sorted(const float* query, const int64_t* query_index, int64_t
                          int64_t pad_row, float* weight, float* exp_avg, float* exp_avg_sq, float lr, float beta1,
                          float beta2, float eps, int64_t step, void* workspace, int64_t workspace_bytes,
                          rsa_stream_t stream);
+
+/* The id census of a step for the in-forward update (rsa_fused_args.dup_bits): for every element id of pos_ids [M]
+ * (nullable) and neg_ids [M, n] (clamped to [0, n_items)): seen |= bit(id); if it was already set, dup |= bit(id).
+ * seen / dup: [(n_items + 31) / 32] uint32 words, zeroed by the caller before the call. */
+int rsa_mark_ids(const int64_t* pos_ids, const int64_t* neg_ids, int64_t n_queries, int32_t num_neg, int64_t n_items,
+                 uint32_t* seen, uint32_t* dup, rsa_stream_t stream);
 
 /* embedding_dense_backward: dst[ids[i]] += src[i] for ids != 0 (padding_idx=0).
  * Used for the user-table gradient.  dst [n_rows, dim] caller-zeroed. */

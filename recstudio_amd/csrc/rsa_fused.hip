@@ -57,6 +57,14 @@ struct FwdParams {
   float* loss_partials;         //   reduce_scratch (rsa_common.hpp, "caller-owned reduction scratch")
   const uint64_t* offset_dev;   // nullable: Philox offset read at run time (graph replays)
   const int64_t* packed_keys;   // num_neg == 1, GIVEN: element e = (query row << 32) | item row (sharded owner side)
+  // In-forward SGD (rsa_fused_args.dup_bits): a row that exactly ONE element of the step touches is updated by the wave
+  // that has it in registers; the elements on rows touched more than once are left to the sorted scatter (apply_neg /
+  // apply_pos: their ids, -1 for the elements already applied here)
+  const uint32_t* dup_bits;
+  const float* upd_scale;
+  float* item_rw;
+  int64_t* apply_neg;
+  int64_t* apply_pos;
   int32_t* step_dropped;        // segment form (seg_stride != 0): <- sum of the segments' header word 1 (nullable)
   int32_t* overflow_sticky;     //   += the same (nullable)
   float* qgrad;      // fused BPR epilogue (nullable): [M, dim] d loss / d query row, accumulated from the rows in flight
@@ -249,10 +257,12 @@ __device__ __forceinline__ void tile_rows(const float* __restrict__ table, int D
 // transpose tree, whose long-lived select masks cost > 100 extra VGPRs here), turns them into d loss/d neg and
 // accumulates the query-gradient fragment qacc += dneg_row * row.  The backward pass then never re-reads the
 // negative rows.  On return lane r holds the dot of row r, as in tile_rows.
-template <int LPR, bool NT>
-__device__ __forceinline__ void tile_rows_qg(const float* __restrict__ table, int32_t id_lane,
+// UPD: bit 31 of id_lane marks an element whose row no other element of the step touches: its row is rewritten right
+// here as row + upd * dneg * q (SGD in place: upd = -lr) while row and query fragment are in registers.
+template <int LPR, bool NT, bool UPD = false>
+__device__ __forceinline__ void tile_rows_qg(const float* table, int32_t id_lane,
                                              const Frag<LPR, false>& qf, float pos_s, float bw, float binv, float& dot,
-                                             float4& qacc) {
+                                             float4& qacc, float* item_rw = nullptr, float upd = 0.f) {
   using F = Frag<LPR, false>;
   constexpr int D = LPR * 4;
   constexpr int BATCH = LPR < RSA_QG_BATCH ? LPR : RSA_QG_BATCH;
@@ -268,7 +278,7 @@ __device__ __forceinline__ void tile_rows_qg(const float* __restrict__ table, in
   auto request = [&](int b) __attribute__((always_inline)) {
 #pragma unroll
     for (int k = 0; k < BATCH; ++k) {
-      const int32_t rid = __shfl(id_lane, gb + b * BATCH + k, 64);
+      const int32_t rid = __shfl(id_lane, gb + b * BATCH + k, 64) & 0x7fffffff;
       frag_load<LPR, false, NT>(x[b & 1][k], table + (size_t)rid * D, sub, D);
     }
   };
@@ -286,10 +296,21 @@ __device__ __forceinline__ void tile_rows_qg(const float* __restrict__ table, in
       qacc.z = __fmaf_rn(g, xv.z, qacc.z);
       qacc.w = __fmaf_rn(g, xv.w, qacc.w);
       dot = sub == b * BATCH + k ? dk : dot;
+      if constexpr (UPD) {
+        const int32_t idf = __shfl(id_lane, gb + b * BATCH + k, 64);
+        if (idf < 0) {       // lane-group uniform: the row belongs to this element alone
+          const float c = upd * g;
+          const float4 qv = qf.v[0];
+          typedef float v4f __attribute__((ext_vector_type(4)));
+          v4f nv = {__fmaf_rn(c, qv.x, xv.x), __fmaf_rn(c, qv.y, xv.y), __fmaf_rn(c, qv.z, xv.z), __fmaf_rn(c, qv.w, xv.w)};
+          __builtin_nontemporal_store(nv, reinterpret_cast<v4f*>(item_rw + (size_t)(idf & 0x7fffffff) * D + sub * 4));
+        }
+      }
     }
     asm volatile("" : "+v"(gb), "+v"(qacc.x), "+v"(qacc.y), "+v"(qacc.z), "+v"(qacc.w));
   }
 #else
+  static_assert(!UPD, "the in-forward update is built on the pipelined tile");
 #pragma unroll
   for (int b = 0; b < NB; ++b) {
     F x[BATCH];
@@ -376,7 +397,7 @@ __device__ __forceinline__ float finish_score(int mode, float dot, float inorm2,
 #ifndef RSA_FWD_GRID_CAP
 #define RSA_FWD_GRID_CAP (256 * 8)
 #endif
-template <int LPR, bool GENERIC, bool COS, bool QU, bool NT, bool QG = false>
+template <int LPR, bool GENERIC, bool COS, bool QU, bool NT, bool QG = false, bool UPD = false>
 __global__ __launch_bounds__(256, QG ? RSA_QG_MIN_WAVES : RSA_FWD_MIN_WAVES) void fused_fwd_kernel(const FwdParams p) {
   using F = Frag<LPR, GENERIC>;
   const int lane = lane_id();
@@ -522,7 +543,17 @@ __global__ __launch_bounds__(256, QG ? RSA_QG_MIN_WAVES : RSA_FWD_MIN_WAVES) voi
       pos_early = group_sum<LPR>(frag_dot<LPR, GENERIC>(px, qf));
       if (p.mask_pad_pos && pad) pos_early = -INFINITY;
       const float bw = 1.f / (float)n, binv = 1.f / (float)p.n_queries;
-      tile_rows_qg<LPR, NT>(p.item_table, id, qf, pos_early, bw, binv, dot, qacc);
+      if constexpr (UPD) {
+        // rows touched by exactly one element of the step (no second bit in the step's id census) and not the padding
+        // row are updated in the tile; everything else keeps its id in apply_neg for the sorted scatter
+        const float upd = p.upd_scale[0];
+        const bool solo = act && id != 0 && !((p.dup_bits[id >> 5] >> (id & 31)) & 1u);
+        if (act) st_out(&p.apply_neg[e], solo ? (int64_t)-1 : (int64_t)id);
+        tile_rows_qg<LPR, NT, true>(p.item_table, solo ? (id | (int32_t)0x80000000) : id, qf, pos_early, bw, binv, dot, qacc,
+                                    p.item_rw, upd);
+      } else {
+        tile_rows_qg<LPR, NT>(p.item_table, id, qf, pos_early, bw, binv, dot, qacc);
+      }
       // d loss/d query row = sum_j dneg_j * item_j + dpos * item_pos, dpos = -sum_j dneg_j (this tile's share).
       // Written right here, unconditionally (the host only selects this variant with the BPR epilogue on):
       // under the epilogue's run-time conditions the compiler sinks the whole accumulation below the row
@@ -537,6 +568,18 @@ __global__ __launch_bounds__(256, QG ? RSA_QG_MIN_WAVES : RSA_FWD_MIN_WAVES) voi
       qacc.x = __fmaf_rn(-tg, pv.x, qacc.x); qacc.y = __fmaf_rn(-tg, pv.y, qacc.y);
       qacc.z = __fmaf_rn(-tg, pv.z, qacc.z); qacc.w = __fmaf_rn(-tg, pv.w, qacc.w);
       if (lane < LPR) *reinterpret_cast<float4*>(p.qgrad + (size_t)m_lane * D + sub * 4) = qacc;    // n == 64: one tile per query
+      if constexpr (UPD) {
+        // the positive row: d loss/d pos = -sum_j dneg_j, all of it known here (one tile per query)
+        const int64_t pid = pid_u;
+        const bool solo_p = pid != 0 && !pad && !((p.dup_bits[pid >> 5] >> (pid & 31)) & 1u);     // wave-uniform
+        if (lane == 0) p.apply_pos[m_lane] = solo_p ? (int64_t)-1 : pid;
+        if (solo_p && lane < LPR) {
+          const float c = p.upd_scale[0] * -tg;
+          const float4 qv = qf.v[0];
+          *reinterpret_cast<float4*>(p.item_rw + (size_t)pid * D + sub * 4) =
+              make_float4(__fmaf_rn(c, qv.x, pv.x), __fmaf_rn(c, qv.y, pv.y), __fmaf_rn(c, qv.z, pv.z), __fmaf_rn(c, qv.w, pv.w));
+        }
+      }
     } else if constexpr (RSA_FWD_PLAIN_PIPE && QU && !COS && !GENERIC) {
       tile_rows_pipe<LPR, NT>(p.item_table, id, qf, dot);
     } else {
@@ -956,6 +999,11 @@ static void launch_fwd2(const FwdParams& p, dim3 grid, dim3 block, hipStream_t s
   // streaming (nontemporal) row loads once the table cannot live in the 256 MB Infinity Cache
   const bool nt = !GENERIC && (size_t)p.n_items * p.dim * sizeof(float) > (512ull << 20);
   if constexpr (QU && !COS && !GENERIC) {
+    if (p.qgrad != nullptr && p.dup_bits != nullptr) {     // ... + SGD in place for the rows one element owns
+      if (nt) hipLaunchKernelGGL((fused_fwd_kernel<LPR, GENERIC, COS, QU, true, true, true>), grid, block, 0, stream, p);
+      else hipLaunchKernelGGL((fused_fwd_kernel<LPR, GENERIC, COS, QU, false, true, true>), grid, block, 0, stream, p);
+      return;
+    }
     if (p.qgrad != nullptr) {     // training forward: query gradient accumulated from the rows in flight
       if (nt) hipLaunchKernelGGL((fused_fwd_kernel<LPR, GENERIC, COS, QU, true, true>), grid, block, 0, stream, p);
       else hipLaunchKernelGGL((fused_fwd_kernel<LPR, GENERIC, COS, QU, false, true>), grid, block, 0, stream, p);
@@ -1067,6 +1115,11 @@ extern "C" int rsa_fused_sample_gather_score(const rsa_fused_args* a, rsa_stream
   p.offset_dev = a->offset_dev;
   p.loss_partials = nullptr;
   p.packed_keys = a->packed_keys;
+  p.dup_bits = nullptr;
+  p.upd_scale = nullptr;
+  p.item_rw = nullptr;
+  p.apply_neg = nullptr;
+  p.apply_pos = nullptr;
   p.step_dropped = nullptr;
   p.overflow_sticky = nullptr;
   p.seg_stride = 0;
@@ -1119,6 +1172,17 @@ extern "C" int rsa_fused_sample_gather_score(const rsa_fused_args* a, rsa_stream
                     "rsa_fused_sample_gather_score: query_grad needs the inner-product scorer and dim in "
                     "{32, 64, 128, 256}");
       p.qgrad = a->query_grad;
+    }
+    if (a->dup_bits != nullptr) {
+      RSA_CHECK_ARG(bpr && a->num_neg == 64 && a->query_grad && a->upd_scale && a->apply_neg_ids && a->apply_pos_ids &&
+                        a->packed_keys == nullptr && !a->mask_pad_pos,
+                    "rsa_fused_sample_gather_score: the in-forward update (dup_bits) needs fused_loss = BPR with num_neg == 64, "
+                    "query_grad, upd_scale, apply_neg_ids and apply_pos_ids");
+      p.dup_bits = a->dup_bits;
+      p.upd_scale = a->upd_scale;
+      p.item_rw = const_cast<float*>(a->item_table);
+      p.apply_neg = a->apply_neg_ids;
+      p.apply_pos = a->apply_pos_ids;
     }
   }
   if (ssm) {

@@ -253,6 +253,22 @@ __global__ __launch_bounds__(256) void sorted_finish_kernel(int64_t n_chunks, co
   apply_run<NDW>(target, adam, cur, scale, lane, acc, trow, mrow_v, vrow_v);
 }
 
+// Id census of a step (rsa_mark_ids): which item rows are touched by more than one element.
+__global__ __launch_bounds__(256) void mark_ids_kernel(const int64_t* __restrict__ pos_ids, const int64_t* __restrict__ neg_ids,
+                                                       int64_t n_queries, int n, int64_t n_items, uint32_t* __restrict__ seen,
+                                                       uint32_t* __restrict__ dup) {
+  const int64_t n_neg = n_queries * (int64_t)n;
+  const int64_t total = n_neg + (pos_ids ? n_queries : 0);
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+    int64_t id = e < n_neg ? neg_ids[e] : pos_ids[e - n_neg];
+    id = id < 0 ? 0 : (id >= n_items ? n_items - 1 : id);
+    const uint32_t bit = 1u << (id & 31);
+    const uint32_t old = atomicOr(&seen[id >> 5], bit);
+    if (old & bit) atomicOr(&dup[id >> 5], bit);
+  }
+}
+
 static inline int64_t align256s(int64_t b) { return (b + 255) / 256 * 256; }
 
 static size_t sort_temp_bytes(int64_t total, unsigned end_bit) {
@@ -366,4 +382,18 @@ extern "C" int rsa_adam_rows_sorted(const float* query, const int64_t* query_ind
   const AdamArgs adam{exp_avg, exp_avg_sq, 1.f - beta1, 1.f - beta2, eps, (float)((double)lr * sqrt(bc2) / bc1)};
   return scatter_sorted_impl(query, query_index, n_query_rows, dim, pos_ids, neg_ids, n_queries, num_neg, dpos, dneg,
                              upstream, n_items, pad_row, weight, adam, workspace, workspace_bytes, stream);
+}
+
+extern "C" int rsa_mark_ids(const int64_t* pos_ids, const int64_t* neg_ids, int64_t n_queries, int32_t num_neg, int64_t n_items,
+                            uint32_t* seen, uint32_t* dup, rsa_stream_t stream) {
+  RSA_CHECK_ARG(n_queries >= 0 && num_neg >= 0 && n_items >= 1 && n_items < (1ll << 31), "rsa_mark_ids: bad sizes");
+  const int64_t total = n_queries * (int64_t)num_neg + (pos_ids ? n_queries : 0);
+  if (total == 0) return RSA_OK;
+  RSA_CHECK_ARG((neg_ids || num_neg == 0) && seen && dup, "rsa_mark_ids: null pointer");
+  int64_t blocks = (total + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(mark_ids_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, pos_ids, neg_ids, n_queries,
+                     (int)num_neg, n_items, seen, dup);
+  RSA_CHECK_LAUNCH("rsa_mark_ids");
+  return RSA_OK;
 }

@@ -243,7 +243,8 @@ def train_step_no_autograd(item_weight, query_src, num_neg, loss_kind, *, query_
     return loss, score, grads
 
 
-def bpr_sgd_step(item_weight, user_weight, num_neg, lr, *, user_ids, pos_ids, sampler=None, neg_ids=None, atomics=False):
+def bpr_sgd_step(item_weight, user_weight, num_neg, lr, *, user_ids, pos_ids, sampler=None, neg_ids=None, atomics=False,
+                 in_forward=None):
     """One complete SGD training step of a BPR two-tower model (nn.Embedding user and item tables) in three
     launches and WITHOUT gradient tensors: the forward samples, scores, evaluates BPRLoss and accumulates the
     user-row gradients; ``rsa_scatter_rows_sorted`` adds ``-lr * dneg * q`` straight into the touched ITEM rows of the
@@ -251,7 +252,15 @@ def bpr_sgd_step(item_weight, user_weight, num_neg, lr, *, user_ids, pos_ids, sa
     backward kernel's float atomics instead) and a row scatter applies ``-lr * q.grad`` to the touched USER
     rows.  Equal to ``loss.backward(); torch.optim.SGD(lr).step()`` on the dense gradients (no momentum /
     weight decay) up to fp32 summation order -- without the [N, d] gradient zero-fill, scatter and dense update
-    that dominate that path (5.12 GB each at N = 1e7).  Returns (loss, neg_ids).  num_neg % 64 == 0."""
+    that dominate that path (5.12 GB each at N = 1e7).  Returns (loss, neg_ids).  num_neg % 64 == 0.
+
+    ``in_forward`` (default: on for num_neg == 64 and embed_dim in {64, 128, 256}): most item rows of a step are touched
+    by exactly ONE of its elements -- such a row is read by one wave of the forward and by nobody else, so that wave
+    rewrites it on the spot (row + (-lr) * d * q, the row and the query fragment being in registers): no second read of
+    the row, no read of the query row, no place in the sort.  The negatives are drawn first (the Sampler plugin: same
+    ids, same generator consumption as the in-kernel sampler), ``rsa_mark_ids`` takes the census of the step's ids, and
+    only the elements on rows that occur more than once go through the sorted scatter.  Same result as the all-sorted
+    form bit for bit on the solo rows, equal up to fp32 summation order on the shared ones; bit-reproducible."""
     M = user_ids.numel()
     kind = _sampler_kind(sampler) if sampler is not None else nat.SAMPLER_GIVEN
     if kind is None:
@@ -261,6 +270,10 @@ def bpr_sgd_step(item_weight, user_weight, num_neg, lr, *, user_ids, pos_ids, sa
         kw['neg_ids'] = neg_ids.reshape(M, -1)
     elif kind == nat.SAMPLER_POPULAR:
         kw.update(sampler.lookup_kwargs())
+    if in_forward is None:
+        in_forward = num_neg == 64 and item_weight.shape[1] in (64, 128, 256) and not atomics
+    if in_forward:
+        return _bpr_sgd_step_in_forward(item_weight, user_weight, num_neg, lr, user_ids, pos_ids, sampler, kind, kw)
     with torch.no_grad():
         iw, uw = item_weight.data, user_weight.data
         out = ops.fused_forward(iw, uw, num_neg, query_index=user_ids, pos_ids=pos_ids, sampler=kind, want_logp=False,
@@ -275,6 +288,36 @@ def bpr_sgd_step(item_weight, user_weight, num_neg, lr, *, user_ids, pos_ids, sa
         else:
             ops.fused_backward(iw, uw, out['neg_ids'], out['dneg'], query_index=user_ids, pos_ids=pos_ids, dpos=out['dpos'],
                                upstream=step, dense_item_grad=True, item_grad_out=iw, want_query_grad=False)
+        ops.scatter_add_rows(out['query_grad'] * step, user_ids, uw.shape[0], out=uw)
+    return out['loss'], out['neg_ids']
+
+
+_CENSUS = {}
+
+
+def _bpr_sgd_step_in_forward(item_weight, user_weight, num_neg, lr, user_ids, pos_ids, sampler, kind, kw):
+    M = user_ids.numel()
+    with torch.no_grad():
+        iw, uw = item_weight.data, user_weight.data
+        if kind == nat.SAMPLER_GIVEN:
+            neg = kw['neg_ids']
+        else:       # the stand-alone sampler draws what the in-kernel one would (same stream, same generator advance)
+            neg = sampler(torch.empty(M, 1, device=iw.device), num_neg, None)[0]
+        key = (iw.shape[0], iw.device)
+        bufs = _CENSUS.get(key)
+        if bufs is None:
+            if len(_CENSUS) >= 4:
+                _CENSUS.clear()
+            bufs = _CENSUS[key] = ops.mark_ids(pos_ids, neg, iw.shape[0])
+        else:
+            ops.mark_ids(pos_ids, neg, iw.shape[0], *bufs)
+        step = torch.full((1,), -float(lr), dtype=torch.float32, device=iw.device)
+        out = ops.fused_forward(iw, uw, num_neg, query_index=user_ids, pos_ids=pos_ids, neg_ids=neg, sampler=nat.SAMPLER_GIVEN,
+                                fused_bpr=True, want_query_grad=True, inplace_update=(bufs[1], step))
+        # the elements on shared rows: sorted by item id, every such row read-modified-written once (negative ids = the
+        # elements the forward has applied already: dropped)
+        ops.scatter_rows_sorted(iw, uw, out['apply_neg_ids'], out['dneg'], query_index=user_ids, pos_ids=out['apply_pos_ids'],
+                                dpos=out['dpos'], upstream=step, pad_row=0)
         ops.scatter_add_rows(out['query_grad'] * step, user_ids, uw.shape[0], out=uw)
     return out['loss'], out['neg_ids']
 

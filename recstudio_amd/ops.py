@@ -270,7 +270,7 @@ def fused_forward(item_table, query, num_neg, *, query_index=None, pos_ids=None,
                   table=None, pop_prob=None, guide=None, guide_log2=0, generator=None, n_queries=None,
                   out=None, want_logp=True, table_prob=None, fused_bpr=False, want_mean=True, cdf_lut=None,
                   want_query_grad=False, rng_state=None, cdf_lines=None, lines_log2=0, fused_loss=None,
-                  pos_logp=None, neg_logp=None, _plan=None):
+                  pos_logp=None, neg_logp=None, _plan=None, inplace_update=None):
     """One launch of rsa_fused_sample_gather_score.  Returns a dict with
     neg_ids [M,n] int64, neg_score [M,n], pos_score [M] (if pos_ids), and for the
     popularity sampler neg_logp [M,n], pos_logp [M].  ``out``: a dict returned by an earlier
@@ -372,6 +372,15 @@ def fused_forward(item_table, query, num_neg, *, query_index=None, pos_ids=None,
             if 'query_grad' not in out:
                 out['query_grad'] = torch.empty(M, dim, dtype=torch.float32, device=dev)
             a.query_grad = ptr(out['query_grad'])
+        if inplace_update is not None:
+            # (dup_bits, scale): rows touched by exactly one element of the step are updated inside the forward
+            # (item_table += scale * d * q); the rest is handed back in apply_neg_ids / apply_pos_ids
+            dup_bits, upd_scale = inplace_update
+            if 'apply_neg_ids' not in out:
+                out['apply_neg_ids'] = torch.empty(M, n, dtype=torch.int64, device=dev)
+                out['apply_pos_ids'] = torch.empty(M, dtype=torch.int64, device=dev)
+            a.dup_bits, a.upd_scale = ptr(_need(dup_bits, torch.int32, 'dup_bits')), ptr(_need(upd_scale, torch.float32, 'upd_scale'))
+            a.apply_neg_ids, a.apply_pos_ids = ptr(out['apply_neg_ids']), ptr(out['apply_pos_ids'])
     elif want_query_grad:
         raise ValueError('want_query_grad needs a fused loss (fused_bpr=True / fused_loss=...)')
     nat.check(nat.lib().rsa_fused_sample_gather_score(ctypes.byref(a), _stream()), 'rsa_fused_sample_gather_score')
@@ -531,6 +540,26 @@ def fused_backward(item_table, query, neg_ids, dneg, *, query_index=None, pos_id
     a.score_mode = int(cosine) if not isinstance(cosine, bool) else (nat.SCORE_COS if cosine else nat.SCORE_IP)
     nat.check(nat.lib().rsa_fused_backward(ctypes.byref(a), _stream()), 'rsa_fused_backward')
     return item_grad, rows, qgrad
+
+
+@_on_device
+def mark_ids(pos_ids, neg_ids, n_items, seen=None, dup=None):
+    """rsa_mark_ids: the id census of a step -> (seen, dup) int32 bit tables [(n_items + 31) // 32]: bit i of ``dup`` is set
+    iff item i is touched by more than one element (positives included).  ``seen`` / ``dup``: buffers of an earlier
+    call to reuse (they are zeroed here)."""
+    neg_ids = _need(neg_ids, torch.int64, 'neg_ids')
+    pos_ids = _need_opt(pos_ids, torch.int64, 'pos_ids')
+    words = (int(n_items) + 31) // 32
+    if seen is None:
+        both = torch.zeros(2, words, dtype=torch.int32, device=neg_ids.device)
+        seen, dup = both[0], both[1]
+    else:
+        seen.zero_()
+        dup.zero_()
+    M = pos_ids.numel() if pos_ids is not None else neg_ids.shape[0]
+    n = neg_ids.numel() // max(M, 1)
+    nat.check(nat.lib().rsa_mark_ids(ptr(pos_ids), ptr(neg_ids), M, n, int(n_items), ptr(seen), ptr(dup), _stream()), 'rsa_mark_ids')
+    return seen, dup
 
 
 # ------------------------------------------------------------------ full catalog

@@ -753,3 +753,61 @@ def test_fused_step_object_replays_the_call_with_fresh_draws(ra):
         assert torch.equal(o['neg_ids'], want[k]['neg_ids']) and torch.equal(o['loss'], want[k]['loss'])
         assert torch.equal(o['dneg'], want[k]['dneg'])
     assert torch.cuda.default_generators[0].get_offset() == 3 * ra.rng.counter_offset(B * n, ra.rng.grid_threads(B * n, *ra.rng.device_props(DEV)), 4)
+
+
+# --------------------------------------------------------------------------- in-forward SGD for rows one element owns
+@pytest.mark.parametrize('N,d,B,kind', [(200_003, 128, 700, 'uniform'), (3001, 64, 513, 'uniform'), (50_021, 128, 600, 'popular'),
+                                        (97, 256, 64, 'uniform'), (40_009, 128, 300, 'given')])
+def test_bpr_sgd_step_in_forward_equals_all_sorted(ra, N, d, B, kind):
+    """fused.bpr_sgd_step with the in-forward update (rows touched by exactly one element of the step are rewritten by
+    the wave that has them in registers; only the shared rows go through the sort) == the all-sorted step: same loss,
+    same negatives, item and user tables equal (solo rows bit for bit; shared rows up to fp32 summation order), the
+    padding row untouched, bit-reproducible; the census kernel == torch.bincount.  N = 97: almost every row is shared;
+    'given': ids with planted collisions between positives and negatives and padding ids among the negatives."""
+    n, U, lr = 64, 211, 0.3
+    iw, uw = _tables(N, U, d, B)
+    g = torch.Generator().manual_seed(N)
+    uid = torch.randint(1, U, (B,), generator=g).to(DEV)
+    pos = torch.randint(1, N, (B,), generator=g).to(DEV)
+    kw = {}
+    if kind == 'uniform':
+        kw['sampler'] = ra.UniformSampler(N)
+    elif kind == 'popular':
+        counts = (torch.rand(N, generator=g) ** 6 * 1000).long()
+        kw['sampler'] = ra.PopularSamplerModel(counts).to(DEV)
+    else:
+        neg = torch.randint(1, N, (B, n), generator=g)
+        neg[:, 0] = pos.cpu().roll(1)              # a negative that is another query's positive
+        neg[::3, 1] = 0                            # padding ids among the negatives
+        neg[::5, 2] = neg[::5, 3]                  # the same item twice in one query
+        kw['neg_ids'] = neg.to(DEV)
+    results = []
+    for mode in (False, True, True):
+        item, user = iw.to(DEV).clone(), uw.to(DEV).clone()
+        torch.manual_seed(99)
+        loss, ids = ra.fused.bpr_sgd_step(item, user, n, lr, user_ids=uid, pos_ids=pos, in_forward=mode, **kw)
+        results.append((loss.clone(), ids.clone(), item, user))
+    (l0, i0, it0, us0), (l1, i1, it1, us1), (l2, i2, it2, us2) = results
+    assert torch.equal(i0, i1) and torch.equal(l0, l1)
+    assert torch.equal(it1, it2) and torch.equal(us1, us2) and torch.equal(l1, l2)          # run to run
+    assert torch.equal(us0, us1)                                                               # the user side is the same code
+    rel_close(it1.cpu(), it0.cpu(), rtol=1e-5, atol=1e-7)
+    assert not it1[0].any() and not torch.equal(it1, iw.to(DEV))
+    # the census and the split: solo rows (touched by exactly one element) must be exactly the all-sorted result
+    seen, dup = ra.ops.mark_ids(pos, i0, N)
+    cnt = torch.bincount(torch.cat([pos, i0.reshape(-1)]), minlength=N)
+    bits = torch.arange(N, device=DEV)
+    unpack = lambda t: ((t[bits >> 5] >> (bits & 31)) & 1).bool()      # noqa: E731
+    assert torch.equal(unpack(seen), cnt > 0) and torch.equal(unpack(dup), cnt > 1)
+    solo = (cnt == 1)
+    solo[0] = False
+    assert torch.equal(it1[solo], it0[solo])
+    # against torch: dense SGD on the same negatives
+    item_r, user_r = iw.to(DEV).clone().requires_grad_(True), uw.to(DEV).clone().requires_grad_(True)
+    q = user_r[uid]
+    ref = -torch.nn.functional.logsigmoid((q * item_r[pos]).sum(-1, keepdim=True) - (q.unsqueeze(1) * item_r[i0]).sum(-1)).mean(-1).mean()
+    ref.backward()
+    gi = item_r.grad.clone()
+    gi[0] = 0
+    rel_close(it1.cpu(), (iw.to(DEV) - lr * gi).cpu(), rtol=2e-4, atol=1e-6)
+    rel_close(l1.cpu(), ref.detach().cpu(), rtol=1e-5)
