@@ -212,17 +212,15 @@ typedef struct rsa_fused_args {
                                   over cdf_lut / guide. */
   int32_t lines_log2;
   int32_t _pad3;
-  /* In-forward SGD (fused_loss = 1, num_neg == 64, query_grad given; ABI v5).  dup_bits: the step's id census from
-   * rsa_mark_ids (bit i set <=> item i is touched by MORE than one element of the step, positives included).  A row that
-   * exactly one element touches is rewritten by the wave that has it in registers: item[id] += upd_scale[0] * d * q
-   * (d = d loss/d score of that element; upd_scale = -lr is plain SGD) -- nothing else reads or writes that row in the
-   * step, so the result is the one a separate update pass would give, bit for bit in any order.  Elements on shared rows
-   * (and the padding row 0) are NOT applied: apply_neg_ids [M, n] / apply_pos_ids [M] receive their ids (-1 for the
-   * elements already applied) and go to rsa_scatter_rows_sorted, which drops negative ids.  item_table is written. */
-  const uint32_t* dup_bits;    /* nullable [(n_items + 31) / 32] */
+  /* In-forward SGD (fused_loss = 1, num_neg == 64, ids GIVEN, query_grad given; ABI v5).  solo_flags: the classification
+   * of the step's elements by rsa_sort_step_elements (element order m * (num_neg + 1) + c, c = 0 the positive: 1 <=> no
+   * other element of the step touches that item row, and the row is not the padding row).  Such a row is rewritten by
+   * the wave that has it in registers: item[id] += upd_scale[0] * d * q (d = d loss/d score of that element; upd_scale =
+   * -lr is plain SGD) -- nothing else reads or writes that row in the step, so the result is the one a separate update
+   * pass gives.  The other elements are applied by rsa_scatter_rows_presorted on the same workspace, which skips
+   * exactly the flagged ones.  item_table is written. */
+  const uint8_t* solo_flags;   /* nullable [M * (num_neg + 1)] */
   const float* upd_scale;      /* device scalar */
-  int64_t* apply_neg_ids;      /* [M, n] out */
-  int64_t* apply_pos_ids;      /* [M] out */
 } rsa_fused_args;
 
 int rsa_fused_sample_gather_score(const rsa_fused_args* args, rsa_stream_t stream);
@@ -341,11 +339,21 @@ int rsa_adam_rows_sorted(const float* query, const int64_t* query_index, int64_t
                          float beta2, float eps, int64_t step, void* workspace, int64_t workspace_bytes,
                          rsa_stream_t stream);
 
-/* The id census of a step for the in-forward update (rsa_fused_args.dup_bits): for every element id of pos_ids [M]
- * (nullable) and neg_ids [M, n] (clamped to [0, n_items)): seen |= bit(id); if it was already set, dup |= bit(id).
- * seen / dup: [(n_items + 31) / 32] uint32 words, zeroed by the caller before the call. */
-int rsa_mark_ids(const int64_t* pos_ids, const int64_t* neg_ids, int64_t n_queries, int32_t num_neg, int64_t n_items,
-                 uint32_t* seen, uint32_t* dup, rsa_stream_t stream);
+/* rsa_scatter_rows_sorted in two steps, for a forward that updates the rows only one element touches itself
+ * (rsa_fused_args.solo_flags):
+ *   rsa_sort_step_elements   sorts the step's (item id, element) pairs into `workspace` (same size / layout as
+ *     rsa_scatter_rows_sorted) and, with `solo` (uint8 [n_queries * (num_neg + has_pos)], element order
+ *     m * (num_neg + has_pos) + c), classifies them: solo[e] = 1 iff element e is the only one on its row and the row is
+ *     neither pad_row nor a negative (dropped) id; those elements are also flagged inside the workspace;
+ *   rsa_scatter_rows_presorted  is the apply pass of rsa_scatter_rows_sorted over that workspace: every run of equal ids
+ *     summed by one wave, the row read-modified-written once -- except the flagged elements, whose rows it leaves alone.
+ * Nothing may touch the workspace in between.  dim in {64, 128, 256}. */
+int rsa_sort_step_elements(const int64_t* pos_ids, const int64_t* neg_ids, int64_t n_queries, int32_t num_neg, int64_t n_items,
+                           int64_t pad_row, uint8_t* solo, void* workspace, int64_t workspace_bytes, rsa_stream_t stream);
+int rsa_scatter_rows_presorted(const float* query, const int64_t* query_index, int64_t n_query_rows, int32_t dim,
+                               int32_t has_pos, int64_t n_queries, int32_t num_neg, const float* dpos, const float* dneg,
+                               const float* upstream, int64_t n_items, int64_t pad_row, float* target, void* workspace,
+                               int64_t workspace_bytes, rsa_stream_t stream);
 
 /* embedding_dense_backward: dst[ids[i]] += src[i] for ids != 0 (padding_idx=0).
  * Used for the user-table gradient.  dst [n_rows, dim] caller-zeroed. */

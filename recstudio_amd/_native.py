@@ -40,7 +40,7 @@ class FusedArgs(Structure):
         ('fused_loss', c_int32), ('_pad2', c_int32), ('row_loss', c_void_p), ('loss_out', c_void_p),
         ('dpos', c_void_p), ('dneg', c_void_p), ('cdf_lut', c_void_p), ('query_grad', c_void_p), ('packed_keys', c_void_p), ('offset_dev', c_void_p),
         ('elem_base', c_uint64), ('reduce_scratch', c_void_p), ('cdf_lines', c_void_p), ('lines_log2', c_int32), ('_pad3', c_int32),
-        ('dup_bits', c_void_p), ('upd_scale', c_void_p), ('apply_neg_ids', c_void_p), ('apply_pos_ids', c_void_p),
+        ('solo_flags', c_void_p), ('upd_scale', c_void_p),
     ]
 
 
@@ -105,7 +105,10 @@ SIGNATURES = {
     'rsa_mean_rows': (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     'rsa_row_lse': (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_float, c_void_p]),
     'rsa_fused_backward': (c_int, [POINTER(BackwardArgs), c_void_p]),
-    'rsa_mark_ids': (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_int64, c_void_p, c_void_p, c_void_p]),
+    'rsa_sort_step_elements': (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_int64, c_int64, c_void_p, c_void_p, c_int64,
+                                       c_void_p]),
+    'rsa_scatter_rows_presorted': (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int64, c_int32, c_void_p, c_void_p,
+                                           c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_void_p]),
     'rsa_scatter_add_rows': (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_int64, c_void_p]),
     'rsa_seg_gather': (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int32,
                                c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -57,14 +57,11 @@ struct FwdParams {
   float* loss_partials;         //   reduce_scratch (rsa_common.hpp, "caller-owned reduction scratch")
   const uint64_t* offset_dev;   // nullable: Philox offset read at run time (graph replays)
   const int64_t* packed_keys;   // num_neg == 1, GIVEN: element e = (query row << 32) | item row (sharded owner side)
-  // In-forward SGD (rsa_fused_args.dup_bits): a row that exactly ONE element of the step touches is updated by the wave
-  // that has it in registers; the elements on rows touched more than once are left to the sorted scatter (apply_neg /
-  // apply_pos: their ids, -1 for the elements already applied here)
-  const uint32_t* dup_bits;
+  // In-forward SGD (rsa_fused_args.solo_flags): a row that exactly ONE element of the step touches is updated by the wave
+  // that has it in registers; the elements on rows touched more than once are left to the sorted scatter
+  const uint8_t* solo_flags;
   const float* upd_scale;
   float* item_rw;
-  int64_t* apply_neg;
-  int64_t* apply_pos;
   int32_t* step_dropped;        // segment form (seg_stride != 0): <- sum of the segments' header word 1 (nullable)
   int32_t* overflow_sticky;     //   += the same (nullable)
   float* qgrad;      // fused BPR epilogue (nullable): [M, dim] d loss / d query row, accumulated from the rows in flight
@@ -544,11 +541,10 @@ __global__ __launch_bounds__(256, QG ? RSA_QG_MIN_WAVES : RSA_FWD_MIN_WAVES) voi
       if (p.mask_pad_pos && pad) pos_early = -INFINITY;
       const float bw = 1.f / (float)n, binv = 1.f / (float)p.n_queries;
       if constexpr (UPD) {
-        // rows touched by exactly one element of the step (no second bit in the step's id census) and not the padding
-        // row are updated in the tile; everything else keeps its id in apply_neg for the sorted scatter
+        // rows touched by exactly one element of the step (rsa_sort_step_elements' classification, element order
+        // m * (n + 1) + 1 + j) are updated in the tile; the sorted scatter skips exactly those
         const float upd = p.upd_scale[0];
-        const bool solo = act && id != 0 && !((p.dup_bits[id >> 5] >> (id & 31)) & 1u);
-        if (act) st_out(&p.apply_neg[e], solo ? (int64_t)-1 : (int64_t)id);
+        const bool solo = act && p.solo_flags[e + m_lane + 1] != 0;
         tile_rows_qg<LPR, NT, true>(p.item_table, solo ? (id | (int32_t)0x80000000) : id, qf, pos_early, bw, binv, dot, qacc,
                                     p.item_rw, upd);
       } else {
@@ -571,8 +567,7 @@ __global__ __launch_bounds__(256, QG ? RSA_QG_MIN_WAVES : RSA_FWD_MIN_WAVES) voi
       if constexpr (UPD) {
         // the positive row: d loss/d pos = -sum_j dneg_j, all of it known here (one tile per query)
         const int64_t pid = pid_u;
-        const bool solo_p = pid != 0 && !pad && !((p.dup_bits[pid >> 5] >> (pid & 31)) & 1u);     // wave-uniform
-        if (lane == 0) p.apply_pos[m_lane] = solo_p ? (int64_t)-1 : pid;
+        const bool solo_p = p.solo_flags[m_lane * (n + 1)] != 0;     // wave-uniform
         if (solo_p && lane < LPR) {
           const float c = p.upd_scale[0] * -tg;
           const float4 qv = qf.v[0];
@@ -999,7 +994,7 @@ static void launch_fwd2(const FwdParams& p, dim3 grid, dim3 block, hipStream_t s
   // streaming (nontemporal) row loads once the table cannot live in the 256 MB Infinity Cache
   const bool nt = !GENERIC && (size_t)p.n_items * p.dim * sizeof(float) > (512ull << 20);
   if constexpr (QU && !COS && !GENERIC) {
-    if (p.qgrad != nullptr && p.dup_bits != nullptr) {     // ... + SGD in place for the rows one element owns
+    if (p.qgrad != nullptr && p.solo_flags != nullptr) {     // ... + SGD in place for the rows one element owns
       if (nt) hipLaunchKernelGGL((fused_fwd_kernel<LPR, GENERIC, COS, QU, true, true, true>), grid, block, 0, stream, p);
       else hipLaunchKernelGGL((fused_fwd_kernel<LPR, GENERIC, COS, QU, false, true, true>), grid, block, 0, stream, p);
       return;
@@ -1115,11 +1110,9 @@ extern "C" int rsa_fused_sample_gather_score(const rsa_fused_args* a, rsa_stream
   p.offset_dev = a->offset_dev;
   p.loss_partials = nullptr;
   p.packed_keys = a->packed_keys;
-  p.dup_bits = nullptr;
+  p.solo_flags = nullptr;
   p.upd_scale = nullptr;
   p.item_rw = nullptr;
-  p.apply_neg = nullptr;
-  p.apply_pos = nullptr;
   p.step_dropped = nullptr;
   p.overflow_sticky = nullptr;
   p.seg_stride = 0;
@@ -1173,16 +1166,14 @@ extern "C" int rsa_fused_sample_gather_score(const rsa_fused_args* a, rsa_stream
                     "{32, 64, 128, 256}");
       p.qgrad = a->query_grad;
     }
-    if (a->dup_bits != nullptr) {
-      RSA_CHECK_ARG(bpr && a->num_neg == 64 && a->query_grad && a->upd_scale && a->apply_neg_ids && a->apply_pos_ids &&
+    if (a->solo_flags != nullptr) {
+      RSA_CHECK_ARG(bpr && a->num_neg == 64 && a->query_grad && a->upd_scale && a->sampler == RSA_SAMPLER_GIVEN &&
                         a->packed_keys == nullptr && !a->mask_pad_pos,
-                    "rsa_fused_sample_gather_score: the in-forward update (dup_bits) needs fused_loss = BPR with num_neg == 64, "
-                    "query_grad, upd_scale, apply_neg_ids and apply_pos_ids");
-      p.dup_bits = a->dup_bits;
+                    "rsa_fused_sample_gather_score: the in-forward update (solo_flags) needs fused_loss = BPR with num_neg == 64, "
+                    "given ids, query_grad and upd_scale");
+      p.solo_flags = a->solo_flags;
       p.upd_scale = a->upd_scale;
       p.item_rw = const_cast<float*>(a->item_table);
-      p.apply_neg = a->apply_neg_ids;
-      p.apply_pos = a->apply_pos_ids;
     }
   }
   if (ssm) {

@@ -106,13 +106,19 @@ __global__ __launch_bounds__(256) void sorted_apply_kernel(const int32_t* __rest
   const int32_t key = in ? keys[i] : -1;
   int32_t qrow = 0;
   float coef = 0.f;
+  bool solo = false;                  // flagged by classify_solo_kernel: the row has been applied by the forward
   if (in && key != drop_key) {        // empty slots: nothing is read for them (their query index is -1)
-    const int64_t e = vals[i];
+    int64_t e = vals[i];
+    solo = e < 0;
+    e &= 0x7fffffff;
     const int64_t m = e / w;
     const int c = (int)(e - m * w);
-    qrow = (int32_t)(query_index ? query_index[m] : m);
-    coef = (has_pos && c == 0) ? dpos[m] : dneg[m * (int64_t)n + (c - has_pos)];
+    if (!solo) {
+      qrow = (int32_t)(query_index ? query_index[m] : m);
+      coef = (has_pos && c == 0) ? dpos[m] : dneg[m * (int64_t)n + (c - has_pos)];
+    }
   }
+  const uint64_t solo_mask = __ballot(solo);
   const int cnt = (int)(total - begin < 64 ? total - begin : 64);
   const int32_t prev = begin > 0 ? keys[begin - 1] : -1;                     // key in front of the chunk
   const int32_t next = begin + cnt < total ? keys[begin + cnt] : -1;         // key behind it
@@ -151,7 +157,7 @@ __global__ __launch_bounds__(256) void sorted_apply_kernel(const int32_t* __rest
       const int t = t0 + u < 64 ? t0 + u : 63;
       const int32_t qr = __builtin_amdgcn_readlane(qrow, t);
       int32_t kr = __builtin_amdgcn_readlane(key, t);
-      kr = (kr < 0 || kr == drop_key) ? 0 : kr;
+      kr = (kr < 0 || kr == drop_key || ((solo_mask >> t) & 1ull)) ? 0 : kr;      // nothing to read for those: row 0
       const float* qp = query + (size_t)qr * D;
       const float* tp = target + (size_t)kr * D;
 #pragma unroll
@@ -181,7 +187,7 @@ __global__ __launch_bounds__(256) void sorted_apply_kernel(const int32_t* __rest
       const bool head = kt != before;
       if (head) {
         close_segment();
-        cur = kt;
+        cur = ((solo_mask >> t) & 1ull) ? -3 : kt;        // a solo row is a run of one element that is not applied here
 #pragma unroll
         for (int k = 0; k < NDW; ++k) {
           trow[k] = tv[u][k];
@@ -207,7 +213,7 @@ __global__ __launch_bounds__(256) void sorted_apply_kernel(const int32_t* __rest
   int32_t trail_key = -1;
   if (leading) {
     close_segment();                                  // -> lead_part
-  } else if (cur >= 0 && cur != drop_key && next == cur) {
+  } else if (cur >= 0 && cur != drop_key && next == cur) {      // (a solo element is never followed by its own key)
     trail_key = cur;                                  // the run goes on: sorted_finish_kernel owns its row
 #pragma unroll
     for (int k = 0; k < NDW; ++k) trail_part[(size_t)chunk * D + k * 64 + lane] = acc[k];
@@ -253,19 +259,22 @@ __global__ __launch_bounds__(256) void sorted_finish_kernel(int64_t n_chunks, co
   apply_run<NDW>(target, adam, cur, scale, lane, acc, trow, mrow_v, vrow_v);
 }
 
-// Id census of a step (rsa_mark_ids): which item rows are touched by more than one element.
-__global__ __launch_bounds__(256) void mark_ids_kernel(const int64_t* __restrict__ pos_ids, const int64_t* __restrict__ neg_ids,
-                                                       int64_t n_queries, int n, int64_t n_items, uint32_t* __restrict__ seen,
-                                                       uint32_t* __restrict__ dup) {
-  const int64_t n_neg = n_queries * (int64_t)n;
-  const int64_t total = n_neg + (pos_ids ? n_queries : 0);
+// After the sort: an element whose key differs from both neighbours is the ONLY element of the step on its row ("solo").
+// solo[e] (element order) <- 1 for such elements unless the row is the padding row / a dropped id, and bit 31 of the
+// element number in `vals` is set so that the apply kernel leaves the row alone: a forward that updates solo rows
+// itself (rsa_fused_args.solo_flags) has already applied them.
+constexpr int32_t SOLO_BIT = (int32_t)0x80000000;
+__global__ __launch_bounds__(256) void classify_solo_kernel(const int32_t* __restrict__ keys, int32_t* __restrict__ vals,
+                                                            int64_t total, int32_t pad_row, int32_t drop_key,
+                                                            uint8_t* __restrict__ solo) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
-    int64_t id = e < n_neg ? neg_ids[e] : pos_ids[e - n_neg];
-    id = id < 0 ? 0 : (id >= n_items ? n_items - 1 : id);
-    const uint32_t bit = 1u << (id & 31);
-    const uint32_t old = atomicOr(&seen[id >> 5], bit);
-    if (old & bit) atomicOr(&dup[id >> 5], bit);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int32_t k = keys[i];
+    const int32_t before = i > 0 ? keys[i - 1] : -1, after = i + 1 < total ? keys[i + 1] : -1;
+    const bool one = k != before && k != after && k != pad_row && k != drop_key;
+    const int32_t e = vals[i];
+    solo[e] = one ? 1 : 0;
+    if (one) vals[i] = e | SOLO_BIT;
   }
 }
 
@@ -297,59 +306,95 @@ extern "C" int64_t rsa_scatter_rows_sorted_workspace_bytes(int64_t n_queries, in
          2 * align256s(chunks * 256 * 4) + align256s(chunks * META_STRIDE * 4) + 256;
 }
 
-static int scatter_sorted_impl(const float* query, const int64_t* query_index, int64_t n_query_rows, int32_t dim,
-                               const int64_t* pos_ids, const int64_t* neg_ids, int64_t n_queries, int32_t num_neg,
-                               const float* dpos, const float* dneg, const float* upstream, int64_t n_items,
-                               int64_t pad_row, float* target, AdamArgs adam, void* workspace, int64_t workspace_bytes,
-                               rsa_stream_t stream) {
+struct SortedLayout {        // the caller's workspace (rsa_scatter_rows_sorted_workspace_bytes)
+  int32_t *k_in, *v_in, *k_out, *v_out;
+  void* temp;
+  float *lead_part, *trail_part;
+  int32_t* meta;
+};
+
+static SortedLayout sorted_layout(void* workspace, int64_t n_queries, int32_t num_neg, int64_t n_items) {
+  char* ws = reinterpret_cast<char*>(workspace);
+  const int64_t max_total = n_queries * (int64_t)(num_neg + 1);
+  const int64_t seg = align256s(max_total * 4);
+  const int64_t max_chunks = (max_total + 63) / 64;
+  SortedLayout L;
+  L.k_in = reinterpret_cast<int32_t*>(ws);
+  L.v_in = reinterpret_cast<int32_t*>(ws + seg);
+  L.k_out = reinterpret_cast<int32_t*>(ws + 2 * seg);
+  L.v_out = reinterpret_cast<int32_t*>(ws + 3 * seg);
+  L.temp = ws + 4 * seg;
+  char* tail = ws + 4 * seg + align256s((int64_t)sort_temp_bytes(max_total, key_bits(n_items + 1)));
+  L.lead_part = reinterpret_cast<float*>(tail);
+  L.trail_part = reinterpret_cast<float*>(tail + align256s(max_chunks * 256 * 4));
+  L.meta = reinterpret_cast<int32_t*>(tail + 2 * align256s(max_chunks * 256 * 4));
+  return L;
+}
+
+// (item id, element) pairs of a step, radix-sorted by id into the workspace; with `solo` also the classification pass
+static int sort_elements_impl(const int64_t* pos_ids, const int64_t* neg_ids, int64_t n_queries, int32_t num_neg, int64_t n_items,
+                              int64_t pad_row, uint8_t* solo, void* workspace, int64_t workspace_bytes, rsa_stream_t stream,
+                              const char* who) {
+  RSA_CHECK_ARG(n_queries >= 0 && num_neg >= 1 && n_items >= 1 && n_items < (1ll << 31), "%s: bad sizes", who);
+  if (n_queries == 0) return RSA_OK;
+  RSA_CHECK_ARG(neg_ids != nullptr, "%s: neg_ids is null", who);
+  const int has_pos = pos_ids != nullptr ? 1 : 0;
+  const int64_t total = n_queries * (int64_t)(num_neg + has_pos);
+  RSA_CHECK_ARG(total < (1ll << 31), "%s: more than 2^31 elements", who);
+  const int64_t need = rsa_scatter_rows_sorted_workspace_bytes(n_queries, num_neg, n_items);
+  RSA_CHECK_ARG(workspace && workspace_bytes >= need, "%s: workspace too small (%lld < %lld)", who, (long long)workspace_bytes,
+                (long long)need);
+  hipStream_t s = (hipStream_t)stream;
+  const SortedLayout L = sorted_layout(workspace, n_queries, num_neg, n_items);
+  int64_t blocks = (total + 255) / 256;
+  if (blocks > 65536) blocks = 65536;
+  hipLaunchKernelGGL(sorted_keys_kernel, dim3((unsigned)blocks), dim3(256), 0, s, pos_ids, neg_ids, n_queries, (int)num_neg,
+                     n_items, L.k_in, L.v_in);
+  RSA_CHECK_LAUNCH(who);
+  const unsigned bits = key_bits(n_items + 1);      // ids 0 .. n_items-1 and the drop key n_items
+  size_t temp_bytes = sort_temp_bytes(total, bits);
+  if (rocprim::radix_sort_pairs(L.temp, temp_bytes, L.k_in, L.k_out, L.v_in, L.v_out, (size_t)total, 0u, bits, s) != hipSuccess) {
+    rsa::set_error("%s: radix sort failed: %s", who, hipGetErrorString(hipGetLastError()));
+    return RSA_ERR_HIP;
+  }
+  if (solo != nullptr) {
+    const int32_t pad = (int32_t)(pad_row < 0 || pad_row >= (1ll << 31) ? -2 : pad_row);
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(classify_solo_kernel, dim3((unsigned)blocks), dim3(256), 0, s, L.k_out, L.v_out, total, pad,
+                       (int32_t)n_items, solo);
+    RSA_CHECK_LAUNCH(who);
+  }
+  return RSA_OK;
+}
+
+// the apply + finish passes over the sorted pairs in the workspace
+static int apply_sorted_impl(const float* query, const int64_t* query_index, int64_t n_query_rows, int32_t dim, int has_pos,
+                             int64_t n_queries, int32_t num_neg, const float* dpos, const float* dneg, const float* upstream,
+                             int64_t n_items, int64_t pad_row, float* target, AdamArgs adam, void* workspace,
+                             int64_t workspace_bytes, rsa_stream_t stream) {
   RSA_CHECK_ARG(n_queries >= 0 && num_neg >= 1 && n_items >= 1 && n_items < (1ll << 31), "rsa_scatter_rows_sorted: bad sizes");
   if (n_queries == 0) return RSA_OK;
-  RSA_CHECK_ARG(query && neg_ids && dneg && target, "rsa_scatter_rows_sorted: null pointer");
-  RSA_CHECK_ARG(pos_ids == nullptr || dpos != nullptr, "rsa_scatter_rows_sorted: pos_ids without dpos");
+  RSA_CHECK_ARG(query && dneg && target, "rsa_scatter_rows_sorted: null pointer");
+  RSA_CHECK_ARG(!has_pos || dpos != nullptr, "rsa_scatter_rows_sorted: pos_ids without dpos");
   RSA_CHECK_ARG(query_index != nullptr || n_query_rows >= n_queries, "rsa_scatter_rows_sorted: query has fewer rows than n_queries");
   if (dim != 64 && dim != 128 && dim != 256) {
     rsa::set_error("rsa_scatter_rows_sorted: dim=%d: built for dim in {64, 128, 256}", dim);
     return RSA_ERR_UNSUPPORTED;
   }
-  const int has_pos = pos_ids != nullptr ? 1 : 0;
   const int64_t total = n_queries * (int64_t)(num_neg + has_pos);
-  RSA_CHECK_ARG(total < (1ll << 31), "rsa_scatter_rows_sorted: more than 2^31 elements");
   const int64_t need = rsa_scatter_rows_sorted_workspace_bytes(n_queries, num_neg, n_items);
   RSA_CHECK_ARG(workspace && workspace_bytes >= need, "rsa_scatter_rows_sorted: workspace too small (%lld < %lld)",
                 (long long)workspace_bytes, (long long)need);
   hipStream_t s = (hipStream_t)stream;
-  char* ws = reinterpret_cast<char*>(workspace);
-  const int64_t seg = align256s(n_queries * (int64_t)(num_neg + 1) * 4);     // layout of the workspace_bytes call
-  int32_t* k_in = reinterpret_cast<int32_t*>(ws);
-  int32_t* v_in = reinterpret_cast<int32_t*>(ws + seg);
-  int32_t* k_out = reinterpret_cast<int32_t*>(ws + 2 * seg);
-  int32_t* v_out = reinterpret_cast<int32_t*>(ws + 3 * seg);
-  void* temp = ws + 4 * seg;
-  const int64_t max_total = n_queries * (int64_t)(num_neg + 1);
-  const int64_t max_chunks = (max_total + 63) / 64;
-  char* tail = ws + 4 * seg + align256s((int64_t)sort_temp_bytes(max_total, key_bits(n_items + 1)));
-  float* lead_part = reinterpret_cast<float*>(tail);
-  float* trail_part = reinterpret_cast<float*>(tail + align256s(max_chunks * 256 * 4));
-  int32_t* meta = reinterpret_cast<int32_t*>(tail + 2 * align256s(max_chunks * 256 * 4));
-  int64_t blocks = (total + 255) / 256;
-  if (blocks > 65536) blocks = 65536;
-  hipLaunchKernelGGL(sorted_keys_kernel, dim3((unsigned)blocks), dim3(256), 0, s, pos_ids, neg_ids, n_queries, (int)num_neg,
-                     n_items, k_in, v_in);
-  RSA_CHECK_LAUNCH("rsa_scatter_rows_sorted(keys)");
-  const unsigned bits = key_bits(n_items + 1);      // ids 0 .. n_items-1 and the drop key n_items
-  size_t temp_bytes = sort_temp_bytes(total, bits);
-  if (rocprim::radix_sort_pairs(temp, temp_bytes, k_in, k_out, v_in, v_out, (size_t)total, 0u, bits, s) != hipSuccess) {
-    rsa::set_error("rsa_scatter_rows_sorted: radix sort failed: %s", hipGetErrorString(hipGetLastError()));
-    return RSA_ERR_HIP;
-  }
+  const SortedLayout L = sorted_layout(workspace, n_queries, num_neg, n_items);
   const unsigned chunks = (unsigned)((total + 63) / 64);
   dim3 grid((chunks + 3) / 4), block(256);
   const int32_t pad = (int32_t)(pad_row < 0 || pad_row >= (1ll << 31) ? -2 : pad_row);
-#define RSA_SORTED_LAUNCH(NDW)                                                                                          \
-  hipLaunchKernelGGL(sorted_apply_kernel<NDW>, grid, block, 0, s, k_out, v_out, total, query, query_index, (int)num_neg,  \
-                     has_pos, dpos, dneg, upstream, pad, (int32_t)n_items, target, adam, lead_part, trail_part, meta);   \
-  hipLaunchKernelGGL(sorted_finish_kernel<NDW>, grid, block, 0, s, (int64_t)chunks, upstream, pad, target, adam,          \
-                     lead_part, trail_part, meta)
+#define RSA_SORTED_LAUNCH(NDW)                                                                                              \
+  hipLaunchKernelGGL(sorted_apply_kernel<NDW>, grid, block, 0, s, L.k_out, L.v_out, total, query, query_index, (int)num_neg,  \
+                     has_pos, dpos, dneg, upstream, pad, (int32_t)n_items, target, adam, L.lead_part, L.trail_part, L.meta); \
+  hipLaunchKernelGGL(sorted_finish_kernel<NDW>, grid, block, 0, s, (int64_t)chunks, upstream, pad, target, adam,              \
+                     L.lead_part, L.trail_part, L.meta)
   switch (dim) {
     case 64: RSA_SORTED_LAUNCH(1); break;
     case 128: RSA_SORTED_LAUNCH(2); break;
@@ -358,6 +403,39 @@ static int scatter_sorted_impl(const float* query, const int64_t* query_index, i
 #undef RSA_SORTED_LAUNCH
   RSA_CHECK_LAUNCH("rsa_scatter_rows_sorted(apply)");
   return RSA_OK;
+}
+
+static int scatter_sorted_impl(const float* query, const int64_t* query_index, int64_t n_query_rows, int32_t dim,
+                               const int64_t* pos_ids, const int64_t* neg_ids, int64_t n_queries, int32_t num_neg,
+                               const float* dpos, const float* dneg, const float* upstream, int64_t n_items,
+                               int64_t pad_row, float* target, AdamArgs adam, void* workspace, int64_t workspace_bytes,
+                               rsa_stream_t stream) {
+  RSA_CHECK_ARG(pos_ids == nullptr || dpos != nullptr, "rsa_scatter_rows_sorted: pos_ids without dpos");
+  if (dim != 64 && dim != 128 && dim != 256) {
+    rsa::set_error("rsa_scatter_rows_sorted: dim=%d: built for dim in {64, 128, 256}", dim);
+    return RSA_ERR_UNSUPPORTED;
+  }
+  int rc = sort_elements_impl(pos_ids, neg_ids, n_queries, num_neg, n_items, pad_row, nullptr, workspace, workspace_bytes, stream,
+                              "rsa_scatter_rows_sorted");
+  if (rc != RSA_OK) return rc;
+  return apply_sorted_impl(query, query_index, n_query_rows, dim, pos_ids != nullptr, n_queries, num_neg, dpos, dneg, upstream,
+                           n_items, pad_row, target, adam, workspace, workspace_bytes, stream);
+}
+
+extern "C" int rsa_sort_step_elements(const int64_t* pos_ids, const int64_t* neg_ids, int64_t n_queries, int32_t num_neg,
+                                      int64_t n_items, int64_t pad_row, uint8_t* solo, void* workspace, int64_t workspace_bytes,
+                                      rsa_stream_t stream) {
+  return sort_elements_impl(pos_ids, neg_ids, n_queries, num_neg, n_items, pad_row, solo, workspace, workspace_bytes, stream,
+                            "rsa_sort_step_elements");
+}
+
+extern "C" int rsa_scatter_rows_presorted(const float* query, const int64_t* query_index, int64_t n_query_rows, int32_t dim,
+                                          int32_t has_pos, int64_t n_queries, int32_t num_neg, const float* dpos, const float* dneg,
+                                          const float* upstream, int64_t n_items, int64_t pad_row, float* target, void* workspace,
+                                          int64_t workspace_bytes, rsa_stream_t stream) {
+  const AdamArgs none{nullptr, nullptr, 0.f, 0.f, 0.f, 0.f};
+  return apply_sorted_impl(query, query_index, n_query_rows, dim, has_pos != 0, n_queries, num_neg, dpos, dneg, upstream, n_items,
+                           pad_row, target, none, workspace, workspace_bytes, stream);
 }
 
 extern "C" int rsa_scatter_rows_sorted(const float* query, const int64_t* query_index, int64_t n_query_rows, int32_t dim,
@@ -382,18 +460,4 @@ extern "C" int rsa_adam_rows_sorted(const float* query, const int64_t* query_ind
   const AdamArgs adam{exp_avg, exp_avg_sq, 1.f - beta1, 1.f - beta2, eps, (float)((double)lr * sqrt(bc2) / bc1)};
   return scatter_sorted_impl(query, query_index, n_query_rows, dim, pos_ids, neg_ids, n_queries, num_neg, dpos, dneg,
                              upstream, n_items, pad_row, weight, adam, workspace, workspace_bytes, stream);
-}
-
-extern "C" int rsa_mark_ids(const int64_t* pos_ids, const int64_t* neg_ids, int64_t n_queries, int32_t num_neg, int64_t n_items,
-                            uint32_t* seen, uint32_t* dup, rsa_stream_t stream) {
-  RSA_CHECK_ARG(n_queries >= 0 && num_neg >= 0 && n_items >= 1 && n_items < (1ll << 31), "rsa_mark_ids: bad sizes");
-  const int64_t total = n_queries * (int64_t)num_neg + (pos_ids ? n_queries : 0);
-  if (total == 0) return RSA_OK;
-  RSA_CHECK_ARG((neg_ids || num_neg == 0) && seen && dup, "rsa_mark_ids: null pointer");
-  int64_t blocks = (total + 255) / 256;
-  if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(mark_ids_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, pos_ids, neg_ids, n_queries,
-                     (int)num_neg, n_items, seen, dup);
-  RSA_CHECK_LAUNCH("rsa_mark_ids");
-  return RSA_OK;
 }

@@ -257,9 +257,10 @@ def bpr_sgd_step(item_weight, user_weight, num_neg, lr, *, user_ids, pos_ids, sa
     ``in_forward`` (default: on for num_neg == 64 and embed_dim in {64, 128, 256}): most item rows of a step are touched
     by exactly ONE of its elements -- such a row is read by one wave of the forward and by nobody else, so that wave
     rewrites it on the spot (row + (-lr) * d * q, the row and the query fragment being in registers): no second read of
-    the row, no read of the query row, no place in the sort.  The negatives are drawn first (the Sampler plugin: same
-    ids, same generator consumption as the in-kernel sampler), ``rsa_mark_ids`` takes the census of the step's ids, and
-    only the elements on rows that occur more than once go through the sorted scatter.  Same result as the all-sorted
+    the row, no read of the query row.  The negatives are drawn first (the Sampler plugin: same ids, same generator
+    consumption as the in-kernel sampler) and sorted by item id BEFORE the forward (``rsa_sort_step_elements``: the sort the
+    all-sorted form runs after it); a run of length one in the sorted order is a solo row, and only the other elements go
+    through the apply pass (``rsa_scatter_rows_presorted``).  Same result as the all-sorted
     form bit for bit on the solo rows, equal up to fp32 summation order on the shared ones; bit-reproducible."""
     M = user_ids.numel()
     kind = _sampler_kind(sampler) if sampler is not None else nat.SAMPLER_GIVEN
@@ -288,11 +289,19 @@ def bpr_sgd_step(item_weight, user_weight, num_neg, lr, *, user_ids, pos_ids, sa
         else:
             ops.fused_backward(iw, uw, out['neg_ids'], out['dneg'], query_index=user_ids, pos_ids=pos_ids, dpos=out['dpos'],
                                upstream=step, dense_item_grad=True, item_grad_out=iw, want_query_grad=False)
-        ops.scatter_add_rows(out['query_grad'] * step, user_ids, uw.shape[0], out=uw)
+        _apply_user_rows(uw, user_ids, out['query_grad'], step)
     return out['loss'], out['neg_ids']
 
 
-_CENSUS = {}
+def _apply_user_rows(uw, user_ids, qgrad, step):
+    """user[uid] += step * qgrad: duplicates of a user in the batch summed in sorted order, no atomics (bit-reproducible)
+    for the stock dims; the float-atomic row scatter otherwise."""
+    M = user_ids.numel()
+    if uw.shape[1] in (64, 128, 256):
+        ones = torch.ones(M, 1, dtype=torch.float32, device=uw.device)
+        ops.scatter_rows_sorted(uw, qgrad, user_ids.view(M, 1), ones, upstream=step, pad_row=0)
+    else:
+        ops.scatter_add_rows(qgrad * step, user_ids, uw.shape[0], out=uw)
 
 
 def _bpr_sgd_step_in_forward(item_weight, user_weight, num_neg, lr, user_ids, pos_ids, sampler, kind, kw):
@@ -303,22 +312,16 @@ def _bpr_sgd_step_in_forward(item_weight, user_weight, num_neg, lr, user_ids, po
             neg = kw['neg_ids']
         else:       # the stand-alone sampler draws what the in-kernel one would (same stream, same generator advance)
             neg = sampler(torch.empty(M, 1, device=iw.device), num_neg, None)[0]
-        key = (iw.shape[0], iw.device)
-        bufs = _CENSUS.get(key)
-        if bufs is None:
-            if len(_CENSUS) >= 4:
-                _CENSUS.clear()
-            bufs = _CENSUS[key] = ops.mark_ids(pos_ids, neg, iw.shape[0])
-        else:
-            ops.mark_ids(pos_ids, neg, iw.shape[0], *bufs)
+        # the step's (item id, element) pairs sorted by id -- the sort the all-sorted form runs AFTER the forward -- and, from
+        # the sorted order, which elements are alone on their row
+        solo, ws = ops.sort_step_elements(pos_ids, neg, iw.shape[0], pad_row=0)
         step = torch.full((1,), -float(lr), dtype=torch.float32, device=iw.device)
         out = ops.fused_forward(iw, uw, num_neg, query_index=user_ids, pos_ids=pos_ids, neg_ids=neg, sampler=nat.SAMPLER_GIVEN,
-                                fused_bpr=True, want_query_grad=True, inplace_update=(bufs[1], step))
-        # the elements on shared rows: sorted by item id, every such row read-modified-written once (negative ids = the
-        # elements the forward has applied already: dropped)
-        ops.scatter_rows_sorted(iw, uw, out['apply_neg_ids'], out['dneg'], query_index=user_ids, pos_ids=out['apply_pos_ids'],
-                                dpos=out['dpos'], upstream=step, pad_row=0)
-        ops.scatter_add_rows(out['query_grad'] * step, user_ids, uw.shape[0], out=uw)
+                                fused_bpr=True, want_query_grad=True, inplace_update=(solo, step))
+        # the elements on shared rows: every such row read-modified-written once, in sorted order
+        ops.scatter_rows_presorted(iw, uw, ws, M, num_neg, out['dneg'], query_index=user_ids, dpos=out['dpos'], upstream=step,
+                                   pad_row=0)
+        _apply_user_rows(uw, user_ids, out['query_grad'], step)
     return out['loss'], out['neg_ids']
 
 

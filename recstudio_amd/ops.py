@@ -373,14 +373,10 @@ def fused_forward(item_table, query, num_neg, *, query_index=None, pos_ids=None,
                 out['query_grad'] = torch.empty(M, dim, dtype=torch.float32, device=dev)
             a.query_grad = ptr(out['query_grad'])
         if inplace_update is not None:
-            # (dup_bits, scale): rows touched by exactly one element of the step are updated inside the forward
-            # (item_table += scale * d * q); the rest is handed back in apply_neg_ids / apply_pos_ids
-            dup_bits, upd_scale = inplace_update
-            if 'apply_neg_ids' not in out:
-                out['apply_neg_ids'] = torch.empty(M, n, dtype=torch.int64, device=dev)
-                out['apply_pos_ids'] = torch.empty(M, dtype=torch.int64, device=dev)
-            a.dup_bits, a.upd_scale = ptr(_need(dup_bits, torch.int32, 'dup_bits')), ptr(_need(upd_scale, torch.float32, 'upd_scale'))
-            a.apply_neg_ids, a.apply_pos_ids = ptr(out['apply_neg_ids']), ptr(out['apply_pos_ids'])
+            # (solo_flags, scale): rows touched by exactly one element of the step (sort_step_elements) are updated inside
+            # the forward: item_table += scale * d * q
+            solo_flags, upd_scale = inplace_update
+            a.solo_flags, a.upd_scale = ptr(_need(solo_flags, torch.uint8, 'solo_flags')), ptr(_need(upd_scale, torch.float32, 'upd_scale'))
     elif want_query_grad:
         raise ValueError('want_query_grad needs a fused loss (fused_bpr=True / fused_loss=...)')
     nat.check(nat.lib().rsa_fused_sample_gather_score(ctypes.byref(a), _stream()), 'rsa_fused_sample_gather_score')
@@ -543,23 +539,39 @@ def fused_backward(item_table, query, neg_ids, dneg, *, query_index=None, pos_id
 
 
 @_on_device
-def mark_ids(pos_ids, neg_ids, n_items, seen=None, dup=None):
-    """rsa_mark_ids: the id census of a step -> (seen, dup) int32 bit tables [(n_items + 31) // 32]: bit i of ``dup`` is set
-    iff item i is touched by more than one element (positives included).  ``seen`` / ``dup``: buffers of an earlier
-    call to reuse (they are zeroed here)."""
+def sort_step_elements(pos_ids, neg_ids, n_items, pad_row=0):
+    """rsa_sort_step_elements: the step's (item id, element) pairs sorted by id in a workspace, and the classification
+    ``solo [M, 1 + n]`` uint8 (column 0 = the positive): 1 where no other element of the step touches that item row.
+    -> (solo, workspace) for ``fused_forward(inplace_update=...)`` + ``scatter_rows_presorted``."""
     neg_ids = _need(neg_ids, torch.int64, 'neg_ids')
     pos_ids = _need_opt(pos_ids, torch.int64, 'pos_ids')
-    words = (int(n_items) + 31) // 32
-    if seen is None:
-        both = torch.zeros(2, words, dtype=torch.int32, device=neg_ids.device)
-        seen, dup = both[0], both[1]
-    else:
-        seen.zero_()
-        dup.zero_()
     M = pos_ids.numel() if pos_ids is not None else neg_ids.shape[0]
     n = neg_ids.numel() // max(M, 1)
-    nat.check(nat.lib().rsa_mark_ids(ptr(pos_ids), ptr(neg_ids), M, n, int(n_items), ptr(seen), ptr(dup), _stream()), 'rsa_mark_ids')
-    return seen, dup
+    w = n + (1 if pos_ids is not None else 0)
+    solo = torch.empty(M, w, dtype=torch.uint8, device=neg_ids.device)
+    ws_bytes = int(nat.lib().rsa_scatter_rows_sorted_workspace_bytes(M, n, int(n_items)))
+    ws = torch.empty(max(ws_bytes, 8), dtype=torch.uint8, device=neg_ids.device)
+    nat.check(nat.lib().rsa_sort_step_elements(ptr(pos_ids), ptr(neg_ids), M, n, int(n_items), int(pad_row), ptr(solo), ptr(ws),
+                                               ws_bytes, _stream()), 'rsa_sort_step_elements')
+    return solo, ws
+
+
+@_on_device
+def scatter_rows_presorted(target, query, workspace, n_queries, num_neg, dneg, *, query_index=None, dpos=None, upstream=None,
+                           pad_row=0):
+    """rsa_scatter_rows_presorted: the apply pass of scatter_rows_sorted over the pairs ``sort_step_elements`` left in
+    ``workspace`` (elements flagged solo there are skipped: the forward has applied them)."""
+    target = _need(target, torch.float32, 'target')
+    query = _need(query, torch.float32, 'query')
+    dneg = _need(dneg, torch.float32, 'dneg')
+    n_items, dim = target.shape
+    nat.check(nat.lib().rsa_scatter_rows_presorted(ptr(query), ptr(_need_opt(query_index, torch.int64, 'query_index')), query.shape[0],
+                                                   dim, int(dpos is not None), int(n_queries), int(num_neg),
+                                                   ptr(_need_opt(dpos, torch.float32, 'dpos')), ptr(dneg),
+                                                   ptr(_need_opt(upstream, torch.float32, 'upstream')), n_items, int(pad_row),
+                                                   ptr(target), ptr(workspace), workspace.numel(), _stream()),
+              'rsa_scatter_rows_presorted')
+    return target
 
 
 # ------------------------------------------------------------------ full catalog

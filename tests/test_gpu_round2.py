@@ -760,9 +760,9 @@ def test_fused_step_object_replays_the_call_with_fresh_draws(ra):
                                         (97, 256, 64, 'uniform'), (40_009, 128, 300, 'given')])
 def test_bpr_sgd_step_in_forward_equals_all_sorted(ra, N, d, B, kind):
     """fused.bpr_sgd_step with the in-forward update (rows touched by exactly one element of the step are rewritten by
-    the wave that has them in registers; only the shared rows go through the sort) == the all-sorted step: same loss,
+    the wave that has them in registers; only the shared rows go through the apply pass) == the all-sorted step: same loss,
     same negatives, item and user tables equal (solo rows bit for bit; shared rows up to fp32 summation order), the
-    padding row untouched, bit-reproducible; the census kernel == torch.bincount.  N = 97: almost every row is shared;
+    padding row untouched, bit-reproducible; the classification == torch.bincount.  N = 97: almost every row is shared;
     'given': ids with planted collisions between positives and negatives and padding ids among the negatives."""
     n, U, lr = 64, 211, 0.3
     iw, uw = _tables(N, U, d, B)
@@ -793,12 +793,12 @@ def test_bpr_sgd_step_in_forward_equals_all_sorted(ra, N, d, B, kind):
     assert torch.equal(us0, us1)                                                               # the user side is the same code
     rel_close(it1.cpu(), it0.cpu(), rtol=1e-5, atol=1e-7)
     assert not it1[0].any() and not torch.equal(it1, iw.to(DEV))
-    # the census and the split: solo rows (touched by exactly one element) must be exactly the all-sorted result
-    seen, dup = ra.ops.mark_ids(pos, i0, N)
+    # the classification: solo <=> the only element of the step on its row (and not the padding row); those rows must be
+    # exactly the all-sorted result
+    solo_flags, _ = ra.ops.sort_step_elements(pos, i0, N)
     cnt = torch.bincount(torch.cat([pos, i0.reshape(-1)]), minlength=N)
-    bits = torch.arange(N, device=DEV)
-    unpack = lambda t: ((t[bits >> 5] >> (bits & 31)) & 1).bool()      # noqa: E731
-    assert torch.equal(unpack(seen), cnt > 0) and torch.equal(unpack(dup), cnt > 1)
+    all_ids = torch.cat([pos.view(-1, 1), i0], 1)
+    assert torch.equal(solo_flags.bool(), (cnt[all_ids] == 1) & (all_ids != 0))
     solo = (cnt == 1)
     solo[0] = False
     assert torch.equal(it1[solo], it0[solo])
