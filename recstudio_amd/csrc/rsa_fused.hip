@@ -296,10 +296,11 @@ __device__ __forceinline__ void tile_rows_qg(const float* table, int32_t id_lane
       if constexpr (UPD) {
         const int32_t idf = __shfl(id_lane, gb + b * BATCH + k, 64);
         if (idf < 0) {       // lane-group uniform: the row belongs to this element alone
-          const float c = upd * g;
+          // the apply pass's arithmetic, rounding for rounding: acc = d * q, row + scale * acc
           const float4 qv = qf.v[0];
           typedef float v4f __attribute__((ext_vector_type(4)));
-          v4f nv = {__fmaf_rn(c, qv.x, xv.x), __fmaf_rn(c, qv.y, xv.y), __fmaf_rn(c, qv.z, xv.z), __fmaf_rn(c, qv.w, xv.w)};
+          v4f nv = {__fadd_rn(xv.x, __fmul_rn(upd, __fmul_rn(g, qv.x))), __fadd_rn(xv.y, __fmul_rn(upd, __fmul_rn(g, qv.y))),
+                    __fadd_rn(xv.z, __fmul_rn(upd, __fmul_rn(g, qv.z))), __fadd_rn(xv.w, __fmul_rn(upd, __fmul_rn(g, qv.w)))};
           __builtin_nontemporal_store(nv, reinterpret_cast<v4f*>(item_rw + (size_t)(idf & 0x7fffffff) * D + sub * 4));
         }
       }
@@ -394,8 +395,11 @@ __device__ __forceinline__ float finish_score(int mode, float dot, float inorm2,
 #ifndef RSA_FWD_GRID_CAP
 #define RSA_FWD_GRID_CAP (256 * 8)
 #endif
+#ifndef RSA_UPD_MIN_WAVES
+#define RSA_UPD_MIN_WAVES 1
+#endif
 template <int LPR, bool GENERIC, bool COS, bool QU, bool NT, bool QG = false, bool UPD = false>
-__global__ __launch_bounds__(256, QG ? RSA_QG_MIN_WAVES : RSA_FWD_MIN_WAVES) void fused_fwd_kernel(const FwdParams p) {
+__global__ __launch_bounds__(256, UPD ? RSA_UPD_MIN_WAVES : (QG ? RSA_QG_MIN_WAVES : RSA_FWD_MIN_WAVES)) void fused_fwd_kernel(const FwdParams p) {
   using F = Frag<LPR, GENERIC>;
   const int lane = lane_id();
   const int sub = lane % LPR;
@@ -569,10 +573,11 @@ __global__ __launch_bounds__(256, QG ? RSA_QG_MIN_WAVES : RSA_FWD_MIN_WAVES) voi
         const int64_t pid = pid_u;
         const bool solo_p = p.solo_flags[m_lane * (n + 1)] != 0;     // wave-uniform
         if (solo_p && lane < LPR) {
-          const float c = p.upd_scale[0] * -tg;
+          const float us = p.upd_scale[0], dp = -tg;
           const float4 qv = qf.v[0];
           *reinterpret_cast<float4*>(p.item_rw + (size_t)pid * D + sub * 4) =
-              make_float4(__fmaf_rn(c, qv.x, pv.x), __fmaf_rn(c, qv.y, pv.y), __fmaf_rn(c, qv.z, pv.z), __fmaf_rn(c, qv.w, pv.w));
+              make_float4(__fadd_rn(pv.x, __fmul_rn(us, __fmul_rn(dp, qv.x))), __fadd_rn(pv.y, __fmul_rn(us, __fmul_rn(dp, qv.y))),
+                          __fadd_rn(pv.z, __fmul_rn(us, __fmul_rn(dp, qv.z))), __fadd_rn(pv.w, __fmul_rn(us, __fmul_rn(dp, qv.w))));
         }
       }
     } else if constexpr (RSA_FWD_PLAIN_PIPE && QU && !COS && !GENERIC) {
