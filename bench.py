@@ -354,8 +354,9 @@ def main():
             ms_train = time_gpu(train, max(10, args.steps // 4), 5) * 1e3
             t_f = time_gpu(lambda: ra.ops.fused_forward(item, user, n, out=bufs['train'], fused_bpr=True,
                                                         want_query_grad=True, **kw), max(10, args.steps // 4), 5) * 1e3
-            extra['train_step'] = {'profile_step_kernel_ms': (profile_record('train_step_N1e7_popular_n64_B65536') or {}).get('step_kernel_us'),
-                                   'profile_sgd_step_kernel_ms': (profile_record('sgd_step_N1e7_popular_n64_B65536') or {}).get('step_kernel_us'),
+            prof_ms = lambda name: round((profile_record(name) or {}).get('step_kernel_us', 0.0) / 1e3, 4) or None      # noqa: E731
+            extra['train_step'] = {'profile_step_kernel_ms': prof_ms('train_step_N1e7_popular_n64_B65536'),
+                                   'profile_sgd_step_kernel_ms': prof_ms('sgd_step_N1e7_popular_n64_B65536'),
                                    'ms_per_step': round(ms_train, 4), 'value': round(B * n / ms_train / 1e3, 2),
                                    'unit': 'M triplets/s', 'what': 'forward + BPR loss + user-gradient rows (accumulated '
                                    'in the forward) + row-sparse item-gradient rows (no optimizer)',
@@ -381,8 +382,10 @@ def main():
             extra['train_step']['adam_step_ms'] = round(t_adam, 4)
             extra['train_step']['adam_step_what'] = ('forward + BPR loss + lazy Adam (SparseAdam rule) on the touched item '
                                                      'and user rows, gradient sums kept in registers (no gradient tensor)')
-            extra['train_step']['sgd_step_what'] = ('forward + BPR loss + SGD update of the touched item and user rows '
-                                                    'applied in place by the kernels (no [N, d] gradient tensor)')
+            extra['train_step']['sgd_step_what'] = ('negatives drawn and sorted by item id, forward + BPR loss with the SGD update of '
+                                                    'every item row only one element touches applied by the wave that holds it, '
+                                                    'sorted apply pass for the shared rows, sorted user-row update (no [N, d] '
+                                                    'gradient tensor; bit-reproducible)')
         except Exception as e:      # never let the secondary figure kill the bench line
             extra['train_step'] = {'error': repr(e)[:200]}
         if not args.no_sweep:
