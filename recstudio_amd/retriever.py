@@ -551,6 +551,27 @@ class BaseRetriever(torch.nn.Module):
                  'rmsprop': torch.optim.RMSprop}
         return table.get(name, torch.optim.Adam)(params, lr=lr, weight_decay=wd)
 
+    def _get_scheduler(self, optimizer):
+        """recommender.py:476-494: ``train.scheduler`` = 'exponential' (gamma 0.98) | 'onplateau' | None, stepped once
+        per epoch (the plateau scheduler on the monitored validation metric, else on the training loss)."""
+        name = self.config['train'].get('scheduler')
+        if name is None or optimizer is None:
+            return None
+        if name.lower() == 'exponential':
+            return torch.optim.lr_scheduler.ExponentialLR(optimizer, gamma=0.98)
+        if name.lower() == 'onplateau':
+            return torch.optim.lr_scheduler.ReduceLROnPlateau(optimizer, mode=self.config['train'].get('early_stop_mode', 'max'))
+        return None
+
+    def _step_scheduler(self, scheduler, log):
+        if scheduler is None:
+            return
+        if isinstance(scheduler, torch.optim.lr_scheduler.ReduceLROnPlateau):
+            scheduler.step(log.get(getattr(self, 'val_metric', None), log['train_loss']))
+        else:
+            scheduler.step()
+        log['lr'] = float(scheduler.optimizer.param_groups[0]['lr'])
+
     def _to_device(self, batch, device):
         def move(v):
             if isinstance(v, torch.Tensor):
@@ -672,6 +693,9 @@ class BaseRetriever(torch.nn.Module):
             optimizer = self._make_optimizer(params) if params else None
         if not fused:
             self.item_encoder.weight.grad = trainer.item_grad_local       # the exchange accumulates into the block's .grad
+        if fused and tr.get('scheduler'):
+            raise NotImplementedError("multi-GPU fit: train.scheduler needs the torch optimizer (train.fused_optimizer: None)")
+        scheduler = self._get_scheduler(optimizer)
         sh['trainer'] = trainer
         val_metrics = self.config['eval']['val_metrics']
         cutoff = self.config['eval']['cutoff']
@@ -713,6 +737,7 @@ class BaseRetriever(torch.nn.Module):
                     best, best_state, bad = cur, copy.deepcopy(self.state_dict()), 0
                 else:
                     bad += 1
+            self._step_scheduler(scheduler, log)      # (the all-reduced loss / metric: the same decision on every rank)
             self.logged_metrics = log
             if rank == 0:
                 self.logger.info(' '.join(f'{k}={v:.4f}' if isinstance(v, float) else f'{k}={v}' for k, v in log.items()))
@@ -745,6 +770,7 @@ class BaseRetriever(torch.nn.Module):
         optimizer = self._get_optimizer()
         tr = self.config['train']
         fused_step = self._fused_optimizer_step(tr)
+        scheduler = None if fused_step is not None else self._get_scheduler(optimizer)
         val_metrics = self.config['eval']['val_metrics']
         cutoff = self.config['eval']['cutoff']
         cutoff0 = cutoff[0] if isinstance(cutoff, list) else cutoff
@@ -782,6 +808,7 @@ class BaseRetriever(torch.nn.Module):
                     best, best_state, bad = cur, copy.deepcopy(self.state_dict()), 0
                 else:
                     bad += 1
+            self._step_scheduler(scheduler, log)
             self.logged_metrics = log
             self.logger.info(' '.join(f'{k}={v:.4f}' if isinstance(v, float) else f'{k}={v}' for k, v in log.items()))
             if val_data is not None and bad >= tr['early_stop_patience']:
@@ -803,7 +830,7 @@ class BaseRetriever(torch.nn.Module):
         ok = (type(self.loss_fn) is BPRLoss and self.sampler is not None and self._fused_ok()
               and type(self.score_func) is InnerProductScorer and isinstance(self.neg_count, int) and self.neg_count % 64 == 0
               and isinstance(self.query_encoder, torch.nn.Embedding) and self.item_encoder.weight.shape[1] in (64, 128, 256)
-              and not tr.get('weight_decay') and tr.get('grad_clip_norm') is None)
+              and not tr.get('weight_decay') and tr.get('grad_clip_norm') is None and not tr.get('scheduler'))
         if not ok:
             raise NotImplementedError("train.fused_optimizer needs the stock BPR two-tower configuration "
                                       "(see BaseRetriever._fused_optimizer_step)")

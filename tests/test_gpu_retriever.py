@@ -145,6 +145,34 @@ def test_bpr_fit_ml100k(ra, golden):
     assert res['recall@20'] > 0.05 and best > 0.01          # far above chance (20 / 1574 items)
 
 
+@pytest.mark.parametrize('name,lrs', [('exponential', [0.01 * 0.98, 0.01 * 0.98 ** 2, 0.01 * 0.98 ** 3]), ('onplateau', None)])
+def test_fit_steps_the_configured_scheduler(ra, golden, name, lrs):
+    """train.scheduler (recommender.py:476-494: 'exponential' = ExponentialLR(gamma 0.98), 'onplateau' = ReduceLROnPlateau),
+    stepped once per epoch; weight decay and gradient clipping go to the torch optimizer as in the reference."""
+    g = golden('data_ml100k')
+    cfg = {'train': {'epochs': 3, 'negative_count': 64, 'batch_size': 2048, 'learning_rate': 0.01, 'scheduler': name,
+                     'weight_decay': 1e-6, 'grad_clip_norm': 5.0}, 'eval': {'batch_size': 256}}
+    model = ra.BPR(cfg)
+    trn, val, _ = make(ra.TripletDataset, g).build(split_ratio=[0.8, 0.1, 0.1], shuffle=True)
+    seen = []
+    import logging
+
+    class Grab(logging.Handler):
+        def emit(self, record):
+            seen.append(record.getMessage())
+    model.logger.addHandler(Grab())
+    model.logger.setLevel(logging.INFO)
+    model.fit(trn, val)
+    got = [float(m.split('lr=')[1].split()[0]) for m in seen if 'lr=' in m]
+    assert len(got) == 3
+    if lrs is not None:
+        np.testing.assert_allclose(got, lrs, rtol=1e-3)        # (the log prints four decimals)
+    else:
+        assert all(abs(v - 0.01) < 1e-9 for v in got)          # three improving epochs: the plateau scheduler holds the rate
+    with pytest.raises(NotImplementedError):                   # the in-kernel optimizer step has no scheduler hook
+        ra.BPR({'train': dict(cfg['train'], fused_optimizer='sgd')}).fit(trn, val)
+
+
 def test_sasrec_fit_ml100k(ra, golden):
     """BASELINE.json configs[2] shape (scaled down): SASRec on SeqDataset, d = 64, L <= 50,
     SampledSoftmax with the popularity sampler, n = 64."""
