@@ -166,7 +166,7 @@ def test_fit_steps_the_configured_scheduler(ra, golden, name, lrs):
     got = [float(m.split('lr=')[1].split()[0]) for m in seen if 'lr=' in m]
     assert len(got) == 3
     if lrs is not None:
-        np.testing.assert_allclose(got, lrs, rtol=1e-3)        # (the log prints four decimals)
+        np.testing.assert_allclose(got, lrs, rtol=6e-3)        # (the log prints four decimals)
     else:
         assert all(abs(v - 0.01) < 1e-9 for v in got)          # three improving epochs: the plateau scheduler holds the rate
     with pytest.raises(NotImplementedError):                   # the in-kernel optimizer step has no scheduler hook
