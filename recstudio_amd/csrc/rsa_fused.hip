@@ -336,12 +336,12 @@ __device__ __forceinline__ void tile_rows_qg(const float* table, int32_t id_lane
 
 // Plain (no loss) counterpart of the pipelined training tile: batches of RSA_QG_BATCH rows, batch b+1 requested while
 // batch b is reduced with butterfly sums, order pinned by data dependences.  Query-uniform inner product only.
-template <int LPR, bool NT>
+template <int LPR, bool NT, int PB = RSA_QG_BATCH>
 __device__ __forceinline__ void tile_rows_pipe(const float* __restrict__ table, int32_t id_lane,
                                                const Frag<LPR, false>& qf, float& dot) {
   using F = Frag<LPR, false>;
   constexpr int D = LPR * 4;
-  constexpr int BATCH = LPR < RSA_QG_BATCH ? LPR : RSA_QG_BATCH;
+  constexpr int BATCH = LPR < PB ? LPR : PB;
   constexpr int NB = LPR / BATCH;
   const int lane = lane_id();
   const int sub = lane % LPR;
@@ -395,10 +395,18 @@ __device__ __forceinline__ float finish_score(int mode, float dot, float inorm2,
 #ifndef RSA_FWD_GRID_CAP
 #define RSA_FWD_GRID_CAP (256 * 8)
 #endif
+// Small and medium launches (up to RSA_PIPE_MAX_TILES tiles: B = 32768 at n = 64) run the butterfly tile with 8-row batches
+// (tile_rows_pipe<.., 8>) instead of the transposed fold: B = 4096: 37.8 -> 35.5 us, B = 16384: 120 -> 111 us per launch
+// (popularity sampler; uniform and given ids alike), equal within the run-to-run noise at B = 65536, where the transposed
+// fold stays (tools/run_r3f.sh).  With few tiles per wave slot what counts is how early a tile's first rows are
+// requested, not the shuffle count.
+#ifndef RSA_PIPE_MAX_TILES
+#define RSA_PIPE_MAX_TILES 32768
+#endif
 #ifndef RSA_UPD_MIN_WAVES
 #define RSA_UPD_MIN_WAVES 4      // 128 VGPRs (48 bytes of scratch at d = 128): 1-1.5 % faster than 145 VGPRs at 3 waves/SIMD
 #endif
-template <int LPR, bool GENERIC, bool COS, bool QU, bool NT, bool QG = false, bool UPD = false>
+template <int LPR, bool GENERIC, bool COS, bool QU, bool NT, bool QG = false, bool UPD = false, int PIPE = 0>
 __global__ __launch_bounds__(256, UPD ? RSA_UPD_MIN_WAVES : (QG ? RSA_QG_MIN_WAVES : RSA_FWD_MIN_WAVES)) void fused_fwd_kernel(const FwdParams p) {
   using F = Frag<LPR, GENERIC>;
   const int lane = lane_id();
@@ -580,8 +588,8 @@ __global__ __launch_bounds__(256, UPD ? RSA_UPD_MIN_WAVES : (QG ? RSA_QG_MIN_WAV
                           __fadd_rn(pv.z, __fmul_rn(us, __fmul_rn(dp, qv.z))), __fadd_rn(pv.w, __fmul_rn(us, __fmul_rn(dp, qv.w))));
         }
       }
-    } else if constexpr (RSA_FWD_PLAIN_PIPE && QU && !COS && !GENERIC) {
-      tile_rows_pipe<LPR, NT>(p.item_table, id, qf, dot);
+    } else if constexpr ((RSA_FWD_PLAIN_PIPE || PIPE > 0) && QU && !COS && !GENERIC) {
+      tile_rows_pipe<LPR, NT, (PIPE > 0 ? PIPE : RSA_QG_BATCH)>(p.item_table, id, qf, dot);
     } else {
       tile_rows<LPR, GENERIC, COS, QU, NT>(p.item_table, D, id, p.query, qrow_lane, qf, dot, in2, qn2);
     }
@@ -1007,6 +1015,11 @@ static void launch_fwd2(const FwdParams& p, dim3 grid, dim3 block, hipStream_t s
     if (p.qgrad != nullptr) {     // training forward: query gradient accumulated from the rows in flight
       if (nt) hipLaunchKernelGGL((fused_fwd_kernel<LPR, GENERIC, COS, QU, true, true>), grid, block, 0, stream, p);
       else hipLaunchKernelGGL((fused_fwd_kernel<LPR, GENERIC, COS, QU, false, true>), grid, block, 0, stream, p);
+      return;
+    }
+    if (((p.numel + 63) >> 6) <= RSA_PIPE_MAX_TILES) {      // small / medium launch: the butterfly tile
+      if (nt) hipLaunchKernelGGL((fused_fwd_kernel<LPR, GENERIC, COS, QU, true, false, false, 8>), grid, block, 0, stream, p);
+      else hipLaunchKernelGGL((fused_fwd_kernel<LPR, GENERIC, COS, QU, false, false, false, 8>), grid, block, 0, stream, p);
       return;
     }
   }

@@ -13,7 +13,7 @@ item = torch.empty(N, d, device=dev).normal_(0, 0.02, generator=g)
 user = torch.empty(1_000_001, d, device=dev).normal_(0, 0.02, generator=g)
 uid = torch.randint(1, 1_000_001, (B,), device=dev, generator=g)
 pos = torch.randint(1, N, (B,), device=dev, generator=g)
-ps = ra.PopularSamplerModel(zipf_counts(N, 100_000_000)).to(dev)
+ps = (torch.load("/tmp/rsa_ps_1e7.pt", weights_only=False) if os.path.exists("/tmp/rsa_ps_1e7.pt") else ra.PopularSamplerModel(zipf_counts(N, 100_000_000))).to(dev)
 res = {}
 for name, kw in (('popular', dict(sampler=nat.SAMPLER_POPULAR, **ps.lookup_kwargs())), ('uniform', dict(sampler=nat.SAMPLER_UNIFORM)),
                  ('given', dict(neg_ids=torch.randint(1, N, (B, n), device=dev, generator=g)))):
