@@ -722,7 +722,7 @@ class BaseRetriever(torch.nn.Module):
                 loss = trainer.training_step(self._get_query_feat(batch), batch[self.fiid], batch[self.frating])
                 if optimizer is not None:
                     if tr['grad_clip_norm'] is not None:
-                        raise NotImplementedError('multi-GPU fit: grad_clip_norm needs a norm over all shards')
+                        self._clip_grad_norm_sharded(params, tr['grad_clip_norm'], dist)
                     optimizer.step()
                 losses.append(loss.detach().reshape(1))
             step_losses = torch.cat(losses)                     # this rank's shares of the global mean losses
@@ -747,6 +747,28 @@ class BaseRetriever(torch.nn.Module):
             self.load_state_dict(best_state)
             table.item_local = self.item_encoder.weight.data
         return best
+
+    def _clip_grad_norm_sharded(self, params, max_norm, dist):
+        """``torch.nn.utils.clip_grad_norm_`` (recommender.py training loop) over a model whose item table is split over the
+        ranks: the squared norm of this rank's row block is summed over the ranks, the replicated tower's gradients
+        (already summed, identical everywhere) count once; every rank scales by the same coefficient."""
+        block = self.item_encoder.weight
+        sq_block = torch.zeros((), device=block.device)
+        sq_rest = torch.zeros((), device=block.device)
+        for p in params:
+            if p.grad is None:
+                continue
+            if p is block:
+                sq_block = sq_block + p.grad.float().pow(2).sum()
+            else:
+                sq_rest = sq_rest + p.grad.float().pow(2).sum()
+        dist.all_reduce(sq_block)
+        total = (sq_block + sq_rest).sqrt()
+        coef = torch.clamp(max_norm / (total + 1e-6), max=1.0)
+        for p in params:
+            if p.grad is not None:
+                p.grad.mul_(coef)
+        return total
 
     def _make_optimizer(self, params):
         tr = self.config['train']
