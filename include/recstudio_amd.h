@@ -434,7 +434,9 @@ int rsa_topk_mask_history(const float* cand_val, const int64_t* cand_idx, int32_
 
 /* ---- Row-sharded item table (BASELINE.json configs[3]; no counterpart in the reference, whose
  * only multi-device mode re-broadcasts whole tables every step, utils/data_parallel.py:106-159).
- * Shard g owns item rows [g*rows_per_shard, (g+1)*rows_per_shard).  An "element" is one (query,
+ * Shard g owns item rows [g*rows_per_shard, (g+1)*rows_per_shard); with rows_per_shard == 0 the rows
+ * are INTERLEAVED instead: owner(id) = id % n_shards, local row = id / n_shards (every owner holds
+ * 1/n_shards of any id range, so ids ordered by popularity do not make a hot shard).  An "element" is one (query,
  * item) pair of the [n_queries, 1+num_neg] matrix whose column 0 is pos_ids and columns 1.. are
  * neg_ids.  Elements are counting-sorted by owner into contiguous per-owner segments and travel
  * as one packed key = (query_base + query) << 32 | local_row; the fp32 scores come back in the
@@ -486,7 +488,7 @@ typedef struct rsa_shard_route_args {
                                   own cursor by its own share of the launch's workgroups (one cursor per owner makes every
                                   workgroup queue up on one atomic address); n_slices * n_shards * n_banks <= 4096 */
   int32_t _pad0;
-  int64_t rows_per_shard;      /* owner(id) = min(id / rows_per_shard, G - 1) */
+  int64_t rows_per_shard;      /* owner(id) = min(id / rows_per_shard, G - 1); 0: interleaved, owner = id % G, row = id / G */
   int64_t query_base;          /* global index of query 0 (rank * n_queries): goes into the keys */
   int64_t capacity;            /* keys per (slice, owner, bank) segment */
   int64_t n_items;             /* catalog size: uniform ids are drawn from [1, n_items) */

@@ -54,17 +54,32 @@ struct RouteShape {
   const int64_t* neg_ids;
   int64_t n_queries;
   int n, G;
-  int64_t rows_per_shard;
+  int64_t rows_per_shard;    // 0: interleaved ownership (owner = id % G, row = id / G); by_rows then divides by G
   FastDiv by_width, by_rows;
 };
 
+// Owner and row inside the owner's table of item `id`.  Contiguous blocks: owner = id / rows_per_shard (clamped), row =
+// the remainder.  Interleaved (rows_per_shard == 0 at the boundary): owner = id % G, row = id / G -- whatever the ids'
+// popularity order, every owner gets 1/G of any id range.
+template <class DIV>
+__device__ __forceinline__ void owner_and_row(int64_t id, const DIV& by_rows, int64_t rows_per_shard, int G, int& g, int64_t& loc) {
+  const int64_t q = id <= 0 ? 0 : (int64_t)by_rows.div(id);
+  if (rows_per_shard == 0) {
+    g = id <= 0 ? 0 : (int)(id - q * G);
+    loc = q;
+  } else {
+    g = q >= G ? G - 1 : (int)q;
+    loc = id - (int64_t)g * rows_per_shard;
+    if (loc < 0) loc = 0;
+  }
+}
+
 // element e of the [n_queries, 1 + n] (positive, negatives) layout -> (id, query m, column c, owner g)
-__device__ __forceinline__ int64_t route_element(const RouteShape& sh, int64_t e, int64_t& m, int& c, int& g) {
+__device__ __forceinline__ int64_t route_element(const RouteShape& sh, int64_t e, int64_t& m, int& c, int& g, int64_t& loc) {
   m = (int64_t)sh.by_width.div((uint64_t)e);
   c = (int)(e - m * (sh.n + 1));
   const int64_t id = c == 0 ? sh.pos_ids[m] : sh.neg_ids[m * sh.n + (c - 1)];
-  const int64_t q = id < 0 ? 0 : (int64_t)sh.by_rows.div((uint64_t)id);
-  g = q >= sh.G ? sh.G - 1 : (int)q;
+  owner_and_row(id, sh.by_rows, sh.rows_per_shard, sh.G, g, loc);
   return id;
 }
 
@@ -117,7 +132,8 @@ __global__ __launch_bounds__(256) void shard_count_kernel(RouteShape sh, int32_t
       int64_t m;
       int c;
       g[k] = -1;
-      if (e < numel) route_element(sh, e, m, c, g[k]);
+      int64_t loc;
+      if (e < numel) route_element(sh, e, m, c, g[k], loc);
     }
 #pragma unroll
     for (int k = 0; k < ROUTE_EPT; ++k) wave_count<false>(h, g[k] >= 0, g[k], sh.G == 1);
@@ -147,8 +163,9 @@ __global__ __launch_bounds__(256) void shard_route_kernel(RouteShape sh, int64_t
     g[k] = -1;
     local[k] = 0;
     if (e < numel) {
-      const int64_t id = route_element(sh, e, m, c, g[k]);
-      local[k] = (uint32_t)(id - (int64_t)g[k] * sh.rows_per_shard);
+      int64_t loc;
+      route_element(sh, e, m, c, g[k], loc);
+      local[k] = (uint32_t)loc;
     }
   }
   __syncthreads();
@@ -331,12 +348,9 @@ __global__ __launch_bounds__(256) void shard_sample_route_kernel(const RouteV2 a
         const int64_t m = (int64_t)a.by_n.div((uint32_t)flat);
         el[r * 4 + c] = (int32_t)(flat + m + 1);               // = m * (n + 1) + 1 + (flat - m * n)
         int g = 0;
-        if (a.G > 1) {
-          const int64_t q = id < 0 ? 0 : (int64_t)a.by_rows.div((uint32_t)id);
-          g = q >= a.G ? a.G - 1 : (int)q;
-        }
-        const int64_t loc = id - (int64_t)g * a.rows_per_shard;
-        local[r * 4 + c] = (uint32_t)(loc < 0 ? 0 : loc);
+        int64_t loc = id < 0 ? 0 : id;
+        if (a.G > 1) owner_and_row(id, a.by_rows, a.rows_per_shard, a.G, g, loc);
+        local[r * 4 + c] = (uint32_t)loc;
         gl[r * 4 + c] = g << 16;
       }
     } else if (w - a.n_groups < a.n_queries) {
@@ -348,12 +362,9 @@ __global__ __launch_bounds__(256) void shard_sample_route_kernel(const RouteV2 a
       }
       el[r * 4] = (int32_t)(m * (a.n + 1));
       int g = 0;
-      if (a.G > 1) {
-        const int64_t q = id < 0 ? 0 : (int64_t)a.by_rows.div((uint32_t)id);
-        g = q >= a.G ? a.G - 1 : (int)q;
-      }
-      const int64_t loc = id - (int64_t)g * a.rows_per_shard;
-      local[r * 4] = (uint32_t)(loc < 0 ? 0 : loc);
+      int64_t loc = id < 0 ? 0 : id;
+      if (a.G > 1) owner_and_row(id, a.by_rows, a.rows_per_shard, a.G, g, loc);
+      local[r * 4] = (uint32_t)loc;
       gl[r * 4] = g << 16;
     }
   }
@@ -774,7 +785,7 @@ using namespace rsa;
 
 extern "C" int rsa_shard_count(const int64_t* pos_ids, const int64_t* neg_ids, int64_t n_queries, int32_t num_neg,
                                int64_t rows_per_shard, int32_t n_shards, int32_t* counts, rsa_stream_t stream) {
-  RSA_CHECK_ARG(n_queries >= 0 && num_neg >= 0 && rows_per_shard >= 1, "rsa_shard_count: bad sizes");
+  RSA_CHECK_ARG(n_queries >= 0 && num_neg >= 0 && rows_per_shard >= 0, "rsa_shard_count: bad sizes");
   RSA_CHECK_ARG(n_shards >= 1 && n_shards <= 64, "rsa_shard_count: n_shards must be in [1, 64]");
   RSA_CHECK_ARG(counts != nullptr, "rsa_shard_count: counts is null");
   hipError_t e = hipMemsetAsync(counts, 0, sizeof(int32_t) * n_shards, (hipStream_t)stream);
@@ -786,7 +797,7 @@ extern "C" int rsa_shard_count(const int64_t* pos_ids, const int64_t* neg_ids, i
   RSA_CHECK_ARG(pos_ids && (neg_ids || num_neg == 0), "rsa_shard_count: null ids");
   RSA_CHECK_ARG(n_queries * (num_neg + 1) < (1ll << 32), "rsa_shard_count: more than 2^32 elements");
   const RouteShape sh{pos_ids, neg_ids, n_queries, (int)num_neg, (int)n_shards, rows_per_shard,
-                      make_fastdiv((uint64_t)num_neg + 1), make_fastdiv((uint64_t)rows_per_shard)};
+                      make_fastdiv((uint64_t)num_neg + 1), make_fastdiv((uint64_t)(rows_per_shard ? rows_per_shard : n_shards))};
   int64_t count_blocks = (n_queries * (num_neg + 1) + ROUTE_CHUNK - 1) / ROUTE_CHUNK;
   if (count_blocks > 4096) count_blocks = 4096;
   hipLaunchKernelGGL(shard_count_kernel, dim3((unsigned)count_blocks), dim3(256), 0, (hipStream_t)stream, sh, counts);
@@ -797,7 +808,7 @@ extern "C" int rsa_shard_count(const int64_t* pos_ids, const int64_t* neg_ids, i
 extern "C" int rsa_shard_route(const int64_t* pos_ids, const int64_t* neg_ids, int64_t n_queries, int32_t num_neg,
                                int64_t rows_per_shard, int32_t n_shards, int64_t query_base, int32_t* cursor,
                                int64_t* keys, int64_t* positions, rsa_stream_t stream) {
-  RSA_CHECK_ARG(n_queries >= 0 && num_neg >= 0 && rows_per_shard >= 1 && rows_per_shard < (1ll << 32),
+  RSA_CHECK_ARG(n_queries >= 0 && num_neg >= 0 && rows_per_shard >= 0 && rows_per_shard < (1ll << 32),
                 "rsa_shard_route: bad sizes");
   RSA_CHECK_ARG(n_shards >= 1 && n_shards <= 64, "rsa_shard_route: n_shards must be in [1, 64]");
   RSA_CHECK_ARG(query_base >= 0 && query_base + n_queries < (1ll << 31), "rsa_shard_route: query index overflow");
@@ -807,7 +818,7 @@ extern "C" int rsa_shard_route(const int64_t* pos_ids, const int64_t* neg_ids, i
   const int64_t blocks = (numel + ROUTE_CHUNK - 1) / ROUTE_CHUNK;
   RSA_CHECK_ARG(numel < (1ll << 31), "rsa_shard_route: more than 2^31 elements");
   const RouteShape sh{pos_ids, neg_ids, n_queries, (int)num_neg, (int)n_shards, rows_per_shard,
-                      make_fastdiv((uint64_t)num_neg + 1), make_fastdiv((uint64_t)rows_per_shard)};
+                      make_fastdiv((uint64_t)num_neg + 1), make_fastdiv((uint64_t)(rows_per_shard ? rows_per_shard : n_shards))};
   hipLaunchKernelGGL(shard_route_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, sh, query_base, cursor, keys,
                      positions);
   RSA_CHECK_LAUNCH("rsa_shard_route");
@@ -852,7 +863,7 @@ extern "C" int64_t rsa_shard_segment_stride(int64_t capacity) { return capacity 
 
 extern "C" int rsa_shard_sample_route(const rsa_shard_route_args* a, rsa_stream_t stream) {
   RSA_CHECK_ARG(a != nullptr, "rsa_shard_sample_route: args is null");
-  RSA_CHECK_ARG(a->n_queries >= 0 && a->num_neg >= 0 && a->rows_per_shard >= 1 && a->rows_per_shard < (1ll << 32),
+  RSA_CHECK_ARG(a->n_queries >= 0 && a->num_neg >= 0 && a->rows_per_shard >= 0 && a->rows_per_shard < (1ll << 32),
                 "rsa_shard_sample_route: bad sizes");
   RSA_CHECK_ARG(a->n_shards >= 1 && a->n_shards <= 64, "rsa_shard_sample_route: n_shards must be in [1, 64]");
   RSA_CHECK_ARG(a->n_slices >= 1 && a->n_banks >= 1 && (int64_t)a->n_slices * a->n_shards * a->n_banks <= 4096,
@@ -945,7 +956,7 @@ extern "C" int rsa_shard_sample_route(const rsa_shard_route_args* a, rsa_stream_
   r.n_groups = n_neg > 0 ? (int64_t)((k_hi - k_lo + 1) * T) : 0;
   RSA_CHECK_ARG(r.n_groups + a->n_queries < (1ll << 32), "rsa_shard_sample_route: too many work items");
   r.by_width = make_div32((uint64_t)a->num_neg + 1);
-  r.by_rows = make_div32((uint64_t)a->rows_per_shard);
+  r.by_rows = make_div32((uint64_t)(a->rows_per_shard ? a->rows_per_shard : a->n_shards));    // 0: interleaved rows
   r.by_n = make_div32((uint64_t)(a->num_neg > 0 ? a->num_neg : 1));
   r.by_gt = make_div32(T);
   r.by_range = make_div32((uint64_t)(a->n_items - 1));        // 32-bit draws only (ranges below 2^28)

@@ -29,6 +29,8 @@ def main(argv=None):
     ap.add_argument('--steps', type=int, default=50)
     ap.add_argument('--lr', type=float, default=0.05)
     ap.add_argument('--seed', type=int, default=2022)
+    ap.add_argument('--layout', choices=('block', 'interleaved'), default='block',
+                    help="row ownership: contiguous blocks, or rows r, r + G, ... (no hot shard when ids are ordered by popularity)")
     args = ap.parse_args(argv)
 
     import torch.distributed as dist
@@ -44,10 +46,9 @@ def main(argv=None):
         import recstudio_amd as ra
         from recstudio_amd.shard import RowShardPlan, ShardedItemTable, ShardedRetriever
         ra._native.lib()
-        plan = RowShardPlan(args.items, world)
-        lo, hi = plan.bounds(rank)
+        plan = RowShardPlan(args.items, world, layout=args.layout)
         g = torch.Generator(device=dev).manual_seed(args.seed + 17 * rank)
-        item_local = torch.empty(hi - lo, args.dim, device=dev).normal_(0, 0.02, generator=g)   # init.py:18-27
+        item_local = torch.empty(plan.n_local(rank), args.dim, device=dev).normal_(0, 0.02, generator=g)   # init.py:18-27
         if rank == 0:
             item_local[0] = 0                                                                 # padding row
         # the user tower is replicated: identical initial weights on every rank

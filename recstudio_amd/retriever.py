@@ -53,7 +53,7 @@ def default_config():
                   'num_threads': 10, 'sampling_method': 'none', 'sampler': 'uniform', 'negative_count': 0,
                   'excluding_hist': False, 'scheduler': None, 'seed': 2022, 'weight_decay': 0.0,
                   'tensorboard_path': None, 'sparse_grad': False, 'device_loader': True, 'fused_optimizer': None,
-                  'shard_slices': 1},
+                  'shard_slices': 1, 'shard_layout': 'block'},
         'eval': {'batch_size': 128, 'cutoff': [5, 10, 20], 'val_metrics': ['ndcg', 'recall'], 'val_n_epoch': 1,
                  'test_metrics': ['ndcg', 'recall', 'precision', 'map', 'mrr', 'hit'], 'topk': 100,
                  'save_path': './saved/'},
@@ -604,7 +604,8 @@ class BaseRetriever(torch.nn.Module):
         return None
 
     def _setup_shard(self, train_data, dist, backend=None, device=None):
-        """Row-shard the item table over the ranks of ``dist``: rank r keeps rows [lo, hi) of ``item_encoder.weight`` (and,
+        """Row-shard the item table over the ranks of ``dist``: rank r keeps rows [lo, hi) -- with ``train.shard_layout:
+        'interleaved'`` rows r, r + G, ... -- of ``item_encoder.weight`` (and,
         through the optimizer, of its Adam state) as an ``nn.Embedding`` of its own block; sampler and query tower are
         replicated.  Every rank initialises the full model from the same seed first (recommender.py:34-35), so the
         shards are the rows of the very table a single process would train."""
@@ -622,11 +623,11 @@ class BaseRetriever(torch.nn.Module):
             device = torch.device('cuda', int(os.environ.get('LOCAL_RANK', torch.cuda.current_device())))
         device = torch.device(device)
         n_items, d = self.item_encoder.weight.shape
-        plan = shard.RowShardPlan(n_items, world)
-        lo, hi = plan.bounds(rank)
-        block = torch.nn.Embedding(hi - lo, d, padding_idx=0 if rank == 0 else None,
-                                   _weight=self.item_encoder.weight.detach()[lo:hi].clone())
-        self.item_encoder = block                      # the full table is dropped: this rank owns rows [lo, hi)
+        plan = shard.RowShardPlan(n_items, world, layout=self.config['train'].get('shard_layout', 'block'))
+        block = torch.nn.Embedding(plan.n_local(rank), d, padding_idx=0 if rank == 0 else None,
+                                   _weight=plan.take(self.item_encoder.weight.detach(), rank).clone())
+        self.item_encoder = block                      # the full table is dropped: this rank keeps its rows only
+        lo, hi = (None, None) if plan.interleaved else plan.bounds(rank)
         if hasattr(self, 'item_vector'):
             del self.item_vector
         self.to(device)
@@ -634,7 +635,7 @@ class BaseRetriever(torch.nn.Module):
                                        sample_seed=self.config['train']['seed'] or 2022,
                                        chunks=int(self.config['train'].get('shard_slices', 1)))
         self._shard = {'table': table, 'dist': dist, 'rank': rank, 'world': world, 'lo': lo, 'hi': hi, 'device': device,
-                       'n_items': n_items}
+                       'n_items': n_items, 'plan': plan}
         return self._shard
 
     def _topk_sharded(self, query, k, user_h, return_query):

@@ -1,7 +1,8 @@
 """Row-sharded item table over the GPUs of one node (BASELINE.json configs[3]).
 
 One process per GPU (``torch.distributed``; backend "nccl" is RCCL on ROCm).  Rank r owns item
-rows [r*rows_per_shard, (r+1)*rows_per_shard) and B queries per step.  Per step (``exchange='fixed'``, the default):
+rows [r*rows_per_shard, (r+1)*rows_per_shard) -- or, ``RowShardPlan(layout='interleaved')``, rows r, r + G, r + 2G, ... --
+and B queries per step.  Per step (``exchange='fixed'``, the default):
 
   1. all_gather of the [B, d] query block                                      (RCCL all-gather, own communicator)
   2. ONE launch draws the negatives of the own queries (in-kernel Philox / inverse CDF, one job-wide stream) and
@@ -49,18 +50,66 @@ from ._native import ptr
 
 
 class RowShardPlan:
-    """Contiguous row blocks: owner(id) = id // rows_per_shard."""
+    """Which rank owns which row of the [n_items, d] table.
 
-    def __init__(self, n_items, world):
-        self.n_items, self.world = int(n_items), int(world)
+    ``layout='block'`` (default): contiguous row blocks, owner(id) = id // rows_per_shard.
+    ``layout='interleaved'``: owner(id) = id % world, row inside the owner's table = id // world -- every rank holds
+    1/world of ANY id range, so a catalog whose ids are ordered by popularity (the hot head of a Zipf law in one block)
+    does not make a hot shard whose receive count would set every rank's fixed-capacity segments (the capacity is the
+    maximum over the owners)."""
+
+    def __init__(self, n_items, world, layout='block'):
+        if layout not in ('block', 'interleaved'):
+            raise ValueError("layout must be 'block' or 'interleaved'")
+        self.n_items, self.world, self.layout = int(n_items), int(world), layout
+        self.interleaved = layout == 'interleaved'
         self.rows_per_shard = (self.n_items + self.world - 1) // self.world
+        self.rows_arg = 0 if self.interleaved else self.rows_per_shard      # the C ABI's rows_per_shard (0: interleaved)
 
     def bounds(self, rank):
+        """[lo, hi) of a block plan's rank."""
+        if self.interleaved:
+            raise ValueError('an interleaved plan has no row bounds: use n_local / take / global_ids')
         lo = min(self.n_items, rank * self.rows_per_shard)
         return lo, min(self.n_items, lo + self.rows_per_shard)
 
+    def n_local(self, rank):
+        if self.interleaved:
+            return max(0, (self.n_items - rank + self.world - 1) // self.world)
+        lo, hi = self.bounds(rank)
+        return hi - lo
+
+    def take(self, full, rank):
+        """Rank ``rank``'s rows of a full [n_items, ...] tensor (a view)."""
+        if self.interleaved:
+            return full[rank::self.world]
+        lo, hi = self.bounds(rank)
+        return full[lo:hi]
+
+    def global_ids(self, rank, local):
+        """Item ids of rows ``local`` (tensor or int) of rank ``rank``'s table."""
+        return local * self.world + rank if self.interleaved else local + self.bounds(rank)[0]
+
     def owner(self, ids):
+        if self.interleaved:
+            return torch.clamp(ids, min=0) % self.world
         return torch.clamp(ids // self.rows_per_shard, 0, self.world - 1)
+
+    def local(self, ids):
+        """Row of ``ids`` inside their owners' tables."""
+        if self.interleaved:
+            return torch.clamp(ids, min=0) // self.world
+        return torch.clamp(ids - self.owner(ids) * self.rows_per_shard, min=0)
+
+    def assemble(self, parts):
+        """The full table from the ranks' tables (rank order)."""
+        if not self.interleaved:
+            return torch.cat(list(parts))
+        parts = list(parts)
+        full = parts[0].new_empty((self.n_items,) + tuple(parts[0].shape[1:]))
+        for r, t in enumerate(parts):
+            full[r::self.world] = t
+        return full
 
 
 class HipBackend:
@@ -119,7 +168,7 @@ class HipBackend:
         a = nat.ShardRouteArgs()
         kind = spec['kind'] if spec is not None else nat.SAMPLER_GIVEN
         a.pos_ids, a.n_queries, a.num_neg, a.sampler = ptr(ops._need(pos, torch.int64, 'pos')), B, int(n), int(kind)
-        a.n_slices, a.n_shards, a.n_banks, a.rows_per_shard = int(chunks), G, int(banks), plan.rows_per_shard
+        a.n_slices, a.n_shards, a.n_banks, a.rows_per_shard = int(chunks), G, int(banks), plan.rows_arg
         a.query_base, a.capacity = rank * B, int(capacity)
         a.n_items = spec['n_items'] if spec is not None else plan.n_items
         out = {}
@@ -251,7 +300,7 @@ class HipBackend:
     def count(self, pos, neg, plan):
         counts = torch.empty(plan.world, dtype=torch.int32, device=pos.device)
         n = neg.shape[1]
-        nat.check(nat.lib().rsa_shard_count(ptr(pos), ptr(neg), pos.numel(), n, plan.rows_per_shard, plan.world,
+        nat.check(nat.lib().rsa_shard_count(ptr(pos), ptr(neg), pos.numel(), n, plan.rows_arg, plan.world,
                                             ptr(counts), ops._stream()), 'rsa_shard_count')
         return counts
 
@@ -261,7 +310,7 @@ class HipBackend:
         keys = torch.empty(numel, dtype=torch.int64, device=pos.device)
         positions = torch.empty(numel, dtype=torch.int64, device=pos.device)
         cursor = starts.to(device=pos.device, dtype=torch.int32).clone()
-        nat.check(nat.lib().rsa_shard_route(ptr(pos), ptr(neg), B, n, plan.rows_per_shard, plan.world, int(query_base),
+        nat.check(nat.lib().rsa_shard_route(ptr(pos), ptr(neg), B, n, plan.rows_arg, plan.world, int(query_base),
                                             ptr(cursor), ptr(keys), ptr(positions), ops._stream()), 'rsa_shard_route')
         return keys, positions
 
@@ -380,9 +429,9 @@ class ShardedItemTable:
         # order on one stream, so on the main group the key / score exchanges would queue behind the (at n = 64)
         # much larger gather instead of overlapping with it
         self.gather_group = _gather_group(dist) if (group is None and plan.world > 1) else group
-        lo, hi = plan.bounds(rank)
-        if item_local.shape[0] != hi - lo:
-            raise ValueError(f'rank {rank} must hold rows [{lo}, {hi}) of the item table, got {item_local.shape[0]}')
+        if item_local.shape[0] != plan.n_local(rank):
+            raise ValueError(f'rank {rank} must hold its {plan.n_local(rank)} rows of the item table ({plan.layout} layout), '
+                             f'got {item_local.shape[0]}')
 
     # -- collectives (RCCL through torch.distributed) -------------------------------------------
     # With ONE rank every collective of the step is the identity (the all-gather of one block, an all-to-all with
@@ -694,9 +743,8 @@ class ShardedItemTable:
         Per shard: one MFMA pass over the local rows for all G*B gathered queries; across shards only
         (8k + 4) bytes per query per shard travel."""
         B, G = q.shape[0], self.plan.world
-        lo, hi = self.plan.bounds(self.rank)
         has_pad = self.rank == 0
-        real_rows = (hi - lo) - (1 if has_pad else 0)
+        real_rows = self.plan.n_local(self.rank) - (1 if has_pad else 0)
         q_all = self._all_gather_rows(q)
         k_local = min(int(k), real_rows)
         if real_rows <= 0 or (not want_lse and k_local == 0):
@@ -713,7 +761,8 @@ class ShardedItemTable:
         ids = torch.zeros(G * B, k, dtype=torch.int64, device=q.device)
         if k_local:
             vals[:, :k_local] = tv
-            ids[:, :k_local] = ti + (lo if has_pad else lo - 1)          # local 1-based row number -> global id
+            # ti: 1-based number among the scored rows (the padding row, local row 0 of rank 0, is skipped) -> global id
+            ids[:, :k_local] = self.plan.global_ids(self.rank, ti if has_pad else ti - 1)
         vals = self._exchange_partials(vals, B).transpose(0, 1).reshape(B, G * k)
         ids = self._exchange_partials(ids, B).transpose(0, 1).reshape(B, G * k)
         tv, ti = self.backend.merge_topk(vals, ids, k)

@@ -16,11 +16,12 @@ pytestmark = pytest.mark.gpu
 DEV = 'cuda'
 
 
+@pytest.mark.parametrize('layout', ['block', 'interleaved'])
 @pytest.mark.parametrize('world,B,n', [(4, 33, 7), (8, 1000, 64), (2, 5, 1), (3, 17, 100)])
-def test_route_kernels_match_checker(world, B, n):
+def test_route_kernels_match_checker(world, B, n, layout):
     from recstudio_amd.shard import HipBackend, RowShardPlan
     n_items = 10007
-    plan = RowShardPlan(n_items, world)
+    plan = RowShardPlan(n_items, world, layout=layout)
     g = torch.Generator().manual_seed(B + n)
     pos = torch.randint(0, n_items, (B,), generator=g)
     neg = torch.randint(0, n_items, (B, n), generator=g)
@@ -48,7 +49,8 @@ def test_route_kernels_match_checker(world, B, n):
                                                              (3, 16, 100, 4, 0.5, 1), (1, 64, 64, 1, 0.7, 1),
                                                              (8, 1000, 64, 1, 1.3, 8), (2, 700, 128, 2, 0.6, 4), (1, 300, 64, 1, 4.0, 8),
                                                              (2, 41, 200, 1, 0.8, 2), (3, 9, 600, 1, 1.5, 1)])
-def test_sample_route_kernel_matches_checker(world, B, n, chunks, cap_frac, banks):
+@pytest.mark.parametrize('layout', ['block', 'interleaved'])
+def test_sample_route_kernel_matches_checker(world, B, n, chunks, cap_frac, banks, layout):
     """rsa_shard_sample_route on given ids: every (slice, owner) segment holds the same multiset of keys as the
     checker's (order inside a segment is free), its header says how many are live and how many elements the rank
     dropped in the whole step; slot_of points every kept element at its own key and is -1 for a dropped one; the exact
@@ -60,7 +62,7 @@ def test_sample_route_kernel_matches_checker(world, B, n, chunks, cap_frac, bank
     from recstudio_amd._native import ptr
     import recstudio_amd as ra
     n_items, rank = 10007, 1 if world > 1 else 0
-    plan = RowShardPlan(n_items, world)
+    plan = RowShardPlan(n_items, world, layout=layout)
     g = torch.Generator().manual_seed(B + n)
     pos = torch.randint(0, n_items, (B,), generator=g)
     neg = torch.randint(0, n_items, (B, n), generator=g)
@@ -87,7 +89,7 @@ def test_sample_route_kernel_matches_checker(world, B, n, chunks, cap_frac, bank
     # every kept element points at its own key, inside a segment of its owner, below that segment's live count
     ids_flat = torch.cat([pos.view(-1, 1), neg], 1).reshape(-1)
     m = torch.arange(B).repeat_interleave(n + 1)
-    want_key = ((rank * B + m) << 32) | (ids_flat - plan.owner(ids_flat) * plan.rows_per_shard)
+    want_key = ((rank * B + m) << 32) | plan.local(ids_flat)
     assert torch.equal(r['send'].cpu()[slot_of[kept]], want_key[kept])
     seg_of, within = slot_of[kept] // stride, slot_of[kept] % stride
     assert torch.equal((seg_of // banks) % world, plan.owner(ids_flat)[kept])
@@ -148,6 +150,29 @@ def test_sample_route_kernel_matches_checker(world, B, n, chunks, cap_frac, bank
         assert not got['row_loss'].cpu()[gone].any() and not got['dneg'].cpu()[gone].any()
 
 
+def test_interleaved_rows_have_no_hot_shard_under_popularity_ordered_ids():
+    """A Zipf catalog whose ids are in popularity order (id 1 the hottest): with contiguous blocks the owner of the head
+    receives several times the mean -- and the fixed capacity is the maximum over the owners --, with interleaved rows
+    every owner receives the mean +- 3 % (sampling noise of 526 k elements).  Same draw (the in-kernel popularity sampler), same counting kernel."""
+    import recstudio_amd as ra
+    from recstudio_amd.shard import HipBackend, RowShardPlan
+    N, world, B, n = 1_000_001, 8, 2048, 256
+    counts = torch.zeros(N)
+    counts[1:] = (1e9 / (torch.arange(1, N, dtype=torch.float64) + 1000.0)).float()     # shifted Zipf: no single item dominates
+    ps = ra.PopularSamplerModel(counts).to(DEV)
+    hb = HipBackend()
+    spec = hb.sampler_spec(ps)
+    pos = torch.multinomial(counts, B, replacement=True).to(DEV)
+    ratio = {}
+    for layout in ('block', 'interleaved'):
+        plan = RowShardPlan(N, world, layout=layout)
+        gen = torch.Generator(device=DEV).manual_seed(9)
+        c = hb.sample_route(hb.new_state(DEV), plan, 0, pos, n, 1, 0, spec, gen, count_only=True).cpu().double()
+        assert int(c.sum()) == B * (n + 1)
+        ratio[layout] = float(c.max() / c.mean())
+    assert ratio['block'] > 3.0 and ratio['interleaved'] < 1.03, ratio
+
+
 def test_sorted_scatter_drops_negative_ids():
     """rsa_scatter_rows_sorted with ids < 0 (empty slots of the fixed-capacity exchange): nothing read or written for
     them -- the rest equals the scatter of the live elements alone, also when the empty slots are a long run."""
@@ -195,7 +220,7 @@ def _check_pipelined_equals_whole(ra, ShardedItemTable, make_table, user, uid, p
         piped.check_overflow()
 
 
-def _two_rank_worker(rank, world, port, backend, result_dir):
+def _two_rank_worker(rank, world, port, backend, result_dir, layout='block'):
     import torch.distributed as dist
     import recstudio_amd as ra
     from recstudio_amd.shard import RowShardPlan, ShardedItemTable, ShardedRetriever
@@ -228,11 +253,10 @@ def _two_rank_worker(rank, world, port, backend, result_dir):
         gr = torch.Generator().manual_seed(50 + rank)
         uid = torch.randint(1, U, (B,), generator=gr).to(dev)
         pos = torch.randint(1, N, (B,), generator=gr).to(dev)
-        plan = RowShardPlan(N, world)
-        lo, hi = plan.bounds(rank)
+        plan = RowShardPlan(N, world, layout=layout)
         item_d = item.to(dev)
         for si, sampler in enumerate((ra.UniformSampler(N), ra.PopularSamplerModel(counts).to(dev))):
-            table = ShardedItemTable(item_d[lo:hi].contiguous(), plan, rank, comm, sample_seed=17 + si)
+            table = ShardedItemTable(plan.take(item_d, rank).contiguous(), plan, rank, comm, sample_seed=17 + si)
             for step in range(3):                       # step 0: exact split + calibration; 1, 2: fixed capacity
                 out = table.sample_and_score(user, uid, pos, n, sampler, keep_route=True)
                 assert 'send_counts' not in out['route'] and (B, n, 1) in table._cap      # fixed exchange from the first step on
@@ -249,22 +273,22 @@ def _two_rank_worker(rank, world, port, backend, result_dir):
                 assert torch.equal(torch.cat(blocks), one.cpu())
                 # gradient exchange == the unsharded backward kernels on the full table
                 loss, dpos, dneg, _ = ra.ops.pairwise_loss(ra._native.LOSS_BPR, out['pos_score'], out['neg_score'])
-                ig = torch.zeros(hi - lo, d, device=dev)
+                ig = torch.zeros(plan.n_local(rank), d, device=dev)
                 qg = table.backward(out['route'], dpos, dneg, ig)
                 ig2, _, qg2 = ra.ops.fused_backward(item_d, user, ids, dneg, query_index=uid, pos_ids=pos, dpos=dpos)
                 np.testing.assert_allclose(qg.cpu(), qg2.cpu(), rtol=2e-4, atol=1e-8)
                 total = sum_cpu(ig2)                     # this rank's contribution to every row, summed over the ranks
-                np.testing.assert_allclose(ig.cpu(), total[lo:hi], rtol=2e-4, atol=1e-8)
+                np.testing.assert_allclose(ig.cpu(), plan.take(total, rank), rtol=2e-4, atol=1e-8)
             table.check_overflow()
         # the step cut into query slices with asynchronously issued exchanges
         _check_pipelined_equals_whole(ra, ShardedItemTable,
-                                      lambda chunks: ShardedItemTable(item_d[lo:hi].contiguous(), plan, rank, comm,
+                                      lambda chunks: ShardedItemTable(plan.take(item_d, rank).contiguous(), plan, rank, comm,
                                                                       sample_seed=5, chunks=chunks),
                                       user, uid[:256].contiguous(), pos[:256].contiguous(), n, ra.UniformSampler(N),
-                                      hi - lo, d, dev)
+                                      plan.n_local(rank), d, dev)
         # the sharded full-catalog pass
         q = torch.randn(70, d, generator=gr).to(dev) * 0.2
-        table = ShardedItemTable(item_d[lo:hi].contiguous(), plan, rank, comm)
+        table = ShardedItemTable(plan.take(item_d, rank).contiguous(), plan, rank, comm)
         lse, tv, ti = table.full_lse_topk(q, 20)
         _, wl, wv, wi = ra.ops.fullscore(item_d, q, want_lse=True, k=20)
         assert torch.equal(ti, wi)
@@ -274,7 +298,7 @@ def _two_rank_worker(rank, world, port, backend, result_dir):
         tower = torch.nn.Embedding(U, d).to(dev)
         with torch.no_grad():
             tower.weight.copy_(user)
-        tbl = ShardedItemTable(item_d[lo:hi].clone(), plan, rank, comm)
+        tbl = ShardedItemTable(plan.take(item_d, rank).contiguous().clone(), plan, rank, comm)
         trainer = ShardedRetriever(tbl, tower, ra.UniformSampler(N), ra.BPRLoss(), 64, item_sgd_lr=0.5, sparse_query_rows=True)
         assert trainer._fused_loss_kind() == 'bpr'           # loss + routed-order gradient inside the home kernel
         l0 = trainer.training_step(uid, pos)
@@ -290,7 +314,7 @@ def _two_rank_worker(rank, world, port, backend, result_dir):
         tower2 = torch.nn.Embedding(U, d).to(dev)
         with torch.no_grad():
             tower2.weight.copy_(user)
-        tbl2 = ShardedItemTable(item_d[lo:hi].clone(), plan, rank, comm)
+        tbl2 = ShardedItemTable(plan.take(item_d, rank).contiguous().clone(), plan, rank, comm)
         trainer2 = ShardedRetriever(tbl2, tower2, ra.UniformSampler(N), ra.BPRLoss(), 64, item_sgd_lr=0.5, query_sgd_lr=0.25)
         trainer2.training_step(uid, pos)
         np.testing.assert_allclose(tower2.weight.detach().cpu(), (user - 0.25 * trainer.query_grad_dense()).cpu(),
@@ -302,11 +326,13 @@ def _two_rank_worker(rank, world, port, backend, result_dir):
         dist.destroy_process_group()
 
 
-def test_two_ranks_on_one_gpu_hip_backend(tmp_path):
+@pytest.mark.parametrize('layout', ['block', 'interleaved'])
+def test_two_ranks_on_one_gpu_hip_backend(tmp_path, layout):
     """World size 2 with the HIP backend on the single test GPU (collectives staged over gloo): forward with exact and
-    fixed-capacity exchange, G-invariant negatives, gradient exchange, sharded full-catalog pass, training step."""
+    fixed-capacity exchange, G-invariant negatives, gradient exchange, sharded full-catalog pass, training step -- for
+    contiguous row blocks and for interleaved rows (RowShardPlan(layout=...))."""
     import torch.multiprocessing as mp
-    mp.spawn(_two_rank_worker, args=(2, _free_port(), 'gloo', str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_two_rank_worker, args=(2, _free_port(), 'gloo', str(tmp_path), layout), nprocs=2, join=True)
     assert all(os.path.exists(tmp_path / f'ok{r}') for r in range(2))
 
 
@@ -567,7 +593,7 @@ def test_world1_rccl_overflow_step_is_harmless():
         dist.destroy_process_group()
 
 
-def _fit_gpu_worker(rank, world, port, result_dir):
+def _fit_gpu_worker(rank, world, port, result_dir, layout='block'):
     import torch.distributed as dist
     import recstudio_amd as ra
     from recstudio_amd.dataset import TripletDataset
@@ -578,7 +604,7 @@ def _fit_gpu_worker(rank, world, port, result_dir):
     try:
         g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'data_ml100k.npz'))
         conf = {'train': {'epochs': 2, 'batch_size': 2048 // world, 'negative_count': 64, 'seed': 2022, 'learning_rate': 0.01,
-                          'early_stop_patience': 100},
+                          'early_stop_patience': 100, 'shard_layout': layout},
                 'eval': {'batch_size': 128 // world, 'cutoff': [10], 'val_metrics': ['ndcg', 'recall'], 'topk': 50,
                          'test_metrics': ['ndcg', 'recall']},
                 'model': {'embed_dim': 64}}
@@ -616,6 +642,17 @@ def test_fit_two_staged_ranks_equals_one_rank_hip(tmp_path):
     items = torch.cat([two[0]['item'], two[1]['item']])
     np.testing.assert_allclose(items.numpy(), one['item'].numpy(), rtol=1e-3, atol=1e-5)
     assert one['val']['ndcg@10'] > 0.01 and not items[0].any()
+    # train.shard_layout 'interleaved': rank r trains rows r, r + 2, ... of the same table
+    os.makedirs(tmp_path / 'il')
+    mp.spawn(_fit_gpu_worker, args=(2, _free_port(), str(tmp_path / 'il'), 'interleaved'), nprocs=2, join=True)
+    il = [torch.load(tmp_path / 'il' / f'w2r{r}.pt', weights_only=False) for r in range(2)]
+    for t in il:
+        np.testing.assert_allclose(t['losses'].numpy(), one['losses'].numpy(), rtol=2e-5, atol=1e-6)
+        for k in ('ndcg@10', 'recall@10'):
+            assert abs(t['val'][k] - one['val'][k]) < 1e-4 and abs(t['test'][k] - one['test'][k]) < 1e-4
+    items = torch.empty_like(one['item'])
+    items[0::2], items[1::2] = il[0]['item'], il[1]['item']
+    np.testing.assert_allclose(items.numpy(), one['item'].numpy(), rtol=1e-3, atol=1e-5)
 
 
 @pytest.mark.parametrize('d', [32, 128])

@@ -85,7 +85,7 @@ class CheckerBackend:
         stride = capacity + self.HDR
         send = torch.full((C * G * stride,), -7, dtype=torch.int64)           # slack: never read by a consumer
         slot_of = torch.full((B * (n + 1),), -1, dtype=torch.int32)
-        key = ((rank * B + m) << 32) | (ids - owner * plan.rows_per_shard)
+        key = ((rank * B + m) << 32) | plan.local(ids)
         dropped = 0
         for seg in range(C * G):
             sel = torch.nonzero(sl * G + owner == seg).flatten()
@@ -182,7 +182,7 @@ class CheckerBackend:
         order = torch.argsort(owner, stable=True)
         m = torch.arange(B).repeat_interleave(n + 1)
         c = torch.arange(n + 1).repeat(B)
-        key = ((query_base + m) << 32) | (ids - owner * plan.rows_per_shard)
+        key = ((query_base + m) << 32) | plan.local(ids)
         position = torch.where(c == 0, m, B + m * n + (c - 1))
         return key[order], position[order]
 
@@ -246,7 +246,7 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, n_items, d, B, n, result_dir):
+def _worker(rank, world, port, n_items, d, B, n, result_dir, layout='block'):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
@@ -256,9 +256,8 @@ def _worker(rank, world, port, n_items, d, B, n, result_dir):
         item = torch.randn(n_items, d, generator=g)
         item[0] = 0
         user = torch.randn(50, d, generator=g)
-        plan = RowShardPlan(n_items, world)
-        lo, hi = plan.bounds(rank)
-        table = ShardedItemTable(item[lo:hi].clone(), plan, rank, dist, backend=CheckerBackend())
+        plan = RowShardPlan(n_items, world, layout=layout)
+        table = ShardedItemTable(plan.take(item, rank).clone(), plan, rank, dist, backend=CheckerBackend())
         gr = torch.Generator().manual_seed(100 + rank)
         uid = torch.randint(1, 50, (B,), generator=gr)
         pos = torch.randint(1, n_items, (B,), generator=gr)
@@ -290,7 +289,7 @@ def _worker(rank, world, port, n_items, d, B, n, result_dir):
         assert torch.equal(torch.cat(blocks2), ids2)                        # ... in lock-step with a single process
         gg = torch.Generator().manual_seed(500 + rank)
         dpos, dneg = torch.randn(B, generator=gg), torch.randn(B, n, generator=gg)
-        item_grad_local = torch.zeros(hi - lo, d)
+        item_grad_local = torch.zeros(plan.n_local(rank), d)
         qgrad = table.backward(out['route'], dpos, dneg, item_grad_local)
         neg_ids = out['neg_ids']
         want_q = dpos.unsqueeze(1) * item[pos] + (dneg.unsqueeze(-1) * item[neg_ids]).sum(1)
@@ -302,7 +301,7 @@ def _worker(rank, world, port, n_items, d, B, n, result_dir):
         contrib.index_add_(0, neg_ids.reshape(-1), (dneg.unsqueeze(-1) * qv.unsqueeze(1)).reshape(-1, d))
         dist.all_reduce(contrib)                        # what every rank contributed, anywhere
         contrib[0] = 0                                  # padding row: no gradient
-        np.testing.assert_allclose(item_grad_local.numpy(), contrib[lo:hi].numpy(), rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(item_grad_local.numpy(), plan.take(contrib, rank).numpy(), rtol=1e-5, atol=1e-5)
         # skewed ids: everything owned by the last rank, and an empty segment for rank 0
         neg2 = torch.full((B, n), n_items - 1, dtype=torch.int64)
         pos2 = torch.full((B,), n_items - 2, dtype=torch.int64)
@@ -312,12 +311,12 @@ def _worker(rank, world, port, n_items, d, B, n, result_dir):
         np.testing.assert_allclose(s2.numpy(), w2n.numpy(), rtol=1e-6, atol=1e-6)
         table.check_overflow()                                                # nothing was dropped so far
         # the exact (variable-split) exchange gives the same scores
-        exact = ShardedItemTable(item[lo:hi].clone(), plan, rank, dist, backend=CheckerBackend(), exchange='exact')
+        exact = ShardedItemTable(plan.take(item, rank).clone(), plan, rank, dist, backend=CheckerBackend(), exchange='exact')
         p3, s3 = exact.score_ids(user[uid], pos2, neg2)
         assert torch.equal(p3, p2) and torch.equal(s3, s2)
         # an id distribution that outgrows a tight capacity is DETECTED: calibrate on uniform ids without slack, then
         # send everything to one owner
-        tight = ShardedItemTable(item[lo:hi].clone(), plan, rank, dist, backend=CheckerBackend(), slack=1.0, margin=0)
+        tight = ShardedItemTable(plan.take(item, rank).clone(), plan, rank, dist, backend=CheckerBackend(), slack=1.0, margin=0)
         negu = torch.randint(1, n_items, (B, n), generator=gr)
         tight.score_ids(user[uid], pos, negu)
         assert B < 100 or tight._cap[(B, n, 1)] < B * (n + 1)
@@ -342,7 +341,7 @@ def _worker(rank, world, port, n_items, d, B, n, result_dir):
         dist.destroy_process_group()
 
 
-def _chunk_worker(rank, world, port, n_items, d, B, n, chunks, result_dir):
+def _chunk_worker(rank, world, port, n_items, d, B, n, chunks, result_dir, layout='block'):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
@@ -352,14 +351,13 @@ def _chunk_worker(rank, world, port, n_items, d, B, n, chunks, result_dir):
         item = torch.randn(n_items, d, generator=g)
         item[0] = 0
         user = torch.randn(50, d, generator=g)
-        plan = RowShardPlan(n_items, world)
-        lo, hi = plan.bounds(rank)
+        plan = RowShardPlan(n_items, world, layout=layout)
         gr = torch.Generator().manual_seed(100 + rank)
         uid = torch.randint(1, 50, (B,), generator=gr)
         pos = torch.randint(1, n_items, (B,), generator=gr)
         sampler = oracle.UniformSampler(n_items)
-        whole = ShardedItemTable(item[lo:hi].clone(), plan, rank, dist, backend=CheckerBackend())
-        piped = ShardedItemTable(item[lo:hi].clone(), plan, rank, dist, backend=CheckerBackend(), chunks=chunks)
+        whole = ShardedItemTable(plan.take(item, rank).clone(), plan, rank, dist, backend=CheckerBackend())
+        piped = ShardedItemTable(plan.take(item, rank).clone(), plan, rank, dist, backend=CheckerBackend(), chunks=chunks)
         gg = torch.Generator().manual_seed(500 + rank)
         dpos, dneg = torch.randn(B, generator=gg), torch.randn(B, n, generator=gg)
         for step in range(3):                                  # step 0 calibrates (both tables), 1 and 2 run fixed
@@ -369,7 +367,7 @@ def _chunk_worker(rank, world, port, n_items, d, B, n, chunks, result_dir):
             assert torch.equal(a['pos_score'], b['pos_score']) and torch.equal(a['neg_score'], b['neg_score'])
             assert b['route']['C'] == chunks and len(b['route']['recv_keys']) == chunks
             assert (B, n, chunks) in piped._cap and (B, n, 1) not in piped._cap
-            ga, gb = torch.zeros(hi - lo, d), torch.zeros(hi - lo, d)
+            ga, gb = torch.zeros(plan.n_local(rank), d), torch.zeros(plan.n_local(rank), d)
             qa = whole.backward(a['route'], dpos, dneg, ga)
             qb = piped.backward(b['route'], dpos, dneg, gb)
             np.testing.assert_allclose(qb.numpy(), qa.numpy(), rtol=1e-5, atol=1e-5)
@@ -381,7 +379,7 @@ def _chunk_worker(rank, world, port, n_items, d, B, n, chunks, result_dir):
         np.testing.assert_allclose(p1.numpy(), w1p.numpy(), rtol=1e-6, atol=1e-6)
         np.testing.assert_allclose(s1.numpy(), w1n.numpy(), rtol=1e-6, atol=1e-6)
         # overflow inside a slice is detected like in the whole step
-        tight = ShardedItemTable(item[lo:hi].clone(), plan, rank, dist, backend=CheckerBackend(), slack=1.0, margin=0,
+        tight = ShardedItemTable(plan.take(item, rank).clone(), plan, rank, dist, backend=CheckerBackend(), slack=1.0, margin=0,
                                  chunks=chunks)
         tight.score_ids(user[uid], pos, a['neg_ids'])
         Bc = B // chunks
@@ -394,7 +392,7 @@ def _chunk_worker(rank, world, port, n_items, d, B, n, chunks, result_dir):
         dist.destroy_process_group()
 
 
-def _full_worker(rank, world, port, n_items, d, B, k, result_dir):
+def _full_worker(rank, world, port, n_items, d, B, k, result_dir, layout='block'):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
@@ -403,9 +401,8 @@ def _full_worker(rank, world, port, n_items, d, B, k, result_dir):
         g = torch.Generator().manual_seed(11)
         item = torch.randn(n_items, d, generator=g)
         item[0] = 0
-        plan = RowShardPlan(n_items, world)
-        lo, hi = plan.bounds(rank)
-        table = ShardedItemTable(item[lo:hi].clone(), plan, rank, dist, backend=CheckerBackend())
+        plan = RowShardPlan(n_items, world, layout=layout)
+        table = ShardedItemTable(plan.take(item, rank).clone(), plan, rank, dist, backend=CheckerBackend())
         q = torch.randn(B, d, generator=torch.Generator().manual_seed(200 + rank))
         lse, tv, ti = table.full_lse_topk(q, k)
         sc = q @ item[1:].t()
@@ -422,7 +419,7 @@ def _full_worker(rank, world, port, n_items, d, B, k, result_dir):
         dist.destroy_process_group()
 
 
-def _train_worker(rank, world, port, n_items, d, B, n, result_dir):
+def _train_worker(rank, world, port, n_items, d, B, n, result_dir, layout='block'):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
@@ -432,9 +429,8 @@ def _train_worker(rank, world, port, n_items, d, B, n, result_dir):
         item = torch.randn(n_items, d, generator=g) * 0.3
         item[0] = 0
         tower_w = torch.randn(d, 8, generator=g) * 0.3
-        plan = RowShardPlan(n_items, world)
-        lo, hi = plan.bounds(rank)
-        table = ShardedItemTable(item[lo:hi].clone(), plan, rank, dist, backend=CheckerBackend())
+        plan = RowShardPlan(n_items, world, layout=layout)
+        table = ShardedItemTable(plan.take(item, rank).clone(), plan, rank, dist, backend=CheckerBackend())
         tower = torch.nn.Linear(8, d)
         with torch.no_grad():
             tower.weight.copy_(tower_w)
@@ -449,14 +445,14 @@ def _train_worker(rank, world, port, n_items, d, B, n, result_dir):
         trainer = ShardedRetriever(table, tower, oracle.UniformSampler(n_items), bpr, n)
         loss = trainer.training_step(feats[rank], poss[rank])
         # the same step with the item rows updated in place inside the exchange (item_sgd_lr)
-        table2 = ShardedItemTable(item[lo:hi].clone(), plan, rank, dist, backend=CheckerBackend())
+        table2 = ShardedItemTable(plan.take(item, rank).clone(), plan, rank, dist, backend=CheckerBackend())
         tower2 = torch.nn.Linear(8, d)
         with torch.no_grad():
             tower2.weight.copy_(tower_w)
             tower2.bias.zero_()
         trainer2 = ShardedRetriever(table2, tower2, oracle.UniformSampler(n_items), bpr, n, item_sgd_lr=0.7)
         trainer2.training_step(feats[rank], poss[rank])
-        np.testing.assert_allclose(table2.item_local.numpy(), (item[lo:hi] - 0.7 * trainer.item_grad_local).numpy(),
+        np.testing.assert_allclose(table2.item_local.numpy(), (plan.take(item, rank) - 0.7 * trainer.item_grad_local).numpy(),
                                    rtol=1e-5, atol=1e-7)
         np.testing.assert_allclose(tower2.weight.grad.numpy(), tower.weight.grad.numpy(), rtol=1e-5, atol=1e-7)
         # single-process reference on the concatenated batch with the SAME negatives
@@ -480,7 +476,7 @@ def _train_worker(rank, world, port, n_items, d, B, n, result_dir):
         np.testing.assert_allclose(tower.bias.grad.numpy(), tower_ref.bias.grad.numpy(), rtol=1e-4, atol=1e-6)
         want = item_ref.grad.clone()
         want[0] = 0
-        np.testing.assert_allclose(trainer.item_grad_local.numpy(), want[lo:hi].numpy(), rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(trainer.item_grad_local.numpy(), plan.take(want, rank).numpy(), rtol=1e-4, atol=1e-6)
         # a replicated nn.Embedding tower: the gradient is exchanged as (ids, rows), not as a dense all-reduce
         U = 23
         emb_w = torch.randn(U, d, generator=g) * 0.3
@@ -488,7 +484,7 @@ def _train_worker(rank, world, port, n_items, d, B, n, result_dir):
         emb = torch.nn.Embedding(U, d, padding_idx=0)
         with torch.no_grad():
             emb.weight.copy_(emb_w)
-        table3 = ShardedItemTable(item[lo:hi].clone(), plan, rank, dist, backend=CheckerBackend())
+        table3 = ShardedItemTable(plan.take(item, rank).clone(), plan, rank, dist, backend=CheckerBackend())
         assert not ShardedRetriever(table3, emb, oracle.UniformSampler(n_items), bpr, n).sparse_query_rows     # opt-in
         trainer3 = ShardedRetriever(table3, emb, oracle.UniformSampler(n_items), bpr, n, sparse_query_rows=True)
         trainer3.training_step(uids[rank], poss[rank])
@@ -504,7 +500,7 @@ def _train_worker(rank, world, port, n_items, d, B, n, result_dir):
         emb4 = torch.nn.Embedding(U, d, padding_idx=0)
         with torch.no_grad():
             emb4.weight.copy_(emb_w)
-        table4 = ShardedItemTable(item[lo:hi].clone(), plan, rank, dist, backend=CheckerBackend())
+        table4 = ShardedItemTable(plan.take(item, rank).clone(), plan, rank, dist, backend=CheckerBackend())
         ShardedRetriever(table4, emb4, oracle.UniformSampler(n_items), bpr, n, query_sgd_lr=0.3).training_step(uids[rank], poss[rank])
         np.testing.assert_allclose(emb4.weight.detach().numpy(), (emb_w - 0.3 * w_ref.grad).numpy(), rtol=1e-4, atol=1e-6)
         reps = [torch.zeros(U, d) for _ in range(world)]
@@ -516,7 +512,7 @@ def _train_worker(rank, world, port, n_items, d, B, n, result_dir):
         counts = torch.arange(n_items) % 7 + 1
         for loss_cls, ref_loss, smp in ((ra.BPRLoss, 'bpr', oracle.UniformSampler(n_items)),
                                         (ra.SampledSoftmaxLoss, 'ssm', oracle.PopularSamplerModel(counts))):
-            tbl_f = ShardedItemTable(item[lo:hi].clone(), plan, rank, dist, backend=CheckerBackend())
+            tbl_f = ShardedItemTable(plan.take(item, rank).clone(), plan, rank, dist, backend=CheckerBackend())
             tower_f = torch.nn.Linear(8, d)
             with torch.no_grad():
                 tower_f.weight.copy_(tower_w)
@@ -546,46 +542,68 @@ def _train_worker(rank, world, port, n_items, d, B, n, result_dir):
             np.testing.assert_allclose(tower_f.weight.grad.numpy(), tower_r.weight.grad.numpy(), rtol=1e-4, atol=1e-6)
             want_f = item_r.grad.clone()
             want_f[0] = 0
-            np.testing.assert_allclose(tr_f.item_grad_local.numpy(), want_f[lo:hi].numpy(), rtol=1e-4, atol=1e-6)
+            np.testing.assert_allclose(tr_f.item_grad_local.numpy(), plan.take(want_f, rank).numpy(), rtol=1e-4, atol=1e-6)
         open(os.path.join(result_dir, f'ok{rank}'), 'w').write('ok')
     finally:
         dist.destroy_process_group()
 
 
-def test_sharded_training_step_equals_single_process_autograd(tmp_path):
-    """ShardedRetriever.training_step on 2 ranks (item rows sharded, query tower replicated + bucketed
-    all-reduce) == autograd of the global-mean BPR loss in one process."""
+@pytest.mark.parametrize('layout', ['block', 'interleaved'])
+def test_sharded_training_step_equals_single_process_autograd(tmp_path, layout):
+    """ShardedRetriever.training_step on 2 ranks (item rows sharded -- contiguous blocks or interleaved rows --, query
+    tower replicated + bucketed all-reduce) == autograd of the global-mean BPR loss in one process."""
     world = 2
-    mp.spawn(_train_worker, args=(world, _free_port(), 61, 16, 7, 4, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_train_worker, args=(world, _free_port(), 61, 16, 7, 4, str(tmp_path), layout), nprocs=world, join=True)
     assert all(os.path.exists(tmp_path / f'ok{r}') for r in range(world))
 
 
+@pytest.mark.parametrize('layout', ['block', 'interleaved'])
 @pytest.mark.parametrize('n_items,k', [(101, 10), (7, 3), (3, 1)])
-def test_sharded_full_catalog_pass_equals_single_process(tmp_path, n_items, k):
+def test_sharded_full_catalog_pass_equals_single_process(tmp_path, n_items, k, layout):
     """k larger than one shard's row count ((7, 3): shard 0 holds 3 real rows, shard 1 holds 3) and a last
     shard with a single row ((3, 1): rows_per_shard = 2 -> shard 1 = {2})."""
     world = 2
-    mp.spawn(_full_worker, args=(world, _free_port(), n_items, 16, 5, k, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_full_worker, args=(world, _free_port(), n_items, 16, 5, k, str(tmp_path), layout), nprocs=world, join=True)
     assert all(os.path.exists(tmp_path / f'ok{r}') for r in range(world))
 
 
-@pytest.mark.parametrize('n_items,n,B', [(101, 5, 9), (64, 1, 9), (1001, 7, 500)])
-def test_sharded_scores_equal_single_process(tmp_path, n_items, n, B):
+@pytest.mark.parametrize('n_items,n,B,layout', [(101, 5, 9, 'block'), (64, 1, 9, 'block'), (1001, 7, 500, 'block'),
+                                                (101, 5, 9, 'interleaved'), (1001, 7, 500, 'interleaved')])
+def test_sharded_scores_equal_single_process(tmp_path, n_items, n, B, layout):
     """Forward + gradient exchange on 2 ranks == single process: exact-split calibration step, then the fixed-capacity
     exchange; negatives identical to a world-1 draw (G-invariance); overflow of a tight capacity detected (B = 500)."""
     world = 2
-    mp.spawn(_worker, args=(world, _free_port(), n_items, 16, B, n, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), n_items, 16, B, n, str(tmp_path), layout), nprocs=world, join=True)
     assert all(os.path.exists(tmp_path / f'ok{r}') for r in range(world))
 
 
-@pytest.mark.parametrize('B,n,chunks', [(8, 5, 2), (12, 3, 4), (400, 7, 2)])
-def test_pipelined_slices_equal_the_whole_step(tmp_path, B, n, chunks):
+@pytest.mark.parametrize('B,n,chunks,layout', [(8, 5, 2, 'block'), (12, 3, 4, 'block'), (400, 7, 2, 'block'),
+                                               (400, 7, 2, 'interleaved')])
+def test_pipelined_slices_equal_the_whole_step(tmp_path, B, n, chunks, layout):
     """ShardedItemTable(chunks=C): the step cut into C query slices with asynchronously issued exchanges gives the same
     negatives and bit-equal scores as the whole step, the same gradients (summed in a different order), keeps its
     own per-slice capacity, detects overflow, and falls back to the whole step for batches C does not divide."""
     world = 2
-    mp.spawn(_chunk_worker, args=(world, _free_port(), 1001, 16, B, n, chunks, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_chunk_worker, args=(world, _free_port(), 1001, 16, B, n, chunks, str(tmp_path), layout), nprocs=world, join=True)
     assert all(os.path.exists(tmp_path / f'ok{r}') for r in range(world))
+
+
+def test_interleaved_plan_partitions_all_rows():
+    from recstudio_amd.shard import RowShardPlan
+    for n_items, world in ((100_000_001, 8), (101, 2), (7, 8), (64, 4), (3, 2)):
+        plan = RowShardPlan(n_items, world, layout='interleaved')
+        assert sum(plan.n_local(r) for r in range(world)) == n_items and plan.rows_arg == 0
+        ids = torch.tensor([0, 1, n_items // 2, n_items - 1])
+        own, loc = plan.owner(ids), plan.local(ids)
+        for i, o, l in zip(ids.tolist(), own.tolist(), loc.tolist()):
+            assert 0 <= l < plan.n_local(o) and plan.global_ids(o, l) == i
+    plan = RowShardPlan(11, 3, layout='interleaved')
+    full = torch.arange(11.).view(11, 1)
+    parts = [plan.take(full, r) for r in range(3)]
+    assert [p.flatten().tolist() for p in parts] == [[0., 3., 6., 9.], [1., 4., 7., 10.], [2., 5., 8.]]
+    assert torch.equal(plan.assemble(parts), full)
+    with pytest.raises(ValueError):
+        plan.bounds(0)
 
 
 def test_plan_partitions_all_rows():
@@ -628,7 +646,7 @@ def _fit_worker(rank, world, port, result_dir, epochs, batch_global, train_extra
         test = model.evaluate(tst, verbose=False)
         losses = torch.cat(model.train_losses)
         sh = model._shard
-        assert tuple(model.item_encoder.weight.shape) == (sh['hi'] - sh['lo'], 16)     # this rank holds its row block only
+        assert tuple(model.item_encoder.weight.shape) == (sh['plan'].n_local(rank), 16)     # this rank holds its rows only
         # replicas of the tower are bit-equal; the item blocks tile the table
         tower = [torch.zeros_like(model.query_encoder.weight) for _ in range(world)]
         dist.all_gather(tower, model.query_encoder.weight.detach())
@@ -663,6 +681,18 @@ def test_fit_two_ranks_equals_one_rank_on_ml100k(tmp_path):
     assert two[0]['lo'] == 0 and two[1]['lo'] == two[0]['item'].shape[0]
     np.testing.assert_allclose(items.numpy(), one['item'].numpy(), rtol=1e-4, atol=1e-6)
     assert not items[0].any()                                        # the padding row never moves
+    # the same job with train.shard_layout 'interleaved' (rank r holds rows r, r + 2, ...): the same run again
+    os.makedirs(tmp_path / 'il')
+    mp.spawn(_fit_worker, args=(2, _free_port(), str(tmp_path / 'il'), epochs, batch_global, {'shard_layout': 'interleaved'}),
+             nprocs=2, join=True)
+    il = [torch.load(tmp_path / 'il' / f'w2r{r}.pt', weights_only=False) for r in range(2)]
+    for t in il:
+        np.testing.assert_allclose(t['losses'].numpy(), one['losses'].numpy(), rtol=1e-5, atol=1e-6)
+        for k in ('ndcg@10', 'recall@10'):
+            assert abs(t['val'][k] - one['val'][k]) < 1e-5 and abs(t['test'][k] - one['test'][k]) < 1e-5
+    items = torch.empty_like(one['item'])
+    items[0::2], items[1::2] = il[0]['item'], il[1]['item']
+    np.testing.assert_allclose(items.numpy(), one['item'].numpy(), rtol=1e-4, atol=1e-6)
 
 
 def test_fit_two_ranks_clips_the_global_gradient_norm(tmp_path):
