@@ -159,7 +159,7 @@ def test_interleaved_rows_have_no_hot_shard_under_popularity_ordered_ids():
     N, world, B, n = 1_000_001, 8, 2048, 256
     counts = torch.zeros(N)
     counts[1:] = (1e9 / (torch.arange(1, N, dtype=torch.float64) + 1000.0)).float()     # shifted Zipf: no single item dominates
-    ps = ra.PopularSamplerModel(counts).to(DEV)
+    ps = ra.PopularSamplerModel(counts, mode=2).to(DEV)         # sampler.py:233-234: count ** 0.75 (mode 0 takes the log: nearly flat)
     hb = HipBackend()
     spec = hb.sampler_spec(ps)
     pos = torch.multinomial(counts, B, replacement=True).to(DEV)
@@ -170,7 +170,7 @@ def test_interleaved_rows_have_no_hot_shard_under_popularity_ordered_ids():
         c = hb.sample_route(hb.new_state(DEV), plan, 0, pos, n, 1, 0, spec, gen, count_only=True).cpu().double()
         assert int(c.sum()) == B * (n + 1)
         ratio[layout] = float(c.max() / c.mean())
-    assert ratio['block'] > 3.0 and ratio['interleaved'] < 1.03, ratio
+    assert ratio['block'] > 2.5 and ratio['interleaved'] < 1.03, ratio
 
 
 def test_sorted_scatter_drops_negative_ids():
