@@ -93,11 +93,30 @@ for sub, counter, mult in (('fetch', 'FETCH_SIZE', 2.0), ('write', 'WRITE_SIZE',
 if 'FETCH_SIZE' in tot_bytes and 'WRITE_SIZE' in tot_bytes:
     entry['hbm_bytes_per_launch'] = round(tot_bytes['FETCH_SIZE'] + tot_bytes['WRITE_SIZE'])
     lines.append(f'# dominant kernel HBM traffic per launch: 2 x FETCH_SIZE + WRITE_SIZE = {entry["hbm_bytes_per_launch"] / 1e9:.3f} GB')
+# a partial re-collection starts from the committed summaries: entries / blocks of other shapes are kept
+committed = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'profiles')
+for name in ('r03_kernel_profiles.json', 'r03_kernel_profiles.txt'):
+    if not os.path.exists(os.path.join(dst, name)) and os.path.exists(os.path.join(committed, name)):
+        shutil.copy(os.path.join(committed, name), os.path.join(dst, name))
 path = os.path.join(dst, 'r03_kernel_profiles.json')
 allj = json.load(open(path)) if os.path.exists(path) else {}
 allj[shape] = entry
 json.dump(allj, open(path, 'w'), indent=1, sort_keys=True)
-open(os.path.join(dst, 'r03_kernel_profiles.txt'), 'a').write('\n'.join(lines) + '\n\n')
+tpath = os.path.join(dst, 'r03_kernel_profiles.txt')
+blocks, order = {}, []
+if os.path.exists(tpath):
+    cur = None
+    for line in open(tpath).read().split('\n'):
+        if line.startswith('## '):
+            cur = line[3:].strip()
+            order.append(cur)
+            blocks[cur] = []
+        if cur is not None:
+            blocks[cur].append(line)
+if shape not in blocks:
+    order.append(shape)
+blocks[shape] = lines
+open(tpath, 'w').write('\n\n'.join('\n'.join(blocks[k]).rstrip('\n') for k in order) + '\n')
 print('\n'.join(lines))
 print(json.dumps(entry))
 shape_dir = os.path.join(out_dir, shape)
