@@ -145,7 +145,7 @@ elif shape == 'seg_gather_B8192_L50':
 else:
     raise SystemExit(f'unknown shape {shape}')
 
-WARM = 3
+WARM = 20         # enough launches for the clocks to settle before the counted ones
 for _ in range(WARM):
     step()
 torch.cuda.synchronize()
