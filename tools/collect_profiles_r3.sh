@@ -12,9 +12,9 @@ mkdir -p $OUT $DST
 export TMPDIR=/tmp
 for s in $SHAPES; do
   cd /tmp
-  timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/$s/trace -o p -- python $REPO/tools/prof_shapes.py $s 30 > $OUT/$s.trace.log 2>&1
-  timeout 900 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/$s/fetch -o p -- python $REPO/tools/prof_shapes.py $s 8 > $OUT/$s.fetch.log 2>&1
-  timeout 900 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/$s/write -o p -- python $REPO/tools/prof_shapes.py $s 8 > $OUT/$s.write.log 2>&1
+  timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/$s/trace -o p -- python $REPO/tools/prof_shapes.py $s 100 > $OUT/$s.trace.log 2>&1
+  timeout 900 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/$s/fetch -o p -- env PROF_WARM_MS=0 python $REPO/tools/prof_shapes.py $s 8 > $OUT/$s.fetch.log 2>&1
+  timeout 900 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/$s/write -o p -- env PROF_WARM_MS=0 python $REPO/tools/prof_shapes.py $s 8 > $OUT/$s.write.log 2>&1
   cd $REPO
   python tools/summarize_shapes.py $OUT $DST $s >> $OUT/summary.log 2>&1
 done

@@ -145,10 +145,22 @@ elif shape == 'seg_gather_B8192_L50':
 else:
     raise SystemExit(f'unknown shape {shape}')
 
-WARM = 20         # enough launches for the clocks to settle before the counted ones
-for _ in range(WARM):
+# Warm-up by TIME, not by count: a 0.4 ms step launched 20 times is 8 ms of GPU work, not enough for the clocks to settle
+# (the same kernel measured 7 % slower this way than inside bench.py's 250-launch run on the same box).  WARM_MS of
+# back-to-back launches first (counted, so that the summariser can skip them), then the K counted ones.
+import time                                     # noqa: E402
+WARM_MS = float(os.environ.get('PROF_WARM_MS', '120'))
+WARM = 0
+for _ in range(3):
     step()
+    WARM += 1
 torch.cuda.synchronize()
+t0 = time.perf_counter()
+while (time.perf_counter() - t0) * 1e3 < WARM_MS:
+    for _ in range(5):
+        step()
+        WARM += 1
+    torch.cuda.synchronize()
 for _ in range(K):
     step()
 torch.cuda.synchronize()

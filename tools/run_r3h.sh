@@ -13,3 +13,6 @@ RSA_BENCH_STAGED=1 timeout 600 python bench.py --gpus 2 --items 4000001 --users 
 tail -1 $OUT/bench_staged.log | cut -c1-300
 timeout 2400 bash tools/collect_profiles_r3.sh > $OUT/collect.log 2>&1
 grep "^{" gpurun_out/prof_r03/summary.log | cut -c1-160
+# the bench command itself under rocprofv3 (stats + FETCH / WRITE / MFMA passes) -> r03_rocprof_summary.txt, r03_pmc_traffic.json
+timeout 1500 bash tools/collect_profiles.sh r03 > $OUT/collect_bench.log 2>&1
+tail -12 $OUT/collect_bench.log | cut -c1-200

@@ -35,7 +35,7 @@ if c is not None:
     for name, calls, total, avg, pct in c.execute('select name,total_calls,total_duration,average,percentage from top_kernels'):
         lines.append(f'{short(name):96s} {calls:6d} {total / 1e3:10.3f} {avg:10.2f} {pct:6.2f}')
     # the dominant kernel at the bench's B=65536 launch size only (the grid tells the launches apart)
-    rows = list(c.execute("select grid_x, duration from kernels where name like '%fused_fwd_kernel<32, false, false, true, true, false>%'"))
+    rows = list(c.execute("select grid_x, duration from kernels where name like '%fused_fwd_kernel<32, false, false, true, true, false, false, 0>%'"))
     if rows:
         gmax = max(r[0] for r in rows)
         d = [r[1] for r in rows if r[0] == gmax]
@@ -44,7 +44,7 @@ if c is not None:
         out['fused_fwd_max_us'] = max(d) / 1e3
         out['fused_fwd_calls'] = len(d)
         regs = c.execute("select vgpr_count, accum_vgpr_count, sgpr_count, lds_size, scratch_size, workgroup_x, grid_x "
-                         "from kernels where name like '%fused_fwd_kernel<32, false, false, true, true, false>%' limit 1").fetchone()
+                         "from kernels where name like '%fused_fwd_kernel<32, false, false, true, true, false, false, 0>%' limit 1").fetchone()
         lines.append(f'# fused_fwd_kernel dispatch: vgpr={regs[0]} agpr={regs[1]} sgpr={regs[2]} lds={regs[3]} '
                      f'scratch={regs[4]} workgroup={regs[5]} grid={regs[6]}')
         lines.append(f'# fused_fwd_kernel over {len(d)} launches: avg {out["fused_fwd_avg_us"]:.2f} us, '
@@ -63,7 +63,7 @@ for sub, counter in (('pmc_fetch', 'FETCH_SIZE'), ('pmc_write', 'WRITE_SIZE')):
     for name, cnt, avg, mn, mx in c.execute(q, (counter,)):
         lines.append(f'{short(name):96s} launches={cnt:4d} avg={avg:14.1f} min={mn:14.1f} max={mx:14.1f}')
     vals = [r[0] for r in c.execute("select value from counters_collection where counter_name=? and "
-                                    "kernel_name like '%fused_fwd_kernel<32, false, false, true, true, false>%' order by id", (counter,))]
+                                    "kernel_name like '%fused_fwd_kernel<32, false, false, true, true, false, false, 0>%' order by id", (counter,))]
     if vals:
         vals = vals[2:] if len(vals) > 4 else vals       # drop the cold first launches
         out[counter + '_KB_per_launch'] = sum(vals) / len(vals)
