@@ -811,3 +811,38 @@ def test_bpr_sgd_step_in_forward_equals_all_sorted(ra, N, d, B, kind):
     gi[0] = 0
     rel_close(it1.cpu(), (iw.to(DEV) - lr * gi).cpu(), rtol=2e-4, atol=1e-6)
     rel_close(l1.cpu(), ref.detach().cpu(), rtol=1e-5)
+
+
+@pytest.mark.parametrize('kind', ['uniform', 'popular'])
+def test_prefetched_sgd_steps_equal_the_plain_sequence(ra, kind):
+    """fused.PrefetchedBPRSGD: the next step's negatives are drawn, sorted and classified on a side stream while the
+    current step's forward and apply passes run -- five steps over changing batches give the losses, negatives and tables
+    of five ``bpr_sgd_step`` calls bit for bit (the same kernels on the same data, only issued earlier)."""
+    N, U, d, B, n, lr, steps = 50_021, 3001, 128, 4096, 64, 0.2, 5
+    iw, uw = _tables(N, U, d, B)
+    g = torch.Generator().manual_seed(7)
+    batches = [(torch.randint(1, U, (B,), generator=g).to(DEV), torch.randint(1, N, (B,), generator=g).to(DEV)) for _ in range(steps)]
+    if kind == 'uniform':
+        sampler = ra.UniformSampler(N)
+    else:
+        sampler = ra.PopularSamplerModel((torch.rand(N, generator=g) ** 6 * 1000).long()).to(DEV)
+    item0, user0 = iw.to(DEV).clone(), uw.to(DEV).clone()
+    torch.manual_seed(5)
+    want = [ra.fused.bpr_sgd_step(item0, user0, n, lr, user_ids=u, pos_ids=p, sampler=sampler) for u, p in batches]
+    want = [(l.clone(), i.clone()) for l, i in want]
+    for _ in range(2):                                   # twice: run to run as well
+        item1, user1 = iw.to(DEV).clone(), uw.to(DEV).clone()
+        torch.manual_seed(5)
+        stepper = ra.fused.PrefetchedBPRSGD(item1, user1, n, lr, sampler)
+        got = []
+        ticket = stepper.prepare(*batches[0])
+        for k in range(steps):
+            nxt = stepper.prepare(*batches[k + 1]) if k + 1 < steps else None
+            loss, ids = stepper.step(ticket)
+            got.append((loss.clone(), ids.clone()))
+            ticket = nxt
+        torch.cuda.synchronize()
+        for (lw, iw_), (lg, ig) in zip(want, got):
+            assert torch.equal(iw_, ig) and torch.equal(lw, lg)
+        assert torch.equal(item1, item0) and torch.equal(user1, user0)
+    assert not torch.equal(item0, iw.to(DEV))
