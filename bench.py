@@ -366,10 +366,27 @@ def main():
             iw0, uw0 = item.clone(), user.clone()
             t_sgd = time_gpu(lambda: bpr_sgd_step(item, user, n, 1e-3, user_ids=uid, pos_ids=pos, sampler=sampler),
                              max(10, args.steps // 4), 3) * 1e3
+            extra['train_step']['sgd_step_ms'] = round(t_sgd, 4)
+            # the same steps with the weight-independent part of step k+1 (sampling, sort, solo classification) issued on a
+            # side stream while step k runs: same results bit for bit, steady-state time per step
+            from recstudio_amd.fused import PrefetchedBPRSGD
+            stepper = PrefetchedBPRSGD(item, user, n, 1e-3, sampler)
+            tick = {'t': stepper.prepare(uid, pos)}
+
+            def prefetched_step():
+                nxt = stepper.prepare(uid, pos)
+                stepper.step(tick['t'])
+                tick['t'] = nxt
+            t_pf = time_gpu(prefetched_step, max(10, args.steps // 4), 3) * 1e3
+            torch.cuda.synchronize()
+            del stepper, tick
+            extra['train_step']['sgd_step_prefetched_ms'] = round(t_pf, 4)
+            extra['train_step']['sgd_step_prefetched_what'] = ('fused.PrefetchedBPRSGD: the sgd_step above with the next '
+                                                               "step's negatives drawn, sorted and classified on a side stream "
+                                                               'under the current step (wall clock per step; same weights bit for bit)')
             item.copy_(iw0)
             user.copy_(uw0)
             del iw0, uw0
-            extra['train_step']['sgd_step_ms'] = round(t_sgd, 4)
             # complete lazy-Adam step (torch.optim.SparseAdam's rule) on the same machinery
             from recstudio_amd.fused import FusedBPRAdam
             iw0, uw0 = item.clone(), user.clone()

@@ -53,7 +53,7 @@ def default_config():
                   'num_threads': 10, 'sampling_method': 'none', 'sampler': 'uniform', 'negative_count': 0,
                   'excluding_hist': False, 'scheduler': None, 'seed': 2022, 'weight_decay': 0.0,
                   'tensorboard_path': None, 'sparse_grad': False, 'device_loader': True, 'fused_optimizer': None,
-                  'shard_slices': 1, 'shard_layout': 'block'},
+                  'shard_slices': 1, 'shard_layout': 'block', 'fused_prefetch': True},
         'eval': {'batch_size': 128, 'cutoff': [5, 10, 20], 'val_metrics': ['ndcg', 'recall'], 'val_n_epoch': 1,
                  'test_metrics': ['ndcg', 'recall', 'precision', 'map', 'mrr', 'hit'], 'topk': 100,
                  'save_path': './saved/'},
@@ -810,6 +810,19 @@ class BaseRetriever(torch.nn.Module):
                 loader = train_data.device_train_loader(tr['batch_size'], shuffle=True, drop_last=False, device=device)
             else:
                 loader = train_data.train_loader(batch_size=tr['batch_size'], shuffle=True, drop_last=False)
+            if getattr(fused_step, 'stepper', None) is not None:
+                # one batch of look-ahead: the next step's negatives are drawn and sorted on a side stream while this
+                # step's forward and apply passes run (fused.PrefetchedBPRSGD; same weights bit for bit)
+                stepper, ticket = fused_step.stepper, None
+                for batch in loader:
+                    batch = self._to_device(batch, device)
+                    nxt = stepper.prepare(batch[self.fuid], batch[self.fiid])
+                    if ticket is not None:
+                        losses.append(stepper.step(ticket)[0])
+                    ticket = nxt
+                if ticket is not None:
+                    losses.append(stepper.step(ticket)[0])
+                loader = ()
             for batch in loader:
                 batch = self._to_device(batch, device)
                 if fused_step is not None and batch[self.fiid].dim() == 1:
@@ -860,8 +873,13 @@ class BaseRetriever(torch.nn.Module):
         from .fused import FusedBPRAdam, bpr_sgd_step
         iw, uw, lr = self.item_encoder.weight, self.query_encoder.weight, tr['learning_rate']
         if kind == 'sgd':
-            return lambda b: bpr_sgd_step(iw, uw, self.neg_count, lr, user_ids=b[self.fuid], pos_ids=b[self.fiid],
-                                          sampler=self.sampler)[0]
+            def sgd_step(b):
+                return bpr_sgd_step(iw, uw, self.neg_count, lr, user_ids=b[self.fuid], pos_ids=b[self.fiid], sampler=self.sampler)[0]
+            sgd_step.stepper = None
+            if self.neg_count == 64 and tr.get('fused_prefetch', True) and self.fiid is not None:
+                from .fused import PrefetchedBPRSGD
+                sgd_step.stepper = PrefetchedBPRSGD(iw, uw, self.neg_count, lr, self.sampler)
+            return sgd_step
         if kind == 'adam':
             opt = FusedBPRAdam(iw, uw, lr=lr)
             return lambda b: opt.step(self.neg_count, user_ids=b[self.fuid], pos_ids=b[self.fiid], sampler=self.sampler)[0]
