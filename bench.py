@@ -299,7 +299,17 @@ def main():
     extra = {}
     emit_lock, emitted = threading.Lock(), []
 
+    def flush_c_stdio():
+        # RCCL prints its banner through C stdio, which a pipe buffers until exit: push it out first so that the JSON line
+        # is the LAST line of stdout
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+
     def headline_line(value, ms_step, workload, parallelism, roofline, extra):
+        flush_c_stdio()
         line = {'metric': 'M scored (user,pos,neg) triplets/sec at d=128', 'value': round(value, 2),
                 'unit': 'M triplets/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
                 'ms_per_step': round(ms_step, 4), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
