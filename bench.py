@@ -402,11 +402,20 @@ def main():
             iw0, uw0 = item.clone(), user.clone()
             fa = FusedBPRAdam(item, user, lr=1e-3)
             t_adam = time_gpu(lambda: fa.step(n, user_ids=uid, pos_ids=pos, sampler=sampler), max(10, args.steps // 4), 3) * 1e3
+            extra['train_step']['adam_step_ms'] = round(t_adam, 4)
+            atick = {'t': fa.prepare(n, user_ids=uid, pos_ids=pos, sampler=sampler)}
+
+            def adam_ahead():
+                nxt = fa.prepare(n, user_ids=uid, pos_ids=pos, sampler=sampler)
+                fa.step_prepared(atick['t'])
+                atick['t'] = nxt
+            t_adam_pf = time_gpu(adam_ahead, max(10, args.steps // 4), 3) * 1e3
+            torch.cuda.synchronize()
+            extra['train_step']['adam_step_prefetched_ms'] = round(t_adam_pf, 4)
             item.copy_(iw0)
             user.copy_(uw0)
-            del iw0, uw0, fa
+            del iw0, uw0, fa, atick
             torch.cuda.empty_cache()
-            extra['train_step']['adam_step_ms'] = round(t_adam, 4)
             extra['train_step']['adam_step_what'] = ('forward + BPR loss + lazy Adam (SparseAdam rule) on the touched item '
                                                      'and user rows, gradient sums kept in registers (no gradient tensor)')
             extra['train_step']['sgd_step_what'] = ('negatives drawn and sorted by item id, forward + BPR loss with the SGD update of '

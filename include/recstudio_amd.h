@@ -30,7 +30,8 @@
 extern "C" {
 #endif
 
-#define RSA_ABI_VERSION 5   /* 5: version 2 of the fixed-capacity shard exchange (rsa_shard_sample_route: sampling fused into the routing
+#define RSA_ABI_VERSION 6   /* 6: rsa_adam_rows_presorted; rows_per_shard == 0 = interleaved row ownership in the shard routing entry points;
+                               5: version 2 of the fixed-capacity shard exchange (rsa_shard_sample_route: sampling fused into the routing
                                pass, self-describing segments with {count, dropped} headers, 32-bit slots; rsa_shard_score_segments;
                                rsa_shard_home: scatter + loss + mean + routed-order gradient in one launch; rsa_shard_unpack_segments;
                                rsa_shard_scatter_slots); rsa_sample_masked_uniform takes elem_base;
@@ -354,6 +355,15 @@ int rsa_scatter_rows_presorted(const float* query, const int64_t* query_index, i
                                int32_t has_pos, int64_t n_queries, int32_t num_neg, const float* dpos, const float* dneg,
                                const float* upstream, int64_t n_items, int64_t pad_row, float* target, void* workspace,
                                int64_t workspace_bytes, rsa_stream_t stream);
+
+/* The apply pass of rsa_adam_rows_sorted over a workspace rsa_sort_step_elements filled WITHOUT `solo` (no element
+ * flagged): the sort does not read the weights, so a trainer can issue it -- and the sampling in front of it -- for the
+ * next batch on another stream while the current step runs. */
+int rsa_adam_rows_presorted(const float* query, const int64_t* query_index, int64_t n_query_rows, int32_t dim,
+                            int32_t has_pos, int64_t n_queries, int32_t num_neg, const float* dpos, const float* dneg,
+                            const float* upstream, int64_t n_items, int64_t pad_row, float* weight, float* exp_avg,
+                            float* exp_avg_sq, float lr, float beta1, float beta2, float eps, int64_t step,
+                            void* workspace, int64_t workspace_bytes, rsa_stream_t stream);
 
 /* embedding_dense_backward: dst[ids[i]] += src[i] for ids != 0 (padding_idx=0).
  * Used for the user-table gradient.  dst [n_rows, dim] caller-zeroed. */

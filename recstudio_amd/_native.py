@@ -123,6 +123,9 @@ SIGNATURES = {
     'rsa_adam_rows_sorted': (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_int64, c_int32, c_void_p,
                                      c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_float, c_float,
                                      c_float, c_float, c_int64, c_void_p, c_int64, c_void_p]),
+    'rsa_adam_rows_presorted': (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int64, c_int32, c_void_p, c_void_p,
+                                        c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_float, c_float, c_float,
+                                        c_float, c_int64, c_void_p, c_int64, c_void_p]),
     'rsa_rng_advance': (c_int, [c_void_p, c_uint64, c_void_p]),
     'rsa_row_topk': (c_int, [c_void_p, c_int64, c_int64, c_int32, c_void_p, c_void_p, c_void_p]),
     'rsa_topk_mask_history': (c_int, [c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_int64, c_int32, c_void_p,
@@ -163,7 +166,7 @@ def build(verbose=False):
     return LIB_PATH
 
 
-ABI_VERSION = 5      # RSA_ABI_VERSION of include/recstudio_amd.h this binding was written against
+ABI_VERSION = 6      # RSA_ABI_VERSION of include/recstudio_amd.h this binding was written against
 
 
 def lib():

@@ -463,6 +463,19 @@ extern "C" int rsa_scatter_rows_sorted(const float* query, const int64_t* query_
                              upstream, n_items, pad_row, target, none, workspace, workspace_bytes, stream);
 }
 
+extern "C" int rsa_adam_rows_presorted(const float* query, const int64_t* query_index, int64_t n_query_rows, int32_t dim,
+                                       int32_t has_pos, int64_t n_queries, int32_t num_neg, const float* dpos, const float* dneg,
+                                       const float* upstream, int64_t n_items, int64_t pad_row, float* weight, float* exp_avg,
+                                       float* exp_avg_sq, float lr, float beta1, float beta2, float eps, int64_t step,
+                                       void* workspace, int64_t workspace_bytes, rsa_stream_t stream) {
+  RSA_CHECK_ARG(exp_avg && exp_avg_sq && step >= 1 && beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f,
+                "rsa_adam_rows_presorted: bad optimizer state / hyper-parameters");
+  const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+  const AdamArgs adam{exp_avg, exp_avg_sq, 1.f - beta1, 1.f - beta2, eps, (float)((double)lr * sqrt(bc2) / bc1)};
+  return apply_sorted_impl(query, query_index, n_query_rows, dim, has_pos != 0, n_queries, num_neg, dpos, dneg, upstream, n_items,
+                           pad_row, weight, adam, workspace, workspace_bytes, stream);
+}
+
 extern "C" int rsa_adam_rows_sorted(const float* query, const int64_t* query_index, int64_t n_query_rows, int32_t dim,
                                     const int64_t* pos_ids, const int64_t* neg_ids, int64_t n_queries, int32_t num_neg,
                                     const float* dpos, const float* dneg, const float* upstream, int64_t n_items,

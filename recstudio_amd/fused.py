@@ -418,3 +418,39 @@ class FusedBPRAdam:
             ones = torch.ones(M, 1, dtype=torch.float32, device=self.iw.device)
             ops.adam_rows_sorted(self.uw, st['um'], st['uv'], out['query_grad'], user_ids.view(M, 1), ones, pad_row=0, **hp)
         return out['loss'], out['neg_ids']
+
+    # ---- one batch ahead (see PrefetchedBPRSGD): sampling and the item-side sort do not read the weights
+    def prepare(self, num_neg, *, user_ids, pos_ids, sampler):
+        """Draw the negatives of a batch and sort its (item id, element) pairs on a side stream -> ticket for
+        ``step_prepared``.  Tickets are stepped once each, in the order they were prepared; the results are those of the
+        same sequence of ``step`` calls bit for bit."""
+        if _sampler_kind(sampler) not in (nat.SAMPLER_UNIFORM, nat.SAMPLER_POPULAR):
+            raise TypeError(f'FusedBPRAdam.prepare does not cover sampler {type(sampler).__name__}')
+        if getattr(self, 'side', None) is None:
+            self.side = torch.cuda.Stream(device=self.iw.device)
+        main = torch.cuda.current_stream(self.iw.device)
+        self.side.wait_stream(main)
+        with torch.no_grad(), torch.cuda.stream(self.side):
+            neg = sampler(torch.empty(user_ids.numel(), 1, device=self.iw.device), num_neg, None)[0]
+            _, ws = ops.sort_step_elements(pos_ids, neg, self.iw.shape[0], pad_row=0, want_solo=False)
+            ready = torch.cuda.Event()
+            ready.record(self.side)
+        for t in (neg, ws):
+            t.record_stream(main)
+        return {'user_ids': user_ids, 'pos_ids': pos_ids, 'neg': neg, 'ws': ws, 'ready': ready, 'num_neg': int(num_neg)}
+
+    def step_prepared(self, ticket):
+        torch.cuda.current_stream(self.iw.device).wait_event(ticket['ready'])
+        uid, pos, neg, n = ticket['user_ids'], ticket['pos_ids'], ticket['neg'], ticket['num_neg']
+        M = uid.numel()
+        self.t += 1
+        st = self.state
+        with torch.no_grad():
+            out = ops.fused_forward(self.iw, self.uw, n, query_index=uid, pos_ids=pos, neg_ids=neg, sampler=nat.SAMPLER_GIVEN,
+                                    want_logp=False, fused_bpr=True, want_query_grad=True)
+            hp = dict(lr=self.lr, betas=self.betas, eps=self.eps, step=self.t)
+            ops.adam_rows_presorted(self.iw, st['im'], st['iv'], self.uw, ticket['ws'], M, n, out['dneg'], query_index=uid,
+                                    dpos=out['dpos'], pad_row=0, **hp)
+            ones = torch.ones(M, 1, dtype=torch.float32, device=self.iw.device)
+            ops.adam_rows_sorted(self.uw, st['um'], st['uv'], out['query_grad'], uid.view(M, 1), ones, pad_row=0, **hp)
+        return out['loss'], out['neg_ids']

@@ -539,7 +539,7 @@ def fused_backward(item_table, query, neg_ids, dneg, *, query_index=None, pos_id
 
 
 @_on_device
-def sort_step_elements(pos_ids, neg_ids, n_items, pad_row=0):
+def sort_step_elements(pos_ids, neg_ids, n_items, pad_row=0, want_solo=True):
     """rsa_sort_step_elements: the step's (item id, element) pairs sorted by id in a workspace, and the classification
     ``solo [M, 1 + n]`` uint8 (column 0 = the positive): 1 where no other element of the step touches that item row.
     -> (solo, workspace) for ``fused_forward(inplace_update=...)`` + ``scatter_rows_presorted``."""
@@ -548,7 +548,7 @@ def sort_step_elements(pos_ids, neg_ids, n_items, pad_row=0):
     M = pos_ids.numel() if pos_ids is not None else neg_ids.shape[0]
     n = neg_ids.numel() // max(M, 1)
     w = n + (1 if pos_ids is not None else 0)
-    solo = torch.empty(M, w, dtype=torch.uint8, device=neg_ids.device)
+    solo = torch.empty(M, w, dtype=torch.uint8, device=neg_ids.device) if want_solo else None   # None: sort only, nothing flagged
     ws_bytes = int(nat.lib().rsa_scatter_rows_sorted_workspace_bytes(M, n, int(n_items)))
     ws = torch.empty(max(ws_bytes, 8), dtype=torch.uint8, device=neg_ids.device)
     nat.check(nat.lib().rsa_sort_step_elements(ptr(pos_ids), ptr(neg_ids), M, n, int(n_items), int(pad_row), ptr(solo), ptr(ws),
@@ -572,6 +572,26 @@ def scatter_rows_presorted(target, query, workspace, n_queries, num_neg, dneg, *
                                                    ptr(target), ptr(workspace), workspace.numel(), _stream()),
               'rsa_scatter_rows_presorted')
     return target
+
+
+@_on_device
+def adam_rows_presorted(weight, exp_avg, exp_avg_sq, query, workspace, n_queries, num_neg, dneg, *, lr, betas=(0.9, 0.999),
+                        eps=1e-8, step=1, query_index=None, dpos=None, upstream=None, pad_row=0):
+    """rsa_adam_rows_presorted: the apply pass of adam_rows_sorted over the pairs ``sort_step_elements(want_solo=False)``
+    left in ``workspace``."""
+    weight = _need(weight, torch.float32, 'weight')
+    query = _need(query, torch.float32, 'query')
+    dneg = _need(dneg, torch.float32, 'dneg')
+    n_items, dim = weight.shape
+    nat.check(nat.lib().rsa_adam_rows_presorted(ptr(query), ptr(_need_opt(query_index, torch.int64, 'query_index')), query.shape[0],
+                                                dim, int(dpos is not None), int(n_queries), int(num_neg),
+                                                ptr(_need_opt(dpos, torch.float32, 'dpos')), ptr(dneg),
+                                                ptr(_need_opt(upstream, torch.float32, 'upstream')), n_items, int(pad_row),
+                                                ptr(weight), ptr(_need(exp_avg, torch.float32, 'exp_avg')),
+                                                ptr(_need(exp_avg_sq, torch.float32, 'exp_avg_sq')), float(lr), float(betas[0]),
+                                                float(betas[1]), float(eps), int(step), ptr(workspace), workspace.numel(),
+                                                _stream()), 'rsa_adam_rows_presorted')
+    return weight
 
 
 # ------------------------------------------------------------------ full catalog

@@ -882,7 +882,18 @@ class BaseRetriever(torch.nn.Module):
             return sgd_step
         if kind == 'adam':
             opt = FusedBPRAdam(iw, uw, lr=lr)
-            return lambda b: opt.step(self.neg_count, user_ids=b[self.fuid], pos_ids=b[self.fiid], sampler=self.sampler)[0]
+
+            def adam_step(b):
+                return opt.step(self.neg_count, user_ids=b[self.fuid], pos_ids=b[self.fiid], sampler=self.sampler)[0]
+            adam_step.stepper = None
+            if tr.get('fused_prefetch', True):
+                class _Ahead:      # the prepare / step pair the fit loop drives one batch ahead
+                    @staticmethod
+                    def prepare(uid, pos):
+                        return opt.prepare(self.neg_count, user_ids=uid, pos_ids=pos, sampler=self.sampler)
+                    step = staticmethod(opt.step_prepared)
+                adam_step.stepper = _Ahead
+            return adam_step
         raise ValueError(f"train.fused_optimizer must be 'sgd' or 'adam', got {kind!r}")
 
     @torch.no_grad()

@@ -553,9 +553,9 @@ def test_bpr_fit_with_fused_optimizer(ra, golden, kind):
     res = model.evaluate(tst)
     assert np.isfinite(model.logged_metrics['train_loss']) and model.logged_metrics['train_loss'] < 0.68
     assert res['recall@20'] > 0.05
-    if kind == 'sgd':
-        # the default run above drew and sorted every step's negatives one step ahead on a side stream
-        # (fused.PrefetchedBPRSGD); without the look-ahead: the same model bit for bit
+    if True:
+        # the default run above drew and sorted every step's negatives one batch ahead on a side stream
+        # (fused.PrefetchedBPRSGD / FusedBPRAdam.prepare); without the look-ahead: the same model bit for bit
         plain = ra.BPR({**cfg, 'train': dict(cfg['train'], fused_prefetch=False)})
         plain.fit(trn, val)
         assert torch.equal(plain.item_encoder.weight, model.item_encoder.weight)

@@ -846,3 +846,37 @@ def test_prefetched_sgd_steps_equal_the_plain_sequence(ra, kind):
             assert torch.equal(iw_, ig) and torch.equal(lw, lg)
         assert torch.equal(item1, item0) and torch.equal(user1, user0)
     assert not torch.equal(item0, iw.to(DEV))
+
+
+@pytest.mark.parametrize('kind', ['uniform', 'popular'])
+def test_prefetched_adam_steps_equal_the_plain_sequence(ra, kind):
+    """FusedBPRAdam.prepare / step_prepared (sampling + item-side sort one batch ahead on a side stream, apply pass through
+    rsa_adam_rows_presorted) == the same sequence of FusedBPRAdam.step calls: losses, negatives, weights and both moment
+    tables bit for bit."""
+    N, U, d, B, n, steps = 50_021, 3001, 128, 4096, 64, 4
+    iw, uw = _tables(N, U, d, B)
+    g = torch.Generator().manual_seed(8)
+    batches = [(torch.randint(1, U, (B,), generator=g).to(DEV), torch.randint(1, N, (B,), generator=g).to(DEV)) for _ in range(steps)]
+    if kind == 'uniform':
+        sampler = ra.UniformSampler(N)
+    else:
+        sampler = ra.PopularSamplerModel((torch.rand(N, generator=g) ** 6 * 1000).long()).to(DEV)
+    item0, user0 = iw.to(DEV).clone(), uw.to(DEV).clone()
+    torch.manual_seed(6)
+    plain = ra.fused.FusedBPRAdam(item0, user0, lr=0.01)
+    want = [plain.step(n, user_ids=u, pos_ids=p, sampler=sampler) for u, p in batches]
+    want = [(l.clone(), i.clone()) for l, i in want]
+    item1, user1 = iw.to(DEV).clone(), uw.to(DEV).clone()
+    torch.manual_seed(6)
+    ahead = ra.fused.FusedBPRAdam(item1, user1, lr=0.01)
+    ticket = ahead.prepare(n, user_ids=batches[0][0], pos_ids=batches[0][1], sampler=sampler)
+    for k in range(steps):
+        nxt = ahead.prepare(n, user_ids=batches[k + 1][0], pos_ids=batches[k + 1][1], sampler=sampler) if k + 1 < steps else None
+        loss, ids = ahead.step_prepared(ticket)
+        assert torch.equal(ids, want[k][1]) and torch.equal(loss, want[k][0])
+        ticket = nxt
+    torch.cuda.synchronize()
+    assert torch.equal(item1, item0) and torch.equal(user1, user0) and not torch.equal(item0, iw.to(DEV))
+    for k in ('im', 'iv', 'um', 'uv'):
+        assert torch.equal(ahead.state[k], plain.state[k])
+
