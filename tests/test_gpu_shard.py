@@ -505,7 +505,8 @@ def test_world1_rccl_sharded_training_step():
         dist.destroy_process_group()
 
 
-def test_launch_entry_point_world1_loss_decreases():
+@pytest.mark.parametrize('layout', ['block', 'interleaved'])
+def test_launch_entry_point_world1_loss_decreases(layout):
     """recstudio_amd.launch (the multi-GPU training entry point) as a single rank: runs, and SGD on the sharded
     step lowers the BPR loss on a tiny synthetic problem."""
     from recstudio_amd import launch
@@ -513,7 +514,7 @@ def test_launch_entry_point_world1_loss_decreases():
     for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK'):
         os.environ.pop(k, None)
     losses = launch.main(['--items', '2001', '--users', '301', '--dim', '64', '--neg', '16', '--batch', '512',
-                          '--steps', '61', '--lr', '100.0'])
+                          '--steps', '61', '--lr', '100.0', '--layout', layout])
     assert losses[0] == pytest.approx(0.6931, abs=2e-3) and losses[-1] < losses[0] - 0.05
 
 
