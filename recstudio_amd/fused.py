@@ -352,6 +352,10 @@ class PrefetchedBPRSGD:
         self.side = torch.cuda.Stream(device=self.iw.device)
         self.step_scale = torch.full((1,), -float(lr), dtype=torch.float32, device=self.iw.device)
 
+    def set_lr(self, lr):
+        """New learning rate from the next ``step`` on (call between steps, e.g. a scheduler at the end of an epoch)."""
+        self.step_scale.fill_(-float(lr))
+
     def prepare(self, user_ids, pos_ids):
         main = torch.cuda.current_stream(self.iw.device)
         self.side.wait_stream(main)                   # the batch tensors may have been produced on the main stream

@@ -694,9 +694,11 @@ class BaseRetriever(torch.nn.Module):
             optimizer = self._make_optimizer(params) if params else None
         if not fused:
             self.item_encoder.weight.grad = trainer.item_grad_local       # the exchange accumulates into the block's .grad
-        if fused and tr.get('scheduler'):
-            raise NotImplementedError("multi-GPU fit: train.scheduler needs the torch optimizer (train.fused_optimizer: None)")
-        scheduler = self._get_scheduler(optimizer)
+        sched_opt = optimizer
+        if fused and embed_tower and tr.get('scheduler'):      # no torch optimizer at all: a stand-in carries the rate
+            sched_opt = torch.optim.SGD([torch.nn.Parameter(torch.zeros(1))], lr=lr)
+            sched_opt.step()                                   # (a no-op; the schedulers warn when they step first)
+        scheduler = self._get_scheduler(sched_opt)
         sh['trainer'] = trainer
         val_metrics = self.config['eval']['val_metrics']
         cutoff = self.config['eval']['cutoff']
@@ -739,6 +741,8 @@ class BaseRetriever(torch.nn.Module):
                 else:
                     bad += 1
             self._step_scheduler(scheduler, log)      # (the all-reduced loss / metric: the same decision on every rank)
+            if fused and scheduler is not None:
+                trainer.set_sgd_lr(log['lr'])
             self.logged_metrics = log
             if rank == 0:
                 self.logger.info(' '.join(f'{k}={v:.4f}' if isinstance(v, float) else f'{k}={v}' for k, v in log.items()))
@@ -793,7 +797,13 @@ class BaseRetriever(torch.nn.Module):
         optimizer = self._get_optimizer()
         tr = self.config['train']
         fused_step = self._fused_optimizer_step(tr)
-        scheduler = None if fused_step is not None else self._get_scheduler(optimizer)
+        sched_opt = optimizer
+        if fused_step is not None:
+            # train.scheduler with a fused optimizer: the reference's scheduler objects drive a stand-in optimizer whose
+            # learning rate is handed to the kernels after every epoch
+            sched_opt = torch.optim.SGD([torch.nn.Parameter(torch.zeros(1))], lr=tr['learning_rate'])
+            sched_opt.step()                                   # (a no-op; the schedulers warn when they step first)
+        scheduler = self._get_scheduler(sched_opt)
         val_metrics = self.config['eval']['val_metrics']
         cutoff = self.config['eval']['cutoff']
         cutoff0 = cutoff[0] if isinstance(cutoff, list) else cutoff
@@ -845,6 +855,8 @@ class BaseRetriever(torch.nn.Module):
                 else:
                     bad += 1
             self._step_scheduler(scheduler, log)
+            if fused_step is not None and scheduler is not None:
+                fused_step.set_lr(log['lr'])
             self.logged_metrics = log
             self.logger.info(' '.join(f'{k}={v:.4f}' if isinstance(v, float) else f'{k}={v}' for k, v in log.items()))
             if val_data is not None and bad >= tr['early_stop_patience']:
@@ -866,19 +878,28 @@ class BaseRetriever(torch.nn.Module):
         ok = (type(self.loss_fn) is BPRLoss and self.sampler is not None and self._fused_ok()
               and type(self.score_func) is InnerProductScorer and isinstance(self.neg_count, int) and self.neg_count % 64 == 0
               and isinstance(self.query_encoder, torch.nn.Embedding) and self.item_encoder.weight.shape[1] in (64, 128, 256)
-              and not tr.get('weight_decay') and tr.get('grad_clip_norm') is None and not tr.get('scheduler'))
+              and not tr.get('weight_decay') and tr.get('grad_clip_norm') is None)
         if not ok:
             raise NotImplementedError("train.fused_optimizer needs the stock BPR two-tower configuration "
                                       "(see BaseRetriever._fused_optimizer_step)")
         from .fused import FusedBPRAdam, bpr_sgd_step
         iw, uw, lr = self.item_encoder.weight, self.query_encoder.weight, tr['learning_rate']
         if kind == 'sgd':
+            rate = {'lr': lr}
+
             def sgd_step(b):
-                return bpr_sgd_step(iw, uw, self.neg_count, lr, user_ids=b[self.fuid], pos_ids=b[self.fiid], sampler=self.sampler)[0]
+                return bpr_sgd_step(iw, uw, self.neg_count, rate['lr'], user_ids=b[self.fuid], pos_ids=b[self.fiid],
+                                    sampler=self.sampler)[0]
             sgd_step.stepper = None
             if self.neg_count == 64 and tr.get('fused_prefetch', True) and self.fiid is not None:
                 from .fused import PrefetchedBPRSGD
                 sgd_step.stepper = PrefetchedBPRSGD(iw, uw, self.neg_count, lr, self.sampler)
+
+            def set_lr(new):
+                rate['lr'] = float(new)
+                if sgd_step.stepper is not None:
+                    sgd_step.stepper.set_lr(new)
+            sgd_step.set_lr = set_lr
             return sgd_step
         if kind == 'adam':
             opt = FusedBPRAdam(iw, uw, lr=lr)
@@ -893,6 +914,7 @@ class BaseRetriever(torch.nn.Module):
                         return opt.prepare(self.neg_count, user_ids=uid, pos_ids=pos, sampler=self.sampler)
                     step = staticmethod(opt.step_prepared)
                 adam_step.stepper = _Ahead
+            adam_step.set_lr = lambda new: setattr(opt, 'lr', float(new))
             return adam_step
         raise ValueError(f"train.fused_optimizer must be 'sgd' or 'adam', got {kind!r}")
 

@@ -869,6 +869,13 @@ class ShardedRetriever:
             self.item_grad_local = table.item_local
             self.item_scale = torch.full((1,), -float(item_sgd_lr), dtype=torch.float32, device=table.item_local.device)
 
+    def set_sgd_lr(self, lr):
+        """New learning rate for the in-place SGD updates (a scheduler between epochs)."""
+        if self.item_scale is not None:
+            self.item_scale.fill_(-float(lr))
+        if self.query_sgd_lr is not None:
+            self.query_sgd_lr = float(lr)
+
     def _fused_loss_kind(self):
         """'bpr' / 'ssm' when the loss can be evaluated by the home kernel of the fixed exchange (this package's stock
         BPRLoss / SampledSoftmaxLoss, exact types), else None (the loss plugin runs under autograd)."""

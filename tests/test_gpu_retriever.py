@@ -169,8 +169,23 @@ def test_fit_steps_the_configured_scheduler(ra, golden, name, lrs):
         np.testing.assert_allclose(got, lrs, rtol=6e-3)        # (the log prints four decimals)
     else:
         assert all(abs(v - 0.01) < 1e-9 for v in got)          # three improving epochs: the plateau scheduler holds the rate
-    with pytest.raises(NotImplementedError):                   # the in-kernel optimizer step has no scheduler hook
+    with pytest.raises(NotImplementedError):                   # the in-kernel optimizer steps: no weight decay / clipping
         ra.BPR({'train': dict(cfg['train'], fused_optimizer='sgd')}).fit(trn, val)
+    # ... but they follow the scheduler: the rate of the stand-in optimizer is handed to the kernels after every epoch
+    if name == 'exponential':
+        base = dict(cfg['train'], fused_optimizer='sgd', weight_decay=0.0, grad_clip_norm=None, learning_rate=20.0, epochs=2)
+        seen.clear()
+        sched = ra.BPR({'train': base, 'eval': cfg['eval']})
+        sched.logger.addHandler(Grab())
+        sched.logger.setLevel(logging.INFO)
+        sched.fit(trn, val)
+        got = [float(m.split('lr=')[1].split()[0]) for m in seen if 'lr=' in m]
+        np.testing.assert_allclose(got, [19.6, 19.208], rtol=1e-4)
+        const = ra.BPR({'train': dict(base, scheduler=None), 'eval': cfg['eval']})
+        const.fit(trn, val)
+        # epoch 0 ran at the same rate in both; epoch 1 at 19.6 vs 20: different weights, same order of magnitude
+        diff = (sched.item_encoder.weight - const.item_encoder.weight).abs().max()
+        assert 0 < float(diff) < 0.1 * float(const.item_encoder.weight.abs().max())
 
 
 def test_sasrec_fit_ml100k(ra, golden):

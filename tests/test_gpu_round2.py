@@ -458,7 +458,8 @@ def test_config2_sasrec_d128_L50_ssm_n256_training_step(ra, golden):
     rel_close(ga.cpu(), want_g.cpu(), rtol=1e-4, atol=1e-5)
 
 
-def test_config3_per_gpu_shape_properties(ra):
+@pytest.mark.parametrize('layout', ['block', 'interleaved'])
+def test_config3_per_gpu_shape_properties(ra, layout):
     """configs[3] at the per-GPU shape of an 8-way shard: 12.5 M-row block (6.4 GB), n = 1024, B = 4096.
     The negatives drawn INSIDE the routing launch are bit-exact vs torch.randint over the GLOBAL id range (this rank's
     rows of the job-wide call), every element lands once in its owner's fixed-capacity segment without overflow at the
@@ -466,9 +467,9 @@ def test_config3_per_gpu_shape_properties(ra):
     scores find their way home through the slots (BPR loss of the home kernel == the stand-alone loss kernel)."""
     from recstudio_amd.shard import HipBackend, RowShardPlan
     n_global, world, B, n, d, rank = 100_000_001, 8, 4096, 1024, 128, 3
-    plan = RowShardPlan(n_global, world)
+    plan = RowShardPlan(n_global, world, layout=layout)          # contiguous 12.5 M-row blocks, or rows r, r + 8, ...
     rows = plan.rows_per_shard
-    assert rows == 12_500_001
+    assert rows == 12_500_001 and plan.n_local(0) == rows
     gen = torch.Generator(device=DEV).manual_seed(1)
     block = torch.empty(rows, d, device=DEV).normal_(0, 0.02, generator=gen)
     q_all = torch.empty(world * B, d, device=DEV).normal_(0, 0.02, generator=gen)
@@ -493,7 +494,7 @@ def test_config3_per_gpu_shape_properties(ra):
     assert torch.equal(send[:, 0].cpu(), counts) and int(send[:, 1].sum()) == 0        # headers: live counts, nothing dropped
     assert (slot_of >= 0).all() and slot_of.unique().numel() == B * (n + 1)
     keys = r['send'][slot_of]
-    assert torch.equal(keys & 0xffffffff, ids_flat % rows) and torch.equal(slot_of // stride, ids_flat // rows)
+    assert torch.equal(keys & 0xffffffff, plan.local(ids_flat)) and torch.equal(slot_of // stride, plan.owner(ids_flat))
     assert torch.equal(keys >> 32, (rank * B + torch.arange(B, device=DEV)).repeat_interleave(n + 1))
     # owner side: this rank plays owner 5 (rows [5 * rows, 6 * rows)); as if all 8 sources had sent this same segment
     seg = send[5].contiguous()
@@ -511,7 +512,7 @@ def test_config3_per_gpu_shape_properties(ra):
     # BPR loss + gradients == the stand-alone loss kernel on the gathered scores
     fake = (r['send'] & 0xffffffff).float()
     out = hb.home(fake, r['slot_of'], B, n)
-    want_home = (ids_flat % rows).view(B, n + 1).float()
+    want_home = plan.local(ids_flat).view(B, n + 1).float()
     assert torch.equal(out['pos_score'], want_home[:, 0]) and torch.equal(out['neg_score'], want_home[:, 1:])
     sc_rand = torch.randn(world * stride, device=DEV)
     o1 = hb.home(sc_rand, r['slot_of'], B, n)

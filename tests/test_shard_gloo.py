@@ -713,3 +713,27 @@ def test_fit_two_ranks_clips_the_global_gradient_norm(tmp_path):
     mp.spawn(_fit_worker, args=(1, _free_port(), str(tmp_path / 'x'), 1, 2048, dict(extra, grad_clip_norm=None)), nprocs=1, join=True)
     free = torch.load(tmp_path / 'x' / 'w1r0.pt', weights_only=False)
     assert (free['item'] - one['item']).abs().max() > 1e-4           # clipping really was in force
+
+
+def test_fit_two_ranks_fused_sgd_follows_the_scheduler(tmp_path):
+    """``train.fused_optimizer: 'sgd'`` (item rows updated inside the backward exchange, user rows through the row-sparse
+    exchange) with ``train.scheduler: 'exponential'``: the rate the kernels get after each epoch is the scheduler's, two ranks
+    reproduce the one-rank run, and the second epoch really ran at another rate."""
+    extra = {'fused_optimizer': 'sgd', 'scheduler': 'exponential', 'learning_rate': 200.0}
+    for world in (1, 2):
+        mp.spawn(_fit_worker, args=(world, _free_port(), str(tmp_path), 2, 4096, extra), nprocs=world, join=True)
+    one = torch.load(tmp_path / 'w1r0.pt', weights_only=False)
+    two = [torch.load(tmp_path / f'w2r{r}.pt', weights_only=False) for r in range(2)]
+    assert abs(one['val']['lr'] - 200.0 * 0.98 ** 2) < 1e-4
+    for t in two:
+        np.testing.assert_allclose(t['losses'].numpy(), one['losses'].numpy(), rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(t['tower'].numpy(), one['tower'].numpy(), rtol=1e-4, atol=1e-6)
+    items = torch.cat([two[0]['item'], two[1]['item']])
+    np.testing.assert_allclose(items.numpy(), one['item'].numpy(), rtol=1e-4, atol=1e-6)
+    os.makedirs(tmp_path / 'c')
+    mp.spawn(_fit_worker, args=(1, _free_port(), str(tmp_path / 'c'), 2, 4096, dict(extra, scheduler=None)), nprocs=1, join=True)
+    const = torch.load(tmp_path / 'c' / 'w1r0.pt', weights_only=False)
+    n1 = one['losses'].numel() // 2
+    assert torch.equal(const['losses'][:n1], one['losses'][:n1])                 # the first epoch: the same rate
+    assert (const['item'] - one['item']).abs().max() > 1e-5                      # the second: 196 instead of 200
+
