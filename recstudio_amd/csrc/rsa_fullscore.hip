@@ -952,7 +952,7 @@ extern "C" int rsa_fullscore(const float* item_table, int64_t n_items, int32_t d
   float2* part = reinterpret_cast<float2*>(ws);
   ws += align256(n_query * splits * (int64_t)sizeof(float2));
   float2* lp = lse ? part : nullptr;
-  const FilterArgs no_filter{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, item_aux, query_aux};
+  const FilterArgs no_filter{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, item_aux, query_aux, nullptr};
 
   if (pl.filter) {
     float* sample = reinterpret_cast<float*>(ws);      ws += align256(n_query * pl.sample_items * 4);
@@ -982,7 +982,7 @@ extern "C" int rsa_fullscore(const float* item_table, int64_t n_items, int32_t d
       rsa::set_error("rsa_fullscore: memset failed");
       return RSA_ERR_HIP;
     }
-    const FilterArgs flt{thr, seg_cnt, cand_val, cand_idx, nullptr, nullptr, ovf_cnt, ovf_val, ovf_idx, item_aux, query_aux};
+    const FilterArgs flt{thr, seg_cnt, cand_val, cand_idx, nullptr, nullptr, ovf_cnt, ovf_val, ovf_idx, item_aux, query_aux, nullptr};
     gemm_dispatch(dim, score_mode, dim3((unsigned)splits_used, groups), s, item_table, n_items, query, n_query, nullptr, n_cols, lp,
                   (int)splits_used, per, 1, n_cols, flt);
     RSA_CHECK_LAUNCH("rsa_fullscore(gemm+filter)");
@@ -1035,7 +1035,7 @@ extern "C" int rsa_fullscore_softmax(const float* item_table, int64_t n_items, i
   const int64_t splits = fullscore_splits(n_query, n_cols);
   const int64_t per = ((n_cols + splits - 1) / splits + TI - 1) / TI * TI;
   const int64_t splits_used = (n_cols + per - 1) / per;
-  const FilterArgs ep{nullptr, nullptr, nullptr, nullptr, lse, row_scale, nullptr, nullptr, nullptr, nullptr, nullptr};
+  const FilterArgs ep{nullptr, nullptr, nullptr, nullptr, lse, row_scale, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   gemm_dispatch(dim, RSA_SCORE_IP, dim3((unsigned)splits_used, groups), (hipStream_t)stream, item_table, n_items, query, n_query, probs,
                 n_cols, nullptr, (int)splits_used, per, 1, n_cols, ep);
   RSA_CHECK_LAUNCH("rsa_fullscore_softmax");

@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256) void mean_rows_stage1(const float* __restrict_
 __global__ __launch_bounds__(256) void mean_rows_stage2(const float* __restrict__ partial, int n_part, int64_t M,
                                                         const int32_t* __restrict__ denom, float* __restrict__ out) {
   __shared__ float part[4];
-  float acc = threadIdx.x < n_part ? partial[threadIdx.x] : 0.f;
+  float acc = (int)threadIdx.x < n_part ? partial[threadIdx.x] : 0.f;
   acc = group_sum<64>(acc);
   if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
   __syncthreads();

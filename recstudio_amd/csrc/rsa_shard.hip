@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256) void shard_count_kernel(RouteShape sh, int32_t
     for (int k = 0; k < ROUTE_EPT; ++k) wave_count<false>(h, g[k] >= 0, g[k], sh.G == 1);
   }
   __syncthreads();
-  if (threadIdx.x < sh.G && h[threadIdx.x]) atomicAdd(&counts[threadIdx.x], h[threadIdx.x]);
+  if ((int)threadIdx.x < sh.G && h[threadIdx.x]) atomicAdd(&counts[threadIdx.x], h[threadIdx.x]);
 }
 
 // Counting-sort scatter (exact exchange).  Each workgroup owns a contiguous chunk of ROUTE_CHUNK elements, held in
@@ -172,7 +172,7 @@ __global__ __launch_bounds__(256) void shard_route_kernel(RouteShape sh, int64_t
 #pragma unroll
   for (int k = 0; k < ROUTE_EPT; ++k) wave_count<false>(cnt, g[k] >= 0, g[k], sh.G == 1);
   __syncthreads();
-  if (threadIdx.x < sh.G) {
+  if ((int)threadIdx.x < sh.G) {
     base[threadIdx.x] = cnt[threadIdx.x] ? atomicAdd(&cursor[threadIdx.x], cnt[threadIdx.x]) : 0;
     cnt[threadIdx.x] = 0;
   }
@@ -377,7 +377,7 @@ __global__ __launch_bounds__(256) void shard_sample_route_kernel(const RouteV2 a
     if (valid) gl[k] |= ls;
   }
   __syncthreads();
-  if (threadIdx.x < a.G) {
+  if ((int)threadIdx.x < a.G) {
     const int32_t c = cnt[threadIdx.x];
     base[threadIdx.x] = c ? atomicAdd(&a.cursors[((slice * a.G + threadIdx.x) * a.n_banks + bank) * CURSOR_PAD], c) : 0;
   }

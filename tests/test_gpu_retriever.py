@@ -185,7 +185,7 @@ def test_fit_steps_the_configured_scheduler(ra, golden, name, lrs):
         const = ra.BPR({'train': dict(base, scheduler=None), 'eval': cfg['eval']})
         const.fit(trn, val)
         # epoch 0 ran at the same rate in both; epoch 1 at 19.6 vs 20: different weights, same order of magnitude
-        diff = (sched.item_encoder.weight - const.item_encoder.weight).abs().max()
+        diff = (sched.item_encoder.weight - const.item_encoder.weight).detach().abs().max()
         assert 0 < float(diff) < 0.1 * float(const.item_encoder.weight.abs().max())
 
 
