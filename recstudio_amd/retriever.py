@@ -601,6 +601,14 @@ class BaseRetriever(torch.nn.Module):
             td.init_process_group('nccl', device_id=torch.device('cuda', local))
         if td.is_initialized() and td.get_world_size() > 1:
             return td
+        gpu = self.config['train'].get('gpu', 1)
+        n_gpu = len(gpu) if isinstance(gpu, (list, tuple)) else (gpu if isinstance(gpu, int) else 1)
+        if n_gpu > 1:
+            # the reference would now replicate the model over the gpu list inside this process (accelerator 'dp') or raise
+            # ('ddp'); here multi-GPU training is one process per GPU
+            self.logger.warning(f"train.gpu asks for {n_gpu} GPUs but this is a single process: training on one GPU.  Start the "
+                                f"same script with `python -m torch.distributed.run --nproc-per-node {n_gpu} --master-addr "
+                                f"127.0.0.1 script.py` and fit() shards the item table over the ranks.")
         return None
 
     def _setup_shard(self, train_data, dist, backend=None, device=None):
