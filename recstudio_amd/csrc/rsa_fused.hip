@@ -172,13 +172,20 @@ __device__ __forceinline__ void fold(float (&d)[L], int sub, int step) {
 #ifndef RSA_FWD_BATCH
 #define RSA_FWD_BATCH 8
 #endif
+#ifndef RSA_SEG_BATCH
+#define RSA_SEG_BATCH 4      // rows per batch when every row has its own query row (QU = false: the sharded step's scoring kernel): 123 VGPRs =
+                             // 4 waves/SIMD.  With 8 (the query-uniform form's batch) the second fragment per row made it 129 VGPRs = 3 waves:
+                             // in-process A/B (tools/exp_seg.py) 382.5 -> 354.0 us at n = 1024, B = 4096; 399.5 -> 369.8 at n = 64, B = 65536;
+                             // 4 waves forced on the 8-row form (24 bytes of scratch): 372; 2-row batches: 460; 5 waves (96 VGPRs, scratch): 445
+#endif
 template <int LPR, bool GENERIC, bool COS, bool QU, bool NT>
 __device__ __forceinline__ void tile_rows(const float* __restrict__ table, int D, int32_t id_lane,
                                           const float* __restrict__ query, int32_t qrow_lane,
                                           const Frag<LPR, GENERIC>& qf_uniform, float& dot, float& inorm2,
                                           float& qnorm2) {
   using F = Frag<LPR, GENERIC>;
-  constexpr int BATCH = GENERIC ? 2 : (LPR < RSA_FWD_BATCH ? LPR : RSA_FWD_BATCH);
+  constexpr int B0 = QU ? RSA_FWD_BATCH : RSA_SEG_BATCH;     // per-row queries: every row brings a second fragment
+  constexpr int BATCH = GENERIC ? 2 : (LPR < B0 ? LPR : B0);
   constexpr int NB = LPR / BATCH;
   constexpr int NBUF = (RSA_FWD_PIN == 2) ? 2 : 1;
   const int lane = lane_id();
@@ -389,7 +396,8 @@ __device__ __forceinline__ float finish_score(int mode, float dot, float inorm2,
 #define RSA_FWD_MIN_WAVES 1
 #endif
 #ifndef RSA_SSM_BATCH
-#define RSA_SSM_BATCH 4     // double-buffered: 2 * 4 row loads in flight per wave, 141 VGPRs at d = 128 (8: 180)
+#define RSA_SSM_BATCH 2     // double-buffered: 2 * 2 row loads in flight per wave, 122 VGPRs at d = 128 = 4 waves/SIMD (4: 142 = 3 waves;
+                            // in-process A/B at n = 256, B = 8192 with the query gradient: 197.4 vs 205.6 us; 8: 180)
 #endif
 
 #ifndef RSA_FWD_GRID_CAP
@@ -403,11 +411,18 @@ __device__ __forceinline__ float finish_score(int mode, float dot, float inorm2,
 #ifndef RSA_PIPE_MAX_TILES
 #define RSA_PIPE_MAX_TILES 32768
 #endif
+#ifndef RSA_PIPE_BATCH
+#define RSA_PIPE_BATCH 8
+#endif
 #ifndef RSA_UPD_MIN_WAVES
 #define RSA_UPD_MIN_WAVES 4      // 128 VGPRs (48 bytes of scratch at d = 128): 1-1.5 % faster than 145 VGPRs at 3 waves/SIMD
 #endif
+#ifndef RSA_SEG_MIN_WAVES
+#define RSA_SEG_MIN_WAVES 1
+#endif
 template <int LPR, bool GENERIC, bool COS, bool QU, bool NT, bool QG = false, bool UPD = false, int PIPE = 0>
-__global__ __launch_bounds__(256, UPD ? RSA_UPD_MIN_WAVES : (QG ? RSA_QG_MIN_WAVES : RSA_FWD_MIN_WAVES)) void fused_fwd_kernel(const FwdParams p) {
+__global__ __launch_bounds__(256, UPD ? RSA_UPD_MIN_WAVES : (QG ? RSA_QG_MIN_WAVES : ((!QU && !COS && !GENERIC) ? RSA_SEG_MIN_WAVES : RSA_FWD_MIN_WAVES)))
+void fused_fwd_kernel(const FwdParams p) {
   using F = Frag<LPR, GENERIC>;
   const int lane = lane_id();
   const int sub = lane % LPR;
@@ -723,10 +738,10 @@ __device__ __forceinline__ void tile_rows_ssm(const float* __restrict__ table, i
 }
 
 #ifndef RSA_SSM_MIN_WAVES
-#define RSA_SSM_MIN_WAVES 3
+#define RSA_SSM_MIN_WAVES 1      // (4 with 4-row batches: 128 VGPRs + 40 bytes of scratch, no faster than 3 waves)
 #endif
 template <int LPR, bool NT, bool QG>
-__global__ __launch_bounds__(256) void fused_ssm_kernel(const FwdParams p) {
+__global__ __launch_bounds__(256, QG ? RSA_SSM_MIN_WAVES : 1) void fused_ssm_kernel(const FwdParams p) {
   using F = Frag<LPR, false>;
   constexpr int D = LPR * 4;
   const int lane = lane_id();
@@ -842,8 +857,11 @@ __global__ __launch_bounds__(256) void fused_ssm_kernel(const FwdParams p) {
 #ifndef RSA_WALK_TRANSPOSE
 #define RSA_WALK_TRANSPOSE 0     // 1: forward-only tiles through the transposed fold of tile_rows instead of butterfly sums
 #endif
+#ifndef RSA_WALK_MIN_WAVES
+#define RSA_WALK_MIN_WAVES 4      // the query-gradient form at d = 128 with streaming loads: 130 VGPRs = 3 waves/SIMD without it
+#endif
 template <int LPR, bool NT, bool QG>
-__global__ __launch_bounds__(256) void fused_bpr_walk_kernel(const FwdParams p, const int wpq_log2) {
+__global__ __launch_bounds__(256, QG ? RSA_WALK_MIN_WAVES : 1) void fused_bpr_walk_kernel(const FwdParams p, const int wpq_log2) {
   using F = Frag<LPR, false>;
   constexpr int D = LPR * 4;
   __shared__ float s_sum[4][2];
@@ -1018,8 +1036,8 @@ static void launch_fwd2(const FwdParams& p, dim3 grid, dim3 block, hipStream_t s
       return;
     }
     if (((p.numel + 63) >> 6) <= RSA_PIPE_MAX_TILES) {      // small / medium launch: the butterfly tile
-      if (nt) hipLaunchKernelGGL((fused_fwd_kernel<LPR, GENERIC, COS, QU, true, false, false, 8>), grid, block, 0, stream, p);
-      else hipLaunchKernelGGL((fused_fwd_kernel<LPR, GENERIC, COS, QU, false, false, false, 8>), grid, block, 0, stream, p);
+      if (nt) hipLaunchKernelGGL((fused_fwd_kernel<LPR, GENERIC, COS, QU, true, false, false, RSA_PIPE_BATCH>), grid, block, 0, stream, p);
+      else hipLaunchKernelGGL((fused_fwd_kernel<LPR, GENERIC, COS, QU, false, false, false, RSA_PIPE_BATCH>), grid, block, 0, stream, p);
       return;
     }
   }
