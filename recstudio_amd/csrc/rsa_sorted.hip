@@ -16,8 +16,11 @@
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
 
+// rows requested ahead by the apply pass.  4: 78 VGPRs at d = 128 = 6 waves/SIMD; 8: 110 = 4 waves.  In-process A/B
+// (tools/exp_sorted_ab.py, us per launch, 4 vs 8): headline shape all elements 836.2 / 837.7, solo rows skipped 343.7 / 350.4;
+// the sharded backward's scatters onto 4096 query rows 476.5 / 485.5 and onto item rows 839.9 / 843.0; 16 (179 VGPRs): 2-3 x slower
 #ifndef RSA_SORTED_UNROLL
-#define RSA_SORTED_UNROLL 8
+#define RSA_SORTED_UNROLL 4
 #endif
 
 namespace rsa {
@@ -84,8 +87,11 @@ enum { META_LEAD_KEY = 0, META_LEAD_FULL = 1, META_TRAIL_KEY = 2, META_STRIDE = 
 
 // One wave per chunk of 64 sorted elements.  Runs that begin and end inside the chunk are applied here; the open
 // leading / trailing segments leave their partial sums in lead_part / trail_part [chunk, D] for sorted_finish_kernel.
+#ifndef RSA_SORTED_MIN_WAVES
+#define RSA_SORTED_MIN_WAVES 1
+#endif
 template <int NDW>   // dwords per lane per row: D = 64 * NDW
-__global__ __launch_bounds__(256) void sorted_apply_kernel(const int32_t* __restrict__ keys, const int32_t* __restrict__ vals,
+__global__ __launch_bounds__(256, RSA_SORTED_MIN_WAVES) void sorted_apply_kernel(const int32_t* __restrict__ keys, const int32_t* __restrict__ vals,
                                                            int64_t total, const float* __restrict__ query,
                                                            const int64_t* __restrict__ query_index, int n, int has_pos,
                                                            const float* __restrict__ dpos, const float* __restrict__ dneg,
