@@ -15,9 +15,8 @@ uid = torch.randint(1, U, (B,), device=dev, generator=g)
 pos = torch.randint(1, N, (B,), device=dev, generator=g)
 tbl = shard.ShardedItemTable(item, shard.RowShardPlan(N, 1), 0, dist, chunks=int(os.environ.get('CHUNKS', 1)))
 smp = ra.UniformSampler(N)
-def step():
-    o = tbl.sample_and_score(user, uid, pos, n, smp)
-    return ra.ops.pairwise_loss(nat.LOSS_BPR, o['pos_score'], o['neg_score'], want_grad=True)
+def step():        # the bench's sharded_world1 step
+    return tbl.sample_and_score(user, uid, pos, n, smp, fused_loss='bpr', want_ids=False, want_grad=True)
 for _ in range(20): step()
 torch.cuda.synchronize()
 pr = cProfile.Profile()
@@ -26,5 +25,5 @@ for _ in range(300): step()
 torch.cuda.synchronize()
 pr.disable()
 st = pstats.Stats(pr)
-st.sort_stats('cumulative').print_stats(35)
+st.sort_stats('cumulative').print_stats(45)
 dist.destroy_process_group()

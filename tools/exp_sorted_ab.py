@@ -48,11 +48,23 @@ for spec in sys.argv[1:]:
     name, path = spec.split('=')
     h = ctypes.CDLL(path)
     h.rsa_scatter_rows_presorted.restype, h.rsa_scatter_rows_presorted.argtypes = nat.SIGNATURES['rsa_scatter_rows_presorted']
+    h.rsa_adam_rows_presorted.restype, h.rsa_adam_rows_presorted.argtypes = nat.SIGNATURES['rsa_adam_rows_presorted']
     libs[name] = h
 stream = ra.ops._stream()
 
 
+ADAM = os.environ.get('ADAM') == '1'
+if ADAM:
+    m_state, v_state = torch.zeros_like(target), torch.zeros_like(target)
+
+
 def launch(h):
+    if ADAM:
+        rc = h.rsa_adam_rows_presorted(ptr(query), ptr(qidx), query.shape[0], d, int(pos is not None), M, n, ptr(dpos), ptr(dneg),
+                                       None, N, 0, ptr(target), ptr(m_state), ptr(v_state), 1e-3, 0.9, 0.999, 1e-8, 3, ptr(ws),
+                                       ws.numel(), stream)
+        assert rc == 0
+        return
     rc = h.rsa_scatter_rows_presorted(ptr(query), ptr(qidx), query.shape[0], d, int(pos is not None), M, n, ptr(dpos), ptr(dneg),
                                       ptr(up), N, 0, ptr(target), ptr(ws), ws.numel(), stream)
     assert rc == 0
