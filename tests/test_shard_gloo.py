@@ -663,7 +663,7 @@ def test_fit_two_ranks_equals_one_rank_on_ml100k(tmp_path):
     Adam state sharded, tower replicated, every rank on its half of each global batch, one job-wide negative stream) give
     the losses, ndcg@10 / recall@10 and weights of the one-rank run of the same global batch to 1e-5; the loss starts at
     ln 2 (xavier-initialised towers) and falls, the ranking beats chance after two epochs."""
-    epochs, batch_global = 2, 1024
+    epochs, batch_global = 2, 2048
     for world in (1, 2):
         mp.spawn(_fit_worker, args=(world, _free_port(), str(tmp_path), epochs, batch_global), nprocs=world, join=True)
     one = torch.load(tmp_path / 'w1r0.pt', weights_only=False)
