@@ -1,7 +1,7 @@
 """In-process A/B of the fused forward kernels between library builds: ONE set of tables and buffers, the call frozen by
 ops.FusedStep, alternating rounds of 50 launches through each library's rsa_fused_sample_gather_score (process-to-process
 placement noise is +-4 %; in one process the rounds repeat to +-0.2 %).
-usage: SHAPE=headline_pop|headline_uni|given|b4096|b16384|train|ssm|ssm_train|walk|walk_train|upd python tools/exp_fwd_ab.py name=lib.so ..."""
+usage: SHAPE=headline_pop|headline_uni|given|n1e8_uni|n1e8_pop|b4096|b16384|train|ssm|ssm_train|walk|walk_train|upd python tools/exp_fwd_ab.py name=lib.so ..."""
 import ctypes
 import json
 import os
@@ -31,7 +31,20 @@ user = torch.empty(U, d, device=dev).normal_(0, 0.02, generator=gen)
 N = 10_000_001
 n, B = 64, 65536
 kw = dict(fused_bpr=True)
-if shape in ('headline_pop', 'b4096', 'b16384', 'train', 'upd'):
+if shape in ('n1e8_uni', 'n1e8_pop'):
+    N = 100_000_001
+    if shape == 'n1e8_pop':
+        ps_path = '/tmp/rsa_ps_1e8.pt'
+        if os.path.exists(ps_path):
+            ps = torch.load(ps_path, weights_only=False).to(dev)
+        else:
+            ps = ra.PopularSamplerModel(zipf_counts(N, 100_000_000))
+            torch.save(ps, ps_path)
+            ps = ps.to(dev)
+        kw.update(sampler=nat.SAMPLER_POPULAR, **ps.lookup_kwargs())
+    else:
+        kw.update(sampler=nat.SAMPLER_UNIFORM)
+elif shape in ('headline_pop', 'b4096', 'b16384', 'train', 'upd'):
     B = {'b4096': 4096, 'b16384': 16384}.get(shape, 65536)
     ps_path = '/tmp/rsa_ps_1e7.pt'
     if os.path.exists(ps_path):
