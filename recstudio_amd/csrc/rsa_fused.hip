@@ -420,8 +420,11 @@ __device__ __forceinline__ float finish_score(int mode, float dot, float inorm2,
 #ifndef RSA_SEG_MIN_WAVES
 #define RSA_SEG_MIN_WAVES 1
 #endif
+#ifndef RSA_PIPE_MIN_WAVES
+#define RSA_PIPE_MIN_WAVES 1
+#endif
 template <int LPR, bool GENERIC, bool COS, bool QU, bool NT, bool QG = false, bool UPD = false, int PIPE = 0>
-__global__ __launch_bounds__(256, UPD ? RSA_UPD_MIN_WAVES : (QG ? RSA_QG_MIN_WAVES : ((!QU && !COS && !GENERIC) ? RSA_SEG_MIN_WAVES : RSA_FWD_MIN_WAVES)))
+__global__ __launch_bounds__(256, UPD ? RSA_UPD_MIN_WAVES : (QG ? RSA_QG_MIN_WAVES : ((!QU && !COS && !GENERIC) ? RSA_SEG_MIN_WAVES : (PIPE > 0 ? RSA_PIPE_MIN_WAVES : RSA_FWD_MIN_WAVES))))
 void fused_fwd_kernel(const FwdParams p) {
   using F = Frag<LPR, GENERIC>;
   const int lane = lane_id();
@@ -737,6 +740,9 @@ __device__ __forceinline__ void tile_rows_ssm(const float* __restrict__ table, i
   }
 }
 
+#ifndef RSA_SSM_PIPE_BATCH
+#define RSA_SSM_PIPE_BATCH RSA_QG_BATCH      // forward-only tiles of the SampledSoftmax kernel
+#endif
 #ifndef RSA_SSM_MIN_WAVES
 #define RSA_SSM_MIN_WAVES 1      // (4 with 4-row batches: 128 VGPRs + 40 bytes of scratch, no faster than 3 waves)
 #endif
@@ -799,7 +805,7 @@ __global__ __launch_bounds__(256, QG ? RSA_SSM_MIN_WAVES : 1) void fused_ssm_ker
       if constexpr (QG) {
         tile_rows_ssm<LPR, NT>(p.item_table, id, lq, has_lq, qf, dot, gm, qacc);
       } else {
-        tile_rows_pipe<LPR, NT>(p.item_table, id, qf, dot);      // (the transposed-fold tile needs 164 VGPRs in this frame)
+        tile_rows_pipe<LPR, NT, RSA_SSM_PIPE_BATCH>(p.item_table, id, qf, dot);      // (the transposed-fold tile needs 164 VGPRs in this frame)
       }
       st_out(&p.neg_score[e], dot);
       const float z = dot - lq;
@@ -857,11 +863,17 @@ __global__ __launch_bounds__(256, QG ? RSA_SSM_MIN_WAVES : 1) void fused_ssm_ker
 #ifndef RSA_WALK_TRANSPOSE
 #define RSA_WALK_TRANSPOSE 0     // 1: forward-only tiles through the transposed fold of tile_rows instead of butterfly sums
 #endif
+#ifndef RSA_WALK_PIPE_BATCH
+#define RSA_WALK_PIPE_BATCH RSA_QG_BATCH
+#endif
+#ifndef RSA_WALK_FWD_MIN_WAVES
+#define RSA_WALK_FWD_MIN_WAVES 1
+#endif
 #ifndef RSA_WALK_MIN_WAVES
 #define RSA_WALK_MIN_WAVES 4      // the query-gradient form at d = 128 with streaming loads: 130 VGPRs = 3 waves/SIMD without it
 #endif
 template <int LPR, bool NT, bool QG>
-__global__ __launch_bounds__(256, QG ? RSA_WALK_MIN_WAVES : 1) void fused_bpr_walk_kernel(const FwdParams p, const int wpq_log2) {
+__global__ __launch_bounds__(256, QG ? RSA_WALK_MIN_WAVES : RSA_WALK_FWD_MIN_WAVES) void fused_bpr_walk_kernel(const FwdParams p, const int wpq_log2) {
   using F = Frag<LPR, false>;
   constexpr int D = LPR * 4;
   __shared__ float s_sum[4][2];
@@ -919,7 +931,7 @@ __global__ __launch_bounds__(256, QG ? RSA_WALK_MIN_WAVES : 1) void fused_bpr_wa
           float in2, qn2;
           tile_rows<LPR, false, false, true, NT>(p.item_table, D, id, p.query, 0, qf, dot, in2, qn2);
         } else {
-          tile_rows_pipe<LPR, NT>(p.item_table, id, qf, dot);
+          tile_rows_pipe<LPR, NT, RSA_WALK_PIPE_BATCH>(p.item_table, id, qf, dot);
         }
         st_out(&p.neg_score[e], dot);
         const float xd = pos_s - dot;

@@ -60,8 +60,8 @@ elif shape in ('ssm', 'ssm_train'):
     N, n, B = 1_000_001, 256, 8192
     ps = ra.PopularSamplerModel(zipf_counts(N, 100_000_000)).to(dev)
     kw = dict(fused_loss='ssm', sampler=nat.SAMPLER_POPULAR, **ps.lookup_kwargs())
-elif shape in ('walk', 'walk_train'):
-    N, n, B = 12_500_001, 1024, 4096
+elif shape in ('walk', 'walk_train', 'walk_1e8'):
+    N, n, B = (100_000_001 if shape == 'walk_1e8' else 12_500_001), 1024, 4096
     kw.update(sampler=nat.SAMPLER_UNIFORM, want_mean=False)
 item = table(N)
 uid = torch.randint(1, U, (B,), device=dev, generator=gen)
