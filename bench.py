@@ -241,6 +241,8 @@ def main():
     ap.add_argument('--guide-log2', type=int, default=None, help='override the sampler guide-table size (experiments)')
     ap.add_argument('--pop-lookup', default='auto', choices=['auto', 'lines', 'lut', 'guide'],
                     help='inverse-CDF structure of the popularity sampler (experiments)')
+    ap.add_argument('--shard-layout', default='block', choices=['block', 'interleaved'],
+                    help='row ownership of the sharded table (--gpus N > 1): contiguous blocks, or rows r, r + N, ...')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-sweep', action='store_true')
     args = ap.parse_args()
@@ -694,10 +696,10 @@ def main():
         # JOB on every rank alone (a one-rank table: no collectives), MAX over ranks; `efficiency_vs_world1` = that time /
         # ms_per_step, i.e. the weak-scaling efficiency of the exchange itself, independent of the configs[1] N = 1 line.
         from recstudio_amd import shard
-        plan = shard.RowShardPlan(args.items, world)
-        lo, hi = plan.bounds(rank)
+        plan = shard.RowShardPlan(args.items, world, layout=args.shard_layout)
+        n_loc = plan.n_local(rank)
         g = torch.Generator(device=dev).manual_seed(7 + rank)
-        item_local = torch.empty(hi - lo, d, device=dev).normal_(0, 0.02, generator=g)
+        item_local = torch.empty(n_loc, d, device=dev).normal_(0, 0.02, generator=g)
         if rank == 0:
             item_local[0] = 0
         user = torch.empty(args.users, d, device=dev).normal_(0, 0.02, generator=torch.Generator(device=dev).manual_seed(3))
@@ -714,9 +716,9 @@ def main():
             return float(t.item())
 
         # ---- the world-1 reference, in this job: every rank alone on its own block (rows re-based to a one-rank plan)
-        solo_plan = shard.RowShardPlan(hi - lo, 1)
-        solo_pos = (pos % (hi - lo - 1)) + 1
-        solo_sampler = (ra.PopularSamplerModel(counts[lo:hi], lookup=args.pop_lookup) if popular else ra.UniformSampler(hi - lo)).to(dev)
+        solo_plan = shard.RowShardPlan(n_loc, 1)
+        solo_pos = (pos % (n_loc - 1)) + 1
+        solo_sampler = (ra.PopularSamplerModel(plan.take(counts, rank), lookup=args.pop_lookup) if popular else ra.UniformSampler(n_loc)).to(dev)
         solo_tbl = shard.ShardedItemTable(item_local, solo_plan, 0, dist, check_every=0)
         solo_step = make_step(solo_tbl, solo_sampler, uid, solo_pos, n)
         solo_step()
@@ -762,7 +764,7 @@ def main():
             'efficiency_vs_world1': round(ms_solo / ms_step, 4),
             'ranks_seen': int(dist.get_world_size()), 'backend': 'staged-gloo (test harness)' if staged else 'nccl (RCCL)',
             'rccl_version': rccl,
-            'exchange': {'mode': table.exchange, 'slack': table.slack, 'capacity_per_segment': table._cap.get((B, n, 1)),
+            'exchange': {'mode': table.exchange, 'layout': plan.layout, 'slack': table.slack, 'capacity_per_segment': table._cap.get((B, n, 1)),
                          'mean_per_owner': B * (n + 1) // world,
                          'what': 'equal-split all-to-all of fixed-capacity, self-describing segments ({live, dropped} header + '
                                  '8-byte keys); no split sizes on the host (one calibration launch before the timed region)'}})
