@@ -105,8 +105,10 @@ def rank_part(index, rank, world):
     out)."""
     n = index.shape[0]
     per = (n + world - 1) // world
-    if per * world != n:
-        index = torch.cat([index, index[:per * world - n]])
+    pad = per * world - n
+    if pad:
+        # (a batch shorter than the padding -- n = 3 on 8 ranks needs 5 more rows -- wraps around more than once)
+        index = torch.cat([index, index.repeat((pad + n - 1) // n)[:pad]])
     lo = rank * per
     return index[lo:lo + per], max(0, min(per, n - lo))
 

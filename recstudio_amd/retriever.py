@@ -634,6 +634,21 @@ class BaseRetriever(torch.nn.Module):
         plan = shard.RowShardPlan(n_items, world, layout=self.config['train'].get('shard_layout', 'block'))
         block = torch.nn.Embedding(plan.n_local(rank), d, padding_idx=0 if rank == 0 else None,
                                    _weight=plan.take(self.item_encoder.weight.detach(), rank).clone())
+        # An ITEM-TOWER query encoder (SASRec: seq/sasrec.py:14, :42, :107) embeds its input with the very table the
+        # model scores against.  Every place the tower holds that module is re-pointed at the sharded table below
+        # (shard.ShardedRows: ids out, rows back, gradients to the owners), so the embedding stays tied and no rank
+        # keeps -- or dense-all-reduces the gradient of -- a replica of the catalog.
+        full = self.item_encoder
+        tied = []
+        if isinstance(self.query_encoder, torch.nn.Module):
+            tied = [(mod, name) for mod in self.query_encoder.modules() for name, child in mod._modules.items() if child is full]
+            for mod, name in tied:
+                mod._modules[name] = None
+            if any(p is full.weight for p in self.query_encoder.parameters()):
+                for mod, name in tied:
+                    mod._modules[name] = full
+                raise NotImplementedError('multi-GPU fit: the query tower uses item_encoder.weight outside the item_encoder '
+                                          'module itself; only towers that call their item_encoder submodule can be sharded')
         self.item_encoder = block                      # the full table is dropped: this rank keeps its rows only
         lo, hi = (None, None) if plan.interleaved else plan.bounds(rank)
         if hasattr(self, 'item_vector'):
@@ -643,7 +658,12 @@ class BaseRetriever(torch.nn.Module):
                                        sample_seed=self.config['train']['seed'] or 2022,
                                        chunks=int(self.config['train'].get('shard_slices', 1)))
         self._shard = {'table': table, 'dist': dist, 'rank': rank, 'world': world, 'lo': lo, 'hi': hi, 'device': device,
-                       'n_items': n_items, 'plan': plan}
+                       'n_items': n_items, 'plan': plan, 'tower_rows': None}
+        if tied:
+            rows = shard.ShardedRows(table)
+            for mod, name in tied:
+                mod._modules[name] = rows
+            self._shard['tower_rows'] = rows
         return self._shard
 
     def _topk_sharded(self, query, k, user_h, return_query):
@@ -655,14 +675,23 @@ class BaseRetriever(torch.nn.Module):
         table, be = sh['table'], sh['table'].backend
         more = sh.get('hist_width', user_h.size(1) if user_h is not None else 0)
         kc = min(k + more, sh['n_items'] - 1)
-        if kc > ops.FULLSCORE_MAX_K:
-            raise NotImplementedError(f'sharded topk: k + |history| = {kc} exceeds {ops.FULLSCORE_MAX_K}')
-        _, score, topk_items = table.full_lse_topk(query.detach().contiguous(), kc, want_lse=False)
+        mask = be.mask_history if hasattr(be, 'mask_history') else ops.topk_mask_history
+        q = query.detach().contiguous()
+        narrow = min(sh.get('topk_narrow', 512), sh['n_items'] - 1)
+        if user_h is not None and kc > ops.FULLSCORE_MAX_K and 2 * k <= narrow:
+            # a history longer than 1024 - k (ml-1m: ~1.8 k): the single-process strategy (``topk`` above) with
+            # rank-uniform shapes -- 512 candidates over the whole catalog, history dropped; only if ANY row of ANY rank is
+            # left with fewer than k survivors (one flag, all-reduced: every rank takes the same branch) does the batch
+            # go through the wide pass
+            _, score, topk_items = table.full_lse_topk(q, narrow, want_lse=False)
+            score, topk_items = mask(score, topk_items, user_h, k)
+            short = torch.isinf(score[:, k - 1]).any().to(torch.int32).reshape(1)
+            table._all_reduce_max(short)
+            if not int(short):
+                return (score, topk_items, query) if return_query else (score, topk_items)
+        _, score, topk_items = table.full_lse_topk(q, kc, want_lse=False)
         if user_h is not None:
-            if hasattr(be, 'mask_history'):
-                score, topk_items = be.mask_history(score, topk_items, user_h, min(k, score.shape[1]))
-            else:
-                score, topk_items = ops.topk_mask_history(score, topk_items, user_h, min(k, score.shape[1]))
+            score, topk_items = mask(score, topk_items, user_h, min(k, score.shape[1]))
         else:
             score, topk_items = score[:, :k], topk_items[:, :k]
         return (score, topk_items, query) if return_query else (score, topk_items)
@@ -708,6 +737,8 @@ class BaseRetriever(torch.nn.Module):
             sched_opt.step()                                   # (a no-op; the schedulers warn when they step first)
         scheduler = self._get_scheduler(sched_opt)
         sh['trainer'] = trainer
+        if sh['tower_rows'] is not None:
+            sh['tower_rows'].bind(trainer)
         val_metrics = self.config['eval']['val_metrics']
         cutoff = self.config['eval']['cutoff']
         cutoff0 = cutoff[0] if isinstance(cutoff, list) else cutoff
@@ -1058,7 +1089,10 @@ class SASRecQueryEncoder(torch.nn.Module):
         B, L = user_hist.shape
         positions = torch.arange(L, dtype=torch.long, device=user_hist.device).unsqueeze(0).expand(B, L)
         seg = batch.get('_seg')
-        if seg is not None and user_hist.is_cuda:
+        if not isinstance(self.item_encoder, torch.nn.Embedding):
+            # the row-sharded catalog (shard.ShardedRows put here by BaseRetriever._setup_shard): ids out, rows back
+            rows = self.item_encoder(user_hist)
+        elif seg is not None and user_hist.is_cuda:
             # the device loader handed over the CSR view (flat item column, start, end): the fused segment gather emits
             # [B, L, d] directly; ``in_item_id`` only serves the padding mask and the backward
             flat, start, end = seg

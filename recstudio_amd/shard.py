@@ -295,6 +295,8 @@ class HipBackend:
 
     # -- exact (variable-split) exchange ------------------------------------------------------------------------------
     def gather_rows(self, table, ids):
+        if ids.numel() == 0:
+            return table.new_empty(*ids.shape, table.shape[1])
         return ops.embedding_gather(table, ids)
 
     def count(self, pos, neg, plan):
@@ -380,7 +382,11 @@ class HipBackend:
 
     def merge_topk(self, vals, ids, k):
         """vals/ids [B, G*k] (shard-major, each shard's list sorted) -> exact global top-k, ties -> smaller id."""
-        v, cols = ops.row_topk(vals.contiguous(), k)
+        if k > ops.FULLSCORE_MAX_K:          # the wide correctness path (k + |history| beyond the in-kernel select)
+            v, cols = torch.sort(vals, dim=1, descending=True, stable=True)
+            v, cols = v[:, :k].contiguous(), cols[:, :k]
+        else:
+            v, cols = ops.row_topk(vals.contiguous(), k)
         return v, torch.gather(ids, 1, cols)
 
 
@@ -478,7 +484,8 @@ class ShardedItemTable:
             out = torch.empty_like(x) if out is None else out
             self.dist.all_to_all_single(out, x, group=self.group)
             return out
-        out = torch.empty(sum(recv_counts), dtype=x.dtype, device=x.device)
+        if out is None:
+            out = torch.empty(sum(recv_counts), *x.shape[1:], dtype=x.dtype, device=x.device)
         self.dist.all_to_all_single(out, x, output_split_sizes=recv_counts, input_split_sizes=send_counts,
                                     group=self.group)
         return out
@@ -727,6 +734,47 @@ class ShardedItemTable:
         ``forward_queries`` for the keyword arguments)."""
         return self.forward_queries(self.backend.gather_rows(user_table, uid), pos, n, sampler, keep_route=keep_route, **kw)
 
+    # -- row look-ups for an ITEM-TOWER query encoder (SASRec: seq/sasrec.py:14, :42, :107) ----------------------------
+    def lookup_rows(self, ids, keep_route=False):
+        """``item_encoder(ids)`` over the sharded table for a query tower that embeds item ids itself (the history
+        window of SASRec): ids out, ROWS back -- unlike the negatives, whose rows never travel, a tower needs the
+        vectors.  ``ids`` (any shape, GLOBAL item ids, 0 = padding) -> ``[*ids.shape, d]`` with zero rows at the
+        padding (padding ids are not sent anywhere: rank 0, which owns row 0, would be a hot owner otherwise).
+        Variable split: per-owner counts exchanged and read back (one host round trip per call; B*L*512 B per rank come
+        back over xGMI, 105 MB at B = 4096, L = 50).  Every rank must call this in lock-step."""
+        be, plan, d = self.backend, self.plan, self.item_local.shape[1]
+        flat = ids.reshape(-1)
+        M, G = flat.numel(), plan.world
+        sel = torch.nonzero(flat).view(-1)                         # positions that hold a real item
+        vid = flat[sel]
+        owner = plan.owner(vid)
+        order = torch.argsort(owner, stable=True)
+        send_counts, recv_counts = self._exchange_counts(torch.bincount(owner, minlength=G))
+        m_send = int(sel.numel())
+        recv_local = self._all_to_all(plan.local(vid)[order].contiguous(), recv_counts, send_counts)
+        rows_owner = be.gather_rows(self.item_local, recv_local)
+        # the rows come home in send order, behind them ONE zero row every padding position points at
+        home = torch.empty(m_send + 1, d, dtype=self.item_local.dtype, device=flat.device)
+        home[m_send].zero_()
+        self._all_to_all(rows_owner, send_counts, recv_counts, out=home[:m_send])
+        src = sel[order]                                            # position in ``flat`` of every row that came home
+        inv = torch.full((M,), m_send, dtype=torch.int64, device=flat.device)
+        inv[src] = torch.arange(m_send, device=flat.device)
+        out = be.gather_rows(home, inv).view(*ids.shape, d)
+        if keep_route:
+            return out, {'src': src, 'recv_local': recv_local, 'send_counts': send_counts, 'recv_counts': recv_counts}
+        return out
+
+    def lookup_rows_backward(self, route, grad, item_grad_local, scale=1.0):
+        """Backward of ``lookup_rows``: the gradient rows of the real positions go to the owners of their items (the
+        reverse of the forward's row exchange) and are added, times ``scale``, into ``item_grad_local`` -- this rank's
+        block of the dense table gradient, or the weight block itself with ``scale = -lr`` -- by the sorted,
+        atomics-free row scatter."""
+        be, d = self.backend, self.item_local.shape[1]
+        g_send = be.gather_rows(grad.reshape(-1, d).contiguous(), route['src'])
+        g_owner = self._all_to_all(g_send, route['recv_counts'], route['send_counts'])
+        be.apply_rows(item_grad_local, route['recv_local'], g_owner, scale, pad_row=0 if self.rank == 0 else -1)
+
     # -- full-catalog pass (eval top-k / full softmax), sharded the same way --------------------------
     def _exchange_partials(self, x, B):
         """x [G*B, ...] (this shard's partial for EVERY query) -> [G, B, ...] (every shard's partial for the
@@ -791,6 +839,59 @@ class _ShardedScoreFn(torch.autograd.Function):
 
 def sharded_scores(table, q, pos, neg, item_grad_local, item_scale=None):
     return _ShardedScoreFn.apply(q, table, pos, neg, item_grad_local, item_scale)
+
+
+class _ShardedRowsFn(torch.autograd.Function):
+    """``lookup_rows`` under autograd: the backward routes the gradient rows to the items' owners (collective: every
+    rank runs it, at the same point of its backward graph)."""
+
+    @staticmethod
+    def forward(ctx, anchor, ids, module):
+        rows, route = module.table.lookup_rows(ids, keep_route=True)
+        ctx.module, ctx.route = module, route
+        return rows
+
+    @staticmethod
+    def backward(ctx, g):
+        m = ctx.module
+        if m.grad_sink is None:
+            raise RuntimeError('ShardedRows: no gradient sink bound (ShardedRows.bind(trainer)) before backward')
+        m.table.lookup_rows_backward(ctx.route, g.contiguous(), m.grad_sink, m.grad_scale)
+        return None, None, None
+
+
+class ShardedRows(torch.nn.Module):
+    """Stands in for ``item_encoder`` INSIDE a query tower when the item table is row-sharded (an ItemTowerRecommender
+    such as SASRec embeds its history with the very table it scores against, seq/sasrec.py:14, :42, :107):
+    ``module(ids) -> [*ids.shape, d]`` through ``ShardedItemTable.lookup_rows``, and the backward adds the rows'
+    gradients into the owner's block of the table gradient (or, with in-place SGD, into the weight block) -- the
+    embedding stays TIED and no rank holds, trains or all-reduces a replica of the table.  It has no parameters: the
+    tower's ``parameters()`` are its dense weights only (what the bucketed all-reduce sums)."""
+
+    def __init__(self, table):
+        super().__init__()
+        object.__setattr__(self, 'table', table)        # (not a submodule / buffer: the block belongs to item_encoder)
+        self.grad_sink, self.grad_scale = None, 1.0
+        self._anchor = None
+
+    def bind(self, trainer):
+        """Gradients go where the trainer's score exchange puts them: its gradient block, or the weights at -lr."""
+        object.__setattr__(self, 'grad_sink', trainer.item_grad_local)
+        self.grad_scale = 1.0 if trainer.item_sgd_lr is None else -float(trainer.item_sgd_lr)
+        trainer.tower_rows = self
+        return self
+
+    @property
+    def embedding_dim(self):
+        return self.table.item_local.shape[1]
+
+    def forward(self, ids):
+        if not torch.is_grad_enabled():
+            return self.table.lookup_rows(ids)
+        if self._anchor is None or self._anchor.device != ids.device:
+            # autograd only calls a Function's backward when an input requires grad; the ids cannot
+            object.__setattr__(self, '_anchor', torch.zeros((), device=ids.device, requires_grad=True))
+        return _ShardedRowsFn.apply(self._anchor, ids, self)
 
 
 def allreduce_grads(params, dist, group=None, bucket_bytes=64 << 20):
@@ -862,7 +963,12 @@ class ShardedRetriever:
             raise ValueError('query_sgd_lr applies the row-sparse gradient: it needs sparse_query_rows')
         self.sparse_query_rows, self.query_sgd_lr, self.query_rows = bool(sparse_query_rows), query_sgd_lr, None
         self.keep_neg_ids, self.last_neg = bool(keep_neg_ids), None
-        self.item_scale = None
+        self.item_scale, self.item_sgd_lr, self.tower_rows = None, item_sgd_lr, None
+        block = table.item_local
+        for p in query_encoder.parameters() if isinstance(query_encoder, torch.nn.Module) else ():
+            if p.data_ptr() == block.data_ptr() and p.numel():
+                raise ValueError('the query tower holds the sharded item block as a parameter: route its item look-ups '
+                                 'through shard.ShardedRows instead (BaseRetriever._setup_shard does)')
         if item_sgd_lr is None:
             self.item_grad_local = torch.zeros_like(table.item_local)
         else:
@@ -873,6 +979,9 @@ class ShardedRetriever:
         """New learning rate for the in-place SGD updates (a scheduler between epochs)."""
         if self.item_scale is not None:
             self.item_scale.fill_(-float(lr))
+            self.item_sgd_lr = float(lr)
+            if self.tower_rows is not None:
+                self.tower_rows.grad_scale = -float(lr)
         if self.query_sgd_lr is not None:
             self.query_sgd_lr = float(lr)
 

@@ -288,6 +288,12 @@ def test_rank_slices_tile_every_global_batch():
     parts = [rank_part(idx, r, 4) for r in range(4)]
     assert [p[0].tolist() for p in parts] == [[0, 1, 2], [3, 4, 5], [6, 7, 8], [9, 0, 1]] and [p[1] for p in parts] == [3, 3, 3, 1]
     assert [rank_part(torch.arange(2), r, 4)[1] for r in range(4)] == [1, 1, 0, 0]
+    # a batch shorter than its own padding (3 rows on 8 ranks: 5 more needed) wraps around more than once: every rank
+    # still gets the same number of rows (ranks 6 and 7 got empty parts and the collectives mismatched)
+    tiny = [rank_part(torch.arange(3), r, 8) for r in range(8)]
+    assert [p[0].tolist() for p in tiny] == [[0], [1], [2], [0], [1], [2], [0], [1]]
+    assert [p[1] for p in tiny] == [1, 1, 1, 0, 0, 0, 0, 0]
+    assert [rank_part(torch.arange(1), r, 4)[0].tolist() for r in range(4)] == [[0]] * 4
     u, i = synthetic_interactions(60, 300, 4000)
     ds = TripletDataset.from_interactions(u, i)
     trn, val, _ = ds.build(split_ratio=[0.8, 0.1, 0.1])

@@ -13,6 +13,10 @@ import torch.multiprocessing as mp
 import oracle
 from oracle import philox
 
+# the spawned ranks are fresh interpreters: a few OpenMP threads each instead of one per core per rank (8 ranks x all
+# cores made the world-8 cases crawl)
+os.environ.setdefault('OMP_NUM_THREADS', '2')
+
 
 class CheckerBackend:
     """Same interface as recstudio_amd.shard.HipBackend, restated with torch-CPU ops."""
@@ -737,3 +741,188 @@ def test_fit_two_ranks_fused_sgd_follows_the_scheduler(tmp_path):
     assert torch.equal(const['losses'][:n1], one['losses'][:n1])                 # the first epoch: the same rate
     assert (const['item'] - one['item']).abs().max() > 1e-5                      # the second: 196 instead of 200
 
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# ITEM-TOWER query encoders over the sharded table (SASRec embeds its history with the table it scores
+# against, seq/sasrec.py:14, :42, :107 -- the sharded fit must keep that embedding tied and must not replicate the catalog)
+class _HistTower(torch.nn.Module):
+    """A minimal item tower: masked mean of the history's item vectors through one dense layer."""
+
+    def __init__(self, item_encoder, d):
+        super().__init__()
+        self.item_encoder = item_encoder
+        self.lin = torch.nn.Linear(d, d)
+
+    def forward(self, hist):
+        rows = self.item_encoder(hist)                                     # [B, L, d]; padding rows are zero
+        cnt = (hist != 0).sum(-1, keepdim=True).clamp(min=1)
+        return self.lin(rows.sum(1) / cnt)
+
+
+def _item_tower_worker(rank, world, port, n_items, d, B, L, n, result_dir, layout):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        import recstudio_amd as ra
+        from recstudio_amd.shard import RowShardPlan, ShardedItemTable, ShardedRetriever, ShardedRows
+        g = torch.Generator().manual_seed(33)
+        item = torch.randn(n_items, d, generator=g) * 0.3
+        item[0] = 0
+        lin_w, lin_b = torch.randn(d, d, generator=g) * 0.3, torch.randn(d, generator=g) * 0.1
+        plan = RowShardPlan(n_items, world, layout=layout)
+        hists, poss = [], []
+        for r in range(world):
+            gr = torch.Generator().manual_seed(900 + r)
+            h = torch.randint(1, n_items, (B, L), generator=gr)
+            h[torch.arange(L).view(1, -1) >= torch.randint(1, L + 1, (B, 1), generator=gr)] = 0     # right-padded, ragged
+            if r == 0:
+                h[0, :] = n_items - 1                                      # a whole row owned by the last rank
+            hists.append(h)
+            poss.append(torch.randint(1, n_items, (B,), generator=gr))
+
+        def make(loss, **kw):
+            table = ShardedItemTable(plan.take(item, rank).clone(), plan, rank, dist, backend=CheckerBackend())
+            rows = ShardedRows(table)
+            tower = _HistTower(rows, d)
+            with torch.no_grad():
+                tower.lin.weight.copy_(lin_w)
+                tower.lin.bias.copy_(lin_b)
+            assert [tuple(p.shape) for p in tower.parameters()] == [(d, d), (d,)]      # no [N, d] tensor in the tower
+            trainer = ShardedRetriever(table, tower, oracle.UniformSampler(n_items), loss, n, keep_neg_ids=True, **kw)
+            rows.bind(trainer)
+            return table, tower, trainer
+
+        # the look-up itself: rows of the full table, zero rows at the padding, any shape
+        table, tower, trainer = make(ra.BPRLoss())
+        got = table.lookup_rows(hists[rank])
+        assert torch.equal(got, item[hists[rank]]) and not got[hists[rank] == 0].any()
+        assert table.lookup_rows(torch.zeros(0, dtype=torch.int64)).shape == (0, d)
+        assert not table.lookup_rows(torch.zeros(3, dtype=torch.int64)).any()          # nothing but padding: no traffic
+        def bce(label, pos_score, log_pos_prob, neg_score, log_neg_prob):      # loss_func.py:100-132 under autograd
+            return oracle.bce_loss(pos_score, neg_score)
+        for loss, kind in ((ra.BPRLoss(), 'fused'), (bce, 'autograd')):
+            table, tower, trainer = make(loss)
+            assert (trainer._fused_loss_kind() is not None) == (kind == 'fused')
+            loss_r = trainer.training_step(hists[rank], poss[rank], None)
+            negs = [torch.zeros(B, n, dtype=torch.int64) for _ in range(world)]
+            dist.all_gather(negs, trainer.last_neg)
+            # ONE process, ONE table used by the tower and by the scores (tied), the concatenated batch, same negatives
+            item_ref = item.clone().requires_grad_(True)
+            ref_tower = _HistTower(lambda ids: item_ref[ids], d)
+            with torch.no_grad():
+                ref_tower.lin.weight.copy_(lin_w)
+                ref_tower.lin.bias.copy_(lin_b)
+            q = ref_tower(torch.cat(hists))
+            pos, neg = torch.cat(poss), torch.cat(negs)
+            ps, ns = (q * item_ref[pos]).sum(-1), (q.unsqueeze(1) * item_ref[neg]).sum(-1)
+            ref = oracle.bpr_loss(ps, ns) if kind == 'fused' else oracle.bce_loss(ps, ns)
+            ref.backward()
+            total = loss_r.clone()
+            dist.all_reduce(total)
+            np.testing.assert_allclose(total.item(), ref.item(), rtol=1e-5)
+            np.testing.assert_allclose(tower.lin.weight.grad.numpy(), ref_tower.lin.weight.grad.numpy(), rtol=1e-4, atol=1e-6)
+            np.testing.assert_allclose(tower.lin.bias.grad.numpy(), ref_tower.lin.bias.grad.numpy(), rtol=1e-4, atol=1e-6)
+            want = item_ref.grad.clone()          # score-side AND tower-side gradient of the one tied table
+            want[0] = 0
+            np.testing.assert_allclose(trainer.item_grad_local.numpy(), plan.take(want, rank).numpy(), rtol=1e-4, atol=1e-6)
+            # the tower side really contributed (else the test would pass on an untied table)
+            tower_only = torch.zeros(n_items, d).index_add_(0, torch.cat(hists).reshape(-1), torch.ones(world * B * L, d))
+            tower_only[0] = 0
+            assert (want[tower_only[:, 0] > 0].abs().sum(-1) > 0).all()
+            # in-place SGD inside the exchanges: the block moves by -lr * that gradient
+            table2, tower2, trainer2 = make(loss, item_sgd_lr=0.7)
+            trainer2.training_step(hists[rank], poss[rank], None)
+            np.testing.assert_allclose(table2.item_local.numpy(), (plan.take(item, rank) - 0.7 * trainer.item_grad_local).numpy(),
+                                       rtol=1e-4, atol=1e-6)
+            trainer2.set_sgd_lr(0.1)
+            assert tower2.item_encoder.grad_scale == -0.1
+        open(os.path.join(result_dir, f'ok{rank}'), 'w').write('ok')
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world,layout', [(2, 'block'), (2, 'interleaved'), (4, 'block')])
+def test_item_tower_over_the_sharded_table_stays_tied(tmp_path, world, layout):
+    """A query tower that embeds item ids itself (``shard.ShardedRows``: ids out, rows back, gradients to the owners): the
+    look-up equals the full table's rows, and a training step's item gradient -- score side + tower side, summed on the
+    owner -- equals autograd over ONE tied table in one process; the tower's parameters hold no [N, d] tensor."""
+    mp.spawn(_item_tower_worker, args=(world, _free_port(), 67, 16, 6, 5, 3, str(tmp_path), layout), nprocs=world, join=True)
+    assert all(os.path.exists(tmp_path / f'ok{r}') for r in range(world))
+
+
+def _sasrec_fit_worker(rank, world, port, result_dir, layout='block'):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        import recstudio_amd as ra
+        from recstudio_amd import shard
+        from recstudio_amd.dataset import SeqDataset
+        g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'data_ml100k.npz'))
+        conf = {'train': {'epochs': 1, 'batch_size': 4096 // world, 'negative_count': 4, 'seed': 2022, 'learning_rate': 0.01,
+                          'early_stop_patience': 100, 'shard_layout': layout},
+                'eval': {'batch_size': 256 // world, 'cutoff': [10], 'val_metrics': ['ndcg', 'recall'], 'topk': 50,
+                         'test_metrics': ['ndcg', 'recall']},
+                'model': {'embed_dim': 16, 'hidden_size': 16, 'layer_num': 1, 'head_num': 1, 'dropout_rate': 0.0}}
+        # (dropout off: its masks come from each rank's own generator, so they differ with the world size)
+        model = ra.SASRec(conf, loss=ra.SampledSoftmaxLoss())
+        ds = SeqDataset('ml-100k', {'low_rating_thres': 3.0, 'max_seq_len': 8},
+                        _interactions=(g['raw_user'].astype(str), g['raw_item'].astype(str),
+                                       g['raw_rating'].astype(np.float64), g['raw_time'].astype(np.float64)))
+        trn, val, tst = ds.build(split_ratio=2)
+        # an even number of training samples: the last global batch then splits over two ranks without padding (a padded
+        # batch repeats a sample -- dataset.rank_part, torch's DistributedSampler rule -- and is not world-invariant)
+        trn.data_index = trn.data_index[:len(trn.data_index) // 2 * 2]
+        model.sampler = oracle.UniformSampler(trn.num_items)
+        seen = []
+        orig = shard.allreduce_grads
+
+        def spy(params, *a, **k):
+            params = list(params)
+            seen.extend(tuple(p.shape) for p in params)
+            return orig(params, *a, **k)
+        shard.allreduce_grads = spy
+        best = model.fit(trn, val, dist=dist, shard_backend=CheckerBackend(), device='cpu')
+        test = model.evaluate(tst, verbose=False)
+        sh = model._shard
+        # the tower's embedding IS the sharded table: no replica of the catalog anywhere in the tower, none all-reduced
+        assert isinstance(model.query_encoder.item_encoder, shard.ShardedRows) and sh['tower_rows'] is model.query_encoder.item_encoder
+        assert all(s[0] != trn.num_items for s in seen) and all(p.shape[0] != trn.num_items for p in model.query_encoder.parameters())
+        assert tuple(model.item_encoder.weight.shape) == (sh['plan'].n_local(rank), 16)
+        assert 'query_encoder.item_encoder.weight' not in model.state_dict()
+        dense = torch.cat([p.detach().reshape(-1) for p in model.query_encoder.parameters()])
+        reps = [torch.zeros_like(dense) for _ in range(world)]
+        dist.all_gather(reps, dense)
+        assert all(torch.equal(reps[0], t) for t in reps)                  # the dense tower replicas stay bit-equal
+        torch.save({'best': best, 'val': dict(model.logged_metrics), 'test': test, 'losses': torch.cat(model.train_losses),
+                    'item': model.item_encoder.weight.detach().clone(), 'tower': dense}, os.path.join(result_dir, f'w{world}r{rank}.pt'))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sasrec_fit_two_ranks_equals_one_rank_on_ml100k(tmp_path):
+    """SASRec (item tower: history embedded with the scored table) through ``BaseRetriever.fit`` / ``evaluate`` on two ranks
+    == the one-rank run: losses, ndcg@10 / recall@10, the Transformer's weights and the (tied) item table; block and
+    interleaved rows."""
+    for world in (1, 2):
+        mp.spawn(_sasrec_fit_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    os.makedirs(tmp_path / 'il')
+    mp.spawn(_sasrec_fit_worker, args=(2, _free_port(), str(tmp_path / 'il'), 'interleaved'), nprocs=2, join=True)
+    one = torch.load(tmp_path / 'w1r0.pt', weights_only=False)
+    assert float(one['losses'][-1]) < float(one['losses'][0]) - 0.05 and one['val']['ndcg@10'] > 0.01
+    for sub, il in (('', False), ('il', True)):
+        two = [torch.load(tmp_path / sub / f'w2r{r}.pt', weights_only=False) for r in range(2)]
+        for t in two:
+            np.testing.assert_allclose(t['losses'].numpy(), one['losses'].numpy(), rtol=2e-5, atol=1e-6)
+            for k in ('ndcg@10', 'recall@10'):
+                assert abs(t['val'][k] - one['val'][k]) < 1e-4 and abs(t['test'][k] - one['test'][k]) < 1e-4
+            np.testing.assert_allclose(t['tower'].numpy(), one['tower'].numpy(), rtol=1e-3, atol=5e-5)
+        items = torch.empty_like(one['item'])
+        if il:
+            items[0::2], items[1::2] = two[0]['item'], two[1]['item']
+        else:
+            items = torch.cat([two[0]['item'], two[1]['item']])
+        np.testing.assert_allclose(items.numpy(), one['item'].numpy(), rtol=1e-3, atol=1e-5)
+        assert not items[0].any()
