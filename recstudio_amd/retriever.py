@@ -745,7 +745,7 @@ class BaseRetriever(torch.nn.Module):
         self.val_metric = f"{(val_metrics[0] if isinstance(val_metrics, list) else val_metrics)}@{cutoff0}"
         on_gpu = device.type == 'cuda'
         best, best_state, bad = None, None, 0
-        self.train_losses = []
+        self.train_losses, self.history = [], []
         for epoch in range(tr['epochs']):
             t0 = time.time()
             self.train()
@@ -783,6 +783,7 @@ class BaseRetriever(torch.nn.Module):
             if fused and scheduler is not None:
                 trainer.set_sgd_lr(log['lr'])
             self.logged_metrics = log
+            self.history.append(dict(log))
             if rank == 0:
                 self.logger.info(' '.join(f'{k}={v:.4f}' if isinstance(v, float) else f'{k}={v}' for k, v in log.items()))
             if val_data is not None and bad >= tr['early_stop_patience']:
@@ -848,6 +849,7 @@ class BaseRetriever(torch.nn.Module):
         cutoff0 = cutoff[0] if isinstance(cutoff, list) else cutoff
         self.val_metric = f"{(val_metrics[0] if isinstance(val_metrics, list) else val_metrics)}@{cutoff0}"
         best, best_state, bad = None, None, 0
+        self.history = []                                  # one dict per epoch: what the reference logs (recommender.py:249-270)
         for epoch in range(tr['epochs']):
             t0 = time.time()
             self.train()
@@ -897,6 +899,7 @@ class BaseRetriever(torch.nn.Module):
             if fused_step is not None and scheduler is not None:
                 fused_step.set_lr(log['lr'])
             self.logged_metrics = log
+            self.history.append(dict(log))
             self.logger.info(' '.join(f'{k}={v:.4f}' if isinstance(v, float) else f'{k}={v}' for k, v in log.items()))
             if val_data is not None and bad >= tr['early_stop_patience']:
                 break

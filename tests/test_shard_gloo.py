@@ -509,7 +509,7 @@ def _train_worker(rank, world, port, n_items, d, B, n, result_dir, layout='block
         np.testing.assert_allclose(emb4.weight.detach().numpy(), (emb_w - 0.3 * w_ref.grad).numpy(), rtol=1e-4, atol=1e-6)
         reps = [torch.zeros(U, d) for _ in range(world)]
         dist.all_gather(reps, emb4.weight.detach().clone())
-        assert torch.equal(reps[0], reps[1])
+        assert all(torch.equal(reps[0], r) for r in reps)
         # the FUSED step (stock BPRLoss / SampledSoftmaxLoss: loss, mean and d loss/d score inside the exchange's home
         # kernel, no autograd over the scores) == the autograd step above, uniform and popularity sampler
         import recstudio_amd as ra
@@ -552,42 +552,45 @@ def _train_worker(rank, world, port, n_items, d, B, n, result_dir, layout='block
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('layout', ['block', 'interleaved'])
-def test_sharded_training_step_equals_single_process_autograd(tmp_path, layout):
-    """ShardedRetriever.training_step on 2 ranks (item rows sharded -- contiguous blocks or interleaved rows --, query
-    tower replicated + bucketed all-reduce) == autograd of the global-mean BPR loss in one process."""
-    world = 2
+@pytest.mark.parametrize('world,layout', [(2, 'block'), (2, 'interleaved'), (4, 'interleaved'), (8, 'block')])
+def test_sharded_training_step_equals_single_process_autograd(tmp_path, world, layout):
+    """ShardedRetriever.training_step on 2 / 4 / 8 ranks (item rows sharded -- contiguous blocks or interleaved rows --,
+    query tower replicated + bucketed all-reduce) == autograd of the global-mean BPR loss in one process."""
     mp.spawn(_train_worker, args=(world, _free_port(), 61, 16, 7, 4, str(tmp_path), layout), nprocs=world, join=True)
     assert all(os.path.exists(tmp_path / f'ok{r}') for r in range(world))
 
 
-@pytest.mark.parametrize('layout', ['block', 'interleaved'])
-@pytest.mark.parametrize('n_items,k', [(101, 10), (7, 3), (3, 1)])
-def test_sharded_full_catalog_pass_equals_single_process(tmp_path, n_items, k, layout):
+@pytest.mark.parametrize('n_items,k,layout,world', [(101, 10, 'block', 2), (7, 3, 'block', 2), (3, 1, 'block', 2),
+                                                    (101, 10, 'interleaved', 2), (7, 3, 'interleaved', 2),
+                                                    (3, 1, 'interleaved', 2), (101, 10, 'block', 4), (101, 10, 'interleaved', 8),
+                                                    (7, 3, 'block', 8), (7, 3, 'interleaved', 8)])
+def test_sharded_full_catalog_pass_equals_single_process(tmp_path, n_items, k, layout, world):
     """k larger than one shard's row count ((7, 3): shard 0 holds 3 real rows, shard 1 holds 3) and a last
-    shard with a single row ((3, 1): rows_per_shard = 2 -> shard 1 = {2})."""
-    world = 2
+    shard with a single row ((3, 1): rows_per_shard = 2 -> shard 1 = {2}); at world 8 a 7-item catalog leaves ranks with
+    an empty block (block layout: rows_per_shard = 1, rank 7 holds nothing; rank 0 only the padding row)."""
     mp.spawn(_full_worker, args=(world, _free_port(), n_items, 16, 5, k, str(tmp_path), layout), nprocs=world, join=True)
     assert all(os.path.exists(tmp_path / f'ok{r}') for r in range(world))
 
 
-@pytest.mark.parametrize('n_items,n,B,layout', [(101, 5, 9, 'block'), (64, 1, 9, 'block'), (1001, 7, 500, 'block'),
-                                                (101, 5, 9, 'interleaved'), (1001, 7, 500, 'interleaved')])
-def test_sharded_scores_equal_single_process(tmp_path, n_items, n, B, layout):
-    """Forward + gradient exchange on 2 ranks == single process: exact-split calibration step, then the fixed-capacity
-    exchange; negatives identical to a world-1 draw (G-invariance); overflow of a tight capacity detected (B = 500)."""
-    world = 2
+@pytest.mark.parametrize('n_items,n,B,layout,world', [(101, 5, 9, 'block', 2), (64, 1, 9, 'block', 2), (1001, 7, 500, 'block', 2),
+                                                      (101, 5, 9, 'interleaved', 2), (1001, 7, 500, 'interleaved', 2),
+                                                      (1001, 7, 200, 'block', 4), (1001, 7, 120, 'interleaved', 8),
+                                                      (101, 5, 9, 'block', 8)])
+def test_sharded_scores_equal_single_process(tmp_path, n_items, n, B, layout, world):
+    """Forward + gradient exchange on 2 / 4 / 8 ranks == single process: exact-split calibration step, then the
+    fixed-capacity exchange; negatives identical to a world-1 draw (G-invariance); overflow of a tight capacity detected
+    (B >= 100)."""
     mp.spawn(_worker, args=(world, _free_port(), n_items, 16, B, n, str(tmp_path), layout), nprocs=world, join=True)
     assert all(os.path.exists(tmp_path / f'ok{r}') for r in range(world))
 
 
-@pytest.mark.parametrize('B,n,chunks,layout', [(8, 5, 2, 'block'), (12, 3, 4, 'block'), (400, 7, 2, 'block'),
-                                               (400, 7, 2, 'interleaved')])
-def test_pipelined_slices_equal_the_whole_step(tmp_path, B, n, chunks, layout):
+@pytest.mark.parametrize('B,n,chunks,layout,world', [(8, 5, 2, 'block', 2), (12, 3, 4, 'block', 2), (400, 7, 2, 'block', 2),
+                                                     (400, 7, 2, 'interleaved', 2), (120, 7, 2, 'block', 8),
+                                                     (120, 7, 4, 'interleaved', 4)])
+def test_pipelined_slices_equal_the_whole_step(tmp_path, B, n, chunks, layout, world):
     """ShardedItemTable(chunks=C): the step cut into C query slices with asynchronously issued exchanges gives the same
     negatives and bit-equal scores as the whole step, the same gradients (summed in a different order), keeps its
     own per-slice capacity, detects overflow, and falls back to the whole step for batches C does not divide."""
-    world = 2
     mp.spawn(_chunk_worker, args=(world, _free_port(), 1001, 16, B, n, chunks, str(tmp_path), layout), nprocs=world, join=True)
     assert all(os.path.exists(tmp_path / f'ok{r}') for r in range(world))
 
@@ -639,13 +642,19 @@ def _fit_worker(rank, world, port, result_dir, epochs, batch_global, train_extra
                 'eval': {'batch_size': 64 // world, 'cutoff': [10], 'val_metrics': ['ndcg', 'recall'], 'topk': 50,
                          'test_metrics': ['ndcg', 'recall']},
                 'model': {'embed_dim': 16}}
-        conf['train'].update(train_extra or {})
+        train_extra = dict(train_extra or {})
+        trim = train_extra.pop('_trim', None)
+        conf['train'].update(train_extra)
         model = ra.BPR(conf)                                       # seeds everything (recommender.py:34-35) ...
         ds = TripletDataset('ml-100k', {'low_rating_thres': 3.0},
                             _interactions=(g['raw_user'].astype(str), g['raw_item'].astype(str),
                                            g['raw_rating'].astype(np.float64), g['raw_time'].astype(np.float64)))
         trn, val, tst = ds.build(split_ratio=[0.8, 0.1, 0.1], shuffle=True, split_mode='user_entry')    # ... then the data
         model.sampler = oracle.UniformSampler(trn.num_items)       # the checker's stand-in for the in-kernel sampler
+        if trim:
+            # a sample count every world size divides: no global batch is padded (a padded batch repeats samples --
+            # dataset.rank_part, torch's DistributedSampler rule -- and is not world-invariant)
+            trn.data_index = trn.data_index[:len(trn.data_index) // trim * trim]
         best = model.fit(trn, val, dist=dist, shard_backend=CheckerBackend(), device='cpu')
         test = model.evaluate(tst, verbose=False)
         losses = torch.cat(model.train_losses)
@@ -926,3 +935,78 @@ def test_sasrec_fit_two_ranks_equals_one_rank_on_ml100k(tmp_path):
             items = torch.cat([two[0]['item'], two[1]['item']])
         np.testing.assert_allclose(items.numpy(), one['item'].numpy(), rtol=1e-3, atol=1e-5)
         assert not items[0].any()
+
+
+def test_fit_four_and_eight_ranks_equal_one_rank_on_ml100k(tmp_path):
+    """The target world size: ``BaseRetriever.fit`` / ``evaluate`` as 4 and as 8 real processes -- bank /
+    cursor / header logic, rank parts of every batch, the sharded top-k with history mask, metric all-reduce -- reproduce
+    the one-rank run of the same global batches (BPR, ml-100k fixture, one epoch; interleaved rows at world 8)."""
+    epochs, batch_global = 1, 2048
+    runs = ((1, {'_trim': 8}), (4, {'_trim': 8}), (8, {'_trim': 8, 'shard_layout': 'interleaved'}))
+    for world, extra in runs:
+        mp.spawn(_fit_worker, args=(world, _free_port(), str(tmp_path), epochs, batch_global, extra), nprocs=world, join=True)
+    one = torch.load(tmp_path / 'w1r0.pt', weights_only=False)
+    for world, extra in runs[1:]:
+        parts = [torch.load(tmp_path / f'w{world}r{r}.pt', weights_only=False) for r in range(world)]
+        for t in parts:
+            np.testing.assert_allclose(t['losses'].numpy(), one['losses'].numpy(), rtol=1e-5, atol=1e-6)
+            for k in ('ndcg@10', 'recall@10'):
+                assert abs(t['val'][k] - one['val'][k]) < 1e-5 and abs(t['test'][k] - one['test'][k]) < 1e-5
+            np.testing.assert_allclose(t['tower'].numpy(), one['tower'].numpy(), rtol=1e-4, atol=1e-6)
+        if 'shard_layout' in extra:
+            items = torch.empty_like(one['item'])
+            for r, t in enumerate(parts):
+                items[r::world] = t['item']
+        else:
+            items = torch.cat([t['item'] for t in parts])
+            assert [t['lo'] for t in parts] == [r * parts[0]['item'].shape[0] for r in range(world)]
+        np.testing.assert_allclose(items.numpy(), one['item'].numpy(), rtol=1e-4, atol=1e-5)     # (Adam: a different summation order on a near-zero gradient)
+        assert not items[0].any()
+
+
+def _wide_topk_worker(rank, world, port, result_dir):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        import recstudio_amd as ra
+        from recstudio_amd import ops
+        from recstudio_amd.shard import RowShardPlan, ShardedItemTable
+        ops.FULLSCORE_MAX_K = 8                       # (the in-kernel select limit, shrunk so that a 41-item catalog crosses it)
+        n_items, d, B, k, width = 41, 8, 5, 3, 10
+        g = torch.Generator().manual_seed(3)
+        item = torch.randn(n_items, d, generator=g)
+        item[0] = 0
+        plan = RowShardPlan(n_items, world)
+        table = ShardedItemTable(plan.take(item, rank).clone(), plan, rank, dist, backend=CheckerBackend())
+        model = ra.BaseRetriever({'train': {'seed': None}})
+        model._shard = {'table': table, 'n_items': n_items, 'hist_width': width, 'topk_narrow': 6}
+        q = torch.randn(B, d, generator=torch.Generator().manual_seed(50 + rank))
+        calls = []
+        full = table.full_lse_topk
+        table.full_lse_topk = lambda qq, kk, want_lse=True: (calls.append(kk), full(qq, kk, want_lse))[1]
+        best = torch.argsort(-(q @ item[1:].t()), dim=1) + 1
+        for blocked in (False, True):
+            hist = torch.zeros(B, width, dtype=torch.int64)
+            hist[:, :4] = best[:, 10:14]                                   # histories that do not touch the head
+            if blocked and rank == world - 1:
+                hist[2, :6] = best[2, :6]      # ONE row of ONE rank whose history is the whole narrow candidate list
+            del calls[:]
+            score, ids = model._topk_sharded(q, k, hist, False)
+            # k + |history| = 13 > 8: six candidates first; every rank goes wide exactly when some row somewhere ran short
+            assert calls == ([6, 13] if blocked else [6])
+            want_s, want_i = oracle.topk_with_history(q, item, k, hist)
+            assert torch.equal(ids, want_i)
+            np.testing.assert_allclose(score.numpy(), want_s.numpy(), rtol=1e-6, atol=1e-6)
+        open(os.path.join(result_dir, f'ok{rank}'), 'w').write('ok')
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_topk_with_histories_longer_than_the_select(tmp_path):
+    """``k + |history|`` beyond the in-kernel select (ml-1m: ~1.8 k) used to raise after a full epoch.  Now the
+    single-process strategy with rank-uniform shapes: a narrow candidate list, history dropped, and the wide pass only
+    when a row of ANY rank is left short -- decided by one all-reduced flag, so every rank takes the same branch."""
+    world = 2
+    mp.spawn(_wide_topk_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    assert all(os.path.exists(tmp_path / f'ok{r}') for r in range(world))
