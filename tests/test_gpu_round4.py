@@ -238,13 +238,14 @@ def test_sasrec_fit_two_staged_ranks_equals_one_rank_hip(tmp_path):
             np.testing.assert_allclose(t['losses'].numpy(), one['losses'].numpy(), rtol=5e-5, atol=1e-6)
             for k in ('ndcg@10', 'recall@10'):
                 assert abs(t['val'][k] - one['val'][k]) < 2e-3 and abs(t['test'][k] - one['test'][k]) < 2e-3
-            np.testing.assert_allclose(t['tower'].numpy(), one['tower'].numpy(), rtol=5e-3, atol=1e-4)
+            # (Adam at 3e-3: a weight whose gradient is near zero moves by up to the rate on a summation-order difference)
+            np.testing.assert_allclose(t['tower'].numpy(), one['tower'].numpy(), rtol=5e-3, atol=1e-3)
         items = torch.empty_like(one['item'])
         if layout == 'interleaved':
             items[0::2], items[1::2] = two[0]['item'], two[1]['item']
         else:
             items = torch.cat([two[0]['item'], two[1]['item']])
-        np.testing.assert_allclose(items.numpy(), one['item'].numpy(), rtol=5e-3, atol=1e-4)
+        np.testing.assert_allclose(items.numpy(), one['item'].numpy(), rtol=5e-3, atol=1e-3)
         assert not items[0].any()
 
 
