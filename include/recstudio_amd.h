@@ -30,7 +30,10 @@
 extern "C" {
 #endif
 
-#define RSA_ABI_VERSION 6   /* 6: rsa_adam_rows_presorted; rows_per_shard == 0 = interleaved row ownership in the shard routing entry points;
+#define RSA_ABI_VERSION 7   /* 7: rsa_shard_backward_segments (the owner side of the sharded backward in one call: in-tree radix sorts
+                               straight from the received segments, one walk over the query runs that reads every item row once and
+                               updates solo rows in place, sorted apply for the shared rows); the sorted scatters no longer call rocPRIM;
+                               6: rsa_adam_rows_presorted; rows_per_shard == 0 = interleaved row ownership in the shard routing entry points;
                                5: version 2 of the fixed-capacity shard exchange (rsa_shard_sample_route: sampling fused into the routing
                                pass, self-describing segments with {count, dropped} headers, 32-bit slots; rsa_shard_score_segments;
                                rsa_shard_home: scatter + loss + mean + routed-order gradient in one launch; rsa_shard_unpack_segments;
@@ -569,6 +572,38 @@ int rsa_shard_scatter_slots(const float* dpos, const float* dneg, const int32_t*
 int rsa_shard_unpack_segments(const int64_t* keys, int64_t n_segments, int64_t stride, int64_t* local_rows,
                               int64_t* query_index, const float* scale_in, const int32_t* step_dropped, float* scale_out,
                               rsa_stream_t stream);
+
+/* The whole owner side of the sharded backward on received segments (replaces rsa_shard_unpack_segments + two
+ * rsa_scatter_rows_sorted calls, i.e. the ATen sequence autograd runs for the reference's
+ * item_encoder(neg ids) / score_func backward, recommender.py:636-639, on the rows this rank owns):
+ *     qgrad_all[q]   += gate * sum_{slots of query q} d[slot] * item_local[row(slot)]
+ *     item_target[r] += gate * item_scale * sum_{slots on row r} d[slot] * q_all[query(slot)]      (r != item_pad_row)
+ * with gate = step_dropped[0] != 0 ? 0 : 1 (scale_out <- {gate * item_scale, gate}).  item_target == item_local: plain
+ * SGD in place (item_scale = -lr) -- rows that ONE slot of the step touches are rewritten by the walk that reads them
+ * for the query gradient, the others by the sorted apply pass; otherwise item_target is this rank's block of the dense
+ * gradient.  Deterministic (no float atomics).  dim in {64, 128, 256}.  `workspace`: caller-owned,
+ * rsa_shard_backward_workspace_bytes(n_segments, stride, n_query_rows) bytes. */
+typedef struct rsa_shard_backward_args {
+  const float* item_local;     /* [n_rows, dim] this rank's rows */
+  int64_t n_rows;
+  int32_t dim;
+  const float* q_all;          /* [n_query_rows, dim] the gathered queries of all ranks */
+  int64_t n_query_rows;
+  const int64_t* keys;         /* [n_segments, stride] received segments (RSA_SHARD_HDR header words + keys) */
+  int64_t n_segments;
+  int64_t stride;
+  const float* d_owner;        /* [n_segments * stride] d loss / d score in slot order (slack: never read) */
+  float* item_target;          /* item_local itself (in-place SGD) or the [n_rows, dim] gradient block */
+  const float* item_scale;     /* device scalar, nullable (1) */
+  const int32_t* step_dropped; /* device word, nullable (no gate) */
+  float* scale_out;            /* [2] device: {gate * item_scale, gate} */
+  float* qgrad_all;            /* [n_query_rows, dim], accumulated into */
+  int64_t item_pad_row;        /* row that never receives gradient (-1: none) */
+  void* workspace;
+  int64_t workspace_bytes;
+} rsa_shard_backward_args;
+int64_t rsa_shard_backward_workspace_bytes(int64_t n_segments, int64_t stride, int64_t n_query_rows);
+int rsa_shard_backward_segments(const rsa_shard_backward_args* args, rsa_stream_t stream);
 
 #ifdef __cplusplus
 }

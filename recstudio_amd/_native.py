@@ -80,6 +80,16 @@ class ShardHomeArgs(Structure):
     ]
 
 
+class ShardBackwardArgs(Structure):
+    """struct rsa_shard_backward_args (include/recstudio_amd.h)."""
+    _fields_ = [
+        ('item_local', c_void_p), ('n_rows', c_int64), ('dim', c_int32), ('q_all', c_void_p), ('n_query_rows', c_int64),
+        ('keys', c_void_p), ('n_segments', c_int64), ('stride', c_int64), ('d_owner', c_void_p), ('item_target', c_void_p),
+        ('item_scale', c_void_p), ('step_dropped', c_void_p), ('scale_out', c_void_p), ('qgrad_all', c_void_p),
+        ('item_pad_row', c_int64), ('workspace', c_void_p), ('workspace_bytes', c_int64),
+    ]
+
+
 # name -> (restype, argtypes); must list every symbol the header declares.
 SIGNATURES = {
     'rsa_last_error': (c_char_p, []),
@@ -141,6 +151,8 @@ SIGNATURES = {
     'rsa_shard_scatter_slots': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p]),
     'rsa_shard_unpack_segments': (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                           c_void_p]),
+    'rsa_shard_backward_workspace_bytes': (c_int64, [c_int64, c_int64, c_int64]),
+    'rsa_shard_backward_segments': (c_int, [POINTER(ShardBackwardArgs), c_void_p]),
     'rsa_shard_unpack': (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     'rsa_scatter_f32': (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     'rsa_gather_f32': (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
@@ -166,7 +178,7 @@ def build(verbose=False):
     return LIB_PATH
 
 
-ABI_VERSION = 6      # RSA_ABI_VERSION of include/recstudio_amd.h this binding was written against
+ABI_VERSION = 7      # RSA_ABI_VERSION of include/recstudio_amd.h this binding was written against
 
 
 def lib():

@@ -1,0 +1,31 @@
+// Declarations shared between the translation units of librecstudio_amd.so (not part of the C ABI).
+#pragma once
+#include "rsa_common.hpp"
+
+namespace rsa {
+
+struct AdamArgs {            // exp_avg == nullptr: plain accumulate (target[id] += scale * sum)
+  float* exp_avg;
+  float* exp_avg_sq;
+  float one_minus_beta1, one_minus_beta2, eps, step_size;
+};
+
+struct SortedLayout {        // a sorted scatter's workspace (sorted_workspace_bytes)
+  uint64_t *pairs_a, *pairs_b;     // packed (key << 32 | element) pairs: the radix sort's ping-pong buffers
+  void* temp;                      // its digit counters
+  float *lead_part, *trail_part;   // per 64-element chunk: partial sums of the runs that cross its borders
+  int32_t* meta;
+};
+
+int64_t sorted_workspace_bytes(int64_t max_total);
+SortedLayout sorted_layout(void* workspace, int64_t max_total);
+
+// flags[e] <- 1 for the elements that are alone on their row (and bit 31 of the pair's payload is set)
+int classify_solo(uint64_t* pairs, int64_t total, int64_t pad_row, int64_t drop_key, uint8_t* solo, hipStream_t s, const char* who);
+
+// target[row] += upstream * sum d[e] * query[qrow(e)] over row-sorted pairs of received exchange segments (e = slot)
+int apply_sorted_segments(const uint64_t* pairs, int64_t total, const float* query, int32_t dim, const int64_t* keys,
+                          const float* d, const float* upstream, int64_t n_rows, int64_t pad_row, float* target,
+                          const SortedLayout& L, hipStream_t s);
+
+}  // namespace rsa

@@ -1,0 +1,256 @@
+// In-tree LSD radix sort of (32-bit key, 32-bit payload) pairs for gfx950 (wave64), specialised to what the training
+// steps sort: a few million (row id | query index, element number) pairs whose keys have 12 .. 27 significant bits.
+//
+// Replaces rocprim::radix_sort_pairs on the step's hot path.  What the specialisation buys:
+//   * a pair travels as ONE 8-byte word (key << 32 | payload): one load / one store per element and pass, and the
+//     consumers (sorted_apply_kernel, classify_solo_kernel, the owner-side walk) read one array;
+//   * pass 0 reads its keys straight from the producer's tensors through a SOURCE functor (the step's int64 id tensors,
+//     the received exchange segments): no key-extraction launch, no 33 MB id round trip;
+//   * only ceil(bits / 8) passes, 8-bit digits, 4096-element tiles.
+// Per pass: radix_hist_kernel (per-tile digit counts) -> radix_scan_kernel (per digit: exclusive scan over the tiles) ->
+// radix_scatter_kernel (stable rank inside the tile, the tile regrouped by digit in LDS, contiguous runs written out).
+// Stable and deterministic: no atomics decide a position (the LDS atomics of the histogram only count).
+//
+// Ranking inside a tile: a wave owns 1024 consecutive elements and walks them 64 at a time in element order; the lanes
+// that hold the same digit find each other with 8 ballots (one per digit bit), the rank inside the row is a popcount of
+// the lower peers, the row's count goes to the wave's own 256 LDS counters.  The four waves' counters are then prefixed
+// in wave order, so positions follow the element order: stable.
+#pragma once
+#include "rsa_common.hpp"
+
+namespace rsa {
+
+constexpr int RDX_DIGIT_BITS = 8;
+constexpr int RDX_BINS = 1 << RDX_DIGIT_BITS;
+constexpr int RDX_ITEMS = 16;                         // rows of 64 per wave
+constexpr int RDX_WAVE_TILE = 64 * RDX_ITEMS;         // 1024
+constexpr int RDX_TILE = 4 * RDX_WAVE_TILE;           // 4096 elements per workgroup
+
+__host__ __device__ inline uint64_t rdx_pack(uint32_t key, uint32_t val) { return ((uint64_t)key << 32) | val; }
+__host__ __device__ inline uint32_t rdx_key(uint64_t p) { return (uint32_t)(p >> 32); }
+__host__ __device__ inline uint32_t rdx_val(uint64_t p) { return (uint32_t)p; }
+
+// ---- sources of pass 0 (element i -> packed pair)
+struct SrcPairs {                       // an already packed buffer (passes 1..)
+  const uint64_t* p;
+  __device__ __forceinline__ uint64_t operator()(int64_t i) const { return p[i]; }
+};
+
+// (item id, element number) of a step: element e = m * w + c, c = 0 the positive (when given), else negative c - off.
+// A negative id is an empty slot: key n_items sorts behind every real row (its run is skipped by the consumers).
+struct SrcStepIds {
+  const int64_t* pos_ids;
+  const int64_t* neg_ids;
+  int64_t n_items;
+  int32_t n, w, off;
+  __device__ __forceinline__ uint64_t operator()(int64_t e) const {
+    const int64_t m = (uint32_t)e / (uint32_t)w;       // e < 2^31 (checked by the host)
+    const int c = (int)(e - m * w);
+    int64_t id = (off && c == 0) ? pos_ids[m] : neg_ids[m * (int64_t)n + (c - off)];
+    id = id < 0 ? n_items : (id >= n_items ? n_items - 1 : id);
+    return rdx_pack((uint32_t)id, (uint32_t)e);
+  }
+};
+
+// Received exchange segments [n_seg][stride] of 8-byte keys (query << 32 | local row) behind RSA_SHARD_HDR header
+// words: element = slot number; BY_QUERY: key = query index, else the local row; a slot outside its segment's live
+// range gets `dead_key` (sorts last).
+template <bool BY_QUERY>
+struct SrcSegments {
+  const int64_t* keys;
+  uint32_t stride;
+  uint32_t dead_key;
+  __device__ __forceinline__ uint64_t operator()(int64_t i) const {
+    const uint32_t seg = (uint32_t)i / stride, within = (uint32_t)i - seg * stride;
+    const int64_t live = keys[(size_t)seg * stride];
+    uint32_t key = dead_key;
+    if (within >= RSA_SHARD_HDR && (int64_t)(within - RSA_SHARD_HDR) < live) {
+      const int64_t k = keys[i];
+      key = BY_QUERY ? (uint32_t)((k >> 32) & 0x7fffffffll) : (uint32_t)(k & 0xffffffffll);
+      key = key > dead_key ? dead_key : key;          // never index past the tables on a bad key
+    }
+    return rdx_pack(key, (uint32_t)i);
+  }
+};
+
+// exclusive scan of one value per thread over a 256-thread workgroup; returns the exclusive prefix, *total = the sum
+__device__ __forceinline__ uint32_t block_excl_scan_256(uint32_t v, uint32_t* s_wave /*[4]*/, uint32_t* total) {
+  const int lane = lane_id(), wave = threadIdx.x >> 6;
+  uint32_t inc = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t o = __shfl_up(inc, d, 64);
+    if (lane >= d) inc += o;
+  }
+  if (lane == 63) s_wave[wave] = inc;
+  __syncthreads();
+  uint32_t base = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    const uint32_t s = s_wave[w];
+    if (w < wave) base += s;
+    tot += s;
+  }
+  if (total) *total = tot;
+  __syncthreads();               // s_wave may be reused by the caller
+  return base + inc - v;
+}
+
+template <class SRC>
+__global__ __launch_bounds__(256) void radix_hist_kernel(const SRC src, int64_t total, int shift, int64_t n_tiles,
+                                                         uint32_t* __restrict__ counts) {
+  __shared__ uint32_t h[RDX_BINS];
+  h[threadIdx.x] = 0;
+  __syncthreads();
+  const int64_t base = (int64_t)blockIdx.x * RDX_TILE;
+#pragma unroll 4
+  for (int r = 0; r < RDX_ITEMS; ++r) {
+    const int64_t i = base + r * 256 + threadIdx.x;
+    if (i < total) atomicAdd(&h[(uint32_t)(src(i) >> shift) & (RDX_BINS - 1)], 1u);
+  }
+  __syncthreads();
+  counts[(size_t)threadIdx.x * n_tiles + blockIdx.x] = h[threadIdx.x];       // digit-major: the scan is linear per digit
+}
+
+// one workgroup per digit: counts[d][0 .. n_tiles) -> exclusive prefix over the tiles; totals[d] = the digit's count
+static __global__ __launch_bounds__(256) void radix_scan_kernel(uint32_t* __restrict__ counts, int64_t n_tiles,
+                                                         uint32_t* __restrict__ totals) {
+  __shared__ uint32_t s_wave[4];
+  uint32_t* c = counts + (size_t)blockIdx.x * n_tiles;
+  const int64_t per = (n_tiles + 255) / 256;
+  const int64_t lo = threadIdx.x * per, hi = lo + per < n_tiles ? lo + per : n_tiles;
+  uint32_t sum = 0;
+  for (int64_t i = lo; i < hi; ++i) sum += c[i];
+  uint32_t tot;
+  uint32_t run = block_excl_scan_256(sum, s_wave, &tot);
+  for (int64_t i = lo; i < hi; ++i) {
+    const uint32_t t = c[i];
+    c[i] = run;
+    run += t;
+  }
+  if (threadIdx.x == 0) totals[blockIdx.x] = tot;
+}
+
+template <class SRC>
+__global__ __launch_bounds__(256) void radix_scatter_kernel(const SRC src, int64_t total, int shift, int64_t n_tiles,
+                                                            const uint32_t* __restrict__ counts,
+                                                            const uint32_t* __restrict__ totals,
+                                                            uint64_t* __restrict__ out) {
+  __shared__ uint32_t cnt[4][RDX_BINS];      // per-wave digit counters while ranking, then the waves' bases inside a digit
+  __shared__ uint32_t dbase[RDX_BINS];       // first position of digit d inside the regrouped tile
+  __shared__ int64_t gbase[RDX_BINS];        // global position of that element, minus dbase[d]
+  __shared__ uint32_t s_wave[4];
+  __shared__ uint64_t stage[RDX_TILE];       // the tile regrouped by digit
+  const int lane = lane_id(), wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) cnt[w][threadIdx.x] = 0;
+  __syncthreads();
+  const int64_t tile0 = (int64_t)blockIdx.x * RDX_TILE;
+  const int64_t base = tile0 + (int64_t)wave * RDX_WAVE_TILE;
+  uint64_t v[RDX_ITEMS];
+  uint32_t loc[RDX_ITEMS];
+#pragma unroll
+  for (int r = 0; r < RDX_ITEMS; ++r) {
+    const int64_t i = base + r * 64 + lane;
+    v[r] = i < total ? src(i) : ~0ull;
+  }
+  volatile uint32_t* wc = cnt[wave];
+  const uint64_t lt = (1ull << lane) - 1ull;
+#pragma unroll
+  for (int r = 0; r < RDX_ITEMS; ++r) {
+    const bool valid = base + r * 64 + lane < total;
+    const uint32_t d = (uint32_t)(v[r] >> shift) & (RDX_BINS - 1);
+    uint64_t peers = __ballot(valid);
+#pragma unroll
+    for (int b = 0; b < RDX_DIGIT_BITS; ++b) {
+      const bool bit = (d >> b) & 1u;
+      const uint64_t bal = __ballot(bit);
+      peers &= bit ? bal : ~bal;
+    }
+    loc[r] = 0;
+    if (valid) {
+      const uint32_t c0 = wc[d];
+      const uint32_t rank = (uint32_t)__popcll(peers & lt);
+      loc[r] = c0 + rank;
+      if (rank == 0) wc[d] = c0 + (uint32_t)__popcll(peers);       // the row's lowest lane of the digit adds the row's count
+    }
+  }
+  __syncthreads();
+  {   // thread d: the waves' bases inside digit d, the digit's count in the tile and its first position
+    const int d = threadIdx.x;
+    const uint32_t c0 = cnt[0][d], c1 = cnt[1][d], c2 = cnt[2][d], c3 = cnt[3][d];
+    cnt[0][d] = 0;
+    cnt[1][d] = c0;
+    cnt[2][d] = c0 + c1;
+    cnt[3][d] = c0 + c1 + c2;
+    const uint32_t first = block_excl_scan_256(c0 + c1 + c2 + c3, s_wave, nullptr);
+    const uint32_t gstart = block_excl_scan_256(totals[d], s_wave, nullptr);      // elements of smaller digits, all tiles
+    dbase[d] = first;
+    gbase[d] = (int64_t)gstart + (int64_t)counts[(size_t)d * n_tiles + blockIdx.x] - (int64_t)first;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < RDX_ITEMS; ++r) {
+    if (base + r * 64 + lane < total) {
+      const uint32_t d = (uint32_t)(v[r] >> shift) & (RDX_BINS - 1);
+      stage[dbase[d] + cnt[wave][d] + loc[r]] = v[r];
+    }
+  }
+  __syncthreads();
+  const int64_t left = total - tile0;
+  const int tile_n = left < RDX_TILE ? (int)left : RDX_TILE;
+#pragma unroll 4
+  for (int k = 0; k < RDX_ITEMS; ++k) {
+    const int j = k * 256 + threadIdx.x;
+    if (j < tile_n) {
+      const uint64_t p = stage[j];
+      const uint32_t d = (uint32_t)(p >> shift) & (RDX_BINS - 1);
+      out[gbase[d] + j] = p;
+    }
+  }
+}
+
+// ---- host side
+inline unsigned radix_key_bits(int64_t n_keys) {      // bits needed for keys 0 .. n_keys - 1
+  unsigned b = 1;
+  while (b < 32 && (1ll << b) < n_keys) ++b;
+  return b;
+}
+inline int radix_passes(unsigned bits) { return (int)((bits + RDX_DIGIT_BITS - 1) / RDX_DIGIT_BITS); }
+inline int64_t radix_tiles(int64_t total) { return (total + RDX_TILE - 1) / RDX_TILE; }
+inline int64_t radix_temp_bytes(int64_t total) {
+  const int64_t c = RDX_BINS * radix_tiles(total) * 4;
+  return (c + 255) / 256 * 256 + RDX_BINS * 4;
+}
+
+// Sorts `total` pairs by their `bits` low key bits.  Pass 0 reads `src0` and writes buf_a, pass 1 reads buf_a and writes
+// buf_b, ...: the result is in radix_result(buf_a, buf_b, bits).  `temp`: radix_temp_bytes(total) bytes.
+inline uint64_t* radix_result(uint64_t* buf_a, uint64_t* buf_b, unsigned bits) { return (radix_passes(bits) & 1) ? buf_a : buf_b; }
+
+template <class SRC0>
+inline hipError_t radix_sort_pairs(const SRC0& src0, uint64_t* buf_a, uint64_t* buf_b, int64_t total, unsigned bits,
+                                   void* temp, hipStream_t s) {
+  if (total <= 0) return hipSuccess;
+  const int64_t n_tiles = radix_tiles(total);
+  uint32_t* counts = reinterpret_cast<uint32_t*>(temp);
+  uint32_t* totals = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(temp) + (RDX_BINS * n_tiles * 4 + 255) / 256 * 256);
+  const int passes = radix_passes(bits);
+  const dim3 grid((unsigned)n_tiles), block(256);
+  for (int p = 0; p < passes; ++p) {
+    const int shift = 32 + p * RDX_DIGIT_BITS;
+    uint64_t* dst = (p & 1) ? buf_b : buf_a;
+    if (p == 0) {
+      hipLaunchKernelGGL((radix_hist_kernel<SRC0>), grid, block, 0, s, src0, total, shift, n_tiles, counts);
+      hipLaunchKernelGGL(radix_scan_kernel, dim3(RDX_BINS), block, 0, s, counts, n_tiles, totals);
+      hipLaunchKernelGGL((radix_scatter_kernel<SRC0>), grid, block, 0, s, src0, total, shift, n_tiles, counts, totals, dst);
+    } else {
+      const SrcPairs sp{(p & 1) ? buf_a : buf_b};
+      hipLaunchKernelGGL((radix_hist_kernel<SrcPairs>), grid, block, 0, s, sp, total, shift, n_tiles, counts);
+      hipLaunchKernelGGL(radix_scan_kernel, dim3(RDX_BINS), block, 0, s, counts, n_tiles, totals);
+      hipLaunchKernelGGL((radix_scatter_kernel<SrcPairs>), grid, block, 0, s, sp, total, shift, n_tiles, counts, totals, dst);
+    }
+  }
+  return hipGetLastError();
+}
+
+}  // namespace rsa

@@ -4,8 +4,8 @@
 // embedding_dense_backward / index_add_ of the reference (recstudio/model/basemodel/recommender.py:636-639 via
 // autograd) is an atomic scatter in ATen and in rsa_fused_backward's dense mode.  Float atomics from 8 XCDs to
 // one table are performed at the memory side, a dword at a time: 537 M of them cost 2.5 ms per step at
-// B = 65536, n = 64, d = 128.  Here the elements are sorted by item id first (rocPRIM radix sort of (id, element)
-// pairs, stable), every wave sums its 64 sorted elements run by run in element order, and every row is read-modified-
+// B = 65536, n = 64, d = 128.  Here the elements are sorted by item id first (the in-tree LSD radix sort of packed (id,
+// element) pairs, rsa_radix.hpp, stable), every wave sums its 64 sorted elements run by run in element order, and every row is read-modified-
 // written once with full-line accesses: no atomics, bit-reproducible, ~2x faster.  A run that crosses chunk
 // boundaries (rare and short for item ids; the RULE when the key is a query index -- the owner side of the sharded
 // backward sums ~1000 item rows per query) is not walked by one wave: each chunk leaves the partial sum of its
@@ -13,8 +13,9 @@
 // `target` may be a zeroed dense gradient (== the reference's weight.grad) or the weight table itself with
 // scale = -lr (plain SGD applied in place).
 #include "rsa_common.hpp"
+#include "rsa_radix.hpp"
+#include "rsa_internal.hpp"
 #include <cstring>
-#include <rocprim/device/device_radix_sort.hpp>
 
 // rows requested ahead by the apply pass.  4: 78 VGPRs at d = 128 = 6 waves/SIMD; 8: 110 = 4 waves.  In-process A/B
 // (tools/exp_sorted_ab.py, us per launch, 4 vs 8): headline shape all elements 836.2 / 837.7, solo rows skipped 343.7 / 350.4;
@@ -24,31 +25,6 @@
 #endif
 
 namespace rsa {
-
-__global__ __launch_bounds__(256) void sorted_keys_kernel(const int64_t* __restrict__ pos_ids,
-                                                          const int64_t* __restrict__ neg_ids, int64_t n_queries, int n,
-                                                          int64_t n_items, int32_t* __restrict__ keys,
-                                                          int32_t* __restrict__ vals) {
-  const int w = pos_ids ? n + 1 : n;          // elements per query: positive slot only when positives are given
-  const int off = pos_ids ? 1 : 0;
-  const int64_t total = n_queries * (int64_t)w;
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
-    const int64_t m = e / w;
-    const int c = (int)(e - m * w);
-    int64_t id = (off && c == 0) ? pos_ids[m] : neg_ids[m * (int64_t)n + (c - off)];
-    // a negative id is an empty slot: key n_items sorts behind every real row and its run is skipped
-    id = id < 0 ? n_items : (id >= n_items ? n_items - 1 : id);
-    keys[e] = (int32_t)id;
-    vals[e] = (int32_t)e;
-  }
-}
-
-struct AdamArgs {            // exp_avg == nullptr: plain accumulate (target[id] += scale * sum)
-  float* exp_avg;
-  float* exp_avg_sq;
-  float one_minus_beta1, one_minus_beta2, eps, step_size;
-};
 
 // target[cur] (+ lazy Adam state) <- one read-modify-write of the row with the run's sum `acc`; trow / mrow_v / vrow_v
 // are the row's current values (requested earlier, at the head of the run).
@@ -90,11 +66,32 @@ enum { META_LEAD_KEY = 0, META_LEAD_FULL = 1, META_TRAIL_KEY = 2, META_STRIDE = 
 #ifndef RSA_SORTED_MIN_WAVES
 #define RSA_SORTED_MIN_WAVES 1
 #endif
-template <int NDW>   // dwords per lane per row: D = 64 * NDW
-__global__ __launch_bounds__(256, RSA_SORTED_MIN_WAVES) void sorted_apply_kernel(const int32_t* __restrict__ keys, const int32_t* __restrict__ vals,
-                                                           int64_t total, const float* __restrict__ query,
-                                                           const int64_t* __restrict__ query_index, int n, int has_pos,
-                                                           const float* __restrict__ dpos, const float* __restrict__ dneg,
+// What element e of the sorted pairs stands for: its query row and its coefficient d loss/d score.
+struct DecStep {             // a step's [M, (1 +) n] element order: e = m * w + c
+  const int64_t* query_index;
+  const float* dpos;
+  const float* dneg;
+  int n, has_pos;
+  __device__ __forceinline__ void operator()(int64_t e, int32_t& qrow, float& coef) const {
+    const int w = n + has_pos;
+    const int64_t m = (uint32_t)e / (uint32_t)w;
+    const int c = (int)(e - m * w);
+    qrow = (int32_t)(query_index ? query_index[m] : m);
+    coef = (has_pos && c == 0) ? dpos[m] : dneg[m * (int64_t)n + (c - has_pos)];
+  }
+};
+struct DecSegments {         // received exchange segments: e = slot, key = (query << 32 | row), d in slot order
+  const int64_t* keys;
+  const float* d;
+  __device__ __forceinline__ void operator()(int64_t e, int32_t& qrow, float& coef) const {
+    qrow = (int32_t)((keys[e] >> 32) & 0x7fffffffll);
+    coef = d[e];
+  }
+};
+
+template <int NDW, class DEC>   // dwords per lane per row: D = 64 * NDW
+__global__ __launch_bounds__(256, RSA_SORTED_MIN_WAVES) void sorted_apply_kernel(const uint64_t* __restrict__ pairs,
+                                                           int64_t total, const float* __restrict__ query, const DEC dec,
                                                            const float* __restrict__ upstream, int32_t pad_row,
                                                            int32_t drop_key, float* __restrict__ target, AdamArgs adam,
                                                            float* __restrict__ lead_part, float* __restrict__ trail_part,
@@ -105,28 +102,23 @@ __global__ __launch_bounds__(256, RSA_SORTED_MIN_WAVES) void sorted_apply_kernel
   const int64_t begin = chunk * 64;
   if (begin >= total) return;
   const float scale = upstream ? upstream[0] : 1.f;
-  const int w = n + has_pos;
   // this lane's element of the chunk: key, query row, coefficient (all lanes in parallel)
   const int64_t i = begin + lane;
   const bool in = i < total;
-  const int32_t key = in ? keys[i] : -1;
+  const uint64_t pr = in ? pairs[i] : 0ull;
+  const int32_t key = in ? (int32_t)rdx_key(pr) : -1;
   int32_t qrow = 0;
   float coef = 0.f;
   bool solo = false;                  // flagged by classify_solo_kernel: the row has been applied by the forward
   if (in && key != drop_key) {        // empty slots: nothing is read for them (their query index is -1)
-    int64_t e = vals[i];
+    int32_t e = (int32_t)rdx_val(pr);
     solo = e < 0;
     e &= 0x7fffffff;
-    const int64_t m = e / w;
-    const int c = (int)(e - m * w);
-    if (!solo) {
-      qrow = (int32_t)(query_index ? query_index[m] : m);
-      coef = (has_pos && c == 0) ? dpos[m] : dneg[m * (int64_t)n + (c - has_pos)];
-    }
+    if (!solo) dec((int64_t)e, qrow, coef);
   }
   const int cnt = (int)(total - begin < 64 ? total - begin : 64);
-  const int32_t prev = begin > 0 ? keys[begin - 1] : -1;                     // key in front of the chunk
-  const int32_t next = begin + cnt < total ? keys[begin + cnt] : -1;         // key behind it
+  const int32_t prev = begin > 0 ? (int32_t)rdx_key(pairs[begin - 1]) : -1;                     // key in front of the chunk
+  const int32_t next = begin + cnt < total ? (int32_t)rdx_key(pairs[begin + cnt]) : -1;         // key behind it
   float acc[NDW];
   float trow[NDW], mrow_v[NDW], vrow_v[NDW];     // the current run's target (and Adam state) row, requested at its head
 #pragma unroll
@@ -278,34 +270,92 @@ __global__ __launch_bounds__(256) void sorted_finish_kernel(int64_t n_chunks, co
 // element number in `vals` is set so that the apply kernel leaves the row alone: a forward that updates solo rows
 // itself (rsa_fused_args.solo_flags) has already applied them.
 constexpr int32_t SOLO_BIT = (int32_t)0x80000000;
-__global__ __launch_bounds__(256) void classify_solo_kernel(const int32_t* __restrict__ keys, int32_t* __restrict__ vals,
-                                                            int64_t total, int32_t pad_row, int32_t drop_key,
-                                                            uint8_t* __restrict__ solo) {
+__global__ __launch_bounds__(256) void classify_solo_kernel(uint64_t* __restrict__ pairs, int64_t total, int32_t pad_row,
+                                                            int32_t drop_key, uint8_t* __restrict__ solo) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
-    const int32_t k = keys[i];
-    const int32_t before = i > 0 ? keys[i - 1] : -1, after = i + 1 < total ? keys[i + 1] : -1;
+    const uint64_t pr = pairs[i];
+    const int32_t k = (int32_t)rdx_key(pr);
+    const int32_t before = i > 0 ? (int32_t)rdx_key(pairs[i - 1]) : -1, after = i + 1 < total ? (int32_t)rdx_key(pairs[i + 1]) : -1;
     if (k != before && k != after && k != pad_row && k != drop_key) {       // (the flags were zeroed: only the ones are stored --
-      const int32_t e = vals[i];                                            //  a scattered byte store each)
+      const uint32_t e = rdx_val(pr);                                       //  a scattered byte store each)
       solo[e] = 1;
-      vals[i] = e | SOLO_BIT;
+      pairs[i] = pr | (uint64_t)(uint32_t)SOLO_BIT;      // (only the payload word changes: a neighbour reading the key races on nothing)
     }
   }
 }
 
 static inline int64_t align256s(int64_t b) { return (b + 255) / 256 * 256; }
 
-static size_t sort_temp_bytes(int64_t total, unsigned end_bit) {
-  size_t bytes = 0;
-  (void)rocprim::radix_sort_pairs(nullptr, bytes, (const int32_t*)nullptr, (int32_t*)nullptr, (const int32_t*)nullptr,
-                                  (int32_t*)nullptr, (size_t)total, 0u, end_bit, (hipStream_t)0);
-  return bytes;
+// ---- the workspace of a sorted scatter over `max_total` elements: two packed-pair buffers, the radix sort's counters,
+// per 64-element chunk two partial rows (sized for dim = 256) and the segment record
+int64_t sorted_workspace_bytes(int64_t max_total) {
+  const int64_t chunks = (max_total + 63) / 64;
+  return 2 * align256s(max_total * 8) + align256s(radix_temp_bytes(max_total)) + 2 * align256s(chunks * 256 * 4) +
+         align256s(chunks * META_STRIDE * 4) + 256;
 }
 
-static unsigned key_bits(int64_t n_items) {
-  unsigned b = 1;
-  while (b < 31 && (1ll << b) < n_items) ++b;
-  return b;
+SortedLayout sorted_layout(void* workspace, int64_t max_total) {
+  char* ws = reinterpret_cast<char*>(workspace);
+  const int64_t seg = align256s(max_total * 8);
+  const int64_t max_chunks = (max_total + 63) / 64;
+  SortedLayout L;
+  L.pairs_a = reinterpret_cast<uint64_t*>(ws);
+  L.pairs_b = reinterpret_cast<uint64_t*>(ws + seg);
+  L.temp = ws + 2 * seg;
+  char* tail = ws + 2 * seg + align256s(radix_temp_bytes(max_total));
+  L.lead_part = reinterpret_cast<float*>(tail);
+  L.trail_part = reinterpret_cast<float*>(tail + align256s(max_chunks * 256 * 4));
+  L.meta = reinterpret_cast<int32_t*>(tail + 2 * align256s(max_chunks * 256 * 4));
+  return L;
+}
+
+int classify_solo(uint64_t* pairs, int64_t total, int64_t pad_row, int64_t drop_key, uint8_t* solo, hipStream_t s, const char* who) {
+  const int32_t pad = (int32_t)(pad_row < 0 || pad_row >= (1ll << 31) ? -2 : pad_row);
+  if (hipMemsetAsync(solo, 0, (size_t)total, s) != hipSuccess) {
+    rsa::set_error("%s: memset failed", who);
+    return RSA_ERR_HIP;
+  }
+  int64_t blocks = (total + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(classify_solo_kernel, dim3((unsigned)blocks), dim3(256), 0, s, pairs, total, pad, (int32_t)drop_key, solo);
+  RSA_CHECK_LAUNCH(who);
+  return RSA_OK;
+}
+
+// the apply + finish passes over sorted pairs
+template <class DEC>
+static int apply_sorted_pairs(const uint64_t* pairs, int64_t total, const float* query, int32_t dim, const DEC& dec,
+                              const float* upstream, int64_t drop_key, int64_t pad_row, float* target, AdamArgs adam,
+                              const SortedLayout& L, hipStream_t s) {
+  if (dim != 64 && dim != 128 && dim != 256) {
+    rsa::set_error("rsa_scatter_rows_sorted: dim=%d: built for dim in {64, 128, 256}", dim);
+    return RSA_ERR_UNSUPPORTED;
+  }
+  const unsigned chunks = (unsigned)((total + 63) / 64);
+  dim3 grid((chunks + 3) / 4), block(256);
+  const int32_t pad = (int32_t)(pad_row < 0 || pad_row >= (1ll << 31) ? -2 : pad_row);
+#define RSA_SORTED_LAUNCH(NDW)                                                                                                 \
+  hipLaunchKernelGGL((sorted_apply_kernel<NDW, DEC>), grid, block, 0, s, pairs, total, query, dec, upstream, pad,               \
+                     (int32_t)drop_key, target, adam, L.lead_part, L.trail_part, L.meta);                                       \
+  hipLaunchKernelGGL(sorted_finish_kernel<NDW>, grid, block, 0, s, (int64_t)chunks, upstream, pad, target, adam, L.lead_part,   \
+                     L.trail_part, L.meta)
+  switch (dim) {
+    case 64: RSA_SORTED_LAUNCH(1); break;
+    case 128: RSA_SORTED_LAUNCH(2); break;
+    default: RSA_SORTED_LAUNCH(4); break;
+  }
+#undef RSA_SORTED_LAUNCH
+  RSA_CHECK_LAUNCH("rsa_scatter_rows_sorted(apply)");
+  return RSA_OK;
+}
+
+int apply_sorted_segments(const uint64_t* pairs, int64_t total, const float* query, int32_t dim, const int64_t* keys,
+                          const float* d, const float* upstream, int64_t n_rows, int64_t pad_row, float* target,
+                          const SortedLayout& L, hipStream_t s) {
+  const AdamArgs none{nullptr, nullptr, 0.f, 0.f, 0.f, 0.f};
+  const DecSegments dec{keys, d};
+  return apply_sorted_pairs(pairs, total, query, dim, dec, upstream, n_rows, pad_row, target, none, L, s);
 }
 
 }  // namespace rsa
@@ -314,38 +364,13 @@ using namespace rsa;
 
 extern "C" int64_t rsa_scatter_rows_sorted_workspace_bytes(int64_t n_queries, int32_t num_neg, int64_t n_items) {
   if (n_queries <= 0 || num_neg < 0 || n_items < 1) return 0;
-  const int64_t total = n_queries * (int64_t)(num_neg + 1);     // sized for the with-positives layout
-  const int64_t chunks = (total + 63) / 64;
-  // + per chunk: two partial rows (sized for dim = 256) and the segment record
-  // + per chunk: two partial rows (sized for dim = 256) and the segment record
-  return 4 * align256s(total * 4) + align256s((int64_t)sort_temp_bytes(total, key_bits(n_items + 1))) +
-         2 * align256s(chunks * 256 * 4) + align256s(chunks * META_STRIDE * 4) + 256;
+  return sorted_workspace_bytes(n_queries * (int64_t)(num_neg + 1));     // sized for the with-positives layout
 }
 
-struct SortedLayout {        // the caller's workspace (rsa_scatter_rows_sorted_workspace_bytes)
-  int32_t *k_in, *v_in, *k_out, *v_out;
-  void* temp;
-  float *lead_part, *trail_part;
-  int32_t* meta;
-};
-
-
-static SortedLayout sorted_layout(void* workspace, int64_t n_queries, int32_t num_neg, int64_t n_items) {
-  char* ws = reinterpret_cast<char*>(workspace);
-  const int64_t max_total = n_queries * (int64_t)(num_neg + 1);
-  const int64_t seg = align256s(max_total * 4);
-  const int64_t max_chunks = (max_total + 63) / 64;
-  SortedLayout L;
-  L.k_in = reinterpret_cast<int32_t*>(ws);
-  L.v_in = reinterpret_cast<int32_t*>(ws + seg);
-  L.k_out = reinterpret_cast<int32_t*>(ws + 2 * seg);
-  L.v_out = reinterpret_cast<int32_t*>(ws + 3 * seg);
-  L.temp = ws + 4 * seg;
-  char* tail = ws + 4 * seg + align256s((int64_t)sort_temp_bytes(max_total, key_bits(n_items + 1)));
-  L.lead_part = reinterpret_cast<float*>(tail);
-  L.trail_part = reinterpret_cast<float*>(tail + align256s(max_chunks * 256 * 4));
-  L.meta = reinterpret_cast<int32_t*>(tail + 2 * align256s(max_chunks * 256 * 4));
-  return L;
+// where the sorted pairs of a step live in its workspace (a function of the sizes alone: the sort and the apply are
+// separate entry points)
+static uint64_t* step_sorted(const SortedLayout& L, int64_t n_items) {
+  return radix_result(L.pairs_a, L.pairs_b, radix_key_bits(n_items + 1));      // ids 0 .. n_items-1 and the drop key n_items
 }
 
 // (item id, element) pairs of a step, radix-sorted by id into the workspace; with `solo` also the classification pass
@@ -362,29 +387,14 @@ static int sort_elements_impl(const int64_t* pos_ids, const int64_t* neg_ids, in
   RSA_CHECK_ARG(workspace && workspace_bytes >= need, "%s: workspace too small (%lld < %lld)", who, (long long)workspace_bytes,
                 (long long)need);
   hipStream_t s = (hipStream_t)stream;
-  const SortedLayout L = sorted_layout(workspace, n_queries, num_neg, n_items);
-  int64_t blocks = (total + 255) / 256;
-  if (blocks > 65536) blocks = 65536;
-  hipLaunchKernelGGL(sorted_keys_kernel, dim3((unsigned)blocks), dim3(256), 0, s, pos_ids, neg_ids, n_queries, (int)num_neg,
-                     n_items, L.k_in, L.v_in);
-  RSA_CHECK_LAUNCH(who);
-  const unsigned bits = key_bits(n_items + 1);      // ids 0 .. n_items-1 and the drop key n_items
-  size_t temp_bytes = sort_temp_bytes(total, bits);
-  if (rocprim::radix_sort_pairs(L.temp, temp_bytes, L.k_in, L.k_out, L.v_in, L.v_out, (size_t)total, 0u, bits, s) != hipSuccess) {
+  const SortedLayout L = sorted_layout(workspace, n_queries * (int64_t)(num_neg + 1));
+  // pass 0 of the sort reads the id tensors themselves (no key-extraction launch, no id round trip)
+  const SrcStepIds src{pos_ids, neg_ids, n_items, num_neg, num_neg + has_pos, has_pos};
+  if (radix_sort_pairs(src, L.pairs_a, L.pairs_b, total, radix_key_bits(n_items + 1), L.temp, s) != hipSuccess) {
     rsa::set_error("%s: radix sort failed: %s", who, hipGetErrorString(hipGetLastError()));
     return RSA_ERR_HIP;
   }
-  if (solo != nullptr) {
-    const int32_t pad = (int32_t)(pad_row < 0 || pad_row >= (1ll << 31) ? -2 : pad_row);
-    if (hipMemsetAsync(solo, 0, (size_t)total, s) != hipSuccess) {
-      rsa::set_error("%s: memset failed", who);
-      return RSA_ERR_HIP;
-    }
-    if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(classify_solo_kernel, dim3((unsigned)blocks), dim3(256), 0, s, L.k_out, L.v_out, total, pad,
-                       (int32_t)n_items, solo);
-    RSA_CHECK_LAUNCH(who);
-  }
+  if (solo != nullptr) return classify_solo(step_sorted(L, n_items), total, pad_row, n_items, solo, s, who);
   return RSA_OK;
 }
 
@@ -398,32 +408,14 @@ static int apply_sorted_impl(const float* query, const int64_t* query_index, int
   RSA_CHECK_ARG(query && dneg && target, "rsa_scatter_rows_sorted: null pointer");
   RSA_CHECK_ARG(!has_pos || dpos != nullptr, "rsa_scatter_rows_sorted: pos_ids without dpos");
   RSA_CHECK_ARG(query_index != nullptr || n_query_rows >= n_queries, "rsa_scatter_rows_sorted: query has fewer rows than n_queries");
-  if (dim != 64 && dim != 128 && dim != 256) {
-    rsa::set_error("rsa_scatter_rows_sorted: dim=%d: built for dim in {64, 128, 256}", dim);
-    return RSA_ERR_UNSUPPORTED;
-  }
   const int64_t total = n_queries * (int64_t)(num_neg + has_pos);
   const int64_t need = rsa_scatter_rows_sorted_workspace_bytes(n_queries, num_neg, n_items);
   RSA_CHECK_ARG(workspace && workspace_bytes >= need, "rsa_scatter_rows_sorted: workspace too small (%lld < %lld)",
                 (long long)workspace_bytes, (long long)need);
-  hipStream_t s = (hipStream_t)stream;
-  const SortedLayout L = sorted_layout(workspace, n_queries, num_neg, n_items);
-  const unsigned chunks = (unsigned)((total + 63) / 64);
-  dim3 grid((chunks + 3) / 4), block(256);
-  const int32_t pad = (int32_t)(pad_row < 0 || pad_row >= (1ll << 31) ? -2 : pad_row);
-#define RSA_SORTED_LAUNCH(NDW)                                                                                              \
-  hipLaunchKernelGGL(sorted_apply_kernel<NDW>, grid, block, 0, s, L.k_out, L.v_out, total, query, query_index, (int)num_neg,  \
-                     has_pos, dpos, dneg, upstream, pad, (int32_t)n_items, target, adam, L.lead_part, L.trail_part, L.meta); \
-  hipLaunchKernelGGL(sorted_finish_kernel<NDW>, grid, block, 0, s, (int64_t)chunks, upstream, pad, target, adam,              \
-                     L.lead_part, L.trail_part, L.meta)
-  switch (dim) {
-    case 64: RSA_SORTED_LAUNCH(1); break;
-    case 128: RSA_SORTED_LAUNCH(2); break;
-    default: RSA_SORTED_LAUNCH(4); break;
-  }
-#undef RSA_SORTED_LAUNCH
-  RSA_CHECK_LAUNCH("rsa_scatter_rows_sorted(apply)");
-  return RSA_OK;
+  const SortedLayout L = sorted_layout(workspace, n_queries * (int64_t)(num_neg + 1));
+  const DecStep dec{query_index, dpos, dneg, (int)num_neg, has_pos};
+  return apply_sorted_pairs(step_sorted(L, n_items), total, query, dim, dec, upstream, n_items, pad_row, target, adam, L,
+                            (hipStream_t)stream);
 }
 
 static int scatter_sorted_impl(const float* query, const int64_t* query_index, int64_t n_query_rows, int32_t dim,

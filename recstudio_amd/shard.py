@@ -272,19 +272,29 @@ class HipBackend:
         m = n_seg * stride
         if m == 0:
             return
+        scale = state['scale']
+        if item_local.shape[1] in (64, 128, 256):
+            # ONE call (rsa_shard_backward_segments): the slots radix-sorted by row and by query straight from the segments,
+            # one walk over the query runs that reads every item row once (query-gradient partials in registers, rows a
+            # single slot touches updated in place), the sorted apply pass for the rows several slots share
+            a = nat.ShardBackwardArgs()
+            a.item_local, a.n_rows, a.dim = ptr(item_local), item_local.shape[0], item_local.shape[1]
+            a.q_all, a.n_query_rows = ptr(ops._need(q_all, torch.float32, 'q_all')), q_all.shape[0]
+            a.keys, a.n_segments, a.stride = ptr(recv_keys), int(n_seg), int(stride)
+            a.d_owner = ptr(ops._need(d_owner, torch.float32, 'd_owner'))
+            a.item_target, a.item_scale = ptr(item_grad_local), ptr(item_scale)
+            a.step_dropped, a.scale_out, a.qgrad_all = ptr(state['step_dropped']), ptr(scale), ptr(qgrad_all)
+            a.item_pad_row = int(item_pad_row)
+            nbytes = int(nat.lib().rsa_shard_backward_workspace_bytes(int(n_seg), int(stride), q_all.shape[0]))
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=recv_keys.device)
+            a.workspace, a.workspace_bytes = ptr(ws), nbytes
+            nat.check(nat.lib().rsa_shard_backward_segments(ctypes.byref(a), ops._stream()), 'rsa_shard_backward_segments')
+            return
         rows = torch.empty(m, dtype=torch.int64, device=recv_keys.device)
         qidx = torch.empty(m, dtype=torch.int64, device=recv_keys.device)
-        scale = state['scale']
         nat.check(nat.lib().rsa_shard_unpack_segments(ptr(recv_keys), n_seg, stride, ptr(rows), ptr(qidx), ptr(item_scale),
                                                       ptr(state['step_dropped']), ptr(scale), ops._stream()),
                   'rsa_shard_unpack_segments')
-        if item_local.shape[1] in (64, 128, 256):
-            # two atomics-free sorted scatters (by query -- it reads the item rows, so it runs first -- then by item row)
-            ops.scatter_rows_sorted(qgrad_all, item_local, qidx.view(m, 1), d_owner.view(m, 1), query_index=rows,
-                                    upstream=scale[1:2], pad_row=-1)
-            ops.scatter_rows_sorted(item_grad_local, q_all, rows.view(m, 1), d_owner.view(m, 1), query_index=qidx,
-                                    upstream=scale[0:1], pad_row=item_pad_row)
-            return
         if item_scale is not None:
             raise NotImplementedError('in-place item update needs embed_dim in {64, 128, 256}')
         d_owner = torch.where(rows >= 0, d_owner * scale[1], torch.zeros((), device=d_owner.device))

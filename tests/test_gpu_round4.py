@@ -279,3 +279,109 @@ def test_sharded_topk_wide_history_hip(ra):
             rel_close(score.cpu(), want_s, rtol=1e-4, atol=1e-5)
     finally:
         dist.destroy_process_group()
+
+
+# --------------------------------------------------------------------------- the owner side of the sharded backward, one call
+@pytest.mark.parametrize('d,n_rows,Q,n_seg,cap', [(128, 5003, 96, 8, 700), (64, 301, 7, 3, 90), (256, 100_003, 2048, 16, 9000),
+                                                  (128, 17, 4, 2, 3000), (128, 50_021, 64, 8, 20_000)])
+def test_owner_backward_segments_vs_index_add(ra, d, n_rows, Q, n_seg, cap):
+    """rsa_shard_backward_segments (in-tree radix sorts by row and by query straight from the segments, one walk over the
+    query runs, solo rows in place, sorted apply for the shared rows) == two index_add_ in float64: the dense gradient
+    block, plain SGD in place, the padding row, dead slack (NaN coefficients there: never read), a gated step, and
+    bit-equality run to run.  Shapes: few long runs (a 17-row block: every row shared by hundreds of slots), many short
+    runs, runs longer than a tile per wave (cap 20 000 over 64 queries)."""
+    from recstudio_amd.shard import HipBackend
+    be = HipBackend()
+    g = torch.Generator().manual_seed(d + n_rows)
+    stride = cap + be.HDR
+    keys = torch.full((n_seg, stride), -7, dtype=torch.int64)
+    dv = torch.full((n_seg, stride), float('nan'))
+    live = torch.randint(0, cap + 1, (n_seg,), generator=g)
+    live[0] = cap                                                          # a full segment ...
+    if n_seg > 1:
+        live[1] = 0                                                        # ... and an empty one
+    rows_l, q_l, d_l = [], [], []
+    for s_ in range(n_seg):
+        c = int(live[s_])
+        keys[s_, 0], keys[s_, 1] = c, 0
+        r = torch.randint(0, n_rows, (c,), generator=g)
+        if c > 10:
+            r[:5] = 0                                                      # the padding row gets slots too
+        q = torch.randint(0, Q, (c,), generator=g)
+        keys[s_, be.HDR:be.HDR + c] = (q << 32) | r
+        dd = torch.randn(c, generator=g)
+        dv[s_, be.HDR:be.HDR + c] = dd
+        rows_l.append(r), q_l.append(q), d_l.append(dd)
+    rows, qi, dd = torch.cat(rows_l), torch.cat(q_l), torch.cat(d_l)
+    item = torch.randn(n_rows, d, generator=g) * 0.3
+    q_all = torch.randn(Q, d, generator=g) * 0.3
+    keep = rows != 0
+    want_q = torch.zeros(Q, d, dtype=torch.float64).index_add_(0, qi, dd.double().unsqueeze(1) * item[rows].double())
+    want_i = torch.zeros(n_rows, d, dtype=torch.float64).index_add_(0, rows[keep], dd[keep].double().unsqueeze(1) * q_all[qi[keep]].double())
+    keys_d, dv_d, q_d = keys.to(DEV).view(-1), dv.to(DEV).view(-1), q_all.to(DEV)
+
+    def run(target_is_table, lr=None, dropped=0):
+        st = be.new_state(DEV)
+        st['step_dropped'].fill_(dropped)
+        tab = item.to(DEV).clone()
+        tgt = tab if target_is_table else torch.zeros(n_rows, d, device=DEV)
+        qg = torch.zeros(Q, d, device=DEV)
+        sc = None if lr is None else torch.full((1,), -lr, device=DEV)
+        be.backward_segments(st, tab, q_d, keys_d, n_seg, stride, dv_d, tgt, qg, item_pad_row=0, item_scale=sc)
+        return tab, tgt, qg, st
+    # dense gradient block
+    tab, grad, qg, st = run(False)
+    assert torch.equal(tab.cpu(), item)                                    # the table is only read
+    rel_close(qg.cpu(), want_q.float(), rtol=2e-4, atol=2e-5)
+    rel_close(grad.cpu(), want_i.float(), rtol=2e-4, atol=2e-5)
+    assert not grad[0].any() and st['scale'].tolist() == [1.0, 1.0]
+    _, grad2, qg2, _ = run(False)
+    assert torch.equal(grad, grad2) and torch.equal(qg, qg2)                # deterministic
+    # SGD in place: solo rows by the walk, shared rows by the sorted apply, the padding row untouched
+    tab, _, qg3, st = run(True, lr=0.25)
+    rel_close(tab.cpu(), (item.double() - 0.25 * want_i).float(), rtol=2e-4, atol=2e-5)
+    rel_close(qg3.cpu(), want_q.float(), rtol=2e-4, atol=2e-5)
+    assert torch.equal(tab[0].cpu(), item[0]) and st['scale'].tolist() == [-0.25, 1.0]
+    tab_b, _, qg3b, _ = run(True, lr=0.25)
+    assert torch.equal(tab, tab_b) and torch.equal(qg3, qg3b)
+    # a step in which some rank dropped an element changes nothing
+    tab, _, qg4, st = run(True, lr=0.25, dropped=3)
+    assert torch.equal(tab.cpu(), item) and not qg4.any() and st['scale'].tolist() == [0.0, 0.0]
+
+
+@pytest.mark.parametrize('n_items,total_q,n', [(97, 41, 64), (2 ** 24 + 5, 300, 64), (100_000_001, 64, 128), (1000, 70_000, 64)])
+def test_in_tree_radix_sort_through_the_sorted_scatter(ra, n_items, total_q, n):
+    """The in-tree LSD radix sort (rsa_radix.hpp; 1 .. 4 passes of 8 bits: 97 items -> 1 pass, 2^24 + 5 -> 4, 1e8 -> 4) under
+    the sorted scatter: every element lands on its row (== index_add_ in float64 on the touched rows), ids beyond 2^24,
+    negative ids (empty slots) dropped, a padding row skipped, more than one tile per digit (70 000 x 65 elements)."""
+    d = 64
+    g = torch.Generator().manual_seed(n_items % 1000)
+    ids = torch.randint(0, n_items, (total_q, n), generator=g)
+    ids[:, :3] = torch.tensor([n_items - 1, 0, n_items // 2])
+    ids[::7, 5] = -1                                                       # empty slots
+    pos = torch.randint(1, n_items, (total_q,), generator=g)
+    dneg, dpos = torch.randn(total_q, n, generator=g), torch.randn(total_q, generator=g)
+    q = torch.randn(total_q, d, generator=g)
+    # a compact table: the touched rows only (a 1e8 x 64 target would be 25 GB; the sort does not care about the table)
+    touched = torch.unique(torch.cat([ids.reshape(-1).clamp(min=0), pos]))
+    remap = {int(v): i for i, v in enumerate(touched.tolist())}
+    if n_items <= 2 ** 24 + 5 and n_items * d * 4 < 6e9:
+        target = torch.zeros(n_items, d, device=DEV)
+        ra.ops.scatter_rows_sorted(target, q.to(DEV), ids.to(DEV), dneg.to(DEV), pos_ids=pos.to(DEV), dpos=dpos.to(DEV), pad_row=0)
+        got = target[touched.to(DEV)].cpu()
+    else:
+        # the full-size key range through the sort + classification entry point: solo flags == a CPU count
+        solo = ra.ops.sort_step_elements(pos.to(DEV), ids.to(DEV), n_items, pad_row=0)[0].cpu().view(total_q, n + 1)
+        flat = torch.cat([pos.view(-1, 1), ids], 1)
+        uniq, cnt = torch.unique(flat[flat >= 0], return_counts=True)
+        once = set(uniq[cnt == 1].tolist()) - {0}
+        want = torch.tensor([[int(v) in once for v in row] for row in flat.tolist()])
+        assert torch.equal(solo.bool(), want)
+        return
+    want = torch.zeros(len(remap), d, dtype=torch.float64)
+    live = ids.reshape(-1) > 0
+    rows = torch.tensor([remap[int(v)] for v in ids.reshape(-1)[live].tolist()])
+    want.index_add_(0, rows, dneg.reshape(-1)[live].double().unsqueeze(1) * q.repeat_interleave(n, 0)[live].double())
+    want.index_add_(0, torch.tensor([remap[int(v)] for v in pos.tolist()]), dpos.double().unsqueeze(1) * q.double())
+    # (a 1000-row catalog under 4.5 M elements: every row sums ~4500 terms in fp32, the tolerance follows the magnitude)
+    rel_close(got, want.float(), rtol=2e-4, atol=2e-6 * float(want.abs().max()) + 2e-5)
