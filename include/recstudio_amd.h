@@ -30,7 +30,8 @@
 extern "C" {
 #endif
 
-#define RSA_ABI_VERSION 7   /* 7: rsa_shard_backward_segments (the owner side of the sharded backward in one call: in-tree radix sorts
+#define RSA_ABI_VERSION 7   /* 7: rsa_shard_pos_score / rsa_shard_owner_bpr_forward / _finish (the BPR step evaluated on the owners: rows read
+                               once per step); rsa_shard_sample_route: route_pos; rsa_shard_backward_segments (the owner side of the sharded backward in one call: in-tree radix sorts
                                straight from the received segments, one walk over the query runs that reads every item row once and
                                updates solo rows in place, sorted apply for the shared rows); the sorted scatters no longer call rocPRIM;
                                6: rsa_adam_rows_presorted; rows_per_shard == 0 = interleaved row ownership in the shard routing entry points;
@@ -523,6 +524,8 @@ typedef struct rsa_shard_route_args {
   int32_t* cursors;            /* [(n_slices * n_shards * n_banks + 33) * 32] int32 device scratch (one 128-byte line per cursor
                                   and ticket), zeroed ONCE by the caller (self-resetting) */
   int32_t* counts_out;         /* nullable [n_slices * n_shards * n_banks]: exact element counts per segment -- calibration */
+  int32_t skip_pos;            /* != 0: the positives are NOT routed (slot_of of column 0 = -1): the owner-side BPR step
+                                  (rsa_shard_owner_bpr_forward) scores them from the gathered ids instead */
 } rsa_shard_route_args;
 int64_t rsa_shard_segment_stride(int64_t capacity);    /* RSA_SHARD_HDR + capacity: 8-byte words per segment */
 int rsa_shard_sample_route(const rsa_shard_route_args* args, rsa_stream_t stream);
@@ -604,6 +607,57 @@ typedef struct rsa_shard_backward_args {
 } rsa_shard_backward_args;
 int64_t rsa_shard_backward_workspace_bytes(int64_t n_segments, int64_t stride, int64_t n_query_rows);
 int rsa_shard_backward_segments(const rsa_shard_backward_args* args, rsa_stream_t stream);
+
+/* The stock BPR training step (loss_func.py:55-59 on the scores of baseretriever.py:153-171, and its backward) evaluated
+ * ON THE OWNERS of the negatives -- the item rows of a step are then read once instead of twice (scoring pass + backward
+ * pass), and neither scores nor score gradients cross the fabric:
+ *   rsa_shard_pos_score          out[i] = q_all[i] . item_local[pos_rows[i]] for the positives this rank owns (pos_rows[i]
+ *                                >= 0: the local row; < 0: another rank's), 0 for the others -- summed over the ranks
+ *                                (a 4-byte-per-query all-reduce) it is every positive's score on every rank;
+ *   rsa_shard_owner_bpr_forward  over the negatives this rank received (the positives are NOT routed in this protocol):
+ *                                score, loss term -logsigmoid(pos - neg) / num_neg, d = sigmoid(neg - pos) / (num_neg *
+ *                                mean_den) (-> d_slots[slot]), qgrad_all[q] += gate * sum d * row, rows that one element of
+ *                                the step touches updated in place (item_target == item_local, scale = gate * item_scale);
+ *                                dsum_part[q] = the query's sum of d here, loss_part = this rank's share of the mean loss.
+ *                                Also publishes the step's dropped total (the received headers' word 1) into step_dropped /
+ *                                overflow_sticky and the update scales into scale_out, like rsa_shard_score_segments +
+ *                                rsa_shard_backward_segments do in the score-at-home protocol;
+ *   rsa_shard_owner_bpr_finish   with dsum_all = the ranks' dsum_part summed (second small all-reduce): the positives this
+ *                                rank owns -- d loss/d pos = -dsum_all[q] (-> d_slots[slots + q]), qgrad_all[q] += gate *
+ *                                dpos * row, the row updated in place when it is the positive's alone -- and then the
+ *                                sorted apply pass for every row several elements (negatives or positives) touch.
+ * Same workspace (rsa_shard_backward_workspace_bytes) and the same args for both calls of a step.  dim in {64, 128, 256}. */
+typedef struct rsa_shard_owner_bpr_args {
+  const float* item_local;     /* [n_rows, dim] */
+  int64_t n_rows;
+  int32_t dim;
+  int32_t num_neg;             /* negatives per query of the step (the 1/n of BPRLoss) */
+  const float* q_all;          /* [n_query_rows, dim] */
+  int64_t n_query_rows;
+  const int64_t* keys;         /* [n_segments, stride] received segments (negatives only) */
+  int64_t n_segments;
+  int64_t stride;
+  const int64_t* pos_rows;     /* [n_query_rows] local row of each query's positive on this rank, < 0: not owned */
+  const float* pos_score;      /* [n_query_rows] */
+  int64_t mean_den;            /* queries of the step over all ranks (the mean of BPRLoss) */
+  float* item_target;          /* item_local (SGD in place) or the [n_rows, dim] gradient block */
+  const float* item_scale;     /* device scalar, nullable (1) */
+  int32_t* step_dropped;       /* device word, written */
+  int32_t* overflow_sticky;    /* device word, accumulated */
+  float* scale_out;            /* [2] device */
+  float* qgrad_all;            /* [n_query_rows, dim], accumulated into */
+  float* d_slots;              /* [n_segments * stride + n_query_rows] OUT */
+  float* dsum_part;            /* [n_query_rows] OUT */
+  float* loss_part;            /* [1] OUT, nullable */
+  void* reduce_scratch;        /* rsa_scratch_bytes() bytes, zeroed once (with loss_part) */
+  int64_t item_pad_row;
+  void* workspace;
+  int64_t workspace_bytes;
+} rsa_shard_owner_bpr_args;
+int rsa_shard_pos_score(const float* item_local, int64_t n_rows, int32_t dim, const float* q_all, int64_t n_query_rows,
+                        const int64_t* pos_rows, float* out, rsa_stream_t stream);
+int rsa_shard_owner_bpr_forward(const rsa_shard_owner_bpr_args* args, rsa_stream_t stream);
+int rsa_shard_owner_bpr_finish(const rsa_shard_owner_bpr_args* args, const float* dsum_all, rsa_stream_t stream);
 
 #ifdef __cplusplus
 }

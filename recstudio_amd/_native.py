@@ -67,6 +67,7 @@ class ShardRouteArgs(Structure):
         ('table', c_void_p), ('pop_prob', c_void_p), ('guide', c_void_p), ('table_prob', c_void_p), ('cdf_lut', c_void_p),
         ('cdf_lines', c_void_p), ('guide_log2', c_int32), ('lines_log2', c_int32),
         ('send_keys', c_void_p), ('slot_of', c_void_p), ('cursors', c_void_p), ('counts_out', c_void_p),
+        ('skip_pos', c_int32),
     ]
 
 
@@ -86,6 +87,18 @@ class ShardBackwardArgs(Structure):
         ('item_local', c_void_p), ('n_rows', c_int64), ('dim', c_int32), ('q_all', c_void_p), ('n_query_rows', c_int64),
         ('keys', c_void_p), ('n_segments', c_int64), ('stride', c_int64), ('d_owner', c_void_p), ('item_target', c_void_p),
         ('item_scale', c_void_p), ('step_dropped', c_void_p), ('scale_out', c_void_p), ('qgrad_all', c_void_p),
+        ('item_pad_row', c_int64), ('workspace', c_void_p), ('workspace_bytes', c_int64),
+    ]
+
+
+class ShardOwnerBprArgs(Structure):
+    """struct rsa_shard_owner_bpr_args (include/recstudio_amd.h)."""
+    _fields_ = [
+        ('item_local', c_void_p), ('n_rows', c_int64), ('dim', c_int32), ('num_neg', c_int32), ('q_all', c_void_p),
+        ('n_query_rows', c_int64), ('keys', c_void_p), ('n_segments', c_int64), ('stride', c_int64), ('pos_rows', c_void_p),
+        ('pos_score', c_void_p), ('mean_den', c_int64), ('item_target', c_void_p), ('item_scale', c_void_p),
+        ('step_dropped', c_void_p), ('overflow_sticky', c_void_p), ('scale_out', c_void_p), ('qgrad_all', c_void_p),
+        ('d_slots', c_void_p), ('dsum_part', c_void_p), ('loss_part', c_void_p), ('reduce_scratch', c_void_p),
         ('item_pad_row', c_int64), ('workspace', c_void_p), ('workspace_bytes', c_int64),
     ]
 
@@ -153,6 +166,9 @@ SIGNATURES = {
                                           c_void_p]),
     'rsa_shard_backward_workspace_bytes': (c_int64, [c_int64, c_int64, c_int64]),
     'rsa_shard_backward_segments': (c_int, [POINTER(ShardBackwardArgs), c_void_p]),
+    'rsa_shard_pos_score': (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
+    'rsa_shard_owner_bpr_forward': (c_int, [POINTER(ShardOwnerBprArgs), c_void_p]),
+    'rsa_shard_owner_bpr_finish': (c_int, [POINTER(ShardOwnerBprArgs), c_void_p, c_void_p]),
     'rsa_shard_unpack': (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     'rsa_scatter_f32': (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     'rsa_gather_f32': (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),

@@ -72,15 +72,6 @@ struct FwdParams {
   int32_t seg_stride;           // != 0: packed_keys is [n_segments][seg_stride] with RSA_SHARD_HDR header words per segment
 };
 
-// d / d neg of  -w * inv_m * logsigmoid(pos - neg)  =  w * inv_m * sigmoid(neg - pos), written so that the
-// in-loop (query gradient) and epilogue (dneg output) evaluations are the same float operations
-__device__ __forceinline__ float bpr_dneg(float pos, float neg, float w, float inv_m) {
-  const float xd = pos - neg;
-  const float t = __expf(-fabsf(xd));
-  const float r = __frcp_rn(1.f + t);
-  return (xd >= 0.f ? t * r : r) * w * inv_m;
-}
-
 // In-place partial transpose-reduce over the lane-mask bits {step, 2*step, ..., step*L/2}:
 // on entry d[k] belongs to tile row (base + k*step); on return d[0] is the sum, over the lanes
 // that differ only in those mask bits, of the row selected by this lane's own bits.

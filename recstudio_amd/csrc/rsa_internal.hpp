@@ -23,9 +23,10 @@ SortedLayout sorted_layout(void* workspace, int64_t max_total);
 // flags[e] <- 1 for the elements that are alone on their row (and bit 31 of the pair's payload is set)
 int classify_solo(uint64_t* pairs, int64_t total, int64_t pad_row, int64_t drop_key, uint8_t* solo, hipStream_t s, const char* who);
 
-// target[row] += upstream * sum d[e] * query[qrow(e)] over row-sorted pairs of received exchange segments (e = slot)
-int apply_sorted_segments(const uint64_t* pairs, int64_t total, const float* query, int32_t dim, const int64_t* keys,
-                          const float* d, const float* upstream, int64_t n_rows, int64_t pad_row, float* target,
-                          const SortedLayout& L, hipStream_t s);
+// target[row] += upstream * sum d[e] * query[qrow(e)] over row-sorted pairs of received exchange segments (e = slot;
+// elements e >= slots: the positive of query e - slots, coefficient d[e])
+int apply_sorted_segments(const uint64_t* pairs, int64_t total, int64_t slots, const float* query, int32_t dim,
+                          const int64_t* keys, const float* d, const float* upstream, int64_t n_rows, int64_t pad_row,
+                          float* target, const SortedLayout& L, hipStream_t s);
 
 }  // namespace rsa

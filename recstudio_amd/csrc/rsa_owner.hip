@@ -15,6 +15,12 @@
 //   4. the rows several elements touch (29 % of the elements at that shape) go through the sorted apply pass, which
 //      skips everything flagged solo.
 // All of it deterministic: no float atomics, fixed summation orders.
+//
+// The same walk is also the FORWARD of the stock BPR training step (rsa_shard_owner_bpr_forward / _finish): BPR's
+// d loss/d neg = sigmoid(neg - pos) / (n M) needs nothing but the query's positive score, so once every owner holds the
+// positives' scores (rsa_shard_pos_score on the positive's owner + a 4-byte-per-query all-reduce) it evaluates scores,
+// loss terms and gradients of the negatives it received while their rows are in registers: no scores travel home, no
+// gradients travel back, and the item rows are read ONCE per step instead of twice.
 #include "rsa_common.hpp"
 #include "rsa_internal.hpp"
 #include "rsa_radix.hpp"
@@ -43,10 +49,29 @@ struct OwnArgs {
   const float* scale;          // {gate * item_scale, gate}
   int64_t n_rows;
   int32_t n_queries;
+  // SCORE (the BPR training step evaluated on the owner): d is an OUTPUT
+  float* d_out;                // [slots] d loss/d score of every live slot
+  const float* pos_score;      // [n_queries] score of every query's positive
+  float* dsum;                 // [n_queries] <- sum of the query's d over this owner's slots
+  float* loss_out;             // <- this owner's share of the mean loss
+  unsigned int* done_counter;
+  float* loss_partials;
+  float bw, binv;              // 1 / num_neg, 1 / mean_den
+  int64_t mean_den;
 };
 
-__global__ void owner_scale_kernel(const float* __restrict__ scale_in, const int32_t* __restrict__ step_dropped,
-                                   float* __restrict__ scale_out) {
+// keys != nullptr: step_dropped / overflow_sticky are first PUBLISHED from the received segments' header word 1 (what each
+// source could not place this step) -- in the score-at-home protocol rsa_shard_score_segments does that
+__global__ void owner_scale_kernel(const float* __restrict__ scale_in, int32_t* __restrict__ step_dropped,
+                                   float* __restrict__ scale_out, const int64_t* __restrict__ keys, int64_t n_seg,
+                                   int64_t stride, int32_t* __restrict__ overflow_sticky) {
+  if (keys != nullptr && step_dropped != nullptr) {
+    int64_t total = 0;
+    for (int64_t sg = 0; sg < n_seg; ++sg) total += keys[sg * stride + 1];
+    const int32_t t32 = total > 0x7fffffffll ? 0x7fffffff : (int32_t)total;
+    *step_dropped = t32;
+    if (overflow_sticky && t32) atomicAdd(overflow_sticky, t32);
+  }
   const float gate = (step_dropped != nullptr && step_dropped[0] != 0) ? 0.f : 1.f;
   scale_out[0] = gate * (scale_in ? scale_in[0] : 1.f);
   scale_out[1] = gate;
@@ -69,9 +94,13 @@ __global__ __launch_bounds__(256) void query_runs_kernel(const uint64_t* __restr
 
 // 64 elements of ONE query: lane r holds element r's row (bit 31: solo) and coefficient; every lane group streams its
 // rows in batches, qacc += d * row, and a solo row is rewritten as row + upd * (d * q)
-template <int LPR, bool NT, bool UPD>
+// SCORE: d_lane carries the BPR weight of the lane's element instead (1 / n, 0 for an idle lane); every row's dot with
+// the query is completed while its fragment is in registers and turned into d = w * sigmoid(dot - pos_s) / M; on return
+// dot_out is the dot of the lane's own row
+template <int LPR, bool NT, bool UPD, bool SCORE>
 __device__ __forceinline__ void tile_rows_own(const float* table, int32_t id_lane, float d_lane, const Frag<LPR, false>& qf,
-                                              float4& qacc, float* item_rw, float upd) {
+                                              float4& qacc, float* item_rw, float upd, float pos_s, float binv,
+                                              float& dot_out) {
   using F = Frag<LPR, false>;
   constexpr int D = LPR * 4;
   constexpr int BATCH = LPR < RSA_OWN_BATCH ? LPR : RSA_OWN_BATCH;
@@ -94,7 +123,12 @@ __device__ __forceinline__ void tile_rows_own(const float* table, int32_t id_lan
 #pragma unroll
     for (int k = 0; k < BATCH; ++k) {
       const int r = gb + b * BATCH + k;
-      const float g = __shfl(d_lane, r, 64);
+      float g = __shfl(d_lane, r, 64);
+      if constexpr (SCORE) {
+        const float dk = group_sum<LPR>(frag_dot<LPR, false>(x[b & 1][k], qf));
+        g = bpr_dneg(pos_s, dk, g, binv);
+        dot_out = sub == b * BATCH + k ? dk : dot_out;
+      }
       const float4 xv = x[b & 1][k].v[0];
       qacc.x = __fmaf_rn(g, xv.x, qacc.x);
       qacc.y = __fmaf_rn(g, xv.y, qacc.y);
@@ -118,11 +152,13 @@ __device__ __forceinline__ void tile_rows_own(const float* table, int32_t id_lan
 
 // A query belongs to ONE workgroup: wpq = 1 << wpq_log2 of its waves share the run's tiles round-robin and wave 0 of
 // the query adds the partials in wave order through LDS (fixed order, no atomics).
-template <int LPR, bool NT, bool UPD>
+template <int LPR, bool NT, bool UPD, bool SCORE>
 __global__ __launch_bounds__(256, RSA_OWN_MIN_WAVES) void owner_backward_walk_kernel(const OwnArgs a, const int wpq_log2) {
   using F = Frag<LPR, false>;
   constexpr int D = LPR * 4;
   __shared__ float s_q[4][D];
+  __shared__ float s_sum[4];
+  float wave_loss = 0.f;
   const int lane = lane_id();
   const int sub = lane % LPR;
   const int wave = threadIdx.x >> 6;
@@ -139,9 +175,11 @@ __global__ __launch_bounds__(256, RSA_OWN_MIN_WAVES) void owner_backward_walk_ke
       re = a.run_end[m];
     }
     float4 qacc = make_float4(0.f, 0.f, 0.f, 0.f);
+    float gsum = 0.f;            // SCORE: the run's sum of d (this wave's tiles)
     if (re > rs) {
       F qf;
       frag_load<LPR, false>(qf, a.q_all + (size_t)m * D, sub, D);
+      const float pos_s = SCORE ? a.pos_score[m] : 0.f;
       const int T = (re - rs + 63) >> 6;
 #pragma unroll 1
       for (int t = part; t < T; t += wpq) {
@@ -149,15 +187,26 @@ __global__ __launch_bounds__(256, RSA_OWN_MIN_WAVES) void owner_backward_walk_ke
         const bool act = i < re;
         int32_t id = 0;
         float dv = 0.f;
+        uint32_t slot = 0;
         if (act) {
-          const uint32_t slot = rdx_val(a.qpairs[i]);
+          slot = rdx_val(a.qpairs[i]);
           int64_t row = a.keys[slot] & 0xffffffffll;
           row = row >= a.n_rows ? a.n_rows - 1 : row;        // never fault on a bad key
           id = (int32_t)row;
-          dv = a.d[slot];
+          dv = SCORE ? a.bw : a.d[slot];
           if (UPD && a.solo[slot]) id |= (int32_t)0x80000000;
         }
-        tile_rows_own<LPR, NT, UPD>(a.item, id, dv, qf, qacc, a.item_rw, upd);
+        float dot = 0.f;
+        tile_rows_own<LPR, NT, UPD, SCORE>(a.item, id, dv, qf, qacc, a.item_rw, upd, pos_s, a.binv, dot);
+        if constexpr (SCORE) {
+          // the lane's own element: the same float operations as inside the tile, so d_out is the value the updates used
+          const float g = bpr_dneg(pos_s, dot, dv, a.binv);
+          if (act) st_out(&a.d_out[slot], g);
+          const float xd = pos_s - dot;
+          const float tt = __expf(-fabsf(xd));
+          wave_loss -= group_sum<64>(act ? (fminf(xd, 0.f) - __logf(1.f + tt)) * a.bw : 0.f);
+          gsum += group_sum<64>(g);
+        }
       }
 #pragma unroll
       for (int mk = LPR; mk < 64; mk <<= 1) {
@@ -167,14 +216,21 @@ __global__ __launch_bounds__(256, RSA_OWN_MIN_WAVES) void owner_backward_walk_ke
     }
     if (wpq > 1) {         // block-uniform: the partials of a query's waves meet in LDS, added in wave order
       if (part != 0 && lane < LPR) *reinterpret_cast<float4*>(&s_q[wave][sub * 4]) = qacc;
+      if (SCORE && part != 0 && lane == 0) s_sum[wave] = gsum;
       __syncthreads();
-      if (part == 0 && lane < LPR) {
+      if (part == 0) {
         for (int k = 1; k < wpq; ++k) {
-          const float4 o = *reinterpret_cast<const float4*>(&s_q[wave + k][sub * 4]);
-          qacc.x += o.x; qacc.y += o.y; qacc.z += o.z; qacc.w += o.w;
+          if (lane < LPR) {
+            const float4 o = *reinterpret_cast<const float4*>(&s_q[wave + k][sub * 4]);
+            qacc.x += o.x; qacc.y += o.y; qacc.z += o.z; qacc.w += o.w;
+          }
+          if constexpr (SCORE) gsum += s_sum[wave + k];
         }
       }
       __syncthreads();     // the slots are rewritten in the next iteration
+    }
+    if constexpr (SCORE) {
+      if (valid && part == 0 && lane == 0) a.dsum[m] = gsum;      // (0 for a query without slots here)
     }
     if (re > rs && part == 0 && lane < LPR) {
       float4* gp = reinterpret_cast<float4*>(a.qgrad_all + (size_t)m * D + sub * 4);
@@ -184,9 +240,65 @@ __global__ __launch_bounds__(256, RSA_OWN_MIN_WAVES) void owner_backward_walk_ke
       *gp = o;
     }
   }
+  if constexpr (SCORE) {
+    if (a.loss_out != nullptr) reduce_mean_loss(wave_loss, a.loss_out, a.done_counter, a.loss_partials, a.mean_den);
+  }
 }
 
+// One lane group per query i: the POSITIVE's part of the step on the rank that owns its row (pos_rows[i] >= 0):
+// d loss/d pos = -(sum over all owners of the query's d) -> the coefficient slot behind the segments' (for the sorted
+// apply), qgrad_all[i] += gate * dpos * row, and -- when the row is the positive's alone -- the row's update in place.
 template <int LPR>
+__global__ __launch_bounds__(256) void owner_pos_finish_kernel(const float* item, float* item_rw, const float* __restrict__ q_all,
+                                                               float* __restrict__ qgrad_all, const int64_t* __restrict__ pos_rows,
+                                                               const float* __restrict__ dsum_all, float* __restrict__ d_pos_out,
+                                                               const uint8_t* __restrict__ solo_pos, const float* __restrict__ scale,
+                                                               int64_t n_rows, int32_t n_queries) {
+  constexpr int D = LPR * 4, GPB = 256 / LPR;
+  const int sub = threadIdx.x % LPR;
+  const float upd = scale[0], gate = scale[1];
+  for (int64_t i = (int64_t)blockIdx.x * GPB + threadIdx.x / LPR; i < n_queries; i += (int64_t)gridDim.x * GPB) {
+    int64_t row = pos_rows[i];
+    const float dp = row >= 0 ? -dsum_all[i] : 0.f;
+    if (sub == 0) d_pos_out[i] = dp;
+    if (row < 0) continue;
+    row = row >= n_rows ? n_rows - 1 : row;
+    const float4 xv = *reinterpret_cast<const float4*>(item + (size_t)row * D + sub * 4);
+    const float4 qv = *reinterpret_cast<const float4*>(q_all + (size_t)i * D + sub * 4);
+    float4* gp = reinterpret_cast<float4*>(qgrad_all + (size_t)i * D + sub * 4);
+    float4 o = *gp;
+    const float gd = gate * dp;
+    o.x = __fmaf_rn(gd, xv.x, o.x); o.y = __fmaf_rn(gd, xv.y, o.y);
+    o.z = __fmaf_rn(gd, xv.z, o.z); o.w = __fmaf_rn(gd, xv.w, o.w);
+    *gp = o;
+    if (item_rw != nullptr && solo_pos[i]) {
+      *reinterpret_cast<float4*>(item_rw + (size_t)row * D + sub * 4) =
+          make_float4(__fadd_rn(xv.x, __fmul_rn(upd, __fmul_rn(dp, qv.x))), __fadd_rn(xv.y, __fmul_rn(upd, __fmul_rn(dp, qv.y))),
+                      __fadd_rn(xv.z, __fmul_rn(upd, __fmul_rn(dp, qv.z))), __fadd_rn(xv.w, __fmul_rn(upd, __fmul_rn(dp, qv.w))));
+    }
+  }
+}
+
+// out[i] = q_all[i] . item[pos_rows[i]] for the positives this rank owns, 0 for the others (summed over the ranks: the
+// score of every positive everywhere)
+template <int LPR>
+__global__ __launch_bounds__(256) void shard_pos_score_kernel(const float* __restrict__ item, const float* __restrict__ q_all,
+                                                              const int64_t* __restrict__ pos_rows, int64_t n_rows,
+                                                              int32_t n_queries, float* __restrict__ out) {
+  constexpr int D = LPR * 4, GPB = 256 / LPR;
+  const int sub = threadIdx.x % LPR;
+  for (int64_t i = (int64_t)blockIdx.x * GPB + threadIdx.x / LPR; i < n_queries; i += (int64_t)gridDim.x * GPB) {
+    int64_t row = pos_rows[i];
+    const bool own = row >= 0;
+    row = row < 0 ? 0 : (row >= n_rows ? n_rows - 1 : row);
+    const float4 xv = *reinterpret_cast<const float4*>(item + (size_t)row * D + sub * 4);
+    const float4 qv = *reinterpret_cast<const float4*>(q_all + (size_t)i * D + sub * 4);
+    const float s = group_sum<LPR>(dot4(xv, qv));
+    if (sub == 0) out[i] = own ? s : 0.f;
+  }
+}
+
+template <int LPR, bool SCORE>
 static void launch_walk(const OwnArgs& a, bool upd, int64_t slots, hipStream_t s) {
   const bool nt = (size_t)a.n_rows * LPR * 16 > (512ull << 20);
   const int64_t tiles_per_query = slots / (a.n_queries > 0 ? a.n_queries : 1) / 64;
@@ -196,29 +308,29 @@ static void launch_walk(const OwnArgs& a, bool upd, int64_t slots, hipStream_t s
   if (blocks > 4096) blocks = 4096;
   dim3 grid((unsigned)blocks), block(256);
   if (upd) {
-    if (nt) hipLaunchKernelGGL((owner_backward_walk_kernel<LPR, true, true>), grid, block, 0, s, a, wpq_log2);
-    else hipLaunchKernelGGL((owner_backward_walk_kernel<LPR, false, true>), grid, block, 0, s, a, wpq_log2);
+    if (nt) hipLaunchKernelGGL((owner_backward_walk_kernel<LPR, true, true, SCORE>), grid, block, 0, s, a, wpq_log2);
+    else hipLaunchKernelGGL((owner_backward_walk_kernel<LPR, false, true, SCORE>), grid, block, 0, s, a, wpq_log2);
   } else {
-    if (nt) hipLaunchKernelGGL((owner_backward_walk_kernel<LPR, true, false>), grid, block, 0, s, a, wpq_log2);
-    else hipLaunchKernelGGL((owner_backward_walk_kernel<LPR, false, false>), grid, block, 0, s, a, wpq_log2);
+    if (nt) hipLaunchKernelGGL((owner_backward_walk_kernel<LPR, true, false, SCORE>), grid, block, 0, s, a, wpq_log2);
+    else hipLaunchKernelGGL((owner_backward_walk_kernel<LPR, false, false, SCORE>), grid, block, 0, s, a, wpq_log2);
   }
 }
 
 static inline int64_t align256o(int64_t b) { return (b + 255) / 256 * 256; }
 
 struct OwnLayout {
-  void* sorted_ws;              // the row sort + sorted apply workspace (sorted_workspace_bytes(slots))
+  void* sorted_ws;              // the row sort + sorted apply workspace (sorted_workspace_bytes(slots + positives))
   uint64_t *qa, *qb;            // the query sort's ping-pong buffers
   void* qtemp;
   int32_t *run_start, *run_end;
-  uint8_t* solo;
+  uint8_t* solo;                // [slots + positives]
 };
 
 static OwnLayout own_layout(void* workspace, int64_t slots, int64_t n_queries) {
   char* ws = reinterpret_cast<char*>(workspace);
   OwnLayout L;
   L.sorted_ws = ws;
-  ws += align256o(sorted_workspace_bytes(slots));
+  ws += align256o(sorted_workspace_bytes(slots + n_queries));
   L.qa = reinterpret_cast<uint64_t*>(ws);
   ws += align256o(slots * 8);
   L.qb = reinterpret_cast<uint64_t*>(ws);
@@ -233,91 +345,239 @@ static OwnLayout own_layout(void* workspace, int64_t slots, int64_t n_queries) {
   return L;
 }
 
+static int64_t own_workspace_bytes(int64_t slots, int64_t n_queries) {
+  return align256o(sorted_workspace_bytes(slots + n_queries)) + 2 * align256o(slots * 8) + align256o(radix_temp_bytes(slots)) +
+         2 * align256o(n_queries * 4) + align256o(slots + n_queries) + 256;
+}
+
+// What both forms of the owner pass share: the update scales, the row sort (+ classification), the query sort, the runs
+struct OwnCommon {
+  const float* item_local;
+  int64_t n_rows;
+  int32_t dim;
+  const float* q_all;
+  int64_t n_query_rows;
+  const int64_t* keys;
+  int64_t n_segments, stride;
+  const int64_t* pos_rows;      // nullable: the step's positives as extra elements of the row sort
+  float* item_target;
+  const float* item_scale;
+  int32_t* step_dropped;
+  int32_t* overflow_sticky;     // != nullptr: publish the dropped total from the segment headers first
+  float* scale_out;
+  int64_t item_pad_row;
+  void* workspace;
+  int64_t workspace_bytes;
+};
+
+struct OwnPrepared {
+  OwnLayout W;
+  SortedLayout L;
+  uint64_t* row_sorted;
+  const uint64_t* q_sorted;
+  int64_t slots, row_total;
+  bool inplace;
+};
+
+static int owner_prepare(const OwnCommon& c, OwnPrepared& P, bool sort_rows_only, hipStream_t s, const char* who) {
+  RSA_CHECK_ARG(c.n_segments >= 0 && c.stride > RSA_SHARD_HDR, "%s: bad sizes", who);
+  P.slots = c.n_segments * c.stride;
+  RSA_CHECK_ARG(c.scale_out != nullptr, "%s: scale_out is null", who);
+  RSA_CHECK_ARG(P.slots < (1ll << 31) - c.n_query_rows, "%s: more than 2^31 slots", who);
+  RSA_CHECK_ARG(c.item_local && c.q_all && (c.keys || P.slots == 0) && c.item_target, "%s: null pointer", who);
+  RSA_CHECK_ARG(c.n_rows >= 1 && c.n_rows < (1ll << 31) && c.n_query_rows >= 1 && c.n_query_rows < (1ll << 31),
+                "%s: table sizes out of range", who);
+  if (c.dim != 64 && c.dim != 128 && c.dim != 256) {
+    rsa::set_error("%s: dim=%d: built for dim in {64, 128, 256}", who, c.dim);
+    return RSA_ERR_UNSUPPORTED;
+  }
+  const int64_t need = own_workspace_bytes(P.slots, c.n_query_rows);
+  RSA_CHECK_ARG(c.workspace && c.workspace_bytes >= need, "%s: workspace too small (%lld < %lld)", who,
+                (long long)c.workspace_bytes, (long long)need);
+  P.W = own_layout(c.workspace, P.slots, c.n_query_rows);
+  P.row_total = P.slots + (c.pos_rows ? c.n_query_rows : 0);
+  P.L = sorted_layout(P.W.sorted_ws, P.slots + c.n_query_rows);
+  P.inplace = c.item_target == c.item_local;
+  const unsigned row_bits = radix_key_bits(c.n_rows + 1);
+  P.row_sorted = radix_result(P.L.pairs_a, P.L.pairs_b, row_bits);
+  const unsigned q_bits = radix_key_bits(c.n_query_rows + 1);
+  P.q_sorted = radix_result(P.W.qa, P.W.qb, q_bits);
+  if (sort_rows_only) return RSA_OK;       // (the second entry point of a two-call step: the layout only)
+  hipLaunchKernelGGL(owner_scale_kernel, dim3(1), dim3(1), 0, s, c.item_scale, c.step_dropped, c.scale_out,
+                     c.overflow_sticky ? c.keys : nullptr, c.n_segments, c.stride, c.overflow_sticky);
+  RSA_CHECK_LAUNCH(who);
+  if (P.row_total == 0) return RSA_OK;
+  // 1. elements by row (dead slots: key n_rows, behind every real row), solo classification for the in-place update
+  const RdxDiv32 by_stride = rdx_make_div32((uint64_t)c.stride);
+  const SrcSegments<false> by_row{c.keys, c.pos_rows, P.slots, by_stride, (uint32_t)c.n_rows};
+  if (radix_sort_pairs(by_row, P.L.pairs_a, P.L.pairs_b, P.row_total, row_bits, P.L.temp, s) != hipSuccess) {
+    rsa::set_error("%s: row sort failed: %s", who, hipGetErrorString(hipGetLastError()));
+    return RSA_ERR_HIP;
+  }
+  if (P.inplace) {
+    const int rc = classify_solo(P.row_sorted, P.row_total, c.item_pad_row, c.n_rows, P.W.solo, s, who);
+    if (rc != RSA_OK) return rc;
+  }
+  if (P.slots == 0) return RSA_OK;
+  // 2. slots by query, the queries' runs
+  const SrcSegments<true> by_query{c.keys, nullptr, P.slots, by_stride, (uint32_t)c.n_query_rows};
+  if (radix_sort_pairs(by_query, P.W.qa, P.W.qb, P.slots, q_bits, P.W.qtemp, s) != hipSuccess) {
+    rsa::set_error("%s: query sort failed: %s", who, hipGetErrorString(hipGetLastError()));
+    return RSA_ERR_HIP;
+  }
+  if (hipMemsetAsync(P.W.run_start, 0, (size_t)(2 * align256o(c.n_query_rows * 4)), s) != hipSuccess) {
+    rsa::set_error("%s: memset failed", who);
+    return RSA_ERR_HIP;
+  }
+  int64_t blocks = (P.slots + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(query_runs_kernel, dim3((unsigned)blocks), dim3(256), 0, s, P.q_sorted, P.slots, (int32_t)c.n_query_rows,
+                     P.W.run_start, P.W.run_end);
+  RSA_CHECK_LAUNCH(who);
+  return RSA_OK;
+}
+
+static OwnArgs walk_args(const OwnCommon& c, const OwnPrepared& P, float* qgrad_all) {
+  OwnArgs o = {};
+  o.item = c.item_local;
+  o.item_rw = P.inplace ? c.item_target : nullptr;
+  o.q_all = c.q_all;
+  o.qgrad_all = qgrad_all;
+  o.keys = c.keys;
+  o.qpairs = P.q_sorted;
+  o.run_start = P.W.run_start;
+  o.run_end = P.W.run_end;
+  o.solo = P.inplace ? P.W.solo : nullptr;
+  o.scale = c.scale_out;
+  o.n_rows = c.n_rows;
+  o.n_queries = (int32_t)c.n_query_rows;
+  return o;
+}
+
 }  // namespace rsa
 
 using namespace rsa;
 
 extern "C" int64_t rsa_shard_backward_workspace_bytes(int64_t n_segments, int64_t stride, int64_t n_query_rows) {
-  if (n_segments <= 0 || stride <= 0 || n_query_rows <= 0) return 0;
-  const int64_t slots = n_segments * stride;
-  return align256o(sorted_workspace_bytes(slots)) + 2 * align256o(slots * 8) + align256o(radix_temp_bytes(slots)) +
-         2 * align256o(n_query_rows * 4) + align256o(slots) + 256;
+  if (n_segments < 0 || stride <= 0 || n_query_rows <= 0) return 0;
+  return own_workspace_bytes(n_segments * stride, n_query_rows);
 }
 
 extern "C" int rsa_shard_backward_segments(const rsa_shard_backward_args* a, rsa_stream_t stream) {
   RSA_CHECK_ARG(a != nullptr, "rsa_shard_backward_segments: args is null");
-  RSA_CHECK_ARG(a->n_segments >= 0 && a->stride > RSA_SHARD_HDR, "rsa_shard_backward_segments: bad sizes");
-  const int64_t slots = a->n_segments * a->stride;
   hipStream_t s = (hipStream_t)stream;
-  RSA_CHECK_ARG(a->scale_out != nullptr, "rsa_shard_backward_segments: scale_out is null");
-  hipLaunchKernelGGL(owner_scale_kernel, dim3(1), dim3(1), 0, s, a->item_scale, a->step_dropped, a->scale_out);
-  RSA_CHECK_LAUNCH("rsa_shard_backward_segments(scale)");
-  if (slots == 0) return RSA_OK;
-  RSA_CHECK_ARG(slots < (1ll << 31), "rsa_shard_backward_segments: more than 2^31 slots");
-  RSA_CHECK_ARG(a->item_local && a->q_all && a->keys && a->d_owner && a->item_target && a->qgrad_all,
-                "rsa_shard_backward_segments: null pointer");
-  RSA_CHECK_ARG(a->n_rows >= 1 && a->n_rows < (1ll << 31) && a->n_query_rows >= 1 && a->n_query_rows < (1ll << 31),
-                "rsa_shard_backward_segments: table sizes out of range");
-  if (a->dim != 64 && a->dim != 128 && a->dim != 256) {
-    rsa::set_error("rsa_shard_backward_segments: dim=%d: built for dim in {64, 128, 256}", a->dim);
-    return RSA_ERR_UNSUPPORTED;
-  }
-  const int64_t need = rsa_shard_backward_workspace_bytes(a->n_segments, a->stride, a->n_query_rows);
-  RSA_CHECK_ARG(a->workspace && a->workspace_bytes >= need, "rsa_shard_backward_segments: workspace too small (%lld < %lld)",
-                (long long)a->workspace_bytes, (long long)need);
-  const OwnLayout W = own_layout(a->workspace, slots, a->n_query_rows);
-  const SortedLayout L = sorted_layout(W.sorted_ws, slots);
-  const bool inplace = a->item_target == a->item_local;
-  // 1. slots by row (dead slots: key n_rows, behind every real row), solo classification for the in-place update
-  const unsigned row_bits = radix_key_bits(a->n_rows + 1);
-  const SrcSegments<false> by_row{a->keys, (uint32_t)a->stride, (uint32_t)a->n_rows};
-  if (radix_sort_pairs(by_row, L.pairs_a, L.pairs_b, slots, row_bits, L.temp, s) != hipSuccess) {
-    rsa::set_error("rsa_shard_backward_segments: row sort failed: %s", hipGetErrorString(hipGetLastError()));
-    return RSA_ERR_HIP;
-  }
-  uint64_t* row_sorted = radix_result(L.pairs_a, L.pairs_b, row_bits);
-  if (inplace) {
-    const int rc = classify_solo(row_sorted, slots, a->item_pad_row, a->n_rows, W.solo, s, "rsa_shard_backward_segments");
-    if (rc != RSA_OK) return rc;
-  }
-  // 2. slots by query, the queries' runs
-  const unsigned q_bits = radix_key_bits(a->n_query_rows + 1);
-  const SrcSegments<true> by_query{a->keys, (uint32_t)a->stride, (uint32_t)a->n_query_rows};
-  if (radix_sort_pairs(by_query, W.qa, W.qb, slots, q_bits, W.qtemp, s) != hipSuccess) {
-    rsa::set_error("rsa_shard_backward_segments: query sort failed: %s", hipGetErrorString(hipGetLastError()));
-    return RSA_ERR_HIP;
-  }
-  const uint64_t* q_sorted = radix_result(W.qa, W.qb, q_bits);
-  if (hipMemsetAsync(W.run_start, 0, (size_t)(2 * align256o(a->n_query_rows * 4)), s) != hipSuccess) {
-    rsa::set_error("rsa_shard_backward_segments: memset failed");
-    return RSA_ERR_HIP;
-  }
-  int64_t blocks = (slots + 255) / 256;
-  if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(query_runs_kernel, dim3((unsigned)blocks), dim3(256), 0, s, q_sorted, slots, (int32_t)a->n_query_rows,
-                     W.run_start, W.run_end);
+  const OwnCommon c{a->item_local, a->n_rows,       a->dim,        a->q_all,       a->n_query_rows, a->keys,
+                    a->n_segments, a->stride,       nullptr,       a->item_target, a->item_scale,   const_cast<int32_t*>(a->step_dropped),
+                    nullptr,       a->scale_out,    a->item_pad_row, a->workspace, a->workspace_bytes};
+  OwnPrepared P;
+  int rc = owner_prepare(c, P, false, s, "rsa_shard_backward_segments");
+  if (rc != RSA_OK || P.slots == 0) return rc;
+  RSA_CHECK_ARG(a->d_owner && a->qgrad_all, "rsa_shard_backward_segments: null pointer");
   // 3. the walk: query gradients, solo rows in place
-  OwnArgs o;
-  o.item = a->item_local;
-  o.item_rw = inplace ? a->item_target : nullptr;
-  o.q_all = a->q_all;
-  o.qgrad_all = a->qgrad_all;
-  o.keys = a->keys;
+  OwnArgs o = walk_args(c, P, a->qgrad_all);
   o.d = a->d_owner;
-  o.qpairs = q_sorted;
-  o.run_start = W.run_start;
-  o.run_end = W.run_end;
-  o.solo = inplace ? W.solo : nullptr;
-  o.scale = a->scale_out;
-  o.n_rows = a->n_rows;
-  o.n_queries = (int32_t)a->n_query_rows;
   switch (a->dim) {
-    case 64: launch_walk<16>(o, inplace, slots, s); break;
-    case 128: launch_walk<32>(o, inplace, slots, s); break;
-    default: launch_walk<64>(o, inplace, slots, s); break;
+    case 64: launch_walk<16, false>(o, P.inplace, P.slots, s); break;
+    case 128: launch_walk<32, false>(o, P.inplace, P.slots, s); break;
+    default: launch_walk<64, false>(o, P.inplace, P.slots, s); break;
   }
   RSA_CHECK_LAUNCH("rsa_shard_backward_segments(walk)");
   // 4. the rows that several elements touch (or, for a gradient block, every row): sorted apply
-  return apply_sorted_segments(row_sorted, slots, a->q_all, a->dim, a->keys, a->d_owner, a->scale_out, a->n_rows, a->item_pad_row,
-                               a->item_target, L, s);
+  return apply_sorted_segments(P.row_sorted, P.slots, P.slots, a->q_all, a->dim, a->keys, a->d_owner, a->scale_out, a->n_rows,
+                               a->item_pad_row, a->item_target, P.L, s);
+}
+
+extern "C" int rsa_shard_pos_score(const float* item_local, int64_t n_rows, int32_t dim, const float* q_all,
+                                   int64_t n_query_rows, const int64_t* pos_rows, float* out, rsa_stream_t stream) {
+  RSA_CHECK_ARG(n_query_rows >= 0 && n_rows >= 1, "rsa_shard_pos_score: bad sizes");
+  if (n_query_rows == 0) return RSA_OK;
+  RSA_CHECK_ARG(item_local && q_all && pos_rows && out, "rsa_shard_pos_score: null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  int64_t blocks;
+#define RSA_POS_LAUNCH(LPR)                                                                                       \
+  blocks = (n_query_rows + 256 / LPR - 1) / (256 / LPR);                                                          \
+  if (blocks > 4096) blocks = 4096;                                                                               \
+  hipLaunchKernelGGL(shard_pos_score_kernel<LPR>, dim3((unsigned)blocks), dim3(256), 0, s, item_local, q_all, pos_rows, \
+                     n_rows, (int32_t)n_query_rows, out)
+  switch (dim) {
+    case 64: RSA_POS_LAUNCH(16); break;
+    case 128: RSA_POS_LAUNCH(32); break;
+    case 256: RSA_POS_LAUNCH(64); break;
+    default:
+      rsa::set_error("rsa_shard_pos_score: dim=%d: built for dim in {64, 128, 256}", dim);
+      return RSA_ERR_UNSUPPORTED;
+  }
+#undef RSA_POS_LAUNCH
+  RSA_CHECK_LAUNCH("rsa_shard_pos_score");
+  return RSA_OK;
+}
+
+static OwnCommon bpr_common(const rsa_shard_owner_bpr_args* a) {
+  return OwnCommon{a->item_local, a->n_rows,  a->dim,      a->q_all,       a->n_query_rows, a->keys,
+                   a->n_segments, a->stride,  a->pos_rows, a->item_target, a->item_scale,   a->step_dropped,
+                   a->overflow_sticky, a->scale_out, a->item_pad_row, a->workspace, a->workspace_bytes};
+}
+
+extern "C" int rsa_shard_owner_bpr_forward(const rsa_shard_owner_bpr_args* a, rsa_stream_t stream) {
+  RSA_CHECK_ARG(a != nullptr, "rsa_shard_owner_bpr_forward: args is null");
+  RSA_CHECK_ARG(a->pos_rows && a->pos_score && a->d_slots && a->dsum_part && a->qgrad_all && a->num_neg >= 1 && a->mean_den >= 1,
+                "rsa_shard_owner_bpr_forward: null pointer / bad sizes");
+  hipStream_t s = (hipStream_t)stream;
+  const OwnCommon c = bpr_common(a);
+  OwnPrepared P;
+  int rc = owner_prepare(c, P, false, s, "rsa_shard_owner_bpr_forward");
+  if (rc != RSA_OK) return rc;
+  if (hipMemsetAsync(a->dsum_part, 0, (size_t)a->n_query_rows * 4, s) != hipSuccess ||
+      (a->loss_part && hipMemsetAsync(a->loss_part, 0, 4, s) != hipSuccess)) {
+    rsa::set_error("rsa_shard_owner_bpr_forward: memset failed");
+    return RSA_ERR_HIP;
+  }
+  if (P.slots == 0) return RSA_OK;
+  OwnArgs o = walk_args(c, P, a->qgrad_all);
+  o.d_out = a->d_slots;
+  o.pos_score = a->pos_score;
+  o.dsum = a->dsum_part;
+  o.bw = 1.f / (float)a->num_neg;
+  o.binv = 1.f / (float)a->mean_den;
+  o.mean_den = a->mean_den;
+  if (a->loss_part != nullptr) {
+    RSA_CHECK_ARG(a->reduce_scratch != nullptr, "rsa_shard_owner_bpr_forward: loss_part needs reduce_scratch");
+    char* sc = reinterpret_cast<char*>(a->reduce_scratch);
+    o.loss_out = a->loss_part;
+    o.done_counter = reinterpret_cast<unsigned int*>(sc + SCRATCH_COUNTER);
+    o.loss_partials = reinterpret_cast<float*>(sc + SCRATCH_FUSED_PARTIALS);
+  }
+  switch (a->dim) {
+    case 64: launch_walk<16, true>(o, P.inplace, P.slots, s); break;
+    case 128: launch_walk<32, true>(o, P.inplace, P.slots, s); break;
+    default: launch_walk<64, true>(o, P.inplace, P.slots, s); break;
+  }
+  RSA_CHECK_LAUNCH("rsa_shard_owner_bpr_forward(walk)");
+  return RSA_OK;
+}
+
+extern "C" int rsa_shard_owner_bpr_finish(const rsa_shard_owner_bpr_args* a, const float* dsum_all, rsa_stream_t stream) {
+  RSA_CHECK_ARG(a != nullptr && dsum_all != nullptr, "rsa_shard_owner_bpr_finish: null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  const OwnCommon c = bpr_common(a);
+  OwnPrepared P;
+  int rc = owner_prepare(c, P, true, s, "rsa_shard_owner_bpr_finish");
+  if (rc != RSA_OK) return rc;
+  const int64_t Q = a->n_query_rows;
+  int64_t blocks;
+#define RSA_FIN_LAUNCH(LPR)                                                                                          \
+  blocks = (Q + 256 / LPR - 1) / (256 / LPR);                                                                        \
+  if (blocks > 4096) blocks = 4096;                                                                                  \
+  hipLaunchKernelGGL(owner_pos_finish_kernel<LPR>, dim3((unsigned)blocks), dim3(256), 0, s, a->item_local,           \
+                     P.inplace ? a->item_target : nullptr, a->q_all, a->qgrad_all, a->pos_rows, dsum_all,             \
+                     a->d_slots + P.slots, P.W.solo + P.slots, a->scale_out, a->n_rows, (int32_t)Q)
+  switch (a->dim) {
+    case 64: RSA_FIN_LAUNCH(16); break;
+    case 128: RSA_FIN_LAUNCH(32); break;
+    default: RSA_FIN_LAUNCH(64); break;
+  }
+#undef RSA_FIN_LAUNCH
+  RSA_CHECK_LAUNCH("rsa_shard_owner_bpr_finish(positives)");
+  return apply_sorted_segments(P.row_sorted, P.row_total, P.slots, a->q_all, a->dim, a->keys, a->d_slots, a->scale_out, a->n_rows,
+                               a->item_pad_row, a->item_target, P.L, s);
 }

@@ -52,18 +52,41 @@ struct SrcStepIds {
   }
 };
 
+// x / d for 32-bit x by one multiply-high and a correction (magic = floor(2^32 / d); d == 1: magic = 2^32 - 1)
+struct RdxDiv32 {
+  uint32_t d, magic;
+  __device__ __forceinline__ uint32_t div(uint32_t x) const {
+    const uint32_t q = __umulhi(x, magic);
+    return (x - q * d >= d) ? q + 1 : q;
+  }
+};
+inline RdxDiv32 rdx_make_div32(uint64_t d) {
+  RdxDiv32 v;
+  v.d = (uint32_t)d;
+  v.magic = d <= 1 ? 0xffffffffu : (uint32_t)((1ull << 32) / d);
+  return v;
+}
+
 // Received exchange segments [n_seg][stride] of 8-byte keys (query << 32 | local row) behind RSA_SHARD_HDR header
 // words: element = slot number; BY_QUERY: key = query index, else the local row; a slot outside its segment's live
-// range gets `dead_key` (sorts last).
+// range gets `dead_key` (sorts last).  Elements past the `slots` segment slots (row sort only) are the step's POSITIVES,
+// one per query: extra_rows[i] = local row of query i's positive on this rank, or < 0 when another rank owns it.
 template <bool BY_QUERY>
 struct SrcSegments {
   const int64_t* keys;
-  uint32_t stride;
+  const int64_t* extra_rows;
+  int64_t slots;
+  RdxDiv32 by_stride;
   uint32_t dead_key;
   __device__ __forceinline__ uint64_t operator()(int64_t i) const {
-    const uint32_t seg = (uint32_t)i / stride, within = (uint32_t)i - seg * stride;
-    const int64_t live = keys[(size_t)seg * stride];
     uint32_t key = dead_key;
+    if (i >= slots) {
+      const int64_t r = extra_rows[i - slots];
+      if (r >= 0) key = (uint32_t)r > dead_key ? dead_key : (uint32_t)r;
+      return rdx_pack(key, (uint32_t)i);
+    }
+    const uint32_t seg = by_stride.div((uint32_t)i), within = (uint32_t)i - seg * by_stride.d;
+    const int64_t live = keys[(size_t)seg * by_stride.d];
     if (within >= RSA_SHARD_HDR && (int64_t)(within - RSA_SHARD_HDR) < live) {
       const int64_t k = keys[i];
       key = BY_QUERY ? (uint32_t)((k >> 32) & 0x7fffffffll) : (uint32_t)(k & 0xffffffffll);

@@ -283,7 +283,7 @@ struct RouteV2 {
   PhiloxCall pc;
   PopTables pop;
   Div32 by_width, by_rows, by_n, by_gt, by_range;
-  int32_t n, G, sampler, n_slices, unroll, n_banks;
+  int32_t n, G, sampler, n_slices, unroll, n_banks, skip_pos;
 };
 
 constexpr int TICKET_SUB = 32;      // two-level completion ticket: 32 sub-words, then one top word
@@ -360,12 +360,16 @@ __global__ __launch_bounds__(256) void shard_sample_route_kernel(const RouteV2 a
         const int64_t pc_ = id < 0 ? 0 : (id >= a.pop.n_items ? a.pop.n_items - 1 : id);
         a.pos_logp[m] = logf(a.pop.pop_prob[pc_]);
       }
-      el[r * 4] = (int32_t)(m * (a.n + 1));
-      int g = 0;
-      int64_t loc = id < 0 ? 0 : id;
-      if (a.G > 1) owner_and_row(id, a.by_rows, a.rows_per_shard, a.G, g, loc);
-      local[r * 4] = (uint32_t)loc;
-      gl[r * 4] = g << 16;
+      if (a.skip_pos) {      // the positives do not travel (the owners score them from the gathered ids): no slot
+        if (!COUNT_ONLY) a.slot_of[m * (a.n + 1)] = -1;
+      } else {
+        el[r * 4] = (int32_t)(m * (a.n + 1));
+        int g = 0;
+        int64_t loc = id < 0 ? 0 : id;
+        if (a.G > 1) owner_and_row(id, a.by_rows, a.rows_per_shard, a.G, g, loc);
+        local[r * 4] = (uint32_t)loc;
+        gl[r * 4] = g << 16;
+      }
     }
   }
   __syncthreads();
@@ -935,6 +939,7 @@ extern "C" int rsa_shard_sample_route(const rsa_shard_route_args* a, rsa_stream_
   r.sampler = a->sampler;
   r.n_slices = a->n_slices;
   r.n_banks = a->n_banks;
+  r.skip_pos = a->skip_pos;
   // the enumeration of the negatives: Philox blocks of the torch call (see the kernel), or the same shape made up for
   // given ids (four interleaved quarters)
   if (a->sampler == RSA_SAMPLER_GIVEN || n_neg == 0) {

@@ -80,11 +80,12 @@ struct DecStep {             // a step's [M, (1 +) n] element order: e = m * w +
     coef = (has_pos && c == 0) ? dpos[m] : dneg[m * (int64_t)n + (c - has_pos)];
   }
 };
-struct DecSegments {         // received exchange segments: e = slot, key = (query << 32 | row), d in slot order
-  const int64_t* keys;
+struct DecSegments {         // received exchange segments: e = slot, key = (query << 32 | row), d in slot order;
+  const int64_t* keys;       // e >= slots: the positive of query e - slots (its coefficient sits behind the slots' in d)
   const float* d;
+  int64_t slots;
   __device__ __forceinline__ void operator()(int64_t e, int32_t& qrow, float& coef) const {
-    qrow = (int32_t)((keys[e] >> 32) & 0x7fffffffll);
+    qrow = e >= slots ? (int32_t)(e - slots) : (int32_t)((keys[e] >> 32) & 0x7fffffffll);
     coef = d[e];
   }
 };
@@ -350,11 +351,11 @@ static int apply_sorted_pairs(const uint64_t* pairs, int64_t total, const float*
   return RSA_OK;
 }
 
-int apply_sorted_segments(const uint64_t* pairs, int64_t total, const float* query, int32_t dim, const int64_t* keys,
-                          const float* d, const float* upstream, int64_t n_rows, int64_t pad_row, float* target,
-                          const SortedLayout& L, hipStream_t s) {
+int apply_sorted_segments(const uint64_t* pairs, int64_t total, int64_t slots, const float* query, int32_t dim,
+                          const int64_t* keys, const float* d, const float* upstream, int64_t n_rows, int64_t pad_row,
+                          float* target, const SortedLayout& L, hipStream_t s) {
   const AdamArgs none{nullptr, nullptr, 0.f, 0.f, 0.f, 0.f};
-  const DecSegments dec{keys, d};
+  const DecSegments dec{keys, d, slots};
   return apply_sorted_pairs(pairs, total, query, dim, dec, upstream, n_rows, pad_row, target, none, L, s);
 }
 

@@ -61,4 +61,13 @@ __device__ __forceinline__ float frag_dot(const Frag<LPR, GENERIC>& a, const Fra
   return s;
 }
 
+// d / d neg of  -w * inv_m * logsigmoid(pos - neg)  =  w * inv_m * sigmoid(neg - pos), written so that the
+// in-loop (query gradient) and epilogue (dneg output) evaluations are the same float operations
+__device__ __forceinline__ float bpr_dneg(float pos, float neg, float w, float inv_m) {
+  const float xd = pos - neg;
+  const float t = __expf(-fabsf(xd));
+  const float r = __frcp_rn(1.f + t);
+  return (xd >= 0.f ? t * r : r) * w * inv_m;
+}
+
 }  // namespace rsa

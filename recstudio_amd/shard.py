@@ -159,7 +159,7 @@ class HipBackend:
     # -- version 2 of the fixed-capacity exchange (rsa_shard_sample_route / _score_segments / _home) -------------------
     @ops._on_device
     def sample_route(self, state, plan, rank, pos, n, chunks, capacity, spec, generator, neg=None, want_ids=False,
-                     want_logp=False, count_only=False, banks=1):
+                     want_logp=False, count_only=False, banks=1, route_pos=True):
         """One launch: draw (or read) the negatives, route every (query, item) element of all ``chunks`` slices.
         -> dict(send [C*G*banks*stride] int64, slot_of [B*(1+n)] int32, stride, neg_ids / log_neg_prob / log_pos_prob when
         asked for), or the exact per-segment counts [C*G*banks] int32 with ``count_only`` (the generator is not
@@ -170,6 +170,7 @@ class HipBackend:
         a.pos_ids, a.n_queries, a.num_neg, a.sampler = ptr(ops._need(pos, torch.int64, 'pos')), B, int(n), int(kind)
         a.n_slices, a.n_shards, a.n_banks, a.rows_per_shard = int(chunks), G, int(banks), plan.rows_arg
         a.query_base, a.capacity = rank * B, int(capacity)
+        a.skip_pos = 0 if route_pos else 1      # the owner-side BPR step scores the positives from the gathered ids
         a.n_items = spec['n_items'] if spec is not None else plan.n_items
         out = {}
         keep = []
@@ -303,6 +304,50 @@ class HipBackend:
                            dense_item_grad=False, want_query_grad=False, item_grad_out=item_grad_local,
                            query_table_grad=qgrad_all, query_table_pad_row=-1, item_pad_row=item_pad_row)
 
+    # -- the stock BPR step evaluated on the owners (rsa_shard_owner_bpr_forward / _finish) ---------------------------------
+    OWNER_DIMS = (64, 128, 256)
+
+    @ops._on_device
+    def pos_scores(self, item_local, q_all, pos_rows):
+        """[Q] scores of the positives this rank owns (pos_rows >= 0), 0 for the others."""
+        out = torch.empty(pos_rows.numel(), dtype=torch.float32, device=q_all.device)
+        nat.check(nat.lib().rsa_shard_pos_score(ptr(item_local), item_local.shape[0], item_local.shape[1], ptr(q_all), q_all.shape[0],
+                                                ptr(ops._need(pos_rows, torch.int64, 'pos_rows')), ptr(out), ops._stream()),
+                  'rsa_shard_pos_score')
+        return out
+
+    @ops._on_device
+    def owner_bpr_forward(self, state, item_local, q_all, recv_keys, n_seg, stride, pos_rows, pos_score, n, mean_den,
+                          item_target, item_scale, qgrad_all, item_pad_row=-1):
+        """Scores, loss terms and gradients of the received negatives in ONE pass over their rows (see the header);
+        -> ctx for ``owner_bpr_finish`` with ``dsum_part [Q]`` and ``loss_part`` (this rank's share of the mean loss)."""
+        dev, Q = q_all.device, q_all.shape[0]
+        a = nat.ShardOwnerBprArgs()
+        a.item_local, a.n_rows, a.dim, a.num_neg = ptr(item_local), item_local.shape[0], item_local.shape[1], int(n)
+        a.q_all, a.n_query_rows = ptr(ops._need(q_all, torch.float32, 'q_all')), Q
+        a.keys, a.n_segments, a.stride = ptr(recv_keys), int(n_seg), int(stride)
+        keep = {'pos_rows': ops._need(pos_rows, torch.int64, 'pos_rows'), 'pos_score': ops._need(pos_score, torch.float32, 'pos_score'),
+                'd_slots': torch.empty(n_seg * stride + Q, dtype=torch.float32, device=dev),
+                'dsum_part': torch.empty(Q, dtype=torch.float32, device=dev),
+                'loss_part': torch.empty((), dtype=torch.float32, device=dev),
+                'tensors': (item_local, q_all, recv_keys, item_target, item_scale, qgrad_all)}
+        a.pos_rows, a.pos_score, a.mean_den = ptr(keep['pos_rows']), ptr(keep['pos_score']), int(mean_den)
+        a.item_target, a.item_scale = ptr(item_target), ptr(item_scale)
+        a.step_dropped, a.overflow_sticky, a.scale_out = ptr(state['step_dropped']), ptr(state['overflow']), ptr(state['scale'])
+        a.qgrad_all, a.d_slots, a.dsum_part, a.loss_part = ptr(qgrad_all), ptr(keep['d_slots']), ptr(keep['dsum_part']), ptr(keep['loss_part'])
+        a.reduce_scratch, a.item_pad_row = ptr(ops._scratch()), int(item_pad_row)
+        nbytes = int(nat.lib().rsa_shard_backward_workspace_bytes(int(n_seg), int(stride), Q))
+        keep['ws'] = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        a.workspace, a.workspace_bytes = ptr(keep['ws']), nbytes
+        nat.check(nat.lib().rsa_shard_owner_bpr_forward(ctypes.byref(a), ops._stream()), 'rsa_shard_owner_bpr_forward')
+        keep['args'] = a
+        return keep
+
+    @ops._on_device
+    def owner_bpr_finish(self, ctx, dsum_all):
+        nat.check(nat.lib().rsa_shard_owner_bpr_finish(ctypes.byref(ctx['args']), ptr(ops._need(dsum_all, torch.float32, 'dsum_all')),
+                                                       ops._stream()), 'rsa_shard_owner_bpr_finish')
+
     # -- exact (variable-split) exchange ------------------------------------------------------------------------------
     def gather_rows(self, table, ids):
         if ids.numel() == 0:
@@ -425,12 +470,13 @@ def _gather_group(dist):
 
 class ShardedItemTable:
     def __init__(self, item_local, plan, rank, dist, backend=None, group=None, exchange='fixed', slack=1.08,
-                 margin=4096, check_every=16, sample_seed=2022, chunks=1, force_collectives=False):
+                 margin=4096, check_every=16, sample_seed=2022, chunks=1, force_collectives=False, owner_loss=True):
         """``chunks`` > 1 (fixed-capacity exchange only): the step's queries are cut into that many contiguous
         slices, routed by ONE launch, whose exchanges are issued asynchronously, so that slice c+1's key all-to-all and
         slice c-1's score all-to-all travel over xGMI while slice c is being scored (see ``_fixed_step``)."""
         self.item_local, self.plan, self.rank, self.dist = item_local, plan, int(rank), dist
         self.chunks = max(1, int(chunks))
+        self.owner_loss = bool(owner_loss)      # stock BPR training steps are evaluated on the owners (bpr_step_on_owners)
         self._solo = plan.world == 1 and not force_collectives
         self.backend = backend if backend is not None else HipBackend()
         self.group = group
@@ -525,7 +571,7 @@ class ShardedItemTable:
         return out
 
     # -- fixed-capacity bookkeeping -------------------------------------------------------------------
-    def _capacity(self, key, largest):
+    def _capacity(self, key, largest, store=None):
         """Capacity of one (slice, owner) segment from the exact counts of a step: the largest count of ANY rank (so
         that every rank uses the same equal split) plus slack.  One small all-reduce + read-back, on the calibration
         step only."""
@@ -535,8 +581,9 @@ class ShardedItemTable:
         S = int(getattr(self.backend, 'BANKS', 1))
         cap = int(int(m.item()) * self.slack) + (self.margin + S - 1) // S
         cap = min(B * (n + 1), (cap + 255) // 256 * 256)
-        self._cap[key] = max(cap, 1)
-        return self._cap[key]
+        store = key if store is None else store
+        self._cap[store] = max(cap, 1)
+        return self._cap[store]
 
     def check_overflow(self, block=True):
         """Raise if any routed element of ANY rank found its owner's segment full since the last check.  The sticky
@@ -631,6 +678,68 @@ class ShardedItemTable:
             out['route'] = {'B': B, 'n': n, 'C': C, 'GS': GS, 'stride': stride, 'q_all': q_all, 'slot_of': r['slot_of'],
                             'recv_keys': recv_keys, 'd_send': out.pop('d_send', None)}
         return out
+
+    def _all_reduce_sum(self, t):
+        if not self._solo:
+            self.dist.all_reduce(t, group=self.group)
+        return t
+
+    def owner_loss_ok(self):
+        """Can the stock BPR step run in its owner-side form (``bpr_step_on_owners``)?"""
+        return (self.owner_loss and self.exchange == 'fixed' and self.chunks == 1 and hasattr(self.backend, 'owner_bpr_forward')
+                and self.item_local.shape[1] in getattr(self.backend, 'OWNER_DIMS', (64, 128, 256)))
+
+    def bpr_step_on_owners(self, q, pos, n, sampler, item_grad_local, item_scale=None, want_ids=False):
+        """The stock BPR training step with the loss evaluated ON THE OWNERS of the negatives (SURVEY.md 8e, steps 3-5 in one
+        pass; include/recstudio_amd.h, rsa_shard_owner_bpr_forward): BPR's d loss/d neg needs only the query's positive
+        score, so
+
+          1. all-gather of the queries and of the positive ids; the negatives are drawn and routed as usual, the positives
+             are NOT routed;
+          2. the rank that owns a positive's row scores it; a 4-byte-per-query all-reduce gives every rank every positive's
+             score;
+          3. every owner evaluates score, loss term and gradient of the negatives it received while their rows are in
+             registers -- query-gradient partials, in-place updates of the rows one element touches -- and the queries' sums
+             of d; a second 4-byte-per-query all-reduce turns those into d loss/d pos;
+          4. the positives' owners finish (their query-gradient term, their rows), the rows several elements touch go
+             through the sorted apply pass; reduce-scatter of the query gradients.
+
+        No scores travel home, no score gradients travel back (8 instead of 16 bytes per triplet over xGMI), and the item
+        rows of a step are read once instead of twice.  -> (this rank's share of the global mean loss, d loss/d q [B, d],
+        negative ids or None).  The shares of all ranks add up to the loss (each rank holds the terms of the negatives it
+        owns)."""
+        be, st, plan = self.backend, self.state, self.plan
+        B, G = pos.numel(), plan.world
+        S = int(getattr(be, 'BANKS', 1))
+        spec = be.sampler_spec(sampler)
+        q_gather = self._all_gather_rows_start(q)
+        pos_all = self._all_gather_rows(pos.reshape(-1).contiguous())
+        neg = None
+        if spec is None:
+            _, neg, _ = self.sample(sampler, B, n, q.device, pos)
+            neg = neg.contiguous()
+        key = (B, n, 1, 'owners')
+        cap = self._cap.get(key)
+        if cap is None:
+            counts = be.sample_route(st, plan, self.rank, pos, n, 1, 0, spec, self.sample_generator, neg=neg, count_only=True,
+                                     banks=S, route_pos=False)
+            cap = self._capacity(key[:3], int(counts.max()), store=key)
+        r = be.sample_route(st, plan, self.rank, pos, n, 1, cap, spec, self.sample_generator, neg=neg, want_ids=want_ids,
+                            want_logp=False, banks=S, route_pos=False)
+        GS, stride = G * S, r['stride']
+        recv = self._all_to_all(r['send'])
+        q_all = q_gather()
+        mine = plan.owner(pos_all) == self.rank
+        pos_rows = torch.where(mine, plan.local(pos_all), torch.full_like(pos_all, -1))
+        pos_score = self._all_reduce_sum(be.pos_scores(self.item_local, q_all, pos_rows))
+        qgrad_all = torch.zeros_like(q_all)
+        ctx = be.owner_bpr_forward(st, self.item_local, q_all, recv, GS, stride, pos_rows, pos_score, n, B * G, item_grad_local,
+                                   item_scale, qgrad_all, item_pad_row=0 if self.rank == 0 else -1)
+        dsum_all = self._all_reduce_sum(ctx['dsum_part'] if self._solo else ctx['dsum_part'].clone())
+        be.owner_bpr_finish(ctx, dsum_all)
+        dq = self._reduce_scatter_rows(qgrad_all, B)
+        self._after_fixed_step()
+        return ctx['loss_part'], dq, (r.get('neg_ids') if spec is not None else neg)
 
     def backward(self, route, dpos, dneg, item_grad_local, item_scale=None):
         """Gradient exchange for one step.  ``route`` comes from a forward with
@@ -1021,7 +1130,13 @@ class ShardedRetriever:
             q = self.query_encoder(query_feat)
         B = pos_items.numel()
         kind = self._fused_loss_kind()
-        if kind is not None:
+        if kind == 'bpr' and table.owner_loss_ok():
+            # the loss on the owners of the negatives: one pass over the item rows per step (bpr_step_on_owners)
+            loss, dq, self.last_neg = table.bpr_step_on_owners(q.detach(), pos_items, self.neg_count, self.sampler,
+                                                               self.item_grad_local, self.item_scale, want_ids=self.keep_neg_ids)
+            if not self.sparse_query_rows and q.requires_grad:
+                q.backward(dq)
+        elif kind is not None:
             # forward + loss in the exchange's own kernels; d loss/d score leaves the home kernel in routed order
             out = table.forward_queries(q.detach(), pos_items, self.neg_count, self.sampler, keep_route=True, fused_loss=kind,
                                         mean_den=B * world, want_ids=self.keep_neg_ids, want_scores=False)

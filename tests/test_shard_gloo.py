@@ -64,7 +64,7 @@ class CheckerBackend:
         return None
 
     def sample_route(self, state, plan, rank, pos, n, chunks, capacity, spec, generator, neg=None, want_ids=False,
-                     want_logp=False, count_only=False, banks=1):
+                     want_logp=False, count_only=False, banks=1, route_pos=True):
         assert banks == 1                                      # (the checker has no BANKS attribute: one segment per owner)
         B, G, C = pos.numel(), plan.world, chunks
         out = {}
@@ -84,15 +84,19 @@ class CheckerBackend:
         m = torch.arange(B).repeat_interleave(n + 1)
         Bc = B // C
         sl = m // Bc
+        routed = torch.ones(B, n + 1, dtype=torch.bool)
+        if not route_pos:
+            routed[:, 0] = False                               # owner-side BPR step: the positives do not travel
+        routed = routed.reshape(-1)
         if count_only:
-            return torch.bincount(sl * G + owner, minlength=C * G).to(torch.int32)
+            return torch.bincount((sl * G + owner)[routed], minlength=C * G).to(torch.int32)
         stride = capacity + self.HDR
         send = torch.full((C * G * stride,), -7, dtype=torch.int64)           # slack: never read by a consumer
         slot_of = torch.full((B * (n + 1),), -1, dtype=torch.int32)
         key = ((rank * B + m) << 32) | plan.local(ids)
         dropped = 0
         for seg in range(C * G):
-            sel = torch.nonzero(sl * G + owner == seg).flatten()
+            sel = torch.nonzero((sl * G + owner == seg) & routed).flatten()
             dropped += max(0, sel.numel() - capacity)
             sel = sel[:capacity]
             base = seg * stride
@@ -172,6 +176,41 @@ class CheckerBackend:
         qgrad_all.index_add_(0, qidx, gate * dscore.unsqueeze(1) * item_local[rows])       # reads the rows: first
         scale = gate * (1.0 if item_scale is None else float(item_scale))
         item_grad_local.index_add_(0, rows[live], scale * dscore[live].unsqueeze(1) * q_all[qidx[live]])
+
+    # -- the stock BPR step evaluated on the owners, restated with torch-CPU ops -----------------------------------
+    OWNER_DIMS = range(1, 4097)
+
+    def pos_scores(self, item_local, q_all, pos_rows):
+        own = pos_rows >= 0
+        return torch.where(own, (item_local[pos_rows.clamp(min=0)] * q_all).sum(-1), torch.zeros(()))
+
+    def owner_bpr_forward(self, state, item_local, q_all, recv_keys, n_seg, stride, pos_rows, pos_score, n, mean_den,
+                          item_target, item_scale, qgrad_all, item_pad_row=-1):
+        total = int(recv_keys.view(n_seg, stride)[:, 1].sum())
+        state['step_dropped'][0] = total
+        state['overflow'] += total
+        gate = 0.0 if total else 1.0
+        keys = recv_keys[self._live(recv_keys, n_seg, stride)]
+        rows, qidx = keys & 0xffffffff, keys >> 32
+        x = pos_score[qidx] - (item_local[rows] * q_all[qidx]).sum(-1)              # loss_func.py:55-59, one term per element
+        d = torch.sigmoid(-x) / (n * mean_den)
+        loss_part = (-torch.nn.functional.logsigmoid(x) / n).sum() / mean_den
+        qgrad_all.index_add_(0, qidx, gate * d.unsqueeze(1) * item_local[rows])
+        dsum_part = torch.zeros(q_all.shape[0]).index_add_(0, qidx, d)
+        return {'rows': rows, 'qidx': qidx, 'd': d, 'gate': gate, 'item_local': item_local, 'q_all': q_all, 'pos_rows': pos_rows,
+                'item_target': item_target, 'item_scale': item_scale, 'qgrad_all': qgrad_all, 'pad': item_pad_row,
+                'dsum_part': dsum_part, 'loss_part': loss_part}
+
+    def owner_bpr_finish(self, ctx, dsum_all):
+        own = ctx['pos_rows'] >= 0
+        qi = torch.nonzero(own).flatten()
+        rows_p, dpos = ctx['pos_rows'][own], -dsum_all[own]
+        item_local, q_all, gate = ctx['item_local'], ctx['q_all'], ctx['gate']
+        ctx['qgrad_all'].index_add_(0, qi, gate * dpos.unsqueeze(1) * item_local[rows_p])    # reads the rows: before the update
+        rows, qidx, d = torch.cat([ctx['rows'], rows_p]), torch.cat([ctx['qidx'], qi]), torch.cat([ctx['d'], dpos])
+        live = rows != ctx['pad']
+        scale = gate * (1.0 if ctx['item_scale'] is None else float(ctx['item_scale']))
+        ctx['item_target'].index_add_(0, rows[live], scale * d[live].unsqueeze(1) * q_all[qidx[live]])
 
     def _elements(self, pos, neg):
         return torch.cat([pos.view(-1, 1), neg], 1).reshape(-1)
@@ -514,9 +553,14 @@ def _train_worker(rank, world, port, n_items, d, B, n, result_dir, layout='block
         # kernel, no autograd over the scores) == the autograd step above, uniform and popularity sampler
         import recstudio_amd as ra
         counts = torch.arange(n_items) % 7 + 1
-        for loss_cls, ref_loss, smp in ((ra.BPRLoss, 'bpr', oracle.UniformSampler(n_items)),
-                                        (ra.SampledSoftmaxLoss, 'ssm', oracle.PopularSamplerModel(counts))):
-            tbl_f = ShardedItemTable(plan.take(item, rank).clone(), plan, rank, dist, backend=CheckerBackend())
+        for loss_cls, ref_loss, smp, on_owners in ((ra.BPRLoss, 'bpr', oracle.UniformSampler(n_items), True),
+                                                   (ra.BPRLoss, 'bpr', oracle.PopularSamplerModel(counts), True),
+                                                   (ra.BPRLoss, 'bpr', oracle.UniformSampler(n_items), False),
+                                                   (ra.SampledSoftmaxLoss, 'ssm', oracle.PopularSamplerModel(counts), False)):
+            # on_owners: the BPR step with the loss evaluated on the owners of the negatives (no scores travel home);
+            # else the score-at-home protocol (home kernel + gradient exchange), which SampledSoftmax always takes
+            tbl_f = ShardedItemTable(plan.take(item, rank).clone(), plan, rank, dist, backend=CheckerBackend(), owner_loss=on_owners)
+            assert tbl_f.owner_loss_ok() == on_owners
             tower_f = torch.nn.Linear(8, d)
             with torch.no_grad():
                 tower_f.weight.copy_(tower_w)
@@ -547,6 +591,17 @@ def _train_worker(rank, world, port, n_items, d, B, n, result_dir, layout='block
             want_f = item_r.grad.clone()
             want_f[0] = 0
             np.testing.assert_allclose(tr_f.item_grad_local.numpy(), plan.take(want_f, rank).numpy(), rtol=1e-4, atol=1e-6)
+            if on_owners:
+                # ... and with plain SGD applied in place inside the owners' pass
+                tbl_s = ShardedItemTable(plan.take(item, rank).clone(), plan, rank, dist, backend=CheckerBackend())
+                tower_s = torch.nn.Linear(8, d)
+                with torch.no_grad():
+                    tower_s.weight.copy_(tower_w)
+                    tower_s.bias.zero_()
+                ShardedRetriever(tbl_s, tower_s, smp, loss_cls(), n, item_sgd_lr=0.4).training_step(feats[rank], poss[rank])
+                np.testing.assert_allclose(tbl_s.item_local.numpy(), (plan.take(item, rank) - 0.4 * tr_f.item_grad_local).numpy(),
+                                           rtol=1e-4, atol=1e-6)
+                np.testing.assert_allclose(tower_s.weight.grad.numpy(), tower_f.weight.grad.numpy(), rtol=1e-5, atol=1e-7)
         open(os.path.join(result_dir, f'ok{rank}'), 'w').write('ok')
     finally:
         dist.destroy_process_group()

@@ -1,5 +1,5 @@
-"""rocpd databases of one shape (tools/collect_profiles_r3.sh) -> an entry of r03_kernel_profiles.json and a block of
-r03_kernel_profiles.txt; the databases (tens of MB each) are deleted afterwards.
+"""rocpd databases of one shape (tools/collect_profiles.sh) -> an entry of <round>_kernel_profiles.json and a block of
+<round>_kernel_profiles.txt (round tag: $ROUND, default r04); the databases (tens of MB each) are deleted afterwards.
 usage: python tools/summarize_shapes.py OUT_DIR DST_DIR SHAPE
 Entry: dominant kernel (largest time per step among the rsa:: / rocprim / rccl kernels), its rocprofv3 average over the
 launches after the warm-up, HBM bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE (KB counters; the factor 2 is the gfx950
@@ -95,14 +95,15 @@ if 'FETCH_SIZE' in tot_bytes and 'WRITE_SIZE' in tot_bytes:
     lines.append(f'# dominant kernel HBM traffic per launch: 2 x FETCH_SIZE + WRITE_SIZE = {entry["hbm_bytes_per_launch"] / 1e9:.3f} GB')
 # a partial re-collection starts from the committed summaries: entries / blocks of other shapes are kept
 committed = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'profiles')
-for name in ('r03_kernel_profiles.json', 'r03_kernel_profiles.txt'):
+ROUND = os.environ.get('ROUND', 'r04')
+for name in (f'{ROUND}_kernel_profiles.json', f'{ROUND}_kernel_profiles.txt'):
     if not os.path.exists(os.path.join(dst, name)) and os.path.exists(os.path.join(committed, name)):
         shutil.copy(os.path.join(committed, name), os.path.join(dst, name))
-path = os.path.join(dst, 'r03_kernel_profiles.json')
+path = os.path.join(dst, f'{ROUND}_kernel_profiles.json')
 allj = json.load(open(path)) if os.path.exists(path) else {}
 allj[shape] = entry
 json.dump(allj, open(path, 'w'), indent=1, sort_keys=True)
-tpath = os.path.join(dst, 'r03_kernel_profiles.txt')
+tpath = os.path.join(dst, f'{ROUND}_kernel_profiles.txt')
 blocks, order = {}, []
 if os.path.exists(tpath):
     cur = None
