@@ -196,16 +196,23 @@ def cpu_baseline(args, counts, d, B, n):
     return res
 
 
+PROFILE_ROUNDS = ('r04', 'r03')
+
+
 def profile_record(name):
-    """The committed rocprofv3 record of a bench figure (profiles/r03_kernel_profiles.json, written by
-    tools/collect_profiles_r3.sh on a GPU box): kernel average from --kernel-trace --stats and the FETCH_SIZE / WRITE_SIZE
-    passes.  bench.py prints `profile_frac` next to every live fraction that has one, so that a reader sees the tracked
-    number and the live one side by side (boxes of the pool differ by several per cent)."""
-    path = os.path.join(ROOT, 'profiles', 'r03_kernel_profiles.json')
-    try:
-        return json.load(open(path)).get(name)
-    except (OSError, ValueError):
-        return None
+    """The committed rocprofv3 record of a bench figure (profiles/<round>_kernel_profiles.json, written by
+    tools/collect_shapes.sh on a GPU box; the newest round that has the figure): kernel average from --kernel-trace --stats
+    and the FETCH_SIZE / WRITE_SIZE passes.  bench.py prints `profile_frac` next to every live fraction that has one, so
+    that a reader sees the tracked number and the live one side by side (boxes of the pool differ by several per cent)."""
+    for rnd in PROFILE_ROUNDS:
+        path = os.path.join(ROOT, 'profiles', f'{rnd}_kernel_profiles.json')
+        try:
+            rec = json.load(open(path)).get(name)
+        except (OSError, ValueError):
+            rec = None
+        if rec:
+            return dict(rec, _file=f'profiles/{rnd}_kernel_profiles.json')
+    return None
 
 
 def with_profile(entry, name, alg_bytes, whole_step=False, flops=None):
@@ -223,7 +230,7 @@ def with_profile(entry, name, alg_bytes, whole_step=False, flops=None):
             entry['profile_dominant_kernel_share'] = rec.get('dominant_share_of_step')
         elif rec.get('hbm_bytes_per_launch') and alg_bytes:
             entry['profile_traffic_over_alg'] = round(rec['hbm_bytes_per_launch'] / alg_bytes, 3)
-        entry['profile_source'] = f'profiles/r03_kernel_profiles.json["{name}"]'
+        entry['profile_source'] = f'{rec["_file"]}["{name}"]'
     return entry
 
 
@@ -418,6 +425,27 @@ def main():
             user.copy_(uw0)
             del iw0, uw0, fa, atick
             torch.cuda.empty_cache()
+            # Rooflines of the steps, SURVEY.md 8d's byte model: the forward's bytes + the read-modify-write of
+            # the negative's row (2 * 4d) + the query-gradient and positive rows (2 * 4d / n) per triplet; lazy Adam touches
+            # three rows (weight, exp_avg, exp_avg_sq) per updated row: 3 * 2 * 4d.  Whole steps against the HBM peak.
+            fwd_b = bytes_per_triplet(d, n, popular, fused_loss=True)
+            ts = extra['train_step']
+            for key, per_triplet, t_ms, prof in (
+                    ('train', fwd_b + 4 * d + 2 * 4 * d / n, ms_train, 'train_step_N1e7_popular_n64_B65536'),
+                    ('sgd', fwd_b + 2 * 4 * d + 2 * 4 * d / n, t_sgd, 'sgd_step_N1e7_popular_n64_B65536'),
+                    ('sgd_prefetched', fwd_b + 2 * 4 * d + 2 * 4 * d / n, t_pf, None),
+                    ('adam', fwd_b + 3 * 2 * 4 * d + 3 * 2 * 4 * d / n, t_adam, 'adam_step_N1e7_popular_n64_B65536')):
+                algb = per_triplet * B * n
+                ts[f'{key}_alg_bytes_per_triplet'] = round(per_triplet, 1)
+                ts[f'{key}_frac'] = round(algb / t_ms / 1e6 / HBM_PEAK_GBS, 4)
+                rec = prof and profile_record(prof)
+                if rec and rec.get('step_kernel_us'):
+                    ts[f'{key}_profile_frac'] = round(algb / (rec['step_kernel_us'] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
+                    ts[f'{key}_profile_step_kernel_ms'] = round(rec['step_kernel_us'] / 1e3, 4)
+                    ts[f'{key}_profile_source'] = f'{rec["_file"]}["{prof}"]'
+            ts['frac_what'] = ('whole-step algorithmic bytes (SURVEY.md 8d: forward + 2*4d per triplet for the updated row + '
+                               '2*4d/n for the query-gradient and positive rows; train: 4d, the row-sparse gradient written once; '
+                               'adam: 3 rows read-modified-written) / step time / 8 TB/s')
             extra['train_step']['adam_step_what'] = ('forward + BPR loss + lazy Adam (SparseAdam rule) on the touched item '
                                                      'and user rows, gradient sums kept in registers (no gradient tensor)')
             extra['train_step']['sgd_step_what'] = ('negatives drawn and sorted by item id, forward + BPR loss with the SGD update of '
@@ -543,6 +571,9 @@ def main():
                 'not_in_the_step_any_more': {'softmax_recompute_write_alone': round(t_rec, 3),
                                              'grad_query_gemm_rocblas': round(t_gq, 3)},
                 'fp32_mfma_floor_of_the_step_ms': round(4 * flops / 157.3e12 * 1e3, 2)}
+            extra['fullscore']['softmax_train_frac'] = round(4 * flops / 157.3e12 * 1e3 / t_sm, 4)
+            extra['fullscore']['softmax_train_frac_what'] = ('the step is four GEMMs of 2*B*d*N flop (forward scores, recomputed '
+                                                             'scores, dQ, dX): their time at the 157.3 TFLOP/s fp32 matrix peak / step time')
             del probs5
             del w5, qq5
         except Exception as e:
@@ -550,16 +581,30 @@ def main():
         # ---- the headline line: exactly K steps after W warm-up steps, measured after the secondary figures so that the
         # GPU is at steady-state clocks (boxes of the pool differ by several per cent either way)
         hb = {}
+        # a FRESH (user, positive) batch every step (one batch reused for every timed step keeps its
+        # 67 MB of user / positive rows Infinity-Cache resident): drawn before the clock starts, one row per step -- a
+        # row of the id matrix is a view, so the timed region holds exactly the kernels it held before
+        n_batches = args.steps + args.warmup
+        g_b = torch.Generator(device=dev).manual_seed(4242 + rank)
+        uid_all = torch.randint(1, args.users, (n_batches, B), device=dev, generator=g_b)
+        pos_all = torch.randint(1, args.items, (n_batches, B), device=dev, generator=g_b)
+        tick = {'i': 0}
+
+        def fresh_kw():
+            i = tick['i'] % n_batches
+            tick['i'] += 1
+            return dict(kw, query_index=uid_all[i], pos_ids=pos_all[i])
 
         def step():          # sample + gather + score + BPR loss (value, d loss/d score, mean): ONE kernel
-            hb['step'] = ra.ops.fused_forward(item, user, n, out=hb.get('step'), fused_bpr=True, **kw)
+            hb['step'] = ra.ops.fused_forward(item, user, n, out=hb.get('step'), fused_bpr=True, **fresh_kw())
             return hb['step']
 
         def step_unfused():  # the same with the loss as its own kernel
-            hb['fwd'] = ra.ops.fused_forward(item, user, n, out=hb.get('fwd'), **kw)
+            hb['fwd'] = ra.ops.fused_forward(item, user, n, out=hb.get('fwd'), **fresh_kw())
             o = hb['fwd']
             return ra.ops.pairwise_loss(nat.LOSS_BPR, o['pos_score'], o['neg_score'], want_grad=True)
 
+        tick['i'] = 0
         ms_step = time_gpu(step, args.steps, args.warmup) * 1e3
         extra['unfused_loss_ms_per_step'] = round(time_gpu(step_unfused, args.steps, args.warmup) * 1e3, 4)
 
@@ -568,7 +613,7 @@ def main():
         torch.cuda.synchronize()
         for a, b in evs:      # exactly one launch between the events: the fused kernel (no mean reduction)
             a.record()
-            hb['step'] = ra.ops.fused_forward(item, user, n, out=hb['step'], fused_bpr=True, want_mean=False, **kw)
+            hb['step'] = ra.ops.fused_forward(item, user, n, out=hb['step'], fused_bpr=True, want_mean=False, **fresh_kw())
             b.record()
         torch.cuda.synchronize()
         k_ms = sorted(a.elapsed_time(b) for a, b in evs)
@@ -580,8 +625,8 @@ def main():
                     'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': None,
                     'alg_bytes_per_launch': int(alg), 'avg_kernel_ms': round(k_avg, 4),
                     'median_kernel_ms': round(k_ms[len(k_ms) // 2], 4)}
-        # The tracked profile of this very kernel and shape (profiles/r03_kernel_profiles.json: rocprofv3 --kernel-trace --stats
-        # average and the FETCH_SIZE / WRITE_SIZE passes, collected by tools/collect_profiles_r3.sh on another box of the
+        # The tracked profile of this very kernel and shape (profiles/<round>_kernel_profiles.json: rocprofv3 --kernel-trace --stats
+        # average and the FETCH_SIZE / WRITE_SIZE passes, collected by tools/collect_shapes.sh on another box of the
         # pool): `profile_frac` is the same algorithmic bytes over THAT average, printed next to the live `frac`; the PMC
         # traffic is attached only while the two kernel times are within 15 % (a changed kernel must be re-profiled)
         if (args.items, args.batch, args.neg, args.dim, popular, args.pop_lookup) == (10_000_001, 65536, 64, 128, True, 'auto'):
@@ -589,11 +634,11 @@ def main():
             if rec and rec.get('avg_us'):
                 roofline['profile_frac'] = round(alg / (rec['avg_us'] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
                 roofline['profile_avg_kernel_ms'] = round(rec['avg_us'] / 1e3, 4)
-                roofline['profile_source'] = 'profiles/r03_kernel_profiles.json["headline_N1e7_popular_n64_B65536"] (rocprofv3 --kernel-trace --stats)'
+                roofline['profile_source'] = f'{rec["_file"]}["headline_N1e7_popular_n64_B65536"] (rocprofv3 --kernel-trace --stats)'
                 if rec.get('hbm_bytes_per_launch') and abs(rec['avg_us'] / 1e3 - k_avg) / k_avg < 0.15:
                     roofline['traffic'] = int(rec['hbm_bytes_per_launch'])
                     roofline['traffic_source'] = ('same file: FETCH_SIZE + WRITE_SIZE passes, units and gfx950 correction as in '
-                                                  'MI355X_MICROARCH.md (see tools/collect_profiles_r3.sh)')
+                                                  'MI355X_MICROARCH.md (see tools/collect_shapes.sh)')
 
         # north_star target: the fused gather+sample+score(+BPR) on a 100 M-item table (51.2 GB) at d = 128
         if not args.no_sweep and args.dim == 128:
@@ -679,7 +724,30 @@ def main():
                      'with_collectives_ms': round(res1['with_collectives_ms'], 4),
                      'kernels_per_step': 'embedding_gather, shard_sample_route, fused_fwd_kernel (segment form), shard_home'},
                     'sharded_world1_step', alg1, whole_step=True)
-                del blk, tbl
+                # ... and the complete in-place-SGD TRAINING step of that shape (the per-GPU ceiling of an 8-GPU training
+                # curve): the stock BPR step evaluated on the owner of the negatives -- sampling + routing, sorts by row and
+                # by query, ONE pass over the item rows (scores, loss, query-gradient partials, rows one element touches
+                # updated in place), sorted apply for the shared rows, user rows.  SURVEY.md 8d bytes at n = 1024.
+                tower1 = torch.nn.Embedding(args.users, d).to(dev)
+                with torch.no_grad():
+                    tower1.weight.copy_(user)
+                blk0 = blk.clone()
+                tbl_t = shard.ShardedItemTable(blk, shard.RowShardPlan(n_blk, 1), 0, dist1, check_every=0)
+                trainer1 = shard.ShardedRetriever(tbl_t, tower1, us, ra.BPRLoss(), n1k, item_sgd_lr=1e-3, query_sgd_lr=1e-3)
+                trainer1.training_step(u1, p1)
+                t_tr = time_gpu(lambda: trainer1.training_step(u1, p1), 30, 3) * 1e3
+                tbl_t.check_overflow()
+                blk.copy_(blk0)
+                del blk0, tower1, trainer1
+                alg_tr = (bytes_per_triplet(d, n1k, False) + 2 * 4 * d + 2 * 4 * d / n1k) * b1k * n1k
+                tr = with_profile({'ms_per_step': round(t_tr, 4), 'M_triplets_s': round(b1k * n1k / t_tr / 1e3, 2),
+                                   'frac_of_hbm_peak': round(alg_tr / t_tr / 1e6 / HBM_PEAK_GBS, 4),
+                                   'alg_bytes_per_triplet': round(alg_tr / b1k / n1k, 1),
+                                   'what': 'in-place SGD training step of the same shape, BPR evaluated on the owners '
+                                           '(shard.ShardedItemTable.bpr_step_on_owners): item rows read once per step'},
+                                  'sharded_world1_train', alg_tr, whole_step=True)
+                extra['sharded_world1']['train'] = tr
+                del blk, tbl, tbl_t
             except Exception as e:
                 extra['sharded_world1'] = {'error': repr(e)[:200]}
         value = B * n / ms_step / 1e3

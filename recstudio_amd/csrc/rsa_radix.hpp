@@ -86,9 +86,9 @@ struct SrcSegments {
       return rdx_pack(key, (uint32_t)i);
     }
     const uint32_t seg = by_stride.div((uint32_t)i), within = (uint32_t)i - seg * by_stride.d;
+    const int64_t k = keys[i];                        // unconditional (the slack is readable): not behind the header's round trip
     const int64_t live = keys[(size_t)seg * by_stride.d];
     if (within >= RSA_SHARD_HDR && (int64_t)(within - RSA_SHARD_HDR) < live) {
-      const int64_t k = keys[i];
       key = BY_QUERY ? (uint32_t)((k >> 32) & 0x7fffffffll) : (uint32_t)(k & 0xffffffffll);
       key = key > dead_key ? dead_key : key;          // never index past the tables on a bad key
     }

@@ -1,4 +1,4 @@
-"""One bench figure, alone, for rocprofv3 (tools/collect_profiles_r3.sh): builds the shape, runs K launches of its step
+"""One bench figure, alone, for rocprofv3 (tools/collect_shapes.sh): builds the shape, runs K launches of its step
 and prints {"shape", "steps"} so that the summariser can turn totals into per-step figures.
 usage: python tools/prof_shapes.py SHAPE [K]"""
 import json
