@@ -466,6 +466,31 @@ def main():
                 sweep[f'B={b2}'] = with_profile({'ms_per_step': round(t, 4), 'M_triplets_s': round(b2 * n / t / 1e3, 2),
                                                  'frac_of_hbm_peak': round(alg2 / t / 1e6 / HBM_PEAK_GBS, 4)},
                                                 f'N1e7_popular_n64_B{b2}', alg2)
+                # INDEPENDENT steps (forward-only scoring of many batches) alternating over two HIP streams: the sampling
+                # chain of one launch (draw -> bucket line -> slot: ~7 us with the memory system idle) runs under the row
+                # phase of the other instead of behind the stream's barrier packet.  Throughput mode only: the steps of a
+                # training run depend on each other (there fused.PrefetchedBPRSGD overlaps the weight-independent part).
+                try:
+                    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+                    two = []
+                    for s_ in streams:
+                        with torch.cuda.stream(s_):
+                            two.append(ra.ops.FusedStep(item, user, n, fused_bpr=True, **dict(kw, query_index=u2, pos_ids=p2)))
+                    torch.cuda.synchronize()
+                    cnt = {'i': 0}
+
+                    def alternating():
+                        i = cnt['i'] & 1
+                        cnt['i'] += 1
+                        with torch.cuda.stream(streams[i]):
+                            two[i]()
+                    t2s = time_gpu(alternating, args.steps, 10) * 1e3
+                    sweep[f'B={b2}'].update(two_streams_ms_per_step=round(t2s, 4),
+                                            two_streams_frac_of_hbm_peak=round(alg2 / t2s / 1e6 / HBM_PEAK_GBS, 4),
+                                            two_streams_what='independent steps alternating over two streams (throughput mode)')
+                    del two, streams
+                except Exception as e:
+                    sweep[f'B={b2}']['two_streams_error'] = repr(e)[:120]
                 del st
             extra['sweep'] = sweep
         # configs[4]: full-catalog scores on the fp32 MFMA (N = 1e6, d = 128), logsumexp fused, + exact top-100

@@ -18,9 +18,6 @@
 //    accumulated with atomics into a zero-filled [M, d] buffer.
 #include "rsa_common.hpp"
 
-#ifndef RSA_BWD_NT_STORE
-#define RSA_BWD_NT_STORE 1
-#endif
 
 namespace rsa {
 
@@ -180,14 +177,9 @@ __global__ __launch_bounds__(256) void bwd_qu_kernel(const BwdParams p) {
           for (int c = 0; c < CH; ++c) {
             const int col = (c * LPR + sub) * 4;
             if (!GENERIC || col < D) {
-#if RSA_BWD_NT_STORE
               typedef float v4f __attribute__((ext_vector_type(4)));
               v4f v = {s * qf[c].x, s * qf[c].y, s * qf[c].z, s * qf[c].w};
               __builtin_nontemporal_store(v, reinterpret_cast<v4f*>(orow + col));   // written once, read by the optimizer later
-#else
-              *reinterpret_cast<float4*>(orow + col) =
-                  make_float4(s * qf[c].x, s * qf[c].y, s * qf[c].z, s * qf[c].w);
-#endif
             }
           }
         }

@@ -30,13 +30,10 @@ void set_error(const char* fmt, ...);
 // ---------------------------------------------------------------- Philox4x32-10
 // Random123 Philox4x32 with 10 rounds: the generator behind torch's device
 // distributions (rocRAND philox4x32_10_engine::ten_rounds).
-#ifndef RSA_PHILOX_ROUNDS
-#define RSA_PHILOX_ROUNDS 10      // (fewer: timing experiments only -- the ids are then not torch's)
-#endif
 __device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint2 k) {
   constexpr uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
 #pragma unroll
-  for (int r = 0; r < RSA_PHILOX_ROUNDS; ++r) {
+  for (int r = 0; r < 10; ++r) {
     const uint32_t hi0 = __umulhi(M0, c.x), lo0 = M0 * c.x;
     const uint32_t hi1 = __umulhi(M1, c.z), lo1 = M1 * c.z;
     c = make_uint4(hi1 ^ c.y ^ k.x, lo1, hi0 ^ c.w ^ k.y, lo0);
@@ -87,14 +84,7 @@ __device__ __forceinline__ uint4 philox_for_element(const PhiloxCall& pc, uint64
   const uint64_t ctr = pc.offset4 + k;
   const uint4 c = make_uint4((uint32_t)ctr, (uint32_t)(ctr >> 32), (uint32_t)idx, (uint32_t)(idx >> 32));
   const uint2 key = make_uint2((uint32_t)pc.seed, (uint32_t)(pc.seed >> 32));
-#ifdef RSA_PHILOX_EXTRA     // timing experiment: the cost of one more block per element (its result cannot change the draw)
-  uint4 v = philox4x32_10(c, key);
-  const uint4 w = philox4x32_10(make_uint4(c.x ^ 1u, c.y, c.z, c.w), key);
-  if ((w.x ^ w.y ^ w.z ^ w.w) == 0x9e3779b9u && w.x == 0x12345u) v.x ^= 1u;
-  return v;
-#else
   return philox4x32_10(c, key);
-#endif
 }
 
 __device__ __forceinline__ uint32_t pick(const uint4& v, int comp) {

@@ -28,12 +28,6 @@
 #include "rsa_common.hpp"
 #include <type_traits>
 
-// Ablation switches for tools/exp_fs.sh (bit mask; results are WRONG when set -- timing experiments only, never
-// a product build): 1 = A operand from registers instead of LDS, 2 = no stage loads / LDS writes / barrier,
-// 4 = no logsumexp epilogue.
-#ifndef RSA_FS_EXP
-#define RSA_FS_EXP 0
-#endif
 #ifndef RSA_FS_MIN_BLOCKS
 #define RSA_FS_MIN_BLOCKS 1
 #endif
@@ -264,11 +258,6 @@ __global__ __launch_bounds__(256, DQ ? RSA_FS_DQ_MIN_BLOCKS : RSA_FS_MIN_BLOCKS)
   // (a) branch-free online logsumexp: pure VALU, interleaved with the MFMAs by the sched_group_barriers below
   float tile_max = -INFINITY;      // max of the tile's (in-range) scores, left by lse_update for the candidate filter
   auto lse_update = [&](const f32x16& acc, int64_t i0, auto masked) __attribute__((always_inline)) {
-#if RSA_FS_EXP & 4
-    run_s += acc[0] + acc[5] + acc[10] + acc[15];   // experiment: GEMM core without the logsumexp epilogue
-    run_m = 0.f;
-    return;
-#endif
     float v[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -374,11 +363,7 @@ __global__ __launch_bounds__(256, DQ ? RSA_FS_DQ_MIN_BLOCKS : RSA_FS_MIN_BLOCKS)
     const float* arow = tbuf(buf) + lds_off(sub * TI + j, 0) + h * KH;   // lane's item row of this tile, its k half
 #pragma unroll
     for (int c = 0; c < KH / 4; ++c) {
-#if RSA_FS_EXP & 1
-      const float4 a = make_float4(bq[4 * c + 1], bq[4 * c + 2], bq[4 * c + 3], bq[4 * c]);   // experiment: no LDS reads
-#else
       const float4 a = *reinterpret_cast<const float4*>(arow + 4 * c);
-#endif
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bq[4 * c + 0], acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bq[4 * c + 1], acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bq[4 * c + 2], acc, 0, 0, 0);
@@ -427,13 +412,11 @@ __global__ __launch_bounds__(256, DQ ? RSA_FS_DQ_MIN_BLOCKS : RSA_FS_MIN_BLOCKS)
     const int cur = CURC >= 0 ? CURC : (DQ ? rb_cur : (st & 1));
     const int nxt = CURC >= 0 ? (CURC + 1) % NBUF : (DQ ? rb_nxt : (cur ^ 1));
     const int prv = CURC >= 0 ? (CURC + NBUF - 1) % NBUF : (DQ ? rb_prv : (cur ^ 1));
-#if !(RSA_FS_EXP & 2)
     if constexpr (USE_DMA) {
       dma_fetch(st + 1, tbuf(nxt));        // lands in LDS under this stage's MFMA chain
       __builtin_amdgcn_sched_barrier(0);   // keep the loads at the top: the scheduler otherwise sinks them to the barrier
     }
     else if (sub == 0) fetch(st + 1);     // global loads fly under this stage's MFMA chains
-#endif
     // dQ variant on the direct-load path: the previous tile's epilogue -- softmax transform, the score stores, the second
     // product -- goes FIRST, so that the vmcnt(0) at the bottom of the iteration (it counts stores as well as the direct
     // loads) finds the stores long completed instead of waiting a write round trip per tile: 8.88 -> 8.38 ms.  (The
@@ -458,7 +441,6 @@ __global__ __launch_bounds__(256, DQ ? RSA_FS_DQ_MIN_BLOCKS : RSA_FS_MIN_BLOCKS)
       }
     }
     if constexpr (!EMIT_FIRST) emit(acc_prev, i_begin + (int64_t)(u - 1) * TI, prv);
-#if !(RSA_FS_EXP & 2)
     if constexpr (USE_DMA) {
       __builtin_amdgcn_sched_barrier(0);    // ... and the wait at the bottom, behind the whole MFMA chain
       __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0): this wave's direct loads have landed
@@ -467,7 +449,6 @@ __global__ __launch_bounds__(256, DQ ? RSA_FS_DQ_MIN_BLOCKS : RSA_FS_MIN_BLOCKS)
       commit(nxt);
       __syncthreads();
     }
-#endif
     if constexpr (DQ && CURC < 0) {      // (the unrolled loop below runs whole rotations: the indices come back)
       rb_prv = cur;
       rb_cur = nxt;

@@ -21,15 +21,8 @@
 #include "rsa_common.hpp"
 #include "rsa_tile.hpp"
 
-#ifndef RSA_LUT_NT
-#define RSA_LUT_NT 0
-#endif
 #ifndef RSA_QG_BATCH
-#define RSA_QG_BATCH 4     // rows per load batch of the training forward (double-buffered when RSA_QG_PIPELINE)
-#endif
-#ifndef RSA_QG_PIPELINE
-#define RSA_QG_PIPELINE 1  // double-buffered batches pinned by data dependences: 120 VGPRs (4 waves/SIMD) instead of 171;
-                           // measured: the training forward costs +0-3 % over the plain one instead of +4-10 %
+#define RSA_QG_BATCH 4     // rows per load batch of the training forward (double-buffered, order pinned by data dependences: 120 VGPRs = 4 waves/SIMD instead of 171)
 #endif
 
 namespace rsa {
@@ -96,15 +89,6 @@ __device__ __forceinline__ void fold(float (&d)[L], int sub, int step) {
 // Rows are visited BATCH at a time, batch b = rows {b, b+NB, b+2NB, ...} of the lane group, and
 // each batch is folded to one value right away (the depth-first order of the transpose-reduce
 // tree), so only BATCH row fragments + NB partials are live instead of LPR of each.
-#ifndef RSA_FWD_PLAIN_PIPE
-#define RSA_FWD_PLAIN_PIPE 0
-#endif
-#ifndef RSA_FWD_QNT
-#define RSA_FWD_QNT 0      // 1: the query and positive rows of a big-table launch are streamed (nontemporal) too
-#endif
-#ifndef RSA_FWD_PIN
-#define RSA_FWD_PIN 0      // 0: batches ordered by sched heuristics (round 1);  1: batch b+1's loads pinned behind batch b's
-#endif                     // fold by a data dependence;  2: one batch requested ahead (two batches of fragments live)
 #ifndef RSA_FWD_BATCH
 #define RSA_FWD_BATCH 8
 #endif
@@ -123,7 +107,7 @@ __device__ __forceinline__ void tile_rows(const float* __restrict__ table, int D
   constexpr int B0 = QU ? RSA_FWD_BATCH : RSA_SEG_BATCH;     // per-row queries: every row brings a second fragment
   constexpr int BATCH = GENERIC ? 2 : (LPR < B0 ? LPR : B0);
   constexpr int NB = LPR / BATCH;
-  constexpr int NBUF = (RSA_FWD_PIN == 2) ? 2 : 1;
+  constexpr int NBUF = 1;
   const int lane = lane_id();
   const int sub = lane % LPR;
   int gbase = lane - sub;   // first tile row of this lane group
@@ -144,14 +128,9 @@ __device__ __forceinline__ void tile_rows(const float* __restrict__ table, int D
       }
     }
   };
-  if (RSA_FWD_PIN == 2) request(0);
 #pragma unroll
   for (int b = 0; b < NB; ++b) {
-    if (RSA_FWD_PIN == 2) {
-      if (b + 1 < NB) request(b + 1);
-    } else {
-      request(b);
-    }
+    request(b);
     float d[BATCH];
     float d2[COS ? BATCH : 1];
     float d3[(COS && !QU) ? BATCH : 1];
@@ -174,11 +153,6 @@ __device__ __forceinline__ void tile_rows(const float* __restrict__ table, int D
         top3[b] = d3[0];
       }
     }
-#if RSA_FWD_PIN
-    // the source-lane base of the NEXT request depends on this batch's result: the selection DAG cannot move that
-    // request (and its LPR-row fragments) in front of this batch, nor this batch's fold behind the later ones
-    asm volatile("" : "+v"(gbase), "+v"(top[b]));
-#endif
   }
   fold<NB>(top, sub, 1);
   dot = top[0];
@@ -211,7 +185,6 @@ __device__ __forceinline__ void tile_rows_qg(const float* table, int32_t id_lane
   const int sub = lane % LPR;
   const int gbase = lane - sub;
   dot = 0.f;
-#if RSA_QG_PIPELINE
   // batch b+1 requested while batch b is consumed; order pinned by data dependences (see tile_rows_ssm)
   F x[2][BATCH];
   int gb = gbase;
@@ -250,31 +223,6 @@ __device__ __forceinline__ void tile_rows_qg(const float* table, int32_t id_lane
     }
     asm volatile("" : "+v"(gb), "+v"(qacc.x), "+v"(qacc.y), "+v"(qacc.z), "+v"(qacc.w));
   }
-#else
-  static_assert(!UPD, "the in-forward update is built on the pipelined tile");
-#pragma unroll
-  for (int b = 0; b < NB; ++b) {
-    F x[BATCH];
-#pragma unroll
-    for (int k = 0; k < BATCH; ++k) {
-      const int32_t rid = __shfl(id_lane, gbase + b * BATCH + k, 64);     // rows b*BATCH .. of the lane group
-      frag_load<LPR, false, NT>(x[k], table + (size_t)rid * D, sub, D);
-    }
-#pragma unroll
-    for (int k = 0; k < BATCH; ++k) {
-      const float dk = group_sum<LPR>(frag_dot<LPR, false>(x[k], qf));    // all LPR lanes hold the row's dot
-      const float g = bpr_dneg(pos_s, dk, bw, binv);
-      const float4 xv = x[k].v[0];
-      qacc.x = __fmaf_rn(g, xv.x, qacc.x);
-      qacc.y = __fmaf_rn(g, xv.y, qacc.y);
-      qacc.z = __fmaf_rn(g, xv.z, qacc.z);
-      qacc.w = __fmaf_rn(g, xv.w, qacc.w);
-      dot = sub == b * BATCH + k ? dk : dot;
-    }
-    // keep the batches sequential: otherwise the scheduler hoists all LPR row loads to the top (222 VGPRs)
-    __builtin_amdgcn_sched_barrier(0);
-  }
-#endif
 }
 
 // Plain (no loss) counterpart of the pipelined training tile: batches of RSA_QG_BATCH rows, batch b+1 requested while
@@ -325,9 +273,6 @@ __device__ __forceinline__ float finish_score(int mode, float dot, float inorm2,
 #ifndef RSA_QG_MIN_WAVES
 #define RSA_QG_MIN_WAVES 1
 #endif
-#ifndef RSA_FWD_LUT_AHEAD
-#define RSA_FWD_LUT_AHEAD 1
-#endif
 #ifndef RSA_FWD_MIN_WAVES
 #define RSA_FWD_MIN_WAVES 1
 #endif
@@ -336,9 +281,6 @@ __device__ __forceinline__ float finish_score(int mode, float dot, float inorm2,
                             // in-process A/B at n = 256, B = 8192 with the query gradient: 197.4 vs 205.6 us; 8: 180)
 #endif
 
-#ifndef RSA_FWD_GRID_CAP
-#define RSA_FWD_GRID_CAP (256 * 8)
-#endif
 // Small and medium launches (up to RSA_PIPE_MAX_TILES tiles: B = 32768 at n = 64) run the butterfly tile with 8-row batches
 // (tile_rows_pipe<.., 8>) instead of the transposed fold: B = 4096: 37.8 -> 35.5 us, B = 16384: 120 -> 111 us per launch
 // (popularity sampler; uniform and given ids alike), equal within the run-to-run noise at B = 65536, where the transposed
@@ -376,22 +318,14 @@ void fused_fwd_kernel(const FwdParams p) {
   // Popularity sampler with the direct-lookup table: the draw and the LUT entry of the wave's NEXT tile are
   // fetched one tile ahead (5 VGPRs), so that a tile's row loads no longer wait behind the LUT round trip.
   // (bucket lines are NOT fetched ahead: carrying a line's 12 values across a tile measured 2-4 % slower)
-  const bool ahead = RSA_FWD_LUT_AHEAD && QU && p.sampler == RSA_SAMPLER_POPULAR && p.lut != nullptr && p.lines == nullptr;
+  const bool ahead = QU && p.sampler == RSA_SAMPLER_POPULAR && p.lut != nullptr && p.lines == nullptr;
   float u_next = 0.f;
   float4 lut_next = make_float4(0.f, 0.f, 0.f, 0.f);
   auto fetch_ahead = [&](int64_t t) {
     const int64_t e2 = (t << 6) + lane;
     if (e2 < p.numel) {
       u_next = torch_rand_element(pc, (uint64_t)e2);
-#if RSA_LUT_NT
-      {   // the table is read at random and an entry is never reused within a step: streaming hint
-        typedef float v4f __attribute__((ext_vector_type(4)));
-        const v4f v = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(p.lut) + lut_bucket(p.guide_log2, u_next));
-        lut_next = make_float4(v.x, v.y, v.z, v.w);
-      }
-#else
       lut_next = reinterpret_cast<const float4*>(p.lut)[lut_bucket(p.guide_log2, u_next)];
-#endif
     }
   };
   if (ahead && wave0 < n_tiles) fetch_ahead(wave0);
@@ -479,10 +413,10 @@ void fused_fwd_kernel(const FwdParams p) {
     float qn2_u = 0.f;
     bool empty_slot = false;     // packed_keys < 0: the slot's score is 0
     if constexpr (QU) {
-      frag_load<LPR, GENERIC, NT && RSA_FWD_QNT>(qf, p.query + (size_t)qrow_u * D, sub, D);
+      frag_load<LPR, GENERIC>(qf, p.query + (size_t)qrow_u * D, sub, D);
       pad = pid_u == 0;
       pid_u = pid_u < 0 ? 0 : (pid_u >= p.n_items ? p.n_items - 1 : pid_u);
-      frag_load<LPR, GENERIC, NT && RSA_FWD_QNT>(px, p.item_table + (size_t)pid_u * D, sub, D);   // row 0 when there is no positive
+      frag_load<LPR, GENERIC>(px, p.item_table + (size_t)pid_u * D, sub, D);   // row 0 when there is no positive
       if constexpr (COS) qn2_u = group_sum<LPR>(frag_dot<LPR, GENERIC>(qf, qf));
     } else {
       m_lane = act ? e / n : 0;
@@ -542,8 +476,8 @@ void fused_fwd_kernel(const FwdParams p) {
                           __fadd_rn(pv.z, __fmul_rn(us, __fmul_rn(dp, qv.z))), __fadd_rn(pv.w, __fmul_rn(us, __fmul_rn(dp, qv.w))));
         }
       }
-    } else if constexpr ((RSA_FWD_PLAIN_PIPE || PIPE > 0) && QU && !COS && !GENERIC) {
-      tile_rows_pipe<LPR, NT, (PIPE > 0 ? PIPE : RSA_QG_BATCH)>(p.item_table, id, qf, dot);
+    } else if constexpr (PIPE > 0 && QU && !COS && !GENERIC) {
+      tile_rows_pipe<LPR, NT, PIPE>(p.item_table, id, qf, dot);
     } else {
       tile_rows<LPR, GENERIC, COS, QU, NT>(p.item_table, D, id, p.query, qrow_lane, qf, dot, in2, qn2);
     }
@@ -796,9 +730,6 @@ __global__ __launch_bounds__(256, QG ? RSA_SSM_MIN_WAVES : 1) void fused_ssm_ker
 // round-robin, each carrying its sums in registers, and wave 0 of the query adds the partials in wave order through
 // LDS -- fixed order, no atomics, nothing to zero.  BPR needs no second pass over the tiles (the positive score is known
 // before the first negative): d loss/d neg is final when it is written.
-#ifndef RSA_WALK_TRANSPOSE
-#define RSA_WALK_TRANSPOSE 0     // 1: forward-only tiles through the transposed fold of tile_rows instead of butterfly sums
-#endif
 #ifndef RSA_WALK_PIPE_BATCH
 #define RSA_WALK_PIPE_BATCH RSA_QG_BATCH
 #endif
@@ -863,9 +794,6 @@ __global__ __launch_bounds__(256, QG ? RSA_WALK_MIN_WAVES : RSA_WALK_FWD_MIN_WAV
         float dot;
         if constexpr (QG) {
           tile_rows_qg<LPR, NT>(p.item_table, id, qf, pos_s, w, inv_m, dot, qacc);
-        } else if constexpr (RSA_WALK_TRANSPOSE) {
-          float in2, qn2;
-          tile_rows<LPR, false, false, true, NT>(p.item_table, D, id, p.query, 0, qf, dot, in2, qn2);
         } else {
           tile_rows_pipe<LPR, NT, RSA_WALK_PIPE_BATCH>(p.item_table, id, qf, dot);
         }

@@ -5,18 +5,11 @@
 
 namespace rsa {
 
-#ifndef RSA_FWD_NT_STORE
-#define RSA_FWD_NT_STORE 1
-#endif
 // per-element outputs (ids, scores, log-probs, d loss/d score) are written once and consumed by a later kernel:
 // streaming stores keep them from displacing table lines in L2
 template <typename T>
 __device__ __forceinline__ void st_out(T* p, T v) {
-#if RSA_FWD_NT_STORE
   __builtin_nontemporal_store(v, p);
-#else
-  *p = v;
-#endif
 }
 
 template <int LPR, bool GENERIC>
