@@ -564,6 +564,8 @@ def test_bpr_fit_with_fused_optimizer(ra, golden, kind):
     lr = 0.003 if kind == 'adam' else 30.0            # plain SGD on a mean-reduced loss needs a batch-sized rate
     cfg = {'model': {'embed_dim': 64}, 'train': {'epochs': 6, 'negative_count': 64, 'batch_size': 512, 'learning_rate': lr,
            'fused_optimizer': kind, 'init_method': 'normal'}, 'eval': {'batch_size': 256}}
+    if kind == 'adam':
+        cfg['train']['fused_prefetch'] = 'adam'       # (the look-ahead is opt-in for the lazy-Adam step: it does not pay there)
     model = ra.BPR(cfg)
     model.fit(trn, val)
     res = model.evaluate(tst)

@@ -47,3 +47,15 @@ for rep in range(3):
         box['t'] = nxt
     res.setdefault('prefetched_ms', []).append(round(timed(pf), 4))
 print(json.dumps(res))
+# lazy Adam: plain step vs the prepare / step_prepared pair one batch ahead
+fa = ra.fused.FusedBPRAdam(item, user, lr=1e-3)
+for rep in range(3):
+    res.setdefault('adam_plain_ms', []).append(round(timed(lambda: fa.step(n, user_ids=uid, pos_ids=pos, sampler=sampler), 40, 5), 4))
+    abox = {'t': fa.prepare(n, user_ids=uid, pos_ids=pos, sampler=sampler)}
+
+    def apf():
+        nxt = fa.prepare(n, user_ids=uid, pos_ids=pos, sampler=sampler)
+        fa.step_prepared(abox['t'])
+        abox['t'] = nxt
+    res.setdefault('adam_prefetched_ms', []).append(round(timed(apf, 40, 5), 4))
+print(json.dumps(res))
