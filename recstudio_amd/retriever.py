@@ -762,7 +762,16 @@ class BaseRetriever(torch.nn.Module):
                 batch.pop('_n_valid', None)
                 if optimizer is not None:
                     optimizer.zero_grad(set_to_none=False)
-                loss = trainer.training_step(self._get_query_feat(batch), batch[self.fiid], batch[self.frating])
+                try:
+                    loss = trainer.training_step(self._get_query_feat(batch), batch[self.fiid], batch[self.frating])
+                except RuntimeError as err:
+                    # an id distribution that outgrew the calibrated segment capacity: every rank raises at the same step
+                    # (the sticky count is job-wide), the affected steps updated nothing, the capacity is recalibrated on
+                    # the next step -- carry on instead of aborting the run
+                    if 'did not fit their owner segment' not in str(err):
+                        raise
+                    self.logger.warning(str(err))
+                    continue
                 if optimizer is not None:
                     if tr['grad_clip_norm'] is not None:
                         self._clip_grad_norm_sharded(params, tr['grad_clip_norm'], dist)

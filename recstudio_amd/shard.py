@@ -24,8 +24,9 @@ No host round trip in the step: the split is equal, the headers say what is live
 calibration launch (exact counts of the very draw the first step routes, max over slices, owners and ranks, plus
 slack).  An element that finds its segment full is DROPPED with a defined outcome -- no key, no score, no loss term,
 zero gradient -- and counted in the header; the headers of all sources reach every rank with the keys, so every rank
-knows the job-wide dropped count of the step and scales that step's weight updates by 0 on the device: an overflowed
-step changes nothing anywhere.  The count is also kept in a sticky device word that ``check_overflow`` reads off the
+knows the job-wide dropped count of the step and scales that step's GRADIENTS (or in-place SGD updates) by 0 on the
+device: with the in-kernel SGD an overflowed step changes no weight anywhere; a torch optimizer then steps on zero
+gradients (plain SGD: nothing moves; Adam / momentum: only their decaying history does).  The count is also kept in a sticky device word that ``check_overflow`` reads off the
 critical path (same value on every rank, no collective).  ``exchange='exact'`` is the variable-split form (counts
 exchanged and read back each step, ids materialised, separate scatter and loss kernels).
 
@@ -628,14 +629,16 @@ class ShardedItemTable:
         B, G = pos.numel(), plan.world
         C = self.chunks if (self.chunks > 1 and B % self.chunks == 0) else 1
         S = int(getattr(be, 'BANKS', 1))           # segments per (slice, owner): every consumer just sees G * S segments
-        key = (B, n, C)
+        # (the capacity is calibrated per id SOURCE: ids a plugin hands in -- popularity-skewed, say -- must not reuse the
+        # capacity of the in-kernel uniform draw)
+        key = (B, n, C) if spec is not None else (B, n, C, 'given')
         cap = self._cap.get(key)
         if cap is None:
             # calibration: exact per-segment counts of the very draw this step routes (the generator is not advanced),
             # largest over slices, owners, banks and ranks
             counts = be.sample_route(st, plan, self.rank, pos, n, C, 0, spec, self.sample_generator, neg=neg, count_only=True,
                                      banks=S)
-            cap = self._capacity(key, int(counts.max()))
+            cap = self._capacity(key[:3], int(counts.max()), store=key)
         # the sampler's log-probabilities: BPRLoss ignores them (loss_func.py:55-59), everything else gets them
         r = be.sample_route(st, plan, self.rank, pos, n, C, cap, spec, self.sample_generator, neg=neg,
                             want_ids=want_ids, want_logp=want_logp and fused_loss != 'bpr', banks=S)
@@ -675,8 +678,10 @@ class ShardedItemTable:
         self._after_fixed_step()
         out['neg_ids'], out['log_pos_prob'], out['log_neg_prob'] = r.get('neg_ids'), log_pos, log_neg
         if keep_route:
+            # the step's job-wide dropped count travels with the route: a forward issued between this step's forward and
+            # its backward (an evaluation, a second table user) overwrites the table's word
             out['route'] = {'B': B, 'n': n, 'C': C, 'GS': GS, 'stride': stride, 'q_all': q_all, 'slot_of': r['slot_of'],
-                            'recv_keys': recv_keys, 'd_send': out.pop('d_send', None)}
+                            'recv_keys': recv_keys, 'd_send': out.pop('d_send', None), 'dropped': st['step_dropped'].clone()}
         return out
 
     def _all_reduce_sum(self, t):
@@ -755,6 +760,7 @@ class ShardedItemTable:
         pad_row = 0 if self.rank == 0 else -1
         if 'slot_of' in route:
             G, C, stride = route['GS'], route['C'], route['stride']     # G: segments per slice (owners x banks)
+            state = dict(self.state, step_dropped=route.get('dropped', self.state['step_dropped']))
             per = G * stride
             if dpos is None:
                 d_send = route['d_send']
@@ -763,14 +769,14 @@ class ShardedItemTable:
             else:
                 d_send = self.backend.scatter_slots(dpos.reshape(-1), dneg.reshape(B, -1), route['slot_of'], C * per)
             if C == 1:
-                self.backend.backward_segments(self.state, self.item_local, q_all, route['recv_keys'][0], G, stride,
+                self.backend.backward_segments(state, self.item_local, q_all, route['recv_keys'][0], G, stride,
                                                self._all_to_all(d_send), item_grad_local, qgrad_all, item_pad_row=pad_row, **extra)
             else:
                 # all gradient exchanges are issued first, the owner-side scatters follow slice by slice (slice c's
                 # scatter runs while slice c+1's gradients are still on the wire)
                 waits = [self._all_to_all_start(d_send[c * per:(c + 1) * per]) for c in range(C)]
                 for rk, w in zip(route['recv_keys'], waits):
-                    self.backend.backward_segments(self.state, self.item_local, q_all, rk, G, stride, w(), item_grad_local,
+                    self.backend.backward_segments(state, self.item_local, q_all, rk, G, stride, w(), item_grad_local,
                                                    qgrad_all, item_pad_row=pad_row, **extra)
             return self._reduce_scatter_rows(qgrad_all, B)
         dflat = torch.cat([dpos.reshape(-1), dneg.reshape(-1)])

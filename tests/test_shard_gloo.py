@@ -362,8 +362,8 @@ def _worker(rank, world, port, n_items, d, B, n, result_dir, layout='block'):
         tight = ShardedItemTable(plan.take(item, rank).clone(), plan, rank, dist, backend=CheckerBackend(), slack=1.0, margin=0)
         negu = torch.randint(1, n_items, (B, n), generator=gr)
         tight.score_ids(user[uid], pos, negu)
-        assert B < 100 or tight._cap[(B, n, 1)] < B * (n + 1)
-        if tight._cap[(B, n, 1)] < B * (n + 1):
+        assert B < 100 or tight._cap[(B, n, 1, 'given')] < B * (n + 1)     # (calibrated per id source: these ids were given)
+        if tight._cap[(B, n, 1, 'given')] < B * (n + 1):
             w0 = tight.item_local.clone()
             p4, s4, route4 = tight.score_ids(user[uid], pos2, neg2, keep_route=True)
             # a dropped element has a defined outcome: its score reads 0, the others are exact
@@ -426,7 +426,7 @@ def _chunk_worker(rank, world, port, n_items, d, B, n, chunks, result_dir, layou
                                  chunks=chunks)
         tight.score_ids(user[uid], pos, a['neg_ids'])
         Bc = B // chunks
-        if tight._cap[(B, n, chunks)] < Bc * (n + 1):
+        if tight._cap[(B, n, chunks, 'given')] < Bc * (n + 1):
             tight.score_ids(user[uid], torch.full((B,), n_items - 2), torch.full((B, n), n_items - 1))
             with pytest.raises(RuntimeError, match='did not fit'):
                 tight.check_overflow()
