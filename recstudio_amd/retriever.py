@@ -53,7 +53,8 @@ def default_config():
                   'num_threads': 10, 'sampling_method': 'none', 'sampler': 'uniform', 'negative_count': 0,
                   'excluding_hist': False, 'scheduler': None, 'seed': 2022, 'weight_decay': 0.0,
                   'tensorboard_path': None, 'sparse_grad': False, 'device_loader': True, 'fused_optimizer': None,
-                  'shard_slices': 1, 'shard_layout': 'block', 'shard_owner_loss': True, 'fused_prefetch': True},
+                  'shard_slices': 1, 'shard_layout': 'block', 'shard_owner_loss': True, 'shard_init': 'auto',
+                  'fused_prefetch': True},
         'eval': {'batch_size': 128, 'cutoff': [5, 10, 20], 'val_metrics': ['ndcg', 'recall'], 'val_n_epoch': 1,
                  'test_metrics': ['ndcg', 'recall', 'precision', 'map', 'mrr', 'hit'], 'topk': 100,
                  'save_path': './saved/'},
@@ -69,8 +70,46 @@ def seed_everything(seed):
     return seed
 
 
+def _device_init_block(plan, rank, n_items, d, seed, method, device, rows_per_chunk=1 << 16):
+    """This rank's rows of an [n_items, d] embedding table initialised as recstudio/model/init.py does (xavier_normal /
+    xavier_uniform over the FULL shape, normal(0.02)) WITHOUT ever holding the full table: the table is defined chunk by
+    chunk of ``rows_per_chunk`` GLOBAL rows, chunk c drawn from its own generator stream (seed, c) on the device, and a
+    rank generates the chunks its rows fall into and keeps those rows.  The table is therefore a function of (seed, shape)
+    alone: any world size, either row layout, gives the rows of the same table (at 1e8 x 128 the host copy the
+    slice-after-init form needs is 51 GB per rank)."""
+    n_local = plan.n_local(rank)
+    out = torch.empty(n_local, d, dtype=torch.float32, device=device)
+    gen = torch.Generator(device=device)
+    if method == 'xavier_uniform':
+        bound = (6.0 / (n_items + d)) ** 0.5
+    std = (2.0 / (n_items + d)) ** 0.5 if method == 'xavier_normal' else 0.02
+    R, G = int(rows_per_chunk), plan.world
+    lo, hi = (0, n_items) if plan.interleaved else plan.bounds(rank)
+    for c in range(lo // R, (max(hi, lo + 1) - 1) // R + 1):
+        a, b = c * R, min((c + 1) * R, n_items)
+        if b <= a:
+            break
+        gen.manual_seed((int(seed) * 1_000_003 + c) & 0x7fffffffffffffff)
+        if method == 'xavier_uniform':
+            vals = (torch.rand(R, d, generator=gen, device=device) * 2 - 1) * bound
+        else:
+            vals = torch.randn(R, d, generator=gen, device=device) * std
+        if plan.interleaved:
+            first = (rank - a) % G                     # first row of the chunk this rank owns
+            rows = vals[first:b - a:G]
+            at = (a + first - rank) // G
+            out[at:at + rows.shape[0]] = rows
+        else:
+            u, v = max(a, lo), min(b, hi)
+            if v > u:
+                out[u - lo:v - lo] = vals[u - a:v - a]
+    return out
+
+
 def _init_weights(module, method):
     """recstudio/model/init.py: xavier_normal / xavier_uniform / normal(0.02); the padding row is zeroed."""
+    if isinstance(module, torch.nn.Embedding) and module.weight.is_meta:
+        return          # a sharded catalog: its rows are drawn on the owners' devices (_device_init_block)
     if isinstance(module, torch.nn.Embedding):
         if method == 'xavier_normal':
             torch.nn.init.xavier_normal_(module.weight.data)
@@ -180,6 +219,11 @@ class BaseRetriever(torch.nn.Module):
                 self.loss_fn = self._get_loss_func(train_data)
             else:
                 self.loss_fn = self._get_loss_func()
+        if not self.item_encoder and getattr(self, '_item_table_on_meta', False):
+            # multi-GPU fit over a big catalog: the [N, d] table is never materialised on the host -- its shape only (a
+            # meta tensor); every rank fills its own rows on its device (_setup_shard, _device_init_block)
+            with torch.device('meta'):
+                self.item_encoder = self._get_item_encoder(train_data)
         self.item_encoder = self._get_item_encoder(train_data) if not self.item_encoder else self.item_encoder
         self.query_encoder = self._get_query_encoder(train_data) if not self.query_encoder else self.query_encoder
         self.sampler = self._get_sampler(train_data) if not self.sampler else self.sampler
@@ -632,8 +676,14 @@ class BaseRetriever(torch.nn.Module):
         device = torch.device(device)
         n_items, d = self.item_encoder.weight.shape
         plan = shard.RowShardPlan(n_items, world, layout=self.config['train'].get('shard_layout', 'block'))
-        block = torch.nn.Embedding(plan.n_local(rank), d, padding_idx=0 if rank == 0 else None,
-                                   _weight=plan.take(self.item_encoder.weight.detach(), rank).clone())
+        if self.item_encoder.weight.is_meta:
+            rows = _device_init_block(plan, rank, n_items, d, self.config['train']['seed'] or 2022,
+                                      self.config['train']['init_method'], device)
+            if rank == 0 and self.item_encoder.padding_idx is not None:
+                rows[self.item_encoder.padding_idx] = 0
+        else:
+            rows = plan.take(self.item_encoder.weight.detach(), rank).clone()
+        block = torch.nn.Embedding(plan.n_local(rank), d, padding_idx=0 if rank == 0 else None, _weight=rows)
         # An ITEM-TOWER query encoder (SASRec: seq/sasrec.py:14, :42, :107) embeds its input with the very table the
         # model scores against.  Every place the tower holds that module is re-pointed at the sharded table below
         # (shard.ShardedRows: ids out, rows back, gradients to the owners), so the embedding stays tied and no rank
@@ -705,6 +755,12 @@ class BaseRetriever(torch.nn.Module):
         row block (with its block of the optimizer state) and its replica of the tower, whose gradients are summed over
         the ranks first; ``train.fused_optimizer: 'sgd'`` applies plain SGD inside the exchange instead."""
         from . import shard
+        # train.shard_init: 'host' = every rank initialises the full table as a single process would and keeps its rows
+        # (bit-equal to the unsharded model's initial weights); 'device' = the rows are drawn on the owner's device, the
+        # full table never exists anywhere (_device_init_block); 'auto' (default): 'device' once the table exceeds 2 GiB
+        mode = self.config['train'].get('shard_init', 'auto')
+        self._item_table_on_meta = mode == 'device' or (mode == 'auto' and not self.item_encoder and
+                                                          train_data.num_items * self.embed_dim * 4 > (2 << 30))
         self._init_model(train_data)
         self._init_parameter()
         sh = self._setup_shard(train_data, dist, backend, device)

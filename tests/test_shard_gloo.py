@@ -1065,3 +1065,24 @@ def test_sharded_topk_with_histories_longer_than_the_select(tmp_path):
     world = 2
     mp.spawn(_wide_topk_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     assert all(os.path.exists(tmp_path / f'ok{r}') for r in range(world))
+
+
+def test_fit_with_device_initialised_blocks_is_world_invariant(tmp_path):
+    """``train.shard_init: 'device'`` (the default once the table exceeds 2 GiB): no rank ever holds the full item table -- its
+    rows are drawn on the owner's device from per-chunk generator streams -- and the run is still the one-rank run."""
+    extra = {'shard_init': 'device', '_trim': 2}
+    for world in (1, 2):
+        mp.spawn(_fit_worker, args=(world, _free_port(), str(tmp_path), 1, 2048, extra), nprocs=world, join=True)
+    one = torch.load(tmp_path / 'w1r0.pt', weights_only=False)
+    two = [torch.load(tmp_path / f'w2r{r}.pt', weights_only=False) for r in range(2)]
+    for t in two:
+        np.testing.assert_allclose(t['losses'].numpy(), one['losses'].numpy(), rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(t['tower'].numpy(), one['tower'].numpy(), rtol=1e-4, atol=1e-6)
+    items = torch.cat([two[0]['item'], two[1]['item']])
+    np.testing.assert_allclose(items.numpy(), one['item'].numpy(), rtol=1e-4, atol=1e-5)
+    assert not items[0].any() and float(items.std()) > 0
+    # ... and it is NOT the host-initialised table (another stream): the mode really was in force
+    os.makedirs(tmp_path / 'h')
+    mp.spawn(_fit_worker, args=(1, _free_port(), str(tmp_path / 'h'), 1, 2048, {'shard_init': 'host', '_trim': 2}), nprocs=1, join=True)
+    host = torch.load(tmp_path / 'h' / 'w1r0.pt', weights_only=False)
+    assert (host['item'] - one['item']).abs().max() > 1e-3
