@@ -897,6 +897,39 @@ def main():
                                          'what': 'side figure: the headline is the 1-slice time whatever these say'}
         except Exception as e:
             extra['pipelined_slices'] = {'error': repr(e)[:200]}
+        # the TRAINING step on the sharded table: in-place SGD, the stock BPR step evaluated on the owners of the negatives
+        # (shard.ShardedItemTable.bpr_step_on_owners: 8 bytes per triplet over xGMI, the item rows read once per step), with
+        # its own in-job world-1 reference (every rank alone on its block)
+        try:
+            w_keep = item_local.clone()
+            tower_t = torch.nn.Embedding(args.users, d).to(dev)
+            with torch.no_grad():
+                tower_t.weight.copy_(user)
+            res_t = {}
+            for tag, pl, rk, smp_t, pos_t, force in (('world1', shard.RowShardPlan(n_loc, 1), 0,
+                                                       (ra.PopularSamplerModel(plan.take(counts, rank), lookup=args.pop_lookup).to(dev)
+                                                        if popular else ra.UniformSampler(n_loc)), solo_pos, False),
+                                                      ('sharded', plan, rank, sampler, pos, True)):
+                tbl_t = shard.ShardedItemTable(item_local, pl, rk, dist, check_every=0, force_collectives=force)
+                trn_t = shard.ShardedRetriever(tbl_t, tower_t, smp_t, ra.BPRLoss(), n, item_sgd_lr=1e-3, query_sgd_lr=1e-3)
+                res_t[tag] = timed_max(lambda trn_t=trn_t, pos_t=pos_t: trn_t.training_step(uid, pos_t), max(10, args.steps // 4), 3)
+                tbl_t.check_overflow()
+                on_owners = tbl_t.owner_loss_ok()
+                del tbl_t, trn_t
+            item_local.copy_(w_keep)
+            del w_keep, tower_t
+            alg_t = (bytes_per_triplet(d, n, popular) + 2 * 4 * d + 2 * 4 * d / n) * B * n
+            extra['train_step'] = {'ms_per_step': round(res_t['sharded'], 4), 'M_triplets_s': round(world * B * n / res_t['sharded'] / 1e3, 2),
+                                   'frac_of_hbm_peak_per_gpu': round(alg_t / res_t['sharded'] / 1e6 / HBM_PEAK_GBS, 4),
+                                   'world1_reference_ms': round(res_t['world1'], 4),
+                                   'efficiency_vs_world1': round(res_t['world1'] / res_t['sharded'], 4),
+                                   'loss_on_owners': bool(on_owners),
+                                   'what': 'in-place SGD training step (BPR): sample + route, key all-to-all, positives scored by their '
+                                           'owners (4-byte-per-query all-reduce), ONE pass over the received rows (scores, loss, query-'
+                                           'gradient partials, solo rows updated in place), second small all-reduce, sorted apply for the '
+                                           'shared rows, reduce-scatter of the query gradients, user rows'}
+        except Exception as e:
+            extra['train_step'] = {'error': repr(e)[:300]}
         # the exact (variable-split, host read-back) exchange
         try:
             exact = shard.ShardedItemTable(item_local, plan, rank, dist, exchange='exact', check_every=0, force_collectives=True)

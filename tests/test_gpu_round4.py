@@ -389,7 +389,6 @@ def test_in_tree_radix_sort_through_the_sorted_scatter(ra, n_items, total_q, n):
 
 # --------------------------------------------------------------------------- fit on a big catalog: no [N, d] on the host
 def _big_catalog_worker(rank, world, port, result_dir, mode):
-    import resource
     import torch.distributed as dist
     import recstudio_amd as ra
     from staged_dist import StagedDist
@@ -409,11 +408,23 @@ def _big_catalog_worker(rank, world, port, result_dir, mode):
         trn, val, _ = ds.build(split_ratio=[0.98, 0.01, 0.01], shuffle=False)
         assert trn.num_items == n_items + 1
         torch.cuda.synchronize()
-        before = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss                       # KiB, peak so far
+        # the resident set while fit() runs, sampled every 2 ms (the process's all-time peak was set by the dataset build)
+        import threading
+        import psutil
+        proc, stop, seen = psutil.Process(), threading.Event(), [0]
+
+        def watch():
+            while not stop.is_set():
+                seen[0] = max(seen[0], proc.memory_info().rss)
+                stop.wait(0.002)
+        before = proc.memory_info().rss
+        th = threading.Thread(target=watch, daemon=True)
+        th.start()
         model.fit(trn, None, dist=StagedDist(dist), device='cuda:0')
-        peak = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss
+        stop.set()
+        th.join()
         w = model.item_encoder.weight.detach()
-        torch.save({'grew_MiB': (peak - before) / 1024, 'rows': w[:1000].cpu(), 'std': float(w.std()),
+        torch.save({'grew_MiB': (seen[0] - before) / 2 ** 20, 'rows': w[:1000].cpu(), 'std': float(w.std()),
                     'loss': float(model.logged_metrics['train_loss'])}, os.path.join(result_dir, f'{mode}_w{world}r{rank}.pt'))
     finally:
         dist.destroy_process_group()
