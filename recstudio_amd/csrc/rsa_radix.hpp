@@ -233,6 +233,84 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(const SRC src, int64
   }
 }
 
+
+// total <= RDX_TILE: ONE workgroup sorts the whole input in LDS, all passes in one launch (a 4096-element sort through
+// the three-kernels-per-pass form is nine launches of ~5 us each for microseconds of work: the user rows of a sharded
+// step).  The same ranking as radix_scatter_kernel; between passes the tile is re-read from the staging buffer in order.
+template <class SRC>
+__global__ __launch_bounds__(256) void radix_small_kernel(const SRC src, int total, int passes, uint64_t* __restrict__ out) {
+  __shared__ uint32_t cnt[4][RDX_BINS];
+  __shared__ uint32_t dbase[RDX_BINS];
+  __shared__ uint32_t s_wave[4];
+  __shared__ uint64_t stage[RDX_TILE];
+  const int lane = lane_id(), wave = threadIdx.x >> 6;
+  const int base = wave * RDX_WAVE_TILE;
+  uint64_t v[RDX_ITEMS];
+  uint32_t loc[RDX_ITEMS];
+#pragma unroll
+  for (int r = 0; r < RDX_ITEMS; ++r) {
+    const int i = base + r * 64 + lane;
+    v[r] = i < total ? src((int64_t)i) : ~0ull;
+  }
+  const uint64_t lt = (1ull << lane) - 1ull;
+  for (int p = 0; p < passes; ++p) {
+    const int shift = 32 + p * RDX_DIGIT_BITS;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) cnt[w][threadIdx.x] = 0;
+    __syncthreads();
+    volatile uint32_t* wc = cnt[wave];
+#pragma unroll
+    for (int r = 0; r < RDX_ITEMS; ++r) {
+      const bool valid = base + r * 64 + lane < total;
+      const uint32_t d = (uint32_t)(v[r] >> shift) & (RDX_BINS - 1);
+      uint64_t peers = __ballot(valid);
+#pragma unroll
+      for (int b = 0; b < RDX_DIGIT_BITS; ++b) {
+        const bool bit = (d >> b) & 1u;
+        const uint64_t bal = __ballot(bit);
+        peers &= bit ? bal : ~bal;
+      }
+      loc[r] = 0;
+      if (valid) {
+        const uint32_t c0 = wc[d];
+        const uint32_t rank = (uint32_t)__popcll(peers & lt);
+        loc[r] = c0 + rank;
+        if (rank == 0) wc[d] = c0 + (uint32_t)__popcll(peers);
+      }
+    }
+    __syncthreads();
+    {
+      const int d = threadIdx.x;
+      const uint32_t c0 = cnt[0][d], c1 = cnt[1][d], c2 = cnt[2][d], c3 = cnt[3][d];
+      cnt[0][d] = 0;
+      cnt[1][d] = c0;
+      cnt[2][d] = c0 + c1;
+      cnt[3][d] = c0 + c1 + c2;
+      dbase[d] = block_excl_scan_256(c0 + c1 + c2 + c3, s_wave, nullptr);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < RDX_ITEMS; ++r) {
+      if (base + r * 64 + lane < total) {
+        const uint32_t d = (uint32_t)(v[r] >> shift) & (RDX_BINS - 1);
+        stage[dbase[d] + cnt[wave][d] + loc[r]] = v[r];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < RDX_ITEMS; ++r) {        // the regrouped tile, in order: the next pass's input
+      const int i = base + r * 64 + lane;
+      v[r] = i < total ? stage[i] : ~0ull;
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int r = 0; r < RDX_ITEMS; ++r) {
+    const int i = base + r * 64 + lane;
+    if (i < total) out[i] = v[r];
+  }
+}
+
 // ---- host side
 inline unsigned radix_key_bits(int64_t n_keys) {      // bits needed for keys 0 .. n_keys - 1
   unsigned b = 1;
@@ -254,6 +332,11 @@ template <class SRC0>
 inline hipError_t radix_sort_pairs(const SRC0& src0, uint64_t* buf_a, uint64_t* buf_b, int64_t total, unsigned bits,
                                    void* temp, hipStream_t s) {
   if (total <= 0) return hipSuccess;
+  if (total <= RDX_TILE) {       // one workgroup, one launch; the result goes where the multi-pass form would leave it
+    hipLaunchKernelGGL((radix_small_kernel<SRC0>), dim3(1), dim3(256), 0, s, src0, (int)total, radix_passes(bits),
+                       radix_result(buf_a, buf_b, bits));
+    return hipGetLastError();
+  }
   const int64_t n_tiles = radix_tiles(total);
   uint32_t* counts = reinterpret_cast<uint32_t*>(temp);
   uint32_t* totals = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(temp) + (RDX_BINS * n_tiles * 4 + 255) / 256 * 256);
