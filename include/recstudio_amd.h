@@ -526,9 +526,17 @@ typedef struct rsa_shard_route_args {
   int32_t* counts_out;         /* nullable [n_slices * n_shards * n_banks]: exact element counts per segment -- calibration */
   int32_t skip_pos;            /* != 0: the positives are NOT routed (slot_of of column 0 = -1): the owner-side BPR step
                                   (rsa_shard_owner_bpr_forward) scores them from the gathered ids instead */
+  int32_t group_by_query;      /* != 0 (needs skip_pos, an in-kernel sampler and rsa_shard_route_query_groups(...) > 0): a workgroup's
+                                  share of a segment is written query by query -- every query's elements for an owner form ONE
+                                  contiguous run of the segment (rsa_shard_owner_bpr_args.keys_grouped: no sort by query there) */
 } rsa_shard_route_args;
 int64_t rsa_shard_segment_stride(int64_t capacity);    /* RSA_SHARD_HDR + capacity: 8-byte words per segment */
 int rsa_shard_sample_route(const rsa_shard_route_args* args, rsa_stream_t stream);
+/* Queries per workgroup if a call with these parameters can route query-grouped (num_neg a divisor of 1024 and >= 64, the
+ * random call's grid a multiple of 1024 threads, the rank's element base a multiple of num_neg; unroll = 4, or 2 for the
+ * 64-bit draws of catalogs beyond 2^28 items), else 0. */
+int32_t rsa_shard_route_query_groups(int32_t num_neg, uint32_t grid_threads, uint64_t elem_base, int32_t unroll,
+                                     int32_t n_shards);
 
 /* Owner side: scores[i] = <query[key_i >> 32], item_table[key_i & 0xffffffff]> for every live slot of the received
  * segments keys [n_segments][stride] (the fused gather+score kernel of rsa_fused_sample_gather_score reading the
@@ -653,6 +661,8 @@ typedef struct rsa_shard_owner_bpr_args {
   int64_t item_pad_row;
   void* workspace;
   int64_t workspace_bytes;
+  int32_t keys_grouped;        /* != 0: the segments were routed with group_by_query (every query's elements for this owner are
+                                  one contiguous run of one segment): the sort by query is skipped */
 } rsa_shard_owner_bpr_args;
 int rsa_shard_pos_score(const float* item_local, int64_t n_rows, int32_t dim, const float* q_all, int64_t n_query_rows,
                         const int64_t* pos_rows, float* out, rsa_stream_t stream);

@@ -67,7 +67,7 @@ class ShardRouteArgs(Structure):
         ('table', c_void_p), ('pop_prob', c_void_p), ('guide', c_void_p), ('table_prob', c_void_p), ('cdf_lut', c_void_p),
         ('cdf_lines', c_void_p), ('guide_log2', c_int32), ('lines_log2', c_int32),
         ('send_keys', c_void_p), ('slot_of', c_void_p), ('cursors', c_void_p), ('counts_out', c_void_p),
-        ('skip_pos', c_int32),
+        ('skip_pos', c_int32), ('group_by_query', c_int32),
     ]
 
 
@@ -99,7 +99,7 @@ class ShardOwnerBprArgs(Structure):
         ('pos_score', c_void_p), ('mean_den', c_int64), ('item_target', c_void_p), ('item_scale', c_void_p),
         ('step_dropped', c_void_p), ('overflow_sticky', c_void_p), ('scale_out', c_void_p), ('qgrad_all', c_void_p),
         ('d_slots', c_void_p), ('dsum_part', c_void_p), ('loss_part', c_void_p), ('reduce_scratch', c_void_p),
-        ('item_pad_row', c_int64), ('workspace', c_void_p), ('workspace_bytes', c_int64),
+        ('item_pad_row', c_int64), ('workspace', c_void_p), ('workspace_bytes', c_int64), ('keys_grouped', c_int32),
     ]
 
 
@@ -158,6 +158,7 @@ SIGNATURES = {
                                 c_void_p, c_void_p]),
     'rsa_shard_segment_stride': (c_int64, [c_int64]),
     'rsa_shard_sample_route': (c_int, [POINTER(ShardRouteArgs), c_void_p]),
+    'rsa_shard_route_query_groups': (c_int32, [c_int32, c_uint32, c_uint64, c_int32, c_int32]),
     'rsa_shard_score_segments': (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_void_p,
                                          c_void_p, c_void_p, c_void_p]),
     'rsa_shard_home': (c_int, [POINTER(ShardHomeArgs), c_void_p]),

@@ -42,7 +42,7 @@ struct OwnArgs {
   float* qgrad_all;            // [n_queries, D], accumulated into
   const int64_t* keys;         // received segments
   const float* d;              // d loss/d score per slot
-  const uint64_t* qpairs;      // (query, slot) sorted by query
+  const uint64_t* qpairs;      // (query, slot) sorted by query; null: the segments are query-grouped, a run is a run of slots
   const int32_t* run_start;    // [n_queries] first / one-past-last sorted position of each query's run (0, 0: none)
   const int32_t* run_end;
   const uint8_t* solo;         // [slots] or null
@@ -87,6 +87,27 @@ __global__ __launch_bounds__(256) void query_runs_kernel(const uint64_t* __restr
     if (k >= (uint32_t)n_queries) continue;
     const uint32_t before = i > 0 ? rdx_key(pairs[i - 1]) : 0xffffffffu;
     const uint32_t after = i + 1 < total ? rdx_key(pairs[i + 1]) : 0xffffffffu;
+    if (k != before) run_start[k] = (int32_t)i;
+    if (k != after) run_end[k] = (int32_t)(i + 1);
+  }
+}
+
+// The same from QUERY-GROUPED segments (rsa_shard_route_args.group_by_query): every query's elements for this owner are one
+// contiguous run of one segment already, so the runs are read off the slots in place -- no sort by query
+__global__ __launch_bounds__(256) void query_runs_segments_kernel(const int64_t* __restrict__ keys, int64_t slots, RdxDiv32 by_stride,
+                                                                  int32_t n_queries, int32_t* __restrict__ run_start,
+                                                                  int32_t* __restrict__ run_end) {
+  const int64_t step = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < slots; i += step) {
+    const uint32_t seg = by_stride.div((uint32_t)i), within = (uint32_t)i - seg * by_stride.d;
+    if (within < RSA_SHARD_HDR) continue;
+    const int64_t live = keys[(size_t)seg * by_stride.d];
+    const int64_t at = (int64_t)(within - RSA_SHARD_HDR);
+    if (at >= live) continue;
+    const uint32_t k = (uint32_t)((keys[i] >> 32) & 0x7fffffffll);
+    if (k >= (uint32_t)n_queries) continue;
+    const uint32_t before = at > 0 ? (uint32_t)((keys[i - 1] >> 32) & 0x7fffffffll) : 0xffffffffu;
+    const uint32_t after = at + 1 < live ? (uint32_t)((keys[i + 1] >> 32) & 0x7fffffffll) : 0xffffffffu;
     if (k != before) run_start[k] = (int32_t)i;
     if (k != after) run_end[k] = (int32_t)(i + 1);
   }
@@ -189,7 +210,7 @@ __global__ __launch_bounds__(256, RSA_OWN_MIN_WAVES) void owner_backward_walk_ke
         float dv = 0.f;
         uint32_t slot = 0;
         if (act) {
-          slot = rdx_val(a.qpairs[i]);
+          slot = a.qpairs ? rdx_val(a.qpairs[i]) : (uint32_t)i;      // (query-grouped segments: the runs are runs of slots)
           int64_t row = a.keys[slot] & 0xffffffffll;
           row = row >= a.n_rows ? a.n_rows - 1 : row;        // never fault on a bad key
           id = (int32_t)row;
@@ -368,6 +389,7 @@ struct OwnCommon {
   int64_t item_pad_row;
   void* workspace;
   int64_t workspace_bytes;
+  int keys_grouped;             // the router wrote query-grouped segments: no sort by query
 };
 
 struct OwnPrepared {
@@ -401,7 +423,7 @@ static int owner_prepare(const OwnCommon& c, OwnPrepared& P, bool sort_rows_only
   const unsigned row_bits = radix_key_bits(c.n_rows + 1);
   P.row_sorted = radix_result(P.L.pairs_a, P.L.pairs_b, row_bits);
   const unsigned q_bits = radix_key_bits(c.n_query_rows + 1);
-  P.q_sorted = radix_result(P.W.qa, P.W.qb, q_bits);
+  P.q_sorted = c.keys_grouped ? nullptr : radix_result(P.W.qa, P.W.qb, q_bits);
   if (sort_rows_only) return RSA_OK;       // (the second entry point of a two-call step: the layout only)
   hipLaunchKernelGGL(owner_scale_kernel, dim3(1), dim3(1), 0, s, c.item_scale, c.step_dropped, c.scale_out,
                      c.overflow_sticky ? c.keys : nullptr, c.n_segments, c.stride, c.overflow_sticky);
@@ -419,6 +441,19 @@ static int owner_prepare(const OwnCommon& c, OwnPrepared& P, bool sort_rows_only
     if (rc != RSA_OK) return rc;
   }
   if (P.slots == 0) return RSA_OK;
+  if (c.keys_grouped) {       // 2'. the router already grouped the segments by query: read the runs off the slots
+    if (hipMemsetAsync(P.W.run_start, 0, (size_t)(2 * align256o(c.n_query_rows * 4)), s) != hipSuccess) {
+      rsa::set_error("%s: memset failed", who);
+      return RSA_ERR_HIP;
+    }
+    int64_t gblocks = (P.slots + 255) / 256;
+    if (gblocks > 8192) gblocks = 8192;
+    hipLaunchKernelGGL(query_runs_segments_kernel, dim3((unsigned)gblocks), dim3(256), 0, s, c.keys, P.slots, by_stride,
+                       (int32_t)c.n_query_rows, P.W.run_start, P.W.run_end);
+    RSA_CHECK_LAUNCH(who);
+    P.q_sorted = nullptr;
+    return RSA_OK;
+  }
   // 2. slots by query, the queries' runs
   const SrcSegments<true> by_query{c.keys, nullptr, P.slots, by_stride, (uint32_t)c.n_query_rows};
   if (radix_sort_pairs(by_query, P.W.qa, P.W.qb, P.slots, q_bits, P.W.qtemp, s) != hipSuccess) {
@@ -468,7 +503,7 @@ extern "C" int rsa_shard_backward_segments(const rsa_shard_backward_args* a, rsa
   hipStream_t s = (hipStream_t)stream;
   const OwnCommon c{a->item_local, a->n_rows,       a->dim,        a->q_all,       a->n_query_rows, a->keys,
                     a->n_segments, a->stride,       nullptr,       a->item_target, a->item_scale,   const_cast<int32_t*>(a->step_dropped),
-                    nullptr,       a->scale_out,    a->item_pad_row, a->workspace, a->workspace_bytes};
+                    nullptr,       a->scale_out,    a->item_pad_row, a->workspace, a->workspace_bytes, 0};
   OwnPrepared P;
   int rc = owner_prepare(c, P, false, s, "rsa_shard_backward_segments");
   if (rc != RSA_OK || P.slots == 0) return rc;
@@ -515,7 +550,7 @@ extern "C" int rsa_shard_pos_score(const float* item_local, int64_t n_rows, int3
 static OwnCommon bpr_common(const rsa_shard_owner_bpr_args* a) {
   return OwnCommon{a->item_local, a->n_rows,  a->dim,      a->q_all,       a->n_query_rows, a->keys,
                    a->n_segments, a->stride,  a->pos_rows, a->item_target, a->item_scale,   a->step_dropped,
-                   a->overflow_sticky, a->scale_out, a->item_pad_row, a->workspace, a->workspace_bytes};
+                   a->overflow_sticky, a->scale_out, a->item_pad_row, a->workspace, a->workspace_bytes, a->keys_grouped};
 }
 
 extern "C" int rsa_shard_owner_bpr_forward(const rsa_shard_owner_bpr_args* a, rsa_stream_t stream) {

@@ -266,6 +266,7 @@ struct PopTables {
 constexpr int ROUTE_ITEMS = 4;                       // work items per thread
 constexpr int ROUTE_ITEMS_PER_BLOCK = 256 * ROUTE_ITEMS;
 constexpr int CURSOR_PAD = 32;                       // one 128-byte line per cursor: atomics on one line are served in turn
+constexpr int ROUTE_CNT = 1024;                      // LDS counters: owners x queries of a workgroup (grouped routing)
 
 struct RouteV2 {
   const int64_t* pos_ids;
@@ -284,19 +285,27 @@ struct RouteV2 {
   PopTables pop;
   Div32 by_width, by_rows, by_n, by_gt, by_range;
   int32_t n, G, sampler, n_slices, unroll, n_banks, skip_pos;
+  int32_t group_ql;        // > 0: a workgroup's elements are whole queries (group_ql of them): its share of a segment is written query by query
 };
 
 constexpr int TICKET_SUB = 32;      // two-level completion ticket: 32 sub-words, then one top word
 
 template <bool COUNT_ONLY>
 __global__ __launch_bounds__(256) void shard_sample_route_kernel(const RouteV2 a) {
-  __shared__ int32_t cnt[64], base[64];
+  // counters per (owner, query of this workgroup): cnt[g + G * q].  Without grouping q = 0 and cnt[g] is the owner's count.
+  __shared__ int32_t cnt[ROUTE_CNT], qbase[ROUTE_CNT], base[64];
   __shared__ int s_last;
   // contiguous ranges of workgroups: n_slices slices, each cut into n_banks banks
   const int micro = (int)(((int64_t)blockIdx.x * a.n_slices * a.n_banks) / gridDim.x);
   const int slice = micro / a.n_banks, bank = micro - slice * a.n_banks;
-  if (threadIdx.x < 64) cnt[threadIdx.x] = 0;
+  for (int t = threadIdx.x; t < ROUTE_CNT; t += 256) cnt[t] = 0;
   constexpr int EPT = ROUTE_ITEMS * 4;
+  // Query-grouped shares (the host checked: num_neg divides 1024, the grid's threads are a multiple of 1024, this rank's
+  // element base a multiple of num_neg): the 1024 consecutive subsequences of a workgroup are, per Philox component, 1024
+  // consecutive elements = 1024 / n WHOLE queries, and a wave's 64 consecutive elements belong to one of them.  An element's
+  // slot is then its owner's share base + the share's prefix over the workgroup's queries + its rank inside (owner, query):
+  // every query's elements for an owner form ONE contiguous run of the segment, and the owner needs no sort to find them.
+  const int qpc = a.group_ql > 0 ? a.group_ql / a.unroll : 0;      // queries per component
   int32_t gl[EPT];         // owner << 16 | slot inside this workgroup's range; -1: no element
   uint32_t local[EPT];     // row inside the owner's block
   int32_t el[EPT];         // element index in the [n_queries, 1 + n] matrix
@@ -374,15 +383,24 @@ __global__ __launch_bounds__(256) void shard_sample_route_kernel(const RouteV2 a
   }
   __syncthreads();
   // one pass of RETURNING LDS atomics: an element's slot inside this workgroup's share of its owner's segment
+  const int by_n_shift = a.group_ql > 0 ? 31 - __clz(a.n) : 0;     // (n is a power of two when grouped: it divides 1024)
 #pragma unroll
   for (int k = 0; k < EPT; ++k) {
     const bool valid = gl[k] >= 0;
-    const int32_t ls = wave_count<true>(cnt, valid, valid ? gl[k] >> 16 : 0, a.G == 1);
+    // (wave-uniform: a wave's 64 consecutive elements of one component lie inside one query)
+    const int ql = a.group_ql > 0 ? (k & 3) * qpc + (((k >> 2) * 256 + (int)threadIdx.x) >> by_n_shift) : 0;
+    const int32_t ls = wave_count<true>(cnt + a.G * ql, valid, valid ? gl[k] >> 16 : 0, a.G == 1);
     if (valid) gl[k] |= ls;
   }
   __syncthreads();
   if ((int)threadIdx.x < a.G) {
-    const int32_t c = cnt[threadIdx.x];
+    int32_t c = 0;
+    const int nq = a.group_ql > 0 ? a.group_ql : 1;
+    for (int q = 0; q < nq; ++q) {          // the share's prefix over the workgroup's queries
+      qbase[threadIdx.x + a.G * q] = c;
+      c += cnt[threadIdx.x + a.G * q];
+    }
+    cnt[threadIdx.x] = c;                   // (the header pass below reads the cursors, not this)
     base[threadIdx.x] = c ? atomicAdd(&a.cursors[((slice * a.G + threadIdx.x) * a.n_banks + bank) * CURSOR_PAD], c) : 0;
   }
   __syncthreads();      // the returning cursor atomics of this workgroup have been performed
@@ -392,7 +410,8 @@ __global__ __launch_bounds__(256) void shard_sample_route_kernel(const RouteV2 a
     for (int k = 0; k < EPT; ++k) {
       if (gl[k] < 0) continue;
       const int gk = gl[k] >> 16;
-      const int64_t slot = (int64_t)base[gk] + (gl[k] & 0xffff);
+      const int ql = a.group_ql > 0 ? (k & 3) * qpc + (((k >> 2) * 256 + (int)threadIdx.x) >> by_n_shift) : 0;
+      const int64_t slot = (int64_t)base[gk] + qbase[gk + a.G * ql] + (gl[k] & 0xffff);
       if (slot >= a.capacity) {        // no room: the element is dropped -- no key, no score, no gradient
         a.slot_of[el[k]] = -1;
         continue;
@@ -865,6 +884,16 @@ extern "C" int rsa_gather_f32(const float* src, const int64_t* positions, int64_
 // ------------------------------------------------------------------------------------------------ ABI v5 entry points
 extern "C" int64_t rsa_shard_segment_stride(int64_t capacity) { return capacity + RSA_SHARD_HDR; }
 
+// Queries per workgroup when the router can write query-grouped shares (0: it cannot): see the kernel.
+extern "C" int32_t rsa_shard_route_query_groups(int32_t num_neg, uint32_t grid_threads, uint64_t elem_base, int32_t unroll,
+                                                int32_t n_shards) {
+  if (num_neg < 64 || num_neg > 1024 || (1024 % num_neg) != 0 || (grid_threads % 1024u) != 0 || (elem_base % (uint64_t)num_neg) != 0)
+    return 0;
+  if (unroll != 2 && unroll != 4) return 0;
+  const int32_t ql = unroll * (1024 / num_neg);
+  return (int64_t)ql * n_shards <= ROUTE_CNT ? ql : 0;
+}
+
 extern "C" int rsa_shard_sample_route(const rsa_shard_route_args* a, rsa_stream_t stream) {
   RSA_CHECK_ARG(a != nullptr, "rsa_shard_sample_route: args is null");
   RSA_CHECK_ARG(a->n_queries >= 0 && a->num_neg >= 0 && a->rows_per_shard >= 0 && a->rows_per_shard < (1ll << 32),
@@ -958,6 +987,14 @@ extern "C" int rsa_shard_sample_route(const rsa_shard_route_args* a, rsa_stream_
     k_hi = ((r.pc.elem_base + (uint64_t)n_neg - 1) / T) / r.unroll;
   }
   r.k_lo = k_lo;
+  r.group_ql = 0;
+  if (a->group_by_query) {
+    RSA_CHECK_ARG(a->skip_pos && a->sampler != RSA_SAMPLER_GIVEN && n_neg > 0,
+                  "rsa_shard_sample_route: group_by_query needs skip_pos and an in-kernel sampler");
+    r.group_ql = rsa_shard_route_query_groups(a->num_neg, r.pc.grid_threads, r.pc.elem_base, r.unroll, a->n_shards);
+    RSA_CHECK_ARG(r.group_ql > 0, "rsa_shard_sample_route: this shape cannot be routed query-grouped "
+                                  "(rsa_shard_route_query_groups says so beforehand)");
+  }
   r.n_groups = n_neg > 0 ? (int64_t)((k_hi - k_lo + 1) * T) : 0;
   RSA_CHECK_ARG(r.n_groups + a->n_queries < (1ll << 32), "rsa_shard_sample_route: too many work items");
   r.by_width = make_div32((uint64_t)a->num_neg + 1);

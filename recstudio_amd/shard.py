@@ -160,7 +160,7 @@ class HipBackend:
     # -- version 2 of the fixed-capacity exchange (rsa_shard_sample_route / _score_segments / _home) -------------------
     @ops._on_device
     def sample_route(self, state, plan, rank, pos, n, chunks, capacity, spec, generator, neg=None, want_ids=False,
-                     want_logp=False, count_only=False, banks=1, route_pos=True):
+                     want_logp=False, count_only=False, banks=1, route_pos=True, group_by_query=False):
         """One launch: draw (or read) the negatives, route every (query, item) element of all ``chunks`` slices.
         -> dict(send [C*G*banks*stride] int64, slot_of [B*(1+n)] int32, stride, neg_ids / log_neg_prob / log_pos_prob when
         asked for), or the exact per-segment counts [C*G*banks] int32 with ``count_only`` (the generator is not
@@ -187,6 +187,12 @@ class HipBackend:
             if count_only:
                 generator.set_offset(off0)
             a.seed, a.offset, a.grid_threads, a.elem_base = pc.seed, pc.offset, pc.grid_threads, pc.elem_base
+            if group_by_query and not route_pos and not count_only:
+                # whole queries per routing workgroup (n divides 1024, aligned grid): every query's elements for an owner
+                # are then ONE contiguous run of a segment and the owner needs no sort by query
+                ql = int(nat.lib().rsa_shard_route_query_groups(int(n), int(pc.grid_threads), int(pc.elem_base), int(unroll), G))
+                a.group_by_query = 1 if ql > 0 else 0
+                out['grouped'] = ql > 0
             if kind == nat.SAMPLER_POPULAR:
                 t = spec['tables']
                 keep = [ops._need(t['table'], torch.float32, 'table'), ops._need(t['pop_prob'], torch.float32, 'pop_prob')]
@@ -319,7 +325,7 @@ class HipBackend:
 
     @ops._on_device
     def owner_bpr_forward(self, state, item_local, q_all, recv_keys, n_seg, stride, pos_rows, pos_score, n, mean_den,
-                          item_target, item_scale, qgrad_all, item_pad_row=-1):
+                          item_target, item_scale, qgrad_all, item_pad_row=-1, keys_grouped=False):
         """Scores, loss terms and gradients of the received negatives in ONE pass over their rows (see the header);
         -> ctx for ``owner_bpr_finish`` with ``dsum_part [Q]`` and ``loss_part`` (this rank's share of the mean loss)."""
         dev, Q = q_all.device, q_all.shape[0]
@@ -336,7 +342,7 @@ class HipBackend:
         a.item_target, a.item_scale = ptr(item_target), ptr(item_scale)
         a.step_dropped, a.overflow_sticky, a.scale_out = ptr(state['step_dropped']), ptr(state['overflow']), ptr(state['scale'])
         a.qgrad_all, a.d_slots, a.dsum_part, a.loss_part = ptr(qgrad_all), ptr(keep['d_slots']), ptr(keep['dsum_part']), ptr(keep['loss_part'])
-        a.reduce_scratch, a.item_pad_row = ptr(ops._scratch()), int(item_pad_row)
+        a.reduce_scratch, a.item_pad_row, a.keys_grouped = ptr(ops._scratch()), int(item_pad_row), int(bool(keys_grouped))
         nbytes = int(nat.lib().rsa_shard_backward_workspace_bytes(int(n_seg), int(stride), Q))
         keep['ws'] = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         a.workspace, a.workspace_bytes = ptr(keep['ws']), nbytes
@@ -478,6 +484,7 @@ class ShardedItemTable:
         self.item_local, self.plan, self.rank, self.dist = item_local, plan, int(rank), dist
         self.chunks = max(1, int(chunks))
         self.owner_loss = bool(owner_loss)      # stock BPR training steps are evaluated on the owners (bpr_step_on_owners)
+        self.group_by_query = True              # ... with query-grouped routing where the shape allows (no sort by query there)
         self._solo = plan.world == 1 and not force_collectives
         self.backend = backend if backend is not None else HipBackend()
         self.group = group
@@ -730,7 +737,7 @@ class ShardedItemTable:
                                      banks=S, route_pos=False)
             cap = self._capacity(key[:3], int(counts.max()), store=key)
         r = be.sample_route(st, plan, self.rank, pos, n, 1, cap, spec, self.sample_generator, neg=neg, want_ids=want_ids,
-                            want_logp=False, banks=S, route_pos=False)
+                            want_logp=False, banks=S, route_pos=False, group_by_query=self.group_by_query)
         GS, stride = G * S, r['stride']
         recv = self._all_to_all(r['send'])
         q_all = q_gather()
@@ -739,7 +746,8 @@ class ShardedItemTable:
         pos_score = self._all_reduce_sum(be.pos_scores(self.item_local, q_all, pos_rows))
         qgrad_all = torch.zeros_like(q_all)
         ctx = be.owner_bpr_forward(st, self.item_local, q_all, recv, GS, stride, pos_rows, pos_score, n, B * G, item_grad_local,
-                                   item_scale, qgrad_all, item_pad_row=0 if self.rank == 0 else -1)
+                                   item_scale, qgrad_all, item_pad_row=0 if self.rank == 0 else -1,
+                                   keys_grouped=bool(r.get('grouped', False)))
         dsum_all = self._all_reduce_sum(ctx['dsum_part'] if self._solo else ctx['dsum_part'].clone())
         be.owner_bpr_finish(ctx, dsum_all)
         dq = self._reduce_scatter_rows(qgrad_all, B)

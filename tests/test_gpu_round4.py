@@ -455,3 +455,52 @@ def test_fit_on_a_big_catalog_never_holds_the_table_on_the_host(tmp_path):
     assert np.isfinite(dev1['loss']) and np.isfinite(dev2['loss']) and abs(dev1['loss'] - dev2['loss']) < 1e-3
     # (learning rate 0) two ranks drew the rows of the table one rank draws, bit for bit
     assert torch.equal(dev1['rows'], dev2['rows']) and not dev1['rows'][0].any() and float(dev1['rows'][1:].abs().min()) >= 0
+
+
+@pytest.mark.parametrize('n,B,layout', [(64, 512, 'block'), (256, 96, 'block'), (1024, 40, 'interleaved'), (128, 320, 'block'),
+                                        (128, 300, 'block')])
+def test_query_grouped_routing_needs_no_sort_by_query(ra, n, B, layout):
+    """`rsa_shard_route_args.group_by_query`: when n divides 1024 a routing workgroup holds whole queries and writes its
+    share of every segment query by query, so the owner reads the queries' runs off the slots (`keys_grouped`) instead of
+    sorting them -- the training step (loss share, in-place-updated block, user rows, drawn ids) equals the sorted form's,
+    popularity and uniform sampler.  (128, 300): the draw's grid is not a multiple of 1024 threads -- the router says so
+    (`rsa_shard_route_query_groups` = 0) and the step falls back to the sort."""
+    import torch.distributed as dist
+    from recstudio_amd.shard import RowShardPlan, ShardedItemTable, ShardedRetriever
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(_free_port())
+    dist.init_process_group('gloo', rank=0, world_size=1)
+    try:
+        N, U, d = 30_011, 500, 128
+        g = torch.Generator().manual_seed(n + B)
+        item0 = (torch.randn(N, d, generator=g) * 0.2)
+        item0[0] = 0
+        user0 = torch.randn(U, d, generator=g) * 0.2
+        uid = torch.randint(1, U, (B,), generator=g).to(DEV)
+        pos = torch.randint(1, N, (B,), generator=g).to(DEV)
+        counts = (torch.rand(N, generator=g) ** 3 * 50).long()
+        for sampler in (ra.UniformSampler(N), ra.PopularSamplerModel(counts).to(DEV)):
+            res = {}
+            for grouped in (True, False):
+                item = item0.to(DEV).clone()
+                tower = torch.nn.Embedding(U, d).to(DEV)
+                with torch.no_grad():
+                    tower.weight.copy_(user0)
+                table = ShardedItemTable(item, RowShardPlan(N, 1, layout=layout), 0, dist, check_every=0, sample_seed=5)
+                table.group_by_query = grouped
+                seen = []
+                fwd = table.backend.owner_bpr_forward
+                table.backend.owner_bpr_forward = lambda *a, **k: (seen.append(k.get('keys_grouped')), fwd(*a, **k))[1]
+                trainer = ShardedRetriever(table, tower, sampler, ra.BPRLoss(), n, item_sgd_lr=0.3, query_sgd_lr=0.3, keep_neg_ids=True)
+                losses = [float(trainer.training_step(uid, pos)) for _ in range(2)]
+                can_group = (B * n) % 1024 == 0
+                assert seen == [grouped and can_group] * 2
+                res[grouped] = (losses, item.clone(), tower.weight.detach().clone(), trainer.last_neg.clone())
+            a, b = res[True], res[False]
+            assert torch.equal(a[3], b[3])                                  # the same draw
+            rel_close(a[0], b[0], rtol=1e-6)
+            rel_close(a[1].cpu(), b[1].cpu(), rtol=1e-5, atol=1e-7)
+            rel_close(a[2].cpu(), b[2].cpu(), rtol=1e-5, atol=1e-7)
+            assert (a[1].cpu() - item0).abs().max() > 1e-4                  # the step really trained
+    finally:
+        dist.destroy_process_group()

@@ -64,7 +64,7 @@ class CheckerBackend:
         return None
 
     def sample_route(self, state, plan, rank, pos, n, chunks, capacity, spec, generator, neg=None, want_ids=False,
-                     want_logp=False, count_only=False, banks=1, route_pos=True):
+                     want_logp=False, count_only=False, banks=1, route_pos=True, group_by_query=False):
         assert banks == 1                                      # (the checker has no BANKS attribute: one segment per owner)
         B, G, C = pos.numel(), plan.world, chunks
         out = {}
@@ -185,7 +185,7 @@ class CheckerBackend:
         return torch.where(own, (item_local[pos_rows.clamp(min=0)] * q_all).sum(-1), torch.zeros(()))
 
     def owner_bpr_forward(self, state, item_local, q_all, recv_keys, n_seg, stride, pos_rows, pos_score, n, mean_den,
-                          item_target, item_scale, qgrad_all, item_pad_row=-1):
+                          item_target, item_scale, qgrad_all, item_pad_row=-1, keys_grouped=False):
         total = int(recv_keys.view(n_seg, stride)[:, 1].sum())
         state['step_dropped'][0] = total
         state['overflow'] += total
