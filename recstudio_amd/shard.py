@@ -878,6 +878,10 @@ class ShardedItemTable:
         be, plan, d = self.backend, self.plan, self.item_local.shape[1]
         flat = ids.reshape(-1)
         M, G = flat.numel(), plan.world
+        if self._solo:
+            # one rank owns every row (row 0 is the zero padding row): a plain gather, no exchange, no host round trip
+            out = be.gather_rows(self.item_local, flat.contiguous()).view(*ids.shape, d)
+            return (out, {'local': flat}) if keep_route else out
         sel = torch.nonzero(flat).view(-1)                         # positions that hold a real item
         vid = flat[sel]
         owner = plan.owner(vid)
@@ -904,6 +908,9 @@ class ShardedItemTable:
         block of the dense table gradient, or the weight block itself with ``scale = -lr`` -- by the sorted,
         atomics-free row scatter."""
         be, d = self.backend, self.item_local.shape[1]
+        if 'local' in route:
+            be.apply_rows(item_grad_local, route['local'], grad.reshape(-1, d).contiguous(), scale, pad_row=0)
+            return
         g_send = be.gather_rows(grad.reshape(-1, d).contiguous(), route['src'])
         g_owner = self._all_to_all(g_send, route['recv_counts'], route['send_counts'])
         be.apply_rows(item_grad_local, route['recv_local'], g_owner, scale, pad_row=0 if self.rank == 0 else -1)
