@@ -504,3 +504,59 @@ def test_query_grouped_routing_needs_no_sort_by_query(ra, n, B, layout):
             assert (a[1].cpu() - item0).abs().max() > 1e-4                  # the step really trained
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('d,n,B,layout,popular', [(64, 64, 300, 'block', False), (128, 256, 64, 'interleaved', True), (256, 128, 96, 'block', False),
+                                                  (128, 1024, 24, 'block', True), (128, 100, 77, 'block', False), (64, 512, 40, 'interleaved', False)])
+def test_bpr_step_on_owners_vs_autograd(ra, d, n, B, layout, popular):
+    """The BPR training step evaluated on the owner (world size 1; every tile width 16 / 32 / 64 lanes per row, 1 / 2 / 4
+    waves per query run, grouped routing and the sort fallback (n = 100), both samplers, both row layouts): loss, the dense
+    item-gradient block and the user-row gradient == torch autograd of loss_func.py:55-59 on the same negatives; then the
+    same step with SGD in place == weights minus rate times that gradient."""
+    import torch.distributed as dist
+    from recstudio_amd.shard import RowShardPlan, ShardedItemTable, ShardedRetriever
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(_free_port())
+    dist.init_process_group('gloo', rank=0, world_size=1)
+    try:
+        N, U = 20_011, 300
+        g = torch.Generator().manual_seed(d + n)
+        item0 = torch.randn(N, d, generator=g) * 0.2
+        item0[0] = 0
+        user0 = torch.randn(U, d, generator=g) * 0.2
+        uid = torch.randint(1, U, (B,), generator=g).to(DEV)
+        pos = torch.randint(1, N, (B,), generator=g).to(DEV)
+        counts = (torch.rand(N, generator=g) ** 3 * 50).long()
+        sampler = ra.PopularSamplerModel(counts).to(DEV) if popular else ra.UniformSampler(N)
+
+        def make(**kw):
+            item = item0.to(DEV).clone()
+            tower = torch.nn.Embedding(U, d).to(DEV)
+            with torch.no_grad():
+                tower.weight.copy_(user0)
+            table = ShardedItemTable(item, RowShardPlan(N, 1, layout=layout), 0, dist, check_every=0, sample_seed=9)
+            return item, tower, ShardedRetriever(table, tower, sampler, ra.BPRLoss(), n, sparse_query_rows=True, keep_neg_ids=True, **kw)
+        item, tower, tr = make()
+        assert tr.table.owner_loss_ok()
+        loss = tr.training_step(uid, pos)
+        neg = tr.last_neg
+        iw = item0.to(DEV).clone().requires_grad_(True)
+        uw = user0.to(DEV).clone().requires_grad_(True)
+        q = uw[uid]
+        ref = -torch.nn.functional.logsigmoid((q * iw[pos]).sum(-1, keepdim=True) - (q.unsqueeze(1) * iw[neg]).sum(-1)).mean(-1).mean()
+        ref.backward()
+        rel_close(loss.item(), ref.item(), rtol=1e-5)
+        want = iw.grad.clone()
+        want[0] = 0
+        rel_close(tr.item_grad_local.cpu(), want.cpu(), rtol=2e-4, atol=1e-7)
+        rel_close(tr.query_grad_dense().cpu(), uw.grad.cpu(), rtol=2e-4, atol=1e-7)
+        assert torch.equal(item.cpu(), item0)                              # the gradient-block form only reads the table
+        item2, tower2, tr2 = make(item_sgd_lr=0.5, query_sgd_lr=0.5)
+        loss2 = tr2.training_step(uid, pos)
+        # (same draw; the loss to rounding: the order of a query's elements inside its run follows the router's LDS atomics)
+        assert torch.equal(tr2.last_neg, neg)
+        rel_close(loss2.item(), loss.item(), rtol=1e-6)
+        rel_close(item2.cpu(), (item0.to(DEV) - 0.5 * want).cpu(), rtol=2e-4, atol=1e-7)
+        rel_close(tower2.weight.detach().cpu(), (user0.to(DEV) - 0.5 * uw.grad).cpu(), rtol=2e-4, atol=1e-7)
+    finally:
+        dist.destroy_process_group()
