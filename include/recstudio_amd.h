@@ -319,7 +319,7 @@ int rsa_fused_backward(const rsa_backward_args* args, rsa_stream_t stream);
  *     target[id] += upstream * sum_{e : id_e = id} d_e * query[qrow_e]      (rows id != pad_row)
  * over the elements of the step (with pos_ids: the positive of query m first, then its num_neg negatives; without: the
  * negatives only; d = dpos / dneg).
- * The (id, element) pairs are radix-sorted (rocPRIM, stable) and every run of equal ids is summed by one wave in
+ * The (id, element) pairs are radix-sorted (the in-tree stable LSD sort, csrc/rsa_radix.hpp) and every run of equal ids is summed by one wave in
  * element order, then the row is read-modified-written once.  `target` [n_items, dim] is a zeroed dense gradient
  * (== the reference's weight.grad, recommender.py:636-639) or the weight table itself with upstream = -lr (plain
  * SGD in place).  dim in {64, 128, 256}; pos_ids / dpos nullable; query_index nullable (query row m);
