@@ -6,9 +6,11 @@
 This is what replaces recstudio/utils/data_parallel.py (which re-broadcasts every parameter of the model to every
 device on every step, :106-159) and the dead DDP branch (recommender.py:731-740): rank r owns rows
 [r*rows_per_shard, ...) of the item table (and of its optimizer state), a data-parallel slice of the batch and a
-replica of the user tower.  Per step (`shard.ShardedRetriever.training_step`): sample -> route -> RCCL all-to-all
-of 8-byte keys -> owner-side gather+score -> all-to-all of scores -> loss -> the same exchange backwards; the
-item-gradient block never leaves its owner; the replicated user table's row-sparse gradient is all-gathered as
+replica of the user tower.  Per step (`shard.ShardedRetriever.training_step`, BPR evaluated on the owners of the
+negatives): sample -> route -> RCCL all-to-all of 8-byte keys; the positives scored by their owners (4-byte-per-query
+all-reduce); ONE pass over the received rows (scores, loss, query-gradient partials, rows updated in place); a second
+small all-reduce; sorted apply of the shared rows; reduce-scatter of the query gradients.  No score crosses the fabric,
+the item rows never leave their owner; the replicated user table's row-sparse gradient is all-gathered as
 (ids, rows) and applied in place on every replica (an MLP tower's dense gradients would be summed with one bucketed
 all-reduce).  Synthetic interactions (there is no dataset download in scope); the loop is plain SGD.
 """
