@@ -620,7 +620,8 @@ int rsa_shard_backward_segments(const rsa_shard_backward_args* args, rsa_stream_
  * ON THE OWNERS of the negatives -- the item rows of a step are then read once instead of twice (scoring pass + backward
  * pass), and neither scores nor score gradients cross the fabric:
  *   rsa_shard_pos_score          out[i] = q_all[i] . item_local[pos_rows[i]] for the positives this rank owns (pos_rows[i]
- *                                >= 0: the local row; < 0: another rank's), 0 for the others -- summed over the ranks
+ *                                >= 0: the local row; < 0: another rank's; derived from the gathered global ids in the same
+ *                                launch when pos_ids is given), 0 for the others -- summed over the ranks
  *                                (a 4-byte-per-query all-reduce) it is every positive's score on every rank;
  *   rsa_shard_owner_bpr_forward  over the negatives this rank received (the positives are NOT routed in this protocol):
  *                                score, loss term -logsigmoid(pos - neg) / num_neg, d = sigmoid(neg - pos) / (num_neg *
@@ -665,7 +666,10 @@ typedef struct rsa_shard_owner_bpr_args {
                                   one contiguous run of one segment): the sort by query is skipped */
 } rsa_shard_owner_bpr_args;
 int rsa_shard_pos_score(const float* item_local, int64_t n_rows, int32_t dim, const float* q_all, int64_t n_query_rows,
-                        const int64_t* pos_rows, float* out, rsa_stream_t stream);
+                        int64_t* pos_rows, float* out, const int64_t* pos_ids, int64_t rows_per_shard, int32_t n_shards,
+                        int32_t rank, rsa_stream_t stream);   /* pos_ids != NULL: GLOBAL ids in, pos_rows is written (the owner /
+                                                                  local-row rule of rsa_shard_sample_route: rows_per_shard == 0 =
+                                                                  interleaved rows); NULL: pos_rows is the input */
 int rsa_shard_owner_bpr_forward(const rsa_shard_owner_bpr_args* args, rsa_stream_t stream);
 int rsa_shard_owner_bpr_finish(const rsa_shard_owner_bpr_args* args, const float* dsum_all, rsa_stream_t stream);
 

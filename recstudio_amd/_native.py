@@ -167,7 +167,8 @@ SIGNATURES = {
                                           c_void_p]),
     'rsa_shard_backward_workspace_bytes': (c_int64, [c_int64, c_int64, c_int64]),
     'rsa_shard_backward_segments': (c_int, [POINTER(ShardBackwardArgs), c_void_p]),
-    'rsa_shard_pos_score': (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
+    'rsa_shard_pos_score': (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int32,
+                                    c_int32, c_void_p]),
     'rsa_shard_owner_bpr_forward': (c_int, [POINTER(ShardOwnerBprArgs), c_void_p]),
     'rsa_shard_owner_bpr_finish': (c_int, [POINTER(ShardOwnerBprArgs), c_void_p, c_void_p]),
     'rsa_shard_unpack': (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),

@@ -302,14 +302,35 @@ __global__ __launch_bounds__(256) void owner_pos_finish_kernel(const float* item
 
 // out[i] = q_all[i] . item[pos_rows[i]] for the positives this rank owns, 0 for the others (summed over the ranks: the
 // score of every positive everywhere)
+// pos_ids != nullptr: pos_rows is an OUTPUT -- the local row of every positive this rank owns (contiguous row blocks of
+// rows_per_shard rows, or rows_per_shard == 0: rows interleaved, owner = id % n_shards), -1 for the others
 template <int LPR>
 __global__ __launch_bounds__(256) void shard_pos_score_kernel(const float* __restrict__ item, const float* __restrict__ q_all,
-                                                              const int64_t* __restrict__ pos_rows, int64_t n_rows,
-                                                              int32_t n_queries, float* __restrict__ out) {
+                                                              int64_t* __restrict__ pos_rows, int64_t n_rows,
+                                                              int32_t n_queries, float* __restrict__ out,
+                                                              const int64_t* __restrict__ pos_ids, int64_t rows_per_shard,
+                                                              int32_t n_shards, int32_t rank) {
   constexpr int D = LPR * 4, GPB = 256 / LPR;
   const int sub = threadIdx.x % LPR;
   for (int64_t i = (int64_t)blockIdx.x * GPB + threadIdx.x / LPR; i < n_queries; i += (int64_t)gridDim.x * GPB) {
-    int64_t row = pos_rows[i];
+    int64_t row;
+    if (pos_ids != nullptr) {
+      int64_t id = pos_ids[i];
+      id = id < 0 ? 0 : id;
+      int64_t g, loc;
+      if (rows_per_shard == 0) {
+        g = id % n_shards;
+        loc = id / n_shards;
+      } else {
+        g = id / rows_per_shard;
+        g = g >= n_shards ? n_shards - 1 : g;
+        loc = id - g * rows_per_shard;
+      }
+      row = g == rank ? loc : -1;
+      if (sub == 0) pos_rows[i] = row;
+    } else {
+      row = pos_rows[i];
+    }
     const bool own = row >= 0;
     row = row < 0 ? 0 : (row >= n_rows ? n_rows - 1 : row);
     const float4 xv = *reinterpret_cast<const float4*>(item + (size_t)row * D + sub * 4);
@@ -523,8 +544,11 @@ extern "C" int rsa_shard_backward_segments(const rsa_shard_backward_args* a, rsa
 }
 
 extern "C" int rsa_shard_pos_score(const float* item_local, int64_t n_rows, int32_t dim, const float* q_all,
-                                   int64_t n_query_rows, const int64_t* pos_rows, float* out, rsa_stream_t stream) {
+                                   int64_t n_query_rows, int64_t* pos_rows, float* out, const int64_t* pos_ids,
+                                   int64_t rows_per_shard, int32_t n_shards, int32_t rank, rsa_stream_t stream) {
   RSA_CHECK_ARG(n_query_rows >= 0 && n_rows >= 1, "rsa_shard_pos_score: bad sizes");
+  RSA_CHECK_ARG(pos_ids == nullptr || (rows_per_shard >= 0 && n_shards >= 1 && rank >= 0 && rank < n_shards),
+                "rsa_shard_pos_score: bad shard geometry");
   if (n_query_rows == 0) return RSA_OK;
   RSA_CHECK_ARG(item_local && q_all && pos_rows && out, "rsa_shard_pos_score: null pointer");
   hipStream_t s = (hipStream_t)stream;
@@ -533,7 +557,7 @@ extern "C" int rsa_shard_pos_score(const float* item_local, int64_t n_rows, int3
   blocks = (n_query_rows + 256 / LPR - 1) / (256 / LPR);                                                          \
   if (blocks > 4096) blocks = 4096;                                                                               \
   hipLaunchKernelGGL(shard_pos_score_kernel<LPR>, dim3((unsigned)blocks), dim3(256), 0, s, item_local, q_all, pos_rows, \
-                     n_rows, (int32_t)n_query_rows, out)
+                     n_rows, (int32_t)n_query_rows, out, pos_ids, rows_per_shard, n_shards, rank)
   switch (dim) {
     case 64: RSA_POS_LAUNCH(16); break;
     case 128: RSA_POS_LAUNCH(32); break;

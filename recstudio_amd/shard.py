@@ -319,9 +319,21 @@ class HipBackend:
         """[Q] scores of the positives this rank owns (pos_rows >= 0), 0 for the others."""
         out = torch.empty(pos_rows.numel(), dtype=torch.float32, device=q_all.device)
         nat.check(nat.lib().rsa_shard_pos_score(ptr(item_local), item_local.shape[0], item_local.shape[1], ptr(q_all), q_all.shape[0],
-                                                ptr(ops._need(pos_rows, torch.int64, 'pos_rows')), ptr(out), ops._stream()),
-                  'rsa_shard_pos_score')
+                                                ptr(ops._need(pos_rows, torch.int64, 'pos_rows')), ptr(out), None, 0, 1, 0,
+                                                ops._stream()), 'rsa_shard_pos_score')
         return out
+
+    @ops._on_device
+    def pos_rows_and_scores(self, item_local, q_all, pos_all, plan, rank):
+        """The same from the gathered GLOBAL ids, in one launch: (pos_rows [Q] -- local row of every positive this rank
+        owns, -1 for the others --, scores [Q])."""
+        Q = pos_all.numel()
+        rows = torch.empty(Q, dtype=torch.int64, device=q_all.device)
+        out = torch.empty(Q, dtype=torch.float32, device=q_all.device)
+        nat.check(nat.lib().rsa_shard_pos_score(ptr(item_local), item_local.shape[0], item_local.shape[1], ptr(q_all), q_all.shape[0],
+                                                ptr(rows), ptr(out), ptr(ops._need(pos_all, torch.int64, 'pos_all')), plan.rows_arg,
+                                                plan.world, int(rank), ops._stream()), 'rsa_shard_pos_score')
+        return rows, out
 
     @ops._on_device
     def owner_bpr_forward(self, state, item_local, q_all, recv_keys, n_seg, stride, pos_rows, pos_score, n, mean_den,
@@ -741,9 +753,13 @@ class ShardedItemTable:
         GS, stride = G * S, r['stride']
         recv = self._all_to_all(r['send'])
         q_all = q_gather()
-        mine = plan.owner(pos_all) == self.rank
-        pos_rows = torch.where(mine, plan.local(pos_all), torch.full_like(pos_all, -1))
-        pos_score = self._all_reduce_sum(be.pos_scores(self.item_local, q_all, pos_rows))
+        if hasattr(be, 'pos_rows_and_scores'):
+            pos_rows, pos_part = be.pos_rows_and_scores(self.item_local, q_all, pos_all, plan, self.rank)
+        else:
+            mine = plan.owner(pos_all) == self.rank
+            pos_rows = torch.where(mine, plan.local(pos_all), torch.full_like(pos_all, -1))
+            pos_part = be.pos_scores(self.item_local, q_all, pos_rows)
+        pos_score = self._all_reduce_sum(pos_part)
         qgrad_all = torch.zeros_like(q_all)
         ctx = be.owner_bpr_forward(st, self.item_local, q_all, recv, GS, stride, pos_rows, pos_score, n, B * G, item_grad_local,
                                    item_scale, qgrad_all, item_pad_row=0 if self.rank == 0 else -1,
