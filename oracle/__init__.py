@@ -17,7 +17,7 @@ pinned by the Random123 known-answer vectors on CPU and by ``torch.randint`` /
 """
 from .philox import (philox4x32_10, rng_grid_threads, rng_counter_offset,
                      device_randint, device_rand)
-from .path import (UniformSampler, PopularSamplerModel, popular_tables,
+from .path import (UniformSampler, PopularSamplerModel, popular_tables, sasrec_query,
                    searchsorted_left, masked_uniform_from_u, inner_product_score, cosine_score, euclidean_score,
                    norm_score, gmf_score,
                    bpr_loss, sampled_softmax_loss, softmax_loss, bce_loss, weighted_bpr_loss, weighted_bce_loss,

@@ -393,3 +393,25 @@ def seq_gather(item_w, flat_item_ids, start, end, max_len):
         n = int(lens[b])
         ids[b, :n] = flat_item_ids[int(start[b]):int(end[b])]
     return ids, item_w[ids], torch.from_numpy(lens)
+
+
+# --------------------------------------------------------------------------- SASRec query tower
+def sasrec_query(state, hist, seqlen, n_head, hidden_size, n_layer, activation='gelu', layer_norm_eps=1e-12):
+    """recstudio/model/seq/sasrec.py:37-67 (unidirectional, 'last' pooling, dropout 0): item rows of the right-padded
+    history + learned positions -> causal nn.TransformerEncoder with the padding mask -> the output at position seqlen - 1.
+    ``state``: the reference module's state dict (item_encoder.weight, position_emb.weight, transformer_layer.*) as
+    tensors.  Stock torch modules on the CPU, as the reference runs them."""
+    item_w, pos_w = state['item_encoder.weight'], state['position_emb.weight']
+    d = item_w.shape[1]
+    layer = torch.nn.TransformerEncoderLayer(d_model=d, nhead=n_head, dim_feedforward=hidden_size, dropout=0.0,
+                                             activation=activation, layer_norm_eps=layer_norm_eps, batch_first=True,
+                                             norm_first=False)                                            # :19-28
+    enc = torch.nn.TransformerEncoder(layer, num_layers=n_layer)                                         # :29-32
+    enc.load_state_dict({k[len('transformer_layer.'):]: v for k, v in state.items() if k.startswith('transformer_layer.')})
+    enc.train()                     # (the training-mode code path of nn.TransformerEncoder; dropout is 0)
+    L = hist.shape[1]
+    seq = item_w[hist] + pos_w[torch.arange(L)].unsqueeze(0)                                              # :38-42
+    causal = torch.triu(torch.ones(L, L, dtype=torch.bool), 1)                                           # :46-47
+    out = enc(seq, mask=causal, src_key_padding_mask=hist == 0)                                          # :50-53
+    last = (seqlen - 1).view(-1, 1, 1).expand(-1, 1, d)
+    return out.gather(1, last).squeeze(1)                                                                # :55-60 ('last' pooling)

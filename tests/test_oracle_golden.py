@@ -217,3 +217,22 @@ def test_seq_gather_restatement():
     ids, rows, lens = oracle.seq_gather(iw, flat, [0, 2, 7], [2, 7, 8], 6)
     assert ids.tolist() == [[3, 4, 0, 0, 0, 0], [5, 6, 7, 8, 9, 0], [1, 0, 0, 0, 0, 0]]
     assert torch.equal(rows[1, 4], iw[9]) and not rows[0, 2:].any() and lens.tolist() == [2, 5, 1]
+
+
+def test_sasrec_tower(golden):
+    """oracle.sasrec_query (sasrec.py:37-67 restated with stock torch modules) against the recorded run of the reference's
+    own SASRecQueryEncoder (tests/golden/sasrec.npz): tower output, scores and both losses."""
+    g = golden('sasrec')
+    state = {k[3:]: T(g[k]) for k in g.files if k.startswith('w::')}
+    hist, seqlen = T(g['hist']), T(g['seqlen'])
+    with torch.no_grad():
+        q = oracle.sasrec_query(state, hist, seqlen, int(g['heads']), int(g['hidden']), int(g['layers']))
+    np.testing.assert_allclose(q.numpy(), g['ssm_query'], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(q.numpy(), g['bce_query'], rtol=1e-5, atol=1e-6)
+    item_w = state['item_encoder.weight']
+    pos, neg = T(g['pos']), T(g['neg'])
+    ps, ns = oracle.retriever_forward(item_w, q, pos, neg)
+    np.testing.assert_allclose(ns.numpy(), g['ssm_neg_score'], rtol=1e-5, atol=1e-6)
+    ssm = oracle.sampled_softmax_loss(ps, T(g['log_pos']), ns, T(g['log_neg']))
+    np.testing.assert_allclose(ssm.item(), float(g['ssm_loss']), rtol=1e-6)
+    np.testing.assert_allclose(oracle.bce_loss(ps, ns).item(), float(g['bce_loss']), rtol=1e-6)
