@@ -30,7 +30,8 @@
 extern "C" {
 #endif
 
-#define RSA_ABI_VERSION 7   /* 7: rsa_shard_pos_score / rsa_shard_owner_bpr_forward / _finish (the BPR step evaluated on the owners: rows read
+#define RSA_ABI_VERSION 8   /* 8: rsa_shard_owner_bpr_args.finish_parts (the finish call in two parts, for a caller with two streams);
+                               7: rsa_shard_pos_score / rsa_shard_owner_bpr_forward / _finish (the BPR step evaluated on the owners: rows read
                                once per step); rsa_shard_sample_route: route_pos; rsa_shard_backward_segments (the owner side of the sharded backward in one call: in-tree radix sorts
                                straight from the received segments, one walk over the query runs that reads every item row once and
                                updates solo rows in place, sorted apply for the shared rows); the sorted scatters no longer call rocPRIM;
@@ -664,6 +665,10 @@ typedef struct rsa_shard_owner_bpr_args {
   int64_t workspace_bytes;
   int32_t keys_grouped;        /* != 0: the segments were routed with group_by_query (every query's elements for this owner are
                                   one contiguous run of one segment): the sort by query is skipped */
+  int32_t finish_parts;        /* rsa_shard_owner_bpr_finish only: 0 = all of it; 1 = the positives only (qgrad_all is complete
+                                  after this call); 2 = only the sorted apply pass of the shared rows (after a call with 1).  A
+                                  caller can then issue what depends on qgrad_all -- the reduce-scatter, the query tower's
+                                  update -- on another stream, beside the apply pass */
 } rsa_shard_owner_bpr_args;
 int rsa_shard_pos_score(const float* item_local, int64_t n_rows, int32_t dim, const float* q_all, int64_t n_query_rows,
                         int64_t* pos_rows, float* out, const int64_t* pos_ids, int64_t rows_per_shard, int32_t n_shards,

@@ -622,6 +622,10 @@ extern "C" int rsa_shard_owner_bpr_finish(const rsa_shard_owner_bpr_args* a, con
   OwnPrepared P;
   int rc = owner_prepare(c, P, true, s, "rsa_shard_owner_bpr_finish");
   if (rc != RSA_OK) return rc;
+  RSA_CHECK_ARG(a->finish_parts >= 0 && a->finish_parts <= 2, "rsa_shard_owner_bpr_finish: finish_parts must be 0, 1 or 2");
+  if (a->finish_parts == 2)
+    return apply_sorted_segments(P.row_sorted, P.row_total, P.slots, a->q_all, a->dim, a->keys, a->d_slots, a->scale_out, a->n_rows,
+                                 a->item_pad_row, a->item_target, P.L, s);
   const int64_t Q = a->n_query_rows;
   int64_t blocks;
 #define RSA_FIN_LAUNCH(LPR)                                                                                          \
@@ -637,6 +641,7 @@ extern "C" int rsa_shard_owner_bpr_finish(const rsa_shard_owner_bpr_args* a, con
   }
 #undef RSA_FIN_LAUNCH
   RSA_CHECK_LAUNCH("rsa_shard_owner_bpr_finish(positives)");
+  if (a->finish_parts == 1) return RSA_OK;
   return apply_sorted_segments(P.row_sorted, P.row_total, P.slots, a->q_all, a->dim, a->keys, a->d_slots, a->scale_out, a->n_rows,
                                a->item_pad_row, a->item_target, P.L, s);
 }

@@ -6,7 +6,7 @@
 //     consumers (sorted_apply_kernel, classify_solo_kernel, the owner-side walk) read one array;
 //   * pass 0 reads its keys straight from the producer's tensors through a SOURCE functor (the step's int64 id tensors,
 //     the received exchange segments): no key-extraction launch, no 33 MB id round trip;
-//   * only ceil(bits / 8) passes, 8-bit digits, 4096-element tiles.
+//   * only ceil(bits / 8) passes, 8-bit digits, tiles sized so that the scatter pass runs in whole rounds of the chip.
 // Per pass: radix_hist_kernel (per-tile digit counts) -> radix_scan_kernel (per digit: exclusive scan over the tiles) ->
 // radix_scatter_kernel (stable rank inside the tile, the tile regrouped by digit in LDS, contiguous runs written out).
 // Stable and deterministic: no atomics decide a position (the LDS atomics of the histogram only count).
@@ -22,9 +22,17 @@ namespace rsa {
 
 constexpr int RDX_DIGIT_BITS = 8;
 constexpr int RDX_BINS = 1 << RDX_DIGIT_BITS;
-constexpr int RDX_ITEMS = 16;                         // rows of 64 per wave
+constexpr int RDX_ITEMS = 16;                         // rows of 64 per wave in the one-workgroup sort (radix_small_kernel)
 constexpr int RDX_WAVE_TILE = 64 * RDX_ITEMS;         // 1024
-constexpr int RDX_TILE = 4 * RDX_WAVE_TILE;           // 4096 elements per workgroup
+constexpr int RDX_TILE = 4 * RDX_WAVE_TILE;           // 4096 elements: the largest input of the one-workgroup sort
+// The multi-pass kernels take their tile size at run time: `items` rows of 64 per wave, tile = 256 * items elements.  The
+// scatter pass keeps a regrouped tile in LDS (8 bytes per element + 5 KB of counters), so 4 workgroups fit a CU up to
+// items = 17 (39 952 bytes each) and an MI355X holds RDX_SLOTS = 4 x 256 of them at once.  The host picks `items` so that the
+// tiles fill a whole number of such rounds (radix_plan): the headline step's 4.26 M elements are 1041 tiles of 4096 --
+// two rounds, the second for 17 tiles -- but 1024 tiles of 4160.
+constexpr int RDX_ITEMS_MAX = 17;
+constexpr int RDX_ITEMS_MIN = 4;
+constexpr int RDX_SLOTS = 1024;
 
 __host__ __device__ inline uint64_t rdx_pack(uint32_t key, uint32_t val) { return ((uint64_t)key << 32) | val; }
 __host__ __device__ inline uint32_t rdx_key(uint64_t p) { return (uint32_t)(p >> 32); }
@@ -120,14 +128,14 @@ __device__ __forceinline__ uint32_t block_excl_scan_256(uint32_t v, uint32_t* s_
 }
 
 template <class SRC>
-__global__ __launch_bounds__(256) void radix_hist_kernel(const SRC src, int64_t total, int shift, int64_t n_tiles,
+__global__ __launch_bounds__(256) void radix_hist_kernel(const SRC src, int64_t total, int shift, int64_t n_tiles, int items,
                                                          uint32_t* __restrict__ counts) {
   __shared__ uint32_t h[RDX_BINS];
   h[threadIdx.x] = 0;
   __syncthreads();
-  const int64_t base = (int64_t)blockIdx.x * RDX_TILE;
+  const int64_t base = (int64_t)blockIdx.x * (256 * items);
 #pragma unroll 4
-  for (int r = 0; r < RDX_ITEMS; ++r) {
+  for (int r = 0; r < items; ++r) {
     const int64_t i = base + r * 256 + threadIdx.x;
     if (i < total) atomicAdd(&h[(uint32_t)(src(i) >> shift) & (RDX_BINS - 1)], 1u);
   }
@@ -155,80 +163,82 @@ static __global__ __launch_bounds__(256) void radix_scan_kernel(uint32_t* __rest
 }
 
 template <class SRC>
-__global__ __launch_bounds__(256) void radix_scatter_kernel(const SRC src, int64_t total, int shift, int64_t n_tiles,
+__global__ __launch_bounds__(256) void radix_scatter_kernel(const SRC src, int64_t total, int shift, int64_t n_tiles, int items,
                                                             const uint32_t* __restrict__ counts,
                                                             const uint32_t* __restrict__ totals,
                                                             uint64_t* __restrict__ out) {
-  __shared__ uint32_t cnt[4][RDX_BINS];      // per-wave digit counters while ranking, then the waves' bases inside a digit
-  __shared__ uint32_t dbase[RDX_BINS];       // first position of digit d inside the regrouped tile
-  __shared__ int64_t gbase[RDX_BINS];        // global position of that element, minus dbase[d]
+  // 39 952 bytes: four workgroups per CU (see RDX_ITEMS_MAX)
+  __shared__ uint32_t cnt[4][RDX_BINS];      // per-wave digit counters while ranking, then wave w's first slot of digit d in the tile
+  __shared__ uint32_t gbase[RDX_BINS];       // global position of digit d's first element of this tile, minus its slot (mod 2^32)
   __shared__ uint32_t s_wave[4];
-  __shared__ uint64_t stage[RDX_TILE];       // the tile regrouped by digit
+  __shared__ uint64_t stage[256 * RDX_ITEMS_MAX];      // the tile regrouped by digit
   const int lane = lane_id(), wave = threadIdx.x >> 6;
 #pragma unroll
   for (int w = 0; w < 4; ++w) cnt[w][threadIdx.x] = 0;
   __syncthreads();
-  const int64_t tile0 = (int64_t)blockIdx.x * RDX_TILE;
-  const int64_t base = tile0 + (int64_t)wave * RDX_WAVE_TILE;
-  uint64_t v[RDX_ITEMS];
-  uint32_t loc[RDX_ITEMS];
+  const int tile_cap = 256 * items;
+  const int64_t tile0 = (int64_t)blockIdx.x * tile_cap;
+  const int64_t base = tile0 + (int64_t)wave * (64 * items);
+  uint64_t v[RDX_ITEMS_MAX];
+  uint32_t loc[RDX_ITEMS_MAX];
 #pragma unroll
-  for (int r = 0; r < RDX_ITEMS; ++r) {
+  for (int r = 0; r < RDX_ITEMS_MAX; ++r) {
     const int64_t i = base + r * 64 + lane;
-    v[r] = i < total ? src(i) : ~0ull;
+    v[r] = (r < items && i < total) ? src(i) : ~0ull;
   }
   volatile uint32_t* wc = cnt[wave];
   const uint64_t lt = (1ull << lane) - 1ull;
 #pragma unroll
-  for (int r = 0; r < RDX_ITEMS; ++r) {
-    const bool valid = base + r * 64 + lane < total;
-    const uint32_t d = (uint32_t)(v[r] >> shift) & (RDX_BINS - 1);
-    uint64_t peers = __ballot(valid);
+  for (int r = 0; r < RDX_ITEMS_MAX; ++r) {
+    if (r < items) {                         // wave-uniform
+      const bool valid = base + r * 64 + lane < total;
+      const uint32_t d = (uint32_t)(v[r] >> shift) & (RDX_BINS - 1);
+      uint64_t peers = __ballot(valid);
 #pragma unroll
-    for (int b = 0; b < RDX_DIGIT_BITS; ++b) {
-      const bool bit = (d >> b) & 1u;
-      const uint64_t bal = __ballot(bit);
-      peers &= bit ? bal : ~bal;
-    }
-    loc[r] = 0;
-    if (valid) {
-      const uint32_t c0 = wc[d];
-      const uint32_t rank = (uint32_t)__popcll(peers & lt);
-      loc[r] = c0 + rank;
-      if (rank == 0) wc[d] = c0 + (uint32_t)__popcll(peers);       // the row's lowest lane of the digit adds the row's count
+      for (int b = 0; b < RDX_DIGIT_BITS; ++b) {
+        const bool bit = (d >> b) & 1u;
+        const uint64_t bal = __ballot(bit);
+        peers &= bit ? bal : ~bal;
+      }
+      loc[r] = 0;
+      if (valid) {
+        const uint32_t c0 = wc[d];
+        const uint32_t rank = (uint32_t)__popcll(peers & lt);
+        loc[r] = c0 + rank;
+        if (rank == 0) wc[d] = c0 + (uint32_t)__popcll(peers);       // the row's lowest lane of the digit adds the row's count
+      }
     }
   }
   __syncthreads();
-  {   // thread d: the waves' bases inside digit d, the digit's count in the tile and its first position
+  {   // thread d: the digit's count in the tile, its first slot, the waves' first slots inside it
     const int d = threadIdx.x;
     const uint32_t c0 = cnt[0][d], c1 = cnt[1][d], c2 = cnt[2][d], c3 = cnt[3][d];
-    cnt[0][d] = 0;
-    cnt[1][d] = c0;
-    cnt[2][d] = c0 + c1;
-    cnt[3][d] = c0 + c1 + c2;
     const uint32_t first = block_excl_scan_256(c0 + c1 + c2 + c3, s_wave, nullptr);
     const uint32_t gstart = block_excl_scan_256(totals[d], s_wave, nullptr);      // elements of smaller digits, all tiles
-    dbase[d] = first;
-    gbase[d] = (int64_t)gstart + (int64_t)counts[(size_t)d * n_tiles + blockIdx.x] - (int64_t)first;
+    cnt[0][d] = first;
+    cnt[1][d] = first + c0;
+    cnt[2][d] = first + c0 + c1;
+    cnt[3][d] = first + c0 + c1 + c2;
+    gbase[d] = gstart + counts[(size_t)d * n_tiles + blockIdx.x] - first;
   }
   __syncthreads();
 #pragma unroll
-  for (int r = 0; r < RDX_ITEMS; ++r) {
-    if (base + r * 64 + lane < total) {
+  for (int r = 0; r < RDX_ITEMS_MAX; ++r) {
+    if (r < items && base + r * 64 + lane < total) {
       const uint32_t d = (uint32_t)(v[r] >> shift) & (RDX_BINS - 1);
-      stage[dbase[d] + cnt[wave][d] + loc[r]] = v[r];
+      stage[cnt[wave][d] + loc[r]] = v[r];
     }
   }
   __syncthreads();
   const int64_t left = total - tile0;
-  const int tile_n = left < RDX_TILE ? (int)left : RDX_TILE;
+  const int tile_n = left < tile_cap ? (int)left : tile_cap;
 #pragma unroll 4
-  for (int k = 0; k < RDX_ITEMS; ++k) {
+  for (int k = 0; k < items; ++k) {
     const int j = k * 256 + threadIdx.x;
     if (j < tile_n) {
       const uint64_t p = stage[j];
       const uint32_t d = (uint32_t)(p >> shift) & (RDX_BINS - 1);
-      out[gbase[d] + j] = p;
+      out[(uint32_t)(gbase[d] + (uint32_t)j)] = p;
     }
   }
 }
@@ -236,19 +246,25 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(const SRC src, int64
 
 // total <= RDX_TILE: ONE workgroup sorts the whole input in LDS, all passes in one launch (a 4096-element sort through
 // the three-kernels-per-pass form is nine launches of ~5 us each for microseconds of work: the user rows of a sharded
-// step).  The same ranking as radix_scatter_kernel; between passes the tile is re-read from the staging buffer in order.
+// step, every sort of a small-batch `fit`).  The same ranking as radix_scatter_kernel over 16 waves of 256 elements (four
+// waves per SIMD hide the LDS round trips of the ranking; four waves of 1024 elements took 33 us for three passes);
+// between passes the tile is re-read from the staging buffer in order.
+constexpr int RDX_SMALL_WAVES = 16;
+constexpr int RDX_SMALL_ROWS = RDX_TILE / (64 * RDX_SMALL_WAVES);      // 4 rows of 64 per wave
+
 template <class SRC>
-__global__ __launch_bounds__(256) void radix_small_kernel(const SRC src, int total, int passes, uint64_t* __restrict__ out) {
-  __shared__ uint32_t cnt[4][RDX_BINS];
+__global__ __launch_bounds__(64 * RDX_SMALL_WAVES) void radix_small_kernel(const SRC src, int total, int passes,
+                                                                           uint64_t* __restrict__ out) {
+  __shared__ uint32_t cnt[RDX_SMALL_WAVES][RDX_BINS];      // per-wave digit counters, then the waves' bases inside a digit
   __shared__ uint32_t dbase[RDX_BINS];
   __shared__ uint32_t s_wave[4];
   __shared__ uint64_t stage[RDX_TILE];
   const int lane = lane_id(), wave = threadIdx.x >> 6;
-  const int base = wave * RDX_WAVE_TILE;
-  uint64_t v[RDX_ITEMS];
-  uint32_t loc[RDX_ITEMS];
+  const int base = wave * (64 * RDX_SMALL_ROWS);
+  uint64_t v[RDX_SMALL_ROWS];
+  uint32_t loc[RDX_SMALL_ROWS];
 #pragma unroll
-  for (int r = 0; r < RDX_ITEMS; ++r) {
+  for (int r = 0; r < RDX_SMALL_ROWS; ++r) {
     const int i = base + r * 64 + lane;
     v[r] = i < total ? src((int64_t)i) : ~0ull;
   }
@@ -256,11 +272,11 @@ __global__ __launch_bounds__(256) void radix_small_kernel(const SRC src, int tot
   for (int p = 0; p < passes; ++p) {
     const int shift = 32 + p * RDX_DIGIT_BITS;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) cnt[w][threadIdx.x] = 0;
+    for (int k = 0; k < RDX_BINS / 64; ++k) cnt[wave][k * 64 + lane] = 0;
     __syncthreads();
     volatile uint32_t* wc = cnt[wave];
 #pragma unroll
-    for (int r = 0; r < RDX_ITEMS; ++r) {
+    for (int r = 0; r < RDX_SMALL_ROWS; ++r) {
       const bool valid = base + r * 64 + lane < total;
       const uint32_t d = (uint32_t)(v[r] >> shift) & (RDX_BINS - 1);
       uint64_t peers = __ballot(valid);
@@ -279,18 +295,34 @@ __global__ __launch_bounds__(256) void radix_small_kernel(const SRC src, int tot
       }
     }
     __syncthreads();
-    {
+    uint32_t inc = 0, tot_d = 0;
+    if (threadIdx.x < RDX_BINS) {     // thread d: the waves' bases inside digit d, then the digits' first slots
       const int d = threadIdx.x;
-      const uint32_t c0 = cnt[0][d], c1 = cnt[1][d], c2 = cnt[2][d], c3 = cnt[3][d];
-      cnt[0][d] = 0;
-      cnt[1][d] = c0;
-      cnt[2][d] = c0 + c1;
-      cnt[3][d] = c0 + c1 + c2;
-      dbase[d] = block_excl_scan_256(c0 + c1 + c2 + c3, s_wave, nullptr);
+#pragma unroll
+      for (int w = 0; w < RDX_SMALL_WAVES; ++w) {
+        const uint32_t c = cnt[w][d];
+        cnt[w][d] = tot_d;
+        tot_d += c;
+      }
+      inc = tot_d;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t up = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += up;
+      }
+      if (lane == 63) s_wave[wave] = inc;
+    }
+    __syncthreads();
+    if (threadIdx.x < RDX_BINS) {
+      uint32_t before = 0;
+#pragma unroll
+      for (int w = 0; w < 4; ++w)
+        if (w < wave) before += s_wave[w];
+      dbase[threadIdx.x] = before + inc - tot_d;
     }
     __syncthreads();
 #pragma unroll
-    for (int r = 0; r < RDX_ITEMS; ++r) {
+    for (int r = 0; r < RDX_SMALL_ROWS; ++r) {
       if (base + r * 64 + lane < total) {
         const uint32_t d = (uint32_t)(v[r] >> shift) & (RDX_BINS - 1);
         stage[dbase[d] + cnt[wave][d] + loc[r]] = v[r];
@@ -298,14 +330,14 @@ __global__ __launch_bounds__(256) void radix_small_kernel(const SRC src, int tot
     }
     __syncthreads();
 #pragma unroll
-    for (int r = 0; r < RDX_ITEMS; ++r) {        // the regrouped tile, in order: the next pass's input
+    for (int r = 0; r < RDX_SMALL_ROWS; ++r) {        // the regrouped tile, in order: the next pass's input
       const int i = base + r * 64 + lane;
       v[r] = i < total ? stage[i] : ~0ull;
     }
     __syncthreads();
   }
 #pragma unroll
-  for (int r = 0; r < RDX_ITEMS; ++r) {
+  for (int r = 0; r < RDX_SMALL_ROWS; ++r) {
     const int i = base + r * 64 + lane;
     if (i < total) out[i] = v[r];
   }
@@ -318,7 +350,19 @@ inline unsigned radix_key_bits(int64_t n_keys) {      // bits needed for keys 0 
   return b;
 }
 inline int radix_passes(unsigned bits) { return (int)((bits + RDX_DIGIT_BITS - 1) / RDX_DIGIT_BITS); }
-inline int64_t radix_tiles(int64_t total) { return (total + RDX_TILE - 1) / RDX_TILE; }
+// tile size of the multi-pass kernels: the fewest rounds of RDX_SLOTS co-resident workgroups, then the smallest tile
+// that still fits the elements into those rounds
+inline int radix_items(int64_t total) {
+  const int64_t round_cap = (int64_t)RDX_SLOTS * 256 * RDX_ITEMS_MAX;
+  const int64_t rounds = total <= round_cap ? 1 : (total + round_cap - 1) / round_cap;
+  const int64_t per = rounds * RDX_SLOTS * 256;
+  const int64_t items = (total + per - 1) / per;
+  return (int)(items < RDX_ITEMS_MIN ? RDX_ITEMS_MIN : items);
+}
+inline int64_t radix_tiles(int64_t total) {
+  const int64_t tile = 256 * (int64_t)radix_items(total);
+  return (total + tile - 1) / tile;
+}
 inline int64_t radix_temp_bytes(int64_t total) {
   const int64_t c = RDX_BINS * radix_tiles(total) * 4;
   return (c + 255) / 256 * 256 + RDX_BINS * 4;
@@ -333,11 +377,12 @@ inline hipError_t radix_sort_pairs(const SRC0& src0, uint64_t* buf_a, uint64_t* 
                                    void* temp, hipStream_t s) {
   if (total <= 0) return hipSuccess;
   if (total <= RDX_TILE) {       // one workgroup, one launch; the result goes where the multi-pass form would leave it
-    hipLaunchKernelGGL((radix_small_kernel<SRC0>), dim3(1), dim3(256), 0, s, src0, (int)total, radix_passes(bits),
+    hipLaunchKernelGGL((radix_small_kernel<SRC0>), dim3(1), dim3(64 * RDX_SMALL_WAVES), 0, s, src0, (int)total, radix_passes(bits),
                        radix_result(buf_a, buf_b, bits));
     return hipGetLastError();
   }
   const int64_t n_tiles = radix_tiles(total);
+  const int items = radix_items(total);
   uint32_t* counts = reinterpret_cast<uint32_t*>(temp);
   uint32_t* totals = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(temp) + (RDX_BINS * n_tiles * 4 + 255) / 256 * 256);
   const int passes = radix_passes(bits);
@@ -346,14 +391,14 @@ inline hipError_t radix_sort_pairs(const SRC0& src0, uint64_t* buf_a, uint64_t* 
     const int shift = 32 + p * RDX_DIGIT_BITS;
     uint64_t* dst = (p & 1) ? buf_b : buf_a;
     if (p == 0) {
-      hipLaunchKernelGGL((radix_hist_kernel<SRC0>), grid, block, 0, s, src0, total, shift, n_tiles, counts);
+      hipLaunchKernelGGL((radix_hist_kernel<SRC0>), grid, block, 0, s, src0, total, shift, n_tiles, items, counts);
       hipLaunchKernelGGL(radix_scan_kernel, dim3(RDX_BINS), block, 0, s, counts, n_tiles, totals);
-      hipLaunchKernelGGL((radix_scatter_kernel<SRC0>), grid, block, 0, s, src0, total, shift, n_tiles, counts, totals, dst);
+      hipLaunchKernelGGL((radix_scatter_kernel<SRC0>), grid, block, 0, s, src0, total, shift, n_tiles, items, counts, totals, dst);
     } else {
       const SrcPairs sp{(p & 1) ? buf_a : buf_b};
-      hipLaunchKernelGGL((radix_hist_kernel<SrcPairs>), grid, block, 0, s, sp, total, shift, n_tiles, counts);
+      hipLaunchKernelGGL((radix_hist_kernel<SrcPairs>), grid, block, 0, s, sp, total, shift, n_tiles, items, counts);
       hipLaunchKernelGGL(radix_scan_kernel, dim3(RDX_BINS), block, 0, s, counts, n_tiles, totals);
-      hipLaunchKernelGGL((radix_scatter_kernel<SrcPairs>), grid, block, 0, s, sp, total, shift, n_tiles, counts, totals, dst);
+      hipLaunchKernelGGL((radix_scatter_kernel<SrcPairs>), grid, block, 0, s, sp, total, shift, n_tiles, items, counts, totals, dst);
     }
   }
   return hipGetLastError();

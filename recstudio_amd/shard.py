@@ -363,7 +363,10 @@ class HipBackend:
         return keep
 
     @ops._on_device
-    def owner_bpr_finish(self, ctx, dsum_all):
+    def owner_bpr_finish(self, ctx, dsum_all, parts=0):
+        """``parts``: 0 = the whole finish; 1 = the positives only (``qgrad_all`` is complete afterwards); 2 = the shared rows'
+        sorted apply pass (after a call with 1)."""
+        ctx['args'].finish_parts = int(parts)
         nat.check(nat.lib().rsa_shard_owner_bpr_finish(ctypes.byref(ctx['args']), ptr(ops._need(dsum_all, torch.float32, 'dsum_all')),
                                                        ops._stream()), 'rsa_shard_owner_bpr_finish')
 
@@ -713,7 +716,7 @@ class ShardedItemTable:
         return (self.owner_loss and self.exchange == 'fixed' and self.chunks == 1 and hasattr(self.backend, 'owner_bpr_forward')
                 and self.item_local.shape[1] in getattr(self.backend, 'OWNER_DIMS', (64, 128, 256)))
 
-    def bpr_step_on_owners(self, q, pos, n, sampler, item_grad_local, item_scale=None, want_ids=False):
+    def bpr_step_on_owners(self, q, pos, n, sampler, item_grad_local, item_scale=None, want_ids=False, defer_rows=False):
         """The stock BPR training step with the loss evaluated ON THE OWNERS of the negatives (SURVEY.md 8e, steps 3-5 in one
         pass; include/recstudio_amd.h, rsa_shard_owner_bpr_forward): BPR's d loss/d neg needs only the query's positive
         score, so
@@ -731,7 +734,11 @@ class ShardedItemTable:
         No scores travel home, no score gradients travel back (8 instead of 16 bytes per triplet over xGMI), and the item
         rows of a step are read once instead of twice.  -> (this rank's share of the global mean loss, d loss/d q [B, d],
         negative ids or None).  The shares of all ranks add up to the loss (each rank holds the terms of the negatives it
-        owns)."""
+        owns).
+
+        ``defer_rows``: the last part of step 4 -- the sorted apply pass of the shared rows -- is NOT issued; a fourth return
+        value is the function that issues it.  Nothing the caller does with ``d loss/d q`` depends on that pass, so a
+        caller with a second stream (``ShardedRetriever``: the query rows' exchange and update) runs the two side by side."""
         be, st, plan = self.backend, self.state, self.plan
         B, G = pos.numel(), plan.world
         S = int(getattr(be, 'BANKS', 1))
@@ -765,10 +772,19 @@ class ShardedItemTable:
                                    item_scale, qgrad_all, item_pad_row=0 if self.rank == 0 else -1,
                                    keys_grouped=bool(r.get('grouped', False)))
         dsum_all = self._all_reduce_sum(ctx['dsum_part'] if self._solo else ctx['dsum_part'].clone())
+        neg_out = r.get('neg_ids') if spec is not None else neg
+        if defer_rows:
+            be.owner_bpr_finish(ctx, dsum_all, parts=1)
+            dq = self._reduce_scatter_rows(qgrad_all, B)
+
+            def finish_rows():
+                be.owner_bpr_finish(ctx, dsum_all, parts=2)
+                self._after_fixed_step()
+            return ctx['loss_part'], dq, neg_out, finish_rows
         be.owner_bpr_finish(ctx, dsum_all)
         dq = self._reduce_scatter_rows(qgrad_all, B)
         self._after_fixed_step()
-        return ctx['loss_part'], dq, (r.get('neg_ids') if spec is not None else neg)
+        return ctx['loss_part'], dq, neg_out
 
     def backward(self, route, dpos, dneg, item_grad_local, item_scale=None):
         """Gradient exchange for one step.  ``route`` comes from a forward with
@@ -1090,7 +1106,7 @@ class ShardedRetriever:
     concatenated batch.  ``sparse_query_rows`` (see ``__init__``) replaces that for a plain ``nn.Embedding`` tower."""
 
     def __init__(self, table, query_encoder, sampler, loss_fn, neg_count, item_sgd_lr=None, sparse_query_rows=None,
-                 query_sgd_lr=None, keep_neg_ids=False):
+                 query_sgd_lr=None, keep_neg_ids=False, overlap_query_rows=True):
         """``item_sgd_lr``: apply plain SGD with this learning rate to the owned item rows INSIDE the backward
         exchange (sorted scatter straight into the weight block, no [rows_local, d] gradient buffer to zero, fill
         and add); the caller then only steps the query tower.
@@ -1104,8 +1120,13 @@ class ShardedRetriever:
         passes ``query_sgd_lr`` (plain SGD in place; sorted, atomics-free: replicas stay bit-equal).  The path reads
         the weight rows directly, so Embedding options that act inside ``forward`` / ``backward`` are refused.
 
-        ``keep_neg_ids``: keep the step's sampled ids in ``last_neg`` (the fused step does not write them otherwise)."""
+        ``keep_neg_ids``: keep the step's sampled ids in ``last_neg`` (the fused step does not write them otherwise).
+
+        ``overlap_query_rows`` (owner-side BPR step with ``sparse_query_rows`` on a GPU): the query rows' exchange and
+        update -- a dozen launches of microseconds each -- run on a second stream beside the sorted apply pass of the
+        shared item rows instead of behind it (neither reads what the other writes; same results)."""
         self.table, self.query_encoder, self.sampler, self.loss_fn = table, query_encoder, sampler, loss_fn
+        self.overlap_query_rows, self._side = bool(overlap_query_rows), None
         self.neg_count = int(neg_count)
         if sparse_query_rows is None:
             sparse_query_rows = query_sgd_lr is not None
@@ -1169,6 +1190,21 @@ class ShardedRetriever:
         kind = self._fused_loss_kind()
         if kind == 'bpr' and table.owner_loss_ok():
             # the loss on the owners of the negatives: one pass over the item rows per step (bpr_step_on_owners)
+            if self.sparse_query_rows and self.overlap_query_rows and q.is_cuda:
+                loss, dq, self.last_neg, finish_rows = table.bpr_step_on_owners(
+                    q.detach(), pos_items, self.neg_count, self.sampler, self.item_grad_local, self.item_scale,
+                    want_ids=self.keep_neg_ids, defer_rows=True)
+                if self._side is None:
+                    self._side = torch.cuda.Stream(device=q.device)
+                main = torch.cuda.current_stream(q.device)
+                fork = torch.cuda.Event()
+                fork.record(main)
+                finish_rows()                            # main stream: the shared item rows
+                with torch.cuda.stream(self._side):      # side stream: the query rows (they wait for dq only)
+                    self._side.wait_event(fork)
+                    self._exchange_query_rows(weight, query_feat, dq)
+                main.wait_stream(self._side)
+                return loss
             loss, dq, self.last_neg = table.bpr_step_on_owners(q.detach(), pos_items, self.neg_count, self.sampler,
                                                                self.item_grad_local, self.item_scale, want_ids=self.keep_neg_ids)
             if not self.sparse_query_rows and q.requires_grad:
@@ -1193,16 +1229,22 @@ class ShardedRetriever:
             self.last_neg = neg
             loss = loss.detach()
         if self.sparse_query_rows:
-            ids_all = table._all_gather_rows(query_feat.reshape(-1).contiguous())
-            rows_all = table._all_gather_rows(dq)
-            pad = self.query_encoder.padding_idx
-            self.query_rows = (ids_all, rows_all)
-            if self.query_sgd_lr is not None:
-                table.backend.apply_rows(weight.data, ids_all, rows_all, -float(self.query_sgd_lr),
-                                         pad_row=-1 if pad is None else int(pad))
+            self._exchange_query_rows(weight, query_feat, dq)
         elif not table._solo:
             allreduce_grads(self.query_encoder.parameters(), table.dist, table.group)
         return loss
+
+    def _exchange_query_rows(self, weight, query_feat, dq):
+        """The row-sparse gradient of the replicated query table: (ids, rows) of every rank, applied in place when
+        ``query_sgd_lr`` is set."""
+        table = self.table
+        ids_all = table._all_gather_rows(query_feat.reshape(-1).contiguous())
+        rows_all = table._all_gather_rows(dq)
+        pad = self.query_encoder.padding_idx
+        self.query_rows = (ids_all, rows_all)
+        if self.query_sgd_lr is not None:
+            table.backend.apply_rows(weight.data, ids_all, rows_all, -float(self.query_sgd_lr),
+                                     pad_row=-1 if pad is None else int(pad))
 
     def query_grad_dense(self):
         """The row-sparse query-table gradient of the last step as a dense ``[n_users, d]`` tensor (tests, small

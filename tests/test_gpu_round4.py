@@ -558,6 +558,12 @@ def test_bpr_step_on_owners_vs_autograd(ra, d, n, B, layout, popular):
         rel_close(loss2.item(), loss.item(), rtol=1e-6)
         rel_close(item2.cpu(), (item0.to(DEV) - 0.5 * want).cpu(), rtol=2e-4, atol=1e-7)
         rel_close(tower2.weight.detach().cpu(), (user0.to(DEV) - 0.5 * uw.grad).cpu(), rtol=2e-4, atol=1e-7)
+        # the query rows' update on the second stream (default) and behind the apply pass: the same step
+        item3, tower3, tr3 = make(item_sgd_lr=0.5, query_sgd_lr=0.5, overlap_query_rows=False)
+        tr3.training_step(uid, pos)
+        assert tr2._side is not None and tr3._side is None
+        rel_close(item3.cpu(), item2.cpu(), rtol=1e-5, atol=1e-7)
+        rel_close(tower3.weight.detach().cpu(), tower2.weight.detach().cpu(), rtol=1e-5, atol=1e-7)
     finally:
         dist.destroy_process_group()
 

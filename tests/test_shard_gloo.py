@@ -201,16 +201,18 @@ class CheckerBackend:
                 'item_target': item_target, 'item_scale': item_scale, 'qgrad_all': qgrad_all, 'pad': item_pad_row,
                 'dsum_part': dsum_part, 'loss_part': loss_part}
 
-    def owner_bpr_finish(self, ctx, dsum_all):
+    def owner_bpr_finish(self, ctx, dsum_all, parts=0):
         own = ctx['pos_rows'] >= 0
         qi = torch.nonzero(own).flatten()
         rows_p, dpos = ctx['pos_rows'][own], -dsum_all[own]
         item_local, q_all, gate = ctx['item_local'], ctx['q_all'], ctx['gate']
-        ctx['qgrad_all'].index_add_(0, qi, gate * dpos.unsqueeze(1) * item_local[rows_p])    # reads the rows: before the update
-        rows, qidx, d = torch.cat([ctx['rows'], rows_p]), torch.cat([ctx['qidx'], qi]), torch.cat([ctx['d'], dpos])
-        live = rows != ctx['pad']
-        scale = gate * (1.0 if ctx['item_scale'] is None else float(ctx['item_scale']))
-        ctx['item_target'].index_add_(0, rows[live], scale * d[live].unsqueeze(1) * q_all[qidx[live]])
+        if parts in (0, 1):
+            ctx['qgrad_all'].index_add_(0, qi, gate * dpos.unsqueeze(1) * item_local[rows_p])    # reads the rows: before the update
+        if parts in (0, 2):
+            rows, qidx, d = torch.cat([ctx['rows'], rows_p]), torch.cat([ctx['qidx'], qi]), torch.cat([ctx['d'], dpos])
+            live = rows != ctx['pad']
+            scale = gate * (1.0 if ctx['item_scale'] is None else float(ctx['item_scale']))
+            ctx['item_target'].index_add_(0, rows[live], scale * d[live].unsqueeze(1) * q_all[qidx[live]])
 
     def _elements(self, pos, neg):
         return torch.cat([pos.view(-1, 1), neg], 1).reshape(-1)

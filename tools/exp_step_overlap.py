@@ -1,0 +1,45 @@
+"""In-process A/B of the sharded training step (configs[3] per-GPU shape, world size 1) with the query rows' exchange and
+update on a second stream (ShardedRetriever(overlap_query_rows=True), the default) and behind the apply pass: alternating
+rounds of whole training steps, HIP events around each round.  usage: python tools/exp_step_overlap.py"""
+import json
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import recstudio_amd as ra                      # noqa: E402
+from recstudio_amd import shard                 # noqa: E402
+import torch.distributed as dist                # noqa: E402
+
+dev = torch.device('cuda', 0)
+torch.cuda.set_device(0)
+os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+os.environ.setdefault('MASTER_PORT', '29581')
+dist.init_process_group('gloo', rank=0, world_size=1)
+n_blk, n_neg, B, d, U = 12_500_001, 1024, 4096, 128, 1_000_001
+item = torch.empty(n_blk, d, device=dev).normal_(0, 0.02)
+item[0] = 0
+tower = torch.nn.Embedding(U, d).to(dev)
+uid = torch.randint(1, U, (B,), device=dev)
+pos = torch.randint(1, n_blk, (B,), device=dev)
+trainers = {}
+for name, flag in (('side_stream', True), ('serial', False)):
+    tbl = shard.ShardedItemTable(item, shard.RowShardPlan(n_blk, 1), 0, dist, check_every=0)
+    trainers[name] = shard.ShardedRetriever(tbl, tower, ra.UniformSampler(n_blk), ra.BPRLoss(), n_neg, item_sgd_lr=1e-3,
+                                            query_sgd_lr=1e-3, overlap_query_rows=flag)
+res = {k: [] for k in trainers}
+for rnd in range(5):
+    for k, tr in trainers.items():
+        for _ in range(5):
+            tr.training_step(uid, pos)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(30):
+            tr.training_step(uid, pos)
+        e1.record()
+        torch.cuda.synchronize()
+        res[k].append(e0.elapsed_time(e1) / 30)
+print(json.dumps({k: {'min_ms': round(min(v), 4), 'median_ms': round(sorted(v)[len(v) // 2], 4)} for k, v in res.items()}))

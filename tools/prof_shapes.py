@@ -93,7 +93,10 @@ elif shape in ('sharded_world1_step', 'sharded_world1_train'):
             tbl.sample_and_score(user, uid, pos, n_neg, us, fused_loss='bpr', want_ids=False, want_grad=True)
     else:
         tower = torch.nn.Embedding(U, d).to(dev)
-        trainer = shard.ShardedRetriever(tbl, tower, us, ra.BPRLoss(), n_neg, item_sgd_lr=0.05, query_sgd_lr=0.05)
+        # one stream: the tracked figure is a SUM of kernel durations (with the query rows on the second stream, the default,
+        # the kernels that run side by side would each be charged the whole overlap)
+        trainer = shard.ShardedRetriever(tbl, tower, us, ra.BPRLoss(), n_neg, item_sgd_lr=0.05, query_sgd_lr=0.05,
+                                         overlap_query_rows=False)
 
         def step():
             trainer.training_step(uid, pos)
