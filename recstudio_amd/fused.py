@@ -351,6 +351,7 @@ class PrefetchedBPRSGD:
         self.num_neg, self.sampler = int(num_neg), sampler
         self.side = torch.cuda.Stream(device=self.iw.device)
         self.step_scale = torch.full((1,), -float(lr), dtype=torch.float32, device=self.iw.device)
+        self._ones = None
 
     def set_lr(self, lr):
         """New learning rate from the next ``step`` on (call between steps, e.g. a scheduler at the end of an epoch)."""
@@ -362,11 +363,15 @@ class PrefetchedBPRSGD:
         with torch.no_grad(), torch.cuda.stream(self.side):
             neg = self.sampler(torch.empty(user_ids.numel(), 1, device=self.iw.device), self.num_neg, None)[0]
             solo, ws = ops.sort_step_elements(pos_ids, neg, self.iw.shape[0], pad_row=0)
+            ws_user = None
+            if self.uw.shape[1] in (64, 128, 256):    # the user rows' sort does not read the weights either
+                ws_user = ops.sort_step_elements(None, user_ids.view(-1, 1), self.uw.shape[0], pad_row=0, want_solo=False)[1]
             ready = torch.cuda.Event()
             ready.record(self.side)
-        for t in (neg, solo, ws):                     # allocated on the side stream, consumed (and freed) on the main one
-            t.record_stream(main)
-        return {'user_ids': user_ids, 'pos_ids': pos_ids, 'neg': neg, 'solo': solo, 'ws': ws, 'ready': ready}
+        for t in (neg, solo, ws, ws_user):            # allocated on the side stream, consumed (and freed) on the main one
+            if t is not None:
+                t.record_stream(main)
+        return {'user_ids': user_ids, 'pos_ids': pos_ids, 'neg': neg, 'solo': solo, 'ws': ws, 'ws_user': ws_user, 'ready': ready}
 
     def step(self, ticket):
         """The weight-dependent part of the step on the current stream; returns (loss, neg_ids)."""
@@ -379,7 +384,13 @@ class PrefetchedBPRSGD:
                                     inplace_update=(ticket['solo'], self.step_scale))
             ops.scatter_rows_presorted(self.iw, self.uw, ticket['ws'], M, self.num_neg, out['dneg'], query_index=uid,
                                        dpos=out['dpos'], upstream=self.step_scale, pad_row=0)
-            _apply_user_rows(self.uw, uid, out['query_grad'], self.step_scale)
+            if ticket['ws_user'] is not None:         # _apply_user_rows with its sort done ahead
+                if self._ones is None or self._ones.shape[0] != M:
+                    self._ones = torch.ones(M, 1, dtype=torch.float32, device=self.uw.device)
+                ops.scatter_rows_presorted(self.uw, out['query_grad'], ticket['ws_user'], M, 1, self._ones,
+                                           upstream=self.step_scale, pad_row=0)
+            else:
+                _apply_user_rows(self.uw, uid, out['query_grad'], self.step_scale)
         return out['loss'], out['neg_ids']
 
 
@@ -423,7 +434,7 @@ class FusedBPRAdam:
             ops.adam_rows_sorted(self.uw, st['um'], st['uv'], out['query_grad'], user_ids.view(M, 1), ones, pad_row=0, **hp)
         return out['loss'], out['neg_ids']
 
-    # ---- one batch ahead (see PrefetchedBPRSGD): sampling and the item-side sort do not read the weights
+    # ---- one batch ahead (see PrefetchedBPRSGD): sampling and the two sorts (item rows, user rows) do not read the weights
     def prepare(self, num_neg, *, user_ids, pos_ids, sampler):
         """Draw the negatives of a batch and sort its (item id, element) pairs on a side stream -> ticket for
         ``step_prepared``.  Tickets are stepped once each, in the order they were prepared; the results are those of the
@@ -437,11 +448,13 @@ class FusedBPRAdam:
         with torch.no_grad(), torch.cuda.stream(self.side):
             neg = sampler(torch.empty(user_ids.numel(), 1, device=self.iw.device), num_neg, None)[0]
             _, ws = ops.sort_step_elements(pos_ids, neg, self.iw.shape[0], pad_row=0, want_solo=False)
+            _, ws_user = ops.sort_step_elements(None, user_ids.view(-1, 1), self.uw.shape[0], pad_row=0, want_solo=False)
             ready = torch.cuda.Event()
             ready.record(self.side)
-        for t in (neg, ws):
+        for t in (neg, ws, ws_user):
             t.record_stream(main)
-        return {'user_ids': user_ids, 'pos_ids': pos_ids, 'neg': neg, 'ws': ws, 'ready': ready, 'num_neg': int(num_neg)}
+        return {'user_ids': user_ids, 'pos_ids': pos_ids, 'neg': neg, 'ws': ws, 'ws_user': ws_user, 'ready': ready,
+                'num_neg': int(num_neg)}
 
     def step_prepared(self, ticket):
         torch.cuda.current_stream(self.iw.device).wait_event(ticket['ready'])
@@ -456,5 +469,5 @@ class FusedBPRAdam:
             ops.adam_rows_presorted(self.iw, st['im'], st['iv'], self.uw, ticket['ws'], M, n, out['dneg'], query_index=uid,
                                     dpos=out['dpos'], pad_row=0, **hp)
             ones = torch.ones(M, 1, dtype=torch.float32, device=self.iw.device)
-            ops.adam_rows_sorted(self.uw, st['um'], st['uv'], out['query_grad'], uid.view(M, 1), ones, pad_row=0, **hp)
+            ops.adam_rows_presorted(self.uw, st['um'], st['uv'], out['query_grad'], ticket['ws_user'], M, 1, ones, pad_row=0, **hp)
         return out['loss'], out['neg_ids']
