@@ -762,14 +762,29 @@ def main():
                 trainer1.training_step(u1, p1)
                 t_tr = time_gpu(lambda: trainer1.training_step(u1, p1), 30, 3) * 1e3
                 tbl_t.check_overflow()
+                # ... and one batch ahead: the next step's negatives, routing, key exchange and owner-side sorts on a second
+                # stream under the current step (ShardedRetriever.prepare_step; wall clock per step, the same weights)
+                look = {'t': trainer1.prepare_step(u1, p1)}
+
+                def ahead_step():
+                    nxt = trainer1.prepare_step(u1, p1)
+                    trainer1.training_step(u1, p1, ticket=look['t'])
+                    look['t'] = nxt
+                t_la = time_gpu(ahead_step, 30, 3) * 1e3
+                trainer1.training_step(u1, p1, ticket=look['t'])
+                tbl_t.check_overflow()
                 blk.copy_(blk0)
                 del blk0, tower1, trainer1
                 alg_tr = (bytes_per_triplet(d, n1k, False) + 2 * 4 * d + 2 * 4 * d / n1k) * b1k * n1k
                 tr = with_profile({'ms_per_step': round(t_tr, 4), 'M_triplets_s': round(b1k * n1k / t_tr / 1e3, 2),
                                    'frac_of_hbm_peak': round(alg_tr / t_tr / 1e6 / HBM_PEAK_GBS, 4),
                                    'alg_bytes_per_triplet': round(alg_tr / b1k / n1k, 1),
+                                   'one_batch_ahead_ms': round(t_la, 4),
+                                   'one_batch_ahead_frac': round(alg_tr / t_la / 1e6 / HBM_PEAK_GBS, 4),
                                    'what': 'in-place SGD training step of the same shape, BPR evaluated on the owners '
-                                           '(shard.ShardedItemTable.bpr_step_on_owners): item rows read once per step'},
+                                           '(shard.ShardedItemTable.bpr_step_on_owners): item rows read once per step; '
+                                           'one_batch_ahead: the weight-independent half of the next step (negatives, routing, '
+                                           'key exchange, owner-side sorts) on a second stream under the current one'},
                                   'sharded_world1_train', alg_tr, whole_step=True)
                 extra['sharded_world1']['train'] = tr
                 del blk, tbl, tbl_t
@@ -914,6 +929,17 @@ def main():
                 trn_t = shard.ShardedRetriever(tbl_t, tower_t, smp_t, ra.BPRLoss(), n, item_sgd_lr=1e-3, query_sgd_lr=1e-3)
                 res_t[tag] = timed_max(lambda trn_t=trn_t, pos_t=pos_t: trn_t.training_step(uid, pos_t), max(10, args.steps // 4), 3)
                 tbl_t.check_overflow()
+                if tag == 'sharded' and trn_t.can_prepare():
+                    # one batch ahead: the key exchange of step t + 1 (and the owner-side sorts behind it) under step t
+                    look = {'t': trn_t.prepare_step(uid, pos_t)}
+
+                    def ahead_step(trn_t=trn_t, pos_t=pos_t, look=look):
+                        nxt = trn_t.prepare_step(uid, pos_t)
+                        trn_t.training_step(uid, pos_t, ticket=look['t'])
+                        look['t'] = nxt
+                    res_t['ahead'] = timed_max(ahead_step, max(10, args.steps // 4), 3)
+                    trn_t.training_step(uid, pos_t, ticket=look['t'])
+                    tbl_t.check_overflow()
                 on_owners = tbl_t.owner_loss_ok()
                 del tbl_t, trn_t
             item_local.copy_(w_keep)
@@ -924,6 +950,7 @@ def main():
                                    'world1_reference_ms': round(res_t['world1'], 4),
                                    'efficiency_vs_world1': round(res_t['world1'] / res_t['sharded'], 4),
                                    'loss_on_owners': bool(on_owners),
+                                   'one_batch_ahead_ms': round(res_t['ahead'], 4) if 'ahead' in res_t else None,
                                    'what': 'in-place SGD training step (BPR): sample + route, key all-to-all, positives scored by their '
                                            'owners (4-byte-per-query all-reduce), ONE pass over the received rows (scores, loss, query-'
                                            'gradient partials, solo rows updated in place), second small all-reduce, sorted apply for the '

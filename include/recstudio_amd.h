@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define RSA_ABI_VERSION 8   /* 8: rsa_shard_owner_bpr_args.finish_parts (the finish call in two parts, for a caller with two streams);
+#define RSA_ABI_VERSION 8   /* 8: rsa_shard_owner_bpr_args.finish_parts / forward_parts (the owner-side step in parts, for a caller with two streams);
                                7: rsa_shard_pos_score / rsa_shard_owner_bpr_forward / _finish (the BPR step evaluated on the owners: rows read
                                once per step); rsa_shard_sample_route: route_pos; rsa_shard_backward_segments (the owner side of the sharded backward in one call: in-tree radix sorts
                                straight from the received segments, one walk over the query runs that reads every item row once and
@@ -669,6 +669,11 @@ typedef struct rsa_shard_owner_bpr_args {
                                   after this call); 2 = only the sorted apply pass of the shared rows (after a call with 1).  A
                                   caller can then issue what depends on qgrad_all -- the reduce-scatter, the query tower's
                                   update -- on another stream, beside the apply pass */
+  int32_t forward_parts;       /* rsa_shard_owner_bpr_forward only: 0 = all of it; 1 = only what reads nothing but the received
+                                  keys and pos_rows -- the sort by row, the solo classification, the queries' runs -- into the
+                                  workspace (q_all, pos_score, qgrad_all and the outputs may be null): a caller can issue it
+                                  for the NEXT step, behind that step's key exchange, on another stream; 2 = the rest (update
+                                  scales from the headers, then the pass over the rows) over a workspace a call with 1 filled */
 } rsa_shard_owner_bpr_args;
 int rsa_shard_pos_score(const float* item_local, int64_t n_rows, int32_t dim, const float* q_all, int64_t n_query_rows,
                         int64_t* pos_rows, float* out, const int64_t* pos_ids, int64_t rows_per_shard, int32_t n_shards,

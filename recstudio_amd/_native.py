@@ -99,7 +99,7 @@ class ShardOwnerBprArgs(Structure):
         ('pos_score', c_void_p), ('mean_den', c_int64), ('item_target', c_void_p), ('item_scale', c_void_p),
         ('step_dropped', c_void_p), ('overflow_sticky', c_void_p), ('scale_out', c_void_p), ('qgrad_all', c_void_p),
         ('d_slots', c_void_p), ('dsum_part', c_void_p), ('loss_part', c_void_p), ('reduce_scratch', c_void_p),
-        ('item_pad_row', c_int64), ('workspace', c_void_p), ('workspace_bytes', c_int64), ('keys_grouped', c_int32), ('finish_parts', c_int32),
+        ('item_pad_row', c_int64), ('workspace', c_void_p), ('workspace_bytes', c_int64), ('keys_grouped', c_int32), ('finish_parts', c_int32), ('forward_parts', c_int32),
     ]
 
 

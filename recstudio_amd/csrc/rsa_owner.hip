@@ -422,12 +422,17 @@ struct OwnPrepared {
   bool inplace;
 };
 
-static int owner_prepare(const OwnCommon& c, OwnPrepared& P, bool sort_rows_only, hipStream_t s, const char* who) {
+// which part of the preparation a call issues: everything (one-call steps), the layout only (a later entry point of the
+// same step), the sorts / classification / runs only (they read the received keys, nothing else: a caller may issue them a
+// step ahead, on another stream), or the update scales only (the step's own half of such a split)
+enum OwnPrep { OWN_PREP_ALL = 0, OWN_PREP_LAYOUT = 1, OWN_PREP_SORTS = 2, OWN_PREP_SCALE = 3 };
+
+static int owner_prepare(const OwnCommon& c, OwnPrepared& P, OwnPrep mode, hipStream_t s, const char* who) {
   RSA_CHECK_ARG(c.n_segments >= 0 && c.stride > RSA_SHARD_HDR, "%s: bad sizes", who);
   P.slots = c.n_segments * c.stride;
   RSA_CHECK_ARG(c.scale_out != nullptr, "%s: scale_out is null", who);
   RSA_CHECK_ARG(P.slots < (1ll << 31) - c.n_query_rows, "%s: more than 2^31 slots", who);
-  RSA_CHECK_ARG(c.item_local && c.q_all && (c.keys || P.slots == 0) && c.item_target, "%s: null pointer", who);
+  RSA_CHECK_ARG(c.item_local && (c.q_all || mode == OWN_PREP_SORTS) && (c.keys || P.slots == 0) && c.item_target, "%s: null pointer", who);
   RSA_CHECK_ARG(c.n_rows >= 1 && c.n_rows < (1ll << 31) && c.n_query_rows >= 1 && c.n_query_rows < (1ll << 31),
                 "%s: table sizes out of range", who);
   if (c.dim != 64 && c.dim != 128 && c.dim != 256) {
@@ -445,10 +450,13 @@ static int owner_prepare(const OwnCommon& c, OwnPrepared& P, bool sort_rows_only
   P.row_sorted = radix_result(P.L.pairs_a, P.L.pairs_b, row_bits);
   const unsigned q_bits = radix_key_bits(c.n_query_rows + 1);
   P.q_sorted = c.keys_grouped ? nullptr : radix_result(P.W.qa, P.W.qb, q_bits);
-  if (sort_rows_only) return RSA_OK;       // (the second entry point of a two-call step: the layout only)
-  hipLaunchKernelGGL(owner_scale_kernel, dim3(1), dim3(1), 0, s, c.item_scale, c.step_dropped, c.scale_out,
-                     c.overflow_sticky ? c.keys : nullptr, c.n_segments, c.stride, c.overflow_sticky);
-  RSA_CHECK_LAUNCH(who);
+  if (mode == OWN_PREP_LAYOUT) return RSA_OK;
+  if (mode != OWN_PREP_SORTS) {
+    hipLaunchKernelGGL(owner_scale_kernel, dim3(1), dim3(1), 0, s, c.item_scale, c.step_dropped, c.scale_out,
+                       c.overflow_sticky ? c.keys : nullptr, c.n_segments, c.stride, c.overflow_sticky);
+    RSA_CHECK_LAUNCH(who);
+  }
+  if (mode == OWN_PREP_SCALE) return RSA_OK;
   if (P.row_total == 0) return RSA_OK;
   // 1. elements by row (dead slots: key n_rows, behind every real row), solo classification for the in-place update
   const RdxDiv32 by_stride = rdx_make_div32((uint64_t)c.stride);
@@ -526,7 +534,7 @@ extern "C" int rsa_shard_backward_segments(const rsa_shard_backward_args* a, rsa
                     a->n_segments, a->stride,       nullptr,       a->item_target, a->item_scale,   const_cast<int32_t*>(a->step_dropped),
                     nullptr,       a->scale_out,    a->item_pad_row, a->workspace, a->workspace_bytes, 0};
   OwnPrepared P;
-  int rc = owner_prepare(c, P, false, s, "rsa_shard_backward_segments");
+  int rc = owner_prepare(c, P, OWN_PREP_ALL, s, "rsa_shard_backward_segments");
   if (rc != RSA_OK || P.slots == 0) return rc;
   RSA_CHECK_ARG(a->d_owner && a->qgrad_all, "rsa_shard_backward_segments: null pointer");
   // 3. the walk: query gradients, solo rows in place
@@ -579,13 +587,16 @@ static OwnCommon bpr_common(const rsa_shard_owner_bpr_args* a) {
 
 extern "C" int rsa_shard_owner_bpr_forward(const rsa_shard_owner_bpr_args* a, rsa_stream_t stream) {
   RSA_CHECK_ARG(a != nullptr, "rsa_shard_owner_bpr_forward: args is null");
-  RSA_CHECK_ARG(a->pos_rows && a->pos_score && a->d_slots && a->dsum_part && a->qgrad_all && a->num_neg >= 1 && a->mean_den >= 1,
+  RSA_CHECK_ARG(a->forward_parts >= 0 && a->forward_parts <= 2, "rsa_shard_owner_bpr_forward: forward_parts must be 0, 1 or 2");
+  RSA_CHECK_ARG(a->pos_rows && a->num_neg >= 1 && a->mean_den >= 1 &&
+                    (a->forward_parts == 1 || (a->pos_score && a->d_slots && a->dsum_part && a->qgrad_all)),
                 "rsa_shard_owner_bpr_forward: null pointer / bad sizes");
   hipStream_t s = (hipStream_t)stream;
   const OwnCommon c = bpr_common(a);
   OwnPrepared P;
-  int rc = owner_prepare(c, P, false, s, "rsa_shard_owner_bpr_forward");
-  if (rc != RSA_OK) return rc;
+  int rc = owner_prepare(c, P, a->forward_parts == 1 ? OWN_PREP_SORTS : a->forward_parts == 2 ? OWN_PREP_SCALE : OWN_PREP_ALL, s,
+                         "rsa_shard_owner_bpr_forward");
+  if (rc != RSA_OK || a->forward_parts == 1) return rc;
   if (hipMemsetAsync(a->dsum_part, 0, (size_t)a->n_query_rows * 4, s) != hipSuccess ||
       (a->loss_part && hipMemsetAsync(a->loss_part, 0, 4, s) != hipSuccess)) {
     rsa::set_error("rsa_shard_owner_bpr_forward: memset failed");
@@ -620,7 +631,7 @@ extern "C" int rsa_shard_owner_bpr_finish(const rsa_shard_owner_bpr_args* a, con
   hipStream_t s = (hipStream_t)stream;
   const OwnCommon c = bpr_common(a);
   OwnPrepared P;
-  int rc = owner_prepare(c, P, true, s, "rsa_shard_owner_bpr_finish");
+  int rc = owner_prepare(c, P, OWN_PREP_LAYOUT, s, "rsa_shard_owner_bpr_finish");
   if (rc != RSA_OK) return rc;
   RSA_CHECK_ARG(a->finish_parts >= 0 && a->finish_parts <= 2, "rsa_shard_owner_bpr_finish: finish_parts must be 0, 1 or 2");
   if (a->finish_parts == 2)

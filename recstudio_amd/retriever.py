@@ -54,6 +54,7 @@ def default_config():
                   'excluding_hist': False, 'scheduler': None, 'seed': 2022, 'weight_decay': 0.0,
                   'tensorboard_path': None, 'sparse_grad': False, 'device_loader': True, 'fused_optimizer': None,
                   'shard_slices': 1, 'shard_layout': 'block', 'shard_owner_loss': True, 'shard_init': 'auto',
+                  'shard_lookahead': False,
                   'fused_prefetch': True},
         'eval': {'batch_size': 128, 'cutoff': [5, 10, 20], 'val_metrics': ['ndcg', 'recall'], 'val_n_epoch': 1,
                  'test_metrics': ['ndcg', 'recall', 'precision', 'map', 'mrr', 'hit'], 'topk': 100,
@@ -747,6 +748,12 @@ class BaseRetriever(torch.nn.Module):
             score, topk_items = score[:, :k], topk_items[:, :k]
         return (score, topk_items, query) if return_query else (score, topk_items)
 
+    def _prepared_batches(self, loader, device):
+        for batch in loader:
+            batch = self._to_device(batch, device)
+            batch.pop('_n_valid', None)
+            yield batch
+
     def _fit_sharded(self, train_data, val_data, dist, backend=None, device=None):
         """One process per GPU, item table row-sharded, query tower replicated (``shard.ShardedRetriever``): rank r trains on
         its contiguous 1/G of every global batch (``train.batch_size`` is per rank), the negatives come from one job-wide
@@ -813,14 +820,23 @@ class BaseRetriever(torch.nn.Module):
             else:
                 loader = train_data.train_loader(batch_size=tr['batch_size'], shuffle=True, drop_last=False, ddp=True,
                                                  rank=rank, world=world)
-            for batch in loader:
-                batch = self._to_device(batch, device)
-                batch.pop('_n_valid', None)
+            # train.shard_lookahead: the weight-independent half of the NEXT batch's step (negatives, routing, key exchange,
+            # the owner's sorts) is issued on a second stream before the current batch is stepped (ShardedRetriever.prepare_step)
+            ahead = bool(tr.get('shard_lookahead', False)) and trainer.can_prepare()
+            self._shard['lookahead'] = ahead
+            ticket = None
+            for batch, batch_next in _with_next(self._prepared_batches(loader, device)):
+                if ahead and ticket is None:
+                    ticket = trainer.prepare_step(self._get_query_feat(batch), batch[self.fiid])
+                ticket_next = trainer.prepare_step(self._get_query_feat(batch_next), batch_next[self.fiid]) \
+                    if ahead and batch_next is not None else None
                 if optimizer is not None:
                     optimizer.zero_grad(set_to_none=False)
                 try:
-                    loss = trainer.training_step(self._get_query_feat(batch), batch[self.fiid], batch[self.frating])
+                    loss = trainer.training_step(self._get_query_feat(batch), batch[self.fiid], batch[self.frating], ticket=ticket)
+                    ticket = ticket_next
                 except RuntimeError as err:
+                    ticket = ticket_next
                     # an id distribution that outgrew the calibrated segment capacity: every rank raises at the same step
                     # (the sticky count is job-wide), the affected steps updated nothing, the capacity is recalibrated on
                     # the next step -- carry on instead of aborting the run
@@ -1108,6 +1124,16 @@ class _EmbedFn(torch.autograd.Function):
     def backward(ctx, g):
         (ids,) = ctx.saved_tensors
         return _embedding_grad(g, ids, ctx.n_rows), None
+
+
+def _with_next(it):
+    """(x0, x1), (x1, x2), ..., (x_last, None)"""
+    it = iter(it)
+    cur = next(it, None)
+    while cur is not None:
+        nxt = next(it, None)
+        yield cur, nxt
+        cur = nxt
 
 
 def _embedding_grad(g, ids, n_rows):

@@ -340,27 +340,56 @@ class HipBackend:
                           item_target, item_scale, qgrad_all, item_pad_row=-1, keys_grouped=False):
         """Scores, loss terms and gradients of the received negatives in ONE pass over their rows (see the header);
         -> ctx for ``owner_bpr_finish`` with ``dsum_part [Q]`` and ``loss_part`` (this rank's share of the mean loss)."""
-        dev, Q = q_all.device, q_all.shape[0]
+        ctx = self._owner_ctx(state, item_local, q_all.shape[0], recv_keys, n_seg, stride, pos_rows, n, mean_den, item_target,
+                              item_scale, item_pad_row, keys_grouped)
+        return self._owner_launch(ctx, q_all, pos_score, qgrad_all, parts=0)
+
+    def _owner_ctx(self, state, item_local, Q, recv_keys, n_seg, stride, pos_rows, n, mean_den, item_target, item_scale,
+                   item_pad_row, keys_grouped):
+        dev = item_local.device
         a = nat.ShardOwnerBprArgs()
         a.item_local, a.n_rows, a.dim, a.num_neg = ptr(item_local), item_local.shape[0], item_local.shape[1], int(n)
-        a.q_all, a.n_query_rows = ptr(ops._need(q_all, torch.float32, 'q_all')), Q
+        a.n_query_rows = int(Q)
         a.keys, a.n_segments, a.stride = ptr(recv_keys), int(n_seg), int(stride)
-        keep = {'pos_rows': ops._need(pos_rows, torch.int64, 'pos_rows'), 'pos_score': ops._need(pos_score, torch.float32, 'pos_score'),
+        keep = {'pos_rows': ops._need(pos_rows, torch.int64, 'pos_rows'),
                 'd_slots': torch.empty(n_seg * stride + Q, dtype=torch.float32, device=dev),
                 'dsum_part': torch.empty(Q, dtype=torch.float32, device=dev),
                 'loss_part': torch.empty((), dtype=torch.float32, device=dev),
-                'tensors': (item_local, q_all, recv_keys, item_target, item_scale, qgrad_all)}
-        a.pos_rows, a.pos_score, a.mean_den = ptr(keep['pos_rows']), ptr(keep['pos_score']), int(mean_den)
+                'tensors': [item_local, recv_keys, item_target, item_scale]}
+        a.pos_rows, a.mean_den = ptr(keep['pos_rows']), int(mean_den)
         a.item_target, a.item_scale = ptr(item_target), ptr(item_scale)
         a.step_dropped, a.overflow_sticky, a.scale_out = ptr(state['step_dropped']), ptr(state['overflow']), ptr(state['scale'])
-        a.qgrad_all, a.d_slots, a.dsum_part, a.loss_part = ptr(qgrad_all), ptr(keep['d_slots']), ptr(keep['dsum_part']), ptr(keep['loss_part'])
+        a.d_slots, a.dsum_part, a.loss_part = ptr(keep['d_slots']), ptr(keep['dsum_part']), ptr(keep['loss_part'])
         a.reduce_scratch, a.item_pad_row, a.keys_grouped = ptr(ops._scratch()), int(item_pad_row), int(bool(keys_grouped))
-        nbytes = int(nat.lib().rsa_shard_backward_workspace_bytes(int(n_seg), int(stride), Q))
+        nbytes = int(nat.lib().rsa_shard_backward_workspace_bytes(int(n_seg), int(stride), int(Q)))
         keep['ws'] = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         a.workspace, a.workspace_bytes = ptr(keep['ws']), nbytes
-        nat.check(nat.lib().rsa_shard_owner_bpr_forward(ctypes.byref(a), ops._stream()), 'rsa_shard_owner_bpr_forward')
         keep['args'] = a
         return keep
+
+    def _owner_launch(self, ctx, q_all, pos_score, qgrad_all, parts):
+        a = ctx['args']
+        if parts != 1:
+            ctx['pos_score'] = ops._need(pos_score, torch.float32, 'pos_score')
+            ctx['tensors'] += [q_all, qgrad_all]
+            a.q_all, a.pos_score, a.qgrad_all = ptr(ops._need(q_all, torch.float32, 'q_all')), ptr(ctx['pos_score']), ptr(qgrad_all)
+        a.forward_parts = int(parts)
+        nat.check(nat.lib().rsa_shard_owner_bpr_forward(ctypes.byref(a), ops._stream()), 'rsa_shard_owner_bpr_forward')
+        return ctx
+
+    @ops._on_device
+    def owner_bpr_prepare(self, state, item_local, Q, recv_keys, n_seg, stride, pos_rows, n, mean_den, item_target, item_scale,
+                          item_pad_row=-1, keys_grouped=False):
+        """The part of ``owner_bpr_forward`` that reads only the received keys and the positives' rows -- sort by row, solo
+        classification, the queries' runs (``forward_parts = 1``) -- on the current stream; -> ctx for ``owner_bpr_walk``."""
+        ctx = self._owner_ctx(state, item_local, Q, recv_keys, n_seg, stride, pos_rows, n, mean_den, item_target, item_scale,
+                              item_pad_row, keys_grouped)
+        return self._owner_launch(ctx, None, None, None, parts=1)
+
+    @ops._on_device
+    def owner_bpr_walk(self, ctx, q_all, pos_score, qgrad_all):
+        """The rest of the forward over a prepared ctx (``forward_parts = 2``): update scales, the pass over the rows."""
+        return self._owner_launch(ctx, q_all, pos_score, qgrad_all, parts=2)
 
     @ops._on_device
     def owner_bpr_finish(self, ctx, dsum_all, parts=0):
@@ -716,7 +745,8 @@ class ShardedItemTable:
         return (self.owner_loss and self.exchange == 'fixed' and self.chunks == 1 and hasattr(self.backend, 'owner_bpr_forward')
                 and self.item_local.shape[1] in getattr(self.backend, 'OWNER_DIMS', (64, 128, 256)))
 
-    def bpr_step_on_owners(self, q, pos, n, sampler, item_grad_local, item_scale=None, want_ids=False, defer_rows=False):
+    def bpr_step_on_owners(self, q, pos, n, sampler, item_grad_local, item_scale=None, want_ids=False, defer_rows=False,
+                           ticket=None):
         """The stock BPR training step with the loss evaluated ON THE OWNERS of the negatives (SURVEY.md 8e, steps 3-5 in one
         pass; include/recstudio_amd.h, rsa_shard_owner_bpr_forward): BPR's d loss/d neg needs only the query's positive
         score, so
@@ -738,41 +768,36 @@ class ShardedItemTable:
 
         ``defer_rows``: the last part of step 4 -- the sorted apply pass of the shared rows -- is NOT issued; a fourth return
         value is the function that issues it.  Nothing the caller does with ``d loss/d q`` depends on that pass, so a
-        caller with a second stream (``ShardedRetriever``: the query rows' exchange and update) runs the two side by side."""
+        caller with a second stream (``ShardedRetriever``: the query rows' exchange and update) runs the two side by side.
+        ``ticket``: what ``bpr_prepare_on_owners`` has issued for this batch already (``pos`` / ``sampler`` are then unused)."""
         be, st, plan = self.backend, self.state, self.plan
         B, G = pos.numel(), plan.world
-        S = int(getattr(be, 'BANKS', 1))
-        spec = be.sampler_spec(sampler)
         q_gather = self._all_gather_rows_start(q)
-        pos_all = self._all_gather_rows(pos.reshape(-1).contiguous())
-        neg = None
-        if spec is None:
-            _, neg, _ = self.sample(sampler, B, n, q.device, pos)
-            neg = neg.contiguous()
-        key = (B, n, 1, 'owners')
-        cap = self._cap.get(key)
-        if cap is None:
-            counts = be.sample_route(st, plan, self.rank, pos, n, 1, 0, spec, self.sample_generator, neg=neg, count_only=True,
-                                     banks=S, route_pos=False)
-            cap = self._capacity(key[:3], int(counts.max()), store=key)
-        r = be.sample_route(st, plan, self.rank, pos, n, 1, cap, spec, self.sample_generator, neg=neg, want_ids=want_ids,
-                            want_logp=False, banks=S, route_pos=False, group_by_query=self.group_by_query)
-        GS, stride = G * S, r['stride']
-        recv = self._all_to_all(r['send'])
+        if ticket is None:
+            pos_all, r, recv, neg_out = self._bpr_route(pos, n, sampler, want_ids)
+        else:
+            if ticket['B'] != B or ticket['n'] != n:
+                raise ValueError('bpr_step_on_owners: the ticket was prepared for another batch shape')
+            r, recv, neg_out = ticket['route'], ticket['recv'], ticket['neg_out']
+        GS, stride = G * int(getattr(be, 'BANKS', 1)), r['stride']
         q_all = q_gather()
-        if hasattr(be, 'pos_rows_and_scores'):
+        if ticket is not None:
+            pos_rows = ticket['pos_rows']
+            pos_part = be.pos_scores(self.item_local, q_all, pos_rows)
+        elif hasattr(be, 'pos_rows_and_scores'):
             pos_rows, pos_part = be.pos_rows_and_scores(self.item_local, q_all, pos_all, plan, self.rank)
         else:
-            mine = plan.owner(pos_all) == self.rank
-            pos_rows = torch.where(mine, plan.local(pos_all), torch.full_like(pos_all, -1))
+            pos_rows = self._own_pos_rows(pos_all)
             pos_part = be.pos_scores(self.item_local, q_all, pos_rows)
         pos_score = self._all_reduce_sum(pos_part)
         qgrad_all = torch.zeros_like(q_all)
-        ctx = be.owner_bpr_forward(st, self.item_local, q_all, recv, GS, stride, pos_rows, pos_score, n, B * G, item_grad_local,
-                                   item_scale, qgrad_all, item_pad_row=0 if self.rank == 0 else -1,
-                                   keys_grouped=bool(r.get('grouped', False)))
+        if ticket is not None:
+            ctx = be.owner_bpr_walk(ticket['ctx'], q_all, pos_score, qgrad_all)
+        else:
+            ctx = be.owner_bpr_forward(st, self.item_local, q_all, recv, GS, stride, pos_rows, pos_score, n, B * G, item_grad_local,
+                                       item_scale, qgrad_all, item_pad_row=0 if self.rank == 0 else -1,
+                                       keys_grouped=bool(r.get('grouped', False)))
         dsum_all = self._all_reduce_sum(ctx['dsum_part'] if self._solo else ctx['dsum_part'].clone())
-        neg_out = r.get('neg_ids') if spec is not None else neg
         if defer_rows:
             be.owner_bpr_finish(ctx, dsum_all, parts=1)
             dq = self._reduce_scatter_rows(qgrad_all, B)
@@ -785,6 +810,50 @@ class ShardedItemTable:
         dq = self._reduce_scatter_rows(qgrad_all, B)
         self._after_fixed_step()
         return ctx['loss_part'], dq, neg_out
+
+    def _own_pos_rows(self, pos_all):
+        mine = self.plan.owner(pos_all) == self.rank
+        return torch.where(mine, self.plan.local(pos_all), torch.full_like(pos_all, -1))
+
+    def _bpr_route(self, pos, n, sampler, want_ids):
+        """Steps 1 of ``bpr_step_on_owners`` that do not read a weight: the positives' ids gathered, the negatives drawn
+        and routed (the positives are not), the key exchange.  -> (pos_all, route, received segments, negative ids or None)."""
+        be, st, plan = self.backend, self.state, self.plan
+        B = pos.numel()
+        S = int(getattr(be, 'BANKS', 1))
+        spec = be.sampler_spec(sampler)
+        pos_all = self._all_gather_rows(pos.reshape(-1).contiguous())
+        neg = None
+        if spec is None:
+            _, neg, _ = self.sample(sampler, B, n, pos.device, pos)
+            neg = neg.contiguous()
+        key = (B, n, 1, 'owners')
+        cap = self._cap.get(key)
+        if cap is None:
+            counts = be.sample_route(st, plan, self.rank, pos, n, 1, 0, spec, self.sample_generator, neg=neg, count_only=True,
+                                     banks=S, route_pos=False)
+            cap = self._capacity(key[:3], int(counts.max()), store=key)
+        r = be.sample_route(st, plan, self.rank, pos, n, 1, cap, spec, self.sample_generator, neg=neg, want_ids=want_ids,
+                            want_logp=False, banks=S, route_pos=False, group_by_query=self.group_by_query)
+        recv = self._all_to_all(r['send'])
+        return pos_all, r, recv, (r.get('neg_ids') if spec is not None else neg)
+
+    def bpr_prepare_on_owners(self, pos, n, sampler, item_grad_local, item_scale=None, want_ids=False):
+        """The half of ``bpr_step_on_owners`` that reads no weight and no query -- the positives' ids gathered, the negatives
+        drawn and routed, the key exchange, and on the owner the sort by row, the solo classification and the queries' runs
+        -- issued on the CURRENT stream; -> ticket for ``bpr_step_on_owners(..., ticket=)``.  A trainer calls it for batch
+        t + 1 on a second stream before it steps batch t (``ShardedRetriever.prepare_step``): the exchange of the keys
+        and a fifth of the step's kernel time then run under the previous step.  Tickets are stepped once each, in the
+        order they were prepared (the draws consume the job's sample stream in that order: the negatives -- and every
+        weight -- are those of the same sequence of unprepared steps)."""
+        be, plan = self.backend, self.plan
+        B, G = pos.numel(), plan.world
+        pos_all, r, recv, neg_out = self._bpr_route(pos, n, sampler, want_ids)
+        pos_rows = self._own_pos_rows(pos_all)
+        GS = G * int(getattr(be, 'BANKS', 1))
+        ctx = be.owner_bpr_prepare(self.state, self.item_local, B * G, recv, GS, r['stride'], pos_rows, n, B * G, item_grad_local,
+                                   item_scale, item_pad_row=0 if self.rank == 0 else -1, keys_grouped=bool(r.get('grouped', False)))
+        return {'B': B, 'n': n, 'route': r, 'recv': recv, 'neg_out': neg_out, 'pos_rows': pos_rows, 'ctx': ctx}
 
     def backward(self, route, dpos, dneg, item_grad_local, item_scale=None):
         """Gradient exchange for one step.  ``route`` comes from a forward with
@@ -1095,6 +1164,19 @@ def allreduce_grads(params, dist, group=None, bucket_bytes=64 << 20):
     flush()
 
 
+def _record_stream_all(obj, stream):
+    """``Tensor.record_stream(stream)`` on every CUDA tensor reachable through dicts / lists / tuples of ``obj``."""
+    if torch.is_tensor(obj):
+        if obj.is_cuda:
+            obj.record_stream(stream)
+    elif isinstance(obj, dict):
+        for v in obj.values():
+            _record_stream_all(v, stream)
+    elif isinstance(obj, (list, tuple)):
+        for v in obj:
+            _record_stream_all(v, stream)
+
+
 class ShardedRetriever:
     """Two-tower training step with the item table row-sharded over the ranks and the query tower replicated
     (data parallel).  ``query_encoder(batch_feat) -> [B, d]``; ``sampler`` / ``loss_fn`` are the usual plugins
@@ -1126,7 +1208,7 @@ class ShardedRetriever:
         update -- a dozen launches of microseconds each -- run on a second stream beside the sorted apply pass of the
         shared item rows instead of behind it (neither reads what the other writes; same results)."""
         self.table, self.query_encoder, self.sampler, self.loss_fn = table, query_encoder, sampler, loss_fn
-        self.overlap_query_rows, self._side = bool(overlap_query_rows), None
+        self.overlap_query_rows, self._side, self._prep = bool(overlap_query_rows), None, None
         self.neg_count = int(neg_count)
         if sparse_query_rows is None:
             sparse_query_rows = query_sgd_lr is not None
@@ -1174,7 +1256,46 @@ class ShardedRetriever:
             return 'ssm'
         return None
 
-    def training_step(self, query_feat, pos_items, label=None):
+    def can_prepare(self):
+        """Does ``prepare_step`` cover this trainer's step (the owner-side BPR step)?"""
+        return self._fused_loss_kind() == 'bpr' and self.table.owner_loss_ok()
+
+    def prepare_step(self, query_feat, pos_items):
+        """One batch ahead: the half of the owner-side BPR step that reads no weight -- the negatives drawn and routed, the
+        key exchange, the owner's sort by row / solo classification / query runs (``ShardedItemTable.bpr_prepare_on_owners``)
+        -- issued on a second stream, so that it runs UNDER the step in front of it instead of at the head of its own:
+
+            ticket = trainer.prepare_step(feat0, pos0)
+            for feat1, pos1 in following_batches:
+                nxt = trainer.prepare_step(feat1, pos1)            # second stream: overlaps the step below
+                loss = trainer.training_step(feat0, pos0, ticket=ticket)
+                feat0, pos0, ticket = feat1, pos1, nxt
+
+        Tickets are stepped once each, in the order they were prepared; the negatives and every weight are those of the
+        same sequence of ``training_step`` calls without tickets (the same work, moved in time).  Between a ``prepare_step``
+        and the step of its ticket nothing else may route through this table (an evaluation pass, another trainer)."""
+        table = self.table
+        if not self.can_prepare():
+            raise NotImplementedError('prepare_step covers the owner-side BPR step (stock BPRLoss, ShardedItemTable(owner_loss=True), '
+                                      'embed_dim in the backend\'s OWNER_DIMS)')
+        args = (pos_items, self.neg_count, self.sampler, self.item_grad_local, self.item_scale)
+        if not pos_items.is_cuda:
+            with torch.no_grad():
+                return dict(table.bpr_prepare_on_owners(*args, want_ids=self.keep_neg_ids), ready=None)
+        dev = pos_items.device
+        if self._prep is None:
+            self._prep = torch.cuda.Stream(device=dev)
+        main = torch.cuda.current_stream(dev)
+        self._prep.wait_stream(main)                  # the batch tensors may have been produced on the main stream
+        with torch.no_grad(), torch.cuda.stream(self._prep):
+            ticket = table.bpr_prepare_on_owners(*args, want_ids=self.keep_neg_ids)
+            ready = torch.cuda.Event()
+            ready.record(self._prep)
+        _record_stream_all(ticket, main)              # allocated on the second stream, consumed (and freed) on the main one
+        ticket['ready'] = ready
+        return ticket
+
+    def training_step(self, query_feat, pos_items, label=None, ticket=None):
         """Returns this rank's share of the global mean loss (local mean / world size) after running backward:
         ``item_grad_local`` holds the gradient of the GLOBAL mean loss for the rows this rank owns (or the rows have
         been updated in place, ``item_sgd_lr``), and the query tower's gradient is the one a single process would
@@ -1188,12 +1309,17 @@ class ShardedRetriever:
             q = self.query_encoder(query_feat)
         B = pos_items.numel()
         kind = self._fused_loss_kind()
+        if ticket is not None:
+            if not (kind == 'bpr' and table.owner_loss_ok()):
+                raise ValueError('training_step(ticket=...): tickets belong to the owner-side BPR step')
+            if ticket.get('ready') is not None:
+                torch.cuda.current_stream(q.device).wait_event(ticket['ready'])
         if kind == 'bpr' and table.owner_loss_ok():
             # the loss on the owners of the negatives: one pass over the item rows per step (bpr_step_on_owners)
             if self.sparse_query_rows and self.overlap_query_rows and q.is_cuda:
                 loss, dq, self.last_neg, finish_rows = table.bpr_step_on_owners(
                     q.detach(), pos_items, self.neg_count, self.sampler, self.item_grad_local, self.item_scale,
-                    want_ids=self.keep_neg_ids, defer_rows=True)
+                    want_ids=self.keep_neg_ids, defer_rows=True, ticket=ticket)
                 if self._side is None:
                     self._side = torch.cuda.Stream(device=q.device)
                 main = torch.cuda.current_stream(q.device)
@@ -1206,7 +1332,8 @@ class ShardedRetriever:
                 main.wait_stream(self._side)
                 return loss
             loss, dq, self.last_neg = table.bpr_step_on_owners(q.detach(), pos_items, self.neg_count, self.sampler,
-                                                               self.item_grad_local, self.item_scale, want_ids=self.keep_neg_ids)
+                                                               self.item_grad_local, self.item_scale, want_ids=self.keep_neg_ids,
+                                                               ticket=ticket)
             if not self.sparse_query_rows and q.requires_grad:
                 q.backward(dq)
         elif kind is not None:

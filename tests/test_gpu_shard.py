@@ -321,6 +321,34 @@ def _two_rank_worker(rank, world, port, backend, result_dir, layout='block'):
                                    rtol=1e-5, atol=1e-7)
         reps = gather_cpu(tower2.weight.detach())
         assert torch.equal(reps[0], reps[1])
+        # three steps one batch ahead (prepare_step on the second stream / ticket) == the same three steps in place
+        runs = []
+        batches = [(uid.roll(k), pos.roll(2 * k)) for k in range(3)]
+        for ahead in (False, True):
+            tower3 = torch.nn.Embedding(U, d).to(dev)
+            with torch.no_grad():
+                tower3.weight.copy_(user)
+            tbl3 = ShardedItemTable(plan.take(item_d, rank).contiguous().clone(), plan, rank, comm, sample_seed=23)
+            tr3 = ShardedRetriever(tbl3, tower3, ra.UniformSampler(N), ra.BPRLoss(), 64, item_sgd_lr=0.5, query_sgd_lr=0.25,
+                                   keep_neg_ids=True)
+            seen = []
+            if ahead:
+                tk = tr3.prepare_step(*batches[0])
+                for k in range(3):
+                    nxt = tr3.prepare_step(*batches[k + 1]) if k < 2 else None
+                    seen.append((float(tr3.training_step(*batches[k], ticket=tk)), tr3.last_neg.clone()))
+                    tk = nxt
+            else:
+                for k in range(3):
+                    seen.append((float(tr3.training_step(*batches[k])), tr3.last_neg.clone()))
+            tbl3.check_overflow()
+            runs.append((tbl3.item_local.clone(), tower3.weight.detach().clone(), seen))
+        for (la, na), (lb, nb) in zip(runs[0][2], runs[1][2]):
+            assert torch.equal(na, nb)                                       # the same draws
+            np.testing.assert_allclose(la, lb, rtol=1e-5)
+        np.testing.assert_allclose(runs[1][0].cpu(), runs[0][0].cpu(), rtol=1e-5, atol=1e-7)
+        np.testing.assert_allclose(runs[1][1].cpu(), runs[0][1].cpu(), rtol=1e-5, atol=1e-7)
+        assert (runs[0][0] - plan.take(item_d, rank)).abs().max() > 1e-4     # the steps trained
         open(os.path.join(result_dir, f'ok{rank}'), 'w').write('ok')
     finally:
         dist.destroy_process_group()

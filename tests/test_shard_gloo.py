@@ -201,6 +201,16 @@ class CheckerBackend:
                 'item_target': item_target, 'item_scale': item_scale, 'qgrad_all': qgrad_all, 'pad': item_pad_row,
                 'dsum_part': dsum_part, 'loss_part': loss_part}
 
+    def owner_bpr_prepare(self, state, item_local, Q, recv_keys, n_seg, stride, pos_rows, n, mean_den, item_target, item_scale,
+                          item_pad_row=-1, keys_grouped=False):
+        return {'prepared': (state, item_local, recv_keys, n_seg, stride, pos_rows, n, mean_den, item_target, item_scale,
+                             item_pad_row, keys_grouped)}
+
+    def owner_bpr_walk(self, ctx, q_all, pos_score, qgrad_all):
+        state, item_local, recv_keys, n_seg, stride, pos_rows, n, mean_den, item_target, item_scale, pad, grouped = ctx['prepared']
+        return self.owner_bpr_forward(state, item_local, q_all, recv_keys, n_seg, stride, pos_rows, pos_score, n, mean_den,
+                                      item_target, item_scale, qgrad_all, item_pad_row=pad, keys_grouped=grouped)
+
     def owner_bpr_finish(self, ctx, dsum_all, parts=0):
         own = ctx['pos_rows'] >= 0
         qi = torch.nonzero(own).flatten()
@@ -604,6 +614,30 @@ def _train_worker(rank, world, port, n_items, d, B, n, result_dir, layout='block
                 np.testing.assert_allclose(tbl_s.item_local.numpy(), (plan.take(item, rank) - 0.4 * tr_f.item_grad_local).numpy(),
                                            rtol=1e-4, atol=1e-6)
                 np.testing.assert_allclose(tower_s.weight.grad.numpy(), tower_f.weight.grad.numpy(), rtol=1e-5, atol=1e-7)
+                # ... and three such steps one batch ahead (prepare_step / ticket): the same draws, the same weights
+                runs = []
+                for ahead in (False, True):
+                    tbl_a = ShardedItemTable(plan.take(item, rank).clone(), plan, rank, dist, backend=CheckerBackend(), sample_seed=77)
+                    emb_a = torch.nn.Embedding(U, d, padding_idx=0)
+                    with torch.no_grad():
+                        emb_a.weight.copy_(emb_w)
+                    tr_a = ShardedRetriever(tbl_a, emb_a, smp, loss_cls(), n, item_sgd_lr=0.2, query_sgd_lr=0.2, keep_neg_ids=True)
+                    batches = [(uids[(rank + k) % world], poss[(rank + k) % world]) for k in range(3)]
+                    seen = []
+                    if ahead:
+                        tk = tr_a.prepare_step(*batches[0])
+                        for k in range(3):
+                            nxt = tr_a.prepare_step(*batches[k + 1]) if k < 2 else None
+                            seen.append((tr_a.training_step(*batches[k], ticket=tk).clone(), tr_a.last_neg.clone()))
+                            tk = nxt
+                    else:
+                        for k in range(3):
+                            seen.append((tr_a.training_step(*batches[k]).clone(), tr_a.last_neg.clone()))
+                    runs.append((tbl_a.item_local.clone(), emb_a.weight.detach().clone(), seen))
+                assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1])
+                for (la, na), (lb, nb) in zip(runs[0][2], runs[1][2]):
+                    assert torch.equal(la, lb) and torch.equal(na, nb)
+                assert not torch.equal(runs[0][0], plan.take(item, rank))
         open(os.path.join(result_dir, f'ok{rank}'), 'w').write('ok')
     finally:
         dist.destroy_process_group()
@@ -722,7 +756,8 @@ def _fit_worker(rank, world, port, result_dir, epochs, batch_global, train_extra
         dist.all_gather(tower, model.query_encoder.weight.detach())
         assert all(torch.equal(tower[0], t) for t in tower)
         torch.save({'best': best, 'val': dict(model.logged_metrics), 'test': test, 'losses': losses,
-                    'item': model.item_encoder.weight.detach().clone(), 'lo': sh['lo'], 'tower': tower[0]},
+                    'item': model.item_encoder.weight.detach().clone(), 'lo': sh['lo'], 'tower': tower[0],
+                    'lookahead': bool(sh.get('lookahead'))},
                    os.path.join(result_dir, f'w{world}r{rank}.pt'))
     finally:
         dist.destroy_process_group()
@@ -806,6 +841,13 @@ def test_fit_two_ranks_fused_sgd_follows_the_scheduler(tmp_path):
     n1 = one['losses'].numel() // 2
     assert torch.equal(const['losses'][:n1], one['losses'][:n1])                 # the first epoch: the same rate
     assert (const['item'] - one['item']).abs().max() > 1e-5                      # the second: 196 instead of 200
+    # train.shard_lookahead: every step's negatives / routing / key exchange / owner sorts issued one batch ahead -- the same run
+    os.makedirs(tmp_path / 'la')
+    mp.spawn(_fit_worker, args=(2, _free_port(), str(tmp_path / 'la'), 2, 4096, dict(extra, shard_lookahead=True)), nprocs=2, join=True)
+    la = [torch.load(tmp_path / 'la' / f'w2r{r}.pt', weights_only=False) for r in range(2)]
+    for t, ref in zip(la, two):
+        assert t['lookahead'] and not ref['lookahead']
+        assert torch.equal(t['losses'], ref['losses']) and torch.equal(t['item'], ref['item']) and torch.equal(t['tower'], ref['tower'])
 
 
 

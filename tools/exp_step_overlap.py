@@ -1,6 +1,7 @@
 """In-process A/B of the sharded training step (configs[3] per-GPU shape, world size 1) with the query rows' exchange and
-update on a second stream (ShardedRetriever(overlap_query_rows=True), the default) and behind the apply pass: alternating
-rounds of whole training steps, HIP events around each round.  usage: python tools/exp_step_overlap.py"""
+update on a second stream (ShardedRetriever(overlap_query_rows=True), the default), behind the apply pass, and one batch
+ahead (prepare_step: routing, key exchange, the owner's sorts under the step in front): alternating rounds of whole
+training steps, HIP events around each round.  usage: python tools/exp_step_overlap.py"""
 import json
 import os
 import sys
@@ -29,16 +30,29 @@ for name, flag in (('side_stream', True), ('serial', False)):
     tbl = shard.ShardedItemTable(item, shard.RowShardPlan(n_blk, 1), 0, dist, check_every=0)
     trainers[name] = shard.ShardedRetriever(tbl, tower, ra.UniformSampler(n_blk), ra.BPRLoss(), n_neg, item_sgd_lr=1e-3,
                                             query_sgd_lr=1e-3, overlap_query_rows=flag)
+trainers['one_batch_ahead'] = trainers['side_stream']
+
+
+def run(k, tr, steps):
+    if k != 'one_batch_ahead':
+        for _ in range(steps):
+            tr.training_step(uid, pos)
+        return
+    ticket = tr.prepare_step(uid, pos)
+    for i in range(steps):
+        nxt = tr.prepare_step(uid, pos) if i + 1 < steps else None      # second stream: under the step below
+        tr.training_step(uid, pos, ticket=ticket)
+        ticket = nxt
+
+
 res = {k: [] for k in trainers}
 for rnd in range(5):
     for k, tr in trainers.items():
-        for _ in range(5):
-            tr.training_step(uid, pos)
+        run(k, tr, 5)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        for _ in range(30):
-            tr.training_step(uid, pos)
+        run(k, tr, 30)
         e1.record()
         torch.cuda.synchronize()
         res[k].append(e0.elapsed_time(e1) / 30)
