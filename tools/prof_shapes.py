@@ -164,7 +164,10 @@ while (time.perf_counter() - t0) * 1e3 < WARM_MS:
         step()
         WARM += 1
     torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
 for _ in range(K):
     step()
+e1.record()
 torch.cuda.synchronize()
-print(json.dumps({'shape': shape, 'steps': K, 'warmup': WARM}))
+print(json.dumps({'shape': shape, 'steps': K, 'warmup': WARM, 'event_us_per_step': round(e0.elapsed_time(e1) / K * 1e3, 2)}))
