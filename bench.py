@@ -739,6 +739,18 @@ def main():
                     st1()
                     res1[key] = time_gpu(st1, 50, 5) * 1e3
                     tbl.check_overflow()
+                    if key == 'ms_per_step':
+                        # one batch ahead: the next step's draw + routing (+ key exchange) on a second stream under this one
+                        look1 = {'t': tbl.prepare_forward(p1, n1k, us, fused_loss='bpr', want_ids=False)}
+
+                        def st1_ahead(tbl=tbl, look1=look1):
+                            nxt = tbl.prepare_forward(p1, n1k, us, fused_loss='bpr', want_ids=False)
+                            tbl.sample_and_score(user, u1, p1, n1k, us, fused_loss='bpr', want_ids=False, want_grad=True, ticket=look1['t'])
+                            look1['t'] = nxt
+                        st1_ahead()
+                        res1['one_batch_ahead_ms'] = time_gpu(st1_ahead, 50, 5) * 1e3
+                        tbl.sample_and_score(user, u1, p1, n1k, us, fused_loss='bpr', want_ids=False, want_grad=True, ticket=look1['t'])
+                        tbl.check_overflow()
                 t1 = res1['ms_per_step']
                 alg1 = bytes_per_triplet(d, n1k, False) * b1k * n1k
                 extra['sharded_world1'] = with_profile(
@@ -747,6 +759,7 @@ def main():
                      'ms_per_step': round(t1, 4), 'M_triplets_s': round(b1k * n1k / t1 / 1e3, 2),
                      'frac_of_hbm_peak': round(alg1 / t1 / 1e6 / HBM_PEAK_GBS, 4),
                      'with_collectives_ms': round(res1['with_collectives_ms'], 4),
+                     'one_batch_ahead_ms': round(res1['one_batch_ahead_ms'], 4),
                      'kernels_per_step': 'embedding_gather, shard_sample_route, fused_fwd_kernel (segment form), shard_home'},
                     'sharded_world1_step', alg1, whole_step=True)
                 # ... and the complete in-place-SGD TRAINING step of that shape (the per-GPU ceiling of an 8-GPU training
@@ -901,6 +914,26 @@ def main():
         def timed_max(fn, steps, warm):
             fn()
             return max_over_ranks(time_gpu(fn, steps, warm, dist) * 1e3)
+        # The same K steps ONE BATCH AHEAD: step t + 1's draw, routing and key exchange -- the largest message of the step --
+        # issued on a second stream before step t is scored (ShardedItemTable.prepare_forward).  Beside the headline.
+        try:
+            tbl_a = shard.ShardedItemTable(item_local, plan, rank, dist, slack=table.slack, check_every=0, force_collectives=True)
+            look_a = {'t': tbl_a.prepare_forward(pos, n, sampler, fused_loss='bpr', want_ids=False)}
+
+            def ahead_fwd():
+                nxt = tbl_a.prepare_forward(pos, n, sampler, fused_loss='bpr', want_ids=False)
+                tbl_a.sample_and_score(user, uid, pos, n, sampler, fused_loss='bpr', want_ids=False, want_grad=True, ticket=look_a['t'])
+                look_a['t'] = nxt
+            ms_a = timed_max(ahead_fwd, args.steps, args.warmup)
+            tbl_a.sample_and_score(user, uid, pos, n, sampler, fused_loss='bpr', want_ids=False, want_grad=True, ticket=look_a['t'])
+            tbl_a.check_overflow()
+            extra['one_batch_ahead'] = {'ms_per_step': round(ms_a, 4), 'M_triplets_s': round(world * B * n / ms_a / 1e3, 2),
+                                        'efficiency_vs_world1': round(ms_solo / ms_a, 4),
+                                        'what': 'side figure: the same K steps with the next step\'s draw, routing and key exchange on '
+                                                'a second stream under the current step; the headline is the in-place step'}
+            del tbl_a
+        except Exception as e:
+            extra['one_batch_ahead'] = {'error': repr(e)[:200]}
         # The same K steps with the step cut into 2 / 4 slices whose exchanges overlap the scoring of the neighbouring
         # slices (ShardedItemTable(chunks=...)): reported BESIDE the headline, which stays the single-slice time
         try:

@@ -669,15 +669,11 @@ class ShardedItemTable:
             self._poll_due = self._steps + self.LAG
 
     # -- the step ---------------------------------------------------------------------------------
-    def _fixed_step(self, q_gather, pos, n, spec, neg=None, keep_route=False, fused_loss=None, mean_den=None,
-                    log_pos=None, log_neg=None, want_ids=True, want_logp=True, want_scores=True, want_grad=False):
-        """Version 2 of the fixed-capacity step.  Issue order on the current stream: ONE routing launch for all
-        ``chunks`` query slices (each slice's key all-to-all follows on the communicator's stream), then per slice:
-        wait for its keys, score, start the score all-to-all; finally wait for all scores and run the home kernel
-        once.  Collectives of one communicator run in issue order, so slice c's keys arrive while slice c-1 is being
-        scored and its scores go back while slice c+1 is being scored.  Every rank issues the same sequence."""
+    def _route_and_exchange(self, pos, n, spec, neg, fused_loss, want_ids, want_logp):
+        """The part of the fixed step that reads no weight and no query: calibration (first call), the routing launch, the key
+        exchange of every slice.  -> (route, slices, [wait functions of the key exchanges])."""
         be, st, plan = self.backend, self.state, self.plan
-        B, G = pos.numel(), plan.world
+        B = pos.numel()
         C = self.chunks if (self.chunks > 1 and B % self.chunks == 0) else 1
         S = int(getattr(be, 'BANKS', 1))           # segments per (slice, owner): every consumer just sees G * S segments
         # (the capacity is calibrated per id SOURCE: ids a plugin hands in -- popularity-skewed, say -- must not reuse the
@@ -693,21 +689,78 @@ class ShardedItemTable:
         # the sampler's log-probabilities: BPRLoss ignores them (loss_func.py:55-59), everything else gets them
         r = be.sample_route(st, plan, self.rank, pos, n, C, cap, spec, self.sample_generator, neg=neg,
                             want_ids=want_ids, want_logp=want_logp and fused_loss != 'bpr', banks=S)
+        per = plan.world * S * r['stride']
+        send = r['send']
+        if C == 1:
+            return r, C, [lambda: self._all_to_all(send)]
+        return r, C, [self._all_to_all_start(send[c * per:(c + 1) * per]) for c in range(C)]
+
+    def prepare_forward(self, pos, n, sampler, fused_loss=None, want_ids=True, want_logp=True):
+        """One batch ahead (fixed exchange, in-kernel sampler): the negatives of ``pos``'s batch drawn and routed and the key
+        exchange done, on a SECOND stream when the ids live on a GPU -- under whatever the main stream is doing (the step in
+        front).  -> ticket for ``forward_queries(..., ticket=)`` / ``sample_and_score(..., ticket=)`` with the same ``n`` /
+        ``fused_loss``.  Tickets are consumed once each, in the order they were prepared (the draws follow the job's sample
+        stream in that order); nothing else may route through this table in between."""
+        spec = self.backend.sampler_spec(sampler) if self.exchange == 'fixed' else None
+        if spec is None:
+            raise NotImplementedError("prepare_forward: exchange='fixed' with one of this package's in-kernel samplers")
+
+        def issue():
+            r, C, waits = self._route_and_exchange(pos, n, spec, None, fused_loss, want_ids, want_logp)
+            return {'B': pos.numel(), 'n': int(n), 'C': C, 'fused_loss': fused_loss, 'route': r, 'recv': [w() for w in waits]}
+        return self._on_second_stream(issue, pos)
+
+    def _on_second_stream(self, issue, like):
+        """``issue()`` on this table's second stream (CPU tensors: in place); the ticket it returns gets a ``ready`` event and
+        its tensors are handed to the main stream."""
+        if not like.is_cuda:
+            with torch.no_grad():
+                return dict(issue(), ready=None)
+        dev = like.device
+        if getattr(self, '_second', None) is None:
+            self._second = torch.cuda.Stream(device=dev)
+        main = torch.cuda.current_stream(dev)
+        self._second.wait_stream(main)                # the batch tensors may have been produced on the main stream
+        with torch.no_grad(), torch.cuda.stream(self._second):
+            ticket = issue()
+            ready = torch.cuda.Event()
+            ready.record(self._second)
+        _record_stream_all(ticket, main)              # allocated on the second stream, consumed (and freed) on the main one
+        ticket['ready'] = ready
+        return ticket
+
+    def _fixed_step(self, q_gather, pos, n, spec, neg=None, keep_route=False, fused_loss=None, mean_den=None,
+                    log_pos=None, log_neg=None, want_ids=True, want_logp=True, want_scores=True, want_grad=False, ticket=None):
+        """Version 2 of the fixed-capacity step.  Issue order on the current stream: ONE routing launch for all
+        ``chunks`` query slices (each slice's key all-to-all follows on the communicator's stream), then per slice:
+        wait for its keys, score, start the score all-to-all; finally wait for all scores and run the home kernel
+        once.  Collectives of one communicator run in issue order, so slice c's keys arrive while slice c-1 is being
+        scored and its scores go back while slice c+1 is being scored.  Every rank issues the same sequence."""
+        be, st, plan = self.backend, self.state, self.plan
+        B, G = pos.numel(), plan.world
+        S = int(getattr(be, 'BANKS', 1))
+        if ticket is None:
+            r, C, waits = self._route_and_exchange(pos, n, spec, neg, fused_loss, want_ids, want_logp)
+        else:
+            if (ticket['B'], ticket['n'], ticket['fused_loss']) != (B, int(n), fused_loss):
+                raise ValueError('the ticket was prepared for another batch shape / loss')
+            if ticket.get('ready') is not None:
+                torch.cuda.current_stream(pos.device).wait_event(ticket['ready'])
+            r, C = ticket['route'], ticket['C']
+            waits = [(lambda rk=rk: rk) for rk in ticket['recv']]
         GS = G * S
         stride, per = r['stride'], GS * r['stride']
-        send = r['send']
-        scores_home = torch.empty(C * per, dtype=torch.float32, device=send.device)
+        scores_home = torch.empty(C * per, dtype=torch.float32, device=r['send'].device)
         recv_keys = []
         if C == 1:
             q_all = q_gather()
-            rk = self._all_to_all(send)
+            rk = waits[0]()
             recv_keys.append(rk)
             if self._solo:
                 be.score_segments(st, self.item_local, q_all, rk, GS, stride, first=True, out=scores_home)
             else:
                 self._all_to_all(be.score_segments(st, self.item_local, q_all, rk, GS, stride, first=True), out=scores_home)
         else:
-            waits = [self._all_to_all_start(send[c * per:(c + 1) * per]) for c in range(C)]
             q_all = q_gather()
             back = []
             for c, w in enumerate(waits):
@@ -932,19 +985,22 @@ class ShardedItemTable:
                                    shard=(self.rank, self.plan.world, self.sample_generator))
 
     def forward_queries(self, q, pos, n, sampler, keep_route=False, fused_loss=None, mean_den=None, want_ids=True,
-                        want_scores=True, want_grad=False):
+                        want_scores=True, want_grad=False, ticket=None):
         """BaseRetriever.forward (+ optionally the loss) for the own query vectors ``q [B, d]`` against the sharded
         table.  With one of this package's in-kernel samplers and the fixed exchange the negatives are drawn inside
         the routing launch (``neg_ids`` only with ``want_ids``); any other Sampler plugin is called and its ids are
         routed as given.  ``fused_loss`` ('bpr' | 'ssm', fixed exchange): the home kernel evaluates the loss --
         ``loss`` = sum of the row losses / ``mean_den`` (default B) -- and, with ``keep_route``, leaves d loss/d score
-        in routed order in the route for ``backward(route, None, None, ...)``."""
+        in routed order in the route for ``backward(route, None, None, ...)``.  ``ticket``: what ``prepare_forward`` issued
+        for this batch one step earlier (routing + key exchange)."""
         B = pos.numel()
         q_gather = self._all_gather_rows_start(q)
         spec = self.backend.sampler_spec(sampler) if self.exchange == 'fixed' else None
+        if ticket is not None and spec is None:
+            raise ValueError('forward_queries(ticket=...): tickets belong to the fixed exchange with an in-kernel sampler')
         if spec is not None:
             out = self._fixed_step(q_gather, pos, n, spec, keep_route=keep_route, fused_loss=fused_loss, mean_den=mean_den,
-                                   want_ids=want_ids, want_scores=want_scores, want_grad=want_grad)
+                                   want_ids=want_ids, want_scores=want_scores, want_grad=want_grad, ticket=ticket)
             if out['log_neg_prob'] is None:          # UniformSampler: int64 zeros (sampler.py:113-114), cached constants
                 out['log_pos_prob'] = ops.zero_logp(pos.shape, pos.device)
                 out['log_neg_prob'] = ops.zero_logp((B, n), pos.device)
@@ -1208,7 +1264,7 @@ class ShardedRetriever:
         update -- a dozen launches of microseconds each -- run on a second stream beside the sorted apply pass of the
         shared item rows instead of behind it (neither reads what the other writes; same results)."""
         self.table, self.query_encoder, self.sampler, self.loss_fn = table, query_encoder, sampler, loss_fn
-        self.overlap_query_rows, self._side, self._prep = bool(overlap_query_rows), None, None
+        self.overlap_query_rows, self._side = bool(overlap_query_rows), None
         self.neg_count = int(neg_count)
         if sparse_query_rows is None:
             sparse_query_rows = query_sgd_lr is not None
@@ -1278,22 +1334,9 @@ class ShardedRetriever:
         if not self.can_prepare():
             raise NotImplementedError('prepare_step covers the owner-side BPR step (stock BPRLoss, ShardedItemTable(owner_loss=True), '
                                       'embed_dim in the backend\'s OWNER_DIMS)')
-        args = (pos_items, self.neg_count, self.sampler, self.item_grad_local, self.item_scale)
-        if not pos_items.is_cuda:
-            with torch.no_grad():
-                return dict(table.bpr_prepare_on_owners(*args, want_ids=self.keep_neg_ids), ready=None)
-        dev = pos_items.device
-        if self._prep is None:
-            self._prep = torch.cuda.Stream(device=dev)
-        main = torch.cuda.current_stream(dev)
-        self._prep.wait_stream(main)                  # the batch tensors may have been produced on the main stream
-        with torch.no_grad(), torch.cuda.stream(self._prep):
-            ticket = table.bpr_prepare_on_owners(*args, want_ids=self.keep_neg_ids)
-            ready = torch.cuda.Event()
-            ready.record(self._prep)
-        _record_stream_all(ticket, main)              # allocated on the second stream, consumed (and freed) on the main one
-        ticket['ready'] = ready
-        return ticket
+        return table._on_second_stream(
+            lambda: table.bpr_prepare_on_owners(pos_items, self.neg_count, self.sampler, self.item_grad_local, self.item_scale,
+                                                want_ids=self.keep_neg_ids), pos_items)
 
     def training_step(self, query_feat, pos_items, label=None, ticket=None):
         """Returns this rank's share of the global mean loss (local mean / world size) after running backward:

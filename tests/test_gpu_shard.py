@@ -349,6 +349,22 @@ def _two_rank_worker(rank, world, port, backend, result_dir, layout='block'):
         np.testing.assert_allclose(runs[1][0].cpu(), runs[0][0].cpu(), rtol=1e-5, atol=1e-7)
         np.testing.assert_allclose(runs[1][1].cpu(), runs[0][1].cpu(), rtol=1e-5, atol=1e-7)
         assert (runs[0][0] - plan.take(item_d, rank)).abs().max() > 1e-4     # the steps trained
+        # the forward step one batch ahead (prepare_forward on the second stream / ticket), whole and in two slices
+        for ch in (1, 2):
+            plain = ShardedItemTable(plan.take(item_d, rank).contiguous(), plan, rank, comm, sample_seed=41, chunks=ch)
+            ahead = ShardedItemTable(plan.take(item_d, rank).contiguous(), plan, rank, comm, sample_seed=41, chunks=ch)
+            smp = ra.UniformSampler(N)
+            b256 = [(uid[:256].roll(k).contiguous(), pos[:256].roll(k).contiguous()) for k in range(3)]
+            tk = ahead.prepare_forward(b256[0][1], n, smp, fused_loss='bpr')
+            for k in range(3):
+                nxt = ahead.prepare_forward(b256[k + 1][1], n, smp, fused_loss='bpr') if k < 2 else None
+                a = plain.sample_and_score(user, *b256[k], n, smp, fused_loss='bpr', want_grad=True)
+                b = ahead.sample_and_score(user, *b256[k], n, smp, fused_loss='bpr', want_grad=True, ticket=tk)
+                tk = nxt
+                assert torch.equal(a['neg_ids'], b['neg_ids'])
+                assert torch.equal(a['pos_score'], b['pos_score']) and torch.equal(a['neg_score'], b['neg_score'])
+                np.testing.assert_allclose(float(a['loss']), float(b['loss']), rtol=1e-6)
+            ahead.check_overflow()
         open(os.path.join(result_dir, f'ok{rank}'), 'w').write('ok')
     finally:
         dist.destroy_process_group()

@@ -428,6 +428,29 @@ def _chunk_worker(rank, world, port, n_items, d, B, n, chunks, result_dir, layou
             np.testing.assert_allclose(qb.numpy(), qa.numpy(), rtol=1e-5, atol=1e-5)
             np.testing.assert_allclose(gb.numpy(), ga.numpy(), rtol=1e-5, atol=1e-5)
         piped.check_overflow()
+        # one batch ahead (prepare_forward / ticket), whole and sliced: the same draws, scores, loss and gradients as in place
+        for ch in (1, chunks):
+            plain = ShardedItemTable(plan.take(item, rank).clone(), plan, rank, dist, backend=CheckerBackend(), chunks=ch, sample_seed=31)
+            ahead = ShardedItemTable(plan.take(item, rank).clone(), plan, rank, dist, backend=CheckerBackend(), chunks=ch, sample_seed=31)
+            batches = [(uid.roll(k), pos.roll(k)) for k in range(3)]
+            tk = ahead.prepare_forward(batches[0][1], n, sampler, fused_loss='bpr')
+            for k in range(3):
+                nxt = ahead.prepare_forward(batches[k + 1][1], n, sampler, fused_loss='bpr') if k < 2 else None
+                u_k, p_k = batches[k]
+                a = plain.sample_and_score(user, u_k, p_k, n, sampler, keep_route=True, fused_loss='bpr')
+                b = ahead.sample_and_score(user, u_k, p_k, n, sampler, keep_route=True, fused_loss='bpr', ticket=tk)
+                tk = nxt
+                assert torch.equal(a['neg_ids'], b['neg_ids']) and torch.equal(a['loss'], b['loss'])
+                assert torch.equal(a['pos_score'], b['pos_score']) and torch.equal(a['neg_score'], b['neg_score'])
+                ga, gb = torch.zeros(plan.n_local(rank), d), torch.zeros(plan.n_local(rank), d)
+                qa = plain.backward(a['route'], None, None, ga)
+                qb = ahead.backward(b['route'], None, None, gb)
+                assert torch.equal(qa, qb) and torch.equal(ga, gb)
+            with pytest.raises(ValueError, match='another batch shape'):
+                ahead.sample_and_score(user, uid[:B // 2], pos[:B // 2], n, sampler,
+                                       ticket=dict(ahead.prepare_forward(pos, n, sampler), ready=None))
+            ahead.sample_and_score(user, uid, pos, n, sampler)          # (consumes nothing of the stale ticket: a fresh route)
+            ahead.check_overflow()
         # a batch the slices do not divide runs whole
         p1, s1 = piped.score_ids(user[uid[:B - 1]], pos[:B - 1], a['neg_ids'][:B - 1])
         w1p, w1n = oracle.retriever_forward(item, user[uid[:B - 1]], pos[:B - 1], a['neg_ids'][:B - 1])
