@@ -293,6 +293,8 @@ def main():
 
     import recstudio_amd as ra
     from recstudio_amd import _native as nat
+    from recstudio_amd.retriever import _above_second_stream
+    hi_cache = {}
     ra._native.lib()     # no extension, no benchmark
     if world > 1:        # torchrun pins OMP_NUM_THREADS=1: give each rank its share of the host cores for table builds
         torch.set_num_threads(max(1, (os.cpu_count() or 8) // world))
@@ -747,9 +749,10 @@ def main():
                             nxt = tbl.prepare_forward(p1, n1k, us, fused_loss='bpr', want_ids=False)
                             tbl.sample_and_score(user, u1, p1, n1k, us, fused_loss='bpr', want_ids=False, want_grad=True, ticket=look1['t'])
                             look1['t'] = nxt
-                        st1_ahead()
-                        res1['one_batch_ahead_ms'] = time_gpu(st1_ahead, 50, 5) * 1e3
-                        tbl.sample_and_score(user, u1, p1, n1k, us, fused_loss='bpr', want_ids=False, want_grad=True, ticket=look1['t'])
+                        with _above_second_stream(True, dev, hi_cache):
+                            st1_ahead()
+                            res1['one_batch_ahead_ms'] = time_gpu(st1_ahead, 50, 5) * 1e3
+                            tbl.sample_and_score(user, u1, p1, n1k, us, fused_loss='bpr', want_ids=False, want_grad=True, ticket=look1['t'])
                         tbl.check_overflow()
                 t1 = res1['ms_per_step']
                 alg1 = bytes_per_triplet(d, n1k, False) * b1k * n1k
@@ -783,8 +786,9 @@ def main():
                     nxt = trainer1.prepare_step(u1, p1)
                     trainer1.training_step(u1, p1, ticket=look['t'])
                     look['t'] = nxt
-                t_la = time_gpu(ahead_step, 30, 3) * 1e3
-                trainer1.training_step(u1, p1, ticket=look['t'])
+                with _above_second_stream(True, dev, hi_cache):     # the steps on a high-priority stream, the look-ahead below it
+                    t_la = time_gpu(ahead_step, 30, 3) * 1e3
+                    trainer1.training_step(u1, p1, ticket=look['t'])
                 tbl_t.check_overflow()
                 blk.copy_(blk0)
                 del blk0, tower1, trainer1
@@ -797,7 +801,7 @@ def main():
                                    'what': 'in-place SGD training step of the same shape, BPR evaluated on the owners '
                                            '(shard.ShardedItemTable.bpr_step_on_owners): item rows read once per step; '
                                            'one_batch_ahead: the weight-independent half of the next step (negatives, routing, '
-                                           'key exchange, owner-side sorts) on a second stream under the current one'},
+                                           'key exchange, owner-side sorts) on a second stream under the current one (the steps on a high-priority stream)'},
                                   'sharded_world1_train', alg_tr, whole_step=True)
                 extra['sharded_world1']['train'] = tr
                 del blk, tbl, tbl_t
@@ -924,8 +928,9 @@ def main():
                 nxt = tbl_a.prepare_forward(pos, n, sampler, fused_loss='bpr', want_ids=False)
                 tbl_a.sample_and_score(user, uid, pos, n, sampler, fused_loss='bpr', want_ids=False, want_grad=True, ticket=look_a['t'])
                 look_a['t'] = nxt
-            ms_a = timed_max(ahead_fwd, args.steps, args.warmup)
-            tbl_a.sample_and_score(user, uid, pos, n, sampler, fused_loss='bpr', want_ids=False, want_grad=True, ticket=look_a['t'])
+            with _above_second_stream(True, dev, hi_cache):
+                ms_a = timed_max(ahead_fwd, args.steps, args.warmup)
+                tbl_a.sample_and_score(user, uid, pos, n, sampler, fused_loss='bpr', want_ids=False, want_grad=True, ticket=look_a['t'])
             tbl_a.check_overflow()
             extra['one_batch_ahead'] = {'ms_per_step': round(ms_a, 4), 'M_triplets_s': round(world * B * n / ms_a / 1e3, 2),
                                         'efficiency_vs_world1': round(ms_solo / ms_a, 4),
@@ -970,8 +975,9 @@ def main():
                         nxt = trn_t.prepare_step(uid, pos_t)
                         trn_t.training_step(uid, pos_t, ticket=look['t'])
                         look['t'] = nxt
-                    res_t['ahead'] = timed_max(ahead_step, max(10, args.steps // 4), 3)
-                    trn_t.training_step(uid, pos_t, ticket=look['t'])
+                    with _above_second_stream(True, dev, hi_cache):
+                        res_t['ahead'] = timed_max(ahead_step, max(10, args.steps // 4), 3)
+                        trn_t.training_step(uid, pos_t, ticket=look['t'])
                     tbl_t.check_overflow()
                 on_owners = tbl_t.owner_loss_ok()
                 del tbl_t, trn_t

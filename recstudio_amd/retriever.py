@@ -825,30 +825,31 @@ class BaseRetriever(torch.nn.Module):
             ahead = bool(tr.get('shard_lookahead', False)) and trainer.can_prepare()
             self._shard['lookahead'] = ahead
             ticket = None
-            for batch, batch_next in _with_next(self._prepared_batches(loader, device)):
-                if ahead and ticket is None:
-                    ticket = trainer.prepare_step(self._get_query_feat(batch), batch[self.fiid])
-                ticket_next = trainer.prepare_step(self._get_query_feat(batch_next), batch_next[self.fiid]) \
-                    if ahead and batch_next is not None else None
-                if optimizer is not None:
-                    optimizer.zero_grad(set_to_none=False)
-                try:
-                    loss = trainer.training_step(self._get_query_feat(batch), batch[self.fiid], batch[self.frating], ticket=ticket)
-                    ticket = ticket_next
-                except RuntimeError as err:
-                    ticket = ticket_next
-                    # an id distribution that outgrew the calibrated segment capacity: every rank raises at the same step
-                    # (the sticky count is job-wide), the affected steps updated nothing, the capacity is recalibrated on
-                    # the next step -- carry on instead of aborting the run
-                    if 'did not fit their owner segment' not in str(err):
-                        raise
-                    self.logger.warning(str(err))
-                    continue
-                if optimizer is not None:
-                    if tr['grad_clip_norm'] is not None:
-                        self._clip_grad_norm_sharded(params, tr['grad_clip_norm'], dist)
-                    optimizer.step()
-                losses.append(loss.detach().reshape(1))
+            with _above_second_stream(ahead and on_gpu, device, self._shard):
+                for batch, batch_next in _with_next(self._prepared_batches(loader, device)):
+                    if ahead and ticket is None:
+                        ticket = trainer.prepare_step(self._get_query_feat(batch), batch[self.fiid])
+                    ticket_next = trainer.prepare_step(self._get_query_feat(batch_next), batch_next[self.fiid]) \
+                        if ahead and batch_next is not None else None
+                    if optimizer is not None:
+                        optimizer.zero_grad(set_to_none=False)
+                    try:
+                        loss = trainer.training_step(self._get_query_feat(batch), batch[self.fiid], batch[self.frating], ticket=ticket)
+                        ticket = ticket_next
+                    except RuntimeError as err:
+                        ticket = ticket_next
+                        # an id distribution that outgrew the calibrated segment capacity: every rank raises at the same step
+                        # (the sticky count is job-wide), the affected steps updated nothing, the capacity is recalibrated on
+                        # the next step -- carry on instead of aborting the run
+                        if 'did not fit their owner segment' not in str(err):
+                            raise
+                        self.logger.warning(str(err))
+                        continue
+                    if optimizer is not None:
+                        if tr['grad_clip_norm'] is not None:
+                            self._clip_grad_norm_sharded(params, tr['grad_clip_norm'], dist)
+                        optimizer.step()
+                    losses.append(loss.detach().reshape(1))
             step_losses = torch.cat(losses)                     # this rank's shares of the global mean losses
             dist.all_reduce(step_losses)
             self.train_losses.append(step_losses.cpu())
@@ -1124,6 +1125,32 @@ class _EmbedFn(torch.autograd.Function):
     def backward(ctx, g):
         (ids,) = ctx.saved_tensors
         return _embedding_grad(g, ids, ctx.n_rows), None
+
+
+class _above_second_stream:
+    """``with`` block whose work runs on a HIGH-priority stream (entered after, left before, the stream that was current):
+    the look-ahead's second stream then sits below the steps it runs under and fills their gaps instead of competing with
+    them (sharded training step one batch ahead, in process: 1.166 ms with both at the default priority, 1.136 ms so)."""
+
+    def __init__(self, on, device, cache):
+        self.on, self.device, self.cache = bool(on), device, cache
+
+    def __enter__(self):
+        if self.on:
+            self.prev = torch.cuda.current_stream(self.device)
+            hi = self.cache.get('hi_stream')
+            if hi is None:
+                hi = self.cache['hi_stream'] = torch.cuda.Stream(device=self.device, priority=-1)
+            hi.wait_stream(self.prev)
+            torch.cuda.set_stream(hi)
+            self.hi = hi
+        return self
+
+    def __exit__(self, *exc):
+        if self.on:
+            self.prev.wait_stream(self.hi)
+            torch.cuda.set_stream(self.prev)
+        return False
 
 
 def _with_next(it):

@@ -638,7 +638,7 @@ def test_world1_rccl_overflow_step_is_harmless():
         dist.destroy_process_group()
 
 
-def _fit_gpu_worker(rank, world, port, result_dir, layout='block'):
+def _fit_gpu_worker(rank, world, port, result_dir, layout='block', train_extra=None):
     import torch.distributed as dist
     import recstudio_amd as ra
     from recstudio_amd.dataset import TripletDataset
@@ -653,6 +653,7 @@ def _fit_gpu_worker(rank, world, port, result_dir, layout='block'):
                 'eval': {'batch_size': 128 // world, 'cutoff': [10], 'val_metrics': ['ndcg', 'recall'], 'topk': 50,
                          'test_metrics': ['ndcg', 'recall']},
                 'model': {'embed_dim': 64}}
+        conf['train'].update(train_extra or {})
         model = ra.BPR(conf)
         ds = TripletDataset('ml-100k', {'low_rating_thres': 3.0},
                             _interactions=(g['raw_user'].astype(str), g['raw_item'].astype(str),
@@ -663,7 +664,8 @@ def _fit_gpu_worker(rank, world, port, result_dir, layout='block'):
         test = model.evaluate(tst, verbose=False)
         torch.save({'best': best, 'val': dict(model.logged_metrics), 'test': test, 'losses': torch.cat(model.train_losses),
                     'item': model.item_encoder.weight.detach().cpu(), 'lo': model._shard['lo'],
-                    'tower': model.query_encoder.weight.detach().cpu()}, os.path.join(result_dir, f'w{world}r{rank}.pt'))
+                    'tower': model.query_encoder.weight.detach().cpu(), 'lookahead': bool(model._shard.get('lookahead'))},
+                   os.path.join(result_dir, f'w{world}r{rank}.pt'))
     finally:
         dist.destroy_process_group()
 
@@ -698,6 +700,25 @@ def test_fit_two_staged_ranks_equals_one_rank_hip(tmp_path):
     items = torch.empty_like(one['item'])
     items[0::2], items[1::2] = il[0]['item'], il[1]['item']
     np.testing.assert_allclose(items.numpy(), one['item'].numpy(), rtol=1e-3, atol=1e-5)
+
+
+def test_fit_two_staged_ranks_one_batch_ahead_hip(tmp_path):
+    """``train.shard_lookahead`` through ``BaseRetriever.fit`` with the HIP backend (two staged ranks, in-kernel SGD so that the
+    step is the owner-side BPR step with in-place updates): every step's negatives / routing / key exchange / owner sorts
+    issued one batch ahead on the second stream, the epoch loop on a high-priority stream -- the same run as without."""
+    import torch.multiprocessing as mp
+    extra = {'fused_optimizer': 'sgd', 'learning_rate': 200.0, 'epochs': 1}
+    runs = {}
+    for tag, ex in (('plain', extra), ('ahead', dict(extra, shard_lookahead=True))):
+        os.makedirs(tmp_path / tag)
+        mp.spawn(_fit_gpu_worker, args=(2, _free_port(), str(tmp_path / tag), 'block', ex), nprocs=2, join=True)
+        runs[tag] = [torch.load(tmp_path / tag / f'w2r{r}.pt', weights_only=False) for r in range(2)]
+    for a, b in zip(runs['plain'], runs['ahead']):
+        assert b['lookahead'] and not a['lookahead']
+        np.testing.assert_allclose(b['losses'].numpy(), a['losses'].numpy(), rtol=2e-5, atol=1e-6)
+        np.testing.assert_allclose(b['item'].numpy(), a['item'].numpy(), rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(b['tower'].numpy(), a['tower'].numpy(), rtol=1e-4, atol=1e-6)
+    assert float(runs['plain'][0]['losses'][-1]) < float(runs['plain'][0]['losses'][0]) - 2e-4      # the epoch trained
 
 
 @pytest.mark.parametrize('d', [32, 128])

@@ -45,6 +45,8 @@ def run(k, tr, steps):
         ticket = nxt
 
 
+main_stream = torch.cuda.Stream(priority=-1) if os.environ.get('MAIN_HIGH') == '1' else torch.cuda.current_stream()
+torch.cuda.set_stream(main_stream)          # MAIN_HIGH=1: the steps on a high-priority stream, the second stream below it
 res = {k: [] for k in trainers}
 for rnd in range(5):
     for k, tr in trainers.items():
