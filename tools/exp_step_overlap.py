@@ -5,6 +5,7 @@ training steps, HIP events around each round.  usage: python tools/exp_step_over
 import json
 import os
 import sys
+import time
 
 import torch
 
@@ -48,14 +49,18 @@ def run(k, tr, steps):
 main_stream = torch.cuda.Stream(priority=-1) if os.environ.get('MAIN_HIGH') == '1' else torch.cuda.current_stream()
 torch.cuda.set_stream(main_stream)          # MAIN_HIGH=1: the steps on a high-priority stream, the second stream below it
 res = {k: [] for k in trainers}
+host = {k: [] for k in trainers}
 for rnd in range(5):
     for k, tr in trainers.items():
         run(k, tr, 5)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
+        h0 = time.perf_counter()
         run(k, tr, 30)
+        host[k].append((time.perf_counter() - h0) / 30 * 1e3)       # host time to ISSUE a step (no synchronisation inside)
         e1.record()
         torch.cuda.synchronize()
         res[k].append(e0.elapsed_time(e1) / 30)
-print(json.dumps({k: {'min_ms': round(min(v), 4), 'median_ms': round(sorted(v)[len(v) // 2], 4)} for k, v in res.items()}))
+print(json.dumps({k: {'min_ms': round(min(v), 4), 'median_ms': round(sorted(v)[len(v) // 2], 4),
+                      'host_issue_ms': round(min(host[k]), 4)} for k, v in res.items()}))
