@@ -334,3 +334,19 @@ def test_device_initialised_row_blocks_tile_one_table():
     assert not torch.equal(other, full)
     uni = _device_init_block(RowShardPlan(N, 1), 0, N, d, 2022, 'xavier_uniform', 'cpu')
     assert float(uni.abs().max()) <= (6.0 / (N + d)) ** 0.5 * (1 + 1e-6) and abs(float(uni.std()) - (2.0 / (N + d)) ** 0.5) < 1e-4
+
+
+def test_lookahead_helpers_on_the_host():
+    """The pieces of the one-batch-ahead loop that run without a GPU: the (current, next) pairing of a loader's batches, the
+    stream block that is a no-op when the look-ahead is off, the recursive record_stream walk on CPU tensors."""
+    import torch
+    from recstudio_amd.retriever import _above_second_stream, _with_next
+    from recstudio_amd.shard import _record_stream_all
+    assert list(_with_next([])) == []
+    assert list(_with_next(iter([1]))) == [(1, None)]
+    assert list(_with_next(x for x in 'abc')) == [('a', 'b'), ('b', 'c'), ('c', None)]
+    cache = {}
+    with _above_second_stream(False, torch.device('cpu'), cache) as blk:
+        assert blk.on is False
+    assert cache == {}
+    _record_stream_all({'a': torch.zeros(2), 'b': [torch.ones(1), (None, 3, {'c': torch.zeros(1)})], 'args': object()}, None)
