@@ -271,6 +271,9 @@ __global__ __launch_bounds__(256) void sorted_finish_kernel(int64_t n_chunks, co
 // element number in `vals` is set so that the apply kernel leaves the row alone: a forward that updates solo rows
 // itself (rsa_fused_args.solo_flags) has already applied them.
 constexpr int32_t SOLO_BIT = (int32_t)0x80000000;
+// MOSTLY_SOLO: the flags were preset to 1 and the elements that are NOT solo store a 0 -- the scattered byte stores are the cost
+// of this pass (each its own 64-byte write request: 3 M of them 38 us), so the host picks the polarity with fewer of them.
+template <bool MOSTLY_SOLO>
 __global__ __launch_bounds__(256) void classify_solo_kernel(uint64_t* __restrict__ pairs, int64_t total, int32_t pad_row,
                                                             int32_t drop_key, uint8_t* __restrict__ solo) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -278,10 +281,12 @@ __global__ __launch_bounds__(256) void classify_solo_kernel(uint64_t* __restrict
     const uint64_t pr = pairs[i];
     const int32_t k = (int32_t)rdx_key(pr);
     const int32_t before = i > 0 ? (int32_t)rdx_key(pairs[i - 1]) : -1, after = i + 1 < total ? (int32_t)rdx_key(pairs[i + 1]) : -1;
-    if (k != before && k != after && k != pad_row && k != drop_key) {       // (the flags were zeroed: only the ones are stored --
-      const uint32_t e = rdx_val(pr);                                       //  a scattered byte store each)
-      solo[e] = 1;
+    const uint32_t e = rdx_val(pr);
+    if (k != before && k != after && k != pad_row && k != drop_key) {
+      if (!MOSTLY_SOLO) solo[e] = 1;                     // (the flags were zeroed: only the ones are stored)
       pairs[i] = pr | (uint64_t)(uint32_t)SOLO_BIT;      // (only the payload word changes: a neighbour reading the key races on nothing)
+    } else if (MOSTLY_SOLO) {
+      solo[e] = 0;
     }
   }
 }
@@ -313,13 +318,20 @@ SortedLayout sorted_layout(void* workspace, int64_t max_total) {
 
 int classify_solo(uint64_t* pairs, int64_t total, int64_t pad_row, int64_t drop_key, uint8_t* solo, hipStream_t s, const char* who) {
   const int32_t pad = (int32_t)(pad_row < 0 || pad_row >= (1ll << 31) ? -2 : pad_row);
-  if (hipMemsetAsync(solo, 0, (size_t)total, s) != hipSuccess) {
+  // `total` draws over `drop_key` rows (drop_key = the row count): under a uniform draw a row is alone with probability
+  // exp(-total / rows), i.e. most elements are solo below total / rows = ln 2.  A skewed draw has fewer solo elements than that;
+  // the guess only decides which of the two polarities stores fewer bytes.
+  const bool mostly_solo = (double)total < 0.69 * (double)drop_key;
+  if (hipMemsetAsync(solo, mostly_solo ? 1 : 0, (size_t)total, s) != hipSuccess) {
     rsa::set_error("%s: memset failed", who);
     return RSA_ERR_HIP;
   }
   int64_t blocks = (total + 255) / 256;
   if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(classify_solo_kernel, dim3((unsigned)blocks), dim3(256), 0, s, pairs, total, pad, (int32_t)drop_key, solo);
+  if (mostly_solo)
+    hipLaunchKernelGGL(classify_solo_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, pairs, total, pad, (int32_t)drop_key, solo);
+  else
+    hipLaunchKernelGGL(classify_solo_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, pairs, total, pad, (int32_t)drop_key, solo);
   RSA_CHECK_LAUNCH(who);
   return RSA_OK;
 }
