@@ -196,7 +196,73 @@ def cpu_baseline(args, counts, d, B, n):
     return res
 
 
-PROFILE_ROUNDS = ('r04', 'r03')
+def _smi_json(*flags):
+    import subprocess
+    try:
+        out = subprocess.run(['rocm-smi', *flags, '--json'], capture_output=True, text=True, timeout=20).stdout
+        return json.loads(out[out.index('{'):])
+    except Exception:
+        return {}
+
+
+def box_state(busy_fn=None, device=0):
+    """The state of the box this process measured on (two boxes ran the same binary 10 % apart and
+    nothing said why): engine / memory / fabric clocks and socket power sampled by rocm-smi WHILE `busy_fn` keeps the GPU
+    busy (a thread launches it back to back for the duration of the query), the power cap, the performance level and the
+    compute / memory partition modes.  Numbers only; {} when rocm-smi is missing."""
+    stop = threading.Event()
+    th = None
+    if busy_fn is not None:
+        def spin():
+            torch.cuda.set_device(device)
+            while not stop.is_set():
+                for _ in range(50):
+                    busy_fn()
+                torch.cuda.synchronize()
+        th = threading.Thread(target=spin, daemon=True)
+        th.start()
+        time.sleep(0.5)
+    try:
+        load = _smi_json('--showclocks', '--showpower', '--showtemp')
+    finally:
+        stop.set()
+        if th is not None:
+            th.join()
+    static = _smi_json('--showmaxpower', '--showperflevel', '--showcomputepartition', '--showmemorypartition')
+    card = next(iter(load.values()), {}) if load else {}
+    card.update(next(iter(static.values()), {}) if static else {})
+    import re
+    out = {}
+
+    def num(v):
+        m = re.search(r'(-?\d+(?:\.\d+)?)', str(v))
+        return float(m.group(1)) if m else None
+    for key, val in card.items():
+        k = key.lower()
+        if 'sclk clock speed' in k:
+            out['sclk_mhz'] = num(val)
+        elif 'mclk clock speed' in k:
+            out['mclk_mhz'] = num(val)
+        elif 'fclk clock speed' in k:
+            out['fclk_mhz'] = num(val)
+        elif 'package power' in k or k.startswith('average graphics package power') or 'socket power' in k:
+            out['power_w'] = num(val)
+        elif 'max graphics package power' in k:
+            out['power_cap_w'] = num(val)
+        elif 'performance level' in k:
+            out['perf_level'] = str(val)
+        elif 'compute partition' in k:
+            out['compute_partition'] = str(val)
+        elif 'memory partition' in k:
+            out['memory_partition'] = str(val)
+        elif 'temperature (sensor junction)' in k:
+            out['temp_junction_c'] = num(val)
+        elif 'temperature (sensor hbm' in k or 'temperature (sensor memory)' in k:
+            out['temp_hbm_c'] = max(out.get('temp_hbm_c') or 0.0, num(val) or 0.0)
+    return out
+
+
+PROFILE_ROUNDS = ('r05', 'r04', 'r03')
 
 
 def profile_record(name):
@@ -234,6 +300,53 @@ def with_profile(entry, name, alg_bytes, whole_step=False, flops=None):
     return entry
 
 
+def side_figures(extra):
+    """Compact copy (numbers only) of the side figures the claims rest on, for `roofline.side`: fractions of the HBM peak
+    (fp32 MFMA peak for `fullscore_*`) by step time unless the key says otherwise, ms where the key ends in `_ms`."""
+    side = {}
+
+    def put(key, *path):
+        v = extra
+        for k in path:
+            if not isinstance(v, dict) or k not in v:
+                return
+            v = v[k]
+        if isinstance(v, (int, float)):
+            side[key] = v
+    put('n1e8_uniform_frac', 'table_100M', 'n=64,B=65536', 'frac_of_hbm_peak')
+    put('n1e8_walk_n1024_frac', 'table_100M', 'n=1024,B=4096', 'frac_of_hbm_peak')
+    put('n1e8_popular_frac', 'table_100M', 'popular,n=64,B=65536', 'frac_of_hbm_peak')
+    put('b4096_frac', 'sweep', 'B=4096', 'frac_of_hbm_peak')
+    put('b16384_frac', 'sweep', 'B=16384', 'frac_of_hbm_peak')
+    put('b4096_two_streams_frac', 'sweep', 'B=4096', 'two_streams_frac_of_hbm_peak')
+    put('b16384_two_streams_frac', 'sweep', 'B=16384', 'two_streams_frac_of_hbm_peak')
+    put('b4096_queue_frac', 'sweep', 'B=4096', 'queue_frac_of_hbm_peak')
+    put('b16384_queue_frac', 'sweep', 'B=16384', 'queue_frac_of_hbm_peak')
+    put('ssm_n256_frac', 'seq_softmax', 'frac_of_hbm_peak')
+    put('train_step_frac', 'train_step', 'train_frac')
+    put('sgd_step_frac', 'train_step', 'sgd_frac')
+    put('sgd_step_prefetched_frac', 'train_step', 'sgd_prefetched_frac')
+    put('sgd_step_prefetched_ms', 'train_step', 'sgd_step_prefetched_ms')
+    put('adam_step_frac', 'train_step', 'adam_frac')
+    put('sharded_world1_frac', 'sharded_world1', 'frac_of_hbm_peak')
+    put('sharded_world1_train_frac', 'sharded_world1', 'train', 'frac_of_hbm_peak')
+    put('sharded_world1_train_ssm_ms', 'sharded_world1', 'train_ssm', 'ms_per_step')
+    put('fullscore_frac', 'fullscore', 'frac_of_peak')
+    put('fullscore_tflops', 'fullscore', 'gemm_lse_tflops')
+    put('fullscore_top100_ms', 'fullscore', 'with_top100_ms')
+    put('fullscore_top100_frac', 'fullscore', 'with_top100_frac')
+    put('softmax_train_step_ms', 'fullscore', 'softmax_train_step_ms')
+    put('softmax_train_frac', 'fullscore', 'softmax_train_frac')
+    put('fit_c1_train_s_per_epoch', 'fit', 'c1_bpr_ml100k', 'train_s_per_epoch')
+    put('fit_c1_valid_s_per_epoch', 'fit', 'c1_bpr_ml100k', 'valid_s_per_epoch')
+    for b in (65536, 4096):
+        put(f'fit_loop_B{b}_ms', 'fit', f'c2_B{b}', 'loop_ms_per_step')
+        put(f'fit_stepper_B{b}_ms', 'fit', f'c2_B{b}', 'stepper_ms_per_step')
+        put(f'fit_loop_over_stepper_B{b}', 'fit', f'c2_B{b}', 'loop_over_stepper')
+        put(f'fit_loop_B{b}_M_triplets_s', 'fit', f'c2_B{b}', 'loop_M_triplets_s')
+    return side
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -252,6 +365,7 @@ def main():
                     help='row ownership of the sharded table (--gpus N > 1): contiguous blocks, or rows r, r + N, ...')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-sweep', action='store_true')
+    ap.add_argument('--no-fit', action='store_true', help='skip the BaseRetriever.fit figures (tools/bench_fit.py)')
     args = ap.parse_args()
 
     if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
@@ -812,6 +926,32 @@ def main():
         workload = (f'BPR two-tower d={d}, synthetic {args.items} items / {args.users} users / 1e8-interaction Zipf '
                     f'popularity, {args.sampler} sampler neg={n}, InnerProduct + BPR loss, B={B} queries/step '
                     f'(BASELINE.json configs[1])')
+        # the thing users run: BaseRetriever.fit end to end (tools/bench_fit.py) -- configs[0] on the committed ml-100k
+        # fixture next to the reference's published epoch times, and configs[1]-shaped fit through loader + stepper
+        if not args.no_sweep and not args.no_fit and args.dim == 128:
+            try:
+                torch.cuda.empty_cache()
+                sys.path.insert(0, os.path.join(ROOT, 'tools'))
+                from bench_fit import fit_figures
+                seed_state = torch.cuda.get_rng_state(dev)
+                extra['fit'] = fit_figures(ra, dev, n_items=args.items, n_users=args.users)
+                torch.cuda.set_rng_state(seed_state, dev)
+            except Exception as e:
+                extra['fit'] = {'error': repr(e)[:300]}
+        # box state under load + the side figures the claims rest on, numbers only, INSIDE `roofline` (the driver's record
+        # keeps that object whole and only the names of the other extra keys)
+        try:
+            item_b = torch.empty(2_000_001, d, device=dev).normal_(0, 0.02)
+            pb, bb = pos % 2_000_000 + 1, {}
+
+            def busy():      # any HBM-bound launch of the path: what the clocks are under THIS kind of load
+                bb['o'] = ra.ops.fused_forward(item_b, user, n, out=bb.get('o'), query_index=uid, pos_ids=pb,
+                                               sampler=nat.SAMPLER_UNIFORM, fused_bpr=True, want_mean=False)
+            roofline['box'] = box_state(busy, device=local)
+            del item_b, bb
+        except Exception as e:
+            roofline['box'] = {'error': repr(e)[:120]}
+        roofline['side'] = side_figures(extra)
         if rank == 0 and not args.no_cpu_baseline:
             extra['cpu_baseline'] = cpu_baseline(args, counts, d, B, n)
     else:

@@ -30,7 +30,13 @@
 extern "C" {
 #endif
 
-#define RSA_ABI_VERSION 8   /* 8: rsa_shard_owner_bpr_args.finish_parts / forward_parts (the owner-side step in parts, for a caller with two streams);
+#define RSA_ABI_VERSION 9   /* 9: every entry point that took more than 12 positional arguments takes ONE argument block whose first field is its
+                               own size (see "Versioned argument blocks"): rsa_popular_args (rsa_sample_popular, rsa_popular_lookup), rsa_loss_args
+                               (rsa_pairwise_loss -- which now covers the kinds of the former rsa_pairwise_loss_ex --, rsa_ssm_shared_loss),
+                               rsa_seg_gather_args, rsa_fullscore_args, rsa_rows_update_args (rsa_sort_step_elements, rsa_rows_update_sorted,
+                               rsa_rows_update_presorted: the former rsa_scatter_rows_sorted / _presorted / rsa_adam_rows_sorted / _presorted);
+                               rsa_bpr_sgd_prepare / rsa_bpr_sgd_apply (the whole in-place SGD step of a BPR two-tower model as two calls);
+                               8: rsa_shard_owner_bpr_args.finish_parts / forward_parts (the owner-side step in parts, for a caller with two streams);
                                7: rsa_shard_pos_score / rsa_shard_owner_bpr_forward / _finish (the BPR step evaluated on the owners: rows read
                                once per step); rsa_shard_sample_route: route_pos; rsa_shard_backward_segments (the owner side of the sharded backward in one call: in-tree radix sorts
                                straight from the received segments, one walk over the query runs that reads every item row once and
@@ -64,6 +70,13 @@ enum rsa_sampler_kind { RSA_SAMPLER_GIVEN = 0, RSA_SAMPLER_UNIFORM = 1, RSA_SAMP
 enum rsa_loss_kind { RSA_LOSS_BPR = 0, RSA_LOSS_SSM = 1, RSA_LOSS_BCE = 2,
                      /* rsa_pairwise_loss_ex: */ RSA_LOSS_WBPR = 3, RSA_LOSS_WBCE = 4, RSA_LOSS_HINGE = 5, RSA_LOSS_NCE = 6,
                      RSA_LOSS_CCL = 7 };
+
+/* ---- Versioned argument blocks (ABI 9) --------------------------------------------------------------------------
+ * The structs below whose FIRST field is `int64_t size` are read as follows: the caller sets size = sizeof(the struct)
+ * as ITS header declares it; the library copies min(size, its own sizeof) bytes into a zero-filled block of its own.  Fields
+ * are only ever appended, and 0 / NULL always means "not given": a caller compiled against an older header keeps working
+ * against a newer library (the new fields read as 0), and a newer caller against an older library has its extra fields
+ * ignored.  rsa_fused_args / rsa_backward_args / the rsa_shard_* blocks predate this and are covered by RSA_ABI_VERSION. */
 
 const char* rsa_last_error(void);
 int rsa_abi_version(void);
@@ -110,18 +123,31 @@ int rsa_sample_masked_uniform(const int64_t* user_hist, int64_t n_rows, int32_t 
  * n_items (u above table[-1]) is clamped to n_items-1.  neg_logp / u_out may be
  * null.  cdf_lut / cdf_lines (nullable, see rsa_fused_args) are faster forms of the same lookup; with
  * cdf_lines the guide may be null. */
-int rsa_sample_popular(const float* table, const float* pop_prob, const int32_t* guide,
-                       int64_t n_items, int32_t guide_log2,
-                       int64_t* neg_ids, float* neg_logp, float* u_out, int64_t numel,
-                       uint64_t seed, uint64_t offset, uint32_t grid_threads, uint64_t elem_base,
-                       const float* cdf_lut, const float* cdf_lines, int32_t lines_log2, rsa_stream_t stream);
+typedef struct rsa_popular_args {
+  int64_t size;                /* sizeof(rsa_popular_args) */
+  const float* table;          /* [n_items] CDF */
+  const float* pop_prob;       /* [n_items] */
+  const int32_t* guide;        /* nullable with cdf_lines */
+  int64_t n_items;
+  int32_t guide_log2;
+  int32_t lines_log2;
+  const float* cdf_lut;        /* nullable */
+  const float* cdf_lines;      /* nullable */
+  const float* u_in;           /* rsa_popular_lookup: the uniforms [numel]; ignored by rsa_sample_popular */
+  int64_t* ids;                /* [numel] out */
+  float* logp;                 /* nullable [numel] out */
+  float* u_out;                /* nullable [numel] out (rsa_sample_popular: the uniforms drawn) */
+  int64_t numel;
+  uint64_t seed, offset;       /* "Philox state" (rsa_sample_popular) */
+  uint32_t grid_threads;
+  uint32_t _pad;
+  uint64_t elem_base;
+} rsa_popular_args;
+int rsa_sample_popular(const rsa_popular_args* args, rsa_stream_t stream);
 
-/* The same inverse-CDF lookup for caller-supplied uniforms u[numel] (used by the
+/* The same inverse-CDF lookup for caller-supplied uniforms u_in[numel] (used by the
  * parity tests to hit exact table edges). */
-int rsa_popular_lookup(const float* table, const float* pop_prob, const int32_t* guide,
-                       int64_t n_items, int32_t guide_log2, const float* u,
-                       int64_t* ids, float* logp, int64_t numel, const float* cdf_lut /* nullable */,
-                       const float* cdf_lines /* nullable */, int32_t lines_log2, rsa_stream_t stream);
+int rsa_popular_lookup(const rsa_popular_args* args, rsa_stream_t stream);
 
 /* PopularSamplerModel.compute_item_p -- recstudio/ann/sampler.py:257-258:
  * logp[i] = log(pop_prob[ids[i]]). */
@@ -242,29 +268,38 @@ int rsa_rng_advance(uint64_t* offset_dev, uint64_t increment, rsa_stream_t strea
  * (treated as 0; the reference's UniformSampler hands int64 zeros).  loss_out[1]
  * = mean over rows; row_loss [M] scratch/out; dpos [M] and dneg [M, n] (nullable)
  * = d loss_out / d score. */
-int rsa_pairwise_loss(int32_t loss_kind, const float* pos_score, const float* neg_score,
-                      const float* pos_logp, const float* neg_logp, int64_t n_rows, int32_t num_neg,
-                      float* row_loss, float* loss_out, float* dpos, float* dneg, void* scratch, rsa_stream_t stream);
+typedef struct rsa_loss_args {
+  int64_t size;                /* sizeof(rsa_loss_args) */
+  int32_t loss_kind;           /* rsa_loss_kind */
+  int32_t n_pos;               /* rsa_ssm_shared_loss: positives per row (L); ignored by rsa_pairwise_loss */
+  const float* pos_score;      /* [n_rows] ([n_rows, n_pos] for rsa_ssm_shared_loss) */
+  const float* neg_score;      /* [n_rows, num_neg] */
+  const float* pos_logp;       /* nullable, like pos_score */
+  const float* neg_logp;       /* nullable, like neg_score */
+  int64_t n_rows;
+  int32_t num_neg;
+  int32_t _pad;
+  float param0, param1;        /* RSA_LOSS_HINGE: margin; RSA_LOSS_CCL: margin, neg_weight */
+  float* row_loss;             /* [n_rows] scratch / out */
+  float* loss_out;             /* [1] out: the mean over rows */
+  float* dpos;                 /* nullable out, like pos_score */
+  float* dneg;                 /* nullable out, like neg_score */
+  void* scratch;               /* rsa_scratch_bytes() */
+} rsa_loss_args;
+int rsa_pairwise_loss(const rsa_loss_args* args, rsa_stream_t stream);
 
-/* The other PairwiseLoss classes of recstudio/model/loss_func.py, value + d loss/d score in one pass like
- * rsa_pairwise_loss:  RSA_LOSS_WBPR WeightedBPRLoss (:93-97; the softmax(neg - logQ) weights are differentiated
+/* loss_kind >= RSA_LOSS_WBPR -- the other PairwiseLoss classes of recstudio/model/loss_func.py, value + d loss/d score in
+ * one pass:  RSA_LOSS_WBPR WeightedBPRLoss (:93-97; the softmax(neg - logQ) weights are differentiated
  * through, as in the reference), RSA_LOSS_WBCE WeightedBinaryCrossEntropyLoss (:135-137 on :105-127, padded -inf
  * positives dropped), RSA_LOSS_HINGE HingeLoss (:140-154, num_items=None; param0 = margin), RSA_LOSS_NCE NCELoss
  * (:163-168), RSA_LOSS_CCL CCLLoss (:171-186; param0 = margin, param1 = neg_weight).  InfoNCELoss (:157-160) is
- * rsa_pairwise_loss(RSA_LOSS_SSM) with null log-probabilities.  Top1Loss (:66-78) is not offered: the reference's
- * forward modifies a sigmoid output in place and cannot be back-propagated. */
-int rsa_pairwise_loss_ex(int32_t loss_kind, const float* pos_score, const float* neg_score,
-                         const float* pos_logp, const float* neg_logp, int64_t n_rows, int32_t num_neg,
-                         float param0, float param1, float* row_loss, float* loss_out, float* dpos, float* dneg,
-                         void* scratch, rsa_stream_t stream);
-
-/* SampledSoftmaxLoss.forward when pos_score [B, L] and neg_score [B, n] have the SAME rank
- * (recstudio/model/loss_func.py:84-89): the L positives of a row share its n negatives; padded
+ * RSA_LOSS_SSM with null log-probabilities.  Top1Loss (:66-78) is not offered: the reference's
+ * forward modifies a sigmoid output in place and cannot be back-propagated.
+ *
+ * rsa_ssm_shared_loss: SampledSoftmaxLoss.forward when pos_score [B, L] and neg_score [B, n] have the SAME rank
+ * (recstudio/model/loss_func.py:84-89): the L = n_pos positives of a row share its n negatives; padded
  * positives (+-inf) contribute nothing and are not counted.  Value + gradients in one pass. */
-int rsa_ssm_shared_loss(const float* pos_score, const float* pos_logp, const float* neg_score,
-                        const float* neg_logp, int64_t n_rows, int32_t n_pos, int32_t num_neg,
-                        float* row_loss, float* loss_out, float* dpos, float* dneg, void* scratch,
-                        rsa_stream_t stream);
+int rsa_ssm_shared_loss(const rsa_loss_args* args, rsa_stream_t stream);
 
 /* out[0] = mean(row_loss[0..n_rows)) in a fixed summation order (two tiny launches). */
 int rsa_mean_rows(const float* row_loss, int64_t n_rows, float* out, void* scratch, rsa_stream_t stream);
@@ -327,48 +362,108 @@ int rsa_fused_backward(const rsa_backward_args* args, rsa_stream_t stream);
  * upstream: nullable device scalar; pad_row < 0: none.  Elements whose id is NEGATIVE are dropped (empty slots of
  * the fixed-capacity shard exchange): nothing is read or written for them.  Workspace from the _workspace_bytes call. */
 int64_t rsa_scatter_rows_sorted_workspace_bytes(int64_t n_queries, int32_t num_neg, int64_t n_items);
-int rsa_scatter_rows_sorted(const float* query, const int64_t* query_index, int64_t n_query_rows, int32_t dim,
-                            const int64_t* pos_ids, const int64_t* neg_ids, int64_t n_queries, int32_t num_neg,
-                            const float* dpos, const float* dneg, const float* upstream, int64_t n_items,
-                            int64_t pad_row, float* target, void* workspace, int64_t workspace_bytes,
-                            rsa_stream_t stream);
 
-/* The same sorted pass with a LAZY ADAM update of every touched row instead of the accumulate (the update rule of
+/* With exp_avg / exp_avg_sq given the accumulate becomes a LAZY ADAM update of every touched row (the update rule of
  * torch.optim.SparseAdam on the coalesced gradient g[id] = upstream * sum_e d_e * query[qrow_e]):
  *     m += (g - m)(1 - beta1);  v += (g^2 - v)(1 - beta2);  weight -= lr * sqrt(1 - beta2^step) / (1 - beta1^step) * m / (sqrt(v) + eps)
  * exp_avg / exp_avg_sq: [n_items, dim] optimizer state, updated in place; rows not in the step are untouched (lazy).
  * The row sums never leave registers: no gradient tensor, no coalesce pass.  step >= 1 is the 1-based step count. */
-int rsa_adam_rows_sorted(const float* query, const int64_t* query_index, int64_t n_query_rows, int32_t dim,
-                         const int64_t* pos_ids, const int64_t* neg_ids, int64_t n_queries, int32_t num_neg,
-                         const float* dpos, const float* dneg, const float* upstream, int64_t n_items,
-                         int64_t pad_row, float* weight, float* exp_avg, float* exp_avg_sq, float lr, float beta1,
-                         float beta2, float eps, int64_t step, void* workspace, int64_t workspace_bytes,
-                         rsa_stream_t stream);
+typedef struct rsa_rows_update_args {
+  int64_t size;                /* sizeof(rsa_rows_update_args) */
+  const float* query;          /* [n_query_rows, dim] */
+  const int64_t* query_index;  /* nullable [n_queries] (null: query row m) */
+  int64_t n_query_rows;
+  int32_t dim;                 /* 64, 128 or 256 */
+  int32_t has_pos;             /* rsa_rows_update_presorted: the workspace was sorted WITH positives (pos_ids given to the sort) */
+  const int64_t* pos_ids;      /* nullable [n_queries] */
+  const int64_t* neg_ids;      /* [n_queries, num_neg] */
+  int64_t n_queries;
+  int32_t num_neg;
+  int32_t _pad;
+  const float* dpos;           /* [n_queries] (nullable iff no positives) */
+  const float* dneg;           /* [n_queries, num_neg] */
+  const float* upstream;       /* nullable device scalar */
+  int64_t n_items;             /* rows of target */
+  int64_t pad_row;             /* < 0: none */
+  float* target;               /* [n_items, dim]: a zeroed dense gradient, or the weight table (upstream = -lr: SGD in place) */
+  float* exp_avg;              /* nullable: lazy Adam state (then target = the weights) */
+  float* exp_avg_sq;
+  float lr, beta1, beta2, eps;
+  int64_t step;
+  uint8_t* solo;               /* rsa_sort_step_elements: nullable [n_queries * (num_neg + has_pos)] out */
+  void* workspace;
+  int64_t workspace_bytes;     /* >= rsa_scatter_rows_sorted_workspace_bytes(n_queries, num_neg, n_items) */
+} rsa_rows_update_args;
 
-/* rsa_scatter_rows_sorted in two steps, for a forward that updates the rows only one element touches itself
+/* sort + apply in one call (the former rsa_scatter_rows_sorted / rsa_adam_rows_sorted) */
+int rsa_rows_update_sorted(const rsa_rows_update_args* args, rsa_stream_t stream);
+
+/* The same in two steps, for a forward that updates the rows only one element touches itself
  * (rsa_fused_args.solo_flags):
- *   rsa_sort_step_elements   sorts the step's (item id, element) pairs into `workspace` (same size / layout as
- *     rsa_scatter_rows_sorted) and, with `solo` (uint8 [n_queries * (num_neg + has_pos)], element order
+ *   rsa_sort_step_elements   sorts the step's (item id, element) pairs into `workspace` (reads pos_ids, neg_ids, n_queries,
+ *     num_neg, n_items, pad_row) and, with `solo` (uint8 [n_queries * (num_neg + has_pos)], element order
  *     m * (num_neg + has_pos) + c), classifies them: solo[e] = 1 iff element e is the only one on its row and the row is
  *     neither pad_row nor a negative (dropped) id; those elements are also flagged inside the workspace;
- *   rsa_scatter_rows_presorted  is the apply pass of rsa_scatter_rows_sorted over that workspace: every run of equal ids
- *     summed by one wave, the row read-modified-written once -- except the flagged elements, whose rows it leaves alone.
+ *   rsa_rows_update_presorted  is the apply pass over that workspace: every run of equal ids
+ *     summed by one wave, the row read-modified-written once -- except the flagged elements, whose rows it leaves alone
+ *     (has_pos says whether the sort saw positives; pos_ids / neg_ids are not read).  With the lazy-Adam fields: over a
+ *     workspace sorted WITHOUT `solo` -- the sort does not read the weights, so a trainer can issue it, and the sampling in
+ *     front of it, for the next batch on another stream while the current step runs.
  * Nothing may touch the workspace in between.  dim in {64, 128, 256}. */
-int rsa_sort_step_elements(const int64_t* pos_ids, const int64_t* neg_ids, int64_t n_queries, int32_t num_neg, int64_t n_items,
-                           int64_t pad_row, uint8_t* solo, void* workspace, int64_t workspace_bytes, rsa_stream_t stream);
-int rsa_scatter_rows_presorted(const float* query, const int64_t* query_index, int64_t n_query_rows, int32_t dim,
-                               int32_t has_pos, int64_t n_queries, int32_t num_neg, const float* dpos, const float* dneg,
-                               const float* upstream, int64_t n_items, int64_t pad_row, float* target, void* workspace,
-                               int64_t workspace_bytes, rsa_stream_t stream);
+int rsa_sort_step_elements(const rsa_rows_update_args* args, rsa_stream_t stream);
+int rsa_rows_update_presorted(const rsa_rows_update_args* args, rsa_stream_t stream);
 
-/* The apply pass of rsa_adam_rows_sorted over a workspace rsa_sort_step_elements filled WITHOUT `solo` (no element
- * flagged): the sort does not read the weights, so a trainer can issue it -- and the sampling in front of it -- for the
- * next batch on another stream while the current step runs. */
-int rsa_adam_rows_presorted(const float* query, const int64_t* query_index, int64_t n_query_rows, int32_t dim,
-                            int32_t has_pos, int64_t n_queries, int32_t num_neg, const float* dpos, const float* dneg,
-                            const float* upstream, int64_t n_items, int64_t pad_row, float* weight, float* exp_avg,
-                            float* exp_avg_sq, float lr, float beta1, float beta2, float eps, int64_t step,
-                            void* workspace, int64_t workspace_bytes, rsa_stream_t stream);
+/* ---- The whole in-place SGD training step of a BPR two-tower model (nn.Embedding user and item tables, inner product,
+ * BPRLoss, num_neg == 64) as TWO calls -- what `fit(train.fused_optimizer: 'sgd')` issues per batch.  Replaces, per step of
+ * recstudio/model/basemodel/recommender.py:596-646: sampler.forward (ann/sampler.py:86-111 / :243-258), the two tower
+ * look-ups, score_func, BPRLoss, loss.backward() and optimizer.step() of torch.optim.SGD (no momentum / weight decay).
+ *   rsa_bpr_sgd_prepare  the part that does not read the weights: the negatives (the device random stream, "Philox
+ *     state"; sampler RSA_SAMPLER_UNIFORM: ids in [1, n_items); RSA_SAMPLER_POPULAR: `pop`), the step's (item id, element)
+ *     pairs sorted by id + the solo classification (item_workspace, solo), the (user id, query) pairs sorted (user_workspace).
+ *     A trainer issues it for batch k + 1 on a second stream while batch k's apply runs.
+ *   rsa_bpr_sgd_apply    forward + loss + update: rsa_fused_sample_gather_score with the ids given, fused BPR epilogue, user
+ *     gradient accumulated in the forward, solo item rows updated in the forward; the shared item rows
+ *     (rsa_rows_update_presorted) and the user rows.  loss_out = the batch's mean BPR loss.
+ * Bit-identical to the same sequence issued entry point by entry point.  dim in {64, 128, 256}. */
+typedef struct rsa_bpr_sgd_args {
+  int64_t size;                /* sizeof(rsa_bpr_sgd_args) */
+  float* item_table;           /* [n_items, dim], updated in place */
+  int64_t n_items;
+  float* user_table;           /* [n_users, dim], updated in place */
+  int64_t n_users;
+  int32_t dim;
+  int32_t num_neg;             /* 64 */
+  const int64_t* user_ids;     /* [n_queries] */
+  const int64_t* pos_ids;      /* [n_queries] */
+  int64_t n_queries;
+  int32_t sampler;             /* RSA_SAMPLER_UNIFORM / RSA_SAMPLER_POPULAR (prepare) */
+  int32_t _pad;
+  const rsa_popular_args* pop; /* HOST pointer, RSA_SAMPLER_POPULAR: the tables (ids / logp / numel / philox fields ignored) */
+  uint64_t seed, offset;       /* "Philox state" of the draw (prepare) */
+  uint32_t grid_threads;
+  uint32_t _pad2;
+  uint64_t elem_base;
+  const float* step_scale;     /* device scalar: -lr */
+  int64_t* neg_ids;            /* [n_queries, num_neg]: out of prepare, in of apply */
+  uint8_t* solo;               /* [n_queries, 1 + num_neg]: out of prepare, in of apply */
+  void* item_workspace;        /* rsa_scatter_rows_sorted_workspace_bytes(n_queries, num_neg, n_items) */
+  int64_t item_workspace_bytes;
+  void* user_workspace;        /* rsa_scatter_rows_sorted_workspace_bytes(n_queries, 1, n_users) */
+  int64_t user_workspace_bytes;
+  float* pos_score;            /* [n_queries] out */
+  float* neg_score;            /* [n_queries, num_neg] out */
+  float* row_loss;             /* [n_queries] out */
+  float* dpos;                 /* [n_queries] out */
+  float* dneg;                 /* [n_queries, num_neg] out */
+  float* query_grad;           /* [n_queries, dim] out */
+  const float* ones;           /* [n_queries] of 1.0f (the coefficients of the user-row apply) */
+  float* loss_out;             /* [1] out */
+  void* reduce_scratch;        /* rsa_scratch_bytes(), of the stream apply runs on */
+  int64_t uniform_high;        /* RSA_SAMPLER_UNIFORM: ids drawn in [1, uniform_high); 0 = n_items (UniformSampler(num_items) of a
+                                  model whose table has num_items rows, mf/bpr.py:24-25) */
+} rsa_bpr_sgd_args;
+int rsa_bpr_sgd_prepare(const rsa_bpr_sgd_args* args, rsa_stream_t stream);
+int rsa_bpr_sgd_apply(const rsa_bpr_sgd_args* args, rsa_stream_t stream);
 
 /* embedding_dense_backward: dst[ids[i]] += src[i] for ids != 0 (padding_idx=0).
  * Used for the user-table gradient.  dst [n_rows, dim] caller-zeroed. */
@@ -381,10 +476,22 @@ int rsa_scatter_add_rows(const float* src, const int64_t* ids, int64_t numel, in
  * out_ids [B, max_len] int64 (nullable), out_rows [B, max_len, dim] (nullable),
  * out_len [B] int64 (nullable).  Segments longer than max_len keep their LAST
  * max_len items (dataset.py:1400,1409 windows to the most recent max_seq_len). */
-int rsa_seg_gather(const float* item_table, int64_t n_items, int32_t dim,
-                   const int64_t* flat_item_ids, int64_t n_flat,
-                   const int64_t* seg_start, const int64_t* seg_end, int64_t n_seg, int32_t max_len,
-                   int64_t* out_ids, float* out_rows, int64_t* out_len, rsa_stream_t stream);
+typedef struct rsa_seg_gather_args {
+  int64_t size;                /* sizeof(rsa_seg_gather_args) */
+  const float* item_table;     /* nullable when out_rows is null */
+  int64_t n_items;
+  int32_t dim;
+  int32_t max_len;
+  const int64_t* flat_item_ids;
+  int64_t n_flat;
+  const int64_t* seg_start;
+  const int64_t* seg_end;
+  int64_t n_seg;
+  int64_t* out_ids;            /* nullable [n_seg, max_len] */
+  float* out_rows;             /* nullable [n_seg, max_len, dim] */
+  int64_t* out_len;            /* nullable [n_seg] */
+} rsa_seg_gather_args;
+int rsa_seg_gather(const rsa_seg_gather_args* args, rsa_stream_t stream);
 
 /* aux[r] of every row of a [n_rows, dim] table, the per-row operand of the cosine / Euclidean full-catalog scores:
  * RSA_SCORE_COS -> 1 / ||row||_2 (inf for a zero row: the reference divides by zero too, scorer.py:21-24),
@@ -408,11 +515,26 @@ int rsa_row_sqnorm(const float* table, int64_t n_rows, int32_t dim, int32_t scor
  *     query_aux [B] from rsa_row_sqnorm of the same mode; both null for RSA_SCORE_IP.
  *   workspace: device scratch of rsa_fullscore_workspace_bytes(B, n_items, k) bytes. */
 int64_t rsa_fullscore_workspace_bytes(int64_t n_query, int64_t n_items, int32_t k);
-int rsa_fullscore(const float* item_table, int64_t n_items, int32_t dim,
-                  const float* query, int64_t n_query,
-                  float* scores, float* lse, float* topk_val, int64_t* topk_idx, int32_t k,
-                  int32_t score_mode, const float* item_aux, const float* query_aux,
-                  void* workspace, int64_t workspace_bytes, rsa_stream_t stream);
+typedef struct rsa_fullscore_args {
+  int64_t size;                /* sizeof(rsa_fullscore_args) */
+  const float* item_table;
+  int64_t n_items;
+  int32_t dim;
+  int32_t score_mode;
+  const float* query;
+  int64_t n_query;
+  float* scores;               /* nullable */
+  float* lse;                  /* nullable */
+  float* topk_val;             /* nullable */
+  int64_t* topk_idx;           /* nullable */
+  int32_t k;
+  int32_t _pad;
+  const float* item_aux;       /* nullable */
+  const float* query_aux;      /* nullable */
+  void* workspace;
+  int64_t workspace_bytes;
+} rsa_fullscore_args;
+int rsa_fullscore(const rsa_fullscore_args* args, rsa_stream_t stream);
 
 /* Backward of logsumexp over the full catalog (SoftmaxLoss, loss_func.py:39-47, when the forward was
  * rsa_fullscore(..., lse) and [B, N-1] was never written):  probs[b, i-1] = row_scale[b] * exp(<q_b, item_i> - lse[b])

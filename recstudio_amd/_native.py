@@ -103,6 +103,89 @@ class ShardOwnerBprArgs(Structure):
     ]
 
 
+class _Sized(Structure):
+    """A versioned argument block (include/recstudio_amd.h, "Versioned argument blocks"): ``size`` is filled in here."""
+
+    def __init__(self, *a, **kw):
+        super().__init__(*a, **kw)
+        self.size = ctypes.sizeof(type(self))
+
+
+class PopularArgs(_Sized):
+    """struct rsa_popular_args."""
+    _fields_ = [
+        ('size', c_int64), ('table', c_void_p), ('pop_prob', c_void_p), ('guide', c_void_p), ('n_items', c_int64),
+        ('guide_log2', c_int32), ('lines_log2', c_int32), ('cdf_lut', c_void_p), ('cdf_lines', c_void_p), ('u_in', c_void_p),
+        ('ids', c_void_p), ('logp', c_void_p), ('u_out', c_void_p), ('numel', c_int64), ('seed', c_uint64), ('offset', c_uint64),
+        ('grid_threads', c_uint32), ('_pad', c_uint32), ('elem_base', c_uint64),
+    ]
+
+
+class LossArgs(_Sized):
+    """struct rsa_loss_args."""
+    _fields_ = [
+        ('size', c_int64), ('loss_kind', c_int32), ('n_pos', c_int32), ('pos_score', c_void_p), ('neg_score', c_void_p),
+        ('pos_logp', c_void_p), ('neg_logp', c_void_p), ('n_rows', c_int64), ('num_neg', c_int32), ('_pad', c_int32),
+        ('param0', c_float), ('param1', c_float), ('row_loss', c_void_p), ('loss_out', c_void_p), ('dpos', c_void_p),
+        ('dneg', c_void_p), ('scratch', c_void_p),
+    ]
+
+
+class RowsUpdateArgs(_Sized):
+    """struct rsa_rows_update_args."""
+    _fields_ = [
+        ('size', c_int64), ('query', c_void_p), ('query_index', c_void_p), ('n_query_rows', c_int64), ('dim', c_int32),
+        ('has_pos', c_int32), ('pos_ids', c_void_p), ('neg_ids', c_void_p), ('n_queries', c_int64), ('num_neg', c_int32),
+        ('_pad', c_int32), ('dpos', c_void_p), ('dneg', c_void_p), ('upstream', c_void_p), ('n_items', c_int64),
+        ('pad_row', c_int64), ('target', c_void_p), ('exp_avg', c_void_p), ('exp_avg_sq', c_void_p), ('lr', c_float),
+        ('beta1', c_float), ('beta2', c_float), ('eps', c_float), ('step', c_int64), ('solo', c_void_p), ('workspace', c_void_p),
+        ('workspace_bytes', c_int64),
+    ]
+
+
+class BprSgdArgs(_Sized):
+    """struct rsa_bpr_sgd_args."""
+    _fields_ = [
+        ('size', c_int64), ('item_table', c_void_p), ('n_items', c_int64), ('user_table', c_void_p), ('n_users', c_int64),
+        ('dim', c_int32), ('num_neg', c_int32), ('user_ids', c_void_p), ('pos_ids', c_void_p), ('n_queries', c_int64),
+        ('sampler', c_int32), ('_pad', c_int32), ('pop', POINTER(PopularArgs)), ('seed', c_uint64), ('offset', c_uint64),
+        ('grid_threads', c_uint32), ('_pad2', c_uint32), ('elem_base', c_uint64), ('step_scale', c_void_p), ('neg_ids', c_void_p),
+        ('solo', c_void_p), ('item_workspace', c_void_p), ('item_workspace_bytes', c_int64), ('user_workspace', c_void_p),
+        ('user_workspace_bytes', c_int64), ('pos_score', c_void_p), ('neg_score', c_void_p), ('row_loss', c_void_p),
+        ('dpos', c_void_p), ('dneg', c_void_p), ('query_grad', c_void_p), ('ones', c_void_p), ('loss_out', c_void_p),
+        ('reduce_scratch', c_void_p), ('uniform_high', c_int64),
+    ]
+
+
+class SegGatherArgs(_Sized):
+    """struct rsa_seg_gather_args."""
+    _fields_ = [
+        ('size', c_int64), ('item_table', c_void_p), ('n_items', c_int64), ('dim', c_int32), ('max_len', c_int32),
+        ('flat_item_ids', c_void_p), ('n_flat', c_int64), ('seg_start', c_void_p), ('seg_end', c_void_p), ('n_seg', c_int64),
+        ('out_ids', c_void_p), ('out_rows', c_void_p), ('out_len', c_void_p),
+    ]
+
+
+class FullscoreArgs(_Sized):
+    """struct rsa_fullscore_args."""
+    _fields_ = [
+        ('size', c_int64), ('item_table', c_void_p), ('n_items', c_int64), ('dim', c_int32), ('score_mode', c_int32),
+        ('query', c_void_p), ('n_query', c_int64), ('scores', c_void_p), ('lse', c_void_p), ('topk_val', c_void_p),
+        ('topk_idx', c_void_p), ('k', c_int32), ('_pad', c_int32), ('item_aux', c_void_p), ('query_aux', c_void_p),
+        ('workspace', c_void_p), ('workspace_bytes', c_int64),
+    ]
+
+
+# every `typedef struct rsa_* {...}` of the header and its ctypes mirror (tests/test_native_abi.py checks the list against the
+# header and every field offset against the C compiler)
+STRUCTS = {
+    'rsa_fused_args': FusedArgs, 'rsa_backward_args': BackwardArgs, 'rsa_shard_route_args': ShardRouteArgs,
+    'rsa_shard_home_args': ShardHomeArgs, 'rsa_shard_backward_args': ShardBackwardArgs,
+    'rsa_shard_owner_bpr_args': ShardOwnerBprArgs, 'rsa_popular_args': PopularArgs, 'rsa_loss_args': LossArgs,
+    'rsa_rows_update_args': RowsUpdateArgs, 'rsa_bpr_sgd_args': BprSgdArgs, 'rsa_seg_gather_args': SegGatherArgs,
+    'rsa_fullscore_args': FullscoreArgs,
+}
+
 # name -> (restype, argtypes); must list every symbol the header declares.
 SIGNATURES = {
     'rsa_last_error': (c_char_p, []),
@@ -112,43 +195,29 @@ SIGNATURES = {
     'rsa_sample_uniform': (c_int, [c_void_p, c_int64, c_int64, c_int64, c_uint64, c_uint64, c_uint32, c_uint64, c_void_p]),
     'rsa_sample_masked_uniform': (c_int, [c_void_p, c_int64, c_int32, c_int64, c_int32, c_void_p, c_uint64, c_uint64,
                                           c_uint32, c_uint64, c_void_p]),
-    'rsa_sample_popular': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p,
-                                   c_int64, c_uint64, c_uint64, c_uint32, c_uint64, c_void_p, c_void_p, c_int32, c_void_p]),
-    'rsa_popular_lookup': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p,
-                                   c_int64, c_void_p, c_void_p, c_int32, c_void_p]),
+    'rsa_sample_popular': (c_int, [POINTER(PopularArgs), c_void_p]),
+    'rsa_popular_lookup': (c_int, [POINTER(PopularArgs), c_void_p]),
     'rsa_item_logp': (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p]),
     'rsa_embedding_gather': (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_int64, c_void_p, c_void_p]),
     'rsa_fused_sample_gather_score': (c_int, [POINTER(FusedArgs), c_void_p]),
-    'rsa_pairwise_loss': (c_int, [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p,
-                                  c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
-    'rsa_pairwise_loss_ex': (c_int, [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_float, c_float,
-                                     c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
-    'rsa_ssm_shared_loss': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p,
-                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'rsa_pairwise_loss': (c_int, [POINTER(LossArgs), c_void_p]),
+    'rsa_ssm_shared_loss': (c_int, [POINTER(LossArgs), c_void_p]),
     'rsa_mean_rows': (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     'rsa_row_lse': (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_float, c_void_p]),
     'rsa_fused_backward': (c_int, [POINTER(BackwardArgs), c_void_p]),
-    'rsa_sort_step_elements': (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_int64, c_int64, c_void_p, c_void_p, c_int64,
-                                       c_void_p]),
-    'rsa_scatter_rows_presorted': (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int64, c_int32, c_void_p, c_void_p,
-                                           c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_void_p]),
+    'rsa_sort_step_elements': (c_int, [POINTER(RowsUpdateArgs), c_void_p]),
+    'rsa_rows_update_presorted': (c_int, [POINTER(RowsUpdateArgs), c_void_p]),
     'rsa_scatter_add_rows': (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_int64, c_void_p]),
-    'rsa_seg_gather': (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int32,
-                               c_void_p, c_void_p, c_void_p, c_void_p]),
+    'rsa_seg_gather': (c_int, [POINTER(SegGatherArgs), c_void_p]),
     'rsa_fullscore_softmax': (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_int64, c_void_p, c_void_p, c_void_p,
                                       c_void_p]),
     'rsa_fullscore_softmax_dq_workspace_bytes': (c_int64, [c_int64, c_int64, c_int32]),
     'rsa_fullscore_softmax_dq': (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_int64, c_void_p, c_void_p, c_void_p,
                                          c_void_p, c_void_p, c_int64, c_void_p]),
     'rsa_scatter_rows_sorted_workspace_bytes': (c_int64, [c_int64, c_int32, c_int64]),
-    'rsa_scatter_rows_sorted': (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_int64, c_int32, c_void_p,
-                                        c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_void_p]),
-    'rsa_adam_rows_sorted': (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_int64, c_int32, c_void_p,
-                                     c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_float, c_float,
-                                     c_float, c_float, c_int64, c_void_p, c_int64, c_void_p]),
-    'rsa_adam_rows_presorted': (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int64, c_int32, c_void_p, c_void_p,
-                                        c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_float, c_float, c_float,
-                                        c_float, c_int64, c_void_p, c_int64, c_void_p]),
+    'rsa_rows_update_sorted': (c_int, [POINTER(RowsUpdateArgs), c_void_p]),
+    'rsa_bpr_sgd_prepare': (c_int, [POINTER(BprSgdArgs), c_void_p]),
+    'rsa_bpr_sgd_apply': (c_int, [POINTER(BprSgdArgs), c_void_p]),
     'rsa_rng_advance': (c_int, [c_void_p, c_uint64, c_void_p]),
     'rsa_row_topk': (c_int, [c_void_p, c_int64, c_int64, c_int32, c_void_p, c_void_p, c_void_p]),
     'rsa_topk_mask_history': (c_int, [c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_int64, c_int32, c_void_p,
@@ -175,8 +244,7 @@ SIGNATURES = {
     'rsa_scatter_f32': (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     'rsa_gather_f32': (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     'rsa_fullscore_workspace_bytes': (c_int64, [c_int64, c_int64, c_int32]),
-    'rsa_fullscore': (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
-                              c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    'rsa_fullscore': (c_int, [POINTER(FullscoreArgs), c_void_p]),
     'rsa_row_sqnorm': (c_int, [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p]),
 }
 
@@ -196,7 +264,7 @@ def build(verbose=False):
     return LIB_PATH
 
 
-ABI_VERSION = 8      # RSA_ABI_VERSION of include/recstudio_amd.h this binding was written against
+ABI_VERSION = 9      # RSA_ABI_VERSION of include/recstudio_amd.h this binding was written against
 
 
 def lib():

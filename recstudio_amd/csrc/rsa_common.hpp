@@ -27,6 +27,19 @@ void set_error(const char* fmt, ...);
     }                                                                            \
   } while (0)
 
+// Versioned argument blocks (include/recstudio_amd.h, ABI 9): copy min(caller's size, ours) bytes of `src` into the
+// zero-filled `dst` -- fields the caller's header did not have read as 0 / null, fields ours does not have are ignored.
+template <class T>
+static inline int load_args(T& dst, const T* src, const char* who) {
+  RSA_CHECK_ARG(src != nullptr, "%s: args is null", who);
+  const int64_t sz = *reinterpret_cast<const int64_t*>(src);
+  RSA_CHECK_ARG(sz >= 16 && sz <= (1 << 16), "%s: args->size = %lld (set it to sizeof the argument struct)", who, (long long)sz);
+  __builtin_memset(&dst, 0, sizeof(T));
+  __builtin_memcpy(&dst, src, (size_t)sz < sizeof(T) ? (size_t)sz : sizeof(T));
+  dst.size = (int64_t)sizeof(T);
+  return RSA_OK;
+}
+
 // ---------------------------------------------------------------- Philox4x32-10
 // Random123 Philox4x32 with 10 rounds: the generator behind torch's device
 // distributions (rocRAND philox4x32_10_engine::ten_rounds).

@@ -902,10 +902,22 @@ static void gemm_dispatch(int dim, int mode, dim3 grid, hipStream_t s, const flo
 #undef RSA_DIM
 }
 
-extern "C" int rsa_fullscore(const float* item_table, int64_t n_items, int32_t dim, const float* query,
-                             int64_t n_query, float* scores, float* lse, float* topk_val, int64_t* topk_idx, int32_t k,
-                             int32_t score_mode, const float* item_aux, const float* query_aux,
-                             void* workspace, int64_t workspace_bytes, rsa_stream_t stream) {
+static int fullscore_impl(const float* item_table, int64_t n_items, int32_t dim, const float* query,
+                          int64_t n_query, float* scores, float* lse, float* topk_val, int64_t* topk_idx, int32_t k,
+                          int32_t score_mode, const float* item_aux, const float* query_aux,
+                          void* workspace, int64_t workspace_bytes, rsa_stream_t stream);
+
+extern "C" int rsa_fullscore(const rsa_fullscore_args* args, rsa_stream_t stream) {
+  rsa_fullscore_args a;
+  if (int rc = load_args(a, args, "rsa_fullscore")) return rc;
+  return fullscore_impl(a.item_table, a.n_items, a.dim, a.query, a.n_query, a.scores, a.lse, a.topk_val, a.topk_idx, a.k,
+                        a.score_mode, a.item_aux, a.query_aux, a.workspace, a.workspace_bytes, stream);
+}
+
+static int fullscore_impl(const float* item_table, int64_t n_items, int32_t dim, const float* query,
+                          int64_t n_query, float* scores, float* lse, float* topk_val, int64_t* topk_idx, int32_t k,
+                          int32_t score_mode, const float* item_aux, const float* query_aux,
+                          void* workspace, int64_t workspace_bytes, rsa_stream_t stream) {
   RSA_CHECK_ARG(n_query >= 0 && n_items >= 2, "rsa_fullscore: need n_items >= 2");
   if (n_query == 0) return RSA_OK;
   RSA_CHECK_ARG(item_table && query, "rsa_fullscore: item_table/query is null");

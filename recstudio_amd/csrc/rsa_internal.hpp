@@ -29,4 +29,10 @@ int apply_sorted_segments(const uint64_t* pairs, int64_t total, int64_t slots, c
                           const int64_t* keys, const float* d, const float* upstream, int64_t n_rows, int64_t pad_row,
                           float* target, const SortedLayout& L, hipStream_t s);
 
+// PopularSamplerModel.forward on explicit arguments (rsa_sample.hip; the body behind rsa_sample_popular)
+int sample_popular_impl(const float* table, const float* pop_prob, const int32_t* guide, int64_t n_items,
+                        int32_t guide_log2, int64_t* neg_ids, float* neg_logp, float* u_out, int64_t numel,
+                        uint64_t seed, uint64_t offset, uint32_t grid_threads, uint64_t elem_base,
+                        const float* cdf_lut, const float* cdf_lines, int32_t lines_log2, rsa_stream_t stream);
+
 }  // namespace rsa

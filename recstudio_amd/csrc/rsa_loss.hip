@@ -393,10 +393,29 @@ static int mean_rows_impl(const float* row_loss, int64_t n_rows, const int32_t* 
   return RSA_OK;
 }
 
-extern "C" int rsa_pairwise_loss(int32_t loss_kind, const float* pos_score, const float* neg_score,
+static int pairwise_loss_ex_impl(int32_t loss_kind, const float* pos_score, const float* neg_score,
                                  const float* pos_logp, const float* neg_logp, int64_t n_rows, int32_t num_neg,
-                                 float* row_loss, float* loss_out, float* dpos, float* dneg, void* scratch,
-                                 rsa_stream_t stream) {
+                                 float param0, float param1, float* row_loss, float* loss_out, float* dpos,
+                                 float* dneg, void* scratch, rsa_stream_t stream);
+static int pairwise_loss_impl(int32_t loss_kind, const float* pos_score, const float* neg_score,
+                              const float* pos_logp, const float* neg_logp, int64_t n_rows, int32_t num_neg,
+                              float* row_loss, float* loss_out, float* dpos, float* dneg, void* scratch,
+                              rsa_stream_t stream);
+
+extern "C" int rsa_pairwise_loss(const rsa_loss_args* args, rsa_stream_t stream) {
+  rsa_loss_args a;
+  if (int rc = load_args(a, args, "rsa_pairwise_loss")) return rc;
+  if (a.loss_kind >= RSA_LOSS_WBPR)
+    return pairwise_loss_ex_impl(a.loss_kind, a.pos_score, a.neg_score, a.pos_logp, a.neg_logp, a.n_rows, a.num_neg, a.param0,
+                                 a.param1, a.row_loss, a.loss_out, a.dpos, a.dneg, a.scratch, stream);
+  return pairwise_loss_impl(a.loss_kind, a.pos_score, a.neg_score, a.pos_logp, a.neg_logp, a.n_rows, a.num_neg, a.row_loss,
+                            a.loss_out, a.dpos, a.dneg, a.scratch, stream);
+}
+
+static int pairwise_loss_impl(int32_t loss_kind, const float* pos_score, const float* neg_score,
+                              const float* pos_logp, const float* neg_logp, int64_t n_rows, int32_t num_neg,
+                              float* row_loss, float* loss_out, float* dpos, float* dneg, void* scratch,
+                              rsa_stream_t stream) {
   RSA_CHECK_ARG(scratch != nullptr, "rsa_pairwise_loss: scratch is null");
   int32_t* g_count = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(scratch) + SCRATCH_BCE_COUNT);
   RSA_CHECK_ARG(loss_kind == RSA_LOSS_BPR || loss_kind == RSA_LOSS_SSM || loss_kind == RSA_LOSS_BCE,
@@ -442,10 +461,10 @@ extern "C" int rsa_pairwise_loss(int32_t loss_kind, const float* pos_score, cons
   return rsa_mean_rows(row_loss, n_rows, loss_out, scratch, stream);
 }
 
-extern "C" int rsa_pairwise_loss_ex(int32_t loss_kind, const float* pos_score, const float* neg_score,
-                                    const float* pos_logp, const float* neg_logp, int64_t n_rows, int32_t num_neg,
-                                    float param0, float param1, float* row_loss, float* loss_out, float* dpos,
-                                    float* dneg, void* scratch, rsa_stream_t stream) {
+static int pairwise_loss_ex_impl(int32_t loss_kind, const float* pos_score, const float* neg_score,
+                                 const float* pos_logp, const float* neg_logp, int64_t n_rows, int32_t num_neg,
+                                 float param0, float param1, float* row_loss, float* loss_out, float* dpos,
+                                 float* dneg, void* scratch, rsa_stream_t stream) {
   RSA_CHECK_ARG(scratch != nullptr, "rsa_pairwise_loss_ex: scratch is null");
   int32_t* g_count = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(scratch) + SCRATCH_BCE_COUNT);
   RSA_CHECK_ARG(loss_kind >= RSA_LOSS_WBPR && loss_kind <= RSA_LOSS_CCL, "rsa_pairwise_loss_ex: unknown loss %d",
@@ -482,10 +501,14 @@ extern "C" int rsa_pairwise_loss_ex(int32_t loss_kind, const float* pos_score, c
   return mean_rows_impl(row_loss, n_rows, count, loss_out, scratch, stream);
 }
 
-extern "C" int rsa_ssm_shared_loss(const float* pos_score, const float* pos_logp, const float* neg_score,
-                                   const float* neg_logp, int64_t n_rows, int32_t n_pos, int32_t num_neg,
-                                   float* row_loss, float* loss_out, float* dpos, float* dneg, void* scratch,
-                                   rsa_stream_t stream) {
+extern "C" int rsa_ssm_shared_loss(const rsa_loss_args* args, rsa_stream_t stream) {
+  rsa_loss_args a;
+  if (int rc = load_args(a, args, "rsa_ssm_shared_loss")) return rc;
+  const float *pos_score = a.pos_score, *pos_logp = a.pos_logp, *neg_score = a.neg_score, *neg_logp = a.neg_logp;
+  const int64_t n_rows = a.n_rows;
+  const int32_t n_pos = a.n_pos, num_neg = a.num_neg;
+  float *row_loss = a.row_loss, *loss_out = a.loss_out, *dpos = a.dpos, *dneg = a.dneg;
+  void* scratch = a.scratch;
   RSA_CHECK_ARG(n_rows >= 1 && n_pos >= 1 && num_neg >= 1, "rsa_ssm_shared_loss: bad sizes");
   RSA_CHECK_ARG(pos_score && neg_score && row_loss && loss_out, "rsa_ssm_shared_loss: null pointer");
   int64_t blocks = (n_rows + 3) / 4;

@@ -121,10 +121,15 @@ extern "C" int rsa_embedding_gather(const float* table, int64_t n_rows, int32_t 
   return RSA_OK;
 }
 
-extern "C" int rsa_seg_gather(const float* item_table, int64_t n_items, int32_t dim, const int64_t* flat_item_ids,
-                              int64_t n_flat, const int64_t* seg_start, const int64_t* seg_end, int64_t n_seg,
-                              int32_t max_len, int64_t* out_ids, float* out_rows, int64_t* out_len,
-                              rsa_stream_t stream) {
+extern "C" int rsa_seg_gather(const rsa_seg_gather_args* args, rsa_stream_t stream) {
+  rsa_seg_gather_args a;
+  if (int rc = load_args(a, args, "rsa_seg_gather")) return rc;
+  const float* item_table = a.item_table;
+  const int64_t n_items = a.n_items, n_flat = a.n_flat, n_seg = a.n_seg;
+  const int32_t dim = a.dim, max_len = a.max_len;
+  const int64_t *flat_item_ids = a.flat_item_ids, *seg_start = a.seg_start, *seg_end = a.seg_end;
+  int64_t *out_ids = a.out_ids, *out_len = a.out_len;
+  float* out_rows = a.out_rows;
   RSA_CHECK_ARG(n_seg >= 0 && max_len >= 1 && n_flat >= 0, "rsa_seg_gather: bad sizes");
   if (n_seg == 0) return RSA_OK;
   RSA_CHECK_ARG(flat_item_ids && seg_start && seg_end, "rsa_seg_gather: null input pointer");

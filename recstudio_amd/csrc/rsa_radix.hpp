@@ -377,8 +377,19 @@ inline int64_t radix_tiles(int64_t total) {
   const int64_t tile = 256 * (int64_t)radix_items(total);
   return (total + tile - 1) / tile;
 }
-inline int64_t radix_temp_bytes(int64_t total) {
-  const int64_t c = RDX_BINS * radix_tiles(total) * 4;
+// Counter space for a sort of ANY total <= max_total.  radix_tiles() is not monotone in the total (the tile size steps up at
+// every whole round of the chip), and callers size one workspace for the largest step and then sort fewer elements in it (the
+// owner side of the sharded backward: slots vs slots + queries) -- so the size is taken from an upper bound of the tile count
+// that IS monotone: tiles(t) <= t / (256 * RDX_ITEMS_MIN) and tiles(t) <= rounds(t) * RDX_SLOTS.
+inline int64_t radix_tiles_upper(int64_t max_total) {
+  if (max_total <= 0) return 1;
+  const int64_t by_min_tile = (max_total + 256 * (int64_t)RDX_ITEMS_MIN - 1) / (256 * (int64_t)RDX_ITEMS_MIN);
+  const int64_t round_cap = (int64_t)RDX_SLOTS * 256 * RDX_ITEMS_MAX;
+  const int64_t by_rounds = ((max_total + round_cap - 1) / round_cap) * RDX_SLOTS;
+  return by_min_tile < by_rounds ? by_min_tile : by_rounds;
+}
+inline int64_t radix_temp_bytes(int64_t max_total) {
+  const int64_t c = RDX_BINS * radix_tiles_upper(max_total) * 4;
   return (c + 255) / 256 * 256 + RDX_BINS * 4;
 }
 
@@ -397,6 +408,7 @@ inline hipError_t radix_sort_pairs(const SRC0& src0, uint64_t* buf_a, uint64_t* 
   }
   const int64_t n_tiles = radix_tiles(total);
   const int items = radix_items(total);
+  if (n_tiles > radix_tiles_upper(total)) return hipErrorInvalidValue;      // (cannot happen: the bound above)
   uint32_t* counts = reinterpret_cast<uint32_t*>(temp);
   uint32_t* totals = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(temp) + (RDX_BINS * n_tiles * 4 + 255) / 256 * 256);
   const int passes = radix_passes(bits);

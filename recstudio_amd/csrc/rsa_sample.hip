@@ -8,6 +8,7 @@
 // points exist for the Sampler plugin surface (a Sampler used on its own) and as
 // the unit the parity tests compare with torch.randint / torch.rand on device.
 #include "rsa_common.hpp"
+#include "rsa_internal.hpp"
 
 namespace rsa {
 
@@ -243,11 +244,17 @@ static int check_popular(const char* fn, const float* table, const float* pop_pr
   return RSA_OK;
 }
 
-extern "C" int rsa_sample_popular(const float* table, const float* pop_prob, const int32_t* guide, int64_t n_items,
-                                  int32_t guide_log2, int64_t* neg_ids, float* neg_logp, float* u_out, int64_t numel,
-                                  uint64_t seed, uint64_t offset, uint32_t grid_threads, uint64_t elem_base,
-                                  const float* cdf_lut, const float* cdf_lines, int32_t lines_log2,
-                                  rsa_stream_t stream) {
+extern "C" int rsa_sample_popular(const rsa_popular_args* args, rsa_stream_t stream) {
+  rsa_popular_args a;
+  if (int rc = load_args(a, args, "rsa_sample_popular")) return rc;
+  return sample_popular_impl(a.table, a.pop_prob, a.guide, a.n_items, a.guide_log2, a.ids, a.logp, a.u_out, a.numel, a.seed,
+                             a.offset, a.grid_threads, a.elem_base, a.cdf_lut, a.cdf_lines, a.lines_log2, stream);
+}
+
+int rsa::sample_popular_impl(const float* table, const float* pop_prob, const int32_t* guide, int64_t n_items,
+                             int32_t guide_log2, int64_t* neg_ids, float* neg_logp, float* u_out, int64_t numel,
+                             uint64_t seed, uint64_t offset, uint32_t grid_threads, uint64_t elem_base,
+                             const float* cdf_lut, const float* cdf_lines, int32_t lines_log2, rsa_stream_t stream) {
   RSA_CHECK_ARG(numel >= 0, "rsa_sample_popular: numel < 0");
   if (numel == 0) return RSA_OK;
   if (int rc = check_popular("rsa_sample_popular", table, pop_prob, guide, n_items, guide_log2, cdf_lines, lines_log2)) return rc;
@@ -268,10 +275,20 @@ extern "C" int rsa_sample_popular(const float* table, const float* pop_prob, con
   return RSA_OK;
 }
 
-extern "C" int rsa_popular_lookup(const float* table, const float* pop_prob, const int32_t* guide, int64_t n_items,
-                                  int32_t guide_log2, const float* u, int64_t* ids, float* logp, int64_t numel,
-                                  const float* cdf_lut, const float* cdf_lines, int32_t lines_log2,
-                                  rsa_stream_t stream) {
+static int popular_lookup_impl(const float* table, const float* pop_prob, const int32_t* guide, int64_t n_items,
+                               int32_t guide_log2, const float* u, int64_t* ids, float* logp, int64_t numel,
+                               const float* cdf_lut, const float* cdf_lines, int32_t lines_log2, rsa_stream_t stream);
+
+extern "C" int rsa_popular_lookup(const rsa_popular_args* args, rsa_stream_t stream) {
+  rsa_popular_args a;
+  if (int rc = load_args(a, args, "rsa_popular_lookup")) return rc;
+  return popular_lookup_impl(a.table, a.pop_prob, a.guide, a.n_items, a.guide_log2, a.u_in, a.ids, a.logp, a.numel, a.cdf_lut,
+                             a.cdf_lines, a.lines_log2, stream);
+}
+
+static int popular_lookup_impl(const float* table, const float* pop_prob, const int32_t* guide, int64_t n_items,
+                               int32_t guide_log2, const float* u, int64_t* ids, float* logp, int64_t numel,
+                               const float* cdf_lut, const float* cdf_lines, int32_t lines_log2, rsa_stream_t stream) {
   RSA_CHECK_ARG(numel >= 0, "rsa_popular_lookup: numel < 0");
   if (numel == 0) return RSA_OK;
   if (int rc = check_popular("rsa_popular_lookup", table, pop_prob, guide, n_items, guide_log2, cdf_lines, lines_log2)) return rc;

@@ -448,55 +448,38 @@ static int scatter_sorted_impl(const float* query, const int64_t* query_index, i
                            n_items, pad_row, target, adam, workspace, workspace_bytes, stream);
 }
 
-extern "C" int rsa_sort_step_elements(const int64_t* pos_ids, const int64_t* neg_ids, int64_t n_queries, int32_t num_neg,
-                                      int64_t n_items, int64_t pad_row, uint8_t* solo, void* workspace, int64_t workspace_bytes,
-                                      rsa_stream_t stream) {
-  return sort_elements_impl(pos_ids, neg_ids, n_queries, num_neg, n_items, pad_row, solo, workspace, workspace_bytes, stream,
-                            "rsa_sort_step_elements");
+static AdamArgs adam_of(const rsa_rows_update_args& a) {
+  if (a.exp_avg == nullptr) return AdamArgs{nullptr, nullptr, 0.f, 0.f, 0.f, 0.f};
+  const double bc1 = 1.0 - pow((double)a.beta1, (double)a.step), bc2 = 1.0 - pow((double)a.beta2, (double)a.step);
+  return AdamArgs{a.exp_avg, a.exp_avg_sq, 1.f - a.beta1, 1.f - a.beta2, a.eps, (float)((double)a.lr * sqrt(bc2) / bc1)};
 }
 
-extern "C" int rsa_scatter_rows_presorted(const float* query, const int64_t* query_index, int64_t n_query_rows, int32_t dim,
-                                          int32_t has_pos, int64_t n_queries, int32_t num_neg, const float* dpos, const float* dneg,
-                                          const float* upstream, int64_t n_items, int64_t pad_row, float* target, void* workspace,
-                                          int64_t workspace_bytes, rsa_stream_t stream) {
-  const AdamArgs none{nullptr, nullptr, 0.f, 0.f, 0.f, 0.f};
-  return apply_sorted_impl(query, query_index, n_query_rows, dim, has_pos != 0, n_queries, num_neg, dpos, dneg, upstream, n_items,
-                           pad_row, target, none, workspace, workspace_bytes, stream);
+static int check_adam(const rsa_rows_update_args& a, const char* who) {
+  if (a.exp_avg == nullptr && a.exp_avg_sq == nullptr) return RSA_OK;
+  RSA_CHECK_ARG(a.exp_avg && a.exp_avg_sq && a.step >= 1 && a.beta1 >= 0.f && a.beta1 < 1.f && a.beta2 >= 0.f && a.beta2 < 1.f,
+                "%s: bad optimizer state / hyper-parameters", who);
+  return RSA_OK;
 }
 
-extern "C" int rsa_scatter_rows_sorted(const float* query, const int64_t* query_index, int64_t n_query_rows, int32_t dim,
-                                       const int64_t* pos_ids, const int64_t* neg_ids, int64_t n_queries,
-                                       int32_t num_neg, const float* dpos, const float* dneg, const float* upstream,
-                                       int64_t n_items, int64_t pad_row, float* target, void* workspace,
-                                       int64_t workspace_bytes, rsa_stream_t stream) {
-  const AdamArgs none{nullptr, nullptr, 0.f, 0.f, 0.f, 0.f};
-  return scatter_sorted_impl(query, query_index, n_query_rows, dim, pos_ids, neg_ids, n_queries, num_neg, dpos, dneg,
-                             upstream, n_items, pad_row, target, none, workspace, workspace_bytes, stream);
+extern "C" int rsa_sort_step_elements(const rsa_rows_update_args* args, rsa_stream_t stream) {
+  rsa_rows_update_args a;
+  if (int rc = load_args(a, args, "rsa_sort_step_elements")) return rc;
+  return sort_elements_impl(a.pos_ids, a.neg_ids, a.n_queries, a.num_neg, a.n_items, a.pad_row, a.solo, a.workspace,
+                            a.workspace_bytes, stream, "rsa_sort_step_elements");
 }
 
-extern "C" int rsa_adam_rows_presorted(const float* query, const int64_t* query_index, int64_t n_query_rows, int32_t dim,
-                                       int32_t has_pos, int64_t n_queries, int32_t num_neg, const float* dpos, const float* dneg,
-                                       const float* upstream, int64_t n_items, int64_t pad_row, float* weight, float* exp_avg,
-                                       float* exp_avg_sq, float lr, float beta1, float beta2, float eps, int64_t step,
-                                       void* workspace, int64_t workspace_bytes, rsa_stream_t stream) {
-  RSA_CHECK_ARG(exp_avg && exp_avg_sq && step >= 1 && beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f,
-                "rsa_adam_rows_presorted: bad optimizer state / hyper-parameters");
-  const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
-  const AdamArgs adam{exp_avg, exp_avg_sq, 1.f - beta1, 1.f - beta2, eps, (float)((double)lr * sqrt(bc2) / bc1)};
-  return apply_sorted_impl(query, query_index, n_query_rows, dim, has_pos != 0, n_queries, num_neg, dpos, dneg, upstream, n_items,
-                           pad_row, weight, adam, workspace, workspace_bytes, stream);
+extern "C" int rsa_rows_update_presorted(const rsa_rows_update_args* args, rsa_stream_t stream) {
+  rsa_rows_update_args a;
+  if (int rc = load_args(a, args, "rsa_rows_update_presorted")) return rc;
+  if (int rc = check_adam(a, "rsa_rows_update_presorted")) return rc;
+  return apply_sorted_impl(a.query, a.query_index, a.n_query_rows, a.dim, a.has_pos != 0, a.n_queries, a.num_neg, a.dpos, a.dneg,
+                           a.upstream, a.n_items, a.pad_row, a.target, adam_of(a), a.workspace, a.workspace_bytes, stream);
 }
 
-extern "C" int rsa_adam_rows_sorted(const float* query, const int64_t* query_index, int64_t n_query_rows, int32_t dim,
-                                    const int64_t* pos_ids, const int64_t* neg_ids, int64_t n_queries, int32_t num_neg,
-                                    const float* dpos, const float* dneg, const float* upstream, int64_t n_items,
-                                    int64_t pad_row, float* weight, float* exp_avg, float* exp_avg_sq, float lr,
-                                    float beta1, float beta2, float eps, int64_t step, void* workspace,
-                                    int64_t workspace_bytes, rsa_stream_t stream) {
-  RSA_CHECK_ARG(exp_avg && exp_avg_sq && step >= 1 && beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f,
-                "rsa_adam_rows_sorted: bad optimizer state / hyper-parameters");
-  const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
-  const AdamArgs adam{exp_avg, exp_avg_sq, 1.f - beta1, 1.f - beta2, eps, (float)((double)lr * sqrt(bc2) / bc1)};
-  return scatter_sorted_impl(query, query_index, n_query_rows, dim, pos_ids, neg_ids, n_queries, num_neg, dpos, dneg,
-                             upstream, n_items, pad_row, weight, adam, workspace, workspace_bytes, stream);
+extern "C" int rsa_rows_update_sorted(const rsa_rows_update_args* args, rsa_stream_t stream) {
+  rsa_rows_update_args a;
+  if (int rc = load_args(a, args, "rsa_rows_update_sorted")) return rc;
+  if (int rc = check_adam(a, "rsa_rows_update_sorted")) return rc;
+  return scatter_sorted_impl(a.query, a.query_index, a.n_query_rows, a.dim, a.pos_ids, a.neg_ids, a.n_queries, a.num_neg, a.dpos,
+                             a.dneg, a.upstream, a.n_items, a.pad_row, a.target, adam_of(a), a.workspace, a.workspace_bytes, stream);
 }

@@ -164,6 +164,8 @@ class _DeviceLoader:
     the per-batch Python ``torch.cat([arange ...])`` + ``pad_sequence`` (dataset.py:1428-1434).  Batches have
     the same keys, dtypes and values as the host loader's."""
 
+    EPOCH_GATHER_BYTES = 8 << 30      # epochs whose permuted columns fit this are gathered once (see __iter__)
+
     def __init__(self, dataset, batch_size, shuffle, drop_last, device, rank=0, world=1):
         """``world`` > 1: ``batch_size`` is per rank; the epoch's order is drawn for the GLOBAL batches of
         ``batch_size * world`` samples from the device generator (the same state on every rank after ``seed_everything``)
@@ -202,6 +204,17 @@ class _DeviceLoader:
         else:
             order = torch.randperm(n, device=self.device) if self.shuffle else torch.arange(n, device=self.device)
         ds = self.ds
+        if not self.seq and self.world == 1 and n * 8 * (len(self.cols) + 1) <= self.EPOCH_GATHER_BYTES:
+            # the whole epoch's columns in its order with ONE gather per column; a batch is then a dict of views -- no
+            # kernel and no allocation per step (per-batch gathers: 1 + len(cols) launches, a B = 4096 step's worth of time)
+            rows = self.index[order]
+            epoch = {k: v[rows] for k, v in self.cols.items()}
+            del rows
+            for lo in range(0, n, self.batch_size):
+                if self.drop_last and lo + self.batch_size > n:
+                    break
+                yield {k: v[lo:lo + self.batch_size] for k, v in epoch.items()}
+            return
         for lo in range(0, n, self.batch_size):
             sel = order[lo:lo + self.batch_size]
             if self.drop_last and sel.numel() < self.batch_size:
@@ -263,6 +276,38 @@ class TripletDataset:
         n = len(users)
         ratings = np.ones(n, dtype=np.float32) if ratings is None else np.asarray(ratings, dtype=np.float64)
         return cls(name, config, _interactions=(users, items, ratings, timestamps))
+
+    @classmethod
+    def from_mapped_ids(cls, users, items, ratings=None, n_users=None, n_items=None, config=None, name='synthetic'):
+        """Build from id columns that are ALREADY mapped (int64, 1-based, 0 = padding) -- the state ``load_cache`` restores --
+        without the token factorisation of ``from_interactions``: synthetic streams and externally preprocessed data at
+        sizes where a host-side ``np.unique`` over the stream is the slow part.  ``n_users`` / ``n_items`` are the table sizes
+        (ids < n; default max id + 1).  Every interaction is a training sample (``data_index`` = all rows) until ``build``
+        splits it."""
+        self = cls.__new__(cls)
+        self.name = name
+        self.config = dict(DEFAULT_CONFIG)
+        if config:
+            self.config.update(config)
+        self.fuid = self.config['user_id_field'].split(':')[0]
+        self.fiid = self.config['item_id_field'].split(':')[0]
+        self.frating = self.config['rating_field'].split(':')[0]
+        self.ftime = self.config['time_field'].split(':')[0] if self.config['time_field'] else None
+        users, items = torch.as_tensor(users, dtype=torch.int64), torch.as_tensor(items, dtype=torch.int64)
+        if users.shape != items.shape or users.dim() != 1:
+            raise ValueError('users and items must be 1-D id columns of the same length')
+        self._n_users = int(n_users) if n_users is not None else int(users.max()) + 1
+        self._n_items = int(n_items) if n_items is not None else int(items.max()) + 1
+        if len(users) and (int(users.max()) >= self._n_users or int(items.max()) >= self._n_items or int(users.min()) < 0
+                           or int(items.min()) < 0):
+            raise ValueError('mapped ids must lie in [0, n_users) / [0, n_items)')
+        ratings = torch.ones(len(users), dtype=torch.float32) if ratings is None else torch.as_tensor(ratings, dtype=torch.float32)
+        self.field2tokens = {}
+        self.inter_feat = {self.fuid: users, self.fiid: items, self.frating: ratings}
+        self.data_index = torch.arange(len(users))
+        self._use_field = {self.fuid, self.fiid, self.frating}
+        self.eval_mode = False
+        return self
 
     # ------------------------------------------------------------------ flat binary cache
     def save_cache(self, path):

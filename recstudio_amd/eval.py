@@ -34,9 +34,9 @@ def ndcg(pred, target, k):
     pred_dcg = _dcg(pred.float(), k)
     ideal = _dcg(torch.sort((target > 0).float(), descending=True)[0], k)
     irrelevant = torch.all(target <= sys.float_info.epsilon, dim=-1)
-    pred_dcg[irrelevant] = 0
-    pred_dcg[~irrelevant] /= ideal[~irrelevant]
-    return pred_dcg.mean()
+    # (same values as the reference's two masked assignments, eval/__init__.py:129-131, without their boolean-mask
+    # indexing: each of those is a nonzero() -> a host synchronisation per metric per evaluation batch)
+    return torch.where(irrelevant, torch.zeros_like(pred_dcg), pred_dcg / ideal).mean()
 
 
 def mrr(pred, target, k):

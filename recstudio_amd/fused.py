@@ -8,10 +8,13 @@ materialising the [B, n, d] negative rows.  Its backward is ``rsa_fused_backward
 autograd produces in the reference (dense ``weight.grad`` with row 0 untouched), or row-sparse
 COO gradients when ``sparse_grad=True`` (the only workable form at N = 1e7..1e8).
 """
+import ctypes
+
 import torch
 
 from . import _native as nat
-from . import ops
+from . import ops, rng
+from ._native import ptr
 from .sampler import PopularSamplerModel, Sampler, UniformSampler
 
 
@@ -342,56 +345,140 @@ class PrefetchedBPRSGD:
     those of the same sequence of ``bpr_sgd_step`` calls, bit for bit (the work is the same, only its place in time
     moves).  A ticket is stepped exactly once, in the order the tickets were prepared."""
 
+    RING = 2          # buffer sets in flight: the batch being stepped and the one being prepared
+
     def __init__(self, item_weight, user_weight, num_neg, lr, sampler):
         self.iw, self.uw = item_weight.data, user_weight.data
         if not (num_neg == 64 and self.iw.shape[1] in (64, 128, 256)):
             raise NotImplementedError('PrefetchedBPRSGD: num_neg == 64 and embed_dim in {64, 128, 256} (the in-forward update)')
-        if _sampler_kind(sampler) not in (nat.SAMPLER_UNIFORM, nat.SAMPLER_POPULAR):
+        self.kind = _sampler_kind(sampler)
+        if self.kind not in (nat.SAMPLER_UNIFORM, nat.SAMPLER_POPULAR):
             raise TypeError(f'PrefetchedBPRSGD does not cover sampler {type(sampler).__name__}')
-        self.num_neg, self.sampler = int(num_neg), sampler
-        self.side = torch.cuda.Stream(device=self.iw.device)
-        self.step_scale = torch.full((1,), -float(lr), dtype=torch.float32, device=self.iw.device)
-        self._ones = None
+        if not (self.iw.is_cuda and self.iw.is_contiguous() and self.uw.is_contiguous() and self.uw.device == self.iw.device
+                and self.iw.dtype == self.uw.dtype == torch.float32):
+            raise RuntimeError('PrefetchedBPRSGD: contiguous fp32 tables on one GPU (there is no CPU fallback)')
+        self.num_neg, self.sampler, self.dev = int(num_neg), sampler, self.iw.device
+        self.side = torch.cuda.Stream(device=self.dev)
+        self.step_scale = torch.full((1,), -float(lr), dtype=torch.float32, device=self.dev)
+        self._fork = torch.cuda.Event()           # "everything the main stream was given so far", for the side stream to wait on
+        self._slots, self._count = {}, 0
+        self._lib = nat.lib()
+        self._pop = self._pop_src = None
+        self._unroll = 4 if self.kind == nat.SAMPLER_POPULAR else None
 
     def set_lr(self, lr):
         """New learning rate from the next ``step`` on (call between steps, e.g. a scheduler at the end of an epoch)."""
         self.step_scale.fill_(-float(lr))
 
+    # -- the argument blocks: one per buffer set and batch size, filled once; a step rewrites the batch pointers and the Philox state
+    def _popular_tables(self):
+        src = self.sampler._buffers.get('table')
+        if self._pop is None or src is not self._pop_src:        # (re)built tables after load_state_dict / .to()
+            kw = self.sampler.lookup_kwargs()
+            kw.pop('table_prob', None)
+            self._pop = ops.popular_args(**kw)
+            self._pop_keep = kw
+            self._pop_src = src
+            for slots in self._slots.values():
+                for sl in slots:
+                    sl['args'].pop = ctypes.pointer(self._pop)
+        return self._pop
+
+    def _slot(self, M):
+        slots = self._slots.get(M)
+        if slots is None:
+            lib, dev, n, d = self._lib, self.dev, self.num_neg, self.iw.shape[1]
+            N, U = self.iw.shape[0], self.uw.shape[0]
+            iws = int(lib.rsa_scatter_rows_sorted_workspace_bytes(M, n, N))
+            uws = int(lib.rsa_scatter_rows_sorted_workspace_bytes(M, 1, U))
+            ones = torch.ones(M, dtype=torch.float32, device=dev)
+            slots = []
+            for _ in range(self.RING):
+                f32 = dict(dtype=torch.float32, device=dev)
+                b = {'neg': torch.empty(M, n, dtype=torch.int64, device=dev), 'solo': torch.empty(M, n + 1, dtype=torch.uint8, device=dev),
+                     'iws': torch.empty(max(iws, 8), dtype=torch.uint8, device=dev),
+                     'uws': torch.empty(max(uws, 8), dtype=torch.uint8, device=dev),
+                     'pos_score': torch.empty(M, **f32), 'neg_score': torch.empty(M, n, **f32), 'row_loss': torch.empty(M, **f32),
+                     'dpos': torch.empty(M, **f32), 'dneg': torch.empty(M, n, **f32), 'query_grad': torch.empty(M, d, **f32),
+                     'ones': ones, 'ready': torch.cuda.Event()}
+                a = nat.BprSgdArgs()
+                a.item_table, a.n_items, a.user_table, a.n_users, a.dim, a.num_neg = ptr(self.iw), N, ptr(self.uw), U, d, n
+                a.n_queries, a.sampler, a.step_scale = M, self.kind, ptr(self.step_scale)
+                a.neg_ids, a.solo = ptr(b['neg']), ptr(b['solo'])
+                a.item_workspace, a.item_workspace_bytes = ptr(b['iws']), iws
+                a.user_workspace, a.user_workspace_bytes = ptr(b['uws']), uws
+                a.pos_score, a.neg_score, a.row_loss = ptr(b['pos_score']), ptr(b['neg_score']), ptr(b['row_loss'])
+                a.dpos, a.dneg, a.query_grad, a.ones = ptr(b['dpos']), ptr(b['dneg']), ptr(b['query_grad']), ptr(ones)
+                if self.kind == nat.SAMPLER_UNIFORM:
+                    a.uniform_high = int(self.sampler.num_items) + 1
+                else:
+                    a.pop = ctypes.pointer(self._popular_tables())
+                b['args'], b['ref'] = a, ctypes.byref(a)
+                slots.append(b)
+            self._slots[M] = slots
+        return slots[self._count % self.RING]
+
     def prepare(self, user_ids, pos_ids):
-        main = torch.cuda.current_stream(self.iw.device)
-        self.side.wait_stream(main)                   # the batch tensors may have been produced on the main stream
-        with torch.no_grad(), torch.cuda.stream(self.side):
-            neg = self.sampler(torch.empty(user_ids.numel(), 1, device=self.iw.device), self.num_neg, None)[0]
-            solo, ws = ops.sort_step_elements(pos_ids, neg, self.iw.shape[0], pad_row=0)
-            ws_user = None
-            if self.uw.shape[1] in (64, 128, 256):    # the user rows' sort does not read the weights either
-                ws_user = ops.sort_step_elements(None, user_ids.view(-1, 1), self.uw.shape[0], pad_row=0, want_solo=False)[1]
-            ready = torch.cuda.Event()
-            ready.record(self.side)
-        for t in (neg, solo, ws, ws_user):            # allocated on the side stream, consumed (and freed) on the main one
-            if t is not None:
-                t.record_stream(main)
-        return {'user_ids': user_ids, 'pos_ids': pos_ids, 'neg': neg, 'solo': solo, 'ws': ws, 'ws_user': ws_user, 'ready': ready}
+        """Issue the weight-independent part of a step (negatives, sorts, classification) on the side stream -> ticket."""
+        if not (user_ids.is_cuda and user_ids.dtype == pos_ids.dtype == torch.int64 and user_ids.is_contiguous()
+                and pos_ids.is_contiguous() and user_ids.numel() == pos_ids.numel() and user_ids.device == self.dev):
+            raise TypeError('PrefetchedBPRSGD.prepare: contiguous int64 user / positive ids on the tables\' device')
+        M = user_ids.numel()
+        if self.kind == nat.SAMPLER_POPULAR:
+            self._popular_tables()
+        b = self._slot(M)
+        self._count += 1
+        a = b['args']
+        a.user_ids, a.pos_ids = user_ids.data_ptr(), pos_ids.data_ptr()
+        unroll = self._unroll if self._unroll is not None else rng.randint_unroll(1, int(self.sampler.num_items) + 1)
+        pc = rng.reserve(M * self.num_neg, unroll, self.dev, None)
+        a.seed, a.offset, a.grid_threads, a.elem_base = pc.seed, pc.offset, pc.grid_threads, pc.elem_base
+        main = torch.cuda.current_stream(self.dev)
+        self._fork.record(main)                      # the batch tensors may have been produced on the main stream, and the
+        self.side.wait_event(self._fork)             # buffer set's previous step must be over
+        with _device_of(self.dev):
+            rc = self._lib.rsa_bpr_sgd_prepare(b['ref'], self.side.cuda_stream)
+        if rc != 0:
+            nat.check(rc, 'rsa_bpr_sgd_prepare')
+        b['ready'].record(self.side)
+        return {'user_ids': user_ids, 'pos_ids': pos_ids, 'neg': b['neg'], 'slot': b, 'seq': self._count}
 
     def step(self, ticket):
-        """The weight-dependent part of the step on the current stream; returns (loss, neg_ids)."""
-        torch.cuda.current_stream(self.iw.device).wait_event(ticket['ready'])
-        uid, pos, neg = ticket['user_ids'], ticket['pos_ids'], ticket['neg']
-        M = uid.numel()
-        with torch.no_grad():
-            out = ops.fused_forward(self.iw, self.uw, self.num_neg, query_index=uid, pos_ids=pos, neg_ids=neg,
-                                    sampler=nat.SAMPLER_GIVEN, fused_bpr=True, want_query_grad=True,
-                                    inplace_update=(ticket['solo'], self.step_scale))
-            ops.scatter_rows_presorted(self.iw, self.uw, ticket['ws'], M, self.num_neg, out['dneg'], query_index=uid,
-                                       dpos=out['dpos'], upstream=self.step_scale, pad_row=0)
-            if ticket['ws_user'] is not None:         # _apply_user_rows with its sort done ahead
-                if self._ones is None or self._ones.shape[0] != M:
-                    self._ones = torch.ones(M, 1, dtype=torch.float32, device=self.uw.device)
-                ops.scatter_rows_presorted(self.uw, out['query_grad'], ticket['ws_user'], M, 1, self._ones,
-                                           upstream=self.step_scale, pad_row=0)
-            else:
-                _apply_user_rows(self.uw, uid, out['query_grad'], self.step_scale)
-        return out['loss'], out['neg_ids']
+        """The weight-dependent part of the step on the current stream; returns (loss, neg_ids).  ``neg_ids`` (and the
+        other per-step buffers) belong to the stepper and are overwritten by the RING-th ``prepare`` call after this
+        ticket's: copy what must outlive that."""
+        b = ticket['slot']
+        if ticket['seq'] + self.RING <= self._count:
+            raise RuntimeError('PrefetchedBPRSGD.step: this ticket\'s buffers were reused (tickets are stepped in order, at most '
+                               f'{self.RING - 1} prepared ahead)')
+        main = torch.cuda.current_stream(self.dev)
+        main.wait_event(b['ready'])
+        loss = torch.empty((), dtype=torch.float32, device=self.dev)
+        a = b['args']
+        a.loss_out = loss.data_ptr()
+        with _device_of(self.dev):
+            a.reduce_scratch = ptr(ops._scratch_for(self.dev, main.cuda_stream))
+            rc = self._lib.rsa_bpr_sgd_apply(b['ref'], main.cuda_stream)
+        if rc != 0:
+            nat.check(rc, 'rsa_bpr_sgd_apply')
+        return loss, ticket['neg']
+
+
+class _device_of:
+    """``with _device_of(dev):`` -- dev current for the duration of a native call (a no-op when it already is)."""
+    __slots__ = ('dev', 'guard')
+
+    def __init__(self, dev):
+        self.dev, self.guard = dev, None
+
+    def __enter__(self):
+        if self.dev.index != torch.cuda.current_device():
+            self.guard = torch.cuda.device(self.dev)
+            self.guard.__enter__()
+
+    def __exit__(self, *exc):
+        if self.guard is not None:
+            self.guard.__exit__(*exc)
 
 
 class FusedBPRAdam:

@@ -119,7 +119,11 @@ _SCRATCH = {}
 
 def _scratch():
     dev = _LAUNCH_DEV[-1] if _LAUNCH_DEV else torch.device('cuda', torch.cuda.current_device())
-    key = (dev.index, _raw_stream(dev))
+    return _scratch_for(dev, _raw_stream(dev))
+
+
+def _scratch_for(dev, raw_stream):
+    key = (dev.index, raw_stream)
     t = _SCRATCH.get(key)
     if t is None:
         if len(_SCRATCH) >= 64:          # short-lived streams: forget the oldest blocks (a block is only ever used on its stream)
@@ -171,6 +175,16 @@ def sample_masked_uniform(user_hist, num_items, per_row, generator=None):
     return out
 
 
+def popular_args(table, pop_prob, guide, guide_log2, cdf_lut=None, cdf_lines=None, lines_log2=0):
+    """rsa_popular_args with the sampler's tables filled in (checked device fp32 / int32 tensors)"""
+    a = nat.PopularArgs()
+    a.table, a.pop_prob, a.guide = ptr(table), ptr(pop_prob), ptr(guide)
+    a.n_items, a.guide_log2, a.lines_log2 = table.numel(), int(guide_log2), int(lines_log2)
+    a.cdf_lut = ptr(_need_opt(cdf_lut, torch.float32, 'cdf_lut'))
+    a.cdf_lines = ptr(_need_opt(cdf_lines, torch.float32, 'cdf_lines'))
+    return a
+
+
 @_on_device
 def sample_popular(table, pop_prob, guide, guide_log2, numel, generator=None, want_u=False, cdf_lut=None,
                    cdf_lines=None, lines_log2=0):
@@ -183,12 +197,10 @@ def sample_popular(table, pop_prob, guide, guide_log2, numel, generator=None, wa
     u = torch.empty(int(numel), dtype=torch.float32, device=dev) if want_u else None
     if numel:
         pc = rng.reserve(numel, 4, dev, generator)
-        nat.check(nat.lib().rsa_sample_popular(ptr(table), ptr(pop_prob), ptr(guide), table.numel(), int(guide_log2),
-                                               ptr(ids), ptr(logp), ptr(u), int(numel), pc.seed, pc.offset,
-                                               pc.grid_threads, pc.elem_base,
-                                               ptr(_need_opt(cdf_lut, torch.float32, 'cdf_lut')),
-                                               ptr(_need_opt(cdf_lines, torch.float32, 'cdf_lines')), int(lines_log2),
-                                               _stream()), 'rsa_sample_popular')
+        a = popular_args(table, pop_prob, guide, guide_log2, cdf_lut, cdf_lines, lines_log2)
+        a.ids, a.logp, a.u_out, a.numel = ptr(ids), ptr(logp), ptr(u), int(numel)
+        a.seed, a.offset, a.grid_threads, a.elem_base = pc.seed, pc.offset, pc.grid_threads, pc.elem_base
+        nat.check(nat.lib().rsa_sample_popular(ctypes.byref(a), _stream()), 'rsa_sample_popular')
     return (ids, logp, u) if want_u else (ids, logp)
 
 
@@ -200,12 +212,9 @@ def popular_lookup(table, pop_prob, guide, guide_log2, u, cdf_lut=None, cdf_line
     u = _need(u, torch.float32, 'u')
     ids = torch.empty(u.numel(), dtype=torch.int64, device=u.device)
     logp = torch.empty(u.numel(), dtype=torch.float32, device=u.device)
-    nat.check(nat.lib().rsa_popular_lookup(ptr(table), ptr(pop_prob), ptr(guide), table.numel(), int(guide_log2),
-                                           ptr(u), ptr(ids), ptr(logp), u.numel(),
-                                           ptr(_need_opt(cdf_lut, torch.float32, 'cdf_lut')),
-                                           ptr(_need_opt(cdf_lines, torch.float32, 'cdf_lines')), int(lines_log2),
-                                           _stream()),
-              'rsa_popular_lookup')
+    a = popular_args(table, pop_prob, guide, guide_log2, cdf_lut, cdf_lines, lines_log2)
+    a.u_in, a.ids, a.logp, a.numel = ptr(u), ptr(ids), ptr(logp), u.numel()
+    nat.check(nat.lib().rsa_popular_lookup(ctypes.byref(a), _stream()), 'rsa_popular_lookup')
     return ids.view(u.shape), logp.view(u.shape)
 
 
@@ -258,9 +267,20 @@ def seg_gather(item_table, flat_item_ids, seg_start, seg_end, max_len, want_rows
     ids = torch.empty(B, max_len, dtype=torch.int64, device=dev) if want_ids else None
     rows = torch.empty(B, max_len, dim, dtype=torch.float32, device=dev) if want_rows else None
     lens = torch.empty(B, dtype=torch.int64, device=dev)
-    nat.check(nat.lib().rsa_seg_gather(ptr(tab), n_items, dim, ptr(flat), flat.numel(), ptr(s), ptr(e), B,
-                                       int(max_len), ptr(ids), ptr(rows), ptr(lens), _stream()), 'rsa_seg_gather')
+    a = nat.SegGatherArgs()
+    a.item_table, a.n_items, a.dim, a.max_len = ptr(tab), n_items, dim, int(max_len)
+    a.flat_item_ids, a.n_flat, a.seg_start, a.seg_end, a.n_seg = ptr(flat), flat.numel(), ptr(s), ptr(e), B
+    a.out_ids, a.out_rows, a.out_len = ptr(ids), ptr(rows), ptr(lens)
+    nat.check(nat.lib().rsa_seg_gather(ctypes.byref(a), _stream()), 'rsa_seg_gather')
     return ids, rows, lens
+
+
+def _loss_args(kind, pos_score, neg_score, pos_logp, neg_logp, n_rows, num_neg, row_loss, loss_out, dpos, dneg):
+    a = nat.LossArgs()
+    a.loss_kind, a.n_rows, a.num_neg = int(kind), int(n_rows), int(num_neg)
+    a.pos_score, a.neg_score, a.pos_logp, a.neg_logp = ptr(pos_score), ptr(neg_score), ptr(pos_logp), ptr(neg_logp)
+    a.row_loss, a.loss_out, a.dpos, a.dneg, a.scratch = ptr(row_loss), ptr(loss_out), ptr(dpos), ptr(dneg), ptr(_scratch())
+    return a
 
 
 # ------------------------------------------------------------------ fused forward / backward
@@ -452,15 +472,14 @@ def pairwise_loss(kind, pos_score, neg_score, pos_logp=None, neg_logp=None, want
     loss = torch.empty((), dtype=torch.float32, device=dev)
     dpos = torch.empty(pos_score.shape, dtype=torch.float32, device=dev) if want_grad else None
     dneg = torch.empty(neg_score.shape, dtype=torch.float32, device=dev) if want_grad else None
-    nat.check(nat.lib().rsa_pairwise_loss(int(kind), ptr(pos_score), ptr(neg_score), ptr(pos_logp), ptr(neg_logp),
-                                          M, n, ptr(row), ptr(loss), ptr(dpos), ptr(dneg), ptr(_scratch()), _stream()),
-              'rsa_pairwise_loss')
+    a = _loss_args(kind, pos_score, neg_score, pos_logp, neg_logp, M, n, row, loss, dpos, dneg)
+    nat.check(nat.lib().rsa_pairwise_loss(ctypes.byref(a), _stream()), 'rsa_pairwise_loss')
     return loss, dpos, dneg, row
 
 
 @_on_device
 def pairwise_loss_ex(kind, pos_score, neg_score, pos_logp=None, neg_logp=None, param0=0.0, param1=0.0):
-    """rsa_pairwise_loss_ex (WeightedBPR / WeightedBCE / Hinge / NCE / CCL): (loss, dpos, dneg)."""
+    """rsa_pairwise_loss, kinds WeightedBPR / WeightedBCE / Hinge / NCE / CCL: (loss, dpos, dneg)."""
     pos_score = _need(pos_score, torch.float32, 'pos_score')
     neg_score = _need(neg_score, torch.float32, 'neg_score')
     M = pos_score.numel()
@@ -473,9 +492,11 @@ def pairwise_loss_ex(kind, pos_score, neg_score, pos_logp=None, neg_logp=None, p
     row = torch.empty(M, dtype=torch.float32, device=dev)
     loss = torch.empty((), dtype=torch.float32, device=dev)
     dpos, dneg = torch.empty_like(pos_score), torch.empty_like(neg_score)
-    nat.check(nat.lib().rsa_pairwise_loss_ex(int(kind), ptr(pos_score), ptr(neg_score), ptr(pos_logp), ptr(neg_logp), M, n,
-                                             float(param0), float(param1), ptr(row), ptr(loss), ptr(dpos), ptr(dneg),
-                                             ptr(_scratch()), _stream()), 'rsa_pairwise_loss_ex')
+    if not nat.LOSS_WBPR <= int(kind) <= nat.LOSS_CCL:
+        raise ValueError(f'pairwise_loss_ex: unknown loss kind {kind}')
+    a = _loss_args(kind, pos_score, neg_score, pos_logp, neg_logp, M, n, row, loss, dpos, dneg)
+    a.param0, a.param1 = float(param0), float(param1)
+    nat.check(nat.lib().rsa_pairwise_loss(ctypes.byref(a), _stream()), 'rsa_pairwise_loss')
     return loss, dpos, dneg
 
 
@@ -492,9 +513,9 @@ def ssm_shared_loss(pos_score, neg_score, pos_logp=None, neg_logp=None):
     row = torch.empty(B, dtype=torch.float32, device=dev)
     loss = torch.empty((), dtype=torch.float32, device=dev)
     dpos, dneg = torch.empty_like(pos_score), torch.empty_like(neg_score)
-    nat.check(nat.lib().rsa_ssm_shared_loss(ptr(pos_score), ptr(pos_logp), ptr(neg_score), ptr(neg_logp), B, L, n,
-                                            ptr(row), ptr(loss), ptr(dpos), ptr(dneg), ptr(_scratch()), _stream()),
-              'rsa_ssm_shared_loss')
+    a = _loss_args(nat.LOSS_SSM, pos_score, neg_score, pos_logp, neg_logp, B, n, row, loss, dpos, dneg)
+    a.n_pos = L
+    nat.check(nat.lib().rsa_ssm_shared_loss(ctypes.byref(a), _stream()), 'rsa_ssm_shared_loss')
     return loss, dpos, dneg
 
 
@@ -538,6 +559,21 @@ def fused_backward(item_table, query, neg_ids, dneg, *, query_index=None, pos_id
     return item_grad, rows, qgrad
 
 
+def _rows_update_args(target, query, query_index, n_queries, num_neg, dpos, dneg, upstream, pad_row):
+    a = nat.RowsUpdateArgs()
+    a.query, a.query_index, a.n_query_rows = ptr(query), ptr(_need_opt(query_index, torch.int64, 'query_index')), query.shape[0]
+    a.dim, a.n_queries, a.num_neg = target.shape[1], int(n_queries), int(num_neg)
+    a.dpos, a.dneg = ptr(_need_opt(dpos, torch.float32, 'dpos')), ptr(dneg)
+    a.upstream = ptr(_need_opt(upstream, torch.float32, 'upstream'))
+    a.n_items, a.pad_row, a.target = target.shape[0], int(pad_row), ptr(target)
+    return a
+
+
+def _adam_fields(a, exp_avg, exp_avg_sq, lr, betas, eps, step):
+    a.exp_avg, a.exp_avg_sq = ptr(_need(exp_avg, torch.float32, 'exp_avg')), ptr(_need(exp_avg_sq, torch.float32, 'exp_avg_sq'))
+    a.lr, a.beta1, a.beta2, a.eps, a.step = float(lr), float(betas[0]), float(betas[1]), float(eps), int(step)
+
+
 @_on_device
 def sort_step_elements(pos_ids, neg_ids, n_items, pad_row=0, want_solo=True):
     """rsa_sort_step_elements: the step's (item id, element) pairs sorted by id in a workspace, and the classification
@@ -551,46 +587,41 @@ def sort_step_elements(pos_ids, neg_ids, n_items, pad_row=0, want_solo=True):
     solo = torch.empty(M, w, dtype=torch.uint8, device=neg_ids.device) if want_solo else None   # None: sort only, nothing flagged
     ws_bytes = int(nat.lib().rsa_scatter_rows_sorted_workspace_bytes(M, n, int(n_items)))
     ws = torch.empty(max(ws_bytes, 8), dtype=torch.uint8, device=neg_ids.device)
-    nat.check(nat.lib().rsa_sort_step_elements(ptr(pos_ids), ptr(neg_ids), M, n, int(n_items), int(pad_row), ptr(solo), ptr(ws),
-                                               ws_bytes, _stream()), 'rsa_sort_step_elements')
+    a = nat.RowsUpdateArgs()
+    a.pos_ids, a.neg_ids, a.n_queries, a.num_neg, a.n_items, a.pad_row = ptr(pos_ids), ptr(neg_ids), M, n, int(n_items), int(pad_row)
+    a.solo, a.workspace, a.workspace_bytes = ptr(solo), ptr(ws), ws_bytes
+    nat.check(nat.lib().rsa_sort_step_elements(ctypes.byref(a), _stream()), 'rsa_sort_step_elements')
     return solo, ws
 
 
 @_on_device
 def scatter_rows_presorted(target, query, workspace, n_queries, num_neg, dneg, *, query_index=None, dpos=None, upstream=None,
                            pad_row=0):
-    """rsa_scatter_rows_presorted: the apply pass of scatter_rows_sorted over the pairs ``sort_step_elements`` left in
+    """rsa_rows_update_presorted: the apply pass of scatter_rows_sorted over the pairs ``sort_step_elements`` left in
     ``workspace`` (elements flagged solo there are skipped: the forward has applied them)."""
     target = _need(target, torch.float32, 'target')
     query = _need(query, torch.float32, 'query')
     dneg = _need(dneg, torch.float32, 'dneg')
     n_items, dim = target.shape
-    nat.check(nat.lib().rsa_scatter_rows_presorted(ptr(query), ptr(_need_opt(query_index, torch.int64, 'query_index')), query.shape[0],
-                                                   dim, int(dpos is not None), int(n_queries), int(num_neg),
-                                                   ptr(_need_opt(dpos, torch.float32, 'dpos')), ptr(dneg),
-                                                   ptr(_need_opt(upstream, torch.float32, 'upstream')), n_items, int(pad_row),
-                                                   ptr(target), ptr(workspace), workspace.numel(), _stream()),
-              'rsa_scatter_rows_presorted')
+    a = _rows_update_args(target, query, query_index, n_queries, num_neg, dpos, dneg, upstream, pad_row)
+    a.has_pos, a.workspace, a.workspace_bytes = int(dpos is not None), ptr(workspace), workspace.numel()
+    nat.check(nat.lib().rsa_rows_update_presorted(ctypes.byref(a), _stream()), 'rsa_rows_update_presorted')
     return target
 
 
 @_on_device
 def adam_rows_presorted(weight, exp_avg, exp_avg_sq, query, workspace, n_queries, num_neg, dneg, *, lr, betas=(0.9, 0.999),
                         eps=1e-8, step=1, query_index=None, dpos=None, upstream=None, pad_row=0):
-    """rsa_adam_rows_presorted: the apply pass of adam_rows_sorted over the pairs ``sort_step_elements(want_solo=False)``
+    """rsa_rows_update_presorted with the lazy-Adam state: the apply pass of adam_rows_sorted over the pairs ``sort_step_elements(want_solo=False)``
     left in ``workspace``."""
     weight = _need(weight, torch.float32, 'weight')
     query = _need(query, torch.float32, 'query')
     dneg = _need(dneg, torch.float32, 'dneg')
     n_items, dim = weight.shape
-    nat.check(nat.lib().rsa_adam_rows_presorted(ptr(query), ptr(_need_opt(query_index, torch.int64, 'query_index')), query.shape[0],
-                                                dim, int(dpos is not None), int(n_queries), int(num_neg),
-                                                ptr(_need_opt(dpos, torch.float32, 'dpos')), ptr(dneg),
-                                                ptr(_need_opt(upstream, torch.float32, 'upstream')), n_items, int(pad_row),
-                                                ptr(weight), ptr(_need(exp_avg, torch.float32, 'exp_avg')),
-                                                ptr(_need(exp_avg_sq, torch.float32, 'exp_avg_sq')), float(lr), float(betas[0]),
-                                                float(betas[1]), float(eps), int(step), ptr(workspace), workspace.numel(),
-                                                _stream()), 'rsa_adam_rows_presorted')
+    a = _rows_update_args(weight, query, query_index, n_queries, num_neg, dpos, dneg, upstream, pad_row)
+    a.has_pos, a.workspace, a.workspace_bytes = int(dpos is not None), ptr(workspace), workspace.numel()
+    _adam_fields(a, exp_avg, exp_avg_sq, lr, betas, eps, step)
+    nat.check(nat.lib().rsa_rows_update_presorted(ctypes.byref(a), _stream()), 'rsa_rows_update_presorted(adam)')
     return weight
 
 
@@ -669,9 +700,11 @@ def fullscore(item_table, query, *, want_scores=False, want_lse=False, k=0, item
     ti = torch.empty(B, k, dtype=torch.int64, device=dev) if k else None
     ws_bytes = int(nat.lib().rsa_fullscore_workspace_bytes(B, n_items, int(k)))
     ws = torch.empty(max(ws_bytes, 8), dtype=torch.uint8, device=dev)
-    nat.check(nat.lib().rsa_fullscore(table_ptr, n_items, dim, ptr(query), B, ptr(scores), ptr(lse), ptr(tv),
-                                      ptr(ti), int(k), score_mode, ptr(ia), ptr(qa), ptr(ws), ws_bytes, _stream()),
-              'rsa_fullscore')
+    a = nat.FullscoreArgs()
+    a.item_table, a.n_items, a.dim, a.score_mode, a.query, a.n_query = table_ptr, n_items, dim, score_mode, ptr(query), B
+    a.scores, a.lse, a.topk_val, a.topk_idx, a.k = ptr(scores), ptr(lse), ptr(tv), ptr(ti), int(k)
+    a.item_aux, a.query_aux, a.workspace, a.workspace_bytes = ptr(ia), ptr(qa), ptr(ws), ws_bytes
+    nat.check(nat.lib().rsa_fullscore(ctypes.byref(a), _stream()), 'rsa_fullscore')
     return scores, lse, tv, ti
 
 
@@ -764,7 +797,7 @@ def rng_advance(offset_dev, increment):
 @_on_device
 def scatter_rows_sorted(target, query, neg_ids, dneg, *, query_index=None, pos_ids=None, dpos=None, upstream=None,
                         pad_row=0):
-    """rsa_scatter_rows_sorted: target[id] += upstream * sum_e d_e * query[qrow_e], sorted by id, no atomics.
+    """rsa_rows_update_sorted: target[id] += upstream * sum_e d_e * query[qrow_e], sorted by id, no atomics.
     ``target``: [n_items, d] (a zeroed dense gradient, or the weight table with upstream = -lr)."""
     target = _need(target, torch.float32, 'target')
     query = _need(query, torch.float32, 'query')
@@ -781,16 +814,16 @@ def scatter_rows_sorted(target, query, neg_ids, dneg, *, query_index=None, pos_i
     n = neg_ids.numel() // M
     ws_bytes = int(nat.lib().rsa_scatter_rows_sorted_workspace_bytes(M, n, n_items))
     ws = torch.empty(max(ws_bytes, 8), dtype=torch.uint8, device=target.device)
-    nat.check(nat.lib().rsa_scatter_rows_sorted(ptr(query), ptr(query_index), query.shape[0], dim, ptr(pos_ids), ptr(neg_ids),
-                                                M, n, ptr(dpos), ptr(dneg), ptr(upstream), n_items, int(pad_row), ptr(target),
-                                                ptr(ws), ws_bytes, _stream()), 'rsa_scatter_rows_sorted')
+    a = _rows_update_args(target, query, query_index, M, n, dpos, dneg, upstream, pad_row)
+    a.pos_ids, a.neg_ids, a.workspace, a.workspace_bytes = ptr(pos_ids), ptr(neg_ids), ptr(ws), ws_bytes
+    nat.check(nat.lib().rsa_rows_update_sorted(ctypes.byref(a), _stream()), 'rsa_rows_update_sorted')
     return target
 
 
 @_on_device
 def adam_rows_sorted(weight, exp_avg, exp_avg_sq, query, neg_ids, dneg, *, lr, betas=(0.9, 0.999), eps=1e-8, step=1,
                      query_index=None, pos_ids=None, dpos=None, upstream=None, pad_row=0):
-    """rsa_adam_rows_sorted: lazy Adam (torch.optim.SparseAdam's rule) on the rows touched by the step, from the
+    """rsa_rows_update_sorted with the lazy-Adam state: lazy Adam (torch.optim.SparseAdam's rule) on the rows touched by the step, from the
     factored gradient (ids, coefficients, query rows) -- no gradient tensor."""
     weight = _need(weight, torch.float32, 'weight')
     exp_avg = _need(exp_avg, torch.float32, 'exp_avg')
@@ -809,8 +842,8 @@ def adam_rows_sorted(weight, exp_avg, exp_avg_sq, query, neg_ids, dneg, *, lr, b
     n = neg_ids.numel() // M
     ws_bytes = int(nat.lib().rsa_scatter_rows_sorted_workspace_bytes(M, n, n_items))
     ws = torch.empty(max(ws_bytes, 8), dtype=torch.uint8, device=weight.device)
-    nat.check(nat.lib().rsa_adam_rows_sorted(ptr(query), ptr(query_index), query.shape[0], dim, ptr(pos_ids), ptr(neg_ids), M, n,
-                                             ptr(dpos), ptr(dneg), ptr(upstream), n_items, int(pad_row), ptr(weight),
-                                             ptr(exp_avg), ptr(exp_avg_sq), float(lr), float(betas[0]), float(betas[1]),
-                                             float(eps), int(step), ptr(ws), ws_bytes, _stream()), 'rsa_adam_rows_sorted')
+    a = _rows_update_args(weight, query, query_index, M, n, dpos, dneg, upstream, pad_row)
+    a.pos_ids, a.neg_ids, a.workspace, a.workspace_bytes = ptr(pos_ids), ptr(neg_ids), ptr(ws), ws_bytes
+    _adam_fields(a, exp_avg, exp_avg_sq, lr, betas, eps, step)
+    nat.check(nat.lib().rsa_rows_update_sorted(ctypes.byref(a), _stream()), 'rsa_rows_update_sorted(adam)')
     return weight

@@ -801,6 +801,7 @@ class BaseRetriever(torch.nn.Module):
             sched_opt.step()                                   # (a no-op; the schedulers warn when they step first)
         scheduler = self._get_scheduler(sched_opt)
         sh['trainer'] = trainer
+        trainer.table.defer_overflow = True          # report a capacity overflow after the step instead of raising inside it
         if sh['tower_rows'] is not None:
             sh['tower_rows'].bind(trainer)
         val_metrics = self.config['eval']['val_metrics']
@@ -833,23 +834,20 @@ class BaseRetriever(torch.nn.Module):
                         if ahead and batch_next is not None else None
                     if optimizer is not None:
                         optimizer.zero_grad(set_to_none=False)
-                    try:
-                        loss = trainer.training_step(self._get_query_feat(batch), batch[self.fiid], batch[self.frating], ticket=ticket)
-                        ticket = ticket_next
-                    except RuntimeError as err:
-                        ticket = ticket_next
-                        # an id distribution that outgrew the calibrated segment capacity: every rank raises at the same step
-                        # (the sticky count is job-wide), the affected steps updated nothing, the capacity is recalibrated on
-                        # the next step -- carry on instead of aborting the run
-                        if 'did not fit their owner segment' not in str(err):
-                            raise
-                        self.logger.warning(str(err))
-                        continue
+                    loss = trainer.training_step(self._get_query_feat(batch), batch[self.fiid], batch[self.frating], ticket=ticket)
+                    ticket = ticket_next
                     if optimizer is not None:
                         if tr['grad_clip_norm'] is not None:
                             self._clip_grad_norm_sharded(params, tr['grad_clip_norm'], dist)
                         optimizer.step()
                     losses.append(loss.detach().reshape(1))
+                    # an id distribution that outgrew the calibrated segment capacity: the poll (every rank sees the job-wide
+                    # sticky count at the same step) reports it HERE, after the whole step -- the steps in which elements were
+                    # dropped updated nothing (their scale was 0 on the device), the step the lagging poll landed in is a healthy
+                    # one and has run to its end, the capacity is recalibrated on the next step; carry on
+                    msg = trainer.table.take_overflow()
+                    if msg:
+                        self.logger.warning(msg)
             step_losses = torch.cat(losses)                     # this rank's shares of the global mean losses
             dist.all_reduce(step_losses)
             self.train_losses.append(step_losses.cpu())
@@ -933,6 +931,11 @@ class BaseRetriever(torch.nn.Module):
         self.val_metric = f"{(val_metrics[0] if isinstance(val_metrics, list) else val_metrics)}@{cutoff0}"
         best, best_state, bad = None, None, 0
         self.history = []                                  # one dict per epoch: what the reference logs (recommender.py:249-270)
+        self._fused_step = fused_step
+        # the device-resident loader is built once: its columns are uploaded once, every epoch re-draws the order
+        dev_loader = None
+        if tr.get('device_loader', True) and hasattr(train_data, 'device_train_loader'):
+            dev_loader = train_data.device_train_loader(tr['batch_size'], shuffle=True, drop_last=False, device=device)
         for epoch in range(tr['epochs']):
             t0 = time.time()
             self.train()
@@ -940,8 +943,8 @@ class BaseRetriever(torch.nn.Module):
             if self.sampler is not None:
                 self.sampler.update(item_embs=self.item_vector)                 # recommender.py:564-570
             losses = []
-            if tr.get('device_loader', True) and hasattr(train_data, 'device_train_loader'):
-                loader = train_data.device_train_loader(tr['batch_size'], shuffle=True, drop_last=False, device=device)
+            if dev_loader is not None:
+                loader = dev_loader
             else:
                 loader = train_data.train_loader(batch_size=tr['batch_size'], shuffle=True, drop_last=False)
             if getattr(fused_step, 'stepper', None) is not None:
@@ -971,7 +974,9 @@ class BaseRetriever(torch.nn.Module):
                 losses.append(loss.detach())
             log = {'epoch': epoch, 'train_loss': float(torch.stack(losses).mean()), 'train_time': time.time() - t0}
             if val_data is not None and (epoch + 1) % self.config['eval']['val_n_epoch'] == 0:
+                t1 = time.time()
                 log.update(self._eval_epoch(val_data, self.validation_step, device))
+                log['valid_time'] = time.time() - t1              # the reference logs both (recommender.py:262-266)
                 cur = log[self.val_metric]
                 better = best is None or (cur > best if tr['early_stop_mode'] == 'max' else cur < best)
                 if better:
@@ -1055,12 +1060,22 @@ class BaseRetriever(torch.nn.Module):
             loader = data.eval_loader(batch_size=self.config['eval']['batch_size'])
         else:       # this rank's contiguous part of every global evaluation batch (dataset.py:1141-1142)
             loader = data.eval_loader(batch_size=self.config['eval']['batch_size'], ddp=True, rank=sh['rank'], world=sh['world'])
-        total, acc = 0, {}
-        for batch in loader:
-            metrics, bs = step(self._to_device(batch, device))
-            for k, v in metrics.items():
-                acc[k] = acc.get(k, 0.0) + float(v) * bs                       # weighted mean, recommender.py:308-324
+        total, rows, sizes = 0, [], []
+        for batch in self._eval_batches(data, loader, device, cache=sh is None):
+            metrics, bs = step(batch)
+            # per-batch values stay on the device until the epoch ends: float(v) here was one host synchronisation per
+            # metric per batch (most of an ml-100k validation epoch)
+            rows.append(metrics)
+            sizes.append(bs)
             total += bs
+        acc = {}
+        if rows:
+            keys = list(rows[0])
+            vals = torch.stack([torch.stack([torch.as_tensor(m[k], dtype=torch.float32, device=device) for k in keys])
+                                for m in rows]).double().cpu()
+            for r, bs in enumerate(sizes):                                         # weighted mean, recommender.py:308-324
+                for c, k in enumerate(keys):
+                    acc[k] = acc.get(k, 0.0) + float(vals[r, c]) * bs
         if sh is not None:                                                     # sums over the ranks' parts
             keys = sorted(acc)
             t = torch.tensor([acc[k] for k in keys] + [float(total)], dtype=torch.float64, device=device)
@@ -1069,6 +1084,32 @@ class BaseRetriever(torch.nn.Module):
             sh['dist'].all_reduce(t)
             acc, total = {k: float(v) for k, v in zip(keys, t[:-1])}, float(t[-1])
         return {k: v / max(total, 1) for k, v in acc.items()}
+
+    EVAL_CACHE_BYTES = 1 << 30
+
+    def _eval_batches(self, data, loader, device, cache=True):
+        """The evaluation batches of ``data`` on the device.  An evaluation split does not change between epochs, so the
+        host loader's work (per-user ragged slices, ``pad_sequence``, the history rows, the uploads) is done once: the
+        device-resident batches of a split are kept (up to EVAL_CACHE_BYTES over all splits) and replayed every epoch."""
+        store = self.__dict__.setdefault('_eval_cache', {})
+        key = (id(data), self.config['eval']['batch_size'], str(device), len(data))
+        hit = store.get(key)
+        if hit is not None and hit[0] is data:
+            yield from hit[1]
+            return
+        kept, size = [], 0
+        budget = self.EVAL_CACHE_BYTES - sum(v[2] for v in store.values())
+        for batch in loader:
+            batch = self._to_device(batch, device)
+            if cache and kept is not None:
+                size += sum(v.numel() * v.element_size() for v in batch.values() if isinstance(v, torch.Tensor))
+                if size > budget:
+                    kept = None
+                else:
+                    kept.append(batch)
+            yield batch
+        if cache and kept is not None:
+            store[key] = (data, kept, size)
 
     def evaluate(self, test_data, verbose=True, **kwargs):
         test_data.use_field = self.fields

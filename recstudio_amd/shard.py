@@ -460,20 +460,22 @@ class HipBackend:
                            dense_item_grad=False, want_query_grad=False, item_grad_out=item_grad_local,
                            query_table_grad=qgrad_all, query_table_pad_row=-1, item_pad_row=item_pad_row)
 
-    def apply_rows(self, table, ids, rows, scale, pad_row=0):
-        """table[ids[e]] += scale * rows[e] for ids != pad_row (pad_row < 0: every row), duplicates summed in sorted
+    def apply_rows(self, table, ids, rows, scale, pad_row=0, gate=None):
+        """table[ids[e]] += gate * scale * rows[e] for ids != pad_row (pad_row < 0: every row), duplicates summed in sorted
         order without atomics for embed_dim in {64, 128, 256}: every replica that applies the same (ids, rows) ends up
-        with the same bits.  Other dims: ``index_add_`` (float atomics: equal up to summation order)."""
+        with the same bits.  Other dims: ``index_add_`` (float atomics: equal up to summation order).  ``gate``: an optional
+        device scalar (the step's overflow gate, 0 or 1)."""
         m = ids.numel()
         if m == 0:
             return
         d = rows.shape[1]
         if d in (64, 128, 256):
             ops.scatter_rows_sorted(table, rows, ids.view(m, 1), torch.full((m, 1), float(scale), device=rows.device),
-                                    query_index=torch.arange(m, device=ids.device), pad_row=pad_row)
+                                    query_index=torch.arange(m, device=ids.device), pad_row=pad_row, upstream=gate)
         else:
             keep = ids != pad_row
-            table.index_add_(0, ids[keep], rows[keep] * float(scale))
+            upd = rows[keep] * float(scale)
+            table.index_add_(0, ids[keep], upd if gate is None else upd * gate)
 
     def full_partial(self, item_local, q_all, k, want_lse, has_pad_row):
         """This shard's part of the full-catalog pass (BASELINE.json configs[4] sharded):
@@ -487,7 +489,8 @@ class HipBackend:
         return ops.row_lse(parts.contiguous())[0]
 
     def merge_topk(self, vals, ids, k):
-        """vals/ids [B, G*k] (shard-major, each shard's list sorted) -> exact global top-k, ties -> smaller id."""
+        """vals/ids [B, G*k] -> exact global top-k, ties -> smaller COLUMN (the caller hands the candidates over in an order
+        in which that is the smaller id: shard-major for contiguous row blocks, id-sorted for interleaved rows)."""
         if k > ops.FULLSCORE_MAX_K:          # the wide correctness path (k + |history| beyond the in-kernel select)
             v, cols = torch.sort(vals, dim=1, descending=True, stable=True)
             v, cols = v[:, :k].contiguous(), cols[:, :k]
@@ -654,6 +657,11 @@ class ShardedItemTable:
                                f'{self.slack}); the affected steps were skipped (their weight updates were scaled by 0) '
                                "-- raise `slack` / `margin` or use exchange='exact' for id distributions that drift this fast")
 
+    def take_overflow(self):
+        """The message of an overflow the deferred poll found since the last call (None: none) -- see ``defer_overflow``."""
+        msg, self.overflow_message = getattr(self, 'overflow_message', None), None
+        return msg
+
     LAG = 4          # steps between starting the read-back of the overflow word and looking at it
 
     def _after_fixed_step(self):
@@ -663,7 +671,17 @@ class ShardedItemTable:
         if self.check_every <= 0:
             return
         if self._poll is not None and self._steps >= self._poll_due:
-            self.check_overflow()
+            if getattr(self, 'defer_overflow', False):
+                # a training loop asked to be TOLD instead of interrupted: the poll lags LAG steps behind the overflowed
+                # step, so raising here would cut a healthy step in half -- its item rows already updated in place, its
+                # query-row exchange, tower backward, all-reduce and optimizer step not run.  The message waits
+                # in `overflow_message` for `take_overflow()` at the END of the step.
+                try:
+                    self.check_overflow()
+                except RuntimeError as err:
+                    self.overflow_message = str(err)
+            else:
+                self.check_overflow()
         if self._poll is None and self._steps % self.check_every == 0:
             self._poll = self.backend.flag_read_async(self.state['overflow'])
             self._poll_due = self._steps + self.LAG
@@ -707,8 +725,31 @@ class ShardedItemTable:
 
         def issue():
             r, C, waits = self._route_and_exchange(pos, n, spec, None, fused_loss, want_ids, want_logp)
-            return {'B': pos.numel(), 'n': int(n), 'C': C, 'fused_loss': fused_loss, 'route': r, 'recv': [w() for w in waits]}
+            return self._stamp({'B': pos.numel(), 'n': int(n), 'C': C, 'fused_loss': fused_loss, 'route': r,
+                                'recv': [w() for w in waits]}, pos, want_ids=bool(want_ids), want_logp=bool(want_logp))
         return self._on_second_stream(issue, pos)
+
+    # -- ticket identity: a ticket is consumed once, in preparation order, by the batch it was prepared for -------------------
+    def _stamp(self, ticket, pos, **what):
+        self._tickets_issued = getattr(self, '_tickets_issued', 0) + 1
+        ticket.update(seq=self._tickets_issued, pos_key=(pos.data_ptr(), tuple(pos.shape)), **what)
+        return ticket
+
+    def _claim(self, ticket, pos, who, **expect):
+        """Refuse a ticket stepped out of order, a second time, with another batch's positives or with other output
+        requests than it was prepared with -- each of which would silently train / score the new queries against the
+        prepared batch's positives and negatives."""
+        done = getattr(self, '_tickets_claimed', 0)
+        if not isinstance(ticket.get('seq'), int) or ticket['seq'] <= done:       # (an abandoned ticket may be skipped over)
+            raise ValueError(f"{who}: tickets are consumed once each, in the order they were prepared (this is ticket "
+                             f"#{ticket.get('seq')}; #{done} has been consumed already)")
+        nxt = ticket['seq']
+        if pos is not None and ticket.get('pos_key') != (pos.data_ptr(), tuple(pos.shape)):
+            raise ValueError(f'{who}: the ticket was prepared for another batch (its positives are not the tensor passed here)')
+        for k, v in expect.items():
+            if ticket.get(k) != v:
+                raise ValueError(f'{who}: the ticket was prepared with {k}={ticket.get(k)!r}, this call asks for {k}={v!r}')
+        self._tickets_claimed = nxt
 
     def _on_second_stream(self, issue, like):
         """``issue()`` on this table's second stream (CPU tensors: in place); the ticket it returns gets a ``ready`` event and
@@ -744,6 +785,7 @@ class ShardedItemTable:
         else:
             if (ticket['B'], ticket['n'], ticket['fused_loss']) != (B, int(n), fused_loss):
                 raise ValueError('the ticket was prepared for another batch shape / loss')
+            self._claim(ticket, pos, 'forward_queries(ticket=)', want_ids=bool(want_ids), want_logp=bool(want_logp))
             if ticket.get('ready') is not None:
                 torch.cuda.current_stream(pos.device).wait_event(ticket['ready'])
             r, C = ticket['route'], ticket['C']
@@ -831,6 +873,7 @@ class ShardedItemTable:
         else:
             if ticket['B'] != B or ticket['n'] != n:
                 raise ValueError('bpr_step_on_owners: the ticket was prepared for another batch shape')
+            self._claim(ticket, pos, 'bpr_step_on_owners(ticket=)', sampler_id=id(sampler))
             r, recv, neg_out = ticket['route'], ticket['recv'], ticket['neg_out']
         GS, stride = G * int(getattr(be, 'BANKS', 1)), r['stride']
         q_all = q_gather()
@@ -906,7 +949,8 @@ class ShardedItemTable:
         GS = G * int(getattr(be, 'BANKS', 1))
         ctx = be.owner_bpr_prepare(self.state, self.item_local, B * G, recv, GS, r['stride'], pos_rows, n, B * G, item_grad_local,
                                    item_scale, item_pad_row=0 if self.rank == 0 else -1, keys_grouped=bool(r.get('grouped', False)))
-        return {'B': B, 'n': n, 'route': r, 'recv': recv, 'neg_out': neg_out, 'pos_rows': pos_rows, 'ctx': ctx}
+        return self._stamp({'B': B, 'n': n, 'route': r, 'recv': recv, 'neg_out': neg_out, 'pos_rows': pos_rows, 'ctx': ctx},
+                           pos, sampler_id=id(sampler))
 
     def backward(self, route, dpos, dneg, item_grad_local, item_scale=None):
         """Gradient exchange for one step.  ``route`` comes from a forward with
@@ -1065,12 +1109,15 @@ class ShardedItemTable:
         block of the dense table gradient, or the weight block itself with ``scale = -lr`` -- by the sorted,
         atomics-free row scatter."""
         be, d = self.backend, self.item_local.shape[1]
+        # an overflowed step changes no weight anywhere: the in-place form (scale = -lr into the weight block) is multiplied by
+        # the step's gate (state['scale'][1] = 0 when any rank dropped an element, else 1), like the score-side update
+        gate = self.state['scale'][1:2] if (item_grad_local is self.item_local and 'scale' in self.state) else None
         if 'local' in route:
-            be.apply_rows(item_grad_local, route['local'], grad.reshape(-1, d).contiguous(), scale, pad_row=0)
+            be.apply_rows(item_grad_local, route['local'], grad.reshape(-1, d).contiguous(), scale, pad_row=0, gate=gate)
             return
         g_send = be.gather_rows(grad.reshape(-1, d).contiguous(), route['src'])
         g_owner = self._all_to_all(g_send, route['recv_counts'], route['send_counts'])
-        be.apply_rows(item_grad_local, route['recv_local'], g_owner, scale, pad_row=0 if self.rank == 0 else -1)
+        be.apply_rows(item_grad_local, route['recv_local'], g_owner, scale, pad_row=0 if self.rank == 0 else -1, gate=gate)
 
     # -- full-catalog pass (eval top-k / full softmax), sharded the same way --------------------------
     def _exchange_partials(self, x, B):
@@ -1110,6 +1157,12 @@ class ShardedItemTable:
             ids[:, :k_local] = self.plan.global_ids(self.rank, ti if has_pad else ti - 1)
         vals = self._exchange_partials(vals, B).transpose(0, 1).reshape(B, G * k)
         ids = self._exchange_partials(ids, B).transpose(0, 1).reshape(B, G * k)
+        if self.plan.interleaved and G > 1:
+            # the merge breaks ties towards the smaller COLUMN; with contiguous row blocks shard-major columns of equal value
+            # are in id order, with interleaved rows they are not -- put the candidates in id order first so that equal
+            # scores resolve to the smaller id on either layout, like the single-GPU kernel
+            order = torch.sort(ids, dim=1, stable=True).indices
+            vals, ids = torch.gather(vals, 1, order), torch.gather(ids, 1, order)
         tv, ti = self.backend.merge_topk(vals, ids, k)
         return lse, tv, ti
 

@@ -350,3 +350,24 @@ def test_lookahead_helpers_on_the_host():
         assert blk.on is False
     assert cache == {}
     _record_stream_all({'a': torch.zeros(2), 'b': [torch.ones(1), (None, 3, {'c': torch.zeros(1)})], 'args': object()}, None)
+
+
+def test_shard_tickets_are_claimed_once_in_order_for_their_batch():
+    """a ticket stepped out of order, twice, with another batch's positives or with other output requests than
+    it was prepared with must be refused (it would silently train the new queries against the prepared batch)."""
+    from recstudio_amd.shard import ShardedItemTable
+    t = ShardedItemTable.__new__(ShardedItemTable)          # the ticket book-keeping alone: no table, no backend
+    pos_a, pos_b = torch.arange(4), torch.arange(4) + 10
+    ta = t._stamp({'B': 4}, pos_a, want_ids=True)
+    tb = t._stamp({'B': 4}, pos_b, want_ids=False)
+    with pytest.raises(ValueError, match='another batch'):
+        t._claim(ta, pos_b, 'step')
+    with pytest.raises(ValueError, match='want_ids'):
+        t._claim(ta, pos_a, 'step', want_ids=False)
+    t._claim(ta, pos_a, 'step', want_ids=True)
+    with pytest.raises(ValueError, match='consumed once'):
+        t._claim(ta, pos_a, 'step', want_ids=True)              # a second time
+    tc = t._stamp({'B': 4}, pos_a)
+    t._claim(tc, pos_a, 'step')                                  # tb abandoned: skipping forward is allowed ...
+    with pytest.raises(ValueError, match='consumed once'):
+        t._claim(tb, pos_b, 'step', want_ids=False)              # ... going back is not

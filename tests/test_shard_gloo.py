@@ -265,9 +265,10 @@ class CheckerBackend:
         item_grad_local.index_add_(0, rows[live], scale * dscore[live].unsqueeze(1) * q_all[qidx[live]])
 
 
-    def apply_rows(self, table, ids, rows, scale, pad_row=0):
+    def apply_rows(self, table, ids, rows, scale, pad_row=0, gate=None):
         keep = ids != pad_row
-        table.index_add_(0, ids[keep], rows[keep] * float(scale))
+        upd = rows[keep] * float(scale)
+        table.index_add_(0, ids[keep], upd if gate is None else upd * gate)
 
     def full_partial(self, item_local, q_all, k, want_lse, has_pad_row):
         rows = item_local[1:] if has_pad_row else item_local

@@ -1,16 +1,16 @@
 #!/bin/bash
 # Build another copy of the library with extra -D switches for A/B measurements on the GPU box:
-#   tools/build_variant.sh qgpipe -DRSA_QG_PIPELINE=1 -DRSA_QG_BATCH=4
+#   tools/build_variant.sh qg4 -DRSA_QG_BATCH=4
 #   VARIANT_FILES=rsa_fullscore tools/build_variant.sh dq1 -DRSA_FS_DQ_MIN_BLOCKS=1
-# writes recstudio_amd/librecstudio_amd_qgpipe.so (git-ignored, travels with gpurun); select it with
-#   RSA_LIB=$PWD/recstudio_amd/librecstudio_amd_qgpipe.so python bench.py ...
+# writes recstudio_amd/librecstudio_amd_qg4.so (git-ignored, travels with gpurun); select it with
+#   RSA_LIB=$PWD/recstudio_amd/librecstudio_amd_qg4.so python bench.py ...
 set -e
 NAME=$1; shift
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$ROOT/recstudio_amd/csrc/variant_$NAME
 mkdir -p $OUT
 FLAGS="-O3 -std=c++17 --offload-arch=gfx950 -fPIC -Wall -Wno-unused-function -ffp-contract=off $*"
-for f in rsa_misc rsa_sample rsa_fused rsa_loss rsa_backward rsa_fullscore rsa_shard rsa_sorted rsa_owner; do
+for f in rsa_misc rsa_sample rsa_fused rsa_loss rsa_backward rsa_fullscore rsa_shard rsa_sorted rsa_owner rsa_step; do
   # only the sources named in VARIANT_FILES (default: the fused forward) are recompiled with the switches; the other
   # objects are reused from the default build
   if [[ " ${VARIANT_FILES:-rsa_fused} " == *" $f "* ]] || [ ! -f $ROOT/recstudio_amd/csrc/$f.o ]; then

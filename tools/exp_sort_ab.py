@@ -42,7 +42,10 @@ for M, n in sizes:
     def run(name, reps):
         h, (ws, wsb) = libs[name], keep[name]
         for _ in range(reps):
-            rc = h.rsa_sort_step_elements(ptr(pos), ptr(neg), M, n, N, 0, ptr(solo), ptr(ws), wsb, stream)
+            a = nat.RowsUpdateArgs()
+            a.pos_ids, a.neg_ids, a.n_queries, a.num_neg, a.n_items, a.pad_row = ptr(pos), ptr(neg), M, n, N, 0
+            a.solo, a.workspace, a.workspace_bytes = ptr(solo), ptr(ws), wsb
+            rc = h.rsa_sort_step_elements(ctypes.byref(a), stream)
             assert rc == 0, rc
     for name in libs:
         run(name, 20)

@@ -47,8 +47,7 @@ libs = {'default': nat.lib()}
 for spec in sys.argv[1:]:
     name, path = spec.split('=')
     h = ctypes.CDLL(path)
-    h.rsa_scatter_rows_presorted.restype, h.rsa_scatter_rows_presorted.argtypes = nat.SIGNATURES['rsa_scatter_rows_presorted']
-    h.rsa_adam_rows_presorted.restype, h.rsa_adam_rows_presorted.argtypes = nat.SIGNATURES['rsa_adam_rows_presorted']
+    h.rsa_rows_update_presorted.restype, h.rsa_rows_update_presorted.argtypes = nat.SIGNATURES['rsa_rows_update_presorted']
     libs[name] = h
 stream = ra.ops._stream()
 
@@ -59,14 +58,15 @@ if ADAM:
 
 
 def launch(h):
+    a = nat.RowsUpdateArgs()
+    a.query, a.query_index, a.n_query_rows, a.dim, a.has_pos = ptr(query), ptr(qidx), query.shape[0], d, int(pos is not None)
+    a.n_queries, a.num_neg, a.dpos, a.dneg, a.n_items, a.pad_row, a.target = M, n, ptr(dpos), ptr(dneg), N, 0, ptr(target)
+    a.workspace, a.workspace_bytes = ptr(ws), ws.numel()
     if ADAM:
-        rc = h.rsa_adam_rows_presorted(ptr(query), ptr(qidx), query.shape[0], d, int(pos is not None), M, n, ptr(dpos), ptr(dneg),
-                                       None, N, 0, ptr(target), ptr(m_state), ptr(v_state), 1e-3, 0.9, 0.999, 1e-8, 3, ptr(ws),
-                                       ws.numel(), stream)
-        assert rc == 0
-        return
-    rc = h.rsa_scatter_rows_presorted(ptr(query), ptr(qidx), query.shape[0], d, int(pos is not None), M, n, ptr(dpos), ptr(dneg),
-                                      ptr(up), N, 0, ptr(target), ptr(ws), ws.numel(), stream)
+        a.exp_avg, a.exp_avg_sq, a.lr, a.beta1, a.beta2, a.eps, a.step = ptr(m_state), ptr(v_state), 1e-3, 0.9, 0.999, 1e-8, 3
+    else:
+        a.upstream = ptr(up)
+    rc = h.rsa_rows_update_presorted(ctypes.byref(a), stream)
     assert rc == 0
 
 
