@@ -245,10 +245,10 @@ def box_state(busy_fn=None, device=0):
             out['mclk_mhz'] = num(val)
         elif 'fclk clock speed' in k:
             out['fclk_mhz'] = num(val)
-        elif 'package power' in k or k.startswith('average graphics package power') or 'socket power' in k:
-            out['power_w'] = num(val)
         elif 'max graphics package power' in k:
             out['power_cap_w'] = num(val)
+        elif 'package power' in k or 'socket power' in k:
+            out['power_w'] = num(val)
         elif 'performance level' in k:
             out['perf_level'] = str(val)
         elif 'compute partition' in k:
@@ -607,6 +607,22 @@ def main():
                     del two, streams
                 except Exception as e:
                     sweep[f'B={b2}']['two_streams_error'] = repr(e)[:120]
+                # a QUEUE of S independent batches consumed by ONE resident grid (rsa_fused_args.n_batches): every batch
+                # draws its negatives from its own torch call (== S consecutive launches bit for bit, tests/test_gpu_round5.py),
+                # the waves of different batches are out of phase, so one batch's sampling chain runs under another's row reads
+                try:
+                    S_q = max(2, 65536 // b2)
+                    gq = torch.Generator(device=dev).manual_seed(77)
+                    uq = torch.randint(1, args.users, (S_q * b2,), device=dev, generator=gq)
+                    pq = torch.randint(1, args.items, (S_q * b2,), device=dev, generator=gq)
+                    stq = ra.ops.FusedStep(item, user, n, fused_bpr=True, n_batches=S_q, **dict(kw, query_index=uq, pos_ids=pq))
+                    tq = time_gpu(stq, max(5, args.steps // 2), 5) * 1e3 / S_q
+                    sweep[f'B={b2}'].update(queue_batches=S_q, queue_ms_per_batch=round(tq, 4),
+                                            queue_frac_of_hbm_peak=round(alg2 / tq / 1e6 / HBM_PEAK_GBS, 4),
+                                            queue_what='S independent batches in one launch (throughput mode; ids == S consecutive launches)')
+                    del stq, uq, pq
+                except Exception as e:
+                    sweep[f'B={b2}']['queue_error'] = repr(e)[:160]
                 del st
             extra['sweep'] = sweep
         # configs[4]: full-catalog scores on the fp32 MFMA (N = 1e6, d = 128), logsumexp fused, + exact top-100

@@ -253,6 +253,17 @@ typedef struct rsa_fused_args {
    * exactly the flagged ones.  item_table is written. */
   const uint8_t* solo_flags;   /* nullable [M * (num_neg + 1)] */
   const float* upd_scale;      /* device scalar */
+  /* A QUEUE of independent batches consumed by one resident grid (ABI 9; forward-only scoring / loss evaluation of many
+   * batches: a small batch's launch is a sampling phase followed by a row phase, and in a stream of such launches the
+   * first has nothing to hide under -- inside ONE grid the waves of different batches are out of phase, so one batch's
+   * draw -> bucket line -> slot chain runs under another's row reads).  n_batches > 1: the n_queries queries are n_batches
+   * consecutive batches of n_queries / n_batches; batch k's negatives are those of ITS OWN torch call -- (seed, offset +
+   * k * batch_offset_step, grid_threads of ONE batch's numel) -- i.e. exactly what n_batches consecutive launches draw.
+   * In-kernel samplers, num_neg % 64 == 0, loss_out null (row_loss holds every query's loss; the per-batch means are the
+   * caller's), the BPR epilogue with num_neg == 64. */
+  int32_t n_batches;           /* 0 / 1: one batch */
+  int32_t _pad4;
+  uint64_t batch_offset_step;  /* Philox offset consumed by one batch's torch call (multiple of 4) */
 } rsa_fused_args;
 
 int rsa_fused_sample_gather_score(const rsa_fused_args* args, rsa_stream_t stream);
@@ -554,6 +565,13 @@ int64_t rsa_fullscore_softmax_dq_workspace_bytes(int64_t n_query, int64_t n_item
 int rsa_fullscore_softmax_dq(const float* item_table, int64_t n_items, int32_t dim, const float* query,
                              int64_t n_query, const float* lse, const float* row_scale, float* probs,
                              float* query_grad, void* workspace, int64_t workspace_bytes, rsa_stream_t stream);
+
+/* The other backward GEMM, d lse / d items[1:] = probs^T @ query (ATen's mm backward of scorer.py:16 under loss_func.py:39-47),
+ * item-stationary on the fp32 matrix cores: out[i, :] = sum_b probs[b, i] * query[b, :] for i in [0, n_cols) -- every output row
+ * written once, no atomics, no split-K partials.  probs [n_query, ld] (ld >= n_cols: its row stride), query [n_query, dim],
+ * out [n_cols, dim] (the caller passes item_grad + dim: row 1 of the table gradient; row 0 stays zero), dim in {32, 64, 128}. */
+int rsa_probs_t_query(const float* probs, int64_t n_query, int64_t n_cols, int64_t ld, const float* query, int32_t dim,
+                      float* out, rsa_stream_t stream);
 
 /* torch.topk(values, k) over the last dim of a [n_rows, n_cols] matrix (k <= 1024): values in descending
  * order and their COLUMN indices (equal values -> smaller column first).  Used by the 'dns' sampling method

@@ -40,7 +40,8 @@ class FusedArgs(Structure):
         ('fused_loss', c_int32), ('_pad2', c_int32), ('row_loss', c_void_p), ('loss_out', c_void_p),
         ('dpos', c_void_p), ('dneg', c_void_p), ('cdf_lut', c_void_p), ('query_grad', c_void_p), ('packed_keys', c_void_p), ('offset_dev', c_void_p),
         ('elem_base', c_uint64), ('reduce_scratch', c_void_p), ('cdf_lines', c_void_p), ('lines_log2', c_int32), ('_pad3', c_int32),
-        ('solo_flags', c_void_p), ('upd_scale', c_void_p),
+        ('solo_flags', c_void_p), ('upd_scale', c_void_p), ('n_batches', c_int32), ('_pad4', c_int32),
+        ('batch_offset_step', c_uint64),
     ]
 
 
@@ -218,6 +219,7 @@ SIGNATURES = {
     'rsa_rows_update_sorted': (c_int, [POINTER(RowsUpdateArgs), c_void_p]),
     'rsa_bpr_sgd_prepare': (c_int, [POINTER(BprSgdArgs), c_void_p]),
     'rsa_bpr_sgd_apply': (c_int, [POINTER(BprSgdArgs), c_void_p]),
+    'rsa_probs_t_query': (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int32, c_void_p, c_void_p]),
     'rsa_rng_advance': (c_int, [c_void_p, c_uint64, c_void_p]),
     'rsa_row_topk': (c_int, [c_void_p, c_int64, c_int64, c_int32, c_void_p, c_void_p, c_void_p]),
     'rsa_topk_mask_history': (c_int, [c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_int64, c_int32, c_void_p,

@@ -1,0 +1,165 @@
+// d loss / d item rows of the full softmax:  out[i][:] = sum_b probs[b][i] * query[b][:]   (i over the catalog, b over the batch)
+//
+// The last library GEMM of the full-softmax training step (BASELINE.json configs[4]): the reference gets it from autograd
+// -- scorer.py:16 (`query @ items.T`) under loss_func.py:39-47, i.e. ATen's mm backward `probs.T @ query` -- and rounds 1-4 of
+// this package called torch.matmul -> rocBLAS for it.  Item-stationary on the fp32 matrix cores:
+//
+//   * a workgroup of four waves owns 128 consecutive items, wave w the 32 items i0 + 32 w .. + 31, for ALL D columns: the
+//     [32 x D] block of the result lives in D/32 accumulator tiles (64 VGPRs at D = 128) for the whole batch loop -- every
+//     output row is written exactly once, no atomics, no split-K partials;
+//   * v_mfma_f32_32x32x2_f32 with the items as rows: step t takes two batch rows b, b + 1; lane (j, h) supplies
+//     A = probs[b + h][i0 + j] -- the half-wave reads 128 contiguous bytes of one probs row -- and, for column block c,
+//     B = query[b + h][NC j + c]: output column block c of lane j is column NC j + c (NC = D/32), so a lane's NC operand
+//     values are ONE contiguous 16-byte read of the query row and its NC results of an item are one 16-byte store;
+//   * the query chunk of a step group (32 batch rows x D floats = 16 KB) is staged once per workgroup in LDS, double buffered
+//     (it is shared by the four waves and by every workgroup: 1 MB at B = 2048, L2 resident); probs -- the 4 B N bytes the
+//     kernel exists to stream -- goes straight to registers, a whole step group (16 dwords per lane) ahead of its use.
+//
+// flops 2 B N D; bytes 4 B N (probs once) + 4 N D (result once).  Bound: fp32 matrix peak (157.3 TFLOP/s) above B ~ 64.
+#include "rsa_common.hpp"
+
+namespace rsa {
+
+using f32x16 = float __attribute__((ext_vector_type(16)));
+
+constexpr int DX_KB = 32;            // batch rows per staged query chunk
+constexpr int DX_STEPS = DX_KB / 2;  // MFMA steps per chunk (two batch rows each)
+
+template <int D>
+__global__ __launch_bounds__(256, 2) void probs_t_query_kernel(const float* __restrict__ probs, int64_t n_cols, int64_t ld,
+                                                               const float* __restrict__ query, int64_t n_query,
+                                                               float* __restrict__ out) {
+  constexpr int NC = D / 32;
+  __shared__ __attribute__((aligned(16))) float qs[2][DX_KB * D];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 31, h = lane >> 5;
+  const int64_t i0 = (int64_t)blockIdx.x * 128 + wave * 32;      // this wave's first column of probs (item i0 + 1)
+  const int64_t col = i0 + j;
+  const bool col_ok = col < n_cols;
+  const float* pcol = probs + (col_ok ? col : 0);
+
+  f32x16 acc[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) acc[c] = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+
+  const int64_t n_chunks = (n_query + DX_KB - 1) / DX_KB;
+  // cooperative stage of a query chunk: DX_KB * D / 4 float4 over 256 threads
+  constexpr int QLOADS = DX_KB * D / 4 / 256;
+  static_assert(DX_KB * D / 4 % 256 == 0, "query chunk must split evenly over the workgroup");
+  float4 qstage[QLOADS];
+  auto q_fetch = [&](int64_t chunk) __attribute__((always_inline)) {
+#pragma unroll
+    for (int f = 0; f < QLOADS; ++f) {
+      const int idx = f * 256 + tid;
+      const int row = idx / (D / 4), c4 = idx - row * (D / 4);
+      const int64_t b = chunk * DX_KB + row;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (b < n_query) v = reinterpret_cast<const float4*>(query + (size_t)b * D)[c4];
+      qstage[f] = v;
+    }
+  };
+  auto q_commit = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int f = 0; f < QLOADS; ++f) reinterpret_cast<float4*>(qs[buf])[f * 256 + tid] = qstage[f];
+  };
+  float pa[DX_STEPS], pb[DX_STEPS];
+  auto p_fetch = [&](int64_t chunk, float (&dst)[DX_STEPS]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int t = 0; t < DX_STEPS; ++t) {
+      const int64_t b = chunk * DX_KB + 2 * t + h;
+      // rows past the batch are clamped to a valid address and multiplied by the zero query rows staged for them; columns
+      // past the catalog are never stored
+      dst[t] = pcol[(size_t)(b < n_query ? b : n_query - 1) * ld];
+    }
+  };
+  auto run_chunk = [&](int buf, const float (&p)[DX_STEPS]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int t = 0; t < DX_STEPS; ++t) {
+      const float* qrow = qs[buf] + (2 * t + h) * D + NC * j;
+      float qv[NC];
+      if constexpr (NC == 4) {
+        const float4 v = *reinterpret_cast<const float4*>(qrow);
+        qv[0] = v.x; qv[1] = v.y; qv[2] = v.z; qv[3] = v.w;
+      } else if constexpr (NC == 2) {
+        const float2 v = *reinterpret_cast<const float2*>(qrow);
+        qv[0] = v.x; qv[1] = v.y;
+      } else {
+        qv[0] = qrow[0];
+      }
+#pragma unroll
+      for (int c = 0; c < NC; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(p[t], qv[c], acc[c], 0, 0, 0);
+    }
+  };
+
+  q_fetch(0);
+  p_fetch(0, pa);
+  q_commit(0);
+  __syncthreads();
+  for (int64_t chunk = 0; chunk < n_chunks; chunk += 2) {
+    // even chunk: operands in (qs[0], pa); the next chunk's go to (qs[1], pb) under this chunk's MFMA chain
+    const bool more1 = chunk + 1 < n_chunks;
+    if (more1) {
+      q_fetch(chunk + 1);
+      p_fetch(chunk + 1, pb);
+    }
+    run_chunk(0, pa);
+    if (more1) q_commit(1);
+    __syncthreads();
+    if (!more1) break;
+    const bool more2 = chunk + 2 < n_chunks;
+    if (more2) {
+      q_fetch(chunk + 2);
+      p_fetch(chunk + 2, pa);
+    }
+    run_chunk(1, pb);
+    if (more2) q_commit(0);
+    __syncthreads();
+  }
+  // acc[c][r] = out[item row(r, h)][NC j + c], row(r, h) = (r & 3) + 8 (r >> 2) + 4 h
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int64_t item = i0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+    if (item < n_cols) {
+      float* dst = out + (size_t)item * D + NC * j;
+      if constexpr (NC == 4) {
+        *reinterpret_cast<float4*>(dst) = make_float4(acc[0][r], acc[1][r], acc[2][r], acc[3][r]);
+      } else if constexpr (NC == 2) {
+        *reinterpret_cast<float2*>(dst) = make_float2(acc[0][r], acc[1][r]);
+      } else {
+        dst[0] = acc[0][r];
+      }
+    }
+  }
+}
+
+}  // namespace rsa
+
+using namespace rsa;
+
+extern "C" int rsa_probs_t_query(const float* probs, int64_t n_query, int64_t n_cols, int64_t ld, const float* query, int32_t dim,
+                                 float* out, rsa_stream_t stream) {
+  RSA_CHECK_ARG(n_query >= 0 && n_cols >= 0 && ld >= n_cols, "rsa_probs_t_query: bad sizes");
+  if (n_cols == 0) return RSA_OK;
+  RSA_CHECK_ARG(out != nullptr, "rsa_probs_t_query: out is null");
+  hipStream_t s = (hipStream_t)stream;
+  if (n_query == 0) {
+    if (hipMemsetAsync(out, 0, (size_t)n_cols * dim * sizeof(float), s) != hipSuccess) {
+      rsa::set_error("rsa_probs_t_query: memset failed");
+      return RSA_ERR_HIP;
+    }
+    return RSA_OK;
+  }
+  RSA_CHECK_ARG(probs && query, "rsa_probs_t_query: null pointer");
+  RSA_CHECK_ARG(((uintptr_t)query & 15) == 0 && ((uintptr_t)out & 15) == 0, "rsa_probs_t_query: query / out must be 16-byte aligned");
+  const dim3 grid((unsigned)((n_cols + 127) / 128)), block(256);
+  switch (dim) {
+    case 32: hipLaunchKernelGGL(probs_t_query_kernel<32>, grid, block, 0, s, probs, n_cols, ld, query, n_query, out); break;
+    case 64: hipLaunchKernelGGL(probs_t_query_kernel<64>, grid, block, 0, s, probs, n_cols, ld, query, n_query, out); break;
+    case 128: hipLaunchKernelGGL(probs_t_query_kernel<128>, grid, block, 0, s, probs, n_cols, ld, query, n_query, out); break;
+    default:
+      rsa::set_error("rsa_probs_t_query: dim=%d: built for dim in {32, 64, 128}", dim);
+      return RSA_ERR_UNSUPPORTED;
+  }
+  RSA_CHECK_LAUNCH("rsa_probs_t_query");
+  return RSA_OK;
+}

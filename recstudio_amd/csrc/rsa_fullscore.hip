@@ -62,8 +62,8 @@ constexpr int OVF = 1024;
 struct FilterArgs {
   const float* thr;     // [n_query] per-query threshold (null: no filtering)
   int32_t* seg_cnt;     // [n_query, splits, 2] candidates seen per segment (may exceed SEG: overflow marker)
-  float* cand_val;      // [n_query, splits, 2, SEG]
-  int32_t* cand_idx;    // [n_query, splits, 2, SEG] item ids
+  float2* cand;         // [n_query, splits, 2, SEG] {score, item id as int32 bits}: ONE 8-byte store per candidate (every
+                        // scattered store is its own 64-byte write request: two arrays cost two)
   // SCORES epilogue transform (backward of the full softmax): with sm_lse set the stored value is
   // sm_scale[q] * exp(score - sm_lse[q]) instead of the raw score
   const float* sm_lse;    // [n_query] or null
@@ -343,8 +343,7 @@ __global__ __launch_bounds__(256, DQ ? RSA_FS_DQ_MIN_BLOCKS : RSA_FS_MIN_BLOCKS)
           const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
           if (acc[r] > thr && i0 + row < i_end) {
             if (my_cnt < SEG) {
-              flt.cand_val[seg * SEG + my_cnt] = acc[r];
-              flt.cand_idx[seg * SEG + my_cnt] = (int32_t)(i0 + row);
+              flt.cand[seg * SEG + my_cnt] = make_float2(acc[r], __int_as_float((int32_t)(i0 + row)));
               ++my_cnt;
             } else {
               const int pos = atomicAdd(&flt.ovf_cnt[q], 1);
@@ -500,6 +499,40 @@ __global__ __launch_bounds__(256) void lse_merge_kernel(const float2* __restrict
   lse[q] = m + logf(acc);
 }
 
+// ------------------------------------------------------------------ candidate threshold from group maxima
+// thr[q] = the j-th largest of the G group maxima part[q][g].x (the running max the logsumexp instantiation of the GEMM
+// leaves per (query, item range): in SAMPLE mode a range is a group of g sampled items).  The number of groups whose
+// maximum beats a score T estimates the tail mass above T just as the number of SAMPLES above T does -- P(group max > T)
+// = 1 - (1 - p)^g -- so the sampled scores need not be written (268 MB at B = 2048) and radix-selected (three passes
+// over them): 180 + 194 us -> 150 + 6 us.  The threshold is a heuristic either way: too few / too many survivors are
+// caught by the select pass and recomputed exactly.  One wave per query, rank by counting (G <= 1024).
+__global__ __launch_bounds__(256) void group_threshold_kernel(const float2* __restrict__ part, int64_t n_query, int G, int ld, int j,
+                                                              float* __restrict__ thr) {
+  __shared__ float vals[4][1024];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t q = (int64_t)blockIdx.x * 4 + wave;
+  const bool live = q < n_query;
+  float* v = vals[wave];
+  if (live)
+    for (int g = lane; g < G; g += 64) v[g] = part[(size_t)q * ld + g].x;
+  __syncthreads();
+  float found = -INFINITY;
+  if (live) {
+    for (int g = lane; g < G; g += 64) {
+      const float x = v[g];
+      int rank = 0;                          // values ahead of x in (value desc, index asc) order
+      for (int o = 0; o < G; ++o) {
+        const float y = v[o];
+        rank += (y > x || (y == x && o < g)) ? 1 : 0;
+      }
+      if (rank == j - 1) found = x;
+    }
+  }
+#pragma unroll
+  for (int off = 32; off; off >>= 1) found = fmaxf(found, __shfl_xor(found, off, 64));
+  if (lane == 0 && live) thr[q] = found;
+}
+
 // ------------------------------------------------------------------ exact top-k of one row
 __device__ __forceinline__ uint32_t order_key(float x) {   // monotone float -> uint
   const uint32_t u = __float_as_uint(x);
@@ -513,8 +546,8 @@ enum { SEL_DENSE = 0, SEL_CAND = 1, SEL_RECOMPUTE = 2, SEL_THRESHOLD = 3 };
 
 constexpr int CAND_MAX = 4096;   // candidates of one query that the select kernel compacts into LDS
 struct SelectArgs {
-  const float* values;      // DENSE/THRESHOLD: [n_rows, ld] score rows;  CAND: [n_rows, n_seg, SEG] candidate scores
-  const int32_t* cand_idx;  // CAND: [n_rows, n_seg, SEG] item ids
+  const float* values;      // DENSE/THRESHOLD: [n_rows, ld] score rows
+  const float2* cand;       // CAND: [n_rows, n_seg, SEG] {score, item id bits}
   const int32_t* seg_cnt;   // CAND: [n_rows, n_seg] candidates seen per segment
   int32_t n_seg;            // CAND: segments per row (splits x 2)
   const int32_t* ovf_cnt;   // CAND: [n_rows] entries appended to the row's overflow list (may exceed OVF)
@@ -616,8 +649,9 @@ __global__ __launch_bounds__(1024) void topk_row_kernel(SelectArgs a, int k, flo
       const int32_t end = (int32_t)hist[b], beg = b ? (int32_t)hist[b - 1] : 0;
       const size_t src = ((size_t)r * a.n_seg + b) * SEG;
       for (int32_t e = beg; e < end; ++e) {
-        cval[e] = a.values[src + (e - beg)];
-        cidx[e] = a.cand_idx[src + (e - beg)];
+        const float2 c = a.cand[src + (e - beg)];
+        cval[e] = c.x;
+        cidx[e] = __float_as_int(c.y);
       }
     }
     for (int32_t e = tid; e < total - seg_total; e += 1024) {
@@ -815,10 +849,13 @@ static int64_t fullscore_splits(int64_t n_query, int64_t n_positions, int64_t mi
 constexpr int64_t SAMPLE_TILES_MAX = 1024;  // 32 768 sampled items
 constexpr int64_t FILTER_MIN_ITEMS = 32768; // below this the dense radix select is cheaper
 
+constexpr int64_t GROUP_TILES = 4;          // sampled tiles per threshold group (128 items)
 struct TopkPlan {
   bool filter;
   int64_t sample_tiles, tile_stride, sample_items;
-  int32_t j;   // threshold rank inside the sample
+  int64_t groups;       // threshold groups per query (item ranges of the sample pass), <= 1024
+  int32_t j;            // threshold = the j-th largest group maximum
+  double expect;        // catalog items expected above it
   int64_t min_splits;   // item-range splits needed to keep the per-segment candidate count far below SEG
 };
 
@@ -831,18 +868,26 @@ static TopkPlan plan_topk(int64_t n_items, int32_t k, bool scores_given) {
   pl.sample_tiles = tiles / 4 < SAMPLE_TILES_MAX ? tiles / 4 : SAMPLE_TILES_MAX;
   pl.tile_stride = tiles / pl.sample_tiles;
   pl.sample_items = pl.sample_tiles * TI;
-  // expected catalog items above the j-th sampled score ~ j * n_cols / sample_items: aim at 3k + margin
-  const double ratio = (double)pl.sample_items / (double)n_cols;
-  int64_t j = (int64_t)(3.0 * k * ratio) + 16;
-  if (j > 1024) j = 1024;
-  if (j > pl.sample_items) j = pl.sample_items;
-  pl.j = (int32_t)j;
-  if ((double)j / ratio > 0.6 * CAND_MAX) pl.filter = false;   // would crowd the candidate lists
+  // The threshold is the j-th largest of the per-GROUP maxima of the sample (group = GROUP_TILES consecutive sampled tiles):
+  // with tail mass p above a score, a group of g samples has its maximum above it with probability 1 - (1 - p)^g.  Aim at
+  // E = 3k + 300 catalog items above the threshold (k = 100: 600; the relative spread of the true count is ~ 1/sqrt(j)).
+  pl.groups = (pl.sample_tiles + GROUP_TILES - 1) / GROUP_TILES;
+  const double g_items = (double)(GROUP_TILES * TI);
+  pl.expect = 3.0 * k + 300.0;
+  const double p_tail = pl.expect / (double)n_cols;
+  double jj = (double)pl.groups * (1.0 - pow(1.0 - (p_tail < 1.0 ? p_tail : 1.0), g_items));
+  if (jj < 12.0) {                       // too few groups above the target for a stable rank: take rank 12 and what it implies
+    jj = 12.0;
+    const double pg = jj / (double)pl.groups;
+    pl.expect = pg < 1.0 ? (1.0 - pow(1.0 - pg, 1.0 / g_items)) * (double)n_cols : (double)n_cols;
+  }
+  pl.j = (int32_t)(jj + 0.5);
+  if (pl.j > pl.groups / 2 || pl.expect > 0.6 * CAND_MAX || pl.expect < 2.0 * k) pl.filter = false;   // would crowd / starve the candidate lists
   // a (query, split, lane half) segment holds SEG = 32 candidates; with ~6 expected per segment an overflow
   // (-> the slow exact recompute of that row) has probability ~1e-14 for exchangeable scores.  Large k at
   // large B (few default splits) used to sit at ~16 per segment: a handful of overflowing rows per call, each
   // costing a full single-workgroup pass over the catalog (460 ms instead of 5 ms at B = 2048, k = 500).
-  pl.min_splits = (int64_t)((double)j / ratio / (2.0 * 6.0)) + 1;
+  pl.min_splits = (int64_t)(pl.expect / (2.0 * 6.0)) + 1;
   return pl;
 }
 
@@ -855,11 +900,11 @@ extern "C" int64_t rsa_fullscore_workspace_bytes(int64_t n_query, int64_t n_item
                            (int64_t)sizeof(float2));   // lse partials
   if (k > 0) {
     if (pl.filter) {
-      bytes += align256(n_query * pl.sample_items * 4);        // sample scores
+      bytes += align256(n_query * pl.groups * (int64_t)sizeof(float2));   // group maxima of the sample pass
       const int64_t n_seg = fullscore_splits(n_query, n_items - 1, pl.min_splits) * 2;
       bytes += 2 * align256(n_query * 4);                       // thresholds, flags
       bytes += align256(n_query * n_seg * 4);                   // per-segment counts
-      bytes += 2 * align256(n_query * n_seg * (int64_t)SEG * 4);   // candidate values + ids
+      bytes += align256(n_query * n_seg * (int64_t)SEG * 8);    // candidates {score, id}
       bytes += align256(n_query * 4) + 2 * align256(n_query * (int64_t)OVF * 4);   // overflow lists
     } else {
       bytes += align256(n_query * (n_items - 1) * (int64_t)sizeof(float));   // dense score rows
@@ -945,43 +990,38 @@ static int fullscore_impl(const float* item_table, int64_t n_items, int32_t dim,
   float2* part = reinterpret_cast<float2*>(ws);
   ws += align256(n_query * splits * (int64_t)sizeof(float2));
   float2* lp = lse ? part : nullptr;
-  const FilterArgs no_filter{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, item_aux, query_aux, nullptr};
+  const FilterArgs no_filter{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, item_aux, query_aux, nullptr};
 
   if (pl.filter) {
-    float* sample = reinterpret_cast<float*>(ws);      ws += align256(n_query * pl.sample_items * 4);
+    float2* gmax = reinterpret_cast<float2*>(ws);      ws += align256(n_query * pl.groups * (int64_t)sizeof(float2));
     const int64_t n_seg = splits_used * 2;
     float* thr = reinterpret_cast<float*>(ws);         ws += align256(n_query * 4);
     int32_t* flags = reinterpret_cast<int32_t*>(ws);   ws += align256(n_query * 4);
     int32_t* seg_cnt = reinterpret_cast<int32_t*>(ws); ws += align256(n_query * splits * 2 * 4);
-    float* cand_val = reinterpret_cast<float*>(ws);    ws += align256(n_query * splits * 2 * (int64_t)SEG * 4);
-    int32_t* cand_idx = reinterpret_cast<int32_t*>(ws); ws += align256(n_query * splits * 2 * (int64_t)SEG * 4);
+    float2* cand = reinterpret_cast<float2*>(ws);      ws += align256(n_query * splits * 2 * (int64_t)SEG * 8);
     int32_t* ovf_cnt = reinterpret_cast<int32_t*>(ws);  ws += align256(n_query * 4);
     float* ovf_val = reinterpret_cast<float*>(ws);      ws += align256(n_query * (int64_t)OVF * 4);
     int32_t* ovf_idx = reinterpret_cast<int32_t*>(ws);
-    // A. sample GEMM + per-query threshold
-    const int64_t ssplits = fullscore_splits(n_query, pl.sample_items);
-    const int64_t sper = ((pl.sample_items + ssplits - 1) / ssplits + TI - 1) / TI * TI;
-    const int64_t ssplits_used = (pl.sample_items + sper - 1) / sper;
-    gemm_dispatch(dim, score_mode, dim3((unsigned)ssplits_used, groups), s, item_table, n_items, query, n_query, sample,
-                  pl.sample_items, nullptr, (int)ssplits_used, sper, pl.tile_stride, pl.sample_items, no_filter);
+    // A. sample GEMM (the logsumexp instantiation: its per-range running maximum is the group maximum) + per-query threshold
+    const int64_t sper = GROUP_TILES * TI;
+    gemm_dispatch(dim, score_mode, dim3((unsigned)pl.groups, groups), s, item_table, n_items, query, n_query, nullptr,
+                  pl.sample_items, gmax, (int)pl.groups, sper, pl.tile_stride, pl.sample_items, no_filter);
     RSA_CHECK_LAUNCH("rsa_fullscore(sample gemm)");
-    SelectArgs sa{};
-    sa.values = sample; sa.ld = pl.sample_items; sa.n_cols = pl.sample_items; sa.thr_out = thr;
-    hipLaunchKernelGGL(topk_row_kernel<SEL_THRESHOLD>, dim3((unsigned)n_query), dim3(1024), 0, s, sa, (int)pl.j,
-                       (float*)nullptr, (int64_t*)nullptr);
+    hipLaunchKernelGGL(group_threshold_kernel, dim3((unsigned)((n_query + 3) / 4)), dim3(256), 0, s, gmax, n_query, (int)pl.groups,
+                       (int)pl.groups, (int)pl.j, thr);
     RSA_CHECK_LAUNCH("rsa_fullscore(threshold)");
     // B. full GEMM with the filter epilogue (+ fused logsumexp)
     if (hipMemsetAsync(ovf_cnt, 0, (size_t)n_query * 4, s) != hipSuccess) {
       rsa::set_error("rsa_fullscore: memset failed");
       return RSA_ERR_HIP;
     }
-    const FilterArgs flt{thr, seg_cnt, cand_val, cand_idx, nullptr, nullptr, ovf_cnt, ovf_val, ovf_idx, item_aux, query_aux, nullptr};
+    const FilterArgs flt{thr, seg_cnt, cand, nullptr, nullptr, ovf_cnt, ovf_val, ovf_idx, item_aux, query_aux, nullptr};
     gemm_dispatch(dim, score_mode, dim3((unsigned)splits_used, groups), s, item_table, n_items, query, n_query, nullptr, n_cols, lp,
                   (int)splits_used, per, 1, n_cols, flt);
     RSA_CHECK_LAUNCH("rsa_fullscore(gemm+filter)");
     // C. exact select over the candidates;  D. exact recompute of flagged rows
     SelectArgs ca{};
-    ca.values = cand_val; ca.cand_idx = cand_idx; ca.seg_cnt = seg_cnt; ca.n_seg = (int32_t)n_seg; ca.flags = flags;
+    ca.cand = cand; ca.seg_cnt = seg_cnt; ca.n_seg = (int32_t)n_seg; ca.flags = flags;
     ca.ovf_cnt = ovf_cnt; ca.ovf_val = ovf_val; ca.ovf_idx = ovf_idx;
     hipLaunchKernelGGL(topk_row_kernel<SEL_CAND>, dim3((unsigned)n_query), dim3(1024), 0, s, ca, (int)k, topk_val,
                        topk_idx);
@@ -1028,7 +1068,7 @@ extern "C" int rsa_fullscore_softmax(const float* item_table, int64_t n_items, i
   const int64_t splits = fullscore_splits(n_query, n_cols);
   const int64_t per = ((n_cols + splits - 1) / splits + TI - 1) / TI * TI;
   const int64_t splits_used = (n_cols + per - 1) / per;
-  const FilterArgs ep{nullptr, nullptr, nullptr, nullptr, lse, row_scale, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  const FilterArgs ep{nullptr, nullptr, nullptr, lse, row_scale, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   gemm_dispatch(dim, RSA_SCORE_IP, dim3((unsigned)splits_used, groups), (hipStream_t)stream, item_table, n_items, query, n_query, probs,
                 n_cols, nullptr, (int)splits_used, per, 1, n_cols, ep);
   RSA_CHECK_LAUNCH("rsa_fullscore_softmax");
@@ -1080,7 +1120,7 @@ extern "C" int rsa_fullscore_softmax_dq(const float* item_table, int64_t n_items
   int64_t per, splits_used;
   softmax_plan(n_query, n_items, per, splits_used);
   float* part = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
-  const FilterArgs ep{nullptr, nullptr, nullptr, nullptr, lse, row_scale, nullptr, nullptr, nullptr, nullptr, nullptr, part};
+  const FilterArgs ep{nullptr, nullptr, nullptr, lse, row_scale, nullptr, nullptr, nullptr, nullptr, nullptr, part};
   hipStream_t s = (hipStream_t)stream;
   const dim3 grid((unsigned)splits_used, groups);
 #define RSA_DQ(DD)                                                                                                        \

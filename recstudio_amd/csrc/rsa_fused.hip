@@ -63,6 +63,11 @@ struct FwdParams {
   PhiloxCall pc;
   int32_t dim, num_neg, sampler, mask_pad_pos, guide_log2, score_mode, lines_log2;
   int32_t seg_stride;           // != 0: packed_keys is [n_segments][seg_stride] with RSA_SHARD_HDR header words per segment
+  // a QUEUE of independent batches in one launch (rsa_fused_args.n_batches > 1): tile t belongs to batch t / tiles_per_batch,
+  // whose elements draw from their own torch call -- element e - batch * batch_numel at Philox offset + batch * batch_offset4
+  uint32_t tiles_per_batch;     // 0: one batch
+  int64_t batch_numel;
+  uint64_t batch_offset4;
 };
 
 // In-place partial transpose-reduce over the lane-mask bits {step, 2*step, ..., step*L/2}:
@@ -364,12 +369,22 @@ void fused_fwd_kernel(const FwdParams p) {
     // ---- 1. the id of element e (lane-parallel: one Philox / one CDF search per lane)
     int32_t id = 0;
     int64_t key_lane = -1;       // packed_keys: this lane's key, -1 = empty slot
+    // queue of batches: this tile's batch draws from its own torch call (wave-uniform arithmetic)
+    PhiloxCall pcb = pc;
+    uint64_t eb = (uint64_t)e;
+    if constexpr (QU) {
+      if (p.tiles_per_batch) {
+        const uint32_t k = (uint32_t)tile / p.tiles_per_batch;
+        pcb.offset4 += (uint64_t)k * p.batch_offset4;
+        eb -= (uint64_t)k * (uint64_t)p.batch_numel;
+      }
+    }
     if (act) {
       if (p.sampler == RSA_SAMPLER_UNIFORM) {
-        id = (int32_t)torch_randint_element(pc, (uint64_t)e, (uint64_t)(p.n_items - 1), 1);
+        id = (int32_t)torch_randint_element(pcb, eb, (uint64_t)(p.n_items - 1), 1);
         st_out(&p.neg_ids[e], (int64_t)id);
       } else if (p.sampler == RSA_SAMPLER_POPULAR) {
-        const float u = ahead ? u_cur : torch_rand_element(pc, (uint64_t)e);
+        const float u = ahead ? u_cur : torch_rand_element(pcb, eb);
         float pr;
         if (ahead) {
           if (p.table_prob)
@@ -1032,6 +1047,9 @@ extern "C" int rsa_fused_sample_gather_score(const rsa_fused_args* a, rsa_stream
   p.n_query_rows = a->n_query_rows;
   p.n_queries = a->n_queries;
   p.pc = PhiloxCall{a->seed, a->offset >> 2, a->grid_threads, a->elem_base};
+  p.tiles_per_batch = 0;
+  p.batch_numel = 0;
+  p.batch_offset4 = 0;
   p.dim = a->dim;
   p.num_neg = a->num_neg;
   p.sampler = a->sampler;
@@ -1112,6 +1130,18 @@ extern "C" int rsa_fused_sample_gather_score(const rsa_fused_args* a, rsa_stream
   RSA_CHECK_ARG(!bpr || a->num_neg == 64,
                 "rsa_fused_sample_gather_score: the BPR epilogue with num_neg > 64 needs the inner-product scorer and dim in "
                 "{32, 64, 128, 256}");
+  if (a->n_batches > 1) {
+    // a queue of n_batches independent batches of n_queries / n_batches queries each, consumed by ONE resident grid
+    RSA_CHECK_ARG(qu && a->sampler != RSA_SAMPLER_GIVEN && a->n_queries % a->n_batches == 0 && a->offset_dev == nullptr &&
+                      a->loss_out == nullptr && a->elem_base == 0 && (a->batch_offset_step & 3) == 0 &&
+                      (a->sampler != RSA_SAMPLER_POPULAR || a->cdf_lines != nullptr || a->cdf_lut == nullptr),
+                  "rsa_fused_sample_gather_score: n_batches > 1 needs an in-kernel sampler, num_neg %% 64 == 0, equal batches, no "
+                  "loss_out (per-batch means are the caller's), no offset_dev / elem_base, and not the LUT form of the popularity lookup");
+    p.batch_numel = (a->n_queries / a->n_batches) * (int64_t)a->num_neg;
+    RSA_CHECK_ARG(p.batch_numel / 64 < (1ll << 31), "rsa_fused_sample_gather_score: batches of more than 2^37 elements");
+    p.tiles_per_batch = (uint32_t)(p.batch_numel / 64);
+    p.batch_offset4 = a->batch_offset_step >> 2;
+  }
   switch (a->dim) {
     case 32: rc = launch_fwd<8, false>(p, cos, qu, s); break;
     case 64: rc = launch_fwd<16, false>(p, cos, qu, s); break;

@@ -290,7 +290,7 @@ def fused_forward(item_table, query, num_neg, *, query_index=None, pos_ids=None,
                   table=None, pop_prob=None, guide=None, guide_log2=0, generator=None, n_queries=None,
                   out=None, want_logp=True, table_prob=None, fused_bpr=False, want_mean=True, cdf_lut=None,
                   want_query_grad=False, rng_state=None, cdf_lines=None, lines_log2=0, fused_loss=None,
-                  pos_logp=None, neg_logp=None, _plan=None, inplace_update=None):
+                  pos_logp=None, neg_logp=None, _plan=None, inplace_update=None, n_batches=1):
     """One launch of rsa_fused_sample_gather_score.  Returns a dict with
     neg_ids [M,n] int64, neg_score [M,n], pos_score [M] (if pos_ids), and for the
     popularity sampler neg_logp [M,n], pos_logp [M].  ``out``: a dict returned by an earlier
@@ -303,7 +303,11 @@ def fused_forward(item_table, query, num_neg, *, query_index=None, pos_ids=None,
     ``fused_loss='ssm'`` (same conditions, inner product, dim in {32, 64, 128, 256}): SampledSoftmaxLoss in the
     epilogue instead (one wave per query carries the logsumexp over its num_neg / 64 tiles); with ids given,
     ``pos_logp`` / ``neg_logp`` are the INPUT log-probabilities.  ``cdf_lines`` / ``lines_log2``: the bucket-line
-    form of the popularity sampler's inverse CDF (PopularSamplerModel.cdf_lines)."""
+    form of the popularity sampler's inverse CDF (PopularSamplerModel.cdf_lines).
+    ``n_batches`` = S > 1: a QUEUE of S independent batches consumed by one launch -- ``query_index`` / ``pos_ids`` hold the
+    S batches back to back ([S * B]); the outputs are those of S consecutive ``fused_forward`` calls over B queries each,
+    concatenated (every batch draws its negatives from its own torch call: the generator is advanced S times), ``loss``
+    is the [S] vector of the batches' mean losses.  In-kernel samplers only."""
     item_table = _need(item_table, torch.float32, 'item_table')
     query = _need(query, torch.float32, 'query')
     dev = item_table.device
@@ -332,6 +336,16 @@ def fused_forward(item_table, query, num_neg, *, query_index=None, pos_ids=None,
             cu, mt = rng.device_props(dev)
             a.seed, a.offset, a.grid_threads = int(seed) & 0xFFFFFFFFFFFFFFFF, 0, rng.grid_threads(M * n, cu, mt)
             a.offset_dev = ptr(offset_dev)
+        elif n_batches > 1:
+            if M % n_batches:
+                raise ValueError('n_batches must divide the number of queries')
+            per = M // int(n_batches) * n
+            pc = rng.reserve(per, unroll, dev, generator, repeat=int(n_batches))
+            if pc.elem_base:
+                raise NotImplementedError('fused_forward(n_batches=...) inside rng.sharded_stream')
+            a.seed, a.offset, a.grid_threads, a.elem_base = pc.seed, pc.offset, pc.grid_threads, 0
+            a.n_batches, a.batch_offset_step = int(n_batches), rng.counter_offset(per, pc.grid_threads, unroll)
+            want_mean = False
         else:
             pc = rng.reserve(M * n, unroll, dev, generator)
             a.seed, a.offset, a.grid_threads, a.elem_base = pc.seed, pc.offset, pc.grid_threads, pc.elem_base
@@ -399,9 +413,13 @@ def fused_forward(item_table, query, num_neg, *, query_index=None, pos_ids=None,
             a.solo_flags, a.upd_scale = ptr(_need(solo_flags, torch.uint8, 'solo_flags')), ptr(_need(upd_scale, torch.float32, 'upd_scale'))
     elif want_query_grad:
         raise ValueError('want_query_grad needs a fused loss (fused_bpr=True / fused_loss=...)')
+    if n_batches > 1 and (sampler == nat.SAMPLER_GIVEN or rng_state is not None):
+        raise ValueError('fused_forward(n_batches=...) draws its negatives in the kernel from the torch generator')
     nat.check(nat.lib().rsa_fused_sample_gather_score(ctypes.byref(a), _stream()), 'rsa_fused_sample_gather_score')
+    if n_batches > 1 and fused_loss is not None:
+        out['loss'] = out['row_loss'].view(int(n_batches), -1).mean(1)       # per batch (the kernel's mean is per launch)
     if _plan is not None:
-        _plan.update(args=a, out=out, device=dev, generator=generator, numel=M * n, keep=(item_table, query, query_index, pos_ids,
+        _plan.update(args=a, out=out, device=dev, generator=generator, numel=M * n, n_batches=int(n_batches), keep=(item_table, query, query_index, pos_ids,
                                                                                          neg_ids, table, pop_prob, guide))
         _plan['unroll'] = None if sampler == nat.SAMPLER_GIVEN or rng_state is not None else \
             (4 if sampler == nat.SAMPLER_POPULAR else rng.randint_unroll(1, n_items))
@@ -427,7 +445,8 @@ class FusedStep:
     def __call__(self):
         p = self._p
         if p['unroll'] is not None:
-            pc = rng.reserve(p['numel'], p['unroll'], p['device'], p['generator'])
+            nb = p.get('n_batches', 1)
+            pc = rng.reserve(p['numel'] // nb, p['unroll'], p['device'], p['generator'], repeat=nb)
             a = p['args']
             a.seed, a.offset, a.grid_threads, a.elem_base = pc.seed, pc.offset, pc.grid_threads, pc.elem_base
         rc = self._fn(self._ref, ctypes.c_void_p(_raw_stream(p['device'])))
@@ -760,6 +779,35 @@ def fullscore_softmax(item_table, query, lse, row_scale=None, want_query_grad=Fa
                                               ptr(_need_opt(row_scale, torch.float32, 'row_scale')), ptr(probs),
                                               _stream()), 'rsa_fullscore_softmax')
     return probs
+
+
+@_on_device
+def probs_t_query(probs, query, out=None):
+    """rsa_probs_t_query: ``probs.t() @ query`` ([B, n] x [B, d] -> [n, d]) on the fp32 matrix cores, item-stationary -- the
+    d/d items GEMM of the full-softmax backward.  d in {32, 64, 128} (other dims: zero-padded columns, sliced off)."""
+    probs = _need(probs, torch.float32, 'probs')
+    query = _need(query, torch.float32, 'query')
+    B, n = probs.shape
+    d = query.shape[1]
+    if query.shape[0] != B:
+        raise ValueError('probs_t_query: probs [B, n] and query [B, d] must share B')
+    if d not in (32, 64, 128):
+        if d > 128:
+            raise NotImplementedError('probs_t_query: embed_dim <= 128')
+        dp = 32 if d <= 32 else (64 if d <= 64 else 128)
+        qp = torch.zeros(B, dp, dtype=torch.float32, device=query.device)
+        qp[:, :d] = query
+        res = probs_t_query(probs, qp)[:, :d]
+        if out is not None:
+            out.copy_(res)
+            return out
+        return res.contiguous()
+    if out is None:
+        out = torch.empty(n, d, dtype=torch.float32, device=probs.device)
+    elif tuple(out.shape) != (n, d) or not out.is_contiguous() or out.dtype != torch.float32:
+        raise ValueError('probs_t_query: out must be a contiguous fp32 [n, d] tensor')
+    nat.check(nat.lib().rsa_probs_t_query(ptr(probs), B, n, probs.stride(0), ptr(query), d, ptr(out), _stream()), 'rsa_probs_t_query')
+    return out
 
 
 @_on_device

@@ -82,11 +82,14 @@ class sharded_stream:
         _SHARD.pop()
 
 
-def reserve(numel, unroll, device, generator=None, props=None):
-    """Consume the generator state one torch distribution call over ``numel`` outputs would."""
+def reserve(numel, unroll, device, generator=None, props=None, repeat=1):
+    """Consume the generator state one torch distribution call over ``numel`` outputs would (``repeat`` consecutive such
+    calls: the state of the FIRST is returned, call k starts ``k * counter_offset(numel, grid_threads, unroll)`` later)."""
     if numel <= 0:
         return PhiloxCall(0, 0, BLOCK)
     if _SHARD:
+        if repeat != 1:
+            raise NotImplementedError('reserve(repeat=...) inside sharded_stream')
         rank, world, gen = _SHARD[-1]
         with _no_shard():
             pc = reserve(numel * world, unroll, device, gen if gen is not None else generator, props)
@@ -102,5 +105,5 @@ def reserve(numel, unroll, device, generator=None, props=None):
     g = grid_threads(numel, cu, mt)
     seed = int(generator.initial_seed())
     offset = int(generator.get_offset())
-    generator.set_offset(offset + counter_offset(numel, g, unroll))
+    generator.set_offset(offset + int(repeat) * counter_offset(numel, g, unroll))
     return PhiloxCall(seed & 0xFFFFFFFFFFFFFFFF, offset, g)

@@ -163,7 +163,10 @@ class _FullLseFn(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             gw = torch.empty_like(weight)
             gw[0].zero_()
-            torch.matmul(probs.t(), query, out=gw[1:])
+            if weight.shape[1] <= 128:         # in-tree item-stationary MFMA kernel (rounds 1-4: torch.matmul -> rocBLAS)
+                ops.probs_t_query(probs, query, out=gw[1:])
+            else:
+                torch.matmul(probs.t(), query, out=gw[1:])
         return gq, gw
 
 

@@ -10,7 +10,7 @@ ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$ROOT/recstudio_amd/csrc/variant_$NAME
 mkdir -p $OUT
 FLAGS="-O3 -std=c++17 --offload-arch=gfx950 -fPIC -Wall -Wno-unused-function -ffp-contract=off $*"
-for f in rsa_misc rsa_sample rsa_fused rsa_loss rsa_backward rsa_fullscore rsa_shard rsa_sorted rsa_owner rsa_step; do
+for f in rsa_misc rsa_sample rsa_fused rsa_loss rsa_backward rsa_fullscore rsa_shard rsa_sorted rsa_owner rsa_step rsa_dx; do
   # only the sources named in VARIANT_FILES (default: the fused forward) are recompiled with the switches; the other
   # objects are reused from the default build
   if [[ " ${VARIANT_FILES:-rsa_fused} " == *" $f "* ]] || [ ! -f $ROOT/recstudio_amd/csrc/$f.o ]; then
