@@ -334,6 +334,7 @@ def side_figures(extra):
     put('fullscore_frac', 'fullscore', 'frac_of_peak')
     put('fullscore_tflops', 'fullscore', 'gemm_lse_tflops')
     put('fullscore_top100_ms', 'fullscore', 'with_top100_ms')
+    put('fullscore_grad_items_tflops', 'fullscore', 'grad_items_tflops')
     put('fullscore_top100_frac', 'fullscore', 'with_top100_frac')
     put('softmax_train_step_ms', 'fullscore', 'softmax_train_step_ms')
     put('softmax_train_frac', 'fullscore', 'softmax_train_frac')
@@ -638,7 +639,8 @@ def main():
             extra['fullscore'] = with_profile(
                 {'workload': f'B={b5} queries x N={n5} items, d={d}, fp32 MFMA (BASELINE.json configs[4])',
                  'gemm_lse_ms': round(t_lse, 3), 'gemm_lse_tflops': round(flops / t_lse / 1e9, 1),
-                 'with_top100_ms': round(t_topk, 3), 'peak_tflops_fp32_matrix': 157.3,
+                 'with_top100_ms': round(t_topk, 3), 'with_top100_frac': round(flops / t_topk / 1e9 / 157.3, 3),
+                 'peak_tflops_fp32_matrix': 157.3,
                  'frac_of_peak': round(flops / t_lse / 1e9 / 157.3, 3)}, 'fullscore_lse_B2048_N1e6', 0, flops=flops)
         except Exception as e:
             extra['fullscore'] = {'error': repr(e)[:200]}
@@ -711,8 +713,8 @@ def main():
                 full_lse(qq5, w5).mean().backward()
             t_sm = time_gpu(softmax_step, 5, 2) * 1e3
             extra['fullscore']['softmax_train_step_ms'] = round(t_sm, 3)
-            # where the step goes: in-tree MFMA kernels (forward logsumexp, softmax recompute that writes [B, N-1] once)
-            # vs the two plain library GEMMs of the backward (rocBLAS through torch.matmul; DESIGN.md 4.4 for why they stay)
+            # where the step goes: all in-tree MFMA kernels since round 5 (forward logsumexp; softmax recompute that writes
+            # [B, N-1] once with d/d query in the same pass; d/d items item-stationary) -- next to the library GEMMs they replaced
             lse5 = ra.ops.fullscore(w5.detach(), qq5.detach(), want_lse=True)[1]
             scale5 = torch.full((b5,), 1.0 / b5, device=dev)
             t_rec = time_gpu(lambda: ra.ops.fullscore_softmax(w5.detach(), qq5.detach(), lse5, scale5), 5, 2) * 1e3
@@ -720,12 +722,17 @@ def main():
             t_rec_dq = time_gpu(lambda: ra.ops.fullscore_softmax(w5.detach(), qq5.detach(), lse5, scale5,
                                                                  want_query_grad=True), 5, 2) * 1e3
             t_gq = time_gpu(lambda: probs5 @ w5.detach()[1:], 5, 2) * 1e3
-            t_gx = time_gpu(lambda: probs5.t() @ qq5.detach(), 5, 2) * 1e3
+            t_gx_lib = time_gpu(lambda: probs5.t() @ qq5.detach(), 5, 2) * 1e3
+            gx5 = torch.empty(n5 - 1, d, device=dev)
+            t_gx = time_gpu(lambda: ra.ops.probs_t_query(probs5, qq5.detach(), out=gx5), 5, 2) * 1e3
+            del gx5
+            extra['fullscore']['grad_items_tflops'] = round(flops / t_gx / 1e9, 1)
             extra['fullscore']['softmax_train_step_parts_ms'] = {
                 'forward_lse_in_tree': round(t_lse, 3),
                 'softmax_recompute_write_and_grad_query_in_tree': round(t_rec_dq, 3),
-                'grad_items_gemm_rocblas': round(t_gx, 3),
+                'grad_items_gemm_in_tree': round(t_gx, 3),
                 'not_in_the_step_any_more': {'softmax_recompute_write_alone': round(t_rec, 3),
+                                             'grad_items_gemm_rocblas': round(t_gx_lib, 3),
                                              'grad_query_gemm_rocblas': round(t_gq, 3)},
                 'fp32_mfma_floor_of_the_step_ms': round(4 * flops / 157.3e12 * 1e3, 2)}
             extra['fullscore']['softmax_train_frac'] = round(4 * flops / 157.3e12 * 1e3 / t_sm, 4)

@@ -22,11 +22,20 @@ namespace rsa {
 
 using f32x16 = float __attribute__((ext_vector_type(16)));
 
-constexpr int DX_KB = 32;            // batch rows per staged query chunk
+#ifndef RSA_DX_KB
+#define RSA_DX_KB 32
+#endif
+constexpr int DX_KB = RSA_DX_KB;     // batch rows per staged query chunk
 constexpr int DX_STEPS = DX_KB / 2;  // MFMA steps per chunk (two batch rows each)
 
+#ifndef RSA_DX_MIN_BLOCKS
+#define RSA_DX_MIN_BLOCKS 2
+#endif
+#ifndef RSA_DX_QAHEAD
+#define RSA_DX_QAHEAD 2          // LDS reads of the query operand issued this many steps ahead of their MFMAs
+#endif
 template <int D>
-__global__ __launch_bounds__(256, 2) void probs_t_query_kernel(const float* __restrict__ probs, int64_t n_cols, int64_t ld,
+__global__ __launch_bounds__(256, RSA_DX_MIN_BLOCKS) void probs_t_query_kernel(const float* __restrict__ probs, int64_t n_cols, int64_t ld,
                                                                const float* __restrict__ query, int64_t n_query,
                                                                float* __restrict__ out) {
   constexpr int NC = D / 32;
@@ -42,19 +51,27 @@ __global__ __launch_bounds__(256, 2) void probs_t_query_kernel(const float* __re
 #pragma unroll
   for (int c = 0; c < NC; ++c) acc[c] = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 
-  const int64_t n_chunks = (n_query + DX_KB - 1) / DX_KB;
   // cooperative stage of a query chunk: DX_KB * D / 4 float4 over 256 threads
   constexpr int QLOADS = DX_KB * D / 4 / 256;
   static_assert(DX_KB * D / 4 % 256 == 0, "query chunk must split evenly over the workgroup");
   float4 qstage[QLOADS];
+  // FULL chunks (all DX_KB batch rows exist) are fetched without a single bounds check: a predicated load is a branch, and a
+  // branch in front of the MFMA chain is a merge point at which the wait-count pass takes the minimum over both paths -- step t
+  // of a chunk then waits for the t-th load of the NEXT chunk issued just above it (a memory round trip exposed per trip:
+  // 4.69 ms = 112 TFLOP/s at B = 2048, N = 1e6 in the first version).  The odd full chunk and the partial last chunk go
+  // through the checked forms after the pipelined loop.
   auto q_fetch = [&](int64_t chunk) __attribute__((always_inline)) {
+#pragma unroll
+    for (int f = 0; f < QLOADS; ++f)
+      qstage[f] = reinterpret_cast<const float4*>(query + (size_t)chunk * DX_KB * D)[f * 256 + tid];
+  };
+  auto q_fetch_checked = [&](int64_t chunk) __attribute__((always_inline)) {
 #pragma unroll
     for (int f = 0; f < QLOADS; ++f) {
       const int idx = f * 256 + tid;
-      const int row = idx / (D / 4), c4 = idx - row * (D / 4);
-      const int64_t b = chunk * DX_KB + row;
+      const int64_t b = chunk * DX_KB + idx / (D / 4);
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (b < n_query) v = reinterpret_cast<const float4*>(query + (size_t)b * D)[c4];
+      if (b < n_query) v = reinterpret_cast<const float4*>(query + (size_t)chunk * DX_KB * D)[idx];
       qstage[f] = v;
     }
   };
@@ -64,56 +81,75 @@ __global__ __launch_bounds__(256, 2) void probs_t_query_kernel(const float* __re
   };
   float pa[DX_STEPS], pb[DX_STEPS];
   auto p_fetch = [&](int64_t chunk, float (&dst)[DX_STEPS]) __attribute__((always_inline)) {
+    const float* src = pcol + (size_t)(chunk * DX_KB + h) * ld;
+#pragma unroll
+    for (int t = 0; t < DX_STEPS; ++t) dst[t] = src[(size_t)(2 * t) * ld];
+  };
+  auto p_fetch_checked = [&](int64_t chunk, float (&dst)[DX_STEPS]) __attribute__((always_inline)) {
 #pragma unroll
     for (int t = 0; t < DX_STEPS; ++t) {
       const int64_t b = chunk * DX_KB + 2 * t + h;
-      // rows past the batch are clamped to a valid address and multiplied by the zero query rows staged for them; columns
-      // past the catalog are never stored
-      dst[t] = pcol[(size_t)(b < n_query ? b : n_query - 1) * ld];
+      dst[t] = b < n_query ? pcol[(size_t)b * ld] : 0.f;      // (the query rows staged for b >= n_query are zero as well)
+    }
+  };
+  auto q_read = [&](int buf, int t, float (&qv)[NC]) __attribute__((always_inline)) {
+    const float* qrow = qs[buf] + (2 * t + h) * D + NC * j;
+    if constexpr (NC == 4) {
+      const float4 v = *reinterpret_cast<const float4*>(qrow);
+      qv[0] = v.x; qv[1] = v.y; qv[2] = v.z; qv[3] = v.w;
+    } else if constexpr (NC == 2) {
+      const float2 v = *reinterpret_cast<const float2*>(qrow);
+      qv[0] = v.x; qv[1] = v.y;
+    } else {
+      qv[0] = qrow[0];
     }
   };
   auto run_chunk = [&](int buf, const float (&p)[DX_STEPS]) __attribute__((always_inline)) {
+    constexpr int AH = RSA_DX_QAHEAD;
+    float qv[AH + 1][NC];
+#pragma unroll
+    for (int t = 0; t < AH; ++t) q_read(buf, t, qv[t]);
 #pragma unroll
     for (int t = 0; t < DX_STEPS; ++t) {
-      const float* qrow = qs[buf] + (2 * t + h) * D + NC * j;
-      float qv[NC];
-      if constexpr (NC == 4) {
-        const float4 v = *reinterpret_cast<const float4*>(qrow);
-        qv[0] = v.x; qv[1] = v.y; qv[2] = v.z; qv[3] = v.w;
-      } else if constexpr (NC == 2) {
-        const float2 v = *reinterpret_cast<const float2*>(qrow);
-        qv[0] = v.x; qv[1] = v.y;
-      } else {
-        qv[0] = qrow[0];
-      }
+      if (t + AH < DX_STEPS) q_read(buf, t + AH, qv[(t + AH) % (AH + 1)]);
 #pragma unroll
-      for (int c = 0; c < NC; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(p[t], qv[c], acc[c], 0, 0, 0);
+      for (int c = 0; c < NC; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(p[t], qv[t % (AH + 1)][c], acc[c], 0, 0, 0);
     }
   };
 
-  q_fetch(0);
-  p_fetch(0, pa);
-  q_commit(0);
-  __syncthreads();
-  for (int64_t chunk = 0; chunk < n_chunks; chunk += 2) {
-    // even chunk: operands in (qs[0], pa); the next chunk's go to (qs[1], pb) under this chunk's MFMA chain
-    const bool more1 = chunk + 1 < n_chunks;
-    if (more1) {
+  const int64_t n_full = n_query / DX_KB;          // chunks with all their batch rows
+  const int64_t n_pipe = n_full & ~(int64_t)1;     // ... taken two per trip by the pipelined loop
+  if (n_pipe > 0) {
+    const int64_t last = n_pipe - 1;
+    q_fetch(0);
+    p_fetch(0, pa);
+    q_commit(0);
+    __syncthreads();
+    for (int64_t chunk = 0; chunk < n_pipe; chunk += 2) {
+      // even chunk: operands in (qs[0], pa); the next chunk's go to (qs[1], pb) under this chunk's MFMA chain.  Past the last
+      // chunk the last one is fetched again (and never used): no conditional anywhere in the trip.
       q_fetch(chunk + 1);
       p_fetch(chunk + 1, pb);
+      __builtin_amdgcn_sched_barrier(0);     // the loads stay at the top: the scheduler otherwise sinks them behind the MFMA chain
+      run_chunk(0, pa);
+      q_commit(1);
+      __syncthreads();
+      const int64_t nxt = chunk + 2 < last ? chunk + 2 : last;
+      q_fetch(nxt);
+      p_fetch(nxt, pa);
+      __builtin_amdgcn_sched_barrier(0);
+      run_chunk(1, pb);
+      q_commit(0);
+      __syncthreads();
     }
+  }
+  for (int64_t chunk = n_pipe; chunk * DX_KB < n_query; ++chunk) {      // at most one full and one partial chunk
+    q_fetch_checked(chunk);
+    p_fetch_checked(chunk, pa);
+    __syncthreads();
+    q_commit(0);
+    __syncthreads();
     run_chunk(0, pa);
-    if (more1) q_commit(1);
-    __syncthreads();
-    if (!more1) break;
-    const bool more2 = chunk + 2 < n_chunks;
-    if (more2) {
-      q_fetch(chunk + 2);
-      p_fetch(chunk + 2, pa);
-    }
-    run_chunk(1, pb);
-    if (more2) q_commit(0);
-    __syncthreads();
   }
   // acc[c][r] = out[item row(r, h)][NC j + c], row(r, h) = (r & 3) + 8 (r >> 2) + 4 h
 #pragma unroll

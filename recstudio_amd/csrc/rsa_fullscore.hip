@@ -679,10 +679,17 @@ __global__ __launch_bounds__(1024) void topk_row_kernel(SelectArgs a, int k, flo
     if (MODE == SEL_CAND) return cval[i];
     return row[i];
   };
+  // CAND with at most 1024 candidates (the usual case: the threshold aims at 3k + 300): they all fit the sort below -- no radix
+  // select, no winner collection (three histogram passes + six 2048-bin scans: half of this kernel's barriers)
+  const bool direct = MODE == SEL_CAND && n <= 1024;
+  if (direct) {
+    okey[tid] = tid < n ? order_key(cval[tid]) : 0u;
+    oidx[tid] = tid < n ? cidx[tid] : 0x7fffffff;
+  }
   uint32_t prefix = 0, pmask = 0;
   uint32_t k_rem = (uint32_t)k;
   const int shifts[3] = {21, 10, 0}, nbits[3] = {11, 11, 10};
-  for (int pass = 0; pass < 3; ++pass) {
+  for (int pass = 0; pass < (direct ? 0 : 3); ++pass) {
     const int shift = shifts[pass], nb = 1 << nbits[pass];
     for (int b = tid; b < 2048; b += 1024) hist[b] = 0;
     __syncthreads();
@@ -717,14 +724,16 @@ __global__ __launch_bounds__(1024) void topk_row_kernel(SelectArgs a, int k, flo
   // remaining ties bail out with one LDS read.
   __shared__ int32_t s_tie_max;
   const uint32_t n_gt = (uint32_t)k - k_rem;
-  if (tid == 0) {
-    s_cnt_gt = 0;
-    s_tie_max = 0x7fffffff;
+  if (!direct) {
+    if (tid == 0) {
+      s_cnt_gt = 0;
+      s_tie_max = 0x7fffffff;
+    }
+    okey[tid] = (tid >= (int)n_gt && tid < k) ? prefix : 0u;
+    oidx[tid] = 0x7fffffff;
   }
-  okey[tid] = (tid >= (int)n_gt && tid < k) ? prefix : 0u;
-  oidx[tid] = 0x7fffffff;
   __syncthreads();
-  for (int64_t i = tid; i < n; i += 1024) {
+  for (int64_t i = tid; i < (direct ? 0 : n); i += 1024) {
     const uint32_t key = order_key(value_at(i));
     const int32_t id = MODE == SEL_CAND ? cidx[i] : (int32_t)i + (MODE == SEL_DENSE ? a.idx_base : 1);   // item id
     if (key > prefix) {
@@ -849,7 +858,7 @@ static int64_t fullscore_splits(int64_t n_query, int64_t n_positions, int64_t mi
 constexpr int64_t SAMPLE_TILES_MAX = 1024;  // 32 768 sampled items
 constexpr int64_t FILTER_MIN_ITEMS = 32768; // below this the dense radix select is cheaper
 
-constexpr int64_t GROUP_TILES = 4;          // sampled tiles per threshold group (128 items)
+constexpr int64_t GROUP_TILES = 8;          // sampled tiles per threshold group (256 items)
 struct TopkPlan {
   bool filter;
   int64_t sample_tiles, tile_stride, sample_items;
@@ -870,10 +879,15 @@ static TopkPlan plan_topk(int64_t n_items, int32_t k, bool scores_given) {
   pl.sample_items = pl.sample_tiles * TI;
   // The threshold is the j-th largest of the per-GROUP maxima of the sample (group = GROUP_TILES consecutive sampled tiles):
   // with tail mass p above a score, a group of g samples has its maximum above it with probability 1 - (1 - p)^g.  Aim at
-  // E = 3k + 300 catalog items above the threshold (k = 100: 600; the relative spread of the true count is ~ 1/sqrt(j)).
+  // E = 2k + 250 catalog items above the threshold (k = 100: 450, rank j = 14 of 128 group maxima; the relative spread of
+  // the true count is ~ 1/sqrt(j): fewer than k survivors -- the exact-recompute path -- has probability ~3e-6 per query).
   pl.groups = (pl.sample_tiles + GROUP_TILES - 1) / GROUP_TILES;
   const double g_items = (double)(GROUP_TILES * TI);
-  pl.expect = 3.0 * k + 300.0;
+#ifndef RSA_FS_EXPECT_MULT
+#define RSA_FS_EXPECT_MULT 2.0     // in-process A/B at B = 2048, N = 1e6, k = 100 (ms, logsumexp + top-100): 3k + 300 -> 4.586,
+#define RSA_FS_EXPECT_ADD 250.0    // 2k + 250 -> 4.528, 2k + 150 -> 4.505 (logsumexp alone 3.93)
+#endif
+  pl.expect = RSA_FS_EXPECT_MULT * k + RSA_FS_EXPECT_ADD;
   const double p_tail = pl.expect / (double)n_cols;
   double jj = (double)pl.groups * (1.0 - pow(1.0 - (p_tail < 1.0 ? p_tail : 1.0), g_items));
   if (jj < 12.0) {                       // too few groups above the target for a stable rank: take rank 12 and what it implies

@@ -60,6 +60,7 @@ struct FwdParams {
   int32_t* overflow_sticky;     //   += the same (nullable)
   float* qgrad;      // fused BPR epilogue (nullable): [M, dim] d loss / d query row, accumulated from the rows in flight
   int64_t n_items, n_query_rows, n_queries, numel;
+  int64_t mean_queries;         // queries the fused loss is the mean over: n_queries, or one batch of a queue
   PhiloxCall pc;
   int32_t dim, num_neg, sampler, mask_pad_pos, guide_log2, score_mode, lines_log2;
   int32_t seg_stride;           // != 0: packed_keys is [n_segments][seg_stride] with RSA_SHARD_HDR header words per segment
@@ -454,7 +455,7 @@ void fused_fwd_kernel(const FwdParams p) {
       // is needed while their rows are in registers
       pos_early = group_sum<LPR>(frag_dot<LPR, GENERIC>(px, qf));
       if (p.mask_pad_pos && pad) pos_early = -INFINITY;
-      const float bw = 1.f / (float)n, binv = 1.f / (float)p.n_queries;
+      const float bw = 1.f / (float)n, binv = 1.f / (float)p.mean_queries;
       if constexpr (UPD) {
         // rows touched by exactly one element of the step (rsa_sort_step_elements' classification, element order
         // m * (n + 1) + 1 + j) are updated in the tile; the sorted scatter skips exactly those
@@ -520,7 +521,7 @@ void fused_fwd_kernel(const FwdParams p) {
           if (first && p.pos_logp && lane == 0) p.pos_logp[m_lane] = logf(p.pop_prob[pid]);
           if (fuse) {
             // BPRLoss (loss_func.py:55-59): -mean_m (1/n) sum_j logsigmoid(pos - neg_j), with its gradient
-            const float w = 1.f / (float)n, inv_m = 1.f / (float)p.n_queries;
+            const float w = 1.f / (float)n, inv_m = 1.f / (float)p.mean_queries;
             // one hardware exp + one log per element: t = exp(-|x|) serves logsigmoid and sigmoid(-x)
             // (absolute error ~1e-7 on terms of O(1), far inside the 1e-4 contract)
             const float xd = s - neg_s;
@@ -1046,6 +1047,7 @@ extern "C" int rsa_fused_sample_gather_score(const rsa_fused_args* a, rsa_stream
   p.n_items = a->n_items;
   p.n_query_rows = a->n_query_rows;
   p.n_queries = a->n_queries;
+  p.mean_queries = a->n_queries;
   p.pc = PhiloxCall{a->seed, a->offset >> 2, a->grid_threads, a->elem_base};
   p.tiles_per_batch = 0;
   p.batch_numel = 0;
@@ -1075,6 +1077,19 @@ extern "C" int rsa_fused_sample_gather_score(const rsa_fused_args* a, rsa_stream
                 a->fused_loss);
   RSA_CHECK_ARG(a->query_grad == nullptr || bpr || ssm,
                 "rsa_fused_sample_gather_score: query_grad is an output of the fused loss epilogue (fused_loss != 0)");
+  if (a->n_batches > 1) {
+    // a queue of n_batches independent batches of n_queries / n_batches queries each, consumed by ONE resident grid
+    RSA_CHECK_ARG(qu && !ssm && !(bpr && a->num_neg != 64) && a->sampler != RSA_SAMPLER_GIVEN && a->n_queries % a->n_batches == 0 && a->offset_dev == nullptr &&
+                      a->loss_out == nullptr && a->elem_base == 0 && (a->batch_offset_step & 3) == 0 &&
+                      (a->sampler != RSA_SAMPLER_POPULAR || a->cdf_lines != nullptr || a->cdf_lut == nullptr),
+                  "rsa_fused_sample_gather_score: n_batches > 1 needs an in-kernel sampler, num_neg %% 64 == 0, equal batches, no "
+                  "loss_out (per-batch means are the caller's), no offset_dev / elem_base, and not the LUT form of the popularity lookup");
+    p.batch_numel = (a->n_queries / a->n_batches) * (int64_t)a->num_neg;
+    RSA_CHECK_ARG(p.batch_numel / 64 < (1ll << 31), "rsa_fused_sample_gather_score: batches of more than 2^37 elements");
+    p.tiles_per_batch = (uint32_t)(p.batch_numel / 64);
+    p.batch_offset4 = a->batch_offset_step >> 2;
+    p.mean_queries = a->n_queries / a->n_batches;
+  }
   if (bpr || ssm) {
     RSA_CHECK_ARG(qu && a->pos_ids && a->pos_score && a->row_loss,
                   "rsa_fused_sample_gather_score: the fused loss epilogue needs num_neg %% 64 == 0, pos_ids, pos_score "
@@ -1130,18 +1145,6 @@ extern "C" int rsa_fused_sample_gather_score(const rsa_fused_args* a, rsa_stream
   RSA_CHECK_ARG(!bpr || a->num_neg == 64,
                 "rsa_fused_sample_gather_score: the BPR epilogue with num_neg > 64 needs the inner-product scorer and dim in "
                 "{32, 64, 128, 256}");
-  if (a->n_batches > 1) {
-    // a queue of n_batches independent batches of n_queries / n_batches queries each, consumed by ONE resident grid
-    RSA_CHECK_ARG(qu && a->sampler != RSA_SAMPLER_GIVEN && a->n_queries % a->n_batches == 0 && a->offset_dev == nullptr &&
-                      a->loss_out == nullptr && a->elem_base == 0 && (a->batch_offset_step & 3) == 0 &&
-                      (a->sampler != RSA_SAMPLER_POPULAR || a->cdf_lines != nullptr || a->cdf_lut == nullptr),
-                  "rsa_fused_sample_gather_score: n_batches > 1 needs an in-kernel sampler, num_neg %% 64 == 0, equal batches, no "
-                  "loss_out (per-batch means are the caller's), no offset_dev / elem_base, and not the LUT form of the popularity lookup");
-    p.batch_numel = (a->n_queries / a->n_batches) * (int64_t)a->num_neg;
-    RSA_CHECK_ARG(p.batch_numel / 64 < (1ll << 31), "rsa_fused_sample_gather_score: batches of more than 2^37 elements");
-    p.tiles_per_batch = (uint32_t)(p.batch_numel / 64);
-    p.batch_offset4 = a->batch_offset_step >> 2;
-  }
   switch (a->dim) {
     case 32: rc = launch_fwd<8, false>(p, cos, qu, s); break;
     case 64: rc = launch_fwd<16, false>(p, cos, qu, s); break;
@@ -1176,6 +1179,7 @@ extern "C" int rsa_shard_score_segments(const float* item_table, int64_t n_rows,
   p.n_items = n_rows;
   p.n_query_rows = n_query_rows;
   p.n_queries = numel;
+  p.mean_queries = numel;
   p.numel = numel;
   p.pc = PhiloxCall{0, 0, 256, 0};
   p.dim = dim;

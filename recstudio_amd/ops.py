@@ -717,13 +717,25 @@ def fullscore(item_table, query, *, want_scores=False, want_lse=False, k=0, item
     lse = torch.empty(B, dtype=torch.float32, device=dev) if want_lse else None
     tv = torch.empty(B, k, dtype=torch.float32, device=dev) if k else None
     ti = torch.empty(B, k, dtype=torch.int64, device=dev) if k else None
-    ws_bytes = int(nat.lib().rsa_fullscore_workspace_bytes(B, n_items, int(k)))
-    ws = torch.empty(max(ws_bytes, 8), dtype=torch.uint8, device=dev)
-    a = nat.FullscoreArgs()
-    a.item_table, a.n_items, a.dim, a.score_mode, a.query, a.n_query = table_ptr, n_items, dim, score_mode, ptr(query), B
-    a.scores, a.lse, a.topk_val, a.topk_idx, a.k = ptr(scores), ptr(lse), ptr(tv), ptr(ti), int(k)
-    a.item_aux, a.query_aux, a.workspace, a.workspace_bytes = ptr(ia), ptr(qa), ptr(ws), ws_bytes
-    nat.check(nat.lib().rsa_fullscore(ctypes.byref(a), _stream()), 'rsa_fullscore')
+    lib = nat.lib()
+
+    def launch(lo, hi, stream):
+        nq = hi - lo
+        ws_bytes = int(lib.rsa_fullscore_workspace_bytes(nq, n_items, int(k)))
+        ws = torch.empty(max(ws_bytes, 8), dtype=torch.uint8, device=dev)
+        a = nat.FullscoreArgs()
+        a.item_table, a.n_items, a.dim, a.score_mode, a.n_query = table_ptr, n_items, dim, score_mode, nq
+        a.query = query.data_ptr() + lo * dim * 4
+        a.scores = None if scores is None else scores.data_ptr() + lo * (n_items - 1) * 4
+        a.lse = None if lse is None else lse.data_ptr() + lo * 4
+        a.topk_val = None if tv is None else tv.data_ptr() + lo * k * 4
+        a.topk_idx = None if ti is None else ti.data_ptr() + lo * k * 8
+        a.k, a.item_aux, a.workspace, a.workspace_bytes = int(k), ptr(ia), ptr(ws), ws_bytes
+        a.query_aux = None if qa is None else qa.data_ptr() + lo * 4
+        nat.check(lib.rsa_fullscore(ctypes.byref(a), stream), 'rsa_fullscore')
+        return ws
+
+    launch(0, B, _stream())
     return scores, lse, tv, ti
 
 
