@@ -814,6 +814,11 @@ typedef struct rsa_shard_owner_bpr_args {
                                   workspace (q_all, pos_score, qgrad_all and the outputs may be null): a caller can issue it
                                   for the NEXT step, behind that step's key exchange, on another stream; 2 = the rest (update
                                   scales from the headers, then the pass over the rows) over a workspace a call with 1 filled */
+  /* rsa_shard_owner_ssm_forward / _finish (ABI 9): */
+  const float* logq_rows;      /* nullable [n_rows]: log-probability under the sampler of each LOCAL row's item (null: 0, the uniform sampler) */
+  float* run_max;              /* [n_query_rows] OUT of the forward: max over this owner's slots of z = score - log q (-inf: none) */
+  float* run_sum;              /* [n_query_rows] OUT: sum exp(z - run_max) */
+  float* run_acc;              /* [n_query_rows, dim] OUT: sum exp(z - run_max) * row */
 } rsa_shard_owner_bpr_args;
 int rsa_shard_pos_score(const float* item_local, int64_t n_rows, int32_t dim, const float* q_all, int64_t n_query_rows,
                         int64_t* pos_rows, float* out, const int64_t* pos_ids, int64_t rows_per_shard, int32_t n_shards,
@@ -822,6 +827,23 @@ int rsa_shard_pos_score(const float* item_local, int64_t n_rows, int32_t dim, co
                                                                   interleaved rows); NULL: pos_rows is the input */
 int rsa_shard_owner_bpr_forward(const rsa_shard_owner_bpr_args* args, rsa_stream_t stream);
 int rsa_shard_owner_bpr_finish(const rsa_shard_owner_bpr_args* args, const float* dsum_all, rsa_stream_t stream);
+
+/* SampledSoftmaxLoss (recstudio/model/loss_func.py:80-90, one positive per row) evaluated ON THE OWNERS of the negatives, for the
+ * same routed step (positives not routed, pos_rows per rank): loss_q = logsumexp(z_pos, z_1 .. z_n) - z_pos with z = score -
+ * log q spans all owners of a query's negatives, so the owner pass has two phases around an 8-byte-per-query all-reduce:
+ *   rsa_shard_owner_ssm_forward  sort by row (no solo classification: no row is updated by a walk in this step), the queries'
+ *     runs, and ONE walk over the received negatives' rows: z per slot (d_slots), and per query over this owner's slots
+ *     run_max = max z, run_sum = sum exp(z - run_max), run_acc = sum exp(z - run_max) * row (flash-attention style partials);
+ *   [caller: m = max(z_pos, all-reduce-max(run_max)); s = all-reduce-sum(run_sum * exp(run_max - m));
+ *            lse = m + log(s + exp(z_pos - m))]
+ *   rsa_shard_owner_ssm_finish   (args.pos_score = z_pos) d = exp(z - lse) / mean_den per slot; qgrad_all += gate *
+ *     exp(run_max - lse) / mean_den * run_acc -- the query gradient needs NO second pass over the rows --; the positives'
+ *     owners add (softmax_pos - 1) / mean_den * row_pos; every touched item row gets gate * item_scale * sum d * q through the
+ *     sorted apply pass.
+ * The loss itself is lse - z_pos on the caller's side.  No scores travel home, no score gradients travel back (8 instead of
+ * 16 bytes per triplet over xGMI).  dims in {64, 128, 256}; same workspace as the BPR form. */
+int rsa_shard_owner_ssm_forward(const rsa_shard_owner_bpr_args* args, rsa_stream_t stream);
+int rsa_shard_owner_ssm_finish(const rsa_shard_owner_bpr_args* args, const float* lse_all, rsa_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -101,6 +101,7 @@ class ShardOwnerBprArgs(Structure):
         ('step_dropped', c_void_p), ('overflow_sticky', c_void_p), ('scale_out', c_void_p), ('qgrad_all', c_void_p),
         ('d_slots', c_void_p), ('dsum_part', c_void_p), ('loss_part', c_void_p), ('reduce_scratch', c_void_p),
         ('item_pad_row', c_int64), ('workspace', c_void_p), ('workspace_bytes', c_int64), ('keys_grouped', c_int32), ('finish_parts', c_int32), ('forward_parts', c_int32),
+        ('logq_rows', c_void_p), ('run_max', c_void_p), ('run_sum', c_void_p), ('run_acc', c_void_p),
     ]
 
 
@@ -242,6 +243,8 @@ SIGNATURES = {
                                     c_int32, c_void_p]),
     'rsa_shard_owner_bpr_forward': (c_int, [POINTER(ShardOwnerBprArgs), c_void_p]),
     'rsa_shard_owner_bpr_finish': (c_int, [POINTER(ShardOwnerBprArgs), c_void_p, c_void_p]),
+    'rsa_shard_owner_ssm_forward': (c_int, [POINTER(ShardOwnerBprArgs), c_void_p]),
+    'rsa_shard_owner_ssm_finish': (c_int, [POINTER(ShardOwnerBprArgs), c_void_p, c_void_p]),
     'rsa_shard_unpack': (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     'rsa_scatter_f32': (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     'rsa_gather_f32': (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),

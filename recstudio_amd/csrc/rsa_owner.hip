@@ -58,6 +58,12 @@ struct OwnArgs {
   float* loss_partials;
   float bw, binv;              // 1 / num_neg, 1 / mean_den
   int64_t mean_den;
+  // SampledSoftmax on the owners, phase 1 (owner_ssm_walk_kernel): z = dot - logq per slot into d_out, and per query over this
+  // owner's slots the running maximum, sum of exp(z - max) and sum of exp(z - max) * row
+  const float* logq_rows;      // nullable [n_rows]: the sampler's log-probability of each LOCAL row's item
+  float* run_max;              // [n_queries]
+  float* run_sum;              // [n_queries]
+  float* run_acc;              // [n_queries, D]
 };
 
 // keys != nullptr: step_dropped / overflow_sticky are first PUBLISHED from the received segments' header word 1 (what each
@@ -266,6 +272,188 @@ __global__ __launch_bounds__(256, RSA_OWN_MIN_WAVES) void owner_backward_walk_ke
   }
 }
 
+// ---- SampledSoftmaxLoss evaluated on the owners (loss_func.py:80-90 across shards) ------------------------------------------
+// loss_q = logsumexp(z_pos, z_1 .. z_n) - z_pos with z = score - log q spans ALL owners of a query's negatives, so the step
+// takes two phases.  Phase 1 (this walk): every owner reads the rows of the negatives it received ONCE and leaves, per query,
+// the flash-attention style partials over ITS slots -- m = max z, s = sum exp(z - m), acc = sum exp(z - m) * row -- plus z
+// per slot.  After an 8-byte-per-query all-reduce (max, then the rescaled sums) every rank knows logsumexp_q, and phase 2
+// needs no row for the QUERY gradient any more: qgrad += exp(m - lse) / M * acc.  The item rows get their update
+// d_j * q, d_j = exp(z_j - lse) / M, through the sorted apply pass (one read-modify-write per touched row).
+// 64 elements of one query: lane r holds element r's row and log q (+inf for an idle lane: z = -inf, weight 0).
+template <int LPR, bool NT>
+__device__ __forceinline__ void tile_rows_ssm(const float* table, int32_t id_lane, float lq_lane, const Frag<LPR, false>& qf,
+                                              float4& acc, float& mg, float& sg, float& z_out) {
+  using F = Frag<LPR, false>;
+  constexpr int D = LPR * 4;
+  constexpr int BATCH = LPR < RSA_OWN_BATCH ? LPR : RSA_OWN_BATCH;
+  constexpr int NB = LPR / BATCH;
+  const int lane = lane_id();
+  const int sub = lane % LPR;
+  F x[2][BATCH];
+  int gb = lane - sub;
+  auto request = [&](int b) __attribute__((always_inline)) {
+#pragma unroll
+    for (int k = 0; k < BATCH; ++k) {
+      const int32_t rid = __shfl(id_lane, gb + b * BATCH + k, 64);
+      frag_load<LPR, false, NT>(x[b & 1][k], table + (size_t)rid * D, sub, D);
+    }
+  };
+  request(0);
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    if (b + 1 < NB) request(b + 1);
+#pragma unroll
+    for (int k = 0; k < BATCH; ++k) {
+      const int r = gb + b * BATCH + k;
+      const float lq = __shfl(lq_lane, r, 64);
+      const float dk = group_sum<LPR>(frag_dot<LPR, false>(x[b & 1][k], qf));
+      const float z = dk - lq;                       // idle lane: -inf
+      z_out = sub == b * BATCH + k ? z : z_out;
+      const float mn = fmaxf(mg, z);
+      const float ms = mn == -INFINITY ? 0.f : mn;   // nothing seen yet: exp(-inf - 0) = 0 everywhere
+      const float so = __expf(mg - ms), e = __expf(z - ms);
+      const float4 xv = x[b & 1][k].v[0];
+      acc.x = __fmaf_rn(e, xv.x, acc.x * so);
+      acc.y = __fmaf_rn(e, xv.y, acc.y * so);
+      acc.z = __fmaf_rn(e, xv.z, acc.z * so);
+      acc.w = __fmaf_rn(e, xv.w, acc.w * so);
+      sg = __fmaf_rn(sg, so, e);
+      mg = mn;
+    }
+    asm volatile("" : "+v"(gb), "+v"(acc.x), "+v"(acc.y), "+v"(acc.z), "+v"(acc.w), "+v"(sg), "+v"(mg));
+  }
+}
+
+// (m, s, acc) <- the merge of two partials; symmetric in its operands bit for bit (both sides of a shuffle get the same value)
+__device__ __forceinline__ void ssm_merge(float& m, float& s, float4& a, float mo, float so, const float4& ao) {
+  const float mn = fmaxf(m, mo);
+  const float ms = mn == -INFINITY ? 0.f : mn;
+  const float ea = __expf(m - ms), eb = __expf(mo - ms);
+  a.x = __fmaf_rn(a.x, ea, ao.x * eb); a.y = __fmaf_rn(a.y, ea, ao.y * eb);
+  a.z = __fmaf_rn(a.z, ea, ao.z * eb); a.w = __fmaf_rn(a.w, ea, ao.w * eb);
+  s = __fmaf_rn(s, ea, so * eb);
+  m = mn;
+}
+
+template <int LPR, bool NT>
+__global__ __launch_bounds__(256, RSA_OWN_MIN_WAVES) void owner_ssm_walk_kernel(const OwnArgs a, const int wpq_log2) {
+  using F = Frag<LPR, false>;
+  constexpr int D = LPR * 4;
+  __shared__ float s_q[4][D];
+  __shared__ float s_ms[4][2];
+  const int lane = lane_id();
+  const int sub = lane % LPR;
+  const int wave = threadIdx.x >> 6;
+  const int wpq = 1 << wpq_log2, qpb = 4 >> wpq_log2;
+  const int qslot = wave >> wpq_log2, part = wave & (wpq - 1);
+  const int64_t groups = ((int64_t)a.n_queries + qpb - 1) / qpb;
+  for (int64_t grp = blockIdx.x; grp < groups; grp += gridDim.x) {
+    const int64_t m = grp * qpb + qslot;
+    const bool valid = m < a.n_queries;                      // wave-uniform
+    int32_t rs = 0, re = 0;
+    if (valid) {
+      rs = a.run_start[m];
+      re = a.run_end[m];
+    }
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    float mg = -INFINITY, sg = 0.f;
+    if (re > rs) {
+      F qf;
+      frag_load<LPR, false>(qf, a.q_all + (size_t)m * D, sub, D);
+      const int T = (re - rs + 63) >> 6;
+#pragma unroll 1
+      for (int t = part; t < T; t += wpq) {
+        const int32_t i = rs + (t << 6) + lane;
+        const bool act = i < re;
+        int32_t id = 0;
+        float lq = INFINITY;
+        uint32_t slot = 0;
+        if (act) {
+          slot = a.qpairs ? rdx_val(a.qpairs[i]) : (uint32_t)i;
+          int64_t row = a.keys[slot] & 0xffffffffll;
+          row = row >= a.n_rows ? a.n_rows - 1 : row;        // never fault on a bad key
+          id = (int32_t)row;
+          lq = a.logq_rows ? a.logq_rows[row] : 0.f;
+        }
+        float z = -INFINITY;
+        tile_rows_ssm<LPR, NT>(a.item, id, lq, qf, acc, mg, sg, z);
+        if (act) st_out(&a.d_out[slot], z);
+      }
+      // the lane groups' partials (each group walked its own rows of every tile): xor-butterfly over the group bits.  The
+      // float4 of a lane is its 4 columns of the row: lanes with the same `sub` hold the same columns
+#pragma unroll
+      for (int mk = LPR; mk < 64; mk <<= 1) {
+        const float mo = __shfl_xor(mg, mk, 64), so = __shfl_xor(sg, mk, 64);
+        const float4 ao = make_float4(__shfl_xor(acc.x, mk, 64), __shfl_xor(acc.y, mk, 64), __shfl_xor(acc.z, mk, 64),
+                                      __shfl_xor(acc.w, mk, 64));
+        ssm_merge(mg, sg, acc, mo, so, ao);
+      }
+    }
+    if (wpq > 1) {         // block-uniform: the partials of a query's waves meet in LDS, merged in wave order
+      if (part != 0 && lane < LPR) *reinterpret_cast<float4*>(&s_q[wave][sub * 4]) = acc;
+      if (part != 0 && lane == 0) {
+        s_ms[wave][0] = mg;
+        s_ms[wave][1] = sg;
+      }
+      __syncthreads();
+      if (part == 0) {
+        for (int k = 1; k < wpq; ++k) {
+          const float4 ao = *reinterpret_cast<const float4*>(&s_q[wave + k][(lane % LPR) * 4]);
+          ssm_merge(mg, sg, acc, s_ms[wave + k][0], s_ms[wave + k][1], ao);
+        }
+      }
+      __syncthreads();     // the slots are rewritten in the next iteration
+    }
+    if (valid && part == 0) {
+      if (lane == 0) {
+        a.run_max[m] = mg;               // (-inf, 0, 0 for a query without slots here)
+        a.run_sum[m] = sg;
+      }
+      if (lane < LPR) *reinterpret_cast<float4*>(a.run_acc + (size_t)m * D + sub * 4) = acc;
+    }
+  }
+}
+
+// phase 2, per slot: z -> d loss/d score = exp(z - lse_query) / M for live slots, 0 for the slack (the apply pass reads d of
+// every sorted element, and dead slots sort behind every real row)
+__global__ __launch_bounds__(256) void owner_ssm_d_kernel(const int64_t* __restrict__ keys, int64_t slots, RdxDiv32 by_stride,
+                                                          int32_t n_queries, const float* __restrict__ lse, float binv,
+                                                          float* __restrict__ d_slots) {
+  const int64_t step = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < slots; i += step) {
+    const uint32_t seg = by_stride.div((uint32_t)i), within = (uint32_t)i - seg * by_stride.d;
+    float d = 0.f;
+    if (within >= RSA_SHARD_HDR && (int64_t)(within - RSA_SHARD_HDR) < keys[(size_t)seg * by_stride.d]) {
+      const uint32_t k = (uint32_t)((keys[i] >> 32) & 0x7fffffffll);
+      if (k < (uint32_t)n_queries) d = __expf(d_slots[i] - lse[k]) * binv;
+    }
+    d_slots[i] = d;
+  }
+}
+
+// phase 2, per query: qgrad_all[q] += gate * exp(run_max - lse) / M * run_acc[q];  dsum[q] = (1 - exp(z_pos - lse)) / M, the
+// value owner_pos_finish_kernel negates into d loss/d pos = (softmax_pos - 1) / M
+template <int LPR>
+__global__ __launch_bounds__(256) void owner_ssm_query_kernel(const float* __restrict__ run_max, const float* __restrict__ run_acc,
+                                                              const float* __restrict__ lse, const float* __restrict__ z_pos,
+                                                              float binv, const float* __restrict__ scale,
+                                                              float* __restrict__ qgrad_all, float* __restrict__ dsum, int32_t n_queries) {
+  constexpr int D = LPR * 4, GPB = 256 / LPR;
+  const int sub = threadIdx.x % LPR;
+  const float gate = scale[1];
+  for (int64_t i = (int64_t)blockIdx.x * GPB + threadIdx.x / LPR; i < n_queries; i += (int64_t)gridDim.x * GPB) {
+    const float l = lse[i], mx = run_max[i];
+    if (sub == 0) dsum[i] = (1.f - __expf(z_pos[i] - l)) * binv;
+    if (mx == -INFINITY) continue;
+    const float c = gate * binv * __expf(mx - l);
+    const float4 av = *reinterpret_cast<const float4*>(run_acc + (size_t)i * D + sub * 4);
+    float4* gp = reinterpret_cast<float4*>(qgrad_all + (size_t)i * D + sub * 4);
+    float4 o = *gp;
+    o.x = __fmaf_rn(c, av.x, o.x); o.y = __fmaf_rn(c, av.y, o.y); o.z = __fmaf_rn(c, av.z, o.z); o.w = __fmaf_rn(c, av.w, o.w);
+    *gp = o;
+  }
+}
+
 // One lane group per query i: the POSITIVE's part of the step on the rank that owns its row (pos_rows[i] >= 0):
 // d loss/d pos = -(sum over all owners of the query's d) -> the coefficient slot behind the segments' (for the sorted
 // apply), qgrad_all[i] += gate * dpos * row, and -- when the row is the positive's alone -- the row's update in place.
@@ -411,6 +599,7 @@ struct OwnCommon {
   void* workspace;
   int64_t workspace_bytes;
   int keys_grouped;             // the router wrote query-grouped segments: no sort by query
+  int no_solo = 0;              // never classify (nothing updates rows in a walk: the SampledSoftmax step): every element is applied
 };
 
 struct OwnPrepared {
@@ -465,7 +654,7 @@ static int owner_prepare(const OwnCommon& c, OwnPrepared& P, OwnPrep mode, hipSt
     rsa::set_error("%s: row sort failed: %s", who, hipGetErrorString(hipGetLastError()));
     return RSA_ERR_HIP;
   }
-  if (P.inplace) {
+  if (P.inplace && !c.no_solo) {
     const int rc = classify_solo(P.row_sorted, P.row_total, c.item_pad_row, c.n_rows, P.W.solo, s, who);
     if (rc != RSA_OK) return rc;
   }
@@ -653,6 +842,97 @@ extern "C" int rsa_shard_owner_bpr_finish(const rsa_shard_owner_bpr_args* a, con
 #undef RSA_FIN_LAUNCH
   RSA_CHECK_LAUNCH("rsa_shard_owner_bpr_finish(positives)");
   if (a->finish_parts == 1) return RSA_OK;
+  return apply_sorted_segments(P.row_sorted, P.row_total, P.slots, a->q_all, a->dim, a->keys, a->d_slots, a->scale_out, a->n_rows,
+                               a->item_pad_row, a->item_target, P.L, s);
+}
+
+// ---- SampledSoftmaxLoss on the owners (two phases around an 8-byte-per-query all-reduce; see owner_ssm_walk_kernel)
+extern "C" int rsa_shard_owner_ssm_forward(const rsa_shard_owner_bpr_args* a, rsa_stream_t stream) {
+  RSA_CHECK_ARG(a != nullptr, "rsa_shard_owner_ssm_forward: args is null");
+  RSA_CHECK_ARG(a->pos_rows && a->mean_den >= 1 && a->d_slots && a->run_max && a->run_sum && a->run_acc && a->q_all,
+                "rsa_shard_owner_ssm_forward: null pointer / bad sizes");
+  hipStream_t s = (hipStream_t)stream;
+  OwnCommon c = bpr_common(a);
+  c.no_solo = 1;
+  OwnPrepared P;
+  int rc = owner_prepare(c, P, OWN_PREP_ALL, s, "rsa_shard_owner_ssm_forward");
+  if (rc != RSA_OK) return rc;
+  const int64_t Q = a->n_query_rows;
+  OwnArgs o = walk_args(c, P, nullptr);
+  o.solo = nullptr;
+  o.item_rw = nullptr;
+  o.d_out = a->d_slots;
+  o.logq_rows = a->logq_rows;
+  o.run_max = a->run_max;
+  o.run_sum = a->run_sum;
+  o.run_acc = a->run_acc;
+  // (the walk writes the three per-query outputs of EVERY query, with or without slots -- also when there is no slot at all:
+  // its runs are then all empty)
+  if (P.slots == 0) {
+    if (hipMemsetAsync(P.W.run_start, 0, (size_t)(2 * align256o(Q * 4)), s) != hipSuccess) {
+      rsa::set_error("rsa_shard_owner_ssm_forward: memset failed");
+      return RSA_ERR_HIP;
+    }
+  }
+  const bool nt = (size_t)a->n_rows * a->dim * 4 > (512ull << 20);
+  const int64_t tiles_per_query = P.slots / (Q > 0 ? Q : 1) / 64;
+  const int wpq_log2 = tiles_per_query >= 8 ? 2 : (tiles_per_query >= 3 ? 1 : 0);
+  const int qpb = 4 >> wpq_log2;
+  int64_t blocks = (Q + qpb - 1) / qpb;
+  if (blocks > 4096) blocks = 4096;
+#define RSA_SSM_WALK(LPR)                                                                                                \
+  if (nt) hipLaunchKernelGGL((owner_ssm_walk_kernel<LPR, true>), dim3((unsigned)blocks), dim3(256), 0, s, o, wpq_log2);   \
+  else hipLaunchKernelGGL((owner_ssm_walk_kernel<LPR, false>), dim3((unsigned)blocks), dim3(256), 0, s, o, wpq_log2)
+  switch (a->dim) {
+    case 64: RSA_SSM_WALK(16); break;
+    case 128: RSA_SSM_WALK(32); break;
+    default: RSA_SSM_WALK(64); break;
+  }
+#undef RSA_SSM_WALK
+  RSA_CHECK_LAUNCH("rsa_shard_owner_ssm_forward(walk)");
+  return RSA_OK;
+}
+
+extern "C" int rsa_shard_owner_ssm_finish(const rsa_shard_owner_bpr_args* a, const float* lse_all, rsa_stream_t stream) {
+  RSA_CHECK_ARG(a != nullptr && lse_all != nullptr, "rsa_shard_owner_ssm_finish: null pointer");
+  RSA_CHECK_ARG(a->pos_score && a->qgrad_all && a->dsum_part && a->run_max && a->run_acc && a->d_slots,
+                "rsa_shard_owner_ssm_finish: null pointer (pos_score = z_pos, qgrad_all, dsum_part, run_max, run_acc, d_slots)");
+  hipStream_t s = (hipStream_t)stream;
+  OwnCommon c = bpr_common(a);
+  c.no_solo = 1;
+  OwnPrepared P;
+  int rc = owner_prepare(c, P, OWN_PREP_LAYOUT, s, "rsa_shard_owner_ssm_finish");
+  if (rc != RSA_OK) return rc;
+  const int64_t Q = a->n_query_rows;
+  const float binv = 1.f / (float)a->mean_den;
+  if (P.slots > 0) {
+    int64_t blocks = (P.slots + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(owner_ssm_d_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a->keys, P.slots, rdx_make_div32((uint64_t)a->stride),
+                       (int32_t)Q, lse_all, binv, a->d_slots);
+  }
+  // nothing is flagged solo in this step: the positives' owners only add their query-gradient term and leave d loss/d pos
+  // behind the slots' coefficients for the apply pass
+  if (hipMemsetAsync(P.W.solo + P.slots, 0, (size_t)Q, s) != hipSuccess) {
+    rsa::set_error("rsa_shard_owner_ssm_finish: memset failed");
+    return RSA_ERR_HIP;
+  }
+  int64_t blocks;
+#define RSA_SSM_FIN(LPR)                                                                                                  \
+  blocks = (Q + 256 / LPR - 1) / (256 / LPR);                                                                             \
+  if (blocks > 4096) blocks = 4096;                                                                                       \
+  hipLaunchKernelGGL(owner_ssm_query_kernel<LPR>, dim3((unsigned)blocks), dim3(256), 0, s, a->run_max, a->run_acc, lse_all, \
+                     a->pos_score, binv, a->scale_out, a->qgrad_all, a->dsum_part, (int32_t)Q);                           \
+  hipLaunchKernelGGL(owner_pos_finish_kernel<LPR>, dim3((unsigned)blocks), dim3(256), 0, s, a->item_local, (float*)nullptr, \
+                     a->q_all, a->qgrad_all, a->pos_rows, a->dsum_part, a->d_slots + P.slots, P.W.solo + P.slots,          \
+                     a->scale_out, a->n_rows, (int32_t)Q)
+  switch (a->dim) {
+    case 64: RSA_SSM_FIN(16); break;
+    case 128: RSA_SSM_FIN(32); break;
+    default: RSA_SSM_FIN(64); break;
+  }
+#undef RSA_SSM_FIN
+  RSA_CHECK_LAUNCH("rsa_shard_owner_ssm_finish");
   return apply_sorted_segments(P.row_sorted, P.row_total, P.slots, a->q_all, a->dim, a->keys, a->d_slots, a->scale_out, a->n_rows,
                                a->item_pad_row, a->item_target, P.L, s);
 }

@@ -399,6 +399,36 @@ class HipBackend:
         nat.check(nat.lib().rsa_shard_owner_bpr_finish(ctypes.byref(ctx['args']), ptr(ops._need(dsum_all, torch.float32, 'dsum_all')),
                                                        ops._stream()), 'rsa_shard_owner_bpr_finish')
 
+    @ops._on_device
+    def owner_ssm_forward(self, state, item_local, q_all, recv_keys, n_seg, stride, pos_rows, n, mean_den, item_target, item_scale,
+                          logq_rows=None, item_pad_row=-1, keys_grouped=False):
+        """Phase 1 of SampledSoftmax on the owners (rsa_shard_owner_ssm_forward): one walk over the received negatives' rows
+        -> ctx with ``run_max [Q]``, ``run_sum [Q]`` (and, kept for phase 2, ``run_acc [Q, d]`` and z per slot)."""
+        Q, dev = q_all.shape[0], item_local.device
+        ctx = self._owner_ctx(state, item_local, Q, recv_keys, n_seg, stride, pos_rows, n, mean_den, item_target, item_scale,
+                              item_pad_row, keys_grouped)
+        a = ctx['args']
+        ctx['run_max'] = torch.empty(Q, dtype=torch.float32, device=dev)
+        ctx['run_sum'] = torch.empty(Q, dtype=torch.float32, device=dev)
+        ctx['run_acc'] = torch.empty(Q, item_local.shape[1], dtype=torch.float32, device=dev)
+        ctx['tensors'] += [q_all, logq_rows]
+        a.q_all = ptr(ops._need(q_all, torch.float32, 'q_all'))
+        a.logq_rows = ptr(ops._need_opt(logq_rows, torch.float32, 'logq_rows'))
+        a.run_max, a.run_sum, a.run_acc = ptr(ctx['run_max']), ptr(ctx['run_sum']), ptr(ctx['run_acc'])
+        nat.check(nat.lib().rsa_shard_owner_ssm_forward(ctypes.byref(a), ops._stream()), 'rsa_shard_owner_ssm_forward')
+        return ctx
+
+    @ops._on_device
+    def owner_ssm_finish(self, ctx, lse_all, z_pos_all, qgrad_all):
+        """Phase 2 (rsa_shard_owner_ssm_finish): d per slot, the query-gradient partials from the phase-1 accumulators, the
+        positives' terms, the sorted apply pass over every touched row."""
+        a = ctx['args']
+        ctx['pos_score'] = ops._need(z_pos_all, torch.float32, 'z_pos_all')
+        ctx['tensors'] += [qgrad_all, lse_all]
+        a.pos_score, a.qgrad_all = ptr(ctx['pos_score']), ptr(ops._need(qgrad_all, torch.float32, 'qgrad_all'))
+        nat.check(nat.lib().rsa_shard_owner_ssm_finish(ctypes.byref(a), ptr(ops._need(lse_all, torch.float32, 'lse_all')),
+                                                       ops._stream()), 'rsa_shard_owner_ssm_finish')
+
     # -- exact (variable-split) exchange ------------------------------------------------------------------------------
     def gather_rows(self, table, ids):
         if ids.numel() == 0:
@@ -834,6 +864,75 @@ class ShardedItemTable:
         if not self._solo:
             self.dist.all_reduce(t, group=self.group)
         return t
+
+    def _all_reduce_max(self, t):
+        if not self._solo:
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.group)
+        return t
+
+    def _logq_rows(self, sampler):
+        """log-probability under ``sampler`` of the item of every LOCAL row ([rows_local] fp32; None for samplers whose
+        log-probabilities are zero): the owner-side SampledSoftmax reads it per received negative."""
+        prob = getattr(sampler, 'pop_prob', None)
+        if prob is None:
+            return None
+        hit = getattr(self, '_logq_cache', None)
+        if hit is not None and hit[0] is prob and hit[1] == prob._version:
+            return hit[2]
+        dev = self.item_local.device
+        gid = self.plan.global_ids(self.rank, torch.arange(self.item_local.shape[0], device=dev))
+        logq = torch.log(prob.to(dev)[gid.clamp(max=prob.numel() - 1)]).to(torch.float32).contiguous()
+        self._logq_cache = (prob, prob._version, logq)
+        return logq
+
+    def ssm_owner_ok(self):
+        """Can the stock SampledSoftmax step run in its owner-side form (``ssm_step_on_owners``)?"""
+        return self.owner_loss_ok() and hasattr(self.backend, 'owner_ssm_forward')
+
+    def ssm_step_on_owners(self, q, pos, n, sampler, item_grad_local, item_scale=None, want_ids=False):
+        """The stock SampledSoftmax training step (loss_func.py:80-90, one positive per row) with the loss evaluated ON THE
+        OWNERS of the negatives (include/recstudio_amd.h, rsa_shard_owner_ssm_forward / _finish).  The logsumexp of a query
+        spans every owner of its negatives, so the owner pass has two phases around an 8-byte-per-query all-reduce:
+
+          1. as ``bpr_step_on_owners``: queries and positive ids all-gathered, negatives drawn and routed (positives are not),
+             the positives scored by their owners (4-byte-per-query all-reduce);
+          2. phase 1 on every owner -- ONE walk over the rows of the negatives it received: z = score - log q per slot and,
+             per query, (max z, sum exp(z - max), sum exp(z - max) * row);
+          3. all-reduce of the maxima, then of the rescaled sums: every rank holds every query's logsumexp;
+          4. phase 2: d loss/d score per slot, the query-gradient partials straight from the phase-1 accumulators (no second
+             pass over the rows for them), the positives' terms, the sorted apply pass over every touched item row;
+             reduce-scatter of the query gradients.
+
+        No scores travel home and no score gradients travel back (8 instead of 16 bytes per triplet over xGMI), and the home
+        kernel is gone.  -> (this rank's share of the global mean loss, d loss/d q [B, d], negative ids or None)."""
+        be, st, plan = self.backend, self.state, self.plan
+        B, G = pos.numel(), plan.world
+        q_gather = self._all_gather_rows_start(q)
+        pos_all, r, recv, neg_out = self._bpr_route(pos, n, sampler, want_ids)
+        GS, stride = G * int(getattr(be, 'BANKS', 1)), r['stride']
+        q_all = q_gather()
+        if hasattr(be, 'pos_rows_and_scores'):
+            pos_rows, pos_part = be.pos_rows_and_scores(self.item_local, q_all, pos_all, plan, self.rank)
+        else:
+            pos_rows = self._own_pos_rows(pos_all)
+            pos_part = be.pos_scores(self.item_local, q_all, pos_rows)
+        z_pos = self._all_reduce_sum(pos_part)
+        prob = getattr(sampler, 'pop_prob', None)                         # (samplers without it: log-probabilities 0)
+        if prob is not None:
+            z_pos = z_pos - torch.log(prob.to(z_pos.device)[pos_all]).to(z_pos.dtype)     # loss_func.py:81, compute_item_p
+        ctx = be.owner_ssm_forward(st, self.item_local, q_all, recv, GS, stride, pos_rows, n, B * G, item_grad_local, item_scale,
+                                   logq_rows=self._logq_rows(sampler), item_pad_row=0 if self.rank == 0 else -1,
+                                   keys_grouped=bool(r.get('grouped', False)))
+        run_max = ctx['run_max']
+        m = torch.maximum(self._all_reduce_max(run_max.clone()), z_pos)
+        s = self._all_reduce_sum(ctx['run_sum'] * torch.exp(run_max - m))   # (run_max = -inf, run_sum = 0: no slot on this owner)
+        lse = m + torch.log(s + torch.exp(z_pos - m))
+        qgrad_all = torch.zeros_like(q_all)
+        be.owner_ssm_finish(ctx, lse, z_pos, qgrad_all)
+        dq = self._reduce_scatter_rows(qgrad_all, B)
+        self._after_fixed_step()
+        loss = (lse - z_pos)[self.rank * B:(self.rank + 1) * B].sum() / float(B * G)
+        return loss, dq, neg_out
 
     def owner_loss_ok(self):
         """Can the stock BPR step run in its owner-side form (``bpr_step_on_owners``)?"""
@@ -1297,7 +1396,7 @@ class ShardedRetriever:
     concatenated batch.  ``sparse_query_rows`` (see ``__init__``) replaces that for a plain ``nn.Embedding`` tower."""
 
     def __init__(self, table, query_encoder, sampler, loss_fn, neg_count, item_sgd_lr=None, sparse_query_rows=None,
-                 query_sgd_lr=None, keep_neg_ids=False, overlap_query_rows=True):
+                 query_sgd_lr=None, keep_neg_ids=False, overlap_query_rows=True, owner_ssm=True):
         """``item_sgd_lr``: apply plain SGD with this learning rate to the owned item rows INSIDE the backward
         exchange (sorted scatter straight into the weight block, no [rows_local, d] gradient buffer to zero, fill
         and add); the caller then only steps the query tower.
@@ -1317,6 +1416,7 @@ class ShardedRetriever:
         update -- a dozen launches of microseconds each -- run on a second stream beside the sorted apply pass of the
         shared item rows instead of behind it (neither reads what the other writes; same results)."""
         self.table, self.query_encoder, self.sampler, self.loss_fn = table, query_encoder, sampler, loss_fn
+        self.owner_ssm = bool(owner_ssm)      # stock SampledSoftmaxLoss evaluated on the owners (False: scores home, home kernel)
         self.overlap_query_rows, self._side = bool(overlap_query_rows), None
         self.neg_count = int(neg_count)
         if sparse_query_rows is None:
@@ -1430,6 +1530,12 @@ class ShardedRetriever:
             loss, dq, self.last_neg = table.bpr_step_on_owners(q.detach(), pos_items, self.neg_count, self.sampler,
                                                                self.item_grad_local, self.item_scale, want_ids=self.keep_neg_ids,
                                                                ticket=ticket)
+            if not self.sparse_query_rows and q.requires_grad:
+                q.backward(dq)
+        elif kind == 'ssm' and table.ssm_owner_ok() and self.owner_ssm:
+            # SampledSoftmax on the owners: two phases around an 8-byte-per-query all-reduce (ssm_step_on_owners)
+            loss, dq, self.last_neg = table.ssm_step_on_owners(q.detach(), pos_items, self.neg_count, self.sampler,
+                                                               self.item_grad_local, self.item_scale, want_ids=self.keep_neg_ids)
             if not self.sparse_query_rows and q.requires_grad:
                 q.backward(dq)
         elif kind is not None:

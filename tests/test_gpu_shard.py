@@ -321,6 +321,26 @@ def _two_rank_worker(rank, world, port, backend, result_dir, layout='block'):
                                    rtol=1e-5, atol=1e-7)
         reps = gather_cpu(tower2.weight.detach())
         assert torch.equal(reps[0], reps[1])
+        # SampledSoftmax on the owners (two phases around the (max, sum) all-reduce) == the score-at-home protocol of the same
+        # step at world size 2: same draws, same loss, same item rows and query rows after one in-place SGD step
+        outs = []
+        for own in (True, False):
+            tower_s = torch.nn.Embedding(U, d).to(dev)
+            with torch.no_grad():
+                tower_s.weight.copy_(user)
+            tbl_s = ShardedItemTable(plan.take(item_d, rank).contiguous().clone(), plan, rank, comm, sample_seed=31)
+            tr_s = ShardedRetriever(tbl_s, tower_s, ra.PopularSamplerModel((torch.arange(N) % 11 + 1)).to(dev), ra.SampledSoftmaxLoss(),
+                                    64, item_sgd_lr=0.5, query_sgd_lr=0.25, keep_neg_ids=True, owner_ssm=own)
+            assert tbl_s.ssm_owner_ok()
+            ls = tr_s.training_step(uid, pos)
+            tbl_s.check_overflow()
+            outs.append((float(sum_cpu(ls.detach().reshape(1))), tr_s.last_neg.clone(), tbl_s.item_local.clone(),
+                         tower_s.weight.detach().clone()))
+        assert torch.equal(outs[0][1], outs[1][1])
+        np.testing.assert_allclose(outs[0][0], outs[1][0], rtol=1e-5)
+        np.testing.assert_allclose(outs[0][2].cpu(), outs[1][2].cpu(), rtol=1e-4, atol=1e-7)
+        np.testing.assert_allclose(outs[0][3].cpu(), outs[1][3].cpu(), rtol=1e-4, atol=1e-7)
+        assert (outs[0][2] - plan.take(item_d, rank)).abs().max() > 1e-5
         # three steps one batch ahead (prepare_step on the second stream / ticket) == the same three steps in place
         runs = []
         batches = [(uid.roll(k), pos.roll(2 * k)) for k in range(3)]
@@ -545,6 +565,66 @@ def test_world1_rccl_sharded_training_step():
         plug.training_step(uid, pos)
         np.testing.assert_allclose(tower.weight.grad.cpu(), g_fused.cpu(), rtol=2e-4, atol=1e-8)
         np.testing.assert_allclose(plug.item_grad_local.cpu(), dense.item_grad_local.cpu(), rtol=2e-4, atol=1e-8)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('kind,n', [('uniform', 64), ('popular', 64), ('popular', 256), ('uniform', 16)])
+def test_world1_rccl_sampled_softmax_on_owners(kind, n):
+    """Stock SampledSoftmaxLoss through ShardedRetriever with the loss evaluated ON THE OWNERS (rsa_shard_owner_ssm_forward /
+    _finish: one walk over the received rows leaves per-query (max, sum, sum * row) partials, an 8-byte-per-query all-reduce,
+    then d per slot + the sorted apply pass) == torch autograd of loss_func.py:80-90 with the same negatives: loss, the dense
+    item gradient block, the row-sparse query gradient; the in-place SGD form == the gradient form; == the score-at-home
+    protocol (home kernel) of the same step."""
+    import torch.distributed as dist
+    import recstudio_amd as ra
+    from recstudio_amd.shard import RowShardPlan, ShardedItemTable, ShardedRetriever
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(_free_port())
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+    try:
+        torch.manual_seed(4)
+        N, U, d, B = 20_011, 300, 128, 300
+        item = torch.randn(N, d, device=DEV) * 0.2
+        item[0] = 0
+        tower = torch.nn.Embedding(U, d).to(DEV)
+        uid = torch.randint(1, U, (B,), device=DEV)
+        pos = torch.randint(1, N, (B,), device=DEV)
+        if kind == 'uniform':
+            smp = ra.UniformSampler(N)
+        else:
+            smp = ra.PopularSamplerModel((torch.rand(N) ** 4 * 300).long() + 1).to(DEV)
+
+        def run(**kw):
+            table = ShardedItemTable(item.clone(), RowShardPlan(N, 1), 0, dist, force_collectives=True, sample_seed=9)
+            tr = ShardedRetriever(table, tower, smp, ra.SampledSoftmaxLoss(), n, sparse_query_rows=True, keep_neg_ids=True, **kw)
+            return tr, tr.training_step(uid, pos)
+        trainer, loss = run()
+        assert trainer.table.ssm_owner_ok()
+        neg = trainer.last_neg
+        item_ref = item.clone().requires_grad_(True)
+        w_ref = tower.weight.detach().clone().requires_grad_(True)
+        q = w_ref[uid]
+        zp = (q * item_ref[pos]).sum(-1)
+        zn = (q.unsqueeze(1) * item_ref[neg]).sum(-1)
+        if kind == 'popular':
+            zp = zp - torch.log(smp.pop_prob[pos])
+            zn = zn - torch.log(smp.pop_prob[neg])
+        ref = (torch.logsumexp(torch.cat([zp.view(-1, 1), zn], 1), -1) - zp).mean()
+        ref.backward()
+        np.testing.assert_allclose(loss.item(), ref.item(), rtol=1e-5)
+        want = item_ref.grad.clone()
+        want[0] = 0
+        np.testing.assert_allclose(trainer.item_grad_local.cpu(), want.cpu(), rtol=3e-4, atol=1e-7)
+        np.testing.assert_allclose(trainer.query_grad_dense().cpu(), w_ref.grad.cpu(), rtol=3e-4, atol=1e-7)
+        # the score-at-home protocol of the same step: the same draws (same job-wide stream), the same numbers
+        home, loss_h = run(owner_ssm=False)
+        assert torch.equal(home.last_neg, neg)
+        np.testing.assert_allclose(loss_h.item(), loss.item(), rtol=1e-5)
+        np.testing.assert_allclose(home.item_grad_local.cpu(), trainer.item_grad_local.cpu(), rtol=3e-4, atol=1e-7)
+        # plain SGD in place inside the owners' pass == the gradient block applied by hand
+        sgd, _ = run(item_sgd_lr=0.3)
+        np.testing.assert_allclose(sgd.table.item_local.cpu(), (item - 0.3 * trainer.item_grad_local).cpu(), rtol=1e-5, atol=1e-7)
     finally:
         dist.destroy_process_group()
 

