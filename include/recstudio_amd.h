@@ -670,9 +670,19 @@ typedef struct rsa_shard_route_args {
   int32_t group_by_query;      /* != 0 (needs skip_pos, an in-kernel sampler and rsa_shard_route_query_groups(...) > 0): a workgroup's
                                   share of a segment is written query by query -- every query's elements for an owner form ONE
                                   contiguous run of the segment (rsa_shard_owner_bpr_args.keys_grouped: no sort by query there) */
+  /* DETERMINISTIC slots (ABI 9): with deterministic != 0 no atomic decides where an element's key lands -- a count pass, an
+   * exclusive prefix over the workgroups in launch order and the routing pass (three launches instead of one: +20-45 us at
+   * 4.2 M elements): the send buffer, and with it every sum the owners form in slot order, is then bit-identical run to run.
+   * wg_scratch: caller-owned, 2 * rsa_shard_route_workgroups(args) * n_shards ints (contents irrelevant). */
+  int32_t deterministic;
+  int32_t _pad1;
+  int32_t* wg_scratch;
+  int64_t wg_scratch_ints;
 } rsa_shard_route_args;
 int64_t rsa_shard_segment_stride(int64_t capacity);    /* RSA_SHARD_HDR + capacity: 8-byte words per segment */
 int rsa_shard_sample_route(const rsa_shard_route_args* args, rsa_stream_t stream);
+/* workgroups the call above launches for these arguments (host arithmetic only) */
+int64_t rsa_shard_route_workgroups(const rsa_shard_route_args* args);
 /* Queries per workgroup if a call with these parameters can route query-grouped (num_neg a divisor of 1024 and >= 64, the
  * random call's grid a multiple of 1024 threads, the rank's element base a multiple of num_neg; unroll = 4, or 2 for the
  * 64-bit draws of catalogs beyond 2^28 items), else 0. */

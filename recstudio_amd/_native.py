@@ -69,6 +69,7 @@ class ShardRouteArgs(Structure):
         ('cdf_lines', c_void_p), ('guide_log2', c_int32), ('lines_log2', c_int32),
         ('send_keys', c_void_p), ('slot_of', c_void_p), ('cursors', c_void_p), ('counts_out', c_void_p),
         ('skip_pos', c_int32), ('group_by_query', c_int32),
+        ('deterministic', c_int32), ('_pad1', c_int32), ('wg_scratch', c_void_p), ('wg_scratch_ints', c_int64),
     ]
 
 
@@ -230,6 +231,7 @@ SIGNATURES = {
                                 c_void_p, c_void_p]),
     'rsa_shard_segment_stride': (c_int64, [c_int64]),
     'rsa_shard_sample_route': (c_int, [POINTER(ShardRouteArgs), c_void_p]),
+    'rsa_shard_route_workgroups': (c_int64, [POINTER(ShardRouteArgs)]),
     'rsa_shard_route_query_groups': (c_int32, [c_int32, c_uint32, c_uint64, c_int32, c_int32]),
     'rsa_shard_score_segments': (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_void_p,
                                          c_void_p, c_void_p, c_void_p]),

@@ -286,7 +286,57 @@ struct RouteV2 {
   Div32 by_width, by_rows, by_n, by_gt, by_range;
   int32_t n, G, sampler, n_slices, unroll, n_banks, skip_pos;
   int32_t group_ql;        // > 0: a workgroup's elements are whole queries (group_ql of them): its share of a segment is written query by query
+  // DETERMINISTIC slots (rsa_shard_route_args.deterministic): no atomic decides a position.  Inside a workgroup an element's
+  // rank in its (owner, query) share is (waves before it, in wave order) + (its wave's elements before it, in program order);
+  // across workgroups the share bases are an exclusive prefix over the workgroups in launch order, from a COUNT pass
+  // (det_phase 1: wg_cnt[workgroup][owner]) and a scan (shard_route_scan_kernel -> wg_base, segment totals into the cursors).
+  int32_t det_phase;       // 0: atomic cursors; 1: count pass; 2: routing pass over wg_base
+  int32_t* wg_cnt;         // [gridDim.x, G]
+  const int32_t* wg_base;  // [gridDim.x, G]
 };
+
+// same-key lanes of a wave found by ballot; the wave's OWN counter row is read-modify-written by one lane in program order
+// (no other wave touches it): the returned value is the element's rank inside its wave's share of the key
+__device__ __forceinline__ int32_t wave_rank_det(int32_t* wcnt_wave, bool valid, int key) {
+  const int lane = threadIdx.x & 63;
+  uint64_t todo = __ballot(valid);
+  int32_t slot = 0;
+  while (todo) {
+    const int leader = __ffsll((unsigned long long)todo) - 1;
+    const int kk = __shfl(key, leader, 64);
+    const uint64_t same = __ballot(valid && key == kk);
+    int32_t old = 0;
+    if (lane == leader) {
+      old = wcnt_wave[kk];
+      wcnt_wave[kk] = old + (int32_t)__popcll(same);
+    }
+    old = __shfl(old, leader, 64);
+    if (valid && key == kk) slot = old + (int32_t)__popcll(same & ((1ull << lane) - 1ull));
+    todo &= ~same;
+  }
+  return slot;
+}
+
+// deterministic routing, between the count pass and the routing pass: for every segment (slice, owner, bank) the exclusive
+// prefix of its workgroups' counts in launch order -> wg_base, and the segment's total into its cursor (what the routing
+// pass's header writer reads, and zeroes)
+__global__ __launch_bounds__(256) void shard_route_scan_kernel(const int32_t* __restrict__ wg_cnt, int32_t* __restrict__ wg_base,
+                                                               int32_t* __restrict__ cursors, int n_blocks, int G, int n_slices,
+                                                               int n_banks) {
+  const int sg = blockIdx.x * blockDim.x + threadIdx.x;
+  const int segs = n_slices * G * n_banks;
+  if (sg >= segs) return;
+  const int bank = sg % n_banks, g = (sg / n_banks) % G, slice = sg / (n_banks * G);
+  const int want = slice * n_banks + bank;
+  int32_t run = 0;
+  for (int b = 0; b < n_blocks; ++b) {
+    const int micro = (int)(((int64_t)b * n_slices * n_banks) / n_blocks);
+    if (micro != want) continue;
+    wg_base[(size_t)b * G + g] = run;
+    run += wg_cnt[(size_t)b * G + g];
+  }
+  cursors[(size_t)sg * CURSOR_PAD] = run;
+}
 
 constexpr int TICKET_SUB = 32;      // two-level completion ticket: 32 sub-words, then one top word
 
@@ -294,11 +344,14 @@ template <bool COUNT_ONLY>
 __global__ __launch_bounds__(256) void shard_sample_route_kernel(const RouteV2 a) {
   // counters per (owner, query of this workgroup): cnt[g + G * q].  Without grouping q = 0 and cnt[g] is the owner's count.
   __shared__ int32_t cnt[ROUTE_CNT], qbase[ROUTE_CNT], base[64];
+  __shared__ int32_t wcnt[4][ROUTE_CNT];      // deterministic slots: per-wave counters
   __shared__ int s_last;
   // contiguous ranges of workgroups: n_slices slices, each cut into n_banks banks
   const int micro = (int)(((int64_t)blockIdx.x * a.n_slices * a.n_banks) / gridDim.x);
   const int slice = micro / a.n_banks, bank = micro - slice * a.n_banks;
   for (int t = threadIdx.x; t < ROUTE_CNT; t += 256) cnt[t] = 0;
+  if (a.det_phase)
+    for (int t = threadIdx.x; t < 4 * ROUTE_CNT; t += 256) (&wcnt[0][0])[t] = 0;
   constexpr int EPT = ROUTE_ITEMS * 4;
   // Query-grouped shares (the host checked: num_neg divides 1024, the grid's threads are a multiple of 1024, this rank's
   // element base a multiple of num_neg): the 1024 consecutive subsequences of a workgroup are, per Philox component, 1024
@@ -389,10 +442,30 @@ __global__ __launch_bounds__(256) void shard_sample_route_kernel(const RouteV2 a
     const bool valid = gl[k] >= 0;
     // (wave-uniform: a wave's 64 consecutive elements of one component lie inside one query)
     const int ql = a.group_ql > 0 ? (k & 3) * qpc + (((k >> 2) * 256 + (int)threadIdx.x) >> by_n_shift) : 0;
-    const int32_t ls = wave_count<true>(cnt + a.G * ql, valid, valid ? gl[k] >> 16 : 0, a.G == 1);
+    int32_t ls;
+    if (a.det_phase) ls = wave_rank_det(wcnt[threadIdx.x >> 6], valid, valid ? (gl[k] >> 16) + a.G * ql : 0);
+    else ls = wave_count<true>(cnt + a.G * ql, valid, valid ? gl[k] >> 16 : 0, a.G == 1);
     if (valid) gl[k] |= ls;
   }
   __syncthreads();
+  if (a.det_phase) {       // the waves' shares of every key in wave order; the key's count
+    for (int t = threadIdx.x; t < ROUTE_CNT; t += 256) {
+      const int32_t c0 = wcnt[0][t], c1 = wcnt[1][t], c2 = wcnt[2][t], c3 = wcnt[3][t];
+      cnt[t] = c0 + c1 + c2 + c3;
+      wcnt[0][t] = 0;
+      wcnt[1][t] = c0;
+      wcnt[2][t] = c0 + c1;
+      wcnt[3][t] = c0 + c1 + c2;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+      if (gl[k] < 0) continue;
+      const int ql = a.group_ql > 0 ? (k & 3) * qpc + (((k >> 2) * 256 + (int)threadIdx.x) >> by_n_shift) : 0;
+      gl[k] += wcnt[threadIdx.x >> 6][(gl[k] >> 16) + a.G * ql];
+    }
+    __syncthreads();
+  }
   if ((int)threadIdx.x < a.G) {
     int32_t c = 0;
     const int nq = a.group_ql > 0 ? a.group_ql : 1;
@@ -401,9 +474,17 @@ __global__ __launch_bounds__(256) void shard_sample_route_kernel(const RouteV2 a
       c += cnt[threadIdx.x + a.G * q];
     }
     cnt[threadIdx.x] = c;                   // (the header pass below reads the cursors, not this)
-    base[threadIdx.x] = c ? atomicAdd(&a.cursors[((slice * a.G + threadIdx.x) * a.n_banks + bank) * CURSOR_PAD], c) : 0;
+    if (a.det_phase == 1) {
+      a.wg_cnt[(size_t)blockIdx.x * a.G + threadIdx.x] = c;
+      base[threadIdx.x] = 0;
+    } else if (a.det_phase == 2) {
+      base[threadIdx.x] = a.wg_base[(size_t)blockIdx.x * a.G + threadIdx.x];
+    } else {
+      base[threadIdx.x] = c ? atomicAdd(&a.cursors[((slice * a.G + threadIdx.x) * a.n_banks + bank) * CURSOR_PAD], c) : 0;
+    }
   }
   __syncthreads();      // the returning cursor atomics of this workgroup have been performed
+  if (a.det_phase == 1) return;
   if (!COUNT_ONLY) {
     const int64_t seg_base = (int64_t)slice * a.G * a.n_banks;     // first segment of the slice
 #pragma unroll
@@ -995,6 +1076,9 @@ extern "C" int rsa_shard_sample_route(const rsa_shard_route_args* a, rsa_stream_
     RSA_CHECK_ARG(r.group_ql > 0, "rsa_shard_sample_route: this shape cannot be routed query-grouped "
                                   "(rsa_shard_route_query_groups says so beforehand)");
   }
+  r.det_phase = 0;
+  r.wg_cnt = nullptr;
+  r.wg_base = nullptr;
   r.n_groups = n_neg > 0 ? (int64_t)((k_hi - k_lo + 1) * T) : 0;
   RSA_CHECK_ARG(r.n_groups + a->n_queries < (1ll << 32), "rsa_shard_sample_route: too many work items");
   r.by_width = make_div32((uint64_t)a->num_neg + 1);
@@ -1006,10 +1090,59 @@ extern "C" int rsa_shard_sample_route(const rsa_shard_route_args* a, rsa_stream_
   if (blocks < (int64_t)a->n_slices * a->n_banks) blocks = (int64_t)a->n_slices * a->n_banks;     // every bank owns at least one workgroup
   RSA_CHECK_ARG(blocks < (1ll << 31), "rsa_shard_sample_route: grid too large");
   const dim3 grid((unsigned)blocks), block(256);
+  if (a->deterministic && !count_only) {
+    // count pass -> scan over the workgroups in launch order -> routing pass: no atomic decides a slot
+    RSA_CHECK_ARG(a->wg_scratch != nullptr && a->wg_scratch_ints >= 2 * blocks * a->n_shards,
+                  "rsa_shard_sample_route: deterministic routing needs wg_scratch of 2 * rsa_shard_route_workgroups() * n_shards ints");
+    RSA_CHECK_ARG(a->n_shards <= ROUTE_CNT && (r.group_ql == 0 || r.group_ql * a->n_shards <= ROUTE_CNT),
+                  "rsa_shard_sample_route: too many (owner, query) counters for one workgroup");
+    int32_t* wg_cnt = a->wg_scratch;
+    int32_t* wg_base = a->wg_scratch + blocks * a->n_shards;
+    const int segs = a->n_slices * a->n_shards * a->n_banks;
+    RouteV2 c1 = r;
+    c1.det_phase = 1;
+    c1.wg_cnt = wg_cnt;
+    c1.counts_out = nullptr;
+    hipLaunchKernelGGL(shard_sample_route_kernel<true>, grid, block, 0, (hipStream_t)stream, c1);
+    hipLaunchKernelGGL(shard_route_scan_kernel, dim3((unsigned)((segs + 255) / 256)), dim3(256), 0, (hipStream_t)stream, wg_cnt, wg_base,
+                       a->cursors, (int)blocks, (int)a->n_shards, (int)a->n_slices, (int)a->n_banks);
+    r.det_phase = 2;
+    r.wg_base = wg_base;
+    hipLaunchKernelGGL(shard_sample_route_kernel<false>, grid, block, 0, (hipStream_t)stream, r);
+    RSA_CHECK_LAUNCH("rsa_shard_sample_route(deterministic)");
+    return RSA_OK;
+  }
   if (count_only) hipLaunchKernelGGL(shard_sample_route_kernel<true>, grid, block, 0, (hipStream_t)stream, r);
   else hipLaunchKernelGGL(shard_sample_route_kernel<false>, grid, block, 0, (hipStream_t)stream, r);
   RSA_CHECK_LAUNCH("rsa_shard_sample_route");
   return RSA_OK;
+}
+
+// workgroups rsa_shard_sample_route launches for these arguments (sizes the deterministic mode's wg_scratch: 2 x this x n_shards ints)
+extern "C" int64_t rsa_shard_route_workgroups(const rsa_shard_route_args* a) {
+  if (a == nullptr || a->n_queries <= 0) return 0;
+  const int64_t n_neg = a->n_queries * a->num_neg;
+  uint64_t T;
+  int unroll = 4;
+  uint64_t elem_base = 0;
+  if (a->sampler == RSA_SAMPLER_GIVEN || n_neg == 0) {
+    int64_t quarter = ((n_neg + 3) / 4 + 255) / 256 * 256;
+    if (quarter < 256) quarter = 256;
+    T = (uint64_t)quarter;
+  } else {
+    if (a->grid_threads == 0) return 0;
+    T = a->grid_threads;
+    elem_base = a->elem_base;
+    unroll = (a->sampler == RSA_SAMPLER_UNIFORM && (uint64_t)(a->n_items - 1) >= (1ull << 28)) ? 2 : 4;
+  }
+  int64_t n_groups = 0;
+  if (n_neg > 0) {
+    const uint64_t k_lo = (elem_base / T) / unroll, k_hi = ((elem_base + (uint64_t)n_neg - 1) / T) / unroll;
+    n_groups = (int64_t)((k_hi - k_lo + 1) * T);
+  }
+  int64_t blocks = (n_groups + a->n_queries + ROUTE_ITEMS_PER_BLOCK - 1) / ROUTE_ITEMS_PER_BLOCK;
+  if (blocks < (int64_t)a->n_slices * a->n_banks) blocks = (int64_t)a->n_slices * a->n_banks;
+  return blocks;
 }
 
 extern "C" int rsa_shard_home(const rsa_shard_home_args* a, rsa_stream_t stream) {

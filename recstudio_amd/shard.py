@@ -160,7 +160,7 @@ class HipBackend:
     # -- version 2 of the fixed-capacity exchange (rsa_shard_sample_route / _score_segments / _home) -------------------
     @ops._on_device
     def sample_route(self, state, plan, rank, pos, n, chunks, capacity, spec, generator, neg=None, want_ids=False,
-                     want_logp=False, count_only=False, banks=1, route_pos=True, group_by_query=False):
+                     want_logp=False, count_only=False, banks=1, route_pos=True, group_by_query=False, deterministic=False):
         """One launch: draw (or read) the negatives, route every (query, item) element of all ``chunks`` slices.
         -> dict(send [C*G*banks*stride] int64, slot_of [B*(1+n)] int32, stride, neg_ids / log_neg_prob / log_pos_prob when
         asked for), or the exact per-segment counts [C*G*banks] int32 with ``count_only`` (the generator is not
@@ -218,6 +218,13 @@ class HipBackend:
         out['slot_of'] = torch.empty(B * (n + 1), dtype=torch.int32, device=dev)
         out['stride'] = stride
         a.send_keys, a.slot_of = ptr(out['send']), ptr(out['slot_of'])
+        if deterministic:
+            # no atomic decides a slot: count pass + prefix over the workgroups + routing pass (run-to-run bit-equal segments)
+            ints = 2 * int(nat.lib().rsa_shard_route_workgroups(ctypes.byref(a))) * G
+            wg = state.get('wg_scratch')
+            if wg is None or wg.numel() < ints:
+                wg = state['wg_scratch'] = torch.empty(max(ints, 1), dtype=torch.int32, device=dev)
+            a.deterministic, a.wg_scratch, a.wg_scratch_ints = 1, ptr(wg), wg.numel()
         nat.check(nat.lib().rsa_shard_sample_route(ctypes.byref(a), ops._stream()), 'rsa_shard_sample_route')
         return out
 
@@ -554,13 +561,18 @@ def _gather_group(dist):
 
 class ShardedItemTable:
     def __init__(self, item_local, plan, rank, dist, backend=None, group=None, exchange='fixed', slack=1.08,
-                 margin=4096, check_every=16, sample_seed=2022, chunks=1, force_collectives=False, owner_loss=True):
+                 margin=4096, check_every=16, sample_seed=2022, chunks=1, force_collectives=False, owner_loss=True,
+                 deterministic=False):
         """``chunks`` > 1 (fixed-capacity exchange only): the step's queries are cut into that many contiguous
         slices, routed by ONE launch, whose exchanges are issued asynchronously, so that slice c+1's key all-to-all and
         slice c-1's score all-to-all travel over xGMI while slice c is being scored (see ``_fixed_step``)."""
         self.item_local, self.plan, self.rank, self.dist = item_local, plan, int(rank), dist
         self.chunks = max(1, int(chunks))
         self.owner_loss = bool(owner_loss)      # stock BPR training steps are evaluated on the owners (bpr_step_on_owners)
+        # deterministic: the router takes three launches instead of one (count, prefix over the workgroups, route) and no
+        # atomic decides where a key lands -- a step's segments, and every sum the owners form in slot order, are then
+        # bit-identical run to run (the default's slots follow returning atomics: steps agree to fp32 rounding only)
+        self.deterministic = bool(deterministic)
         self.group_by_query = True              # ... with query-grouped routing where the shape allows (no sort by query there)
         self._solo = plan.world == 1 and not force_collectives
         self.backend = backend if backend is not None else HipBackend()
@@ -736,7 +748,7 @@ class ShardedItemTable:
             cap = self._capacity(key[:3], int(counts.max()), store=key)
         # the sampler's log-probabilities: BPRLoss ignores them (loss_func.py:55-59), everything else gets them
         r = be.sample_route(st, plan, self.rank, pos, n, C, cap, spec, self.sample_generator, neg=neg,
-                            want_ids=want_ids, want_logp=want_logp and fused_loss != 'bpr', banks=S)
+                            want_ids=want_ids, want_logp=want_logp and fused_loss != 'bpr', banks=S, deterministic=self.deterministic)
         per = plan.world * S * r['stride']
         send = r['send']
         if C == 1:
@@ -1029,7 +1041,8 @@ class ShardedItemTable:
                                      banks=S, route_pos=False)
             cap = self._capacity(key[:3], int(counts.max()), store=key)
         r = be.sample_route(st, plan, self.rank, pos, n, 1, cap, spec, self.sample_generator, neg=neg, want_ids=want_ids,
-                            want_logp=False, banks=S, route_pos=False, group_by_query=self.group_by_query)
+                            want_logp=False, banks=S, route_pos=False, group_by_query=self.group_by_query,
+                            deterministic=self.deterministic)
         recv = self._all_to_all(r['send'])
         return pos_all, r, recv, (r.get('neg_ids') if spec is not None else neg)
 

@@ -321,6 +321,18 @@ def _two_rank_worker(rank, world, port, backend, result_dir, layout='block'):
                                    rtol=1e-5, atol=1e-7)
         reps = gather_cpu(tower2.weight.detach())
         assert torch.equal(reps[0], reps[1])
+        # deterministic router at world size 2: two runs of an in-place SGD step agree bit for bit (rows, user rows, loss)
+        det = []
+        for _ in range(2):
+            tower_d = torch.nn.Embedding(U, d).to(dev)
+            with torch.no_grad():
+                tower_d.weight.copy_(user)
+            tbl_d = ShardedItemTable(plan.take(item_d, rank).contiguous().clone(), plan, rank, comm, sample_seed=37, deterministic=True)
+            tr_d = ShardedRetriever(tbl_d, tower_d, ra.UniformSampler(N), ra.BPRLoss(), 64, item_sgd_lr=0.5, query_sgd_lr=0.25)
+            ld = tr_d.training_step(uid, pos)
+            tbl_d.check_overflow()
+            det.append((ld.clone(), tbl_d.item_local.clone(), tower_d.weight.detach().clone()))
+        assert all(torch.equal(x, y) for x, y in zip(det[0], det[1]))
         # SampledSoftmax on the owners (two phases around the (max, sum) all-reduce) == the score-at-home protocol of the same
         # step at world size 2: same draws, same loss, same item rows and query rows after one in-place SGD step
         outs = []
@@ -629,6 +641,51 @@ def test_world1_rccl_sampled_softmax_on_owners(kind, n):
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize('loss_name', ['bpr', 'ssm'])
+@pytest.mark.parametrize('kind', ['uniform', 'popular'])
+def test_deterministic_router_makes_sharded_steps_bit_reproducible(kind, loss_name):
+    """ShardedItemTable(deterministic=True): the router's slots come from a count pass + a prefix over the workgroups instead of
+    atomic cursors, so three in-place SGD training steps (BPR and SampledSoftmax on the owners) leave bit-identical item rows,
+    user rows, losses and send buffers run to run -- and the SAME numbers (to fp32 rounding: another summation order) as the
+    default router.  The draws are those of the default router bit for bit."""
+    import torch.distributed as dist
+    import recstudio_amd as ra
+    from recstudio_amd.shard import RowShardPlan, ShardedItemTable, ShardedRetriever
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(_free_port())
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+    try:
+        torch.manual_seed(6)
+        N, U, d, B, n = 40_009, 700, 128, 1024, 64
+        item = torch.randn(N, d, device=DEV) * 0.2
+        item[0] = 0
+        user = torch.randn(U, d, device=DEV) * 0.2
+        batches = [(torch.randint(1, U, (B,), device=DEV), torch.randint(1, N, (B,), device=DEV)) for _ in range(3)]
+        smp = ra.UniformSampler(N) if kind == 'uniform' else ra.PopularSamplerModel((torch.rand(N) ** 4 * 300).long() + 1).to(DEV)
+        loss_fn = ra.BPRLoss() if loss_name == 'bpr' else ra.SampledSoftmaxLoss()
+
+        def run(det):
+            tower = torch.nn.Embedding(U, d).to(DEV)
+            with torch.no_grad():
+                tower.weight.copy_(user)
+            table = ShardedItemTable(item.clone(), RowShardPlan(N, 1), 0, dist, force_collectives=True, sample_seed=13,
+                                     deterministic=det)
+            tr = ShardedRetriever(table, tower, smp, loss_fn, n, item_sgd_lr=0.4, query_sgd_lr=0.2, keep_neg_ids=True)
+            seen = [(tr.training_step(u, p).clone(), tr.last_neg.clone()) for u, p in batches]
+            table.check_overflow()
+            return table.item_local.clone(), tower.weight.detach().clone(), seen
+        a, b, c = run(True), run(True), run(False)
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+        for (la, na), (lb, nb), (lc, nc) in zip(a[2], b[2], c[2]):
+            assert torch.equal(la, lb) and torch.equal(na, nb) and torch.equal(na, nc)
+            np.testing.assert_allclose(la.item(), lc.item(), rtol=1e-5)
+        np.testing.assert_allclose(a[0].cpu(), c[0].cpu(), rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(a[1].cpu(), c[1].cpu(), rtol=1e-4, atol=1e-6)
+        assert (a[0] - item).abs().max() > 1e-4
+    finally:
+        dist.destroy_process_group()
+
+
 @pytest.mark.parametrize('layout', ['block', 'interleaved'])
 def test_launch_entry_point_world1_loss_decreases(layout):
     """recstudio_amd.launch (the multi-GPU training entry point) as a single rank: runs, and SGD on the sharded
@@ -697,12 +754,13 @@ def test_world1_rccl_overflow_step_is_harmless():
         tower = torch.nn.Embedding(U, d).to(DEV)
         uid = torch.randint(1, U, (B,), device=DEV)
         pos = torch.randint(1, N, (B,), device=DEV)
-        for loss_fn in (ra.BPRLoss(), ra.SampledSoftmaxLoss()):
+        for loss_fn, own in ((ra.BPRLoss(), True), (ra.SampledSoftmaxLoss(), True), (ra.SampledSoftmaxLoss(), False)):
             table = ShardedItemTable(item, RowShardPlan(N, 1), 0, dist, check_every=0)
-            trainer = ShardedRetriever(table, tower, ra.UniformSampler(N), loss_fn, n, item_sgd_lr=0.3, query_sgd_lr=0.3)
+            trainer = ShardedRetriever(table, tower, ra.UniformSampler(N), loss_fn, n, item_sgd_lr=0.3, query_sgd_lr=0.3,
+                                       owner_ssm=own)
             l0 = trainer.training_step(uid, pos)                           # calibrates, trains
             assert torch.isfinite(l0) and int(table.state['step_dropped']) == 0
-            key = (B, n, 1, 'owners') if type(loss_fn) is ra.BPRLoss else (B, n, 1)     # (the BPR step runs on the owners)
+            key = (B, n, 1, 'owners') if own else (B, n, 1)               # (loss on the owners / scores sent home)
             table._cap[key] = table._cap[key] // 2                         # force an overflow: half the elements fit
             w_item, w_user = item.clone(), tower.weight.detach().clone()
             l1 = trainer.training_step(uid, pos)

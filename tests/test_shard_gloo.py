@@ -64,7 +64,7 @@ class CheckerBackend:
         return None
 
     def sample_route(self, state, plan, rank, pos, n, chunks, capacity, spec, generator, neg=None, want_ids=False,
-                     want_logp=False, count_only=False, banks=1, route_pos=True, group_by_query=False):
+                     want_logp=False, count_only=False, banks=1, route_pos=True, group_by_query=False, deterministic=False):
         assert banks == 1                                      # (the checker has no BANKS attribute: one segment per owner)
         B, G, C = pos.numel(), plan.world, chunks
         out = {}
