@@ -678,6 +678,9 @@ typedef struct rsa_shard_route_args {
   int32_t _pad1;
   int32_t* wg_scratch;
   int64_t wg_scratch_ints;
+  int32_t* extra_dropped;      /* nullable device word: elements of this step that were dropped OUTSIDE this call (the fixed-capacity row
+                                  look-up of an item-tower query encoder).  Added to the dropped total the segment headers carry -- the
+                                  owners gate the step like any routing overflow -- and reset to 0 */
 } rsa_shard_route_args;
 int64_t rsa_shard_segment_stride(int64_t capacity);    /* RSA_SHARD_HDR + capacity: 8-byte words per segment */
 int rsa_shard_sample_route(const rsa_shard_route_args* args, rsa_stream_t stream);

@@ -70,6 +70,7 @@ class ShardRouteArgs(Structure):
         ('send_keys', c_void_p), ('slot_of', c_void_p), ('cursors', c_void_p), ('counts_out', c_void_p),
         ('skip_pos', c_int32), ('group_by_query', c_int32),
         ('deterministic', c_int32), ('_pad1', c_int32), ('wg_scratch', c_void_p), ('wg_scratch_ints', c_int64),
+        ('extra_dropped', c_void_p),
     ]
 
 

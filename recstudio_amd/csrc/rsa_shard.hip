@@ -290,6 +290,8 @@ struct RouteV2 {
   // rank in its (owner, query) share is (waves before it, in wave order) + (its wave's elements before it, in program order);
   // across workgroups the share bases are an exclusive prefix over the workgroups in launch order, from a COUNT pass
   // (det_phase 1: wg_cnt[workgroup][owner]) and a scan (shard_route_scan_kernel -> wg_base, segment totals into the cursors).
+  int32_t* extra_dropped;  // nullable device word: elements of this step dropped OUTSIDE the routing (a tower's fixed-capacity row
+                           // look-up): added to the dropped total of the headers -- the step is gated like any other overflow -- and reset
   int32_t det_phase;       // 0: atomic cursors; 1: count pass; 2: routing pass over wg_base
   int32_t* wg_cnt;         // [gridDim.x, G]
   const int32_t* wg_base;  // [gridDim.x, G]
@@ -534,6 +536,11 @@ __global__ __launch_bounds__(256) void shard_sample_route_kernel(const RouteV2 a
     }
 #pragma unroll
     for (int mk = 32; mk >= 1; mk >>= 1) dropped += __shfl_xor((long long)dropped, mk, 64);
+    if (!COUNT_ONLY && a.extra_dropped != nullptr) {
+      dropped += *a.extra_dropped;            // (every lane reads it before lane 0 resets it: the wave runs in lock step)
+      __builtin_amdgcn_wave_barrier();
+      if (threadIdx.x == 0) *a.extra_dropped = 0;
+    }
     for (int sg = threadIdx.x; sg < segs; sg += 64) {
       const int64_t c = __hip_atomic_load(&a.cursors[sg * CURSOR_PAD], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (a.counts_out != nullptr) a.counts_out[sg] = (int32_t)c;
@@ -1076,6 +1083,7 @@ extern "C" int rsa_shard_sample_route(const rsa_shard_route_args* a, rsa_stream_
     RSA_CHECK_ARG(r.group_ql > 0, "rsa_shard_sample_route: this shape cannot be routed query-grouped "
                                   "(rsa_shard_route_query_groups says so beforehand)");
   }
+  r.extra_dropped = a->extra_dropped;
   r.det_phase = 0;
   r.wg_cnt = nullptr;
   r.wg_base = nullptr;

@@ -208,6 +208,8 @@ class HipBackend:
             out['log_pos_prob'] = torch.empty(B, dtype=torch.float32, device=dev)
             a.neg_logp, a.pos_logp = ptr(out['log_neg_prob']), ptr(out['log_pos_prob'])
         a.cursors = ptr(state['cursors'])
+        if not count_only and state.get('lookup_dropped') is not None:
+            a.extra_dropped = ptr(state['lookup_dropped'])     # drops of this step's tower look-ups: gated like a routing overflow
         if count_only:
             counts = torch.empty(chunks * G * banks, dtype=torch.int32, device=dev)
             a.counts_out = ptr(counts)
@@ -510,7 +512,7 @@ class HipBackend:
             ops.scatter_rows_sorted(table, rows, ids.view(m, 1), torch.full((m, 1), float(scale), device=rows.device),
                                     query_index=torch.arange(m, device=ids.device), pad_row=pad_row, upstream=gate)
         else:
-            keep = ids != pad_row
+            keep = (ids != pad_row) & (ids >= 0)
             upd = rows[keep] * float(scale)
             table.index_add_(0, ids[keep], upd if gate is None else upd * gate)
 
@@ -1186,8 +1188,9 @@ class ShardedItemTable:
         window of SASRec): ids out, ROWS back -- unlike the negatives, whose rows never travel, a tower needs the
         vectors.  ``ids`` (any shape, GLOBAL item ids, 0 = padding) -> ``[*ids.shape, d]`` with zero rows at the
         padding (padding ids are not sent anywhere: rank 0, which owns row 0, would be a hot owner otherwise).
-        Variable split: per-owner counts exchanged and read back (one host round trip per call; B*L*512 B per rank come
-        back over xGMI, 105 MB at B = 4096, L = 50).  Every rank must call this in lock-step."""
+        Fixed exchange (default): fixed-capacity segments, no host round trip (``_lookup_rows_fixed``); ``exchange='exact'``:
+        variable split, per-owner counts exchanged and read back (one host round trip per call).  B*L*512 B per rank come
+        back over xGMI either way (105 MB at B = 4096, L = 50).  Every rank must call this in lock-step."""
         be, plan, d = self.backend, self.plan, self.item_local.shape[1]
         flat = ids.reshape(-1)
         M, G = flat.numel(), plan.world
@@ -1195,6 +1198,11 @@ class ShardedItemTable:
             # one rank owns every row (row 0 is the zero padding row): a plain gather, no exchange, no host round trip
             out = be.gather_rows(self.item_local, flat.contiguous()).view(*ids.shape, d)
             return (out, {'local': flat}) if keep_route else out
+        if self.exchange == 'fixed' and keep_route:
+            # a TRAINING step's look-up (its backward follows, and so does the step's routing launch, which carries a dropped
+            # count to every owner): fixed-capacity segments, no host round trip.  Evaluation keeps the variable split -- a
+            # full segment must not hand a zero row to a forward nobody gates.
+            return self._lookup_rows_fixed(ids, flat)
         sel = torch.nonzero(flat).view(-1)                         # positions that hold a real item
         vid = flat[sel]
         owner = plan.owner(vid)
@@ -1215,6 +1223,55 @@ class ShardedItemTable:
             return out, {'src': src, 'recv_local': recv_local, 'send_counts': send_counts, 'recv_counts': recv_counts}
         return out
 
+    def _lookup_rows_fixed(self, ids, flat):
+        """The look-up over FIXED-capacity, self-describing segments (what 5.1 does for the keys): every rank sends every
+        owner ``[count, dropped, C ids]`` and gets ``[C, d]`` rows back, both by EQUAL-split all-to-alls -- no count exchange,
+        no ``.tolist()``, no host round trip in a step (the variable-split form above stalled the stream once per call).
+        ``C`` is calibrated on the first call of a shape (the one read-back: the largest per-owner count over all ranks,
+        plus slack).  A position whose owner segment is full comes back as a ZERO row and is counted: the count joins the
+        step's dropped total through the next routing launch's segment headers (``state['lookup_dropped']`` ->
+        ``rsa_shard_route_args.extra_dropped``), so the step is gated to a no-op and the capacity recalibrated exactly like
+        an overflow of the score-side exchange."""
+        be, plan, d = self.backend, self.plan, self.item_local.shape[1]
+        M, G, dev = flat.numel(), plan.world, flat.device
+        real = flat > 0
+        owner = torch.where(real, plan.owner(flat), torch.full_like(flat, G))          # padding: bucket G, never sent
+        counts = torch.bincount(owner, minlength=G + 1)                                # device
+        key = ('rows',)                      # ONE capacity for every call: the buffers' sizes must not depend on a rank's own shape
+        C = self._cap.get(key)
+        if C is None:                        # calibration (and recalibration after an overflow): the only host read-back
+            m = torch.stack([counts[:G].max(), torch.tensor(M, dtype=counts.dtype, device=dev)])
+            self._all_reduce_max(m)
+            big, m_max = (int(v) for v in m.tolist())
+            C = min(m_max, (int(big * self.slack) + self.margin // max(G, 1) + 255) // 256 * 256)
+            C = self._cap[key] = max(C, 1)
+        order = torch.argsort(owner, stable=True)
+        starts = torch.cumsum(counts, 0) - counts
+        so = owner[order]
+        slot_sorted = torch.arange(M, device=dev) - starts[so]
+        ok = (so < G) & (slot_sorted < C)
+        stride = 2 + C
+        dump = G * stride                                          # one trash word behind the segments
+        send = torch.full((G * stride + 1,), -1, dtype=torch.int64, device=dev)
+        at = torch.where(ok, so * stride + 2 + slot_sorted, torch.full_like(so, dump))
+        send[at] = plan.local(flat[order])
+        kept = torch.minimum(counts[:G], torch.full_like(counts[:G], C))
+        dropped = (counts[:G] - kept).sum()
+        send[torch.arange(G, device=dev) * stride] = kept
+        send[torch.arange(G, device=dev) * stride + 1] = dropped                      # this rank's total, in every header
+        if self.state.get('lookup_dropped') is None:
+            self.state['lookup_dropped'] = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.state['lookup_dropped'] += dropped.to(torch.int32)
+        recv = self._all_to_all(send[:G * stride].contiguous()).view(G, stride)
+        recv_ids = recv[:, 2:].reshape(-1)                                             # -1: dead slot
+        rows_owner = be.gather_rows(self.item_local, recv_ids.clamp(min=0))
+        home = torch.zeros(G * C + 1, d, dtype=self.item_local.dtype, device=dev)      # + ONE zero row for padding / dropped
+        self._all_to_all(rows_owner, out=home[:G * C])
+        inv = torch.full((M,), G * C, dtype=torch.int64, device=dev)
+        inv[order] = torch.where(ok, so * C + slot_sorted, torch.full_like(so, G * C))
+        out = be.gather_rows(home, inv).view(*ids.shape, d)
+        return out, {'inv': inv, 'recv_ids': recv_ids, 'C': C}
+
     def lookup_rows_backward(self, route, grad, item_grad_local, scale=1.0):
         """Backward of ``lookup_rows``: the gradient rows of the real positions go to the owners of their items (the
         reverse of the forward's row exchange) and are added, times ``scale``, into ``item_grad_local`` -- this rank's
@@ -1226,6 +1283,14 @@ class ShardedItemTable:
         gate = self.state['scale'][1:2] if (item_grad_local is self.item_local and 'scale' in self.state) else None
         if 'local' in route:
             be.apply_rows(item_grad_local, route['local'], grad.reshape(-1, d).contiguous(), scale, pad_row=0, gate=gate)
+            return
+        if 'inv' in route:       # fixed-capacity form: the gradient rows travel back in the forward's slots (equal split)
+            G, C = self.plan.world, route['C']
+            g_send = torch.zeros(G * C + 1, d, dtype=grad.dtype, device=grad.device)
+            g_send[route['inv']] = grad.reshape(-1, d)              # (distinct slots; padding / dropped positions: the trash row)
+            g_owner = self._all_to_all(g_send[:G * C].contiguous())
+            # dead slots carry id -1: the sorted scatter drops negative ids
+            be.apply_rows(item_grad_local, route['recv_ids'], g_owner, scale, pad_row=0 if self.rank == 0 else -1, gate=gate)
             return
         g_send = be.gather_rows(grad.reshape(-1, d).contiguous(), route['src'])
         g_owner = self._all_to_all(g_send, route['recv_counts'], route['send_counts'])

@@ -103,6 +103,9 @@ class CheckerBackend:
             send[base] = sel.numel()
             send[base + self.HDR:base + self.HDR + sel.numel()] = key[sel]
             slot_of[sel] = (base + self.HDR + torch.arange(sel.numel())).to(torch.int32)
+        if state.get('lookup_dropped') is not None:            # drops of the step's tower look-ups: gated like a routing overflow
+            dropped += int(state['lookup_dropped'])
+            state['lookup_dropped'].zero_()
         send[1::stride][:C * G] = dropped
         out.update(send=send, slot_of=slot_of, stride=stride)
         return out
@@ -169,6 +172,7 @@ class CheckerBackend:
     def backward_segments(self, state, item_local, q_all, recv_keys, n_seg, stride, d_owner, item_grad_local, qgrad_all,
                           item_pad_row=-1, item_scale=None):
         gate = 0.0 if int(state['step_dropped'][0]) else 1.0
+        self._publish_scale(state, gate, item_scale)
         keep = self._live(recv_keys, n_seg, stride)
         keys, dscore = recv_keys[keep], d_owner[keep]
         rows, qidx = keys & 0xffffffff, keys >> 32
@@ -176,6 +180,12 @@ class CheckerBackend:
         qgrad_all.index_add_(0, qidx, gate * dscore.unsqueeze(1) * item_local[rows])       # reads the rows: first
         scale = gate * (1.0 if item_scale is None else float(item_scale))
         item_grad_local.index_add_(0, rows[live], scale * dscore[live].unsqueeze(1) * q_all[qidx[live]])
+
+    @staticmethod
+    def _publish_scale(state, gate, item_scale):
+        """what the owner kernels leave in scale_out: {gate * item_scale, gate} (read by the tower-side tied update)"""
+        state['scale'][0] = gate * (1.0 if item_scale is None else float(item_scale))
+        state['scale'][1] = gate
 
     # -- the stock BPR step evaluated on the owners, restated with torch-CPU ops -----------------------------------
     OWNER_DIMS = range(1, 4097)
@@ -190,6 +200,7 @@ class CheckerBackend:
         state['step_dropped'][0] = total
         state['overflow'] += total
         gate = 0.0 if total else 1.0
+        self._publish_scale(state, gate, item_scale)
         keys = recv_keys[self._live(recv_keys, n_seg, stride)]
         rows, qidx = keys & 0xffffffff, keys >> 32
         x = pos_score[qidx] - (item_local[rows] * q_all[qidx]).sum(-1)              # loss_func.py:55-59, one term per element
@@ -229,6 +240,7 @@ class CheckerBackend:
         total = int(recv_keys.view(n_seg, stride)[:, 1].sum())
         state['step_dropped'][0] = total
         state['overflow'] += total
+        self._publish_scale(state, 0.0 if total else 1.0, item_scale)
         keys = recv_keys[self._live(recv_keys, n_seg, stride)]
         rows, qidx = keys & 0xffffffff, keys >> 32
         z = (item_local[rows] * q_all[qidx]).sum(-1)
@@ -297,7 +309,7 @@ class CheckerBackend:
 
 
     def apply_rows(self, table, ids, rows, scale, pad_row=0, gate=None):
-        keep = ids != pad_row
+        keep = (ids != pad_row) & (ids >= 0)                    # negative ids: dead slots of a fixed-capacity exchange
         upd = rows[keep] * float(scale)
         table.index_add_(0, ids[keep], upd if gate is None else upd * gate)
 
@@ -1007,6 +1019,21 @@ def _item_tower_worker(rank, world, port, n_items, d, B, L, n, result_dir, layou
                                        rtol=1e-4, atol=1e-6)
             trainer2.set_sgd_lr(0.1)
             assert tower2.item_encoder.grad_scale == -0.1
+        # the TRAINING look-up travels in fixed-capacity segments (no host round trip in a step); one that does not fit them
+        # hands zero rows to the dropped positions AND counts them into the step's dropped total: the step is gated to a no-op
+        # on both sides of the tied table (score-side rows and tower-side rows), the overflow is reported, the capacity
+        # recalibrated by the next step
+        table3, tower3, trainer3 = make(ra.BPRLoss(), item_sgd_lr=0.7)
+        trainer3.training_step(hists[rank], poss[rank], None)
+        assert ('rows',) in table3._cap and int(table3.state['step_dropped']) == 0
+        before = table3.item_local.clone()
+        table3._cap[('rows',)] = 2
+        trainer3.training_step(hists[rank], poss[rank], None)
+        assert int(table3.state['step_dropped']) > 0 and torch.equal(table3.item_local, before)
+        with pytest.raises(RuntimeError, match='did not fit'):
+            table3.check_overflow()
+        trainer3.training_step(hists[rank], poss[rank], None)             # recalibrated: trains again
+        assert int(table3.state['step_dropped']) == 0 and table3._cap[('rows',)] > 2 and not torch.equal(table3.item_local, before)
         open(os.path.join(result_dir, f'ok{rank}'), 'w').write('ok')
     finally:
         dist.destroy_process_group()
