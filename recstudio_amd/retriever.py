@@ -819,6 +819,9 @@ class BaseRetriever(torch.nn.Module):
             if on_gpu and tr.get('device_loader', True) and hasattr(train_data, 'device_train_loader'):
                 loader = train_data.device_train_loader(tr['batch_size'], shuffle=True, drop_last=False, device=device, ddp=True,
                                                         rank=rank, world=world)
+                # the rank parts of one global batch: every rank's history window has the same shape, so a tower's row
+                # look-ups can travel in fixed-capacity segments (no host round trip per step)
+                trainer.table.uniform_lookups = True
             else:
                 loader = train_data.train_loader(batch_size=tr['batch_size'], shuffle=True, drop_last=False, ddp=True,
                                                  rank=rank, world=world)

@@ -1198,10 +1198,12 @@ class ShardedItemTable:
             # one rank owns every row (row 0 is the zero padding row): a plain gather, no exchange, no host round trip
             out = be.gather_rows(self.item_local, flat.contiguous()).view(*ids.shape, d)
             return (out, {'local': flat}) if keep_route else out
-        if self.exchange == 'fixed' and keep_route:
+        if self.exchange == 'fixed' and keep_route and getattr(self, 'uniform_lookups', False):
             # a TRAINING step's look-up (its backward follows, and so does the step's routing launch, which carries a dropped
-            # count to every owner): fixed-capacity segments, no host round trip.  Evaluation keeps the variable split -- a
-            # full segment must not hand a zero row to a forward nobody gates.
+            # count to every owner) whose shape is the SAME ON EVERY RANK (``uniform_lookups``: the caller's promise -- ``fit``
+            # makes it when the device-resident loader deals the rank parts of one global batch; an equal-split exchange needs
+            # equal buffer sizes): fixed-capacity segments, no host round trip.  Evaluation keeps the variable split -- a full
+            # segment must not hand a zero row to a forward nobody gates.
             return self._lookup_rows_fixed(ids, flat)
         sel = torch.nonzero(flat).view(-1)                         # positions that hold a real item
         vid = flat[sel]
@@ -1231,20 +1233,21 @@ class ShardedItemTable:
         plus slack).  A position whose owner segment is full comes back as a ZERO row and is counted: the count joins the
         step's dropped total through the next routing launch's segment headers (``state['lookup_dropped']`` ->
         ``rsa_shard_route_args.extra_dropped``), so the step is gated to a no-op and the capacity recalibrated exactly like
-        an overflow of the score-side exchange."""
+        an overflow of the score-side exchange.  (M = ids.numel() must be the same on every rank: ``uniform_lookups``.)"""
         be, plan, d = self.backend, self.plan, self.item_local.shape[1]
         M, G, dev = flat.numel(), plan.world, flat.device
         real = flat > 0
         owner = torch.where(real, plan.owner(flat), torch.full_like(flat, G))          # padding: bucket G, never sent
         counts = torch.bincount(owner, minlength=G + 1)                                # device
-        key = ('rows',)                      # ONE capacity for every call: the buffers' sizes must not depend on a rank's own shape
-        C = self._cap.get(key)
-        if C is None:                        # calibration (and recalibration after an overflow): the only host read-back
-            m = torch.stack([counts[:G].max(), torch.tensor(M, dtype=counts.dtype, device=dev)])
-            self._all_reduce_max(m)
-            big, m_max = (int(v) for v in m.tolist())
-            C = min(m_max, (int(big * self.slack) + self.margin // max(G, 1) + 255) // 256 * 256)
-            C = self._cap[key] = max(C, 1)
+        # capacity = (the largest share of a call's positions any owner received, over all ranks, at calibration) x M + slack: a
+        # function of the rank-uniform M and one all-reduced ratio, so every rank sizes its buffers alike without a collective
+        # per call.  Calibration (first call, and after an overflow cleared it) is the only host read-back.
+        frac = self._cap.get(('rows_frac',))
+        if frac is None:
+            share = (counts[:G].max().to(torch.float64) / max(M, 1)).reshape(1)
+            self._all_reduce_max(share)
+            frac = self._cap[('rows_frac',)] = max(float(share.item()), 1.0 / G)
+        C = max(1, min(M, (int(frac * M * self.slack) + self.margin // max(G, 1) + 255) // 256 * 256))
         order = torch.argsort(owner, stable=True)
         starts = torch.cumsum(counts, 0) - counts
         so = owner[order]

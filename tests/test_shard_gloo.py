@@ -965,6 +965,7 @@ def _item_tower_worker(rank, world, port, n_items, d, B, L, n, result_dir, layou
 
         def make(loss, **kw):
             table = ShardedItemTable(plan.take(item, rank).clone(), plan, rank, dist, backend=CheckerBackend())
+            table.uniform_lookups = True                                   # every rank looks up a [B, L] window: fixed-capacity segments
             rows = ShardedRows(table)
             tower = _HistTower(rows, d)
             with torch.no_grad():
@@ -1025,15 +1026,15 @@ def _item_tower_worker(rank, world, port, n_items, d, B, L, n, result_dir, layou
         # recalibrated by the next step
         table3, tower3, trainer3 = make(ra.BPRLoss(), item_sgd_lr=0.7)
         trainer3.training_step(hists[rank], poss[rank], None)
-        assert ('rows',) in table3._cap and int(table3.state['step_dropped']) == 0
+        assert ('rows_frac',) in table3._cap and int(table3.state['step_dropped']) == 0
         before = table3.item_local.clone()
-        table3._cap[('rows',)] = 2
+        table3._cap[('rows_frac',)], table3.margin = 1e-9, 0               # capacity 1 slot per owner
         trainer3.training_step(hists[rank], poss[rank], None)
         assert int(table3.state['step_dropped']) > 0 and torch.equal(table3.item_local, before)
         with pytest.raises(RuntimeError, match='did not fit'):
             table3.check_overflow()
         trainer3.training_step(hists[rank], poss[rank], None)             # recalibrated: trains again
-        assert int(table3.state['step_dropped']) == 0 and table3._cap[('rows',)] > 2 and not torch.equal(table3.item_local, before)
+        assert int(table3.state['step_dropped']) == 0 and table3._cap[('rows_frac',)] > 0.01 and not torch.equal(table3.item_local, before)
         open(os.path.join(result_dir, f'ok{rank}'), 'w').write('ok')
     finally:
         dist.destroy_process_group()
