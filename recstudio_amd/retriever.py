@@ -54,7 +54,7 @@ def default_config():
                   'excluding_hist': False, 'scheduler': None, 'seed': 2022, 'weight_decay': 0.0,
                   'tensorboard_path': None, 'sparse_grad': False, 'device_loader': True, 'fused_optimizer': None,
                   'shard_slices': 1, 'shard_layout': 'block', 'shard_owner_loss': True, 'shard_init': 'auto',
-                  'shard_lookahead': False, 'shard_deterministic': False,
+                  'shard_lookahead': False, 'shard_deterministic': False, 'shard_rows_share': None,
                   'fused_prefetch': True},
         'eval': {'batch_size': 128, 'cutoff': [5, 10, 20], 'val_metrics': ['ndcg', 'recall'], 'val_n_epoch': 1,
                  'test_metrics': ['ndcg', 'recall', 'precision', 'map', 'mrr', 'hit'], 'topk': 100,
@@ -709,7 +709,8 @@ class BaseRetriever(torch.nn.Module):
                                        sample_seed=self.config['train']['seed'] or 2022,
                                        chunks=int(self.config['train'].get('shard_slices', 1)),
                                        owner_loss=bool(self.config['train'].get('shard_owner_loss', True)),
-                                       deterministic=bool(self.config['train'].get('shard_deterministic', False)))
+                                       deterministic=bool(self.config['train'].get('shard_deterministic', False)),
+                                       rows_share=self.config['train'].get('shard_rows_share'))
         self._shard = {'table': table, 'dist': dist, 'rank': rank, 'world': world, 'lo': lo, 'hi': hi, 'device': device,
                        'n_items': n_items, 'plan': plan, 'tower_rows': None}
         if tied:

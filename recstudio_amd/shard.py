@@ -564,7 +564,7 @@ def _gather_group(dist):
 class ShardedItemTable:
     def __init__(self, item_local, plan, rank, dist, backend=None, group=None, exchange='fixed', slack=1.08,
                  margin=4096, check_every=16, sample_seed=2022, chunks=1, force_collectives=False, owner_loss=True,
-                 deterministic=False):
+                 deterministic=False, rows_share=None):
         """``chunks`` > 1 (fixed-capacity exchange only): the step's queries are cut into that many contiguous
         slices, routed by ONE launch, whose exchanges are issued asynchronously, so that slice c+1's key all-to-all and
         slice c-1's score all-to-all travel over xGMI while slice c is being scored (see ``_fixed_step``)."""
@@ -575,6 +575,7 @@ class ShardedItemTable:
         # atomic decides where a key lands -- a step's segments, and every sum the owners form in slot order, are then
         # bit-identical run to run (the default's slots follow returning atomics: steps agree to fp32 rounding only)
         self.deterministic = bool(deterministic)
+        self.rows_share = None if rows_share is None else float(rows_share)      # see _lookup_rows_fixed
         self.group_by_query = True              # ... with query-grouped routing where the shape allows (no sort by query there)
         self._solo = plan.world == 1 and not force_collectives
         self.backend = backend if backend is not None else HipBackend()
@@ -1242,11 +1243,16 @@ class ShardedItemTable:
         # capacity = (the largest share of a call's positions any owner received, over all ranks, at calibration) x M + slack: a
         # function of the rank-uniform M and one all-reduced ratio, so every rank sizes its buffers alike without a collective
         # per call.  Calibration (first call, and after an overflow cleared it) is the only host read-back.
-        frac = self._cap.get(('rows_frac',))
+        # ``rows_share`` (``train.shard_rows_share``) fixes the share instead: 1.0 = every segment holds a whole call (no overflow
+        # ever, G x the traffic); the calibrated value carries 25 % headroom and, after an overflow, the largest share seen so far.
+        share_now = (counts[:G].max().to(torch.float64) / max(M, 1)).reshape(1)
+        seen = self.state.get('rows_share_seen')
+        seen = self.state['rows_share_seen'] = share_now if seen is None else torch.maximum(seen, share_now)    # (device, no sync)
+        frac = getattr(self, 'rows_share', None) or self._cap.get(('rows_frac',))
         if frac is None:
-            share = (counts[:G].max().to(torch.float64) / max(M, 1)).reshape(1)
-            self._all_reduce_max(share)
-            frac = self._cap[('rows_frac',)] = max(float(share.item()), 1.0 / G)
+            worst = seen.clone()
+            self._all_reduce_max(worst)
+            frac = self._cap[('rows_frac',)] = min(1.0, max(1.25 * float(worst.item()), 1.0 / G))
         C = max(1, min(M, (int(frac * M * self.slack) + self.margin // max(G, 1) + 255) // 256 * 256))
         order = torch.argsort(owner, stable=True)
         starts = torch.cumsum(counts, 0) - counts

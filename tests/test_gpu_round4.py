@@ -190,8 +190,10 @@ def _sasrec_gpu_worker(rank, world, port, result_dir, layout):
     torch.cuda.set_device(0)
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
+        # shard_rows_share = 1: the tower's fixed-capacity look-up segments hold a whole call (this test compares trajectories to
+        # 5e-5: a gated overflow step under a torch optimizer would show; the overflow path itself: tests/test_shard_gloo.py)
         conf = {'train': {'epochs': 2, 'batch_size': 2048 // world, 'seed': 2022, 'learning_rate': 0.003, 'early_stop_patience': 100,
-                          'shard_layout': layout},
+                          'shard_layout': layout, 'shard_rows_share': 1.0},
                 'eval': {'batch_size': 128 // world, 'cutoff': [10], 'val_metrics': ['ndcg', 'recall'], 'topk': 50,
                          'test_metrics': ['ndcg', 'recall']},
                 'model': {'embed_dim': 64, 'dropout_rate': 0.0}}
