@@ -320,8 +320,8 @@ def side_figures(extra):
     put('b16384_frac', 'sweep', 'B=16384', 'frac_of_hbm_peak')
     put('b4096_two_streams_frac', 'sweep', 'B=4096', 'two_streams_frac_of_hbm_peak')
     put('b16384_two_streams_frac', 'sweep', 'B=16384', 'two_streams_frac_of_hbm_peak')
-    put('b4096_queue_frac', 'sweep', 'B=4096', 'queue_frac_of_hbm_peak')
-    put('b16384_queue_frac', 'sweep', 'B=16384', 'queue_frac_of_hbm_peak')
+    put('b4096_queue_frac', 'sweep', 'B=4096', 'queue', 'frac_of_hbm_peak')
+    put('b16384_queue_frac', 'sweep', 'B=16384', 'queue', 'frac_of_hbm_peak')
     put('ssm_n256_frac', 'seq_softmax', 'frac_of_hbm_peak')
     put('train_step_frac', 'train_step', 'train_frac')
     put('sgd_step_frac', 'train_step', 'sgd_frac')
@@ -331,6 +331,7 @@ def side_figures(extra):
     put('sharded_world1_frac', 'sharded_world1', 'frac_of_hbm_peak')
     put('sharded_world1_train_frac', 'sharded_world1', 'train', 'frac_of_hbm_peak')
     put('sharded_world1_train_ssm_ms', 'sharded_world1', 'train_ssm', 'ms_per_step')
+    put('sharded_world1_train_ssm_frac', 'sharded_world1', 'train_ssm', 'frac_of_hbm_peak')
     put('fullscore_frac', 'fullscore', 'frac_of_peak')
     put('fullscore_tflops', 'fullscore', 'gemm_lse_tflops')
     put('fullscore_top100_ms', 'fullscore', 'with_top100_ms')
@@ -452,6 +453,18 @@ def main():
         os.environ.setdefault('MASTER_PORT', '29533')
         dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
     if world == 1 and not force_shard:
+        # FIRST (a fresh process, like a user's): the thing users run, BaseRetriever.fit end to end (tools/bench_fit.py) -- configs[0] on the committed ml-100k
+        # fixture next to the reference's published epoch times, and configs[1]-shaped fit through loader + stepper
+        if not args.no_sweep and not args.no_fit and args.dim == 128:
+            try:
+                torch.cuda.empty_cache()
+                sys.path.insert(0, os.path.join(ROOT, 'tools'))
+                from bench_fit import fit_figures
+                seed_state = torch.cuda.get_rng_state(dev)
+                extra['fit'] = fit_figures(ra, dev, n_items=args.items, n_users=args.users)
+                torch.cuda.set_rng_state(seed_state, dev)
+            except Exception as e:
+                extra['fit'] = {'error': repr(e)[:300]}
         item, user = make_workload(dev, args.items, args.users, d)
         sampler = (ra.PopularSamplerModel(counts, guide_log2=args.guide_log2, lookup=args.pop_lookup) if popular
                    else ra.UniformSampler(args.items)).to(dev)
@@ -618,9 +631,10 @@ def main():
                     pq = torch.randint(1, args.items, (S_q * b2,), device=dev, generator=gq)
                     stq = ra.ops.FusedStep(item, user, n, fused_bpr=True, n_batches=S_q, **dict(kw, query_index=uq, pos_ids=pq))
                     tq = time_gpu(stq, max(5, args.steps // 2), 5) * 1e3 / S_q
-                    sweep[f'B={b2}'].update(queue_batches=S_q, queue_ms_per_batch=round(tq, 4),
-                                            queue_frac_of_hbm_peak=round(alg2 / tq / 1e6 / HBM_PEAK_GBS, 4),
-                                            queue_what='S independent batches in one launch (throughput mode; ids == S consecutive launches)')
+                    sweep[f'B={b2}']['queue'] = with_profile(
+                        {'batches': S_q, 'ms_per_batch': round(tq, 4), 'frac_of_hbm_peak': round(alg2 / tq / 1e6 / HBM_PEAK_GBS, 4),
+                         'what': 'S independent batches consumed by one launch (throughput mode; ids == S consecutive launches)'},
+                        f'queue_N1e7_popular_n64_B{b2}x{S_q}', alg2 * S_q)
                     del stq, uq, pq
                 except Exception as e:
                     sweep[f'B={b2}']['queue_error'] = repr(e)[:160]
@@ -954,12 +968,13 @@ def main():
                                            'key exchange, owner-side sorts) on a second stream under the current one (the steps on a high-priority stream)'},
                                   'sharded_world1_train', alg_tr, whole_step=True)
                 extra['sharded_world1']['train'] = tr
-                extra['sharded_world1']['train_ssm'] = {
+                extra['sharded_world1']['train_ssm'] = with_profile({
                     'ms_per_step': round(ssm_ms[True], 4), 'frac_of_hbm_peak': round(alg_tr / ssm_ms[True] / 1e6 / HBM_PEAK_GBS, 4),
                     'scores_at_home_ms_per_step': round(ssm_ms[False], 4),
                     'what': 'the same in-place SGD step with SampledSoftmaxLoss evaluated on the owners (ssm_step_on_owners: rows '
                             'read once for scores + query gradient, read-modify-written once by the sorted apply pass) vs the '
-                            'score-at-home protocol; same SURVEY 8d bytes as the BPR step'}
+                            'score-at-home protocol; same SURVEY 8d bytes as the BPR step'},
+                    'sharded_world1_train_ssm', alg_tr, whole_step=True)
                 del blk, tbl, tbl_t
             except Exception as e:
                 extra['sharded_world1'] = {'error': repr(e)[:200]}
@@ -968,18 +983,6 @@ def main():
         workload = (f'BPR two-tower d={d}, synthetic {args.items} items / {args.users} users / 1e8-interaction Zipf '
                     f'popularity, {args.sampler} sampler neg={n}, InnerProduct + BPR loss, B={B} queries/step '
                     f'(BASELINE.json configs[1])')
-        # the thing users run: BaseRetriever.fit end to end (tools/bench_fit.py) -- configs[0] on the committed ml-100k
-        # fixture next to the reference's published epoch times, and configs[1]-shaped fit through loader + stepper
-        if not args.no_sweep and not args.no_fit and args.dim == 128:
-            try:
-                torch.cuda.empty_cache()
-                sys.path.insert(0, os.path.join(ROOT, 'tools'))
-                from bench_fit import fit_figures
-                seed_state = torch.cuda.get_rng_state(dev)
-                extra['fit'] = fit_figures(ra, dev, n_items=args.items, n_users=args.users)
-                torch.cuda.set_rng_state(seed_state, dev)
-            except Exception as e:
-                extra['fit'] = {'error': repr(e)[:300]}
         # box state under load + the side figures the claims rest on, numbers only, INSIDE `roofline` (the driver's record
         # keeps that object whole and only the names of the other extra keys)
         try:

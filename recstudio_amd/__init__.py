@@ -18,6 +18,6 @@ from .dataset import TripletDataset, SeqDataset, DataSampler, SortedDataSampler 
 from .retriever import (BaseRetriever, TwoTowerRecommender, ItemTowerRecommender, BPR, SASRec,   # noqa: F401
                         default_config, seed_everything)
 from . import eval                                                # noqa: F401
-from . import fused, graph                                        # noqa: F401
+from . import fused                                               # noqa: F401
 
 __version__ = '0.1.0'

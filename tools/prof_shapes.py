@@ -51,6 +51,19 @@ if shape in ('headline_N1e7_popular_n64_B65536', 'N1e7_popular_n64_B4096', 'N1e7
 
     def step():
         buf['o'] = ra.ops.fused_forward(item, user, 64, out=buf.get('o'), fused_bpr=True, **kw)
+elif shape in ('queue_N1e7_popular_n64_B4096x16', 'queue_N1e7_popular_n64_B16384x4'):
+    # S independent batches consumed by ONE launch (rsa_fused_args.n_batches): per-batch time = kernel time / S
+    bs = shape.rsplit('_B', 1)[1]
+    B, S = (int(v) for v in bs.split('x'))
+    item = table(10_000_001, 1)
+    ps = popular_sampler(10_000_001, '1e7')
+    uid = torch.randint(1, U, (S * B,), device=dev, generator=gen)
+    pos = torch.randint(1, 10_000_001, (S * B,), device=dev, generator=gen)
+    st = ra.ops.FusedStep(item, user, 64, fused_bpr=True, n_batches=S, query_index=uid, pos_ids=pos, sampler=nat.SAMPLER_POPULAR,
+                          **ps.lookup_kwargs())
+
+    def step():
+        st()
 elif shape.startswith('N1e8_'):
     n8 = 100_000_001
     item = table(n8, 8)
@@ -76,7 +89,7 @@ elif shape == 'ssm_N1e6_popular_n256_B8192':
 
     def step():
         buf['o'] = ra.ops.fused_forward(item, q, n_neg, out=buf.get('o'), fused_loss='ssm', **kw)
-elif shape in ('sharded_world1_step', 'sharded_world1_train'):
+elif shape in ('sharded_world1_step', 'sharded_world1_train', 'sharded_world1_train_ssm', 'sharded_world1_train_det'):
     import torch.distributed as dist
     from recstudio_amd import shard
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
@@ -84,7 +97,7 @@ elif shape in ('sharded_world1_step', 'sharded_world1_train'):
     dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
     n_blk, n_neg, B = 12_500_001, 1024, 4096
     item = table(n_blk, 9)
-    tbl = shard.ShardedItemTable(item, shard.RowShardPlan(n_blk, 1), 0, dist, check_every=0)
+    tbl = shard.ShardedItemTable(item, shard.RowShardPlan(n_blk, 1), 0, dist, check_every=0, deterministic=shape.endswith('_det'))
     us = ra.UniformSampler(n_blk)
     uid = torch.randint(1, U, (B,), device=dev, generator=gen)
     pos = torch.randint(1, n_blk, (B,), device=dev, generator=gen)
@@ -95,7 +108,8 @@ elif shape in ('sharded_world1_step', 'sharded_world1_train'):
         tower = torch.nn.Embedding(U, d).to(dev)
         # one stream: the tracked figure is a SUM of kernel durations (with the query rows on the second stream, the default,
         # the kernels that run side by side would each be charged the whole overlap)
-        trainer = shard.ShardedRetriever(tbl, tower, us, ra.BPRLoss(), n_neg, item_sgd_lr=0.05, query_sgd_lr=0.05,
+        loss_fn = ra.SampledSoftmaxLoss() if shape.endswith('_ssm') else ra.BPRLoss()      # (_ssm: on the owners, two phases)
+        trainer = shard.ShardedRetriever(tbl, tower, us, loss_fn, n_neg, item_sgd_lr=0.05, query_sgd_lr=0.05,
                                          overlap_query_rows=False)
 
         def step():
@@ -135,6 +149,16 @@ elif shape in ('fullscore_lse_B2048_N1e6', 'fullscore_top100_B2048_N1e6'):
 
     def step():
         ra.ops.fullscore(item, q, want_lse=True, k=k)
+elif shape == 'softmax_dx_B2048_N1e6':
+    # d loss/d items of the full softmax: probs^T @ query, item-stationary on the fp32 MFMA (rsa_probs_t_query)
+    item = table(1_000_001, 1)
+    q = user[1:2049].contiguous()
+    lse = ra.ops.fullscore(item, q, want_lse=True)[1]
+    probs = ra.ops.fullscore_softmax(item, q, lse, torch.full((2048,), 1.0 / 2048, device=dev))
+    gx = torch.empty(1_000_000, d, device=dev)
+
+    def step():
+        ra.ops.probs_t_query(probs, q, out=gx)
 elif shape == 'seg_gather_B8192_L50':
     n6, B, L = 1_000_001, 8192, 50
     item = table(n6, 1)
