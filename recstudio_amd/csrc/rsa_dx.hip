@@ -31,6 +31,9 @@ constexpr int DX_STEPS = DX_KB / 2;  // MFMA steps per chunk (two batch rows eac
 #ifndef RSA_DX_MIN_BLOCKS
 #define RSA_DX_MIN_BLOCKS 2
 #endif
+#ifndef RSA_DX_RT
+#define RSA_DX_RT 1              // 32-item row tiles per wave (2: the query operand read from LDS feeds twice as many MFMAs)
+#endif
 #ifndef RSA_DX_QAHEAD
 #define RSA_DX_QAHEAD 2          // LDS reads of the query operand issued this many steps ahead of their MFMAs
 #endif
@@ -42,14 +45,20 @@ __global__ __launch_bounds__(256, RSA_DX_MIN_BLOCKS) void probs_t_query_kernel(c
   __shared__ __attribute__((aligned(16))) float qs[2][DX_KB * D];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j = lane & 31, h = lane >> 5;
-  const int64_t i0 = (int64_t)blockIdx.x * 128 + wave * 32;      // this wave's first column of probs (item i0 + 1)
-  const int64_t col = i0 + j;
-  const bool col_ok = col < n_cols;
-  const float* pcol = probs + (col_ok ? col : 0);
-
-  f32x16 acc[NC];
+  constexpr int RT = RSA_DX_RT;
+  const int64_t i0 = ((int64_t)blockIdx.x * 4 + wave) * (32 * RT);      // this wave's first column of probs (item i0 + 1)
+  const float* pcol[RT];
 #pragma unroll
-  for (int c = 0; c < NC; ++c) acc[c] = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (int rt = 0; rt < RT; ++rt) {
+    const int64_t col = i0 + 32 * rt + j;
+    pcol[rt] = probs + (col < n_cols ? col : 0);
+  }
+
+  f32x16 acc[RT][NC];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+    for (int c = 0; c < NC; ++c) acc[rt][c] = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 
   // cooperative stage of a query chunk: DX_KB * D / 4 float4 over 256 threads
   constexpr int QLOADS = DX_KB * D / 4 / 256;
@@ -79,18 +88,23 @@ __global__ __launch_bounds__(256, RSA_DX_MIN_BLOCKS) void probs_t_query_kernel(c
 #pragma unroll
     for (int f = 0; f < QLOADS; ++f) reinterpret_cast<float4*>(qs[buf])[f * 256 + tid] = qstage[f];
   };
-  float pa[DX_STEPS], pb[DX_STEPS];
-  auto p_fetch = [&](int64_t chunk, float (&dst)[DX_STEPS]) __attribute__((always_inline)) {
-    const float* src = pcol + (size_t)(chunk * DX_KB + h) * ld;
+  float pa[RT][DX_STEPS], pb[RT][DX_STEPS];
+  auto p_fetch = [&](int64_t chunk, float (&dst)[RT][DX_STEPS]) __attribute__((always_inline)) {
 #pragma unroll
-    for (int t = 0; t < DX_STEPS; ++t) dst[t] = src[(size_t)(2 * t) * ld];
-  };
-  auto p_fetch_checked = [&](int64_t chunk, float (&dst)[DX_STEPS]) __attribute__((always_inline)) {
+    for (int rt = 0; rt < RT; ++rt) {
+      const float* src = pcol[rt] + (size_t)(chunk * DX_KB + h) * ld;
 #pragma unroll
-    for (int t = 0; t < DX_STEPS; ++t) {
-      const int64_t b = chunk * DX_KB + 2 * t + h;
-      dst[t] = b < n_query ? pcol[(size_t)b * ld] : 0.f;      // (the query rows staged for b >= n_query are zero as well)
+      for (int t = 0; t < DX_STEPS; ++t) dst[rt][t] = src[(size_t)(2 * t) * ld];
     }
+  };
+  auto p_fetch_checked = [&](int64_t chunk, float (&dst)[RT][DX_STEPS]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int t = 0; t < DX_STEPS; ++t) {
+        const int64_t b = chunk * DX_KB + 2 * t + h;
+        dst[rt][t] = b < n_query ? pcol[rt][(size_t)b * ld] : 0.f;      // (the query rows staged for b >= n_query are zero as well)
+      }
   };
   auto q_read = [&](int buf, int t, float (&qv)[NC]) __attribute__((always_inline)) {
     const float* qrow = qs[buf] + (2 * t + h) * D + NC * j;
@@ -104,7 +118,7 @@ __global__ __launch_bounds__(256, RSA_DX_MIN_BLOCKS) void probs_t_query_kernel(c
       qv[0] = qrow[0];
     }
   };
-  auto run_chunk = [&](int buf, const float (&p)[DX_STEPS]) __attribute__((always_inline)) {
+  auto run_chunk = [&](int buf, const float (&p)[RT][DX_STEPS]) __attribute__((always_inline)) {
     constexpr int AH = RSA_DX_QAHEAD;
     float qv[AH + 1][NC];
 #pragma unroll
@@ -113,7 +127,10 @@ __global__ __launch_bounds__(256, RSA_DX_MIN_BLOCKS) void probs_t_query_kernel(c
     for (int t = 0; t < DX_STEPS; ++t) {
       if (t + AH < DX_STEPS) q_read(buf, t + AH, qv[(t + AH) % (AH + 1)]);
 #pragma unroll
-      for (int c = 0; c < NC; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(p[t], qv[t % (AH + 1)][c], acc[c], 0, 0, 0);
+      for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+          acc[rt][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(p[rt][t], qv[t % (AH + 1)][c], acc[rt][c], 0, 0, 0);
     }
   };
 
@@ -153,19 +170,21 @@ __global__ __launch_bounds__(256, RSA_DX_MIN_BLOCKS) void probs_t_query_kernel(c
   }
   // acc[c][r] = out[item row(r, h)][NC j + c], row(r, h) = (r & 3) + 8 (r >> 2) + 4 h
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int64_t item = i0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-    if (item < n_cols) {
-      float* dst = out + (size_t)item * D + NC * j;
-      if constexpr (NC == 4) {
-        *reinterpret_cast<float4*>(dst) = make_float4(acc[0][r], acc[1][r], acc[2][r], acc[3][r]);
-      } else if constexpr (NC == 2) {
-        *reinterpret_cast<float2*>(dst) = make_float2(acc[0][r], acc[1][r]);
-      } else {
-        dst[0] = acc[0][r];
+  for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int64_t item = i0 + 32 * rt + (r & 3) + 8 * (r >> 2) + 4 * h;
+      if (item < n_cols) {
+        float* dst = out + (size_t)item * D + NC * j;
+        if constexpr (NC == 4) {
+          *reinterpret_cast<float4*>(dst) = make_float4(acc[rt][0][r], acc[rt][1][r], acc[rt][2][r], acc[rt][3][r]);
+        } else if constexpr (NC == 2) {
+          *reinterpret_cast<float2*>(dst) = make_float2(acc[rt][0][r], acc[rt][1][r]);
+        } else {
+          dst[0] = acc[rt][0][r];
+        }
       }
     }
-  }
 }
 
 }  // namespace rsa
@@ -187,7 +206,7 @@ extern "C" int rsa_probs_t_query(const float* probs, int64_t n_query, int64_t n_
   }
   RSA_CHECK_ARG(probs && query, "rsa_probs_t_query: null pointer");
   RSA_CHECK_ARG(((uintptr_t)query & 15) == 0 && ((uintptr_t)out & 15) == 0, "rsa_probs_t_query: query / out must be 16-byte aligned");
-  const dim3 grid((unsigned)((n_cols + 127) / 128)), block(256);
+  const dim3 grid((unsigned)((n_cols + 128 * RSA_DX_RT - 1) / (128 * RSA_DX_RT))), block(256);
   switch (dim) {
     case 32: hipLaunchKernelGGL(probs_t_query_kernel<32>, grid, block, 0, s, probs, n_cols, ld, query, n_query, out); break;
     case 64: hipLaunchKernelGGL(probs_t_query_kernel<64>, grid, block, 0, s, probs, n_cols, ld, query, n_query, out); break;
