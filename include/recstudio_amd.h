@@ -68,7 +68,7 @@ enum rsa_status {
 enum rsa_score_mode { RSA_SCORE_IP = 0, RSA_SCORE_COS = 1, RSA_SCORE_EUC = 2 /* EuclideanScorer, scorer.py:28-34 */ };
 enum rsa_sampler_kind { RSA_SAMPLER_GIVEN = 0, RSA_SAMPLER_UNIFORM = 1, RSA_SAMPLER_POPULAR = 2 };
 enum rsa_loss_kind { RSA_LOSS_BPR = 0, RSA_LOSS_SSM = 1, RSA_LOSS_BCE = 2,
-                     /* rsa_pairwise_loss_ex: */ RSA_LOSS_WBPR = 3, RSA_LOSS_WBCE = 4, RSA_LOSS_HINGE = 5, RSA_LOSS_NCE = 6,
+                     /* rsa_pairwise_loss: */ RSA_LOSS_WBPR = 3, RSA_LOSS_WBCE = 4, RSA_LOSS_HINGE = 5, RSA_LOSS_NCE = 6,
                      RSA_LOSS_CCL = 7 };
 
 /* ---- Versioned argument blocks (ABI 9) --------------------------------------------------------------------------
@@ -249,7 +249,7 @@ typedef struct rsa_fused_args {
    * other element of the step touches that item row, and the row is not the padding row).  Such a row is rewritten by
    * the wave that has it in registers: item[id] += upd_scale[0] * d * q (d = d loss/d score of that element; upd_scale =
    * -lr is plain SGD) -- nothing else reads or writes that row in the step, so the result is the one a separate update
-   * pass gives.  The other elements are applied by rsa_scatter_rows_presorted on the same workspace, which skips
+   * pass gives.  The other elements are applied by rsa_rows_update_presorted on the same workspace, which skips
    * exactly the flagged ones.  item_table is written. */
   const uint8_t* solo_flags;   /* nullable [M * (num_neg + 1)] */
   const float* upd_scale;      /* device scalar */
@@ -731,7 +731,7 @@ int rsa_shard_scatter_slots(const float* dpos, const float* dneg, const int32_t*
                             int32_t num_neg, float* d_send, rsa_stream_t stream);
 
 /* Owner side of the backward: (local row, query index) per slot of the received segments, -1 past a segment's count
- * (rsa_scatter_rows_sorted drops negative ids); scale_out (nullable, 2 floats) = {gate * (scale_in ? scale_in[0] : 1),
+ * (rsa_rows_update_sorted drops negative ids); scale_out (nullable, 2 floats) = {gate * (scale_in ? scale_in[0] : 1),
  * gate} with gate = step_dropped[0] != 0 ? 0 : 1 -- the `upstream` scalars of the item-side and the query-side
  * sorted scatter, so that a step in which any rank dropped an element updates nothing. */
 int rsa_shard_unpack_segments(const int64_t* keys, int64_t n_segments, int64_t stride, int64_t* local_rows,
@@ -739,7 +739,7 @@ int rsa_shard_unpack_segments(const int64_t* keys, int64_t n_segments, int64_t s
                               rsa_stream_t stream);
 
 /* The whole owner side of the sharded backward on received segments (replaces rsa_shard_unpack_segments + two
- * rsa_scatter_rows_sorted calls, i.e. the ATen sequence autograd runs for the reference's
+ * rsa_rows_update_sorted calls, i.e. the ATen sequence autograd runs for the reference's
  * item_encoder(neg ids) / score_func backward, recommender.py:636-639, on the rows this rank owns):
  *     qgrad_all[q]   += gate * sum_{slots of query q} d[slot] * item_local[row(slot)]
  *     item_target[r] += gate * item_scale * sum_{slots on row r} d[slot] * q_all[query(slot)]      (r != item_pad_row)

@@ -465,12 +465,12 @@ static int pairwise_loss_ex_impl(int32_t loss_kind, const float* pos_score, cons
                                  const float* pos_logp, const float* neg_logp, int64_t n_rows, int32_t num_neg,
                                  float param0, float param1, float* row_loss, float* loss_out, float* dpos,
                                  float* dneg, void* scratch, rsa_stream_t stream) {
-  RSA_CHECK_ARG(scratch != nullptr, "rsa_pairwise_loss_ex: scratch is null");
+  RSA_CHECK_ARG(scratch != nullptr, "rsa_pairwise_loss: scratch is null");
   int32_t* g_count = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(scratch) + SCRATCH_BCE_COUNT);
-  RSA_CHECK_ARG(loss_kind >= RSA_LOSS_WBPR && loss_kind <= RSA_LOSS_CCL, "rsa_pairwise_loss_ex: unknown loss %d",
+  RSA_CHECK_ARG(loss_kind >= RSA_LOSS_WBPR && loss_kind <= RSA_LOSS_CCL, "rsa_pairwise_loss: unknown loss %d",
                 loss_kind);
-  RSA_CHECK_ARG(n_rows >= 1 && num_neg >= 1, "rsa_pairwise_loss_ex: need n_rows >= 1 and num_neg >= 1");
-  RSA_CHECK_ARG(pos_score && neg_score && row_loss && loss_out, "rsa_pairwise_loss_ex: null pointer");
+  RSA_CHECK_ARG(n_rows >= 1 && num_neg >= 1, "rsa_pairwise_loss: need n_rows >= 1 and num_neg >= 1");
+  RSA_CHECK_ARG(pos_score && neg_score && row_loss && loss_out, "rsa_pairwise_loss: null pointer");
   hipStream_t s = (hipStream_t)stream;
   const int rl = num_neg <= 2 ? 1 : num_neg <= 8 ? 4 : num_neg <= 32 ? 16 : 64;
   int64_t blocks = (n_rows * rl + 255) / 256;
@@ -479,7 +479,7 @@ static int pairwise_loss_ex_impl(int32_t loss_kind, const float* pos_score, cons
   const int32_t* count = nullptr;
   if (loss_kind == RSA_LOSS_WBCE) {
     if (hipMemsetAsync(g_count, 0, sizeof(int32_t), s) != hipSuccess) {
-      rsa::set_error("rsa_pairwise_loss_ex: memset failed");
+      rsa::set_error("rsa_pairwise_loss: memset failed");
       return RSA_ERR_HIP;
     }
     int64_t cb = (n_rows + 255) / 256;
@@ -497,7 +497,7 @@ static int pairwise_loss_ex_impl(int32_t loss_kind, const float* pos_score, cons
     default: RSA_LAUNCH_EX(64); break;
   }
 #undef RSA_LAUNCH_EX
-  RSA_CHECK_LAUNCH("rsa_pairwise_loss_ex");
+  RSA_CHECK_LAUNCH("rsa_pairwise_loss");
   return mean_rows_impl(row_loss, n_rows, count, loss_out, scratch, stream);
 }
 

@@ -342,7 +342,7 @@ static int apply_sorted_pairs(const uint64_t* pairs, int64_t total, const float*
                               const float* upstream, int64_t drop_key, int64_t pad_row, float* target, AdamArgs adam,
                               const SortedLayout& L, hipStream_t s) {
   if (dim != 64 && dim != 128 && dim != 256) {
-    rsa::set_error("rsa_scatter_rows_sorted: dim=%d: built for dim in {64, 128, 256}", dim);
+    rsa::set_error("rsa_rows_update_sorted: dim=%d: built for dim in {64, 128, 256}", dim);
     return RSA_ERR_UNSUPPORTED;
   }
   const unsigned chunks = (unsigned)((total + 63) / 64);
@@ -359,7 +359,7 @@ static int apply_sorted_pairs(const uint64_t* pairs, int64_t total, const float*
     default: RSA_SORTED_LAUNCH(4); break;
   }
 #undef RSA_SORTED_LAUNCH
-  RSA_CHECK_LAUNCH("rsa_scatter_rows_sorted(apply)");
+  RSA_CHECK_LAUNCH("rsa_rows_update_sorted(apply)");
   return RSA_OK;
 }
 
@@ -416,14 +416,14 @@ static int apply_sorted_impl(const float* query, const int64_t* query_index, int
                              int64_t n_queries, int32_t num_neg, const float* dpos, const float* dneg, const float* upstream,
                              int64_t n_items, int64_t pad_row, float* target, AdamArgs adam, void* workspace,
                              int64_t workspace_bytes, rsa_stream_t stream) {
-  RSA_CHECK_ARG(n_queries >= 0 && num_neg >= 1 && n_items >= 1 && n_items < (1ll << 31), "rsa_scatter_rows_sorted: bad sizes");
+  RSA_CHECK_ARG(n_queries >= 0 && num_neg >= 1 && n_items >= 1 && n_items < (1ll << 31), "rsa_rows_update_sorted: bad sizes");
   if (n_queries == 0) return RSA_OK;
-  RSA_CHECK_ARG(query && dneg && target, "rsa_scatter_rows_sorted: null pointer");
-  RSA_CHECK_ARG(!has_pos || dpos != nullptr, "rsa_scatter_rows_sorted: pos_ids without dpos");
-  RSA_CHECK_ARG(query_index != nullptr || n_query_rows >= n_queries, "rsa_scatter_rows_sorted: query has fewer rows than n_queries");
+  RSA_CHECK_ARG(query && dneg && target, "rsa_rows_update_sorted: null pointer");
+  RSA_CHECK_ARG(!has_pos || dpos != nullptr, "rsa_rows_update_sorted: pos_ids without dpos");
+  RSA_CHECK_ARG(query_index != nullptr || n_query_rows >= n_queries, "rsa_rows_update_sorted: query has fewer rows than n_queries");
   const int64_t total = n_queries * (int64_t)(num_neg + has_pos);
   const int64_t need = rsa_scatter_rows_sorted_workspace_bytes(n_queries, num_neg, n_items);
-  RSA_CHECK_ARG(workspace && workspace_bytes >= need, "rsa_scatter_rows_sorted: workspace too small (%lld < %lld)",
+  RSA_CHECK_ARG(workspace && workspace_bytes >= need, "rsa_rows_update_sorted: workspace too small (%lld < %lld)",
                 (long long)workspace_bytes, (long long)need);
   const SortedLayout L = sorted_layout(workspace, n_queries * (int64_t)(num_neg + 1));
   const DecStep dec{query_index, dpos, dneg, (int)num_neg, has_pos};
@@ -436,13 +436,13 @@ static int scatter_sorted_impl(const float* query, const int64_t* query_index, i
                                const float* dpos, const float* dneg, const float* upstream, int64_t n_items,
                                int64_t pad_row, float* target, AdamArgs adam, void* workspace, int64_t workspace_bytes,
                                rsa_stream_t stream) {
-  RSA_CHECK_ARG(pos_ids == nullptr || dpos != nullptr, "rsa_scatter_rows_sorted: pos_ids without dpos");
+  RSA_CHECK_ARG(pos_ids == nullptr || dpos != nullptr, "rsa_rows_update_sorted: pos_ids without dpos");
   if (dim != 64 && dim != 128 && dim != 256) {
-    rsa::set_error("rsa_scatter_rows_sorted: dim=%d: built for dim in {64, 128, 256}", dim);
+    rsa::set_error("rsa_rows_update_sorted: dim=%d: built for dim in {64, 128, 256}", dim);
     return RSA_ERR_UNSUPPORTED;
   }
   int rc = sort_elements_impl(pos_ids, neg_ids, n_queries, num_neg, n_items, pad_row, nullptr, workspace, workspace_bytes, stream,
-                              "rsa_scatter_rows_sorted");
+                              "rsa_rows_update_sorted");
   if (rc != RSA_OK) return rc;
   return apply_sorted_impl(query, query_index, n_query_rows, dim, pos_ids != nullptr, n_queries, num_neg, dpos, dneg, upstream,
                            n_items, pad_row, target, adam, workspace, workspace_bytes, stream);

@@ -66,7 +66,7 @@ class _ScoreFn(torch.autograd.Function):
             gpos = torch.zeros(pos_ids.numel(), dtype=torch.float32, device=item_weight.device)
         # dense user-table gradient straight from the kernel (no [M, d] intermediate, no second launch)
         qtab = torch.zeros_like(query_src) if (need_q and qi is not None and not sparse) else None
-        # dense item gradient of the inner-product scorer: sorted atomics-free scatter (rsa_scatter_rows_sorted) next to
+        # dense item gradient of the inner-product scorer: sorted atomics-free scatter (rsa_rows_update_sorted) next to
         # a backward launch that only produces the query gradient; other cases: the backward kernel's own scatter
         cos = cfg.get('cosine', False)
         sorted_dense = (need_item and not sparse and (cos is False or cos == nat.SCORE_IP)
@@ -250,7 +250,7 @@ def bpr_sgd_step(item_weight, user_weight, num_neg, lr, *, user_ids, pos_ids, sa
                  in_forward=None):
     """One complete SGD training step of a BPR two-tower model (nn.Embedding user and item tables) in three
     launches and WITHOUT gradient tensors: the forward samples, scores, evaluates BPRLoss and accumulates the
-    user-row gradients; ``rsa_scatter_rows_sorted`` adds ``-lr * dneg * q`` straight into the touched ITEM rows of the
+    user-row gradients; ``rsa_rows_update_sorted`` adds ``-lr * dneg * q`` straight into the touched ITEM rows of the
     weight table (elements sorted by item id, one read-modify-write per row, bit-reproducible; ``atomics=True``: the
     backward kernel's float atomics instead) and a row scatter applies ``-lr * q.grad`` to the touched USER
     rows.  Equal to ``loss.backward(); torch.optim.SGD(lr).step()`` on the dense gradients (no momentum /
@@ -263,7 +263,7 @@ def bpr_sgd_step(item_weight, user_weight, num_neg, lr, *, user_ids, pos_ids, sa
     the row, no read of the query row.  The negatives are drawn first (the Sampler plugin: same ids, same generator
     consumption as the in-kernel sampler) and sorted by item id BEFORE the forward (``rsa_sort_step_elements``: the sort the
     all-sorted form runs after it); a run of length one in the sorted order is a solo row, and only the other elements go
-    through the apply pass (``rsa_scatter_rows_presorted``).  Same result as the all-sorted
+    through the apply pass (``rsa_rows_update_presorted``).  Same result as the all-sorted
     form bit for bit on the solo rows, equal up to fp32 summation order on the shared ones; bit-reproducible."""
     M = user_ids.numel()
     kind = _sampler_kind(sampler) if sampler is not None else nat.SAMPLER_GIVEN
@@ -484,7 +484,7 @@ class _device_of:
 class FusedBPRAdam:
     """Complete lazy-Adam training step of a BPR two-tower model (nn.Embedding user and item tables) without
     gradient tensors: the forward samples, scores, evaluates BPRLoss and accumulates the user-row gradients;
-    ``rsa_adam_rows_sorted`` sorts the step's (item id, element) pairs, sums every touched row's gradient in
+    ``rsa_rows_update_sorted`` sorts the step's (item id, element) pairs, sums every touched row's gradient in
     registers and applies torch.optim.SparseAdam's update to that row of (weight, exp_avg, exp_avg_sq); the user
     rows go through the same kernel with the accumulated row gradients.  Equal (up to fp32 summation order) to
     ``loss.backward()`` with sparse embeddings + ``torch.optim.SparseAdam.step()`` -- whose coalesce pass alone

@@ -1211,7 +1211,7 @@ def _with_next(it):
 
 def _embedding_grad(g, ids, n_rows):
     """Dense ``weight.grad`` of an item-row gather (embedding_dense_backward with padding_idx = 0): rows sorted by item id
-    and summed run by run without atomics (``rsa_scatter_rows_sorted``; bit-reproducible) for the stock dims, the
+    and summed run by run without atomics (``rsa_rows_update_sorted``; bit-reproducible) for the stock dims, the
     float-atomic scatter otherwise."""
     d = g.shape[-1]
     rows = g.reshape(-1, d).contiguous()

@@ -448,7 +448,7 @@ def test_retriever_sampler_wraps_another_retrievers_sampling(ra):
 
 @pytest.mark.parametrize('d', [64, 128, 256])
 def test_sorted_scatter_equals_atomic_backward_and_is_reproducible(ra, d):
-    """rsa_scatter_rows_sorted (radix sort by item id + one RMW per row) == the dense atomic scatter of
+    """rsa_rows_update_sorted (radix sort by item id + one RMW per row) == the dense atomic scatter of
     rsa_fused_backward, twice bit-identical, padding row untouched, heavy duplication included."""
     torch.manual_seed(d)
     N, U, M, n = 3001, 500, 777, 64
@@ -524,7 +524,7 @@ def test_sorted_scatter_long_runs(ra, N, M, n, d):
 
 
 def test_fused_adam_step_equals_sparse_grads_plus_torch_sparse_adam(ra):
-    """fused.FusedBPRAdam (no gradient tensors; lazy Adam applied by rsa_adam_rows_sorted) == loss.backward() with
+    """fused.FusedBPRAdam (no gradient tensors; lazy Adam applied by rsa_rows_update_sorted) == loss.backward() with
     COO gradients + torch.optim.SparseAdam.step(), three steps, same sampled negatives."""
     torch.manual_seed(7)
     N, U, d, B, n, lr = 4001, 301, 64, 200, 64, 0.01

@@ -852,7 +852,7 @@ def test_prefetched_sgd_steps_equal_the_plain_sequence(ra, kind):
 @pytest.mark.parametrize('kind', ['uniform', 'popular'])
 def test_prefetched_adam_steps_equal_the_plain_sequence(ra, kind):
     """FusedBPRAdam.prepare / step_prepared (sampling + item-side sort one batch ahead on a side stream, apply pass through
-    rsa_adam_rows_presorted) == the same sequence of FusedBPRAdam.step calls: losses, negatives, weights and both moment
+    rsa_rows_update_presorted) == the same sequence of FusedBPRAdam.step calls: losses, negatives, weights and both moment
     tables bit for bit."""
     N, U, d, B, n, steps = 50_021, 3001, 128, 4096, 64, 4
     iw, uw = _tables(N, U, d, B)

@@ -174,7 +174,7 @@ def test_interleaved_rows_have_no_hot_shard_under_popularity_ordered_ids():
 
 
 def test_sorted_scatter_drops_negative_ids():
-    """rsa_scatter_rows_sorted with ids < 0 (empty slots of the fixed-capacity exchange): nothing read or written for
+    """rsa_rows_update_sorted with ids < 0 (empty slots of the fixed-capacity exchange): nothing read or written for
     them -- the rest equals the scatter of the live elements alone, also when the empty slots are a long run."""
     import recstudio_amd as ra
     torch.manual_seed(0)

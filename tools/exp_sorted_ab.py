@@ -1,4 +1,4 @@
-"""In-process A/B of the sorted apply pass (rsa_scatter_rows_presorted) between library builds: the step's pairs are sorted
+"""In-process A/B of the sorted apply pass (rsa_rows_update_presorted) between library builds: the step's pairs are sorted
 once, then alternating rounds of launches of the apply pass through each library over the same workspace.
 SHAPE=all (headline shape, every element applied) | presorted (solo rows skipped, as after the in-forward update) |
 dq / item (the two sorted scatters of the sharded backward on the owner: 4.2 M elements onto 4096 query rows / onto their item rows)
