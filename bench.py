@@ -64,7 +64,26 @@ def zipf_counts(n_items, n_inter, seed=1):
     return counts
 
 
-def time_gpu(fn, steps, warmup, dist=None):
+PREWARM_S = 1.5
+
+
+def prewarm(fn, seconds=None):
+    """Keep the GPU busy with `fn` for `seconds` before a measurement.  Found in round 5 (tools/exp_warm.py): after the
+    chip has idled -- a fresh process, a host-side table build -- the SAME launch on the SAME allocation runs 7-11 % slower for
+    about a second (448 -> 431 at 0.5 s -> 419 us from 1 s on; back to 449 after 5 s of idling) while rocm-smi / amd-smi report the
+    same sclk / mclk / fclk.  Rounds 1-4 read that as box-to-box spread: the tracked profiles (120 ms of warm-up in a fresh
+    process) were the cold number, the bench line (measured after half a minute of other figures) the warm one."""
+    seconds = PREWARM_S if seconds is None else seconds
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        for _ in range(20):
+            fn()
+        torch.cuda.synchronize()
+
+
+def time_gpu(fn, steps, warmup, dist=None, warm_s=None):
+    if dist is None:          # (time-based: ranks of a job would run different numbers of collective-bearing steps)
+        prewarm(fn, warm_s)
     for _ in range(warmup):
         fn()
     torch.cuda.synchronize()
@@ -84,7 +103,7 @@ def time_gpu(fn, steps, warmup, dist=None):
 def time_gpu_best(fn, steps, warmup, repeats=3):
     """Secondary figures: best of a few short repeats (a single 50-step window on a shared box occasionally
     lands on a transient stall; the headline line keeps the contract's single K-step window)."""
-    return min(time_gpu(fn, steps, warmup if r == 0 else 1) for r in range(repeats))
+    return min(time_gpu(fn, steps, warmup if r == 0 else 1, warm_s=None if r == 0 else 0.0) for r in range(repeats))
 
 
 def self_launch(n_gpus):

@@ -176,7 +176,9 @@ else:
 # (the same kernel measured 7 % slower this way than inside bench.py's 250-launch run on the same box).  WARM_MS of
 # back-to-back launches first (counted, so that the summariser can skip them), then the K counted ones.
 import time                                     # noqa: E402
-WARM_MS = float(os.environ.get('PROF_WARM_MS', '120'))
+# (round 5: 120 ms was not enough either -- the chip needs about a SECOND of load after idling before the same launch reaches
+# its steady time, tools/exp_warm.py: rounds 1-4's tracked profiles were 7-11 % "cold")
+WARM_MS = float(os.environ.get('PROF_WARM_MS', '2500'))
 WARM = 0
 for _ in range(3):
     step()
