@@ -325,19 +325,34 @@ __device__ __forceinline__ int32_t wave_rank_det(int32_t* wcnt_wave, bool valid,
 __global__ __launch_bounds__(256) void shard_route_scan_kernel(const int32_t* __restrict__ wg_cnt, int32_t* __restrict__ wg_base,
                                                                int32_t* __restrict__ cursors, int n_blocks, int G, int n_slices,
                                                                int n_banks) {
-  const int sg = blockIdx.x * blockDim.x + threadIdx.x;
-  const int segs = n_slices * G * n_banks;
-  if (sg >= segs) return;
+  // one WORKGROUP per segment (a thread per segment walked ~1000 dependent loads: 158 us): the segment's workgroups are a
+  // contiguous range of block ids; every thread sums a contiguous piece of it, the 256 piece sums are scanned in LDS, and
+  // the thread writes its piece's bases
+  __shared__ int32_t part[256];
+  const int sg = blockIdx.x;
   const int bank = sg % n_banks, g = (sg / n_banks) % G, slice = sg / (n_banks * G);
-  const int want = slice * n_banks + bank;
-  int32_t run = 0;
-  for (int b = 0; b < n_blocks; ++b) {
-    const int micro = (int)(((int64_t)b * n_slices * n_banks) / n_blocks);
-    if (micro != want) continue;
+  const int want = slice * n_banks + bank, n_micro = n_slices * n_banks;
+  // blocks b with floor(b * n_micro / n_blocks) == want  <=>  b in [ceil(want * n_blocks / n_micro), ceil((want + 1) * n_blocks / n_micro))
+  const int lo = (int)(((int64_t)want * n_blocks + n_micro - 1) / n_micro);
+  const int hi = (int)(((int64_t)(want + 1) * n_blocks + n_micro - 1) / n_micro);
+  const int len = hi - lo, per = (len + 255) / 256;
+  const int b0 = lo + (int)threadIdx.x * per, b1 = b0 + per < hi ? b0 + per : hi;
+  int32_t sum = 0;
+  for (int b = b0; b < b1; ++b) sum += wg_cnt[(size_t)b * G + g];
+  part[threadIdx.x] = sum;
+  __syncthreads();
+  for (int off = 1; off < 256; off <<= 1) {          // inclusive Hillis-Steele scan of the piece sums
+    const int32_t v = (int)threadIdx.x >= off ? part[threadIdx.x - off] : 0;
+    __syncthreads();
+    part[threadIdx.x] += v;
+    __syncthreads();
+  }
+  int32_t run = part[threadIdx.x] - sum;
+  for (int b = b0; b < b1; ++b) {
     wg_base[(size_t)b * G + g] = run;
     run += wg_cnt[(size_t)b * G + g];
   }
-  cursors[(size_t)sg * CURSOR_PAD] = run;
+  if (threadIdx.x == 255) cursors[(size_t)sg * CURSOR_PAD] = part[255];
 }
 
 constexpr int TICKET_SUB = 32;      // two-level completion ticket: 32 sub-words, then one top word
@@ -1112,7 +1127,7 @@ extern "C" int rsa_shard_sample_route(const rsa_shard_route_args* a, rsa_stream_
     c1.wg_cnt = wg_cnt;
     c1.counts_out = nullptr;
     hipLaunchKernelGGL(shard_sample_route_kernel<true>, grid, block, 0, (hipStream_t)stream, c1);
-    hipLaunchKernelGGL(shard_route_scan_kernel, dim3((unsigned)((segs + 255) / 256)), dim3(256), 0, (hipStream_t)stream, wg_cnt, wg_base,
+    hipLaunchKernelGGL(shard_route_scan_kernel, dim3((unsigned)segs), dim3(256), 0, (hipStream_t)stream, wg_cnt, wg_base,
                        a->cursors, (int)blocks, (int)a->n_shards, (int)a->n_slices, (int)a->n_banks);
     r.det_phase = 2;
     r.wg_base = wg_base;
