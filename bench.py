@@ -822,6 +822,31 @@ def main():
                     'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': None,
                     'alg_bytes_per_launch': int(alg), 'avg_kernel_ms': round(k_avg, 4),
                     'median_kernel_ms': round(k_ms[len(k_ms) // 2], 4)}
+        # The same launch on OTHER allocations of its output buffers (on some boxes some allocations are 10-15 % slower
+        # to write into -- bimodal, stable for the life of the allocation, independent of the layout inside it; `frac` above is
+        # whatever the first allocation of this process got): three more output sets, all kept alive so that each is a new
+        # allocation, the kernel alone between events as above
+        try:
+            held, per_alloc = [hb['step']], [round(k_avg, 4)]
+            for _ in range(3):
+                o2 = ra.ops.fused_forward(item, user, n, fused_bpr=True, want_mean=False, **fresh_kw())
+                held.append(o2)
+
+                def on_o2(o2=o2):
+                    ra.ops.fused_forward(item, user, n, out=o2, fused_bpr=True, want_mean=False, **fresh_kw())
+                prewarm(on_o2, 0.3)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(args.steps):
+                    on_o2()
+                e1.record()
+                torch.cuda.synchronize()
+                per_alloc.append(round(e0.elapsed_time(e1) / args.steps, 4))
+            roofline['kernel_ms_by_output_allocation'] = per_alloc
+            roofline['best_allocation_frac'] = round(alg / (min(per_alloc) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+            del held, o2
+        except Exception as e:
+            roofline['kernel_ms_by_output_allocation_error'] = repr(e)[:120]
         # The tracked profile of this very kernel and shape (profiles/<round>_kernel_profiles.json: rocprofv3 --kernel-trace --stats
         # average and the FETCH_SIZE / WRITE_SIZE passes, collected by tools/collect_shapes.sh on another box of the
         # pool): `profile_frac` is the same algorithmic bytes over THAT average, printed next to the live `frac`; the PMC

@@ -394,13 +394,12 @@ class PrefetchedBPRSGD:
             ones = torch.ones(M, dtype=torch.float32, device=dev)
             slots = []
             for _ in range(self.RING):
-                f32 = dict(dtype=torch.float32, device=dev)
-                b = {'neg': torch.empty(M, n, dtype=torch.int64, device=dev), 'solo': torch.empty(M, n + 1, dtype=torch.uint8, device=dev),
-                     'iws': torch.empty(max(iws, 8), dtype=torch.uint8, device=dev),
-                     'uws': torch.empty(max(uws, 8), dtype=torch.uint8, device=dev),
-                     'pos_score': torch.empty(M, **f32), 'neg_score': torch.empty(M, n, **f32), 'row_loss': torch.empty(M, **f32),
-                     'dpos': torch.empty(M, **f32), 'dneg': torch.empty(M, n, **f32), 'query_grad': torch.empty(M, d, **f32),
-                     'ones': ones, 'ready': torch.cuda.Event()}
+                f32, u8 = torch.float32, torch.uint8
+                # one allocation per slot (ops.carve: buffers a launch writes must not come from separate allocations)
+                b = ops.carve(dev, [('neg', (M, n), torch.int64), ('solo', (M, n + 1), u8), ('iws', (max(iws, 8),), u8),
+                                    ('uws', (max(uws, 8),), u8), ('pos_score', (M,), f32), ('neg_score', (M, n), f32),
+                                    ('row_loss', (M,), f32), ('dpos', (M,), f32), ('dneg', (M, n), f32), ('query_grad', (M, d), f32)])
+                b.update(ones=ones, ready=torch.cuda.Event())
                 a = nat.BprSgdArgs()
                 a.item_table, a.n_items, a.user_table, a.n_users, a.dim, a.num_neg = ptr(self.iw), N, ptr(self.uw), U, d, n
                 a.n_queries, a.sampler, a.step_scale = M, self.kind, ptr(self.step_scale)

@@ -283,6 +283,29 @@ def _loss_args(kind, pos_score, neg_score, pos_logp, neg_logp, n_rows, num_neg, 
     return a
 
 
+def carve(dev, specs, align=4096):
+    """``{key: tensor}`` for ``specs = [(key, shape, dtype), ...]``, every tensor a view of ONE allocation.
+
+    Why: the buffers a launch WRITES must not come from separate allocations.  The headline launch (four [B, n] output arrays,
+    84 MB of the 2.8 GB it moves) ran 404-409 us on every one of 31 layouts of those arrays inside one allocation (any skew
+    between them, any shift, arenas of 86 MB .. 1 GB) and 443-471 us on 5 of 9 sets of separately allocated arrays of the same
+    shapes in the same processes (tools/exp_outbuf.py, exp_outliers.py; moving any ONE of the four into an arena did not help).
+    That lottery -- not the box -- was most of the 405-482 us run-to-run spread of rounds 3-5."""
+    offs, total = [], 0
+    for _, shape, dtype in specs:
+        cnt = 1
+        for v in shape:
+            cnt *= int(v)
+        offs.append((total, cnt))
+        total += (cnt * torch.empty((), dtype=dtype).element_size() + align - 1) // align * align
+    arena = torch.empty(max(total, align), dtype=torch.uint8, device=dev)
+    out = {}
+    for (key, shape, dtype), (off, cnt) in zip(specs, offs):
+        nb = cnt * torch.empty((), dtype=dtype).element_size()
+        out[key] = arena[off:off + nb].view(dtype).view(tuple(int(v) for v in shape))
+    return out
+
+
 # ------------------------------------------------------------------ fused forward / backward
 @_on_device
 def fused_forward(item_table, query, num_neg, *, query_index=None, pos_ids=None, neg_ids=None,
@@ -327,7 +350,7 @@ def fused_forward(item_table, query, num_neg, *, query_index=None, pos_ids=None,
         if neg_ids.numel() != M * n:
             raise ValueError('neg_ids must be [M, num_neg]')
     else:
-        neg_ids = out['neg_ids'] if out is not None else torch.empty(M, n, dtype=torch.int64, device=dev)
+        neg_ids = out['neg_ids'] if out is not None else None          # (allocated with the other outputs below)
         unroll = 4 if sampler == nat.SAMPLER_POPULAR else rng.randint_unroll(1, n_items)
         if rng_state is not None:
             # graph-capturable form: (seed, device int64 tensor holding the offset); the caller advances it
@@ -350,19 +373,32 @@ def fused_forward(item_table, query, num_neg, *, query_index=None, pos_ids=None,
             pc = rng.reserve(M * n, unroll, dev, generator)
             a.seed, a.offset, a.grid_threads, a.elem_base = pc.seed, pc.offset, pc.grid_threads, pc.elem_base
     reuse = out is not None        # caller-provided output buffers (same keys/shapes as returned)
+    if fused_loss is None and fused_bpr:
+        fused_loss = 'bpr'
     if not reuse:
-        out = {'neg_score': torch.empty(M, n, dtype=torch.float32, device=dev)}
+        # every output of the launch out of ONE allocation (carve): see there for why
+        f32 = torch.float32
+        specs = [('neg_score', (M, n), f32)]
+        if sampler != nat.SAMPLER_GIVEN:
+            specs.insert(0, ('neg_ids', (M, n), torch.int64))
         if pos_ids is not None:
-            out['pos_score'] = torch.empty(M, dtype=torch.float32, device=dev)
+            specs.append(('pos_score', (M,), f32))
+        if sampler == nat.SAMPLER_POPULAR and want_logp:
+            specs.append(('neg_logp', (M, n), f32))
+            if pos_ids is not None:
+                specs.append(('pos_logp', (M,), f32))
+        if fused_loss in ('bpr', 'ssm'):
+            specs += [('dneg', (M, n), f32), ('loss', (), f32), ('row_loss', (M,), f32), ('dpos', (M,), f32)]
+            if want_query_grad:
+                specs.append(('query_grad', (M, dim), f32))
+        out = carve(dev, specs)
+        if sampler != nat.SAMPLER_GIVEN:
+            neg_ids = out['neg_ids']
     out['neg_ids'] = neg_ids.view(M, n)
     if sampler == nat.SAMPLER_POPULAR:
         table = _need(table, torch.float32, 'table')
         pop_prob = _need(pop_prob, torch.float32, 'pop_prob')
         guide = _need_opt(guide, torch.int32, 'guide')
-        if not reuse and want_logp:
-            out['neg_logp'] = torch.empty(M, n, dtype=torch.float32, device=dev)
-            if pos_ids is not None:
-                out['pos_logp'] = torch.empty(M, dtype=torch.float32, device=dev)
     a.item_table, a.n_items, a.dim = ptr(item_table), n_items, dim
     a.score_mode = int(cosine) if not isinstance(cosine, bool) else (nat.SCORE_COS if cosine else nat.SCORE_IP)
     a.query, a.query_index, a.n_query_rows = ptr(query), ptr(query_index), query.shape[0]
@@ -372,8 +408,6 @@ def fused_forward(item_table, query, num_neg, *, query_index=None, pos_ids=None,
     a.table_prob = ptr(_need_opt(table_prob, torch.float32, 'table_prob'))
     a.cdf_lut = ptr(_need_opt(cdf_lut, torch.float32, 'cdf_lut'))
     a.cdf_lines, a.lines_log2 = ptr(_need_opt(cdf_lines, torch.float32, 'cdf_lines')), int(lines_log2)
-    if fused_loss is None and fused_bpr:
-        fused_loss = 'bpr'
     if sampler == nat.SAMPLER_GIVEN and fused_loss == 'ssm' and (pos_logp is not None or neg_logp is not None):
         # ids given: the log-probabilities are INPUTS of the SampledSoftmax epilogue
         a.neg_logp, a.pos_logp = ptr(_need_opt(neg_logp, torch.float32, 'neg_logp')), ptr(_need_opt(pos_logp, torch.float32, 'pos_logp'))
@@ -560,10 +594,11 @@ def fused_backward(item_table, query, neg_ids, dneg, *, query_index=None, pos_id
         item_grad = _need(item_grad_out, torch.float32, 'item_grad_out')
     else:
         item_grad = torch.zeros(n_items, dim, dtype=torch.float32, device=dev) if dense_item_grad else None
-    rows = torch.empty(M * (n + 1), dim, dtype=torch.float32, device=dev) if row_item_grad else None
+    bufs = carve(dev, ([('rows', (M * (n + 1), dim), torch.float32)] if row_item_grad else []) +
+                 ([('qgrad', (M, dim), torch.float32)] if want_query_grad else []))
+    rows, qgrad = bufs.get('rows'), bufs.get('qgrad')
     if rows is not None and pos_ids is None:
         rows.zero_()
-    qgrad = torch.empty(M, dim, dtype=torch.float32, device=dev) if want_query_grad else None
     a = nat.BackwardArgs()
     a.item_table, a.n_items, a.dim, a.num_neg = ptr(item_table), n_items, dim, n
     a.query, a.query_index, a.n_query_rows = ptr(query), ptr(query_index), query.shape[0]
@@ -603,9 +638,9 @@ def sort_step_elements(pos_ids, neg_ids, n_items, pad_row=0, want_solo=True):
     M = pos_ids.numel() if pos_ids is not None else neg_ids.shape[0]
     n = neg_ids.numel() // max(M, 1)
     w = n + (1 if pos_ids is not None else 0)
-    solo = torch.empty(M, w, dtype=torch.uint8, device=neg_ids.device) if want_solo else None   # None: sort only, nothing flagged
     ws_bytes = int(nat.lib().rsa_scatter_rows_sorted_workspace_bytes(M, n, int(n_items)))
-    ws = torch.empty(max(ws_bytes, 8), dtype=torch.uint8, device=neg_ids.device)
+    bufs = carve(neg_ids.device, [('ws', (max(ws_bytes, 8),), torch.uint8)] + ([('solo', (M, w), torch.uint8)] if want_solo else []))
+    solo, ws = bufs.get('solo'), bufs['ws']                     # solo None: sort only, nothing flagged
     a = nat.RowsUpdateArgs()
     a.pos_ids, a.neg_ids, a.n_queries, a.num_neg, a.n_items, a.pad_row = ptr(pos_ids), ptr(neg_ids), M, n, int(n_items), int(pad_row)
     a.solo, a.workspace, a.workspace_bytes = ptr(solo), ptr(ws), ws_bytes

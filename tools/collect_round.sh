@@ -7,7 +7,7 @@ export ROUND=${ROUND:-r05}
 mkdir -p gpurun_out/profiles_$ROUND
 smi() { rocm-smi --showclocks --showpower --showmaxpower --showperflevel --showcomputepartition --showmemorypartition --showtemp 2>&1 | grep -v "^=\|^$\|WARNING" ; }
 { echo "# before"; smi; } > gpurun_out/profiles_$ROUND/${ROUND}_box_state.txt
-python bench.py --steps 20 --warmup 5 > gpurun_out/profiles_$ROUND/${ROUND}_bench_line.json 2> gpurun_out/bench_round.err
+python bench.py --steps 20 --warmup 5 2> gpurun_out/bench_round.err | grep "^{" > gpurun_out/profiles_$ROUND/${ROUND}_bench_line.json
 { echo "# after the bench run"; smi; } >> gpurun_out/profiles_$ROUND/${ROUND}_box_state.txt
 bash tools/collect_profiles.sh $ROUND > gpurun_out/collect_profiles.log 2>&1
 { echo "# after the rocprofv3 passes of the bench command"; smi; } >> gpurun_out/profiles_$ROUND/${ROUND}_box_state.txt

@@ -58,6 +58,13 @@ if c is not None and steps:
     entry['avg_us'] = round(per_step[dom_name][0], 2)
     entry['launches'] = int(round(per_step[dom_name][1] * steps))
     entry['step_kernel_us'] = round(sum(v[2] for v in per_step.values()), 2)
+    try:        # the per-allocation event times prof_shapes.py printed (output sets; the counted launches ran on the fastest)
+        for line in open(os.path.join(out_dir, f'{shape}.trace.log')):
+            if line.startswith('{"shape"') and 'out_set_us' in line:
+                j = json.loads(line)
+                entry['out_set_us'], entry['out_set_used'] = j['out_set_us'], j['out_set_used']
+    except OSError:
+        pass
     entry['dominant_share_of_step'] = round(per_step[dom_name][2] / max(entry['step_kernel_us'], 1e-9), 4)
     lines.append(f'# rocprofv3 --kernel-trace --stats -- python tools/prof_shapes.py {shape} {steps}   (kernels of the step, per step)')
     lines.append(f'{"kernel":100s} {"calls/step":>10s} {"avg_us":>10s} {"us/step":>10s}')
