@@ -1225,6 +1225,35 @@ def main():
                                            'shared rows, reduce-scatter of the query gradients, user rows'}
         except Exception as e:
             extra['train_step'] = {'error': repr(e)[:300]}
+        # the same step with SampledSoftmaxLoss evaluated on the owners (ssm_step_on_owners: two phases around an
+        # 8-byte-per-query all-reduce of the queries' (max, sum) partials) and its in-job world-1 reference
+        try:
+            w_keep = item_local.clone()
+            tower_s = torch.nn.Embedding(args.users, d).to(dev)
+            with torch.no_grad():
+                tower_s.weight.copy_(user)
+            res_s = {}
+            for tag, pl, rk, smp_s, pos_s, force in (('world1', shard.RowShardPlan(n_loc, 1), 0,
+                                                       (ra.PopularSamplerModel(plan.take(counts, rank), lookup=args.pop_lookup).to(dev)
+                                                        if popular else ra.UniformSampler(n_loc)), solo_pos, False),
+                                                      ('sharded', plan, rank, sampler, pos, True)):
+                tbl_s = shard.ShardedItemTable(item_local, pl, rk, dist, check_every=0, force_collectives=force)
+                trn_s = shard.ShardedRetriever(tbl_s, tower_s, smp_s, ra.SampledSoftmaxLoss(), n, item_sgd_lr=1e-3, query_sgd_lr=1e-3)
+                res_s[tag] = timed_max(lambda trn_s=trn_s, pos_s=pos_s: trn_s.training_step(uid, pos_s), max(10, args.steps // 4), 3)
+                tbl_s.check_overflow()
+                ssm_own = tbl_s.ssm_owner_ok()
+                del tbl_s, trn_s
+            item_local.copy_(w_keep)
+            del w_keep, tower_s
+            extra['train_step_ssm'] = {'ms_per_step': round(res_s['sharded'], 4), 'M_triplets_s': round(world * B * n / res_s['sharded'] / 1e3, 2),
+                                       'world1_reference_ms': round(res_s['world1'], 4),
+                                       'efficiency_vs_world1': round(res_s['world1'] / res_s['sharded'], 4),
+                                       'loss_on_owners': bool(ssm_own),
+                                       'what': 'in-place SGD training step (SampledSoftmaxLoss) evaluated on the owners: walk (z, per-query '
+                                               'max / sum / weighted-row partials), all-reduce of 8 bytes per query, finish (d, query '
+                                               'gradient from the partials, sorted apply of every touched row)'}
+        except Exception as e:
+            extra['train_step_ssm'] = {'error': repr(e)[:300]}
         # the exact (variable-split, host read-back) exchange
         try:
             exact = shard.ShardedItemTable(item_local, plan, rank, dist, exchange='exact', check_every=0, force_collectives=True)
