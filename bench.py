@@ -822,14 +822,16 @@ def main():
                     'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': None,
                     'alg_bytes_per_launch': int(alg), 'avg_kernel_ms': round(k_avg, 4),
                     'median_kernel_ms': round(k_ms[len(k_ms) // 2], 4)}
-        # The same launch on OTHER allocations of its output buffers (on some boxes some allocations are 10-15 % slower
-        # to write into -- bimodal, stable for the life of the allocation, independent of the layout inside it; `frac` above is
-        # whatever the first allocation of this process got): three more output sets, all kept alive so that each is a new
-        # allocation, the kernel alone between events as above
+        # The same launch on OTHER allocations of its output buffers (some physical regions of the HBM are 10-15 % slower
+        # to write into under read load -- bimodal, stable for the life of the allocation, independent of the layout inside it;
+        # recstudio_amd.placement probes candidates and keeps the fast class): three more output sets from PLAIN allocations,
+        # all kept alive so that each is a new allocation, the kernel alone between events as above
         try:
+            from recstudio_amd import placement
             held, per_alloc = [hb['step']], [round(k_avg, 4)]
             for _ in range(3):
-                o2 = ra.ops.fused_forward(item, user, n, fused_bpr=True, want_mean=False, **fresh_kw())
+                with placement.disabled():        # plain torch allocations: whatever class they land in
+                    o2 = ra.ops.fused_forward(item, user, n, fused_bpr=True, want_mean=False, **fresh_kw())
                 held.append(o2)
 
                 def on_o2(o2=o2):
@@ -843,7 +845,10 @@ def main():
                 torch.cuda.synchronize()
                 per_alloc.append(round(e0.elapsed_time(e1) / args.steps, 4))
             roofline['kernel_ms_by_output_allocation'] = per_alloc
+            roofline['kernel_ms_by_output_allocation_what'] = ('first: the allocation the headline ran on (chosen by recstudio_amd.'
+                                                               'placement unless RSA_PLACEMENT=0); then three plain torch allocations')
             roofline['best_allocation_frac'] = round(alg / (min(per_alloc) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+            roofline['placement'] = placement.summary(dev)
             del held, o2
         except Exception as e:
             roofline['kernel_ms_by_output_allocation_error'] = repr(e)[:120]

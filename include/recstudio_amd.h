@@ -858,6 +858,16 @@ int rsa_shard_owner_bpr_finish(const rsa_shard_owner_bpr_args* args, const float
 int rsa_shard_owner_ssm_forward(const rsa_shard_owner_bpr_args* args, rsa_stream_t stream);
 int rsa_shard_owner_ssm_finish(const rsa_shard_owner_bpr_args* args, const float* lse_all, rsa_stream_t stream);
 
+/* Placement probe (no reference counterpart: the reference allocates through torch and never looks).  On MI355X the same
+ * launch runs 10-15 % slower when the buffers it WRITES live in certain physical regions of the HBM (per allocation, stable,
+ * visible only under concurrent read load -- DESIGN.md 6, profiles/r05_output_placement.json).  This launch reproduces the
+ * access pattern of the fused forward without its arithmetic: per tile of 64 elements 64 random 512-byte rows read from
+ * `source` (any resident buffer much larger than the 256 MB Infinity Cache; its contents do not matter) and 512 + 3 x 256 + 16
+ * bytes written over `region` (four arrays at quarter offsets, at most 65536 tiles).  A caller times it (events on `stream`)
+ * on candidate allocations and keeps the fastest: recstudio_amd/placement.py.  region: 256-byte aligned, >= 1 MiB, OVERWRITTEN. */
+int rsa_placement_probe(void* region, int64_t region_bytes, const void* source, int64_t source_bytes, uint32_t salt,
+                        rsa_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -224,6 +224,7 @@ SIGNATURES = {
     'rsa_bpr_sgd_apply': (c_int, [POINTER(BprSgdArgs), c_void_p]),
     'rsa_probs_t_query': (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int32, c_void_p, c_void_p]),
     'rsa_rng_advance': (c_int, [c_void_p, c_uint64, c_void_p]),
+    'rsa_placement_probe': (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_uint32, c_void_p]),
     'rsa_row_topk': (c_int, [c_void_p, c_int64, c_int64, c_int32, c_void_p, c_void_p, c_void_p]),
     'rsa_topk_mask_history': (c_int, [c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_int64, c_int32, c_void_p,
                                       c_void_p, c_void_p]),

@@ -86,6 +86,40 @@ __global__ __launch_bounds__(256) void row_sqnorm_kernel(const float* __restrict
   }
 }
 
+// Placement probe (rsa_placement_probe): the access pattern of the fused forward without its arithmetic -- per tile of 64
+// elements 64 random 512-byte rows read from `source`, 512 B + 3 x 256 B written to four arrays laid over `region` at quarter
+// offsets, 4 x 4 B to per-tile arrays behind them.  Reads and writes together: the writes of a stand-alone write stream never
+// leave the 256 MB Infinity Cache, it is under read load that the two classes of allocations differ.
+__global__ __launch_bounds__(256) void placement_probe_kernel(char* __restrict__ region, int64_t quarter, uint32_t n_tiles,
+                                                               const float4* __restrict__ source, uint32_t n_rows, uint32_t salt) {
+  const uint32_t wave = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63, n_waves = gridDim.x * 4;
+  char* ids = region;
+  char* f0 = region + quarter;
+  char* f1 = region + 2 * quarter;
+  char* f2 = region + 3 * quarter;
+  char* s0 = f2 + (size_t)n_tiles * 256;
+  auto mix = [](uint32_t x) { x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16; return x; };
+  for (uint32_t t = wave; t < n_tiles; t += n_waves) {
+    float acc = 0.f;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+      float4 v[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {            // 2 half-waves x 16 rows x 2 passes = 64 rows per tile
+        const uint32_t r = mix((t * 64 + pass * 32 + u * 2 + (lane >> 5)) ^ salt) % n_rows;
+        v[u] = source[(size_t)r * 32 + (lane & 31)];
+      }
+#pragma unroll
+      for (int u = 0; u < 16; ++u) acc += v[u].x + v[u].w;
+    }
+    reinterpret_cast<int64_t*>(ids + (size_t)t * 512)[lane] = (int64_t)lane + (int64_t)acc;
+    reinterpret_cast<float*>(f0 + (size_t)t * 256)[lane] = acc;
+    reinterpret_cast<float*>(f1 + (size_t)t * 256)[lane] = acc + 1.f;
+    reinterpret_cast<float*>(f2 + (size_t)t * 256)[lane] = acc + 2.f;
+    if (lane < 4) reinterpret_cast<float*>(s0 + (size_t)lane * n_tiles * 4)[t] = acc;
+  }
+}
+
 }  // namespace rsa
 
 using namespace rsa;
@@ -152,5 +186,22 @@ extern "C" int rsa_row_sqnorm(const float* table, int64_t n_rows, int32_t dim, i
   hipLaunchKernelGGL(rsa::row_sqnorm_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, table, n_rows,
                      (int)dim, (int)score_mode, out);
   RSA_CHECK_LAUNCH("rsa_row_sqnorm");
+  return RSA_OK;
+}
+
+extern "C" int rsa_placement_probe(void* region, int64_t region_bytes, const void* source, int64_t source_bytes, uint32_t salt,
+                                   rsa_stream_t stream) {
+  RSA_CHECK_ARG(region && source, "rsa_placement_probe: null pointer");
+  RSA_CHECK_ARG(region_bytes >= (int64_t)1 << 20 && source_bytes >= (int64_t)1 << 20, "rsa_placement_probe: region and source must hold at least 1 MiB");
+  RSA_CHECK_ARG(((uintptr_t)region & 255) == 0 && ((uintptr_t)source & 15) == 0, "rsa_placement_probe: region must be 256-byte, source 16-byte aligned");
+  // four arrays at quarter offsets; the first needs 512 B per tile, the last 256 B + 16 B per tile
+  const int64_t quarter = region_bytes / 4 / 256 * 256;
+  int64_t tiles = quarter / 512;
+  if (tiles > 65536) tiles = 65536;
+  const int64_t rows = source_bytes / 512;
+  RSA_CHECK_ARG(tiles >= 1 && rows >= 1 && rows <= 0xffffffffLL, "rsa_placement_probe: bad sizes");
+  hipLaunchKernelGGL(placement_probe_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, (char*)region, quarter, (uint32_t)tiles,
+                     (const float4*)source, (uint32_t)rows, salt);
+  RSA_CHECK_LAUNCH("rsa_placement_probe");
   return RSA_OK;
 }

@@ -10,7 +10,7 @@ import functools
 import torch
 
 from . import _native as nat
-from . import rng
+from . import placement, rng
 from ._native import ptr
 
 
@@ -290,7 +290,7 @@ def carve(dev, specs, align=4096):
     84 MB of the 2.8 GB it moves) ran 404-409 us on every one of 31 layouts of those arrays inside one allocation (any skew
     between them, any shift, arenas of 86 MB .. 1 GB) and 443-471 us on 5 of 9 sets of separately allocated arrays of the same
     shapes in the same processes (tools/exp_outbuf.py, exp_outliers.py; moving any ONE of the four into an arena did not help).
-    That lottery -- not the box -- was most of the 405-482 us run-to-run spread of rounds 3-5."""
+    The class belongs to the allocation: ``placement.pick`` probes candidates and returns one of the fast class."""
     offs, total = [], 0
     for _, shape, dtype in specs:
         cnt = 1
@@ -298,7 +298,7 @@ def carve(dev, specs, align=4096):
             cnt *= int(v)
         offs.append((total, cnt))
         total += (cnt * torch.empty((), dtype=dtype).element_size() + align - 1) // align * align
-    arena = torch.empty(max(total, align), dtype=torch.uint8, device=dev)
+    arena = placement.pick(max(total, align), dev)          # of the fast class of allocations when it is large enough to matter
     out = {}
     for (key, shape, dtype), (off, cnt) in zip(specs, offs):
         nb = cnt * torch.empty((), dtype=dtype).element_size()

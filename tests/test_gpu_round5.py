@@ -138,3 +138,44 @@ def test_full_softmax_backward_has_no_library_gemm(ra):
     torch.testing.assert_close(w.grad.double(), wd.grad, rtol=2e-4, atol=1e-9)
     torch.testing.assert_close(q.grad.double(), qd.grad, rtol=2e-4, atol=1e-9)
     assert bool((w.grad[0] == 0).all())
+
+
+def test_placement_changes_addresses_only(ra, monkeypatch):
+    """recstudio_amd.placement: output arenas of >= MIN_BYTES are probed (rsa_placement_probe) and taken from the fast class of
+    allocations; verdicts are cached by address; smaller arenas and ``placement.disabled()`` are plain torch allocations; the
+    results of a launch do not depend on any of it."""
+    from recstudio_amd import placement
+    nat = ra._native
+    dev = torch.device(DEV)
+    monkeypatch.setattr(placement, 'SOURCE_BYTES', 320 << 20)
+    monkeypatch.setattr(placement, 'SPACER_BYTES', 64 << 20)
+    before = placement.summary(dev)['probes']
+    buf = placement.pick(48 << 20, dev)
+    assert buf.dtype == torch.uint8 and buf.numel() == 48 << 20 and buf.device == dev
+    after = placement.summary(dev)
+    assert 1 <= after['probes'] - before <= placement.MAX_TRIES and after['picked'] >= 1
+    us = placement.probe_us(buf)
+    assert 5 < us < 5000
+    again = placement.summary(dev)['probes']
+    with placement.disabled():
+        plain = placement.pick(48 << 20, dev)
+    assert placement.summary(dev)['probes'] == again and plain.numel() == 48 << 20
+    assert placement.pick(1 << 20, dev).numel() == 1 << 20 and placement.summary(dev)['probes'] == again       # too small to probe
+    # argument checks of the entry point
+    lib = nat.lib()
+    assert lib.rsa_placement_probe(None, 1 << 20, None, 1 << 20, 0, None) == -1 and b'null pointer' in lib.rsa_last_error()
+    assert lib.rsa_placement_probe(buf.data_ptr(), 4096, buf.data_ptr(), 1 << 20, 0, None) == -1
+    # a launch whose outputs are placed == the same launch on plain allocations
+    N, U, d, B, n = 300_001, 4001, 128, 32768, 64                     # 32768 x 64 outputs: a 42 MB arena
+    g = torch.Generator(device=DEV).manual_seed(5)
+    item = torch.randn(N, d, device=DEV, generator=g) * 0.1
+    user = torch.randn(U, d, device=DEV, generator=g) * 0.1
+    uid = torch.randint(1, U, (B,), device=DEV, generator=g)
+    pos = torch.randint(1, N, (B,), device=DEV, generator=g)
+    torch.manual_seed(9)
+    placed = ra.ops.fused_forward(item, user, n, query_index=uid, pos_ids=pos, fused_bpr=True, sampler=nat.SAMPLER_UNIFORM)
+    torch.manual_seed(9)
+    with placement.disabled():
+        plain = ra.ops.fused_forward(item, user, n, query_index=uid, pos_ids=pos, fused_bpr=True, sampler=nat.SAMPLER_UNIFORM)
+    for k in ('neg_ids', 'neg_score', 'dneg', 'row_loss', 'dpos', 'loss'):
+        assert torch.equal(placed[k], plain[k]), k

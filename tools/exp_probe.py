@@ -74,30 +74,50 @@ def run(o):
 
 
 import ctypes                                   # noqa: E402
-lib = ctypes.CDLL(os.path.join(ROOT, 'tools', 'exp_tlb', 'libprobe.so'))
-lib.probe_stream.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
-lib.probe_tiles.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int, ctypes.c_void_p]
+from recstudio_amd import placement             # noqa: E402
+lib = nat.lib()
 stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-T = B            # tiles of the headline launch; the pattern needs T * (512 + 3 * 256 + 16) B = 84.9 MB
 
 
-def probe(kind, a):
+def probe_with(a, src):
     def fn():
-        if kind == 'stream':
-            lib.probe_stream(a.data_ptr(), 96 << 20, stream)
-        elif kind == 'tiles':
-            lib.probe_tiles(a.data_ptr(), T, None, 0, 0, 2048, stream)
-        elif kind == 'tiles_small_grid':
-            lib.probe_tiles(a.data_ptr(), T, None, 0, 0, 512, stream)
-        else:
-            lib.probe_tiles(a.data_ptr(), T, item.data_ptr(), N, 7, 2048, stream)
-    return timed(fn, k=40, warm=0.1)
+        lib.rsa_placement_probe(ctypes.c_void_p(a.data_ptr()), a.numel(), ctypes.c_void_p(src.data_ptr()), src.numel() * src.element_size(), 7, stream)
+    return timed(fn, k=20, warm=0.05)
 
 
 res = {'arena': []}
 for a in arenas:
-    rec = {'va': hex(a.data_ptr()), 'us': run(build(a, a))}
-    for kind in ('stream', 'tiles', 'tiles_small_grid', 'tiles_reads'):
-        rec[kind] = probe(kind, a)
-    res['arena'].append(rec)
+    res['arena'].append({'va': hex(a.data_ptr()), 'probe': round(placement.probe_us(a), 1)})
+order = sorted(range(len(arenas)), key=lambda i: res['arena'][i]['probe'])
+f1, f2, s1, s2 = order[0], order[1], order[-1], order[-2]
+res['fast_slow'] = [f1, f2, s1, s2]
+
+
+def ids_in(a):
+    """uid / pos copied into arena `a` (behind where the outputs would be: the last 2 MB)"""
+    base = a.numel() - (2 << 20)
+    u = a[base:base + B * 8].view(torch.int64)
+    p = a[base + (1 << 20):base + (1 << 20) + B * 8].view(torch.int64)
+    u.copy_(uid)
+    p.copy_(pos)
+    return u, p
+
+
+def run_with(out_arena, id_arena):
+    o = build(out_arena, out_arena)
+    u, p = ids_in(id_arena)
+    kw2 = dict(kw)
+
+    def step():
+        ra.ops.fused_forward(item, user, n, out=o, fused_bpr=True, query_index=u, pos_ids=p, **kw2)
+    return timed(step)
+
+
+res['out_fast_ids_original'] = run(build(arenas[f1], arenas[f1]))
+res['out_fast_ids_fast'] = run_with(arenas[f1], arenas[f2])
+res['out_fast_ids_slow'] = run_with(arenas[f1], arenas[s1])
+res['out_slow_ids_fast'] = run_with(arenas[s1], arenas[f2])
+res['out_slow_ids_slow'] = run_with(arenas[s1], arenas[s2])
+# the user table (512 MB, read: one row per query) copied into four fast / four slow arenas is too big for one arena; the
+# sampler's small tables instead: pop_prob / table views are left alone
 print(json.dumps(res))
