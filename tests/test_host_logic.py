@@ -371,3 +371,30 @@ def test_shard_tickets_are_claimed_once_in_order_for_their_batch():
     t._claim(tc, pos_a, 'step')                                  # tb abandoned: skipping forward is allowed ...
     with pytest.raises(ValueError, match='consumed once'):
         t._claim(tb, pos_b, 'step', want_ids=False)              # ... going back is not
+
+
+def test_placement_is_inert_off_the_gpu_and_when_disabled():
+    """recstudio_amd.placement only ever changes WHERE a buffer lives: off the GPU, below MIN_BYTES, or inside ``disabled()`` it
+    is a plain allocation and no probe runs; ``ops.carve`` hands out views of one allocation either way."""
+    import torch
+    from recstudio_amd import ops, placement
+    cpu = torch.device('cpu')
+    t = placement.pick(placement.MIN_BYTES * 2, cpu)
+    assert t.dtype == torch.uint8 and t.numel() == placement.MIN_BYTES * 2 and not placement._state
+    with placement.disabled():
+        assert placement._off[0] == 1
+        with placement.disabled():
+            assert placement._off[0] == 2
+    assert placement._off[0] == 0
+    assert placement._tiles(128 << 20) == 65536 and placement._tiles(32 << 20) == 16384
+    out = ops.carve(cpu, [('ids', (5, 3), torch.int64), ('loss', (), torch.float32), ('none', (0, 3), torch.float32),
+                          ('row', (5,), torch.float32)])
+    assert out['ids'].shape == (5, 3) and out['loss'].shape == () and out['none'].numel() == 0
+    base = out['ids'].untyped_storage().data_ptr()
+    assert all(v.untyped_storage().data_ptr() == base for v in out.values())            # one allocation
+    offs = sorted(v.data_ptr() - base for v in out.values() if v.numel())
+    assert all(o % 4096 == 0 for o in offs) and len(set(offs)) == len(offs)             # 4 KiB-aligned, disjoint
+    out['ids'].fill_(7)
+    out['row'].fill_(1.5)
+    out['loss'].fill_(2.0)
+    assert int(out['ids'].sum()) == 105 and float(out['row'].sum()) == 7.5 and float(out['loss']) == 2.0
