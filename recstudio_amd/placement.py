@@ -29,7 +29,7 @@ SOURCE_BYTES = 1 << 30        # read source of the probe: must dwarf the 256 MB 
 SPACER_BYTES = 768 << 20      # consecutive allocations are physical neighbours and share a class: skip ahead between candidates
 TOLERANCE = 1.05              # the classes are 10-15 % apart, repeats of one class within 1 %
 MAX_TRIES = 6
-WARM_S = 0.6                  # seconds of probe launches before a measurement when the GPU may have idled ...
+WARM_S = float(os.environ.get('RSA_PLACEMENT_WARM_S', '0.6'))   # seconds of probe launches before a measurement when the GPU may have idled ...
 WARM_GAP_S = 0.25             # ... i.e. when the last probe ended longer ago than this
 MAX_PROBES = 256              # per device and process: bounds the cost under allocation churn
 HELD_CAP = 8 << 30            # bytes of slow-class memory kept out of circulation per device
