@@ -75,7 +75,7 @@ def probe_us(buf, dev=None):
     dev = buf.device if dev is None else dev
     st = _st(dev)
     if st['source'] is None:
-        st['source'] = torch.empty(SOURCE_BYTES, dtype=torch.uint8, device=dev)
+        st['source'] = torch.empty(SOURCE_BYTES, dtype=torch.uint8, device=dev)      # (pick() has checked that there is room)
     lib, src = nat.lib(), st['source']
     stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 
@@ -111,6 +111,15 @@ def pick(nbytes, dev):
     if (not ENABLED or _off[0] or dev.type != 'cuda' or nbytes < MIN_BYTES or torch.cuda.is_current_stream_capturing()):
         return torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev)
     st, tiles = _st(dev), _tiles(nbytes)
+    if st.get('no_room'):
+        return torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    if st['source'] is None:
+        # choosing needs head-room: the probe's 1 GiB read source, candidates, spacers.  A job that fills the HBM (a 51 GB table
+        # with three optimizer states) gets plain allocations rather than an out-of-memory error from a placement attempt.
+        free, _ = torch.cuda.mem_get_info(dev)
+        if free < SOURCE_BYTES + MAX_TRIES * (nbytes + SPACER_BYTES) + (4 << 30):
+            st['no_room'] = True
+            return torch.empty(nbytes, dtype=torch.uint8, device=dev)
     epoch = _epoch(dev)
     if epoch != st.get('epoch'):
         st['known'].clear()                  # addresses may have been re-backed since the verdicts were taken
@@ -118,7 +127,12 @@ def pick(nbytes, dev):
     cands, spacers = [], []
     calibrated = tiles in st['best']
     for i in range(MAX_TRIES):
-        t = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        try:
+            t = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        except torch.cuda.OutOfMemoryError:
+            if not cands:
+                raise                        # the caller's own allocation does not fit: its error
+            break
         key = (t.data_ptr(), nbytes)
         us = st['known'].get(key)
         if us is None:
@@ -132,7 +146,10 @@ def pick(nbytes, dev):
         if us <= st['best'][tiles] * TOLERANCE and (calibrated or hi > lo * TOLERANCE):
             break            # of the fast class: as good as the best ever seen here and (first time) we have seen a slower one
         if i + 1 < MAX_TRIES:
-            spacers.append(torch.empty(SPACER_BYTES, dtype=torch.uint8, device=dev))
+            try:
+                spacers.append(torch.empty(SPACER_BYTES, dtype=torch.uint8, device=dev))
+            except torch.cuda.OutOfMemoryError:
+                break
     us, chosen = min(cands, key=lambda c: c[0])
     for u, t in cands:
         if t is chosen:
