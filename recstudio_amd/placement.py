@@ -27,8 +27,10 @@ ENABLED = os.environ.get('RSA_PLACEMENT', '1') != '0'
 MIN_BYTES = 32 << 20          # smaller arenas are not probed (a 25 us probe cannot tell the classes apart)
 SOURCE_BYTES = 1 << 30        # read source of the probe: must dwarf the 256 MB Infinity Cache
 SPACER_BYTES = 768 << 20      # consecutive allocations are physical neighbours and share a class: skip ahead between candidates
-TOLERANCE = 1.05              # the classes are 10-15 % apart, repeats of one class within 1 %
+TOLERANCE = 1.06              # the classes are 10-15 % apart, repeats of one class within 1 %, arena sizes within 3 %
 MAX_TRIES = 6
+BUCKET_BYTES = 16 << 20       # arenas are rounded up to this: a caller whose sizes wander (ragged batches) keeps hitting the same
+                              # recycled blocks -- and their cached verdicts -- instead of probing a new size every step
 WARM_S = float(os.environ.get('RSA_PLACEMENT_WARM_S', '0.6'))   # seconds of probe launches before a measurement when the GPU may have idled ...
 WARM_GAP_S = 0.25             # ... i.e. when the last probe ended longer ago than this
 MAX_PROBES = 256              # per device and process: bounds the cost under allocation churn
@@ -85,7 +87,7 @@ def probe_us(buf, dev=None):
     # the chip runs the same launch 7-11 % slower for about a second after it idled: a probe taken cold would read
     # as the slow class.  Keep the GPU busy with the probe itself first when the last probe was a while ago.
     now = time.perf_counter()
-    if now - st.get('last_busy', 0.0) > WARM_GAP_S:
+    if now - st.get('last_busy', 0.0) > WARM_GAP_S and torch.cuda.current_stream(dev).query():     # (work pending: not idle)
         t_end = now + WARM_S
         while time.perf_counter() < t_end:
             for w in range(50):
@@ -104,13 +106,21 @@ def probe_us(buf, dev=None):
     return e0.elapsed_time(e1) / 3 * 1e3
 
 
+def _ns_per_tile(us, nbytes):
+    """The probe's time per tile: 4.99 .. 5.14 ns over 16 K .. 64 K tiles on the fast class (5.7 on the slow one), so ONE
+    reference per device serves every arena size."""
+    return us * 1e3 / max(_tiles(nbytes), 1)
+
+
 def pick(nbytes, dev):
-    """A uint8 buffer of ``nbytes`` on ``dev`` from the fast class of allocations (see the module docstring); a plain
-    ``torch.empty`` when placement is off, the buffer is small, the stream is being captured or the probe budget is spent."""
+    """A uint8 buffer of at least ``nbytes`` (rounded up to BUCKET_BYTES) on ``dev`` from the fast class of allocations (see
+    the module docstring); a plain ``torch.empty`` when placement is off, the buffer is small, the stream is being captured,
+    the HBM is nearly full or the probe budget is spent."""
     nbytes = int(nbytes)
     if (not ENABLED or _off[0] or dev.type != 'cuda' or nbytes < MIN_BYTES or torch.cuda.is_current_stream_capturing()):
         return torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev)
-    st, tiles = _st(dev), _tiles(nbytes)
+    nbytes = (nbytes + BUCKET_BYTES - 1) // BUCKET_BYTES * BUCKET_BYTES
+    st = _st(dev)
     if st.get('no_room'):
         return torch.empty(nbytes, dtype=torch.uint8, device=dev)
     if st['source'] is None:
@@ -125,7 +135,7 @@ def pick(nbytes, dev):
         st['known'].clear()                  # addresses may have been re-backed since the verdicts were taken
         st['epoch'] = epoch
     cands, spacers = [], []
-    calibrated = tiles in st['best']
+    calibrated = st.get('ref') is not None   # ref: the best ns per tile any candidate on this device ever reached
     for i in range(MAX_TRIES):
         try:
             t = torch.empty(nbytes, dtype=torch.uint8, device=dev)
@@ -134,31 +144,32 @@ def pick(nbytes, dev):
                 raise                        # the caller's own allocation does not fit: its error
             break
         key = (t.data_ptr(), nbytes)
-        us = st['known'].get(key)
-        if us is None:
+        v = st['known'].get(key)
+        if v is None:
             if st['probes'] >= MAX_PROBES:
-                cands.append((st['best'].get(tiles, 0.0), t))        # budget spent: take it as it comes
+                cands.append((st.get('ref') or 0.0, t))              # budget spent: take it as it comes
                 break
-            us = st['known'][key] = probe_us(t, dev)
-        cands.append((us, t))
-        st['best'][tiles] = min(st['best'].get(tiles, us), us)
+            v = st['known'][key] = _ns_per_tile(probe_us(t, dev), nbytes)
+        cands.append((v, t))
+        st['ref'] = v if st.get('ref') is None else min(st['ref'], v)
+        st['best'][_tiles(nbytes)] = min(st['best'].get(_tiles(nbytes), v), v)
         lo, hi = min(c[0] for c in cands), max(c[0] for c in cands)
-        if us <= st['best'][tiles] * TOLERANCE and (calibrated or hi > lo * TOLERANCE):
+        if v <= st['ref'] * TOLERANCE and (calibrated or hi > lo * TOLERANCE):
             break            # of the fast class: as good as the best ever seen here and (first time) we have seen a slower one
         if i + 1 < MAX_TRIES:
             try:
                 spacers.append(torch.empty(SPACER_BYTES, dtype=torch.uint8, device=dev))
             except torch.cuda.OutOfMemoryError:
                 break
-    us, chosen = min(cands, key=lambda c: c[0])
+    v, chosen = min(cands, key=lambda c: c[0])
     for u, t in cands:
         if t is chosen:
             continue
-        if u > st['best'][tiles] * TOLERANCE and st['held_bytes'] + nbytes <= HELD_CAP:
+        if u > st['ref'] * TOLERANCE and st['held_bytes'] + nbytes <= HELD_CAP:
             st['held'].append(t)                     # slow class: never goes back to the caching allocator
             st['held_bytes'] += nbytes
             st['rejected'] += 1
-        st['worst_over_best'] = max(st['worst_over_best'], u / max(st['best'][tiles], 1e-9))
+        st['worst_over_best'] = max(st['worst_over_best'], u / max(st['ref'], 1e-9))
     del spacers, cands
     st['picked'] += 1
     return chosen
@@ -169,4 +180,5 @@ def summary(dev):
     st = _st(dev)
     return {'enabled': bool(ENABLED), 'probes': st['probes'], 'picked': st['picked'], 'rejected_slow': st['rejected'],
             'held_MB': st['held_bytes'] >> 20, 'slowest_over_fastest_probe': round(st['worst_over_best'], 3),
-            'probe_us_best_by_tiles': {str(k): round(v, 1) for k, v in st['best'].items()}}
+            'probe_ns_per_tile_best': round(st['ref'], 3) if st.get('ref') else None,
+            'probe_ns_per_tile_best_by_tiles': {str(k): round(v, 3) for k, v in st['best'].items()}}
