@@ -12,13 +12,14 @@ OUT=$REPO/gpurun_out/prof_$ROUND
 DST=$REPO/gpurun_out/profiles_$ROUND
 mkdir -p $OUT $DST
 export TMPDIR=/tmp
+# (the counter passes need bytes, not times: no output-set selection, no placement probes -- every launch is serialised there)
 for s in $SHAPES; do
   cd /tmp
   for p in $PASSES; do
     case $p in
       trace) timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/$s/trace -o p -- python $REPO/tools/prof_shapes.py $s 100 > $OUT/$s.trace.log 2>&1 ;;
-      fetch) timeout 900 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/$s/fetch -o p -- env PROF_WARM_MS=0 python $REPO/tools/prof_shapes.py $s 8 > $OUT/$s.fetch.log 2>&1 ;;
-      write) timeout 900 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/$s/write -o p -- env PROF_WARM_MS=0 python $REPO/tools/prof_shapes.py $s 8 > $OUT/$s.write.log 2>&1 ;;
+      fetch) timeout 900 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/$s/fetch -o p -- env PROF_WARM_MS=0 PROF_OUT_SETS=1 RSA_PLACEMENT=0 python $REPO/tools/prof_shapes.py $s 8 > $OUT/$s.fetch.log 2>&1 ;;
+      write) timeout 900 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/$s/write -o p -- env PROF_WARM_MS=0 PROF_OUT_SETS=1 RSA_PLACEMENT=0 python $REPO/tools/prof_shapes.py $s 8 > $OUT/$s.write.log 2>&1 ;;
     esac
   done
   cd $REPO
