@@ -844,15 +844,18 @@ int rsa_shard_owner_bpr_finish(const rsa_shard_owner_bpr_args* args, const float
 /* SampledSoftmaxLoss (recstudio/model/loss_func.py:80-90, one positive per row) evaluated ON THE OWNERS of the negatives, for the
  * same routed step (positives not routed, pos_rows per rank): loss_q = logsumexp(z_pos, z_1 .. z_n) - z_pos with z = score -
  * log q spans all owners of a query's negatives, so the owner pass has two phases around an 8-byte-per-query all-reduce:
- *   rsa_shard_owner_ssm_forward  sort by row (no solo classification: no row is updated by a walk in this step), the queries'
+ *   rsa_shard_owner_ssm_forward  sort by row (in place, i.e. item_target == item_local: + the solo classification), the queries'
  *     runs, and ONE walk over the received negatives' rows: z per slot (d_slots), and per query over this owner's slots
  *     run_max = max z, run_sum = sum exp(z - run_max), run_acc = sum exp(z - run_max) * row (flash-attention style partials);
  *   [caller: m = max(z_pos, all-reduce-max(run_max)); s = all-reduce-sum(run_sum * exp(run_max - m));
  *            lse = m + log(s + exp(z_pos - m))]
  *   rsa_shard_owner_ssm_finish   (args.pos_score = z_pos) d = exp(z - lse) / mean_den per slot; qgrad_all += gate *
  *     exp(run_max - lse) / mean_den * run_acc -- the query gradient needs NO second pass over the rows --; the positives'
- *     owners add (softmax_pos - 1) / mean_den * row_pos; every touched item row gets gate * item_scale * sum d * q through the
- *     sorted apply pass.
+ *     owners add (softmax_pos - 1) / mean_den * row_pos; every touched item row gets gate * item_scale * sum d * q: into a
+ *     gradient block through the sorted apply pass; in place, the rows ONE element of the step touches from a second walk by
+ *     query (the query row in registers, d from the z phase 1 left per slot: no dot product, no query row per element) and
+ *     only the rows several elements touch through the sorted apply pass -- 3 row transfers per negative and B query rows
+ *     instead of one per element.
  * The loss itself is lse - z_pos on the caller's side.  No scores travel home, no score gradients travel back (8 instead of
  * 16 bytes per triplet over xGMI).  dims in {64, 128, 256}; same workspace as the BPR form. */
 int rsa_shard_owner_ssm_forward(const rsa_shard_owner_bpr_args* args, rsa_stream_t stream);

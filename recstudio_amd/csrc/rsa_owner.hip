@@ -32,6 +32,9 @@
 #ifndef RSA_OWN_MIN_WAVES
 #define RSA_OWN_MIN_WAVES 1
 #endif
+#ifndef RSA_SSM_UPDATE_WALK
+#define RSA_SSM_UPDATE_WALK 1   // SampledSoftmax on the owners, in place: solo rows from the second walk by query (0: every element through the sorted apply)
+#endif
 
 namespace rsa {
 
@@ -278,7 +281,8 @@ __global__ __launch_bounds__(256, RSA_OWN_MIN_WAVES) void owner_backward_walk_ke
 // the flash-attention style partials over ITS slots -- m = max z, s = sum exp(z - m), acc = sum exp(z - m) * row -- plus z
 // per slot.  After an 8-byte-per-query all-reduce (max, then the rescaled sums) every rank knows logsumexp_q, and phase 2
 // needs no row for the QUERY gradient any more: qgrad += exp(m - lse) / M * acc.  The item rows get their update
-// d_j * q, d_j = exp(z_j - lse) / M, through the sorted apply pass (one read-modify-write per touched row).
+// d_j * q, d_j = exp(z_j - lse) / M, in place: rows ONE element touches from a second walk by query (the query row in
+// registers, owner_ssm_update_walk_kernel), the shared ones from the sorted apply pass -- one read-modify-write per touched row.
 // 64 elements of one query: lane r holds element r's row and log q (+inf for an idle lane: z = -inf, weight 0).
 template <int LPR, bool NT>
 __device__ __forceinline__ void tile_rows_ssm(const float* table, int32_t id_lane, float lq_lane, const Frag<LPR, false>& qf,
@@ -454,6 +458,96 @@ __global__ __launch_bounds__(256) void owner_ssm_query_kernel(const float* __res
   }
 }
 
+// phase 2, the rows ONE element of the step touches (in-place SGD): a second walk by query.  The sorted apply pass reads a
+// query row per ELEMENT (elements in row order hit random query rows: 4.2 M x 512 B at configs[3]'s per-GPU shape, as much
+// again as the rows themselves); here a run is one query, its row sits in registers, and a solo row is rewritten as
+// row + upd * (d * q) by the lane group that read it -- the in-forward update of the BPR walk, the apply pass's arithmetic
+// rounding for rounding.  d = exp(z - lse) / M comes from the z phase 1 left per slot (no second dot product); the rows
+// several elements touch get their d written back and go through the sorted apply pass, which skips everything flagged solo.
+// The tile's solo elements are compacted first (ds_permute: solo lane -> lane rank) so that every row request is a real one.
+template <int LPR, bool NT>
+__global__ __launch_bounds__(256, RSA_OWN_MIN_WAVES) void owner_ssm_update_walk_kernel(const OwnArgs a, const float* __restrict__ lse,
+                                                                                       const int wpq_log2) {
+  using F = Frag<LPR, false>;
+  constexpr int D = LPR * 4;
+  constexpr int G = 64 / LPR;                                    // lane groups per wave: rows in flight per request slot
+  constexpr int BATCH = RSA_OWN_BATCH;
+  constexpr int NB = (LPR + BATCH - 1) / BATCH;                  // batches that cover a full tile (64 solo elements)
+  const int lane = lane_id();
+  const int sub = lane % LPR, grp = lane / LPR;
+  const int wave = threadIdx.x >> 6;
+  const int wpq = 1 << wpq_log2, qpb = 4 >> wpq_log2;
+  const int qslot = wave >> wpq_log2, part = wave & (wpq - 1);
+  const float upd = a.scale[0];
+  const int64_t groups = ((int64_t)a.n_queries + qpb - 1) / qpb;
+  for (int64_t gq = blockIdx.x; gq < groups; gq += gridDim.x) {
+    const int64_t m = gq * qpb + qslot;
+    if (m >= a.n_queries) continue;                              // wave-uniform (no workgroup barrier in this kernel)
+    const int32_t rs = a.run_start[m], re = a.run_end[m];
+    if (re <= rs) continue;
+    F qf;
+    frag_load<LPR, false>(qf, a.q_all + (size_t)m * D, sub, D);
+    const float4 qv = qf.v[0];
+    const float lse_m = lse[m];
+    const int T = (re - rs + 63) >> 6;
+#pragma unroll 1
+    for (int t = part; t < T; t += wpq) {
+      const int32_t i = rs + (t << 6) + lane;
+      const bool act = i < re;
+      int32_t id = 0;
+      float dv = 0.f;
+      bool solo = false;
+      if (act) {
+        const uint32_t slot = a.qpairs ? rdx_val(a.qpairs[i]) : (uint32_t)i;
+        int64_t row = a.keys[slot] & 0xffffffffll;
+        row = row >= a.n_rows ? a.n_rows - 1 : row;              // never fault on a bad key
+        id = (int32_t)row;
+        dv = __expf(a.d_out[slot] - lse_m) * a.binv;
+        solo = a.solo[slot] != 0;
+        if (!solo) st_out(&a.d_out[slot], dv);                   // the apply pass's coefficient
+      }
+      const uint64_t mask = __ballot(solo);
+      const int cnt = __popcll(mask);                            // wave-uniform
+      if (cnt == 0) continue;
+      // compaction: solo lane -> lane (its rank among the solo lanes), the others behind them
+      const uint64_t below = mask & ((1ull << lane) - 1ull);
+      const int rank = solo ? __popcll(below) : cnt + (lane - __popcll(below));
+      const int32_t idc = __builtin_amdgcn_ds_permute(rank << 2, id);
+      const float dc = __int_as_float(__builtin_amdgcn_ds_permute(rank << 2, __float_as_int(dv)));
+      // compacted position p = (b * BATCH + k) * G + grp: the lane groups take alternate positions
+      F x[2][BATCH];
+      auto request = [&](int b) __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < BATCH; ++k) {
+          const int p = (b * BATCH + k) * G + grp;
+          const int32_t got = __shfl(idc, p, 64);                 // (unconditional: a shuffle under a lane predicate reads 0 from
+          const int32_t rid = p < cnt ? got : 0;                  //  the switched-off source lanes); past the last: row 0, always readable
+          frag_load<LPR, false, NT>(x[b & 1][k], a.item + (size_t)rid * D, sub, D);
+        }
+      };
+      request(0);
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        if (b * BATCH * G >= cnt) break;                         // wave-uniform
+        if (b + 1 < NB && (b + 1) * BATCH * G < cnt) request(b + 1);
+#pragma unroll
+        for (int k = 0; k < BATCH; ++k) {
+          const int p = (b * BATCH + k) * G + grp;
+          const int32_t rid = __shfl(idc, p, 64);
+          const float g = __shfl(dc, p, 64);
+          if (p < cnt) {                                          // lane-group uniform
+            const float4 xv = x[b & 1][k].v[0];
+            typedef float v4f __attribute__((ext_vector_type(4)));
+            v4f nv = {__fadd_rn(xv.x, __fmul_rn(upd, __fmul_rn(g, qv.x))), __fadd_rn(xv.y, __fmul_rn(upd, __fmul_rn(g, qv.y))),
+                      __fadd_rn(xv.z, __fmul_rn(upd, __fmul_rn(g, qv.z))), __fadd_rn(xv.w, __fmul_rn(upd, __fmul_rn(g, qv.w)))};
+            __builtin_nontemporal_store(nv, reinterpret_cast<v4f*>(a.item_rw + (size_t)rid * D + sub * 4));
+          }
+        }
+      }
+    }
+  }
+}
+
 // One lane group per query i: the POSITIVE's part of the step on the rank that owns its row (pos_rows[i] >= 0):
 // d loss/d pos = -(sum over all owners of the query's d) -> the coefficient slot behind the segments' (for the sorted
 // apply), qgrad_all[i] += gate * dpos * row, and -- when the row is the positive's alone -- the row's update in place.
@@ -599,7 +693,7 @@ struct OwnCommon {
   void* workspace;
   int64_t workspace_bytes;
   int keys_grouped;             // the router wrote query-grouped segments: no sort by query
-  int no_solo = 0;              // never classify (nothing updates rows in a walk: the SampledSoftmax step): every element is applied
+  int no_solo = 0;              // never classify: every element goes through the sorted apply pass
 };
 
 struct OwnPrepared {
@@ -852,8 +946,8 @@ extern "C" int rsa_shard_owner_ssm_forward(const rsa_shard_owner_bpr_args* a, rs
   RSA_CHECK_ARG(a->pos_rows && a->mean_den >= 1 && a->d_slots && a->run_max && a->run_sum && a->run_acc && a->q_all,
                 "rsa_shard_owner_ssm_forward: null pointer / bad sizes");
   hipStream_t s = (hipStream_t)stream;
-  OwnCommon c = bpr_common(a);
-  c.no_solo = 1;
+  OwnCommon c = bpr_common(a);            // (in place: the row sort also classifies the solo rows for phase 2)
+  c.no_solo = !RSA_SSM_UPDATE_WALK;
   OwnPrepared P;
   int rc = owner_prepare(c, P, OWN_PREP_ALL, s, "rsa_shard_owner_ssm_forward");
   if (rc != RSA_OK) return rc;
@@ -898,34 +992,32 @@ extern "C" int rsa_shard_owner_ssm_finish(const rsa_shard_owner_bpr_args* a, con
   RSA_CHECK_ARG(a->pos_score && a->qgrad_all && a->dsum_part && a->run_max && a->run_acc && a->d_slots,
                 "rsa_shard_owner_ssm_finish: null pointer (pos_score = z_pos, qgrad_all, dsum_part, run_max, run_acc, d_slots)");
   hipStream_t s = (hipStream_t)stream;
-  OwnCommon c = bpr_common(a);
-  c.no_solo = 1;
+  const OwnCommon c = bpr_common(a);
   OwnPrepared P;
   int rc = owner_prepare(c, P, OWN_PREP_LAYOUT, s, "rsa_shard_owner_ssm_finish");
   if (rc != RSA_OK) return rc;
+  if (!RSA_SSM_UPDATE_WALK) P.inplace = false;      // (A/B builds: nothing was classified, every element through the apply pass)
   const int64_t Q = a->n_query_rows;
   const float binv = 1.f / (float)a->mean_den;
-  if (P.slots > 0) {
-    int64_t blocks = (P.slots + 255) / 256;
-    if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(owner_ssm_d_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a->keys, P.slots, rdx_make_div32((uint64_t)a->stride),
-                       (int32_t)Q, lse_all, binv, a->d_slots);
-  }
-  // nothing is flagged solo in this step: the positives' owners only add their query-gradient term and leave d loss/d pos
-  // behind the slots' coefficients for the apply pass
-  if (hipMemsetAsync(P.W.solo + P.slots, 0, (size_t)Q, s) != hipSuccess) {
+  // In place (SGD applied by the kernels) the forward's row sort has flagged the rows one element touches: the positives'
+  // owners update such a row themselves, the second walk below the negatives'.  A gradient BLOCK takes every element through
+  // the apply pass (nothing was classified: the flags behind the slots' are cleared for the positives' kernel).
+  if (!P.inplace && hipMemsetAsync(P.W.solo + P.slots, 0, (size_t)Q, s) != hipSuccess) {
     rsa::set_error("rsa_shard_owner_ssm_finish: memset failed");
     return RSA_ERR_HIP;
   }
   int64_t blocks;
+  // per query: the query-gradient partials from the phase-1 accumulators, then the positives' terms (d loss/d pos behind the
+  // slots' coefficients for the apply pass; a positive alone on its row is updated here).  Both read rows as they were
+  // BEFORE this step's updates: a solo row belongs to one element, and the shared rows change in the apply pass only.
 #define RSA_SSM_FIN(LPR)                                                                                                  \
   blocks = (Q + 256 / LPR - 1) / (256 / LPR);                                                                             \
   if (blocks > 4096) blocks = 4096;                                                                                       \
   hipLaunchKernelGGL(owner_ssm_query_kernel<LPR>, dim3((unsigned)blocks), dim3(256), 0, s, a->run_max, a->run_acc, lse_all, \
                      a->pos_score, binv, a->scale_out, a->qgrad_all, a->dsum_part, (int32_t)Q);                           \
-  hipLaunchKernelGGL(owner_pos_finish_kernel<LPR>, dim3((unsigned)blocks), dim3(256), 0, s, a->item_local, (float*)nullptr, \
-                     a->q_all, a->qgrad_all, a->pos_rows, a->dsum_part, a->d_slots + P.slots, P.W.solo + P.slots,          \
-                     a->scale_out, a->n_rows, (int32_t)Q)
+  hipLaunchKernelGGL(owner_pos_finish_kernel<LPR>, dim3((unsigned)blocks), dim3(256), 0, s, a->item_local,                \
+                     P.inplace ? a->item_target : (float*)nullptr, a->q_all, a->qgrad_all, a->pos_rows, a->dsum_part,      \
+                     a->d_slots + P.slots, P.W.solo + P.slots, a->scale_out, a->n_rows, (int32_t)Q)
   switch (a->dim) {
     case 64: RSA_SSM_FIN(16); break;
     case 128: RSA_SSM_FIN(32); break;
@@ -933,6 +1025,34 @@ extern "C" int rsa_shard_owner_ssm_finish(const rsa_shard_owner_bpr_args* a, con
   }
 #undef RSA_SSM_FIN
   RSA_CHECK_LAUNCH("rsa_shard_owner_ssm_finish");
+  if (P.slots > 0 && !P.inplace) {          // z -> d for every slot
+    int64_t dblocks = (P.slots + 255) / 256;
+    if (dblocks > 8192) dblocks = 8192;
+    hipLaunchKernelGGL(owner_ssm_d_kernel, dim3((unsigned)dblocks), dim3(256), 0, s, a->keys, P.slots, rdx_make_div32((uint64_t)a->stride),
+                       (int32_t)Q, lse_all, binv, a->d_slots);
+    RSA_CHECK_LAUNCH("rsa_shard_owner_ssm_finish(d)");
+  } else if (P.slots > 0) {                 // the second walk by query: z -> d, solo rows rewritten with the query row in registers
+    OwnArgs o = walk_args(c, P, a->qgrad_all);
+    o.d_out = a->d_slots;
+    o.binv = binv;
+    const bool nt = (size_t)a->n_rows * a->dim * 4 > (512ull << 20);
+    const int64_t tiles_per_query = P.slots / (Q > 0 ? Q : 1) / 64;
+    const int wpq_log2 = tiles_per_query >= 8 ? 2 : (tiles_per_query >= 3 ? 1 : 0);
+    const int qpb = 4 >> wpq_log2;
+    int64_t wblocks = (Q + qpb - 1) / qpb;
+    if (wblocks > 4096) wblocks = 4096;
+#define RSA_SSM_UPD(LPR)                                                                                                          \
+  if (nt) hipLaunchKernelGGL((owner_ssm_update_walk_kernel<LPR, true>), dim3((unsigned)wblocks), dim3(256), 0, s, o, lse_all, wpq_log2); \
+  else hipLaunchKernelGGL((owner_ssm_update_walk_kernel<LPR, false>), dim3((unsigned)wblocks), dim3(256), 0, s, o, lse_all, wpq_log2)
+    switch (a->dim) {
+      case 64: RSA_SSM_UPD(16); break;
+      case 128: RSA_SSM_UPD(32); break;
+      default: RSA_SSM_UPD(64); break;
+    }
+#undef RSA_SSM_UPD
+    RSA_CHECK_LAUNCH("rsa_shard_owner_ssm_finish(update walk)");
+  }
+  // the rows several elements touch (or, for a gradient block, every row): sorted apply
   return apply_sorted_segments(P.row_sorted, P.row_total, P.slots, a->q_all, a->dim, a->keys, a->d_slots, a->scale_out, a->n_rows,
                                a->item_pad_row, a->item_target, P.L, s);
 }

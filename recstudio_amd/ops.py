@@ -290,7 +290,8 @@ def carve(dev, specs, align=4096):
     84 MB of the 2.8 GB it moves) ran 404-409 us on every one of 31 layouts of those arrays inside one allocation (any skew
     between them, any shift, arenas of 86 MB .. 1 GB) and 443-471 us on 5 of 9 sets of separately allocated arrays of the same
     shapes in the same processes (tools/exp_outbuf.py, exp_outliers.py; moving any ONE of the four into an arena did not help).
-    The class belongs to the allocation: ``placement.pick`` probes candidates and returns one of the fast class."""
+    The class belongs to the allocation; with ``RSA_PLACEMENT=1`` (opt-in) ``placement.pick`` probes candidates and returns one of
+    the fast class -- by default the arena is one plain ``torch.empty``."""
     offs, total = [], 0
     for _, shape, dtype in specs:
         cnt = 1
@@ -298,7 +299,7 @@ def carve(dev, specs, align=4096):
             cnt *= int(v)
         offs.append((total, cnt))
         total += (cnt * torch.empty((), dtype=dtype).element_size() + align - 1) // align * align
-    arena = placement.pick(max(total, align), dev)          # of the fast class of allocations when it is large enough to matter
+    arena = placement.pick(max(total, align), dev)          # plain torch.empty unless placement was asked for
     out = {}
     for (key, shape, dtype), (off, cnt) in zip(specs, offs):
         nb = cnt * torch.empty((), dtype=dtype).element_size()
@@ -420,6 +421,9 @@ def fused_forward(item_table, query, num_neg, *, query_index=None, pos_ids=None,
         # the inner product; anything else runs the loss as its own (equally deterministic) launch
         if want_query_grad:
             raise ValueError('want_query_grad needs the inner-product scorer and dim in {32, 64, 128, 256}')
+        if n_batches > 1:
+            raise ValueError('fused_forward(n_batches=...) with a fused BPR loss needs num_neg == 64, or the inner-product scorer '
+                             'and dim in {32, 64, 128, 256} (this configuration is composed of two launches)')
         nat.check(nat.lib().rsa_fused_sample_gather_score(ctypes.byref(a), _stream()), 'rsa_fused_sample_gather_score')
         out['loss'], out['dpos'], out['dneg'], out['row_loss'] = pairwise_loss(nat.LOSS_BPR, out['pos_score'], out['neg_score'])
         return out
@@ -451,13 +455,22 @@ def fused_forward(item_table, query, num_neg, *, query_index=None, pos_ids=None,
         raise ValueError('fused_forward(n_batches=...) draws its negatives in the kernel from the torch generator')
     nat.check(nat.lib().rsa_fused_sample_gather_score(ctypes.byref(a), _stream()), 'rsa_fused_sample_gather_score')
     if n_batches > 1 and fused_loss is not None:
-        out['loss'] = out['row_loss'].view(int(n_batches), -1).mean(1)       # per batch (the kernel's mean is per launch)
+        _queue_losses(out, int(n_batches))
     if _plan is not None:
         _plan.update(args=a, out=out, device=dev, generator=generator, numel=M * n, n_batches=int(n_batches), keep=(item_table, query, query_index, pos_ids,
                                                                                          neg_ids, table, pop_prob, guide))
         _plan['unroll'] = None if sampler == nat.SAMPLER_GIVEN or rng_state is not None else \
             (4 if sampler == nat.SAMPLER_POPULAR else rng.randint_unroll(1, n_items))
     return out
+
+
+def _queue_losses(out, n_batches):
+    """out['loss'] [S] <- the per-batch means of a queue launch's row losses (the kernel's own mean is per LAUNCH and is off for a
+    queue), written IN PLACE into one persistent buffer: ``FusedStep`` hands out the same dict on every call."""
+    cur = out.get('loss')
+    if cur is None or cur.dim() != 1 or cur.numel() != n_batches:
+        out['loss'] = torch.empty(n_batches, dtype=torch.float32, device=out['row_loss'].device)
+    torch.mean(out['row_loss'].view(n_batches, -1), dim=1, out=out['loss'])
 
 
 class FusedStep:
@@ -486,6 +499,9 @@ class FusedStep:
         rc = self._fn(self._ref, ctypes.c_void_p(_raw_stream(p['device'])))
         if rc != 0:
             nat.check(rc, 'rsa_fused_sample_gather_score')
+        if p.get('n_batches', 1) > 1 and 'row_loss' in self.out:      # a queue's per-batch losses are the host side's
+            with torch.cuda.device(p['device']):
+                _queue_losses(self.out, p['n_batches'])
         return self.out
 
 

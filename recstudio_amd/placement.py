@@ -13,7 +13,11 @@ candidate -- on each, and returns one of the fast class; slow candidates are kep
 bytes) so that torch's caching allocator cannot hand them back.  Verdicts are cached by address for as long as the allocator
 has not returned memory to the driver: a transient allocation that torch recycles is probed once.  ``ops.carve`` routes every output arena of MIN_BYTES or more through here.
 
-``RSA_PLACEMENT=0`` switches it off (plain ``torch.empty``).  Nothing here changes a result: only addresses."""
+**Opt-in** (round 6): ``RSA_PLACEMENT=1`` or ``with placement.enabled():`` switches it on; by default every arena is a plain
+``torch.empty``.  Five rounds of driver records showed no gain where it counted (a plain allocation beat the placed one on the
+driver's box), the cause of the effect is unknown, and choosing costs a resident 1 GiB probe source, held-back HBM and probe
+launches -- not something a training job should pay for unasked.  bench.py times the headline launch on a placed allocation next
+to plain ones (``roofline.placed_kernel_ms`` / ``plain_kernel_ms_min``).  Nothing here changes a result: only addresses."""
 import contextlib
 import ctypes
 import os
@@ -23,7 +27,7 @@ import torch
 
 from . import _native as nat
 
-ENABLED = os.environ.get('RSA_PLACEMENT', '1') != '0'
+ENABLED = os.environ.get('RSA_PLACEMENT', '0') == '1'
 MIN_BYTES = 32 << 20          # smaller arenas are not probed (a 25 us probe cannot tell the classes apart)
 SOURCE_BYTES = 1 << 30        # read source of the probe: must dwarf the 256 MB Infinity Cache
 SPACER_BYTES = 768 << 20      # consecutive allocations are physical neighbours and share a class: skip ahead between candidates
@@ -38,6 +42,23 @@ HELD_CAP = 8 << 30            # bytes of slow-class memory kept out of circulati
 
 _state = {}
 _off = [0]
+_on = [0]
+
+
+@contextlib.contextmanager
+def enabled():
+    """Placement inside the block whatever RSA_PLACEMENT says (bench.py: the placed-vs-plain comparison)."""
+    _on[0] += 1
+    try:
+        yield
+    finally:
+        _on[0] -= 1
+
+
+def release(dev=None):
+    """Give back everything placement holds (the probe source, the held-back slow blocks) on ``dev`` (None: every device)."""
+    for idx in list(_state) if dev is None else [dev.index]:
+        _state.pop(idx, None)
 
 
 @contextlib.contextmanager
@@ -75,6 +96,11 @@ def _tiles(nbytes):
 def probe_us(buf, dev=None):
     """Microseconds per launch of the placement probe over ``buf`` (a uint8 tensor of >= 1 MiB, OVERWRITTEN)."""
     dev = buf.device if dev is None else dev
+    with torch.cuda.device(dev):          # events and launches on `dev`'s current stream, whatever the caller's current device is
+        return _probe_us(buf, dev)
+
+
+def _probe_us(buf, dev):
     st = _st(dev)
     if st['source'] is None:
         st['source'] = torch.empty(SOURCE_BYTES, dtype=torch.uint8, device=dev)      # (pick() has checked that there is room)
@@ -96,10 +122,10 @@ def probe_us(buf, dev=None):
     for w in range(2):
         launch(w)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
+    e0.record(torch.cuda.current_stream(dev))
     for k in range(3):
         launch(10 + k)
-    e1.record()
+    e1.record(torch.cuda.current_stream(dev))
     e1.synchronize()
     st['probes'] += 1
     st['last_busy'] = time.perf_counter()
@@ -117,19 +143,23 @@ def pick(nbytes, dev):
     the module docstring); a plain ``torch.empty`` when placement is off, the buffer is small, the stream is being captured,
     the HBM is nearly full or the probe budget is spent."""
     nbytes = int(nbytes)
-    if (not ENABLED or _off[0] or dev.type != 'cuda' or nbytes < MIN_BYTES or torch.cuda.is_current_stream_capturing()):
+    if (not (ENABLED or _on[0]) or _off[0] or dev.type != 'cuda' or nbytes < MIN_BYTES or torch.cuda.is_current_stream_capturing()):
         return torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev)
     nbytes = (nbytes + BUCKET_BYTES - 1) // BUCKET_BYTES * BUCKET_BYTES
     st = _st(dev)
-    if st.get('no_room'):
+    # choosing needs head-room: the probe's 1 GiB read source, candidates, spacers -- checked on EVERY pick (the job may have grown
+    # since the last one).  A job that fills the HBM (a 51 GB table with three optimizer states) gets plain allocations, and
+    # what placement holds back is released first, rather than an out-of-memory error from a placement attempt.
+    free, _ = torch.cuda.mem_get_info(dev)
+    need = (0 if st['source'] is not None else SOURCE_BYTES) + MAX_TRIES * (nbytes + SPACER_BYTES) + (4 << 30)
+    if free < need:
+        release(dev)
         return torch.empty(nbytes, dtype=torch.uint8, device=dev)
-    if st['source'] is None:
-        # choosing needs head-room: the probe's 1 GiB read source, candidates, spacers.  A job that fills the HBM (a 51 GB table
-        # with three optimizer states) gets plain allocations rather than an out-of-memory error from a placement attempt.
-        free, _ = torch.cuda.mem_get_info(dev)
-        if free < SOURCE_BYTES + MAX_TRIES * (nbytes + SPACER_BYTES) + (4 << 30):
-            st['no_room'] = True
-            return torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        return _pick(nbytes, dev, st)
+
+
+def _pick(nbytes, dev, st):
     epoch = _epoch(dev)
     if epoch != st.get('epoch'):
         st['known'].clear()                  # addresses may have been re-backed since the verdicts were taken
@@ -178,7 +208,7 @@ def pick(nbytes, dev):
 def summary(dev):
     """Counters for a bench line: probes run, buffers picked / rejected, bytes held back, the largest slow / fast ratio seen."""
     st = _st(dev)
-    return {'enabled': bool(ENABLED), 'probes': st['probes'], 'picked': st['picked'], 'rejected_slow': st['rejected'],
+    return {'enabled': bool(ENABLED or _on[0]), 'probes': st['probes'], 'picked': st['picked'], 'rejected_slow': st['rejected'],
             'held_MB': st['held_bytes'] >> 20, 'slowest_over_fastest_probe': round(st['worst_over_best'], 3),
             'probe_ns_per_tile_best': round(st['ref'], 3) if st.get('ref') else None,
             'probe_ns_per_tile_best_by_tiles': {str(k): round(v, 3) for k, v in st['best'].items()}}

@@ -54,7 +54,7 @@ def default_config():
                   'excluding_hist': False, 'scheduler': None, 'seed': 2022, 'weight_decay': 0.0,
                   'tensorboard_path': None, 'sparse_grad': False, 'device_loader': True, 'fused_optimizer': None,
                   'shard_slices': 1, 'shard_layout': 'block', 'shard_owner_loss': True, 'shard_init': 'auto',
-                  'shard_lookahead': False, 'shard_deterministic': False, 'shard_rows_share': None,
+                  'shard_lookahead': False, 'shard_deterministic': True, 'shard_rows_share': None,
                   'fused_prefetch': True},
         'eval': {'batch_size': 128, 'cutoff': [5, 10, 20], 'val_metrics': ['ndcg', 'recall'], 'val_n_epoch': 1,
                  'test_metrics': ['ndcg', 'recall', 'precision', 'map', 'mrr', 'hit'], 'topk': 100,
@@ -709,7 +709,7 @@ class BaseRetriever(torch.nn.Module):
                                        sample_seed=self.config['train']['seed'] or 2022,
                                        chunks=int(self.config['train'].get('shard_slices', 1)),
                                        owner_loss=bool(self.config['train'].get('shard_owner_loss', True)),
-                                       deterministic=bool(self.config['train'].get('shard_deterministic', False)),
+                                       deterministic=bool(self.config['train'].get('shard_deterministic', True)),
                                        rows_share=self.config['train'].get('shard_rows_share'))
         self._shard = {'table': table, 'dist': dist, 'rank': rank, 'world': world, 'lo': lo, 'hi': hi, 'device': device,
                        'n_items': n_items, 'plan': plan, 'tower_rows': None}
@@ -817,19 +817,22 @@ class BaseRetriever(torch.nn.Module):
             t0 = time.time()
             self.train()
             losses = []
-            if on_gpu and tr.get('device_loader', True) and hasattr(train_data, 'device_train_loader'):
-                loader = train_data.device_train_loader(tr['batch_size'], shuffle=True, drop_last=False, device=device, ddp=True,
-                                                        rank=rank, world=world)
-                # the rank parts of one global batch: every rank's history window has the same shape, so a tower's row
-                # look-ups can travel in fixed-capacity segments (no host round trip per step)
-                trainer.table.uniform_lookups = True
-            else:
-                loader = train_data.train_loader(batch_size=tr['batch_size'], shuffle=True, drop_last=False, ddp=True,
-                                                 rank=rank, world=world)
             # train.shard_lookahead: the weight-independent half of the NEXT batch's step (negatives, routing, key exchange,
             # the owner's sorts) is issued on a second stream before the current batch is stepped (ShardedRetriever.prepare_step)
             ahead = bool(tr.get('shard_lookahead', False)) and trainer.can_prepare()
             self._shard['lookahead'] = ahead
+            if on_gpu and tr.get('device_loader', True) and hasattr(train_data, 'device_train_loader'):
+                loader = train_data.device_train_loader(tr['batch_size'], shuffle=True, drop_last=False, device=device, ddp=True,
+                                                        rank=rank, world=world)
+                # the rank parts of one global batch: every rank's history window has the same shape, so a tower's row
+                # look-ups can travel in fixed-capacity segments (no host round trip per step).  NOT with look-ahead: a
+                # fixed-capacity look-up hands its dropped count to the NEXT routing launch, which with look-ahead belongs to a
+                # batch prepared one or two steps earlier on the other stream -- the step whose look-up overflowed would run
+                # ungated.  The variable-split look-up cannot drop anything.
+                trainer.table.uniform_lookups = not ahead
+            else:
+                loader = train_data.train_loader(batch_size=tr['batch_size'], shuffle=True, drop_last=False, ddp=True,
+                                                 rank=rank, world=world)
             ticket = None
             with _above_second_stream(ahead and on_gpu, device, self._shard):
                 for batch, batch_next in _with_next(self._prepared_batches(loader, device)):

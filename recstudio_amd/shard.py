@@ -561,19 +561,26 @@ def _gather_group(dist):
     return group
 
 
+class ShardOverflow(RuntimeError):
+    """Routed elements did not fit their owner segment (``ShardedItemTable.check_overflow``): the affected steps changed no
+    weight; the capacity is recalibrated on the next step.  Its own type so that a deferred poll can downgrade THIS to a
+    message and nothing else (a HIP / copy failure raised while polling must propagate)."""
+
+
 class ShardedItemTable:
     def __init__(self, item_local, plan, rank, dist, backend=None, group=None, exchange='fixed', slack=1.08,
                  margin=4096, check_every=16, sample_seed=2022, chunks=1, force_collectives=False, owner_loss=True,
-                 deterministic=False, rows_share=None):
+                 deterministic=True, rows_share=None):
         """``chunks`` > 1 (fixed-capacity exchange only): the step's queries are cut into that many contiguous
         slices, routed by ONE launch, whose exchanges are issued asynchronously, so that slice c+1's key all-to-all and
         slice c-1's score all-to-all travel over xGMI while slice c is being scored (see ``_fixed_step``)."""
         self.item_local, self.plan, self.rank, self.dist = item_local, plan, int(rank), dist
         self.chunks = max(1, int(chunks))
         self.owner_loss = bool(owner_loss)      # stock BPR training steps are evaluated on the owners (bpr_step_on_owners)
-        # deterministic: the router takes three launches instead of one (count, prefix over the workgroups, route) and no
-        # atomic decides where a key lands -- a step's segments, and every sum the owners form in slot order, are then
-        # bit-identical run to run (the default's slots follow returning atomics: steps agree to fp32 rounding only)
+        # deterministic (the default since round 6: it is free -- 1164.5 vs 1168.7 us tracked at configs[3]'s per-GPU shape): the
+        # router takes three launches instead of one (count, prefix over the workgroups, route) and no atomic decides where a
+        # key lands -- a step's segments, and every sum the owners form in slot order, are then bit-identical run to run and
+        # "G ranks == 1 rank" holds with torch.equal (False: slots follow returning atomics, steps agree to fp32 rounding only)
         self.deterministic = bool(deterministic)
         self.rows_share = None if rows_share is None else float(rows_share)      # see _lookup_rows_fixed
         self.group_by_query = True              # ... with query-grouped routing where the shape allows (no sort by query there)
@@ -698,7 +705,7 @@ class ShardedItemTable:
         if v:
             self._cap.clear()               # recalibrate on the next step
             self.state['overflow'].zero_()
-            raise RuntimeError(f'sharded exchange: {v} elements (all ranks) did not fit their owner segment (capacity slack '
+            raise ShardOverflow(f'sharded exchange: {v} elements (all ranks) did not fit their owner segment (capacity slack '
                                f'{self.slack}); the affected steps were skipped (their weight updates were scaled by 0) '
                                "-- raise `slack` / `margin` or use exchange='exact' for id distributions that drift this fast")
 
@@ -723,7 +730,7 @@ class ShardedItemTable:
                 # in `overflow_message` for `take_overflow()` at the END of the step.
                 try:
                     self.check_overflow()
-                except RuntimeError as err:
+                except ShardOverflow as err:          # (only this: any other error raised while polling propagates)
                     self.overflow_message = str(err)
             else:
                 self.check_overflow()

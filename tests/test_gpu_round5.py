@@ -53,6 +53,12 @@ def test_batch_queue_equals_consecutive_launches(ra, kind, n):
     first = st.out['neg_ids'].clone()
     st()
     assert torch.equal(first.reshape(-1), got['neg_ids'].reshape(-1)) and not torch.equal(st.out['neg_ids'], first)
+    if bpr:       # the per-batch losses follow every replay (one persistent [S] buffer, recomputed from the new row losses)
+        loss_buf = st.out['loss']
+        torch.testing.assert_close(loss_buf, st.out['row_loss'].view(S, -1).mean(1), rtol=1e-6, atol=1e-7)
+        before = loss_buf.clone()
+        assert st()['loss'] is loss_buf and not torch.equal(loss_buf, before)
+        torch.testing.assert_close(loss_buf, st.out['row_loss'].view(S, -1).mean(1), rtol=1e-6, atol=1e-7)
 
 
 def test_batch_queue_argument_checks(ra):
@@ -141,15 +147,21 @@ def test_full_softmax_backward_has_no_library_gemm(ra):
 
 
 def test_placement_changes_addresses_only(ra, monkeypatch):
-    """recstudio_amd.placement: output arenas of >= MIN_BYTES are probed (rsa_placement_probe) and taken from the fast class of
-    allocations; verdicts are cached by address; smaller arenas and ``placement.disabled()`` are plain torch allocations; the
-    results of a launch do not depend on any of it."""
+    """recstudio_amd.placement (opt-in since round 6: RSA_PLACEMENT=1 / ``placement.enabled()``; off, every arena is a plain torch
+    allocation and nothing is probed or held): switched on, output arenas of >= MIN_BYTES are probed (rsa_placement_probe) and
+    taken from the fast class of allocations; verdicts are cached by address; smaller arenas and ``placement.disabled()`` are
+    plain torch allocations; the results of a launch do not depend on any of it; ``release`` gives everything back."""
     from recstudio_amd import placement
     nat = ra._native
     dev = torch.device(DEV)
     monkeypatch.setattr(placement, 'SOURCE_BYTES', 320 << 20)
     monkeypatch.setattr(placement, 'SPACER_BYTES', 64 << 20)
+    monkeypatch.setattr(placement, 'WARM_S', 0.02)
+    monkeypatch.setattr(placement, 'ENABLED', False)
     before = placement.summary(dev)['probes']
+    off = placement.pick(48 << 20, dev)                        # the default: plain, no probe, nothing resident
+    assert off.numel() == 48 << 20 and placement.summary(dev)['probes'] == before and placement._st(dev)['source'] is None
+    monkeypatch.setattr(placement, 'ENABLED', True)
     buf = placement.pick(48 << 20, dev)
     assert buf.dtype == torch.uint8 and buf.numel() == 48 << 20 and buf.device == dev
     after = placement.summary(dev)
@@ -179,3 +191,5 @@ def test_placement_changes_addresses_only(ra, monkeypatch):
         plain = ra.ops.fused_forward(item, user, n, query_index=uid, pos_ids=pos, fused_bpr=True, sampler=nat.SAMPLER_UNIFORM)
     for k in ('neg_ids', 'neg_score', 'dneg', 'row_loss', 'dpos', 'loss'):
         assert torch.equal(placed[k], plain[k]), k
+    placement.release(dev)
+    assert dev.index not in placement._state

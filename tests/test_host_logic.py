@@ -377,7 +377,12 @@ def test_placement_is_inert_off_the_gpu_and_when_disabled():
     """recstudio_amd.placement only ever changes WHERE a buffer lives: off the GPU, below MIN_BYTES, or inside ``disabled()`` it
     is a plain allocation and no probe runs; ``ops.carve`` hands out views of one allocation either way."""
     import torch
+    import os
     from recstudio_amd import ops, placement
+    assert placement.ENABLED == (os.environ.get('RSA_PLACEMENT') == '1')      # opt-in (round 6): off unless asked for
+    with placement.enabled():
+        assert placement._on[0] == 1
+    assert placement._on[0] == 0
     cpu = torch.device('cpu')
     t = placement.pick(placement.MIN_BYTES * 2, cpu)
     assert t.dtype == torch.uint8 and t.numel() == placement.MIN_BYTES * 2 and not placement._state

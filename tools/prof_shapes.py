@@ -88,7 +88,7 @@ elif shape == 'ssm_N1e6_popular_n256_B8192':
 
     def step():
         buf['o'] = ra.ops.fused_forward(item, q, n_neg, out=buf.get('o'), fused_loss='ssm', **kw)
-elif shape in ('sharded_world1_step', 'sharded_world1_train', 'sharded_world1_train_ssm', 'sharded_world1_train_det'):
+elif shape in ('sharded_world1_step', 'sharded_world1_train', 'sharded_world1_train_ssm', 'sharded_world1_train_nondet'):
     import torch.distributed as dist
     from recstudio_amd import shard
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
@@ -96,7 +96,7 @@ elif shape in ('sharded_world1_step', 'sharded_world1_train', 'sharded_world1_tr
     dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
     n_blk, n_neg, B = 12_500_001, 1024, 4096
     item = table(n_blk, 9)
-    tbl = shard.ShardedItemTable(item, shard.RowShardPlan(n_blk, 1), 0, dist, check_every=0, deterministic=shape.endswith('_det'))
+    tbl = shard.ShardedItemTable(item, shard.RowShardPlan(n_blk, 1), 0, dist, check_every=0, deterministic=not shape.endswith('_nondet'))      # (deterministic router: the default since round 6)
     us = ra.UniformSampler(n_blk)
     uid = torch.randint(1, U, (B,), device=dev, generator=gen)
     pos = torch.randint(1, n_blk, (B,), device=dev, generator=gen)
