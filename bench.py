@@ -328,6 +328,9 @@ def side_figures(extra):
     def put(key, *path):
         v = extra
         for k in path:
+            if isinstance(k, int) and isinstance(v, (list, tuple)) and -len(v) <= k < len(v):
+                v = v[k]
+                continue
             if not isinstance(v, dict) or k not in v:
                 return
             v = v[k]
@@ -360,6 +363,13 @@ def side_figures(extra):
     put('fullscore_top100_frac', 'fullscore', 'with_top100_frac')
     put('softmax_train_step_ms', 'fullscore', 'softmax_train_step_ms')
     put('softmax_train_frac', 'fullscore', 'softmax_train_frac')
+    put('softmax_train_step_peak_extra_mb', 'fullscore', 'softmax_train_step_peak_extra_MB')
+    put('softmax_train_step_b8192_ms', 'fullscore', 'softmax_train_step_B8192_ms')
+    put('softmax_train_b8192_frac', 'fullscore', 'softmax_train_B8192_frac')
+    put('softmax_train_step_store_ms', 'fullscore', 'softmax_train_step_store_ms')
+    put('softmax_train_store_frac', 'fullscore', 'softmax_train_store_frac')
+    put('fullscore_grad_items_recompute_tflops', 'fullscore', 'grad_items_recompute_tflops')
+    put('fullscore_grad_query_recompute_tflops', 'fullscore', 'grad_query_recompute_tflops')
     put('fit_c1_train_s', 'fit', 'c1_bpr_ml100k', 'train_s_per_epoch')
     put('fit_c1_valid_s', 'fit', 'c1_bpr_ml100k', 'valid_s_per_epoch')
     for b in (65536, 4096):
@@ -367,6 +377,15 @@ def side_figures(extra):
         put(f'fit_stepper_B{b}_ms', 'fit', f'c2_B{b}', 'stepper_ms_per_step')
         put(f'fit_loop_over_stepper_b{b}', 'fit', f'c2_B{b}', 'loop_over_stepper')
         put(f'fit_loop_B{b}_M_triplets_s', 'fit', f'c2_B{b}', 'loop_M_triplets_s')
+        put(f'fit_c2_b{b}_loss_first', 'fit', f'c2_B{b}', 'train_loss_first_last', 0)
+        put(f'fit_c2_b{b}_loss_last', 'fit', f'c2_B{b}', 'train_loss_first_last', -1)
+    put('fit_c1_loss_last', 'fit', 'c1_bpr_ml100k', 'train_loss_last')
+    put('fit_c3_sasrec_ms_per_step', 'fit', 'c3_sasrec', 'ms_per_step')
+    put('fit_c3_hot_path_ms', 'fit', 'c3_sasrec', 'hot_path_ms')
+    put('fit_c3_hot_path_share_of_step', 'fit', 'c3_sasrec', 'hot_path_share_of_step')
+    put('fit_c3_transformer_ms', 'fit', 'c3_sasrec', 'step_parts_ms', 'transformer_fwd_bwd_stock_torch')
+    put('fit_c3_loss_first', 'fit', 'c3_sasrec', 'train_loss_first_last', 0)
+    put('fit_c3_loss_last', 'fit', 'c3_sasrec', 'train_loss_first_last', -1)
     return side
 
 
@@ -737,43 +756,69 @@ def main():
                                    'row-sparse item-gradient rows (two_pass: separate loss kernel, backward re-reads the rows)'})
         except Exception as e:
             extra['seq_softmax'] = {'error': repr(e)[:200]}
-        # full softmax training step on configs[4] (forward never writes [B, N]; backward = one softmax write + 2 GEMMs)
+        # full softmax training step on configs[4].  Default backward (round 6): NOTHING of [B, N] is ever written -- d/d query from
+        # the query-stationary recompute pass, d/d items from the item-stationary one (five GEMMs of 2 B d N flop per step);
+        # 'store' = the round-5 form (one [B, N-1] softmax write + read-back: four GEMMs, 8 GB at B = 2048)
         try:
+            from recstudio_amd import scorer as sc_mod
             from recstudio_amd.scorer import full_lse
             w5 = item[:n5].detach().clone().requires_grad_(True)
             qq5 = q5.detach().clone().requires_grad_(True)
 
-            def softmax_step():
-                w5.grad = qq5.grad = None
-                full_lse(qq5, w5).mean().backward()
+            def softmax_step(qq=qq5):
+                w5.grad = qq.grad = None
+                full_lse(qq, w5).mean().backward()
+            fs = extra['fullscore']
+            mode0 = sc_mod.FULL_SOFTMAX_BACKWARD
+            sc_mod.FULL_SOFTMAX_BACKWARD = 'recompute'
             t_sm = time_gpu(softmax_step, 5, 2) * 1e3
-            extra['fullscore']['softmax_train_step_ms'] = round(t_sm, 3)
-            # where the step goes: all in-tree MFMA kernels since round 5 (forward logsumexp; softmax recompute that writes
-            # [B, N-1] once with d/d query in the same pass; d/d items item-stationary) -- next to the library GEMMs they replaced
+            torch.cuda.reset_peak_memory_stats()
+            base_mem = torch.cuda.memory_allocated()
+            softmax_step()
+            torch.cuda.synchronize()
+            fs['softmax_train_step_ms'] = round(t_sm, 3)
+            fs['softmax_train_step_peak_extra_MB'] = round((torch.cuda.max_memory_allocated() - base_mem) / 2 ** 20, 1)
+            fs['softmax_train_frac'] = round(5 * flops / 157.3e12 * 1e3 / t_sm, 4)
+            # B = 8192: 32 GB of [B, N] in the stored form; here the same two recompute passes, 4 x the flops
+            b8k = 8192
+            q8k = user[1:b8k + 1].detach().clone().requires_grad_(True)
+            t_sm8 = time_gpu(lambda: softmax_step(q8k), 3, 1) * 1e3
+            fs['softmax_train_step_B8192_ms'] = round(t_sm8, 3)
+            fs['softmax_train_B8192_frac'] = round(5 * flops * (b8k / b5) / 157.3e12 * 1e3 / t_sm8, 4)
+            del q8k
+            sc_mod.FULL_SOFTMAX_BACKWARD = 'store'
+            t_sm_st = time_gpu(softmax_step, 5, 2) * 1e3
+            torch.cuda.reset_peak_memory_stats()
+            base_mem = torch.cuda.memory_allocated()
+            softmax_step()
+            torch.cuda.synchronize()
+            fs['softmax_train_step_store_ms'] = round(t_sm_st, 3)
+            fs['softmax_train_step_store_peak_extra_MB'] = round((torch.cuda.max_memory_allocated() - base_mem) / 2 ** 20, 1)
+            fs['softmax_train_store_frac'] = round(4 * flops / 157.3e12 * 1e3 / t_sm_st, 4)
+            sc_mod.FULL_SOFTMAX_BACKWARD = mode0
+            # where the step goes: all in-tree MFMA kernels
             lse5 = ra.ops.fullscore(w5.detach(), qq5.detach(), want_lse=True)[1]
             scale5 = torch.full((b5,), 1.0 / b5, device=dev)
-            t_rec = time_gpu(lambda: ra.ops.fullscore_softmax(w5.detach(), qq5.detach(), lse5, scale5), 5, 2) * 1e3
+            t_dq = time_gpu(lambda: ra.ops.fullscore_softmax(w5.detach(), qq5.detach(), lse5, scale5, want_query_grad=True,
+                                                             want_probs=False), 5, 2) * 1e3
+            gw5 = torch.empty_like(w5)
+            t_dw = time_gpu(lambda: ra.ops.fullscore_softmax_dw(w5.detach(), qq5.detach(), lse5, scale5, out=gw5), 5, 2) * 1e3
+            del gw5
             probs5 = ra.ops.fullscore_softmax(w5.detach(), qq5.detach(), lse5, scale5)
             t_rec_dq = time_gpu(lambda: ra.ops.fullscore_softmax(w5.detach(), qq5.detach(), lse5, scale5,
                                                                  want_query_grad=True), 5, 2) * 1e3
-            t_gq = time_gpu(lambda: probs5 @ w5.detach()[1:], 5, 2) * 1e3
-            t_gx_lib = time_gpu(lambda: probs5.t() @ qq5.detach(), 5, 2) * 1e3
             gx5 = torch.empty(n5 - 1, d, device=dev)
             t_gx = time_gpu(lambda: ra.ops.probs_t_query(probs5, qq5.detach(), out=gx5), 5, 2) * 1e3
-            del gx5
-            extra['fullscore']['grad_items_tflops'] = round(flops / t_gx / 1e9, 1)
-            extra['fullscore']['softmax_train_step_parts_ms'] = {
-                'forward_lse_in_tree': round(t_lse, 3),
-                'softmax_recompute_write_and_grad_query_in_tree': round(t_rec_dq, 3),
-                'grad_items_gemm_in_tree': round(t_gx, 3),
-                'not_in_the_step_any_more': {'softmax_recompute_write_alone': round(t_rec, 3),
-                                             'grad_items_gemm_rocblas': round(t_gx_lib, 3),
-                                             'grad_query_gemm_rocblas': round(t_gq, 3)},
-                'fp32_mfma_floor_of_the_step_ms': round(4 * flops / 157.3e12 * 1e3, 2)}
-            extra['fullscore']['softmax_train_frac'] = round(4 * flops / 157.3e12 * 1e3 / t_sm, 4)
-            extra['fullscore']['softmax_train_frac_what'] = ('the step is four GEMMs of 2*B*d*N flop (forward scores, recomputed '
-                                                             'scores, dQ, dX): their time at the 157.3 TFLOP/s fp32 matrix peak / step time')
-            del probs5
+            del gx5, probs5
+            fs['grad_items_tflops'] = round(flops / t_gx / 1e9, 1)
+            fs['grad_items_recompute_tflops'] = round(2 * flops / t_dw / 1e9, 1)
+            fs['grad_query_recompute_tflops'] = round(2 * flops / t_dq / 1e9, 1)
+            fs['softmax_train_step_parts_ms'] = {
+                'forward_lse': round(t_lse, 3),
+                'recompute__grad_query_no_write': round(t_dq, 3),
+                'recompute__grad_items_no_probs': round(t_dw, 3),
+                'store_form': {'recompute_write_and_grad_query': round(t_rec_dq, 3), 'grad_items_from_stored_probs': round(t_gx, 3)},
+                'fp32_mfma_floor_ms': {'five_gemms': round(5 * flops / 157.3e12 * 1e3, 2), 'four_gemms': round(4 * flops / 157.3e12 * 1e3, 2)}}
             del w5, qq5
         except Exception as e:
             extra['fullscore']['softmax_train_step_error'] = repr(e)[:200]
@@ -1147,6 +1192,30 @@ def main():
                     return
                 emitted.append(1)
                 if rank == 0:
+                    # FLAT scalars inside `roofline` (what the driver's record keeps): the in-job world-1 reference and the side figures
+                    def put(key, *path):
+                        v = extra
+                        for k in path:
+                            if not isinstance(v, dict) or k not in v:
+                                return
+                            v = v[k]
+                        if isinstance(v, (int, float)) and not isinstance(v, bool) and key not in roofline:
+                            roofline[key] = v
+                    put('per_gpu_M_triplets_s', 'per_gpu_M_triplets_s')
+                    put('world1_ms_per_step', 'world1_reference', 'ms_per_step')
+                    put('efficiency_vs_world1', 'efficiency_vs_world1')
+                    put('one_batch_ahead_ms', 'one_batch_ahead', 'ms_per_step')
+                    put('train_step_ms', 'train_step', 'ms_per_step')
+                    put('train_step_world1_ms', 'train_step', 'world1_reference_ms')
+                    put('train_step_efficiency_vs_world1', 'train_step', 'efficiency_vs_world1')
+                    put('train_step_frac_per_gpu', 'train_step', 'frac_of_hbm_peak_per_gpu')
+                    put('train_step_one_batch_ahead_ms', 'train_step', 'one_batch_ahead_ms')
+                    put('train_step_ssm_ms', 'train_step_ssm', 'ms_per_step')
+                    put('train_step_ssm_world1_ms', 'train_step_ssm', 'world1_reference_ms')
+                    put('train_step_ssm_efficiency_vs_world1', 'train_step_ssm', 'efficiency_vs_world1')
+                    put('exact_exchange_ms_per_step', 'exact_exchange_ms_per_step')
+                    put('sharded_n64_ms_per_step', 'sharded_n64', 'ms_per_step')
+                    put('other_sampler_ms_per_step', 'other_sampler', 'ms_per_step')
                     print(json.dumps(headline_line(value, ms_step, workload, parallelism, roofline, extra)), flush=True)
         # The side figures below run collectives: should one of them stall (a rank that failed alone leaves the others
         # waiting), the measured headline must still come out -- a watchdog thread prints the line and ends the rank.

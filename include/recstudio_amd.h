@@ -30,7 +30,9 @@
 extern "C" {
 #endif
 
-#define RSA_ABI_VERSION 9   /* 9: every entry point that took more than 12 positional arguments takes ONE argument block whose first field is its
+#define RSA_ABI_VERSION 10  /* 10: rsa_fullscore_softmax_dw (d/d items of the full softmax with the softmax tile recomputed on the matrix cores: no
+                               [B, N] matrix anywhere in the backward); rsa_fullscore_softmax_dq: probs may be NULL (not written);
+                               9: every entry point that took more than 12 positional arguments takes ONE argument block whose first field is its
                                own size (see "Versioned argument blocks"): rsa_popular_args (rsa_sample_popular, rsa_popular_lookup), rsa_loss_args
                                (rsa_pairwise_loss -- which now covers the kinds of the former rsa_pairwise_loss_ex --, rsa_ssm_shared_loss),
                                rsa_seg_gather_args, rsa_fullscore_args, rsa_rows_update_args (rsa_sort_step_elements, rsa_rows_update_sorted,
@@ -565,6 +567,19 @@ int64_t rsa_fullscore_softmax_dq_workspace_bytes(int64_t n_query, int64_t n_item
 int rsa_fullscore_softmax_dq(const float* item_table, int64_t n_items, int32_t dim, const float* query,
                              int64_t n_query, const float* lse, const float* row_scale, float* probs,
                              float* query_grad, void* workspace, int64_t workspace_bytes, rsa_stream_t stream);
+
+/* probs == NULL (ABI 10): the softmax tile feeds the second product and is NOT written -- together with
+ * rsa_fullscore_softmax_dw below a backward that never holds [B, N] ("only if [B, N] is never written"). */
+
+/* d lse / d items WITHOUT probs (ABI 10): item_grad[i, :] = sum_b row_scale[b] * exp(<q_b, item_i> - lse[b]) * q_b for rows
+ * i = 1 .. n_items - 1, item_grad[0, :] = 0 -- the reference's autograd through loss_func.py:39-47 over scorer.py:16.  Item-
+ * stationary: a wave keeps its 32 item rows in registers, recomputes the [32 batch rows x 32 items] score tile per batch chunk
+ * on the fp32 matrix cores, forms the scaled softmax in its accumulator registers and feeds them back as the operand of
+ * item_grad^T += P^T Q (the accumulator layout IS the operand layout when the chunk's rows are taken in that order) -- the
+ * [B, N] matrix exists nowhere, every output row is written once, no atomics.  flops 4 B N d, HBM bytes 8 N d.  row_scale may
+ * be NULL (1).  item_table / query / item_grad 16-byte aligned, dim in {32, 64, 128}. */
+int rsa_fullscore_softmax_dw(const float* item_table, int64_t n_items, int32_t dim, const float* query, int64_t n_query,
+                             const float* lse, const float* row_scale, float* item_grad, rsa_stream_t stream);
 
 /* The other backward GEMM, d lse / d items[1:] = probs^T @ query (ATen's mm backward of scorer.py:16 under loss_func.py:39-47),
  * item-stationary on the fp32 matrix cores: out[i, :] = sum_b probs[b, i] * query[b, :] for i in [0, n_cols) -- every output row

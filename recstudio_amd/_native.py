@@ -223,6 +223,7 @@ SIGNATURES = {
     'rsa_bpr_sgd_prepare': (c_int, [POINTER(BprSgdArgs), c_void_p]),
     'rsa_bpr_sgd_apply': (c_int, [POINTER(BprSgdArgs), c_void_p]),
     'rsa_probs_t_query': (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int32, c_void_p, c_void_p]),
+    'rsa_fullscore_softmax_dw': (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     'rsa_rng_advance': (c_int, [c_void_p, c_uint64, c_void_p]),
     'rsa_placement_probe': (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_uint32, c_void_p]),
     'rsa_row_topk': (c_int, [c_void_p, c_int64, c_int64, c_int32, c_void_p, c_void_p, c_void_p]),
@@ -273,7 +274,7 @@ def build(verbose=False):
     return LIB_PATH
 
 
-ABI_VERSION = 9      # RSA_ABI_VERSION of include/recstudio_amd.h this binding was written against
+ABI_VERSION = 10     # RSA_ABI_VERSION of include/recstudio_amd.h this binding was written against
 
 
 def lib():

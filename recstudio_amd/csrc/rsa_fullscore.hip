@@ -94,7 +94,9 @@ struct FilterArgs {
 // the order the accumulator layout holds them (step r: items row(r, h = 0) and row(r, h = 1)), so nothing moves between
 // lanes; the A operand X[item(r, h)][32 db + j] is a conflict-free 4-byte LDS read of the staged item tile.  dQ stays in
 // 16 * D/32 accumulator registers for the whole item range and leaves the kernel once (per-range partials).
-template <int D, bool LSE, bool SCORES, bool FILTER, int MODE = 0, bool DQ = false>
+// PW = false (DQ only): the P tile feeds the second product and is NOT written -- the backward that never holds [B, N]
+// (rsa_fullscore_softmax_dq with probs == NULL; d/d items then comes from rsa_fullscore_softmax_dw, rsa_dx.hip).
+template <int D, bool LSE, bool SCORES, bool FILTER, int MODE = 0, bool DQ = false, bool PW = true>
 __global__ __launch_bounds__(256, DQ ? RSA_FS_DQ_MIN_BLOCKS : RSA_FS_MIN_BLOCKS) void fullscore_kernel(const float* __restrict__ item_table, int64_t n_items,
                                                         const float* __restrict__ query, int64_t n_query,
                                                         float* __restrict__ scores, int64_t score_ld,
@@ -246,6 +248,7 @@ __global__ __launch_bounds__(256, DQ ? RSA_FS_DQ_MIN_BLOCKS : RSA_FS_MIN_BLOCKS)
 
   float run_m = -INFINITY, run_s = 0.f;
   static_assert(!DQ || (SCORES && !LSE && !FILTER && MODE == 0 && STG == 1 && D % 32 == 0), "DQ: softmax-backward variant only");
+  static_assert(PW || DQ, "PW = false: only the dQ variant can do without the score store");
   constexpr int DB = D / 32;
   f32x16 dq[DQ ? DB : 1];
   if constexpr (DQ) {
@@ -293,7 +296,7 @@ __global__ __launch_bounds__(256, DQ ? RSA_FS_DQ_MIN_BLOCKS : RSA_FS_MIN_BLOCKS)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         pv[r] = softmax_out ? my_scale * __expf(acc[r] - my_lse) : acc[r];
-        tpose[wave][j][(r & 3) + 8 * (r >> 2) + 4 * h] = pv[r];
+        if constexpr (PW) tpose[wave][j][(r & 3) + 8 * (r >> 2) + 4 * h] = pv[r];
       }
       if constexpr (DQ) {
         // rows past the item range are zero in LDS (fetch), so their (finite) P values add nothing
@@ -318,13 +321,15 @@ __global__ __launch_bounds__(256, DQ ? RSA_FS_DQ_MIN_BLOCKS : RSA_FS_MIN_BLOCKS)
             dq[db] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[db], pv[r], dq[db], 0, 0, 0);
         }
       }
-      __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the wave's own LDS writes have landed
+      if constexpr (PW) {
+        __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the wave's own LDS writes have landed
 #pragma unroll
-      for (int tt = 0; tt < 16; ++tt) {
-        const int qq = 2 * tt + h;
-        const int64_t qg = (int64_t)blockIdx.y * QB + wave * 32 + qq;
-        const int64_t item = i0 + j;
-        if (qg < n_query && item < i_end) scores[(size_t)qg * score_ld + (item - 1)] = tpose[wave][qq][j];
+        for (int tt = 0; tt < 16; ++tt) {
+          const int qq = 2 * tt + h;
+          const int64_t qg = (int64_t)blockIdx.y * QB + wave * 32 + qq;
+          const int64_t item = i0 + j;
+          if (qg < n_query && item < i_end) scores[(size_t)qg * score_ld + (item - 1)] = tpose[wave][qq][j];
+        }
       }
     }
     if constexpr (FILTER) {
@@ -1122,7 +1127,7 @@ extern "C" int rsa_fullscore_softmax_dq(const float* item_table, int64_t n_items
                                         rsa_stream_t stream) {
   RSA_CHECK_ARG(n_query >= 0 && n_items >= 2, "rsa_fullscore_softmax_dq: need n_items >= 2");
   if (n_query == 0) return RSA_OK;
-  RSA_CHECK_ARG(item_table && query && lse && probs && query_grad, "rsa_fullscore_softmax_dq: null pointer");
+  RSA_CHECK_ARG(item_table && query && lse && query_grad, "rsa_fullscore_softmax_dq: null pointer");
   if (dim != 32 && dim != 64 && dim != 128) {
     rsa::set_error("rsa_fullscore_softmax_dq: dim=%d: the MFMA full-score kernel is built for dim in {32, 64, 128}", dim);
     return RSA_ERR_UNSUPPORTED;
@@ -1137,9 +1142,14 @@ extern "C" int rsa_fullscore_softmax_dq(const float* item_table, int64_t n_items
   const FilterArgs ep{nullptr, nullptr, nullptr, lse, row_scale, nullptr, nullptr, nullptr, nullptr, nullptr, part};
   hipStream_t s = (hipStream_t)stream;
   const dim3 grid((unsigned)splits_used, groups);
-#define RSA_DQ(DD)                                                                                                        \
-  hipLaunchKernelGGL((fullscore_kernel<DD, false, true, false, 0, true>), grid, dim3(256), 0, s, item_table, n_items, query, \
-                     n_query, probs, n_cols, (float2*)nullptr, (int)splits_used, per, (int64_t)1, n_cols, ep)
+  // probs == NULL: the softmax tile only feeds the second product (nothing of [B, N] is written)
+#define RSA_DQ(DD)                                                                                                                  \
+  if (probs != nullptr)                                                                                                             \
+    hipLaunchKernelGGL((fullscore_kernel<DD, false, true, false, 0, true>), grid, dim3(256), 0, s, item_table, n_items, query,       \
+                       n_query, probs, n_cols, (float2*)nullptr, (int)splits_used, per, (int64_t)1, n_cols, ep);                     \
+  else                                                                                                                              \
+    hipLaunchKernelGGL((fullscore_kernel<DD, false, true, false, 0, true, false>), grid, dim3(256), 0, s, item_table, n_items, query, \
+                       n_query, probs, n_cols, (float2*)nullptr, (int)splits_used, per, (int64_t)1, n_cols, ep)
   switch (dim) {
     case 32: RSA_DQ(32); break;
     case 64: RSA_DQ(64); break;

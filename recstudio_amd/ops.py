@@ -818,10 +818,11 @@ def _fullscore_composed(item_table, query, want_scores, want_lse, k, items_witho
 
 
 @_on_device
-def fullscore_softmax(item_table, query, lse, row_scale=None, want_query_grad=False):
+def fullscore_softmax(item_table, query, lse, row_scale=None, want_query_grad=False, want_probs=True):
     """rsa_fullscore_softmax: probs[b, i-1] = row_scale[b] * exp(<query_b, item_i> - lse[b]) over rows 1.. of
     ``item_table`` (dims in {32, 64, 128}).  ``want_query_grad``: -> (probs, probs @ item_table[1:]), the product
-    accumulated on the matrix cores in the same pass (rsa_fullscore_softmax_dq)."""
+    accumulated on the matrix cores in the same pass (rsa_fullscore_softmax_dq); with ``want_probs=False`` the [B, N-1]
+    matrix is neither allocated nor written (-> (None, query_grad))."""
     item_table = _need(item_table, torch.float32, 'item_table')
     query = _need(query, torch.float32, 'query')
     lse = _need(lse, torch.float32, 'lse')
@@ -829,7 +830,9 @@ def fullscore_softmax(item_table, query, lse, row_scale=None, want_query_grad=Fa
     item_table, query, dim = _pad_k(item_table, query)
     n_items = item_table.shape[0]
     B = query.shape[0]
-    probs = torch.empty(B, n_items - 1, dtype=torch.float32, device=item_table.device)
+    if not want_probs and not want_query_grad:
+        raise ValueError('fullscore_softmax: nothing to compute (want_probs=False needs want_query_grad=True)')
+    probs = torch.empty(B, n_items - 1, dtype=torch.float32, device=item_table.device) if want_probs else None
     if want_query_grad:
         qgrad = torch.empty(B, dim, dtype=torch.float32, device=item_table.device)
         ws_bytes = int(nat.lib().rsa_fullscore_softmax_dq_workspace_bytes(B, n_items, dim))
@@ -842,6 +845,33 @@ def fullscore_softmax(item_table, query, lse, row_scale=None, want_query_grad=Fa
                                               ptr(_need_opt(row_scale, torch.float32, 'row_scale')), ptr(probs),
                                               _stream()), 'rsa_fullscore_softmax')
     return probs
+
+
+@_on_device
+def fullscore_softmax_dw(item_table, query, lse, row_scale=None, out=None):
+    """rsa_fullscore_softmax_dw: d/d item_table of sum_b row_scale[b] * logsumexp_i <query_b, item_i> (rows 1.. of the table; row
+    0 of the result is zero) with the softmax tile recomputed on the matrix cores -- no [B, N] matrix.  embed_dim <= 128."""
+    item_table = _need(item_table, torch.float32, 'item_table')
+    query = _need(query, torch.float32, 'query')
+    lse = _need(lse, torch.float32, 'lse')
+    d_in = item_table.shape[1]
+    tab, q, dim = _pad_k(item_table, query)
+    n_items, B = tab.shape[0], q.shape[0]
+    direct = dim == d_in and out is not None
+    res = out if direct else torch.empty(n_items, dim, dtype=torch.float32, device=tab.device)
+    res = _need(res, torch.float32, 'out')
+    if res.shape != (n_items, dim):
+        raise ValueError(f'fullscore_softmax_dw: out must be [{n_items}, {dim}]')
+    nat.check(nat.lib().rsa_fullscore_softmax_dw(ptr(tab), n_items, dim, ptr(q), B, ptr(lse),
+                                                 ptr(_need_opt(row_scale, torch.float32, 'row_scale')), ptr(res), _stream()),
+              'rsa_fullscore_softmax_dw')
+    if direct:
+        return out
+    res = res if dim == d_in else res[:, :d_in]
+    if out is not None:
+        out.copy_(res)
+        return out
+    return res.contiguous()
 
 
 @_on_device

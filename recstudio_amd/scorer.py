@@ -6,6 +6,8 @@ quirk); the arithmetic runs in HIP.  Inside ``BaseRetriever`` the scorer objects
 as *selectors* for the fused kernel (no [B, n, d] tensor is ever built); calling them
 directly scores already-materialised vectors through the same kernels.
 """
+import os
+
 import torch
 
 from . import _native as nat
@@ -141,10 +143,19 @@ def full_scores(query, items, cosine=False):
     return _FullScoreFn.apply(query, items.contiguous(), mode)
 
 
+# Backward of the full-catalog logsumexp: 'recompute' (default) never holds [B, N] -- d/d query from the query-stationary
+# recompute pass (the softmax tile feeds the second product and is not written), d/d items from the item-stationary one
+# (rsa_fullscore_softmax_dw): five GEMMs of 2 B N d flop per training step, 8 N d bytes of HBM traffic, no [B, N] allocation at any
+# batch size.  'store' is the round-5 form: the recompute pass writes the scaled softmax once ([B, N-1] fp32: 8 GB at B = 2048,
+# N = 1e6, written and read back) and d/d items is a GEMM over it -- four GEMMs, ~15 % faster where the matrix fits.
+FULL_SOFTMAX_BACKWARD = os.environ.get('RSA_FULL_SOFTMAX_BACKWARD', 'recompute')
+
+
 class _FullLseFn(torch.autograd.Function):
-    """logsumexp_i <query_b, weight_i> over item rows 1..N-1 WITHOUT writing [B, N]: the forward is the MFMA
-    kernel's in-register online logsumexp; the backward recomputes the scaled softmax with the same kernel
-    (one [B, N-1] write) and finishes with two library GEMMs."""
+    """logsumexp_i <query_b, weight_i> over item rows 1..N-1 WITHOUT writing [B, N], forward and backward (the reference:
+    loss_func.py:39-47 over the scorer.py:16 matmul, under autograd): the forward is the MFMA kernel's in-register online
+    logsumexp; the backward recomputes the scaled softmax tile by tile on the matrix cores, once query-stationary (d/d query)
+    and once item-stationary (d/d items) -- see FULL_SOFTMAX_BACKWARD."""
 
     @staticmethod
     def forward(ctx, query, weight):
@@ -155,19 +166,30 @@ class _FullLseFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         query, weight, lse = ctx.saved_tensors
-        if ctx.needs_input_grad[0]:     # d/d query leaves the recompute pass itself (second MFMA product per tile)
-            probs, gq = ops.fullscore_softmax(weight, query, lse, g.contiguous(), want_query_grad=True)
-        else:
-            probs, gq = ops.fullscore_softmax(weight, query, lse, g.contiguous()), None
-        gw = None
-        if ctx.needs_input_grad[1]:
-            gw = torch.empty_like(weight)
-            gw[0].zero_()
-            if weight.shape[1] <= 128:         # in-tree item-stationary MFMA kernel (rounds 1-4: torch.matmul -> rocBLAS)
-                ops.probs_t_query(probs, query, out=gw[1:])
-            else:
-                torch.matmul(probs.t(), query, out=gw[1:])
+        need_q, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        g = g.contiguous()
+        if FULL_SOFTMAX_BACKWARD == 'store' or weight.shape[1] > 128:
+            return _full_lse_backward_stored(query, weight, lse, g, need_q, need_w)
+        gq = ops.fullscore_softmax(weight, query, lse, g, want_query_grad=True, want_probs=False)[1] if need_q else None
+        gw = ops.fullscore_softmax_dw(weight, query, lse, g, out=torch.empty_like(weight)) if need_w else None
         return gq, gw
+
+
+def _full_lse_backward_stored(query, weight, lse, g, need_q, need_w):
+    """the round-5 backward: one [B, N-1] write of the scaled softmax (+ d/d query in the same pass), d/d items = probs^T query"""
+    if need_q:     # d/d query leaves the recompute pass itself (second MFMA product per tile)
+        probs, gq = ops.fullscore_softmax(weight, query, lse, g, want_query_grad=True)
+    else:
+        probs, gq = ops.fullscore_softmax(weight, query, lse, g), None
+    gw = None
+    if need_w:
+        gw = torch.empty_like(weight)
+        gw[0].zero_()
+        if weight.shape[1] <= 128:         # in-tree item-stationary MFMA kernel (rounds 1-4: torch.matmul -> rocBLAS)
+            ops.probs_t_query(probs, query, out=gw[1:])
+        else:
+            torch.matmul(probs.t(), query, out=gw[1:])
+    return gq, gw
 
 
 def full_lse(query, item_weight):

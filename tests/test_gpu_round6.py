@@ -1,0 +1,169 @@
+"""Round 6 GPU parity tests: the full-softmax backward that never holds [B, N], float64 referees for the scatter gradients."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+@pytest.fixture(scope='module')
+def ra():
+    import recstudio_amd
+    recstudio_amd._native.lib()
+    return recstudio_amd
+
+
+@pytest.mark.parametrize('N,B,d', [(30_001, 256, 128), (5_003, 77, 64), (1_234, 33, 32), (40_007, 1000, 100), (130, 2048, 128), (60_001, 2048, 32)])
+def test_full_softmax_backward_never_holds_the_score_matrix(ra, N, B, d, monkeypatch):
+    """scorer.full_lse (SoftmaxLoss over the whole catalog: loss_func.py:39-47 over scorer.py:16), default backward: d/d query from
+    the query-stationary recompute pass with the softmax tile NOT written (rsa_fullscore_softmax_dq, probs = NULL), d/d items from
+    the item-stationary recompute pass (rsa_fullscore_softmax_dw) == float64 autograd (rtol 2e-4: fp32 sums of B resp. N terms),
+    row 0 of the table gradient exactly zero, ragged sizes (partial item tiles, partial batch chunks, padded embed_dim), an
+    arbitrary upstream gradient per row (sign and zero included) -- and no [B, N-1] allocation: where that matrix would dwarf
+    everything else (B = 2048, N = 60 001, d = 32: 492 MB against 7.7 MB of table) the peak memory of the backward stays below a
+    QUARTER of its size."""
+    from recstudio_amd import scorer
+    monkeypatch.setattr(scorer, 'FULL_SOFTMAX_BACKWARD', 'recompute')
+    g = torch.Generator(device=DEV).manual_seed(N + B)
+    w = (torch.randn(N, d, device=DEV, generator=g) * 0.1).requires_grad_(True)
+    q = (torch.randn(B, d, device=DEV, generator=g) * 0.3).requires_grad_(True)
+    up = torch.randn(B, device=DEV, generator=g)
+    up[::7] = 0
+    lse = scorer.full_lse(q, w)
+    torch.cuda.synchronize()
+    torch.cuda.reset_peak_memory_stats()
+    base = torch.cuda.memory_allocated()
+    (lse * up).sum().backward()
+    torch.cuda.synchronize()
+    peak = torch.cuda.max_memory_allocated() - base
+    wd, qd = w.detach().double().requires_grad_(True), q.detach().double().requires_grad_(True)
+    ref = torch.logsumexp(qd @ wd[1:].t(), -1)
+    (ref * up.double()).sum().backward()
+    torch.testing.assert_close(lse.detach().double(), ref.detach(), rtol=1e-5, atol=1e-6)
+    scale_w, scale_q = float(wd.grad.abs().max()), float(qd.grad.abs().max())
+    torch.testing.assert_close(w.grad.double(), wd.grad, rtol=2e-4, atol=2e-6 * scale_w)
+    torch.testing.assert_close(q.grad.double(), qd.grad, rtol=2e-4, atol=2e-6 * scale_q)
+    assert bool((w.grad[0] == 0).all())
+    if B * (N - 1) * 4 > (256 << 20):
+        assert peak < B * (N - 1) * 4 // 4, (peak, B * (N - 1) * 4)
+    # the stored-softmax form (round 5: one [B, N-1] write, four GEMMs) gives the same gradients
+    monkeypatch.setattr(scorer, 'FULL_SOFTMAX_BACKWARD', 'store')
+    w2, q2 = w.detach().clone().requires_grad_(True), q.detach().clone().requires_grad_(True)
+    (scorer.full_lse(q2, w2) * up).sum().backward()
+    torch.testing.assert_close(w2.grad, w.grad, rtol=2e-4, atol=2e-6 * scale_w)
+    torch.testing.assert_close(q2.grad, q.grad, rtol=2e-4, atol=2e-6 * scale_q)
+
+
+def test_full_softmax_dw_entry_point_checks(ra):
+    nat = ra._native
+    lib = nat.lib()
+    w = torch.zeros(10, 128, device=DEV)
+    q = torch.zeros(4, 128, device=DEV)
+    lse = torch.zeros(4, device=DEV)
+    out = torch.ones(10, 128, device=DEV)
+    p = nat.ptr
+    assert lib.rsa_fullscore_softmax_dw(p(w), 10, 128, p(q), 0, p(lse), None, p(out), None) == 0       # empty batch: all zero
+    torch.cuda.synchronize()
+    assert float(out.abs().sum()) == 0.0
+    assert lib.rsa_fullscore_softmax_dw(p(w), 10, 96, p(q), 4, p(lse), None, p(out), None) == -3
+    assert lib.rsa_fullscore_softmax_dw(None, 10, 128, p(q), 4, p(lse), None, p(out), None) == -1
+    assert lib.rsa_fullscore_softmax_dw(p(w), 1, 128, p(q), 4, p(lse), None, p(out), None) == -1
+    # uniform scores: softmax = 1 / (N - 1), d/d items = sum_b q_b / (N - 1)
+    q = torch.randn(4, 128, device=DEV)
+    lse = torch.full((4,), float(np.log(9.0)), device=DEV)
+    got = ra.ops.fullscore_softmax_dw(w, q, lse)
+    torch.testing.assert_close(got[1:], (q.sum(0) / 9.0).expand(9, 128), rtol=1e-5, atol=1e-6)
+    assert float(got[0].abs().sum()) == 0.0
+
+
+@pytest.mark.parametrize('loss', ['bpr', 'ssm'])
+def test_scatter_gradients_float64_referee_at_headline_batch(ra, loss):
+    """VERDICT r5 "next" #7: the row-sparse / sorted-scatter gradients of the fused training path are sums of up to hundreds of fp32
+    terms in an order that differs from ATen's, held to rtol 2e-4 .. 3e-4 against the fp32 oracle by the suite.  Here the
+    referee is float64 at the headline batch (B = 65 536, n = 64, d = 128; a 200 001-row catalog, so that a row collects ~21
+    terms and the popular ones thousands): the kernel's item / user gradients are no further from float64 than torch's own fp32
+    autograd on the device is (RMS error ratio <= 1.5, max error <= 2 x + one ulp of the largest gradient), and both sit inside
+    rtol 3e-4 of it."""
+    from recstudio_amd import fused
+    N, U, d, B, n = 200_001, 50_001, 128, 65536, 64
+    g = torch.Generator(device=DEV).manual_seed(17)
+    iw = torch.randn(N, d, device=DEV, generator=g) * 0.1
+    iw[0] = 0
+    uw = torch.randn(U, d, device=DEV, generator=g) * 0.1
+    uid = torch.randint(1, U, (B,), device=DEV, generator=g)
+    pos = torch.randint(1, N, (B,), device=DEV, generator=g)
+    sampler = ra.PopularSamplerModel((torch.rand(N) ** 6 * 5000).long() + 1).to(DEV)
+    wi, wu = iw.clone().requires_grad_(True), uw.clone().requires_grad_(True)
+    fn = fused.fused_bpr_loss if loss == 'bpr' else fused.fused_ssm_loss
+    val, neg = fn(wi, wu, n, query_index=uid, pos_ids=pos, sampler=sampler)
+    val.backward()
+
+    def reference(dtype):
+        a, b = iw.to(dtype).requires_grad_(True), uw.to(dtype).requires_grad_(True)
+        qv = b[uid]
+        ps = (qv * a[pos]).sum(-1)
+        ns = torch.empty(B, n, dtype=dtype, device=DEV)
+        chunk = 8192                                         # [chunk, n, d] gathered rows at a time (float64: 0.5 GB)
+        total = 0
+        for lo in range(0, B, chunk):
+            sl = slice(lo, lo + chunk)
+            nsc = (qv[sl].unsqueeze(1) * a[neg[sl]]).sum(-1)
+            if loss == 'bpr':
+                part = -torch.nn.functional.logsigmoid(ps[sl].unsqueeze(1) - nsc).mean(1).sum() / B
+            else:
+                lp = torch.log(sampler.pop_prob[pos[sl]]).to(dtype)
+                ln = torch.log(sampler.pop_prob[neg[sl]]).to(dtype)
+                zp, zn = ps[sl] - lp, nsc - ln
+                part = (torch.logsumexp(torch.cat([zp.view(-1, 1), zn], 1), -1) - zp).sum() / B
+            part.backward(retain_graph=True)
+            total = total + part.detach()
+        ga = a.grad.clone()
+        ga[0] = 0                                            # nn.Embedding(padding_idx = 0)
+        return total, ga, b.grad
+
+    v64, gi64, gu64 = reference(torch.float64)
+    v32, gi32, gu32 = reference(torch.float32)
+    np.testing.assert_allclose(val.item(), v64.item(), rtol=1e-5)
+    for got, g32, g64, name in ((wi.grad, gi32, gi64, 'item'), (wu.grad, gu32, gu64, 'user')):
+        ek, eo = (got.double() - g64).abs(), (g32.double() - g64).abs()
+        ulp = float(g64.abs().max()) * 2.0 ** -23
+        rms_k, rms_o = float(ek.pow(2).mean().sqrt()), float(eo.pow(2).mean().sqrt())
+        assert rms_k <= 1.5 * rms_o + 1e-12, (name, rms_k, rms_o)
+        assert float(ek.max()) <= 2.0 * float(eo.max()) + ulp, (name, float(ek.max()), float(eo.max()), ulp)
+        torch.testing.assert_close(got.double(), g64, rtol=3e-4, atol=4 * ulp)
+        torch.testing.assert_close(g32.double(), g64, rtol=3e-4, atol=4 * ulp)
+
+
+def test_bench_multi_rank_branch_runs_staged_world2():
+    """VERDICT r5 "next" #9: the N > 1 branch of bench.py cannot rot -- two STAGED ranks on the one test GPU (RSA_BENCH_STAGED=1:
+    collectives carried by gloo through host memory, tools/staged_dist.py) run the `--gpus 2` path at a small size through the
+    launcher the driver uses and print ONE JSON line with the contract's keys, the in-job world-1 reference and the flat
+    side figures inside `roofline`.  Exercises the code path and the keys; not a measurement."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, RSA_BENCH_STAGED='1', RSA_BENCH_EXTRAS_DEADLINE_S='240', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1',
+           '--items', '200001', '--users', '20001', '--batch', '512', '--neg', '64']
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, out.stdout[-2000:]
+    line = json.loads(lines[0])
+    for key in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
+                'dtype', 'data', 'config', 'roofline'):
+        assert key in line, key
+    assert line['n_gpus'] == 2 and line['steps'] == 3 and line['scaling'] == 'weak' and line['value'] > 0
+    assert line['config']['global_batch'] == 1024 and 'row-sharded x2' in line['config']['parallelism']
+    roof = line['roofline']
+    for key in ('frac', 'achieved', 'peak', 'world1_ms_per_step', 'efficiency_vs_world1', 'train_step_ms', 'train_step_ssm_ms'):
+        assert isinstance(roof.get(key), (int, float)), (key, roof)
+    assert line['backend'].startswith('staged') and line['ranks_seen'] == 2

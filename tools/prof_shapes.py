@@ -158,6 +158,27 @@ elif shape == 'softmax_dx_B2048_N1e6':
 
     def step():
         ra.ops.probs_t_query(probs, q, out=gx)
+elif shape in ('softmax_dw_B2048_N1e6', 'softmax_dq_nowrite_B2048_N1e6', 'softmax_train_B2048_N1e6'):
+    # the full-softmax backward that never holds [B, N] (round 6): d/d items with the softmax tile recomputed in registers
+    # (rsa_fullscore_softmax_dw); d/d query from the recompute pass without the score store; the whole training step
+    item = table(1_000_001, 1)
+    q = user[1:2049].contiguous()
+    lse = ra.ops.fullscore(item, q, want_lse=True)[1]
+    sc = torch.full((2048,), 1.0 / 2048, device=dev)
+    gw = torch.empty_like(item)
+    if shape.startswith('softmax_dw'):
+        def step():
+            ra.ops.fullscore_softmax_dw(item, q, lse, sc, out=gw)
+    elif shape.startswith('softmax_dq'):
+        def step():
+            ra.ops.fullscore_softmax(item, q, lse, sc, want_query_grad=True, want_probs=False)
+    else:
+        from recstudio_amd.scorer import full_lse
+        wt, qt = item.requires_grad_(True), q.clone().requires_grad_(True)
+
+        def step():
+            wt.grad = qt.grad = None
+            full_lse(qt, wt).mean().backward()
 elif shape == 'seg_gather_B8192_L50':
     n6, B, L = 1_000_001, 8192, 50
     item = table(n6, 1)
