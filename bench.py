@@ -366,6 +366,11 @@ def side_figures(extra):
     put('softmax_train_step_peak_extra_mb', 'fullscore', 'softmax_train_step_peak_extra_MB')
     put('softmax_train_step_b8192_ms', 'fullscore', 'softmax_train_step_B8192_ms')
     put('softmax_train_b8192_frac', 'fullscore', 'softmax_train_B8192_frac')
+    put('softmax_train_step_b8192_peak_extra_mb', 'fullscore', 'softmax_train_step_B8192_peak_extra_MB')
+    put('softmax_train_step_recompute_ms', 'fullscore', 'softmax_train_step_recompute_ms')
+    put('softmax_train_recompute_frac', 'fullscore', 'softmax_train_recompute_frac')
+    put('softmax_train_step_store_peak_extra_mb', 'fullscore', 'softmax_train_step_store_peak_extra_MB')
+    put('fullscore_flash_forward_tflops', 'fullscore', 'flash_forward_tflops')
     put('softmax_train_step_store_ms', 'fullscore', 'softmax_train_step_store_ms')
     put('softmax_train_store_frac', 'fullscore', 'softmax_train_store_frac')
     put('fullscore_grad_items_recompute_tflops', 'fullscore', 'grad_items_recompute_tflops')
@@ -770,35 +775,43 @@ def main():
                 full_lse(qq, w5).mean().backward()
             fs = extra['fullscore']
             mode0 = sc_mod.FULL_SOFTMAX_BACKWARD
-            sc_mod.FULL_SOFTMAX_BACKWARD = 'recompute'
-            t_sm = time_gpu(softmax_step, 5, 2) * 1e3
-            torch.cuda.reset_peak_memory_stats()
-            base_mem = torch.cuda.memory_allocated()
-            softmax_step()
-            torch.cuda.synchronize()
+
+            def step_ms_and_peak(mode, qq=qq5, steps=5):
+                sc_mod.FULL_SOFTMAX_BACKWARD = mode
+                t = time_gpu(lambda: softmax_step(qq), steps, 2) * 1e3
+                torch.cuda.reset_peak_memory_stats()
+                base_mem = torch.cuda.memory_allocated()
+                softmax_step(qq)
+                torch.cuda.synchronize()
+                return t, round((torch.cuda.max_memory_allocated() - base_mem) / 2 ** 20, 1)
+            # 'flash' (the default): forward = logsumexp + d/d query in one pass, backward = one item-stationary recompute pass:
+            # FOUR products of 2 B d N flop, no [B, N]
+            t_sm, peak_sm = step_ms_and_peak('flash')
             fs['softmax_train_step_ms'] = round(t_sm, 3)
-            fs['softmax_train_step_peak_extra_MB'] = round((torch.cuda.max_memory_allocated() - base_mem) / 2 ** 20, 1)
-            fs['softmax_train_frac'] = round(5 * flops / 157.3e12 * 1e3 / t_sm, 4)
-            # B = 8192: 32 GB of [B, N] in the stored form; here the same two recompute passes, 4 x the flops
+            fs['softmax_train_step_peak_extra_MB'] = peak_sm
+            fs['softmax_train_frac'] = round(4 * flops / 157.3e12 * 1e3 / t_sm, 4)
+            # B = 8192: 32 GB of [B, N] in the stored form; here the same two passes, 4 x the flops
             b8k = 8192
             q8k = user[1:b8k + 1].detach().clone().requires_grad_(True)
-            t_sm8 = time_gpu(lambda: softmax_step(q8k), 3, 1) * 1e3
+            t_sm8, peak8 = step_ms_and_peak('flash', q8k, 3)
             fs['softmax_train_step_B8192_ms'] = round(t_sm8, 3)
-            fs['softmax_train_B8192_frac'] = round(5 * flops * (b8k / b5) / 157.3e12 * 1e3 / t_sm8, 4)
+            fs['softmax_train_step_B8192_peak_extra_MB'] = peak8
+            fs['softmax_train_B8192_frac'] = round(4 * flops * (b8k / b5) / 157.3e12 * 1e3 / t_sm8, 4)
             del q8k
-            sc_mod.FULL_SOFTMAX_BACKWARD = 'store'
-            t_sm_st = time_gpu(softmax_step, 5, 2) * 1e3
-            torch.cuda.reset_peak_memory_stats()
-            base_mem = torch.cuda.memory_allocated()
-            softmax_step()
-            torch.cuda.synchronize()
+            # 'recompute': lse-only forward + two recompute passes (five products, no [B, N]); 'store': round 5 (four products, one
+            # [B, N-1] write + read-back: 8 GB at this shape)
+            t_rc, _ = step_ms_and_peak('recompute')
+            fs['softmax_train_step_recompute_ms'] = round(t_rc, 3)
+            fs['softmax_train_recompute_frac'] = round(5 * flops / 157.3e12 * 1e3 / t_rc, 4)
+            t_sm_st, peak_st = step_ms_and_peak('store')
             fs['softmax_train_step_store_ms'] = round(t_sm_st, 3)
-            fs['softmax_train_step_store_peak_extra_MB'] = round((torch.cuda.max_memory_allocated() - base_mem) / 2 ** 20, 1)
+            fs['softmax_train_step_store_peak_extra_MB'] = peak_st
             fs['softmax_train_store_frac'] = round(4 * flops / 157.3e12 * 1e3 / t_sm_st, 4)
             sc_mod.FULL_SOFTMAX_BACKWARD = mode0
             # where the step goes: all in-tree MFMA kernels
             lse5 = ra.ops.fullscore(w5.detach(), qq5.detach(), want_lse=True)[1]
             scale5 = torch.full((b5,), 1.0 / b5, device=dev)
+            t_fl = time_gpu(lambda: ra.ops.fullscore_lse_grad(w5.detach(), qq5.detach()), 5, 2) * 1e3
             t_dq = time_gpu(lambda: ra.ops.fullscore_softmax(w5.detach(), qq5.detach(), lse5, scale5, want_query_grad=True,
                                                              want_probs=False), 5, 2) * 1e3
             gw5 = torch.empty_like(w5)
@@ -813,12 +826,14 @@ def main():
             fs['grad_items_tflops'] = round(flops / t_gx / 1e9, 1)
             fs['grad_items_recompute_tflops'] = round(2 * flops / t_dw / 1e9, 1)
             fs['grad_query_recompute_tflops'] = round(2 * flops / t_dq / 1e9, 1)
+            fs['flash_forward_tflops'] = round(2 * flops / t_fl / 1e9, 1)
             fs['softmax_train_step_parts_ms'] = {
+                'flash_forward__lse_and_grad_query': round(t_fl, 3),
                 'forward_lse': round(t_lse, 3),
                 'recompute__grad_query_no_write': round(t_dq, 3),
                 'recompute__grad_items_no_probs': round(t_dw, 3),
                 'store_form': {'recompute_write_and_grad_query': round(t_rec_dq, 3), 'grad_items_from_stored_probs': round(t_gx, 3)},
-                'fp32_mfma_floor_ms': {'five_gemms': round(5 * flops / 157.3e12 * 1e3, 2), 'four_gemms': round(4 * flops / 157.3e12 * 1e3, 2)}}
+                'fp32_mfma_floor_ms': {'four_gemms': round(4 * flops / 157.3e12 * 1e3, 2), 'five_gemms': round(5 * flops / 157.3e12 * 1e3, 2)}}
             del w5, qq5
         except Exception as e:
             extra['fullscore']['softmax_train_step_error'] = repr(e)[:200]

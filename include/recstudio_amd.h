@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define RSA_ABI_VERSION 10  /* 10: rsa_fullscore_softmax_dw (d/d items of the full softmax with the softmax tile recomputed on the matrix cores: no
+#define RSA_ABI_VERSION 10  /* 10: rsa_fullscore_lse_grad (flash forward: logsumexp + d/d query in one pass); rsa_fullscore_softmax_dw (d/d items of the full softmax with the softmax tile recomputed on the matrix cores: no
                                [B, N] matrix anywhere in the backward); rsa_fullscore_softmax_dq: probs may be NULL (not written);
                                9: every entry point that took more than 12 positional arguments takes ONE argument block whose first field is its
                                own size (see "Versioned argument blocks"): rsa_popular_args (rsa_sample_popular, rsa_popular_lookup), rsa_loss_args
@@ -570,6 +570,17 @@ int rsa_fullscore_softmax_dq(const float* item_table, int64_t n_items, int32_t d
 
 /* probs == NULL (ABI 10): the softmax tile feeds the second product and is NOT written -- together with
  * rsa_fullscore_softmax_dw below a backward that never holds [B, N] ("only if [B, N] is never written"). */
+
+/* FLASH forward of the full softmax (ABI 10): lse[q] = logsumexp_i <q, item_i> over rows 1 .. n_items - 1 AND
+ * query_grad[q, :] = d lse[q] / d q = softmax_q @ items[1:] in ONE pass over the catalog -- the softmax tile is formed against a
+ * running per-query reference that only moves when a tile's maximum exceeds it by more than 8 (the dQ accumulators and the running
+ * sum are then rescaled: rare after the first tiles), per-item-range records (reference, sum, unnormalised sum P * item) are merged
+ * in range order (reproducible).  A training step of SoftmaxLoss (loss_func.py:39-47 over scorer.py:16) is then this call (two
+ * products of 2 B N d flop) + rsa_fullscore_softmax_dw (two more): d loss/d query = upstream[q] * query_grad[q], no [B, N] matrix,
+ * no second pass for the query gradient.  workspace: rsa_fullscore_lse_grad_workspace_bytes.  dim in {32, 64, 128}. */
+int64_t rsa_fullscore_lse_grad_workspace_bytes(int64_t n_query, int64_t n_items, int32_t dim);
+int rsa_fullscore_lse_grad(const float* item_table, int64_t n_items, int32_t dim, const float* query, int64_t n_query,
+                           float* lse, float* query_grad, void* workspace, int64_t workspace_bytes, rsa_stream_t stream);
 
 /* d lse / d items WITHOUT probs (ABI 10): item_grad[i, :] = sum_b row_scale[b] * exp(<q_b, item_i> - lse[b]) * q_b for rows
  * i = 1 .. n_items - 1, item_grad[0, :] = 0 -- the reference's autograd through loss_func.py:39-47 over scorer.py:16.  Item-

@@ -223,6 +223,8 @@ SIGNATURES = {
     'rsa_bpr_sgd_prepare': (c_int, [POINTER(BprSgdArgs), c_void_p]),
     'rsa_bpr_sgd_apply': (c_int, [POINTER(BprSgdArgs), c_void_p]),
     'rsa_probs_t_query': (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int32, c_void_p, c_void_p]),
+    'rsa_fullscore_lse_grad_workspace_bytes': (c_int64, [c_int64, c_int64, c_int32]),
+    'rsa_fullscore_lse_grad': (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     'rsa_fullscore_softmax_dw': (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     'rsa_rng_advance': (c_int, [c_void_p, c_uint64, c_void_p]),
     'rsa_placement_probe': (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_uint32, c_void_p]),

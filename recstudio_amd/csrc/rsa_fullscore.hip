@@ -96,7 +96,17 @@ struct FilterArgs {
 // 16 * D/32 accumulator registers for the whole item range and leaves the kernel once (per-range partials).
 // PW = false (DQ only): the P tile feeds the second product and is NOT written -- the backward that never holds [B, N]
 // (rsa_fullscore_softmax_dq with probs == NULL; d/d items then comes from rsa_fullscore_softmax_dw, rsa_dx.hip).
-template <int D, bool LSE, bool SCORES, bool FILTER, int MODE = 0, bool DQ = false, bool PW = true>
+// FL = true (DQ, PW = false): FLASH forward of the full softmax -- logsumexp AND d lse/d query = softmax @ items in ONE pass over the
+// catalog (rsa_fullscore_lse_grad).  The softmax tile is formed against a running per-query REFERENCE instead of a known
+// logsumexp: P = exp(S - ref); the reference only moves when a tile's maximum exceeds it by more than FL_SLACK (then the
+// dQ accumulators and the running sum are rescaled by exp(ref_old - ref_new): rare after the first tiles), so P <= e^FL_SLACK
+// and nothing overflows.  Per item range the kernel leaves (ref, sum P) and the unnormalised sum P * item; the merge kernel
+// brings the ranges to a common reference.  With it a training step needs FOUR products of 2 B N d flop and no [B, N] matrix:
+// this pass (2) + rsa_fullscore_softmax_dw (2).
+#ifndef RSA_FS_FL_SLACK
+#define RSA_FS_FL_SLACK 8.f
+#endif
+template <int D, bool LSE, bool SCORES, bool FILTER, int MODE = 0, bool DQ = false, bool PW = true, bool FL = false>
 __global__ __launch_bounds__(256, DQ ? RSA_FS_DQ_MIN_BLOCKS : RSA_FS_MIN_BLOCKS) void fullscore_kernel(const float* __restrict__ item_table, int64_t n_items,
                                                         const float* __restrict__ query, int64_t n_query,
                                                         float* __restrict__ scores, int64_t score_ld,
@@ -249,6 +259,8 @@ __global__ __launch_bounds__(256, DQ ? RSA_FS_DQ_MIN_BLOCKS : RSA_FS_MIN_BLOCKS)
   float run_m = -INFINITY, run_s = 0.f;
   static_assert(!DQ || (SCORES && !LSE && !FILTER && MODE == 0 && STG == 1 && D % 32 == 0), "DQ: softmax-backward variant only");
   static_assert(PW || DQ, "PW = false: only the dQ variant can do without the score store");
+  static_assert(!FL || (DQ && !PW), "FL: the flash forward is the dQ variant without the score store");
+  float fl_ref = -INFINITY, fl_sum = 0.f;     // FL: the query's running reference (same in both lane halves) and this half's sum of P
   constexpr int DB = D / 32;
   f32x16 dq[DQ ? DB : 1];
   if constexpr (DQ) {
@@ -288,15 +300,47 @@ __global__ __launch_bounds__(256, DQ ? RSA_FS_DQ_MIN_BLOCKS : RSA_FS_MIN_BLOCKS)
     run_s = sum;
   };
   // (b) the parts with memory side effects (score rows, candidate lists)
-  auto emit = [&](const f32x16& acc, int64_t i0, int pbuf) __attribute__((always_inline)) {
+  auto emit = [&](const f32x16& acc, int64_t i0, int pbuf, auto masked) __attribute__((always_inline)) {
     if constexpr (SCORES) {
       // transpose the wave's 32 (items) x 32 (queries) tile through LDS so that every half-wave
       // writes 128 contiguous bytes of one query's score row
       f32x16 pv;
+      if constexpr (FL) {
+        float v[16];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        pv[r] = softmax_out ? my_scale * __expf(acc[r] - my_lse) : acc[r];
-        if constexpr (PW) tpose[wave][j][(r & 3) + 8 * (r >> 2) + 4 * h] = pv[r];
+        for (int r = 0; r < 16; ++r) {
+          v[r] = acc[r];
+          if constexpr (decltype(masked)::value) {     // only the last tiles of a range can be partial
+            if (!(i0 + (r & 3) + 8 * (r >> 2) + 4 * h < i_end)) v[r] = -INFINITY;
+          }
+        }
+        float tmax = fmaxf(fmaxf(v[0], v[1]), v[2]);
+#pragma unroll
+        for (int r = 3; r < 15; r += 2) tmax = fmaxf(fmaxf(tmax, v[r]), v[r + 1]);
+        tmax = fmaxf(tmax, v[15]);
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));            // the query's other 16 items of the tile
+        if (__ballot(tmax > fl_ref + RSA_FS_FL_SLACK) != 0ull) {   // wave-uniform, rare: some query's reference moves
+          const float nr = tmax > fl_ref + RSA_FS_FL_SLACK ? tmax : fl_ref;
+          const float sc = nr == fl_ref ? 1.f : __expf(fl_ref - nr);     // (first tile: exp(-inf) = 0 on accumulators that are 0)
+#pragma unroll
+          for (int db = 0; db < DB; ++db) dq[db] *= sc;
+          fl_sum *= sc;
+          fl_ref = nr;
+        }
+        const float ref = fl_ref == -INFINITY ? 0.f : fl_ref;   // (nothing seen yet: every score is -inf, P = 0)
+        float ts = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          pv[r] = __expf(v[r] - ref);
+          ts += pv[r];
+        }
+        fl_sum += ts;
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          pv[r] = softmax_out ? my_scale * __expf(acc[r] - my_lse) : acc[r];
+          if constexpr (PW) tpose[wave][j][(r & 3) + 8 * (r >> 2) + 4 * h] = pv[r];
+        }
       }
       if constexpr (DQ) {
         // rows past the item range are zero in LDS (fetch), so their (finite) P values add nothing
@@ -391,7 +435,7 @@ __global__ __launch_bounds__(256, DQ ? RSA_FS_DQ_MIN_BLOCKS : RSA_FS_MIN_BLOCKS)
   };
   if (n_tiles == 0) {
     store_dq();
-    if (LSE && h == 0 && q < n_query) lse_part[(size_t)q * splits + blockIdx.x] = make_float2(-INFINITY, 0.f);
+    if ((LSE || FL) && h == 0 && q < n_query) lse_part[(size_t)q * splits + blockIdx.x] = make_float2(-INFINITY, 0.f);
     if (FILTER && q < n_query) flt.seg_cnt[seg] = 0;
     return;
   }
@@ -427,7 +471,7 @@ __global__ __launch_bounds__(256, DQ ? RSA_FS_DQ_MIN_BLOCKS : RSA_FS_MIN_BLOCKS)
     // plain score-writing variant loses by the same reordering, 4.82 -> 5.00 ms: its MFMA chain then starts behind the
     // epilogue's VALU / LDS work.)
     constexpr bool EMIT_FIRST = USE_DMA && DQ;
-    if constexpr (EMIT_FIRST) emit(acc_prev, i_begin + (int64_t)(u - 1) * TI, prv);
+    if constexpr (EMIT_FIRST) emit(acc_prev, i_begin + (int64_t)(u - 1) * TI, prv, masked);
     const f32x16 acc = mfma_tile(cur, sub);
     if constexpr (MODE != 0) acc_prev = to_score(acc_prev, i_begin + (int64_t)(u - 1) * TI);
     if constexpr (LSE) {
@@ -444,7 +488,7 @@ __global__ __launch_bounds__(256, DQ ? RSA_FS_DQ_MIN_BLOCKS : RSA_FS_MIN_BLOCKS)
         __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
       }
     }
-    if constexpr (!EMIT_FIRST) emit(acc_prev, i_begin + (int64_t)(u - 1) * TI, prv);
+    if constexpr (!EMIT_FIRST) emit(acc_prev, i_begin + (int64_t)(u - 1) * TI, prv, masked);
     if constexpr (USE_DMA) {
       __builtin_amdgcn_sched_barrier(0);    // ... and the wait at the bottom, behind the whole MFMA chain
       __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0): this wave's direct loads have landed
@@ -477,8 +521,12 @@ __global__ __launch_bounds__(256, DQ ? RSA_FS_DQ_MIN_BLOCKS : RSA_FS_MIN_BLOCKS)
   for (; u < total_tiles; ++u) iteration(u, std::true_type{}, std::false_type{}, NoBuf{});
   if constexpr (MODE != 0) acc_prev = to_score(acc_prev, i_begin + (int64_t)(total_tiles - 1) * TI);
   if constexpr (LSE) lse_update(acc_prev, i_begin + (int64_t)(total_tiles - 1) * TI, std::true_type{});
-  emit(acc_prev, i_begin + (int64_t)(total_tiles - 1) * TI, DQ ? rb_prv : ((total_tiles - 1) & 1));
+  emit(acc_prev, i_begin + (int64_t)(total_tiles - 1) * TI, DQ ? rb_prv : ((total_tiles - 1) & 1), std::true_type{});
   store_dq();
+  if constexpr (FL) {       // (reference, sum of P over this item range): the same record the logsumexp variant leaves
+    const float tot = fl_sum + __shfl_xor(fl_sum, 32, 64);
+    if (h == 0 && q < n_query) lse_part[(size_t)q * splits + blockIdx.x] = make_float2(fl_ref, tot);
+  }
   if (FILTER && q < n_query) flt.seg_cnt[seg] = my_cnt;
   if constexpr (LSE) {
     // fold the two k-halves' item subsets (lanes j and j+32 hold the same query)
@@ -1160,6 +1208,75 @@ extern "C" int rsa_fullscore_softmax_dq(const float* item_table, int64_t n_items
   hipLaunchKernelGGL(dq_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s,
                      reinterpret_cast<const float4*>(part), (int)splits_used, n4, reinterpret_cast<float4*>(query_grad));
   RSA_CHECK_LAUNCH("rsa_fullscore_softmax_dq");
+  return RSA_OK;
+}
+
+// lse[q] and out[q, :] = softmax_q @ items from the flash forward's per-range records: ranges brought to the common
+// reference M = max_s ref_s, summed in range order (reproducible)
+__global__ __launch_bounds__(256) void flash_merge_kernel(const float2* __restrict__ part, const float* __restrict__ dq_part, int splits,
+                                                          int64_t n_query, int dim, float* __restrict__ lse, float* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;      // one thread per (query, 4 columns)
+  const int d4 = dim / 4;
+  if (i >= n_query * d4) return;
+  const int64_t q = i / d4;
+  float m = -INFINITY;
+  for (int s = 0; s < splits; ++s) m = fmaxf(m, part[(size_t)q * splits + s].x);
+  float den = 0.f;
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int s = 0; s < splits; ++s) {
+    const float2 p = part[(size_t)q * splits + s];
+    if (p.x == -INFINITY) continue;
+    const float w = expf(p.x - m);
+    den += p.y * w;
+    const float4 v = reinterpret_cast<const float4*>(dq_part)[(size_t)s * n_query * d4 + i];
+    a.x += v.x * w; a.y += v.y * w; a.z += v.z * w; a.w += v.w * w;
+  }
+  const float inv = 1.f / den;
+  reinterpret_cast<float4*>(out)[i] = make_float4(a.x * inv, a.y * inv, a.z * inv, a.w * inv);
+  if (i - q * d4 == 0) lse[q] = m + logf(den);
+}
+
+extern "C" int64_t rsa_fullscore_lse_grad_workspace_bytes(int64_t n_query, int64_t n_items, int32_t dim) {
+  if (n_query <= 0 || n_items <= 1 || dim <= 0) return 0;
+  int64_t per, splits_used;
+  softmax_plan(n_query, n_items, per, splits_used);
+  return splits_used * n_query * (int64_t)dim * (int64_t)sizeof(float) + align256(splits_used * n_query * (int64_t)sizeof(float2)) + 512;
+}
+
+extern "C" int rsa_fullscore_lse_grad(const float* item_table, int64_t n_items, int32_t dim, const float* query, int64_t n_query,
+                                      float* lse, float* query_grad, void* workspace, int64_t workspace_bytes, rsa_stream_t stream) {
+  RSA_CHECK_ARG(n_query >= 0 && n_items >= 2, "rsa_fullscore_lse_grad: need n_items >= 2");
+  if (n_query == 0) return RSA_OK;
+  RSA_CHECK_ARG(item_table && query && lse && query_grad, "rsa_fullscore_lse_grad: null pointer");
+  if (dim != 32 && dim != 64 && dim != 128) {
+    rsa::set_error("rsa_fullscore_lse_grad: dim=%d: the MFMA full-score kernel is built for dim in {32, 64, 128}", dim);
+    return RSA_ERR_UNSUPPORTED;
+  }
+  RSA_CHECK_ARG(workspace && workspace_bytes >= rsa_fullscore_lse_grad_workspace_bytes(n_query, n_items, dim),
+                "rsa_fullscore_lse_grad: workspace too small (rsa_fullscore_lse_grad_workspace_bytes)");
+  const int64_t n_cols = n_items - 1;
+  const unsigned groups = (unsigned)((n_query + QB - 1) / QB);
+  int64_t per, splits_used;
+  softmax_plan(n_query, n_items, per, splits_used);
+  char* ws = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
+  float2* part = reinterpret_cast<float2*>(ws);
+  float* dq_part = reinterpret_cast<float*>(ws + align256(splits_used * n_query * (int64_t)sizeof(float2)));
+  const FilterArgs ep{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, dq_part};
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 grid((unsigned)splits_used, groups);
+#define RSA_FL(DD)                                                                                                                       \
+  hipLaunchKernelGGL((fullscore_kernel<DD, false, true, false, 0, true, false, true>), grid, dim3(256), 0, s, item_table, n_items, query, \
+                     n_query, (float*)nullptr, n_cols, part, (int)splits_used, per, (int64_t)1, n_cols, ep)
+  switch (dim) {
+    case 32: RSA_FL(32); break;
+    case 64: RSA_FL(64); break;
+    default: RSA_FL(128); break;
+  }
+#undef RSA_FL
+  const int64_t n4 = n_query * dim / 4;
+  hipLaunchKernelGGL(flash_merge_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, part, dq_part, (int)splits_used, n_query,
+                     (int)dim, lse, query_grad);
+  RSA_CHECK_LAUNCH("rsa_fullscore_lse_grad");
   return RSA_OK;
 }
 

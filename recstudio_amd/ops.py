@@ -848,6 +848,24 @@ def fullscore_softmax(item_table, query, lse, row_scale=None, want_query_grad=Fa
 
 
 @_on_device
+def fullscore_lse_grad(item_table, query):
+    """rsa_fullscore_lse_grad: (lse [B], d lse/d query [B, d] = softmax @ item_table[1:]) in ONE pass over the catalog (the flash
+    forward of the full softmax).  embed_dim <= 128."""
+    item_table = _need(item_table, torch.float32, 'item_table')
+    query = _need(query, torch.float32, 'query')
+    d_in = query.shape[1]
+    tab, q, dim = _pad_k(item_table, query)
+    n_items, B, dev = tab.shape[0], q.shape[0], tab.device
+    lse = torch.empty(B, dtype=torch.float32, device=dev)
+    gq = torch.empty(B, dim, dtype=torch.float32, device=dev)
+    ws_bytes = int(nat.lib().rsa_fullscore_lse_grad_workspace_bytes(B, n_items, dim))
+    ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
+    nat.check(nat.lib().rsa_fullscore_lse_grad(ptr(tab), n_items, dim, ptr(q), B, ptr(lse), ptr(gq), ptr(ws), ws_bytes, _stream()),
+              'rsa_fullscore_lse_grad')
+    return lse, (gq if dim == d_in else gq[:, :d_in].contiguous())
+
+
+@_on_device
 def fullscore_softmax_dw(item_table, query, lse, row_scale=None, out=None):
     """rsa_fullscore_softmax_dw: d/d item_table of sum_b row_scale[b] * logsumexp_i <query_b, item_i> (rows 1.. of the table; row
     0 of the result is zero) with the softmax tile recomputed on the matrix cores -- no [B, N] matrix.  embed_dim <= 128."""

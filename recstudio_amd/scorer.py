@@ -143,34 +143,44 @@ def full_scores(query, items, cosine=False):
     return _FullScoreFn.apply(query, items.contiguous(), mode)
 
 
-# Backward of the full-catalog logsumexp: 'recompute' (default) never holds [B, N] -- d/d query from the query-stationary
-# recompute pass (the softmax tile feeds the second product and is not written), d/d items from the item-stationary one
-# (rsa_fullscore_softmax_dw): five GEMMs of 2 B N d flop per training step, 8 N d bytes of HBM traffic, no [B, N] allocation at any
-# batch size.  'store' is the round-5 form: the recompute pass writes the scaled softmax once ([B, N-1] fp32: 8 GB at B = 2048,
-# N = 1e6, written and read back) and d/d items is a GEMM over it -- four GEMMs, ~15 % faster where the matrix fits.
-FULL_SOFTMAX_BACKWARD = os.environ.get('RSA_FULL_SOFTMAX_BACKWARD', 'recompute')
+# Full-catalog logsumexp under autograd, three forms (RSA_FULL_SOFTMAX_BACKWARD):
+#   'flash' (default)  the forward is the FLASH pass: logsumexp AND d lse/d query = softmax @ items from one walk over the catalog
+#                      (rsa_fullscore_lse_grad); the backward multiplies that [B, d] block by the upstream gradient and runs ONE
+#                      item-stationary recompute pass for d/d items (rsa_fullscore_softmax_dw).  Four GEMMs of 2 B N d flop per
+#                      training step, 8 N d bytes of HBM traffic per pass, NO [B, N] matrix at any batch size.
+#   'recompute'        lse-only forward; d/d query from a query-stationary recompute pass (softmax tile not written), d/d items as
+#                      above: five GEMMs, no [B, N] either (what runs when the query needs no gradient costs one GEMM less).
+#   'store'            the round-5 form: the recompute pass writes the scaled softmax once ([B, N-1] fp32: 8 GB at B = 2048,
+#                      N = 1e6, written and read back) and d/d items is a GEMM over it -- four GEMMs + 16 GB of traffic.
+FULL_SOFTMAX_BACKWARD = os.environ.get('RSA_FULL_SOFTMAX_BACKWARD', 'flash')
 
 
 class _FullLseFn(torch.autograd.Function):
     """logsumexp_i <query_b, weight_i> over item rows 1..N-1 WITHOUT writing [B, N], forward and backward (the reference:
-    loss_func.py:39-47 over the scorer.py:16 matmul, under autograd): the forward is the MFMA kernel's in-register online
-    logsumexp; the backward recomputes the scaled softmax tile by tile on the matrix cores, once query-stationary (d/d query)
-    and once item-stationary (d/d items) -- see FULL_SOFTMAX_BACKWARD."""
+    loss_func.py:39-47 over the scorer.py:16 matmul, under autograd) -- see FULL_SOFTMAX_BACKWARD."""
 
     @staticmethod
     def forward(ctx, query, weight):
-        lse = ops.fullscore(weight, query, want_lse=True)[1]
-        ctx.save_for_backward(query, weight, lse)
+        ctx.mode = FULL_SOFTMAX_BACKWARD if weight.shape[1] <= 128 else 'store'
+        gq_unit = None
+        if ctx.mode == 'flash' and ctx.needs_input_grad[0]:
+            lse, gq_unit = ops.fullscore_lse_grad(weight, query)
+        else:
+            lse = ops.fullscore(weight, query, want_lse=True)[1]
+        ctx.save_for_backward(query, weight, lse, gq_unit)
         return lse
 
     @staticmethod
     def backward(ctx, g):
-        query, weight, lse = ctx.saved_tensors
+        query, weight, lse, gq_unit = ctx.saved_tensors
         need_q, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         g = g.contiguous()
-        if FULL_SOFTMAX_BACKWARD == 'store' or weight.shape[1] > 128:
+        if ctx.mode == 'store':
             return _full_lse_backward_stored(query, weight, lse, g, need_q, need_w)
-        gq = ops.fullscore_softmax(weight, query, lse, g, want_query_grad=True, want_probs=False)[1] if need_q else None
+        gq = None
+        if need_q:
+            gq = g.unsqueeze(1) * gq_unit if gq_unit is not None else \
+                ops.fullscore_softmax(weight, query, lse, g, want_query_grad=True, want_probs=False)[1]
         gw = ops.fullscore_softmax_dw(weight, query, lse, g, out=torch.empty_like(weight)) if need_w else None
         return gq, gw
 

@@ -16,43 +16,80 @@ def ra():
 
 @pytest.mark.parametrize('N,B,d', [(30_001, 256, 128), (5_003, 77, 64), (1_234, 33, 32), (40_007, 1000, 100), (130, 2048, 128), (60_001, 2048, 32)])
 def test_full_softmax_backward_never_holds_the_score_matrix(ra, N, B, d, monkeypatch):
-    """scorer.full_lse (SoftmaxLoss over the whole catalog: loss_func.py:39-47 over scorer.py:16), default backward: d/d query from
-    the query-stationary recompute pass with the softmax tile NOT written (rsa_fullscore_softmax_dq, probs = NULL), d/d items from
-    the item-stationary recompute pass (rsa_fullscore_softmax_dw) == float64 autograd (rtol 2e-4: fp32 sums of B resp. N terms),
-    row 0 of the table gradient exactly zero, ragged sizes (partial item tiles, partial batch chunks, padded embed_dim), an
-    arbitrary upstream gradient per row (sign and zero included) -- and no [B, N-1] allocation: where that matrix would dwarf
-    everything else (B = 2048, N = 60 001, d = 32: 492 MB against 7.7 MB of table) the peak memory of the backward stays below a
-    QUARTER of its size."""
+    """scorer.full_lse (SoftmaxLoss over the whole catalog: loss_func.py:39-47 over scorer.py:16) under autograd, the two forms that
+    never write [B, N]:
+      'flash' (default)  forward = rsa_fullscore_lse_grad (logsumexp AND softmax @ items in one pass, running reference with
+                         rescaling), backward = upstream * that block + rsa_fullscore_softmax_dw (item-stationary recompute);
+      'recompute'        lse-only forward, d/d query from the query-stationary recompute pass with the softmax tile NOT written
+                         (rsa_fullscore_softmax_dq, probs = NULL), d/d items as above;
+    both == float64 autograd (rtol 2e-4: fp32 sums of B resp. N terms), logsumexp to 1e-5, row 0 of the table gradient exactly
+    zero, ragged sizes (partial item tiles, partial batch chunks, padded embed_dim), an arbitrary upstream gradient per row
+    (sign and zero included), scores spread over +-30 so that the flash pass's reference moves -- and no [B, N-1] allocation:
+    where that matrix would dwarf everything else (B = 2048, N = 60 001, d = 32: 492 MB against 7.7 MB of table) the peak
+    memory of forward + backward stays below a QUARTER of its size.  == the stored-softmax form of round 5."""
     from recstudio_amd import scorer
-    monkeypatch.setattr(scorer, 'FULL_SOFTMAX_BACKWARD', 'recompute')
     g = torch.Generator(device=DEV).manual_seed(N + B)
-    w = (torch.randn(N, d, device=DEV, generator=g) * 0.1).requires_grad_(True)
-    q = (torch.randn(B, d, device=DEV, generator=g) * 0.3).requires_grad_(True)
+    w0 = torch.randn(N, d, device=DEV, generator=g) * 0.1
+    w0[N // 2:] *= 6.0                                    # the later items score far higher: the running reference has to move
+    q0 = torch.randn(B, d, device=DEV, generator=g) * (1.5 if d >= 64 else 3.0)
     up = torch.randn(B, device=DEV, generator=g)
     up[::7] = 0
-    lse = scorer.full_lse(q, w)
-    torch.cuda.synchronize()
-    torch.cuda.reset_peak_memory_stats()
-    base = torch.cuda.memory_allocated()
-    (lse * up).sum().backward()
-    torch.cuda.synchronize()
-    peak = torch.cuda.max_memory_allocated() - base
-    wd, qd = w.detach().double().requires_grad_(True), q.detach().double().requires_grad_(True)
+    wd, qd = w0.double().requires_grad_(True), q0.double().requires_grad_(True)
     ref = torch.logsumexp(qd @ wd[1:].t(), -1)
     (ref * up.double()).sum().backward()
-    torch.testing.assert_close(lse.detach().double(), ref.detach(), rtol=1e-5, atol=1e-6)
-    scale_w, scale_q = float(wd.grad.abs().max()), float(qd.grad.abs().max())
-    torch.testing.assert_close(w.grad.double(), wd.grad, rtol=2e-4, atol=2e-6 * scale_w)
-    torch.testing.assert_close(q.grad.double(), qd.grad, rtol=2e-4, atol=2e-6 * scale_q)
-    assert bool((w.grad[0] == 0).all())
-    if B * (N - 1) * 4 > (256 << 20):
-        assert peak < B * (N - 1) * 4 // 4, (peak, B * (N - 1) * 4)
-    # the stored-softmax form (round 5: one [B, N-1] write, four GEMMs) gives the same gradients
-    monkeypatch.setattr(scorer, 'FULL_SOFTMAX_BACKWARD', 'store')
-    w2, q2 = w.detach().clone().requires_grad_(True), q.detach().clone().requires_grad_(True)
-    (scorer.full_lse(q2, w2) * up).sum().backward()
-    torch.testing.assert_close(w2.grad, w.grad, rtol=2e-4, atol=2e-6 * scale_w)
-    torch.testing.assert_close(q2.grad, q.grad, rtol=2e-4, atol=2e-6 * scale_q)
+    smax = float((qd.detach() @ wd.detach()[1:].t()).abs().max())
+    assert smax > 12.0
+    # an fp32 score of magnitude s carries ~s * 2^-23 * sqrt(d)/2 of absolute error, which exp() turns into a RELATIVE error of the
+    # softmax entry (any fp32 implementation, torch's included): the absolute tolerance follows the largest score
+    tol = max(2e-6, 1e-6 * smax)
+    scale_w, scale_q = tol / 2e-6 * float(wd.grad.abs().max()), tol / 2e-6 * float(qd.grad.abs().max())
+    got = {}
+    for mode in ('flash', 'recompute', 'store'):
+        monkeypatch.setattr(scorer, 'FULL_SOFTMAX_BACKWARD', mode)
+        w, q = w0.clone().requires_grad_(True), q0.clone().requires_grad_(True)
+        torch.cuda.synchronize()
+        torch.cuda.reset_peak_memory_stats()
+        base = torch.cuda.memory_allocated()
+        lse = scorer.full_lse(q, w)
+        (lse * up).sum().backward()
+        torch.cuda.synchronize()
+        peak = torch.cuda.max_memory_allocated() - base
+        torch.testing.assert_close(lse.detach().double(), ref.detach(), rtol=1e-5, atol=1e-5)
+        torch.testing.assert_close(w.grad.double(), wd.grad, rtol=2e-4, atol=2e-6 * scale_w)
+        torch.testing.assert_close(q.grad.double(), qd.grad, rtol=2e-4, atol=2e-6 * scale_q)
+        assert bool((w.grad[0] == 0).all()), mode
+        if mode != 'store' and B * (N - 1) * 4 > (256 << 20):
+            assert peak < B * (N - 1) * 4 // 4, (mode, peak, B * (N - 1) * 4)
+        got[mode] = (w.grad, q.grad)
+    for mode in ('recompute', 'store'):
+        torch.testing.assert_close(got[mode][0], got['flash'][0], rtol=2e-4, atol=2e-6 * scale_w)
+        torch.testing.assert_close(got[mode][1], got['flash'][1], rtol=2e-4, atol=2e-6 * scale_q)
+    # only the table needs a gradient: no query-gradient work at all (lse-only forward + the item-stationary pass)
+    monkeypatch.setattr(scorer, 'FULL_SOFTMAX_BACKWARD', 'flash')
+    w = w0.clone().requires_grad_(True)
+    (scorer.full_lse(q0, w) * up).sum().backward()
+    torch.testing.assert_close(w.grad, got['flash'][0], rtol=2e-4, atol=2e-6 * scale_w)      # (its lse comes from the lse-only kernel)
+
+
+def test_flash_forward_entry_point(ra):
+    """rsa_fullscore_lse_grad alone: lse and softmax @ items vs float64, an extreme catalog (one item 80 above the rest: the
+    reference jumps, everything before it rescales to ~0), argument checks."""
+    nat = ra._native
+    N, B, d = 20_001, 130, 128
+    g = torch.Generator(device=DEV).manual_seed(2)
+    w = torch.randn(N, d, device=DEV, generator=g) * 0.1
+    q = torch.randn(B, d, device=DEV, generator=g)
+    w[N - 7] = q[5] * 80.0 / float(q[5] @ q[5])           # <q_5, w> = 80
+    lse, gq = ra.ops.fullscore_lse_grad(w, q)
+    S = q.double() @ w.double()[1:].t()
+    torch.testing.assert_close(lse.double(), torch.logsumexp(S, -1), rtol=1e-5, atol=1e-5)
+    want = torch.softmax(S, -1) @ w.double()[1:]
+    torch.testing.assert_close(gq.double(), want, rtol=2e-4, atol=2e-6 * float(want.abs().max()))
+    lib, p = nat.lib(), nat.ptr
+    ws = torch.empty(int(lib.rsa_fullscore_lse_grad_workspace_bytes(B, N, d)), dtype=torch.uint8, device=DEV)
+    assert lib.rsa_fullscore_lse_grad(p(w), N, d, p(q), B, p(lse), p(gq), p(ws), 16, None) == -1
+    assert lib.rsa_fullscore_lse_grad(p(w), N, 96, p(q), B, p(lse), p(gq), p(ws), ws.numel(), None) == -3
+    assert lib.rsa_fullscore_lse_grad(p(w), N, d, p(q), 0, p(lse), p(gq), None, 0, None) == 0
 
 
 def test_full_softmax_dw_entry_point_checks(ra):

@@ -158,7 +158,7 @@ elif shape == 'softmax_dx_B2048_N1e6':
 
     def step():
         ra.ops.probs_t_query(probs, q, out=gx)
-elif shape in ('softmax_dw_B2048_N1e6', 'softmax_dq_nowrite_B2048_N1e6', 'softmax_train_B2048_N1e6'):
+elif shape in ('softmax_dw_B2048_N1e6', 'softmax_dq_nowrite_B2048_N1e6', 'softmax_train_B2048_N1e6', 'softmax_flash_fwd_B2048_N1e6'):
     # the full-softmax backward that never holds [B, N] (round 6): d/d items with the softmax tile recomputed in registers
     # (rsa_fullscore_softmax_dw); d/d query from the recompute pass without the score store; the whole training step
     item = table(1_000_001, 1)
@@ -172,6 +172,9 @@ elif shape in ('softmax_dw_B2048_N1e6', 'softmax_dq_nowrite_B2048_N1e6', 'softma
     elif shape.startswith('softmax_dq'):
         def step():
             ra.ops.fullscore_softmax(item, q, lse, sc, want_query_grad=True, want_probs=False)
+    elif shape.startswith('softmax_flash'):
+        def step():       # the flash forward: logsumexp + d lse/d query in one pass (rsa_fullscore_lse_grad)
+            ra.ops.fullscore_lse_grad(item, q)
     else:
         from recstudio_amd.scorer import full_lse
         wt, qt = item.requires_grad_(True), q.clone().requires_grad_(True)
