@@ -68,7 +68,7 @@ PREWARM_S = 1.5
 
 
 def prewarm(fn, seconds=None):
-    """Keep the GPU busy with `fn` for `seconds` before a measurement.  Found in round 5 (tools/exp_warm.py): after the
+    """Keep the GPU busy with `fn` for `seconds` before a measurement.  Found in round 5 (profiles/r05_warmup_ramp.json, docs/HISTORY.md 6): after the
     chip has idled -- a fresh process, a host-side table build -- the SAME launch on the SAME allocation runs 7-11 % slower for
     about a second (448 -> 431 at 0.5 s -> 419 us from 1 s on; back to 449 after 5 s of idling) while rocm-smi / amd-smi report the
     same sclk / mclk / fclk.  Rounds 1-4 read that as box-to-box spread: the tracked profiles (120 ms of warm-up in a fresh
@@ -539,7 +539,7 @@ def main():
 
         def train():               # user gradient accumulated by the forward: every negative row is read once
             bufs['train'] = ra.ops.fused_forward(item, user, n, out=bufs.get('train'), fused_bpr=True,
-                                                 want_query_grad=True, **kw)
+                                                 want_query_grad=True, want_scores=False, **kw)
             o = bufs['train']
             return ra.ops.fused_backward(item, user, o['neg_ids'], o['dneg'], query_index=uid, pos_ids=pos,
                                          dpos=o['dpos'], dense_item_grad=False, row_item_grad=True, want_query_grad=False)
@@ -547,7 +547,7 @@ def main():
             ms_two = time_gpu(train_two_pass, max(10, args.steps // 4), 5) * 1e3
             ms_train = time_gpu(train, max(10, args.steps // 4), 5) * 1e3
             t_f = time_gpu(lambda: ra.ops.fused_forward(item, user, n, out=bufs['train'], fused_bpr=True,
-                                                        want_query_grad=True, **kw), max(10, args.steps // 4), 5) * 1e3
+                                                        want_query_grad=True, want_scores=False, **kw), max(10, args.steps // 4), 5) * 1e3
             prof_ms = lambda name: round((profile_record(name) or {}).get('step_kernel_us', 0.0) / 1e3, 4) or None      # noqa: E731
             extra['train_step'] = {'profile_step_kernel_ms': prof_ms('train_step_N1e7_popular_n64_B65536'),
                                    'profile_sgd_step_kernel_ms': prof_ms('sgd_step_N1e7_popular_n64_B65536'),

@@ -196,7 +196,7 @@ typedef struct rsa_fused_args {
                                   fused_loss == 2 (null = 0) */
   float* pos_logp;             /* nullable [M] out (POPULAR, needs pos_ids); INPUT like neg_logp for GIVEN + fused_loss 2 */
   float* pos_score;            /* nullable [M] out (needs pos_ids) */
-  float* neg_score;            /* [M, n] out */
+  float* neg_score;            /* [M, n] out; nullable with fused_loss != 0 (a training forward that keeps no scores: 4 B/triplet less) */
   const float* table_prob;     /* nullable [n_items][2]: interleaved copy {table[i], pop_prob[i]}.  When given,
                                   the CDF probes and the log-prob read share cache lines (one Infinity-Cache
                                   round trip fewer per sampled id); results are identical. */

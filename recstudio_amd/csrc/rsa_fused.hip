@@ -498,7 +498,7 @@ void fused_fwd_kernel(const FwdParams p) {
       tile_rows<LPR, GENERIC, COS, QU, NT>(p.item_table, D, id, p.query, qrow_lane, qf, dot, in2, qn2);
     }
     if constexpr (COS && QU) qn2 = qn2_u;
-    if (act && !(p.seg_stride && empty_slot))
+    if (p.neg_score && act && !(p.seg_stride && empty_slot))       // (null: a training forward whose loss is fused keeps no scores)
       st_out(&p.neg_score[e], empty_slot ? 0.f : finish_score(COS ? p.score_mode : RSA_SCORE_IP, dot, in2, qn2));
 
     // ---- 4. positives (+ the fused BPR epilogue: every tile of a query needs the positive score)
@@ -693,7 +693,7 @@ __global__ __launch_bounds__(256, QG ? RSA_SSM_MIN_WAVES : 1) void fused_ssm_ker
       } else {
         tile_rows_pipe<LPR, NT, RSA_SSM_PIPE_BATCH>(p.item_table, id, qf, dot);      // (the transposed-fold tile needs 164 VGPRs in this frame)
       }
-      st_out(&p.neg_score[e], dot);
+      if (p.neg_score) st_out(&p.neg_score[e], dot);
       const float z = dot - lq;
       if (p.dneg) p.dneg[e] = z;               // staged; rewritten below once the logsumexp is known
       const float m_new = fmaxf(run_m, wave_max(z));
@@ -813,7 +813,7 @@ __global__ __launch_bounds__(256, QG ? RSA_WALK_MIN_WAVES : RSA_WALK_FWD_MIN_WAV
         } else {
           tile_rows_pipe<LPR, NT, RSA_WALK_PIPE_BATCH>(p.item_table, id, qf, dot);
         }
-        st_out(&p.neg_score[e], dot);
+        if (p.neg_score) st_out(&p.neg_score[e], dot);
         const float xd = pos_s - dot;
         const float tt = __expf(-fabsf(xd));
         lsum += (fminf(xd, 0.f) - __logf(1.f + tt)) * w;
@@ -989,8 +989,8 @@ extern "C" int rsa_fused_sample_gather_score(const rsa_fused_args* a, rsa_stream
   RSA_CHECK_ARG(a->query_index != nullptr || a->packed_keys != nullptr || a->n_query_rows >= a->n_queries,
                 "rsa_fused_sample_gather_score: query has fewer rows than n_queries");
   if (numel > 0) {
-    RSA_CHECK_ARG((a->neg_ids || a->packed_keys) && a->neg_score,
-                  "rsa_fused_sample_gather_score: neg_ids/neg_score is null");
+    RSA_CHECK_ARG((a->neg_ids || a->packed_keys) && (a->neg_score || a->fused_loss != 0),
+                  "rsa_fused_sample_gather_score: neg_ids is null, or neg_score is null without a fused loss");
     RSA_CHECK_ARG(a->packed_keys == nullptr || (a->sampler == RSA_SAMPLER_GIVEN && a->num_neg == 1 && !a->pos_ids),
                   "rsa_fused_sample_gather_score: packed_keys needs sampler GIVEN, num_neg == 1 and no positives");
     if (a->sampler != RSA_SAMPLER_GIVEN)

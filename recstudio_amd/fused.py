@@ -151,7 +151,7 @@ class _FusedBPRFn(torch.autograd.Function):
         out = ops.fused_forward(item_weight, query_src, cfg['num_neg'], query_index=cfg.get('query_index'),
                                 pos_ids=cfg['pos_ids'], sampler=cfg['sampler'], neg_ids=cfg.get('neg_ids'),
                                 n_queries=cfg['n_queries'], want_logp=False, fused_loss=loss, want_query_grad=fwd_qgrad,
-                                pos_logp=cfg.get('pos_logp'), neg_logp=cfg.get('neg_logp'), **_pop_kw(cfg))
+                                pos_logp=cfg.get('pos_logp'), neg_logp=cfg.get('neg_logp'), want_scores=False, **_pop_kw(cfg))
         cfg['out'] = out
         ctx.cfg = cfg
         ctx.fwd_qgrad = fwd_qgrad

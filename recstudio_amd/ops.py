@@ -289,7 +289,7 @@ def carve(dev, specs, align=4096):
     Why: the buffers a launch WRITES must not come from separate allocations.  The headline launch (four [B, n] output arrays,
     84 MB of the 2.8 GB it moves) ran 404-409 us on every one of 31 layouts of those arrays inside one allocation (any skew
     between them, any shift, arenas of 86 MB .. 1 GB) and 443-471 us on 5 of 9 sets of separately allocated arrays of the same
-    shapes in the same processes (tools/exp_outbuf.py, exp_outliers.py; moving any ONE of the four into an arena did not help).
+    shapes in the same processes (profiles/r05_output_placement.json; moving any ONE of the four into an arena did not help).
     The class belongs to the allocation; with ``RSA_PLACEMENT=1`` (opt-in) ``placement.pick`` probes candidates and returns one of
     the fast class -- by default the arena is one plain ``torch.empty``."""
     offs, total = [], 0
@@ -314,7 +314,7 @@ def fused_forward(item_table, query, num_neg, *, query_index=None, pos_ids=None,
                   table=None, pop_prob=None, guide=None, guide_log2=0, generator=None, n_queries=None,
                   out=None, want_logp=True, table_prob=None, fused_bpr=False, want_mean=True, cdf_lut=None,
                   want_query_grad=False, rng_state=None, cdf_lines=None, lines_log2=0, fused_loss=None,
-                  pos_logp=None, neg_logp=None, _plan=None, inplace_update=None, n_batches=1):
+                  pos_logp=None, neg_logp=None, _plan=None, inplace_update=None, n_batches=1, want_scores=True):
     """One launch of rsa_fused_sample_gather_score.  Returns a dict with
     neg_ids [M,n] int64, neg_score [M,n], pos_score [M] (if pos_ids), and for the
     popularity sampler neg_logp [M,n], pos_logp [M].  ``out``: a dict returned by an earlier
@@ -328,6 +328,8 @@ def fused_forward(item_table, query, num_neg, *, query_index=None, pos_ids=None,
     epilogue instead (one wave per query carries the logsumexp over its num_neg / 64 tiles); with ids given,
     ``pos_logp`` / ``neg_logp`` are the INPUT log-probabilities.  ``cdf_lines`` / ``lines_log2``: the bucket-line
     form of the popularity sampler's inverse CDF (PopularSamplerModel.cdf_lines).
+    ``want_scores=False`` (with a loss the kernel fuses): ``neg_score`` is not written and not returned -- a training forward
+    needs d loss/d score, not the scores (4 B/triplet less).
     ``n_batches`` = S > 1: a QUEUE of S independent batches consumed by one launch -- ``query_index`` / ``pos_ids`` hold the
     S batches back to back ([S * B]); the outputs are those of S consecutive ``fused_forward`` calls over B queries each,
     concatenated (every batch draws its negatives from its own torch call: the generator is advanced S times), ``loss``
@@ -376,10 +378,13 @@ def fused_forward(item_table, query, num_neg, *, query_index=None, pos_ids=None,
     reuse = out is not None        # caller-provided output buffers (same keys/shapes as returned)
     if fused_loss is None and fused_bpr:
         fused_loss = 'bpr'
+    score_mode = int(cosine) if not isinstance(cosine, bool) else (nat.SCORE_COS if cosine else nat.SCORE_IP)
+    composed = fused_loss == 'bpr' and n != 64 and (dim not in (32, 64, 128, 256) or score_mode != nat.SCORE_IP)
+    keep_scores = want_scores or fused_loss not in ('bpr', 'ssm') or composed
     if not reuse:
         # every output of the launch out of ONE allocation (carve): see there for why
         f32 = torch.float32
-        specs = [('neg_score', (M, n), f32)]
+        specs = [('neg_score', (M, n), f32)] if keep_scores else []
         if sampler != nat.SAMPLER_GIVEN:
             specs.insert(0, ('neg_ids', (M, n), torch.int64))
         if pos_ids is not None:
@@ -401,7 +406,7 @@ def fused_forward(item_table, query, num_neg, *, query_index=None, pos_ids=None,
         pop_prob = _need(pop_prob, torch.float32, 'pop_prob')
         guide = _need_opt(guide, torch.int32, 'guide')
     a.item_table, a.n_items, a.dim = ptr(item_table), n_items, dim
-    a.score_mode = int(cosine) if not isinstance(cosine, bool) else (nat.SCORE_COS if cosine else nat.SCORE_IP)
+    a.score_mode = score_mode
     a.query, a.query_index, a.n_query_rows = ptr(query), ptr(query_index), query.shape[0]
     a.pos_ids, a.n_queries, a.num_neg = ptr(pos_ids), M, n
     a.sampler, a.mask_pad_pos, a.guide_log2 = int(sampler), int(bool(mask_pad_pos)), int(guide_log2)
@@ -415,8 +420,8 @@ def fused_forward(item_table, query, num_neg, *, query_index=None, pos_ids=None,
         a.neg_ids = ptr(neg_ids)
     else:
         a.neg_ids, a.neg_logp, a.pos_logp = ptr(neg_ids), ptr(out.get('neg_logp')), ptr(out.get('pos_logp'))
-    a.pos_score, a.neg_score = ptr(out.get('pos_score')), ptr(out['neg_score'])
-    if fused_loss == 'bpr' and n != 64 and (dim not in (32, 64, 128, 256) or a.score_mode != nat.SCORE_IP):
+    a.pos_score, a.neg_score = ptr(out.get('pos_score')), ptr(out['neg_score'] if keep_scores else None)
+    if composed:
         # queries longer than one tile are walked by one workgroup (no atomics): that kernel covers the stock dims and
         # the inner product; anything else runs the loss as its own (equally deterministic) launch
         if want_query_grad:

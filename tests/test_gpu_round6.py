@@ -204,3 +204,35 @@ def test_bench_multi_rank_branch_runs_staged_world2():
     for key in ('frac', 'achieved', 'peak', 'world1_ms_per_step', 'efficiency_vs_world1', 'train_step_ms', 'train_step_ssm_ms'):
         assert isinstance(roof.get(key), (int, float)), (key, roof)
     assert line['backend'].startswith('staged') and line['ranks_seen'] == 2
+
+
+@pytest.mark.parametrize('loss,n,sampler', [('bpr', 64, 'popular'), ('bpr', 1024, 'uniform'), ('ssm', 256, 'popular')])
+def test_training_forward_without_the_score_store(ra, loss, n, sampler):
+    """ops.fused_forward(want_scores=False) -- what the autograd training step issues: the kernel fuses the loss, so the [M, n]
+    scores (4 B per triplet) are neither written nor returned (rsa_fused_args.neg_score = NULL); ids, loss, d loss/d score and
+    d loss/d query are bit-equal to the call that keeps them.  Without a fused loss a null neg_score is an argument error."""
+    nat = ra._native
+    N, U, d, B = 50_001, 4_001, 128, 512
+    g = torch.Generator(device=DEV).manual_seed(7)
+    item = torch.randn(N, d, device=DEV, generator=g) * 0.1
+    user = torch.randn(U, d, device=DEV, generator=g) * 0.1
+    uid = torch.randint(1, U, (B,), device=DEV, generator=g)
+    pos = torch.randint(1, N, (B,), device=DEV, generator=g)
+    kw = dict(query_index=uid, pos_ids=pos, fused_loss=loss, want_query_grad=True)
+    if sampler == 'popular':
+        ps = ra.PopularSamplerModel(torch.randint(0, 50, (N,), generator=torch.Generator().manual_seed(1))).to(DEV)
+        kw.update(sampler=nat.SAMPLER_POPULAR, **ps.lookup_kwargs())
+    else:
+        kw.update(sampler=nat.SAMPLER_UNIFORM)
+    torch.manual_seed(11)
+    full = ra.ops.fused_forward(item, user, n, **kw)
+    torch.manual_seed(11)
+    lean = ra.ops.fused_forward(item, user, n, want_scores=False, **kw)
+    assert 'neg_score' in full and 'neg_score' not in lean
+    for k in ('neg_ids', 'loss', 'row_loss', 'dpos', 'dneg', 'query_grad', 'pos_score'):
+        assert torch.equal(full[k], lean[k]), k
+    a = nat.FusedArgs()
+    a.item_table, a.n_items, a.dim, a.query, a.n_query_rows = nat.ptr(item), N, d, nat.ptr(user), U
+    a.n_queries, a.num_neg, a.sampler, a.neg_ids = B, n, nat.SAMPLER_GIVEN, nat.ptr(full['neg_ids'])
+    import ctypes
+    assert nat.lib().rsa_fused_sample_gather_score(ctypes.byref(a), None) == -1

@@ -2,8 +2,8 @@
 # Run ON THE GPU BOX (through gpurun) from the repo root: ONE box, one call -- the bench line the driver would record, the same
 # command under rocprofv3 (kernel trace + FETCH / WRITE / MFMA counters), rocm-smi before / between / after, then every tracked
 # shape alone (tools/collect_shapes.sh).  Everything lands under gpurun_out/; copy the summaries to profiles/.
-#   ROUND=r05 bash tools/collect_round.sh
-export ROUND=${ROUND:-r05}
+#   ROUND=r06 bash tools/collect_round.sh
+export ROUND=${ROUND:-r06}
 mkdir -p gpurun_out/profiles_$ROUND
 smi() { rocm-smi --showclocks --showpower --showmaxpower --showperflevel --showcomputepartition --showmemorypartition --showtemp 2>&1 | grep -v "^=\|^$\|WARNING" ; }
 { echo "# before"; smi; } > gpurun_out/profiles_$ROUND/${ROUND}_box_state.txt

@@ -5,7 +5,7 @@
 # gpurun_out/profiles_$ROUND/${ROUND}_kernel_profiles.{json,txt} (copy those to profiles/).  PASSES="trace" collects the
 # kernel times only.  tools/summarize_shapes.py deletes the rocpd databases of a shape once it has read them.
 export ROUND=${ROUND:-r06}
-SHAPES=${SHAPES:-"headline_N1e7_popular_n64_B65536 N1e7_popular_n64_B4096 N1e7_popular_n64_B16384 N1e8_uniform_n64_B65536 N1e8_uniform_n1024_B4096 N1e8_popular_n64_B65536 ssm_N1e6_popular_n256_B8192 sharded_world1_step sharded_world1_train sgd_step_N1e7_popular_n64_B65536 adam_step_N1e7_popular_n64_B65536 train_step_N1e7_popular_n64_B65536 fullscore_lse_B2048_N1e6 fullscore_top100_B2048_N1e6 softmax_dx_B2048_N1e6 seg_gather_B8192_L50 queue_N1e7_popular_n64_B4096x16 queue_N1e7_popular_n64_B16384x4 sharded_world1_train_ssm sharded_world1_train_nondet"}
+SHAPES=${SHAPES:-"headline_N1e7_popular_n64_B65536 N1e7_popular_n64_B4096 N1e7_popular_n64_B16384 N1e8_uniform_n64_B65536 N1e8_uniform_n1024_B4096 N1e8_popular_n64_B65536 ssm_N1e6_popular_n256_B8192 sharded_world1_step sharded_world1_train sgd_step_N1e7_popular_n64_B65536 adam_step_N1e7_popular_n64_B65536 train_step_N1e7_popular_n64_B65536 fullscore_lse_B2048_N1e6 fullscore_top100_B2048_N1e6 softmax_dx_B2048_N1e6 softmax_flash_fwd_B2048_N1e6 softmax_dw_B2048_N1e6 softmax_dq_nowrite_B2048_N1e6 softmax_train_B2048_N1e6 seg_gather_B8192_L50 queue_N1e7_popular_n64_B4096x16 queue_N1e7_popular_n64_B16384x4 sharded_world1_train_ssm sharded_world1_train_nondet"}
 PASSES=${PASSES:-"trace fetch write"}
 REPO=$(pwd)
 OUT=$REPO/gpurun_out/prof_$ROUND

@@ -137,7 +137,7 @@ elif shape == 'train_step_N1e7_popular_n64_B65536':
     kw = dict(query_index=uid, pos_ids=pos, sampler=nat.SAMPLER_POPULAR, **ps.lookup_kwargs())
 
     def step():       # forward with the user gradient + write-only row-sparse item-gradient rows (bench.py train_step)
-        buf['o'] = ra.ops.fused_forward(item, user, 64, out=buf.get('o'), fused_bpr=True, want_query_grad=True, **kw)
+        buf['o'] = ra.ops.fused_forward(item, user, 64, out=buf.get('o'), fused_bpr=True, want_query_grad=True, want_scores=False, **kw)
         o = buf['o']
         ra.ops.fused_backward(item, user, o['neg_ids'], o['dneg'], query_index=uid, pos_ids=pos, dpos=o['dpos'],
                               dense_item_grad=False, row_item_grad=True, want_query_grad=False)
@@ -200,7 +200,7 @@ else:
 # back-to-back launches first (counted, so that the summariser can skip them), then the K counted ones.
 import time                                     # noqa: E402
 # (round 5: 120 ms was not enough either -- the chip needs about a SECOND of load after idling before the same launch reaches
-# its steady time, tools/exp_warm.py: rounds 1-4's tracked profiles were 7-11 % "cold")
+# its steady time, profiles/r05_warmup_ramp.json: rounds 1-4's tracked profiles were 7-11 % "cold")
 WARM_MS = float(os.environ.get('PROF_WARM_MS', '2500'))
 WARM = 0
 for _ in range(3):
