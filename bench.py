@@ -281,7 +281,7 @@ def box_state(busy_fn=None, device=0):
     return out
 
 
-PROFILE_ROUNDS = ('r05', 'r04', 'r03')
+PROFILE_ROUNDS = ('r06', 'r05', 'r04', 'r03')
 
 
 def profile_record(name):

@@ -220,7 +220,7 @@ def test_training_forward_without_the_score_store(ra, loss, n, sampler):
     pos = torch.randint(1, N, (B,), device=DEV, generator=g)
     kw = dict(query_index=uid, pos_ids=pos, fused_loss=loss, want_query_grad=True)
     if sampler == 'popular':
-        ps = ra.PopularSamplerModel(torch.randint(0, 50, (N,), generator=torch.Generator().manual_seed(1))).to(DEV)
+        ps = ra.PopularSamplerModel(torch.randint(1, 50, (N,), generator=torch.Generator().manual_seed(1))).to(DEV)     # (no zero-probability positives: their loss is NaN, like the reference's)
         kw.update(sampler=nat.SAMPLER_POPULAR, **ps.lookup_kwargs())
     else:
         kw.update(sampler=nat.SAMPLER_UNIFORM)
@@ -236,3 +236,42 @@ def test_training_forward_without_the_score_store(ra, loss, n, sampler):
     a.n_queries, a.num_neg, a.sampler, a.neg_ids = B, n, nat.SAMPLER_GIVEN, nat.ptr(full['neg_ids'])
     import ctypes
     assert nat.lib().rsa_fused_sample_gather_score(ctypes.byref(a), None) == -1
+
+
+def test_full_softmax_training_step_config5_shape_properties(ra):
+    """BASELINE.json configs[4] at full size through autograd (N = 1e6, d = 128, B = 2048; SoftmaxLoss = loss_func.py:39-47 over
+    scorer.py:16), the default 'flash' form -- size-independent properties + float64 spot checks:
+      * logsumexp == the lse-only kernel's (another code path) to 1e-5, and float64 on a sample of rows;
+      * softmax rows sum to 1, so sum_i d loss/d item_i == sum_b g_b q_b (a checksum of the whole [N, d] gradient);
+      * d loss/d item_0 == 0 (the padding row is not part of the catalog);
+      * d loss/d query == float64 softmax @ items on a sample of rows; item-gradient rows == float64 on a sample of items;
+      * the whole step peaks below 1 GB of extra memory where [B, N] alone would be 8 GB."""
+    from recstudio_amd import scorer
+    assert scorer.FULL_SOFTMAX_BACKWARD == 'flash'
+    N, d, B = 1_000_001, 128, 2048
+    g = torch.Generator(device=DEV).manual_seed(55)
+    w = (torch.randn(N, d, device=DEV, generator=g) * 0.1).requires_grad_(True)
+    q = (torch.randn(B, d, device=DEV, generator=g) * 0.5).requires_grad_(True)
+    up = torch.rand(B, device=DEV, generator=g) / B
+    torch.cuda.synchronize()
+    torch.cuda.reset_peak_memory_stats()
+    base = torch.cuda.memory_allocated()
+    lse = scorer.full_lse(q, w)
+    (lse * up).sum().backward()
+    torch.cuda.synchronize()
+    assert torch.cuda.max_memory_allocated() - base < (1 << 30)
+    lse2 = ra.ops.fullscore(w.detach(), q.detach(), want_lse=True)[1]
+    torch.testing.assert_close(lse.detach(), lse2, rtol=1e-5, atol=1e-5)
+    want_sum = (up.double()[:, None] * q.detach().double()).sum(0)
+    torch.testing.assert_close(w.grad.double().sum(0), want_sum, rtol=1e-4, atol=1e-6 * float(want_sum.abs().max()))
+    assert bool((w.grad[0] == 0).all())
+    rows = torch.tensor([0, 1, 1023, 2047], device=DEV)
+    wd = w.detach().double()
+    S = q.detach()[rows].double() @ wd[1:].t()
+    torch.testing.assert_close(lse.detach()[rows].double(), torch.logsumexp(S, -1), rtol=1e-5, atol=1e-5)
+    gq = up[rows].double()[:, None] * (torch.softmax(S, -1) @ wd[1:])
+    torch.testing.assert_close(q.grad[rows].double(), gq, rtol=2e-4, atol=2e-6 * float(gq.abs().max()))
+    items = torch.tensor([1, 2, 500_000, N - 1], device=DEV)
+    P = torch.exp(q.detach().double() @ wd[items].t() - lse.detach().double()[:, None]) * up.double()[:, None]      # [B, 4]
+    gi = P.t() @ q.detach().double()
+    torch.testing.assert_close(w.grad[items].double(), gi, rtol=2e-4, atol=2e-6 * float(gi.abs().max()))
