@@ -1089,7 +1089,8 @@ def main():
                     'ms_per_step': round(ssm_ms[True], 4), 'frac_of_hbm_peak': round(alg_tr / ssm_ms[True] / 1e6 / HBM_PEAK_GBS, 4),
                     'scores_at_home_ms_per_step': round(ssm_ms[False], 4),
                     'what': 'the same in-place SGD step with SampledSoftmaxLoss evaluated on the owners (ssm_step_on_owners: rows '
-                            'read once for scores + query gradient, read-modify-written once by the sorted apply pass) vs the '
+                            'read once for scores + query gradient; solo rows read-modified-written by a second walk by query, '
+                            'shared rows by the sorted apply pass) vs the '
                             'score-at-home protocol; same SURVEY 8d bytes as the BPR step'},
                     'sharded_world1_train_ssm', alg_tr, whole_step=True)
                 del blk, tbl, tbl_t
