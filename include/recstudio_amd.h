@@ -30,7 +30,8 @@
 extern "C" {
 #endif
 
-#define RSA_ABI_VERSION 10  /* 10: rsa_fullscore_lse_grad (flash forward: logsumexp + d/d query in one pass); rsa_fullscore_softmax_dw (d/d items of the full softmax with the softmax tile recomputed on the matrix cores: no
+#define RSA_ABI_VERSION 11  /* 11: rsa_bpr_sgd_prepare / _apply sort the step's user rows WITH its item rows (one radix sort; item_workspace = rsa_scatter_rows_sorted_workspace_bytes(n_queries, num_neg + 1, n_items), user_workspace unused) and draw the negatives inside that sort's first launch; sampler RSA_SAMPLER_GIVEN accepted (neg_ids is an input);
+                               10: rsa_fullscore_lse_grad (flash forward: logsumexp + d/d query in one pass); rsa_fullscore_softmax_dw (d/d items of the full softmax with the softmax tile recomputed on the matrix cores: no
                                [B, N] matrix anywhere in the backward); rsa_fullscore_softmax_dq: probs may be NULL (not written);
                                9: every entry point that took more than 12 positional arguments takes ONE argument block whose first field is its
                                own size (see "Versioned argument blocks"): rsa_popular_args (rsa_sample_popular, rsa_popular_lookup), rsa_loss_args
@@ -431,12 +432,14 @@ int rsa_rows_update_presorted(const rsa_rows_update_args* args, rsa_stream_t str
  * recstudio/model/basemodel/recommender.py:596-646: sampler.forward (ann/sampler.py:86-111 / :243-258), the two tower
  * look-ups, score_func, BPRLoss, loss.backward() and optimizer.step() of torch.optim.SGD (no momentum / weight decay).
  *   rsa_bpr_sgd_prepare  the part that does not read the weights: the negatives (the device random stream, "Philox
- *     state"; sampler RSA_SAMPLER_UNIFORM: ids in [1, n_items); RSA_SAMPLER_POPULAR: `pop`), the step's (item id, element)
- *     pairs sorted by id + the solo classification (item_workspace, solo), the (user id, query) pairs sorted (user_workspace).
+ *     state"; sampler RSA_SAMPLER_UNIFORM: ids in [1, n_items); RSA_SAMPLER_POPULAR: `pop`; RSA_SAMPLER_GIVEN: neg_ids is
+ *     an INPUT) and ONE radix sort of the step's (item id, element) pairs followed by its (user id, query) pairs (user keys
+ *     behind the item keys; item_workspace), + the solo classification of the item part (solo).  The negatives are drawn by
+ *     the sort's first launch (same ids as rsa_sample_uniform / rsa_sample_popular, stored to neg_ids).
  *     A trainer issues it for batch k + 1 on a second stream while batch k's apply runs.
  *   rsa_bpr_sgd_apply    forward + loss + update: rsa_fused_sample_gather_score with the ids given, fused BPR epilogue, user
- *     gradient accumulated in the forward, solo item rows updated in the forward; the shared item rows
- *     (rsa_rows_update_presorted) and the user rows.  loss_out = the batch's mean BPR loss.
+ *     gradient accumulated in the forward, solo item rows updated in the forward; the shared item rows and the user rows by
+ *     the sorted apply pass over the two parts of the sorted pairs.  loss_out = the batch's mean BPR loss.
  * Bit-identical to the same sequence issued entry point by entry point.  dim in {64, 128, 256}. */
 typedef struct rsa_bpr_sgd_args {
   int64_t size;                /* sizeof(rsa_bpr_sgd_args) */
@@ -449,7 +452,7 @@ typedef struct rsa_bpr_sgd_args {
   const int64_t* user_ids;     /* [n_queries] */
   const int64_t* pos_ids;      /* [n_queries] */
   int64_t n_queries;
-  int32_t sampler;             /* RSA_SAMPLER_UNIFORM / RSA_SAMPLER_POPULAR (prepare) */
+  int32_t sampler;             /* RSA_SAMPLER_UNIFORM / RSA_SAMPLER_POPULAR / RSA_SAMPLER_GIVEN (prepare) */
   int32_t _pad;
   const rsa_popular_args* pop; /* HOST pointer, RSA_SAMPLER_POPULAR: the tables (ids / logp / numel / philox fields ignored) */
   uint64_t seed, offset;       /* "Philox state" of the draw (prepare) */
@@ -457,11 +460,11 @@ typedef struct rsa_bpr_sgd_args {
   uint32_t _pad2;
   uint64_t elem_base;
   const float* step_scale;     /* device scalar: -lr */
-  int64_t* neg_ids;            /* [n_queries, num_neg]: out of prepare, in of apply */
+  int64_t* neg_ids;            /* [n_queries, num_neg]: out of prepare (in with RSA_SAMPLER_GIVEN), in of apply */
   uint8_t* solo;               /* [n_queries, 1 + num_neg]: out of prepare, in of apply */
-  void* item_workspace;        /* rsa_scatter_rows_sorted_workspace_bytes(n_queries, num_neg, n_items) */
+  void* item_workspace;        /* rsa_scatter_rows_sorted_workspace_bytes(n_queries, num_neg + 1, n_items): item AND user elements (ABI 11) */
   int64_t item_workspace_bytes;
-  void* user_workspace;        /* rsa_scatter_rows_sorted_workspace_bytes(n_queries, 1, n_users) */
+  void* user_workspace;        /* unused since ABI 11 (nullable) */
   int64_t user_workspace_bytes;
   float* pos_score;            /* [n_queries] out */
   float* neg_score;            /* [n_queries, num_neg] out */

@@ -276,7 +276,7 @@ def build(verbose=False):
     return LIB_PATH
 
 
-ABI_VERSION = 10     # RSA_ABI_VERSION of include/recstudio_amd.h this binding was written against
+ABI_VERSION = 11     # RSA_ABI_VERSION of include/recstudio_amd.h this binding was written against
 
 
 def lib():

@@ -29,6 +29,18 @@ int apply_sorted_segments(const uint64_t* pairs, int64_t total, int64_t slots, c
                           const int64_t* keys, const float* d, const float* upstream, int64_t n_rows, int64_t pad_row,
                           float* target, const SortedLayout& L, hipStream_t s);
 
+// The in-place SGD step's sort (rsa_sorted.hip): the step's M * (num_neg + 1) item elements and its M user elements in ONE
+// radix sort (user keys behind the item keys), then the solo classification of the item part.  `draw` (nullable; kind 0 = no):
+// pass 0's histogram launch also DRAWS the negatives into neg_ids (rsa_radix.hpp StepDraw).
+struct StepDraw;
+int64_t step_all_workspace_bytes(int64_t n_queries, int32_t num_neg);
+int sort_step_all(const int64_t* pos_ids, int64_t* neg_ids, const int64_t* user_ids, int64_t n_queries, int32_t num_neg,
+                  int64_t n_items, int64_t n_users, uint8_t* solo, void* workspace, int64_t workspace_bytes, const StepDraw* draw,
+                  hipStream_t s, const char* who);
+int apply_step_all(bool users, const float* query, const int64_t* query_index, int32_t dim, int64_t n_queries, int32_t num_neg,
+                   const float* dpos, const float* dneg, const float* upstream, int64_t n_items, int64_t n_users, float* target,
+                   void* workspace, hipStream_t s);
+
 // PopularSamplerModel.forward on explicit arguments (rsa_sample.hip; the body behind rsa_sample_popular)
 int sample_popular_impl(const float* table, const float* pop_prob, const int32_t* guide, int64_t n_items,
                         int32_t guide_log2, int64_t* neg_ids, float* neg_logp, float* u_out, int64_t numel,

@@ -17,6 +17,7 @@
 // in wave order, so positions follow the element order: stable.
 #pragma once
 #include "rsa_common.hpp"
+#include <type_traits>
 
 namespace rsa {
 
@@ -58,6 +59,61 @@ struct SrcStepIds {
     int64_t id = (off && c == 0) ? pos_ids[m] : neg_ids[m * (int64_t)n + (c - off)];
     id = id < 0 ? n_items : (id >= n_items ? n_items - 1 : id);
     return rdx_pack((uint32_t)id, (uint32_t)e);
+  }
+};
+
+// ALL sorted elements of an in-place SGD step in ONE key space: the t_items = M * w item elements of SrcStepIds (keys 0 ..
+// n_items, n_items = the empty slot) followed by the step's M USER elements, element t_items + m with key user_key_base +
+// user id (user_key_base = n_items + 1; a negative user id -> user_key_base + n_users, behind every real user).  Every
+// user key is larger than every item key, so the sorted array is the item sort followed by the user sort, each exactly
+// what its own sort would have produced (stable: equal keys stay in element order) -- the user rows' sort costs no
+// launches of its own (nine of ~4 us for the 65 536 users of the headline step).
+// DRAW: the source also DRAWS the negatives (draw_kind 1: UniformSampler, ids in [low, low + range); 2:
+// PopularSamplerModel through its bucket lines), element f = m * n + j of the torch call exactly as rsa_sample_uniform /
+// rsa_sample_popular draw it, and stores them to neg_out -- handed to the sort as the source of pass 0's HISTOGRAM launch
+// (radix_sort_pairs2), which visits every element once; the scatter launch then reads the stored ids.
+struct StepDraw {
+  int64_t* neg_out;
+  int32_t kind, lines_log2;
+  PhiloxCall pc;
+  uint64_t range;
+  int64_t low;
+  const float *lines, *table, *pop_prob;
+};
+template <bool DRAW>
+struct SrcStepAll {
+  SrcStepIds it;
+  const int64_t* user_ids;       // nullable: no user elements
+  int64_t t_items, n_users;
+  uint32_t user_key_base;
+  StepDraw dr;
+  __device__ __forceinline__ uint64_t operator()(int64_t e) const {
+    if (e >= t_items) {
+      int64_t u = user_ids[e - t_items];
+      u = u < 0 ? n_users : (u >= n_users ? n_users - 1 : u);
+      return rdx_pack(user_key_base + (uint32_t)u, (uint32_t)e);
+    }
+    if constexpr (DRAW) {
+      const int64_t m = (uint32_t)e / (uint32_t)it.w;
+      const int c = (int)(e - m * it.w);
+      int64_t id;
+      if (it.off && c == 0) {
+        id = it.pos_ids[m];
+      } else {
+        const int64_t f = m * (int64_t)it.n + (c - it.off);
+        if (dr.kind == 1) {
+          id = torch_randint_element(dr.pc, (uint64_t)f, dr.range, dr.low);
+        } else {
+          float pr;
+          id = cdf_lookup_line(dr.lines, dr.lines_log2, dr.table, 1, dr.pop_prob, 1, it.n_items, torch_rand_element(dr.pc, (uint64_t)f), pr);
+        }
+        dr.neg_out[f] = id;
+      }
+      id = id < 0 ? it.n_items : (id >= it.n_items ? it.n_items - 1 : id);
+      return rdx_pack((uint32_t)id, (uint32_t)e);
+    } else {
+      return it(e);
+    }
   }
 };
 
@@ -397,11 +453,25 @@ inline int64_t radix_temp_bytes(int64_t max_total) {
 // buf_b, ...: the result is in radix_result(buf_a, buf_b, bits).  `temp`: radix_temp_bytes(total) bytes.
 inline uint64_t* radix_result(uint64_t* buf_a, uint64_t* buf_b, unsigned bits) { return (radix_passes(bits) & 1) ? buf_a : buf_b; }
 
+// `src0h` feeds pass 0's histogram launch, `src0` everything else that reads the producer (pass 0's scatter launch, the
+// one-workgroup sort): the same pairs from both -- a source with a side effect (SrcStepAll<true> DRAWS a step's negatives
+// and stores them) is handed in as `src0h` and runs exactly once per element, before any launch that reads its output.
+template <class SRC0H, class SRC0>
+inline hipError_t radix_sort_pairs2(const SRC0H& src0h, const SRC0& src0, uint64_t* buf_a, uint64_t* buf_b, int64_t total,
+                                    unsigned bits, void* temp, hipStream_t s);
+
 template <class SRC0>
 inline hipError_t radix_sort_pairs(const SRC0& src0, uint64_t* buf_a, uint64_t* buf_b, int64_t total, unsigned bits,
                                    void* temp, hipStream_t s) {
+  return radix_sort_pairs2(src0, src0, buf_a, buf_b, total, bits, temp, s);
+}
+
+template <class SRC0H, class SRC0>
+inline hipError_t radix_sort_pairs2(const SRC0H& src0h, const SRC0& src0, uint64_t* buf_a, uint64_t* buf_b, int64_t total,
+                                    unsigned bits, void* temp, hipStream_t s) {
   if (total <= 0) return hipSuccess;
   if (total <= RDX_TILE) {       // one workgroup, one launch; the result goes where the multi-pass form would leave it
+    if constexpr (!std::is_same<SRC0H, SRC0>::value) return hipErrorInvalidValue;      // (a drawing source needs the multi-pass form)
     hipLaunchKernelGGL((radix_small_kernel<SRC0>), dim3(1), dim3(64 * RDX_SMALL_WAVES), 0, s, src0, (int)total, radix_passes(bits),
                        radix_result(buf_a, buf_b, bits));
     return hipGetLastError();
@@ -419,7 +489,7 @@ inline hipError_t radix_sort_pairs(const SRC0& src0, uint64_t* buf_a, uint64_t* 
     const int shift = 32 + p * RDX_DIGIT_BITS;
     uint64_t* dst = (p & 1) ? buf_b : buf_a;
     if (p == 0) {
-      hipLaunchKernelGGL((radix_hist_kernel<SRC0>), grid, block, 0, s, src0, total, shift, n_tiles, items, counts);
+      hipLaunchKernelGGL((radix_hist_kernel<SRC0H>), grid, block, 0, s, src0h, total, shift, n_tiles, items, counts);
       if (!inline_scan) hipLaunchKernelGGL(radix_scan_kernel, dim3(RDX_BINS), block, 0, s, counts, n_tiles, totals);
       hipLaunchKernelGGL((radix_scatter_kernel<SRC0>), grid, block, 0, s, src0, total, shift, n_tiles, items, counts, tot, dst);
     } else {

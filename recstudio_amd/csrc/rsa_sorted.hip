@@ -114,30 +114,35 @@ __global__ __launch_bounds__(256, RSA_SORTED_MIN_WAVES) void sorted_apply_kernel
                                                            const float* __restrict__ upstream, int32_t pad_row,
                                                            int32_t drop_key, float* __restrict__ target, AdamArgs adam,
                                                            float* __restrict__ lead_part, float* __restrict__ trail_part,
-                                                           int32_t* __restrict__ meta) {
+                                                           int32_t* __restrict__ meta, int32_t key_base, int32_t elem_base,
+                                                           int32_t chunk_elems) {
   constexpr int D = 64 * NDW;
   const int lane = lane_id();
   const int64_t chunk = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int64_t begin = chunk * 64;
+  // chunk_elems = 64, or 16 for a small pass (sorted_chunk_elems): a wave walks its elements a few at a time, one round trip
+  // per group -- the 65 536 user rows of the headline step as 1024 waves x 16 groups took 30 us of latency for 100 MB
+  const int64_t begin = chunk * chunk_elems;
   if (begin >= total) return;
   const float scale = upstream ? upstream[0] : 1.f;
   // this lane's element of the chunk: key, query row, coefficient (all lanes in parallel)
   const int64_t i = begin + lane;
-  const bool in = i < total;
+  const bool in = lane < chunk_elems && i < total;
   const uint64_t pr = in ? pairs[i] : 0ull;
-  const int32_t key = in ? (int32_t)rdx_key(pr) : -1;
+  // key_base / elem_base (0 but for the user part of a merged step sort, sort_step_all): what the part's keys and element
+  // numbers are offset by inside the common sort
+  const int32_t key = in ? (int32_t)(rdx_key(pr) - (uint32_t)key_base) : -1;
   int32_t qrow = 0;
   float coef = 0.f;
   bool solo = false;                  // flagged by classify_solo_kernel: the row has been applied by the forward
   if (in && key != drop_key) {        // empty slots: nothing is read for them (their query index is -1)
     int32_t e = (int32_t)rdx_val(pr);
     solo = e < 0;
-    e &= 0x7fffffff;
+    e = (e & 0x7fffffff) - elem_base;
     if (!solo) dec((int64_t)e, qrow, coef);
   }
-  const int cnt = (int)(total - begin < 64 ? total - begin : 64);
-  const int32_t prev = begin > 0 ? (int32_t)rdx_key(pairs[begin - 1]) : -1;                     // key in front of the chunk
-  const int32_t next = begin + cnt < total ? (int32_t)rdx_key(pairs[begin + cnt]) : -1;         // key behind it
+  const int cnt = (int)(total - begin < chunk_elems ? total - begin : chunk_elems);
+  const int32_t prev = begin > 0 ? (int32_t)(rdx_key(pairs[begin - 1]) - (uint32_t)key_base) : -1;                     // key in front of the chunk
+  const int32_t next = begin + cnt < total ? (int32_t)(rdx_key(pairs[begin + cnt]) - (uint32_t)key_base) : -1;         // key behind it
   float acc[NDW];
   float trow[NDW], mrow_v[NDW], vrow_v[NDW];     // the current run's target (and Adam state) row, requested at its head
 #pragma unroll
@@ -313,8 +318,20 @@ static inline int64_t align256s(int64_t b) { return (b + 255) / 256 * 256; }
 
 // ---- the workspace of a sorted scatter over `max_total` elements: two packed-pair buffers, the radix sort's counters,
 // per 64-element chunk two partial rows (sized for dim = 256) and the segment record
+// Chunks of the apply pass: 64 sorted elements per wave, 16 for a pass over at most SMALL_TOTAL elements (a function of the
+// pass's total ALONE, so that two passes over the same elements sum in the same order wherever they run).  The workspace holds
+// per-chunk records for ANY total <= max_total (callers size it for their largest step): the bound below is monotone.
+constexpr int64_t SORTED_SMALL_TOTAL = 1 << 18;
+int sorted_chunk_elems(int64_t total) { return total <= SORTED_SMALL_TOTAL ? 16 : 64; }
+static int64_t sorted_max_chunks(int64_t max_total) {
+  const int64_t by64 = (max_total + 63) / 64;
+  const int64_t small = max_total < SORTED_SMALL_TOTAL ? max_total : SORTED_SMALL_TOTAL;
+  const int64_t by16 = (small + 15) / 16;
+  return by64 > by16 ? by64 : by16;
+}
+
 int64_t sorted_workspace_bytes(int64_t max_total) {
-  const int64_t chunks = (max_total + 63) / 64;
+  const int64_t chunks = sorted_max_chunks(max_total);
   return 2 * align256s(max_total * 8) + align256s(radix_temp_bytes(max_total)) + 2 * align256s(chunks * 256 * 4) +
          align256s(chunks * META_STRIDE * 4) + 256;
 }
@@ -322,7 +339,7 @@ int64_t sorted_workspace_bytes(int64_t max_total) {
 SortedLayout sorted_layout(void* workspace, int64_t max_total) {
   char* ws = reinterpret_cast<char*>(workspace);
   const int64_t seg = align256s(max_total * 8);
-  const int64_t max_chunks = (max_total + 63) / 64;
+  const int64_t max_chunks = sorted_max_chunks(max_total);
   SortedLayout L;
   L.pairs_a = reinterpret_cast<uint64_t*>(ws);
   L.pairs_b = reinterpret_cast<uint64_t*>(ws + seg);
@@ -358,20 +375,22 @@ int classify_solo(uint64_t* pairs, int64_t total, int64_t pad_row, int64_t drop_
 template <class DEC>
 static int apply_sorted_pairs(const uint64_t* pairs, int64_t total, const float* query, int32_t dim, const DEC& dec,
                               const float* upstream, int64_t drop_key, int64_t pad_row, float* target, AdamArgs adam,
-                              const SortedLayout& L, hipStream_t s) {
+                              const SortedLayout& L, hipStream_t s, int64_t key_base = 0, int64_t elem_base = 0) {
   if (dim != 64 && dim != 128 && dim != 256) {
     rsa::set_error("rsa_rows_update_sorted: dim=%d: built for dim in {64, 128, 256}", dim);
     return RSA_ERR_UNSUPPORTED;
   }
-  const unsigned chunks = (unsigned)((total + 63) / 64);
+  const int ce = sorted_chunk_elems(total);
+  const unsigned chunks = (unsigned)((total + ce - 1) / ce);
   dim3 grid((chunks + 3) / 4), block(256);
   const int32_t pad = (int32_t)(pad_row < 0 || pad_row >= (1ll << 31) ? -2 : pad_row);
   const bool nt = RSA_SORTED_NT == 1 || (RSA_SORTED_NT == 2 && (size_t)drop_key * dim * sizeof(float) > (512ull << 20));      // (drop_key = the table's row count)
 #define RSA_SORTED_LAUNCH(NDW)                                                                                                 \
   if (nt) hipLaunchKernelGGL((sorted_apply_kernel<NDW, DEC, true>), grid, block, 0, s, pairs, total, query, dec, upstream, pad, \
-                             (int32_t)drop_key, target, adam, L.lead_part, L.trail_part, L.meta);                               \
+                             (int32_t)drop_key, target, adam, L.lead_part, L.trail_part, L.meta, (int32_t)key_base,            \
+                             (int32_t)elem_base, (int32_t)ce);                                                                   \
   else hipLaunchKernelGGL((sorted_apply_kernel<NDW, DEC, false>), grid, block, 0, s, pairs, total, query, dec, upstream, pad,   \
-                          (int32_t)drop_key, target, adam, L.lead_part, L.trail_part, L.meta);                                  \
+                          (int32_t)drop_key, target, adam, L.lead_part, L.trail_part, L.meta, (int32_t)key_base, (int32_t)elem_base, (int32_t)ce); \
   hipLaunchKernelGGL(sorted_finish_kernel<NDW>, grid, block, 0, s, (int64_t)chunks, upstream, pad, target, adam, L.lead_part,   \
                      L.trail_part, L.meta)
   switch (dim) {
@@ -390,6 +409,56 @@ int apply_sorted_segments(const uint64_t* pairs, int64_t total, int64_t slots, c
   const AdamArgs none{nullptr, nullptr, 0.f, 0.f, 0.f, 0.f};
   const DecSegments dec{keys, d, slots};
   return apply_sorted_pairs(pairs, total, query, dim, dec, upstream, n_rows, pad_row, target, none, L, s);
+}
+
+// ---- the in-place SGD step (rsa_step.hip): ONE sort for the step's item elements AND its user elements (SrcStepAll)
+static unsigned step_all_bits(int64_t n_items, int64_t n_users) { return radix_key_bits(n_items + n_users + 2); }
+
+int64_t step_all_workspace_bytes(int64_t n_queries, int32_t num_neg) { return sorted_workspace_bytes(n_queries * (int64_t)(num_neg + 2)); }
+
+int sort_step_all(const int64_t* pos_ids, int64_t* neg_ids, const int64_t* user_ids, int64_t n_queries, int32_t num_neg,
+                  int64_t n_items, int64_t n_users, uint8_t* solo, void* workspace, int64_t workspace_bytes, const StepDraw* draw,
+                  hipStream_t s, const char* who) {
+  const int64_t t_items = n_queries * (int64_t)(num_neg + 1), total = t_items + n_queries;
+  RSA_CHECK_ARG(total < (1ll << 31) && n_items + n_users + 2 < (1ll << 31), "%s: more than 2^31 elements / keys", who);
+  const int64_t need = step_all_workspace_bytes(n_queries, num_neg);
+  RSA_CHECK_ARG(workspace && workspace_bytes >= need, "%s: item_workspace too small (%lld < %lld = "
+                "rsa_scatter_rows_sorted_workspace_bytes(n_queries, num_neg + 1, n_items): the user rows are sorted with the item rows)",
+                who, (long long)workspace_bytes, (long long)need);
+  const SortedLayout L = sorted_layout(workspace, total);
+  const unsigned bits = step_all_bits(n_items, n_users);
+  const SrcStepIds it{pos_ids, neg_ids, n_items, num_neg, num_neg + 1, 1};
+  const StepDraw none{nullptr, 0, 0, PhiloxCall{0, 0, 1, 0}, 0, 0, nullptr, nullptr, nullptr};
+  const SrcStepAll<false> rd{it, user_ids, t_items, n_users, (uint32_t)(n_items + 1), none};
+  hipError_t err;
+  if (draw != nullptr && draw->kind != 0) {
+    const SrcStepAll<true> dw{it, user_ids, t_items, n_users, (uint32_t)(n_items + 1), *draw};
+    err = radix_sort_pairs2(dw, rd, L.pairs_a, L.pairs_b, total, bits, L.temp, s);
+  } else {
+    err = radix_sort_pairs(rd, L.pairs_a, L.pairs_b, total, bits, L.temp, s);
+  }
+  if (err != hipSuccess) {
+    rsa::set_error("%s: radix sort failed: %s", who, hipGetErrorString(hipGetLastError()));
+    return RSA_ERR_HIP;
+  }
+  // the item part only: a user row is never updated by the forward
+  return classify_solo(radix_result(L.pairs_a, L.pairs_b, bits), t_items, 0, n_items, solo, s, who);
+}
+
+// the shared item rows (users == false) or the user rows (users == true) of the step sorted by sort_step_all
+int apply_step_all(bool users, const float* query, const int64_t* query_index, int32_t dim, int64_t n_queries, int32_t num_neg,
+                   const float* dpos, const float* dneg, const float* upstream, int64_t n_items, int64_t n_users, float* target,
+                   void* workspace, hipStream_t s) {
+  const int64_t t_items = n_queries * (int64_t)(num_neg + 1), total = t_items + n_queries;
+  const SortedLayout L = sorted_layout(workspace, total);
+  const uint64_t* sorted = radix_result(L.pairs_a, L.pairs_b, step_all_bits(n_items, n_users));
+  const AdamArgs none{nullptr, nullptr, 0.f, 0.f, 0.f, 0.f};
+  if (!users) {
+    const DecStep dec{query_index, dpos, dneg, (int)num_neg, 1};
+    return apply_sorted_pairs(sorted, t_items, query, dim, dec, upstream, n_items, 0, target, none, L, s);
+  }
+  const DecStep dec{nullptr, nullptr, dneg, 1, 0};      // element m: query row m of `query`, coefficient dneg[m]
+  return apply_sorted_pairs(sorted + t_items, n_queries, query, dim, dec, upstream, n_users, 0, target, none, L, s, n_items + 1, t_items);
 }
 
 }  // namespace rsa

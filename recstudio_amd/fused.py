@@ -307,25 +307,84 @@ def _apply_user_rows(uw, user_ids, qgrad, step):
         ops.scatter_add_rows(qgrad * step, user_ids, uw.shape[0], out=uw)
 
 
+def _sgd_step_block(iw, uw, num_neg, M, kind, sampler, step_scale, neg=None):
+    """The buffers and the frozen ``rsa_bpr_sgd_args`` block of an in-place SGD step of M queries: ONE allocation (``ops.carve``)
+    for what the two calls write, the item-AND-user sort workspace (ABI 11), the block filled but for the batch pointers and the
+    Philox state."""
+    lib, dev, n, d = nat.lib(), iw.device, int(num_neg), iw.shape[1]
+    N, U = iw.shape[0], uw.shape[0]
+    ws = int(lib.rsa_scatter_rows_sorted_workspace_bytes(M, n + 1, N))       # M * (n + 2) elements: items, positives, users
+    f32, u8 = torch.float32, torch.uint8
+    specs = [('solo', (M, n + 1), u8), ('iws', (max(ws, 8),), u8), ('pos_score', (M,), f32), ('neg_score', (M, n), f32),
+             ('row_loss', (M,), f32), ('dpos', (M,), f32), ('dneg', (M, n), f32), ('query_grad', (M, d), f32)]
+    if neg is None:
+        specs.insert(0, ('neg', (M, n), torch.int64))
+    b = ops.carve(dev, specs)
+    if neg is not None:
+        b['neg'] = neg
+    b['ones'] = torch.ones(M, dtype=torch.float32, device=dev)
+    a = nat.BprSgdArgs()
+    a.item_table, a.n_items, a.user_table, a.n_users, a.dim, a.num_neg = ptr(iw), N, ptr(uw), U, d, n
+    a.n_queries, a.sampler, a.step_scale = M, kind, ptr(step_scale)
+    a.neg_ids, a.solo = ptr(b['neg']), ptr(b['solo'])
+    a.item_workspace, a.item_workspace_bytes = ptr(b['iws']), ws
+    a.pos_score, a.neg_score, a.row_loss = ptr(b['pos_score']), ptr(b['neg_score']), ptr(b['row_loss'])
+    a.dpos, a.dneg, a.query_grad, a.ones = ptr(b['dpos']), ptr(b['dneg']), ptr(b['query_grad']), ptr(b['ones'])
+    if kind == nat.SAMPLER_UNIFORM:
+        a.uniform_high = int(sampler.num_items) + 1
+    b['args'], b['ref'] = a, ctypes.byref(a)
+    return b
+
+
+def _reserve_draw(a, kind, sampler, M, num_neg, dev):
+    """the Philox state the Sampler plugin's call would consume for this step's negatives -> the argument block"""
+    unroll = 4 if kind == nat.SAMPLER_POPULAR else rng.randint_unroll(1, int(sampler.num_items) + 1)
+    pc = rng.reserve(M * num_neg, unroll, dev, None)
+    a.seed, a.offset, a.grid_threads, a.elem_base = pc.seed, pc.offset, pc.grid_threads, pc.elem_base
+
+
 def _bpr_sgd_step_in_forward(item_weight, user_weight, num_neg, lr, user_ids, pos_ids, sampler, kind, kw):
+    """The in-forward step as the library's two calls on the current stream (``rsa_bpr_sgd_prepare`` / ``_apply``, rsa_step.hip):
+    the negatives drawn inside the first launch of ONE sort that covers the item rows and the user rows, solo classification,
+    forward with in-place solo updates, sorted apply of the shared item rows and of the user rows."""
     M = user_ids.numel()
-    with torch.no_grad():
-        iw, uw = item_weight.data, user_weight.data
-        if kind == nat.SAMPLER_GIVEN:
-            neg = kw['neg_ids']
-        else:       # the stand-alone sampler draws what the in-kernel one would (same stream, same generator advance)
-            neg = sampler(torch.empty(M, 1, device=iw.device), num_neg, None)[0]
-        # the step's (item id, element) pairs sorted by id -- the sort the all-sorted form runs AFTER the forward -- and, from
-        # the sorted order, which elements are alone on their row
-        solo, ws = ops.sort_step_elements(pos_ids, neg, iw.shape[0], pad_row=0)
-        step = torch.full((1,), -float(lr), dtype=torch.float32, device=iw.device)
-        out = ops.fused_forward(iw, uw, num_neg, query_index=user_ids, pos_ids=pos_ids, neg_ids=neg, sampler=nat.SAMPLER_GIVEN,
-                                fused_bpr=True, want_query_grad=True, inplace_update=(solo, step))
-        # the elements on shared rows: every such row read-modified-written once, in sorted order
-        ops.scatter_rows_presorted(iw, uw, ws, M, num_neg, out['dneg'], query_index=user_ids, dpos=out['dpos'], upstream=step,
-                                   pad_row=0)
-        _apply_user_rows(uw, user_ids, out['query_grad'], step)
-    return out['loss'], out['neg_ids']
+    iw, uw = item_weight.data, user_weight.data
+    dev = iw.device
+    if not (iw.is_cuda and iw.is_contiguous() and uw.is_contiguous() and uw.device == dev and iw.dtype == uw.dtype == torch.float32):
+        raise RuntimeError('bpr_sgd_step: contiguous fp32 tables on one GPU (there is no CPU fallback)')
+    if not (user_ids.is_cuda and user_ids.dtype == pos_ids.dtype == torch.int64 and user_ids.device == dev and pos_ids.numel() == M):
+        raise TypeError('bpr_sgd_step: int64 user / positive ids on the tables\' device, one positive per query')
+    user_ids, pos_ids = user_ids.contiguous(), pos_ids.contiguous()
+    neg = None
+    if kind == nat.SAMPLER_GIVEN:
+        neg = kw['neg_ids']
+        if not (neg.dtype == torch.int64 and neg.device == dev and neg.shape == (M, num_neg)):
+            raise TypeError('bpr_sgd_step: neg_ids must be int64 [n_queries, num_neg] on the tables\' device')
+        neg = neg.contiguous()
+    with torch.no_grad(), _device_of(dev):
+        step = torch.full((1,), -float(lr), dtype=torch.float32, device=dev)
+        b = _sgd_step_block(iw, uw, num_neg, M, kind, sampler, step, neg=neg)
+        a = b['args']
+        if kind == nat.SAMPLER_POPULAR:
+            pk = sampler.lookup_kwargs()
+            pk.pop('table_prob', None)
+            pop = ops.popular_args(**pk)
+            a.pop = ctypes.pointer(pop)
+        a.user_ids, a.pos_ids = user_ids.data_ptr(), pos_ids.data_ptr()
+        if kind != nat.SAMPLER_GIVEN:
+            _reserve_draw(a, kind, sampler, M, num_neg, dev)
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        a.loss_out = loss.data_ptr()
+        main = torch.cuda.current_stream(dev)
+        a.reduce_scratch = ptr(ops._scratch_for(dev, main.cuda_stream))
+        lib = nat.lib()
+        rc = lib.rsa_bpr_sgd_prepare(b['ref'], main.cuda_stream)
+        if rc != 0:
+            nat.check(rc, 'rsa_bpr_sgd_prepare')
+        rc = lib.rsa_bpr_sgd_apply(b['ref'], main.cuda_stream)
+        if rc != 0:
+            nat.check(rc, 'rsa_bpr_sgd_apply')
+    return loss, b['neg']
 
 
 class PrefetchedBPRSGD:
@@ -364,7 +423,6 @@ class PrefetchedBPRSGD:
         self._slots, self._count = {}, 0
         self._lib = nat.lib()
         self._pop = self._pop_src = None
-        self._unroll = 4 if self.kind == nat.SAMPLER_POPULAR else None
 
     def set_lr(self, lr):
         """New learning rate from the next ``step`` on (call between steps, e.g. a scheduler at the end of an epoch)."""
@@ -387,32 +445,12 @@ class PrefetchedBPRSGD:
     def _slot(self, M):
         slots = self._slots.get(M)
         if slots is None:
-            lib, dev, n, d = self._lib, self.dev, self.num_neg, self.iw.shape[1]
-            N, U = self.iw.shape[0], self.uw.shape[0]
-            iws = int(lib.rsa_scatter_rows_sorted_workspace_bytes(M, n, N))
-            uws = int(lib.rsa_scatter_rows_sorted_workspace_bytes(M, 1, U))
-            ones = torch.ones(M, dtype=torch.float32, device=dev)
             slots = []
             for _ in range(self.RING):
-                f32, u8 = torch.float32, torch.uint8
-                # one allocation per slot (ops.carve: buffers a launch writes must not come from separate allocations)
-                b = ops.carve(dev, [('neg', (M, n), torch.int64), ('solo', (M, n + 1), u8), ('iws', (max(iws, 8),), u8),
-                                    ('uws', (max(uws, 8),), u8), ('pos_score', (M,), f32), ('neg_score', (M, n), f32),
-                                    ('row_loss', (M,), f32), ('dpos', (M,), f32), ('dneg', (M, n), f32), ('query_grad', (M, d), f32)])
-                b.update(ones=ones, ready=torch.cuda.Event())
-                a = nat.BprSgdArgs()
-                a.item_table, a.n_items, a.user_table, a.n_users, a.dim, a.num_neg = ptr(self.iw), N, ptr(self.uw), U, d, n
-                a.n_queries, a.sampler, a.step_scale = M, self.kind, ptr(self.step_scale)
-                a.neg_ids, a.solo = ptr(b['neg']), ptr(b['solo'])
-                a.item_workspace, a.item_workspace_bytes = ptr(b['iws']), iws
-                a.user_workspace, a.user_workspace_bytes = ptr(b['uws']), uws
-                a.pos_score, a.neg_score, a.row_loss = ptr(b['pos_score']), ptr(b['neg_score']), ptr(b['row_loss'])
-                a.dpos, a.dneg, a.query_grad, a.ones = ptr(b['dpos']), ptr(b['dneg']), ptr(b['query_grad']), ptr(ones)
-                if self.kind == nat.SAMPLER_UNIFORM:
-                    a.uniform_high = int(self.sampler.num_items) + 1
-                else:
-                    a.pop = ctypes.pointer(self._popular_tables())
-                b['args'], b['ref'] = a, ctypes.byref(a)
+                b = _sgd_step_block(self.iw, self.uw, self.num_neg, M, self.kind, self.sampler, self.step_scale)
+                b['ready'] = torch.cuda.Event()
+                if self.kind == nat.SAMPLER_POPULAR:
+                    b['args'].pop = ctypes.pointer(self._popular_tables())
                 slots.append(b)
             self._slots[M] = slots
         return slots[self._count % self.RING]
@@ -429,9 +467,7 @@ class PrefetchedBPRSGD:
         self._count += 1
         a = b['args']
         a.user_ids, a.pos_ids = user_ids.data_ptr(), pos_ids.data_ptr()
-        unroll = self._unroll if self._unroll is not None else rng.randint_unroll(1, int(self.sampler.num_items) + 1)
-        pc = rng.reserve(M * self.num_neg, unroll, self.dev, None)
-        a.seed, a.offset, a.grid_threads, a.elem_base = pc.seed, pc.offset, pc.grid_threads, pc.elem_base
+        _reserve_draw(a, self.kind, self.sampler, M, self.num_neg, self.dev)
         main = torch.cuda.current_stream(self.dev)
         self._fork.record(main)                      # the batch tensors may have been produced on the main stream, and the
         self.side.wait_event(self._fork)             # buffer set's previous step must be over

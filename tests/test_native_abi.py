@@ -35,7 +35,7 @@ def test_header_symbols_all_exported(nat):
 
 def test_abi_version_and_error_channel(nat):
     lib = nat.lib()
-    assert lib.rsa_abi_version() == nat.ABI_VERSION == 10
+    assert lib.rsa_abi_version() == nat.ABI_VERSION == 11
     assert lib.rsa_scratch_bytes() >= 256 + 4 * 2048
     # argument validation happens before any HIP call, so it can be exercised without a GPU
     rc = lib.rsa_sample_uniform(None, 10, 1, 5, 0, 0, 256, 0, None)
