@@ -388,7 +388,10 @@ def side_figures(extra):
     put('fit_c3_sasrec_ms_per_step', 'fit', 'c3_sasrec', 'ms_per_step')
     put('fit_c3_hot_path_ms', 'fit', 'c3_sasrec', 'hot_path_ms')
     put('fit_c3_hot_path_share_of_step', 'fit', 'c3_sasrec', 'hot_path_share_of_step')
-    put('fit_c3_transformer_ms', 'fit', 'c3_sasrec', 'step_parts_ms', 'transformer_fwd_bwd_stock_torch')
+    # (the split is taken on the WIDEST batch of the epoch, L = max_seq_len: its whole step next to its Transformer; the epoch's
+    # mean step above is shorter because most batches are narrower)
+    put('fit_c3_widest_batch_step_ms', 'fit', 'c3_sasrec', 'step_parts_ms', 'whole_step_one_batch')
+    put('fit_c3_widest_batch_transformer_ms', 'fit', 'c3_sasrec', 'step_parts_ms', 'transformer_fwd_bwd_stock_torch')
     put('fit_c3_loss_first', 'fit', 'c3_sasrec', 'train_loss_first_last', 0)
     put('fit_c3_loss_last', 'fit', 'c3_sasrec', 'train_loss_first_last', -1)
     return side

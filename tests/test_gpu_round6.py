@@ -9,6 +9,10 @@ pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'
 
 
+def rel_close(a, b, rtol=1e-4, atol=1e-6):
+    np.testing.assert_allclose(np.asarray(a), np.asarray(b), rtol=rtol, atol=atol)
+
+
 @pytest.fixture(scope='module')
 def ra():
     import recstudio_amd
@@ -323,3 +327,58 @@ def test_lookahead_tickets_do_not_grow_the_allocator():
         assert grown < (256 << 20), grown          # (unbounded: ~10 MB per step here, 6 GB over the loop)
     finally:
         dist.destroy_process_group()
+
+
+def test_sgd_step_headline_shape_properties(ra):
+    """The in-place SGD step (rsa_bpr_sgd_prepare / _apply: negatives drawn inside the first launch of ONE sort over the item AND
+    the user elements, ABI 11) at BASELINE configs[1]'s own size -- N = 1e7 + 1, U = 1e6 + 1, B = 65 536, n = 64, popularity
+    sampler: the negatives == torch's stream (``searchsorted(table, rand)``, sampler.py:246-247), loss == the plain forward's on the
+    same weights, every touched row moved and no other, rows with ONE element == row - lr * d * q exactly as the all-sorted form
+    computes it, user rows == the all-sorted form's bit for bit (same sorted order, same chunking), run-to-run bit equality."""
+    N, U, d, B, n, lr = 10_000_001, 1_000_001, 128, 65536, 64, 3000.0      # (BPRLoss is a mean over B * n terms: lr ~ 0.05 per sample)
+    g = torch.Generator(device=DEV).manual_seed(11)
+    iw0 = torch.empty(N, d, device=DEV).normal_(0, 0.1, generator=g)
+    iw0[0] = 0
+    uw0 = torch.empty(U, d, device=DEV).normal_(0, 0.1, generator=g)
+    counts = (torch.rand(N, generator=torch.Generator().manual_seed(2)) ** 8 * 1e4).long()
+    ps = ra.PopularSamplerModel(counts).to(DEV)
+    uid = torch.randint(1, U, (B,), device=DEV, generator=g)
+    uid[:64] = uid[64:128]                         # users that occur twice in the batch
+    pos = torch.randint(1, N, (B,), device=DEV, generator=g)
+    res = []
+    for mode in (True, True, False):
+        iw, uw = iw0.clone(), uw0.clone()
+        torch.manual_seed(5)
+        loss, ids = ra.fused.bpr_sgd_step(iw, uw, n, lr, user_ids=uid, pos_ids=pos, sampler=ps, in_forward=mode)
+        res.append((loss.clone(), ids.clone(), iw, uw))
+        torch.cuda.synchronize()
+    (l1, i1, it1, us1), (l2, i2, it2, us2), (l0, i0, it0, us0) = res
+    torch.manual_seed(5)
+    want = torch.searchsorted(ps.table, torch.rand(B, n, device=DEV)).clamp_(max=N - 1)
+    assert torch.equal(i1, want) and torch.equal(i0, want)
+    assert torch.equal(l1, l2) and torch.equal(it1, it2) and torch.equal(us1, us2)          # run to run
+    assert torch.equal(l1, l0) and torch.equal(us1, us0)
+    torch.manual_seed(5)
+    o = ra.ops.fused_forward(iw0, uw0, n, query_index=uid, pos_ids=pos, sampler=ra._native.SAMPLER_POPULAR, fused_bpr=True,
+                             **ps.lookup_kwargs())
+    assert torch.equal(o['neg_ids'], i1)
+    rel_close(l1.cpu(), o['loss'].cpu(), rtol=1e-6)
+    # which rows moved: exactly the touched ones (padding row 0 never)
+    touched = torch.zeros(N, dtype=torch.bool, device=DEV)
+    touched[pos] = True
+    touched[i1.reshape(-1)] = True
+    touched[0] = False
+    moved = (it1 != iw0).any(1)
+    assert not bool((moved & ~touched).any()) and not it1[0].any()
+    assert int((touched & ~moved).sum()) <= 8          # (a gradient that rounds to nothing on every component: practically never)
+    cnt = torch.bincount(torch.cat([pos, i1.reshape(-1)]), minlength=N)
+    solo = cnt == 1
+    solo[0] = False
+    assert 0.3 < float(solo[i1.reshape(-1)].float().mean()) < 0.7
+    assert torch.equal(it1[solo], it0[solo])            # solo rows: the apply pass's arithmetic, rounding for rounding
+    shared = touched & ~solo
+    rel_close(it1[shared].cpu(), it0[shared].cpu(), rtol=1e-5, atol=1e-7)
+    um = torch.zeros(U, dtype=torch.bool, device=DEV)
+    um[uid] = True
+    um[0] = False
+    assert torch.equal((us1 != uw0).any(1), um)
