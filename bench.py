@@ -24,6 +24,10 @@ import os
 import sys
 import time
 
+# (the hosts' driver only supports dmabuf IPC: without this RCCL's cross-process handles fail with `hipIpcGetMemHandle: invalid
+# argument`; exported on the GPU boxes already, set here as well so that a bare `torchrun bench.py` cannot miss it)
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
