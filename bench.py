@@ -365,6 +365,8 @@ def side_figures(extra):
     put('fullscore_top100_ms', 'fullscore', 'with_top100_ms')
     put('fullscore_grad_items_tflops', 'fullscore', 'grad_items_tflops')
     put('fullscore_top100_frac', 'fullscore', 'with_top100_frac')
+    put('fullscore_top100_only_ms', 'fullscore', 'top100_only_ms')
+    put('fullscore_top100_only_frac', 'fullscore', 'top100_only_frac')
     put('softmax_train_step_ms', 'fullscore', 'softmax_train_step_ms')
     put('softmax_train_frac', 'fullscore', 'softmax_train_frac')
     put('softmax_train_step_peak_extra_mb', 'fullscore', 'softmax_train_step_peak_extra_MB')
@@ -701,11 +703,14 @@ def main():
             q5 = user[1:b5 + 1].contiguous()
             t_lse = time_gpu(lambda: ra.ops.fullscore(it5, q5, want_lse=True), 10, 3) * 1e3
             t_topk = time_gpu(lambda: ra.ops.fullscore(it5, q5, want_lse=True, k=k5), 5, 2) * 1e3
+            # what BaseRetriever.topk issues at evaluation (baseretriever.py:374-397): the exact top-k alone, no logsumexp
+            t_topk_only = time_gpu(lambda: ra.ops.fullscore(it5, q5, k=k5), 5, 2) * 1e3
             flops = 2.0 * b5 * d * (n5 - 1)
             extra['fullscore'] = with_profile(
                 {'workload': f'B={b5} queries x N={n5} items, d={d}, fp32 MFMA (BASELINE.json configs[4])',
                  'gemm_lse_ms': round(t_lse, 3), 'gemm_lse_tflops': round(flops / t_lse / 1e9, 1),
                  'with_top100_ms': round(t_topk, 3), 'with_top100_frac': round(flops / t_topk / 1e9 / 157.3, 3),
+                 'top100_only_ms': round(t_topk_only, 3), 'top100_only_frac': round(flops / t_topk_only / 1e9 / 157.3, 3),
                  'peak_tflops_fp32_matrix': 157.3,
                  'frac_of_peak': round(flops / t_lse / 1e9 / 157.3, 3)}, 'fullscore_lse_B2048_N1e6', 0, flops=flops)
         except Exception as e:
