@@ -759,7 +759,7 @@ def test_fused_step_object_replays_the_call_with_fresh_draws(ra):
 # --------------------------------------------------------------------------- in-forward SGD for rows one element owns
 @pytest.mark.parametrize('N,d,B,kind', [(200_003, 128, 700, 'uniform'), (3001, 64, 513, 'uniform'), (50_021, 128, 600, 'popular'),
                                         (97, 256, 64, 'uniform'), (40_009, 128, 300, 'given'),
-                                        (1009, 64, 40, 'uniform'), (2003, 128, 33, 'popular')])     # one-workgroup sort: items + users <= 4096 elements
+                                        (1009, 64, 40, 'uniform'), (2003, 128, 33, 'popular'), (211, 64, 1, 'uniform')])     # one-workgroup sort: items + users <= 4096 elements
 def test_bpr_sgd_step_in_forward_equals_all_sorted(ra, N, d, B, kind):
     """fused.bpr_sgd_step with the in-forward update (rows touched by exactly one element of the step are rewritten by
     the wave that has them in registers; only the shared rows go through the apply pass) == the all-sorted step: same loss,
