@@ -7,6 +7,8 @@
 //   WR = 3  only the 4 per-query floats
 //   WR = 4  WR 2 with the per-element outputs staged in LDS per workgroup and written as 4-tile bursts after a barrier
 //   WR = 5  WR 1 with plain (cached) stores instead of streaming ones
+//   WR = 7  WR 1 with a CONTIGUOUS chunk of tiles per wave (every concurrent wave writes into pages of its own)
+//   WR = 8  WR 1 with the workgroups of one XCD (blockIdx % 8) covering one contiguous eighth of every window of tiles
 //   WR = 6  WR 1, but a wave keeps the outputs of all its tiles (<= 8) in registers and writes them when it has read its last row
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -24,13 +26,21 @@ __global__ __launch_bounds__(256) void wr_kernel(const float* __restrict__ table
   __shared__ float s_f[3][4][64];
   const int lane = threadIdx.x & 63, sub = lane & 31, gbase = lane - sub, wave = threadIdx.x >> 6;
   const int64_t n_tiles = numel >> 6;
-  const int64_t wave0 = (int64_t)blockIdx.x * 4 + wave;
-  const int64_t wstride = (int64_t)gridDim.x * 4;
+  int64_t bid = blockIdx.x;
+  if (WR == 8) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);     // (gridDim.x % 8 == 0)
+  int64_t wave0 = bid * 4 + wave;
+  int64_t wstride = (int64_t)gridDim.x * 4;
+  if (WR == 7) {
+    const int64_t per = ((numel >> 6) + wstride - 1) / wstride;
+    wave0 = wave0 * per;
+    wstride = 1;
+  }
+  const int64_t t_last = WR == 7 ? wave0 + (((numel >> 6) + (int64_t)gridDim.x * 4 - 1) / ((int64_t)gridDim.x * 4)) : (int64_t)1 << 62;
   float acc = 0.f;
   int32_t k_id[8];
   float k_dot[8];
   int kt = 0;
-  for (int64_t tile = wave0; tile < n_tiles + 3; tile += wstride) {     // (+3: whole workgroups iterate together for WR 4)
+  for (int64_t tile = wave0; tile < n_tiles + 3 && tile < t_last; tile += wstride) {     // (+3: whole workgroups iterate together for WR 4)
     const bool live = tile < n_tiles;
     const int64_t e = (tile << 6) + lane;
     int32_t id = 1;
@@ -57,7 +67,7 @@ __global__ __launch_bounds__(256) void wr_kernel(const float* __restrict__ table
       }
       acc += dot;
     }
-    if (WR == 1 || WR == 2) {
+    if (WR == 1 || WR == 2 || WR == 7 || WR == 8) {
       if (live) {
         st_stream(&o_id[e], (int64_t)id);
         st_stream(&o_a[e], dot);
@@ -135,7 +145,7 @@ extern "C" int exp_wr(const float* table, const int32_t* ids, const float* aux, 
   hipStream_t s = (hipStream_t)stream;
   dim3 g(blocks), b(256);
   switch (mode) {
-    CASE(0) CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6)
+    CASE(0) CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8)
     default: return -1;
   }
   return hipGetLastError() == hipSuccess ? 0 : -2;

@@ -42,16 +42,16 @@ def outputs():
 
 
 names = {0: 'no writes', 1: 'per-element 20 B', 2: 'per-element + 4 per-query floats', 3: 'per-query floats only',
-         4: 'per-element staged in LDS (4-tile bursts) + per-query', 5: 'per-element, cached stores', 6: 'per-element, written when the wave has read its last row'}
+         4: 'per-element staged in LDS (4-tile bursts) + per-query', 5: 'per-element, cached stores', 6: 'per-element, written when the wave has read its last row', 7: 'contiguous chunk of tiles per wave', 8: 'XCD-contiguous tiles'}
 warm = torch.empty(1 << 28, device=dev)
 t_end = torch.cuda.Event(enable_timing=True)
 for _ in range(300):          # ~1.5 s of load: the chip's ramp (docs/HISTORY.md 6, cause 1)
     warm.add_(1.0)
 torch.cuda.synchronize()
-sets = [outputs() for _ in range(6)]
+sets = [outputs() for _ in range(int(os.environ.get("EXP_SETS", "6")))]
 for si, (arena, o) in enumerate(sets):
     row = []
-    for mode in range(7):
+    for mode in [int(x) for x in os.environ.get("EXP_MODES", "0,1,2,3,4,5,6,7,8").split(",")]:
         us = timeit(lambda: lib.exp_wr(P(table), P(ids), P(aux), P(aux_idx), ctypes.c_int64(numel), mode, 2048, *[P(t) for t in o], P(out), st))
         row.append(f'{us:7.1f}')
     print(f'output set {si} @ {arena.data_ptr():#x}: ' + ' '.join(row), flush=True)
